@@ -1,0 +1,311 @@
+"""Parameter tables (name -> shape) of the three networks on the hot path, in the
+reference's own state-dict order, plus a deterministic, library-version-independent
+weight generator used for random-init benchmarks and parity fixtures.
+
+Key names follow the reference so that its checkpoints load unchanged:
+  * U-Net: diffusers/models/unet_2d_condition_guided.py:256-567 (module registration order),
+    unet_2d_blocks.py:825-906,503-586,1934-2015,2081-2127, resnet.py:418-547,
+    transformer_2d.py:145-216, attention.py:226-274,
+  * VAE decoder: audioldm/variational_autoencoder/modules.py:546-648, autoencoder.py:36-37,
+  * HiFi-GAN: audioldm/hifigan/models.py:72-99 (weight_norm removed, utilities.py:71).
+"""
+from collections import OrderedDict
+
+import numpy as np
+
+LIGHT_UNET_CONFIG = {
+    "act_fn": "silu",
+    "attention_head_dim": [5, 10, 20, 20],
+    "block_out_channels": [256, 512, 1024, 1024],
+    "center_input_sample": False,
+    "cross_attention_dim": 1024,
+    "down_block_types": ["CrossAttnDownBlock2D", "CrossAttnDownBlock2D",
+                         "CrossAttnDownBlock2D", "DownBlock2D"],
+    "downsample_padding": 1,
+    "flip_sin_to_cos": True,
+    "freq_shift": 0,
+    "in_channels": 8,
+    "layers_per_block": 2,
+    "mid_block_scale_factor": 1,
+    "norm_eps": 1e-5,
+    "norm_num_groups": 32,
+    "out_channels": 8,
+    "up_block_types": ["UpBlock2D", "CrossAttnUpBlock2D", "CrossAttnUpBlock2D",
+                       "CrossAttnUpBlock2D"],
+    "use_linear_projection": True,
+    "upcast_attention": True,
+}
+
+FULL_UNET_CONFIG = dict(LIGHT_UNET_CONFIG, block_out_channels=[320, 640, 1280, 1280])
+
+# audioldm/utils.py:75-88 (first_stage_config.params.ddconfig) + embed_dim
+VAE_DDCONFIG = {
+    "double_z": True, "z_channels": 8, "resolution": 256, "in_channels": 1, "out_ch": 1,
+    "ch": 128, "ch_mult": [1, 2, 4], "num_res_blocks": 2, "attn_resolutions": [],
+    "dropout": 0.0,
+}
+
+# audioldm/hifigan/utilities.py:9-39
+HIFIGAN_16K_64 = {
+    "upsample_rates": [5, 4, 2, 2, 2],
+    "upsample_kernel_sizes": [16, 16, 8, 4, 4],
+    "upsample_initial_channel": 1024,
+    "resblock_kernel_sizes": [3, 7, 11],
+    "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5], [1, 3, 5]],
+    "num_mels": 64,
+}
+
+
+def _as_list(v, n):
+    return list(v) if isinstance(v, (list, tuple)) else [v] * n
+
+
+def unet_levels(cfg):
+    """Per-level derived quantities shared by the table below, the oracle and the engine."""
+    boc = list(cfg["block_out_channels"])
+    n = len(boc)
+    heads = _as_list(cfg.get("num_attention_heads") or cfg["attention_head_dim"], n)
+    layers = _as_list(cfg["layers_per_block"], n)
+    return boc, heads, layers
+
+
+def _resnet(sd, p, cin, cout, temb):
+    sd[p + "norm1.weight"] = (cin,)
+    sd[p + "norm1.bias"] = (cin,)
+    sd[p + "conv1.weight"] = (cout, cin, 3, 3)
+    sd[p + "conv1.bias"] = (cout,)
+    sd[p + "time_emb_proj.weight"] = (cout, temb)
+    sd[p + "time_emb_proj.bias"] = (cout,)
+    sd[p + "norm2.weight"] = (cout,)
+    sd[p + "norm2.bias"] = (cout,)
+    sd[p + "conv2.weight"] = (cout, cout, 3, 3)
+    sd[p + "conv2.bias"] = (cout,)
+    if cin != cout:
+        sd[p + "conv_shortcut.weight"] = (cout, cin, 1, 1)
+        sd[p + "conv_shortcut.bias"] = (cout,)
+
+
+def _transformer(sd, p, c, heads, xdim):
+    inner = heads * (c // heads)  # unet_2d_blocks.py:873-875: dim_head = out_channels // heads
+    sd[p + "norm.weight"] = (c,)
+    sd[p + "norm.bias"] = (c,)
+    sd[p + "proj_in.weight"] = (inner, c)
+    sd[p + "proj_in.bias"] = (inner,)
+    t = p + "transformer_blocks.0."
+    sd[t + "attn1.to_q.weight"] = (inner, inner)
+    sd[t + "attn1.to_k.weight"] = (inner, inner)
+    sd[t + "attn1.to_v.weight"] = (inner, inner)
+    sd[t + "attn1.to_out.0.weight"] = (inner, inner)
+    sd[t + "attn1.to_out.0.bias"] = (inner,)
+    sd[t + "ff.net.0.proj.weight"] = (inner * 8, inner)
+    sd[t + "ff.net.0.proj.bias"] = (inner * 8,)
+    sd[t + "ff.net.2.weight"] = (inner, inner * 4)
+    sd[t + "ff.net.2.bias"] = (inner,)
+    sd[t + "attn2.to_q.weight"] = (inner, inner)
+    sd[t + "attn2.to_k.weight"] = (inner, xdim)
+    sd[t + "attn2.to_v.weight"] = (inner, xdim)
+    sd[t + "attn2.to_out.0.weight"] = (inner, inner)
+    sd[t + "attn2.to_out.0.bias"] = (inner,)
+    for k in ("norm1", "norm2", "norm3"):
+        sd[t + k + ".weight"] = (inner,)
+        sd[t + k + ".bias"] = (inner,)
+    sd[p + "proj_out.weight"] = (c, inner)
+    sd[p + "proj_out.bias"] = (c,)
+
+
+def unet_param_spec(cfg, guided=True):
+    """OrderedDict name -> shape for UNet2DConditionGuidedModel (guided=True) or
+    UNet2DConditionModel (teacher, guided=False)."""
+    boc, heads, layers = unet_levels(cfg)
+    n = len(boc)
+    temb = boc[0] * 4
+    xdim = cfg["cross_attention_dim"]
+    down_types = cfg["down_block_types"]
+    up_types = cfg["up_block_types"]
+    sd = OrderedDict()
+    sd["conv_in.weight"] = (boc[0], cfg["in_channels"], 3, 3)
+    sd["conv_in.bias"] = (boc[0],)
+    if guided:
+        sd["guidance_proj.weight"] = (temb // 2,)
+    sd["time_embedding.linear_1.weight"] = (temb, boc[0])
+    sd["time_embedding.linear_1.bias"] = (temb,)
+    sd["time_embedding.linear_2.weight"] = (temb, temb)
+    sd["time_embedding.linear_2.bias"] = (temb,)
+    if guided:
+        sd["guidance_embedding.linear_1.weight"] = (temb, temb)
+        sd["guidance_embedding.linear_1.bias"] = (temb,)
+        sd["guidance_embedding.linear_2.weight"] = (temb, temb)
+        sd["guidance_embedding.linear_2.bias"] = (temb,)
+    out_c = boc[0]
+    for i in range(n):
+        in_c, out_c = out_c, boc[i]
+        p = "down_blocks.%d." % i
+        if down_types[i] == "CrossAttnDownBlock2D":
+            for j in range(layers[i]):
+                _transformer(sd, p + "attentions.%d." % j, out_c, heads[i], xdim)
+        for j in range(layers[i]):
+            _resnet(sd, p + "resnets.%d." % j, in_c if j == 0 else out_c, out_c, temb)
+        if i != n - 1:
+            sd[p + "downsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            sd[p + "downsamplers.0.conv.bias"] = (out_c,)
+    rboc, rheads, rlayers = boc[::-1], heads[::-1], layers[::-1]
+    out_c = rboc[0]
+    for i in range(n):
+        prev_c, out_c = out_c, rboc[i]
+        in_c = rboc[min(i + 1, n - 1)]
+        nl = rlayers[i] + 1
+        p = "up_blocks.%d." % i
+        if up_types[i] == "CrossAttnUpBlock2D":
+            for j in range(nl):
+                _transformer(sd, p + "attentions.%d." % j, out_c, rheads[i], xdim)
+        for j in range(nl):
+            skip_c = in_c if j == nl - 1 else out_c
+            rin = prev_c if j == 0 else out_c
+            _resnet(sd, p + "resnets.%d." % j, rin + skip_c, out_c, temb)
+        if i != n - 1:
+            sd[p + "upsamplers.0.conv.weight"] = (out_c, out_c, 3, 3)
+            sd[p + "upsamplers.0.conv.bias"] = (out_c,)
+    _transformer(sd, "mid_block.attentions.0.", boc[-1], heads[-1], xdim)
+    _resnet(sd, "mid_block.resnets.0.", boc[-1], boc[-1], temb)
+    _resnet(sd, "mid_block.resnets.1.", boc[-1], boc[-1], temb)
+    sd["conv_norm_out.weight"] = (boc[0],)
+    sd["conv_norm_out.bias"] = (boc[0],)
+    sd["conv_out.weight"] = (cfg["out_channels"], boc[0], 3, 3)
+    sd["conv_out.bias"] = (cfg["out_channels"],)
+    return sd
+
+
+def _vae_resblock(sd, p, cin, cout):
+    sd[p + "norm1.weight"] = (cin,)
+    sd[p + "norm1.bias"] = (cin,)
+    sd[p + "conv1.weight"] = (cout, cin, 3, 3)
+    sd[p + "conv1.bias"] = (cout,)
+    sd[p + "norm2.weight"] = (cout,)
+    sd[p + "norm2.bias"] = (cout,)
+    sd[p + "conv2.weight"] = (cout, cout, 3, 3)
+    sd[p + "conv2.bias"] = (cout,)
+    if cin != cout:
+        sd[p + "nin_shortcut.weight"] = (cout, cin, 1, 1)
+        sd[p + "nin_shortcut.bias"] = (cout,)
+
+
+def vae_decoder_param_spec(dd=VAE_DDCONFIG, embed_dim=8):
+    """decoder.* and post_quant_conv.* keys of AutoencoderKL (modules.py:546-648)."""
+    ch, mult, nrb = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"]
+    nres = len(mult)
+    block_in = ch * mult[-1]
+    sd = OrderedDict()
+    sd["decoder.conv_in.weight"] = (block_in, dd["z_channels"], 3, 3)
+    sd["decoder.conv_in.bias"] = (block_in,)
+    _vae_resblock(sd, "decoder.mid.block_1.", block_in, block_in)
+    a = "decoder.mid.attn_1."
+    sd[a + "norm.weight"] = (block_in,)
+    sd[a + "norm.bias"] = (block_in,)
+    for k in ("q", "k", "v", "proj_out"):
+        sd[a + k + ".weight"] = (block_in, block_in, 1, 1)
+        sd[a + k + ".bias"] = (block_in,)
+    _vae_resblock(sd, "decoder.mid.block_2.", block_in, block_in)
+    per_level = {}
+    for lvl in reversed(range(nres)):
+        block_out = ch * mult[lvl]
+        entries = OrderedDict()
+        for b in range(nrb + 1):
+            _vae_resblock(entries, "decoder.up.%d.block.%d." % (lvl, b), block_in, block_out)
+            block_in = block_out
+        if lvl != 0:
+            entries["decoder.up.%d.upsample.conv.weight" % lvl] = (block_in, block_in, 3, 3)
+            entries["decoder.up.%d.upsample.conv.bias" % lvl] = (block_in,)
+        per_level[lvl] = entries
+    for lvl in range(nres):  # self.up.insert(0, up): state-dict order is level 0 first
+        sd.update(per_level[lvl])
+    sd["decoder.norm_out.weight"] = (block_in,)
+    sd["decoder.norm_out.bias"] = (block_in,)
+    sd["decoder.conv_out.weight"] = (dd["out_ch"], block_in, 3, 3)
+    sd["decoder.conv_out.bias"] = (dd["out_ch"],)
+    sd["post_quant_conv.weight"] = (dd["z_channels"], embed_dim, 1, 1)
+    sd["post_quant_conv.bias"] = (dd["z_channels"],)
+    return sd
+
+
+def hifigan_param_spec(h=HIFIGAN_16K_64, prefix="vocoder."):
+    """Generator keys after remove_weight_norm (bias registered before weight)."""
+    sd = OrderedDict()
+    c0 = h["upsample_initial_channel"]
+    sd[prefix + "conv_pre.bias"] = (c0,)
+    sd[prefix + "conv_pre.weight"] = (c0, h["num_mels"], 7)
+    nk = len(h["resblock_kernel_sizes"])
+    for i, (u, k) in enumerate(zip(h["upsample_rates"], h["upsample_kernel_sizes"])):
+        sd[prefix + "ups.%d.bias" % i] = (c0 // 2 ** (i + 1),)
+        sd[prefix + "ups.%d.weight" % i] = (c0 // 2 ** i, c0 // 2 ** (i + 1), k)
+    ch = c0
+    for i in range(len(h["upsample_rates"])):
+        ch = c0 // 2 ** (i + 1)
+        for j, k in enumerate(h["resblock_kernel_sizes"]):
+            p = prefix + "resblocks.%d." % (i * nk + j)
+            for grp in ("convs1", "convs2"):
+                for d in range(3):
+                    sd[p + "%s.%d.bias" % (grp, d)] = (ch,)
+                    sd[p + "%s.%d.weight" % (grp, d)] = (ch, ch, k)
+    sd[prefix + "conv_post.bias"] = (1,)
+    sd[prefix + "conv_post.weight"] = (1, ch, 7)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------
+# Deterministic generator: value i of tensor `name` is a pure function of (seed, name, i).
+# splitmix64 counter stream -> 24-bit uniform -> float32; only IEEE basic ops, so the
+# result is identical under any numpy/torch version.
+# ----------------------------------------------------------------------------------------
+_M = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _fnv1a(s):
+    h = 0xCBF29CE484222325
+    for b in s.encode("utf-8"):
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def det_uniform(name, shape, seed=0):
+    """float32 array in [-1, 1)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    base = np.uint64((_fnv1a(name) ^ (seed * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF)
+    with np.errstate(over="ignore"):
+        z = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) + base
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    u = (z >> np.uint64(40)).astype(np.float32) * np.float32(2.0 ** -24)  # [0,1)
+    return (u * np.float32(2.0) - np.float32(1.0)).reshape(shape)
+
+
+def det_weight(name, shape, seed=0):
+    """Random-init value for a parameter, by name class.  Scales are chosen so that
+    activations stay O(1) through ~100 layers (unit-gain fan-in init, damped residual
+    branches); there is no checkpoint on either box (no network), see BASELINE.md §3."""
+    shape = tuple(shape)
+    u = det_uniform(name, shape, seed)
+    leaf = name.rsplit(".", 1)[-1]
+    if name.endswith("guidance_proj.weight"):
+        return (u * np.float32(np.sqrt(3.0))).astype(np.float32)  # ~ unit variance
+    is_norm = any(t in name for t in (".norm", "norm1.", "norm2.", "norm3.", "norm_out",
+                                      "conv_norm_out", "norm."))
+    if len(shape) == 1:
+        if is_norm and leaf == "weight":
+            return (np.float32(1.0) + np.float32(0.2) * u).astype(np.float32)
+        return (np.float32(0.05) * u).astype(np.float32)  # biases
+    if "vocoder.ups." in name:
+        # ConvTranspose1d weight (Cin, Cout, k): each output sees Cin * k/u taps
+        fan_in = shape[0] * max(1, shape[2] // 2)
+    else:
+        fan_in = int(np.prod(shape[1:]))
+    gain = 1.0
+    if any(t in name for t in ("conv2.", "to_out.0.", "ff.net.2.", "proj_out.", "convs2.")):
+        gain = 0.5  # residual-branch outputs
+    a = np.float32(gain * np.sqrt(3.0 / fan_in))
+    return (a * u).astype(np.float32)
+
+
+def det_state_dict(spec, seed=0, prefix=""):
+    """name -> float32 numpy array for every entry of a spec table."""
+    return OrderedDict((k, det_weight(prefix + k, s, seed)) for k, s in spec.items())

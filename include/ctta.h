@@ -1,0 +1,277 @@
+/*
+ * ctta.h -- C ABI of the MI355X-native ConsistencyTTA hot path (libctta_hip.so).
+ *
+ * The reference (Bai-YT/ConsistencyTTA) has no FFI: its "plugin boundary" for this path is
+ * the PyTorch nn.Module protocol.  Each entry point below replaces one of
+ * those module calls and cites it.  All pointers are raw DEVICE pointers unless marked
+ * host; all calls are asynchronous on `stream` (a hipStream_t passed as void*), borrow
+ * their arguments for the duration of the call only, and return a ctta_status (no
+ * exceptions cross the boundary; ctta_last_error() gives the message for this thread).
+ * Handles own their pre-packed bf16 weights and activation arena and are freed by
+ * *_destroy.  One handle per (device, model); calls on one handle must not overlap.
+ *
+ * Layout contract at the boundary: fp32, the reference's own layouts (NCHW latents/mel,
+ * (B,L,X) text states, (B,L) uint8 mask).  Internally activations are NHWC bf16 with fp32
+ * accumulation (the reference's own GPU recipe is bf16 autocast, inference.py:190).
+ */
+#ifndef CTTA_H
+#define CTTA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  CTTA_OK = 0,
+  CTTA_ERR_INVALID = 1,     /* bad argument / unsupported shape (reference: ValueError/assert) */
+  CTTA_ERR_HIP = 2,         /* a HIP runtime call failed */
+  CTTA_ERR_MISSING_KEY = 3, /* weight table lacks a state-dict key (reference: load_state_dict) */
+  CTTA_ERR_NOMEM = 4
+} ctta_status;
+
+const char* ctta_last_error(void);
+int ctta_version(void);
+
+/* One entry of a state dict: reference key name, fp32 device data, shape. */
+typedef struct {
+  const char* name;
+  const float* data;
+  int ndim;
+  int64_t shape[4];
+} ctta_tensor;
+
+/* ------------------------------------------------------------------------------------ *
+ * U-Net.  Replaces UNet2DConditionGuidedModel.forward
+ * (diffusers/models/unet_2d_condition_guided.py:716-945) and, with guided=0, the teacher
+ * UNet2DConditionModel.forward (unet_2d_condition.py:668-907).
+ * ------------------------------------------------------------------------------------ */
+#define CTTA_MAX_LEVELS 4
+typedef struct {
+  int in_channels, out_channels;
+  int n_levels;                             /* len(block_out_channels), <= 4 */
+  int block_out_channels[CTTA_MAX_LEVELS];
+  int heads[CTTA_MAX_LEVELS];               /* config "attention_head_dim" = head COUNT */
+  int layers_per_block[CTTA_MAX_LEVELS];
+  int down_cross[CTTA_MAX_LEVELS];          /* 1: CrossAttnDownBlock2D, 0: DownBlock2D */
+  int up_cross[CTTA_MAX_LEVELS];            /* 1: CrossAttnUpBlock2D,   0: UpBlock2D   */
+  int cross_attention_dim;
+  int norm_num_groups;
+  float norm_eps;
+  int flip_sin_to_cos;
+  float freq_shift;
+  int guided;                               /* 1: guidance Fourier branch present */
+  int max_batch, height, width, max_text_len; /* arena sizing */
+  int debug_taps;                           /* 1: keep every named intermediate (tests) */
+} ctta_unet_config;
+
+typedef struct ctta_unet ctta_unet;
+
+ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_tensor* weights,
+                             int n_weights, void* stream, ctta_unet** out);
+void ctta_unet_destroy(ctta_unet* h);
+/* Re-reads (re-packs) all weights from a new table, e.g. after an optimizer/EMA step. */
+ctta_status ctta_unet_load_weights(ctta_unet* h, const ctta_tensor* weights, int n_weights,
+                                   void* stream);
+/* sample (B,C,H,W) f32; timesteps (B) f32; guidance (B) f64 or NULL when !guided;
+ * enc (B,L,X) f32; mask (B,L) u8 (1 = keep) or NULL; out (B,Cout,H,W) f32. */
+ctta_status ctta_unet_forward(ctta_unet* h, const float* sample, const float* timesteps,
+                              const double* guidance, const float* enc, const uint8_t* mask,
+                              int batch, int text_len, float* out, void* stream);
+size_t ctta_unet_arena_bytes(const ctta_unet* h);
+/* Debug taps (only when cfg.debug_taps): named NCHW fp32 copies of intermediates. */
+int ctta_unet_num_taps(const ctta_unet* h);
+ctta_status ctta_unet_tap_info(const ctta_unet* h, int i, const char** name, int dims[4]);
+ctta_status ctta_unet_tap_read(ctta_unet* h, int i, float* dst_nchw, void* stream);
+
+/* ------------------------------------------------------------------------------------ *
+ * VAE decoder + vocoder.  Replaces AutoencoderKL.decode_first_stage
+ * (audioldm/variational_autoencoder/autoencoder.py:103-106 -> Decoder.forward
+ * modules.py:650-683) and AutoencoderKL.decode_to_waveform (autoencoder.py:108-111 ->
+ * vocoder_infer hifigan/utilities.py:76-91 -> Generator.forward hifigan/models.py:101-117).
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+  int z_channels, embed_dim, ch, out_ch, n_levels, num_res_blocks;
+  int ch_mult[CTTA_MAX_LEVELS];
+  float scale_factor;
+  int max_batch, latent_h, latent_w;
+  int debug_taps;
+} ctta_vae_config;
+
+typedef struct ctta_vae ctta_vae;
+ctta_status ctta_vae_create(const ctta_vae_config* cfg, const ctta_tensor* weights,
+                            int n_weights, void* stream, ctta_vae** out);
+void ctta_vae_destroy(ctta_vae* h);
+/* z (B,zc,T,F) f32 -> mel (B,out_ch,4T,4F) f32 */
+ctta_status ctta_vae_decode(ctta_vae* h, const float* z, int batch, float* mel, void* stream);
+size_t ctta_vae_arena_bytes(const ctta_vae* h);
+int ctta_vae_num_taps(const ctta_vae* h);
+ctta_status ctta_vae_tap_info(const ctta_vae* h, int i, const char** name, int dims[4]);
+ctta_status ctta_vae_tap_read(ctta_vae* h, int i, float* dst_nchw, void* stream);
+
+#define CTTA_MAX_UPS 8
+typedef struct {
+  int num_mels, upsample_initial_channel, n_ups, n_kernels;
+  int upsample_rates[CTTA_MAX_UPS], upsample_kernel_sizes[CTTA_MAX_UPS];
+  int resblock_kernel_sizes[4];
+  int resblock_dilations[4][3];
+  int max_batch, max_frames;
+  int debug_taps;
+} ctta_hifigan_config;
+
+typedef struct ctta_hifigan ctta_hifigan;
+ctta_status ctta_hifigan_create(const ctta_hifigan_config* cfg, const ctta_tensor* weights,
+                                int n_weights, void* stream, ctta_hifigan** out);
+void ctta_hifigan_destroy(ctta_hifigan* h);
+int64_t ctta_hifigan_out_len(const ctta_hifigan* h, int frames);
+/* mel (B,frames,num_mels) f32 (== (B,1,T,F) NCHW mel) -> wav (B,out_len) f32 in (-1,1),
+ * BEFORE the reference's batch-global centring. */
+ctta_status ctta_hifigan_forward(ctta_hifigan* h, const float* mel, int batch, int frames,
+                                 float* wav, void* stream);
+/* vocoder_infer post-processing (utilities.py:83-86): wav -= (max+min)/2 over the WHOLE
+ * batch, *32768, truncation to int16.  `scratch` >= 2 floats of device memory.
+ * centred (float, may be NULL) and pcm (int16, may be NULL) receive the results. */
+ctta_status ctta_wav_finalize(const float* wav, int64_t n, float* scratch, float* centred,
+                              int16_t* pcm, void* stream);
+size_t ctta_hifigan_arena_bytes(const ctta_hifigan* h);
+int ctta_hifigan_num_taps(const ctta_hifigan* h);
+ctta_status ctta_hifigan_tap_info(const ctta_hifigan* h, int i, const char** name, int dims[4]);
+ctta_status ctta_hifigan_tap_read(ctta_hifigan* h, int i, float* dst_ncl, void* stream);
+
+/* ------------------------------------------------------------------------------------ *
+ * Heun solver elementwise steps with PER-SAMPLE sigmas.  Replace
+ * HeunDiscreteScheduler.{scale_model_input,add_noise,step}
+ * (diffusers/schedulers/scheduling_heun_discrete.py:151-172,364-385,273-362), v-prediction.
+ * x etc. are (B, n_per_sample) f32; sigma arrays are (B) f32 on device.
+ * ------------------------------------------------------------------------------------ */
+ctta_status ctta_heun_scale_model_input(const float* x, const float* sigma, float* out,
+                                        int batch, int64_t n_per_sample, void* stream);
+ctta_status ctta_heun_add_noise(const float* x0, const float* noise, const float* sigma,
+                                float* out, int batch, int64_t n_per_sample, void* stream);
+/* 1st-order half: prev = x + d*(sigma_next-sigma), d = (x - x0_hat)/sigma; writes d. */
+ctta_status ctta_heun_step_first(const float* v, const float* x, const float* sigma,
+                                 const float* sigma_next, float* prev, float* deriv,
+                                 int batch, int64_t n_per_sample, void* stream);
+/* 2nd-order half: d2 at (x_hat, sigma_next); prev = x_stored + (d_prev+d2)/2*(sigma_next-sigma) */
+ctta_status ctta_heun_step_second(const float* v, const float* x_hat, const float* x_stored,
+                                  const float* deriv_prev, const float* sigma,
+                                  const float* sigma_next, float* prev, int batch,
+                                  int64_t n_per_sample, void* stream);
+/* AudioDistilledModel._query_teacher CFG combine (models/audio_distilled_model.py:313-319):
+ * out = (1-w)*uncond + w*cond, per-sample w (B) f32. */
+ctta_status ctta_cfg_combine(const float* uncond, const float* cond, const float* w, float* out,
+                             int batch, int64_t n_per_sample, void* stream);
+/* get_loss with MSELoss('instance') and SNR clamp (models/audio_consistency_model.py:250-266,
+ * tools/losses.py:28-33): loss = mean_b( mean((pred-target)^2) * min(sigma^-2, gamma) ).
+ * gamma <= 0 disables the weighting.  loss: 1 float on device. */
+ctta_status ctta_snr_mse_loss(const float* pred, const float* target, const float* sigma,
+                              float gamma, float* per_instance, float* loss, int batch,
+                              int64_t n_per_sample, void* stream);
+
+/* ------------------------------------------------------------------------------------ *
+ * Fused two-shadow EMA.  Replaces do_ema_update (tools/train_utils.py:255-282) as called by
+ * AudioLCM.update_ema (models/audio_consistency_model.py:221-227): for each shadow s_k:
+ * s_k += (1-decay_k)*(p - s_k), fp32, in place.  shadow_b/decay_b may be NULL/0.
+ * ------------------------------------------------------------------------------------ */
+ctta_status ctta_ema_update2(const float* param, float* shadow_a, float decay_a, float* shadow_b,
+                             float decay_b, int64_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------ *
+ * Operator-level entry points (used by the engines; exported for per-op parity tests and
+ * micro-benchmarks).  bf16 tensors are uint16_t bit patterns, NHWC.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+  const void* x0; int c0;     /* NHWC bf16 source, channel count == row stride */
+  const void* x1; int c1;     /* optional second source, concatenated after x0's channels */
+  int batch, hi, wi;          /* LOGICAL input extent (after the optional x2 upsample) */
+  int upsample;               /* 1: sources are (hi/2, wi/2), nearest-upsampled on the fly */
+  int ho, wo;
+  int kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
+  const void* w;              /* packed bf16 [n_rows >= n][k_pad], k = (kh,kw,c), zero padded */
+  int k_pad;                  /* row stride of w, multiple of 64 */
+  int n;                      /* valid output channels, multiple of 4 */
+  const float* bias;          /* [n] or NULL */
+  const float* rowvec; int rowvec_ld;   /* + rowvec[b*ld + n] (time-embedding shift) or NULL */
+  const void* res; int res_ld;          /* + res[m*ld + n] bf16 or NULL */
+  int in_act;                 /* on the A operand: 0 none, 1 leaky_relu(in_slope) */
+  float in_slope;
+  int out_act;                /* 0 none, 1 silu, 2 tanh */
+  float alpha;                /* v = alpha*(acc + bias + rowvec + res [+ old out]) */
+  int accumulate;             /* 1: add the existing output before scaling */
+  void* out; int ldc;         /* bf16 (or f32 when out_f32) [m][ldc] */
+  int out_f32;
+  int64_t out_batch_stride;   /* 0 -> ho*wo*ldc */
+  int64_t out_offset;         /* element offset added inside a batch (ConvTranspose remap) */
+  int64_t out_limit;          /* >0: store only if 0 <= idx_in_batch < out_limit */
+  /* batched GEMM (grid.z): extra strides in elements; 0 = shared */
+  int groups; int64_t x_group_stride, w_group_stride, out_group_stride;
+  int tile;                   /* 0 = auto; else force a kernel variant id (tuning) */
+} ctta_conv_desc;
+
+ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream);
+int ctta_conv_gemm_num_variants(void);
+const char* ctta_conv_gemm_variant_name(int id);
+
+/* Direct convolution for tiny Cout (<= 8): bf16 NHWC in, fp32 weights [n][kh][kw][c],
+ * fp32 planar (NCHW) out, optional input leaky-relu and output tanh. */
+ctta_status ctta_conv_small_n(const void* x, int c, int batch, int hi, int wi, int kh, int kw,
+                              int pad_h, int pad_w, const float* w, const float* bias, int n,
+                              int in_act, float in_slope, int out_act, float* out_nchw,
+                              void* out_bf16_nhwc, void* stream);
+
+/* fp32 weight matrix -> packed bf16 [n_rows][k_pad]: dst[r][k] = src[row_off[r]+col_off[k]]
+ * (zero when either offset < 0, or when aux_limit > 0 and row_aux[r]+col_aux[k] >= aux_limit).
+ * All index arrays are DEVICE int32. */
+ctta_status ctta_pack_weight(const float* src, const int32_t* row_off, const int32_t* col_off,
+                             const int32_t* row_aux, const int32_t* col_aux, int aux_limit,
+                             int n_rows, int k_pad, void* dst, void* stream);
+
+ctta_status ctta_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int batch, int c, int h,
+                                       int w, int c_pad, float scale, void* stream);
+ctta_status ctta_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int batch, int c, int h,
+                                       int w, int c_stride, void* stream);
+ctta_status ctta_rows_f32_to_bf16(const float* src, void* dst, int64_t rows, int cols,
+                                  int cols_pad, void* stream);
+ctta_status ctta_concat_channels(const void* a, int ca, const void* b, int cb, void* dst,
+                                 int64_t pixels, void* stream);
+
+/* GroupNorm over NHWC bf16 (+ optional SiLU): F.group_norm semantics (biased variance).
+ * scratch: fp32 device buffer of ctta_groupnorm_scratch_floats(...) floats. */
+size_t ctta_groupnorm_scratch_floats(int batch, int hw, int c, int groups);
+ctta_status ctta_groupnorm(const void* x, void* y, int batch, int hw, int c, int groups,
+                           const float* gamma, const float* beta, float eps, int silu,
+                           float* scratch, void* stream);
+/* LayerNorm over rows of a padded bf16 matrix: dims [rows][ld], true width d (pad -> 0). */
+ctta_status ctta_layernorm(const void* x, void* y, int64_t rows, int d, int ld,
+                           const float* gamma, const float* beta, float eps, void* stream);
+/* GEGLU: in [rows][2*hp] = [value | gate] -> out [rows][hp] = value * gelu_erf(gate) */
+ctta_status ctta_geglu(const void* in, void* out, int64_t rows, int hp, void* stream);
+/* Row softmax: fp32 scores [rows][cols] * scale -> bf16 probabilities [rows][cols] */
+ctta_status ctta_softmax_rows(const float* s, void* p, int64_t rows, int cols, float scale,
+                              void* stream);
+
+/* Multi-head attention, head dim padded to 64 (pad lanes must be zero):
+ * q [B][nq][..] row stride q_ld, head h at column h*64; k likewise; vt is V TRANSPOSED:
+ * [B][heads*64][vt_ld] (keys contiguous).  bias (B, nk) f32 additive per key or NULL.
+ * softmax(q k^T * scale + bias) v  ->  out [B][nq][out_ld], head h at column h*64. */
+ctta_status ctta_attention(const void* q, int q_ld, const void* k, int k_ld, const void* vt,
+                           int vt_ld, const float* bias, void* out, int out_ld, int batch,
+                           int heads, int nq, int nk, float scale, void* stream);
+
+/* Small fp32 linear: y[m][n] = act_out(sum_k act_in(x[m][k]) * w[n][k] + b[n]); m <= 1024.
+ * act: 0 none, 1 silu. */
+ctta_status ctta_linear_f32(const float* x, const float* w, const float* b, float* y, int m,
+                            int n, int k, int act_in, int act_out, void* stream);
+/* Sinusoidal timestep features (embeddings.py:25-65) and Gaussian Fourier features
+ * (embeddings.py:239-249) in one launch.  freqs: [dim/2] f32 table. */
+ctta_status ctta_time_features(const float* t, const float* freqs, int dim, int flip, float* out,
+                               int batch, void* stream);
+ctta_status ctta_fourier_features(const double* w, const float* weight, int half, int flip,
+                                  float* out, int batch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CTTA_H */

@@ -1,0 +1,308 @@
+"""fp32 PyTorch-CPU restatement of the three networks on the hot path (test oracle).
+
+All functions take a flat `sd` mapping (reference state-dict key -> torch.float32 tensor)
+so that the same weights feed the reference modules, this oracle and the HIP engine.
+`taps`, when given, collects named intermediates (NCHW) for layer-by-layer localisation.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from consistencytta_amd.spec import unet_levels
+
+
+# ----------------------------------------------------------------------------- embeddings
+def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0, max_period=10000):
+    """diffusers/models/embeddings.py:25-65 (sinusoid always in fp32)."""
+    half = dim // 2
+    exponent = -math.log(max_period) * torch.arange(half, dtype=torch.float32)
+    exponent = exponent / (half - freq_shift)
+    emb = t[:, None].float() * torch.exp(exponent)[None, :]
+    emb = torch.cat([torch.sin(emb), torch.cos(emb)], dim=-1)
+    if flip_sin_to_cos:
+        emb = torch.cat([emb[:, half:], emb[:, :half]], dim=-1)
+    return emb
+
+
+def fourier_embedding(w, weight, flip_sin_to_cos=True):
+    """GaussianFourierProjection.forward, embeddings.py:239-249 (log=False)."""
+    x = w[:, None] * weight[None, :] * 2 * math.pi
+    if flip_sin_to_cos:
+        return torch.cat([torch.cos(x), torch.sin(x)], dim=-1)
+    return torch.cat([torch.sin(x), torch.cos(x)], dim=-1)
+
+
+def _mlp(sd, p, x):
+    """TimestepEmbedding.forward, embeddings.py:188-202."""
+    x = F.linear(x, sd[p + "linear_1.weight"], sd[p + "linear_1.bias"])
+    x = F.silu(x)
+    return F.linear(x, sd[p + "linear_2.weight"], sd[p + "linear_2.bias"])
+
+
+# ----------------------------------------------------------------------------- U-Net blocks
+def resnet_block(sd, p, x, temb, groups, eps):
+    """ResnetBlock2D.forward, resnet.py:549-597 (time_embedding_norm='default',
+    output_scale_factor=1)."""
+    h = F.group_norm(x, groups, sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps)
+    h = F.silu(h)
+    h = F.conv2d(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
+    t = F.linear(F.silu(temb), sd[p + "time_emb_proj.weight"], sd[p + "time_emb_proj.bias"])
+    h = h + t[:, :, None, None]
+    h = F.group_norm(h, groups, sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps)
+    h = F.silu(h)
+    h = F.conv2d(h, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    if (p + "conv_shortcut.weight") in sd:
+        x = F.conv2d(x, sd[p + "conv_shortcut.weight"], sd[p + "conv_shortcut.bias"])
+    return x + h
+
+
+def attention(sd, p, x, heads, ctx=None, bias=None):
+    """Attention + AttnProcessor2_0.__call__, attention_processor.py:1068-1147.
+    `bias` is the additive (B,1,L) mask bias; scale is 1/sqrt(head_dim) (SDPA default)."""
+    B, N, inner = x.shape
+    src = x if ctx is None else ctx
+    q = F.linear(x, sd[p + "to_q.weight"])
+    k = F.linear(src, sd[p + "to_k.weight"])
+    v = F.linear(src, sd[p + "to_v.weight"])
+    d = inner // heads
+    q = q.view(B, -1, heads, d).transpose(1, 2)
+    k = k.view(B, -1, heads, d).transpose(1, 2)
+    v = v.view(B, -1, heads, d).transpose(1, 2)
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(d)
+    if bias is not None:
+        s = s + bias[:, None, :, :]  # (B,1,1,L) broadcast over heads and queries
+    o = torch.matmul(torch.softmax(s, dim=-1), v)
+    o = o.transpose(1, 2).reshape(B, -1, heads * d)
+    return F.linear(o, sd[p + "to_out.0.weight"], sd[p + "to_out.0.bias"])
+
+
+def transformer_block(sd, p, x, heads, ctx, bias):
+    """BasicTransformerBlock.forward, attention.py:276-334."""
+    dim = x.shape[-1]
+    n = F.layer_norm(x, (dim,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-5)
+    x = attention(sd, p + "attn1.", n, heads) + x
+    n = F.layer_norm(x, (dim,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-5)
+    x = attention(sd, p + "attn2.", n, heads, ctx, bias) + x
+    n = F.layer_norm(x, (dim,), sd[p + "norm3.weight"], sd[p + "norm3.bias"], 1e-5)
+    hgate = F.linear(n, sd[p + "ff.net.0.proj.weight"], sd[p + "ff.net.0.proj.bias"])
+    hval, gate = hgate.chunk(2, dim=-1)  # GEGLU.forward attention.py:430-432
+    ff = F.linear(hval * F.gelu(gate), sd[p + "ff.net.2.weight"], sd[p + "ff.net.2.bias"])
+    return ff + x
+
+
+def transformer_2d(sd, p, x, heads, groups, ctx, bias):
+    """Transformer2DModel.forward (use_linear_projection), transformer_2d.py:218-332;
+    the GroupNorm eps is hard-coded 1e-6 (:149)."""
+    B, C, H, W = x.shape
+    res = x
+    h = F.group_norm(x, groups, sd[p + "norm.weight"], sd[p + "norm.bias"], 1e-6)
+    h = h.permute(0, 2, 3, 1).reshape(B, H * W, C)
+    h = F.linear(h, sd[p + "proj_in.weight"], sd[p + "proj_in.bias"])
+    h = transformer_block(sd, p + "transformer_blocks.0.", h, heads, ctx, bias)
+    h = F.linear(h, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+    h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    return h + res
+
+
+def unet_forward(cfg, sd, sample, timestep, guidance, enc, enc_mask, taps=None):
+    """UNet2DConditionGuidedModel.forward, unet_2d_condition_guided.py:716-945.
+    `guidance=None` selects the teacher UNet2DConditionModel.forward
+    (unet_2d_condition.py:668-907: identical minus the guidance branch).
+    sample (B,C,H,W); timestep/guidance (B,) or scalars; enc (B,L,X); enc_mask (B,L) bool."""
+    boc, heads, layers = unet_levels(cfg)
+    n = len(boc)
+    groups, eps = cfg["norm_num_groups"], cfg["norm_eps"]
+    B = sample.shape[0]
+    sample = sample.float()
+    enc = enc.float()
+
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t.detach().clone()
+
+    bias = None
+    if enc_mask is not None:  # :793-795
+        bias = ((1 - enc_mask.to(sample.dtype)) * -10000.0).unsqueeze(1)
+
+    def prep(v):  # _prepare_tensor :699-714 -- Python floats become float64 tensors
+        if not torch.is_tensor(v):
+            v = torch.tensor([v], dtype=torch.float64 if isinstance(v, float) else torch.int64)
+        elif v.ndim == 0:
+            v = v[None]
+        return v.expand(B)
+
+    t = prep(timestep)
+    t_emb = timestep_embedding(t, boc[0], cfg["flip_sin_to_cos"], cfg["freq_shift"])
+    emb = _mlp(sd, "time_embedding.", t_emb.to(sample.dtype))
+    if guidance is not None:
+        g = prep(guidance)
+        g_emb = fourier_embedding(g, sd["guidance_proj.weight"].to(g.dtype)
+                                  if g.dtype == torch.float64 else sd["guidance_proj.weight"],
+                                  cfg["flip_sin_to_cos"])
+        emb = emb + _mlp(sd, "guidance_embedding.", g_emb.to(sample.dtype))
+    tap("emb", emb)
+
+    h = F.conv2d(sample, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    tap("conv_in", h)
+    skips = [h]
+    for i in range(n):
+        p = "down_blocks.%d." % i
+        cross = cfg["down_block_types"][i] == "CrossAttnDownBlock2D"
+        for j in range(layers[i]):
+            h = resnet_block(sd, p + "resnets.%d." % j, h, emb, groups, eps)
+            tap(p + "resnets.%d" % j, h)
+            if cross:
+                h = transformer_2d(sd, p + "attentions.%d." % j, h, heads[i], groups, enc, bias)
+                tap(p + "attentions.%d" % j, h)
+            skips.append(h)
+        if i != n - 1:  # Downsample2D resnet.py:199-208
+            h = F.conv2d(h, sd[p + "downsamplers.0.conv.weight"],
+                         sd[p + "downsamplers.0.conv.bias"], stride=2,
+                         padding=cfg["downsample_padding"])
+            tap(p + "downsamplers.0", h)
+            skips.append(h)
+
+    p = "mid_block."
+    h = resnet_block(sd, p + "resnets.0.", h, emb, groups, eps)
+    h = transformer_2d(sd, p + "attentions.0.", h, heads[-1], groups, enc, bias)
+    h = resnet_block(sd, p + "resnets.1.", h, emb, groups, eps)
+    tap("mid_block", h)
+
+    rheads, rlayers = heads[::-1], layers[::-1]
+    for i in range(n):
+        p = "up_blocks.%d." % i
+        cross = cfg["up_block_types"][i] == "CrossAttnUpBlock2D"
+        for j in range(rlayers[i] + 1):
+            h = torch.cat([h, skips.pop()], dim=1)
+            h = resnet_block(sd, p + "resnets.%d." % j, h, emb, groups, eps)
+            tap(p + "resnets.%d" % j, h)
+            if cross:
+                h = transformer_2d(sd, p + "attentions.%d." % j, h, rheads[i], groups, enc, bias)
+                tap(p + "attentions.%d" % j, h)
+        if i != n - 1:  # Upsample2D resnet.py:126-161
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = F.conv2d(h, sd[p + "upsamplers.0.conv.weight"],
+                         sd[p + "upsamplers.0.conv.bias"], padding=1)
+            tap(p + "upsamplers.0", h)
+
+    h = F.group_norm(h, groups, sd["conv_norm_out.weight"], sd["conv_norm_out.bias"], eps)
+    h = F.silu(h)
+    h = F.conv2d(h, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+    tap("conv_out", h)
+    return h
+
+
+# ----------------------------------------------------------------------------- VAE decoder
+def _vae_norm(sd, p, x, groups=32):
+    return F.group_norm(x, groups, sd[p + "weight"], sd[p + "bias"], 1e-6)  # modules.py:38-41
+
+
+def vae_resblock(sd, p, x, groups=32):
+    """ResnetBlock.forward (temb=None), modules.py:155-175."""
+    h = _vae_norm(sd, p + "norm1.", x, groups)
+    h = h * torch.sigmoid(h)
+    h = F.conv2d(h, sd[p + "conv1.weight"], sd[p + "conv1.bias"], padding=1)
+    h = _vae_norm(sd, p + "norm2.", h, groups)
+    h = h * torch.sigmoid(h)
+    h = F.conv2d(h, sd[p + "conv2.weight"], sd[p + "conv2.bias"], padding=1)
+    if (p + "nin_shortcut.weight") in sd:
+        x = F.conv2d(x, sd[p + "nin_shortcut.weight"], sd[p + "nin_shortcut.bias"])
+    return x + h
+
+
+def vae_attn(sd, p, x, groups=32):
+    """AttnBlock.forward, modules.py:204-230 (single head over H*W tokens, d = C)."""
+    B, C, H, W = x.shape
+    h = _vae_norm(sd, p + "norm.", x, groups)
+    q = F.conv2d(h, sd[p + "q.weight"], sd[p + "q.bias"]).reshape(B, C, H * W).permute(0, 2, 1)
+    k = F.conv2d(h, sd[p + "k.weight"], sd[p + "k.bias"]).reshape(B, C, H * W)
+    v = F.conv2d(h, sd[p + "v.weight"], sd[p + "v.bias"]).reshape(B, C, H * W)
+    w = torch.bmm(q, k) * (int(C) ** (-0.5))
+    w = torch.softmax(w, dim=2)
+    o = torch.bmm(v, w.permute(0, 2, 1)).reshape(B, C, H, W)
+    o = F.conv2d(o, sd[p + "proj_out.weight"], sd[p + "proj_out.bias"])
+    return x + o
+
+
+def vae_decode(dd, sd, z, scale_factor, taps=None, groups=32):
+    """AutoencoderKL.decode_first_stage/decode (autoencoder.py:91-106) + Decoder.forward
+    (modules.py:650-683).  z (B,8,T,F) -> mel (B,1,4T,4F)."""
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t.detach().clone()
+
+    nres = len(dd["ch_mult"])
+    z = z.float() / scale_factor
+    z = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+    p = "decoder."
+    h = F.conv2d(z, sd[p + "conv_in.weight"], sd[p + "conv_in.bias"], padding=1)
+    tap("conv_in", h)
+    h = vae_resblock(sd, p + "mid.block_1.", h, groups)
+    tap("mid.block_1", h)
+    h = vae_attn(sd, p + "mid.attn_1.", h, groups)
+    tap("mid.attn_1", h)
+    h = vae_resblock(sd, p + "mid.block_2.", h, groups)
+    tap("mid.block_2", h)
+    for lvl in reversed(range(nres)):
+        for b in range(dd["num_res_blocks"] + 1):
+            h = vae_resblock(sd, p + "up.%d.block.%d." % (lvl, b), h, groups)
+            tap("up.%d.block.%d" % (lvl, b), h)
+        if lvl != 0:  # Upsample.forward modules.py:53-57
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = F.conv2d(h, sd[p + "up.%d.upsample.conv.weight" % lvl],
+                         sd[p + "up.%d.upsample.conv.bias" % lvl], padding=1)
+            tap("up.%d.upsample" % lvl, h)
+    h = _vae_norm(sd, p + "norm_out.", h, groups)
+    h = h * torch.sigmoid(h)
+    h = F.conv2d(h, sd[p + "conv_out.weight"], sd[p + "conv_out.bias"], padding=1)
+    return h
+
+
+# ----------------------------------------------------------------------------- HiFi-GAN
+def hifigan_forward(hcfg, sd, mel, prefix="vocoder.", taps=None):
+    """Generator.forward, hifigan/models.py:101-117; ResBlock.forward :56-63.
+    mel (B, num_mels, T) -> (B, 1, T * prod(upsample_rates) [+ tails])."""
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t.detach().clone()
+
+    P = prefix
+    nk = len(hcfg["resblock_kernel_sizes"])
+    x = F.conv1d(mel, sd[P + "conv_pre.weight"], sd[P + "conv_pre.bias"], padding=3)
+    tap("conv_pre", x)
+    for i, (u, k) in enumerate(zip(hcfg["upsample_rates"], hcfg["upsample_kernel_sizes"])):
+        x = F.leaky_relu(x, 0.1)
+        x = F.conv_transpose1d(x, sd[P + "ups.%d.weight" % i], sd[P + "ups.%d.bias" % i],
+                               stride=u, padding=(k - u) // 2)
+        tap("ups.%d" % i, x)
+        xs = None
+        for j, (rk, dil) in enumerate(zip(hcfg["resblock_kernel_sizes"],
+                                          hcfg["resblock_dilation_sizes"])):
+            rp = P + "resblocks.%d." % (i * nk + j)
+            r = x
+            for m, d in enumerate(dil):
+                xt = F.leaky_relu(r, 0.1)
+                xt = F.conv1d(xt, sd[rp + "convs1.%d.weight" % m], sd[rp + "convs1.%d.bias" % m],
+                              dilation=d, padding=(rk * d - d) // 2)
+                xt = F.leaky_relu(xt, 0.1)
+                xt = F.conv1d(xt, sd[rp + "convs2.%d.weight" % m], sd[rp + "convs2.%d.bias" % m],
+                              padding=(rk - 1) // 2)
+                r = xt + r
+            xs = r if xs is None else xs + r
+        x = xs / nk
+        tap("stage.%d" % i, x)
+    x = F.leaky_relu(x)  # default slope 0.01, models.py:113
+    x = F.conv1d(x, sd[P + "conv_post.weight"], sd[P + "conv_post.bias"], padding=3)
+    return torch.tanh(x)
+
+
+def mel_to_waveform(hcfg, sd, mel_b1tf, prefix="vocoder."):
+    """AutoencoderKL.decode_to_waveform (autoencoder.py:108-111) + vocoder_infer
+    (hifigan/utilities.py:76-91).  Returns (float waveform before centring, centred float
+    waveform, int16 numpy) -- the batch-global (max+min)/2 centring is the reference's."""
+    dec = mel_b1tf.squeeze(1).permute(0, 2, 1)
+    wav = hifigan_forward(hcfg, sd, dec, prefix).squeeze(1).float()
+    centred = wav - (wav.max() + wav.min()) / 2
+    pcm = (centred.cpu().numpy() * 32768).astype("int16")
+    return wav, centred, pcm

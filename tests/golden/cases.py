@@ -1,0 +1,70 @@
+"""Shared definitions of the parity cases: configs, deterministic inputs, weights.
+
+Inputs and weights are pure functions of (name, shape, seed) via
+`consistencytta_amd.spec.det_uniform/det_weight`, so fixtures only need to hold the
+reference's OUTPUTS.  Used by make_golden.py (reference side), the oracle tests and the
+GPU parity tests.
+"""
+import numpy as np
+import torch
+
+from consistencytta_amd import spec
+
+# Tiny U-Net: exercises inner_dim != channels (heads that do not divide C: 40//3=13 -> 39),
+# GroupNorm group sizes that are not multiples of 8 (5, 10, 15), concat widths, 4 levels.
+TINY_UNET = dict(spec.LIGHT_UNET_CONFIG,
+                 block_out_channels=[40, 80, 80, 80],
+                 attention_head_dim=[3, 3, 6, 6],
+                 cross_attention_dim=48,
+                 norm_num_groups=8)
+
+TINY_VAE_DD = dict(spec.VAE_DDCONFIG, ch=32)
+TINY_VAE_GROUPS = 32  # Normalize() hard-codes 32 groups (modules.py:38-41): ch=32 -> 1 ch/group
+
+TINY_HIFIGAN = dict(spec.HIFIGAN_16K_64, upsample_initial_channel=64)
+
+SIGMA_MAX = 14.6146
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def unet_weights(cfg, guided=True, seed=0):
+    sp = spec.unet_param_spec(cfg, guided)
+    return {k: t(v) for k, v in spec.det_state_dict(sp, seed, prefix="unet.").items()}
+
+
+def vae_weights(dd, seed=0):
+    sp = spec.vae_decoder_param_spec(dd)
+    return {k: t(v) for k, v in spec.det_state_dict(sp, seed, prefix="vae.").items()}
+
+
+def hifigan_weights(h, seed=0):
+    sp = spec.hifigan_param_spec(h)
+    return {k: t(v) for k, v in spec.det_state_dict(sp, seed, prefix="vae.").items()}
+
+
+def unet_inputs(cfg, B, H, W, L, tag, per_sample=True):
+    """sample, timestep, guidance, encoder states, mask for a case called `tag`."""
+    C = cfg["in_channels"]
+    X = cfg["cross_attention_dim"]
+    sample = t(spec.det_uniform(tag + ".sample", (B, C, H, W), 1)) * 1.7
+    enc = t(spec.det_uniform(tag + ".enc", (B, L, X), 2)) * 0.5
+    lens = (np.abs(spec.det_uniform(tag + ".len", (B,), 3)) * (L - 1)).astype(np.int64) + 1
+    lens[0] = L
+    mask = torch.arange(L)[None, :] < t(lens)[:, None]
+    if per_sample:
+        ts = t(np.abs(spec.det_uniform(tag + ".t", (B,), 4)).astype(np.float64) * 999.0)
+        gs = t(np.abs(spec.det_uniform(tag + ".w", (B,), 5)) * 6.0)
+    else:
+        ts, gs = 999.0, 4.0
+    return sample, ts, gs, enc, mask
+
+
+def vae_inputs(B, T, Fq, tag):
+    return t(spec.det_uniform(tag + ".z", (B, 8, T, Fq), 6)) * 2.0
+
+
+def mel_inputs(B, T, nmel, tag):
+    return t(spec.det_uniform(tag + ".mel", (B, 1, T, nmel), 7)) * 1.5

@@ -1,0 +1,177 @@
+"""Generates tests/golden/*.npz from the REFERENCE's own modules (build container only).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Each fixture holds only outputs (and tiny metadata); inputs/weights are regenerated from
+names and seeds by tests/golden/cases.py.  The reference modules are instantiated from
+/root/reference/easy_inference (see ref_import.py) and loaded with those weights.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import cases  # noqa: E402
+import ref_import  # noqa: E402
+from consistencytta_amd import spec  # noqa: E402
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def ref_unet(ns, cfg, guided, seed=0):
+    cls = ns.UNet2DConditionGuidedModel if guided else ns.UNet2DConditionModel
+    full = dict(cls.load_config(ns.light_config_path))
+    full.update(cfg)
+    m = cls.from_config(full)
+    sd = cases.unet_weights(cfg, guided, seed)
+    ref_keys = list(m.state_dict().keys())
+    assert ref_keys == list(sd.keys()), "state-dict key order differs from the reference"
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(sd[k].shape), k
+    m.load_state_dict(sd)
+    return m.eval().requires_grad_(False)
+
+
+def golden_unet(ns):
+    torch.manual_seed(0)
+    with torch.no_grad():
+        # tiny guided, per-sample t / w
+        cfg = cases.TINY_UNET
+        m = ref_unet(ns, cfg, True)
+        x, ts, gs, enc, mask = cases.unet_inputs(cfg, 2, 32, 8, 7, "unet_tiny")
+        out = m(x, ts, guidance=gs, encoder_hidden_states=enc, encoder_attention_mask=mask).sample
+        # scalar python t / w (fp64 Fourier path)
+        x2, _, _, enc2, mask2 = cases.unet_inputs(cfg, 2, 16, 8, 5, "unet_tiny_s", False)
+        out2 = m(x2, 999.0, guidance=4.0, encoder_hidden_states=enc2,
+                 encoder_attention_mask=mask2).sample
+        # teacher (no guidance branch)
+        mt = ref_unet(ns, cfg, False)
+        out3 = mt(x, ts, enc, encoder_attention_mask=mask).sample
+        save("unet_tiny", guided=out.numpy(), guided_scalar=out2.numpy(), teacher=out3.numpy(),
+             keys=np.array(list(m.state_dict().keys())))
+        # light config, B=1, L=16 (config 1 of BASELINE.json)
+        cfg = spec.LIGHT_UNET_CONFIG
+        m = ref_unet(ns, cfg, True)
+        n_params = sum(p.numel() for p in m.parameters())
+        x, _, _, enc, mask = cases.unet_inputs(cfg, 1, 256, 16, 16, "unet_light", False)
+        x = x / 1.7 * cases.SIGMA_MAX / ((cases.SIGMA_MAX ** 2 + 1) ** 0.5)
+        out = m(x, 999.0, guidance=4.0, encoder_hidden_states=enc,
+                encoder_attention_mask=mask).sample
+        save("unet_light", out=out.numpy(), n_params=n_params)
+
+
+def ref_vae(ns, dd, hcfg, seed=0):
+    cfg = ns.default_audioldm_config("audioldm-s-full")
+    vc = dict(cfg["model"]["params"]["first_stage_config"]["params"])
+    vc["ddconfig"] = dict(vc["ddconfig"], **{k: dd[k] for k in ("ch", "ch_mult", "num_res_blocks")})
+    vc["scale_factor"] = 0.9227914214134216
+    ns.hifigan_utilities.HIFIGAN_16K_64.update(
+        {k: hcfg[k] for k in ("upsample_initial_channel",)})
+    vae = ns.autoencoder.AutoencoderKL(**vc)
+    sd = dict(cases.vae_weights(dd, seed))
+    sd.update(cases.hifigan_weights(hcfg, seed))
+    ref_sd = vae.state_dict()
+    for k, v in sd.items():
+        assert tuple(ref_sd[k].shape) == tuple(v.shape), k
+    dec_keys = [k for k in ref_sd if k.startswith(("decoder.", "post_quant_conv."))]
+    assert dec_keys == list(spec.vae_decoder_param_spec(dd).keys())
+    voc_keys = [k for k in ref_sd if k.startswith("vocoder.")]
+    assert voc_keys == list(spec.hifigan_param_spec(hcfg).keys())
+    missing, unexpected = vae.load_state_dict(sd, strict=False)
+    assert not unexpected
+    assert all(k.startswith(("encoder.", "quant_conv.")) for k in missing), missing
+    return vae.eval().requires_grad_(False), vc["scale_factor"]
+
+
+def golden_vae(ns):
+    with torch.no_grad():
+        vae, sf = ref_vae(ns, cases.TINY_VAE_DD, cases.TINY_HIFIGAN)
+        z = cases.vae_inputs(2, 16, 8, "vae_tiny")
+        mel = vae.decode_first_stage(z)
+        mel_in = cases.mel_inputs(2, 24, 64, "hifigan_tiny")
+        wav = vae.vocoder(mel_in.squeeze(1).permute(0, 2, 1)).squeeze(1).float()
+        pcm = vae.decode_to_waveform(mel_in)
+        save("vae_tiny", mel=mel.numpy(), wav=wav.numpy(), pcm=pcm, scale_factor=sf)
+
+        vae, sf = ref_vae(ns, spec.VAE_DDCONFIG, spec.HIFIGAN_16K_64)
+        z = cases.vae_inputs(1, 64, 16, "vae_full")  # full widths, quarter length
+        mel = vae.decode_first_stage(z)
+        mel_in = cases.mel_inputs(1, 64, 64, "hifigan_full")
+        wav = vae.vocoder(mel_in.squeeze(1).permute(0, 2, 1)).squeeze(1).float()
+        save("vae_full", mel=mel.numpy(), wav=wav.numpy(), scale_factor=sf)
+
+
+def golden_heun(ns):
+    out = {}
+    for n in (1, 2, 18, 200):
+        s = ref_import.make_heun(ns)
+        s.set_timesteps(n)
+        out["timesteps_%d" % n] = s.timesteps.numpy()
+        out["sigmas_%d" % n] = s.sigmas.numpy()
+        out["init_sigma_%d" % n] = float(s.init_noise_sigma)
+    s = ref_import.make_heun(ns)
+    s.set_timesteps(18)
+    B = 3
+    x = cases.t(spec.det_uniform("heun.x", (B, 8, 16, 4), 1)) * 3
+    v1 = cases.t(spec.det_uniform("heun.v1", (B, 8, 16, 4), 2))
+    v2 = cases.t(spec.det_uniform("heun.v2", (B, 8, 16, 4), 3))
+    noise = cases.t(spec.det_uniform("heun.n", (B, 8, 16, 4), 4))
+    idx = torch.tensor([0, 6, 32])
+    t_a = s.timesteps[idx]
+    t_b = s.timesteps[idx + 2]
+    out["scaled"] = s.scale_model_input(x, t_a).numpy()
+    out["noised"] = s.add_noise(x, noise, t_a).numpy()
+    first = s.step(v1, t_a, x).prev_sample
+    out["step1"] = first.numpy()
+    assert not s.state_in_first_order
+    out["scaled2"] = s.scale_model_input(first, t_b).numpy()
+    second = s.step(v2, t_b, first).prev_sample
+    out["step2"] = second.numpy()
+    assert s.state_in_first_order
+    out["idx"] = idx.numpy()
+    save("heun", **out)
+
+
+def golden_pipeline(ns):
+    """Config 1 of BASELINE.json end to end with the reference modules: noise -> latent
+    (1 U-Net query, w=4, no post-CFG) -> mel -> float waveform."""
+    with torch.no_grad():
+        cfg = spec.LIGHT_UNET_CONFIG
+        m = ref_unet(ns, cfg, True)
+        vae, sf = ref_vae(ns, spec.VAE_DDCONFIG, spec.HIFIGAN_16K_64)
+        s = ref_import.make_heun(ns)
+        s.set_timesteps(18)
+        _, _, _, enc, mask = cases.unet_inputs(cfg, 1, 256, 16, 16, "pipe", False)
+        noise = cases.t(spec.det_uniform("pipe.noise", (1, 8, 256, 16), 9)) * np.float32(np.sqrt(3.0))
+        z_N = noise * s.init_noise_sigma
+        z_in = s.scale_model_input(z_N, s.timesteps[0])
+        lat = m(z_in, s.timesteps[0], guidance=4.0, encoder_hidden_states=enc,
+                encoder_attention_mask=mask).sample
+        mel = vae.decode_first_stage(lat.float())
+        wav = vae.vocoder(mel.squeeze(1).permute(0, 2, 1)).squeeze(1).float()
+        save("pipeline_light", latent=lat.numpy(), mel=mel.numpy(),
+             wav=wav.numpy().astype(np.float16), wav_head=wav.numpy()[:, :8192],
+             wav_absmax=float(wav.abs().max()), scale_factor=sf)
+
+
+if __name__ == "__main__":
+    ns = ref_import.load()
+    torch.set_num_threads(os.cpu_count())
+    which = sys.argv[1:] or ["heun", "unet", "vae", "pipeline"]
+    if "heun" in which:
+        golden_heun(ns)
+    if "unet" in which:
+        golden_unet(ns)
+    if "vae" in which:
+        golden_vae(ns)
+    if "pipeline" in which:
+        golden_pipeline(ns)

@@ -1,0 +1,108 @@
+"""Pins the CPU oracle against fixtures produced by the reference's own modules
+(tests/golden/make_golden.py).  fp32 vs fp32 on the same CPU kernels: tolerance is
+round-off only."""
+import numpy as np
+import pytest
+import torch
+
+import cases
+from consistencytta_amd import spec
+from oracle import heun, nets
+
+
+def close(a, b, rtol=2e-4, atol=2e-5):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(1e-6, float(np.abs(b).max()))
+    err = float(np.abs(a - b).max())
+    assert err <= atol + rtol * scale, "max abs err %.3e (scale %.3e)" % (err, scale)
+
+
+def test_param_specs_match_reference_key_order(golden):
+    g = golden("unet_tiny")
+    assert list(spec.unet_param_spec(cases.TINY_UNET, True).keys()) == [str(k) for k in g["keys"]]
+    light = spec.unet_param_spec(spec.LIGHT_UNET_CONFIG, True)
+    n = sum(int(np.prod(s)) for s in light.values())
+    assert n == int(golden("unet_light")["n_params"]) == 559209676
+
+
+def test_heun_tables(golden):
+    g = golden("heun")
+    for n in (1, 2, 18, 200):
+        ts, sig = heun.set_timesteps(n)
+        np.testing.assert_array_equal(ts, g["timesteps_%d" % n])
+        np.testing.assert_array_equal(sig, g["sigmas_%d" % n])
+        assert float(sig.max()) == float(g["init_sigma_%d" % n])
+    ts, sig = heun.set_timesteps(18)
+    assert len(ts) == 35 and len(sig) == 36
+    assert abs(float(sig[0]) - 14.6146) < 1e-3
+
+
+def test_heun_steps(golden):
+    g = golden("heun")
+    _, sig = heun.set_timesteps(18)
+    sig = torch.from_numpy(sig)
+    idx = torch.from_numpy(g["idx"])
+    x = cases.t(spec.det_uniform("heun.x", (3, 8, 16, 4), 1)) * 3
+    v1 = cases.t(spec.det_uniform("heun.v1", (3, 8, 16, 4), 2))
+    v2 = cases.t(spec.det_uniform("heun.v2", (3, 8, 16, 4), 3))
+    noise = cases.t(spec.det_uniform("heun.n", (3, 8, 16, 4), 4))
+    close(heun.scale_model_input(x, sig[idx]), g["scaled"], 1e-6, 1e-7)
+    close(heun.add_noise(x, noise, sig[idx]), g["noised"], 1e-6, 1e-7)
+    first, d, dt = heun.step_first(v1, x, sig[idx], sig[idx + 1])
+    close(first, g["step1"], 1e-6, 1e-7)
+    # 2nd-order call happens at timestep index idx+2, in second-order state:
+    # index_for_timestep returns (first match) - 1 = idx+1; sigma=sig[idx], sigma_next=sig[idx+1]
+    close(heun.scale_model_input(first, sig[idx + 2]), g["scaled2"], 1e-6, 1e-7)
+    second = heun.step_second(v2, first, sig[idx + 1], x, d, dt)
+    close(second, g["step2"], 1e-6, 1e-7)
+
+
+def test_unet_tiny(golden):
+    g = golden("unet_tiny")
+    cfg = cases.TINY_UNET
+    with torch.no_grad():
+        sd = cases.unet_weights(cfg, True)
+        x, ts, gs, enc, mask = cases.unet_inputs(cfg, 2, 32, 8, 7, "unet_tiny")
+        close(nets.unet_forward(cfg, sd, x, ts, gs, enc, mask), g["guided"])
+        x2, _, _, enc2, mask2 = cases.unet_inputs(cfg, 2, 16, 8, 5, "unet_tiny_s", False)
+        close(nets.unet_forward(cfg, sd, x2, 999.0, 4.0, enc2, mask2), g["guided_scalar"])
+        sdt = cases.unet_weights(cfg, False)
+        close(nets.unet_forward(cfg, sdt, x, ts, None, enc, mask), g["teacher"])
+
+
+@pytest.mark.slow
+def test_unet_light(golden):
+    g = golden("unet_light")
+    cfg = spec.LIGHT_UNET_CONFIG
+    with torch.no_grad():
+        sd = cases.unet_weights(cfg, True)
+        x, _, _, enc, mask = cases.unet_inputs(cfg, 1, 256, 16, 16, "unet_light", False)
+        x = x / 1.7 * cases.SIGMA_MAX / ((cases.SIGMA_MAX ** 2 + 1) ** 0.5)
+        close(nets.unet_forward(cfg, sd, x, 999.0, 4.0, enc, mask), g["out"])
+
+
+def test_vae_hifigan_tiny(golden):
+    g = golden("vae_tiny")
+    with torch.no_grad():
+        sd = dict(cases.vae_weights(cases.TINY_VAE_DD))
+        sd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
+        z = cases.vae_inputs(2, 16, 8, "vae_tiny")
+        close(nets.vae_decode(cases.TINY_VAE_DD, sd, z, float(g["scale_factor"])), g["mel"])
+        mel_in = cases.mel_inputs(2, 24, 64, "hifigan_tiny")
+        wav, centred, pcm = nets.mel_to_waveform(cases.TINY_HIFIGAN, sd, mel_in)
+        close(wav, g["wav"])
+        assert np.abs(pcm.astype(np.int64) - g["pcm"].astype(np.int64)).max() <= 1
+
+
+@pytest.mark.slow
+def test_vae_hifigan_full_width(golden):
+    g = golden("vae_full")
+    with torch.no_grad():
+        sd = dict(cases.vae_weights(spec.VAE_DDCONFIG))
+        sd.update(cases.hifigan_weights(spec.HIFIGAN_16K_64))
+        z = cases.vae_inputs(1, 64, 16, "vae_full")
+        close(nets.vae_decode(spec.VAE_DDCONFIG, sd, z, float(g["scale_factor"])), g["mel"])
+        mel_in = cases.mel_inputs(1, 64, 64, "hifigan_full")
+        wav, _, _ = nets.mel_to_waveform(spec.HIFIGAN_16K_64, sd, mel_in)
+        close(wav, g["wav"])
