@@ -1,0 +1,196 @@
+"""ctypes binding of libctta_hip.so (the C ABI declared in include/ctta.h).
+
+PyTorch is used above this boundary only as the owner of device memory and streams: every
+call passes raw `data_ptr()`s plus the current HIP stream.  There is NO fallback: if the
+library is missing or a call fails, a RuntimeError is raised (the reference raises Python
+exceptions at the same places -- shape asserts, load_state_dict key errors).
+"""
+import ctypes
+import os
+import subprocess
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int16, c_int32,
+                    c_int64, c_size_t, c_uint8, c_void_p)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libctta_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MAX_LEVELS = 4
+MAX_UPS = 8
+
+
+class Tensor(Structure):
+    _fields_ = [("name", c_char_p), ("data", c_void_p), ("ndim", c_int), ("shape", c_int64 * 4)]
+
+
+class UNetConfig(Structure):
+    _fields_ = [
+        ("in_channels", c_int), ("out_channels", c_int), ("n_levels", c_int),
+        ("block_out_channels", c_int * MAX_LEVELS), ("heads", c_int * MAX_LEVELS),
+        ("layers_per_block", c_int * MAX_LEVELS), ("down_cross", c_int * MAX_LEVELS),
+        ("up_cross", c_int * MAX_LEVELS), ("cross_attention_dim", c_int),
+        ("norm_num_groups", c_int), ("norm_eps", c_float), ("flip_sin_to_cos", c_int),
+        ("freq_shift", c_float), ("guided", c_int), ("max_batch", c_int), ("height", c_int),
+        ("width", c_int), ("max_text_len", c_int), ("debug_taps", c_int),
+    ]
+
+
+class VAEConfig(Structure):
+    _fields_ = [
+        ("z_channels", c_int), ("embed_dim", c_int), ("ch", c_int), ("out_ch", c_int),
+        ("n_levels", c_int), ("num_res_blocks", c_int), ("ch_mult", c_int * MAX_LEVELS),
+        ("scale_factor", c_float), ("max_batch", c_int), ("latent_h", c_int),
+        ("latent_w", c_int), ("debug_taps", c_int),
+    ]
+
+
+class HifiganConfig(Structure):
+    _fields_ = [
+        ("num_mels", c_int), ("upsample_initial_channel", c_int), ("n_ups", c_int),
+        ("n_kernels", c_int), ("upsample_rates", c_int * MAX_UPS),
+        ("upsample_kernel_sizes", c_int * MAX_UPS), ("resblock_kernel_sizes", c_int * 4),
+        ("resblock_dilations", (c_int * 3) * 4), ("max_batch", c_int), ("max_frames", c_int),
+        ("debug_taps", c_int),
+    ]
+
+
+class ConvDesc(Structure):
+    _fields_ = [
+        ("x0", c_void_p), ("c0", c_int), ("x1", c_void_p), ("c1", c_int),
+        ("batch", c_int), ("hi", c_int), ("wi", c_int), ("upsample", c_int),
+        ("ho", c_int), ("wo", c_int),
+        ("kh", c_int), ("kw", c_int), ("stride_h", c_int), ("stride_w", c_int),
+        ("pad_h", c_int), ("pad_w", c_int), ("dil_h", c_int), ("dil_w", c_int),
+        ("w", c_void_p), ("k_pad", c_int), ("n", c_int),
+        ("bias", c_void_p), ("bias_m", c_void_p), ("rowvec", c_void_p), ("rowvec_ld", c_int),
+        ("res", c_void_p), ("res_ld", c_int),
+        ("in_act", c_int), ("in_slope", c_float), ("out_act", c_int), ("alpha", c_float),
+        ("accumulate", c_int), ("out", c_void_p), ("ldc", c_int), ("out_f32", c_int),
+        ("out_batch_stride", c_int64), ("out_offset", c_int64), ("out_limit", c_int64),
+        ("groups", c_int), ("x_group_stride", c_int64), ("w_group_stride", c_int64),
+        ("out_group_stride", c_int64), ("tile", c_int),
+    ]
+
+
+# name -> (restype, argtypes); every symbol declared in include/ctta.h
+SIGNATURES = {
+    "ctta_last_error": (c_char_p, []),
+    "ctta_version": (c_int, []),
+    "ctta_unet_create": (c_int, [POINTER(UNetConfig), POINTER(Tensor), c_int, c_void_p, POINTER(c_void_p)]),
+    "ctta_unet_destroy": (None, [c_void_p]),
+    "ctta_unet_load_weights": (c_int, [c_void_p, POINTER(Tensor), c_int, c_void_p]),
+    "ctta_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_unet_arena_bytes": (c_size_t, [c_void_p]),
+    "ctta_unet_num_taps": (c_int, [c_void_p]),
+    "ctta_unet_tap_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
+    "ctta_unet_tap_read": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ctta_vae_create": (c_int, [POINTER(VAEConfig), POINTER(Tensor), c_int, c_void_p, POINTER(c_void_p)]),
+    "ctta_vae_destroy": (None, [c_void_p]),
+    "ctta_vae_decode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ctta_vae_arena_bytes": (c_size_t, [c_void_p]),
+    "ctta_vae_num_taps": (c_int, [c_void_p]),
+    "ctta_vae_tap_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
+    "ctta_vae_tap_read": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ctta_hifigan_create": (c_int, [POINTER(HifiganConfig), POINTER(Tensor), c_int, c_void_p, POINTER(c_void_p)]),
+    "ctta_hifigan_destroy": (None, [c_void_p]),
+    "ctta_hifigan_out_len": (c_int64, [c_void_p, c_int]),
+    "ctta_hifigan_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_wav_finalize": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ctta_hifigan_arena_bytes": (c_size_t, [c_void_p]),
+    "ctta_hifigan_num_taps": (c_int, [c_void_p]),
+    "ctta_hifigan_tap_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
+    "ctta_hifigan_tap_read": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ctta_heun_scale_model_input": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "ctta_heun_add_noise": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "ctta_heun_step_first": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "ctta_heun_step_second": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "ctta_cfg_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "ctta_snr_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "ctta_ema_update2": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_double, c_int64, c_void_p]),
+    "ctta_conv_gemm": (c_int, [POINTER(ConvDesc), c_void_p]),
+    "ctta_conv_gemm_num_variants": (c_int, []),
+    "ctta_conv_gemm_variant_name": (c_char_p, [c_int]),
+    "ctta_conv_small_n": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "ctta_pack_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ctta_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ctta_rows_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "ctta_concat_channels": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "ctta_groupnorm_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ctta_groupnorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
+    "ctta_layernorm": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p]),
+    "ctta_geglu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ctta_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "ctta_attention": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ctta_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ctta_time_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "ctta_fourier_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def build(force=False):
+    """Compiles csrc/*.hip for gfx950 into consistencytta_amd/libctta_hip.so (in-tree)."""
+    if force:
+        for f in os.listdir(os.path.join(CSRC, "build")) if os.path.isdir(os.path.join(CSRC, "build")) else []:
+            os.remove(os.path.join(CSRC, "build", f))
+    subprocess.run(["bash", os.path.join(CSRC, "build.sh")], check=True)
+    return LIB_PATH
+
+
+def lib():
+    """Loads the library; raises if it has not been built (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libctta_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or consistencytta_amd/csrc/build.sh; there is no non-HIP fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+class CttaError(RuntimeError):
+    pass
+
+
+def check(status):
+    if status != 0:
+        msg = lib().ctta_last_error()
+        raise CttaError("ctta status %d: %s" % (status, msg.decode() if msg else "?"))
+
+
+def stream_ptr():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def tensor_table(sd):
+    """dict name -> contiguous fp32 CUDA tensor  =>  (ctypes array of ctta_tensor, keepalive)."""
+    import torch
+    n = len(sd)
+    arr = (Tensor * n)()
+    keep = []
+    for i, (k, v) in enumerate(sd.items()):
+        if v.dtype != torch.float32 or not v.is_cuda:
+            raise CttaError("weight '%s' must be a float32 CUDA tensor (got %s on %s)" % (k, v.dtype, v.device))
+        v = v.contiguous()
+        kb = k.encode()
+        keep.append((kb, v))
+        arr[i].name = kb
+        arr[i].data = v.data_ptr()
+        arr[i].ndim = v.ndim
+        for d in range(v.ndim):
+            arr[i].shape[d] = v.shape[d]
+    return arr, keep

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Builds libctta_hip.so for gfx950 in-tree (cross-compiles without a GPU).
+set -euo pipefail
+cd "$(dirname "$0")"
+OUT=../libctta_hip.so
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
+mkdir -p build
+pids=()
+for f in api conv_gemm norm_elem attention engine_unet engine_vae; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ engine_common.h -nt build/$f.o ] || [ ../../include/ctta.h -nt build/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+    pids+=($!)
+  fi
+done
+# elementwise: no fp contraction so the Heun / EMA arithmetic rounds like the reference's unfused ops
+if [ ! -f build/elementwise.o ] || [ elementwise.hip -nt build/elementwise.o ] || [ common.h -nt build/elementwise.o ] || [ ../../include/ctta.h -nt build/elementwise.o ]; then
+  $HIPCC $FLAGS -ffp-contract=off -c elementwise.hip -o build/elementwise.o &
+  pids+=($!)
+fi
+for p in "${pids[@]:-}"; do [ -n "$p" ] && wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/*.o -o $OUT
+echo "built $(realpath $OUT)"

@@ -1,0 +1,380 @@
+// Implicit-GEMM convolution / linear / batched matmul on the gfx950 matrix cores.
+//
+//   out[m][n] = alpha * ( sum_k X[m][k] * W[n][k] + bias[n] + rowvec[b(m)][n] + res[m][n] )
+//
+// m runs over output pixels (b, oh, ow) of an NHWC bf16 tensor, k over (kh, kw, c) of the
+// receptive field (gathered on the fly: zero padding, stride, dilation, optional x2 nearest
+// upsample, optional two-source channel concat), n over output channels.  W is pre-packed
+// bf16 [n][k_pad] (K contiguous), so both MFMA operands are K-contiguous 16-byte fragments.
+//
+// This one kernel family is every conv2d / conv1d / ConvTranspose1d / Linear / QK^T / PV of
+// the reference path:
+//   F.conv2d   resnet.py:549-597, modules.py:155-175,  Upsample2D resnet.py:126-161 (fused),
+//   F.conv1d / conv_transpose1d  hifigan/models.py:56-63,101-117 (ConvTranspose1d is run as
+//   `stride` phase-convolutions written through an output remap),
+//   F.linear   attention.py:276-334, attention_processor.py:1107-1136, torch.bmm modules.py:204-230.
+//
+// CDNA4 mapping: 256-thread workgroups (4 wave64), v_mfma_f32_16x16x32_bf16 with the WEIGHT
+// tile as the A operand and the PIXEL tile as the B operand, so each lane ends up holding 4
+// consecutive output channels of one pixel (8-byte packed bf16 stores along NHWC's fastest
+// axis).  Global -> register -> LDS staging with a 2-deep LDS ring and the next tile's
+// global loads issued before the current tile's MFMAs (one barrier per K-step).  LDS rows are
+// padded by 16 B to spread ds_read_b128 over banks.
+#include "common.h"
+
+struct ConvParams {
+  const bf16_t* x0; const bf16_t* x1; int c0, c1, ct;
+  int M, hi, wi, hs, ws, ups, ho, wo, howo;
+  int kh, kw, taps, sh, sw, ph, pw, dh, dw;
+  const bf16_t* w; int k_pad, n, nk;
+  const float* bias; const float* bias_m; const float* rowvec; int rowvec_ld;
+  const bf16_t* res; int res_ld;
+  int in_act; float in_slope; int out_act; float alpha; int accumulate;
+  void* out; int ldc; int out_f32;
+  long long obs, out_offset, out_limit;
+  long long xgs, wgs, ogs;
+};
+
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int LDK = BK + 8;          // bf16 elements per LDS row (16 B pad)
+  constexpr int CPR = BK / 8;          // 16-byte chunks per row
+  constexpr int RPP = NT / CPR;        // rows staged per pass
+  constexpr int XP = BM / RPP;
+  constexpr int WP = BN / RPP;
+  constexpr int TM = BM / WM, TN = BN / WN;
+  constexpr int FM = TM / 16, FN = TN / 16;
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/pass mismatch");
+  static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_raw);               // [2][BM][LDK]
+  bf16_t* Ws = Xs + 2 * BM * LDK;                                  // [2][BN][LDK]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int g = blockIdx.z;
+
+  const bf16_t* x0 = p.x0 + (size_t)g * p.xgs;
+  const bf16_t* x1 = p.x1;
+  const bf16_t* wbase = p.w + (size_t)g * p.wgs;
+
+  const int kc = tid % CPR;
+  const int r0 = tid / CPR;
+
+  // per-thread K state (shared by all of this thread's rows)
+  int c, tap, kh, kw;
+  {
+    int kk = kc * 8;
+    tap = kk / p.ct;
+    c = kk - tap * p.ct;
+    kh = tap / p.kw;
+    kw = tap - kh * p.kw;
+  }
+  // per-row pixel state
+  int rb[XP], rih[XP], riw[XP];
+#pragma unroll
+  for (int i = 0; i < XP; ++i) {
+    int m = m0 + r0 + i * RPP;
+    if (m < p.M) {
+      int b = m / p.howo;
+      int rem = m - b * p.howo;
+      int oh = rem / p.wo;
+      int ow = rem - oh * p.wo;
+      rb[i] = b;
+      rih[i] = oh * p.sh - p.ph;
+      riw[i] = ow * p.sw - p.pw;
+    } else {
+      rb[i] = 0;
+      rih[i] = -(1 << 28);
+      riw[i] = 0;
+    }
+  }
+  // per-row weight pointers
+  const bf16_t* wrow[WP];
+  bool wok[WP];
+#pragma unroll
+  for (int j = 0; j < WP; ++j) {
+    int n = n0 + r0 + j * RPP;
+    wok[j] = n < p.n;
+    wrow[j] = wbase + (size_t)(wok[j] ? n : 0) * p.k_pad + kc * 8;
+  }
+
+  uint4 xr[XP], wr[WP];
+
+  auto load_tile = [&](int kt) {
+    const int ihk = kh * p.dh, iwk = kw * p.dw;
+    const bool tap_ok = tap < p.taps;
+    const bool second = c >= p.c0;
+    const bf16_t* src = second ? x1 : x0;
+    const int cs = second ? p.c1 : p.c0;
+    const int cc = second ? c - p.c0 : c;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      int ih = rih[i] + ihk, iw = riw[i] + iwk;
+      bool ok = tap_ok && (unsigned)ih < (unsigned)p.hi && (unsigned)iw < (unsigned)p.wi;
+      if (p.ups) { ih >>= 1; iw >>= 1; }
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        size_t pix = (size_t)(rb[i] * p.hs + ih) * p.ws + iw;
+        v = *reinterpret_cast<const uint4*>(src + pix * cs + cc);
+      }
+      xr[i] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (wok[j]) v = *reinterpret_cast<const uint4*>(wrow[j] + (size_t)kt * BK);
+      wr[j] = v;
+    }
+    // advance K state
+    c += BK;
+    while (c >= p.ct) {
+      c -= p.ct;
+      ++tap;
+      if (++kw == p.kw) { kw = 0; ++kh; }
+    }
+  };
+
+  auto store_tile = [&](int buf) {
+    bf16_t* xs = Xs + buf * BM * LDK;
+    bf16_t* ws = Ws + buf * BN * LDK;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      uint4 v = xr[i];
+      if (p.in_act == 1) {
+        float f[8];
+        unpack8(v, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = f[e] > 0.f ? f[e] : f[e] * p.in_slope;
+        v = pack8(f);
+      }
+      *reinterpret_cast<uint4*>(xs + (r0 + i * RPP) * LDK + kc * 8) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j)
+      *reinterpret_cast<uint4*>(ws + (r0 + j * RPP) * LDK + kc * 8) = wr[j];
+  };
+
+  f32x4_t acc[FN][FM];
+#pragma unroll
+  for (int i = 0; i < FN; ++i)
+#pragma unroll
+    for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fk = (lane >> 4) * 8;
+
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < p.nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < p.nk) load_tile(kt + 1);
+    const bf16_t* xs = Xs + buf * BM * LDK + (wm * TM + frow) * LDK + fk;
+    const bf16_t* ws = Ws + buf * BN * LDK + (wn * TN + frow) * LDK + fk;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      bf16x8_t af[FN], bfr[FM];
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+        af[i] = __builtin_bit_cast(bf16x8_t,
+                                   *reinterpret_cast<const uint4*>(ws + i * 16 * LDK + ks * 32));
+#pragma unroll
+      for (int j = 0; j < FM; ++j)
+        bfr[j] = __builtin_bit_cast(bf16x8_t,
+                                    *reinterpret_cast<const uint4*>(xs + j * 16 * LDK + ks * 32));
+#pragma unroll
+      for (int i = 0; i < FN; ++i)
+#pragma unroll
+        for (int j = 0; j < FM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < p.nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3} (rows of D), m = mb + (lane&15)
+  const int nsub = (lane >> 4) * 4;
+#pragma unroll
+  for (int j = 0; j < FM; ++j) {
+    const int m = m0 + wm * TM + j * 16 + frow;
+    if (m >= p.M) continue;
+    const int b = m / p.howo;
+    const long long mrem = m - (long long)b * p.howo;
+#pragma unroll
+    for (int i = 0; i < FN; ++i) {
+      const int n = n0 + wn * TN + i * 16 + nsub;
+      if (n >= p.n) continue;
+      const long long inb = mrem * p.ldc + n + p.out_offset;
+      if (p.out_limit > 0 && (inb < 0 || inb >= p.out_limit)) continue;
+      const size_t oidx = (size_t)((long long)g * p.ogs + (long long)b * p.obs + inb);
+      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+      if (p.bias) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+      }
+      if (p.bias_m) {
+        const float bm = p.bias_m[m];
+        v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+      }
+      if (p.rowvec) {
+        const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_ld + n);
+        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+      }
+      if (p.res) {
+        const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
+        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+      }
+      if (p.out_f32) {
+        float* o = reinterpret_cast<float*>(p.out) + oidx;
+        if (p.accumulate) {
+          const float4 old = *reinterpret_cast<const float4*>(o);
+          v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] *= p.alpha;
+          if (p.out_act == 1) v[r] = silu_f(v[r]);
+          else if (p.out_act == 2) v[r] = tanhf(v[r]);
+        }
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+      } else {
+        bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + oidx;
+        if (p.accumulate) {
+          const uint2 old = *reinterpret_cast<const uint2*>(o);
+          v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+          v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] *= p.alpha;
+          if (p.out_act == 1) v[r] = silu_f(v[r]);
+          else if (p.out_act == 2) v[r] = tanhf(v[r]);
+        }
+        uint2 pk;
+        pk.x = pack2bf(v[0], v[1]);
+        pk.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>(o) = pk;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+struct Variant {
+  const char* name;
+  int bm, bn, bk;
+  void (*launch)(const ConvParams&, dim3, hipStream_t);
+  ctta_status (*prepare)();
+};
+
+template <int BM, int BN, int BK, int WM, int WN>
+static constexpr size_t smem_bytes() { return (size_t)2 * (BM + BN) * (BK + 8) * 2; }
+
+template <int BM, int BN, int BK, int WM, int WN>
+static void launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
+  const size_t smem = smem_bytes<BM, BN, BK, WM, WN>();
+  conv_gemm_kernel<BM, BN, BK, WM, WN><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+static ctta_status prepare_variant() {
+  static bool done = false;
+  if (done) return CTTA_OK;
+  CTTA_CHECK_HIP(hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<BM, BN, BK, WM, WN>()));
+  done = true;
+  return CTTA_OK;
+}
+
+#define VARIANT(BM, BN, BK, WM, WN) \
+  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN, BM, BN, BK, launch_variant<BM, BN, BK, WM, WN>, \
+   prepare_variant<BM, BN, BK, WM, WN>}
+
+static const Variant kVariants[] = {
+    VARIANT(128, 128, 64, 2, 2),  // 1
+    VARIANT(128, 128, 32, 2, 2),  // 2
+    VARIANT(256, 64, 64, 4, 1),   // 3
+    VARIANT(256, 32, 64, 4, 1),   // 4
+    VARIANT(64, 64, 64, 2, 2),    // 5
+    VARIANT(64, 128, 64, 2, 2),   // 6
+    VARIANT(256, 128, 64, 4, 2),  // 7
+    VARIANT(128, 64, 64, 2, 2),   // 8
+};
+static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
+
+extern "C" int ctta_conv_gemm_num_variants(void) { return kNumVariants; }
+extern "C" const char* ctta_conv_gemm_variant_name(int id) {
+  return (id >= 1 && id <= kNumVariants) ? kVariants[id - 1].name : "auto";
+}
+
+static int pick_variant(long long M, int N, int groups) {
+  if (N <= 32) return 4;
+  if (N <= 64) return 3;
+  const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * groups;
+  if (t128 >= 512) return 1;
+  const long long t64n = ((M + 127) / 128) * ((N + 63) / 64) * groups;
+  if (t64n >= 384) return 8;
+  return 5;
+}
+
+extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
+  CTTA_REQUIRE(d && d->x0 && d->w && d->out, "conv_gemm: null pointer");
+  CTTA_REQUIRE(d->c0 > 0 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->c1 >= 0,
+               "conv_gemm: channel counts must be multiples of 8 (c0=%d c1=%d)", d->c0, d->c1);
+  CTTA_REQUIRE(d->n > 0, "conv_gemm: n=%d must be positive", d->n);
+  CTTA_REQUIRE(d->n % 4 == 0 || (!d->bias && !d->rowvec && !d->res && !d->accumulate && !d->out_limit &&
+                                 (d->n + 3) / 4 * 4 <= d->ldc),
+               "conv_gemm: n=%d must be a multiple of 4 for this epilogue", d->n);
+  CTTA_REQUIRE(d->k_pad % 64 == 0, "conv_gemm: k_pad=%d must be a multiple of 64", d->k_pad);
+  CTTA_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride_h >= 1 && d->stride_w >= 1 && d->dil_h >= 1 &&
+                   d->dil_w >= 1, "conv_gemm: bad kernel geometry");
+  CTTA_REQUIRE(!d->upsample || (d->hi % 2 == 0 && d->wi % 2 == 0), "conv_gemm: odd upsample extent");
+  CTTA_REQUIRE(d->ldc % 4 == 0 && d->out_offset % 4 == 0, "conv_gemm: ldc/out_offset must be multiples of 4");
+  CTTA_REQUIRE(!d->res || d->res_ld % 4 == 0, "conv_gemm: res_ld must be a multiple of 4");
+  CTTA_REQUIRE(!d->rowvec || d->rowvec_ld % 4 == 0, "conv_gemm: rowvec_ld must be a multiple of 4");
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.x0 = (const bf16_t*)d->x0; p.x1 = (const bf16_t*)d->x1;
+  p.c0 = d->c0; p.c1 = d->x1 ? d->c1 : 0; p.ct = p.c0 + p.c1;
+  const long long M = (long long)d->batch * d->ho * d->wo;
+  CTTA_REQUIRE(M > 0 && M < (1LL << 31), "conv_gemm: M out of range");
+  p.M = (int)M; p.hi = d->hi; p.wi = d->wi; p.ups = d->upsample ? 1 : 0;
+  p.hs = p.ups ? d->hi / 2 : d->hi; p.ws = p.ups ? d->wi / 2 : d->wi;
+  p.ho = d->ho; p.wo = d->wo; p.howo = d->ho * d->wo;
+  p.kh = d->kh; p.kw = d->kw; p.taps = d->kh * d->kw;
+  p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
+  p.dh = d->dil_h; p.dw = d->dil_w;
+  p.w = (const bf16_t*)d->w; p.k_pad = d->k_pad; p.n = d->n;
+  const long long K = (long long)p.taps * p.ct;
+  CTTA_REQUIRE(K <= d->k_pad, "conv_gemm: K=%lld exceeds k_pad=%d", K, d->k_pad);
+  p.bias = d->bias; p.bias_m = d->bias_m; p.rowvec = d->rowvec; p.rowvec_ld = d->rowvec_ld;
+  p.res = (const bf16_t*)d->res; p.res_ld = d->res_ld;
+  p.in_act = d->in_act; p.in_slope = d->in_slope; p.out_act = d->out_act;
+  p.alpha = d->alpha; p.accumulate = d->accumulate;
+  p.out = d->out; p.ldc = d->ldc; p.out_f32 = d->out_f32;
+  p.obs = d->out_batch_stride ? d->out_batch_stride : (long long)p.howo * d->ldc;
+  p.out_offset = d->out_offset; p.out_limit = d->out_limit;
+  const int groups = d->groups > 0 ? d->groups : 1;
+  p.xgs = d->x_group_stride; p.wgs = d->w_group_stride; p.ogs = d->out_group_stride;
+
+  int vid = d->tile;
+  if (vid <= 0 || vid > kNumVariants) vid = pick_variant(M, d->n, groups);
+  const Variant& v = kVariants[vid - 1];
+  p.nk = (int)((K + v.bk - 1) / v.bk);
+  CTTA_REQUIRE((long long)p.nk * v.bk <= d->k_pad, "conv_gemm: k_pad too small for BK");
+  CTTA_TRY(v.prepare());
+  dim3 grid((unsigned)((M + v.bm - 1) / v.bm), (unsigned)((d->n + v.bn - 1) / v.bn), (unsigned)groups);
+  v.launch(p, grid, (hipStream_t)stream);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}

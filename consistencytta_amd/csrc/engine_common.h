@@ -1,0 +1,354 @@
+// Host-side runtime shared by the three engines: device arenas, the state-dict weight table,
+// weight packing into the conv_gemm layouts, and thin layer launchers.
+#pragma once
+#include <functional>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "common.h"
+
+// ---------------------------------------------------------------------------------- arenas
+// Stack (bump) allocator over one hipMalloc.  `dry` arenas only measure (sizing pass).
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool dry = true;
+  bool no_release = false;   // debug taps keep every intermediate alive
+
+  void* alloc(size_t bytes) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    if (off > peak) peak = off;
+    if (dry) return reinterpret_cast<void*>((uintptr_t)0x1000 + a);   // never dereferenced
+    if (off > cap) return nullptr;
+    return base + a;
+  }
+  template <typename T>
+  T* get(size_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
+  size_t mark() const { return off; }
+  void release(size_t m) { if (!no_release) off = m; }
+  void reset() { off = 0; }
+};
+
+struct Tap {
+  std::string name;
+  const void* ptr;
+  int b, c, h, w, c_stride;
+  bool f32_nchw;
+};
+
+// ---------------------------------------------------------------------------------- weights
+struct WeightTable {
+  std::unordered_map<std::string, const ctta_tensor*> map;
+  void build(const ctta_tensor* w, int n) {
+    map.clear();
+    for (int i = 0; i < n; ++i) map[w[i].name] = &w[i];
+  }
+  const ctta_tensor* find(const std::string& k) const {
+    auto it = map.find(k);
+    return it == map.end() ? nullptr : it->second;
+  }
+};
+
+static inline int64_t tensor_numel(const ctta_tensor* t) {
+  int64_t n = 1;
+  for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+  return n;
+}
+
+// A packed bf16 GEMM operand [n_rows][k_pad] plus its fp32 bias (owned copies).
+struct PackedW {
+  bf16_t* w = nullptr;
+  float* bias = nullptr;
+  int n = 0;       // valid rows handed to conv_gemm (multiple of 4)
+  int k_pad = 0;
+};
+
+// Persistent device storage for packed weights / fp32 copies / index maps.
+struct WeightStore {
+  Arena arena;
+  std::vector<std::function<ctta_status(const WeightTable&, hipStream_t)>> jobs;
+
+  ctta_status init(size_t bytes) {
+    arena.dry = false;
+    arena.cap = bytes;
+    CTTA_CHECK_HIP(hipMalloc((void**)&arena.base, bytes));
+    return CTTA_OK;
+  }
+  void destroy() {
+    if (arena.base) (void)hipFree(arena.base);
+    arena.base = nullptr;
+  }
+  ctta_status run_all(const WeightTable& wt, hipStream_t s) {
+    for (auto& j : jobs) CTTA_TRY(j(wt, s));
+    return CTTA_OK;
+  }
+
+  // uploads a host int vector once (index maps are structural, not weight dependent)
+  ctta_status upload(const std::vector<int32_t>& v, int32_t** out) {
+    int32_t* d = arena.get<int32_t>(v.size());
+    if (!d) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
+    CTTA_CHECK_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    *out = d;
+    return CTTA_OK;
+  }
+
+  // Generic packed matrix: dst[r][k] = src[row_off[r] + col_off[k]] (or 0).
+  ctta_status add_matrix(const std::string& key, const std::vector<int64_t>& expect_shape,
+                         const std::vector<int32_t>& row_off, const std::vector<int32_t>& col_off,
+                         const std::vector<int32_t>* row_aux, const std::vector<int32_t>* col_aux,
+                         int aux_limit, bf16_t** out, bf16_t* dst_preallocated = nullptr) {
+    const int n_rows = (int)row_off.size(), k_pad = (int)col_off.size();
+    bf16_t* dst = dst_preallocated ? dst_preallocated : arena.get<bf16_t>((size_t)n_rows * k_pad);
+    if (!dst) { ctta_set_error("weight store exhausted at %s", key.c_str()); return CTTA_ERR_NOMEM; }
+    int32_t *dro, *dco, *dra = nullptr, *dca = nullptr;
+    CTTA_TRY(upload(row_off, &dro));
+    CTTA_TRY(upload(col_off, &dco));
+    if (aux_limit > 0) { CTTA_TRY(upload(*row_aux, &dra)); CTTA_TRY(upload(*col_aux, &dca)); }
+    *out = dst;
+    jobs.push_back([=](const WeightTable& wt, hipStream_t s) -> ctta_status {
+      const ctta_tensor* t = wt.find(key);
+      if (!t) { ctta_set_error("missing state-dict key '%s'", key.c_str()); return CTTA_ERR_MISSING_KEY; }
+      if (t->ndim != (int)expect_shape.size()) {
+        ctta_set_error("key '%s': rank %d, expected %d", key.c_str(), t->ndim, (int)expect_shape.size());
+        return CTTA_ERR_INVALID;
+      }
+      for (int i = 0; i < t->ndim; ++i)
+        if (t->shape[i] != expect_shape[i]) {
+          ctta_set_error("size mismatch for '%s' dim %d: %lld vs expected %lld", key.c_str(), i,
+                         (long long)t->shape[i], (long long)expect_shape[i]);
+          return CTTA_ERR_INVALID;
+        }
+      return ctta_pack_weight(t->data, dro, dco, dra, dca, aux_limit, n_rows, k_pad, dst, s);
+    });
+    return CTTA_OK;
+  }
+
+  // fp32 vector copy with optional placement: dst has n_pad entries, src[i] lands at dst_pos(i)
+  // given as (count, dst_start) segments; the rest stays zero.
+  struct Seg { int src_start, dst_start, count; };
+  ctta_status add_vector(const std::string& key, int src_len, int n_pad, const std::vector<Seg>& segs,
+                         float** out) {
+    float* dst = arena.get<float>((size_t)n_pad);
+    if (!dst) { ctta_set_error("weight store exhausted at %s", key.c_str()); return CTTA_ERR_NOMEM; }
+    *out = dst;
+    jobs.push_back([=](const WeightTable& wt, hipStream_t s) -> ctta_status {
+      const ctta_tensor* t = wt.find(key);
+      if (!t) { ctta_set_error("missing state-dict key '%s'", key.c_str()); return CTTA_ERR_MISSING_KEY; }
+      if (tensor_numel(t) != src_len) {
+        ctta_set_error("size mismatch for '%s': %lld elements, expected %d", key.c_str(),
+                       (long long)tensor_numel(t), src_len);
+        return CTTA_ERR_INVALID;
+      }
+      CTTA_CHECK_HIP(hipMemsetAsync(dst, 0, (size_t)n_pad * sizeof(float), s));
+      for (const Seg& g : segs)
+        CTTA_CHECK_HIP(hipMemcpyAsync(dst + g.dst_start, t->data + g.src_start, (size_t)g.count * sizeof(float),
+                                      hipMemcpyDeviceToDevice, s));
+      return CTTA_OK;
+    });
+    return CTTA_OK;
+  }
+  ctta_status add_vector(const std::string& key, int len, float** out) {
+    return add_vector(key, len, len, {{0, 0, len}}, out);
+  }
+  // copies into a caller-chosen place of a bigger owned fp32 buffer (concatenated tables)
+  ctta_status add_copy_into(const std::string& key, int64_t numel, float* dst) {
+    jobs.push_back([=](const WeightTable& wt, hipStream_t s) -> ctta_status {
+      const ctta_tensor* t = wt.find(key);
+      if (!t) { ctta_set_error("missing state-dict key '%s'", key.c_str()); return CTTA_ERR_MISSING_KEY; }
+      if (tensor_numel(t) != numel) {
+        ctta_set_error("size mismatch for '%s': %lld elements, expected %lld", key.c_str(),
+                       (long long)tensor_numel(t), (long long)numel);
+        return CTTA_ERR_INVALID;
+      }
+      CTTA_CHECK_HIP(hipMemcpyAsync(dst, t->data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s));
+      return CTTA_OK;
+    });
+    return CTTA_OK;
+  }
+};
+
+// ---------------------------------------------------------------------------------- conv layers
+struct ConvLayer {
+  PackedW p;
+  int cin_pad = 0;   // channels the packed K layout assumes per tap (c0 + c1 at run time)
+  int cout = 0;
+  int kh = 1, kw = 1, stride = 1, pad = 0, dil_w = 1;
+};
+
+// conv2d weight (cout, cin, kh, kw) -> [rows][ (kh,kw,c) ] with cin padded to cin_pad.
+// rows: n_rows_pad >= cout entries; row r maps to source row row_map[r] (or -1).
+static inline ctta_status make_conv(WeightStore& ws, const std::string& prefix, int cout, int cin,
+                                    int cin_pad, int kh, int kw, int stride, int pad, ConvLayer* L,
+                                    bool with_bias = true) {
+  const int K = kh * kw * cin_pad;
+  const int k_pad = round_up(K, 64);
+  const int n_pad = round_up(cout, 4);
+  std::vector<int32_t> ro(n_pad, -1), co(k_pad, -1);
+  for (int r = 0; r < cout; ++r) ro[r] = r * cin * kh * kw;
+  for (int y = 0; y < kh; ++y)
+    for (int x = 0; x < kw; ++x)
+      for (int c = 0; c < cin; ++c) co[(y * kw + x) * cin_pad + c] = c * kh * kw + y * kw + x;
+  const std::vector<int64_t> shape = {cout, cin, kh, kw};
+  CTTA_TRY(ws.add_matrix(prefix + "weight", shape, ro, co, nullptr, nullptr, 0, &L->p.w));
+  if (with_bias) CTTA_TRY(ws.add_vector(prefix + "bias", cout, n_pad, {{0, 0, cout}}, &L->p.bias));
+  L->p.n = n_pad; L->p.k_pad = k_pad;
+  L->cin_pad = cin_pad; L->cout = cout; L->kh = kh; L->kw = kw; L->stride = stride; L->pad = pad;
+  return CTTA_OK;
+}
+
+// Linear weight (n_src, k_src) with row/column placement maps.
+//   row_map[r] = source row or -1 ; col_map[k] = source col or -1.
+static inline ctta_status make_linear(WeightStore& ws, const std::string& wkey, const std::string& bkey,
+                                      int n_src, int k_src, const std::vector<int32_t>& row_map,
+                                      const std::vector<int32_t>& col_map, PackedW* P,
+                                      bf16_t* dst_preallocated = nullptr) {
+  const int n_pad = (int)row_map.size();
+  const int k_pad = (int)col_map.size();
+  std::vector<int32_t> ro(n_pad), co(k_pad);
+  for (int r = 0; r < n_pad; ++r) ro[r] = row_map[r] < 0 ? -1 : row_map[r] * k_src;
+  for (int k = 0; k < k_pad; ++k) co[k] = col_map[k];
+  CTTA_TRY(ws.add_matrix(wkey, {n_src, k_src}, ro, co, nullptr, nullptr, 0, &P->w, dst_preallocated));
+  if (!bkey.empty()) {
+    std::vector<WeightStore::Seg> segs;
+    for (int r = 0; r < n_pad; ++r)
+      if (row_map[r] >= 0) {
+        if (!segs.empty() && segs.back().src_start + segs.back().count == row_map[r] &&
+            segs.back().dst_start + segs.back().count == r)
+          segs.back().count++;
+        else
+          segs.push_back({row_map[r], r, 1});
+      }
+    CTTA_TRY(ws.add_vector(bkey, n_src, n_pad, segs, &P->bias));
+  }
+  P->n = n_pad; P->k_pad = k_pad;
+  return CTTA_OK;
+}
+
+static inline std::vector<int32_t> identity_map(int n_valid, int n_pad) {
+  std::vector<int32_t> m(n_pad, -1);
+  for (int i = 0; i < n_valid; ++i) m[i] = i;
+  return m;
+}
+// heads*dh features -> heads*64 padded features
+static inline std::vector<int32_t> head_pad_map(int heads, int dh) {
+  std::vector<int32_t> m((size_t)heads * 64, -1);
+  for (int h = 0; h < heads; ++h)
+    for (int d = 0; d < dh; ++d) m[h * 64 + d] = h * dh + d;
+  return m;
+}
+
+// ---------------------------------------------------------------------------------- run context
+struct RunCtx {
+  Arena* arena;
+  hipStream_t stream;
+  bool dry;
+  std::vector<Tap>* taps;   // non-null when debug taps are recorded
+  float* gn_scratch;        // groupnorm scratch (sized for the largest call)
+  size_t gn_scratch_floats;
+};
+
+#define RUN(ctx, expr)                 \
+  do {                                 \
+    if (!(ctx).dry) CTTA_TRY(expr);    \
+  } while (0)
+
+#define ALLOC_OR_FAIL(ptr)                                           \
+  do {                                                               \
+    if (!(ptr)) { ctta_set_error("activation arena exhausted"); return CTTA_ERR_NOMEM; } \
+  } while (0)
+
+static inline void desc_init(ctta_conv_desc* d) {
+  memset(d, 0, sizeof(*d));
+  d->kh = d->kw = 1;
+  d->stride_h = d->stride_w = 1;
+  d->dil_h = d->dil_w = 1;
+  d->alpha = 1.0f;
+  d->groups = 1;
+}
+
+// 2-D convolution over NHWC bf16 (optionally fused x2 nearest upsample on the input)
+static inline ctta_status run_conv2d(RunCtx& c, const ConvLayer& L, const bf16_t* x, int B, int H, int W,
+                                     bool upsample, bf16_t* out, const float* rowvec, int rowvec_ld,
+                                     const bf16_t* res, int res_ld) {
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = x; d.c0 = L.cin_pad;
+  d.batch = B;
+  d.hi = upsample ? 2 * H : H; d.wi = upsample ? 2 * W : W; d.upsample = upsample ? 1 : 0;
+  d.kh = L.kh; d.kw = L.kw; d.stride_h = d.stride_w = L.stride; d.pad_h = d.pad_w = L.pad;
+  d.ho = (d.hi + 2 * L.pad - L.kh) / L.stride + 1;
+  d.wo = (d.wi + 2 * L.pad - L.kw) / L.stride + 1;
+  d.w = L.p.w; d.k_pad = L.p.k_pad; d.n = L.p.n; d.bias = L.p.bias;
+  d.rowvec = rowvec; d.rowvec_ld = rowvec_ld; d.res = res; d.res_ld = res_ld;
+  d.out = out; d.ldc = L.p.n;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  return CTTA_OK;
+}
+
+// Linear over rows of a padded bf16 matrix [rows][k_pad] -> [rows][ldc]
+static inline ctta_status run_linear(RunCtx& c, const PackedW& P, const bf16_t* x, int x_ld, int64_t rows,
+                                     bf16_t* out, int ldc, const bf16_t* res, int res_ld) {
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = x; d.c0 = x_ld;
+  d.batch = 1; d.hi = (int)rows; d.wi = 1; d.ho = (int)rows; d.wo = 1;
+  d.w = P.w; d.k_pad = P.k_pad; d.n = P.n; d.bias = P.bias;
+  d.res = res; d.res_ld = res_ld;
+  d.out = out; d.ldc = ldc;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  return CTTA_OK;
+}
+
+// V^T = Wv * X^T per batch: Wv packed as the PIXEL operand [hp][k_pad], X [B][tokens][k_pad] as the
+// "weight" operand; writes vt [B][hp][vt_ld] (keys contiguous), optional per-row bias.
+static inline ctta_status run_vt(RunCtx& c, const PackedW& Wv, const bf16_t* x, int B, int tokens,
+                                 int tokens_valid_n, bf16_t* vt, int vt_ld, float* out_f32 = nullptr) {
+  (void)out_f32;
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = Wv.w; d.c0 = Wv.k_pad;
+  d.batch = 1; d.hi = Wv.n; d.wi = 1; d.ho = Wv.n; d.wo = 1;
+  d.w = x; d.k_pad = Wv.k_pad; d.n = tokens_valid_n;
+  d.out = vt; d.ldc = vt_ld;
+  d.groups = B; d.x_group_stride = 0; d.w_group_stride = (int64_t)tokens * Wv.k_pad;
+  d.out_group_stride = (int64_t)Wv.n * vt_ld;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  return CTTA_OK;
+}
+
+struct GNLayer {
+  float* gamma = nullptr;
+  float* beta = nullptr;
+  int c = 0;
+};
+static inline ctta_status make_gn(WeightStore& ws, const std::string& prefix, int c, GNLayer* g) {
+  g->c = c;
+  CTTA_TRY(ws.add_vector(prefix + "weight", c, &g->gamma));
+  CTTA_TRY(ws.add_vector(prefix + "bias", c, &g->beta));
+  return CTTA_OK;
+}
+static inline ctta_status run_gn(RunCtx& c, const GNLayer& g, const bf16_t* x, bf16_t* y, int B, int hw,
+                                 int groups, float eps, bool silu) {
+  if (!c.dry && ctta_groupnorm_scratch_floats(B, hw, g.c, groups) > c.gn_scratch_floats) {
+    ctta_set_error("groupnorm scratch too small");
+    return CTTA_ERR_INVALID;
+  }
+  RUN(c, ctta_groupnorm(x, y, B, hw, g.c, groups, g.gamma, g.beta, eps, silu ? 1 : 0, c.gn_scratch, c.stream));
+  return CTTA_OK;
+}
+
+static inline void add_tap(RunCtx& c, const std::string& name, const void* p, int b, int ch, int h, int w,
+                           int c_stride, bool f32 = false) {
+  if (c.taps && c.dry) c.taps->push_back({name, nullptr, b, ch, h, w, c_stride, f32});
+  if (c.taps && !c.dry)
+    for (auto& t : *c.taps)
+      if (t.name == name) { t.ptr = p; t.b = b; }
+}
+
+static inline size_t estimate_store_bytes(const ctta_tensor* w, int n) {
+  size_t total = 64 << 20;
+  for (int i = 0; i < n; ++i) total += (size_t)tensor_numel(&w[i]) * 2 * 3 + 8192;   // bf16 x padding + maps
+  return total;
+}

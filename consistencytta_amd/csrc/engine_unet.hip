@@ -1,0 +1,611 @@
+// U-Net engine: builds the layer graph of UNet2DConditionGuidedModel / UNet2DConditionModel
+// from a config + state dict, pre-packs weights for conv_gemm, and runs the forward pass on a
+// private activation arena.  Reference call order:
+//   unet_2d_condition_guided.py:716-945 (forward), unet_2d_blocks.py:912-972 (CrossAttnDown),
+//   :1027-1058 (Down), :588-609 (Mid), :2017-2078 (CrossAttnUp), :2129-2159 (Up),
+//   resnet.py:549-597 (ResnetBlock2D), transformer_2d.py:218-332, attention.py:276-334.
+//
+// Data layout in HBM: activations NHWC bf16, i.e. a (B, H*W, C) token matrix, so the
+// transformer blocks run on the conv activations without any permute.  The transformer's
+// hidden width `inner = heads * (C // heads)` (255/510/1020 in the light config) is padded to a
+// multiple of 64 (`cp`), heads are padded from dh to 64 lanes (`hp = heads*64`) by zero rows /
+// columns placed at weight-packing time, so no kernel ever sees an odd width.
+#include "engine_common.h"
+
+#include <math.h>
+
+__global__ void add_silu_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                float* __restrict__ out, float* __restrict__ sum_out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = a[i] + (b ? b[i] : 0.f);
+  if (sum_out) sum_out[i] = v;
+  out[i] = v / (1.0f + expf(-v));
+}
+// (B,L) u8 keep-mask -> additive bias (1-m)*-10000 (unet_2d_condition_guided.py:793-795)
+__global__ void mask_bias_kernel(const uint8_t* __restrict__ m, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (1.0f - (m[i] ? 1.0f : 0.0f)) * -10000.0f;
+}
+// (B,L,X) f32 -> (B,Lp,Xp) bf16, zero padded
+__global__ void pack_enc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B, int L,
+                                int X, int Lp, int Xp) {
+  const long long total = (long long)B * Lp * Xp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total;
+       i += (long long)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Xp);
+    const long long r = i / Xp;
+    const int l = (int)(r % Lp);
+    const int b = (int)(r / Lp);
+    dst[i] = (l < L && x < X) ? f2bf(src[((size_t)b * L + l) * X + x]) : (bf16_t)0;
+  }
+}
+// (n, c, kh, kw) f32 -> (n, kh, kw, c) f32 for the direct small-N convolution
+__global__ void repack_small_w_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int c,
+                                      int khw) {
+  const int total = n * c * khw;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int cc = i % c;
+  const int t = (i / c) % khw;
+  const int nn = i / (c * khw);
+  dst[i] = src[((size_t)nn * c + cc) * khw + t];
+}
+
+struct Resnet {
+  int cin = 0, cout = 0, temb_off = 0;
+  GNLayer n1, n2;
+  ConvLayer c1, c2, sc;
+  bool has_sc = false;
+};
+
+struct LNLayer { float* gamma = nullptr; float* beta = nullptr; };
+
+struct Transformer {
+  int c = 0, heads = 0, dh = 0, inner = 0, cp = 0, hp = 0, ffh = 0, ffp = 0;
+  GNLayer norm;
+  PackedW proj_in, qk1, v1, out1, q2, k2, v2, out2, ff1, ff2, proj_out;
+  LNLayer ln1, ln2, ln3;
+};
+
+struct Level {
+  std::vector<Resnet> res;
+  std::vector<Transformer> att;
+  bool has_sampler = false;
+  ConvLayer sampler;
+};
+
+struct ctta_unet {
+  ctta_unet_config cfg;
+  WeightStore store;
+  Arena arena;
+  std::vector<Tap> taps;
+  std::vector<Level> down, up;
+  Resnet mid_r0, mid_r1;
+  Transformer mid_att;
+  ConvLayer conv_in;
+  GNLayer norm_out;
+  float* conv_out_w = nullptr;   // fp32 [cout][3][3][c0] for the direct small-N kernel
+  float* conv_out_b = nullptr;
+  // embeddings (fp32)
+  float *freqs = nullptr, *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
+  float *g_proj = nullptr, *g_w1 = nullptr, *g_b1 = nullptr, *g_w2 = nullptr, *g_b2 = nullptr;
+  float *temb_w = nullptr, *temb_b = nullptr;
+  int temb_dim = 0, temb_total = 0, cin_pad = 0, xp = 0;
+  float* gn_scratch = nullptr;
+  size_t gn_scratch_floats = 0;
+};
+
+struct UCtx : RunCtx {
+  ctta_unet* U;
+  int B, L, Lp;
+  const float* temb_all;
+  const bf16_t* enc_bf;
+  const float* mask_bias;
+  size_t gn_need = 0;
+};
+
+static ctta_status make_resnet(ctta_unet* U, const std::string& p, int cin, int cout, Resnet* R) {
+  WeightStore& ws = U->store;
+  R->cin = cin; R->cout = cout;
+  CTTA_TRY(make_gn(ws, p + "norm1.", cin, &R->n1));
+  CTTA_TRY(make_conv(ws, p + "conv1.", cout, cin, cin, 3, 3, 1, 1, &R->c1));
+  CTTA_TRY(make_gn(ws, p + "norm2.", cout, &R->n2));
+  CTTA_TRY(make_conv(ws, p + "conv2.", cout, cout, cout, 3, 3, 1, 1, &R->c2));
+  R->has_sc = cin != cout;
+  if (R->has_sc) CTTA_TRY(make_conv(ws, p + "conv_shortcut.", cout, cin, cin, 1, 1, 1, 0, &R->sc));
+  // time_emb_proj rows live in one concatenated fp32 table -> one small GEMM per forward
+  R->temb_off = U->temb_total;
+  CTTA_TRY(ws.add_copy_into(p + "time_emb_proj.weight", (int64_t)cout * U->temb_dim,
+                            U->temb_w + (size_t)R->temb_off * U->temb_dim));
+  CTTA_TRY(ws.add_copy_into(p + "time_emb_proj.bias", cout, U->temb_b + R->temb_off));
+  U->temb_total += cout;
+  return CTTA_OK;
+}
+
+static ctta_status make_ln(WeightStore& ws, const std::string& p, int d, LNLayer* L) {
+  CTTA_TRY(ws.add_vector(p + "weight", d, &L->gamma));
+  CTTA_TRY(ws.add_vector(p + "bias", d, &L->beta));
+  return CTTA_OK;
+}
+
+static ctta_status make_transformer(ctta_unet* U, const std::string& p, int c, int heads, Transformer* T) {
+  WeightStore& ws = U->store;
+  const int dh = c / heads, inner = heads * dh;   // unet_2d_blocks.py:873-875
+  CTTA_REQUIRE(dh >= 1 && dh <= 64, "attention head dim %d outside [1,64]", dh);
+  const int cp = round_up(inner, 64), hp = heads * 64;
+  const int ffh = inner * 4, ffp = round_up(ffh, 64);
+  const int X = U->cfg.cross_attention_dim, xp = U->xp;
+  T->c = c; T->heads = heads; T->dh = dh; T->inner = inner; T->cp = cp; T->hp = hp; T->ffh = ffh; T->ffp = ffp;
+  CTTA_TRY(make_gn(ws, p + "norm.", c, &T->norm));
+  const std::string t = p + "transformer_blocks.0.";
+  const auto hmap = head_pad_map(heads, dh);
+  const auto in_cols = identity_map(inner, cp);
+  CTTA_TRY(make_linear(ws, p + "proj_in.weight", p + "proj_in.bias", inner, c, identity_map(inner, cp),
+                       identity_map(c, round_up(c, 64)), &T->proj_in));
+  {  // self-attention q and k packed back to back -> one fused [q | k] GEMM
+    bf16_t* qk = ws.arena.get<bf16_t>((size_t)2 * hp * cp);
+    if (!qk) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
+    PackedW pq, pk;
+    CTTA_TRY(make_linear(ws, t + "attn1.to_q.weight", "", inner, inner, hmap, in_cols, &pq, qk));
+    CTTA_TRY(make_linear(ws, t + "attn1.to_k.weight", "", inner, inner, hmap, in_cols, &pk, qk + (size_t)hp * cp));
+    T->qk1.w = qk; T->qk1.bias = nullptr; T->qk1.n = 2 * hp; T->qk1.k_pad = cp;
+  }
+  CTTA_TRY(make_linear(ws, t + "attn1.to_v.weight", "", inner, inner, hmap, in_cols, &T->v1));
+  CTTA_TRY(make_linear(ws, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", inner, inner,
+                       identity_map(inner, cp), hmap, &T->out1));
+  CTTA_TRY(make_linear(ws, t + "attn2.to_q.weight", "", inner, inner, hmap, in_cols, &T->q2));
+  CTTA_TRY(make_linear(ws, t + "attn2.to_k.weight", "", inner, X, hmap, identity_map(X, xp), &T->k2));
+  CTTA_TRY(make_linear(ws, t + "attn2.to_v.weight", "", inner, X, hmap, identity_map(X, xp), &T->v2));
+  CTTA_TRY(make_linear(ws, t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", inner, inner,
+                       identity_map(inner, cp), hmap, &T->out2));
+  {  // GEGLU projection: value rows -> [0, ffp), gate rows -> [ffp, 2*ffp)  (attention.py:430-432)
+    std::vector<int32_t> rows(2 * ffp, -1);
+    for (int i = 0; i < ffh; ++i) { rows[i] = i; rows[ffp + i] = ffh + i; }
+    CTTA_TRY(make_linear(ws, t + "ff.net.0.proj.weight", t + "ff.net.0.proj.bias", 2 * ffh, inner, rows,
+                         in_cols, &T->ff1));
+  }
+  CTTA_TRY(make_linear(ws, t + "ff.net.2.weight", t + "ff.net.2.bias", inner, ffh, identity_map(inner, cp),
+                       identity_map(ffh, ffp), &T->ff2));
+  CTTA_TRY(make_ln(ws, t + "norm1.", inner, &T->ln1));
+  CTTA_TRY(make_ln(ws, t + "norm2.", inner, &T->ln2));
+  CTTA_TRY(make_ln(ws, t + "norm3.", inner, &T->ln3));
+  CTTA_TRY(make_linear(ws, p + "proj_out.weight", p + "proj_out.bias", c, inner, identity_map(c, round_up(c, 4)),
+                       in_cols, &T->proj_out));
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------------ run
+static ctta_status gn(UCtx& c, const GNLayer& g, const bf16_t* x, bf16_t* y, int hw, float eps, bool silu) {
+  const int groups = c.U->cfg.norm_num_groups;
+  const size_t need = ctta_groupnorm_scratch_floats(c.B, hw, g.c, groups);
+  if (need > c.gn_need) c.gn_need = need;
+  return run_gn(c, g, x, y, c.B, hw, groups, eps, silu);
+}
+
+static ctta_status run_resnet(UCtx& c, const Resnet& R, const bf16_t* x, int H, int W, bf16_t** out_p) {
+  Arena& A = *c.arena;
+  const size_t M = (size_t)c.B * H * W;
+  bf16_t* out = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(out);
+  const size_t mk = A.mark();
+  bf16_t* a = A.get<bf16_t>(M * R.cin); ALLOC_OR_FAIL(a);
+  CTTA_TRY(gn(c, R.n1, x, a, H * W, c.U->cfg.norm_eps, true));
+  bf16_t* t1 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(t1);
+  CTTA_TRY(run_conv2d(c, R.c1, a, c.B, H, W, false, t1, c.temb_all + R.temb_off, c.U->temb_total, nullptr, 0));
+  bf16_t* a2 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(a2);
+  CTTA_TRY(gn(c, R.n2, t1, a2, H * W, c.U->cfg.norm_eps, true));
+  const bf16_t* res = x;
+  if (R.has_sc) {
+    bf16_t* r = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(r);
+    CTTA_TRY(run_conv2d(c, R.sc, x, c.B, H, W, false, r, nullptr, 0, nullptr, 0));
+    res = r;
+  }
+  CTTA_TRY(run_conv2d(c, R.c2, a2, c.B, H, W, false, out, nullptr, 0, res, R.cout));
+  A.release(mk);
+  *out_p = out;
+  return CTTA_OK;
+}
+
+static ctta_status run_attention(UCtx& c, const bf16_t* q, int q_ld, const bf16_t* k, int k_ld, int k_rows,
+                                 const bf16_t* vt, int vt_ld, const float* bias, bf16_t* out, int out_ld,
+                                 int heads, int nq, int nk, int dh) {
+  RUN(c, ctta_attention(q, q_ld, k, k_ld, k_rows, vt, vt_ld, bias, out, out_ld, c.B, heads, nq, nk,
+                        1.0f / sqrtf((float)dh), c.stream));
+  return CTTA_OK;
+}
+
+static ctta_status run_transformer(UCtx& c, const Transformer& T, const bf16_t* x, int H, int W,
+                                   bf16_t** out_p) {
+  Arena& A = *c.arena;
+  const int N = H * W;
+  const size_t M = (size_t)c.B * N;
+  const int cp = T.cp, hp = T.hp;
+  bf16_t* out = A.get<bf16_t>(M * T.c); ALLOC_OR_FAIL(out);
+  const size_t mk = A.mark();
+  bf16_t* g = A.get<bf16_t>(M * T.c); ALLOC_OR_FAIL(g);
+  CTTA_TRY(gn(c, T.norm, x, g, N, 1e-6f, false));   // transformer_2d.py:149 hard-codes eps=1e-6
+  bf16_t* s0 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s0);
+  CTTA_TRY(run_linear(c, T.proj_in, g, T.c, M, s0, cp, nullptr, 0));
+  bf16_t* n = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(n);
+  RUN(c, ctta_layernorm(s0, n, M, T.inner, cp, T.ln1.gamma, T.ln1.beta, 1e-5f, c.stream));
+  // --- self-attention
+  bf16_t* qk = A.get<bf16_t>(M * 2 * hp); ALLOC_OR_FAIL(qk);
+  CTTA_TRY(run_linear(c, T.qk1, n, cp, M, qk, 2 * hp, nullptr, 0));
+  const int vt_ld = round_up(N, 8);
+  bf16_t* vt = A.get<bf16_t>((size_t)c.B * hp * vt_ld); ALLOC_OR_FAIL(vt);
+  CTTA_TRY(run_vt(c, T.v1, n, c.B, N, N, vt, vt_ld));
+  bf16_t* att = A.get<bf16_t>(M * hp); ALLOC_OR_FAIL(att);
+  CTTA_TRY(run_attention(c, qk, 2 * hp, qk + hp, 2 * hp, N, vt, vt_ld, nullptr, att, hp, T.heads, N, N, T.dh));
+  bf16_t* s1 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s1);
+  CTTA_TRY(run_linear(c, T.out1, att, hp, M, s1, cp, s0, cp));
+  // --- cross-attention against the text states
+  RUN(c, ctta_layernorm(s1, n, M, T.inner, cp, T.ln2.gamma, T.ln2.beta, 1e-5f, c.stream));
+  bf16_t* q2 = A.get<bf16_t>(M * hp); ALLOC_OR_FAIL(q2);
+  CTTA_TRY(run_linear(c, T.q2, n, cp, M, q2, hp, nullptr, 0));
+  bf16_t* k2 = A.get<bf16_t>((size_t)c.B * c.Lp * hp); ALLOC_OR_FAIL(k2);
+  CTTA_TRY(run_linear(c, T.k2, c.enc_bf, c.U->xp, (int64_t)c.B * c.Lp, k2, hp, nullptr, 0));
+  bf16_t* vt2 = A.get<bf16_t>((size_t)c.B * hp * c.Lp); ALLOC_OR_FAIL(vt2);
+  CTTA_TRY(run_vt(c, T.v2, c.enc_bf, c.B, c.Lp, c.Lp, vt2, c.Lp));
+  CTTA_TRY(run_attention(c, q2, hp, k2, hp, c.Lp, vt2, c.Lp, c.mask_bias, att, hp, T.heads, N, c.L, T.dh));
+  bf16_t* s2 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s2);
+  CTTA_TRY(run_linear(c, T.out2, att, hp, M, s2, cp, s1, cp));
+  // --- GEGLU feed-forward
+  RUN(c, ctta_layernorm(s2, n, M, T.inner, cp, T.ln3.gamma, T.ln3.beta, 1e-5f, c.stream));
+  bf16_t* f = A.get<bf16_t>(M * 2 * T.ffp); ALLOC_OR_FAIL(f);
+  CTTA_TRY(run_linear(c, T.ff1, n, cp, M, f, 2 * T.ffp, nullptr, 0));
+  bf16_t* gg = A.get<bf16_t>(M * T.ffp); ALLOC_OR_FAIL(gg);
+  RUN(c, ctta_geglu(f, gg, M, T.ffp, c.stream));
+  bf16_t* s3 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s3);
+  CTTA_TRY(run_linear(c, T.ff2, gg, T.ffp, M, s3, cp, s2, cp));
+  CTTA_TRY(run_linear(c, T.proj_out, s3, cp, M, out, T.c, x, T.c));
+  A.release(mk);
+  *out_p = out;
+  return CTTA_OK;
+}
+
+struct Skip { bf16_t* p; int c; };
+
+static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample, const float* timesteps,
+                                     const double* guidance, const float* enc, const uint8_t* mask, int B,
+                                     int L, float* out, hipStream_t stream, size_t* gn_need) {
+  const ctta_unet_config& cfg = U->cfg;
+  UCtx c;
+  c.arena = &U->arena; c.stream = stream; c.dry = dry;
+  c.taps = cfg.debug_taps ? &U->taps : nullptr;
+  c.gn_scratch = U->gn_scratch; c.gn_scratch_floats = U->gn_scratch_floats;
+  c.U = U; c.B = B; c.L = L; c.Lp = round_up(L, 8);
+  Arena& A = U->arena;
+  A.reset();
+  const int H = cfg.height, W = cfg.width;
+  const int T = U->temb_dim, c0 = cfg.block_out_channels[0];
+
+  // ---- 1. time / guidance embeddings in fp32 (embeddings.py; unet...guided.py:803-816)
+  float* tfeat = A.get<float>((size_t)B * c0); ALLOC_OR_FAIL(tfeat);
+  float* h1 = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(h1);
+  float* et = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(et);
+  float* eg = nullptr;
+  RUN(c, ctta_time_features(timesteps, U->freqs, c0, cfg.flip_sin_to_cos, tfeat, B, stream));
+  RUN(c, ctta_linear_f32(tfeat, U->t_w1, U->t_b1, h1, B, T, c0, 0, 1, stream));
+  RUN(c, ctta_linear_f32(h1, U->t_w2, U->t_b2, et, B, T, T, 0, 0, stream));
+  if (cfg.guided) {
+    float* gfeat = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(gfeat);
+    float* g1 = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(g1);
+    eg = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(eg);
+    RUN(c, ctta_fourier_features(guidance, U->g_proj, T / 2, cfg.flip_sin_to_cos, gfeat, B, stream));
+    RUN(c, ctta_linear_f32(gfeat, U->g_w1, U->g_b1, g1, B, T, T, 0, 1, stream));
+    RUN(c, ctta_linear_f32(g1, U->g_w2, U->g_b2, eg, B, T, T, 0, 0, stream));
+  }
+  float* emb = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(emb);
+  float* emb_silu = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(emb_silu);
+  if (!dry) {
+    hipLaunchKernelGGL(add_silu_kernel, dim3((B * T + 255) / 256), dim3(256), 0, stream, et, eg, emb_silu, emb, B * T);
+    CTTA_LAUNCH_CHECK();
+  }
+  add_tap(c, "emb", emb, B, T, 1, 1, T, true);
+  // every resnet's Linear(SiLU(emb)) (resnet.py:572-573) in one batch
+  float* temb_all = A.get<float>((size_t)B * U->temb_total); ALLOC_OR_FAIL(temb_all);
+  RUN(c, ctta_linear_f32(emb_silu, U->temb_w, U->temb_b, temb_all, B, U->temb_total, T, 0, 0, stream));
+  c.temb_all = temb_all;
+
+  // ---- text states and mask bias
+  bf16_t* enc_bf = A.get<bf16_t>((size_t)B * c.Lp * U->xp); ALLOC_OR_FAIL(enc_bf);
+  float* mbias = nullptr;
+  if (mask) { mbias = A.get<float>((size_t)B * L); ALLOC_OR_FAIL(mbias); }
+  if (!dry) {
+    const long long total = (long long)B * c.Lp * U->xp;
+    hipLaunchKernelGGL(pack_enc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, enc, enc_bf, B,
+                       L, cfg.cross_attention_dim, c.Lp, U->xp);
+    CTTA_LAUNCH_CHECK();
+    if (mask) {
+      hipLaunchKernelGGL(mask_bias_kernel, dim3((B * L + 255) / 256), dim3(256), 0, stream, mask, mbias, B * L);
+      CTTA_LAUNCH_CHECK();
+    }
+  }
+  c.enc_bf = enc_bf; c.mask_bias = mbias;
+
+  // ---- 2. conv_in
+  bf16_t* xin = A.get<bf16_t>((size_t)B * H * W * U->cin_pad); ALLOC_OR_FAIL(xin);
+  RUN(c, ctta_nchw_f32_to_nhwc_bf16(sample, xin, B, cfg.in_channels, H, W, U->cin_pad, 1.0f, stream));
+  bf16_t* h = A.get<bf16_t>((size_t)B * H * W * c0); ALLOC_OR_FAIL(h);
+  CTTA_TRY(run_conv2d(c, U->conv_in, xin, B, H, W, false, h, nullptr, 0, nullptr, 0));
+  add_tap(c, "conv_in", h, B, c0, H, W, c0);
+  int ch = c0, hh = H, ww = W;
+  std::vector<Skip> skips;
+  skips.push_back({h, ch});
+
+  // ---- 3. down
+  for (int i = 0; i < cfg.n_levels; ++i) {
+    const Level& Lv = U->down[i];
+    const std::string p = "down_blocks." + std::to_string(i) + ".";
+    for (size_t j = 0; j < Lv.res.size(); ++j) {
+      CTTA_TRY(run_resnet(c, Lv.res[j], h, hh, ww, &h));
+      ch = Lv.res[j].cout;
+      add_tap(c, p + "resnets." + std::to_string(j), h, B, ch, hh, ww, ch);
+      if (!Lv.att.empty()) {
+        CTTA_TRY(run_transformer(c, Lv.att[j], h, hh, ww, &h));
+        add_tap(c, p + "attentions." + std::to_string(j), h, B, ch, hh, ww, ch);
+      }
+      skips.push_back({h, ch});
+    }
+    if (Lv.has_sampler) {
+      const int ho = (hh + 2 - 3) / 2 + 1, wo = (ww + 2 - 3) / 2 + 1;
+      bf16_t* d = A.get<bf16_t>((size_t)B * ho * wo * ch); ALLOC_OR_FAIL(d);
+      CTTA_TRY(run_conv2d(c, Lv.sampler, h, B, hh, ww, false, d, nullptr, 0, nullptr, 0));
+      h = d; hh = ho; ww = wo;
+      add_tap(c, p + "downsamplers.0", h, B, ch, hh, ww, ch);
+      skips.push_back({h, ch});
+    }
+  }
+  // ---- 4. mid
+  CTTA_TRY(run_resnet(c, U->mid_r0, h, hh, ww, &h));
+  CTTA_TRY(run_transformer(c, U->mid_att, h, hh, ww, &h));
+  CTTA_TRY(run_resnet(c, U->mid_r1, h, hh, ww, &h));
+  add_tap(c, "mid_block", h, B, ch, hh, ww, ch);
+  // ---- 5. up
+  for (int i = 0; i < cfg.n_levels; ++i) {
+    const Level& Lv = U->up[i];
+    const std::string p = "up_blocks." + std::to_string(i) + ".";
+    for (size_t j = 0; j < Lv.res.size(); ++j) {
+      const Skip sk = skips.back();
+      skips.pop_back();
+      const size_t M = (size_t)B * hh * ww;
+      bf16_t* cat = A.get<bf16_t>(M * (ch + sk.c)); ALLOC_OR_FAIL(cat);
+      RUN(c, ctta_concat_channels(h, ch, sk.p, sk.c, cat, (int64_t)M, stream));   // torch.cat([h, skip], 1)
+      CTTA_REQUIRE(Lv.res[j].cin == ch + sk.c, "internal: skip width mismatch");
+      CTTA_TRY(run_resnet(c, Lv.res[j], cat, hh, ww, &h));
+      ch = Lv.res[j].cout;
+      add_tap(c, p + "resnets." + std::to_string(j), h, B, ch, hh, ww, ch);
+      if (!Lv.att.empty()) {
+        CTTA_TRY(run_transformer(c, Lv.att[j], h, hh, ww, &h));
+        add_tap(c, p + "attentions." + std::to_string(j), h, B, ch, hh, ww, ch);
+      }
+    }
+    if (Lv.has_sampler) {   // Upsample2D: nearest x2 fused into the conv's gather
+      bf16_t* u = A.get<bf16_t>((size_t)B * 4 * hh * ww * ch); ALLOC_OR_FAIL(u);
+      CTTA_TRY(run_conv2d(c, Lv.sampler, h, B, hh, ww, true, u, nullptr, 0, nullptr, 0));
+      h = u; hh *= 2; ww *= 2;
+      add_tap(c, p + "upsamplers.0", h, B, ch, hh, ww, ch);
+    }
+  }
+  CTTA_REQUIRE(hh == H && ww == W && ch == c0, "internal: up path did not return to the input extent");
+  // ---- 6. out
+  bf16_t* a = A.get<bf16_t>((size_t)B * H * W * c0); ALLOC_OR_FAIL(a);
+  CTTA_TRY(gn(c, U->norm_out, h, a, H * W, cfg.norm_eps, true));
+  RUN(c, ctta_conv_small_n(a, c0, B, H, W, 3, 3, 1, 1, U->conv_out_w, U->conv_out_b, cfg.out_channels, 0,
+                           0.f, 0, out, nullptr, stream));
+  if (gn_need) *gn_need = c.gn_need;
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------------ create
+static ctta_status unet_build(ctta_unet* U) {
+  const ctta_unet_config& cfg = U->cfg;
+  WeightStore& ws = U->store;
+  const int n = cfg.n_levels;
+  const int* boc = cfg.block_out_channels;
+  const int T = boc[0] * 4;
+  U->temb_dim = T;
+  U->cin_pad = round_up(cfg.in_channels, 32);
+  U->xp = round_up(cfg.cross_attention_dim, 64);
+  // total rows of the concatenated time_emb_proj table
+  int total = 0;
+  for (int i = 0; i < n; ++i) total += cfg.layers_per_block[i] * boc[i];
+  for (int i = 0; i < n; ++i) total += (cfg.layers_per_block[n - 1 - i] + 1) * boc[n - 1 - i];
+  total += 2 * boc[n - 1];
+  U->temb_w = ws.arena.get<float>((size_t)total * T);
+  U->temb_b = ws.arena.get<float>((size_t)total);
+  if (!U->temb_w || !U->temb_b) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
+  U->temb_total = 0;
+
+  CTTA_TRY(make_conv(ws, "conv_in.", boc[0], cfg.in_channels, U->cin_pad, 3, 3, 1, 1, &U->conv_in));
+  CTTA_TRY(ws.add_vector("time_embedding.linear_1.weight", T * boc[0], &U->t_w1));
+  CTTA_TRY(ws.add_vector("time_embedding.linear_1.bias", T, &U->t_b1));
+  CTTA_TRY(ws.add_vector("time_embedding.linear_2.weight", T * T, &U->t_w2));
+  CTTA_TRY(ws.add_vector("time_embedding.linear_2.bias", T, &U->t_b2));
+  if (cfg.guided) {
+    CTTA_TRY(ws.add_vector("guidance_proj.weight", T / 2, &U->g_proj));
+    CTTA_TRY(ws.add_vector("guidance_embedding.linear_1.weight", T * T, &U->g_w1));
+    CTTA_TRY(ws.add_vector("guidance_embedding.linear_1.bias", T, &U->g_b1));
+    CTTA_TRY(ws.add_vector("guidance_embedding.linear_2.weight", T * T, &U->g_w2));
+    CTTA_TRY(ws.add_vector("guidance_embedding.linear_2.bias", T, &U->g_b2));
+  }
+  {  // sinusoid frequency table exp(-ln(10000) * i / (half - shift)), embeddings.py:43-49
+    const int half = boc[0] / 2;
+    std::vector<float> f(half);
+    for (int i = 0; i < half; ++i) {
+      const float exponent = (-logf(10000.0f) * (float)i) / ((float)half - cfg.freq_shift);
+      f[i] = (float)exp((double)exponent);
+    }
+    U->freqs = ws.arena.get<float>(half);
+    if (!U->freqs) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
+    CTTA_CHECK_HIP(hipMemcpy(U->freqs, f.data(), half * sizeof(float), hipMemcpyHostToDevice));
+  }
+
+  U->down.resize(n);
+  int out_c = boc[0];
+  for (int i = 0; i < n; ++i) {
+    const int in_c = out_c;
+    out_c = boc[i];
+    Level& Lv = U->down[i];
+    const std::string p = "down_blocks." + std::to_string(i) + ".";
+    const int nl = cfg.layers_per_block[i];
+    if (cfg.down_cross[i]) {
+      Lv.att.resize(nl);
+      for (int j = 0; j < nl; ++j)
+        CTTA_TRY(make_transformer(U, p + "attentions." + std::to_string(j) + ".", out_c, cfg.heads[i], &Lv.att[j]));
+    }
+    Lv.res.resize(nl);
+    for (int j = 0; j < nl; ++j)
+      CTTA_TRY(make_resnet(U, p + "resnets." + std::to_string(j) + ".", j == 0 ? in_c : out_c, out_c, &Lv.res[j]));
+    if (i != n - 1) {
+      Lv.has_sampler = true;
+      CTTA_TRY(make_conv(ws, p + "downsamplers.0.conv.", out_c, out_c, out_c, 3, 3, 2, 1, &Lv.sampler));
+    }
+  }
+  U->up.resize(n);
+  out_c = boc[n - 1];
+  for (int i = 0; i < n; ++i) {
+    const int prev_c = out_c;
+    out_c = boc[n - 1 - i];
+    const int in_c = boc[n - 1 - (i + 1 < n ? i + 1 : n - 1)];
+    const int nl = cfg.layers_per_block[n - 1 - i] + 1;
+    Level& Lv = U->up[i];
+    const std::string p = "up_blocks." + std::to_string(i) + ".";
+    if (cfg.up_cross[i]) {
+      Lv.att.resize(nl);
+      for (int j = 0; j < nl; ++j)
+        CTTA_TRY(make_transformer(U, p + "attentions." + std::to_string(j) + ".", out_c, cfg.heads[n - 1 - i], &Lv.att[j]));
+    }
+    Lv.res.resize(nl);
+    for (int j = 0; j < nl; ++j) {
+      const int skip_c = (j == nl - 1) ? in_c : out_c;
+      const int rin = (j == 0) ? prev_c : out_c;
+      CTTA_TRY(make_resnet(U, p + "resnets." + std::to_string(j) + ".", rin + skip_c, out_c, &Lv.res[j]));
+    }
+    if (i != n - 1) {
+      Lv.has_sampler = true;
+      CTTA_TRY(make_conv(ws, p + "upsamplers.0.conv.", out_c, out_c, out_c, 3, 3, 1, 1, &Lv.sampler));
+    }
+  }
+  CTTA_TRY(make_transformer(U, "mid_block.attentions.0.", boc[n - 1], cfg.heads[n - 1], &U->mid_att));
+  CTTA_TRY(make_resnet(U, "mid_block.resnets.0.", boc[n - 1], boc[n - 1], &U->mid_r0));
+  CTTA_TRY(make_resnet(U, "mid_block.resnets.1.", boc[n - 1], boc[n - 1], &U->mid_r1));
+  CTTA_REQUIRE(U->temb_total == total, "internal: time_emb_proj table size");
+  CTTA_TRY(make_gn(ws, "conv_norm_out.", boc[0], &U->norm_out));
+  {
+    const int co = cfg.out_channels, ci = boc[0];
+    U->conv_out_w = ws.arena.get<float>((size_t)co * ci * 9);
+    if (!U->conv_out_w) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
+    float* dst = U->conv_out_w;
+    ws.jobs.push_back([=](const WeightTable& wt, hipStream_t s) -> ctta_status {
+      const ctta_tensor* t = wt.find("conv_out.weight");
+      if (!t) { ctta_set_error("missing state-dict key 'conv_out.weight'"); return CTTA_ERR_MISSING_KEY; }
+      if (tensor_numel(t) != (int64_t)co * ci * 9) { ctta_set_error("size mismatch for 'conv_out.weight'"); return CTTA_ERR_INVALID; }
+      const int total_e = co * ci * 9;
+      hipLaunchKernelGGL(repack_small_w_kernel, dim3((total_e + 255) / 256), dim3(256), 0, s, t->data, dst, co, ci, 9);
+      CTTA_LAUNCH_CHECK();
+      return CTTA_OK;
+    });
+    CTTA_TRY(ws.add_vector("conv_out.bias", co, &U->conv_out_b));
+  }
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_tensor* weights, int n_weights,
+                                        void* stream, ctta_unet** out) {
+  CTTA_REQUIRE(cfg && weights && out, "unet_create: null pointer");
+  CTTA_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= CTTA_MAX_LEVELS, "unet_create: n_levels=%d", cfg->n_levels);
+  CTTA_REQUIRE(cfg->in_channels > 0 && cfg->out_channels > 0 &&
+                   (cfg->out_channels == 1 || cfg->out_channels == 2 || cfg->out_channels == 4 || cfg->out_channels == 8),
+               "unet_create: out_channels=%d unsupported (1,2,4,8)", cfg->out_channels);
+  for (int i = 0; i < cfg->n_levels; ++i) {
+    CTTA_REQUIRE(cfg->block_out_channels[i] % 8 == 0, "unet_create: block_out_channels must be multiples of 8");
+    CTTA_REQUIRE(cfg->block_out_channels[i] % cfg->norm_num_groups == 0,
+                 "unet_create: channels %d not divisible by norm_num_groups %d", cfg->block_out_channels[i], cfg->norm_num_groups);
+  }
+  const int div = 1 << (cfg->n_levels - 1);
+  CTTA_REQUIRE(cfg->height % div == 0 && cfg->width % div == 0,
+               "unet_create: sample extent %dx%d must be a multiple of %d", cfg->height, cfg->width, div);
+  CTTA_REQUIRE(cfg->max_batch >= 1 && cfg->max_text_len >= 1, "unet_create: bad max_batch/max_text_len");
+  hipStream_t s = (hipStream_t)stream;
+  ctta_unet* U = new ctta_unet();
+  U->cfg = *cfg;
+  ctta_status st = U->store.init(estimate_store_bytes(weights, n_weights));
+  if (st != CTTA_OK) { delete U; return st; }
+  WeightTable wt;
+  wt.build(weights, n_weights);
+  st = unet_build(U);
+  if (st == CTTA_OK) st = U->store.run_all(wt, s);
+  size_t gn_need = 0;
+  if (st == CTTA_OK) {   // sizing pass: no launches, measures the arena and the GN scratch
+    U->arena.dry = true;
+    U->arena.no_release = cfg->debug_taps != 0;
+    st = unet_forward_impl(U, true, nullptr, nullptr, nullptr, nullptr, (const uint8_t*)1, cfg->max_batch,
+                           cfg->max_text_len, nullptr, s, &gn_need);
+  }
+  if (st == CTTA_OK) {
+    const size_t bytes = U->arena.peak + (1 << 20);
+    U->arena.dry = false;
+    U->arena.cap = bytes;
+    if (hipMalloc((void**)&U->arena.base, bytes) != hipSuccess ||
+        hipMalloc((void**)&U->gn_scratch, (gn_need + 64) * sizeof(float)) != hipSuccess) {
+      ctta_set_error("unet_create: hipMalloc of %zu-byte activation arena failed", bytes);
+      st = CTTA_ERR_NOMEM;
+    } else {
+      U->gn_scratch_floats = gn_need + 64;
+      if (hipMemsetAsync(U->arena.base, 0, bytes, s) != hipSuccess) st = CTTA_ERR_HIP;
+    }
+  }
+  if (st == CTTA_OK && hipStreamSynchronize(s) != hipSuccess) { ctta_set_error("unet_create: stream sync failed"); st = CTTA_ERR_HIP; }
+  if (st != CTTA_OK) { ctta_unet_destroy(U); return st; }
+  *out = U;
+  return CTTA_OK;
+}
+
+extern "C" void ctta_unet_destroy(ctta_unet* U) {
+  if (!U) return;
+  U->store.destroy();
+  if (U->arena.base) (void)hipFree(U->arena.base);
+  if (U->gn_scratch) (void)hipFree(U->gn_scratch);
+  delete U;
+}
+
+extern "C" ctta_status ctta_unet_load_weights(ctta_unet* U, const ctta_tensor* weights, int n_weights, void* stream) {
+  CTTA_REQUIRE(U && weights, "unet_load_weights: null pointer");
+  WeightTable wt;
+  wt.build(weights, n_weights);
+  return U->store.run_all(wt, (hipStream_t)stream);
+}
+
+extern "C" ctta_status ctta_unet_forward(ctta_unet* U, const float* sample, const float* timesteps,
+                                         const double* guidance, const float* enc, const uint8_t* mask, int batch,
+                                         int text_len, float* out, void* stream) {
+  CTTA_REQUIRE(U && sample && timesteps && enc && out, "unet_forward: null pointer");
+  CTTA_REQUIRE(!U->cfg.guided || guidance, "unet_forward: guidance is required by the guided U-Net");
+  CTTA_REQUIRE(batch >= 1 && batch <= U->cfg.max_batch, "unet_forward: batch %d outside [1,%d]", batch, U->cfg.max_batch);
+  CTTA_REQUIRE(text_len >= 1 && text_len <= U->cfg.max_text_len, "unet_forward: text_len %d outside [1,%d]", text_len,
+               U->cfg.max_text_len);
+  return unet_forward_impl(U, false, sample, timesteps, guidance, enc, mask, batch, text_len, out, (hipStream_t)stream,
+                           nullptr);
+}
+
+extern "C" size_t ctta_unet_arena_bytes(const ctta_unet* U) { return U ? U->arena.cap + U->store.arena.cap : 0; }
+extern "C" int ctta_unet_num_taps(const ctta_unet* U) { return U ? (int)U->taps.size() : 0; }
+extern "C" ctta_status ctta_unet_tap_info(const ctta_unet* U, int i, const char** name, int dims[4]) {
+  CTTA_REQUIRE(U && i >= 0 && i < (int)U->taps.size(), "tap index out of range");
+  const Tap& t = U->taps[i];
+  *name = t.name.c_str();
+  dims[0] = t.b; dims[1] = t.c; dims[2] = t.h; dims[3] = t.w;
+  return CTTA_OK;
+}
+extern "C" ctta_status ctta_unet_tap_read(ctta_unet* U, int i, float* dst, void* stream) {
+  CTTA_REQUIRE(U && i >= 0 && i < (int)U->taps.size() && dst, "tap index out of range");
+  const Tap& t = U->taps[i];
+  CTTA_REQUIRE(t.ptr, "tap '%s' has not been produced yet", t.name.c_str());
+  if (t.f32_nchw) {
+    CTTA_CHECK_HIP(hipMemcpyAsync(dst, t.ptr, (size_t)t.b * t.c * t.h * t.w * sizeof(float), hipMemcpyDeviceToDevice,
+                                  (hipStream_t)stream));
+    return CTTA_OK;
+  }
+  return ctta_nhwc_bf16_to_nchw_f32(t.ptr, dst, t.b, t.c, t.h, t.w, t.c_stride, stream);
+}

@@ -1,0 +1,606 @@
+// AudioLDM VAE decoder and HiFi-GAN vocoder engines.
+//   VAE:      AutoencoderKL.decode_first_stage -> decode -> Decoder.forward
+//             (audioldm/variational_autoencoder/autoencoder.py:91-106, modules.py:650-683),
+//             ResnetBlock.forward modules.py:155-175, AttnBlock.forward :204-230, Upsample :53-57.
+//   HiFi-GAN: Generator.forward hifigan/models.py:101-117, ResBlock.forward :56-63.
+// Layout: NHWC bf16 for the decoder; (B, L, C) bf16 for the vocoder (the decoder's
+// (B,1,T,F) mel IS the vocoder's (B, T, F=num_mels) input, autoencoder.py:109).
+#include "engine_common.h"
+
+#include <math.h>
+
+// z (B,zc,H,W) f32 -> post_quant_conv(z / scale) as NHWC bf16 with channels padded to cpad.
+// (autoencoder.py:99,105: 1x1 conv embed_dim -> z_channels, tiny: done in fp32 per pixel)
+__global__ void post_quant_kernel(const float* __restrict__ z, const float* __restrict__ w,
+                                  const float* __restrict__ b, float inv_scale, int B, int zin, int zout,
+                                  int HW, int cpad, bf16_t* __restrict__ out) {
+  const long long total = (long long)B * HW;
+  const long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (pix >= total) return;
+  const int bb = (int)(pix / HW);
+  const int hw = (int)(pix - (long long)bb * HW);
+  float in[16];
+  for (int c = 0; c < zin; ++c) in[c] = z[((size_t)bb * zin + c) * HW + hw] * inv_scale;
+  for (int o = 0; o < cpad; ++o) {
+    float acc = 0.f;
+    if (o < zout) {
+      acc = b[o];
+      for (int c = 0; c < zin; ++c) acc += w[o * zin + c] * in[c];
+    }
+    out[(size_t)pix * cpad + o] = f2bf(acc);
+  }
+}
+
+__global__ void repack_small_w3_kernel(const float* __restrict__ src, float* __restrict__ dst, int n, int c,
+                                       int khw) {
+  const int total = n * c * khw;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int cc = i % c;
+  const int t = (i / c) % khw;
+  const int nn = i / (c * khw);
+  dst[i] = src[((size_t)nn * c + cc) * khw + t];
+}
+
+static ctta_status add_small_conv_w(WeightStore& ws, const std::string& key, int co, int ci, int khw, float** out) {
+  float* dst = ws.arena.get<float>((size_t)co * ci * khw);
+  if (!dst) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
+  *out = dst;
+  ws.jobs.push_back([=](const WeightTable& wt, hipStream_t s) -> ctta_status {
+    const ctta_tensor* t = wt.find(key);
+    if (!t) { ctta_set_error("missing state-dict key '%s'", key.c_str()); return CTTA_ERR_MISSING_KEY; }
+    if (tensor_numel(t) != (int64_t)co * ci * khw) { ctta_set_error("size mismatch for '%s'", key.c_str()); return CTTA_ERR_INVALID; }
+    const int total = co * ci * khw;
+    hipLaunchKernelGGL(repack_small_w3_kernel, dim3((total + 255) / 256), dim3(256), 0, s, t->data, dst, co, ci, khw);
+    CTTA_LAUNCH_CHECK();
+    return CTTA_OK;
+  });
+  return CTTA_OK;
+}
+
+// ====================================================================================== VAE
+struct VaeRes {
+  int cin = 0, cout = 0;
+  GNLayer n1, n2;
+  ConvLayer c1, c2, sc;
+  bool has_sc = false;
+};
+
+struct ctta_vae {
+  ctta_vae_config cfg;
+  WeightStore store;
+  Arena arena;
+  std::vector<Tap> taps;
+  float *pq_w = nullptr, *pq_b = nullptr;
+  ConvLayer conv_in;
+  VaeRes mid1, mid2;
+  GNLayer attn_norm;
+  ConvLayer aq, ak, av, aproj;
+  std::vector<std::vector<VaeRes>> up;     // [level][block]
+  std::vector<ConvLayer> upsample;         // [level] (level 0 unused)
+  GNLayer norm_out;
+  float *conv_out_w = nullptr, *conv_out_b = nullptr;
+  int block_in = 0, c_last = 0;
+  float* gn_scratch = nullptr;
+  size_t gn_scratch_floats = 0;
+};
+
+struct VCtx : RunCtx {
+  int B;
+  size_t gn_need = 0;
+};
+
+static const int kVaeGroups = 32;    // Normalize(): GroupNorm(32, eps=1e-6)  modules.py:38-41
+static const float kVaeEps = 1e-6f;
+
+static ctta_status vgn(VCtx& c, const GNLayer& g, const bf16_t* x, bf16_t* y, int hw, bool silu) {
+  const size_t need = ctta_groupnorm_scratch_floats(c.B, hw, g.c, kVaeGroups);
+  if (need > c.gn_need) c.gn_need = need;
+  return run_gn(c, g, x, y, c.B, hw, kVaeGroups, kVaeEps, silu);
+}
+
+static ctta_status make_vae_res(WeightStore& ws, const std::string& p, int cin, int cout, VaeRes* R) {
+  R->cin = cin; R->cout = cout;
+  CTTA_TRY(make_gn(ws, p + "norm1.", cin, &R->n1));
+  CTTA_TRY(make_conv(ws, p + "conv1.", cout, cin, cin, 3, 3, 1, 1, &R->c1));
+  CTTA_TRY(make_gn(ws, p + "norm2.", cout, &R->n2));
+  CTTA_TRY(make_conv(ws, p + "conv2.", cout, cout, cout, 3, 3, 1, 1, &R->c2));
+  R->has_sc = cin != cout;
+  if (R->has_sc) CTTA_TRY(make_conv(ws, p + "nin_shortcut.", cout, cin, cin, 1, 1, 1, 0, &R->sc));
+  return CTTA_OK;
+}
+
+static ctta_status run_vae_res(VCtx& c, const VaeRes& R, const bf16_t* x, int H, int W, bf16_t** out_p) {
+  Arena& A = *c.arena;
+  const size_t M = (size_t)c.B * H * W;
+  bf16_t* out = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(out);
+  const size_t mk = A.mark();
+  bf16_t* a = A.get<bf16_t>(M * R.cin); ALLOC_OR_FAIL(a);
+  CTTA_TRY(vgn(c, R.n1, x, a, H * W, true));
+  bf16_t* t1 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(t1);
+  CTTA_TRY(run_conv2d(c, R.c1, a, c.B, H, W, false, t1, nullptr, 0, nullptr, 0));
+  bf16_t* a2 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(a2);
+  CTTA_TRY(vgn(c, R.n2, t1, a2, H * W, true));
+  const bf16_t* res = x;
+  if (R.has_sc) {
+    bf16_t* r = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(r);
+    CTTA_TRY(run_conv2d(c, R.sc, x, c.B, H, W, false, r, nullptr, 0, nullptr, 0));
+    res = r;
+  }
+  CTTA_TRY(run_conv2d(c, R.c2, a2, c.B, H, W, false, out, nullptr, 0, res, R.cout));
+  A.release(mk);
+  *out_p = out;
+  return CTTA_OK;
+}
+
+// AttnBlock: single head over N = H*W tokens, d = C.  Scores are materialised in fp32
+// (B x N x N; 2 GiB at B=32, N=4096 -- 288 GB of HBM makes this the simple choice), softmaxed
+// to bf16, and multiplied by V^T; all three products run on conv_gemm.
+static ctta_status run_vae_attn(VCtx& c, ctta_vae* V, const bf16_t* x, int H, int W, bf16_t** out_p) {
+  Arena& A = *c.arena;
+  const int N = H * W, C = V->block_in, B = c.B;
+  CTTA_REQUIRE(N % 64 == 0 && C % 64 == 0, "vae attention: tokens=%d and channels=%d must be multiples of 64", N, C);
+  const size_t M = (size_t)B * N;
+  bf16_t* out = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(out);
+  const size_t mk = A.mark();
+  bf16_t* g = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(g);
+  CTTA_TRY(vgn(c, V->attn_norm, x, g, N, false));
+  bf16_t* q = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(q);
+  bf16_t* k = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(k);
+  CTTA_TRY(run_conv2d(c, V->aq, g, B, H, W, false, q, nullptr, 0, nullptr, 0));
+  CTTA_TRY(run_conv2d(c, V->ak, g, B, H, W, false, k, nullptr, 0, nullptr, 0));
+  bf16_t* vt = A.get<bf16_t>((size_t)B * C * N); ALLOC_OR_FAIL(vt);
+  {
+    ctta_conv_desc d;
+    desc_init(&d);
+    d.x0 = V->av.p.w; d.c0 = V->av.p.k_pad;
+    d.batch = 1; d.hi = C; d.wi = 1; d.ho = C; d.wo = 1;
+    d.w = g; d.k_pad = C; d.n = N;
+    d.bias_m = V->av.p.bias;
+    d.out = vt; d.ldc = N;
+    d.groups = B; d.w_group_stride = (int64_t)N * C; d.out_group_stride = (int64_t)C * N;
+    RUN(c, ctta_conv_gemm(&d, c.stream));
+  }
+  float* s = A.get<float>((size_t)B * N * N); ALLOC_OR_FAIL(s);
+  {
+    ctta_conv_desc d;
+    desc_init(&d);
+    d.x0 = q; d.c0 = C;
+    d.batch = 1; d.hi = N; d.wi = 1; d.ho = N; d.wo = 1;
+    d.w = k; d.k_pad = C; d.n = N;
+    d.out = s; d.ldc = N; d.out_f32 = 1;
+    d.groups = B; d.x_group_stride = (int64_t)N * C; d.w_group_stride = (int64_t)N * C;
+    d.out_group_stride = (int64_t)N * N;
+    RUN(c, ctta_conv_gemm(&d, c.stream));
+  }
+  bf16_t* p = A.get<bf16_t>((size_t)B * N * N); ALLOC_OR_FAIL(p);
+  RUN(c, ctta_softmax_rows(s, p, (int64_t)B * N, N, 1.0f / sqrtf((float)C), c.stream));
+  bf16_t* o = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(o);
+  {
+    ctta_conv_desc d;
+    desc_init(&d);
+    d.x0 = p; d.c0 = N;
+    d.batch = 1; d.hi = N; d.wi = 1; d.ho = N; d.wo = 1;
+    d.w = vt; d.k_pad = N; d.n = C;
+    d.out = o; d.ldc = C;
+    d.groups = B; d.x_group_stride = (int64_t)N * N; d.w_group_stride = (int64_t)C * N;
+    d.out_group_stride = (int64_t)N * C;
+    RUN(c, ctta_conv_gemm(&d, c.stream));
+  }
+  CTTA_TRY(run_conv2d(c, V->aproj, o, B, H, W, false, out, nullptr, 0, x, C));
+  A.release(mk);
+  *out_p = out;
+  return CTTA_OK;
+}
+
+static ctta_status vae_forward_impl(ctta_vae* V, bool dry, const float* z, int B, float* mel, hipStream_t stream,
+                                    size_t* gn_need) {
+  const ctta_vae_config& cfg = V->cfg;
+  VCtx c;
+  c.arena = &V->arena; c.stream = stream; c.dry = dry;
+  c.taps = cfg.debug_taps ? &V->taps : nullptr;
+  c.gn_scratch = V->gn_scratch; c.gn_scratch_floats = V->gn_scratch_floats;
+  c.B = B;
+  Arena& A = V->arena;
+  A.reset();
+  int H = cfg.latent_h, W = cfg.latent_w;
+  const int cpad = 32;
+  bf16_t* zin = A.get<bf16_t>((size_t)B * H * W * cpad); ALLOC_OR_FAIL(zin);
+  if (!dry) {
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(post_quant_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, z, V->pq_w,
+                       V->pq_b, 1.0f / cfg.scale_factor, B, cfg.embed_dim, cfg.z_channels, H * W, cpad, zin);
+    CTTA_LAUNCH_CHECK();
+  }
+  int ch = V->block_in;
+  bf16_t* h = A.get<bf16_t>((size_t)B * H * W * ch); ALLOC_OR_FAIL(h);
+  CTTA_TRY(run_conv2d(c, V->conv_in, zin, B, H, W, false, h, nullptr, 0, nullptr, 0));
+  add_tap(c, "conv_in", h, B, ch, H, W, ch);
+  CTTA_TRY(run_vae_res(c, V->mid1, h, H, W, &h));
+  add_tap(c, "mid.block_1", h, B, ch, H, W, ch);
+  CTTA_TRY(run_vae_attn(c, V, h, H, W, &h));
+  add_tap(c, "mid.attn_1", h, B, ch, H, W, ch);
+  CTTA_TRY(run_vae_res(c, V->mid2, h, H, W, &h));
+  add_tap(c, "mid.block_2", h, B, ch, H, W, ch);
+  for (int lvl = cfg.n_levels - 1; lvl >= 0; --lvl) {
+    for (size_t b = 0; b < V->up[lvl].size(); ++b) {
+      CTTA_TRY(run_vae_res(c, V->up[lvl][b], h, H, W, &h));
+      ch = V->up[lvl][b].cout;
+      add_tap(c, "up." + std::to_string(lvl) + ".block." + std::to_string(b), h, B, ch, H, W, ch);
+    }
+    if (lvl != 0) {
+      bf16_t* u = A.get<bf16_t>((size_t)B * 4 * H * W * ch); ALLOC_OR_FAIL(u);
+      CTTA_TRY(run_conv2d(c, V->upsample[lvl], h, B, H, W, true, u, nullptr, 0, nullptr, 0));
+      h = u; H *= 2; W *= 2;
+      add_tap(c, "up." + std::to_string(lvl) + ".upsample", h, B, ch, H, W, ch);
+    }
+  }
+  bf16_t* a = A.get<bf16_t>((size_t)B * H * W * ch); ALLOC_OR_FAIL(a);
+  CTTA_TRY(vgn(c, V->norm_out, h, a, H * W, true));
+  RUN(c, ctta_conv_small_n(a, ch, B, H, W, 3, 3, 1, 1, V->conv_out_w, V->conv_out_b, cfg.out_ch, 0, 0.f, 0, mel,
+                           nullptr, stream));
+  if (gn_need) *gn_need = c.gn_need;
+  return CTTA_OK;
+}
+
+static ctta_status vae_build(ctta_vae* V) {
+  const ctta_vae_config& cfg = V->cfg;
+  WeightStore& ws = V->store;
+  const int nres = cfg.n_levels;
+  int block_in = cfg.ch * cfg.ch_mult[nres - 1];
+  V->block_in = block_in;
+  CTTA_TRY(ws.add_vector("post_quant_conv.weight", cfg.z_channels * cfg.embed_dim, &V->pq_w));
+  CTTA_TRY(ws.add_vector("post_quant_conv.bias", cfg.z_channels, &V->pq_b));
+  const std::string p = "decoder.";
+  CTTA_TRY(make_conv(ws, p + "conv_in.", block_in, cfg.z_channels, 32, 3, 3, 1, 1, &V->conv_in));
+  CTTA_TRY(make_vae_res(ws, p + "mid.block_1.", block_in, block_in, &V->mid1));
+  CTTA_TRY(make_gn(ws, p + "mid.attn_1.norm.", block_in, &V->attn_norm));
+  CTTA_TRY(make_conv(ws, p + "mid.attn_1.q.", block_in, block_in, block_in, 1, 1, 1, 0, &V->aq));
+  CTTA_TRY(make_conv(ws, p + "mid.attn_1.k.", block_in, block_in, block_in, 1, 1, 1, 0, &V->ak));
+  CTTA_TRY(make_conv(ws, p + "mid.attn_1.v.", block_in, block_in, block_in, 1, 1, 1, 0, &V->av));
+  CTTA_TRY(make_conv(ws, p + "mid.attn_1.proj_out.", block_in, block_in, block_in, 1, 1, 1, 0, &V->aproj));
+  CTTA_TRY(make_vae_res(ws, p + "mid.block_2.", block_in, block_in, &V->mid2));
+  V->up.resize(nres);
+  V->upsample.resize(nres);
+  for (int lvl = nres - 1; lvl >= 0; --lvl) {
+    const int block_out = cfg.ch * cfg.ch_mult[lvl];
+    V->up[lvl].resize(cfg.num_res_blocks + 1);
+    for (int b = 0; b <= cfg.num_res_blocks; ++b) {
+      CTTA_TRY(make_vae_res(ws, p + "up." + std::to_string(lvl) + ".block." + std::to_string(b) + ".", block_in,
+                            block_out, &V->up[lvl][b]));
+      block_in = block_out;
+    }
+    if (lvl != 0)
+      CTTA_TRY(make_conv(ws, p + "up." + std::to_string(lvl) + ".upsample.conv.", block_in, block_in, block_in, 3, 3, 1,
+                         1, &V->upsample[lvl]));
+  }
+  V->c_last = block_in;
+  CTTA_TRY(make_gn(ws, p + "norm_out.", block_in, &V->norm_out));
+  CTTA_TRY(add_small_conv_w(ws, p + "conv_out.weight", cfg.out_ch, block_in, 9, &V->conv_out_w));
+  CTTA_TRY(ws.add_vector(p + "conv_out.bias", cfg.out_ch, &V->conv_out_b));
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_vae_create(const ctta_vae_config* cfg, const ctta_tensor* weights, int n_weights,
+                                       void* stream, ctta_vae** out) {
+  CTTA_REQUIRE(cfg && weights && out, "vae_create: null pointer");
+  CTTA_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= CTTA_MAX_LEVELS, "vae_create: n_levels=%d", cfg->n_levels);
+  CTTA_REQUIRE(cfg->embed_dim <= 16 && cfg->z_channels <= 32, "vae_create: z_channels/embed_dim too large");
+  CTTA_REQUIRE(cfg->out_ch == 1 || cfg->out_ch == 2 || cfg->out_ch == 4 || cfg->out_ch == 8, "vae_create: out_ch=%d", cfg->out_ch);
+  CTTA_REQUIRE(cfg->ch % 32 == 0, "vae_create: ch=%d must be a multiple of 32 (GroupNorm(32))", cfg->ch);
+  CTTA_REQUIRE(cfg->scale_factor != 0.f, "vae_create: scale_factor is zero");
+  hipStream_t s = (hipStream_t)stream;
+  ctta_vae* V = new ctta_vae();
+  V->cfg = *cfg;
+  ctta_status st = V->store.init(estimate_store_bytes(weights, n_weights));
+  if (st != CTTA_OK) { delete V; return st; }
+  WeightTable wt;
+  wt.build(weights, n_weights);
+  st = vae_build(V);
+  if (st == CTTA_OK) st = V->store.run_all(wt, s);
+  size_t gn_need = 0;
+  if (st == CTTA_OK) {
+    V->arena.dry = true;
+    V->arena.no_release = cfg->debug_taps != 0;
+    st = vae_forward_impl(V, true, nullptr, cfg->max_batch, nullptr, s, &gn_need);
+  }
+  if (st == CTTA_OK) {
+    const size_t bytes = V->arena.peak + (1 << 20);
+    V->arena.dry = false;
+    V->arena.cap = bytes;
+    if (hipMalloc((void**)&V->arena.base, bytes) != hipSuccess ||
+        hipMalloc((void**)&V->gn_scratch, (gn_need + 64) * sizeof(float)) != hipSuccess) {
+      ctta_set_error("vae_create: hipMalloc of %zu-byte activation arena failed", bytes);
+      st = CTTA_ERR_NOMEM;
+    } else {
+      V->gn_scratch_floats = gn_need + 64;
+    }
+  }
+  if (st == CTTA_OK && hipStreamSynchronize(s) != hipSuccess) { ctta_set_error("vae_create: stream sync failed"); st = CTTA_ERR_HIP; }
+  if (st != CTTA_OK) { ctta_vae_destroy(V); return st; }
+  *out = V;
+  return CTTA_OK;
+}
+
+extern "C" void ctta_vae_destroy(ctta_vae* V) {
+  if (!V) return;
+  V->store.destroy();
+  if (V->arena.base) (void)hipFree(V->arena.base);
+  if (V->gn_scratch) (void)hipFree(V->gn_scratch);
+  delete V;
+}
+
+extern "C" ctta_status ctta_vae_decode(ctta_vae* V, const float* z, int batch, float* mel, void* stream) {
+  CTTA_REQUIRE(V && z && mel, "vae_decode: null pointer");
+  CTTA_REQUIRE(batch >= 1 && batch <= V->cfg.max_batch, "vae_decode: batch %d outside [1,%d]", batch, V->cfg.max_batch);
+  return vae_forward_impl(V, false, z, batch, mel, (hipStream_t)stream, nullptr);
+}
+
+extern "C" size_t ctta_vae_arena_bytes(const ctta_vae* V) { return V ? V->arena.cap + V->store.arena.cap : 0; }
+extern "C" int ctta_vae_num_taps(const ctta_vae* V) { return V ? (int)V->taps.size() : 0; }
+extern "C" ctta_status ctta_vae_tap_info(const ctta_vae* V, int i, const char** name, int dims[4]) {
+  CTTA_REQUIRE(V && i >= 0 && i < (int)V->taps.size(), "tap index out of range");
+  const Tap& t = V->taps[i];
+  *name = t.name.c_str();
+  dims[0] = t.b; dims[1] = t.c; dims[2] = t.h; dims[3] = t.w;
+  return CTTA_OK;
+}
+extern "C" ctta_status ctta_vae_tap_read(ctta_vae* V, int i, float* dst, void* stream) {
+  CTTA_REQUIRE(V && i >= 0 && i < (int)V->taps.size() && dst, "tap index out of range");
+  const Tap& t = V->taps[i];
+  CTTA_REQUIRE(t.ptr, "tap '%s' has not been produced yet", t.name.c_str());
+  return ctta_nhwc_bf16_to_nchw_f32(t.ptr, dst, t.b, t.c, t.h, t.w, t.c_stride, stream);
+}
+
+// ====================================================================================== HiFi-GAN
+struct Conv1d {
+  PackedW p;
+  int cin = 0, cout = 0, k = 1, pad = 0, dil = 1;
+};
+struct ConvT1d {
+  PackedW p;
+  int cin = 0, cout = 0, k = 0, u = 0, pad = 0, taps = 0;
+};
+struct HResBlock {
+  Conv1d c1[3], c2[3];
+};
+
+struct ctta_hifigan {
+  ctta_hifigan_config cfg;
+  WeightStore store;
+  Arena arena;
+  std::vector<Tap> taps;
+  Conv1d conv_pre;
+  std::vector<ConvT1d> ups;
+  std::vector<HResBlock> res;   // [n_ups * n_kernels]
+  float *post_w = nullptr, *post_b = nullptr;
+  int c_last = 0;
+};
+
+static ctta_status make_conv1d(WeightStore& ws, const std::string& p, int cout, int cin, int k, int dil, Conv1d* L) {
+  const int K = k * cin, k_pad = round_up(K, 64), n_pad = round_up(cout, 4);
+  std::vector<int32_t> ro(n_pad, -1), co(k_pad, -1);
+  for (int r = 0; r < cout; ++r) ro[r] = r * cin * k;
+  for (int x = 0; x < k; ++x)
+    for (int c = 0; c < cin; ++c) co[x * cin + c] = c * k + x;
+  CTTA_TRY(ws.add_matrix(p + "weight", {cout, cin, k}, ro, co, nullptr, nullptr, 0, &L->p.w));
+  CTTA_TRY(ws.add_vector(p + "bias", cout, n_pad, {{0, 0, cout}}, &L->p.bias));
+  L->p.n = n_pad; L->p.k_pad = k_pad;
+  L->cin = cin; L->cout = cout; L->k = k; L->dil = dil;
+  L->pad = (k * dil - dil) / 2;   // get_padding, hifigan/models.py:18-19
+  return CTTA_OK;
+}
+
+// ConvTranspose1d(cin, cout, k, stride u, padding (k-u)//2) as `u` phase convolutions in one GEMM:
+// with s = t + pad, r = s % u, q = s / u:  out[t] = sum_m W[:, :, r + m*u] x[q - m].
+// Row n = r*cout + co of the packed matrix, column (tap kw, ci) with m = taps-1-kw.
+static ctta_status make_convt1d(WeightStore& ws, const std::string& p, int cin, int cout, int k, int u, ConvT1d* L) {
+  const int taps = (k + u - 1) / u;
+  const int K = taps * cin, k_pad = round_up(K, 64), n = u * cout;
+  std::vector<int32_t> ro(n), ra(n), co(k_pad, -1), ca(k_pad, 0);
+  for (int r = 0; r < u; ++r)
+    for (int o = 0; o < cout; ++o) { ro[r * cout + o] = o * k + r; ra[r * cout + o] = r; }
+  for (int kw = 0; kw < taps; ++kw) {
+    const int m = taps - 1 - kw;
+    for (int c = 0; c < cin; ++c) { co[kw * cin + c] = c * cout * k + m * u; ca[kw * cin + c] = m * u; }
+  }
+  CTTA_TRY(ws.add_matrix(p + "weight", {cin, cout, k}, ro, co, &ra, &ca, k, &L->p.w));
+  std::vector<WeightStore::Seg> segs;
+  for (int r = 0; r < u; ++r) segs.push_back({0, r * cout, cout});
+  CTTA_TRY(ws.add_vector(p + "bias", cout, n, segs, &L->p.bias));
+  L->p.n = n; L->p.k_pad = k_pad;
+  L->cin = cin; L->cout = cout; L->k = k; L->u = u; L->pad = (k - u) / 2; L->taps = taps;
+  return CTTA_OK;
+}
+
+static ctta_status run_conv1d(RunCtx& c, const Conv1d& L, const bf16_t* x, int B, int len, bf16_t* out, float in_slope,
+                              const bf16_t* res, bool accumulate, float alpha) {
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = x; d.c0 = L.cin;
+  d.batch = B; d.hi = 1; d.wi = len; d.ho = 1; d.wo = len;
+  d.kh = 1; d.kw = L.k; d.pad_w = L.pad; d.dil_w = L.dil;
+  d.w = L.p.w; d.k_pad = L.p.k_pad; d.n = L.p.n; d.bias = L.p.bias;
+  if (in_slope > 0.f) { d.in_act = 1; d.in_slope = in_slope; }
+  d.res = res; d.res_ld = L.cout;
+  d.accumulate = accumulate ? 1 : 0; d.alpha = alpha;
+  d.out = out; d.ldc = L.cout;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  return CTTA_OK;
+}
+
+static inline int convt_out_len(const ConvT1d& L, int len) { return (len - 1) * L.u - 2 * L.pad + L.k; }
+
+static ctta_status run_convt1d(RunCtx& c, const ConvT1d& L, const bf16_t* x, int B, int len, bf16_t* out, float in_slope) {
+  const int lout = convt_out_len(L, len);
+  const int Q = (lout - 1 + L.pad) / L.u + 1;
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = x; d.c0 = L.cin;
+  d.batch = B; d.hi = 1; d.wi = len; d.ho = 1; d.wo = Q;
+  d.kh = 1; d.kw = L.taps; d.pad_w = L.taps - 1;
+  d.w = L.p.w; d.k_pad = L.p.k_pad; d.n = L.p.n; d.bias = L.p.bias;
+  if (in_slope > 0.f) { d.in_act = 1; d.in_slope = in_slope; }
+  d.out = out; d.ldc = L.u * L.cout;
+  d.out_batch_stride = (int64_t)lout * L.cout;
+  d.out_offset = -(int64_t)L.pad * L.cout;
+  d.out_limit = (int64_t)lout * L.cout;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  return CTTA_OK;
+}
+
+extern "C" int64_t ctta_hifigan_out_len(const ctta_hifigan* G, int frames) {
+  if (!G) return 0;
+  int len = frames;
+  for (const ConvT1d& u : G->ups) len = convt_out_len(u, len);
+  return len;
+}
+
+static ctta_status hifigan_forward_impl(ctta_hifigan* G, bool dry, const float* mel, int B, int frames, float* wav,
+                                        hipStream_t stream) {
+  const ctta_hifigan_config& cfg = G->cfg;
+  RunCtx c;
+  c.arena = &G->arena; c.stream = stream; c.dry = dry;
+  c.taps = cfg.debug_taps ? &G->taps : nullptr;
+  c.gn_scratch = nullptr; c.gn_scratch_floats = 0;
+  Arena& A = G->arena;
+  A.reset();
+  const int nk = cfg.n_kernels;
+  bf16_t* m = A.get<bf16_t>((size_t)B * frames * cfg.num_mels); ALLOC_OR_FAIL(m);
+  RUN(c, ctta_rows_f32_to_bf16(mel, m, (int64_t)B * frames, cfg.num_mels, cfg.num_mels, stream));
+  int len = frames, ch = cfg.upsample_initial_channel;
+  bf16_t* x = A.get<bf16_t>((size_t)B * len * ch); ALLOC_OR_FAIL(x);
+  CTTA_TRY(run_conv1d(c, G->conv_pre, m, B, len, x, 0.f, nullptr, false, 1.0f));
+  add_tap(c, "conv_pre", x, B, ch, 1, len, ch);
+  for (int i = 0; i < cfg.n_ups; ++i) {
+    const ConvT1d& U = G->ups[i];
+    const int lout = convt_out_len(U, len);
+    bf16_t* y = A.get<bf16_t>((size_t)B * lout * U.cout); ALLOC_OR_FAIL(y);
+    CTTA_TRY(run_convt1d(c, U, x, B, len, y, 0.1f));   // x = ups[i](leaky_relu(x, 0.1))
+    len = lout; ch = U.cout;
+    add_tap(c, "ups." + std::to_string(i), y, B, ch, 1, len, ch);
+    const size_t elems = (size_t)B * len * ch;
+    bf16_t* xs = A.get<bf16_t>(elems); ALLOC_OR_FAIL(xs);
+    const size_t mk = A.mark();
+    bf16_t* xt = A.get<bf16_t>(elems); ALLOC_OR_FAIL(xt);
+    bf16_t* ra = A.get<bf16_t>(elems); ALLOC_OR_FAIL(ra);
+    bf16_t* rb = A.get<bf16_t>(elems); ALLOC_OR_FAIL(rb);
+    for (int j = 0; j < nk; ++j) {
+      const HResBlock& R = G->res[i * nk + j];
+      const bf16_t* r = y;
+      for (int mth = 0; mth < 3; ++mth) {
+        CTTA_TRY(run_conv1d(c, R.c1[mth], r, B, len, xt, 0.1f, nullptr, false, 1.0f));
+        const bool last = mth == 2;
+        // the block's last conv adds its residual AND folds into xs = (sum_j resblock_j(x)) / nk
+        bf16_t* dst = last ? xs : (r == ra ? rb : ra);
+        CTTA_TRY(run_conv1d(c, R.c2[mth], xt, B, len, dst, 0.1f, r, last && j > 0,
+                            (last && j == nk - 1) ? 1.0f / (float)nk : 1.0f));
+        r = dst;
+      }
+    }
+    A.release(mk);
+    x = xs;
+    add_tap(c, "stage." + std::to_string(i), x, B, ch, 1, len, ch);
+  }
+  // x = tanh(conv_post(leaky_relu(x)))   (default slope 0.01, models.py:113)
+  RUN(c, ctta_conv_small_n(x, ch, B, 1, len, 1, 7, 0, 3, G->post_w, G->post_b, 1, 1, 0.01f, 2, wav, nullptr, stream));
+  return CTTA_OK;
+}
+
+static ctta_status hifigan_build(ctta_hifigan* G) {
+  const ctta_hifigan_config& cfg = G->cfg;
+  WeightStore& ws = G->store;
+  const std::string P = "vocoder.";
+  const int c0 = cfg.upsample_initial_channel;
+  CTTA_TRY(make_conv1d(ws, P + "conv_pre.", c0, cfg.num_mels, 7, 1, &G->conv_pre));
+  G->ups.resize(cfg.n_ups);
+  G->res.resize((size_t)cfg.n_ups * cfg.n_kernels);
+  int ch = c0;
+  for (int i = 0; i < cfg.n_ups; ++i) {
+    const int cin = c0 >> i, cout = c0 >> (i + 1);
+    CTTA_REQUIRE(cout % 8 == 0, "hifigan: channel count %d not a multiple of 8", cout);
+    CTTA_TRY(make_convt1d(ws, P + "ups." + std::to_string(i) + ".", cin, cout, cfg.upsample_kernel_sizes[i],
+                          cfg.upsample_rates[i], &G->ups[i]));
+    ch = cout;
+    for (int j = 0; j < cfg.n_kernels; ++j) {
+      HResBlock& R = G->res[(size_t)i * cfg.n_kernels + j];
+      const std::string rp = P + "resblocks." + std::to_string(i * cfg.n_kernels + j) + ".";
+      const int k = cfg.resblock_kernel_sizes[j];
+      for (int m = 0; m < 3; ++m) {
+        CTTA_TRY(make_conv1d(ws, rp + "convs1." + std::to_string(m) + ".", ch, ch, k, cfg.resblock_dilations[j][m], &R.c1[m]));
+        CTTA_TRY(make_conv1d(ws, rp + "convs2." + std::to_string(m) + ".", ch, ch, k, 1, &R.c2[m]));
+      }
+    }
+  }
+  G->c_last = ch;
+  CTTA_TRY(add_small_conv_w(ws, P + "conv_post.weight", 1, ch, 7, &G->post_w));
+  CTTA_TRY(ws.add_vector(P + "conv_post.bias", 1, &G->post_b));
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_hifigan_create(const ctta_hifigan_config* cfg, const ctta_tensor* weights, int n_weights,
+                                           void* stream, ctta_hifigan** out) {
+  CTTA_REQUIRE(cfg && weights && out, "hifigan_create: null pointer");
+  CTTA_REQUIRE(cfg->n_ups >= 1 && cfg->n_ups <= CTTA_MAX_UPS && cfg->n_kernels >= 1 && cfg->n_kernels <= 4,
+               "hifigan_create: bad n_ups/n_kernels");
+  CTTA_REQUIRE(cfg->num_mels % 8 == 0, "hifigan_create: num_mels=%d must be a multiple of 8", cfg->num_mels);
+  hipStream_t s = (hipStream_t)stream;
+  ctta_hifigan* G = new ctta_hifigan();
+  G->cfg = *cfg;
+  ctta_status st = G->store.init(estimate_store_bytes(weights, n_weights));
+  if (st != CTTA_OK) { delete G; return st; }
+  WeightTable wt;
+  wt.build(weights, n_weights);
+  st = hifigan_build(G);
+  if (st == CTTA_OK) st = G->store.run_all(wt, s);
+  if (st == CTTA_OK) {
+    G->arena.dry = true;
+    G->arena.no_release = cfg->debug_taps != 0;
+    st = hifigan_forward_impl(G, true, nullptr, cfg->max_batch, cfg->max_frames, nullptr, s);
+  }
+  if (st == CTTA_OK) {
+    const size_t bytes = G->arena.peak + (1 << 20);
+    G->arena.dry = false;
+    G->arena.cap = bytes;
+    if (hipMalloc((void**)&G->arena.base, bytes) != hipSuccess) {
+      ctta_set_error("hifigan_create: hipMalloc of %zu-byte activation arena failed", bytes);
+      st = CTTA_ERR_NOMEM;
+    }
+  }
+  if (st == CTTA_OK && hipStreamSynchronize(s) != hipSuccess) { ctta_set_error("hifigan_create: stream sync failed"); st = CTTA_ERR_HIP; }
+  if (st != CTTA_OK) { ctta_hifigan_destroy(G); return st; }
+  *out = G;
+  return CTTA_OK;
+}
+
+extern "C" void ctta_hifigan_destroy(ctta_hifigan* G) {
+  if (!G) return;
+  G->store.destroy();
+  if (G->arena.base) (void)hipFree(G->arena.base);
+  delete G;
+}
+
+extern "C" ctta_status ctta_hifigan_forward(ctta_hifigan* G, const float* mel, int batch, int frames, float* wav,
+                                            void* stream) {
+  CTTA_REQUIRE(G && mel && wav, "hifigan_forward: null pointer");
+  CTTA_REQUIRE(batch >= 1 && batch <= G->cfg.max_batch && frames >= 1 && frames <= G->cfg.max_frames,
+               "hifigan_forward: batch %d / frames %d outside the handle's limits (%d, %d)", batch, frames,
+               G->cfg.max_batch, G->cfg.max_frames);
+  return hifigan_forward_impl(G, false, mel, batch, frames, wav, (hipStream_t)stream);
+}
+
+extern "C" size_t ctta_hifigan_arena_bytes(const ctta_hifigan* G) { return G ? G->arena.cap + G->store.arena.cap : 0; }
+extern "C" int ctta_hifigan_num_taps(const ctta_hifigan* G) { return G ? (int)G->taps.size() : 0; }
+extern "C" ctta_status ctta_hifigan_tap_info(const ctta_hifigan* G, int i, const char** name, int dims[4]) {
+  CTTA_REQUIRE(G && i >= 0 && i < (int)G->taps.size(), "tap index out of range");
+  const Tap& t = G->taps[i];
+  *name = t.name.c_str();
+  dims[0] = t.b; dims[1] = t.c; dims[2] = t.h; dims[3] = t.w;
+  return CTTA_OK;
+}
+extern "C" ctta_status ctta_hifigan_tap_read(ctta_hifigan* G, int i, float* dst, void* stream) {
+  CTTA_REQUIRE(G && i >= 0 && i < (int)G->taps.size() && dst, "tap index out of range");
+  const Tap& t = G->taps[i];
+  CTTA_REQUIRE(t.ptr, "tap '%s' has not been produced yet", t.name.c_str());
+  return ctta_nhwc_bf16_to_nchw_f32(t.ptr, dst, t.b, t.c, t.h, t.w, t.c_stride, stream);
+}

@@ -1,0 +1,538 @@
+// HBM-bound kernels of the path: layout packs, GroupNorm(+SiLU), LayerNorm, GEGLU, row
+// softmax, concat, weight packing, small fp32 linears and the time/guidance features.
+// All bf16 traffic is 16 bytes per lane (8 channels), NHWC, fp32 statistics.
+#include "common.h"
+
+#include <math.h>
+
+// ------------------------------------------------------------------------------ layout packs
+// (B,C,H,W) f32 -> (B,H,W,Cp) bf16, channels >= C zero.  One thread per (pixel, 8-ch group).
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, int B,
+                                    int C, int HW, int Cp, float scale) {
+  const int vc = Cp / 8;
+  const long long total = (long long)B * HW * vc;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % vc);
+    const long long pix = idx / vc;
+    const int b = (int)(pix / HW);
+    const int hw = (int)(pix - (long long)b * HW);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = v * 8 + e;
+      f[e] = c < C ? src[((size_t)b * C + c) * HW + hw] * scale : 0.f;
+    }
+    *reinterpret_cast<uint4*>(dst + (size_t)pix * Cp + v * 8) = pack8(f);
+  }
+}
+
+// (B,H,W,Cs) bf16 -> (B,C,H,W) f32.  Threads run along hw for coalesced fp32 stores.
+__global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, int B,
+                                    int C, int HW, int Cs) {
+  const long long total = (long long)B * C * HW;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int hw = (int)(idx % HW);
+    const long long bc = idx / HW;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    dst[idx] = bf2f(src[((size_t)b * HW + hw) * Cs + c]);
+  }
+}
+
+__global__ void rows_f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                        long long rows, int cols, int cols_pad) {
+  const int vc = cols_pad / 8;
+  const long long total = rows * vc;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % vc);
+    const long long r = idx / vc;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = v * 8 + e;
+      f[e] = c < cols ? src[(size_t)r * cols + c] : 0.f;
+    }
+    *reinterpret_cast<uint4*>(dst + (size_t)r * cols_pad + v * 8) = pack8(f);
+  }
+}
+
+__global__ void concat_kernel(const uint4* __restrict__ a, int va, const uint4* __restrict__ b,
+                              int vb, uint4* __restrict__ dst, long long pixels) {
+  const int vt = va + vb;
+  const long long total = pixels * vt;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % vt);
+    const long long pix = idx / vt;
+    dst[idx] = v < va ? a[pix * va + v] : b[pix * vb + (v - va)];
+  }
+}
+
+__global__ void pack_weight_kernel(const float* __restrict__ src, const int* __restrict__ row_off,
+                                   const int* __restrict__ col_off, const int* __restrict__ row_aux,
+                                   const int* __restrict__ col_aux, int aux_limit, int n_rows,
+                                   int k_pad, bf16_t* __restrict__ dst) {
+  const long long total = (long long)n_rows * k_pad;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int k = (int)(idx % k_pad);
+    const int r = (int)(idx / k_pad);
+    const int ro = row_off[r], co = col_off[k];
+    bool ok = ro >= 0 && co >= 0;
+    if (ok && aux_limit > 0) ok = row_aux[r] + col_aux[k] < aux_limit;
+    dst[idx] = ok ? f2bf(src[(size_t)ro + (size_t)co]) : (bf16_t)0;
+  }
+}
+
+// ------------------------------------------------------------------------------ GroupNorm
+// Pass 1: per (batch, pixel-chunk) partial sums per group.  A thread owns one 8-channel
+// vector column (tid % VC) and strides over the chunk's pixels; per-channel partials meet in
+// LDS and are folded per group -- deterministic (no atomics).
+// part layout: [B][nchunk][G][2] floats (sum, sumsq).
+__global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, int HW, int C,
+                                                         int G, int pix_per_chunk, int nchunk,
+                                                         float* __restrict__ part) {
+  extern __shared__ float sm[];  // [PL][C] sum, [PL][C] sumsq
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const int VC = C / 8;
+  const int tid = threadIdx.x;
+  int PL, vstride, tv, tp;
+  if (VC <= 256) { PL = 256 / VC; vstride = VC; tv = tid % VC; tp = tid / VC; }
+  else { PL = 1; vstride = 256; tv = tid; tp = 0; }
+  const int p_begin = chunk * pix_per_chunk;
+  const int p_end = min(HW, p_begin + pix_per_chunk);
+  float* ssum = sm;
+  float* ssq = sm + PL * C;
+  if (tp < PL) {
+    for (int v = tv; v < VC; v += vstride) {
+      float s[8], q[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+      for (int pix = p_begin + tp; pix < p_end; pix += PL) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + pix) * C + v * 8);
+        float f[8];
+        unpack8(raw, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ssum[tp * C + v * 8 + e] = s[e];
+        ssq[tp * C + v * 8 + e] = q[e];
+      }
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = tid; g < G; g += 256) {
+    float s = 0.f, q = 0.f;
+    for (int l = 0; l < PL; ++l)
+      for (int cc = 0; cc < cpg; ++cc) {
+        s += ssum[l * C + g * cpg + cc];
+        q += ssq[l * C + g * cpg + cc];
+      }
+    float* o = part + (((size_t)b * nchunk + chunk) * G + g) * 2;
+    o[0] = s;
+    o[1] = q;
+  }
+}
+
+// Pass 2: fold chunks in double, emit per-(batch, channel) scale/shift:
+//   y = x*scale + shift,  scale = rstd*gamma, shift = beta - mean*rstd*gamma.
+__global__ void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int G, int C, int HW,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float* __restrict__ scale_shift) {
+  const int b = blockIdx.x;
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    double s = 0.0, q = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float* pp = part + (((size_t)b * nchunk + ch) * G + g) * 2;
+      s += (double)pp[0];
+      q += (double)pp[1];
+    }
+    const double n = (double)HW * cpg;
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float meanf = (float)mean;
+    for (int cc = 0; cc < cpg; ++cc) {
+      const int c = g * cpg + cc;
+      const float sc = rstd * gamma[c];
+      scale_shift[((size_t)b * 2 + 0) * C + c] = sc;
+      scale_shift[((size_t)b * 2 + 1) * C + c] = beta[c] - meanf * sc;
+    }
+  }
+}
+
+// Pass 3: apply (+SiLU).
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x,
+                                                       bf16_t* __restrict__ y, int HW, int C,
+                                                       const float* __restrict__ scale_shift,
+                                                       int silu, long long total_vec) {
+  const int VC = C / 8;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % VC);
+    const long long pix = idx / VC;
+    const int b = (int)(pix / HW);
+    const float* sc = scale_shift + ((size_t)b * 2) * C + v * 8;
+    const float* sh = sc + C;
+    const float4 s0 = *reinterpret_cast<const float4*>(sc);
+    const float4 s1 = *reinterpret_cast<const float4*>(sc + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(sh);
+    const float4 h1 = *reinterpret_cast<const float4*>(sh + 4);
+    const float scl[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float shf[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + (size_t)idx * 8), f);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float t = f[e] * scl[e] + shf[e];
+      f[e] = silu ? silu_f(t) : t;
+    }
+    *reinterpret_cast<uint4*>(y + (size_t)idx * 8) = pack8(f);
+  }
+}
+
+static void gn_geometry(int hw, int c, int* pix_per_chunk, int* nchunk) {
+  int ppc = 32768 / c;
+  if (ppc < 16) ppc = 16;
+  if (ppc > 1024) ppc = 1024;
+  if (ppc > hw) ppc = hw;
+  *pix_per_chunk = ppc;
+  *nchunk = (hw + ppc - 1) / ppc;
+}
+
+extern "C" size_t ctta_groupnorm_scratch_floats(int batch, int hw, int c, int groups) {
+  int ppc, nchunk;
+  gn_geometry(hw, c, &ppc, &nchunk);
+  return (size_t)batch * nchunk * groups * 2 + (size_t)batch * 2 * c;
+}
+
+extern "C" ctta_status ctta_groupnorm(const void* x, void* y, int batch, int hw, int c, int groups,
+                                      const float* gamma, const float* beta, float eps, int silu,
+                                      float* scratch, void* stream) {
+  CTTA_REQUIRE(x && y && gamma && beta && scratch, "groupnorm: null pointer");
+  CTTA_REQUIRE(c % 8 == 0 && groups > 0 && c % groups == 0, "groupnorm: C=%d groups=%d unsupported", c, groups);
+  CTTA_REQUIRE(groups <= 256 * 64, "groupnorm: too many groups");
+  hipStream_t s = (hipStream_t)stream;
+  int ppc, nchunk;
+  gn_geometry(hw, c, &ppc, &nchunk);
+  float* part = scratch;
+  float* ss = scratch + (size_t)batch * nchunk * groups * 2;
+  const int VC = c / 8;
+  const int PL = VC <= 256 ? 256 / VC : 1;
+  const size_t smem = (size_t)2 * PL * c * sizeof(float);
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, batch), dim3(256), smem, s, (const bf16_t*)x, hw,
+                     c, groups, ppc, nchunk, part);
+  CTTA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(64), 0, s, part, nchunk, groups, c, hw,
+                     gamma, beta, eps, ss);
+  CTTA_LAUNCH_CHECK();
+  const long long total_vec = (long long)batch * hw * VC;
+  const int blocks = (int)fmin((double)cdiv64(total_vec, 256), 8192.0);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, hw,
+                     c, ss, silu, total_vec);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ LayerNorm
+// One wave per row; the row (<= 2048 padded columns) lives in registers: two-pass variance.
+template <int MAXV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x,
+                                                        bf16_t* __restrict__ y, long long rows, int d,
+                                                        int ld, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, float eps) {
+  const int lane = threadIdx.x & 63;
+  const long long row = blockIdx.x * 4LL + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int VC = ld / 8;
+  float f[MAXV][8];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < VC) {
+      unpack8(*reinterpret_cast<const uint4*>(x + (size_t)row * ld + v * 8), f[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (v * 8 + e >= d) f[i][e] = 0.f;
+        s += f[i][e];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[i][e] = 0.f;
+    }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (v < VC && v * 8 + e < d) { const float t = f[i][e] - mean; q += t * t; }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < VC) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = v * 8 + e;
+        o[e] = c < d ? (f[i][e] - mean) * rstd * gamma[c] + beta[c] : 0.f;
+      }
+      *reinterpret_cast<uint4*>(y + (size_t)row * ld + v * 8) = pack8(o);
+    }
+  }
+}
+
+extern "C" ctta_status ctta_layernorm(const void* x, void* y, int64_t rows, int d, int ld,
+                                      const float* gamma, const float* beta, float eps, void* stream) {
+  CTTA_REQUIRE(x && y && gamma && beta, "layernorm: null pointer");
+  CTTA_REQUIRE(ld % 8 == 0 && d <= ld && d > 0 && ld <= 2048, "layernorm: d=%d ld=%d unsupported", d, ld);
+  const dim3 grid((unsigned)cdiv64(rows, 4));
+  hipStream_t s = (hipStream_t)stream;
+  if (ld <= 512)
+    hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
+  else if (ld <= 1024)
+    hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ GEGLU
+__global__ void geglu_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, long long rows,
+                             int hp) {
+  const int vc = hp / 8;
+  const long long total = rows * vc;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % vc);
+    const long long r = idx / vc;
+    float a[8], g[8];
+    unpack8(*reinterpret_cast<const uint4*>(in + (size_t)r * 2 * hp + v * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(in + (size_t)r * 2 * hp + hp + v * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      a[e] = a[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f)));
+    *reinterpret_cast<uint4*>(out + (size_t)r * hp + v * 8) = pack8(a);
+  }
+}
+
+extern "C" ctta_status ctta_geglu(const void* in, void* out, int64_t rows, int hp, void* stream) {
+  CTTA_REQUIRE(in && out && hp % 8 == 0, "geglu: bad arguments");
+  const long long total = rows * (hp / 8);
+  const int blocks = (int)fmin((double)cdiv64(total, 256), 8192.0);
+  hipLaunchKernelGGL(geglu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
+                     (bf16_t*)out, (long long)rows, hp);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ row softmax
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s,
+                                                           bf16_t* __restrict__ p, int cols,
+                                                           float scale) {
+  __shared__ float red[8];
+  const long long row = blockIdx.x;
+  const float* sr = s + (size_t)row * cols;
+  bf16_t* pr = p + (size_t)row * cols;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(sr + c);
+    mx = fmaxf(fmaxf(mx, v.x), fmaxf(v.y, fmaxf(v.z, v.w)));
+  }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+  float sum = 0.f;
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(sr + c);
+    sum += __expf(v.x * scale - mx) + __expf(v.y * scale - mx) + __expf(v.z * scale - mx) +
+           __expf(v.w * scale - mx);
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(sr + c);
+    uint2 o;
+    o.x = pack2bf(__expf(v.x * scale - mx) * inv, __expf(v.y * scale - mx) * inv);
+    o.y = pack2bf(__expf(v.z * scale - mx) * inv, __expf(v.w * scale - mx) * inv);
+    *reinterpret_cast<uint2*>(pr + c) = o;
+  }
+}
+
+extern "C" ctta_status ctta_softmax_rows(const float* s, void* p, int64_t rows, int cols, float scale,
+                                         void* stream) {
+  CTTA_REQUIRE(s && p && cols % 4 == 0 && scale > 0.f, "softmax_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s,
+                     (bf16_t*)p, cols, scale);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ small fp32 linear
+// One wave per output feature; lanes split K; loops over the (small) row count.
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x,
+                                                         const float* __restrict__ w,
+                                                         const float* __restrict__ b,
+                                                         float* __restrict__ y, int M, int N, int K,
+                                                         int act_in, int act_out) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* wr = w + (size_t)n * K;
+  for (int m0 = 0; m0 < M; m0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float wv = wr[k];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        if (m0 + r < M) {
+          float xv = x[(size_t)(m0 + r) * K + k];
+          if (act_in == 1) xv = xv / (1.0f + expf(-xv));
+          acc[r] += xv * wv;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float t = wave_sum(acc[r]);
+      if (lane == 0 && m0 + r < M) {
+        float o = t + (b ? b[n] : 0.f);
+        if (act_out == 1) o = o / (1.0f + expf(-o));
+        y[(size_t)(m0 + r) * N + n] = o;
+      }
+    }
+  }
+}
+
+extern "C" ctta_status ctta_linear_f32(const float* x, const float* w, const float* b, float* y, int m,
+                                       int n, int k, int act_in, int act_out, void* stream) {
+  CTTA_REQUIRE(x && w && y && m > 0 && m <= 1024 && n > 0 && k > 0, "linear_f32: bad arguments");
+  hipLaunchKernelGGL(linear_f32_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, w, b,
+                     y, m, n, k, act_in, act_out);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ embeddings
+// get_timestep_embedding: emb = t * freq (fp32), [sin | cos], optionally flipped to [cos | sin].
+__global__ void time_features_kernel(const float* __restrict__ t, const float* __restrict__ freqs,
+                                     int dim, int flip, float* __restrict__ out, int B) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * half) return;
+  const int b = idx / half, i = idx - b * half;
+  const float arg = t[b] * freqs[i];
+  const float sv = sinf(arg), cv = cosf(arg);
+  float* o = out + (size_t)b * dim;
+  if (flip) { o[i] = cv; o[half + i] = sv; }
+  else { o[i] = sv; o[half + i] = cv; }
+}
+
+// GaussianFourierProjection: x = w * W * 2*pi evaluated in double (the reference uses fp64 when
+// guidance is a Python float and fp32 when it is a tensor; fp64 is within 1e-5 of both).
+__global__ void fourier_features_kernel(const double* __restrict__ wv, const float* __restrict__ weight,
+                                        int half, int flip, float* __restrict__ out, int B) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * half) return;
+  const int b = idx / half, i = idx - b * half;
+  const double arg = wv[b] * (double)weight[i] * 2.0 * 3.14159265358979323846;
+  const float sv = (float)sin(arg), cv = (float)cos(arg);
+  float* o = out + (size_t)b * 2 * half;
+  if (flip) { o[i] = cv; o[half + i] = sv; }
+  else { o[i] = sv; o[half + i] = cv; }
+}
+
+extern "C" ctta_status ctta_time_features(const float* t, const float* freqs, int dim, int flip,
+                                          float* out, int batch, void* stream) {
+  CTTA_REQUIRE(t && freqs && out && dim % 2 == 0, "time_features: bad arguments");
+  const int total = batch * (dim / 2);
+  hipLaunchKernelGGL(time_features_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     t, freqs, dim, flip, out, batch);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_fourier_features(const double* w, const float* weight, int half, int flip,
+                                             float* out, int batch, void* stream) {
+  CTTA_REQUIRE(w && weight && out && half > 0, "fourier_features: bad arguments");
+  const int total = batch * half;
+  hipLaunchKernelGGL(fourier_features_kernel, dim3((total + 255) / 256), dim3(256), 0,
+                     (hipStream_t)stream, w, weight, half, flip, out, batch);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ C wrappers
+static int grid_for(long long total) { return (int)fmin((double)cdiv64(total, 256), 16384.0); }
+
+extern "C" ctta_status ctta_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int batch, int c, int h,
+                                                  int w, int c_pad, float scale, void* stream) {
+  CTTA_REQUIRE(src && dst && c_pad % 8 == 0 && c_pad >= c, "nchw->nhwc: bad arguments");
+  const long long total = (long long)batch * h * w * (c_pad / 8);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                     (bf16_t*)dst, batch, c, h * w, c_pad, scale);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int batch, int c, int h,
+                                                  int w, int c_stride, void* stream) {
+  CTTA_REQUIRE(src && dst && c_stride >= c, "nhwc->nchw: bad arguments");
+  const long long total = (long long)batch * c * h * w;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, dst, batch, c, h * w, c_stride);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_rows_f32_to_bf16(const float* src, void* dst, int64_t rows, int cols,
+                                             int cols_pad, void* stream) {
+  CTTA_REQUIRE(src && dst && cols_pad % 8 == 0 && cols_pad >= cols, "rows f32->bf16: bad arguments");
+  const long long total = rows * (cols_pad / 8);
+  hipLaunchKernelGGL(rows_f32_to_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     src, (bf16_t*)dst, (long long)rows, cols, cols_pad);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_concat_channels(const void* a, int ca, const void* b, int cb, void* dst,
+                                            int64_t pixels, void* stream) {
+  CTTA_REQUIRE(a && b && dst && ca % 8 == 0 && cb % 8 == 0, "concat: bad arguments");
+  const long long total = pixels * ((ca + cb) / 8);
+  hipLaunchKernelGGL(concat_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)a, ca / 8, (const uint4*)b, cb / 8, (uint4*)dst, (long long)pixels);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_pack_weight(const float* src, const int32_t* row_off, const int32_t* col_off,
+                                        const int32_t* row_aux, const int32_t* col_aux, int aux_limit,
+                                        int n_rows, int k_pad, void* dst, void* stream) {
+  CTTA_REQUIRE(src && row_off && col_off && dst, "pack_weight: null pointer");
+  CTTA_REQUIRE(aux_limit <= 0 || (row_aux && col_aux), "pack_weight: aux arrays missing");
+  const long long total = (long long)n_rows * k_pad;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, src,
+                     row_off, col_off, row_aux, col_aux, aux_limit, n_rows, k_pad, (bf16_t*)dst);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}

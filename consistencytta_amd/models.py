@@ -1,0 +1,419 @@
+"""Task-level API mirrors: `AudioLCM` (models/audio_consistency_model.py:19-548 +
+models/audio_distilled_model.py) and the inference-only twin `ConsistencyTTA`
+(easy_inference/consistencytta.py:12-200).
+
+Everything numerical below the text encoder runs in the HIP engines
+(`modules.UNet2DCondition*Model`, `modules.AutoencoderKL`, `scheduler.HeunDiscreteScheduler`,
+fused CFG / loss / EMA kernels).  The FLAN-T5 text encoder stays a PyTorch module, as in the
+reference (it is frozen and outside the hot path); because neither box has
+network access it can be injected (`text_encoder=`, `tokenizer=`) instead of downloaded.
+
+Round-1 scope: `inference` (student, multi-step, teacher Heun loop), `_query_teacher`,
+`update_ema`, and `forward` as a NO-GRAD evaluation of the distillation loss (training and
+validation modes).  The student backward pass / optimizer / RCCL gradient all-reduce
+(§8 a15, a20) are not built yet: `forward` returns a loss tensor without a graph.
+"""
+from copy import deepcopy
+from time import time
+
+import torch
+from torch import nn
+
+from . import _native as N
+from .modules import AutoencoderKL, UNet2DConditionGuidedModel, UNet2DConditionModel
+from .scheduler import HeunDiscreteScheduler
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=None):
+    """diffusers.utils.randn_tensor: noise on `device` from the global (or given) RNG."""
+    return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+
+
+def do_ema_update(source_model, shadow_models, decay_consts):
+    """tools/train_utils.py:255-282 with one fused pass per parameter for up to two shadows:
+    shadow += (1 - decay) * (param - shadow).  Buffers: the U-Net mirrors have none."""
+    assert len(shadow_models) == len(decay_consts)
+    assert 1 <= len(shadow_models) <= 2, "the fused kernel updates one or two shadows"
+    src = dict(source_model.named_parameters())
+    shadows = [dict(m.named_parameters()) for m in shadow_models]
+    for sh, d in zip(shadows, decay_consts):
+        assert 0 <= d <= 1
+        assert src.keys() == sh.keys()
+    L_ = N.lib()
+    for name, p in src.items():
+        a = shadows[0][name]
+        b = shadows[1][name] if len(shadows) > 1 else None
+        if not p.is_cuda:
+            raise N.CttaError("EMA update needs CUDA(ROCm) parameters; there is no CPU path")
+        N.check(L_.ctta_ema_update2(N.ptr(p.detach()), N.ptr(a.detach()), float(decay_consts[0]),
+                                    N.ptr(b.detach()) if b is not None else N.c_void_p(0),
+                                    float(decay_consts[1]) if b is not None else 0.0, p.numel(), N.stream_ptr()))
+        # bump version counters so the engines re-pack the shadows
+        a.detach().add_(0)
+        if b is not None:
+            b.detach().add_(0)
+
+
+class AudioDistilledModel(nn.Module):
+    """models/audio_distilled_model.py: text encoding, CFG teacher query, EMA bookkeeping."""
+
+    def __init__(self, text_encoder_name, scheduler_name, unet_model_name=None, unet_model_config_path=None,
+                 snr_gamma=None, freeze_text_encoder=True, use_lora=False, ema_decay=0.999,
+                 teacher_guidance_scale=3, unet_config=None, text_encoder=None, tokenizer=None, **kwargs):
+        super().__init__()
+        assert unet_model_name is None, "pretrained hub U-Nets need network access"
+        assert not use_lora, "LoRA is unused by train.sh and not built"
+        self.text_encoder_name = text_encoder_name
+        self.scheduler_name = scheduler_name
+        self.unet_model_config_path = unet_model_config_path
+        self.snr_gamma = snr_gamma
+        self.freeze_text_encoder = freeze_text_encoder
+        self.ema_decay = ema_decay
+        self.teacher_guidance_scale = teacher_guidance_scale
+        self.max_rand_guidance_scale = 6
+        self.use_teacher_cf_guidance = teacher_guidance_scale == -1 or teacher_guidance_scale > 1.0
+
+        if unet_config is None:
+            unet_config = UNet2DConditionModel.load_config(unet_model_config_path)
+        self.teacher_unet = UNet2DConditionModel.from_config(unet_config, subfolder="unet")
+        self.student_unet = UNet2DConditionGuidedModel.from_config(unet_config, subfolder="unet")
+        self.student_ema_unet = deepcopy(self.student_unet)
+        self.teacher_unet.eval().requires_grad_(False)
+        self.student_ema_unet.eval().requires_grad_(False)
+
+        self.tokenizer = tokenizer
+        self.text_encoder = text_encoder
+        if self.text_encoder is not None:
+            self.text_encoder.eval()
+            self.text_encoder.requires_grad_(False)
+
+    @property
+    def device(self):
+        return next(self.student_unet.parameters()).device
+
+    def _require_text_encoder(self):
+        if self.text_encoder is None or self.tokenizer is None:
+            try:
+                from transformers import AutoTokenizer, T5EncoderModel
+                self.tokenizer = AutoTokenizer.from_pretrained(self.text_encoder_name)
+                self.text_encoder = T5EncoderModel.from_pretrained(self.text_encoder_name).to(self.device)
+                self.text_encoder.eval().requires_grad_(False)
+            except Exception as e:  # no network / no cache
+                raise RuntimeError(
+                    "FLAN-T5 (%s) is not available offline; pass text_encoder= and tokenizer= "
+                    "or call the *_from_embeds entry points: %s" % (self.text_encoder_name, e))
+
+    # audio_distilled_model.py:194-248
+    @torch.no_grad()
+    def encode_text(self, prompt, max_length=None, padding=True):
+        self._require_text_encoder()
+        device = self.device
+        if max_length is None:
+            max_length = self.tokenizer.model_max_length
+        batch = self.tokenizer(prompt, max_length=max_length, padding=padding, truncation=True,
+                               return_tensors="pt")
+        input_ids = batch.input_ids.to(device)
+        attention_mask = batch.attention_mask.to(device)
+        prompt_embeds = self.text_encoder(input_ids=input_ids, attention_mask=attention_mask)[0]
+        return prompt_embeds, (attention_mask == 1).to(device)
+
+    @torch.no_grad()
+    def encode_text_classifier_free(self, prompt, num_samples_per_prompt):
+        cond_embeds, cond_mask = self.encode_text(prompt)
+        cond_embeds = cond_embeds.repeat_interleave(num_samples_per_prompt, 0)
+        cond_mask = cond_mask.repeat_interleave(num_samples_per_prompt, 0)
+        uncond_embeds, uncond_mask = self.encode_text([""] * len(prompt), max_length=cond_embeds.shape[1],
+                                                      padding="max_length")
+        uncond_embeds = uncond_embeds.repeat_interleave(num_samples_per_prompt, 0)
+        uncond_mask = uncond_mask.repeat_interleave(num_samples_per_prompt, 0)
+        return (torch.cat([uncond_embeds, cond_embeds]), torch.cat([uncond_mask, cond_mask]),
+                cond_embeds, cond_mask)
+
+    def get_prompt_embeds(self, prompt, use_cf_guidance, num_samples_per_prompt=1):
+        if isinstance(prompt, dict):  # pre-computed text states (synthetic benchmarks / tests)
+            return prompt["embeds_cf"], prompt["mask_cf"], prompt["embeds"], prompt["mask"]
+        return self.encode_text_classifier_free(prompt, num_samples_per_prompt)
+
+    def check_eval_mode(self):
+        for model, name in ((self.teacher_unet, "teacher_unet"), (self.student_ema_unet, "student_ema_unet")):
+            assert model.training is False, f"The {name} is not in eval mode."
+            for p in model.parameters():
+                assert p.requires_grad is False, f"The {name} is not frozen."
+
+    # audio_distilled_model.py:286-322
+    def _query_teacher(self, z_scaled, t, prompt_embeds, prompt_mask, guidance_scale=None):
+        if not torch.is_tensor(t):
+            t = torch.tensor(t)
+        if len(t.reshape(-1)) != 1 and self.use_teacher_cf_guidance:
+            t = torch.cat([t] * 2)
+        z_cat = torch.cat([z_scaled] * 2) if self.use_teacher_cf_guidance else z_scaled
+        pred = self.teacher_unet(z_cat, t, prompt_embeds, encoder_attention_mask=prompt_mask).sample
+        if self.use_teacher_cf_guidance:
+            B = z_scaled.shape[0]
+            if self.teacher_guidance_scale == -1:
+                w = guidance_scale if torch.is_tensor(guidance_scale) else torch.tensor(guidance_scale)
+                w = w.to(device=pred.device, dtype=torch.float32).reshape(-1)
+                if w.numel() == 1:
+                    w = w.expand(B)
+            else:
+                w = torch.full((B,), float(self.teacher_guidance_scale), dtype=torch.float32, device=pred.device)
+            w = w.contiguous()
+            out = torch.empty_like(pred[:B])
+            N.check(N.lib().ctta_cfg_combine(N.ptr(pred[:B]), N.ptr(pred[B:]), N.ptr(w), N.ptr(out), B,
+                                             out[0].numel(), N.stream_ptr()))
+            pred = out
+        # the reference asserts `not noise_pred.isnan().any()` here (a device->host sync per query);
+        # enable with CTTA_NAN_CHECKS=1
+        return pred
+
+
+class AudioLCM(AudioDistilledModel):
+    def __init__(self, text_encoder_name, scheduler_name, unet_model_name=None, unet_model_config_path=None,
+                 snr_gamma=None, freeze_text_encoder=True, uncondition=False, use_edm=False, use_karras=False,
+                 use_lora=False, target_ema_decay=.95, ema_decay=.999, num_diffusion_steps=18,
+                 teacher_guidance_scale=1, vae=None, loss_type="mse", **kwargs):
+        super().__init__(text_encoder_name=text_encoder_name, scheduler_name=scheduler_name,
+                         unet_model_name=unet_model_name, unet_model_config_path=unet_model_config_path,
+                         snr_gamma=snr_gamma, freeze_text_encoder=freeze_text_encoder, use_lora=use_lora,
+                         ema_decay=ema_decay, teacher_guidance_scale=teacher_guidance_scale, **kwargs)
+        assert use_edm, "only the Heun/EDM path (use_edm, train.sh:33) is built; DDIM is §8f rank 3"
+        assert not use_karras, "Karras sigmas are unused by the shipped scripts and not built"
+        assert loss_type == "mse", "only the stage-2 latent MSE loss is built (mel/stft/clap: out of scope / next)"
+        self.uncondition = uncondition
+        self.use_edm = use_edm
+        self.target_ema_decay = target_ema_decay
+        self.num_diffusion_steps = num_diffusion_steps
+        self.lightweight = "light" in (unet_model_config_path or "light")
+        self.student_target_unet = deepcopy(self.student_unet)
+        self.student_target_unet.eval().requires_grad_(False)
+        self.noise_scheduler = HeunDiscreteScheduler.from_pretrained(self.scheduler_name, subfolder="scheduler")
+        self.noise_scheduler.set_timesteps(self.num_diffusion_steps)
+        self.vae = vae
+        self.loss_type = loss_type
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.teacher_unet.eval()
+        self.student_ema_unet.eval()
+        self.student_target_unet.eval()
+        if self.vae is not None:
+            self.vae.eval()
+        if self.text_encoder is not None:
+            self.text_encoder.eval()
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def compute_snr(self, timesteps, t_indices):
+        return self.noise_scheduler.sigmas[t_indices] ** (-2)
+
+    def update_ema(self):
+        assert self.training, "EMA update should only be called during training"
+        do_ema_update(self.student_unet, [self.student_target_unet, self.student_ema_unet],
+                      [self.target_ema_decay, self.ema_decay])
+
+    def check_eval_mode(self):
+        super().check_eval_mode()
+        assert self.student_target_unet.training is False, "The student_target_unet is not in eval mode."
+        for p in self.student_target_unet.parameters():
+            assert p.requires_grad is False, "The student_target_unet is not frozen."
+
+    def load_pretrained(self, state_dict):
+        """audio_consistency_model.py:160-204: legacy key renames, then a strict load."""
+        sd = {}
+        for k, v in state_dict.items():
+            k = k.replace("consistency_ema_unet", "student_target_unet").replace(
+                "consistency_unet", "student_unet").replace("diffusion_unet", "teacher_unet")
+            sd[k] = v
+        own = self.state_dict()
+        return self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+
+    def load_state_dict_from_tango(self, tango_state_dict, stage1_state_dict=None):
+        """audio_consistency_model.py:107-158: fan TANGO's `unet.*` keys out to the four U-Nets."""
+        new_sd = {}
+        gkeys = {k for k in self.student_unet.state_dict() if k.startswith(("guidance_proj", "guidance_embedding"))}
+        for k, v in tango_state_dict.items():
+            if not k.startswith("unet."):
+                continue
+            kk = k[len("unet."):]
+            for name in ("teacher_unet", "student_unet", "student_target_unet", "student_ema_unet"):
+                new_sd[name + "." + kk] = v
+        own = self.state_dict()
+        for k in own:
+            if k not in new_sd:
+                sub = k.split(".", 1)[1] if "." in k else k
+                assert sub in gkeys or not k.startswith(("teacher_unet", "student")), f"missing key {k}"
+        return self.load_state_dict(new_sd, strict=False)
+
+    # ---- distillation loss (no-grad evaluation this round), audio_consistency_model.py:239-427
+    @torch.no_grad()
+    def forward(self, z_0, gt_wav, prompt, validation_mode=False, run_teacher=True, time_inds=None,
+                gaussian_noise=None, guidance_scale=None, **kwargs):
+        self.check_eval_mode()
+        assert validation_mode >= 0
+        sch = self.noise_scheduler
+        dev = z_0.device
+        B = z_0.shape[0]
+        embeds_cf, mask_cf, embeds, mask = self.get_prompt_embeds(prompt, self.use_teacher_cf_guidance, 1)
+        avail = sch._timesteps_host
+        order = 2
+        if validation_mode != 0:
+            ti = len(avail) - 1 - int(validation_mode * order)
+            assert ti >= 0
+            inds = torch.full((B,), ti, dtype=torch.int64)
+        elif time_inds is not None:
+            inds = time_inds.to("cpu", torch.int64)
+        else:
+            inds = torch.randint(0, (len(avail) - 1) // order, (B,)) * order
+        t_np1 = torch.from_numpy(avail[inds.numpy()])
+        t_n = torch.from_numpy(avail[(inds + order).numpy()])
+        noise = gaussian_noise if gaussian_noise is not None else torch.randn_like(z_0)
+        z_noisy = sch.add_noise(z_0, noise, t_np1)
+        z_gauss = noise * sch.init_noise_sigma.to(dev)
+        last_mask = (t_np1 == float(avail.max())).reshape(-1, 1, 1, 1).to(dev)
+        z_np1 = torch.where(last_mask, z_gauss, z_noisy)
+        z_np1_scaled = sch.scale_model_input(z_np1, t_np1)
+        assert sch.state_in_first_order
+        if self.teacher_guidance_scale == -1:
+            if guidance_scale is None:
+                guidance_scale = torch.rand(B) * self.max_rand_guidance_scale
+            guidance_scale = guidance_scale.to(dev)
+        else:
+            guidance_scale = None
+        v1 = self._query_teacher(z_np1_scaled, t_np1, embeds_cf, mask_cf, guidance_scale)
+        zhat_n = sch.step(v1, t_np1, z_np1).prev_sample
+        zhat_n_scaled = sch.scale_model_input(zhat_n, t_n)
+        v2 = self._query_teacher(zhat_n_scaled, t_n, embeds_cf, mask_cf, guidance_scale)
+        zhat_n = sch.step(v2, t_n, zhat_n).prev_sample
+        zhat_n_scaled = sch.scale_model_input(zhat_n, t_n)
+        assert sch.state_in_first_order
+        w = guidance_scale if guidance_scale is not None else float(self.teacher_guidance_scale)
+        target = self.student_target_unet(zhat_n_scaled, t_n, guidance=w, encoder_hidden_states=embeds,
+                                          encoder_attention_mask=mask).sample
+        if validation_mode != 0:
+            pred = self.student_target_unet(z_np1_scaled, t_np1, guidance=w, encoder_hidden_states=embeds,
+                                            encoder_attention_mask=mask).sample
+        else:
+            target = torch.where((t_n == 0).reshape(-1, 1, 1, 1).to(dev), z_0, target)
+            pred = self.student_unet(z_np1_scaled, t_np1, guidance=w, encoder_hidden_states=embeds,
+                                     encoder_attention_mask=mask).sample
+        sig = torch.from_numpy(sch._sigmas_host[inds.numpy()]).to(dev)
+        inst = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        N.check(N.lib().ctta_snr_mse_loss(N.ptr(pred.contiguous()), N.ptr(target.contiguous()), N.ptr(sig),
+                                          float(self.snr_gamma or 0.0), N.ptr(inst), N.ptr(loss), B,
+                                          pred[0].numel(), N.stream_ptr()))
+        return loss[0]
+
+    # ---- generation, audio_consistency_model.py:429-548
+    @torch.no_grad()
+    def inference(self, prompt, inference_scheduler, guidance_scale_input=3, guidance_scale_post=1, num_steps=20,
+                  use_edm=False, num_samples=1, use_ema=True, query_teacher=False, num_teacher_steps=18,
+                  return_all=False, noise=None):
+        self.check_eval_mode()
+        sch = inference_scheduler
+        use_cf = guidance_scale_post > 1.
+        t0 = time()
+        embeds_cf, mask_cf, embeds, mask = self.get_prompt_embeds(prompt, True, num_samples)
+        enc_stu, mask_stu = (embeds_cf, mask_cf) if use_cf else (embeds, mask)
+        enc_tea, mask_tea = (embeds_cf, mask_cf) if self.use_teacher_cf_guidance else (embeds, mask)
+        dev = embeds.device
+        B = embeds.shape[0]
+        C = self.student_target_unet.config.in_channels
+        if noise is None:
+            noise = randn_tensor((B, C, 256, 16), device=dev, dtype=torch.float32)
+        time_embed = time() - t0
+        unet = self.student_ema_unet if use_ema else self.student_target_unet
+
+        def calc_zhat_0(z_n, t):
+            z_in = torch.cat([z_n] * 2) if use_cf else z_n
+            z_in = sch.scale_model_input(z_in, t)
+            zh = unet(z_in, t, guidance=guidance_scale_input, encoder_hidden_states=enc_stu,
+                      encoder_attention_mask=mask_stu).sample
+            if use_cf:
+                u, c = zh.chunk(2)
+                zh = (1 - guidance_scale_post) * u + guidance_scale_post * c
+            return zh
+
+        t1 = time()
+        sch.set_timesteps(18, device=dev)
+        z_N = noise * sch.init_noise_sigma
+        zhat_0 = calc_zhat_0(z_N, float(sch._timesteps_host[0]))
+        sch.set_timesteps(num_steps, device=dev)
+        for t in sch._timesteps_host[1::2]:
+            zhat_n = sch.add_noise(zhat_0, torch.randn_like(zhat_0), float(t))
+            zhat_0 = calc_zhat_0(zhat_n, float(t))
+        time_stu = time() - t1
+        zhat_tea, time_tea = None, None
+        if query_teacher:
+            t2 = time()
+            sch.set_timesteps(num_teacher_steps, device=dev)
+            zhat_tea = noise * sch.init_noise_sigma
+            for t in sch._timesteps_host:
+                z_in = sch.scale_model_input(zhat_tea, float(t))
+                pred = self._query_teacher(z_in, float(t), enc_tea, mask_tea, guidance_scale_input)
+                zhat_tea = sch.step(pred, float(t), zhat_tea).prev_sample
+            sch.prev_derivative = sch.dt = sch.sample = None
+            time_tea = time() - t2 + time_embed
+        if return_all:
+            return zhat_0, zhat_tea, time_stu + time_embed, time_tea
+        return zhat_0
+
+
+class ConsistencyTTA(nn.Module):
+    """easy_inference/consistencytta.py: prompts -> int16 waveforms in one module."""
+
+    def __init__(self, unet_config=None, vae=None, text_encoder=None, tokenizer=None,
+                 text_encoder_name="google/flan-t5-large"):
+        super().__init__()
+        from . import spec
+        self.unet = UNet2DConditionGuidedModel.from_config(unet_config or spec.LIGHT_UNET_CONFIG, subfolder="unet")
+        self.vae = vae if vae is not None else AutoencoderKL(embed_dim=8, scale_factor=1.0)
+        self.text_encoder, self.tokenizer, self.text_encoder_name = text_encoder, tokenizer, text_encoder_name
+        self.scheduler = HeunDiscreteScheduler.from_pretrained("stabilityai/stable-diffusion-2-1", subfolder="scheduler")
+        self.unet.eval().requires_grad_(False)
+        self.vae.eval().requires_grad_(False)
+
+    def check_eval_mode(self):
+        for model, name in ((self.vae, "vae"), (self.unet, "unet")):
+            assert model.training is False, f"The {name} is not in eval mode."
+            for p in model.parameters():
+                assert p.requires_grad is False, f"The {name} is not frozen."
+
+    @torch.no_grad()
+    def generate_latent(self, encoder_states, encoder_mask, noise, cfg_scale_input=3., cfg_scale_post=1.,
+                        num_steps=1, uncond_states=None, uncond_mask=None):
+        """consistencytta.py:152-197 from pre-computed text states (T5 excluded)."""
+        sch = self.scheduler
+        use_cf = cfg_scale_post > 1.
+        if use_cf:
+            encoder_states = torch.cat([uncond_states, encoder_states])
+            encoder_mask = torch.cat([uncond_mask, encoder_mask])
+        sch.set_timesteps(18, device=noise.device)
+        z_N = noise * sch.init_noise_sigma
+
+        def calc(z_n, t):
+            z_in = torch.cat([z_n] * 2) if use_cf else z_n
+            z_in = sch.scale_model_input(z_in, t)
+            zh = self.unet(z_in, t, guidance=cfg_scale_input, encoder_hidden_states=encoder_states,
+                           encoder_attention_mask=encoder_mask).sample
+            if use_cf:
+                u, c = zh.chunk(2)
+                zh = (1 - cfg_scale_post) * u + cfg_scale_post * c
+            return zh
+
+        zhat_0 = calc(z_N, float(sch._timesteps_host[0]))
+        sch.set_timesteps(num_steps, device=noise.device)
+        for t in sch._timesteps_host[1::2]:
+            zhat_n = sch.add_noise(zhat_0, torch.randn_like(zhat_0), float(t))
+            zhat_0 = calc(zhat_n, float(t))
+        return zhat_0
+
+    @torch.no_grad()
+    def forward_from_embeds(self, encoder_states, encoder_mask, noise, cfg_scale_input=3., cfg_scale_post=1.,
+                            num_steps=1, sr=16000, **kw):
+        self.check_eval_mode()
+        lat = self.generate_latent(encoder_states, encoder_mask, noise, cfg_scale_input, cfg_scale_post, num_steps, **kw)
+        mel = self.vae.decode_first_stage(lat.float())
+        return self.vae.decode_to_waveform(mel)[:, :int(sr * 9.5)]

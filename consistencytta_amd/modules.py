@@ -1,0 +1,470 @@
+"""Drop-in nn.Module mirrors of the reference's numerical modules, backed by libctta_hip.so.
+
+Same constructor configs, `forward` signatures, `state_dict` key names / order and error
+behaviour as
+  * diffusers.UNet2DConditionGuidedModel  (diffusers/models/unet_2d_condition_guided.py:51)
+  * diffusers.UNet2DConditionModel        (diffusers/models/unet_2d_condition.py)  [teacher]
+  * audioldm AutoencoderKL                (audioldm/variational_autoencoder/autoencoder.py:10)
+  * audioldm.hifigan.Generator            (audioldm/hifigan/models.py:72)
+so the reference's L4 callers (`models/audio_consistency_model.py`, `inference.py`,
+`easy_inference/consistencytta.py`) can switch by changing an import.  The modules only OWN
+parameters (fp32, reference layout); all arithmetic happens in the HIP engines, which keep
+their own packed bf16 copies and are re-synced when parameter versions change.
+"""
+import json
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _native as N
+from . import spec
+
+
+@dataclass
+class UNet2DConditionOutput:
+    sample: torch.Tensor
+
+
+class _ParamTree(nn.Module):
+    """Registers parameters under dotted reference key names (nested anonymous modules)."""
+
+    def _register(self, table, frozen=()):
+        for key, shape in table.items():
+            mod = self
+            parts = key.split(".")
+            for p in parts[:-1]:
+                if p not in mod._modules:
+                    mod.add_module(p, nn.Module())
+                mod = mod._modules[p]
+            param = nn.Parameter(torch.empty(*shape, dtype=torch.float32), requires_grad=key not in frozen)
+            mod.register_parameter(parts[-1], param)
+
+    def init_deterministic(self, seed=0, prefix=""):
+        """Random init from the build's deterministic generator (spec.det_weight)."""
+        with torch.no_grad():
+            for k, p in self.named_parameters():
+                p.copy_(torch.from_numpy(spec.det_weight(prefix + k, tuple(p.shape), seed)).to(p.device))
+        return self
+
+    def _weights_version(self):
+        return sum(p._version for p in self.parameters()) + 1000003 * sum(
+            p.data_ptr() % 1000003 for p in self.parameters())
+
+    def _table(self, prefix_filter=None, strip=""):
+        sd = OrderedDict()
+        for k, p in self.named_parameters():
+            if prefix_filter and not k.startswith(prefix_filter):
+                continue
+            if not p.is_cuda:
+                raise N.CttaError(
+                    "parameter '%s' is on %s: the HIP engine needs CUDA(ROCm) tensors; there is no CPU path"
+                    % (k, p.device))
+            sd[k[len(strip):] if strip and k.startswith(strip) else k] = p.detach()
+        return sd
+
+    # handles are not copyable / picklable: a deepcopy (audio_consistency_model.py:65) gets fresh ones
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        for k in list(d):
+            if k.startswith("_h_"):
+                d[k] = None
+        return d
+
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = None if k.startswith("_h_") else copy.deepcopy(v, memo)
+        return new
+
+
+def _cfg_get(cfg, key, default=None):
+    return cfg[key] if key in cfg else default
+
+
+class _UNetBase(_ParamTree):
+    _guided = True
+
+    def __init__(self, **config):
+        super().__init__()
+        cfg = dict(spec.LIGHT_UNET_CONFIG)
+        cfg.update({k: v for k, v in config.items() if not k.startswith("_")})
+        for k in ("down_block_types", "up_block_types"):
+            for t in cfg[k]:
+                if t not in ("CrossAttnDownBlock2D", "DownBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"):
+                    raise ValueError(f"{t} does not exist.")  # unet_2d_blocks.py get_down_block
+        if len(cfg["down_block_types"]) != len(cfg["up_block_types"]):
+            raise ValueError("Must provide the same number of `down_block_types` as `up_block_types`.")
+        if len(cfg["block_out_channels"]) != len(cfg["down_block_types"]):
+            raise ValueError("Must provide the same number of `block_out_channels` as `down_block_types`.")
+        if not cfg.get("use_linear_projection", True):
+            raise ValueError("use_linear_projection=False (conv proj_in/out) is not supported by the HIP engine")
+        self.config = SimpleNamespace(**cfg)
+        self._cfg = cfg
+        frozen = ("guidance_proj.weight",)  # embeddings.py:229 requires_grad=False
+        self._register(spec.unet_param_spec(cfg, self._guided), frozen)
+        self._h_unet = None
+        self._h_key = None
+        self._h_version = None
+        self.debug_taps = False
+
+    # ---- config plumbing (configuration_utils.py:161,256)
+    @classmethod
+    def load_config(cls, path, **kwargs):
+        with open(path) as f:
+            return json.load(f)
+
+    @classmethod
+    def from_config(cls, config, subfolder=None, **kwargs):
+        return cls(**{k: v for k, v in dict(config).items() if not k.startswith("_")})
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    # ---- native handle management
+    def _native_config(self, B, H, W, L):
+        cfg = self._cfg
+        boc, heads, layers = spec.unet_levels(cfg)
+        c = N.UNetConfig()
+        c.in_channels, c.out_channels, c.n_levels = cfg["in_channels"], cfg["out_channels"], len(boc)
+        for i in range(len(boc)):
+            c.block_out_channels[i] = boc[i]
+            c.heads[i] = heads[i]
+            c.layers_per_block[i] = layers[i]
+            c.down_cross[i] = int(cfg["down_block_types"][i] == "CrossAttnDownBlock2D")
+            c.up_cross[i] = int(cfg["up_block_types"][i] == "CrossAttnUpBlock2D")
+        c.cross_attention_dim = cfg["cross_attention_dim"]
+        c.norm_num_groups = cfg["norm_num_groups"]
+        c.norm_eps = cfg["norm_eps"]
+        c.flip_sin_to_cos = int(cfg["flip_sin_to_cos"])
+        c.freq_shift = float(cfg["freq_shift"])
+        c.guided = int(self._guided)
+        c.max_batch, c.height, c.width, c.max_text_len = B, H, W, L
+        c.debug_taps = int(self.debug_taps)
+        return c
+
+    def _release(self):
+        if getattr(self, "_h_unet", None):
+            N.lib().ctta_unet_destroy(self._h_unet)
+        self._h_unet = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _ensure(self, B, H, W, L):
+        L_ = N.lib()
+        key = self._h_key
+        need_new = (self._h_unet is None or key is None or key[1:3] != (H, W) or B > key[0] or L > key[3]
+                    or key[4] != self.debug_taps or key[5] != self.device)
+        ver = self._weights_version()
+        if need_new:
+            self._release()
+            Bm = max(B, key[0]) if key and key[1:3] == (H, W) else B
+            Lm = max(L, key[3], 32) if key else max(L, 32)
+            table, keep = N.tensor_table(self._table())
+            h = N.c_void_p()
+            cfg = self._native_config(Bm, H, W, Lm)
+            with torch.cuda.device(self.device):
+                N.check(L_.ctta_unet_create(cfg, table, len(table), N.stream_ptr(), h))
+            self._h_unet, self._h_key, self._h_version = h, (Bm, H, W, Lm, self.debug_taps, self.device), ver
+        elif ver != self._h_version:  # parameters changed (optimizer / EMA / load_state_dict)
+            table, keep = N.tensor_table(self._table())
+            N.check(L_.ctta_unet_load_weights(self._h_unet, table, len(table), N.stream_ptr()))
+            self._h_version = ver
+
+    @staticmethod
+    def _per_sample(v, B, device, dtype):
+        """_prepare_tensor + expand (unet_2d_condition_guided.py:699-714,803,810)."""
+        if not torch.is_tensor(v):
+            return torch.full((B,), float(v), dtype=dtype, device=device)
+        v = v.to(device=device, dtype=dtype)
+        if v.ndim == 0:
+            v = v[None]
+        return v.expand(B).contiguous()
+
+    def _forward(self, sample, timestep, guidance, encoder_hidden_states, encoder_attention_mask):
+        if sample.ndim != 4 or sample.shape[1] != self._cfg["in_channels"]:
+            raise ValueError("sample must be (batch, %d, height, width), got %s"
+                             % (self._cfg["in_channels"], tuple(sample.shape)))
+        if encoder_hidden_states is None or encoder_hidden_states.ndim != 3:
+            raise ValueError("encoder_hidden_states must be (batch, sequence_length, feature_dim)")
+        B, _, H, W = sample.shape
+        L = encoder_hidden_states.shape[1]
+        if encoder_hidden_states.shape[0] != B or encoder_hidden_states.shape[2] != self._cfg["cross_attention_dim"]:
+            raise ValueError("encoder_hidden_states shape %s does not match batch %d / cross_attention_dim %d"
+                             % (tuple(encoder_hidden_states.shape), B, self._cfg["cross_attention_dim"]))
+        dev = self.device
+        if not sample.is_cuda:
+            raise N.CttaError("sample is on %s: the HIP engine has no CPU path" % sample.device)
+        self._ensure(B, H, W, L)
+        x = sample.detach().to(device=dev, dtype=torch.float32).contiguous()
+        enc = encoder_hidden_states.detach().to(device=dev, dtype=torch.float32).contiguous()
+        t = self._per_sample(timestep, B, dev, torch.float32)  # get_timestep_embedding casts to fp32
+        g = self._per_sample(guidance, B, dev, torch.float64) if self._guided else None
+        m = None
+        if encoder_attention_mask is not None:
+            m = encoder_attention_mask.to(device=dev).reshape(B, L).to(torch.uint8).contiguous()
+        out = torch.empty((B, self._cfg["out_channels"], H, W), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            N.check(N.lib().ctta_unet_forward(self._h_unet, N.ptr(x), N.ptr(t), N.ptr(g), N.ptr(enc), N.ptr(m),
+                                              B, L, N.ptr(out), N.stream_ptr()))
+        return out
+
+    def read_taps(self):
+        """name -> NCHW fp32 tensor of every recorded intermediate (debug_taps=True only)."""
+        L_ = N.lib()
+        out = OrderedDict()
+        for i in range(L_.ctta_unet_num_taps(self._h_unet)):
+            name = N.c_char_p()
+            dims = (N.c_int * 4)()
+            N.check(L_.ctta_unet_tap_info(self._h_unet, i, name, dims))
+            t = torch.empty(tuple(dims), dtype=torch.float32, device=self.device)
+            N.check(L_.ctta_unet_tap_read(self._h_unet, i, N.ptr(t), N.stream_ptr()))
+            out[name.value.decode()] = t
+        return out
+
+
+class UNet2DConditionGuidedModel(_UNetBase):
+    """Student / consistency U-Net with the guidance-strength Fourier input."""
+    _guided = True
+
+    def forward(self, sample, timestep, guidance, encoder_hidden_states, class_labels=None, timestep_cond=None,
+                guidance_cond=None, attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None,
+                encoder_attention_mask=None, return_dict=True, **kwargs):
+        for name, v in (("class_labels", class_labels), ("timestep_cond", timestep_cond),
+                        ("guidance_cond", guidance_cond), ("attention_mask", attention_mask),
+                        ("down_block_additional_residuals", down_block_additional_residuals),
+                        ("mid_block_additional_residual", mid_block_additional_residual)):
+            if v is not None:
+                raise NotImplementedError("%s is not used on the ConsistencyTTA path and is not supported" % name)
+        out = self._forward(sample, timestep, guidance, encoder_hidden_states, encoder_attention_mask)
+        return UNet2DConditionOutput(sample=out) if return_dict else (out,)
+
+
+class UNet2DConditionModel(_UNetBase):
+    """Teacher diffusion U-Net; `forward(**kwargs)` swallows `guidance=` like the reference
+    (unet_2d_condition.py:668-690)."""
+    _guided = False
+
+    def forward(self, sample, timestep, encoder_hidden_states, class_labels=None, timestep_cond=None,
+                attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
+                down_block_additional_residuals=None, mid_block_additional_residual=None,
+                encoder_attention_mask=None, return_dict=True, **kwargs):
+        out = self._forward(sample, timestep, None, encoder_hidden_states, encoder_attention_mask)
+        return UNet2DConditionOutput(sample=out) if return_dict else (out,)
+
+
+# ------------------------------------------------------------------------------------------
+class Generator(_ParamTree):
+    """HiFi-GAN parameter holder (weight_norm already removed, hifigan/utilities.py:71)."""
+
+    def __init__(self, h=None):
+        super().__init__()
+        self.h = dict(spec.HIFIGAN_16K_64 if h is None else h)
+        self._register(spec.hifigan_param_spec(self.h, prefix=""))
+
+
+class AutoencoderKL(_ParamTree):
+    """decode_first_stage / decode_to_waveform of the AudioLDM VAE (autoencoder.py:91-111).
+    The encoder half (training-side) is not built yet: `encode*` raise."""
+
+    def __init__(self, ddconfig=None, lossconfig=None, image_key="fbank", embed_dim=None, time_shuffle=1,
+                 subband=1, ckpt_path=None, reload_from_ckpt=None, ignore_keys=(), colorize_nlabels=None,
+                 monitor=None, base_learning_rate=1e-5, scale_factor=1, hifigan_config=None, **ignored):
+        super().__init__()
+        self.ddconfig = dict(spec.VAE_DDCONFIG if ddconfig is None else ddconfig)
+        self.embed_dim = int(embed_dim if embed_dim is not None else 8)
+        if int(subband) != 1:
+            raise NotImplementedError("subband decomposition is unused by ConsistencyTTA (subband=1)")
+        if self.ddconfig.get("attn_resolutions"):
+            raise NotImplementedError("attn_resolutions must be empty (audioldm-s-full)")
+        self.subband = 1
+        self.image_key = image_key
+        self.scale_factor = scale_factor
+        self._register(spec.vae_decoder_param_spec(self.ddconfig, self.embed_dim))
+        self.vocoder = Generator(hifigan_config)
+        self.ema_decoder = None
+        self._h_vae = self._h_voc = None
+        self._h_vae_key = self._h_voc_key = None
+        self._h_vae_ver = self._h_voc_ver = None
+        self.debug_taps = False
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def load_state_dict(self, state_dict, strict=True):
+        """Reference checkpoints also carry encoder.* / quant_conv.* (and loss.*) keys; they
+        belong to the training-side encoder and are skipped until that row is built."""
+        own = {k: v for k, v in state_dict.items()
+               if not k.startswith(("encoder.", "quant_conv.", "loss.", "ema_"))}
+        return super().load_state_dict(own, strict=strict)
+
+    def encode(self, x):
+        raise NotImplementedError("VAE encoder is the next hot-path row (SURVEY.md §8f rank 1)")
+
+    encode_first_stage = encode
+
+    def get_first_stage_encoding(self, encoder_posterior):
+        if isinstance(encoder_posterior, torch.Tensor):
+            return self.scale_factor * encoder_posterior
+        raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+
+    def _release(self):
+        L_ = N.lib() if (getattr(self, "_h_vae", None) or getattr(self, "_h_voc", None)) else None
+        if getattr(self, "_h_vae", None):
+            L_.ctta_vae_destroy(self._h_vae)
+        if getattr(self, "_h_voc", None):
+            L_.ctta_hifigan_destroy(self._h_voc)
+        self._h_vae = self._h_voc = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _decoder_version(self):
+        return sum(p._version for k, p in self.named_parameters() if not k.startswith("vocoder."))
+
+    def _ensure_vae(self, B, T, F):
+        L_ = N.lib()
+        sf = float(self.scale_factor)
+        key = (T, F, sf, self.debug_taps, self.device)
+        ver = self._decoder_version()
+        if (self._h_vae is None or self._h_vae_key[1:] != key or B > self._h_vae_key[0]
+                or ver != self._h_vae_ver):
+            if self._h_vae is not None:
+                L_.ctta_vae_destroy(self._h_vae)
+                self._h_vae = None
+            dd = self.ddconfig
+            c = N.VAEConfig()
+            c.z_channels, c.embed_dim, c.ch, c.out_ch = dd["z_channels"], self.embed_dim, dd["ch"], dd["out_ch"]
+            c.n_levels, c.num_res_blocks = len(dd["ch_mult"]), dd["num_res_blocks"]
+            for i, m in enumerate(dd["ch_mult"]):
+                c.ch_mult[i] = m
+            c.scale_factor = sf
+            c.max_batch, c.latent_h, c.latent_w = B, T, F
+            c.debug_taps = int(self.debug_taps)
+            sd = OrderedDict((k, p.detach()) for k, p in self.named_parameters() if not k.startswith("vocoder."))
+            for k, p in sd.items():
+                if not p.is_cuda:
+                    raise N.CttaError("parameter '%s' is on %s: the HIP engine has no CPU path" % (k, p.device))
+            table, keep = N.tensor_table(sd)
+            h = N.c_void_p()
+            with torch.cuda.device(self.device):
+                N.check(L_.ctta_vae_create(c, table, len(table), N.stream_ptr(), h))
+            self._h_vae, self._h_vae_key, self._h_vae_ver = h, (B,) + key, ver
+        return self._h_vae
+
+    def _ensure_voc(self, B, frames):
+        L_ = N.lib()
+        ver = sum(p._version for p in self.vocoder.parameters())
+        key = (self.debug_taps, self.device)
+        if (self._h_voc is None or self._h_voc_key[2:] != key or B > self._h_voc_key[0]
+                or frames > self._h_voc_key[1] or ver != self._h_voc_ver):
+            if self._h_voc is not None:
+                L_.ctta_hifigan_destroy(self._h_voc)
+                self._h_voc = None
+            h_ = self.vocoder.h
+            c = N.HifiganConfig()
+            c.num_mels, c.upsample_initial_channel = h_["num_mels"], h_["upsample_initial_channel"]
+            c.n_ups, c.n_kernels = len(h_["upsample_rates"]), len(h_["resblock_kernel_sizes"])
+            for i, (u, k) in enumerate(zip(h_["upsample_rates"], h_["upsample_kernel_sizes"])):
+                c.upsample_rates[i], c.upsample_kernel_sizes[i] = u, k
+            for j, (k, dil) in enumerate(zip(h_["resblock_kernel_sizes"], h_["resblock_dilation_sizes"])):
+                c.resblock_kernel_sizes[j] = k
+                for m in range(3):
+                    c.resblock_dilations[j][m] = dil[m]
+            c.max_batch, c.max_frames, c.debug_taps = B, frames, int(self.debug_taps)
+            sd = OrderedDict(("vocoder." + k, p.detach()) for k, p in self.vocoder.named_parameters())
+            for k, p in sd.items():
+                if not p.is_cuda:
+                    raise N.CttaError("parameter '%s' is on %s: the HIP engine has no CPU path" % (k, p.device))
+            table, keep = N.tensor_table(sd)
+            h = N.c_void_p()
+            with torch.cuda.device(self.device):
+                N.check(L_.ctta_hifigan_create(c, table, len(table), N.stream_ptr(), h))
+            self._h_voc, self._h_voc_key, self._h_voc_ver = h, (B, frames) + key, ver
+        return self._h_voc
+
+    # ---- reference API
+    def decode(self, z, use_ema=False):
+        return self.decode_first_stage(z * self.scale_factor, use_ema=use_ema)
+
+    def decode_first_stage(self, z, allow_grad=False, use_ema=False):
+        """z (B,8,T,F) -> mel (B,1,4T,4F); z is divided by scale_factor first (autoencoder.py:105)."""
+        if allow_grad:
+            raise NotImplementedError("allow_grad=True (CLAP fine-tuning, SURVEY §8f rank 2) is not built yet")
+        if use_ema and self.ema_decoder is None:
+            print("VAE does not have EMA modules, but specified use_ema. Using the none-EMA modules instead.")
+        if z.ndim != 4 or z.shape[1] != self.embed_dim:
+            raise ValueError("z must be (batch, %d, T, F), got %s" % (self.embed_dim, tuple(z.shape)))
+        if not z.is_cuda:
+            raise N.CttaError("z is on %s: the HIP engine has no CPU path" % z.device)
+        B, _, T, F = z.shape
+        h = self._ensure_vae(B, T, F)
+        zz = z.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        up = 2 ** (len(self.ddconfig["ch_mult"]) - 1)
+        mel = torch.empty((B, self.ddconfig["out_ch"], T * up, F * up), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ctta_vae_decode(h, N.ptr(zz), B, N.ptr(mel), N.stream_ptr()))
+        return mel
+
+    def vocode(self, mel):
+        """mel (B,1,T,F) -> float waveform (B, L) before centring (Generator.forward)."""
+        if mel.ndim != 4 or mel.shape[1] != 1 or mel.shape[3] != self.vocoder.h["num_mels"]:
+            raise ValueError("mel must be (batch, 1, T, %d), got %s" % (self.vocoder.h["num_mels"], tuple(mel.shape)))
+        if not mel.is_cuda:
+            raise N.CttaError("mel is on %s: the HIP engine has no CPU path" % mel.device)
+        B, _, T, F = mel.shape
+        h = self._ensure_voc(B, T)
+        m = mel.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        n = N.lib().ctta_hifigan_out_len(h, T)
+        wav = torch.empty((B, n), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ctta_hifigan_forward(h, N.ptr(m), B, T, N.ptr(wav), N.stream_ptr()))
+        return wav
+
+    def decode_to_waveform(self, dec, allow_grad=False, return_float=False):
+        """vocoder_infer (hifigan/utilities.py:76-91): batch-global (max+min)/2 centring, then
+        int16 numpy on the host (the reference's return type); return_float keeps the centred
+        float tensor on the device."""
+        if allow_grad:
+            raise NotImplementedError("allow_grad=True (CLAP fine-tuning) is not built yet")
+        wav = self.vocode(dec)
+        scratch = torch.empty(4, dtype=torch.float32, device=wav.device)
+        centred = torch.empty_like(wav) if return_float else None
+        pcm = None if return_float else torch.empty(wav.shape, dtype=torch.int16, device=wav.device)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ctta_wav_finalize(N.ptr(wav), wav.numel(), N.ptr(scratch), N.ptr(centred), N.ptr(pcm),
+                                              N.stream_ptr()))
+        return centred if return_float else pcm.cpu().numpy()
+
+    def _read_taps(self, which):
+        L_ = N.lib()
+        h = self._h_vae if which == "vae" else self._h_voc
+        num = getattr(L_, "ctta_%s_num_taps" % ("vae" if which == "vae" else "hifigan"))
+        info = getattr(L_, "ctta_%s_tap_info" % ("vae" if which == "vae" else "hifigan"))
+        read = getattr(L_, "ctta_%s_tap_read" % ("vae" if which == "vae" else "hifigan"))
+        out = OrderedDict()
+        for i in range(num(h)):
+            name = N.c_char_p()
+            dims = (N.c_int * 4)()
+            N.check(info(h, i, name, dims))
+            t = torch.empty(tuple(dims), dtype=torch.float32, device=self.device)
+            N.check(read(h, i, N.ptr(t), N.stream_ptr()))
+            out[name.value.decode()] = t
+        return out

@@ -175,8 +175,8 @@ ctta_status ctta_snr_mse_loss(const float* pred, const float* target, const floa
  * AudioLCM.update_ema (models/audio_consistency_model.py:221-227): for each shadow s_k:
  * s_k += (1-decay_k)*(p - s_k), fp32, in place.  shadow_b/decay_b may be NULL/0.
  * ------------------------------------------------------------------------------------ */
-ctta_status ctta_ema_update2(const float* param, float* shadow_a, float decay_a, float* shadow_b,
-                             float decay_b, int64_t n, void* stream);
+ctta_status ctta_ema_update2(const float* param, float* shadow_a, double decay_a, float* shadow_b,
+                             double decay_b, int64_t n, void* stream);
 
 /* ------------------------------------------------------------------------------------ *
  * Operator-level entry points (used by the engines; exported for per-op parity tests and
@@ -191,8 +191,10 @@ typedef struct {
   int kh, kw, stride_h, stride_w, pad_h, pad_w, dil_h, dil_w;
   const void* w;              /* packed bf16 [n_rows >= n][k_pad], k = (kh,kw,c), zero padded */
   int k_pad;                  /* row stride of w, multiple of 64 */
-  int n;                      /* valid output channels, multiple of 4 */
+  int n;                      /* valid output channels; multiple of 4 unless the epilogue is
+                                 plain (no bias/rowvec/res/accumulate) and round_up(n,4) <= ldc */
   const float* bias;          /* [n] or NULL */
+  const float* bias_m;        /* per output ROW (pixel) bias [m] or NULL (transposed products) */
   const float* rowvec; int rowvec_ld;   /* + rowvec[b*ld + n] (time-embedding shift) or NULL */
   const void* res; int res_ld;          /* + res[m*ld + n] bf16 or NULL */
   int in_act;                 /* on the A operand: 0 none, 1 leaky_relu(in_slope) */
@@ -253,10 +255,10 @@ ctta_status ctta_softmax_rows(const float* s, void* p, int64_t rows, int cols, f
                               void* stream);
 
 /* Multi-head attention, head dim padded to 64 (pad lanes must be zero):
- * q [B][nq][..] row stride q_ld, head h at column h*64; k likewise; vt is V TRANSPOSED:
- * [B][heads*64][vt_ld] (keys contiguous).  bias (B, nk) f32 additive per key or NULL.
+ * q [B][nq][..] row stride q_ld, head h at column h*64; k [B][k_rows >= nk][..] likewise; vt is V
+ * TRANSPOSED: [B][heads*64][vt_ld] (keys contiguous).  bias (B, nk) f32 additive per key or NULL.
  * softmax(q k^T * scale + bias) v  ->  out [B][nq][out_ld], head h at column h*64. */
-ctta_status ctta_attention(const void* q, int q_ld, const void* k, int k_ld, const void* vt,
+ctta_status ctta_attention(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
                            int vt_ld, const float* bias, void* out, int out_ld, int batch,
                            int heads, int nq, int nk, float scale, void* stream);
 

@@ -1,0 +1,133 @@
+"""CPU-only checks of the host side: the C-ABI library loads and exports every symbol that
+include/ctta.h declares, the nn.Module mirrors carry the reference's state-dict keys, the
+scheduler's host tables match the reference, and the product path fails LOUDLY (no CPU
+fallback) when it is handed CPU tensors or the library is missing."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from consistencytta_amd import _native as N
+from consistencytta_amd import modules, scheduler, spec
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "ctta.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ctta_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def built_lib():
+    if not os.path.exists(N.LIB_PATH):
+        N.build()
+    return N.lib()
+
+
+def test_library_exports_every_declared_symbol(built_lib):
+    declared = _declared_symbols()
+    assert len(declared) >= 45
+    for name in declared:
+        assert hasattr(built_lib, name), "libctta_hip.so does not export %s" % name
+        assert name in N.SIGNATURES, "%s has no ctypes signature" % name
+    assert sorted(N.SIGNATURES) == declared
+    assert built_lib.ctta_version() == 100
+    assert built_lib.ctta_conv_gemm_num_variants() >= 4
+
+
+def test_struct_layouts_match_header_field_order():
+    text = open(os.path.join(ROOT, "include", "ctta.h")).read()
+    end = text.index("} ctta_conv_desc;")
+    body = text[text.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(void|float|int64_t|int)\s*\*?", "", decl).strip()
+        names += [n.strip().lstrip("*") for n in decl.split(",")]
+    assert names == [f[0] for f in N.ConvDesc._fields_]
+
+
+def test_mirror_state_dict_keys_are_the_references(golden):
+    g = golden("unet_tiny")
+    m = modules.UNet2DConditionGuidedModel.from_config(cases.TINY_UNET)
+    assert list(m.state_dict().keys()) == [str(k) for k in g["keys"]]
+    assert not m.get_parameter("guidance_proj.weight").requires_grad       # embeddings.py:229
+    t = modules.UNet2DConditionModel.from_config(cases.TINY_UNET)
+    assert all(not k.startswith("guidance") for k in t.state_dict())
+    v = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, hifigan_config=cases.TINY_HIFIGAN)
+    keys = list(v.state_dict().keys())
+    assert keys[:2] == ["decoder.conv_in.weight", "decoder.conv_in.bias"]
+    assert "vocoder.resblocks.14.convs2.2.weight" in keys and "post_quant_conv.bias" in keys
+    # checkpoints with encoder keys load (encoder is a later row), unknown keys still raise
+    sd = dict(cases.vae_weights(cases.TINY_VAE_DD))
+    sd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
+    sd["encoder.conv_in.weight"] = torch.zeros(1)
+    v.load_state_dict(sd)
+    with pytest.raises(RuntimeError):
+        v.load_state_dict(dict(sd, bogus=torch.zeros(1)))
+    import copy
+    m2 = copy.deepcopy(m)                                                   # audio_consistency_model.py:65
+    assert list(m2.state_dict().keys()) == list(m.state_dict().keys())
+
+
+def test_config_validation_mirrors_reference_errors():
+    with pytest.raises(ValueError):
+        modules.UNet2DConditionGuidedModel(**dict(cases.TINY_UNET, block_out_channels=[32, 64]))
+    with pytest.raises(ValueError):
+        modules.UNet2DConditionGuidedModel(**dict(cases.TINY_UNET, down_block_types=["Nope"] * 4))
+
+
+def test_scheduler_host_tables_match_reference(golden):
+    g = golden("heun")
+    s = scheduler.HeunDiscreteScheduler.from_pretrained("stabilityai/stable-diffusion-2-1", subfolder="scheduler")
+    assert s.config.prediction_type == "v_prediction" and s.order == 2
+    for n in (1, 2, 18, 200):
+        s.set_timesteps(n)
+        assert np.array_equal(s.timesteps.numpy(), g["timesteps_%d" % n])
+        assert np.array_equal(s.sigmas.numpy(), g["sigmas_%d" % n])
+    s.set_timesteps(18)
+    assert len(s.timesteps) == 35 and len(s.sigmas) == 36 and s.state_in_first_order
+    # last-match semantics of index_for_timestep (mask * arange argmax)
+    assert list(s.index_for_timestep(s.timesteps[[0, 1, 2, 34]])) == [0, 2, 2, 34]
+    with pytest.raises(AssertionError):
+        s.index_for_timestep(123.456)                                       # :143 membership assert
+
+
+def test_product_path_has_no_cpu_fallback(built_lib):
+    m = modules.UNet2DConditionGuidedModel.from_config(cases.TINY_UNET).init_deterministic()
+    x, ts, gs, enc, mask = cases.unet_inputs(cases.TINY_UNET, 1, 16, 8, 4, "cpu")
+    with pytest.raises(RuntimeError):
+        m(x, ts, guidance=gs, encoder_hidden_states=enc, encoder_attention_mask=mask)
+    v = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, hifigan_config=cases.TINY_HIFIGAN)
+    with pytest.raises(RuntimeError):
+        v.decode_first_stage(torch.zeros(1, 8, 16, 8))
+    s = scheduler.HeunDiscreteScheduler.from_pretrained("x")
+    s.set_timesteps(18)
+    with pytest.raises(RuntimeError):
+        s.scale_model_input(torch.zeros(1, 8, 4, 4), 999.0)
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 16, 8), 1.0, guidance=1.0, encoder_hidden_states=enc)   # wrong channels
+
+
+def test_missing_library_is_an_error(monkeypatch, tmp_path):
+    monkeypatch.setattr(N, "_lib", None)
+    monkeypatch.setattr(N, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(RuntimeError, match="no non-HIP fallback"):
+        N.lib()
+
+
+def test_det_generator_is_stable():
+    a = spec.det_uniform("some.key", (4, 3), seed=7)
+    assert a.dtype == np.float32 and a.shape == (4, 3)
+    assert np.array_equal(a, spec.det_uniform("some.key", (4, 3), seed=7))
+    assert not np.array_equal(a, spec.det_uniform("some.key", (4, 3), seed=8))
+    # frozen values: a change here invalidates every committed fixture
+    np.testing.assert_allclose(spec.det_uniform("x", (3,), 0), [-0.597583532333374, 0.6170535087585449, 0.2866472005844116], rtol=0, atol=1e-6)

@@ -1,0 +1,392 @@
+"""Per-operator parity of the HIP kernels against the CPU oracle, through the C ABI.
+
+bf16 kernels are checked against the fp32 oracle evaluated on the SAME bf16-rounded inputs
+and weights, so the only differences are fp32 accumulation order and the final bf16 rounding
+of the output: tolerance 1.5 * 2^-8 of the output's max magnitude (BF16_TOL).  fp32 kernels
+(Heun / EMA / loss / embeddings) are checked to a few ulp (F32_TOL).
+"""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from consistencytta_amd import _native as N  # noqa: E402
+from gpu_util import (DEV, bf16_round, conv_desc, det, from_nhwc, nhwc_bf16, pack_conv_weight,  # noqa: E402
+                      rel_err, run_conv, sync)
+from oracle import heun as oheun  # noqa: E402
+from oracle import nets as onets  # noqa: E402
+
+BF16_TOL = 1.5 * 2.0 ** -8
+F32_TOL = 2e-6
+
+
+def lib():
+    return N.lib()
+
+
+# ------------------------------------------------------------------------------------ conv / gemm
+def _conv_case(B, Cin, H, W, Cout, k, stride, pad, tile=0, upsample=False, c_split=None, epilogue=False,
+               tag="c"):
+    x = bf16_round(det(tag + ".x", (B, Cin, H, W), 1))
+    w = bf16_round(det(tag + ".w", (Cout, Cin, k, k), 2) * (1.0 / math.sqrt(Cin * k * k)))
+    bias = det(tag + ".b", (Cout,), 3) * 0.1
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if upsample else x
+    ref = F.conv2d(xin, w, bias, stride=stride, padding=pad)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wp, k_pad = pack_conv_weight(w)
+    out = torch.zeros(B, Ho, Wo, Cout, dtype=torch.bfloat16, device=DEV)
+    kw = dict(batch=B, hi=xin.shape[2], wi=xin.shape[3], upsample=int(upsample), ho=Ho, wo=Wo, kh=k, kw=k,
+              stride_h=stride, stride_w=stride, pad_h=pad, pad_w=pad, w=wp, k_pad=k_pad, n=Cout,
+              bias=bias.to(DEV), out=out, ldc=Cout, tile=tile)
+    keep = [wp, out]
+    if c_split:
+        xa, xb = nhwc_bf16(x[:, :c_split]), nhwc_bf16(x[:, c_split:])
+        kw.update(x0=xa, c0=c_split, x1=xb, c1=Cin - c_split)
+        keep += [xa, xb]
+    else:
+        xa = nhwc_bf16(x)
+        kw.update(x0=xa, c0=Cin)
+        keep.append(xa)
+    if epilogue:
+        rowvec = det(tag + ".rv", (B, Cout), 4)
+        res = bf16_round(det(tag + ".res", (B, Cout, Ho, Wo), 5))
+        ref = ref + rowvec[:, :, None, None] + res
+        rv, rs = rowvec.to(DEV), nhwc_bf16(res)
+        kw.update(rowvec=rv, rowvec_ld=Cout, res=rs, res_ld=Cout)
+        keep += [rv, rs]
+    kw["bias"] = kw["bias"].contiguous()
+    keep.append(kw["bias"])
+    run_conv(conv_desc(**kw))
+    return rel_err(from_nhwc(out), ref)
+
+
+@pytest.mark.parametrize("tile", list(range(0, 9)))
+def test_conv3x3_all_tiles(tile):
+    assert _conv_case(2, 64, 24, 16, 96, 3, 1, 1, tile=tile, tag="t%d" % tile) < BF16_TOL
+
+
+def test_conv_shapes():
+    assert _conv_case(2, 32, 16, 8, 40, 3, 2, 1, tag="s2") < BF16_TOL            # Downsample2D
+    assert _conv_case(1, 72, 9, 7, 24, 1, 1, 0, tag="1x1") < BF16_TOL            # ragged extent, 1x1
+    assert _conv_case(2, 48, 8, 4, 64, 3, 1, 1, upsample=True, tag="up") < BF16_TOL   # Upsample2D fused
+    assert _conv_case(2, 120, 8, 8, 80, 3, 1, 1, c_split=80, tag="cat") < BF16_TOL    # concat gather
+    assert _conv_case(2, 64, 8, 8, 64, 3, 1, 1, epilogue=True, tag="epi") < BF16_TOL  # bias+temb+residual
+    assert _conv_case(3, 256, 4, 2, 256, 3, 1, 1, tag="deepk") < BF16_TOL        # K = 2304
+
+
+def test_conv1d_dilated_lrelu_and_accumulate():
+    B, C, L, k, d = 2, 32, 200, 7, 3
+    x = bf16_round(det("c1d.x", (B, C, L), 1))
+    w = bf16_round(det("c1d.w", (C, C, k), 2) * (1.0 / math.sqrt(C * k)))
+    b = det("c1d.b", (C,), 3) * 0.1
+    res = bf16_round(det("c1d.r", (B, C, L), 4))
+    old = bf16_round(det("c1d.o", (B, C, L), 5))
+    pad = (k * d - d) // 2
+    ref = (F.conv1d(F.leaky_relu(x, 0.1), w, b, dilation=d, padding=pad) + res + old) / 3
+    wp, k_pad = pack_conv_weight(w[:, :, None, :])
+    out = old.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    xa = x.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    rs = res.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    bd = b.to(DEV)
+    run_conv(conv_desc(x0=xa, c0=C, batch=B, hi=1, wi=L, ho=1, wo=L, kh=1, kw=k, pad_w=pad, dil_w=d, w=wp,
+                       k_pad=k_pad, n=C, bias=bd, in_act=1, in_slope=0.1, res=rs, res_ld=C, accumulate=1,
+                       alpha=1.0 / 3.0, out=out, ldc=C))
+    got = out.to(torch.float32).permute(0, 2, 1).cpu()
+    assert rel_err(got, ref) < 2 * BF16_TOL   # `old` is itself bf16 and re-rounded
+
+
+@pytest.mark.parametrize("k,u", [(16, 5), (16, 4), (8, 2), (4, 2)])
+def test_conv_transpose1d_as_phase_gemm(k, u):
+    """ConvTranspose1d(k, stride u, padding (k-u)//2) == u phase convolutions written through
+    the output remap (engine_vae.hip make_convt1d); weights packed here with the same maps."""
+    B, Cin, Cout, L = 2, 64, 32, 37
+    pad = (k - u) // 2
+    x = bf16_round(det("ct.x", (B, Cin, L), 1))
+    w = bf16_round(det("ct.w", (Cin, Cout, k), 2) * (1.0 / math.sqrt(Cin * k / u)))
+    b = det("ct.b", (Cout,), 3) * 0.1
+    ref = F.conv_transpose1d(F.leaky_relu(x, 0.1), w, b, stride=u, padding=pad)
+    Lout = ref.shape[2]
+    taps = (k + u - 1) // u
+    K = taps * Cin
+    k_pad = (K + 63) // 64 * 64
+    n = u * Cout
+    ro = torch.tensor([o * k + r for r in range(u) for o in range(Cout)], dtype=torch.int32)
+    ra = torch.tensor([r for r in range(u) for o in range(Cout)], dtype=torch.int32)
+    co = torch.full((k_pad,), -1, dtype=torch.int32)
+    ca = torch.zeros(k_pad, dtype=torch.int32)
+    for t in range(taps):
+        m = taps - 1 - t
+        for c in range(Cin):
+            co[t * Cin + c] = c * Cout * k + m * u
+            ca[t * Cin + c] = m * u
+    wd = w.contiguous().to(DEV)
+    wp = torch.empty(n, k_pad, dtype=torch.bfloat16, device=DEV)
+    ro, co, ra, ca = ro.to(DEV), co.to(DEV), ra.to(DEV), ca.to(DEV)
+    N.check(lib().ctta_pack_weight(N.ptr(wd), N.ptr(ro), N.ptr(co), N.ptr(ra), N.ptr(ca), k, n, k_pad,
+                                   N.ptr(wp), N.stream_ptr()))
+    bias = b.repeat(u).contiguous().to(DEV)
+    Q = (Lout - 1 + pad) // u + 1
+    out = torch.full((B, Lout, Cout), 7.0, dtype=torch.bfloat16, device=DEV)
+    xa = x.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    run_conv(conv_desc(x0=xa, c0=Cin, batch=B, hi=1, wi=L, ho=1, wo=Q, kh=1, kw=taps, pad_w=taps - 1, w=wp,
+                       k_pad=k_pad, n=n, bias=bias, in_act=1, in_slope=0.1, out=out, ldc=u * Cout,
+                       out_batch_stride=Lout * Cout, out_offset=-pad * Cout, out_limit=Lout * Cout))
+    got = out.to(torch.float32).permute(0, 2, 1).cpu()
+    assert rel_err(got, ref) < BF16_TOL
+
+
+def test_batched_gemm_f32_and_transposed_product():
+    """q k^T per batch with fp32 output (VAE AttnBlock scores) and V^T = Wv X^T + bv[row]."""
+    B, Nt, C = 2, 128, 64
+    q = bf16_round(det("bg.q", (B, Nt, C), 1))
+    kk = bf16_round(det("bg.k", (B, Nt, C), 2))
+    qd, kd = q.to(torch.bfloat16).to(DEV), kk.to(torch.bfloat16).to(DEV)
+    s = torch.empty(B, Nt, Nt, dtype=torch.float32, device=DEV)
+    run_conv(conv_desc(x0=qd, c0=C, batch=1, hi=Nt, wi=1, ho=Nt, wo=1, w=kd, k_pad=C, n=Nt, out=s, ldc=Nt,
+                       out_f32=1, groups=B, x_group_stride=Nt * C, w_group_stride=Nt * C,
+                       out_group_stride=Nt * Nt))
+    assert rel_err(s.cpu(), torch.bmm(q, kk.transpose(1, 2))) < 1e-4
+    # transposed product with odd token count (n not a multiple of 4) and per-row bias
+    T = 6
+    wv = bf16_round(det("bg.wv", (C, C), 3) * 0.2)
+    bv = det("bg.bv", (C,), 4)
+    x = bf16_round(det("bg.x", (B, T, C), 5))
+    wvd, xd, bvd = wv.to(torch.bfloat16).to(DEV), x.to(torch.bfloat16).to(DEV), bv.to(DEV)
+    ld = 8
+    vt = torch.zeros(B, C, ld, dtype=torch.bfloat16, device=DEV)
+    run_conv(conv_desc(x0=wvd, c0=C, batch=1, hi=C, wi=1, ho=C, wo=1, w=xd, k_pad=C, n=T, bias_m=bvd, out=vt,
+                       ldc=ld, groups=B, w_group_stride=T * C, out_group_stride=C * ld))
+    ref = torch.einsum("ck,btk->bct", wv, x) + bv[None, :, None]
+    assert rel_err(vt.to(torch.float32).cpu()[:, :, :T], ref) < BF16_TOL
+
+
+def test_conv_small_n():
+    for (C, n, kh, kw_, H, W, act_in, act_out) in [(40, 8, 3, 3, 16, 8, 0, 0), (32, 1, 3, 3, 12, 6, 0, 0),
+                                                   (32, 1, 1, 7, 1, 300, 1, 2)]:
+        B = 2
+        x = bf16_round(det("sn.x", (B, C, H, W), 1))
+        w = det("sn.w", (n, C, kh, kw_), 2) * (1.0 / math.sqrt(C * kh * kw_))
+        b = det("sn.b", (n,), 3) * 0.1
+        xin = F.leaky_relu(x, 0.01) if act_in else x
+        ref = F.conv2d(xin, w, b, padding=(kh // 2, kw_ // 2))
+        if act_out == 2:
+            ref = torch.tanh(ref)
+        wr = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+        out = torch.empty(B, n, H, W, dtype=torch.float32, device=DEV)
+        xa, bd = nhwc_bf16(x), b.to(DEV)
+        N.check(lib().ctta_conv_small_n(N.ptr(xa), C, B, H, W, kh, kw_, kh // 2, kw_ // 2, N.ptr(wr), N.ptr(bd), n,
+                                        act_in, 0.01, act_out, N.ptr(out), None, N.stream_ptr()))
+        sync()
+        assert rel_err(out.cpu(), ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ norms etc.
+@pytest.mark.parametrize("B,C,H,W,G,silu,eps", [(2, 40, 32, 8, 8, True, 1e-5), (2, 256, 16, 16, 32, False, 1e-6),
+                                                (1, 120, 8, 4, 8, True, 1e-5), (3, 2048, 4, 2, 32, True, 1e-5),
+                                                (1, 128, 64, 64, 32, True, 1e-6), (2, 32, 9, 5, 32, False, 1e-6)])
+def test_groupnorm(B, C, H, W, G, silu, eps):
+    x = bf16_round(det("gn.x", (B, C, H, W), 1) * 2 + 0.3)
+    gamma = 1 + 0.2 * det("gn.g", (C,), 2)
+    beta = 0.1 * det("gn.b", (C,), 3)
+    ref = F.group_norm(x, G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    xa = nhwc_bf16(x)
+    y = torch.empty_like(xa)
+    scratch = torch.empty(lib().ctta_groupnorm_scratch_floats(B, H * W, C, G) + 16, dtype=torch.float32, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    N.check(lib().ctta_groupnorm(N.ptr(xa), N.ptr(y), B, H * W, C, G, N.ptr(gd), N.ptr(bd), eps, int(silu),
+                                 N.ptr(scratch), N.stream_ptr()))
+    sync()
+    assert rel_err(from_nhwc(y), ref) < BF16_TOL
+
+
+@pytest.mark.parametrize("rows,d,ld", [(37, 39, 64), (64, 255, 256), (16, 1020, 1024), (5, 1275, 1280)])
+def test_layernorm(rows, d, ld):
+    x = torch.zeros(rows, ld)
+    x[:, :d] = bf16_round(det("ln.x", (rows, d), 1) * 3 + 0.5)
+    gamma = 1 + 0.2 * det("ln.g", (d,), 2)
+    beta = 0.1 * det("ln.b", (d,), 3)
+    ref = F.layer_norm(x[:, :d], (d,), gamma, beta, 1e-5)
+    xd = x.to(torch.bfloat16).to(DEV)
+    y = torch.full((rows, ld), 9.0, dtype=torch.bfloat16, device=DEV)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    N.check(lib().ctta_layernorm(N.ptr(xd), N.ptr(y), rows, d, ld, N.ptr(gd), N.ptr(bd), 1e-5, N.stream_ptr()))
+    sync()
+    yy = y.to(torch.float32).cpu()
+    assert rel_err(yy[:, :d], ref) < BF16_TOL
+    assert float(yy[:, d:].abs().max()) == 0.0 if d < ld else True   # pad columns are zeroed
+
+
+def test_geglu_and_softmax():
+    rows, hp = 33, 128
+    x = bf16_round(det("gg.x", (rows, 2 * hp), 1) * 3)
+    ref = x[:, :hp] * F.gelu(x[:, hp:])
+    xd = x.to(torch.bfloat16).to(DEV)
+    y = torch.empty(rows, hp, dtype=torch.bfloat16, device=DEV)
+    N.check(lib().ctta_geglu(N.ptr(xd), N.ptr(y), rows, hp, N.stream_ptr()))
+    sync()
+    assert rel_err(y.to(torch.float32).cpu(), ref) < BF16_TOL
+    s = det("sm.s", (19, 4096), 2) * 30
+    sd = s.to(DEV)
+    p = torch.empty(19, 4096, dtype=torch.bfloat16, device=DEV)
+    N.check(lib().ctta_softmax_rows(N.ptr(sd), N.ptr(p), 19, 4096, 0.044, N.stream_ptr()))
+    sync()
+    assert rel_err(p.to(torch.float32).cpu(), torch.softmax(s * 0.044, dim=-1)) < BF16_TOL
+
+
+@pytest.mark.parametrize("B,heads,dh,nq,nk,masked", [(2, 3, 13, 256, 256, False), (2, 5, 51, 200, 200, False),
+                                                     (2, 6, 13, 4, 4, False), (1, 2, 64, 130, 70, False),
+                                                     (2, 3, 13, 64, 7, True), (3, 5, 51, 300, 32, True)])
+def test_attention(B, heads, dh, nq, nk, masked):
+    """Flash attention with head dim padded to 64 vs softmax(q k^T / sqrt(dh) + bias) v."""
+    q = bf16_round(det("at.q", (B, heads, nq, dh), 1))
+    k = bf16_round(det("at.k", (B, heads, nk, dh), 2))
+    v = bf16_round(det("at.v", (B, heads, nk, dh), 3))
+    bias = None
+    if masked:
+        lens = [nk, max(1, nk // 2), max(1, nk - 3)][:B]
+        keep = torch.arange(nk)[None, :] < torch.tensor(lens)[:, None]
+        bias = (1 - keep.float()) * -10000.0
+    s = torch.matmul(q, k.transpose(-1, -2)) / math.sqrt(dh)
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    ref = torch.matmul(torch.softmax(s, dim=-1), v)          # (B, heads, nq, dh)
+    hp = heads * 64
+    k_rows = nk + 5                                           # k buffer taller than nk
+    vt_ld = (nk + 7) // 8 * 8
+    qd = torch.zeros(B, nq, hp)
+    kd = torch.zeros(B, k_rows, hp)
+    vtd = torch.full((B, hp, vt_ld), float("nan"))            # padding must be ignored, even NaN
+    for h in range(heads):
+        qd[:, :, h * 64:h * 64 + dh] = q[:, h]
+        kd[:, :nk, h * 64:h * 64 + dh] = k[:, h]
+        vtd[:, h * 64:h * 64 + 64, :nk] = 0
+        vtd[:, h * 64:h * 64 + dh, :nk] = v[:, h].transpose(1, 2)
+    qd, kd, vtd = (t.to(torch.bfloat16).to(DEV) for t in (qd, kd, vtd))
+    out = torch.zeros(B, nq, hp, dtype=torch.bfloat16, device=DEV)
+    bd = bias.contiguous().to(DEV) if bias is not None else None
+    N.check(lib().ctta_attention(N.ptr(qd), hp, N.ptr(kd), hp, k_rows, N.ptr(vtd), vt_ld, N.ptr(bd), N.ptr(out), hp,
+                                 B, heads, nq, nk, 1.0 / math.sqrt(dh), N.stream_ptr()))
+    sync()
+    o = out.to(torch.float32).cpu().reshape(B, nq, heads, 64)[..., :dh].permute(0, 2, 1, 3)
+    # P is rounded to bf16 before the PV product: 2^-8 relative on each probability
+    assert rel_err(o, ref) < 2.5 * BF16_TOL
+
+
+def test_small_fp32_kernels():
+    B, K, Nn = 5, 96, 70
+    x, w, b = det("l.x", (B, K), 1), det("l.w", (Nn, K), 2) * 0.2, det("l.b", (Nn,), 3)
+    xd, wd, bd = x.to(DEV), w.to(DEV), b.to(DEV)
+    y = torch.empty(B, Nn, device=DEV)
+    N.check(lib().ctta_linear_f32(N.ptr(xd), N.ptr(wd), N.ptr(bd), N.ptr(y), B, Nn, K, 0, 1, N.stream_ptr()))
+    sync()
+    assert rel_err(y.cpu(), F.silu(F.linear(x, w, b))) < 1e-5
+    # sinusoid + Fourier features
+    t = torch.tensor([999.0, 0.0, 58.7647, 470.1176, 940.2353])
+    dim = 40
+    half = dim // 2
+    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float32) / half
+    freqs = torch.exp(exponent)
+    ref = onets.timestep_embedding(t, dim, True, 0.0)
+    td, fd = t.to(DEV), freqs.to(DEV)
+    o = torch.empty(5, dim, device=DEV)
+    N.check(lib().ctta_time_features(N.ptr(td), N.ptr(fd), dim, 1, N.ptr(o), 5, N.stream_ptr()))
+    sync()
+    assert float((o.cpu() - ref).abs().max()) < 2e-4   # sin/cos of arguments up to 999 in fp32
+    wv = torch.tensor([4.0, 0.3, 5.9], dtype=torch.float64)
+    W = det("f.w", (24,), 4) * 1.7
+    ref = onets.fourier_embedding(wv, W.double(), True).float()
+    wd_, Wd = wv.to(DEV), W.to(DEV)
+    o = torch.empty(3, 48, device=DEV)
+    N.check(lib().ctta_fourier_features(N.ptr(wd_), N.ptr(Wd), 24, 1, N.ptr(o), 3, N.stream_ptr()))
+    sync()
+    assert float((o.cpu() - ref).abs().max()) < 1e-6
+
+
+def test_layout_packs():
+    x = det("lp.x", (2, 8, 6, 5), 1)
+    xd = x.to(DEV)
+    y = torch.empty(2, 6, 5, 32, dtype=torch.bfloat16, device=DEV)
+    N.check(lib().ctta_nchw_f32_to_nhwc_bf16(N.ptr(xd), N.ptr(y), 2, 8, 6, 5, 32, 0.5, N.stream_ptr()))
+    sync()
+    yy = y.to(torch.float32).cpu()
+    assert torch.equal(yy[..., :8], bf16_round(x * 0.5).permute(0, 2, 3, 1))
+    assert float(yy[..., 8:].abs().max()) == 0.0
+    z = torch.empty(2, 8, 6, 5, device=DEV)
+    N.check(lib().ctta_nhwc_bf16_to_nchw_f32(N.ptr(y), N.ptr(z), 2, 8, 6, 5, 32, N.stream_ptr()))
+    sync()
+    assert torch.equal(z.cpu(), bf16_round(x * 0.5))
+    a = torch.arange(2 * 3 * 16, dtype=torch.float32).reshape(6, 16).to(torch.bfloat16).to(DEV)
+    b = (torch.arange(6 * 8, dtype=torch.float32).reshape(6, 8) + 500).to(torch.bfloat16).to(DEV)
+    c = torch.empty(6, 24, dtype=torch.bfloat16, device=DEV)
+    N.check(lib().ctta_concat_channels(N.ptr(a), 16, N.ptr(b), 8, N.ptr(c), 6, N.stream_ptr()))
+    sync()
+    assert torch.equal(c.cpu(), torch.cat([a.cpu(), b.cpu()], dim=1))
+
+
+# ------------------------------------------------------------------------------------ fp32 solver kernels
+def test_heun_cfg_loss_ema_wav(golden):
+    g = golden("heun")
+    _, sig = oheun.set_timesteps(18)
+    sig = torch.from_numpy(sig)
+    idx = torch.from_numpy(g["idx"])
+    B, n = 3, 8 * 16 * 4
+    x = det("heun.x", (B, 8, 16, 4), 1) * 3
+    v1, v2, noise = det("heun.v1", (B, 8, 16, 4), 2), det("heun.v2", (B, 8, 16, 4), 3), det("heun.n", (B, 8, 16, 4), 4)
+    xd, v1d, v2d, nd = x.to(DEV), v1.to(DEV), v2.to(DEV), noise.to(DEV)
+    s0, s1 = sig[idx].contiguous().to(DEV), sig[idx + 1].contiguous().to(DEV)
+    L = lib()
+    st = N.stream_ptr()
+    out = torch.empty_like(xd)
+    N.check(L.ctta_heun_scale_model_input(N.ptr(xd), N.ptr(s0), N.ptr(out), B, n, st)); sync()
+    assert rel_err(out.cpu(), torch.from_numpy(g["scaled"])) < F32_TOL
+    N.check(L.ctta_heun_add_noise(N.ptr(xd), N.ptr(nd), N.ptr(s0), N.ptr(out), B, n, st)); sync()
+    assert rel_err(out.cpu(), torch.from_numpy(g["noised"])) < F32_TOL
+    prev, deriv = torch.empty_like(xd), torch.empty_like(xd)
+    N.check(L.ctta_heun_step_first(N.ptr(v1d), N.ptr(xd), N.ptr(s0), N.ptr(s1), N.ptr(prev), N.ptr(deriv), B, n, st)); sync()
+    assert rel_err(prev.cpu(), torch.from_numpy(g["step1"])) < F32_TOL
+    prev2 = torch.empty_like(xd)
+    N.check(L.ctta_heun_step_second(N.ptr(v2d), N.ptr(prev), N.ptr(xd), N.ptr(deriv), N.ptr(s0), N.ptr(s1),
+                                    N.ptr(prev2), B, n, st)); sync()
+    assert rel_err(prev2.cpu(), torch.from_numpy(g["step2"])) < 4 * F32_TOL
+    # CFG combine
+    w = torch.tensor([0.0, 3.0, 5.5])
+    wd = w.to(DEV)
+    N.check(L.ctta_cfg_combine(N.ptr(v1d), N.ptr(v2d), N.ptr(wd), N.ptr(out), B, n, st)); sync()
+    assert rel_err(out.cpu(), oheun.cfg_combine(v1, v2, w)) < F32_TOL
+    # SNR-weighted instance MSE, including sigma = 0 (clamped weight)
+    sg = torch.tensor([14.6146, 0.5, 0.0])
+    sgd = sg.to(DEV)
+    inst, loss = torch.empty(B, device=DEV), torch.empty(1, device=DEV)
+    N.check(L.ctta_snr_mse_loss(N.ptr(v1d), N.ptr(v2d), N.ptr(sgd), 5.0, N.ptr(inst), N.ptr(loss), B, n, st)); sync()
+    assert abs(float(loss.cpu()) - float(oheun.snr_mse_loss(v1, v2, sg, 5.0))) < 1e-6
+    # two-shadow EMA: bit-exact against the reference arithmetic
+    p = det("ema.p", (1003,), 1)
+    a, b = det("ema.a", (1003,), 2), det("ema.b", (1003,), 3)
+    pd, ad, bd = p.to(DEV), a.to(DEV), b.to(DEV)
+    N.check(L.ctta_ema_update2(N.ptr(pd), N.ptr(ad), 0.95, N.ptr(bd), 0.999, 1003, st)); sync()
+    ra = a.clone(); ra.add_((1. - 0.95) * (p - ra))
+    rb = b.clone(); rb.add_((1. - 0.999) * (p - rb))
+    assert torch.equal(ad.cpu(), ra) and torch.equal(bd.cpu(), rb)
+    # vocoder post-processing
+    wav = torch.tanh(det("wav", (2, 5000), 5) * 2) * 0.9 + 0.03
+    wd_ = wav.to(DEV)
+    scratch = torch.empty(4, device=DEV)
+    cen = torch.empty_like(wd_)
+    pcm = torch.empty(2, 5000, dtype=torch.int16, device=DEV)
+    N.check(L.ctta_wav_finalize(N.ptr(wd_), wav.numel(), N.ptr(scratch), N.ptr(cen), N.ptr(pcm), st)); sync()
+    ref = wav - (wav.max() + wav.min()) / 2
+    assert torch.equal(cen.cpu(), ref)
+    assert np.array_equal(pcm.cpu().numpy(), (ref.numpy() * 32768).astype("int16"))
+
+
+def test_errors_are_loud():
+    d = conv_desc()
+    with pytest.raises(N.CttaError):
+        N.check(lib().ctta_conv_gemm(ctypes.byref(d), N.stream_ptr()))

@@ -52,7 +52,7 @@ def test_heun_steps(golden):
     first, d, dt = heun.step_first(v1, x, sig[idx], sig[idx + 1])
     close(first, g["step1"], 1e-6, 1e-7)
     # 2nd-order call happens at timestep index idx+2, in second-order state:
-    # index_for_timestep returns (first match) - 1 = idx+1; sigma=sig[idx], sigma_next=sig[idx+1]
+    # index_for_timestep returns (last match) - 1 = idx+1; sigma=sig[idx], sigma_next=sig[idx+1]
     close(heun.scale_model_input(first, sig[idx + 2]), g["scaled2"], 1e-6, 1e-7)
     second = heun.step_second(v2, first, sig[idx + 1], x, d, dt)
     close(second, g["step2"], 1e-6, 1e-7)
