@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 10 s audio clips / second for single-step consistency generation
+(text states -> latent -> mel -> 16 kHz waveform; FLAN-T5 excluded) on N MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1] (SURVEY.md §8d "Config 2"): batch 32 per GPU, L = 32 text
+tokens with per-row valid lengths ~U{6..32}, guidance w = 4, one U-Net query, AudioLDM VAE
+decode, HiFi-GAN vocoder, int16 conversion.  A "step" is one such batch.  Clips are
+independent, so N GPUs run N replicas of the batch (weak scaling, no data-path collective);
+the only collectives are the timing barrier / max-reduce over RCCL.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     -- conv_gemm (the implicit-GEMM MFMA kernel family = >95 % of the step's FLOPs):
+                  algorithmic FLOPs per step / summed launch time per step, measured live with
+                  HIP events on the launch stream (ctta_prof_*), against the dense bf16 MFMA peak.
+  cpu_baseline -- the CPU oracle (fp32 PyTorch-CPU restatement of the reference) timed on this
+                  box's host cores for the same pipeline at B=1 (reference recipe, config 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# Algorithmic FLOPs per clip (2*MAC), SURVEY.md §2a / §8d "Algorithmic work per unit"
+GF_UNET_CONV, GF_UNET_LINEAR_L16, GF_UNET_LINEAR_PER_16TOK = 267.9, 163.2, 1.3
+GF_UNET_SELF_ATTN, GF_UNET_CROSS_ATTN_L16 = 97.6, 0.59
+GF_VAE_CONV, GF_VAE_ATTN = 636.1, 34.4
+GF_HIFIGAN = 1027.0
+GF_SMALL_N = 0.15 + 0.15 + 0.07          # conv_out (U-Net, VAE) and conv_post run on the direct kernel
+PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA peak, MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--text-len", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-csv", default=None, help="append one line per MFMA launch (tuning aid)")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from consistencytta_amd import _native as N
+    from consistencytta_amd import modules, spec
+    from consistencytta_amd.models import ConsistencyTTA
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, L = args.batch, args.text_len
+    # ---- models: light U-Net + AudioLDM-s VAE/vocoder architecture, random init (no checkpoints offline)
+    vae = modules.AutoencoderKL(ddconfig=spec.VAE_DDCONFIG, embed_dim=8, scale_factor=0.9227914214134216)
+    pipe = ConsistencyTTA(unet_config=spec.LIGHT_UNET_CONFIG, vae=vae)
+    pipe.to(dev)
+    pipe.unet.init_random_(seed=0)
+    vae.init_random_(seed=1)
+    pipe.eval().requires_grad_(False)
+
+    # ---- synthetic AudioCaps-shaped inputs, resident in HBM
+    g = torch.Generator(device="cpu").manual_seed(3 + rank)
+    enc = (torch.randn(B, L, 1024, generator=g) * 0.25).to(dev)
+    lens = torch.randint(6, L + 1, (B,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(dev)
+    noise = torch.randn(B, 8, 256, 16, generator=torch.Generator(device="cpu").manual_seed(4 + rank)).to(dev)
+    scratch = torch.empty(4, dtype=torch.float32, device=dev)
+    state = {}
+
+    def step():
+        lat = pipe.generate_latent(enc, mask, noise, cfg_scale_input=4.0, cfg_scale_post=1.0, num_steps=1)
+        mel = vae.decode_first_stage(lat)
+        wav = vae.vocode(mel)
+        pcm = state.get("pcm")
+        if pcm is None:
+            pcm = state["pcm"] = torch.empty(wav.shape, dtype=torch.int16, device=dev)
+        N.check(N.lib().ctta_wav_finalize(N.ptr(wav), wav.numel(), N.ptr(scratch), None, N.ptr(pcm), N.stream_ptr()))
+        return lat, mel, wav, pcm
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    lat, mel, wav, pcm = out
+    assert bool(torch.isfinite(wav).all()), "non-finite waveform"
+    clips_per_s = world * B * args.steps / dt
+
+    result = {
+        "metric": "10s_audio_clips_per_sec_1step_gen", "value": round(clips_per_s, 3), "unit": "clips/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "configs[1]: batch-32 single-step consistency inference, U-Net(light, 559M) + "
+                               "AudioLDM VAE decoder + HiFi-GAN, 10 s clips, L=32 text tokens, w=4, T5 excluded",
+                   "batch_per_gpu": B, "global_batch": B * world, "text_len": L, "latent": [8, 256, 16],
+                   "waveform_samples": int(wav.shape[1]), "weights": "random-init (no checkpoints offline)",
+                   "parallelism": "replicas x%d (clips sharded, no data-path collective)" % world},
+    }
+
+    if rank == 0:
+        # ---- per-stage split (HIP events on the current stream)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        ev[0].record()
+        l_ = pipe.generate_latent(enc, mask, noise, cfg_scale_input=4.0, cfg_scale_post=1.0, num_steps=1)
+        ev[1].record()
+        m_ = vae.decode_first_stage(l_)
+        ev[2].record()
+        vae.vocode(m_)
+        ev[3].record()
+        torch.cuda.synchronize()
+        result["stage_ms"] = {"unet": round(ev[0].elapsed_time(ev[1]), 3), "vae_decoder": round(ev[1].elapsed_time(ev[2]), 3),
+                              "hifigan": round(ev[2].elapsed_time(ev[3]), 3)}
+        # ---- roofline of the dominant kernel family, measured live with HIP events per launch
+        import ctypes
+        L_ = N.lib()
+        nprof = 2
+        L_.ctta_prof_enable(1)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        L_.ctta_prof_enable(0)
+        ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        csv = args.profile_csv.encode() if args.profile_csv else None
+        # attention first (keeps the CSV complete), then conv_gemm
+        import copy
+        N.check(L_.ctta_prof_collect(-1, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt), csv))
+        all_ms, all_fl, all_cnt = ms.value / nprof, fl.value / nprof, cnt.value // nprof
+        # second pass restricted to conv_gemm launches
+        L_.ctta_prof_enable(1)
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        L_.ctta_prof_enable(0)
+        N.check(L_.ctta_prof_collect(0, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt), None))
+        conv_ms, conv_exec_fl, conv_cnt = ms.value / nprof, fl.value / nprof, cnt.value // nprof
+        gf_clip = (GF_UNET_CONV + GF_UNET_LINEAR_L16 + GF_UNET_LINEAR_PER_16TOK * max(0, (L - 16) / 16.0)
+                   + GF_VAE_CONV + GF_VAE_ATTN + GF_HIFIGAN - GF_SMALL_N)
+        algo_flops = gf_clip * 1e9 * B
+        achieved = algo_flops / (conv_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "kernel": "conv_gemm_kernel (implicit-GEMM conv / linear / bmm, v_mfma_f32_16x16x32_bf16)",
+            "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "algorithmic_gflop_per_clip": round(gf_clip, 1), "launches_per_step": int(conv_cnt),
+            "kernel_ms_per_step": round(conv_ms, 3), "avg_launch_ms": round(conv_ms / max(1, conv_cnt), 4),
+            "executed_tflops_incl_padding": round(conv_exec_fl / (conv_ms * 1e-3) / 1e12, 2),
+            "share_of_step_time": round(conv_ms / (dt / args.steps * 1e3), 3),
+            "mfma_launch_ms_per_step_all_kinds": round(all_ms, 3),
+        }
+        # ---- PCIe-inclusive variant (the reference's decode_to_waveform ends on the host)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(2):
+            step()[3].cpu()
+        torch.cuda.synchronize()
+        result["pcie_inclusive_clips_per_s"] = round(2 * B / (time.perf_counter() - t1), 3)
+
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(pipe, vae, enc, mask, noise)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(pipe, vae, enc, mask, noise):
+    """The CPU oracle on this box's host cores: B=1, fp32, the easy_inference recipe
+    (1 U-Net query at t=999, w=4, VAE decode, HiFi-GAN), same weights as the GPU leg."""
+    import torch
+    from consistencytta_amd import spec
+    from oracle import heun as oheun
+    from oracle import nets as onets
+
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    usd = {k: v.detach().float().cpu() for k, v in pipe.unet.state_dict().items()}
+    vsd = {k: v.detach().float().cpu() for k, v in vae.state_dict().items()}
+    _, sig = oheun.set_timesteps(18)
+    sigma = torch.tensor([float(sig[0])])
+    e, m, nz = enc[:1].cpu(), mask[:1].cpu(), noise[:1].cpu()
+
+    def clip():
+        with torch.no_grad():
+            z = oheun.scale_model_input(nz * sigma, sigma)
+            lat = onets.unet_forward(spec.LIGHT_UNET_CONFIG, usd, z, 999.0, 4.0, e, m)
+            mel = onets.vae_decode(spec.VAE_DDCONFIG, vsd, lat, float(vae.scale_factor))
+            return onets.mel_to_waveform(spec.HIFIGAN_16K_64, vsd, mel)[2]
+
+    clip()  # warm-up
+    n = 3
+    t0 = time.perf_counter()
+    for _ in range(n):
+        clip()
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "clips/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d clips at B=1 (config 1: 1-step, w=4, L=%d), fp32 PyTorch-CPU oracle, %.1f s"
+                      % (n, e.shape[1], dt)}
+
+
+if __name__ == "__main__":
+    main()

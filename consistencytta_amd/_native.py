@@ -125,6 +125,8 @@ SIGNATURES = {
     "ctta_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_time_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "ctta_fourier_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "ctta_prof_enable": (None, [c_int]),
+    "ctta_prof_collect": (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_char_p]),
 }
 
 _lib = None

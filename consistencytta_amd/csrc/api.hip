@@ -14,3 +14,59 @@ void ctta_set_error(const char* fmt, ...) {
 
 extern "C" const char* ctta_last_error(void) { return g_err; }
 extern "C" int ctta_version(void) { return 100; }
+
+// ------------------------------------------------------------------------------------------
+// Opt-in launch profiler: brackets conv_gemm / attention launches with HIP events ON THE
+// LAUNCH STREAM (bench.py's live roofline measurement; off by default, zero cost when off).
+#include <mutex>
+#include <vector>
+
+struct ProfRec { hipEvent_t a, b; int kind, variant; long long m, n, k, groups; double flops; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static std::mutex g_prof_mu;
+
+bool ctta_prof_active() { return g_prof_on; }
+
+void ctta_prof_begin(int kind, int variant, long long m, long long n, long long k, long long groups,
+                     hipStream_t s) {
+  ProfRec r;
+  r.kind = kind; r.variant = variant; r.m = m; r.n = n; r.k = k; r.groups = groups;
+  r.flops = 2.0 * (double)m * (double)n * (double)k * (double)groups;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+  (void)hipEventRecord(r.a, s);
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof.push_back(r);
+}
+void ctta_prof_end(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof.empty()) (void)hipEventRecord(g_prof.back().b, s);
+}
+
+extern "C" void ctta_prof_enable(int on) { g_prof_on = on != 0; }
+
+// Synchronises, sums the records of `kind` (0 conv_gemm, 1 attention, -1 all), optionally appends
+// one CSV line per launch to `csv_path`, and clears the log.
+extern "C" ctta_status ctta_prof_collect(int kind, double* total_ms, double* total_flops, int64_t* launches,
+                                         const char* csv_path) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double ms = 0.0, fl = 0.0;
+  int64_t cnt = 0;
+  FILE* f = csv_path ? fopen(csv_path, "a") : nullptr;
+  for (ProfRec& r : g_prof) {
+    float t = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) {
+      if (kind < 0 || kind == r.kind) { ms += t; fl += r.flops; ++cnt; }
+      if (f) fprintf(f, "%d,%d,%lld,%lld,%lld,%lld,%.6f,%.3f\n", r.kind, r.variant, r.m, r.n, r.k, r.groups, t,
+                     r.flops / (t * 1e-3) / 1e12);
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  if (f) fclose(f);
+  g_prof.clear();
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (launches) *launches = cnt;
+  return CTTA_OK;
+}

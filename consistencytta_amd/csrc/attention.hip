@@ -202,9 +202,13 @@ extern "C" ctta_status ctta_attention(const void* q, int q_ld, const void* k, in
                "attention: row strides must be multiples of 8");
   CTTA_REQUIRE(nq > 0 && nk > 0 && k_rows >= nk && vt_ld >= ((nk + 7) / 8) * 8, "attention: bad lengths nq=%d nk=%d vt_ld=%d", nq, nk, vt_ld);
   dim3 grid((nq + 127) / 128, batch * heads);
+  const bool prof = ctta_prof_active();
+  // executed flops: QK^T and PV over the padded head dim (2 * 2*nq*nk*64 per head)
+  if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
   hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
                      (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, bias, (bf16_t*)out, out_ld, heads,
                      nq, nk, scale * 1.4426950408889634f);
+  if (prof) ctta_prof_end((hipStream_t)stream);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

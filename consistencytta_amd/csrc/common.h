@@ -55,6 +55,9 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // ---- host side ---------------------------------------------------------------------------
 void ctta_set_error(const char* fmt, ...);
+bool ctta_prof_active();
+void ctta_prof_begin(int kind, int variant, long long m, long long n, long long k, long long groups, hipStream_t s);
+void ctta_prof_end(hipStream_t s);
 
 #define CTTA_CHECK_HIP(expr)                                                         \
   do {                                                                               \

@@ -374,7 +374,10 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   CTTA_REQUIRE((long long)p.nk * v.bk <= d->k_pad, "conv_gemm: k_pad too small for BK");
   CTTA_TRY(v.prepare());
   dim3 grid((unsigned)((M + v.bm - 1) / v.bm), (unsigned)((d->n + v.bn - 1) / v.bn), (unsigned)groups);
+  const bool prof = ctta_prof_active();
+  if (prof) ctta_prof_begin(0, vid, M, d->n, K, groups, (hipStream_t)stream);
   v.launch(p, grid, (hipStream_t)stream);
+  if (prof) ctta_prof_end((hipStream_t)stream);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

@@ -51,6 +51,17 @@ class _ParamTree(nn.Module):
                 p.copy_(torch.from_numpy(spec.det_weight(prefix + k, tuple(p.shape), seed)).to(p.device))
         return self
 
+    def init_random_(self, seed=0, prefix=""):
+        """Fast on-device random init with the same scale rule (benchmarks: values need not be
+        reproducible across boxes, only well-conditioned)."""
+        gen = torch.Generator(device=self.device if hasattr(self, "device") else "cpu")
+        gen.manual_seed(seed)
+        with torch.no_grad():
+            for k, p in self.named_parameters():
+                off, amp = spec.weight_rule(prefix + k, tuple(p.shape))
+                p.copy_(off + amp * (torch.rand(p.shape, generator=gen, device=p.device) * 2 - 1))
+        return self
+
     def _weights_version(self):
         return sum(p._version for p in self.parameters()) + 1000003 * sum(
             p.data_ptr() % 1000003 for p in self.parameters())

@@ -279,21 +279,21 @@ def det_uniform(name, shape, seed=0):
     return (u * np.float32(2.0) - np.float32(1.0)).reshape(shape)
 
 
-def det_weight(name, shape, seed=0):
-    """Random-init value for a parameter, by name class.  Scales are chosen so that
-    activations stay O(1) through ~100 layers (unit-gain fan-in init, damped residual
-    branches); there is no checkpoint on either box (no network), see BASELINE.md §3."""
+def weight_rule(name, shape):
+    """(offset, amplitude) of the random-init value `offset + amplitude * u`, u ~ U[-1,1), by
+    name class.  Scales are chosen so that activations stay O(1) through ~100 layers (unit-gain
+    fan-in init, damped residual branches); there is no checkpoint on either box (no network),
+    see BASELINE.md §3."""
     shape = tuple(shape)
-    u = det_uniform(name, shape, seed)
     leaf = name.rsplit(".", 1)[-1]
     if name.endswith("guidance_proj.weight"):
-        return (u * np.float32(np.sqrt(3.0))).astype(np.float32)  # ~ unit variance
+        return 0.0, float(np.sqrt(3.0))  # ~ unit variance
     is_norm = any(t in name for t in (".norm", "norm1.", "norm2.", "norm3.", "norm_out",
                                       "conv_norm_out", "norm."))
     if len(shape) == 1:
         if is_norm and leaf == "weight":
-            return (np.float32(1.0) + np.float32(0.2) * u).astype(np.float32)
-        return (np.float32(0.05) * u).astype(np.float32)  # biases
+            return 1.0, 0.2
+        return 0.0, 0.05  # biases
     if "vocoder.ups." in name:
         # ConvTranspose1d weight (Cin, Cout, k): each output sees Cin * k/u taps
         fan_in = shape[0] * max(1, shape[2] // 2)
@@ -302,8 +302,14 @@ def det_weight(name, shape, seed=0):
     gain = 1.0
     if any(t in name for t in ("conv2.", "to_out.0.", "ff.net.2.", "proj_out.", "convs2.")):
         gain = 0.5  # residual-branch outputs
-    a = np.float32(gain * np.sqrt(3.0 / fan_in))
-    return (a * u).astype(np.float32)
+    return 0.0, float(gain * np.sqrt(3.0 / fan_in))
+
+
+def det_weight(name, shape, seed=0):
+    """Deterministic random-init value for a parameter (see weight_rule)."""
+    off, amp = weight_rule(name, shape)
+    u = det_uniform(name, tuple(shape), seed)
+    return (np.float32(off) + np.float32(amp) * u).astype(np.float32)
 
 
 def det_state_dict(spec, seed=0, prefix=""):

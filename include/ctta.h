@@ -273,6 +273,14 @@ ctta_status ctta_time_features(const float* t, const float* freqs, int dim, int 
 ctta_status ctta_fourier_features(const double* w, const float* weight, int half, int flip,
                                   float* out, int batch, void* stream);
 
+/* Opt-in launch profiler (bench.py's live roofline leg): when enabled, every conv_gemm (kind 0)
+ * and attention (kind 1) launch is bracketed by hipEvents on its own stream.  collect() waits
+ * for the recorded launches, returns their summed duration / executed FLOPs / count, optionally
+ * appends one CSV line per launch (kind,variant,m,n,k,groups,ms,tflops) and clears the log. */
+void ctta_prof_enable(int on);
+ctta_status ctta_prof_collect(int kind, double* total_ms, double* total_flops, int64_t* launches,
+                              const char* csv_path);
+
 #ifdef __cplusplus
 }
 #endif

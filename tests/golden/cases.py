@@ -21,7 +21,7 @@ TINY_UNET = dict(spec.LIGHT_UNET_CONFIG,
 TINY_VAE_DD = dict(spec.VAE_DDCONFIG, ch=32)
 TINY_VAE_GROUPS = 32  # Normalize() hard-codes 32 groups (modules.py:38-41): ch=32 -> 1 ch/group
 
-TINY_HIFIGAN = dict(spec.HIFIGAN_16K_64, upsample_initial_channel=64)
+TINY_HIFIGAN = dict(spec.HIFIGAN_16K_64, upsample_initial_channel=256)  # 128,64,32,16,8 channels
 
 SIGMA_MAX = 14.6146
 

@@ -155,8 +155,10 @@ def test_scheduler_mirror_matches_reference_tables_and_steps(golden):
     for n in (1, 2, 18, 200):
         s.set_timesteps(n, device=DEV)
         assert np.array_equal(s.timesteps.cpu().numpy(), g["timesteps_%d" % n])
-        assert np.array_equal(s.sigmas.cpu().numpy(), g["sigmas_%d" % n])
-        assert float(s.init_noise_sigma) == float(g["init_sigma_%d" % n])
+        # sigmas come from fp32 torch.linspace/cumprod on the HOST cpu: last-bit differences between
+        # CPU models (FMA / vector width) are the reference's own, hence 1e-6 instead of equality
+        np.testing.assert_allclose(s.sigmas.cpu().numpy(), g["sigmas_%d" % n], rtol=1e-6, atol=0)
+        assert abs(float(s.init_noise_sigma) - float(g["init_sigma_%d" % n])) <= 1e-6 * float(g["init_sigma_%d" % n])
     s.set_timesteps(18, device=DEV)
     idx = torch.from_numpy(g["idx"])
     x = (cases.t(spec.det_uniform("heun.x", (3, 8, 16, 4), 1)) * 3).to(DEV)

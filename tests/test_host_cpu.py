@@ -92,7 +92,7 @@ def test_scheduler_host_tables_match_reference(golden):
     for n in (1, 2, 18, 200):
         s.set_timesteps(n)
         assert np.array_equal(s.timesteps.numpy(), g["timesteps_%d" % n])
-        assert np.array_equal(s.sigmas.numpy(), g["sigmas_%d" % n])
+        np.testing.assert_allclose(s.sigmas.numpy(), g["sigmas_%d" % n], rtol=1e-6, atol=0)  # host-CPU fp32
     s.set_timesteps(18)
     assert len(s.timesteps) == 35 and len(s.sigmas) == 36 and s.state_in_first_order
     # last-match semantics of index_for_timestep (mask * arange argmax)

@@ -31,8 +31,9 @@ def test_heun_tables(golden):
     for n in (1, 2, 18, 200):
         ts, sig = heun.set_timesteps(n)
         np.testing.assert_array_equal(ts, g["timesteps_%d" % n])
-        np.testing.assert_array_equal(sig, g["sigmas_%d" % n])
-        assert float(sig.max()) == float(g["init_sigma_%d" % n])
+        # fp32 torch.linspace/cumprod on the host: last-bit differences between CPU models allowed
+        np.testing.assert_allclose(sig, g["sigmas_%d" % n], rtol=1e-6, atol=0)
+        assert abs(float(sig.max()) - float(g["init_sigma_%d" % n])) <= 1e-6 * float(sig.max())
     ts, sig = heun.set_timesteps(18)
     assert len(ts) == 35 and len(sig) == 36
     assert abs(float(sig[0]) - 14.6146) < 1e-3
