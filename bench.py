@@ -52,23 +52,20 @@ def parse():
 def main():
     args = parse()
     import torch
-    import torch.distributed as dist
 
     from consistencytta_amd import _native as N
+    from consistencytta_amd import dist_util as du
     from consistencytta_amd import modules, spec
     from consistencytta_amd.models import ConsistencyTTA
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank = du.env_world()
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    du.init("nccl", dev)   # "nccl" is RCCL on ROCm; only used for the timing barrier / max-reduce
 
     B, L = args.batch, args.text_len
     # ---- models: light U-Net + AudioLDM-s VAE/vocoder architecture, random init (no checkpoints offline)
@@ -98,24 +95,14 @@ def main():
         N.check(N.lib().ctta_wav_finalize(N.ptr(wav), wav.numel(), N.ptr(scratch), None, N.ptr(pcm), N.stream_ptr()))
         return lat, mel, wav, pcm
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
-    barrier()
+    du.barrier(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    du.barrier(dev)
+    dt = du.max_over_ranks(time.perf_counter() - t0, dev)
     lat, mel, wav, pcm = out
     assert bool(torch.isfinite(wav).all()), "non-finite waveform"
     clips_per_s = world * B * args.steps / dt
@@ -157,7 +144,6 @@ def main():
         ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         csv = args.profile_csv.encode() if args.profile_csv else None
         # attention first (keeps the CSV complete), then conv_gemm
-        import copy
         N.check(L_.ctta_prof_collect(-1, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt), csv))
         all_ms, all_fl, all_cnt = ms.value / nprof, fl.value / nprof, cnt.value // nprof
         # second pass restricted to conv_gemm launches
@@ -193,9 +179,20 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(pipe, vae, enc, mask, noise)
         print(json.dumps(result), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    du.finish()
+
+
+def host_cores():
+    """Cores this process may really use: affinity mask, capped by the cgroup CPU quota and at 64
+    (B=1 convolutions stop scaling long before that; oversubscribed OpenMP teams crawl)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 64))
 
 
 def cpu_baseline(pipe, vae, enc, mask, noise):
@@ -206,7 +203,7 @@ def cpu_baseline(pipe, vae, enc, mask, noise):
     from oracle import heun as oheun
     from oracle import nets as onets
 
-    threads = os.cpu_count() or 1
+    threads = host_cores()
     torch.set_num_threads(threads)
     usd = {k: v.detach().float().cpu() for k, v in pipe.unet.state_dict().items()}
     vsd = {k: v.detach().float().cpu() for k, v in vae.state_dict().items()}
@@ -221,8 +218,10 @@ def cpu_baseline(pipe, vae, enc, mask, noise):
             mel = onets.vae_decode(spec.VAE_DDCONFIG, vsd, lat, float(vae.scale_factor))
             return onets.mel_to_waveform(spec.HIFIGAN_16K_64, vsd, mel)[2]
 
-    clip()  # warm-up
-    n = 3
+    t0 = time.perf_counter()
+    clip()  # warm-up (also bounds the sample: a slow host times just one more clip)
+    warm = time.perf_counter() - t0
+    n = 3 if warm < 8.0 else 1
     t0 = time.perf_counter()
     for _ in range(n):
         clip()

@@ -64,8 +64,9 @@ class ConvDesc(Structure):
         ("w", c_void_p), ("k_pad", c_int), ("n", c_int),
         ("bias", c_void_p), ("bias_m", c_void_p), ("rowvec", c_void_p), ("rowvec_ld", c_int),
         ("res", c_void_p), ("res_ld", c_int),
-        ("in_act", c_int), ("in_slope", c_float), ("out_act", c_int), ("alpha", c_float),
-        ("accumulate", c_int), ("out", c_void_p), ("ldc", c_int), ("out_f32", c_int),
+        ("in_act", c_int), ("in_slope", c_float), ("out_act", c_int), ("out_slope", c_float),
+        ("alpha", c_float), ("accumulate", c_int), ("out", c_void_p), ("ldc", c_int), ("out_f32", c_int),
+        ("out2", c_void_p), ("out2_slope", c_float),
         ("out_batch_stride", c_int64), ("out_offset", c_int64), ("out_limit", c_int64),
         ("groups", c_int), ("x_group_stride", c_int64), ("w_group_stride", c_int64),
         ("out_group_stride", c_int64), ("tile", c_int),

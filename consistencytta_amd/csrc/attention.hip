@@ -19,14 +19,15 @@
 #include <math.h>
 
 #define ATT_KT 64          // keys per tile
-#define ATT_LD 72          // LDS row stride in bf16 (64 + 8 pad)
+#define ATT_LDK 80         // K tile row stride (bf16): 160 B rows are conflict-free for ds_read_b128
+#define ATT_LDV 72         // V^T tile row stride: 144 B rows are conflict-free for the paired ds_read_b64
 
 __global__ __launch_bounds__(256, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int q_ld, const bf16_t* __restrict__ k, int k_ld, int k_rows,
     const bf16_t* __restrict__ vt, int vt_ld, const float* __restrict__ bias,
     bf16_t* __restrict__ out, int out_ld, int heads, int nq, int nk, float scale_log2e) {
-  __shared__ __attribute__((aligned(16))) bf16_t Ks[ATT_KT * ATT_LD];   // [key][d]
-  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * ATT_LD];       // [d][key]
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[ATT_KT * ATT_LDK];   // [key][d]
+  __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * ATT_LDV];       // [d][key]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y;
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
       const int r = chunk >> 3, cc = (chunk & 7) * 8;
       uint4 kv = make_uint4(0, 0, 0, 0);
       if (key0 + r < nk) kv = *reinterpret_cast<const uint4*>(kb + (size_t)(key0 + r) * k_ld + cc);
-      *reinterpret_cast<uint4*>(Ks + r * ATT_LD + cc) = kv;
+      *reinterpret_cast<uint4*>(Ks + r * ATT_LDK + cc) = kv;
       uint4 vv = make_uint4(0, 0, 0, 0);
       const int valid = nk - (key0 + cc);   // keys of this chunk that exist
       if (valid > 0) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
           vv = make_uint4(wv[0], wv[1], wv[2], wv[3]);
         }
       }
-      *reinterpret_cast<uint4*>(Vs + r * ATT_LD + cc) = vv;
+      *reinterpret_cast<uint4*>(Vs + r * ATT_LDV + cc) = vv;
     }
     __syncthreads();
 
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 #pragma unroll
       for (int ds = 0; ds < 2; ++ds) {
         const bf16x8_t kf = __builtin_bit_cast(
-            bf16x8_t, *reinterpret_cast<const uint4*>(Ks + (ik * 16 + lq) * ATT_LD + ds * 32 + lg * 8));
+            bf16x8_t, *reinterpret_cast<const uint4*>(Ks + (ik * 16 + lq) * ATT_LDK + ds * 32 + lg * 8));
 #pragma unroll
         for (int jq = 0; jq < 2; ++jq)
           s[ik][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[jq][ds], s[ik][jq], 0, 0, 0);
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
       }
 #pragma unroll
       for (int jd = 0; jd < 4; ++jd) {
-        const bf16_t* vr = Vs + (jd * 16 + lq) * ATT_LD + kk * 32 + lg * 4;
+        const bf16_t* vr = Vs + (jd * 16 + lq) * ATT_LDV + kk * 32 + lg * 4;
         const uint2 lo = *reinterpret_cast<const uint2*>(vr);        // keys (2kk)*16 + lg*4 ..+3
         const uint2 hi = *reinterpret_cast<const uint2*>(vr + 16);   // keys (2kk+1)*16 + lg*4 ..+3
         const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));

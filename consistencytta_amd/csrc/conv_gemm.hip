@@ -29,8 +29,8 @@ struct ConvParams {
   const bf16_t* w; int k_pad, n, nk;
   const float* bias; const float* bias_m; const float* rowvec; int rowvec_ld;
   const bf16_t* res; int res_ld;
-  int in_act; float in_slope; int out_act; float alpha; int accumulate;
-  void* out; int ldc; int out_f32;
+  int in_act; float in_slope; int out_act; float out_slope; float alpha; int accumulate;
+  void* out; int ldc; int out_f32; bf16_t* out2; float out2_slope; int scalar_store;
   long long obs, out_offset, out_limit;
   long long xgs, wgs, ogs;
 };
@@ -38,7 +38,11 @@ struct ConvParams {
 template <int BM, int BN, int BK, int WM, int WN>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p) {
   constexpr int NT = 64 * WM * WN;
-  constexpr int LDK = BK + 8;          // bf16 elements per LDS row (16 B pad)
+  constexpr int LDK = BK;              // bf16 elements per LDS row: no padding, XOR-swizzled chunks
+  // 16-byte chunk c of row r lives at chunk position c ^ swz(r): conflict-free for the 16-lane
+  // groups of ds_read_b128 (rows r..r+15 at one logical chunk) and for the row-contiguous writes.
+  constexpr int SWZ_SHIFT = (BK == 64) ? 0 : 1;
+  constexpr int SWZ_MASK = BK / 8 - 1;
   constexpr int CPR = BK / 8;          // 16-byte chunks per row
   constexpr int RPP = NT / CPR;        // rows staged per pass
   constexpr int XP = BM / RPP;
@@ -154,11 +158,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         for (int e = 0; e < 8; ++e) f[e] = f[e] > 0.f ? f[e] : f[e] * p.in_slope;
         v = pack8(f);
       }
-      *reinterpret_cast<uint4*>(xs + (r0 + i * RPP) * LDK + kc * 8) = v;
+      const int r = r0 + i * RPP;
+      *reinterpret_cast<uint4*>(xs + r * LDK + ((kc ^ ((r >> SWZ_SHIFT) & SWZ_MASK)) * 8)) = v;
     }
 #pragma unroll
-    for (int j = 0; j < WP; ++j)
-      *reinterpret_cast<uint4*>(ws + (r0 + j * RPP) * LDK + kc * 8) = wr[j];
+    for (int j = 0; j < WP; ++j) {
+      const int r = r0 + j * RPP;
+      *reinterpret_cast<uint4*>(ws + r * LDK + ((kc ^ ((r >> SWZ_SHIFT) & SWZ_MASK)) * 8)) = wr[j];
+    }
   };
 
   f32x4_t acc[FN][FM];
@@ -168,7 +175,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15;
-  const int fk = (lane >> 4) * 8;
+  const int fchunk = lane >> 4;                       // logical 16-byte chunk within a 32-wide k-slab
+  const int fswz = (frow >> SWZ_SHIFT) & SWZ_MASK;    // tile/frag row offsets are multiples of 16
 
   load_tile(0);
   store_tile(0);
@@ -177,19 +185,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   for (int kt = 0; kt < p.nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < p.nk) load_tile(kt + 1);
-    const bf16_t* xs = Xs + buf * BM * LDK + (wm * TM + frow) * LDK + fk;
-    const bf16_t* ws = Ws + buf * BN * LDK + (wn * TN + frow) * LDK + fk;
+    const bf16_t* xs = Xs + buf * BM * LDK + (wm * TM + frow) * LDK;
+    const bf16_t* ws = Ws + buf * BN * LDK + (wn * TN + frow) * LDK;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8_t af[FN], bfr[FM];
+      const int koff = (((ks * 4 + fchunk) ^ fswz) & SWZ_MASK) * 8;
 #pragma unroll
       for (int i = 0; i < FN; ++i)
-        af[i] = __builtin_bit_cast(bf16x8_t,
-                                   *reinterpret_cast<const uint4*>(ws + i * 16 * LDK + ks * 32));
+        af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ws + i * 16 * LDK + koff));
 #pragma unroll
       for (int j = 0; j < FM; ++j)
-        bfr[j] = __builtin_bit_cast(bf16x8_t,
-                                    *reinterpret_cast<const uint4*>(xs + j * 16 * LDK + ks * 32));
+        bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xs + j * 16 * LDK + koff));
 #pragma unroll
       for (int i = 0; i < FN; ++i)
 #pragma unroll
@@ -217,8 +224,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       const size_t oidx = (size_t)((long long)g * p.ogs + (long long)b * p.obs + inb);
       float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
       if (p.bias) {
-        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-        v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        if (p.scalar_store) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) if (n + r < p.n) v[r] += p.bias[n + r];
+        } else {
+          const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        }
       }
       if (p.bias_m) {
         const float bm = p.bias_m[m];
@@ -233,6 +245,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
         v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
       }
+      if (p.scalar_store) {
+        // tiny Cout (ldc not a multiple of 4): element-wise fp32 / bf16 stores of the valid channels
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (n + r >= p.n) continue;
+          float t = v[r] * p.alpha;
+          if (p.out_act == 1) t = silu_f(t);
+          else if (p.out_act == 2) t = tanhf(t);
+          else if (p.out_act == 3) t = t > 0.f ? t : t * p.out_slope;
+          if (p.out_f32) reinterpret_cast<float*>(p.out)[oidx + r] = t;
+          else reinterpret_cast<bf16_t*>(p.out)[oidx + r] = f2bf(t);
+        }
+        continue;
+      }
       if (p.out_f32) {
         float* o = reinterpret_cast<float*>(p.out) + oidx;
         if (p.accumulate) {
@@ -244,6 +270,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
           v[r] *= p.alpha;
           if (p.out_act == 1) v[r] = silu_f(v[r]);
           else if (p.out_act == 2) v[r] = tanhf(v[r]);
+          else if (p.out_act == 3) v[r] = v[r] > 0.f ? v[r] : v[r] * p.out_slope;
         }
         *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
       } else {
@@ -258,11 +285,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
           v[r] *= p.alpha;
           if (p.out_act == 1) v[r] = silu_f(v[r]);
           else if (p.out_act == 2) v[r] = tanhf(v[r]);
+          else if (p.out_act == 3) v[r] = v[r] > 0.f ? v[r] : v[r] * p.out_slope;
         }
         uint2 pk;
         pk.x = pack2bf(v[0], v[1]);
         pk.y = pack2bf(v[2], v[3]);
         *reinterpret_cast<uint2*>(o) = pk;
+        if (p.out2) {   // second output: leaky_relu of the SAME (bf16-rounded) values, for the next conv's input
+          float w[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float q = bf2f(f2bf(v[r]));
+            w[r] = q > 0.f ? q : q * p.out2_slope;
+          }
+          uint2 pk2;
+          pk2.x = pack2bf(w[0], w[1]);
+          pk2.y = pack2bf(w[2], w[3]);
+          *reinterpret_cast<uint2*>(p.out2 + oidx) = pk2;
+        }
       }
     }
   }
@@ -277,7 +317,7 @@ struct Variant {
 };
 
 template <int BM, int BN, int BK, int WM, int WN>
-static constexpr size_t smem_bytes() { return (size_t)2 * (BM + BN) * (BK + 8) * 2; }
+static constexpr size_t smem_bytes() { return (size_t)2 * (BM + BN) * BK * 2; }
 
 template <int BM, int BN, int BK, int WM, int WN>
 static void launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
@@ -332,14 +372,18 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   CTTA_REQUIRE(d->c0 > 0 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->c1 >= 0,
                "conv_gemm: channel counts must be multiples of 8 (c0=%d c1=%d)", d->c0, d->c1);
   CTTA_REQUIRE(d->n > 0, "conv_gemm: n=%d must be positive", d->n);
-  CTTA_REQUIRE(d->n % 4 == 0 || (!d->bias && !d->rowvec && !d->res && !d->accumulate && !d->out_limit &&
-                                 (d->n + 3) / 4 * 4 <= d->ldc),
+  const bool scalar_store = d->ldc % 4 != 0;
+  CTTA_REQUIRE(scalar_store || d->n % 4 == 0 ||
+                   (!d->bias && !d->rowvec && !d->res && !d->accumulate && !d->out_limit && (d->n + 3) / 4 * 4 <= d->ldc),
                "conv_gemm: n=%d must be a multiple of 4 for this epilogue", d->n);
+  CTTA_REQUIRE(!scalar_store || (!d->rowvec && !d->res && !d->accumulate && !d->out2 && !d->out_limit && d->out_offset == 0),
+               "conv_gemm: scalar-store mode (ldc %% 4 != 0) supports only bias/bias_m epilogues");
+  CTTA_REQUIRE(!d->out2 || !d->out_f32, "conv_gemm: out2 needs a bf16 primary output");
   CTTA_REQUIRE(d->k_pad % 64 == 0, "conv_gemm: k_pad=%d must be a multiple of 64", d->k_pad);
   CTTA_REQUIRE(d->kh >= 1 && d->kw >= 1 && d->stride_h >= 1 && d->stride_w >= 1 && d->dil_h >= 1 &&
                    d->dil_w >= 1, "conv_gemm: bad kernel geometry");
   CTTA_REQUIRE(!d->upsample || (d->hi % 2 == 0 && d->wi % 2 == 0), "conv_gemm: odd upsample extent");
-  CTTA_REQUIRE(d->ldc % 4 == 0 && d->out_offset % 4 == 0, "conv_gemm: ldc/out_offset must be multiples of 4");
+  CTTA_REQUIRE(d->out_offset % 4 == 0, "conv_gemm: out_offset must be a multiple of 4");
   CTTA_REQUIRE(!d->res || d->res_ld % 4 == 0, "conv_gemm: res_ld must be a multiple of 4");
   CTTA_REQUIRE(!d->rowvec || d->rowvec_ld % 4 == 0, "conv_gemm: rowvec_ld must be a multiple of 4");
   ConvParams p;
@@ -359,7 +403,8 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   CTTA_REQUIRE(K <= d->k_pad, "conv_gemm: K=%lld exceeds k_pad=%d", K, d->k_pad);
   p.bias = d->bias; p.bias_m = d->bias_m; p.rowvec = d->rowvec; p.rowvec_ld = d->rowvec_ld;
   p.res = (const bf16_t*)d->res; p.res_ld = d->res_ld;
-  p.in_act = d->in_act; p.in_slope = d->in_slope; p.out_act = d->out_act;
+  p.in_act = d->in_act; p.in_slope = d->in_slope; p.out_act = d->out_act; p.out_slope = d->out_slope;
+  p.out2 = (bf16_t*)d->out2; p.out2_slope = d->out2_slope; p.scalar_store = scalar_store ? 1 : 0;
   p.alpha = d->alpha; p.accumulate = d->accumulate;
   p.out = d->out; p.ldc = d->ldc; p.out_f32 = d->out_f32;
   p.obs = d->out_batch_stride ? d->out_batch_stride : (long long)p.howo * d->ldc;

@@ -79,7 +79,7 @@ struct ctta_vae {
   std::vector<std::vector<VaeRes>> up;     // [level][block]
   std::vector<ConvLayer> upsample;         // [level] (level 0 unused)
   GNLayer norm_out;
-  float *conv_out_w = nullptr, *conv_out_b = nullptr;
+  ConvLayer conv_out;
   int block_in = 0, c_last = 0;
   float* gn_scratch = nullptr;
   size_t gn_scratch_floats = 0;
@@ -237,8 +237,16 @@ static ctta_status vae_forward_impl(ctta_vae* V, bool dry, const float* z, int B
   }
   bf16_t* a = A.get<bf16_t>((size_t)B * H * W * ch); ALLOC_OR_FAIL(a);
   CTTA_TRY(vgn(c, V->norm_out, h, a, H * W, true));
-  RUN(c, ctta_conv_small_n(a, ch, B, H, W, 3, 3, 1, 1, V->conv_out_w, V->conv_out_b, cfg.out_ch, 0, 0.f, 0, mel,
-                           nullptr, stream));
+  {  // conv_out (Cout = out_ch = 1): MFMA kernel with element-wise fp32 stores; NCHW with C=1 == [m]
+    ctta_conv_desc d;
+    desc_init(&d);
+    d.x0 = a; d.c0 = ch;
+    d.batch = B; d.hi = H; d.wi = W; d.ho = H; d.wo = W;
+    d.kh = 3; d.kw = 3; d.pad_h = d.pad_w = 1;
+    d.w = V->conv_out.p.w; d.k_pad = V->conv_out.p.k_pad; d.n = cfg.out_ch; d.bias = V->conv_out.p.bias;
+    d.out = mel; d.ldc = cfg.out_ch; d.out_f32 = 1;
+    RUN(c, ctta_conv_gemm(&d, c.stream));
+  }
   if (gn_need) *gn_need = c.gn_need;
   return CTTA_OK;
 }
@@ -276,8 +284,7 @@ static ctta_status vae_build(ctta_vae* V) {
   }
   V->c_last = block_in;
   CTTA_TRY(make_gn(ws, p + "norm_out.", block_in, &V->norm_out));
-  CTTA_TRY(add_small_conv_w(ws, p + "conv_out.weight", cfg.out_ch, block_in, 9, &V->conv_out_w));
-  CTTA_TRY(ws.add_vector(p + "conv_out.bias", cfg.out_ch, &V->conv_out_b));
+  CTTA_TRY(make_conv(ws, p + "conv_out.", cfg.out_ch, block_in, block_in, 3, 3, 1, 1, &V->conv_out));
   return CTTA_OK;
 }
 
@@ -286,7 +293,7 @@ extern "C" ctta_status ctta_vae_create(const ctta_vae_config* cfg, const ctta_te
   CTTA_REQUIRE(cfg && weights && out, "vae_create: null pointer");
   CTTA_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= CTTA_MAX_LEVELS, "vae_create: n_levels=%d", cfg->n_levels);
   CTTA_REQUIRE(cfg->embed_dim <= 16 && cfg->z_channels <= 32, "vae_create: z_channels/embed_dim too large");
-  CTTA_REQUIRE(cfg->out_ch == 1 || cfg->out_ch == 2 || cfg->out_ch == 4 || cfg->out_ch == 8, "vae_create: out_ch=%d", cfg->out_ch);
+  CTTA_REQUIRE(cfg->out_ch == 1, "vae_create: out_ch=%d (only the 1-channel mel decoder is built)", cfg->out_ch);
   CTTA_REQUIRE(cfg->ch % 32 == 0, "vae_create: ch=%d must be a multiple of 32 (GroupNorm(32))", cfg->ch);
   CTTA_REQUIRE(cfg->scale_factor != 0.f, "vae_create: scale_factor is zero");
   hipStream_t s = (hipStream_t)stream;
@@ -413,17 +420,28 @@ static ctta_status make_convt1d(WeightStore& ws, const std::string& p, int cin, 
   return CTTA_OK;
 }
 
-static ctta_status run_conv1d(RunCtx& c, const Conv1d& L, const bf16_t* x, int B, int len, bf16_t* out, float in_slope,
-                              const bf16_t* res, bool accumulate, float alpha) {
+// Output-side activation plumbing of one vocoder conv: every LeakyReLU of Generator.forward /
+// ResBlock.forward is applied ONCE, in the epilogue of the conv that produces its argument
+// (out_slope: the only consumer wants lrelu(out); out2: both out and lrelu(out) are needed),
+// instead of on every K-step re-read of the operand.
+struct OutAct {
+  float out_slope = 0.f;     // > 0: out = leaky_relu(v, out_slope)
+  bf16_t* out2 = nullptr;    // != null: out2 = leaky_relu(out, out2_slope)
+  float out2_slope = 0.f;
+};
+
+static ctta_status run_conv1d(RunCtx& c, const Conv1d& L, const bf16_t* x, int B, int len, bf16_t* out,
+                              const bf16_t* res, bool accumulate, float alpha, const OutAct& oa) {
   ctta_conv_desc d;
   desc_init(&d);
   d.x0 = x; d.c0 = L.cin;
   d.batch = B; d.hi = 1; d.wi = len; d.ho = 1; d.wo = len;
   d.kh = 1; d.kw = L.k; d.pad_w = L.pad; d.dil_w = L.dil;
   d.w = L.p.w; d.k_pad = L.p.k_pad; d.n = L.p.n; d.bias = L.p.bias;
-  if (in_slope > 0.f) { d.in_act = 1; d.in_slope = in_slope; }
   d.res = res; d.res_ld = L.cout;
   d.accumulate = accumulate ? 1 : 0; d.alpha = alpha;
+  if (oa.out_slope > 0.f) { d.out_act = 3; d.out_slope = oa.out_slope; }
+  d.out2 = oa.out2; d.out2_slope = oa.out2_slope;
   d.out = out; d.ldc = L.cout;
   RUN(c, ctta_conv_gemm(&d, c.stream));
   return CTTA_OK;
@@ -431,7 +449,8 @@ static ctta_status run_conv1d(RunCtx& c, const Conv1d& L, const bf16_t* x, int B
 
 static inline int convt_out_len(const ConvT1d& L, int len) { return (len - 1) * L.u - 2 * L.pad + L.k; }
 
-static ctta_status run_convt1d(RunCtx& c, const ConvT1d& L, const bf16_t* x, int B, int len, bf16_t* out, float in_slope) {
+static ctta_status run_convt1d(RunCtx& c, const ConvT1d& L, const bf16_t* x, int B, int len, bf16_t* out,
+                               const OutAct& oa) {
   const int lout = convt_out_len(L, len);
   const int Q = (lout - 1 + L.pad) / L.u + 1;
   ctta_conv_desc d;
@@ -440,7 +459,7 @@ static ctta_status run_convt1d(RunCtx& c, const ConvT1d& L, const bf16_t* x, int
   d.batch = B; d.hi = 1; d.wi = len; d.ho = 1; d.wo = Q;
   d.kh = 1; d.kw = L.taps; d.pad_w = L.taps - 1;
   d.w = L.p.w; d.k_pad = L.p.k_pad; d.n = L.p.n; d.bias = L.p.bias;
-  if (in_slope > 0.f) { d.in_act = 1; d.in_slope = in_slope; }
+  d.out2 = oa.out2; d.out2_slope = oa.out2_slope;
   d.out = out; d.ldc = L.u * L.cout;
   d.out_batch_stride = (int64_t)lout * L.cout;
   d.out_offset = -(int64_t)L.pad * L.cout;
@@ -469,41 +488,63 @@ static ctta_status hifigan_forward_impl(ctta_hifigan* G, bool dry, const float* 
   bf16_t* m = A.get<bf16_t>((size_t)B * frames * cfg.num_mels); ALLOC_OR_FAIL(m);
   RUN(c, ctta_rows_f32_to_bf16(mel, m, (int64_t)B * frames, cfg.num_mels, cfg.num_mels, stream));
   int len = frames, ch = cfg.upsample_initial_channel;
-  bf16_t* x = A.get<bf16_t>((size_t)B * len * ch); ALLOC_OR_FAIL(x);
-  CTTA_TRY(run_conv1d(c, G->conv_pre, m, B, len, x, 0.f, nullptr, false, 1.0f));
-  add_tap(c, "conv_pre", x, B, ch, 1, len, ch);
+  // xa always holds leaky_relu(x): the raw conv_pre / stage outputs have no other consumer
+  bf16_t* xa = A.get<bf16_t>((size_t)B * len * ch); ALLOC_OR_FAIL(xa);
+  {
+    OutAct oa; oa.out_slope = 0.1f;
+    CTTA_TRY(run_conv1d(c, G->conv_pre, m, B, len, xa, nullptr, false, 1.0f, oa));
+  }
+  add_tap(c, "lrelu.conv_pre", xa, B, ch, 1, len, ch);
   for (int i = 0; i < cfg.n_ups; ++i) {
     const ConvT1d& U = G->ups[i];
     const int lout = convt_out_len(U, len);
-    bf16_t* y = A.get<bf16_t>((size_t)B * lout * U.cout); ALLOC_OR_FAIL(y);
-    CTTA_TRY(run_convt1d(c, U, x, B, len, y, 0.1f));   // x = ups[i](leaky_relu(x, 0.1))
+    const size_t elems = (size_t)B * lout * U.cout;
+    bf16_t* y = A.get<bf16_t>(elems); ALLOC_OR_FAIL(y);        // x = ups[i](leaky_relu(x, 0.1))
+    bf16_t* ya = A.get<bf16_t>(elems); ALLOC_OR_FAIL(ya);      // leaky_relu(x, 0.1) for the 3 resblocks
+    {
+      OutAct oa; oa.out2 = ya; oa.out2_slope = 0.1f;
+      CTTA_TRY(run_convt1d(c, U, xa, B, len, y, oa));
+    }
     len = lout; ch = U.cout;
     add_tap(c, "ups." + std::to_string(i), y, B, ch, 1, len, ch);
-    const size_t elems = (size_t)B * len * ch;
     bf16_t* xs = A.get<bf16_t>(elems); ALLOC_OR_FAIL(xs);
     const size_t mk = A.mark();
     bf16_t* xt = A.get<bf16_t>(elems); ALLOC_OR_FAIL(xt);
     bf16_t* ra = A.get<bf16_t>(elems); ALLOC_OR_FAIL(ra);
     bf16_t* rb = A.get<bf16_t>(elems); ALLOC_OR_FAIL(rb);
+    bf16_t* aa = A.get<bf16_t>(elems); ALLOC_OR_FAIL(aa);
+    bf16_t* ab = A.get<bf16_t>(elems); ALLOC_OR_FAIL(ab);
+    const bool last_stage = i == cfg.n_ups - 1;
     for (int j = 0; j < nk; ++j) {
       const HResBlock& R = G->res[i * nk + j];
-      const bf16_t* r = y;
+      const bf16_t* r = y;       // residual stream (raw)
+      const bf16_t* ract = ya;   // leaky_relu(r, 0.1)
       for (int mth = 0; mth < 3; ++mth) {
-        CTTA_TRY(run_conv1d(c, R.c1[mth], r, B, len, xt, 0.1f, nullptr, false, 1.0f));
+        OutAct o1; o1.out_slope = 0.1f;                 // xt is only ever consumed through leaky_relu
+        CTTA_TRY(run_conv1d(c, R.c1[mth], ract, B, len, xt, nullptr, false, 1.0f, o1));
         const bool last = mth == 2;
-        // the block's last conv adds its residual AND folds into xs = (sum_j resblock_j(x)) / nk
-        bf16_t* dst = last ? xs : (r == ra ? rb : ra);
-        CTTA_TRY(run_conv1d(c, R.c2[mth], xt, B, len, dst, 0.1f, r, last && j > 0,
-                            (last && j == nk - 1) ? 1.0f / (float)nk : 1.0f));
-        r = dst;
+        if (!last) {
+          bf16_t* dst = (r == ra) ? rb : ra;
+          bf16_t* dact = (ract == aa) ? ab : aa;
+          OutAct o2; o2.out2 = dact; o2.out2_slope = 0.1f;
+          CTTA_TRY(run_conv1d(c, R.c2[mth], xt, B, len, dst, r, false, 1.0f, o2));
+          r = dst; ract = dact;
+        } else {
+          // the block's last conv adds its residual AND folds into xs = (sum_j resblock_j(x)) / nk;
+          // the final fold also applies the NEXT consumer's leaky_relu (slope 0.1, or 0.01 before conv_post)
+          const bool fin = j == nk - 1;
+          OutAct o2;
+          if (fin) o2.out_slope = last_stage ? 0.01f : 0.1f;
+          CTTA_TRY(run_conv1d(c, R.c2[mth], xt, B, len, xs, r, j > 0, fin ? 1.0f / (float)nk : 1.0f, o2));
+        }
       }
     }
     A.release(mk);
-    x = xs;
-    add_tap(c, "stage." + std::to_string(i), x, B, ch, 1, len, ch);
+    xa = xs;
+    add_tap(c, "lrelu.stage." + std::to_string(i), xa, B, ch, 1, len, ch);
   }
-  // x = tanh(conv_post(leaky_relu(x)))   (default slope 0.01, models.py:113)
-  RUN(c, ctta_conv_small_n(x, ch, B, 1, len, 1, 7, 0, 3, G->post_w, G->post_b, 1, 1, 0.01f, 2, wav, nullptr, stream));
+  // x = tanh(conv_post(leaky_relu(x)))  -- the leaky_relu (default slope 0.01, models.py:113) is already in xa
+  RUN(c, ctta_conv_small_n(xa, ch, B, 1, len, 1, 7, 0, 3, G->post_w, G->post_b, 1, 0, 0.f, 2, wav, nullptr, stream));
   return CTTA_OK;
 }
 

@@ -199,11 +199,14 @@ typedef struct {
   const void* res; int res_ld;          /* + res[m*ld + n] bf16 or NULL */
   int in_act;                 /* on the A operand: 0 none, 1 leaky_relu(in_slope) */
   float in_slope;
-  int out_act;                /* 0 none, 1 silu, 2 tanh */
+  int out_act;                /* 0 none, 1 silu, 2 tanh, 3 leaky_relu(out_slope) */
+  float out_slope;
   float alpha;                /* v = alpha*(acc + bias + rowvec + res [+ old out]) */
   int accumulate;             /* 1: add the existing output before scaling */
-  void* out; int ldc;         /* bf16 (or f32 when out_f32) [m][ldc] */
+  void* out; int ldc;         /* bf16 (or f32 when out_f32) [m][ldc]; ldc %% 4 != 0 selects
+                                 element-wise stores (tiny Cout, bias-only epilogue) */
   int out_f32;
+  void* out2; float out2_slope; /* optional 2nd bf16 output = leaky_relu(out, out2_slope), same indexing */
   int64_t out_batch_stride;   /* 0 -> ho*wo*ldc */
   int64_t out_offset;         /* element offset added inside a batch (ConvTranspose remap) */
   int64_t out_limit;          /* >0: store only if 0 <= idx_in_batch < out_limit */

@@ -1,0 +1,49 @@
+"""world_size-2 gloo test of the one-process-per-GPU plumbing used by bench.py (timing barrier,
+MAX-reduce of elapsed time, clip sharding, global waveform extrema)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world), RANK=str(rank),
+                      LOCAL_RANK=str(rank))
+    from consistencytta_amd import dist_util as du
+    dev = torch.device("cpu")
+    w, r = du.init("gloo")
+    assert (w, r) == (world, rank)
+    du.barrier(dev)
+    t = du.max_over_ranks(1.0 + rank, dev)              # slowest rank defines the step time
+    mine = du.shard_clips(7, w, r)
+    wav = torch.linspace(-0.5 - 0.1 * rank, 0.3 + 0.2 * rank, 11)
+    mx, mn = du.global_wav_extrema(float(wav.max()), float(wav.min()), dev)
+    q.put((rank, t, mine, mx, mn))
+    du.finish()
+
+
+def test_two_rank_protocol():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [2.0, 2.0]
+    assert res[0][2] == [0, 2, 4, 6] and res[1][2] == [1, 3, 5]
+    assert sorted(res[0][2] + res[1][2]) == list(range(7))       # every clip owned exactly once
+    for r in res:
+        assert abs(r[3] - 0.5) < 1e-6 and abs(r[4] + 0.6) < 1e-6  # extrema agree on all ranks

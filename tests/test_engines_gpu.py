@@ -129,8 +129,15 @@ def test_vae_and_hifigan_tiny(golden):
     taps = {}
     with torch.no_grad():
         onets.hifigan_forward(cases.TINY_HIFIGAN, sd, mel_in.squeeze(1).permute(0, 2, 1), taps=taps)
+    n_ups = len(cases.TINY_HIFIGAN["upsample_rates"])
     for name, t in v._read_taps("voc").items():
-        _report("hifigan tap " + name, t.squeeze(2), taps[name])
+        if name.startswith("lrelu."):   # the engine stores leaky_relu(x) where x has no other consumer
+            slope = 0.01 if name == "lrelu.stage.%d" % (n_ups - 1) else 0.1
+            ref = torch.nn.functional.leaky_relu(taps[name[len("lrelu."):]], slope)
+        else:
+            ref = taps[name]
+        l2, _ = _report("hifigan tap " + name, t.squeeze(2), ref)
+        assert l2 <= REL_L2
     _check("hifigan_tiny wav vs reference golden", wav, torch.from_numpy(g["wav"]))
     pcm = v.decode_to_waveform(mel_in.to(DEV))
     assert pcm.dtype == np.int16 and pcm.shape == g["pcm"].shape

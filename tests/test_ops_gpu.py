@@ -100,6 +100,39 @@ def test_conv1d_dilated_lrelu_and_accumulate():
     assert rel_err(got, ref) < 2 * BF16_TOL   # `old` is itself bf16 and re-rounded
 
 
+def test_conv_fused_output_activations_and_scalar_store():
+    """out_act=leaky_relu, the second (activated) output, and element-wise stores for Cout=1."""
+    B, C, L, k = 2, 64, 150, 3
+    x = bf16_round(det("oa.x", (B, C, L), 1))
+    w = bf16_round(det("oa.w", (C, C, k), 2) * (1.0 / math.sqrt(C * k)))
+    b = det("oa.b", (C,), 3) * 0.1
+    ref = F.conv1d(x, w, b, padding=1)
+    wp, k_pad = pack_conv_weight(w[:, :, None, :])
+    xa = x.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    bd = b.to(DEV)
+    out = torch.empty(B, L, C, dtype=torch.bfloat16, device=DEV)
+    out2 = torch.empty(B, L, C, dtype=torch.bfloat16, device=DEV)
+    run_conv(conv_desc(x0=xa, c0=C, batch=B, hi=1, wi=L, ho=1, wo=L, kh=1, kw=k, pad_w=1, w=wp, k_pad=k_pad, n=C,
+                       bias=bd, out=out, ldc=C, out2=out2, out2_slope=0.1))
+    o = out.to(torch.float32).permute(0, 2, 1).cpu()
+    assert rel_err(o, ref) < BF16_TOL
+    assert torch.equal(out2.to(torch.float32).cpu(), bf16_round(F.leaky_relu(out.to(torch.float32).cpu(), 0.1)))
+    run_conv(conv_desc(x0=xa, c0=C, batch=B, hi=1, wi=L, ho=1, wo=L, kh=1, kw=k, pad_w=1, w=wp, k_pad=k_pad, n=C,
+                       bias=bd, out=out, ldc=C, out_act=3, out_slope=0.01))
+    assert rel_err(out.to(torch.float32).permute(0, 2, 1).cpu(), F.leaky_relu(ref, 0.01)) < BF16_TOL
+    # Cout = 1, fp32 planar output (the VAE's conv_out): ldc = 1 -> element-wise stores
+    x2 = bf16_round(det("oa.x2", (B, 32, 12, 10), 4))
+    w2 = bf16_round(det("oa.w2", (1, 32, 3, 3), 5) * 0.1)
+    b2 = det("oa.b2", (1,), 6)
+    ref2 = F.conv2d(x2, w2, b2, padding=1)
+    wp2, kp2 = pack_conv_weight(w2)
+    x2a, b2d = nhwc_bf16(x2), b2.to(DEV)
+    o2 = torch.empty(B, 1, 12, 10, dtype=torch.float32, device=DEV)
+    run_conv(conv_desc(x0=x2a, c0=32, batch=B, hi=12, wi=10, ho=12, wo=10, kh=3, kw=3, pad_h=1, pad_w=1, w=wp2,
+                       k_pad=kp2, n=1, bias=b2d, out=o2, ldc=1, out_f32=1))
+    assert rel_err(o2.cpu(), ref2) < 1e-4
+
+
 @pytest.mark.parametrize("k,u", [(16, 5), (16, 4), (8, 2), (4, 2)])
 def test_conv_transpose1d_as_phase_gemm(k, u):
     """ConvTranspose1d(k, stride u, padding (k-u)//2) == u phase convolutions written through
