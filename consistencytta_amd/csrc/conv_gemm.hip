@@ -22,6 +22,8 @@
 // padded by 16 B to spread ds_read_b128 over banks.
 #include "common.h"
 
+#include <stdlib.h>
+
 struct ConvParams {
   const bf16_t* x0; const bf16_t* x1; int c0, c1, ct;
   int M, hi, wi, hs, ws, ups, ho, wo, howo;
@@ -33,9 +35,14 @@ struct ConvParams {
   void* out; int ldc; int out_f32; bf16_t* out2; float out2_slope; int scalar_store;
   long long obs, out_offset, out_limit;
   long long xgs, wgs, ogs;
+  const bf16_t* zero;   // >= 16 bytes of zeros: source of out-of-range chunks in the direct-to-LDS path
 };
 
-template <int BM, int BN, int BK, int WM, int WN>
+// GLDS = true: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
+// ds_write): the LDS image is lane-linear per wave instruction (8 rows x 128 B for BK = 64), so the
+// XOR swizzle is applied to the per-lane SOURCE chunk instead of the destination; padding / tail
+// chunks read a zero page.  GLDS = false stages through registers (needed for in_act).
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p) {
   constexpr int NT = 64 * WM * WN;
   constexpr int LDK = BK;              // bf16 elements per LDS row: no padding, XOR-swizzled chunks
@@ -68,8 +75,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   const bf16_t* x1 = p.x1;
   const bf16_t* wbase = p.w + (size_t)g * p.wgs;
 
-  const int kc = tid % CPR;
   const int r0 = tid / CPR;
+  // logical 16-byte K chunk this thread fetches: register path -> position tid % CPR (swizzled on
+  // store); direct-to-LDS path -> the chunk whose swizzled home is position tid % CPR
+  const int kc = GLDS ? ((tid % CPR) ^ ((r0 >> SWZ_SHIFT) & SWZ_MASK)) : (tid % CPR);
+  const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int ROWS_PER_INSTR = 64 / CPR;   // rows one wave-wide 1 KiB LDS-DMA covers
 
   // per-thread K state (shared by all of this thread's rows)
   int c, tap, kh, kw;
@@ -168,6 +179,40 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     }
   };
 
+  // direct global -> LDS issue of K-tile kt into ring slot buf (same row/chunk ownership as above)
+  auto issue_tile = [&](int kt, int buf) {
+    const int ihk = kh * p.dh, iwk = kw * p.dw;
+    const bool tap_ok = tap < p.taps;
+    const bool second = c >= p.c0;
+    const bf16_t* src = second ? x1 : x0;
+    const int cs = second ? p.c1 : p.c0;
+    const int cc = second ? c - p.c0 : c;
+    bf16_t* xs = Xs + buf * BM * LDK + wave_u * ROWS_PER_INSTR * LDK;
+    bf16_t* ws = Ws + buf * BN * LDK + wave_u * ROWS_PER_INSTR * LDK;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      int ih = rih[i] + ihk, iw = riw[i] + iwk;
+      const bool ok = tap_ok && (unsigned)ih < (unsigned)p.hi && (unsigned)iw < (unsigned)p.wi;
+      if (p.ups) { ih >>= 1; iw >>= 1; }
+      const bf16_t* g = p.zero;
+      if (ok) g = src + ((size_t)(rb[i] * p.hs + ih) * p.ws + iw) * cs + cc;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(xs + i * RPP * LDK), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j) {
+      const bf16_t* g = wok[j] ? wrow[j] + (size_t)kt * BK : p.zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                       (__attribute__((address_space(3))) void*)(ws + j * RPP * LDK), 16, 0, 0);
+    }
+    c += BK;
+    while (c >= p.ct) {
+      c -= p.ct;
+      ++tap;
+      if (++kw == p.kw) { kw = 0; ++kh; }
+    }
+  };
+
   f32x4_t acc[FN][FM];
 #pragma unroll
   for (int i = 0; i < FN; ++i)
@@ -178,13 +223,20 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   const int fchunk = lane >> 4;                       // logical 16-byte chunk within a 32-wide k-slab
   const int fswz = (frow >> SWZ_SHIFT) & SWZ_MASK;    // tile/frag row offsets are multiples of 16
 
-  load_tile(0);
-  store_tile(0);
+  if constexpr (GLDS) {
+    issue_tile(0, 0);
+  } else {
+    load_tile(0);
+    store_tile(0);
+  }
   __syncthreads();
 
   for (int kt = 0; kt < p.nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < p.nk) load_tile(kt + 1);
+    if (kt + 1 < p.nk) {
+      if constexpr (GLDS) issue_tile(kt + 1, buf ^ 1);
+      else load_tile(kt + 1);
+    }
     const bf16_t* xs = Xs + buf * BM * LDK + (wm * TM + frow) * LDK;
     const bf16_t* ws = Ws + buf * BN * LDK + (wn * TN + frow) * LDK;
 #pragma unroll
@@ -203,7 +255,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         for (int j = 0; j < FM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < p.nk) store_tile(buf ^ 1);
+    if constexpr (!GLDS) {
+      if (kt + 1 < p.nk) store_tile(buf ^ 1);
+    }
     __syncthreads();
   }
 
@@ -312,6 +366,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 struct Variant {
   const char* name;
   int bm, bn, bk;
+  bool glds;
   void (*launch)(const ConvParams&, dim3, hipStream_t);
   ctta_status (*prepare)();
 };
@@ -319,42 +374,68 @@ struct Variant {
 template <int BM, int BN, int BK, int WM, int WN>
 static constexpr size_t smem_bytes() { return (size_t)2 * (BM + BN) * BK * 2; }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS>
 static void launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
   const size_t smem = smem_bytes<BM, BN, BK, WM, WN>();
-  conv_gemm_kernel<BM, BN, BK, WM, WN><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
+  conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS>
 static ctta_status prepare_variant() {
   static bool done = false;
   if (done) return CTTA_OK;
   CTTA_CHECK_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN>),
+      reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS>),
       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<BM, BN, BK, WM, WN>()));
   done = true;
   return CTTA_OK;
 }
 
-#define VARIANT(BM, BN, BK, WM, WN) \
-  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN, BM, BN, BK, launch_variant<BM, BN, BK, WM, WN>, \
-   prepare_variant<BM, BN, BK, WM, WN>}
+#define VARIANT(BM, BN, BK, WM, WN, G) \
+  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN #G, BM, BN, BK, G, launch_variant<BM, BN, BK, WM, WN, G>, \
+   prepare_variant<BM, BN, BK, WM, WN, G>}
 
 static const Variant kVariants[] = {
-    VARIANT(128, 128, 64, 2, 2),  // 1
-    VARIANT(128, 128, 32, 2, 2),  // 2
-    VARIANT(256, 64, 64, 4, 1),   // 3
-    VARIANT(256, 32, 64, 4, 1),   // 4
-    VARIANT(64, 64, 64, 2, 2),    // 5
-    VARIANT(64, 128, 64, 2, 2),   // 6
-    VARIANT(256, 128, 64, 4, 2),  // 7
-    VARIANT(128, 64, 64, 2, 2),   // 8
+    VARIANT(128, 128, 64, 2, 2, false),  // 1
+    VARIANT(128, 128, 32, 2, 2, false),  // 2
+    VARIANT(256, 64, 64, 4, 1, false),   // 3
+    VARIANT(256, 32, 64, 4, 1, false),   // 4
+    VARIANT(64, 64, 64, 2, 2, false),    // 5
+    VARIANT(64, 128, 64, 2, 2, false),   // 6
+    VARIANT(256, 128, 64, 4, 2, false),  // 7
+    VARIANT(128, 64, 64, 2, 2, false),   // 8
+    VARIANT(128, 128, 64, 2, 2, true),   // 9   direct-to-LDS twins of 1..8
+    VARIANT(128, 128, 32, 2, 2, true),   // 10
+    VARIANT(256, 64, 64, 4, 1, true),    // 11
+    VARIANT(256, 32, 64, 4, 1, true),    // 12
+    VARIANT(64, 64, 64, 2, 2, true),     // 13
+    VARIANT(64, 128, 64, 2, 2, true),    // 14
+    VARIANT(256, 128, 64, 4, 2, true),   // 15
+    VARIANT(128, 64, 64, 2, 2, true),    // 16
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
 extern "C" int ctta_conv_gemm_num_variants(void) { return kNumVariants; }
 extern "C" const char* ctta_conv_gemm_variant_name(int id) {
   return (id >= 1 && id <= kNumVariants) ? kVariants[id - 1].name : "auto";
+}
+
+static const bf16_t* zero_page() {
+  static bf16_t* z = nullptr;
+  if (!z) {
+    if (hipMalloc((void**)&z, 256) != hipSuccess) return nullptr;
+    if (hipMemset(z, 0, 256) != hipSuccess) return nullptr;
+  }
+  return z;
+}
+
+static bool glds_default() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("CTTA_GLDS");
+    v = e ? atoi(e) : 0;
+  }
+  return v != 0;
 }
 
 static int pick_variant(long long M, int N, int groups) {
@@ -413,8 +494,14 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   p.xgs = d->x_group_stride; p.wgs = d->w_group_stride; p.ogs = d->out_group_stride;
 
   int vid = d->tile;
-  if (vid <= 0 || vid > kNumVariants) vid = pick_variant(M, d->n, groups);
+  if (vid <= 0 || vid > kNumVariants) {
+    vid = pick_variant(M, d->n, groups);
+    if (glds_default() && !d->in_act) vid += 8;
+  }
+  CTTA_REQUIRE(!(kVariants[vid - 1].glds && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
   const Variant& v = kVariants[vid - 1];
+  p.zero = zero_page();
+  CTTA_REQUIRE(p.zero, "conv_gemm: could not allocate the zero page");
   p.nk = (int)((K + v.bk - 1) / v.bk);
   CTTA_REQUIRE((long long)p.nk * v.bk <= d->k_pad, "conv_gemm: k_pad too small for BK");
   CTTA_TRY(v.prepare());

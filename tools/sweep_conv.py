@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Times every conv_gemm tile variant on the layer shapes of the B=32 pipeline (GPU box only).
+
+    python tools/sweep_conv.py [out.json]
+
+Prints one line per shape with the TFLOP/s of each variant (executed FLOPs, random data) and
+writes the table as JSON; the result drives pick_variant() in csrc/conv_gemm.hip."""
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from consistencytta_amd import _native as N  # noqa: E402
+
+DEV = "cuda:0"
+
+# (tag, batch, H, W, Cin, Cout, kh, kw, dil_w)   -- NHWC, stride 1, "same" padding
+SHAPES = [
+    ("vae512 256x16 3x3", 32, 256, 16, 512, 512, 3, 3, 1),
+    ("vae 512x32 512>256", 32, 512, 32, 512, 256, 3, 3, 1),
+    ("vae 512x32 256>256", 32, 512, 32, 256, 256, 3, 3, 1),
+    ("vae 1024x64 256>128", 32, 1024, 64, 256, 128, 3, 3, 1),
+    ("vae 1024x64 128>128", 32, 1024, 64, 128, 128, 3, 3, 1),
+    ("vae 1024x64 256>256", 32, 1024, 64, 256, 256, 3, 3, 1),
+    ("unet 256x16 256>256", 32, 256, 16, 256, 256, 3, 3, 1),
+    ("unet 256x16 512>256", 32, 256, 16, 512, 256, 3, 3, 1),
+    ("unet 128x8 512>512", 32, 128, 8, 512, 512, 3, 3, 1),
+    ("unet 64x4 1024>1024", 32, 64, 4, 1024, 1024, 3, 3, 1),
+    ("unet 32x2 2048>1024", 32, 32, 2, 2048, 1024, 3, 3, 1),
+    ("hifi L5121 C512 k11", 32, 1, 5121, 512, 512, 1, 11, 1),
+    ("hifi L5121 C512 k3", 32, 1, 5121, 512, 512, 1, 3, 3),
+    ("hifi L20484 C256 k11", 32, 1, 20484, 256, 256, 1, 11, 5),
+    ("hifi L20484 C256 k3", 32, 1, 20484, 256, 256, 1, 3, 1),
+    ("hifi L40968 C128 k11", 32, 1, 40968, 128, 128, 1, 11, 1),
+    ("hifi L40968 C128 k3", 32, 1, 40968, 128, 128, 1, 3, 1),
+    ("hifi L81936 C64 k11", 32, 1, 81936, 64, 64, 1, 11, 3),
+    ("hifi L81936 C64 k3", 32, 1, 81936, 64, 64, 1, 3, 1),
+    ("hifi L163872 C32 k11", 32, 1, 163872, 32, 32, 1, 11, 1),
+    ("hifi L163872 C32 k3", 32, 1, 163872, 32, 32, 1, 3, 5),
+    ("lin M131072 256>256", 32, 4096, 1, 256, 256, 1, 1, 1),
+    ("lin M131072 256>640", 32, 4096, 1, 256, 640, 1, 1, 1),
+    ("lin M131072 256>2048", 32, 4096, 1, 256, 2048, 1, 1, 1),
+    ("lin M131072 1024>256", 32, 4096, 1, 1024, 256, 1, 1, 1),
+    ("lin M32768 512>4096", 32, 1024, 1, 512, 4096, 1, 1, 1),
+    ("lin M32768 2048>512", 32, 1024, 1, 2048, 512, 1, 1, 1),
+    ("lin M8192 1024>8192", 32, 256, 1, 1024, 8192, 1, 1, 1),
+    ("lin M8192 4096>1024", 32, 256, 1, 4096, 1024, 1, 1, 1),
+    ("lin M2048 1024>8192", 32, 64, 1, 1024, 8192, 1, 1, 1),
+]
+
+
+def main():
+    L = N.lib()
+    nvar = L.ctta_conv_gemm_num_variants()
+    names = [L.ctta_conv_gemm_variant_name(i + 1).decode() for i in range(nvar)]
+    print("variants:", names)
+    results = []
+    for (tag, B, H, W, Cin, Cout, kh, kw, dil) in SHAPES:
+        x = (torch.randn(B, H, W, Cin, device=DEV) * 0.5).to(torch.bfloat16)
+        K = kh * kw * Cin
+        k_pad = (K + 63) // 64 * 64
+        w = (torch.randn(Cout, k_pad, device=DEV) * 0.05).to(torch.bfloat16)
+        bias = torch.randn(Cout, device=DEV)
+        out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+        M = B * H * W
+        flops = 2.0 * M * Cout * K
+        row = {"tag": tag, "M": M, "N": Cout, "K": K, "tflops": {}}
+        for v in range(1, nvar + 1):
+            d = N.ConvDesc()
+            d.x0, d.c0 = x.data_ptr(), Cin
+            d.batch, d.hi, d.wi, d.ho, d.wo = B, H, W, H, W
+            d.kh, d.kw, d.stride_h, d.stride_w = kh, kw, 1, 1
+            d.dil_h, d.dil_w = 1, dil
+            d.pad_h, d.pad_w = (kh - 1) // 2, (kw - 1) * dil // 2
+            d.w, d.k_pad, d.n = w.data_ptr(), k_pad, Cout
+            d.bias = bias.data_ptr()
+            d.alpha, d.groups = 1.0, 1
+            d.out, d.ldc, d.tile = out.data_ptr(), Cout, v
+            st = N.stream_ptr()
+            for _ in range(2):
+                N.check(L.ctta_conv_gemm(ctypes.byref(d), st))
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            reps = 5
+            e0.record()
+            for _ in range(reps):
+                N.check(L.ctta_conv_gemm(ctypes.byref(d), st))
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            row["tflops"][names[v - 1]] = round(flops / (ms * 1e-3) / 1e12, 1)
+        best = max(row["tflops"], key=row["tflops"].get)
+        row["best"] = best
+        results.append(row)
+        print("%-24s M=%8d N=%5d K=%6d  best %-22s %s" % (tag, M, Cout, K, best,
+              " ".join("%6.0f" % row["tflops"][n] for n in names)), flush=True)
+        del x, w, out
+    if len(sys.argv) > 1:
+        json.dump({"variants": names, "shapes": results}, open(sys.argv[1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
