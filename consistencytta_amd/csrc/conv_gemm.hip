@@ -42,8 +42,12 @@ struct ConvParams {
 // ds_write): the LDS image is lane-linear per wave instruction (8 rows x 128 B for BK = 64), so the
 // XOR swizzle is applied to the per-lane SOURCE chunk instead of the destination; padding / tail
 // chunks read a zero page.  GLDS = false stages through registers (needed for in_act).
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS>
+// STAGES > 2 (GLDS only): an S-slot LDS ring with S-1 tiles in flight; the wait for tile kt is a
+// COUNTED s_waitcnt vmcnt((S-2) * loads_per_tile) followed by a raw s_barrier, so younger tiles stay
+// in flight across the barrier (a __syncthreads() would drain them: its release carries vmcnt(0)).
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p) {
+  static_assert(STAGES == 2 || GLDS, "multi-stage ring needs the direct-to-LDS path");
   constexpr int NT = 64 * WM * WN;
   constexpr int LDK = BK;              // bf16 elements per LDS row: no padding, XOR-swizzled chunks
   // 16-byte chunk c of row r lives at chunk position c ^ swz(r): conflict-free for the 16-lane
@@ -60,8 +64,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_raw);               // [2][BM][LDK]
-  bf16_t* Ws = Xs + 2 * BM * LDK;                                  // [2][BN][LDK]
+  bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_raw);               // [STAGES][BM][LDK]
+  bf16_t* Ws = Xs + STAGES * BM * LDK;                             // [STAGES][BN][LDK]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -223,20 +227,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   const int fchunk = lane >> 4;                       // logical 16-byte chunk within a 32-wide k-slab
   const int fswz = (frow >> SWZ_SHIFT) & SWZ_MASK;    // tile/frag row offsets are multiples of 16
 
-  if constexpr (GLDS) {
-    issue_tile(0, 0);
-  } else {
-    load_tile(0);
-    store_tile(0);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < p.nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < p.nk) {
-      if constexpr (GLDS) issue_tile(kt + 1, buf ^ 1);
-      else load_tile(kt + 1);
-    }
+  auto compute_tile = [&](int buf) {
     const bf16_t* xs = Xs + buf * BM * LDK + (wm * TM + frow) * LDK;
     const bf16_t* ws = Ws + buf * BN * LDK + (wn * TN + frow) * LDK;
 #pragma unroll
@@ -255,10 +246,46 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         for (int j = 0; j < FM; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if constexpr (!GLDS) {
-      if (kt + 1 < p.nk) store_tile(buf ^ 1);
+  };
+
+  if constexpr (STAGES > 2) {
+    constexpr int LPT = XP + WP;                 // LDS-DMA instructions per wave per tile
+    constexpr int INFLIGHT = (STAGES - 2) * LPT; // what may stay outstanding while tile kt is consumed
+    int issued = 0;
+    for (; issued < STAGES - 1 && issued < p.nk; ++issued) issue_tile(issued, issued);
+    int slot = 0, fill = issued % STAGES;
+    for (int kt = 0; kt < p.nk; ++kt) {
+      if (issued - kt - 1 >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();              // tile kt landed for every wave; slot `fill` is free
+      if (issued < p.nk) {
+        issue_tile(issued, fill);
+        ++issued;
+        fill = (fill + 1 == STAGES) ? 0 : fill + 1;
+      }
+      compute_tile(slot);
+      slot = (slot + 1 == STAGES) ? 0 : slot + 1;
+    }
+  } else {
+    if constexpr (GLDS) {
+      issue_tile(0, 0);
+    } else {
+      load_tile(0);
+      store_tile(0);
     }
     __syncthreads();
+    for (int kt = 0; kt < p.nk; ++kt) {
+      const int buf = kt & 1;
+      if (kt + 1 < p.nk) {
+        if constexpr (GLDS) issue_tile(kt + 1, buf ^ 1);
+        else load_tile(kt + 1);
+      }
+      compute_tile(buf);
+      if constexpr (!GLDS) {
+        if (kt + 1 < p.nk) store_tile(buf ^ 1);
+      }
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3} (rows of D), m = mb + (lane&15)
@@ -371,47 +398,57 @@ struct Variant {
   ctta_status (*prepare)();
 };
 
-template <int BM, int BN, int BK, int WM, int WN>
-static constexpr size_t smem_bytes() { return (size_t)2 * (BM + BN) * BK * 2; }
+template <int BM, int BN, int BK, int STAGES>
+static constexpr size_t smem_bytes() { return (size_t)STAGES * (BM + BN) * BK * 2; }
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int STAGES>
 static void launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
-  const size_t smem = smem_bytes<BM, BN, BK, WM, WN>();
-  conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
+  const size_t smem = smem_bytes<BM, BN, BK, STAGES>();
+  conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS>
+template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int STAGES>
 static ctta_status prepare_variant() {
   static bool done = false;
   if (done) return CTTA_OK;
   CTTA_CHECK_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<BM, BN, BK, WM, WN>()));
+      reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<BM, BN, BK, STAGES>()));
   done = true;
   return CTTA_OK;
 }
 
-#define VARIANT(BM, BN, BK, WM, WN, G) \
-  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN #G, BM, BN, BK, G, launch_variant<BM, BN, BK, WM, WN, G>, \
-   prepare_variant<BM, BN, BK, WM, WN, G>}
+#define VARIANT(BM, BN, BK, WM, WN, G, S) \
+  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN "_g" #G "_s" #S, BM, BN, BK, G != 0, \
+   launch_variant<BM, BN, BK, WM, WN, (G != 0), S>, prepare_variant<BM, BN, BK, WM, WN, (G != 0), S>}
 
 static const Variant kVariants[] = {
-    VARIANT(128, 128, 64, 2, 2, false),  // 1
-    VARIANT(128, 128, 32, 2, 2, false),  // 2
-    VARIANT(256, 64, 64, 4, 1, false),   // 3
-    VARIANT(256, 32, 64, 4, 1, false),   // 4
-    VARIANT(64, 64, 64, 2, 2, false),    // 5
-    VARIANT(64, 128, 64, 2, 2, false),   // 6
-    VARIANT(256, 128, 64, 4, 2, false),  // 7
-    VARIANT(128, 64, 64, 2, 2, false),   // 8
-    VARIANT(128, 128, 64, 2, 2, true),   // 9   direct-to-LDS twins of 1..8
-    VARIANT(128, 128, 32, 2, 2, true),   // 10
-    VARIANT(256, 64, 64, 4, 1, true),    // 11
-    VARIANT(256, 32, 64, 4, 1, true),    // 12
-    VARIANT(64, 64, 64, 2, 2, true),     // 13
-    VARIANT(64, 128, 64, 2, 2, true),    // 14
-    VARIANT(256, 128, 64, 4, 2, true),   // 15
-    VARIANT(128, 64, 64, 2, 2, true),    // 16
+    VARIANT(128, 128, 64, 2, 2, 0, 2),  // 1   register-staged (support in_act)
+    VARIANT(128, 128, 32, 2, 2, 0, 2),  // 2
+    VARIANT(256, 64, 64, 4, 1, 0, 2),   // 3
+    VARIANT(256, 32, 64, 4, 1, 0, 2),   // 4
+    VARIANT(64, 64, 64, 2, 2, 0, 2),    // 5
+    VARIANT(64, 128, 64, 2, 2, 0, 2),   // 6
+    VARIANT(256, 128, 64, 4, 2, 0, 2),  // 7
+    VARIANT(128, 64, 64, 2, 2, 0, 2),   // 8
+    VARIANT(128, 128, 64, 2, 2, 1, 2),  // 9   direct-to-LDS twins of 1..8
+    VARIANT(128, 128, 32, 2, 2, 1, 2),  // 10
+    VARIANT(256, 64, 64, 4, 1, 1, 2),   // 11
+    VARIANT(256, 32, 64, 4, 1, 1, 2),   // 12
+    VARIANT(64, 64, 64, 2, 2, 1, 2),    // 13
+    VARIANT(64, 128, 64, 2, 2, 1, 2),   // 14
+    VARIANT(256, 128, 64, 4, 2, 1, 2),  // 15
+    VARIANT(128, 64, 64, 2, 2, 1, 2),   // 16
+    VARIANT(128, 128, 32, 2, 2, 1, 4),  // 17  multi-stage rings (counted vmcnt)
+    VARIANT(128, 128, 32, 2, 2, 1, 3),  // 18
+    VARIANT(128, 128, 64, 2, 2, 1, 3),  // 19
+    VARIANT(64, 128, 64, 2, 2, 1, 3),   // 20
+    VARIANT(128, 64, 64, 2, 2, 1, 3),   // 21
+    VARIANT(64, 64, 64, 2, 2, 1, 4),    // 22
+    VARIANT(256, 32, 64, 4, 1, 1, 3),   // 23
+    VARIANT(256, 128, 64, 4, 2, 1, 3),  // 24
+    VARIANT(64, 128, 32, 2, 2, 1, 4),   // 25
+    VARIANT(256, 128, 32, 4, 2, 1, 4),  // 26
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 

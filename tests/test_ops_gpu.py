@@ -65,7 +65,7 @@ def _conv_case(B, Cin, H, W, Cout, k, stride, pad, tile=0, upsample=False, c_spl
     return rel_err(from_nhwc(out), ref)
 
 
-@pytest.mark.parametrize("tile", list(range(0, 17)))
+@pytest.mark.parametrize("tile", list(range(0, 27)))
 def test_conv3x3_all_tiles(tile):
     assert _conv_case(2, 64, 24, 16, 96, 3, 1, 1, tile=tile, tag="t%d" % tile) < BF16_TOL
 
