@@ -470,19 +470,22 @@ static bool glds_default() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("CTTA_GLDS");
-    v = e ? atoi(e) : 0;
+    v = e ? atoi(e) : 1;
   }
   return v != 0;
 }
 
-static int pick_variant(long long M, int N, int groups) {
-  if (N <= 32) return 4;
-  if (N <= 64) return 3;
+// Tile choice from the on-device sweep (tools/sweep_conv.py, profiles/sweep_r01.json); ids index
+// kVariants (1-based).  Returns a register-staged id (1..8); +8 selects its direct-to-LDS twin.
+static int pick_variant(long long M, int N, long long K, int groups) {
+  if (N <= 32) return 4;                                   // 256x32
+  if (N <= 64) return K >= 512 ? 8 : 5;                    // 128x64 / 64x64
   const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * groups;
-  if (t128 >= 512) return 1;
-  const long long t64n = ((M + 127) / 128) * ((N + 63) / 64) * groups;
-  if (t64n >= 384) return 8;
-  return 5;
+  if (t128 < 200) return 5;                                // too few 128x128 tiles to fill 256 CUs
+  if (K >= 4096) return 1;                                 // 128x128x64
+  if (K > 1536) return M >= 400000 ? 6 : 2;                // 64x128x64 / 128x128x32
+  if (K > 512) return 2;                                   // 128x128x32
+  return 6;                                                // short K: 64x128x64
 }
 
 extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
@@ -532,7 +535,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
 
   int vid = d->tile;
   if (vid <= 0 || vid > kNumVariants) {
-    vid = pick_variant(M, d->n, groups);
+    vid = pick_variant(M, d->n, K, groups);
     if (glds_default() && !d->in_act) vid += 8;
   }
   CTTA_REQUIRE(!(kVariants[vid - 1].glds && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
