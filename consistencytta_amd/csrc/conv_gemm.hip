@@ -36,6 +36,7 @@ struct ConvParams {
   long long obs, out_offset, out_limit;
   long long xgs, wgs, ogs;
   const bf16_t* zero;   // >= 16 bytes of zeros: source of out-of-range chunks in the direct-to-LDS path
+  unsigned x_bytes, w_bytes;   // buffer extents for the descriptor (MODE 2) path
 };
 
 // GLDS = true: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
@@ -45,8 +46,15 @@ struct ConvParams {
 // STAGES > 2 (GLDS only): an S-slot LDS ring with S-1 tiles in flight; the wait for tile kt is a
 // COUNTED s_waitcnt vmcnt((S-2) * loads_per_tile) followed by a raw s_barrier, so younger tiles stay
 // in flight across the barrier (a __syncthreads() would drain them: its release carries vmcnt(0)).
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int STAGES>
+// MODE 0: register-staged tiles (supports in_act).  MODE 1: direct-to-LDS, generic gather (per-lane
+// global pointers, zero page).  MODE 2: direct-to-LDS through BUFFER descriptors with the address
+// work hoisted out of the K loop: requires ct % BK == 0 (a K-tile never straddles a tap, so tap /
+// channel base are wave-uniform scalars), <= 32 taps and one source; per row only a pixel base and
+// a tap-validity bitmask are kept, padding chunks are sent out of range (hardware returns zeros),
+// weight rows >= n fall outside the descriptor, and the per-step K advance rides in soffset.
+template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p) {
+  constexpr bool GLDS = MODE != 0;
   static_assert(STAGES == 2 || GLDS, "multi-stage ring needs the direct-to-LDS path");
   constexpr int NT = 64 * WM * WN;
   constexpr int LDK = BK;              // bf16 elements per LDS row: no padding, XOR-swizzled chunks
@@ -217,6 +225,80 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     }
   };
 
+  // ---------------- MODE 2: descriptor path, K-loop-invariant address work hoisted
+  unsigned fvoff[XP], fmask[XP], fph[XP], fpw[XP], fwoff[WP];
+  int ftap = 0, fkh = 0, fkw = 0, fcb = 0;   // wave-uniform K state (tap index, its (kh,kw), channel base)
+  __amdgpu_buffer_rsrc_t rsx, rsw;
+  if constexpr (MODE == 2) {
+    rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, p.x_bytes, 0x00020000);
+    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int m = m0 + r0 + i * RPP;
+      unsigned mask = 0;
+      int pix = 0, ph = 0, pw = 0;
+      if (m < p.M) {
+        const int b = m / p.howo;
+        const int rem = m - b * p.howo;
+        const int oh = rem / p.wo;
+        const int ow = rem - oh * p.wo;
+        const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
+        int t = 0;
+        for (int a = 0; a < p.kh; ++a)
+          for (int bq = 0; bq < p.kw; ++bq, ++t) {
+            const int ih = ih0 + a * p.dh, iw = iw0 + bq * p.dw;
+            if ((unsigned)ih < (unsigned)p.hi && (unsigned)iw < (unsigned)p.wi) mask |= 1u << t;
+          }
+        if (p.ups) {   // 3x3 / pad 1 / stride 1 on a x2 nearest-upsampled source: base = (oh>>1, ow>>1)
+          pix = (b * p.hs + (oh >> 1)) * p.ws + (ow >> 1);
+          ph = oh & 1; pw = ow & 1;
+        } else {
+          pix = (b * p.hs + ih0) * p.ws + iw0;
+        }
+      }
+      fmask[i] = mask;
+      fvoff[i] = (unsigned)(pix * p.c0 + kc * 8) * 2u;      // bytes; wraps correctly for border rows
+      fph[i] = ph ? (unsigned)(p.ws * p.c0) * 2u : 0u;
+      fpw[i] = pw ? (unsigned)p.c0 * 2u : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < WP; ++j) fwoff[j] = (unsigned)((n0 + r0 + j * RPP) * p.k_pad + kc * 8) * 2u;
+  }
+  auto issue_fast = [&](int kt, int buf) {
+    bf16_t* xs = Xs + buf * BM * LDK + wave_u * ROWS_PER_INSTR * LDK;
+    bf16_t* ws = Ws + buf * BN * LDK + wave_u * ROWS_PER_INSTR * LDK;
+    unsigned s_u;          // uniform byte offset of (tap, channel base)
+    bool use_h = false, use_w = false;
+    if (p.ups) {           // dy = (kh==0 ? ph-1 : kh==1 ? 0 : ph), same for dx
+      const int bh = fkh == 0 ? -1 : 0, bw = fkw == 0 ? -1 : 0;
+      use_h = fkh != 1; use_w = fkw != 1;
+      s_u = (unsigned)((bh * p.ws + bw) * p.c0 + fcb) * 2u;
+    } else {
+      s_u = (unsigned)((fkh * p.dh * p.ws + fkw * p.dw) * p.c0 + fcb) * 2u;
+    }
+    const unsigned tbit = 1u << ftap;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      unsigned v = fvoff[i] + s_u;
+      if (use_h) v += fph[i];
+      if (use_w) v += fpw[i];
+      v = (fmask[i] & tbit) ? v : 0xFFFFFFF0u;   // out of range -> the buffer unit returns zeros
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(xs + i * RPP * LDK), 16,
+                                               (int)v, 0, 0, 0);
+    }
+    const int soff = kt * BK * 2;
+#pragma unroll
+    for (int j = 0; j < WP; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ws + j * RPP * LDK), 16,
+                                               (int)fwoff[j], soff, 0, 0);
+    fcb += BK;
+    if (fcb >= p.ct) {
+      fcb = 0;
+      ++ftap;
+      if (++fkw == p.kw) { fkw = 0; ++fkh; }
+    }
+  };
+
   f32x4_t acc[FN][FM];
 #pragma unroll
   for (int i = 0; i < FN; ++i)
@@ -252,14 +334,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     constexpr int LPT = XP + WP;                 // LDS-DMA instructions per wave per tile
     constexpr int INFLIGHT = (STAGES - 2) * LPT; // what may stay outstanding while tile kt is consumed
     int issued = 0;
-    for (; issued < STAGES - 1 && issued < p.nk; ++issued) issue_tile(issued, issued);
+    for (; issued < STAGES - 1 && issued < p.nk; ++issued) {
+      if constexpr (MODE == 2) issue_fast(issued, issued); else issue_tile(issued, issued);
+    }
     int slot = 0, fill = issued % STAGES;
     for (int kt = 0; kt < p.nk; ++kt) {
       if (issued - kt - 1 >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();              // tile kt landed for every wave; slot `fill` is free
       if (issued < p.nk) {
-        issue_tile(issued, fill);
+        if constexpr (MODE == 2) issue_fast(issued, fill); else issue_tile(issued, fill);
         ++issued;
         fill = (fill + 1 == STAGES) ? 0 : fill + 1;
       }
@@ -267,7 +351,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       slot = (slot + 1 == STAGES) ? 0 : slot + 1;
     }
   } else {
-    if constexpr (GLDS) {
+    if constexpr (MODE == 2) {
+      issue_fast(0, 0);
+    } else if constexpr (MODE == 1) {
       issue_tile(0, 0);
     } else {
       load_tile(0);
@@ -277,7 +363,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     for (int kt = 0; kt < p.nk; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < p.nk) {
-        if constexpr (GLDS) issue_tile(kt + 1, buf ^ 1);
+        if constexpr (MODE == 2) issue_fast(kt + 1, buf ^ 1);
+        else if constexpr (MODE == 1) issue_tile(kt + 1, buf ^ 1);
         else load_tile(kt + 1);
       }
       compute_tile(buf);
@@ -393,7 +480,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 struct Variant {
   const char* name;
   int bm, bn, bk;
-  bool glds;
+  int mode;
   void (*launch)(const ConvParams&, dim3, hipStream_t);
   ctta_status (*prepare)();
 };
@@ -401,13 +488,13 @@ struct Variant {
 template <int BM, int BN, int BK, int STAGES>
 static constexpr size_t smem_bytes() { return (size_t)STAGES * (BM + BN) * BK * 2; }
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int STAGES>
+template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES>
 static void launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
   const size_t smem = smem_bytes<BM, BN, BK, STAGES>();
   conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool GLDS, int STAGES>
+template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES>
 static ctta_status prepare_variant() {
   static bool done = false;
   if (done) return CTTA_OK;
@@ -419,8 +506,8 @@ static ctta_status prepare_variant() {
 }
 
 #define VARIANT(BM, BN, BK, WM, WN, G, S) \
-  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN "_g" #G "_s" #S, BM, BN, BK, G != 0, \
-   launch_variant<BM, BN, BK, WM, WN, (G != 0), S>, prepare_variant<BM, BN, BK, WM, WN, (G != 0), S>}
+  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN "_m" #G "_s" #S, BM, BN, BK, G, \
+   launch_variant<BM, BN, BK, WM, WN, G, S>, prepare_variant<BM, BN, BK, WM, WN, G, S>}
 
 static const Variant kVariants[] = {
     VARIANT(128, 128, 64, 2, 2, 0, 2),  // 1   register-staged (support in_act)
@@ -431,7 +518,7 @@ static const Variant kVariants[] = {
     VARIANT(64, 128, 64, 2, 2, 0, 2),   // 6
     VARIANT(256, 128, 64, 4, 2, 0, 2),  // 7
     VARIANT(128, 64, 64, 2, 2, 0, 2),   // 8
-    VARIANT(128, 128, 64, 2, 2, 1, 2),  // 9   direct-to-LDS twins of 1..8
+    VARIANT(128, 128, 64, 2, 2, 1, 2),  // 9   direct-to-LDS, generic gather: twins of 1..8
     VARIANT(128, 128, 32, 2, 2, 1, 2),  // 10
     VARIANT(256, 64, 64, 4, 1, 1, 2),   // 11
     VARIANT(256, 32, 64, 4, 1, 1, 2),   // 12
@@ -439,16 +526,18 @@ static const Variant kVariants[] = {
     VARIANT(64, 128, 64, 2, 2, 1, 2),   // 14
     VARIANT(256, 128, 64, 4, 2, 1, 2),  // 15
     VARIANT(128, 64, 64, 2, 2, 1, 2),   // 16
-    VARIANT(128, 128, 32, 2, 2, 1, 4),  // 17  multi-stage rings (counted vmcnt)
-    VARIANT(128, 128, 32, 2, 2, 1, 3),  // 18
-    VARIANT(128, 128, 64, 2, 2, 1, 3),  // 19
-    VARIANT(64, 128, 64, 2, 2, 1, 3),   // 20
-    VARIANT(128, 64, 64, 2, 2, 1, 3),   // 21
-    VARIANT(64, 64, 64, 2, 2, 1, 4),    // 22
-    VARIANT(256, 32, 64, 4, 1, 1, 3),   // 23
-    VARIANT(256, 128, 64, 4, 2, 1, 3),  // 24
-    VARIANT(64, 128, 32, 2, 2, 1, 4),   // 25
-    VARIANT(256, 128, 32, 4, 2, 1, 4),  // 26
+    VARIANT(128, 128, 64, 2, 2, 2, 2),  // 17  direct-to-LDS, descriptor fast path: twins of 1..8
+    VARIANT(128, 128, 32, 2, 2, 2, 2),  // 18
+    VARIANT(256, 64, 64, 4, 1, 2, 2),   // 19
+    VARIANT(256, 32, 64, 4, 1, 2, 2),   // 20
+    VARIANT(64, 64, 64, 2, 2, 2, 2),    // 21
+    VARIANT(64, 128, 64, 2, 2, 2, 2),   // 22
+    VARIANT(256, 128, 64, 4, 2, 2, 2),  // 23
+    VARIANT(128, 64, 64, 2, 2, 2, 2),   // 24
+    VARIANT(128, 128, 32, 2, 2, 1, 4),  // 25  multi-stage rings (counted vmcnt)
+    VARIANT(128, 128, 32, 2, 2, 2, 3),  // 26
+    VARIANT(64, 128, 64, 2, 2, 2, 3),   // 27
+    VARIANT(256, 128, 32, 4, 2, 2, 2),  // 28
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -533,13 +622,23 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   const int groups = d->groups > 0 ? d->groups : 1;
   p.xgs = d->x_group_stride; p.wgs = d->w_group_stride; p.ogs = d->out_group_stride;
 
+  const long long x_bytes = (long long)d->batch * p.hs * p.ws * p.c0 * 2;
+  const long long w_bytes = (long long)d->n * d->k_pad * 2;
+  auto fast_ok = [&](int bk) {
+    return p.ct % bk == 0 && p.taps <= 32 && p.c1 == 0 && !d->in_act && x_bytes < 0xFFFFFF00LL && w_bytes < 0xFFFFFF00LL &&
+           (!p.ups || (d->kh == 3 && d->kw == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 &&
+                       d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1));
+  };
   int vid = d->tile;
   if (vid <= 0 || vid > kNumVariants) {
     vid = pick_variant(M, d->n, K, groups);
-    if (glds_default() && !d->in_act) vid += 8;
+    if (!d->in_act && glds_default()) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
   }
-  CTTA_REQUIRE(!(kVariants[vid - 1].glds && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
+  CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
+  CTTA_REQUIRE(kVariants[vid - 1].mode != 2 || fast_ok(kVariants[vid - 1].bk),
+               "conv_gemm: variant %s needs (c0+c1) %% BK == 0, one source and <= 32 taps", kVariants[vid - 1].name);
   const Variant& v = kVariants[vid - 1];
+  p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;
   p.zero = zero_page();
   CTTA_REQUIRE(p.zero, "conv_gemm: could not allocate the zero page");
   p.nk = (int)((K + v.bk - 1) / v.bk);

@@ -65,7 +65,7 @@ def _conv_case(B, Cin, H, W, Cout, k, stride, pad, tile=0, upsample=False, c_spl
     return rel_err(from_nhwc(out), ref)
 
 
-@pytest.mark.parametrize("tile", list(range(0, 27)))
+@pytest.mark.parametrize("tile", list(range(0, 29)))
 def test_conv3x3_all_tiles(tile):
     assert _conv_case(2, 64, 24, 16, 96, 3, 1, 1, tile=tile, tag="t%d" % tile) < BF16_TOL
 
@@ -77,6 +77,17 @@ def test_conv_shapes():
     assert _conv_case(2, 120, 8, 8, 80, 3, 1, 1, c_split=80, tag="cat") < BF16_TOL    # concat gather
     assert _conv_case(2, 64, 8, 8, 64, 3, 1, 1, epilogue=True, tag="epi") < BF16_TOL  # bias+temb+residual
     assert _conv_case(3, 256, 4, 2, 256, 3, 1, 1, tag="deepk") < BF16_TOL        # K = 2304
+
+
+@pytest.mark.parametrize("tile", [0, 9, 17, 18, 22, 24])
+def test_conv_geometries_on_direct_to_lds_paths(tile):
+    """Upsample-fused, stride-2, ragged and deep-K geometries through the generic (mode 1) and
+    descriptor (mode 2) direct-to-LDS paths (Cin multiples of 64 so that mode 2 is eligible)."""
+    assert _conv_case(2, 64, 8, 4, 64, 3, 1, 1, upsample=True, tile=tile, tag="g_up") < BF16_TOL
+    assert _conv_case(2, 64, 16, 8, 72, 3, 2, 1, tile=tile, tag="g_s2") < BF16_TOL
+    assert _conv_case(1, 128, 9, 7, 24, 1, 1, 0, tile=tile, tag="g_1x1") < BF16_TOL
+    assert _conv_case(3, 256, 4, 2, 256, 3, 1, 1, tile=tile, tag="g_deepk") < BF16_TOL
+    assert _conv_case(2, 64, 8, 8, 64, 3, 1, 1, epilogue=True, tile=tile, tag="g_epi") < BF16_TOL
 
 
 def test_conv1d_dilated_lrelu_and_accumulate():
