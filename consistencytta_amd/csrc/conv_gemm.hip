@@ -46,6 +46,97 @@ struct ConvParams {
 // STAGES > 2 (GLDS only): an S-slot LDS ring with S-1 tiles in flight; the wait for tile kt is a
 // COUNTED s_waitcnt vmcnt((S-2) * loads_per_tile) followed by a raw s_barrier, so younger tiles stay
 // in flight across the barrier (a __syncthreads() would drain them: its release carries vmcnt(0)).
+// One accumulator fragment (4 consecutive output channels of one pixel) through the fused epilogue.
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, const f32x4_t a, int m, int n, int b,
+                                               long long mrem, int g) {
+  const long long inb = mrem * p.ldc + n + p.out_offset;
+  if (p.out_limit > 0 && (inb < 0 || inb >= p.out_limit)) return;
+  const size_t oidx = (size_t)((long long)g * p.ogs + (long long)b * p.obs + inb);
+  float v[4] = {a[0], a[1], a[2], a[3]};
+  if (p.bias) {
+    if (p.scalar_store) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (n + r < p.n) v[r] += p.bias[n + r];
+    } else {
+      const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    }
+  }
+  if (p.bias_m) {
+    const float bm = p.bias_m[m];
+    v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+  }
+  if (p.rowvec) {
+    const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_ld + n);
+    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+  }
+  if (p.res) {
+    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
+    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+  }
+  if (p.scalar_store) {
+    // tiny Cout (ldc not a multiple of 4): element-wise fp32 / bf16 stores of the valid channels
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n + r < p.n) {
+        float t = v[r] * p.alpha;
+        if (p.out_act == 1) t = silu_f(t);
+        else if (p.out_act == 2) t = tanhf(t);
+        else if (p.out_act == 3) t = t > 0.f ? t : t * p.out_slope;
+        if (p.out_f32) reinterpret_cast<float*>(p.out)[oidx + r] = t;
+        else reinterpret_cast<bf16_t*>(p.out)[oidx + r] = f2bf(t);
+      }
+    }
+    return;
+  }
+  if (p.out_f32) {
+    float* o = reinterpret_cast<float*>(p.out) + oidx;
+    if (p.accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(o);
+      v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] *= p.alpha;
+      if (p.out_act == 1) v[r] = silu_f(v[r]);
+      else if (p.out_act == 2) v[r] = tanhf(v[r]);
+      else if (p.out_act == 3) v[r] = v[r] > 0.f ? v[r] : v[r] * p.out_slope;
+    }
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    return;
+  }
+  bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + oidx;
+  if (p.accumulate) {
+    const uint2 old = *reinterpret_cast<const uint2*>(o);
+    v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+    v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    v[r] *= p.alpha;
+    if (p.out_act == 1) v[r] = silu_f(v[r]);
+    else if (p.out_act == 2) v[r] = tanhf(v[r]);
+    else if (p.out_act == 3) v[r] = v[r] > 0.f ? v[r] : v[r] * p.out_slope;
+  }
+  uint2 pk;
+  pk.x = pack2bf(v[0], v[1]);
+  pk.y = pack2bf(v[2], v[3]);
+  *reinterpret_cast<uint2*>(o) = pk;
+  if (p.out2) {   // second output: leaky_relu of the SAME (bf16-rounded) values, for the next conv's input
+    float w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float q = bf2f(f2bf(v[r]));
+      w[r] = q > 0.f ? q : q * p.out2_slope;
+    }
+    uint2 pk2;
+    pk2.x = pack2bf(w[0], w[1]);
+    pk2.y = pack2bf(w[2], w[3]);
+    *reinterpret_cast<uint2*>(p.out2 + oidx) = pk2;
+  }
+}
+
 // MODE 0: register-staged tiles (supports in_act).  MODE 1: direct-to-LDS, generic gather (per-lane
 // global pointers, zero page).  MODE 2: direct-to-LDS through BUFFER descriptors with the address
 // work hoisted out of the K loop: requires ct % BK == 0 (a K-tile never straddles a tap, so tap /
@@ -377,99 +468,44 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 
   // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3} (rows of D), m = mb + (lane&15)
   const int nsub = (lane >> 4) * 4;
+  if constexpr (FM * FN <= 16) {
 #pragma unroll
-  for (int j = 0; j < FM; ++j) {
-    const int m = m0 + wm * TM + j * 16 + frow;
-    if (m >= p.M) continue;
-    const int b = m / p.howo;
-    const long long mrem = m - (long long)b * p.howo;
+    for (int j = 0; j < FM; ++j) {
+      const int m = m0 + wm * TM + j * 16 + frow;
+      const bool m_ok = m < p.M;
+      const int b = m_ok ? m / p.howo : 0;
+      const long long mrem = m - (long long)b * p.howo;
 #pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      const int n = n0 + wn * TN + i * 16 + nsub;
-      if (n >= p.n) continue;
-      const long long inb = mrem * p.ldc + n + p.out_offset;
-      if (p.out_limit > 0 && (inb < 0 || inb >= p.out_limit)) continue;
-      const size_t oidx = (size_t)((long long)g * p.ogs + (long long)b * p.obs + inb);
-      float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-      if (p.bias) {
-        if (p.scalar_store) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) if (n + r < p.n) v[r] += p.bias[n + r];
-        } else {
-          const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
-        }
+      for (int i = 0; i < FN; ++i) {
+        const int n = n0 + wn * TN + i * 16 + nsub;
+        if (m_ok && n < p.n) epilogue_store(p, acc[i][j], m, n, b, mrem, g);
       }
-      if (p.bias_m) {
-        const float bm = p.bias_m[m];
-        v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
-      }
-      if (p.rowvec) {
-        const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_ld + n);
-        v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-      }
-      if (p.res) {
-        const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
-        v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-        v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-      }
-      if (p.scalar_store) {
-        // tiny Cout (ldc not a multiple of 4): element-wise fp32 / bf16 stores of the valid channels
+    }
+  } else {
+    // Large wave tiles: unrolling the generic epilogue once per fragment would blow the code size (and
+    // a rolled loop cannot index registers), so fragments bounce through thread-private LDS slots in
+    // chunks of 8 and a ROLLED loop runs the epilogue on them.  The ring is dead by now.
+    constexpr int CH = 8;
+    static_assert((FM * FN) % CH == 0 && (size_t)CH * NT * 16 <= (size_t)STAGES * (BM + BN) * BK * 2, "stage size");
+    __syncthreads();
+    float4* stage = reinterpret_cast<float4*>(smem_raw);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (n + r >= p.n) continue;
-          float t = v[r] * p.alpha;
-          if (p.out_act == 1) t = silu_f(t);
-          else if (p.out_act == 2) t = tanhf(t);
-          else if (p.out_act == 3) t = t > 0.f ? t : t * p.out_slope;
-          if (p.out_f32) reinterpret_cast<float*>(p.out)[oidx + r] = t;
-          else reinterpret_cast<bf16_t*>(p.out)[oidx + r] = f2bf(t);
-        }
-        continue;
+    for (int c0_ = 0; c0_ < FM * FN; c0_ += CH) {
+#pragma unroll
+      for (int f = 0; f < CH; ++f) {
+        const f32x4_t a = acc[(c0_ + f) / FM][(c0_ + f) % FM];
+        stage[f * NT + tid] = make_float4(a[0], a[1], a[2], a[3]);
       }
-      if (p.out_f32) {
-        float* o = reinterpret_cast<float*>(p.out) + oidx;
-        if (p.accumulate) {
-          const float4 old = *reinterpret_cast<const float4*>(o);
-          v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] *= p.alpha;
-          if (p.out_act == 1) v[r] = silu_f(v[r]);
-          else if (p.out_act == 2) v[r] = tanhf(v[r]);
-          else if (p.out_act == 3) v[r] = v[r] > 0.f ? v[r] : v[r] * p.out_slope;
-        }
-        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-      } else {
-        bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + oidx;
-        if (p.accumulate) {
-          const uint2 old = *reinterpret_cast<const uint2*>(o);
-          v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-          v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] *= p.alpha;
-          if (p.out_act == 1) v[r] = silu_f(v[r]);
-          else if (p.out_act == 2) v[r] = tanhf(v[r]);
-          else if (p.out_act == 3) v[r] = v[r] > 0.f ? v[r] : v[r] * p.out_slope;
-        }
-        uint2 pk;
-        pk.x = pack2bf(v[0], v[1]);
-        pk.y = pack2bf(v[2], v[3]);
-        *reinterpret_cast<uint2*>(o) = pk;
-        if (p.out2) {   // second output: leaky_relu of the SAME (bf16-rounded) values, for the next conv's input
-          float w[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float q = bf2f(f2bf(v[r]));
-            w[r] = q > 0.f ? q : q * p.out2_slope;
-          }
-          uint2 pk2;
-          pk2.x = pack2bf(w[0], w[1]);
-          pk2.y = pack2bf(w[2], w[3]);
-          *reinterpret_cast<uint2*>(p.out2 + oidx) = pk2;
+#pragma unroll 1
+      for (int f = 0; f < CH; ++f) {
+        const int idx = c0_ + f;
+        const int i = idx / FM, j = idx % FM;
+        const float4 q = stage[f * NT + tid];
+        const int m = m0 + wm * TM + j * 16 + frow;
+        const int n = n0 + wn * TN + i * 16 + nsub;
+        if (m < p.M && n < p.n) {
+          const int b = m / p.howo;
+          epilogue_store(p, (f32x4_t){q.x, q.y, q.z, q.w}, m, n, b, m - (long long)b * p.howo, g);
         }
       }
     }
@@ -538,6 +574,10 @@ static const Variant kVariants[] = {
     VARIANT(128, 128, 32, 2, 2, 2, 3),  // 26
     VARIANT(64, 128, 64, 2, 2, 2, 3),   // 27
     VARIANT(256, 128, 32, 4, 2, 2, 2),  // 28
+    VARIANT(256, 256, 64, 2, 4, 2, 2),  // 29  8 waves, 128x64 per wave
+    VARIANT(256, 256, 32, 2, 4, 2, 2),  // 30
+    VARIANT(256, 128, 64, 2, 2, 2, 2),  // 31  4 waves, 128x64 per wave
+    VARIANT(256, 128, 32, 2, 2, 2, 2),  // 32
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 

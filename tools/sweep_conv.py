@@ -80,8 +80,10 @@ def main():
             d.alpha, d.groups = 1.0, 1
             d.out, d.ldc, d.tile = out.data_ptr(), Cout, v
             st = N.stream_ptr()
-            for _ in range(2):
-                N.check(L.ctta_conv_gemm(ctypes.byref(d), st))
+            if L.ctta_conv_gemm(ctypes.byref(d), st) != 0:   # variant not eligible for this shape
+                row["tflops"][names[v - 1]] = 0.0
+                continue
+            N.check(L.ctta_conv_gemm(ctypes.byref(d), st))
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             reps = 5
