@@ -604,16 +604,23 @@ static bool glds_default() {
   return v != 0;
 }
 
-// Tile choice from the on-device sweep (tools/sweep_conv.py, profiles/sweep_r01.json); ids index
-// kVariants (1-based).  Returns a register-staged id (1..8); +8 selects its direct-to-LDS twin.
+// Tile choice from the on-device sweep (tools/sweep_conv.py, profiles/sweep_r01*.json); ids index
+// kVariants (1-based).  Returns a register-staged id (1..8); the caller adds +8 / +16 for the
+// direct-to-LDS twins.  kBigTile (256x256x64, 8 waves of 128x64) is chosen separately: it halves the
+// L1->LDS bytes per FLOP, which is what bounds the 128-wide tiles (64 B/clk/CU vs 512 MFMA-cycles).
+static const int kBigTile = 29;
+static bool want_big_tile(long long M, int N, long long K, int groups) {
+  const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * groups;
+  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= 768 && t256 >= 192;
+}
 static int pick_variant(long long M, int N, long long K, int groups) {
   if (N <= 32) return 4;                                   // 256x32
   if (N <= 64) return K >= 512 ? 8 : 5;                    // 128x64 / 64x64
   const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * groups;
   if (t128 < 200) return 5;                                // too few 128x128 tiles to fill 256 CUs
-  if (K >= 4096) return 1;                                 // 128x128x64
+  if (K >= 4096) return N >= 256 ? 1 : 6;                  // 128x128x64 / 64x128x64
   if (K > 1536) return M >= 400000 ? 6 : 2;                // 64x128x64 / 128x128x32
-  if (K > 512) return 2;                                   // 128x128x32
+  if (K > 512) return N >= 256 ? 2 : 6;                    // 128x128x32 / 64x128x64
   return 6;                                                // short K: 64x128x64
 }
 
@@ -671,8 +678,12 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   };
   int vid = d->tile;
   if (vid <= 0 || vid > kNumVariants) {
-    vid = pick_variant(M, d->n, K, groups);
-    if (!d->in_act && glds_default()) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
+    if (!d->in_act && glds_default() && want_big_tile(M, d->n, K, groups) && fast_ok(kVariants[kBigTile - 1].bk)) {
+      vid = kBigTile;
+    } else {
+      vid = pick_variant(M, d->n, K, groups);
+      if (!d->in_act && glds_default()) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
+    }
   }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
   CTTA_REQUIRE(kVariants[vid - 1].mode != 2 || fast_ok(kVariants[vid - 1].bk),
