@@ -291,20 +291,34 @@ class AudioLCM(AudioDistilledModel):
         w = guidance_scale if guidance_scale is not None else float(self.teacher_guidance_scale)
         target = self.student_target_unet(zhat_n_scaled, t_n, guidance=w, encoder_hidden_states=embeds,
                                           encoder_attention_mask=mask).sample
-        if validation_mode != 0:
-            pred = self.student_target_unet(z_np1_scaled, t_np1, guidance=w, encoder_hidden_states=embeds,
-                                            encoder_attention_mask=mask).sample
-        else:
-            target = torch.where((t_n == 0).reshape(-1, 1, 1, 1).to(dev), z_0, target)
-            pred = self.student_unet(z_np1_scaled, t_np1, guidance=w, encoder_hidden_states=embeds,
-                                     encoder_attention_mask=mask).sample
         sig = torch.from_numpy(sch._sigmas_host[inds.numpy()]).to(dev)
-        inst = torch.empty(B, dtype=torch.float32, device=dev)
-        loss = torch.empty(1, dtype=torch.float32, device=dev)
-        N.check(N.lib().ctta_snr_mse_loss(N.ptr(pred.contiguous()), N.ptr(target.contiguous()), N.ptr(sig),
-                                          float(self.snr_gamma or 0.0), N.ptr(inst), N.ptr(loss), B,
-                                          pred[0].numel(), N.stream_ptr()))
-        return loss[0]
+
+        def mse(a, b, sigma=None, gamma=0.0):
+            inst = torch.empty(B, dtype=torch.float32, device=dev)
+            out = torch.empty(1, dtype=torch.float32, device=dev)
+            N.check(N.lib().ctta_snr_mse_loss(N.ptr(a.contiguous()), N.ptr(b.contiguous()), N.ptr(sigma), float(gamma),
+                                              N.ptr(inst), N.ptr(out), B, a[0].numel(), N.stream_ptr()))
+            return out[0]
+
+        if validation_mode != 0:   # :354-405
+            from_np1 = self.student_target_unet(z_np1_scaled, t_np1, guidance=w, encoder_hidden_states=embeds,
+                                                encoder_attention_mask=mask).sample
+            if run_teacher:        # the teacher continues from t_n down to 0 with the full Heun schedule
+                for j in range(int(inds[0]) + order, len(avail)):
+                    t = float(avail[j])
+                    z_in = sch.scale_model_input(zhat_n, t)
+                    pred = self._query_teacher(z_in, t, embeds_cf, mask_cf, guidance_scale)
+                    zhat_n = sch.step(pred, t, zhat_n).prev_sample
+                sch.prev_derivative = sch.dt = sch.sample = None
+            loss_w_gt = mse(from_np1, z_0)
+            loss_w_teacher = mse(from_np1, zhat_n)
+            loss_consis = mse(from_np1, target, sig, self.snr_gamma or 0.0)
+            loss_teacher = mse(zhat_n, z_0)
+            return loss_w_gt, loss_w_teacher, loss_consis, loss_teacher
+        target = torch.where((t_n == 0).reshape(-1, 1, 1, 1).to(dev), z_0, target)
+        pred = self.student_unet(z_np1_scaled, t_np1, guidance=w, encoder_hidden_states=embeds,
+                                 encoder_attention_mask=mask).sample
+        return mse(pred, target, sig, self.snr_gamma or 0.0)
 
     # ---- generation, audio_consistency_model.py:429-548
     @torch.no_grad()

@@ -68,3 +68,16 @@ def vae_inputs(B, T, Fq, tag):
 
 def mel_inputs(B, T, nmel, tag):
     return t(spec.det_uniform(tag + ".mel", (B, 1, T, nmel), 7)) * 1.5
+
+
+def prompt_states(cfg, B, L, tag):
+    """cond / uncond text states + masks (what encode_text_classifier_free would return)."""
+    X = cfg["cross_attention_dim"]
+    cond = t(spec.det_uniform(tag + ".cond", (B, L, X), 11)) * 0.5
+    uncond = t(spec.det_uniform(tag + ".uncond", (B, L, X), 12)) * 0.5
+    lens = (np.abs(spec.det_uniform(tag + ".len", (B,), 13)) * (L - 1)).astype(np.int64) + 1
+    lens[0] = L
+    cmask = torch.arange(L)[None, :] < t(lens)[:, None]
+    umask = torch.zeros(B, L, dtype=torch.bool)
+    umask[:, 0] = True        # "" pads to the cond length: one valid token (audio_distilled_model.py:230-233)
+    return dict(embeds_cf=torch.cat([uncond, cond]), mask_cf=torch.cat([umask, cmask]), embeds=cond, mask=cmask)

@@ -1,0 +1,98 @@
+"""Task-level parity: models.AudioLCM on the HIP path against fixtures
+produced by the reference's own models.AudioLCM (tests/golden/make_golden_distill.py), with the
+reference's internal random draws replayed."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import cases  # noqa: E402
+from consistencytta_amd import scheduler, spec  # noqa: E402
+from consistencytta_amd.models import AudioLCM  # noqa: E402
+from gpu_util import DEV, rel_err, rel_l2  # noqa: E402
+
+REL_L2 = 2.5e-2
+
+
+def _model():
+    cfg = cases.TINY_UNET
+    m = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                 unet_model_config_path="tiny_light.json", unet_config=cfg, snr_gamma=5.0, use_edm=True,
+                 teacher_guidance_scale=-1, num_diffusion_steps=18, vae=None, loss_type="mse",
+                 target_ema_decay=0.95, ema_decay=0.999)
+    m.teacher_unet.load_state_dict(cases.unet_weights(cfg, False, 0))
+    m.student_unet.load_state_dict(cases.unet_weights(cfg, True, 1))
+    m.student_target_unet.load_state_dict(cases.unet_weights(cfg, True, 2))
+    m.student_ema_unet.load_state_dict(cases.unet_weights(cfg, True, 3))
+    m.to(DEV)
+    P = {k: v.to(DEV) for k, v in cases.prompt_states(cfg, 3, 6, "distill").items()}
+    z0 = (cases.t(spec.det_uniform("distill.z0", (3, 8, 32, 8), 14)) * 0.9).to(DEV)
+    return m, P, z0
+
+
+def test_distillation_forward_losses_and_teacher_query(golden):
+    g = golden("distill_tiny")
+    m, P, z0 = _model()
+    m.train()   # as in train_one_epoch; frozen sub-nets stay in eval mode
+    loss = m(z0, None, P, time_inds=torch.from_numpy(g["time_inds"]) * 2,
+             gaussian_noise=torch.from_numpy(g["noise"]).to(DEV), guidance_scale=torch.from_numpy(g["guidance"]))
+    ref = float(g["train_loss"])
+    print("distillation loss hip %.6f ref %.6f" % (float(loss), ref))
+    assert abs(float(loss) - ref) <= 5e-2 * ref     # a squared bf16 error budget: 2 * REL_L2
+    m.eval()
+    vl = m(z0, None, P, validation_mode=2, run_teacher=True, gaussian_noise=torch.from_numpy(g["val_noise"]).to(DEV),
+           guidance_scale=torch.from_numpy(g["val_guidance"]))
+    got = np.array([float(v) for v in vl])
+    print("validation losses hip", got, "ref", g["val_losses"])
+    np.testing.assert_allclose(got, g["val_losses"], rtol=6e-2)
+    assert m.noise_scheduler.state_in_first_order
+    ts = m.noise_scheduler.timesteps[torch.tensor([0, 6, 32])]
+    zq = cases.t(spec.det_uniform("distill.zq", (3, 8, 32, 8), 15)).to(DEV)
+    q = m._query_teacher(zq, ts, P["embeds_cf"], P["mask_cf"], torch.tensor([0.5, 3.0, 5.5]))
+    assert rel_l2(q, torch.from_numpy(g["query_teacher"])) <= REL_L2
+
+
+def test_inference_student_multistep_and_heun_teacher(golden):
+    g = golden("distill_tiny")
+    m, P, _ = _model()
+    m.eval()
+    sched = scheduler.HeunDiscreteScheduler.from_pretrained("stabilityai/stable-diffusion-2-1", subfolder="scheduler")
+    noise = (cases.t(spec.det_uniform("distill.inf_noise", (3, 8, 256, 16), 16)) * np.float32(np.sqrt(3.0))).to(DEV)
+    stu, tea, _, _ = m.inference(P, sched, guidance_scale_input=4.0, guidance_scale_post=1.0, num_steps=1, use_edm=True,
+                                 use_ema=True, query_teacher=True, num_teacher_steps=3, return_all=True, noise=noise)
+    l2s, l2t = rel_l2(stu, torch.from_numpy(g["inf_student_1step"])), rel_l2(tea, torch.from_numpy(g["inf_teacher_3steps"]))
+    print("inference 1-step rel_l2 %.3e, Heun teacher (5 CFG queries) rel_l2 %.3e" % (l2s, l2t))
+    assert l2s <= REL_L2 and l2t <= 2 * REL_L2      # the teacher chains 5 U-Net evaluations
+    assert sched.state_in_first_order
+    # 2-step generation with post-CFG: replay the reference's re-noising draw
+    ren = torch.from_numpy(g["inf_renoise"]).to(DEV)
+    orig = torch.randn_like
+    torch.randn_like = lambda x, *a, **k: ren.clone()
+    try:
+        stu2 = m.inference(P, sched, guidance_scale_input=3.0, guidance_scale_post=2.0, num_steps=2, use_edm=True,
+                           use_ema=False, noise=noise)
+    finally:
+        torch.randn_like = orig
+    l2 = rel_l2(stu2, torch.from_numpy(g["inf_student_2step_cfg"]))
+    print("inference 2-step + post-CFG rel_l2 %.3e" % l2)
+    assert l2 <= 2 * REL_L2
+
+
+def test_update_ema_matches_reference_and_resyncs_engines(golden):
+    g = golden("distill_tiny")
+    m, P, z0 = _model()
+    key = str(g["ema_key"])
+    m.train()
+    x, ts, gs, enc, mask = cases.unet_inputs(cases.TINY_UNET, 1, 16, 8, 4, "ema")
+    args = dict(encoder_hidden_states=enc.to(DEV), encoder_attention_mask=mask.to(DEV))
+    before = m.student_target_unet(x.to(DEV), ts.to(DEV), guidance=gs.to(DEV), **args).sample.clone()
+    m.update_ema()
+    sd_t, sd_e = m.student_target_unet.state_dict(), m.student_ema_unet.state_dict()
+    assert torch.equal(sd_t[key][:4].cpu(), torch.from_numpy(g["ema_target_after"]))    # bit-exact
+    assert torch.equal(sd_e[key][:4].cpu(), torch.from_numpy(g["ema_ema_after"]))
+    after = m.student_target_unet(x.to(DEV), ts.to(DEV), guidance=gs.to(DEV), **args).sample
+    assert not torch.equal(before, after)     # the engine re-packed the updated shadow weights
+    m.eval()
+    with pytest.raises(AssertionError):
+        m.update_ema()                         # "EMA update should only be called during training"

@@ -107,3 +107,46 @@ def test_vae_hifigan_full_width(golden):
         mel_in = cases.mel_inputs(1, 64, 64, "hifigan_full")
         wav, _, _ = nets.mel_to_waveform(spec.HIFIGAN_16K_64, sd, mel_in)
         close(wav, g["wav"])
+
+
+def _distill_setup():
+    prompt_states = cases.prompt_states
+    from oracle import distill
+    cfg = cases.TINY_UNET
+    n = distill.Nets(cfg, cases.unet_weights(cfg, False, 0), cases.unet_weights(cfg, True, 1),
+                     cases.unet_weights(cfg, True, 2), cases.unet_weights(cfg, True, 3))
+    P = prompt_states(cfg, 3, 6, "distill")
+    z0 = cases.t(spec.det_uniform("distill.z0", (3, 8, 32, 8), 14)) * 0.9
+    return distill, n, P, z0
+
+
+def test_distillation_loss_and_teacher_query(golden):
+    """oracle.distill vs the reference's own AudioLCM.forward / _query_teacher (a13, a15, a16)."""
+    g = golden("distill_tiny")
+    distill, n, P, z0 = _distill_setup()
+    with torch.no_grad():
+        inds = torch.from_numpy(g["time_inds"]) * 2
+        loss = distill.distill_loss(n, P, z0, torch.from_numpy(g["noise"]), inds, torch.from_numpy(g["guidance"]))
+        assert abs(float(loss) - float(g["train_loss"])) <= 2e-4 * float(g["train_loss"])
+        _, sig = heun.set_timesteps(18)
+        ts, _ = heun.set_timesteps(18)
+        zq = cases.t(spec.det_uniform("distill.zq", (3, 8, 32, 8), 15))
+        tq = torch.from_numpy(ts[[0, 6, 32]])
+        close(distill.query_teacher(n, zq, tq, P["embeds_cf"], P["mask_cf"], torch.tensor([0.5, 3.0, 5.5])),
+              g["query_teacher"])
+        vl = distill.validation_losses(n, P, z0, torch.from_numpy(g["val_noise"]), 2,
+                                       torch.from_numpy(g["val_guidance"]))
+        np.testing.assert_allclose([float(v) for v in vl], g["val_losses"], rtol=5e-4)
+
+
+@pytest.mark.slow
+def test_inference_student_and_teacher_loops(golden):
+    """oracle.distill inference vs AudioLCM.inference (a14): 1-step, 2-step + post-CFG, Heun teacher."""
+    g = golden("distill_tiny")
+    distill, n, P, _ = _distill_setup()
+    noise = cases.t(spec.det_uniform("distill.inf_noise", (3, 8, 256, 16), 16)) * np.float32(np.sqrt(3.0))
+    with torch.no_grad():
+        close(distill.inference_student(n, n.ema, P, noise, 4.0, 1.0, 1), g["inf_student_1step"])
+        close(distill.inference_student(n, n.target, P, noise, 3.0, 2.0, 2, torch.from_numpy(g["inf_renoise"])),
+              g["inf_student_2step_cfg"])
+        close(distill.inference_teacher(n, P, noise, 4.0, 3), g["inf_teacher_3steps"], 5e-4, 5e-5)
