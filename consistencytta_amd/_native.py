@@ -69,7 +69,7 @@ class ConvDesc(Structure):
         ("out2", c_void_p), ("out2_slope", c_float),
         ("out_batch_stride", c_int64), ("out_offset", c_int64), ("out_limit", c_int64),
         ("groups", c_int), ("x_group_stride", c_int64), ("w_group_stride", c_int64),
-        ("out_group_stride", c_int64), ("tile", c_int),
+        ("out_group_stride", c_int64), ("tile", c_int), ("x_stride", c_int),
     ]
 
 
@@ -126,6 +126,23 @@ SIGNATURES = {
     "ctta_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_time_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "ctta_fourier_features": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "ctta_transpose_bf16": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "ctta_im2col_t": (c_int, [c_void_p] + [c_int] * 13 + [c_void_p, c_int, c_int, c_void_p]),
+    "ctta_wgrad_scatter": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "ctta_row_scatter": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "ctta_groupnorm_bwd_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "ctta_groupnorm_stats": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "ctta_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ctta_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "ctta_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ctta_add_slices": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "ctta_zero_insert2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ctta_pool2_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ctta_softmax_bias_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "ctta_softmax_bwd_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "ctta_linear_f32_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ctta_snr_mse_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "ctta_prof_enable": (None, [c_int]),
     "ctta_prof_collect": (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_char_p]),
 }

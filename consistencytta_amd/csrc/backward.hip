@@ -1,0 +1,812 @@
+// Backward-pass kernels of the consistency-distillation step (student U-Net only; the teacher,
+// target and EMA networks are inference-only).  Every contraction of the backward pass runs on
+// conv_gemm: data gradients with re-packed (flipped / transposed) weights, weight gradients as
+//     dW[k][n] = sum_m  Q[k][m] * P[n][m],   Q = im2col(X)^T (+ indicator rows),  P = dY^T
+// where both operands are made m-contiguous by the transpose kernels below (the extra rows of Q
+// give the bias gradient and the per-sample time-embedding gradient from the same GEMM).
+// The kernels here are the HBM-bound glue: transposes, GroupNorm / LayerNorm / GEGLU / softmax
+// backward, gradient scatter into the reference parameter layout, AdamW.
+// Reference semantics: torch autograd of resnet.py:549-597, attention.py:276-334,
+// attention_processor.py:1068-1147; optimizer tools/train_utils.py:59-63 (torch.optim.AdamW).
+#include "common.h"
+
+#include <math.h>
+
+static int grid1d(long long total, int per = 256, int cap = 16384) {
+  long long b = (total + per - 1) / per;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// ------------------------------------------------------------------------------ transposes
+// dst[g][c][r] = src[g][r][col0 + c] for r < rows, 0 for rows <= r < dst_ld.   64x64 tiles via LDS.
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, long long sgs, int rows,
+                                                        int cols, int src_ld, int col0, bf16_t* __restrict__ dst,
+                                                        long long dgs, int dst_ld) {
+  __shared__ bf16_t tile[64][72];
+  const int g = blockIdx.z;
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const bf16_t* s = src + (size_t)g * sgs;
+  bf16_t* d = dst + (size_t)g * dgs;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = tid + i * 256;
+    const int r = ch >> 3, cc = (ch & 7) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < rows && c0 + cc < cols) v = *reinterpret_cast<const uint4*>(s + (size_t)(r0 + r) * src_ld + col0 + c0 + cc);
+    *reinterpret_cast<uint4*>(&tile[r][cc]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = tid + i * 256;
+    const int c = ch >> 3, rr = (ch & 7) * 8;
+    if (c0 + c < cols && r0 + rr < dst_ld) {
+      uint32_t w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[rr + 2 * e][c] | ((uint32_t)tile[rr + 2 * e + 1][c] << 16);
+      *reinterpret_cast<uint4*>(d + (size_t)(c0 + c) * dst_ld + r0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+
+extern "C" ctta_status ctta_transpose_bf16(const void* src, int64_t src_group_stride, int rows, int cols, int src_ld,
+                                           int col0, void* dst, int64_t dst_group_stride, int dst_ld, int groups,
+                                           void* stream) {
+  CTTA_REQUIRE(src && dst && cols % 8 == 0 && src_ld % 8 == 0 && col0 % 8 == 0 && dst_ld % 8 == 0 && dst_ld >= rows,
+               "transpose: bad arguments (cols=%d src_ld=%d col0=%d dst_ld=%d rows=%d)", cols, src_ld, col0, dst_ld, rows);
+  dim3 grid((dst_ld + 63) / 64, (cols + 63) / 64, groups);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     (long long)src_group_stride, rows, cols, src_ld, col0, (bf16_t*)dst, (long long)dst_group_stride,
+                     dst_ld);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// Q[(t*C + c)][m] = X[pixel(m, tap t)][c] (0 outside the image), m = (b, oh, ow); rows padded to m_pad.
+struct Im2colParams {
+  const bf16_t* x; int C, B, hi, wi, hs, ws, ups, ho, wo, kh, kw, sh, sw, ph, pw, dh, dw, M, m_pad;
+  bf16_t* dst;
+};
+__global__ __launch_bounds__(256) void im2col_t_kernel(Im2colParams p) {
+  __shared__ bf16_t tile[64][72];
+  const int t = blockIdx.z;
+  const int kh = t / p.kw, kw = t - kh * p.kw;
+  const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = tid + i * 256;
+    const int r = ch >> 3, cc = (ch & 7) * 8;
+    const int m = m0 + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (m < p.M && c0 + cc < p.C) {
+      const int howo = p.ho * p.wo;
+      const int b = m / howo;
+      const int rem = m - b * howo;
+      const int oh = rem / p.wo, ow = rem - oh * p.wo;
+      int ih = oh * p.sh - p.ph + kh * p.dh, iw = ow * p.sw - p.pw + kw * p.dw;
+      if ((unsigned)ih < (unsigned)p.hi && (unsigned)iw < (unsigned)p.wi) {
+        if (p.ups) { ih >>= 1; iw >>= 1; }
+        v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(b * p.hs + ih) * p.ws + iw) * p.C + c0 + cc);
+      }
+    }
+    *reinterpret_cast<uint4*>(&tile[r][cc]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = tid + i * 256;
+    const int c = ch >> 3, rr = (ch & 7) * 8;
+    if (c0 + c < p.C && m0 + rr < p.m_pad) {
+      uint32_t w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[rr + 2 * e][c] | ((uint32_t)tile[rr + 2 * e + 1][c] << 16);
+      *reinterpret_cast<uint4*>(p.dst + ((size_t)t * p.C + c0 + c) * p.m_pad + m0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+// rows: [0] = 1 for m < M ; [1 + b] = 1 for pixels of sample b (n_batch rows; 0 disables)
+__global__ void indicator_rows_kernel(bf16_t* __restrict__ dst, int M, int m_pad, int per_batch, int n_batch) {
+  const long long total = (long long)(1 + n_batch) * m_pad;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i % m_pad);
+    const int r = (int)(i / m_pad);
+    bool one = m < M && (r == 0 || m / per_batch == r - 1);
+    dst[i] = one ? (bf16_t)0x3F80 : (bf16_t)0;
+  }
+}
+
+extern "C" ctta_status ctta_im2col_t(const void* x, int c, int batch, int hi, int wi, int upsample, int ho, int wo,
+                                     int kh, int kw, int stride, int pad_h, int pad_w, int dil_w, void* dst, int m_pad,
+                                     int indicator_batches, void* stream) {
+  CTTA_REQUIRE(x && dst && c % 8 == 0 && m_pad % 8 == 0, "im2col_t: bad arguments");
+  Im2colParams p;
+  p.x = (const bf16_t*)x; p.C = c; p.B = batch; p.hi = hi; p.wi = wi; p.ups = upsample ? 1 : 0;
+  p.hs = p.ups ? hi / 2 : hi; p.ws = p.ups ? wi / 2 : wi; p.ho = ho; p.wo = wo; p.kh = kh; p.kw = kw;
+  p.sh = p.sw = stride; p.ph = pad_h; p.pw = pad_w; p.dh = 1; p.dw = dil_w;
+  p.M = batch * ho * wo; p.m_pad = m_pad; p.dst = (bf16_t*)dst;
+  CTTA_REQUIRE(m_pad >= p.M, "im2col_t: m_pad < M");
+  dim3 grid((m_pad + 63) / 64, (c + 63) / 64, kh * kw);
+  hipLaunchKernelGGL(im2col_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+  CTTA_LAUNCH_CHECK();
+  if (indicator_batches >= 0) {
+    bf16_t* rows = (bf16_t*)dst + (size_t)kh * kw * c * m_pad;
+    const long long total = (long long)(1 + indicator_batches) * m_pad;
+    hipLaunchKernelGGL(indicator_rows_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, rows, p.M, m_pad,
+                       ho * wo, indicator_batches);
+    CTTA_LAUNCH_CHECK();
+  }
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ gradient scatter
+// slabs [S][R][ldn] fp32 (R >= k_rows (+ extra rows)); weight grad:
+//   grad_w[row_off[n] + col_off[k]] (+)= sum_s slab[s][k][n]     (k < k_rows, n < n_cols, offsets >= 0, aux ok)
+__global__ void wgrad_scatter_kernel(const float* __restrict__ slabs, int S, long long slab_stride, int ldn, int k_rows,
+                                     int n_cols, const int* __restrict__ row_off, const int* __restrict__ col_off,
+                                     const int* __restrict__ row_aux, const int* __restrict__ col_aux, int aux_limit,
+                                     float* __restrict__ grad, int accumulate) {
+  const long long total = (long long)k_rows * n_cols;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % n_cols);
+    const int k = (int)(i / n_cols);
+    const int ro = row_off[n], co = col_off[k];
+    if (ro < 0 || co < 0) continue;
+    if (aux_limit > 0 && row_aux[n] + col_aux[k] >= aux_limit) continue;
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += slabs[(size_t)s * slab_stride + (size_t)k * ldn + n];
+    float* g = grad + (size_t)ro + (size_t)co;
+    *g = accumulate ? *g + v : v;
+  }
+}
+// vector grad (bias / per-sample rows): dst[idx[n]] (+)= sum_s slab[s][row][n]  (idx[n] < 0 skipped; idx NULL = identity)
+__global__ void row_scatter_kernel(const float* __restrict__ slabs, int S, long long slab_stride, int ldn, int row,
+                                   int n_cols, const int* __restrict__ idx, float* __restrict__ dst, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_cols) return;
+  const int j = idx ? idx[n] : n;
+  if (j < 0) return;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += slabs[(size_t)s * slab_stride + (size_t)row * ldn + n];
+  dst[j] = accumulate ? dst[j] + v : v;
+}
+
+extern "C" ctta_status ctta_wgrad_scatter(const float* slabs, int n_slabs, int64_t slab_stride, int ldn, int k_rows,
+                                          int n_cols, const int32_t* row_off, const int32_t* col_off,
+                                          const int32_t* row_aux, const int32_t* col_aux, int aux_limit, float* grad,
+                                          int accumulate, void* stream) {
+  CTTA_REQUIRE(slabs && row_off && col_off && grad && n_slabs >= 1, "wgrad_scatter: bad arguments");
+  const long long total = (long long)k_rows * n_cols;
+  hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs,
+                     (long long)slab_stride, ldn, k_rows, n_cols, row_off, col_off, row_aux, col_aux, aux_limit, grad,
+                     accumulate);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+extern "C" ctta_status ctta_row_scatter(const float* slabs, int n_slabs, int64_t slab_stride, int ldn, int row,
+                                        int n_cols, const int32_t* idx, float* dst, int accumulate, void* stream) {
+  CTTA_REQUIRE(slabs && dst && n_slabs >= 1, "row_scatter: bad arguments");
+  hipLaunchKernelGGL(row_scatter_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs,
+                     (long long)slab_stride, ldn, row, n_cols, idx, dst, accumulate);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ GroupNorm backward
+// y = silu?(xhat*gamma + beta), xhat = (x - mean)*rstd.  stats: [B][G][2] = (mean, rstd).
+__device__ __forceinline__ float silu_grad(float z) {
+  const float s = 1.0f / (1.0f + __expf(-z));
+  return s * (1.0f + z * (1.0f - s));
+}
+// pass 1: per (b, chunk) per-channel sums  A = sum dz, Bc = sum dz*xhat     part: [B][nchunk][2][C]
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                             int HW, int C, int G, int ppc, int nchunk,
+                                                             const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int silu,
+                                                             float* __restrict__ part) {
+  extern __shared__ float sm[];   // [PL][C] A, [PL][C] Bc
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int VC = C / 8, cpg = C / G;
+  int PL, vstride, tv, tp;
+  if (VC <= 256) { PL = 256 / VC; vstride = VC; tv = tid % VC; tp = tid / VC; }
+  else { PL = 1; vstride = 256; tv = tid; tp = 0; }
+  const int p0 = chunk * ppc, p1 = min(HW, p0 + ppc);
+  float* sA = sm;
+  float* sB = sm + PL * C;
+  if (tp < PL) {
+    for (int v = tv; v < VC; v += vstride) {
+      float a[8], bb[8], mean[8], rstd[8], gm[8], bt[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = v * 8 + e;
+        const float* st = stats + ((size_t)b * G + c / cpg) * 2;
+        mean[e] = st[0]; rstd[e] = st[1]; gm[e] = gamma[c]; bt[e] = beta[c];
+        a[e] = 0.f; bb[e] = 0.f;
+      }
+      for (int pix = p0 + tp; pix < p1; pix += PL) {
+        float fx[8], fd[8];
+        const size_t off = ((size_t)b * HW + pix) * C + v * 8;
+        unpack8(*reinterpret_cast<const uint4*>(x + off), fx);
+        unpack8(*reinterpret_cast<const uint4*>(dy + off), fd);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (fx[e] - mean[e]) * rstd[e];
+          float dz = fd[e];
+          if (silu) dz *= silu_grad(xh * gm[e] + bt[e]);
+          a[e] += dz; bb[e] += dz * xh;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sA[tp * C + v * 8 + e] = a[e]; sB[tp * C + v * 8 + e] = bb[e]; }
+    }
+  }
+  __syncthreads();
+  float* o = part + ((size_t)b * nchunk + chunk) * 2 * C;
+  for (int c = tid; c < C; c += 256) {
+    float a = 0.f, bb = 0.f;
+    for (int l = 0; l < PL; ++l) { a += sA[l * C + c]; bb += sB[l * C + c]; }
+    o[c] = a; o[C + c] = bb;
+  }
+}
+// pass 2: fold chunks; coef[b][g] = (S1/n, S2/n) with S1 = sum_c gamma*A, S2 = sum_c gamma*Bc;
+// dgamma[c] (+)= sum_b Bc, dbeta[c] (+)= sum_b A.  One block.
+__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int B, int nchunk, int G, int C, int HW,
+                                       const float* __restrict__ gamma, float* __restrict__ coef,
+                                       float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                       int accumulate) {
+  // red: [B][2][C] folded per-channel sums (scratch)
+  const int cpg = C / G;
+  for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
+    const int b = i / C, c = i - b * C;
+    double a = 0.0, bb = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float* o = part + ((size_t)b * nchunk + ch) * 2 * C;
+      a += (double)o[c]; bb += (double)o[C + c];
+    }
+    red[((size_t)b * 2) * C + c] = (float)a;
+    red[((size_t)b * 2 + 1) * C + c] = (float)bb;
+  }
+  __syncthreads();
+  const double n = (double)HW * cpg;
+  for (int i = threadIdx.x; i < B * G; i += blockDim.x) {
+    const int b = i / G, g = i - b * G;
+    double s1 = 0.0, s2 = 0.0;
+    for (int cc = 0; cc < cpg; ++cc) {
+      const int c = g * cpg + cc;
+      s1 += (double)gamma[c] * red[((size_t)b * 2) * C + c];
+      s2 += (double)gamma[c] * red[((size_t)b * 2 + 1) * C + c];
+    }
+    coef[(size_t)i * 2] = (float)(s1 / n);
+    coef[(size_t)i * 2 + 1] = (float)(s2 / n);
+  }
+  if (dgamma) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      double a = 0.0, bb = 0.0;
+      for (int b = 0; b < B; ++b) { a += red[((size_t)b * 2) * C + c]; bb += red[((size_t)b * 2 + 1) * C + c]; }
+      dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+      dgamma[c] = accumulate ? dgamma[c] + (float)bb : (float)bb;
+    }
+  }
+}
+// pass 3: dx = rstd * (dz*gamma - S1/n - xhat*S2/n)   (+ existing dx when acc_dx)
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           bf16_t* __restrict__ dx, int HW, int C, int G,
+                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ coef,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int silu, int acc_dx,
+                                                           long long total_vec) {
+  const int VC = C / 8, cpg = C / G;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % VC);
+    const int b = (int)((idx / VC) / HW);
+    float fx[8], fd[8], fo[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + (size_t)idx * 8), fx);
+    unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)idx * 8), fd);
+    if (acc_dx) unpack8(*reinterpret_cast<const uint4*>(dx + (size_t)idx * 8), fo);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = v * 8 + e;
+      const int g = c / cpg;
+      const float* st = stats + ((size_t)b * G + g) * 2;
+      const float* cf = coef + ((size_t)b * G + g) * 2;
+      const float xh = (fx[e] - st[0]) * st[1];
+      float dz = fd[e];
+      if (silu) dz *= silu_grad(xh * gamma[c] + beta[c]);
+      const float r = st[1] * (dz * gamma[c] - cf[0] - xh * cf[1]);
+      fo[e] = acc_dx ? fo[e] + r : r;
+    }
+    *reinterpret_cast<uint4*>(dx + (size_t)idx * 8) = pack8(fo);
+  }
+}
+
+static void gnb_geometry(int hw, int c, int* ppc, int* nchunk) {
+  int p = 16384 / c;
+  if (p < 16) p = 16;
+  if (p > 1024) p = 1024;
+  if (p > hw) p = hw;
+  *ppc = p;
+  *nchunk = (hw + p - 1) / p;
+}
+extern "C" size_t ctta_groupnorm_bwd_scratch_floats(int batch, int hw, int c, int groups) {
+  int ppc, nchunk;
+  gnb_geometry(hw, c, &ppc, &nchunk);
+  return (size_t)batch * nchunk * 2 * c + (size_t)batch * 2 * c + (size_t)batch * groups * 2 + 64;
+}
+extern "C" ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* dx, int batch, int hw, int c, int groups,
+                                          const float* stats, const float* gamma, const float* beta, int silu,
+                                          int accumulate_dx, float* dgamma, float* dbeta, int accumulate_param,
+                                          float* scratch, void* stream) {
+  CTTA_REQUIRE(x && dy && dx && stats && gamma && beta && scratch, "groupnorm_bwd: null pointer");
+  CTTA_REQUIRE(c % 8 == 0 && c % groups == 0, "groupnorm_bwd: C=%d groups=%d", c, groups);
+  hipStream_t s = (hipStream_t)stream;
+  int ppc, nchunk;
+  gnb_geometry(hw, c, &ppc, &nchunk);
+  float* part = scratch;
+  float* red = part + (size_t)batch * nchunk * 2 * c;
+  float* coef = red + (size_t)batch * 2 * c;
+  const int VC = c / 8, PL = VC <= 256 ? 256 / VC : 1;
+  hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, batch), dim3(256), (size_t)2 * PL * c * sizeof(float), s,
+                     (const bf16_t*)x, (const bf16_t*)dy, hw, c, groups, ppc, nchunk, stats, gamma, beta, silu, part);
+  CTTA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, part, batch, nchunk, groups, c, hw, gamma, coef,
+                     red, dgamma, dbeta, accumulate_param);
+  CTTA_LAUNCH_CHECK();
+  const long long total_vec = (long long)batch * hw * VC;
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid1d(total_vec, 256, 8192)), dim3(256), 0, s, (const bf16_t*)x,
+                     (const bf16_t*)dy, (bf16_t*)dx, hw, c, groups, stats, coef, gamma, beta, silu, accumulate_dx,
+                     total_vec);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// GroupNorm statistics (mean, rstd) per (batch, group) for the training forward: reuses the forward
+// partial sums layout; one small kernel that recomputes them from x (saved-tensor friendly).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* __restrict__ x, int HW, int C, int G, float eps,
+                                                       float* __restrict__ stats) {
+  __shared__ double red[2][256];
+  const int b = blockIdx.y, g = blockIdx.x, cpg = C / G;
+  double s = 0.0, q = 0.0;
+  const long long n = (long long)HW * cpg;
+  for (long long i = threadIdx.x; i < n; i += 256) {
+    const int pix = (int)(i / cpg), cc = (int)(i - (long long)pix * cpg);
+    const float v = bf2f(x[((size_t)b * HW + pix) * C + g * cpg + cc]);
+    s += v; q += (double)v * v;
+  }
+  red[0][threadIdx.x] = s; red[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double mean = red[0][0] / (double)n;
+    double var = red[1][0] / (double)n - mean * mean;
+    if (var < 0) var = 0;
+    stats[((size_t)b * G + g) * 2] = (float)mean;
+    stats[((size_t)b * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+  }
+}
+extern "C" ctta_status ctta_groupnorm_stats(const void* x, int batch, int hw, int c, int groups, float eps, float* stats,
+                                            void* stream) {
+  CTTA_REQUIRE(x && stats && c % groups == 0, "groupnorm_stats: bad arguments");
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(groups, batch), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, hw, c,
+                     groups, eps, stats);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ LayerNorm backward
+// One wave per row, ROWS_PER_BLOCK rows per wave-slot; dgamma/dbeta via LDS + one atomicAdd per block/column.
+template <int MAXV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                     bf16_t* __restrict__ dx, long long rows, int d, int ld,
+                                                     const float* __restrict__ gamma, float eps, int acc_dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     int rows_per_block) {
+  extern __shared__ float sm[];   // [2][ld]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int VC = ld / 8;
+  for (int i = threadIdx.x; i < 2 * ld; i += 256) sm[i] = 0.f;
+  __syncthreads();
+  float gacc[MAXV][8], bacc[MAXV][8];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { gacc[i][e] = 0.f; bacc[i][e] = 0.f; }
+  const long long r_begin = (long long)blockIdx.x * rows_per_block;
+  const long long r_end = r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows;
+  for (long long row = r_begin + wave; row < r_end; row += 4) {
+    float fx[MAXV][8], fd[MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * 64;
+      if (v < VC) {
+        unpack8(*reinterpret_cast<const uint4*>(x + (size_t)row * ld + v * 8), fx[i]);
+        unpack8(*reinterpret_cast<const uint4*>(dy + (size_t)row * ld + v * 8), fd[i]);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if (!(v < VC && v * 8 + e < d)) { fx[i][e] = 0.f; fd[i][e] = 0.f; }
+        s += fx[i][e];
+      }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = (lane + i * 64) * 8 + e;
+        if (c < d) { const float t = fx[i][e] - mean; q += t * t; }
+      }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int c = (lane + i * 64) * 8 + e;
+        if (c < d) {
+          const float xh = (fx[i][e] - mean) * rstd;
+          const float dg = fd[i][e] * gamma[c];
+          s1 += dg; s2 += dg * xh;
+          gacc[i][e] += fd[i][e] * xh; bacc[i][e] += fd[i][e];
+          fx[i][e] = xh; fd[i][e] = dg;
+        }
+      }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * 64;
+      if (v < VC) {
+        float o[8];
+        if (acc_dx) unpack8(*reinterpret_cast<const uint4*>(dx + (size_t)row * ld + v * 8), o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = v * 8 + e;
+          const float r = c < d ? rstd * (fd[i][e] - s1 - fx[i][e] * s2) : 0.f;
+          o[e] = acc_dx ? o[e] + r : r;
+        }
+        *reinterpret_cast<uint4*>(dx + (size_t)row * ld + v * 8) = pack8(o);
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int v = lane + i * 64;
+    if (v < VC)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sm[v * 8 + e], gacc[i][e]);
+        atomicAdd(&sm[ld + v * 8 + e], bacc[i][e]);
+      }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    atomicAdd(&dgamma[c], sm[c]);
+    atomicAdd(&dbeta[c], sm[ld + c]);
+  }
+}
+extern "C" ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t rows, int d, int ld,
+                                          const float* gamma, float eps, int accumulate_dx, float* dgamma, float* dbeta,
+                                          void* stream) {
+  CTTA_REQUIRE(x && dy && dx && gamma && dgamma && dbeta, "layernorm_bwd: null pointer (dgamma/dbeta must be zeroed or hold the running sum)");
+  CTTA_REQUIRE(ld % 8 == 0 && d <= ld && ld <= 2048, "layernorm_bwd: d=%d ld=%d", d, ld);
+  const int rpb = 64;
+  const dim3 grid((unsigned)cdiv64(rows, rpb));
+  const size_t smem = (size_t)2 * ld * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define LNB(MV) hipLaunchKernelGGL(ln_bwd_kernel<MV>, grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, \
+                                   (bf16_t*)dx, (long long)rows, d, ld, gamma, eps, accumulate_dx, dgamma, dbeta, rpb)
+  if (ld <= 512) LNB(1); else if (ld <= 1024) LNB(2); else LNB(4);
+#undef LNB
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ GEGLU / SiLU / adds
+// f = [value | gate] (rows x 2hp), dout (rows x hp) -> df (rows x 2hp)
+__global__ void geglu_bwd_kernel(const bf16_t* __restrict__ f, const bf16_t* __restrict__ dout, bf16_t* __restrict__ df,
+                                 long long rows, int hp) {
+  const int vc = hp / 8;
+  const long long total = rows * vc;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % vc);
+    const long long r = idx / vc;
+    float a[8], g[8], dd[8], da[8], dg[8];
+    unpack8(*reinterpret_cast<const uint4*>(f + (size_t)r * 2 * hp + v * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(f + (size_t)r * 2 * hp + hp + v * 8), g);
+    unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * hp + v * 8), dd);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float cdf = 0.5f * (1.0f + erff(g[e] * 0.70710678118654752f));
+      const float pdf = 0.3989422804014327f * __expf(-0.5f * g[e] * g[e]);
+      da[e] = dd[e] * g[e] * cdf;
+      dg[e] = dd[e] * a[e] * (cdf + g[e] * pdf);
+    }
+    *reinterpret_cast<uint4*>(df + (size_t)r * 2 * hp + v * 8) = pack8(da);
+    *reinterpret_cast<uint4*>(df + (size_t)r * 2 * hp + hp + v * 8) = pack8(dg);
+  }
+}
+extern "C" ctta_status ctta_geglu_bwd(const void* f, const void* dout, void* df, int64_t rows, int hp, void* stream) {
+  CTTA_REQUIRE(f && dout && df && hp % 8 == 0, "geglu_bwd: bad arguments");
+  hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid1d(rows * (hp / 8), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)f, (const bf16_t*)dout, (bf16_t*)df, (long long)rows, hp);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// out = a + b (bf16, 8-wide); b may be a column slice (ldb, colb) of a wider matrix, a/out likewise
+__global__ void add_slices_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ b, int ldb,
+                                  bf16_t* __restrict__ out, int ldo, long long rows, int cols) {
+  const int vc = cols / 8;
+  const long long total = rows * vc;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % vc);
+    const long long r = idx / vc;
+    float fa[8], fb[8];
+    unpack8(*reinterpret_cast<const uint4*>(a + (size_t)r * lda + v * 8), fa);
+    if (b) {
+      unpack8(*reinterpret_cast<const uint4*>(b + (size_t)r * ldb + v * 8), fb);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)r * ldo + v * 8) = pack8(fa);
+  }
+}
+extern "C" ctta_status ctta_add_slices(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows,
+                                       int cols, void* stream) {
+  CTTA_REQUIRE(a && out && cols % 8 == 0 && lda % 8 == 0 && ldo % 8 == 0 && (!b || ldb % 8 == 0), "add_slices: bad arguments");
+  hipLaunchKernelGGL(add_slices_kernel, dim3(grid1d(rows * (cols / 8), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, (long long)rows, cols);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// stride-2 conv data gradient helper: dyz[b][2oh][2ow][c] = dy[b][oh][ow][c], zeros elsewhere (extent hz x wz)
+__global__ void zero_insert_kernel(const uint4* __restrict__ dy, uint4* __restrict__ dz, int B, int ho, int wo, int hz,
+                                   int wz, int vc) {
+  const long long total = (long long)B * hz * wz * vc;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % vc);
+    long long p = idx / vc;
+    const int w = (int)(p % wz); p /= wz;
+    const int h = (int)(p % hz);
+    const int b = (int)(p / hz);
+    uint4 val = make_uint4(0, 0, 0, 0);
+    if (!(h & 1) && !(w & 1) && (h >> 1) < ho && (w >> 1) < wo)
+      val = dy[(((size_t)b * ho + (h >> 1)) * wo + (w >> 1)) * vc + v];
+    dz[idx] = val;
+  }
+}
+extern "C" ctta_status ctta_zero_insert2(const void* dy, void* dz, int batch, int ho, int wo, int hz, int wz, int c,
+                                         void* stream) {
+  CTTA_REQUIRE(dy && dz && c % 8 == 0, "zero_insert2: bad arguments");
+  const long long total = (long long)batch * hz * wz * (c / 8);
+  hipLaunchKernelGGL(zero_insert_kernel, dim3(grid1d(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)dy, (uint4*)dz, batch, ho, wo, hz, wz, c / 8);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+// nearest x2 upsample backward: dx[b][h][w] (+)= sum of the 2x2 block of dup
+__global__ void pool2_sum_kernel(const bf16_t* __restrict__ du, bf16_t* __restrict__ dx, int B, int h, int w, int C,
+                                 int acc) {
+  const int vc = C / 8;
+  const long long total = (long long)B * h * w * vc;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % vc);
+    long long p = idx / vc;
+    const int x = (int)(p % w); p /= w;
+    const int y = (int)(p % h);
+    const int b = (int)(p / h);
+    float s[8];
+    if (acc) unpack8(*reinterpret_cast<const uint4*>(dx + (size_t)idx * 8), s);
+    else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    }
+#pragma unroll
+    for (int dyy = 0; dyy < 2; ++dyy)
+#pragma unroll
+      for (int dxx = 0; dxx < 2; ++dxx) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(du + ((((size_t)b * 2 * h + 2 * y + dyy) * 2 * w) + 2 * x + dxx) * C + v * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[e] += f[e];
+      }
+    *reinterpret_cast<uint4*>(dx + (size_t)idx * 8) = pack8(s);
+  }
+}
+extern "C" ctta_status ctta_pool2_sum(const void* dup, void* dx, int batch, int h, int w, int c, int accumulate,
+                                      void* stream) {
+  CTTA_REQUIRE(dup && dx && c % 8 == 0, "pool2_sum: bad arguments");
+  const long long total = (long long)batch * h * w * (c / 8);
+  hipLaunchKernelGGL(pool2_sum_kernel, dim3(grid1d(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)dup, (bf16_t*)dx, batch, h, w, c, accumulate);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ softmax (training) + backward
+// scores fp32 [rows][cols]; optional additive per-(batch,col) bias (rows_per_batch rows share a bias row)
+__global__ __launch_bounds__(256) void softmax_bias_kernel(const float* __restrict__ s, const float* __restrict__ bias,
+                                                           int rows_per_bias, bf16_t* __restrict__ p, int cols,
+                                                           int ldp, float scale) {
+  __shared__ float red[8];
+  const long long row = blockIdx.x;
+  const float* sr = s + (size_t)row * cols;
+  const float* br = bias ? bias + (size_t)(row / rows_per_bias) * cols : nullptr;
+  bf16_t* pr = p + (size_t)row * ldp;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, sr[c] * scale + (br ? br[c] : 0.f));
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float sum = 0.f;
+  for (int c = tid; c < cols; c += 256) sum += __expf(sr[c] * scale + (br ? br[c] : 0.f) - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = tid; c < ldp; c += 256)
+    pr[c] = c < cols ? f2bf(__expf(sr[c] * scale + (br ? br[c] : 0.f) - mx) * inv) : (bf16_t)0;
+}
+extern "C" ctta_status ctta_softmax_bias_rows(const float* s, const float* bias, int rows_per_bias, void* p, int64_t rows,
+                                              int cols, int ldp, float scale, void* stream) {
+  CTTA_REQUIRE(s && p && cols >= 1 && ldp >= cols && rows_per_bias >= 1, "softmax_bias_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_bias_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, bias,
+                     rows_per_bias, (bf16_t*)p, cols, ldp, scale);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+// dS = P * (dP - sum_j P_j dP_j) * scale      P bf16 [rows][ldp], dP fp32 [rows][cols] -> dS bf16 [rows][ldp]
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ p, const float* __restrict__ dp,
+                                                          bf16_t* __restrict__ ds, int cols, int ldp, float scale) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const bf16_t* pr = p + (size_t)row * ldp;
+  const float* dr = dp + (size_t)row * cols;
+  bf16_t* o = ds + (size_t)row * ldp;
+  const int tid = threadIdx.x;
+  float acc = 0.f;
+  for (int c = tid; c < cols; c += 256) acc += bf2f(pr[c]) * dr[c];
+  acc = wave_sum(acc);
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  const float dot = red[0] + red[1] + red[2] + red[3];
+  for (int c = tid; c < ldp; c += 256) o[c] = c < cols ? f2bf(bf2f(pr[c]) * (dr[c] - dot) * scale) : (bf16_t)0;
+}
+extern "C" ctta_status ctta_softmax_bwd_rows(const void* p, const float* dp, void* ds, int64_t rows, int cols, int ldp,
+                                             float scale, void* stream) {
+  CTTA_REQUIRE(p && dp && ds && ldp >= cols, "softmax_bwd_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, dp,
+                     (bf16_t*)ds, cols, ldp, scale);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ fp32 embedding-MLP backward
+// y = x W^T + b (W [N][K]);  given dy [M][N]:  dx[m][k] = sum_n dy[m][n] W[n][k] (* silu'(xpre) when xpre given),
+// dW[n][k] (+)= sum_m dy[m][n] x[m][k], db[n] (+)= sum_m dy[m][n]
+__global__ void linear_f32_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                         const float* __restrict__ xpre, float* __restrict__ dx, int M, int N, int K,
+                                         int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * K) return;
+  const int m = i / K, k = i - m * K;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n) acc += dy[(size_t)m * N + n] * w[(size_t)n * K + k];
+  if (xpre) {
+    const float z = xpre[i];
+    const float s = 1.0f / (1.0f + expf(-z));
+    acc *= s * (1.0f + z * (1.0f - s));
+  }
+  dx[i] = accumulate ? dx[i] + acc : acc;
+}
+__global__ void linear_f32_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                         float* __restrict__ dw, float* __restrict__ db, int M, int N, int K,
+                                         int accumulate) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i >= (long long)N * K) return;
+  const int n = (int)(i / K), k = (int)(i - (long long)n * K);
+  float acc = 0.f, bs = 0.f;
+  for (int m = 0; m < M; ++m) {
+    const float d = dy[(size_t)m * N + n];
+    acc += d * x[(size_t)m * K + k];
+    bs += d;
+  }
+  dw[i] = accumulate ? dw[i] + acc : acc;
+  if (db && k == 0) db[n] = accumulate ? db[n] + bs : bs;
+}
+extern "C" ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const float* dy, const float* xpre_silu,
+                                           float* dx, float* dw, float* db, int m, int n, int k, int accumulate_dx,
+                                           int accumulate_param, void* stream) {
+  CTTA_REQUIRE(x && w && dy, "linear_f32_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (dx) {
+    hipLaunchKernelGGL(linear_f32_bwd_dx_kernel, dim3((m * k + 255) / 256), dim3(256), 0, s, dy, w, xpre_silu, dx, m, n, k,
+                       accumulate_dx);
+    CTTA_LAUNCH_CHECK();
+  }
+  if (dw) {
+    const long long total = (long long)n * k;
+    hipLaunchKernelGGL(linear_f32_bwd_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dy, x, dw, db, m,
+                       n, k, accumulate_param);
+    CTTA_LAUNCH_CHECK();
+  }
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ loss gradient
+// loss = mean_b( w_b * mean((pred-target)^2) ), w_b = min(sigma_b^-2, gamma) (1 when gamma <= 0)
+// d pred (NCHW fp32) -> NHWC bf16 [B][HW][Cpad] gradient, scaled by loss_scale
+__global__ void snr_mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                    const float* __restrict__ sigma, float gamma, float loss_scale, int B, int C, int HW,
+                                    int cpad, bf16_t* __restrict__ out) {
+  const long long total = (long long)B * HW * cpad;
+  const float n = (float)C * (float)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad);
+    const long long pix = i / cpad;
+    const int b = (int)(pix / HW);
+    const int hw = (int)(pix - (long long)b * HW);
+    float g = 0.f;
+    if (c < C) {
+      float w = 1.0f;
+      if (gamma > 0.f) { const float sg = sigma[b]; w = fminf(1.0f / (sg * sg), gamma); }
+      const size_t j = ((size_t)b * C + c) * HW + hw;
+      g = 2.0f * w / (n * (float)B) * (pred[j] - target[j]) * loss_scale;
+    }
+    out[i] = f2bf(g);
+  }
+}
+extern "C" ctta_status ctta_snr_mse_grad(const float* pred, const float* target, const float* sigma, float gamma,
+                                         float loss_scale, int batch, int c, int hw, int c_pad, void* dpred_nhwc,
+                                         void* stream) {
+  CTTA_REQUIRE(pred && target && dpred_nhwc && (gamma <= 0.f || sigma) && c_pad >= c, "snr_mse_grad: bad arguments");
+  const long long total = (long long)batch * hw * c_pad;
+  hipLaunchKernelGGL(snr_mse_grad_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, pred, target, sigma,
+                     gamma, loss_scale, batch, c, hw, c_pad, (bf16_t*)dpred_nhwc);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ AdamW (torch.optim.AdamW, no amsgrad)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, long long n, float lr, float beta1, float beta2, float eps, float wd,
+                             float bc1, float bc2_sqrt, float grad_scale) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gr = g[i] * grad_scale;
+    float pp = p[i] * (1.0f - lr * wd);
+    const float mm = m[i] + (1.0f - beta1) * (gr - m[i]);          // exp_avg.lerp_(grad, 1 - beta1)
+    const float vv = beta2 * v[i] + (1.0f - beta2) * gr * gr;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pp -= (lr / bc1) * (mm / denom);
+    p[i] = pp; m[i] = mm; v[i] = vv;
+  }
+}
+extern "C" ctta_status ctta_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                       float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                                       float grad_scale, void* stream) {
+  CTTA_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adamw_step: bad arguments");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}

@@ -37,6 +37,7 @@ struct ConvParams {
   long long xgs, wgs, ogs;
   const bf16_t* zero;   // >= 16 bytes of zeros: source of out-of-range chunks in the direct-to-LDS path
   unsigned x_bytes, w_bytes;   // buffer extents for the descriptor (MODE 2) path
+  int xs0;                     // row stride (elements) of source 0: c0 unless a wider matrix is sliced
 };
 
 // GLDS = true: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     const bool tap_ok = tap < p.taps;
     const bool second = c >= p.c0;
     const bf16_t* src = second ? x1 : x0;
-    const int cs = second ? p.c1 : p.c0;
+    const int cs = second ? p.c1 : p.xs0;
     const int cc = second ? c - p.c0 : c;
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     const bool tap_ok = tap < p.taps;
     const bool second = c >= p.c0;
     const bf16_t* src = second ? x1 : x0;
-    const int cs = second ? p.c1 : p.c0;
+    const int cs = second ? p.c1 : p.xs0;
     const int cc = second ? c - p.c0 : c;
     bf16_t* xs = Xs + buf * BM * LDK + wave_u * ROWS_PER_INSTR * LDK;
     bf16_t* ws = Ws + buf * BN * LDK + wave_u * ROWS_PER_INSTR * LDK;
@@ -348,9 +349,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         }
       }
       fmask[i] = mask;
-      fvoff[i] = (unsigned)(pix * p.c0 + kc * 8) * 2u;      // bytes; wraps correctly for border rows
-      fph[i] = ph ? (unsigned)(p.ws * p.c0) * 2u : 0u;
-      fpw[i] = pw ? (unsigned)p.c0 * 2u : 0u;
+      fvoff[i] = (unsigned)(pix * p.xs0 + kc * 8) * 2u;      // bytes; wraps correctly for border rows
+      fph[i] = ph ? (unsigned)(p.ws * p.xs0) * 2u : 0u;
+      fpw[i] = pw ? (unsigned)p.xs0 * 2u : 0u;
     }
 #pragma unroll
     for (int j = 0; j < WP; ++j) fwoff[j] = (unsigned)((n0 + r0 + j * RPP) * p.k_pad + kc * 8) * 2u;
@@ -363,9 +364,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     if (p.ups) {           // dy = (kh==0 ? ph-1 : kh==1 ? 0 : ph), same for dx
       const int bh = fkh == 0 ? -1 : 0, bw = fkw == 0 ? -1 : 0;
       use_h = fkh != 1; use_w = fkw != 1;
-      s_u = (unsigned)((bh * p.ws + bw) * p.c0 + fcb) * 2u;
+      s_u = (unsigned)((bh * p.ws + bw) * p.xs0 + fcb) * 2u;
     } else {
-      s_u = (unsigned)((fkh * p.dh * p.ws + fkw * p.dw) * p.c0 + fcb) * 2u;
+      s_u = (unsigned)((fkh * p.dh * p.ws + fkw * p.dw) * p.xs0 + fcb) * 2u;
     }
     const unsigned tbit = 1u << ftap;
 #pragma unroll
@@ -647,6 +648,8 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   memset(&p, 0, sizeof(p));
   p.x0 = (const bf16_t*)d->x0; p.x1 = (const bf16_t*)d->x1;
   p.c0 = d->c0; p.c1 = d->x1 ? d->c1 : 0; p.ct = p.c0 + p.c1;
+  p.xs0 = d->x_stride > 0 ? d->x_stride : d->c0;
+  CTTA_REQUIRE(p.xs0 >= d->c0 && p.xs0 % 8 == 0, "conv_gemm: x_stride=%d must be >= c0 and a multiple of 8", p.xs0);
   const long long M = (long long)d->batch * d->ho * d->wo;
   CTTA_REQUIRE(M > 0 && M < (1LL << 31), "conv_gemm: M out of range");
   p.M = (int)M; p.hi = d->hi; p.wi = d->wi; p.ups = d->upsample ? 1 : 0;
@@ -669,7 +672,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   const int groups = d->groups > 0 ? d->groups : 1;
   p.xgs = d->x_group_stride; p.wgs = d->w_group_stride; p.ogs = d->out_group_stride;
 
-  const long long x_bytes = (long long)d->batch * p.hs * p.ws * p.c0 * 2;
+  const long long x_bytes = (((long long)d->batch * p.hs * p.ws - 1) * p.xs0 + p.c0) * 2;
   const long long w_bytes = (long long)d->n * d->k_pad * 2;
   auto fast_ok = [&](int bk) {
     return p.ct % bk == 0 && p.taps <= 32 && p.c1 == 0 && !d->in_act && x_bytes < 0xFFFFFF00LL && w_bytes < 0xFFFFFF00LL &&

@@ -183,7 +183,7 @@ ctta_status ctta_ema_update2(const float* param, float* shadow_a, double decay_a
  * micro-benchmarks).  bf16 tensors are uint16_t bit patterns, NHWC.
  * ------------------------------------------------------------------------------------ */
 typedef struct {
-  const void* x0; int c0;     /* NHWC bf16 source, channel count == row stride */
+  const void* x0; int c0;     /* NHWC bf16 source, channel count (== row stride unless x_stride) */
   const void* x1; int c1;     /* optional second source, concatenated after x0's channels */
   int batch, hi, wi;          /* LOGICAL input extent (after the optional x2 upsample) */
   int upsample;               /* 1: sources are (hi/2, wi/2), nearest-upsampled on the fly */
@@ -213,6 +213,7 @@ typedef struct {
   /* batched GEMM (grid.z): extra strides in elements; 0 = shared */
   int groups; int64_t x_group_stride, w_group_stride, out_group_stride;
   int tile;                   /* 0 = auto; else force a kernel variant id (tuning) */
+  int x_stride;               /* 0 -> c0; else row stride of x0 in elements (column slice of a wider matrix) */
 } ctta_conv_desc;
 
 ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream);
@@ -275,6 +276,61 @@ ctta_status ctta_time_features(const float* t, const float* freqs, int dim, int 
                                int batch, void* stream);
 ctta_status ctta_fourier_features(const double* w, const float* weight, int half, int flip,
                                   float* out, int batch, void* stream);
+
+/* ------------------------------------------------------------------------------------ *
+ * Backward-pass operators of the distillation step (student U-Net); torch-autograd semantics of
+ * the reference modules.  All contractions run on ctta_conv_gemm; these are the glue kernels.
+ * ------------------------------------------------------------------------------------ */
+/* dst[g][c][r] = src[g][r][col0 + c] (r < rows), zero for rows <= r < dst_ld */
+ctta_status ctta_transpose_bf16(const void* src, int64_t src_group_stride, int rows, int cols, int src_ld,
+                                int col0, void* dst, int64_t dst_group_stride, int dst_ld, int groups,
+                                void* stream);
+/* Q[(tap*c + ch)][m] = X[pixel(m, tap)][ch] (transposed im2col, rows padded to m_pad); when
+ * indicator_batches >= 0 appends 1 + indicator_batches rows: all-ones, then per-sample indicators. */
+ctta_status ctta_im2col_t(const void* x, int c, int batch, int hi, int wi, int upsample, int ho, int wo,
+                          int kh, int kw, int stride, int pad_h, int pad_w, int dil_w, void* dst, int m_pad,
+                          int indicator_batches, void* stream);
+/* grad_w[row_off[n] + col_off[k]] (+)= sum_s slabs[s][k][n]: inverse of ctta_pack_weight */
+ctta_status ctta_wgrad_scatter(const float* slabs, int n_slabs, int64_t slab_stride, int ldn, int k_rows,
+                               int n_cols, const int32_t* row_off, const int32_t* col_off,
+                               const int32_t* row_aux, const int32_t* col_aux, int aux_limit, float* grad,
+                               int accumulate, void* stream);
+ctta_status ctta_row_scatter(const float* slabs, int n_slabs, int64_t slab_stride, int ldn, int row,
+                             int n_cols, const int32_t* idx, float* dst, int accumulate, void* stream);
+/* GroupNorm(+SiLU) backward; stats [B][G][2] = (mean, rstd) from ctta_groupnorm_stats */
+size_t ctta_groupnorm_bwd_scratch_floats(int batch, int hw, int c, int groups);
+ctta_status ctta_groupnorm_stats(const void* x, int batch, int hw, int c, int groups, float eps, float* stats,
+                                 void* stream);
+ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* dx, int batch, int hw, int c, int groups,
+                               const float* stats, const float* gamma, const float* beta, int silu,
+                               int accumulate_dx, float* dgamma, float* dbeta, int accumulate_param,
+                               float* scratch, void* stream);
+/* LayerNorm backward (statistics recomputed); dgamma/dbeta are ACCUMULATED into (atomics) */
+ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t rows, int d, int ld,
+                               const float* gamma, float eps, int accumulate_dx, float* dgamma, float* dbeta,
+                               void* stream);
+ctta_status ctta_geglu_bwd(const void* f, const void* dout, void* df, int64_t rows, int hp, void* stream);
+ctta_status ctta_add_slices(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows,
+                            int cols, void* stream);
+ctta_status ctta_zero_insert2(const void* dy, void* dz, int batch, int ho, int wo, int hz, int wz, int c,
+                              void* stream);
+ctta_status ctta_pool2_sum(const void* dup, void* dx, int batch, int h, int w, int c, int accumulate,
+                           void* stream);
+ctta_status ctta_softmax_bias_rows(const float* s, const float* bias, int rows_per_bias, void* p, int64_t rows,
+                                   int cols, int ldp, float scale, void* stream);
+ctta_status ctta_softmax_bwd_rows(const void* p, const float* dp, void* ds, int64_t rows, int cols, int ldp,
+                                  float scale, void* stream);
+ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const float* dy, const float* xpre_silu,
+                                float* dx, float* dw, float* db, int m, int n, int k, int accumulate_dx,
+                                int accumulate_param, void* stream);
+/* d/dpred of get_loss (MSE 'instance' x SNR clamp, models/audio_consistency_model.py:250-266) as NHWC bf16 */
+ctta_status ctta_snr_mse_grad(const float* pred, const float* target, const float* sigma, float gamma,
+                              float loss_scale, int batch, int c, int hw, int c_pad, void* dpred_nhwc,
+                              void* stream);
+/* torch.optim.AdamW step (tools/train_utils.py:59-63): decoupled weight decay, bias correction by `step` */
+ctta_status ctta_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                            float grad_scale, void* stream);
 
 /* Opt-in launch profiler (bench.py's live roofline leg): when enabled, every conv_gemm (kind 0)
  * and attention (kind 1) launch is bracketed by hipEvents on its own stream.  collect() waits

@@ -1,0 +1,251 @@
+"""Backward-pass operators vs torch autograd on the CPU oracle ops (bf16-rounded inputs, fp32
+reference): data gradients through conv_gemm with flipped weights, weight / bias / per-sample
+gradients through the transposed-im2col GEMM, GroupNorm / LayerNorm / GEGLU / softmax backward,
+the SNR-weighted loss gradient and AdamW."""
+import ctypes
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from consistencytta_amd import _native as N  # noqa: E402
+from gpu_util import DEV, bf16_round, conv_desc, det, from_nhwc, nhwc_bf16, pack_conv_weight, rel_err, run_conv, sync  # noqa: E402
+
+BF16_TOL = 1.5 * 2.0 ** -8
+
+
+def lib():
+    return N.lib()
+
+
+def rup(a, b):
+    return (a + b - 1) // b * b
+
+
+def wgrad(x_nhwc, dy_nhwc, B, H, W, Cin, Cout, k, stride, pad, ups, Ho, Wo, splits=2):
+    """dW (Cout,Cin,k,k), db (Cout), per-sample sums (B,Cout) via im2col^T GEMM, as the engine does."""
+    L = lib()
+    st = N.stream_ptr()
+    M = B * Ho * Wo
+    mp = rup(M, 64 * splits)
+    K = k * k * Cin
+    R = K + 1 + B
+    q = torch.empty(R, mp, dtype=torch.bfloat16, device=DEV)
+    N.check(L.ctta_im2col_t(N.ptr(x_nhwc), Cin, B, H * (2 if ups else 1), W * (2 if ups else 1), int(ups), Ho, Wo, k, k,
+                            stride, pad, pad, 1, N.ptr(q), mp, B, st))
+    pt = torch.empty(Cout, mp, dtype=torch.bfloat16, device=DEV)
+    N.check(L.ctta_transpose_bf16(N.ptr(dy_nhwc), 0, M, Cout, Cout, 0, N.ptr(pt), 0, mp, 1, st))
+    slabs = torch.empty(splits, R, Cout, dtype=torch.float32, device=DEV)
+    seg = mp // splits
+    run_conv(conv_desc(x0=q, c0=seg, x_stride=mp, batch=1, hi=R, wi=1, ho=R, wo=1, w=pt, k_pad=mp, n=Cout, out=slabs,
+                       ldc=Cout, out_f32=1, groups=splits, x_group_stride=seg, w_group_stride=seg,
+                       out_group_stride=R * Cout))
+    ro = (torch.arange(Cout, dtype=torch.int32) * (Cin * k * k)).to(DEV)
+    co = torch.empty(K, dtype=torch.int32)
+    for y in range(k):
+        for xx in range(k):
+            for c in range(Cin):
+                co[(y * k + xx) * Cin + c] = c * k * k + y * k + xx
+    co = co.to(DEV)
+    dw = torch.zeros(Cout, Cin, k, k, device=DEV)
+    N.check(L.ctta_wgrad_scatter(N.ptr(slabs), splits, R * Cout, Cout, K, Cout, N.ptr(ro), N.ptr(co), None, None, 0,
+                                 N.ptr(dw), 0, st))
+    db = torch.zeros(Cout, device=DEV)
+    N.check(L.ctta_row_scatter(N.ptr(slabs), splits, R * Cout, Cout, K, Cout, None, N.ptr(db), 0, st))
+    ps = torch.zeros(B, Cout, device=DEV)
+    for b in range(B):
+        N.check(L.ctta_row_scatter(N.ptr(slabs), splits, R * Cout, Cout, K + 1 + b, Cout, None, N.ptr(ps[b]), 0, st))
+    sync()
+    return dw.cpu(), db.cpu(), ps.cpu()
+
+
+def dgrad(dy_nhwc, w, B, Ho, Wo, Cin, Cout, k, pad, H, W):
+    """dX = conv(dY, W rotated by 180 degrees with in/out channels swapped), stride 1."""
+    wf = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()      # (Cin, Cout, k, k)
+    wp, k_pad = pack_conv_weight(wf)
+    dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+    run_conv(conv_desc(x0=dy_nhwc, c0=Cout, batch=B, hi=Ho, wi=Wo, ho=H, wo=W, kh=k, kw=k, pad_h=k - 1 - pad,
+                       pad_w=k - 1 - pad, w=wp, k_pad=k_pad, n=Cin, out=dx, ldc=Cin))
+    return dx
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,stride,ups", [(2, 64, 96, 8, 8, 3, 1, False), (3, 40, 24, 6, 4, 3, 1, False),
+                                                         (2, 64, 64, 8, 8, 1, 1, False), (2, 32, 40, 8, 8, 3, 2, False),
+                                                         (2, 48, 64, 4, 4, 3, 1, True)])
+def test_conv_backward(B, Cin, Cout, H, W, k, stride, ups):
+    pad = k // 2
+    x = bf16_round(det("cb.x", (B, Cin, H, W), 1)).requires_grad_(True)
+    w = bf16_round(det("cb.w", (Cout, Cin, k, k), 2) / math.sqrt(Cin * k * k)).requires_grad_(True)
+    b = (det("cb.b", (Cout,), 3) * 0.1).requires_grad_(True)
+    xin = F.interpolate(x, scale_factor=2.0, mode="nearest") if ups else x
+    y = F.conv2d(xin, w, b, stride=stride, padding=pad)
+    Ho, Wo = y.shape[2], y.shape[3]
+    dy = bf16_round(det("cb.dy", tuple(y.shape), 4))
+    y.backward(dy)
+    xa, dya = nhwc_bf16(x.detach()), nhwc_bf16(dy)
+    dw, db, ps = wgrad(xa, dya, B, H, W, Cin, Cout, k, stride, pad, ups, Ho, Wo)
+    assert rel_err(dw, w.grad) < 2e-3          # fp32 accumulation of bf16 products
+    assert rel_err(db, b.grad) < 2e-3
+    assert rel_err(ps, dy.sum(dim=(2, 3))) < 2e-3
+    # data gradient
+    L = lib()
+    st = N.stream_ptr()
+    if stride == 2:
+        hz, wz = H, W
+        dz = torch.empty(B, hz, wz, Cout, dtype=torch.bfloat16, device=DEV)
+        N.check(L.ctta_zero_insert2(N.ptr(dya), N.ptr(dz), B, Ho, Wo, hz, wz, Cout, st))
+        dx = dgrad(dz, w.detach(), B, hz, wz, Cin, Cout, k, pad, H, W)
+    elif ups:
+        dup = dgrad(dya, w.detach(), B, Ho, Wo, Cin, Cout, k, pad, 2 * H, 2 * W)
+        dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=DEV)
+        N.check(L.ctta_pool2_sum(N.ptr(dup), N.ptr(dx), B, H, W, Cin, 0, st))
+    else:
+        dx = dgrad(dya, w.detach(), B, Ho, Wo, Cin, Cout, k, pad, H, W)
+    sync()
+    assert rel_err(from_nhwc(dx), x.grad) < (2.5 if ups else 1.0) * BF16_TOL
+
+
+@pytest.mark.parametrize("B,C,H,W,G,silu,eps", [(2, 40, 16, 8, 8, True, 1e-5), (3, 256, 8, 8, 32, False, 1e-6),
+                                                (2, 120, 4, 2, 8, True, 1e-5)])
+def test_groupnorm_backward(B, C, H, W, G, silu, eps):
+    x = bf16_round(det("gb.x", (B, C, H, W), 1) * 2 + 0.3).requires_grad_(True)
+    gamma = (1 + 0.2 * det("gb.g", (C,), 2)).requires_grad_(True)
+    beta = (0.1 * det("gb.b", (C,), 3)).requires_grad_(True)
+    y = F.group_norm(x, G, gamma, beta, eps)
+    if silu:
+        y = F.silu(y)
+    dy = bf16_round(det("gb.dy", (B, C, H, W), 4))
+    y.backward(dy)
+    L = lib()
+    st = N.stream_ptr()
+    xa, dya = nhwc_bf16(x.detach()), nhwc_bf16(dy)
+    stats = torch.empty(B, G, 2, device=DEV)
+    N.check(L.ctta_groupnorm_stats(N.ptr(xa), B, H * W, C, G, eps, N.ptr(stats), st))
+    scratch = torch.empty(L.ctta_groupnorm_bwd_scratch_floats(B, H * W, C, G), device=DEV)
+    dx = torch.empty_like(xa)
+    dg, dbt = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    gd, bd = gamma.detach().to(DEV), beta.detach().to(DEV)
+    N.check(L.ctta_groupnorm_bwd(N.ptr(xa), N.ptr(dya), N.ptr(dx), B, H * W, C, G, N.ptr(stats), N.ptr(gd), N.ptr(bd),
+                                 int(silu), 0, N.ptr(dg), N.ptr(dbt), 0, N.ptr(scratch), st))
+    sync()
+    assert rel_err(from_nhwc(dx), x.grad) < 2 * BF16_TOL
+    assert rel_err(dg.cpu(), gamma.grad) < 2e-3 and rel_err(dbt.cpu(), beta.grad) < 2e-3
+
+
+@pytest.mark.parametrize("rows,d,ld", [(70, 39, 64), (130, 255, 256), (9, 1020, 1024)])
+def test_layernorm_geglu_backward(rows, d, ld):
+    x = bf16_round(det("lb.x", (rows, d), 1) * 3 + 0.5).requires_grad_(True)
+    gamma = (1 + 0.2 * det("lb.g", (d,), 2)).requires_grad_(True)
+    beta = (0.1 * det("lb.b", (d,), 3)).requires_grad_(True)
+    y = F.layer_norm(x, (d,), gamma, beta, 1e-5)
+    dy = bf16_round(det("lb.dy", (rows, d), 4))
+    y.backward(dy)
+    xp, dyp = torch.zeros(rows, ld), torch.zeros(rows, ld)
+    xp[:, :d], dyp[:, :d] = x.detach(), dy
+    xd, dyd = xp.to(torch.bfloat16).to(DEV), dyp.to(torch.bfloat16).to(DEV)
+    dx = torch.empty_like(xd)
+    dg, dbt = torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    gd = gamma.detach().to(DEV)
+    N.check(lib().ctta_layernorm_bwd(N.ptr(xd), N.ptr(dyd), N.ptr(dx), rows, d, ld, N.ptr(gd), 1e-5, 0, N.ptr(dg),
+                                     N.ptr(dbt), N.stream_ptr()))
+    sync()
+    assert rel_err(dx.float().cpu()[:, :d], x.grad) < 2 * BF16_TOL
+    assert rel_err(dg.cpu(), gamma.grad) < 2e-3 and rel_err(dbt.cpu(), beta.grad) < 2e-3
+    # GEGLU
+    hp = ld
+    f = bf16_round(det("gg.f", (rows, 2 * hp), 5) * 2).requires_grad_(True)
+    out = f[:, :hp] * F.gelu(f[:, hp:])
+    do = bf16_round(det("gg.do", (rows, hp), 6))
+    out.backward(do)
+    fd, dod = f.detach().to(torch.bfloat16).to(DEV), do.to(torch.bfloat16).to(DEV)
+    df = torch.empty_like(fd)
+    N.check(lib().ctta_geglu_bwd(N.ptr(fd), N.ptr(dod), N.ptr(df), rows, hp, N.stream_ptr()))
+    sync()
+    assert rel_err(df.float().cpu(), f.grad) < 2 * BF16_TOL
+
+
+def test_softmax_forward_bias_and_backward():
+    rows, cols, ldp, rpb = 12, 37, 40, 4
+    s = (det("sb.s", (rows, cols), 1) * 8).requires_grad_(True)
+    bias = torch.zeros(rows // rpb, cols)
+    bias[1, 20:] = -10000.0
+    p = torch.softmax(s * 0.14 + bias.repeat_interleave(rpb, 0), dim=-1)
+    dp = det("sb.dp", (rows, cols), 2)
+    p.backward(dp)
+    L = lib()
+    st = N.stream_ptr()
+    sd, bd, dpd = s.detach().to(DEV), bias.to(DEV), dp.to(DEV)
+    pd = torch.empty(rows, ldp, dtype=torch.bfloat16, device=DEV)
+    N.check(L.ctta_softmax_bias_rows(N.ptr(sd), N.ptr(bd), rpb, N.ptr(pd), rows, cols, ldp, 0.14, st))
+    ds = torch.empty(rows, ldp, dtype=torch.bfloat16, device=DEV)
+    N.check(L.ctta_softmax_bwd_rows(N.ptr(pd), N.ptr(dpd), N.ptr(ds), rows, cols, ldp, 0.14, st))
+    sync()
+    assert rel_err(pd.float().cpu()[:, :cols], p.detach()) < BF16_TOL
+    assert float(pd.float().cpu()[:, cols:].abs().max()) == 0.0
+    assert rel_err(ds.float().cpu()[:, :cols], s.grad) < 3 * BF16_TOL
+
+
+def test_transpose_and_add_slices():
+    g, rows, cols, ld = 3, 50, 24, 40
+    x = bf16_round(det("tr.x", (g, rows, ld), 1))
+    xd = x.to(torch.bfloat16).to(DEV)
+    dst = torch.full((g, cols, 56), 7.0, dtype=torch.bfloat16, device=DEV)
+    N.check(lib().ctta_transpose_bf16(N.ptr(xd), rows * ld, rows, cols, ld, 8, N.ptr(dst), cols * 56, 56, g, N.stream_ptr()))
+    sync()
+    got = dst.float().cpu()
+    assert torch.equal(got[:, :, :rows], x[:, :, 8:8 + cols].transpose(1, 2))
+    assert float(got[:, :, rows:].abs().max()) == 0.0
+    a, b = bf16_round(det("as.a", (20, 32), 2)), bf16_round(det("as.b", (20, 48), 3))
+    ad, bd = a.to(torch.bfloat16).to(DEV), b.to(torch.bfloat16).to(DEV)
+    o = torch.empty(20, 16, dtype=torch.bfloat16, device=DEV)
+    N.check(lib().ctta_add_slices(N.ptr(ad[:, 16:]), 32, N.ptr(bd[:, 8:]), 48, N.ptr(o), 16, 20, 16, N.stream_ptr()))
+    sync()
+    assert torch.equal(o.float().cpu(), bf16_round(a[:, 16:] + b[:, 8:24]))
+
+
+def test_embedding_mlp_backward_loss_grad_and_adamw():
+    M, Kd, Nn = 5, 48, 36
+    x = det("lf.x", (M, Kd), 1).requires_grad_(True)
+    w = (det("lf.w", (Nn, Kd), 2) * 0.3).requires_grad_(True)
+    b = det("lf.b", (Nn,), 3).requires_grad_(True)
+    dy = det("lf.dy", (M, Nn), 4)
+    F.linear(F.silu(x), w, b).backward(dy)
+    L = lib()
+    st = N.stream_ptr()
+    xs = F.silu(x.detach()).to(DEV)
+    dx, dw, db = torch.empty(M, Kd, device=DEV), torch.empty(Nn, Kd, device=DEV), torch.empty(Nn, device=DEV)
+    xpre, wd, dyd = x.detach().to(DEV), w.detach().to(DEV), dy.to(DEV)
+    N.check(L.ctta_linear_f32_bwd(N.ptr(xs), N.ptr(wd), N.ptr(dyd), N.ptr(xpre), N.ptr(dx), N.ptr(dw), N.ptr(db), M, Nn,
+                                  Kd, 0, 0, st))
+    sync()
+    assert rel_err(dx.cpu(), x.grad) < 1e-5 and rel_err(dw.cpu(), w.grad) < 1e-5 and rel_err(db.cpu(), b.grad) < 1e-5
+    # loss gradient
+    B, C, H, W = 3, 8, 6, 4
+    pred = det("lg.p", (B, C, H, W), 5).requires_grad_(True)
+    tgt = det("lg.t", (B, C, H, W), 6)
+    sig = torch.tensor([14.6, 0.4, 0.0])
+    inst = ((pred - tgt) ** 2).mean(dim=(1, 2, 3))
+    (inst * torch.clamp(sig ** -2, max=5.0)).mean().backward()
+    out = torch.empty(B, H * W, 8, dtype=torch.bfloat16, device=DEV)
+    pd, td, sd = pred.detach().to(DEV), tgt.to(DEV), sig.to(DEV)
+    N.check(L.ctta_snr_mse_grad(N.ptr(pd), N.ptr(td), N.ptr(sd), 5.0, 1.0, B, C, H * W, 8, N.ptr(out), st))
+    sync()
+    got = out.float().cpu().reshape(B, H, W, 8).permute(0, 3, 1, 2)
+    assert rel_err(got, pred.grad) < BF16_TOL
+    # AdamW: two steps against torch.optim.AdamW
+    p0, g1, g2 = det("aw.p", (1000,), 7), det("aw.g1", (1000,), 8) * 0.1, det("aw.g2", (1000,), 9) * 0.1
+    pt = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pt], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    for g in (g1, g2):
+        pt.grad = g.clone()
+        opt.step()
+    pd, m, v = p0.clone().to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for i, g in enumerate((g1, g2)):
+        gd = g.to(DEV)
+        N.check(L.ctta_adamw_step(N.ptr(pd), N.ptr(gd), N.ptr(m), N.ptr(v), 1000, 1e-3, 0.9, 0.999, 1e-8, 1e-2, i + 1, 1.0, st))
+    sync()
+    assert rel_err(pd.cpu(), pt.detach()) < 2e-6
