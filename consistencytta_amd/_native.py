@@ -31,7 +31,7 @@ class UNetConfig(Structure):
         ("up_cross", c_int * MAX_LEVELS), ("cross_attention_dim", c_int),
         ("norm_num_groups", c_int), ("norm_eps", c_float), ("flip_sin_to_cos", c_int),
         ("freq_shift", c_float), ("guided", c_int), ("max_batch", c_int), ("height", c_int),
-        ("width", c_int), ("max_text_len", c_int), ("debug_taps", c_int),
+        ("width", c_int), ("max_text_len", c_int), ("debug_taps", c_int), ("enable_training", c_int),
     ]
 
 
@@ -81,6 +81,8 @@ SIGNATURES = {
     "ctta_unet_destroy": (None, [c_void_p]),
     "ctta_unet_load_weights": (c_int, [c_void_p, POINTER(Tensor), c_int, c_void_p]),
     "ctta_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_unet_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_unet_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ctta_unet_arena_bytes": (c_size_t, [c_void_p]),
     "ctta_unet_num_taps": (c_int, [c_void_p]),
     "ctta_unet_tap_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
@@ -138,8 +140,8 @@ SIGNATURES = {
     "ctta_add_slices": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "ctta_zero_insert2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_pool2_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "ctta_softmax_bias_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
-    "ctta_softmax_bwd_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "ctta_softmax_bias_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "ctta_softmax_bwd_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "ctta_linear_f32_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_snr_mse_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),

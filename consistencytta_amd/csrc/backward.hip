@@ -641,12 +641,12 @@ extern "C" ctta_status ctta_pool2_sum(const void* dup, void* dx, int batch, int 
 
 // ------------------------------------------------------------------------------ softmax (training) + backward
 // scores fp32 [rows][cols]; optional additive per-(batch,col) bias (rows_per_batch rows share a bias row)
-__global__ __launch_bounds__(256) void softmax_bias_kernel(const float* __restrict__ s, const float* __restrict__ bias,
-                                                           int rows_per_bias, bf16_t* __restrict__ p, int cols,
-                                                           int ldp, float scale) {
+__global__ __launch_bounds__(256) void softmax_bias_kernel(const float* __restrict__ s, int lds,
+                                                           const float* __restrict__ bias, int rows_per_bias,
+                                                           bf16_t* __restrict__ p, int cols, int ldp, float scale) {
   __shared__ float red[8];
   const long long row = blockIdx.x;
-  const float* sr = s + (size_t)row * cols;
+  const float* sr = s + (size_t)row * lds;
   const float* br = bias ? bias + (size_t)(row / rows_per_bias) * cols : nullptr;
   bf16_t* pr = p + (size_t)row * ldp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -665,21 +665,22 @@ __global__ __launch_bounds__(256) void softmax_bias_kernel(const float* __restri
   for (int c = tid; c < ldp; c += 256)
     pr[c] = c < cols ? f2bf(__expf(sr[c] * scale + (br ? br[c] : 0.f) - mx) * inv) : (bf16_t)0;
 }
-extern "C" ctta_status ctta_softmax_bias_rows(const float* s, const float* bias, int rows_per_bias, void* p, int64_t rows,
-                                              int cols, int ldp, float scale, void* stream) {
-  CTTA_REQUIRE(s && p && cols >= 1 && ldp >= cols && rows_per_bias >= 1, "softmax_bias_rows: bad arguments");
-  hipLaunchKernelGGL(softmax_bias_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, bias,
+extern "C" ctta_status ctta_softmax_bias_rows(const float* s, int lds, const float* bias, int rows_per_bias, void* p,
+                                              int64_t rows, int cols, int ldp, float scale, void* stream) {
+  CTTA_REQUIRE(s && p && cols >= 1 && ldp >= cols && lds >= cols && rows_per_bias >= 1, "softmax_bias_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_bias_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, lds, bias,
                      rows_per_bias, (bf16_t*)p, cols, ldp, scale);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }
 // dS = P * (dP - sum_j P_j dP_j) * scale      P bf16 [rows][ldp], dP fp32 [rows][cols] -> dS bf16 [rows][ldp]
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restrict__ p, const float* __restrict__ dp,
-                                                          bf16_t* __restrict__ ds, int cols, int ldp, float scale) {
+                                                          int lddp, bf16_t* __restrict__ ds, int cols, int ldp,
+                                                          float scale) {
   __shared__ float red[4];
   const long long row = blockIdx.x;
   const bf16_t* pr = p + (size_t)row * ldp;
-  const float* dr = dp + (size_t)row * cols;
+  const float* dr = dp + (size_t)row * lddp;
   bf16_t* o = ds + (size_t)row * ldp;
   const int tid = threadIdx.x;
   float acc = 0.f;
@@ -690,11 +691,11 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const bf16_t* __restri
   const float dot = red[0] + red[1] + red[2] + red[3];
   for (int c = tid; c < ldp; c += 256) o[c] = c < cols ? f2bf(bf2f(pr[c]) * (dr[c] - dot) * scale) : (bf16_t)0;
 }
-extern "C" ctta_status ctta_softmax_bwd_rows(const void* p, const float* dp, void* ds, int64_t rows, int cols, int ldp,
-                                             float scale, void* stream) {
-  CTTA_REQUIRE(p && dp && ds && ldp >= cols, "softmax_bwd_rows: bad arguments");
+extern "C" ctta_status ctta_softmax_bwd_rows(const void* p, const float* dp, int lddp, void* ds, int64_t rows, int cols,
+                                             int ldp, float scale, void* stream) {
+  CTTA_REQUIRE(p && dp && ds && ldp >= cols && lddp >= cols, "softmax_bwd_rows: bad arguments");
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)p, dp,
-                     (bf16_t*)ds, cols, ldp, scale);
+                     lddp, (bf16_t*)ds, cols, ldp, scale);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

@@ -8,7 +8,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wn
 mkdir -p build
 pids=()
 for f in api conv_gemm norm_elem attention backward engine_unet engine_vae; do
-  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ engine_common.h -nt build/$f.o ] || [ ../../include/ctta.h -nt build/$f.o ]; then
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ engine_common.h -nt build/$f.o ] || [ engine_unet_train.h -nt build/$f.o ] || [ ../../include/ctta.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)
   fi

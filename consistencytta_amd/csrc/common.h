@@ -93,3 +93,4 @@ void ctta_prof_end(hipStream_t s);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+static inline int64_t round_up64(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

@@ -65,6 +65,16 @@ struct PackedW {
   int k_pad = 0;
 };
 
+// Where a packed operand came from, kept for the backward pass: the inverse of the packing
+// (ctta_wgrad_scatter) adds a [K][N] gradient slab back into the reference parameter layout.
+struct PackMap {
+  std::string wkey, bkey;
+  int32_t *ro = nullptr, *co = nullptr;   // device copies of the pack maps (row_off[n], col_off[k])
+  int32_t* bidx = nullptr;                // bias placement (NULL = identity over n_bias entries)
+  int n = 0;                              // packed rows (GEMM N, padding included)
+  int n_bias = 0;
+};
+
 // Persistent device storage for packed weights / fp32 copies / index maps.
 struct WeightStore {
   Arena arena;
@@ -98,7 +108,8 @@ struct WeightStore {
   ctta_status add_matrix(const std::string& key, const std::vector<int64_t>& expect_shape,
                          const std::vector<int32_t>& row_off, const std::vector<int32_t>& col_off,
                          const std::vector<int32_t>* row_aux, const std::vector<int32_t>* col_aux,
-                         int aux_limit, bf16_t** out, bf16_t* dst_preallocated = nullptr) {
+                         int aux_limit, bf16_t** out, bf16_t* dst_preallocated = nullptr,
+                         PackMap* pm = nullptr) {
     const int n_rows = (int)row_off.size(), k_pad = (int)col_off.size();
     bf16_t* dst = dst_preallocated ? dst_preallocated : arena.get<bf16_t>((size_t)n_rows * k_pad);
     if (!dst) { ctta_set_error("weight store exhausted at %s", key.c_str()); return CTTA_ERR_NOMEM; }
@@ -107,6 +118,7 @@ struct WeightStore {
     CTTA_TRY(upload(col_off, &dco));
     if (aux_limit > 0) { CTTA_TRY(upload(*row_aux, &dra)); CTTA_TRY(upload(*col_aux, &dca)); }
     *out = dst;
+    if (pm) { pm->wkey = key; pm->ro = dro; pm->co = dco; pm->n = n_rows; }
     jobs.push_back([=](const WeightTable& wt, hipStream_t s) -> ctta_status {
       const ctta_tensor* t = wt.find(key);
       if (!t) { ctta_set_error("missing state-dict key '%s'", key.c_str()); return CTTA_ERR_MISSING_KEY; }
@@ -181,7 +193,7 @@ struct ConvLayer {
 // rows: n_rows_pad >= cout entries; row r maps to source row row_map[r] (or -1).
 static inline ctta_status make_conv(WeightStore& ws, const std::string& prefix, int cout, int cin,
                                     int cin_pad, int kh, int kw, int stride, int pad, ConvLayer* L,
-                                    bool with_bias = true) {
+                                    bool with_bias = true, PackMap* pm = nullptr) {
   const int K = kh * kw * cin_pad;
   const int k_pad = round_up(K, 64);
   const int n_pad = round_up(cout, 4);
@@ -191,8 +203,9 @@ static inline ctta_status make_conv(WeightStore& ws, const std::string& prefix, 
     for (int x = 0; x < kw; ++x)
       for (int c = 0; c < cin; ++c) co[(y * kw + x) * cin_pad + c] = c * kh * kw + y * kw + x;
   const std::vector<int64_t> shape = {cout, cin, kh, kw};
-  CTTA_TRY(ws.add_matrix(prefix + "weight", shape, ro, co, nullptr, nullptr, 0, &L->p.w));
+  CTTA_TRY(ws.add_matrix(prefix + "weight", shape, ro, co, nullptr, nullptr, 0, &L->p.w, nullptr, pm));
   if (with_bias) CTTA_TRY(ws.add_vector(prefix + "bias", cout, n_pad, {{0, 0, cout}}, &L->p.bias));
+  if (pm && with_bias) { pm->bkey = prefix + "bias"; pm->n_bias = cout; }
   L->p.n = n_pad; L->p.k_pad = k_pad;
   L->cin_pad = cin_pad; L->cout = cout; L->kh = kh; L->kw = kw; L->stride = stride; L->pad = pad;
   return CTTA_OK;
@@ -203,13 +216,17 @@ static inline ctta_status make_conv(WeightStore& ws, const std::string& prefix, 
 static inline ctta_status make_linear(WeightStore& ws, const std::string& wkey, const std::string& bkey,
                                       int n_src, int k_src, const std::vector<int32_t>& row_map,
                                       const std::vector<int32_t>& col_map, PackedW* P,
-                                      bf16_t* dst_preallocated = nullptr) {
+                                      bf16_t* dst_preallocated = nullptr, PackMap* pm = nullptr) {
   const int n_pad = (int)row_map.size();
   const int k_pad = (int)col_map.size();
   std::vector<int32_t> ro(n_pad), co(k_pad);
   for (int r = 0; r < n_pad; ++r) ro[r] = row_map[r] < 0 ? -1 : row_map[r] * k_src;
   for (int k = 0; k < k_pad; ++k) co[k] = col_map[k];
-  CTTA_TRY(ws.add_matrix(wkey, {n_src, k_src}, ro, co, nullptr, nullptr, 0, &P->w, dst_preallocated));
+  CTTA_TRY(ws.add_matrix(wkey, {n_src, k_src}, ro, co, nullptr, nullptr, 0, &P->w, dst_preallocated, pm));
+  if (pm && !bkey.empty()) {
+    pm->bkey = bkey; pm->n_bias = n_pad;
+    CTTA_TRY(ws.upload(row_map, &pm->bidx));
+  }
   if (!bkey.empty()) {
     std::vector<WeightStore::Seg> segs;
     for (int r = 0; r < n_pad; ++r)
@@ -223,6 +240,37 @@ static inline ctta_status make_linear(WeightStore& ws, const std::string& wkey, 
     CTTA_TRY(ws.add_vector(bkey, n_src, n_pad, segs, &P->bias));
   }
   P->n = n_pad; P->k_pad = k_pad;
+  return CTTA_OK;
+}
+
+// Data-gradient operands.  conv: dX = conv(dY, W rotated 180 deg, in/out channels swapped), so the
+// packed rows are the forward INPUT channels and K = (kh, kw, cout); linear: W^T.
+static inline ctta_status make_conv_dgrad(WeightStore& ws, const std::string& prefix, int cout, int cin, int kh,
+                                          int kw, int pad, ConvLayer* D, int cout_pad = 0) {
+  if (cout_pad < cout) cout_pad = cout;   // channel stride of the dY operand
+  const int K = kh * kw * cout_pad;
+  const int k_pad = round_up(K, 64);
+  const int n_pad = round_up(cin, 4);
+  std::vector<int32_t> ro(n_pad, -1), co(k_pad, -1);
+  for (int ci = 0; ci < cin; ++ci) ro[ci] = ci * kh * kw;
+  for (int a = 0; a < kh; ++a)
+    for (int b = 0; b < kw; ++b)
+      for (int o = 0; o < cout; ++o) co[(a * kw + b) * cout_pad + o] = o * cin * kh * kw + (kh - 1 - a) * kw + (kw - 1 - b);
+  CTTA_TRY(ws.add_matrix(prefix + "weight", {cout, cin, kh, kw}, ro, co, nullptr, nullptr, 0, &D->p.w));
+  D->p.bias = nullptr; D->p.n = n_pad; D->p.k_pad = k_pad;
+  D->cin_pad = cout_pad; D->cout = cin; D->kh = kh; D->kw = kw; D->stride = 1; D->pad = kh - 1 - pad;
+  return CTTA_OK;
+}
+static inline ctta_status make_linear_dgrad(WeightStore& ws, const std::string& wkey, int n_src, int k_src,
+                                            const std::vector<int32_t>& row_map, const std::vector<int32_t>& col_map,
+                                            PackedW* D) {
+  const int n_pad = (int)row_map.size(), k_pad = (int)col_map.size();
+  const int kd = round_up(n_pad, 64);
+  std::vector<int32_t> ro(k_pad), co(kd, -1);
+  for (int k = 0; k < k_pad; ++k) ro[k] = col_map[k];
+  for (int n = 0; n < n_pad; ++n) co[n] = row_map[n] < 0 ? -1 : row_map[n] * k_src;
+  CTTA_TRY(ws.add_matrix(wkey, {n_src, k_src}, ro, co, nullptr, nullptr, 0, &D->w));
+  D->bias = nullptr; D->n = k_pad; D->k_pad = kd;
   return CTTA_OK;
 }
 
@@ -322,9 +370,10 @@ struct GNLayer {
   float* gamma = nullptr;
   float* beta = nullptr;
   int c = 0;
+  std::string key;   // state-dict prefix ("...norm1.")
 };
 static inline ctta_status make_gn(WeightStore& ws, const std::string& prefix, int c, GNLayer* g) {
-  g->c = c;
+  g->c = c; g->key = prefix;
   CTTA_TRY(ws.add_vector(prefix + "weight", c, &g->gamma));
   CTTA_TRY(ws.add_vector(prefix + "bias", c, &g->beta));
   return CTTA_OK;
@@ -350,5 +399,10 @@ static inline void add_tap(RunCtx& c, const std::string& name, const void* p, in
 static inline size_t estimate_store_bytes(const ctta_tensor* w, int n) {
   size_t total = 64 << 20;
   for (int i = 0; i < n; ++i) total += (size_t)tensor_numel(&w[i]) * 2 * 3 + 8192;   // bf16 x padding + maps
+  return total;
+}
+static inline size_t estimate_store_bytes_training(const ctta_tensor* w, int n) {
+  size_t total = 64 << 20;   // forward packs + data-gradient packs + fp32 tables
+  for (int i = 0; i < n; ++i) total += (size_t)tensor_numel(&w[i]) * 2 * 5 + 16384;
   return total;
 }

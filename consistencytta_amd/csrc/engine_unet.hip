@@ -52,20 +52,37 @@ __global__ void repack_small_w_kernel(const float* __restrict__ src, float* __re
   dst[i] = src[((size_t)nn * c + cc) * khw + t];
 }
 
+// Training-only companions of a conv / linear: the data-gradient operand and the pack map that
+// routes the weight-gradient slab back into the state-dict layout.
+struct ConvTrain { ConvLayer d; PackMap m; };
+struct LinTrain { PackedW d; PackMap m; };
+
 struct Resnet {
   int cin = 0, cout = 0, temb_off = 0;
   GNLayer n1, n2;
   ConvLayer c1, c2, sc;
   bool has_sc = false;
+  std::string key;
+  ConvTrain t1, t2, tsc;
+  // tensors the training forward keeps for the backward pass
+  struct Saved { const bf16_t *x = nullptr, *a = nullptr, *t1 = nullptr, *a2 = nullptr; float *st1 = nullptr, *st2 = nullptr; int H = 0, W = 0; } sv;
 };
 
-struct LNLayer { float* gamma = nullptr; float* beta = nullptr; };
+struct LNLayer { float* gamma = nullptr; float* beta = nullptr; std::string key; };
 
 struct Transformer {
   int c = 0, heads = 0, dh = 0, inner = 0, cp = 0, hp = 0, ffh = 0, ffp = 0;
   GNLayer norm;
   PackedW proj_in, qk1, v1, out1, q2, k2, v2, out2, ff1, ff2, proj_out;
   LNLayer ln1, ln2, ln3;
+  LinTrain t_proj_in, t_q1, t_k1, t_v1, t_out1, t_q2, t_k2, t_v2, t_out2, t_ff1, t_ff2, t_proj_out;
+  struct Saved {
+    const bf16_t *x = nullptr, *g = nullptr, *s0 = nullptr, *n1 = nullptr, *qk = nullptr, *vt = nullptr, *att1 = nullptr,
+                 *s1 = nullptr, *n2 = nullptr, *q2 = nullptr, *k2 = nullptr, *vt2 = nullptr, *att2 = nullptr, *s2 = nullptr,
+                 *n3 = nullptr, *f = nullptr, *gg = nullptr, *s3 = nullptr;
+    float* st = nullptr;
+    int H = 0, W = 0;
+  } sv;
 };
 
 struct Level {
@@ -73,6 +90,17 @@ struct Level {
   std::vector<Transformer> att;
   bool has_sampler = false;
   ConvLayer sampler;
+  ConvTrain tsampler;
+};
+
+// One entry per layer the training forward ran, replayed in reverse by the backward pass.
+struct TapeOp {
+  enum Kind { CONV_IN, SKIP_PUSH, RESNET, TRANSFORMER, DOWNSAMPLE, CONCAT, UPSAMPLE } kind;
+  Resnet* R = nullptr;
+  Transformer* T = nullptr;
+  Level* Lv = nullptr;
+  const bf16_t* x = nullptr;   // layer input (samplers, conv_in)
+  int H = 0, W = 0, ch = 0, skc = 0, skip_idx = -1;
 };
 
 struct ctta_unet {
@@ -94,6 +122,18 @@ struct ctta_unet {
   int temb_dim = 0, temb_total = 0, cin_pad = 0, xp = 0;
   float* gn_scratch = nullptr;
   size_t gn_scratch_floats = 0;
+  // ---- training state (cfg.enable_training)
+  ConvTrain t_conv_in, t_conv_out;
+  std::vector<TapeOp> tape;
+  struct TrainSaved {
+    bool valid = false;
+    int B = 0, L = 0, Lp = 0, n_skips = 0;
+    size_t arena_off = 0;
+    const float *tfeat = nullptr, *t_h1pre = nullptr, *t_h1 = nullptr, *gfeat = nullptr, *g_h1pre = nullptr,
+                *g_h1 = nullptr, *emb = nullptr, *emb_silu = nullptr;
+    const bf16_t *enc_bf = nullptr, *xin = nullptr, *h_last = nullptr, *a_out = nullptr;
+    const float *mask_bias = nullptr, *st_out = nullptr;
+  } ts;
 };
 
 struct UCtx : RunCtx {
@@ -103,17 +143,24 @@ struct UCtx : RunCtx {
   const bf16_t* enc_bf;
   const float* mask_bias;
   size_t gn_need = 0;
+  bool train = false;
 };
 
 static ctta_status make_resnet(ctta_unet* U, const std::string& p, int cin, int cout, Resnet* R) {
   WeightStore& ws = U->store;
-  R->cin = cin; R->cout = cout;
+  R->cin = cin; R->cout = cout; R->key = p;
+  const bool tr = U->cfg.enable_training != 0;
   CTTA_TRY(make_gn(ws, p + "norm1.", cin, &R->n1));
-  CTTA_TRY(make_conv(ws, p + "conv1.", cout, cin, cin, 3, 3, 1, 1, &R->c1));
+  CTTA_TRY(make_conv(ws, p + "conv1.", cout, cin, cin, 3, 3, 1, 1, &R->c1, true, tr ? &R->t1.m : nullptr));
   CTTA_TRY(make_gn(ws, p + "norm2.", cout, &R->n2));
-  CTTA_TRY(make_conv(ws, p + "conv2.", cout, cout, cout, 3, 3, 1, 1, &R->c2));
+  CTTA_TRY(make_conv(ws, p + "conv2.", cout, cout, cout, 3, 3, 1, 1, &R->c2, true, tr ? &R->t2.m : nullptr));
   R->has_sc = cin != cout;
-  if (R->has_sc) CTTA_TRY(make_conv(ws, p + "conv_shortcut.", cout, cin, cin, 1, 1, 1, 0, &R->sc));
+  if (R->has_sc) CTTA_TRY(make_conv(ws, p + "conv_shortcut.", cout, cin, cin, 1, 1, 1, 0, &R->sc, true, tr ? &R->tsc.m : nullptr));
+  if (tr) {
+    CTTA_TRY(make_conv_dgrad(ws, p + "conv1.", cout, cin, 3, 3, 1, &R->t1.d));
+    CTTA_TRY(make_conv_dgrad(ws, p + "conv2.", cout, cout, 3, 3, 1, &R->t2.d));
+    if (R->has_sc) CTTA_TRY(make_conv_dgrad(ws, p + "conv_shortcut.", cout, cin, 1, 1, 0, &R->tsc.d));
+  }
   // time_emb_proj rows live in one concatenated fp32 table -> one small GEMM per forward
   R->temb_off = U->temb_total;
   CTTA_TRY(ws.add_copy_into(p + "time_emb_proj.weight", (int64_t)cout * U->temb_dim,
@@ -124,6 +171,7 @@ static ctta_status make_resnet(ctta_unet* U, const std::string& p, int cin, int 
 }
 
 static ctta_status make_ln(WeightStore& ws, const std::string& p, int d, LNLayer* L) {
+  L->key = p;
   CTTA_TRY(ws.add_vector(p + "weight", d, &L->gamma));
   CTTA_TRY(ws.add_vector(p + "bias", d, &L->beta));
   return CTTA_OK;
@@ -141,59 +189,81 @@ static ctta_status make_transformer(ctta_unet* U, const std::string& p, int c, i
   const std::string t = p + "transformer_blocks.0.";
   const auto hmap = head_pad_map(heads, dh);
   const auto in_cols = identity_map(inner, cp);
-  CTTA_TRY(make_linear(ws, p + "proj_in.weight", p + "proj_in.bias", inner, c, identity_map(inner, cp),
-                       identity_map(c, round_up(c, 64)), &T->proj_in));
+  const bool tr = U->cfg.enable_training != 0;
+  // forward pack (+ pack map and data-gradient pack when training)
+  auto lin = [&](const std::string& wkey, const std::string& bkey, int n_src, int k_src,
+                 const std::vector<int32_t>& rows, const std::vector<int32_t>& cols, PackedW* P, LinTrain* LT,
+                 bf16_t* pre = nullptr, bool need_dgrad = true) -> ctta_status {
+    CTTA_TRY(make_linear(ws, wkey, bkey, n_src, k_src, rows, cols, P, pre, tr ? &LT->m : nullptr));
+    if (tr && need_dgrad) CTTA_TRY(make_linear_dgrad(ws, wkey, n_src, k_src, rows, cols, &LT->d));
+    return CTTA_OK;
+  };
+  CTTA_TRY(lin(p + "proj_in.weight", p + "proj_in.bias", inner, c, identity_map(inner, cp),
+               identity_map(c, round_up(c, 64)), &T->proj_in, &T->t_proj_in));
   {  // self-attention q and k packed back to back -> one fused [q | k] GEMM
     bf16_t* qk = ws.arena.get<bf16_t>((size_t)2 * hp * cp);
     if (!qk) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
     PackedW pq, pk;
-    CTTA_TRY(make_linear(ws, t + "attn1.to_q.weight", "", inner, inner, hmap, in_cols, &pq, qk));
-    CTTA_TRY(make_linear(ws, t + "attn1.to_k.weight", "", inner, inner, hmap, in_cols, &pk, qk + (size_t)hp * cp));
+    CTTA_TRY(lin(t + "attn1.to_q.weight", "", inner, inner, hmap, in_cols, &pq, &T->t_q1, qk));
+    CTTA_TRY(lin(t + "attn1.to_k.weight", "", inner, inner, hmap, in_cols, &pk, &T->t_k1, qk + (size_t)hp * cp));
     T->qk1.w = qk; T->qk1.bias = nullptr; T->qk1.n = 2 * hp; T->qk1.k_pad = cp;
   }
-  CTTA_TRY(make_linear(ws, t + "attn1.to_v.weight", "", inner, inner, hmap, in_cols, &T->v1));
-  CTTA_TRY(make_linear(ws, t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", inner, inner,
-                       identity_map(inner, cp), hmap, &T->out1));
-  CTTA_TRY(make_linear(ws, t + "attn2.to_q.weight", "", inner, inner, hmap, in_cols, &T->q2));
-  CTTA_TRY(make_linear(ws, t + "attn2.to_k.weight", "", inner, X, hmap, identity_map(X, xp), &T->k2));
-  CTTA_TRY(make_linear(ws, t + "attn2.to_v.weight", "", inner, X, hmap, identity_map(X, xp), &T->v2));
-  CTTA_TRY(make_linear(ws, t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", inner, inner,
-                       identity_map(inner, cp), hmap, &T->out2));
+  CTTA_TRY(lin(t + "attn1.to_v.weight", "", inner, inner, hmap, in_cols, &T->v1, &T->t_v1));
+  CTTA_TRY(lin(t + "attn1.to_out.0.weight", t + "attn1.to_out.0.bias", inner, inner, identity_map(inner, cp), hmap,
+               &T->out1, &T->t_out1));
+  CTTA_TRY(lin(t + "attn2.to_q.weight", "", inner, inner, hmap, in_cols, &T->q2, &T->t_q2));
+  // the text states carry no gradient: no data-gradient packs for attn2.to_k / to_v
+  CTTA_TRY(lin(t + "attn2.to_k.weight", "", inner, X, hmap, identity_map(X, xp), &T->k2, &T->t_k2, nullptr, false));
+  CTTA_TRY(lin(t + "attn2.to_v.weight", "", inner, X, hmap, identity_map(X, xp), &T->v2, &T->t_v2, nullptr, false));
+  CTTA_TRY(lin(t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", inner, inner, identity_map(inner, cp), hmap,
+               &T->out2, &T->t_out2));
   {  // GEGLU projection: value rows -> [0, ffp), gate rows -> [ffp, 2*ffp)  (attention.py:430-432)
     std::vector<int32_t> rows(2 * ffp, -1);
     for (int i = 0; i < ffh; ++i) { rows[i] = i; rows[ffp + i] = ffh + i; }
-    CTTA_TRY(make_linear(ws, t + "ff.net.0.proj.weight", t + "ff.net.0.proj.bias", 2 * ffh, inner, rows,
-                         in_cols, &T->ff1));
+    CTTA_TRY(lin(t + "ff.net.0.proj.weight", t + "ff.net.0.proj.bias", 2 * ffh, inner, rows, in_cols, &T->ff1, &T->t_ff1));
   }
-  CTTA_TRY(make_linear(ws, t + "ff.net.2.weight", t + "ff.net.2.bias", inner, ffh, identity_map(inner, cp),
-                       identity_map(ffh, ffp), &T->ff2));
+  CTTA_TRY(lin(t + "ff.net.2.weight", t + "ff.net.2.bias", inner, ffh, identity_map(inner, cp), identity_map(ffh, ffp),
+               &T->ff2, &T->t_ff2));
   CTTA_TRY(make_ln(ws, t + "norm1.", inner, &T->ln1));
   CTTA_TRY(make_ln(ws, t + "norm2.", inner, &T->ln2));
   CTTA_TRY(make_ln(ws, t + "norm3.", inner, &T->ln3));
-  CTTA_TRY(make_linear(ws, p + "proj_out.weight", p + "proj_out.bias", c, inner, identity_map(c, round_up(c, 4)),
-                       in_cols, &T->proj_out));
+  CTTA_TRY(lin(p + "proj_out.weight", p + "proj_out.bias", c, inner, identity_map(c, round_up(c, 4)), in_cols,
+               &T->proj_out, &T->t_proj_out));
   return CTTA_OK;
 }
 
 // ------------------------------------------------------------------------------------ run
-static ctta_status gn(UCtx& c, const GNLayer& g, const bf16_t* x, bf16_t* y, int hw, float eps, bool silu) {
+// GroupNorm (+SiLU); the training forward also keeps (mean, rstd) per (sample, group) for the backward pass
+static ctta_status gn(UCtx& c, const GNLayer& g, const bf16_t* x, bf16_t* y, int hw, float eps, bool silu,
+                      float** stats_out = nullptr) {
   const int groups = c.U->cfg.norm_num_groups;
-  const size_t need = ctta_groupnorm_scratch_floats(c.B, hw, g.c, groups);
+  size_t need = ctta_groupnorm_scratch_floats(c.B, hw, g.c, groups);
+  if (c.train) {
+    const size_t nb = ctta_groupnorm_bwd_scratch_floats(c.B, hw, g.c, groups);
+    if (nb > need) need = nb;
+  }
   if (need > c.gn_need) c.gn_need = need;
-  return run_gn(c, g, x, y, c.B, hw, groups, eps, silu);
+  CTTA_TRY(run_gn(c, g, x, y, c.B, hw, groups, eps, silu));
+  if (c.train && stats_out) {
+    float* st = c.arena->get<float>((size_t)c.B * groups * 2); ALLOC_OR_FAIL(st);
+    RUN(c, ctta_groupnorm_stats(x, c.B, hw, g.c, groups, eps, st, c.stream));
+    *stats_out = st;
+  }
+  return CTTA_OK;
 }
 
-static ctta_status run_resnet(UCtx& c, const Resnet& R, const bf16_t* x, int H, int W, bf16_t** out_p) {
+static ctta_status run_resnet(UCtx& c, Resnet& R, const bf16_t* x, int H, int W, bf16_t** out_p) {
   Arena& A = *c.arena;
   const size_t M = (size_t)c.B * H * W;
   bf16_t* out = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(out);
   const size_t mk = A.mark();
   bf16_t* a = A.get<bf16_t>(M * R.cin); ALLOC_OR_FAIL(a);
-  CTTA_TRY(gn(c, R.n1, x, a, H * W, c.U->cfg.norm_eps, true));
+  CTTA_TRY(gn(c, R.n1, x, a, H * W, c.U->cfg.norm_eps, true, &R.sv.st1));
   bf16_t* t1 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(t1);
   CTTA_TRY(run_conv2d(c, R.c1, a, c.B, H, W, false, t1, c.temb_all + R.temb_off, c.U->temb_total, nullptr, 0));
   bf16_t* a2 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(a2);
-  CTTA_TRY(gn(c, R.n2, t1, a2, H * W, c.U->cfg.norm_eps, true));
+  CTTA_TRY(gn(c, R.n2, t1, a2, H * W, c.U->cfg.norm_eps, true, &R.sv.st2));
+  if (c.train) { R.sv.x = x; R.sv.a = a; R.sv.t1 = t1; R.sv.a2 = a2; R.sv.H = H; R.sv.W = W; }
   const bf16_t* res = x;
   if (R.has_sc) {
     bf16_t* r = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(r);
@@ -214,7 +284,7 @@ static ctta_status run_attention(UCtx& c, const bf16_t* q, int q_ld, const bf16_
   return CTTA_OK;
 }
 
-static ctta_status run_transformer(UCtx& c, const Transformer& T, const bf16_t* x, int H, int W,
+static ctta_status run_transformer(UCtx& c, Transformer& T, const bf16_t* x, int H, int W,
                                    bf16_t** out_p) {
   Arena& A = *c.arena;
   const int N = H * W;
@@ -223,7 +293,7 @@ static ctta_status run_transformer(UCtx& c, const Transformer& T, const bf16_t* 
   bf16_t* out = A.get<bf16_t>(M * T.c); ALLOC_OR_FAIL(out);
   const size_t mk = A.mark();
   bf16_t* g = A.get<bf16_t>(M * T.c); ALLOC_OR_FAIL(g);
-  CTTA_TRY(gn(c, T.norm, x, g, N, 1e-6f, false));   // transformer_2d.py:149 hard-codes eps=1e-6
+  CTTA_TRY(gn(c, T.norm, x, g, N, 1e-6f, false, &T.sv.st));   // transformer_2d.py:149 hard-codes eps=1e-6
   bf16_t* s0 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s0);
   CTTA_TRY(run_linear(c, T.proj_in, g, T.c, M, s0, cp, nullptr, 0));
   bf16_t* n = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(n);
@@ -239,7 +309,14 @@ static ctta_status run_transformer(UCtx& c, const Transformer& T, const bf16_t* 
   bf16_t* s1 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s1);
   CTTA_TRY(run_linear(c, T.out1, att, hp, M, s1, cp, s0, cp));
   // --- cross-attention against the text states
+  bf16_t* const n1 = n;
+  bf16_t* const att1 = att;
+  if (c.train) {   // the backward pass needs every LayerNorm / attention output: no buffer reuse
+    n = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(n);
+    att = A.get<bf16_t>(M * hp); ALLOC_OR_FAIL(att);
+  }
   RUN(c, ctta_layernorm(s1, n, M, T.inner, cp, T.ln2.gamma, T.ln2.beta, 1e-5f, c.stream));
+  bf16_t* const n2 = n;
   bf16_t* q2 = A.get<bf16_t>(M * hp); ALLOC_OR_FAIL(q2);
   CTTA_TRY(run_linear(c, T.q2, n, cp, M, q2, hp, nullptr, 0));
   bf16_t* k2 = A.get<bf16_t>((size_t)c.B * c.Lp * hp); ALLOC_OR_FAIL(k2);
@@ -250,6 +327,7 @@ static ctta_status run_transformer(UCtx& c, const Transformer& T, const bf16_t* 
   bf16_t* s2 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s2);
   CTTA_TRY(run_linear(c, T.out2, att, hp, M, s2, cp, s1, cp));
   // --- GEGLU feed-forward
+  if (c.train) { n = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(n); }
   RUN(c, ctta_layernorm(s2, n, M, T.inner, cp, T.ln3.gamma, T.ln3.beta, 1e-5f, c.stream));
   bf16_t* f = A.get<bf16_t>(M * 2 * T.ffp); ALLOC_OR_FAIL(f);
   CTTA_TRY(run_linear(c, T.ff1, n, cp, M, f, 2 * T.ffp, nullptr, 0));
@@ -258,6 +336,11 @@ static ctta_status run_transformer(UCtx& c, const Transformer& T, const bf16_t* 
   bf16_t* s3 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s3);
   CTTA_TRY(run_linear(c, T.ff2, gg, T.ffp, M, s3, cp, s2, cp));
   CTTA_TRY(run_linear(c, T.proj_out, s3, cp, M, out, T.c, x, T.c));
+  if (c.train) {
+    Transformer::Saved& S = T.sv;
+    S.x = x; S.g = g; S.s0 = s0; S.n1 = n1; S.qk = qk; S.vt = vt; S.att1 = att1; S.s1 = s1; S.n2 = n2; S.q2 = q2;
+    S.k2 = k2; S.vt2 = vt2; S.att2 = att; S.s2 = s2; S.n3 = n; S.f = f; S.gg = gg; S.s3 = s3; S.H = H; S.W = W;
+  }
   A.release(mk);
   *out_p = out;
   return CTTA_OK;
@@ -267,15 +350,19 @@ struct Skip { bf16_t* p; int c; };
 
 static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample, const float* timesteps,
                                      const double* guidance, const float* enc, const uint8_t* mask, int B,
-                                     int L, float* out, hipStream_t stream, size_t* gn_need) {
+                                     int L, float* out, hipStream_t stream, size_t* gn_need, bool train = false) {
   const ctta_unet_config& cfg = U->cfg;
   UCtx c;
+  c.train = train;
+  U->ts.valid = false;
+  U->tape.clear();
   c.arena = &U->arena; c.stream = stream; c.dry = dry;
   c.taps = cfg.debug_taps ? &U->taps : nullptr;
   c.gn_scratch = U->gn_scratch; c.gn_scratch_floats = U->gn_scratch_floats;
   c.U = U; c.B = B; c.L = L; c.Lp = round_up(L, 8);
   Arena& A = U->arena;
   A.reset();
+  A.no_release = cfg.debug_taps != 0 || train;   // the backward pass reads every intermediate
   const int H = cfg.height, W = cfg.width;
   const int T = U->temb_dim, c0 = cfg.block_out_channels[0];
 
@@ -285,15 +372,30 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   float* et = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(et);
   float* eg = nullptr;
   RUN(c, ctta_time_features(timesteps, U->freqs, c0, cfg.flip_sin_to_cos, tfeat, B, stream));
-  RUN(c, ctta_linear_f32(tfeat, U->t_w1, U->t_b1, h1, B, T, c0, 0, 1, stream));
+  // hidden = SiLU(linear_1(x)); the training forward keeps the pre-activation for SiLU'
+  auto mlp_hidden = [&](const float* x, const float* w, const float* b, int k, float* hid, const float** pre_out) -> ctta_status {
+    if (!train) { RUN(c, ctta_linear_f32(x, w, b, hid, B, T, k, 0, 1, stream)); return CTTA_OK; }
+    float* pre = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(pre);
+    RUN(c, ctta_linear_f32(x, w, b, pre, B, T, k, 0, 0, stream));
+    if (!dry) {
+      hipLaunchKernelGGL(add_silu_kernel, dim3((B * T + 255) / 256), dim3(256), 0, stream, pre, (const float*)nullptr, hid,
+                         (float*)nullptr, B * T);
+      CTTA_LAUNCH_CHECK();
+    }
+    *pre_out = pre;
+    return CTTA_OK;
+  };
+  CTTA_TRY(mlp_hidden(tfeat, U->t_w1, U->t_b1, c0, h1, &U->ts.t_h1pre));
   RUN(c, ctta_linear_f32(h1, U->t_w2, U->t_b2, et, B, T, T, 0, 0, stream));
+  U->ts.tfeat = tfeat; U->ts.t_h1 = h1;
   if (cfg.guided) {
     float* gfeat = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(gfeat);
     float* g1 = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(g1);
     eg = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(eg);
     RUN(c, ctta_fourier_features(guidance, U->g_proj, T / 2, cfg.flip_sin_to_cos, gfeat, B, stream));
-    RUN(c, ctta_linear_f32(gfeat, U->g_w1, U->g_b1, g1, B, T, T, 0, 1, stream));
+    CTTA_TRY(mlp_hidden(gfeat, U->g_w1, U->g_b1, T, g1, &U->ts.g_h1pre));
     RUN(c, ctta_linear_f32(g1, U->g_w2, U->g_b2, eg, B, T, T, 0, 0, stream));
+    U->ts.gfeat = gfeat; U->ts.g_h1 = g1;
   }
   float* emb = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(emb);
   float* emb_silu = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(emb_silu);
@@ -301,6 +403,7 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
     hipLaunchKernelGGL(add_silu_kernel, dim3((B * T + 255) / 256), dim3(256), 0, stream, et, eg, emb_silu, emb, B * T);
     CTTA_LAUNCH_CHECK();
   }
+  U->ts.emb = emb; U->ts.emb_silu = emb_silu;
   add_tap(c, "emb", emb, B, T, 1, 1, T, true);
   // every resnet's Linear(SiLU(emb)) (resnet.py:572-573) in one batch
   float* temb_all = A.get<float>((size_t)B * U->temb_total); ALLOC_OR_FAIL(temb_all);
@@ -322,6 +425,8 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
     }
   }
   c.enc_bf = enc_bf; c.mask_bias = mbias;
+  U->ts.enc_bf = enc_bf; U->ts.mask_bias = mbias;
+  auto tape = [&](TapeOp op) { if (train) U->tape.push_back(op); };
 
   // ---- 2. conv_in
   bf16_t* xin = A.get<bf16_t>((size_t)B * H * W * U->cin_pad); ALLOC_OR_FAIL(xin);
@@ -331,39 +436,54 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   add_tap(c, "conv_in", h, B, c0, H, W, c0);
   int ch = c0, hh = H, ww = W;
   std::vector<Skip> skips;
-  skips.push_back({h, ch});
+  int n_skips = 0;
+  U->ts.xin = xin;
+  { TapeOp op; op.kind = TapeOp::CONV_IN; op.x = xin; op.H = H; op.W = W; tape(op); }
+  auto push_skip = [&](bf16_t* p, int cc) {
+    skips.push_back({p, cc});
+    TapeOp op; op.kind = TapeOp::SKIP_PUSH; op.skip_idx = n_skips++; op.ch = cc; op.H = hh; op.W = ww; tape(op);
+  };
+  auto tape_res = [&](Resnet& R) { TapeOp op; op.kind = TapeOp::RESNET; op.R = &R; op.H = hh; op.W = ww; tape(op); };
+  auto tape_att = [&](Transformer& Tr) { TapeOp op; op.kind = TapeOp::TRANSFORMER; op.T = &Tr; op.H = hh; op.W = ww; tape(op); };
+  push_skip(h, ch);
 
   // ---- 3. down
   for (int i = 0; i < cfg.n_levels; ++i) {
-    const Level& Lv = U->down[i];
+    Level& Lv = U->down[i];
     const std::string p = "down_blocks." + std::to_string(i) + ".";
     for (size_t j = 0; j < Lv.res.size(); ++j) {
       CTTA_TRY(run_resnet(c, Lv.res[j], h, hh, ww, &h));
+      tape_res(Lv.res[j]);
       ch = Lv.res[j].cout;
       add_tap(c, p + "resnets." + std::to_string(j), h, B, ch, hh, ww, ch);
       if (!Lv.att.empty()) {
         CTTA_TRY(run_transformer(c, Lv.att[j], h, hh, ww, &h));
+        tape_att(Lv.att[j]);
         add_tap(c, p + "attentions." + std::to_string(j), h, B, ch, hh, ww, ch);
       }
-      skips.push_back({h, ch});
+      push_skip(h, ch);
     }
     if (Lv.has_sampler) {
       const int ho = (hh + 2 - 3) / 2 + 1, wo = (ww + 2 - 3) / 2 + 1;
       bf16_t* d = A.get<bf16_t>((size_t)B * ho * wo * ch); ALLOC_OR_FAIL(d);
       CTTA_TRY(run_conv2d(c, Lv.sampler, h, B, hh, ww, false, d, nullptr, 0, nullptr, 0));
+      { TapeOp op; op.kind = TapeOp::DOWNSAMPLE; op.Lv = &Lv; op.x = h; op.H = hh; op.W = ww; op.ch = ch; tape(op); }
       h = d; hh = ho; ww = wo;
       add_tap(c, p + "downsamplers.0", h, B, ch, hh, ww, ch);
-      skips.push_back({h, ch});
+      push_skip(h, ch);
     }
   }
   // ---- 4. mid
   CTTA_TRY(run_resnet(c, U->mid_r0, h, hh, ww, &h));
+  tape_res(U->mid_r0);
   CTTA_TRY(run_transformer(c, U->mid_att, h, hh, ww, &h));
+  tape_att(U->mid_att);
   CTTA_TRY(run_resnet(c, U->mid_r1, h, hh, ww, &h));
+  tape_res(U->mid_r1);
   add_tap(c, "mid_block", h, B, ch, hh, ww, ch);
   // ---- 5. up
   for (int i = 0; i < cfg.n_levels; ++i) {
-    const Level& Lv = U->up[i];
+    Level& Lv = U->up[i];
     const std::string p = "up_blocks." + std::to_string(i) + ".";
     for (size_t j = 0; j < Lv.res.size(); ++j) {
       const Skip sk = skips.back();
@@ -372,17 +492,21 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
       bf16_t* cat = A.get<bf16_t>(M * (ch + sk.c)); ALLOC_OR_FAIL(cat);
       RUN(c, ctta_concat_channels(h, ch, sk.p, sk.c, cat, (int64_t)M, stream));   // torch.cat([h, skip], 1)
       CTTA_REQUIRE(Lv.res[j].cin == ch + sk.c, "internal: skip width mismatch");
+      { TapeOp op; op.kind = TapeOp::CONCAT; op.ch = ch; op.skc = sk.c; op.skip_idx = (int)skips.size(); op.H = hh; op.W = ww; tape(op); }
       CTTA_TRY(run_resnet(c, Lv.res[j], cat, hh, ww, &h));
+      tape_res(Lv.res[j]);
       ch = Lv.res[j].cout;
       add_tap(c, p + "resnets." + std::to_string(j), h, B, ch, hh, ww, ch);
       if (!Lv.att.empty()) {
         CTTA_TRY(run_transformer(c, Lv.att[j], h, hh, ww, &h));
+        tape_att(Lv.att[j]);
         add_tap(c, p + "attentions." + std::to_string(j), h, B, ch, hh, ww, ch);
       }
     }
     if (Lv.has_sampler) {   // Upsample2D: nearest x2 fused into the conv's gather
       bf16_t* u = A.get<bf16_t>((size_t)B * 4 * hh * ww * ch); ALLOC_OR_FAIL(u);
       CTTA_TRY(run_conv2d(c, Lv.sampler, h, B, hh, ww, true, u, nullptr, 0, nullptr, 0));
+      { TapeOp op; op.kind = TapeOp::UPSAMPLE; op.Lv = &Lv; op.x = h; op.H = hh; op.W = ww; op.ch = ch; tape(op); }
       h = u; hh *= 2; ww *= 2;
       add_tap(c, p + "upsamplers.0", h, B, ch, hh, ww, ch);
     }
@@ -390,12 +514,21 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   CTTA_REQUIRE(hh == H && ww == W && ch == c0, "internal: up path did not return to the input extent");
   // ---- 6. out
   bf16_t* a = A.get<bf16_t>((size_t)B * H * W * c0); ALLOC_OR_FAIL(a);
-  CTTA_TRY(gn(c, U->norm_out, h, a, H * W, cfg.norm_eps, true));
+  float* st_out = nullptr;
+  CTTA_TRY(gn(c, U->norm_out, h, a, H * W, cfg.norm_eps, true, &st_out));
   RUN(c, ctta_conv_small_n(a, c0, B, H, W, 3, 3, 1, 1, U->conv_out_w, U->conv_out_b, cfg.out_channels, 0,
                            0.f, 0, out, nullptr, stream));
+  if (train) {
+    U->ts.h_last = h; U->ts.a_out = a; U->ts.st_out = st_out;
+    U->ts.B = B; U->ts.L = L; U->ts.Lp = c.Lp; U->ts.n_skips = n_skips; U->ts.arena_off = A.off;
+    U->ts.valid = !dry;
+  }
   if (gn_need) *gn_need = c.gn_need;
   return CTTA_OK;
 }
+
+#include "engine_unet_train.h"
+
 
 // ------------------------------------------------------------------------------------ create
 static ctta_status unet_build(ctta_unet* U) {
@@ -417,7 +550,9 @@ static ctta_status unet_build(ctta_unet* U) {
   if (!U->temb_w || !U->temb_b) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
   U->temb_total = 0;
 
-  CTTA_TRY(make_conv(ws, "conv_in.", boc[0], cfg.in_channels, U->cin_pad, 3, 3, 1, 1, &U->conv_in));
+  const bool tr = cfg.enable_training != 0;
+  CTTA_TRY(make_conv(ws, "conv_in.", boc[0], cfg.in_channels, U->cin_pad, 3, 3, 1, 1, &U->conv_in, true,
+                     tr ? &U->t_conv_in.m : nullptr));
   CTTA_TRY(ws.add_vector("time_embedding.linear_1.weight", T * boc[0], &U->t_w1));
   CTTA_TRY(ws.add_vector("time_embedding.linear_1.bias", T, &U->t_b1));
   CTTA_TRY(ws.add_vector("time_embedding.linear_2.weight", T * T, &U->t_w2));
@@ -459,7 +594,9 @@ static ctta_status unet_build(ctta_unet* U) {
       CTTA_TRY(make_resnet(U, p + "resnets." + std::to_string(j) + ".", j == 0 ? in_c : out_c, out_c, &Lv.res[j]));
     if (i != n - 1) {
       Lv.has_sampler = true;
-      CTTA_TRY(make_conv(ws, p + "downsamplers.0.conv.", out_c, out_c, out_c, 3, 3, 2, 1, &Lv.sampler));
+      CTTA_TRY(make_conv(ws, p + "downsamplers.0.conv.", out_c, out_c, out_c, 3, 3, 2, 1, &Lv.sampler, true,
+                         tr ? &Lv.tsampler.m : nullptr));
+      if (tr) CTTA_TRY(make_conv_dgrad(ws, p + "downsamplers.0.conv.", out_c, out_c, 3, 3, 1, &Lv.tsampler.d));
     }
   }
   U->up.resize(n);
@@ -484,7 +621,9 @@ static ctta_status unet_build(ctta_unet* U) {
     }
     if (i != n - 1) {
       Lv.has_sampler = true;
-      CTTA_TRY(make_conv(ws, p + "upsamplers.0.conv.", out_c, out_c, out_c, 3, 3, 1, 1, &Lv.sampler));
+      CTTA_TRY(make_conv(ws, p + "upsamplers.0.conv.", out_c, out_c, out_c, 3, 3, 1, 1, &Lv.sampler, true,
+                         tr ? &Lv.tsampler.m : nullptr));
+      if (tr) CTTA_TRY(make_conv_dgrad(ws, p + "upsamplers.0.conv.", out_c, out_c, 3, 3, 1, &Lv.tsampler.d));
     }
   }
   CTTA_TRY(make_transformer(U, "mid_block.attentions.0.", boc[n - 1], cfg.heads[n - 1], &U->mid_att));
@@ -507,6 +646,18 @@ static ctta_status unet_build(ctta_unet* U) {
       return CTTA_OK;
     });
     CTTA_TRY(ws.add_vector("conv_out.bias", co, &U->conv_out_b));
+    if (tr) {   // conv_out runs on the direct small-N kernel in the forward; the backward uses conv_gemm
+      CTTA_REQUIRE(co <= 8, "unet_create: training supports out_channels <= 8");
+      CTTA_TRY(make_conv_dgrad(ws, "conv_out.", co, ci, 3, 3, 1, &U->t_conv_out.d, 8));
+      std::vector<int32_t> ro(8, -1), cmap((size_t)9 * ci);
+      for (int r = 0; r < co; ++r) ro[r] = r * ci * 9;
+      for (int t = 0; t < 9; ++t)
+        for (int cc = 0; cc < ci; ++cc) cmap[(size_t)t * ci + cc] = cc * 9 + t;
+      PackMap& m = U->t_conv_out.m;
+      m.wkey = "conv_out.weight"; m.bkey = "conv_out.bias"; m.n = 8; m.n_bias = co; m.bidx = nullptr;
+      CTTA_TRY(ws.upload(ro, &m.ro));
+      CTTA_TRY(ws.upload(cmap, &m.co));
+    }
   }
   return CTTA_OK;
 }
@@ -530,7 +681,8 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
   hipStream_t s = (hipStream_t)stream;
   ctta_unet* U = new ctta_unet();
   U->cfg = *cfg;
-  ctta_status st = U->store.init(estimate_store_bytes(weights, n_weights));
+  ctta_status st = U->store.init(cfg->enable_training ? estimate_store_bytes_training(weights, n_weights)
+                                                      : estimate_store_bytes(weights, n_weights));
   if (st != CTTA_OK) { delete U; return st; }
   WeightTable wt;
   wt.build(weights, n_weights);
@@ -542,6 +694,14 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
     U->arena.no_release = cfg->debug_taps != 0;
     st = unet_forward_impl(U, true, nullptr, nullptr, nullptr, nullptr, (const uint8_t*)1, cfg->max_batch,
                            cfg->max_text_len, nullptr, s, &gn_need);
+    if (st == CTTA_OK && cfg->enable_training) {   // training forward + backward need the larger arena
+      size_t gn2 = 0;
+      st = unet_forward_impl(U, true, nullptr, nullptr, nullptr, nullptr, (const uint8_t*)1, cfg->max_batch,
+                             cfg->max_text_len, nullptr, s, &gn2, true);
+      if (gn2 > gn_need) gn_need = gn2;
+      if (st == CTTA_OK) st = unet_backward_impl(U, true, nullptr, nullptr, s, nullptr);
+      U->ts.valid = false;
+    }
   }
   if (st == CTTA_OK) {
     const size_t bytes = U->arena.peak + (1 << 20);

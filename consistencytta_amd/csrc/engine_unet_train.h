@@ -1,0 +1,515 @@
+// Backward pass of the student U-Net for the consistency-distillation step (included by
+// engine_unet.hip; same translation unit).  The reference gets these gradients from torch autograd
+// over UNet2DConditionGuidedModel.forward (train.py:332-346 -> accelerator.backward(loss)); here the
+// tape the training forward recorded is replayed in reverse with hand-written operators:
+//   * data gradients   : conv_gemm against the re-packed (rotated / transposed) weights,
+//   * weight gradients : one split-M GEMM  dW[k][n] = sum_m Q[k][m] * dY^T[n][m]  per layer, where
+//                        Q = im2col(X)^T plus an all-ones row (bias gradient) and, for the resnets'
+//                        conv1, one indicator row per sample (time-embedding gradient),
+//   * attention        : probabilities recomputed per head (S = QK^T materialised in fp32), then
+//                        dV = P^T dO, dP = dO V^T, dS = softmax'(P, dP), dQ = dS K, dK = dS^T Q,
+//   * norms / GEGLU / embedding MLP: the kernels in backward.hip.
+// Gradients are ACCUMULATED into the caller's fp32 tensors (same names / shapes as the state dict),
+// i.e. `.grad` semantics; the caller zeroes them.  Activation gradients travel in bf16.
+
+struct GradTable {
+  std::unordered_map<std::string, float*> map;
+  void build(const ctta_tensor* g, int n) {
+    map.clear();
+    for (int i = 0; i < n; ++i) map[g[i].name] = const_cast<float*>(g[i].data);   // ctta_tensor is shared with the (read-only) weight tables
+  }
+};
+
+struct BCtx : UCtx {
+  const GradTable* grads = nullptr;
+  float* dtemb_all = nullptr;   // [B][temb_total] fp32, filled from the conv1 indicator rows
+};
+
+static ctta_status grad_ptr(BCtx& c, const std::string& key, float** out) {
+  *out = nullptr;
+  if (c.dry) return CTTA_OK;
+  auto it = c.grads->map.find(key);
+  if (it == c.grads->map.end() || !it->second) {
+    ctta_set_error("unet_backward: no gradient tensor for '%s'", key.c_str());
+    return CTTA_ERR_MISSING_KEY;
+  }
+  *out = it->second;
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ weight gradients
+struct Slabs { float* p = nullptr; int S = 1, R = 0, N = 0; };
+
+static int pick_splits(int64_t M, int R, int N) {
+  const int64_t tiles = (int64_t)((R + 127) / 128) * ((N + 127) / 128);
+  int S = 1;
+  while (tiles * S < 256 && S < 16 && M / (2 * S) >= 256) S *= 2;
+  return S;
+}
+
+// slabs[s][r][n] = sum_{m in segment s} Q[r][m] * dY[m][n];  x is the layer input in NHWC (a linear
+// is the 1x1 case with batch=1, hi=rows), dy [M][N] contiguous.  Rows of Q: (tap, channel) then
+// the all-ones row, then `nb` per-sample indicator rows.
+static ctta_status wgrad_slabs(BCtx& c, const bf16_t* x, int C, int B, int hi, int wi, bool ups, int ho, int wo, int kh,
+                               int kw, int stride, int pad, const bf16_t* dy, int N, int nb, Slabs* out) {
+  Arena& A = *c.arena;
+  const int64_t M = (int64_t)B * ho * wo;
+  const int K = kh * kw * C;
+  const int R = K + 1 + nb;
+  const int S = pick_splits(M, R, N);
+  const int mp = (int)round_up64(M, 64 * S);
+  const int seg = mp / S;
+  bf16_t* q = A.get<bf16_t>((size_t)R * mp); ALLOC_OR_FAIL(q);
+  bf16_t* pt = A.get<bf16_t>((size_t)N * mp); ALLOC_OR_FAIL(pt);
+  float* slabs = A.get<float>((size_t)S * R * N); ALLOC_OR_FAIL(slabs);
+  RUN(c, ctta_im2col_t(x, C, B, hi, wi, ups ? 1 : 0, ho, wo, kh, kw, stride, pad, pad, 1, q, mp, nb, c.stream));
+  RUN(c, ctta_transpose_bf16(dy, 0, (int)M, N, N, 0, pt, 0, mp, 1, c.stream));
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = q; d.c0 = seg; d.x_stride = mp;
+  d.batch = 1; d.hi = R; d.wi = 1; d.ho = R; d.wo = 1;
+  d.w = pt; d.k_pad = mp; d.n = N;
+  d.out = slabs; d.ldc = N; d.out_f32 = 1;
+  d.groups = S; d.x_group_stride = seg; d.w_group_stride = seg; d.out_group_stride = (int64_t)R * N;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  out->p = slabs; out->S = S; out->R = R; out->N = N;
+  return CTTA_OK;
+}
+
+// slab columns [col0, col0 + m.n) -> weight / bias gradients of the layer described by `m`
+static ctta_status scatter_wgrad(BCtx& c, const Slabs& sl, int k_rows, const PackMap& m, int col0 = 0) {
+  const int64_t stride = (int64_t)sl.R * sl.N;
+  float* gw;
+  CTTA_TRY(grad_ptr(c, m.wkey, &gw));
+  RUN(c, ctta_wgrad_scatter(sl.p + col0, sl.S, stride, sl.N, k_rows, m.n, m.ro, m.co, nullptr, nullptr, 0, gw, 1, c.stream));
+  if (!m.bkey.empty()) {
+    float* gb;
+    CTTA_TRY(grad_ptr(c, m.bkey, &gb));
+    RUN(c, ctta_row_scatter(sl.p + col0, sl.S, stride, sl.N, k_rows, m.n_bias, m.bidx, gb, 1, c.stream));
+  }
+  return CTTA_OK;
+}
+
+static ctta_status conv_wgrad(BCtx& c, const ConvLayer& L, const PackMap& m, const bf16_t* x, int H, int W, bool ups,
+                              const bf16_t* dy, int temb_off = -1) {
+  Arena& A = *c.arena;
+  const size_t mk = A.mark();
+  const int hi = ups ? 2 * H : H, wi = ups ? 2 * W : W;
+  const int ho = (hi + 2 * L.pad - L.kh) / L.stride + 1, wo = (wi + 2 * L.pad - L.kw) / L.stride + 1;
+  const int nb = temb_off >= 0 ? c.B : 0;
+  Slabs sl;
+  CTTA_TRY(wgrad_slabs(c, x, L.cin_pad, c.B, hi, wi, ups, ho, wo, L.kh, L.kw, L.stride, L.pad, dy, L.p.n, nb, &sl));
+  const int K = L.kh * L.kw * L.cin_pad;
+  CTTA_TRY(scatter_wgrad(c, sl, K, m));
+  for (int b = 0; b < nb; ++b)   // d temb[b][off + n] = sum over the sample's pixels of dY
+    RUN(c, ctta_row_scatter(sl.p, sl.S, (int64_t)sl.R * sl.N, sl.N, K + 1 + b, L.cout, nullptr,
+                            c.dtemb_all + (size_t)b * c.U->temb_total + temb_off, 0, c.stream));
+  A.release(mk);
+  return CTTA_OK;
+}
+
+// linear y = x W^T (+b): x [rows][x_ld] (the first k_rows columns are the GEMM K), dy [rows][N]
+static ctta_status linear_wgrad(BCtx& c, const PackMap& m, const PackMap* m2, const bf16_t* x, int x_ld, int64_t rows,
+                                const bf16_t* dy, int N) {
+  Arena& A = *c.arena;
+  const size_t mk = A.mark();
+  Slabs sl;
+  CTTA_TRY(wgrad_slabs(c, x, x_ld, 1, (int)rows, 1, false, (int)rows, 1, 1, 1, 1, 0, dy, N, 0, &sl));
+  CTTA_TRY(scatter_wgrad(c, sl, x_ld, m, 0));
+  if (m2) CTTA_TRY(scatter_wgrad(c, sl, x_ld, *m2, m.n));   // fused [q | k]
+  A.release(mk);
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ data gradients
+static ctta_status conv_dgrad(BCtx& c, const ConvLayer& D, const bf16_t* dy, int Hdy, int Wdy, bf16_t* dx, int Hout,
+                              int Wout, bool accumulate) {
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = dy; d.c0 = D.cin_pad;
+  d.batch = c.B; d.hi = Hdy; d.wi = Wdy; d.ho = Hout; d.wo = Wout;
+  d.kh = D.kh; d.kw = D.kw; d.pad_h = d.pad_w = D.pad;
+  d.w = D.p.w; d.k_pad = D.p.k_pad; d.n = D.p.n;
+  d.out = dx; d.ldc = D.cout; d.accumulate = accumulate ? 1 : 0;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  return CTTA_OK;
+}
+// dx [rows][ldx] (first n_out columns written) (+)= dy[:, :k] * W   with dy row stride dy_ld
+static ctta_status linear_dgrad(BCtx& c, const PackedW& D, const bf16_t* dy, int dy_k, int dy_ld, int64_t rows, bf16_t* dx,
+                                int n_out, int ldx, bool accumulate) {
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = dy; d.c0 = dy_k; d.x_stride = dy_ld;
+  d.batch = 1; d.hi = (int)rows; d.wi = 1; d.ho = (int)rows; d.wo = 1;
+  d.w = D.w; d.k_pad = D.k_pad; d.n = n_out;
+  d.out = dx; d.ldc = ldx; d.accumulate = accumulate ? 1 : 0;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  return CTTA_OK;
+}
+
+static ctta_status gn_backward(BCtx& c, const GNLayer& g, const bf16_t* x, const bf16_t* dy, bf16_t* dx, int hw,
+                               const float* stats, bool silu, bool accumulate_dx) {
+  float *dg, *db;
+  CTTA_TRY(grad_ptr(c, g.key + "weight", &dg));
+  CTTA_TRY(grad_ptr(c, g.key + "bias", &db));
+  const int groups = c.U->cfg.norm_num_groups;
+  if (!c.dry && ctta_groupnorm_bwd_scratch_floats(c.B, hw, g.c, groups) > c.gn_scratch_floats) {
+    ctta_set_error("groupnorm backward scratch too small");
+    return CTTA_ERR_INVALID;
+  }
+  RUN(c, ctta_groupnorm_bwd(x, dy, dx, c.B, hw, g.c, groups, stats, g.gamma, g.beta, silu ? 1 : 0, accumulate_dx ? 1 : 0,
+                            dg, db, 1, c.gn_scratch, c.stream));
+  return CTTA_OK;
+}
+static ctta_status ln_backward(BCtx& c, const LNLayer& l, const bf16_t* x, const bf16_t* dy, bf16_t* dx, int64_t rows,
+                               int d, int ld, bool accumulate_dx) {
+  float *dg, *db;
+  CTTA_TRY(grad_ptr(c, l.key + "weight", &dg));
+  CTTA_TRY(grad_ptr(c, l.key + "bias", &db));
+  RUN(c, ctta_layernorm_bwd(x, dy, dx, rows, d, ld, l.gamma, 1e-5f, accumulate_dx ? 1 : 0, dg, db, c.stream));
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ resnet
+// out = conv2(silu(gn2(t1))) + shortcut(x),  t1 = conv1(silu(gn1(x))) + temb   (resnet.py:549-597)
+static ctta_status bwd_resnet(BCtx& c, Resnet& R, const bf16_t* dout, bf16_t** dx_p) {
+  Arena& A = *c.arena;
+  const Resnet::Saved& S = R.sv;
+  const int H = S.H, W = S.W;
+  const size_t M = (size_t)c.B * H * W;
+  bf16_t* dx = A.get<bf16_t>(M * R.cin); ALLOC_OR_FAIL(dx);
+  const size_t mk = A.mark();
+  bf16_t* da2 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(da2);
+  CTTA_TRY(conv_dgrad(c, R.t2.d, dout, H, W, da2, H, W, false));
+  CTTA_TRY(conv_wgrad(c, R.c2, R.t2.m, S.a2, H, W, false, dout));
+  bf16_t* dt1 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(dt1);
+  CTTA_TRY(gn_backward(c, R.n2, S.t1, da2, dt1, H * W, S.st2, true, false));
+  CTTA_TRY(conv_wgrad(c, R.c1, R.t1.m, S.a, H, W, false, dt1, R.temb_off));
+  bf16_t* da = A.get<bf16_t>(M * R.cin); ALLOC_OR_FAIL(da);
+  CTTA_TRY(conv_dgrad(c, R.t1.d, dt1, H, W, da, H, W, false));
+  if (R.has_sc) {
+    CTTA_TRY(conv_dgrad(c, R.tsc.d, dout, H, W, dx, H, W, false));
+    CTTA_TRY(conv_wgrad(c, R.sc, R.tsc.m, S.x, H, W, false, dout));
+  } else {
+    RUN(c, ctta_add_slices(dout, R.cout, nullptr, 0, dx, R.cin, (int64_t)M, R.cin, c.stream));
+  }
+  CTTA_TRY(gn_backward(c, R.n1, S.x, da, dx, H * W, S.st1, true, true));
+  A.release(mk);
+  *dx_p = dx;
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ attention
+// q [B][nq][ldq], k [B][krows][ldk] (head h at columns h*64), vt [B][hp][vt_ld]; dO [B*nq][hp].
+// Writes dq [B*nq][lddq], dk [B*krows][lddk], dv [B*krows][hp] (head-padded lanes come out zero).
+static ctta_status bwd_attention(BCtx& c, int heads, int dh, const bf16_t* q, int ldq, const bf16_t* k, int ldk, int krows,
+                                 const bf16_t* vt, int vt_ld, const float* bias, int nq, int nk, const bf16_t* dO, int hp,
+                                 bf16_t* dq, int lddq, bf16_t* dk, int lddk, bf16_t* dv) {
+  Arena& A = *c.arena;
+  const int B = c.B;
+  const int nk64 = round_up(krows > nk ? krows : nk, 64), nq64 = round_up(nq, 64);
+  const int ncols = krows;   // GEMM N for the score products (rows of k beyond nk are zero text rows)
+  const float scale = 1.0f / sqrtf((float)dh);
+  const size_t rows = (size_t)B * nq;
+  for (int h = 0; h < heads; ++h) {
+    const size_t mk = A.mark();
+    float* S = A.get<float>(rows * nk64); ALLOC_OR_FAIL(S);
+    bf16_t* P = A.get<bf16_t>(rows * nk64); ALLOC_OR_FAIL(P);
+    bf16_t* Vh = A.get<bf16_t>((size_t)B * nk64 * 64); ALLOC_OR_FAIL(Vh);
+    bf16_t* KhT = A.get<bf16_t>((size_t)B * 64 * nk64); ALLOC_OR_FAIL(KhT);
+    bf16_t* QhT = A.get<bf16_t>((size_t)B * 64 * nq64); ALLOC_OR_FAIL(QhT);
+    bf16_t* dOhT = A.get<bf16_t>((size_t)B * 64 * nq64); ALLOC_OR_FAIL(dOhT);
+    bf16_t* T1 = A.get<bf16_t>((size_t)B * nk64 * nq64); ALLOC_OR_FAIL(T1);   // P^T, then dS^T
+    ctta_conv_desc d;
+    // S = Q_h K_h^T
+    desc_init(&d);
+    d.x0 = q + h * 64; d.c0 = 64; d.x_stride = ldq; d.batch = 1; d.hi = nq; d.wi = 1; d.ho = nq; d.wo = 1;
+    d.w = k + h * 64; d.k_pad = ldk; d.n = ncols; d.out = S; d.ldc = nk64; d.out_f32 = 1;
+    d.groups = B; d.x_group_stride = (int64_t)nq * ldq; d.w_group_stride = (int64_t)krows * ldk;
+    d.out_group_stride = (int64_t)nq * nk64;
+    RUN(c, ctta_conv_gemm(&d, c.stream));
+    RUN(c, ctta_softmax_bias_rows(S, nk64, bias, nq, P, (int64_t)rows, nk, nk64, scale, c.stream));
+    // dV_h = P^T dO_h
+    RUN(c, ctta_transpose_bf16(P, (int64_t)nq * nk64, nq, nk64, nk64, 0, T1, (int64_t)nk64 * nq64, nq64, B, c.stream));
+    RUN(c, ctta_transpose_bf16(dO + h * 64, (int64_t)nq * hp, nq, 64, hp, 0, dOhT, (int64_t)64 * nq64, nq64, B, c.stream));
+    desc_init(&d);
+    d.x0 = T1; d.c0 = nq64; d.batch = 1; d.hi = nk; d.wi = 1; d.ho = nk; d.wo = 1;
+    d.w = dOhT; d.k_pad = nq64; d.n = 64; d.out = dv + h * 64; d.ldc = hp;
+    d.groups = B; d.x_group_stride = (int64_t)nk64 * nq64; d.w_group_stride = (int64_t)64 * nq64;
+    d.out_group_stride = (int64_t)krows * hp;
+    RUN(c, ctta_conv_gemm(&d, c.stream));
+    // dP = dO_h V_h^T  (into the score buffer), dS = softmax'(P, dP) (into P)
+    RUN(c, ctta_transpose_bf16(vt + (size_t)h * 64 * vt_ld, (int64_t)hp * vt_ld, 64, vt_ld, vt_ld, 0, Vh, (int64_t)nk64 * 64,
+                               64, B, c.stream));
+    desc_init(&d);
+    d.x0 = dO + h * 64; d.c0 = 64; d.x_stride = hp; d.batch = 1; d.hi = nq; d.wi = 1; d.ho = nq; d.wo = 1;
+    d.w = Vh; d.k_pad = 64; d.n = ncols; d.out = S; d.ldc = nk64; d.out_f32 = 1;
+    d.groups = B; d.x_group_stride = (int64_t)nq * hp; d.w_group_stride = (int64_t)nk64 * 64;
+    d.out_group_stride = (int64_t)nq * nk64;
+    RUN(c, ctta_conv_gemm(&d, c.stream));
+    RUN(c, ctta_softmax_bwd_rows(P, S, nk64, P, (int64_t)rows, nk, nk64, scale, c.stream));
+    // dQ_h = dS K_h
+    RUN(c, ctta_transpose_bf16(k + h * 64, (int64_t)krows * ldk, nk, 64, ldk, 0, KhT, (int64_t)64 * nk64, nk64, B, c.stream));
+    desc_init(&d);
+    d.x0 = P; d.c0 = nk64; d.batch = 1; d.hi = nq; d.wi = 1; d.ho = nq; d.wo = 1;
+    d.w = KhT; d.k_pad = nk64; d.n = 64; d.out = dq + h * 64; d.ldc = lddq;
+    d.groups = B; d.x_group_stride = (int64_t)nq * nk64; d.w_group_stride = (int64_t)64 * nk64;
+    d.out_group_stride = (int64_t)nq * lddq;
+    RUN(c, ctta_conv_gemm(&d, c.stream));
+    // dK_h = dS^T Q_h
+    RUN(c, ctta_transpose_bf16(P, (int64_t)nq * nk64, nq, nk64, nk64, 0, T1, (int64_t)nk64 * nq64, nq64, B, c.stream));
+    RUN(c, ctta_transpose_bf16(q + h * 64, (int64_t)nq * ldq, nq, 64, ldq, 0, QhT, (int64_t)64 * nq64, nq64, B, c.stream));
+    desc_init(&d);
+    d.x0 = T1; d.c0 = nq64; d.batch = 1; d.hi = nk; d.wi = 1; d.ho = nk; d.wo = 1;
+    d.w = QhT; d.k_pad = nq64; d.n = 64; d.out = dk + h * 64; d.ldc = lddk;
+    d.groups = B; d.x_group_stride = (int64_t)nk64 * nq64; d.w_group_stride = (int64_t)64 * nq64;
+    d.out_group_stride = (int64_t)krows * lddk;
+    RUN(c, ctta_conv_gemm(&d, c.stream));
+    A.release(mk);
+  }
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ transformer
+// transformer_2d.py:218-332 + attention.py:276-334 in reverse (see run_transformer for the forward)
+static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, bf16_t** dx_p) {
+  Arena& A = *c.arena;
+  const Transformer::Saved& S = T.sv;
+  const int N = S.H * S.W;
+  const int64_t M = (int64_t)c.B * N;
+  const int cp = T.cp, hp = T.hp, ffp = T.ffp;
+  const int vt_ld = round_up(N, 8);
+  bf16_t* dx = A.get<bf16_t>((size_t)M * T.c); ALLOC_OR_FAIL(dx);
+  const size_t mk = A.mark();
+  // out = proj_out(s3) + x
+  bf16_t* ds = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(ds);   // running gradient of the token stream
+  CTTA_TRY(linear_dgrad(c, T.t_proj_out.d, dout, T.c, T.c, M, ds, cp, cp, false));
+  CTTA_TRY(linear_wgrad(c, T.t_proj_out.m, nullptr, S.s3, cp, M, dout, T.proj_out.n));
+  {  // s3 = ff2(geglu(ff1(ln3(s2)))) + s2
+    const size_t m2 = A.mark();
+    bf16_t* dgg = A.get<bf16_t>((size_t)M * ffp); ALLOC_OR_FAIL(dgg);
+    CTTA_TRY(linear_dgrad(c, T.t_ff2.d, ds, cp, cp, M, dgg, ffp, ffp, false));
+    CTTA_TRY(linear_wgrad(c, T.t_ff2.m, nullptr, S.gg, ffp, M, ds, cp));
+    bf16_t* df = A.get<bf16_t>((size_t)M * 2 * ffp); ALLOC_OR_FAIL(df);
+    RUN(c, ctta_geglu_bwd(S.f, dgg, df, M, ffp, c.stream));
+    bf16_t* dn = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(dn);
+    CTTA_TRY(linear_dgrad(c, T.t_ff1.d, df, 2 * ffp, 2 * ffp, M, dn, cp, cp, false));
+    CTTA_TRY(linear_wgrad(c, T.t_ff1.m, nullptr, S.n3, cp, M, df, 2 * ffp));
+    CTTA_TRY(ln_backward(c, T.ln3, S.s2, dn, ds, M, T.inner, cp, true));
+    A.release(m2);
+  }
+  {  // s2 = out2(attn(q2(ln2(s1)), k2(enc), v2(enc))) + s1
+    const size_t m2 = A.mark();
+    const int Lp = c.Lp;
+    bf16_t* datt = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(datt);
+    CTTA_TRY(linear_dgrad(c, T.t_out2.d, ds, cp, cp, M, datt, hp, hp, false));
+    CTTA_TRY(linear_wgrad(c, T.t_out2.m, nullptr, S.att2, hp, M, ds, cp));
+    bf16_t* dq = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(dq);
+    const size_t kv = (size_t)c.B * Lp * hp;
+    bf16_t* dk = A.get<bf16_t>(kv); ALLOC_OR_FAIL(dk);
+    bf16_t* dv = A.get<bf16_t>(kv); ALLOC_OR_FAIL(dv);
+    if (!c.dry) {   // rows of padded text positions are never written by the per-head GEMMs
+      CTTA_CHECK_HIP(hipMemsetAsync(dk, 0, kv * sizeof(bf16_t), c.stream));
+      CTTA_CHECK_HIP(hipMemsetAsync(dv, 0, kv * sizeof(bf16_t), c.stream));
+    }
+    CTTA_TRY(bwd_attention(c, T.heads, T.dh, S.q2, hp, S.k2, hp, Lp, S.vt2, Lp, c.mask_bias, N, c.L, datt, hp, dq, hp, dk,
+                           hp, dv));
+    bf16_t* dn = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(dn);
+    CTTA_TRY(linear_dgrad(c, T.t_q2.d, dq, hp, hp, M, dn, cp, cp, false));
+    CTTA_TRY(linear_wgrad(c, T.t_q2.m, nullptr, S.n2, cp, M, dq, hp));
+    CTTA_TRY(linear_wgrad(c, T.t_k2.m, nullptr, c.enc_bf, c.U->xp, (int64_t)c.B * Lp, dk, hp));
+    CTTA_TRY(linear_wgrad(c, T.t_v2.m, nullptr, c.enc_bf, c.U->xp, (int64_t)c.B * Lp, dv, hp));
+    CTTA_TRY(ln_backward(c, T.ln2, S.s1, dn, ds, M, T.inner, cp, true));
+    A.release(m2);
+  }
+  {  // s1 = out1(attn(q1(n1), k1(n1), v1(n1))) + s0,  n1 = ln1(s0)
+    const size_t m2 = A.mark();
+    bf16_t* datt = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(datt);
+    CTTA_TRY(linear_dgrad(c, T.t_out1.d, ds, cp, cp, M, datt, hp, hp, false));
+    CTTA_TRY(linear_wgrad(c, T.t_out1.m, nullptr, S.att1, hp, M, ds, cp));
+    bf16_t* dqk = A.get<bf16_t>((size_t)M * 2 * hp); ALLOC_OR_FAIL(dqk);
+    bf16_t* dv = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(dv);
+    CTTA_TRY(bwd_attention(c, T.heads, T.dh, S.qk, 2 * hp, S.qk + hp, 2 * hp, N, S.vt, vt_ld, nullptr, N, N, datt, hp, dqk,
+                           2 * hp, dqk + hp, 2 * hp, dv));
+    bf16_t* dn = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(dn);
+    CTTA_TRY(linear_dgrad(c, T.t_q1.d, dqk, hp, 2 * hp, M, dn, cp, cp, false));
+    CTTA_TRY(linear_dgrad(c, T.t_k1.d, dqk + hp, hp, 2 * hp, M, dn, cp, cp, true));
+    CTTA_TRY(linear_dgrad(c, T.t_v1.d, dv, hp, hp, M, dn, cp, cp, true));
+    CTTA_TRY(linear_wgrad(c, T.t_q1.m, &T.t_k1.m, S.n1, cp, M, dqk, 2 * hp));
+    CTTA_TRY(linear_wgrad(c, T.t_v1.m, nullptr, S.n1, cp, M, dv, hp));
+    CTTA_TRY(ln_backward(c, T.ln1, S.s0, dn, ds, M, T.inner, cp, true));
+    A.release(m2);
+  }
+  // s0 = proj_in(gn(x))
+  bf16_t* dg = A.get<bf16_t>((size_t)M * T.c); ALLOC_OR_FAIL(dg);
+  CTTA_TRY(linear_dgrad(c, T.t_proj_in.d, ds, cp, cp, M, dg, T.c, T.c, false));
+  CTTA_TRY(linear_wgrad(c, T.t_proj_in.m, nullptr, S.g, T.c, M, ds, cp));
+  RUN(c, ctta_add_slices(dout, T.c, nullptr, 0, dx, T.c, M, T.c, c.stream));
+  CTTA_TRY(gn_backward(c, T.norm, S.x, dg, dx, N, S.st, false, true));
+  A.release(mk);
+  *dx_p = dx;
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ embeddings
+__global__ void add_rows_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n) {
+  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (i < n) dst[i] += src[i];
+}
+
+static ctta_status bwd_embeddings(BCtx& c) {
+  ctta_unet* U = c.U;
+  Arena& A = *c.arena;
+  const ctta_unet::TrainSaved& S = U->ts;
+  const int B = c.B, T = U->temb_dim, total = U->temb_total, c0 = U->cfg.block_out_channels[0];
+  // temb_all = Linear(SiLU(emb)) over the concatenated time_emb_proj table
+  float* dw = A.get<float>((size_t)total * T); ALLOC_OR_FAIL(dw);
+  float* db = A.get<float>((size_t)total); ALLOC_OR_FAIL(db);
+  float* demb = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(demb);
+  RUN(c, ctta_linear_f32_bwd(S.emb_silu, U->temb_w, c.dtemb_all, S.emb, demb, dw, db, B, total, T, 0, 0, c.stream));
+  auto scatter_res = [&](Resnet& R) -> ctta_status {
+    float *gw, *gb;
+    CTTA_TRY(grad_ptr(c, R.key + "time_emb_proj.weight", &gw));
+    CTTA_TRY(grad_ptr(c, R.key + "time_emb_proj.bias", &gb));
+    if (!c.dry) {
+      const long long n = (long long)R.cout * T;
+      hipLaunchKernelGGL(add_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, gw,
+                         dw + (size_t)R.temb_off * T, n);
+      hipLaunchKernelGGL(add_rows_f32_kernel, dim3((R.cout + 255) / 256), dim3(256), 0, c.stream, gb, db + R.temb_off,
+                         (long long)R.cout);
+      CTTA_LAUNCH_CHECK();
+    }
+    return CTTA_OK;
+  };
+  for (auto& Lv : U->down) for (auto& R : Lv.res) CTTA_TRY(scatter_res(R));
+  for (auto& Lv : U->up) for (auto& R : Lv.res) CTTA_TRY(scatter_res(R));
+  CTTA_TRY(scatter_res(U->mid_r0));
+  CTTA_TRY(scatter_res(U->mid_r1));
+  // emb = linear_2(SiLU(linear_1(feat)))  for the time (and guidance) branch; d emb feeds both
+  auto mlp = [&](const std::string& name, const float* feat, int k, const float* hpre, const float* hid, const float* w1,
+                 const float* w2) -> ctta_status {
+    float *gw1, *gb1, *gw2, *gb2;
+    CTTA_TRY(grad_ptr(c, name + "linear_1.weight", &gw1));
+    CTTA_TRY(grad_ptr(c, name + "linear_1.bias", &gb1));
+    CTTA_TRY(grad_ptr(c, name + "linear_2.weight", &gw2));
+    CTTA_TRY(grad_ptr(c, name + "linear_2.bias", &gb2));
+    float* dh = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(dh);
+    RUN(c, ctta_linear_f32_bwd(hid, w2, demb, hpre, dh, gw2, gb2, B, T, T, 0, 1, c.stream));
+    RUN(c, ctta_linear_f32_bwd(feat, w1, dh, nullptr, nullptr, gw1, gb1, B, T, k, 0, 1, c.stream));
+    return CTTA_OK;
+  };
+  CTTA_TRY(mlp("time_embedding.", S.tfeat, c0, S.t_h1pre, S.t_h1, U->t_w1, U->t_w2));
+  if (U->cfg.guided) CTTA_TRY(mlp("guidance_embedding.", S.gfeat, T, S.g_h1pre, S.g_h1, U->g_w1, U->g_w2));
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ whole network
+static ctta_status unet_backward_impl(ctta_unet* U, bool dry, const bf16_t* dpred, const GradTable* grads,
+                                      hipStream_t stream, size_t* gn_need) {
+  const ctta_unet_config& cfg = U->cfg;
+  const ctta_unet::TrainSaved& S = U->ts;
+  BCtx c;
+  c.arena = &U->arena; c.stream = stream; c.dry = dry; c.taps = nullptr;
+  c.gn_scratch = U->gn_scratch; c.gn_scratch_floats = U->gn_scratch_floats;
+  c.U = U; c.B = S.B; c.L = S.L; c.Lp = S.Lp; c.train = true;
+  c.enc_bf = S.enc_bf; c.mask_bias = S.mask_bias; c.grads = grads;
+  Arena& A = U->arena;
+  A.off = S.arena_off;
+  A.no_release = false;
+  const int B = S.B, H = cfg.height, W = cfg.width, c0 = cfg.block_out_channels[0];
+  c.dtemb_all = A.get<float>((size_t)B * U->temb_total); ALLOC_OR_FAIL(c.dtemb_all);
+  std::vector<bf16_t*> dskip((size_t)S.n_skips, nullptr);
+
+  // ---- conv_out, conv_norm_out
+  const size_t M0 = (size_t)B * H * W;
+  bf16_t* dh = A.get<bf16_t>(M0 * c0); ALLOC_OR_FAIL(dh);
+  {
+    const size_t mk = A.mark();
+    bf16_t* da = A.get<bf16_t>(M0 * c0); ALLOC_OR_FAIL(da);
+    CTTA_TRY(conv_dgrad(c, U->t_conv_out.d, dpred, H, W, da, H, W, false));
+    ConvLayer co;   // geometry of conv_out for the weight gradient (the forward runs it on the small-N kernel)
+    co.cin_pad = c0; co.cout = cfg.out_channels; co.kh = co.kw = 3; co.stride = 1; co.pad = 1; co.p.n = 8;
+    CTTA_TRY(conv_wgrad(c, co, U->t_conv_out.m, S.a_out, H, W, false, dpred));
+    CTTA_TRY(gn_backward(c, U->norm_out, S.h_last, da, dh, H * W, S.st_out, true, false));
+    A.release(mk);
+  }
+  // ---- the tape in reverse
+  for (size_t i = U->tape.size(); i-- > 0;) {
+    TapeOp& op = U->tape[i];
+    const size_t M = (size_t)B * op.H * op.W;
+    switch (op.kind) {
+      case TapeOp::RESNET: CTTA_TRY(bwd_resnet(c, *op.R, dh, &dh)); break;
+      case TapeOp::TRANSFORMER: CTTA_TRY(bwd_transformer(c, *op.T, dh, &dh)); break;
+      case TapeOp::UPSAMPLE: {   // y = conv(nearest_x2(x)): dx = 2x2 sum-pool of the conv data gradient
+        bf16_t* dx = A.get<bf16_t>(M * op.ch); ALLOC_OR_FAIL(dx);
+        const size_t mk = A.mark();
+        bf16_t* dup = A.get<bf16_t>(M * 4 * op.ch); ALLOC_OR_FAIL(dup);
+        CTTA_TRY(conv_dgrad(c, op.Lv->tsampler.d, dh, 2 * op.H, 2 * op.W, dup, 2 * op.H, 2 * op.W, false));
+        RUN(c, ctta_pool2_sum(dup, dx, B, op.H, op.W, op.ch, 0, stream));
+        CTTA_TRY(conv_wgrad(c, op.Lv->sampler, op.Lv->tsampler.m, op.x, op.H, op.W, true, dh));
+        A.release(mk);
+        dh = dx;
+        break;
+      }
+      case TapeOp::DOWNSAMPLE: {   // stride-2 conv: zero-insert dY, then a stride-1 data-gradient conv
+        bf16_t* dx = A.get<bf16_t>(M * op.ch); ALLOC_OR_FAIL(dx);
+        const size_t mk = A.mark();
+        const int ho = (op.H + 2 - 3) / 2 + 1, wo = (op.W + 2 - 3) / 2 + 1;
+        bf16_t* dz = A.get<bf16_t>(M * op.ch); ALLOC_OR_FAIL(dz);
+        RUN(c, ctta_zero_insert2(dh, dz, B, ho, wo, op.H, op.W, op.ch, stream));
+        CTTA_TRY(conv_dgrad(c, op.Lv->tsampler.d, dz, op.H, op.W, dx, op.H, op.W, false));
+        CTTA_TRY(conv_wgrad(c, op.Lv->sampler, op.Lv->tsampler.m, op.x, op.H, op.W, false, dh));
+        A.release(mk);
+        dh = dx;
+        break;
+      }
+      case TapeOp::CONCAT: {   // torch.cat([h, skip], 1): split the gradient
+        bf16_t* d0 = A.get<bf16_t>(M * op.ch); ALLOC_OR_FAIL(d0);
+        bf16_t* d1 = A.get<bf16_t>(M * op.skc); ALLOC_OR_FAIL(d1);
+        const int ld = op.ch + op.skc;
+        RUN(c, ctta_add_slices(dh, ld, nullptr, 0, d0, op.ch, (int64_t)M, op.ch, stream));
+        RUN(c, ctta_add_slices(dh + op.ch, ld, nullptr, 0, d1, op.skc, (int64_t)M, op.skc, stream));
+        dskip[op.skip_idx] = d1;
+        dh = d0;
+        break;
+      }
+      case TapeOp::SKIP_PUSH: {
+        bf16_t* ds = dskip[op.skip_idx];
+        CTTA_REQUIRE(ds, "internal: skip %d has no gradient", op.skip_idx);
+        RUN(c, ctta_add_slices(dh, op.ch, ds, op.ch, dh, op.ch, (int64_t)M, op.ch, stream));
+        break;
+      }
+      case TapeOp::CONV_IN:
+        CTTA_TRY(conv_wgrad(c, U->conv_in, U->t_conv_in.m, op.x, op.H, op.W, false, dh));
+        break;
+    }
+  }
+  CTTA_TRY(bwd_embeddings(c));
+  if (gn_need) *gn_need = c.gn_need;
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_unet_forward_train(ctta_unet* U, const float* sample, const float* timesteps,
+                                               const double* guidance, const float* enc, const uint8_t* mask, int batch,
+                                               int text_len, float* out, void* stream) {
+  CTTA_REQUIRE(U && sample && timesteps && enc && out, "unet_forward_train: null pointer");
+  CTTA_REQUIRE(U->cfg.enable_training, "unet_forward_train: handle was created without enable_training");
+  CTTA_REQUIRE(!U->cfg.guided || guidance, "unet_forward_train: guidance is required by the guided U-Net");
+  CTTA_REQUIRE(batch >= 1 && batch <= U->cfg.max_batch, "unet_forward_train: batch %d outside [1,%d]", batch, U->cfg.max_batch);
+  CTTA_REQUIRE(text_len >= 1 && text_len <= U->cfg.max_text_len, "unet_forward_train: text_len %d outside [1,%d]", text_len,
+               U->cfg.max_text_len);
+  return unet_forward_impl(U, false, sample, timesteps, guidance, enc, mask, batch, text_len, out, (hipStream_t)stream,
+                           nullptr, true);
+}
+
+extern "C" ctta_status ctta_unet_backward(ctta_unet* U, const void* dout_nhwc, const ctta_tensor* grads, int n_grads,
+                                          void* stream) {
+  CTTA_REQUIRE(U && dout_nhwc && grads, "unet_backward: null pointer");
+  CTTA_REQUIRE(U->cfg.enable_training, "unet_backward: handle was created without enable_training");
+  CTTA_REQUIRE(U->ts.valid, "unet_backward: no training forward to differentiate (call ctta_unet_forward_train first)");
+  GradTable gt;
+  gt.build(grads, n_grads);
+  const ctta_status st = unet_backward_impl(U, false, (const bf16_t*)dout_nhwc, &gt, (hipStream_t)stream, nullptr);
+  U->ts.valid = false;   // the saved activations have been overwritten by backward temporaries
+  return st;
+}

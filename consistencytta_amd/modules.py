@@ -64,7 +64,43 @@ class _ParamTree(nn.Module):
 
     def _weights_version(self):
         return sum(p._version for p in self.parameters()) + 1000003 * sum(
-            p.data_ptr() % 1000003 for p in self.parameters())
+            p.data_ptr() % 1000003 for p in self.parameters()) + 7 * getattr(self, "_manual_version", 0)
+
+    def mark_weights_changed(self):
+        """Call after parameters were updated through raw pointers (fused AdamW / EMA kernels)."""
+        self._manual_version = getattr(self, "_manual_version", 0) + 1
+
+    def flatten_parameters_(self):
+        """Re-homes every parameter into ONE contiguous fp32 buffer (views keep names/shapes), so the
+        optimizer, EMA and gradient all-reduce run as single launches over the whole model.
+        Returns the flat buffer; `flat_grad_()` gives the matching gradient buffer."""
+        params = list(self.parameters())
+        if getattr(self, "_flat", None) is not None and all(p.data_ptr() >= self._flat.data_ptr() for p in params):
+            return self._flat
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
+        off = 0
+        for p in params:
+            n = p.numel()
+            flat[off:off + n].copy_(p.data.reshape(-1))
+            p.data = flat[off:off + n].view(p.shape)
+            off += n
+        self._flat = flat
+        self._flat_grad = None
+        return flat
+
+    def flat_grad_(self):
+        """Flat fp32 gradient buffer aliased by every `p.grad` (zero-initialised on first use)."""
+        flat = self.flatten_parameters_()
+        if getattr(self, "_flat_grad", None) is None:
+            g = torch.zeros_like(flat)
+            off = 0
+            for p in self.parameters():
+                n = p.numel()
+                p.grad = g[off:off + n].view(p.shape)
+                off += n
+            self._flat_grad = g
+        return self._flat_grad
 
     def _table(self, prefix_filter=None, strip=""):
         sd = OrderedDict()
@@ -125,6 +161,7 @@ class _UNetBase(_ParamTree):
         self._h_key = None
         self._h_version = None
         self.debug_taps = False
+        self.enable_training = False   # True: the native handle also carries the backward pass
 
     # ---- config plumbing (configuration_utils.py:161,256)
     @classmethod
@@ -160,6 +197,7 @@ class _UNetBase(_ParamTree):
         c.guided = int(self._guided)
         c.max_batch, c.height, c.width, c.max_text_len = B, H, W, L
         c.debug_taps = int(self.debug_taps)
+        c.enable_training = int(self.enable_training)
         return c
 
     def _release(self):
@@ -177,7 +215,7 @@ class _UNetBase(_ParamTree):
         L_ = N.lib()
         key = self._h_key
         need_new = (self._h_unet is None or key is None or key[1:3] != (H, W) or B > key[0] or L > key[3]
-                    or key[4] != self.debug_taps or key[5] != self.device)
+                    or key[4] != (self.debug_taps, self.enable_training) or key[5] != self.device)
         ver = self._weights_version()
         if need_new:
             self._release()
@@ -188,7 +226,8 @@ class _UNetBase(_ParamTree):
             cfg = self._native_config(Bm, H, W, Lm)
             with torch.cuda.device(self.device):
                 N.check(L_.ctta_unet_create(cfg, table, len(table), N.stream_ptr(), h))
-            self._h_unet, self._h_key, self._h_version = h, (Bm, H, W, Lm, self.debug_taps, self.device), ver
+            self._h_unet, self._h_key, self._h_version = (
+                h, (Bm, H, W, Lm, (self.debug_taps, self.enable_training), self.device), ver)
         elif ver != self._h_version:  # parameters changed (optimizer / EMA / load_state_dict)
             table, keep = N.tensor_table(self._table())
             N.check(L_.ctta_unet_load_weights(self._h_unet, table, len(table), N.stream_ptr()))
@@ -204,7 +243,7 @@ class _UNetBase(_ParamTree):
             v = v[None]
         return v.expand(B).contiguous()
 
-    def _forward(self, sample, timestep, guidance, encoder_hidden_states, encoder_attention_mask):
+    def _forward(self, sample, timestep, guidance, encoder_hidden_states, encoder_attention_mask, train=False):
         if sample.ndim != 4 or sample.shape[1] != self._cfg["in_channels"]:
             raise ValueError("sample must be (batch, %d, height, width), got %s"
                              % (self._cfg["in_channels"], tuple(sample.shape)))
@@ -227,10 +266,42 @@ class _UNetBase(_ParamTree):
         if encoder_attention_mask is not None:
             m = encoder_attention_mask.to(device=dev).reshape(B, L).to(torch.uint8).contiguous()
         out = torch.empty((B, self._cfg["out_channels"], H, W), dtype=torch.float32, device=dev)
+        fn = N.lib().ctta_unet_forward_train if train else N.lib().ctta_unet_forward
         with torch.cuda.device(dev):
-            N.check(N.lib().ctta_unet_forward(self._h_unet, N.ptr(x), N.ptr(t), N.ptr(g), N.ptr(enc), N.ptr(m),
-                                              B, L, N.ptr(out), N.stream_ptr()))
+            N.check(fn(self._h_unet, N.ptr(x), N.ptr(t), N.ptr(g), N.ptr(enc), N.ptr(m), B, L, N.ptr(out),
+                       N.stream_ptr()))
         return out
+
+    # ---- distillation step: the reference differentiates `forward` with torch autograd
+    # (train.py:332-346); here the engine keeps the activations and runs its own backward pass.
+    def forward_train(self, sample, timestep, guidance, encoder_hidden_states, encoder_attention_mask=None):
+        """`forward` that keeps what `backward` needs.  Returns the prediction (B,C,H,W) fp32, detached."""
+        if not self.enable_training:
+            self.enable_training = True
+        return self._forward(sample, timestep, guidance if self._guided else None, encoder_hidden_states,
+                             encoder_attention_mask, train=True)
+
+    def backward(self, grad_output=None, grad_output_nhwc=None):
+        """Accumulates dL/d(param) of the last `forward_train` into `p.grad` (fp32, allocated on first
+        use).  `grad_output`: dL/d(prediction) (B,C,H,W) fp32, or `grad_output_nhwc`: the same as the
+        (B, H*W, 8) bf16 tensor ctta_snr_mse_grad writes."""
+        dev = self.device
+        if grad_output_nhwc is None:
+            B, C, H, W = grad_output.shape
+            g = torch.zeros(B, H * W, 8, dtype=torch.bfloat16, device=dev)
+            g[:, :, :C] = grad_output.detach().to(dev).permute(0, 2, 3, 1).reshape(B, H * W, C).to(torch.bfloat16)
+            grad_output_nhwc = g
+        table = OrderedDict()
+        for k, p in self.named_parameters():
+            if not p.requires_grad:
+                continue
+            if p.grad is None:
+                p.grad = torch.zeros_like(p.data)
+            table[k] = p.grad
+        tab, keep = N.tensor_table(table)
+        with torch.cuda.device(dev):
+            N.check(N.lib().ctta_unet_backward(self._h_unet, N.ptr(grad_output_nhwc.contiguous()), tab, len(tab),
+                                               N.stream_ptr()))
 
     def read_taps(self):
         """name -> NCHW fp32 tensor of every recorded intermediate (debug_taps=True only)."""

@@ -65,6 +65,8 @@ typedef struct {
   int guided;                               /* 1: guidance Fourier branch present */
   int max_batch, height, width, max_text_len; /* arena sizing */
   int debug_taps;                           /* 1: keep every named intermediate (tests) */
+  int enable_training;                      /* 1: also build the data-gradient packs and size the arena for
+                                               ctta_unet_forward_train + ctta_unet_backward */
 } ctta_unet_config;
 
 typedef struct ctta_unet ctta_unet;
@@ -81,6 +83,16 @@ ctta_status ctta_unet_forward(ctta_unet* h, const float* sample, const float* ti
                               const double* guidance, const float* enc, const uint8_t* mask,
                               int batch, int text_len, float* out, void* stream);
 size_t ctta_unet_arena_bytes(const ctta_unet* h);
+/* Distillation step (train.py:332-346: loss = model(...); accelerator.backward(loss)).
+ * forward_train = forward that keeps every activation the backward pass needs; backward takes
+ * dL/d(out) as NHWC bf16 [B][H*W][8] (ctta_snr_mse_grad writes exactly that) and ACCUMULATES
+ * dL/d(param) into `grads`: fp32 tensors with the names / shapes of the state dict (`.grad`
+ * semantics; guidance_proj.weight has requires_grad=False in the reference and gets none). */
+ctta_status ctta_unet_forward_train(ctta_unet* h, const float* sample, const float* timesteps,
+                                    const double* guidance, const float* enc, const uint8_t* mask,
+                                    int batch, int text_len, float* out, void* stream);
+ctta_status ctta_unet_backward(ctta_unet* h, const void* dout_nhwc, const ctta_tensor* grads,
+                               int n_grads, void* stream);
 /* Debug taps (only when cfg.debug_taps): named NCHW fp32 copies of intermediates. */
 int ctta_unet_num_taps(const ctta_unet* h);
 ctta_status ctta_unet_tap_info(const ctta_unet* h, int i, const char** name, int dims[4]);
@@ -316,10 +328,10 @@ ctta_status ctta_zero_insert2(const void* dy, void* dz, int batch, int ho, int w
                               void* stream);
 ctta_status ctta_pool2_sum(const void* dup, void* dx, int batch, int h, int w, int c, int accumulate,
                            void* stream);
-ctta_status ctta_softmax_bias_rows(const float* s, const float* bias, int rows_per_bias, void* p, int64_t rows,
-                                   int cols, int ldp, float scale, void* stream);
-ctta_status ctta_softmax_bwd_rows(const void* p, const float* dp, void* ds, int64_t rows, int cols, int ldp,
-                                  float scale, void* stream);
+ctta_status ctta_softmax_bias_rows(const float* s, int lds, const float* bias, int rows_per_bias, void* p,
+                                   int64_t rows, int cols, int ldp, float scale, void* stream);
+ctta_status ctta_softmax_bwd_rows(const void* p, const float* dp, int lddp, void* ds, int64_t rows, int cols,
+                                  int ldp, float scale, void* stream);
 ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const float* dy, const float* xpre_silu,
                                 float* dx, float* dw, float* db, int m, int n, int k, int accumulate_dx,
                                 int accumulate_param, void* stream);

@@ -180,9 +180,9 @@ def test_softmax_forward_bias_and_backward():
     st = N.stream_ptr()
     sd, bd, dpd = s.detach().to(DEV), bias.to(DEV), dp.to(DEV)
     pd = torch.empty(rows, ldp, dtype=torch.bfloat16, device=DEV)
-    N.check(L.ctta_softmax_bias_rows(N.ptr(sd), N.ptr(bd), rpb, N.ptr(pd), rows, cols, ldp, 0.14, st))
+    N.check(L.ctta_softmax_bias_rows(N.ptr(sd), cols, N.ptr(bd), rpb, N.ptr(pd), rows, cols, ldp, 0.14, st))
     ds = torch.empty(rows, ldp, dtype=torch.bfloat16, device=DEV)
-    N.check(L.ctta_softmax_bwd_rows(N.ptr(pd), N.ptr(dpd), N.ptr(ds), rows, cols, ldp, 0.14, st))
+    N.check(L.ctta_softmax_bwd_rows(N.ptr(pd), N.ptr(dpd), cols, N.ptr(ds), rows, cols, ldp, 0.14, st))
     sync()
     assert rel_err(pd.float().cpu()[:, :cols], p.detach()) < BF16_TOL
     assert float(pd.float().cpu()[:, cols:].abs().max()) == 0.0
