@@ -804,8 +804,9 @@ extern "C" ctta_status ctta_adamw_step(float* param, const float* grad, float* e
                                        float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                        float grad_scale, void* stream) {
   CTTA_REQUIRE(param && grad && exp_avg && exp_avg_sq && step >= 1, "adamw_step: bad arguments");
-  const float bc1 = 1.0f - powf(beta1, (float)step);
-  const float bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+  // bias corrections in double on the host, like torch's Python-float arithmetic (optim/adamw.py)
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
                      exp_avg_sq, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
   CTTA_LAUNCH_CHECK();

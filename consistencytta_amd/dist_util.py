@@ -53,6 +53,29 @@ def global_wav_extrema(local_max, local_min, device):
     return float(t[0]), -float(t[1])
 
 
+def allreduce_sum_(flat, bucket_elems=64 << 20):
+    """In-place SUM all-reduce of a flat gradient buffer in large buckets (default 256 MiB of fp32):
+    xGMI rings are per-link bound, so few big collectives beat many small ones; the buckets are issued
+    asynchronously back to back and waited for together.  The 1/world factor is folded into the
+    optimizer kernel (`FusedAdamW.step(grad_scale=1/world)`), saving a pass over the gradients.
+    No-op when torch.distributed is not initialised (single process)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 1
+    works = []
+    n = flat.numel()
+    for off in range(0, n, bucket_elems):
+        works.append(dist.all_reduce(flat[off:min(n, off + bucket_elems)], op=dist.ReduceOp.SUM, async_op=True))
+    for w in works:
+        w.wait()
+    return dist.get_world_size()
+
+
+def broadcast_(flat, src=0):
+    """Rank `src`'s parameters to every rank (what DDP does at wrap time)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(flat, src=src)
+
+
 def finish():
     if dist.is_initialized():
         dist.barrier()

@@ -8,10 +8,13 @@ fused CFG / loss / EMA kernels).  The FLAN-T5 text encoder stays a PyTorch modul
 reference (it is frozen and outside the hot path); because neither box has
 network access it can be injected (`text_encoder=`, `tokenizer=`) instead of downloaded.
 
-Round-1 scope: `inference` (student, multi-step, teacher Heun loop), `_query_teacher`,
-`update_ema`, and `forward` as a NO-GRAD evaluation of the distillation loss (training and
-validation modes).  The student backward pass / optimizer / RCCL gradient all-reduce
-(§8 a15, a20) are not built yet: `forward` returns a loss tensor without a graph.
+Scope: `inference` (student, multi-step, teacher Heun loop), `_query_teacher`, `update_ema`,
+`forward` (distillation loss; in training mode the returned loss carries a grad_fn whose backward
+runs the HIP engine's own backward pass and fills `student_unet` `.grad`s, so the reference loop
+`loss = model(...); loss.backward(); optimizer.step()` works unchanged on one GPU), and
+`train_step` = the fused multi-GPU step (backward, RCCL gradient all-reduce over the flat gradient
+buffer, fused AdamW, two-shadow EMA) that replaces accelerate's DDP wrapper (train.py:377-379),
+whose autograd hooks cannot see gradients produced outside autograd.
 """
 from copy import deepcopy
 from time import time
@@ -20,6 +23,7 @@ import torch
 from torch import nn
 
 from . import _native as N
+from . import dist_util
 from .modules import AutoencoderKL, UNet2DConditionGuidedModel, UNet2DConditionModel
 from .scheduler import HeunDiscreteScheduler
 
@@ -40,6 +44,19 @@ def do_ema_update(source_model, shadow_models, decay_consts):
         assert 0 <= d <= 1
         assert src.keys() == sh.keys()
     L_ = N.lib()
+    flats = [getattr(m, "_flat", None) for m in [source_model] + list(shadow_models)]
+    if all(f is not None and f.numel() == flats[0].numel() for f in flats):
+        # every network lives in one flat buffer with the same layout: one launch for the whole model
+        fa = flats[1]
+        fb = flats[2] if len(flats) > 2 else None
+        with torch.cuda.device(flats[0].device):
+            N.check(L_.ctta_ema_update2(N.ptr(flats[0]), N.ptr(fa), float(decay_consts[0]),
+                                        N.ptr(fb) if fb is not None else N.c_void_p(0),
+                                        float(decay_consts[1]) if fb is not None else 0.0, flats[0].numel(),
+                                        N.stream_ptr()))
+        for m in shadow_models:
+            m.mark_weights_changed()
+        return
     for name, p in src.items():
         a = shadows[0][name]
         b = shadows[1][name] if len(shadows) > 1 else None
@@ -52,6 +69,21 @@ def do_ema_update(source_model, shadow_models, decay_consts):
         a.detach().add_(0)
         if b is not None:
             b.detach().add_(0)
+
+
+class _DistillLoss(torch.autograd.Function):
+    """Gives the distillation loss a grad_fn: autograd's only job is to call the engine's backward."""
+
+    @staticmethod
+    def forward(ctx, anchor, loss, model, pred, target, sig, gamma):
+        ctx.model, ctx.saved = model, (pred, target, sig, gamma)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pred, target, sig, gamma = ctx.saved
+        ctx.model._student_backward(pred, target, sig, gamma, float(grad_out))
+        return (None,) * 7
 
 
 class AudioDistilledModel(nn.Module):
@@ -246,10 +278,70 @@ class AudioLCM(AudioDistilledModel):
                 assert sub in gkeys or not k.startswith(("teacher_unet", "student")), f"missing key {k}"
         return self.load_state_dict(new_sd, strict=False)
 
-    # ---- distillation loss (no-grad evaluation this round), audio_consistency_model.py:239-427
-    @torch.no_grad()
+    # ---- distillation loss, audio_consistency_model.py:239-427
     def forward(self, z_0, gt_wav, prompt, validation_mode=False, run_teacher=True, time_inds=None,
                 gaussian_noise=None, guidance_scale=None, **kwargs):
+        """Training mode (validation_mode == 0) with grad enabled: the loss has a grad_fn; `.backward()`
+        accumulates the student U-Net's parameter gradients through the engine's backward pass."""
+        want_grad = (not validation_mode and self.training and torch.is_grad_enabled()
+                     and any(p.requires_grad for p in self.student_unet.parameters()))
+        with torch.no_grad():
+            out = self._forward_impl(z_0, gt_wav, prompt, validation_mode, run_teacher, time_inds, gaussian_noise,
+                                     guidance_scale, want_grad)
+        if not want_grad:
+            return out
+        loss, pred, target, sig, gamma = out
+        return _DistillLoss.apply(self._grad_anchor(), loss, self, pred, target, sig, gamma)
+
+    def _grad_anchor(self):
+        a = getattr(self, "_anchor", None)
+        if a is None or a.device != self.device:
+            a = self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        return a
+
+    def _student_backward(self, pred, target, sig, gamma, loss_scale=1.0):
+        """d loss / d pred of get_loss (audio_consistency_model.py:250-266) -> engine backward."""
+        B, C, H, W = pred.shape
+        d = torch.empty(B, H * W, 8, dtype=torch.bfloat16, device=pred.device)
+        with torch.cuda.device(pred.device):
+            N.check(N.lib().ctta_snr_mse_grad(N.ptr(pred), N.ptr(target.contiguous()), N.ptr(sig), float(gamma),
+                                              float(loss_scale), B, C, H * W, 8, N.ptr(d), N.stream_ptr()))
+        self.student_unet.backward(grad_output_nhwc=d)
+
+    def prepare_training(self, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, broadcast=True):
+        """Flat parameter buffers for the student family, rank-0 weights on every rank (DDP's wrap-time
+        broadcast) and the fused AdamW over the student (tools/train_utils.py:59-63)."""
+        from .optim import FusedAdamW
+        self.student_unet.enable_training = True
+        for m in (self.student_unet, self.student_target_unet, self.student_ema_unet):
+            flat = m.flatten_parameters_()
+            if broadcast:
+                dist_util.broadcast_(flat)
+                m.mark_weights_changed()
+        return FusedAdamW(self.student_unet, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def train_step(self, z_0, prompt, optimizer, lr_scheduler=None, gt_wav=None, skip_nan=True, **fw):
+        """One optimisation step of tools/train_utils.py:150-190 (gradient_accumulation_steps=1):
+        loss -> backward -> gradient all-reduce (RCCL) -> AdamW -> lr schedule -> zero_grad -> EMA.
+        Returns the loss as a Python float (the reference reads `loss.item()` every step too)."""
+        assert self.training, "train_step needs model.train()"
+        with torch.no_grad():
+            loss, pred, target, sig, gamma = self._forward_impl(
+                z_0, gt_wav, prompt, False, True, fw.pop("time_inds", None), fw.pop("gaussian_noise", None),
+                fw.pop("guidance_scale", None), True)
+            self._student_backward(pred, target, sig, gamma, 1.0)
+            world = dist_util.allreduce_sum_(optimizer.grad[:optimizer.n])
+            value = float(loss.item())
+            if not (skip_nan and value != value):      # train_utils.py:167-172: a NaN loss skips the update
+                optimizer.step(grad_scale=1.0 / world)
+                if lr_scheduler is not None:
+                    lr_scheduler.step()
+            optimizer.zero_grad()
+            self.update_ema()
+        return value
+
+    def _forward_impl(self, z_0, gt_wav, prompt, validation_mode, run_teacher, time_inds, gaussian_noise,
+                      guidance_scale, want_grad):
         self.check_eval_mode()
         assert validation_mode >= 0
         sch = self.noise_scheduler
@@ -316,6 +408,10 @@ class AudioLCM(AudioDistilledModel):
             loss_teacher = mse(zhat_n, z_0)
             return loss_w_gt, loss_w_teacher, loss_consis, loss_teacher
         target = torch.where((t_n == 0).reshape(-1, 1, 1, 1).to(dev), z_0, target)
+        if want_grad:
+            pred = self.student_unet.forward_train(z_np1_scaled, t_np1, w, embeds, mask)
+            gamma = self.snr_gamma or 0.0
+            return mse(pred, target, sig, gamma), pred, target.contiguous(), sig, gamma
         pred = self.student_unet(z_np1_scaled, t_np1, guidance=w, encoder_hidden_states=embeds,
                                  encoder_attention_mask=mask).sample
         return mse(pred, target, sig, self.snr_gamma or 0.0)

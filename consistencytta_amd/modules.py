@@ -34,6 +34,7 @@ class _ParamTree(nn.Module):
     """Registers parameters under dotted reference key names (nested anonymous modules)."""
 
     def _register(self, table, frozen=()):
+        self._frozen_keys = tuple(frozen)
         for key, shape in table.items():
             mod = self
             parts = key.split(".")
@@ -74,9 +75,11 @@ class _ParamTree(nn.Module):
         """Re-homes every parameter into ONE contiguous fp32 buffer (views keep names/shapes), so the
         optimizer, EMA and gradient all-reduce run as single launches over the whole model.
         Returns the flat buffer; `flat_grad_()` gives the matching gradient buffer."""
-        params = list(self.parameters())
-        if getattr(self, "_flat", None) is not None and all(p.data_ptr() >= self._flat.data_ptr() for p in params):
-            return self._flat
+        params = self._flat_order()
+        flat0 = getattr(self, "_flat", None)
+        if flat0 is not None and all(
+                flat0.data_ptr() <= p.data_ptr() < flat0.data_ptr() + flat0.numel() * 4 for p in params):
+            return flat0
         total = sum(p.numel() for p in params)
         flat = torch.empty(total, dtype=torch.float32, device=params[0].device)
         off = 0
@@ -95,12 +98,24 @@ class _ParamTree(nn.Module):
         if getattr(self, "_flat_grad", None) is None:
             g = torch.zeros_like(flat)
             off = 0
-            for p in self.parameters():
+            for p in self._flat_order():
                 n = p.numel()
-                p.grad = g[off:off + n].view(p.shape)
+                if p.requires_grad:
+                    p.grad = g[off:off + n].view(p.shape)
                 off += n
             self._flat_grad = g
         return self._flat_grad
+
+    def _flat_order(self):
+        """Trainable parameters first (state-dict order), frozen ones last, so optimizer / all-reduce
+        kernels cover exactly the prefix `[0, n_trainable())` of the flat buffers."""
+        frozen = set(getattr(self, "_frozen_keys", ()))
+        named = list(self.named_parameters())
+        return [p for k, p in named if k not in frozen] + [p for k, p in named if k in frozen]
+
+    def n_trainable(self):
+        frozen = set(getattr(self, "_frozen_keys", ()))
+        return sum(p.numel() for k, p in self.named_parameters() if k not in frozen)
 
     def _table(self, prefix_filter=None, strip=""):
         sd = OrderedDict()
@@ -128,7 +143,7 @@ class _ParamTree(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k.startswith("_h_") else copy.deepcopy(v, memo)
+            new.__dict__[k] = None if k.startswith(("_h_", "_flat")) else copy.deepcopy(v, memo)
         return new
 
 

@@ -1,0 +1,86 @@
+"""Optimizer of the distillation step: torch.optim.AdamW semantics (tools/train_utils.py:59-63) as ONE
+fused launch over the student's flat parameter / gradient / moment buffers, plus the constant-with-
+warmup / linear schedules the reference builds with transformers.get_scheduler (train_utils.py:77-81).
+"""
+import math
+
+import torch
+
+from . import _native as N
+
+
+class FusedAdamW:
+    """AdamW over a `_ParamTree` whose parameters were re-homed into one flat fp32 buffer.
+
+    The trainable prefix of the flat buffers is updated by `ctta_adamw_step` (decoupled weight decay,
+    bias correction by step count, no amsgrad); frozen parameters (guidance_proj.weight) are never
+    touched, exactly as torch skips parameters without a gradient."""
+
+    def __init__(self, module, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.module = module
+        self.flat = module.flatten_parameters_()
+        self.grad = module.flat_grad_()
+        self.n = module.n_trainable()
+        self.exp_avg = torch.zeros(self.n, dtype=torch.float32, device=self.flat.device)
+        self.exp_avg_sq = torch.zeros(self.n, dtype=torch.float32, device=self.flat.device)
+        self.param_groups = [dict(lr=float(lr), betas=tuple(betas), eps=float(eps), weight_decay=float(weight_decay))]
+        self.step_count = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.grad.zero_()
+
+    def step(self, grad_scale=1.0):
+        """One update; `grad_scale` multiplies the gradient inside the kernel (1/world_size after a
+        SUM all-reduce, 1/accumulation_steps, ...)."""
+        g = self.param_groups[0]
+        self.step_count += 1
+        with torch.cuda.device(self.flat.device):
+            N.check(N.lib().ctta_adamw_step(N.ptr(self.flat), N.ptr(self.grad), N.ptr(self.exp_avg),
+                                            N.ptr(self.exp_avg_sq), self.n, g["lr"], g["betas"][0], g["betas"][1],
+                                            g["eps"], g["weight_decay"], self.step_count, float(grad_scale),
+                                            N.stream_ptr()))
+        self.module.mark_weights_changed()
+
+    # checkpoint / resume (accelerator.save_state stores the optimizer state, train.py:497-505)
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "param_groups": [dict(g) for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.exp_avg.copy_(sd["exp_avg"])
+        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.param_groups = [dict(g) for g in sd["param_groups"]]
+
+
+class WarmupSchedule:
+    """transformers.get_scheduler('linear' | 'constant' | 'constant_with_warmup') on a FusedAdamW."""
+
+    def __init__(self, optimizer, name="linear", num_warmup_steps=0, num_training_steps=None):
+        if name not in ("linear", "constant", "constant_with_warmup"):
+            raise ValueError("lr schedule '%s' is not built (linear, constant, constant_with_warmup)" % name)
+        if name == "linear" and not num_training_steps:
+            raise ValueError("linear schedule needs num_training_steps")
+        self.opt, self.name, self.warm, self.total = optimizer, name, int(num_warmup_steps), num_training_steps
+        self.base_lr = optimizer.param_groups[0]["lr"]
+        self.last_step = 0
+        self._apply()
+
+    def _factor(self, s):
+        if self.name == "constant":
+            return 1.0
+        if s < self.warm:
+            return float(s) / float(max(1, self.warm))
+        if self.name == "constant_with_warmup":
+            return 1.0
+        return max(0.0, float(self.total - s) / float(max(1, self.total - self.warm)))
+
+    def _apply(self):
+        self.opt.param_groups[0]["lr"] = self.base_lr * self._factor(self.last_step)
+
+    def step(self):
+        self.last_step += 1
+        self._apply()
+
+    def get_last_lr(self):
+        return [self.opt.param_groups[0]["lr"]]

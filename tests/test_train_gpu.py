@@ -95,3 +95,125 @@ def test_backward_requires_a_training_forward():
     from consistencytta_amd import _native as N
     with pytest.raises(N.CttaError, match="no training forward"):
         m.backward(torch.zeros(1, cfg["out_channels"], 16, 8))
+
+
+# ------------------------------------------------------------------------------------------------
+# The whole distillation step (SURVEY §8 a15 + a18 + a20): loss with a grad_fn, fused AdamW, EMA.
+def _lcm():
+    from consistencytta_amd.models import AudioLCM
+    cfg = cases.TINY_UNET
+    m = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                 unet_model_config_path="tiny_light.json", unet_config=cfg, snr_gamma=5.0, use_edm=True,
+                 teacher_guidance_scale=-1, num_diffusion_steps=18, vae=None, loss_type="mse",
+                 target_ema_decay=0.95, ema_decay=0.999)
+    m.teacher_unet.load_state_dict(cases.unet_weights(cfg, False, 0))
+    m.student_unet.load_state_dict(cases.unet_weights(cfg, True, 1))
+    m.student_target_unet.load_state_dict(cases.unet_weights(cfg, True, 2))
+    m.student_ema_unet.load_state_dict(cases.unet_weights(cfg, True, 3))
+    m.to(DEV)
+    P = {k: v.to(DEV) for k, v in cases.prompt_states(cfg, 3, 6, "distill").items()}
+    z0 = (cases.t(spec.det_uniform("distill.z0", (3, 8, 32, 8), 14)) * 0.9).to(DEV)
+    return m, P, z0
+
+
+def _oracle_distill_grads(g):
+    """torch autograd through oracle.distill.distill_loss w.r.t. the student's parameters, with the
+    reference's recorded random draws (the fixture made by the reference's own AudioLCM.forward)."""
+    from oracle import distill
+    cfg = cases.TINY_UNET
+    student = {k: v.clone().requires_grad_(k != "guidance_proj.weight") for k, v in cases.unet_weights(cfg, True, 1).items()}
+    n = distill.Nets(cfg, cases.unet_weights(cfg, False, 0), student, cases.unet_weights(cfg, True, 2),
+                     cases.unet_weights(cfg, True, 3))
+    P = cases.prompt_states(cfg, 3, 6, "distill")
+    z0 = cases.t(spec.det_uniform("distill.z0", (3, 8, 32, 8), 14)) * 0.9
+    noise, inds, w = torch.from_numpy(g["noise"]), torch.from_numpy(g["time_inds"]) * 2, torch.from_numpy(g["guidance"])
+    with torch.no_grad():   # teacher / target side carries no gradient (audio_consistency_model.py:314-351)
+        ts, sig = distill._tables()
+        z_np1_scaled, t_np1, zhat, zhat_scaled, t_n, s_np1 = distill._teacher_two_queries(n, P, z0, noise, inds, w, ts, sig)
+        target = onets.unet_forward(cfg, n.target, zhat_scaled, t_n, w, P["embeds"], P["mask"])
+        target = torch.where((t_n == 0).reshape(-1, 1, 1, 1), z0, target)
+    from oracle import heun
+    pred = onets.unet_forward(cfg, student, z_np1_scaled, t_np1, w, P["embeds"], P["mask"])
+    loss = heun.snr_mse_loss(pred, target, s_np1, 5.0)
+    loss.backward()
+    return float(loss), {k: p.grad for k, p in student.items() if p.requires_grad}
+
+
+def test_distillation_loss_backward_matches_oracle_autograd(golden):
+    g = golden("distill_tiny")
+    ref_loss, ref = _oracle_distill_grads(g)
+    assert abs(ref_loss - float(g["train_loss"])) <= 2e-4 * ref_loss     # oracle == reference's own forward
+    m, P, z0 = _lcm()
+    m.train()
+    loss = m(z0, None, P, time_inds=torch.from_numpy(g["time_inds"]) * 2,
+             gaussian_noise=torch.from_numpy(g["noise"]).to(DEV), guidance_scale=torch.from_numpy(g["guidance"]))
+    assert loss.requires_grad and loss.grad_fn is not None
+    assert abs(float(loss) - ref_loss) <= 5e-2 * ref_loss
+    loss.backward()                                          # accelerator.backward(loss), train_utils.py:166
+    torch.cuda.synchronize()
+    grads = {k: p.grad for k, p in m.student_unet.named_parameters() if p.requires_grad}
+    total, worst = _compare(grads, ref)
+    # the student's input differs from the oracle's by the teacher's bf16 error too: a slightly wider budget
+    assert np.isfinite(total) and total <= 1.5 * GRAD_REL_L2_ALL
+    for name in ("teacher_unet", "student_target_unet", "student_ema_unet"):
+        assert all(p.grad is None for p in getattr(m, name).parameters())
+    # eval / no_grad calls stay graph-free
+    with torch.no_grad():
+        l2 = m(z0, None, P, time_inds=torch.from_numpy(g["time_inds"]) * 2,
+               gaussian_noise=torch.from_numpy(g["noise"]).to(DEV), guidance_scale=torch.from_numpy(g["guidance"]))
+    assert not l2.requires_grad
+
+
+def test_train_step_adamw_and_ema_match_torch(golden):
+    """train_step = backward + fused AdamW + lr schedule + two-shadow EMA.  Given the gradients the
+    engine produced, the parameter update must equal torch.optim.AdamW's and the shadows the
+    reference's do_ema_update (tools/train_utils.py:255-282), to fp32 round-off."""
+    from consistencytta_amd.optim import WarmupSchedule
+    g = golden("distill_tiny")
+    m, P, z0 = _lcm()
+    m.train()
+    opt = m.prepare_training(lr=1e-3, weight_decay=1e-2, broadcast=False)
+    sched = WarmupSchedule(opt, "linear", num_warmup_steps=2, num_training_steps=10)
+    # shadow copies on the CPU driven by torch's own optimizer
+    cpu = {k: p.detach().cpu().clone().requires_grad_(p.requires_grad) for k, p in m.student_unet.named_parameters()}
+    topt = torch.optim.AdamW([p for p in cpu.values() if p.requires_grad], lr=1e-3, betas=(0.9, 0.999), weight_decay=1e-2,
+                             eps=1e-8)
+    tsched = torch.optim.lr_scheduler.LambdaLR(topt, sched._factor)
+    tgt = {k: p.detach().cpu().clone() for k, p in m.student_target_unet.named_parameters()}
+    ema = {k: p.detach().cpu().clone() for k, p in m.student_ema_unet.named_parameters()}
+    kw = dict(time_inds=torch.from_numpy(g["time_inds"]) * 2, gaussian_noise=torch.from_numpy(g["noise"]).to(DEV),
+              guidance_scale=torch.from_numpy(g["guidance"]))
+    for it in range(3):
+        # the engine's gradients for this step, captured through the autograd-compatible path
+        loss = m(z0, None, P, **kw)
+        loss.backward()
+        torch.cuda.synchronize()
+        for k, p in m.student_unet.named_parameters():
+            if p.requires_grad:
+                cpu[k].grad = p.grad.detach().cpu().clone()
+        opt.zero_grad()
+        value = m.train_step(z0, P, opt, sched, **kw)
+        assert abs(value - float(loss)) <= 1e-6 * abs(value) + 1e-9
+        topt.step()
+        tsched.step()
+        with torch.no_grad():
+            for k in tgt:
+                tgt[k] += np.float32(1. - 0.95) * (cpu[k].detach() - tgt[k])
+                ema[k] += np.float32(1. - 0.999) * (cpu[k].detach() - ema[k])
+        torch.cuda.synchronize()
+        worst = 0.0
+        for k, p in m.student_unet.named_parameters():
+            d = float((p.detach().cpu() - cpu[k].detach()).abs().max())
+            worst = max(worst, d / (float(cpu[k].detach().abs().max()) + 1e-12))
+        print("step %d: loss %.6f  max relative parameter difference vs torch.optim.AdamW %.3e" % (it, value, worst))
+        assert worst <= 2e-5          # deterministic engine -> same gradients in both passes; fp32 update round-off
+        for name, refsd in (("student_target_unet", tgt), ("student_ema_unet", ema)):
+            for k, p in getattr(m, name).named_parameters():
+                assert float((p.detach().cpu() - refsd[k]).abs().max()) <= 1e-6 * (1 + float(refsd[k].abs().max())), (name, k)
+        assert abs(opt.param_groups[0]["lr"] - topt.param_groups[0]["lr"]) < 1e-12
+        assert float(opt.grad.abs().max()) == 0.0            # zero_grad
+    # frozen Fourier projection never moves (embeddings.py:229)
+    k = "guidance_proj.weight"
+    assert torch.equal(m.student_unet.get_parameter(k).detach().cpu(), cases.unet_weights(cases.TINY_UNET, True, 1)[k])
+    # the engines picked the new weights up: the next loss differs from the first one
+    assert abs(m.train_step(z0, P, opt, sched, **kw) - float(g["train_loss"])) > 1e-6
