@@ -45,12 +45,17 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=("both", "gen", "distill"), default="both",
+                    help="gen: configs[1] only; distill: configs[3] leg only (value stays the generation metric)")
+    ap.add_argument("--distill-batch", type=int, default=9, help="per-GPU micro-batch of the distillation leg (train.sh)")
     ap.add_argument("--profile-csv", default=None, help="append one line per MFMA launch (tuning aid)")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    if args.mode == "distill":
+        args.no_cpu_baseline = True
     import torch
 
     from consistencytta_amd import _native as N
@@ -178,8 +183,112 @@ def main():
 
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(pipe, vae, enc, mask, noise)
+    if args.mode != "gen":
+        del pipe, vae
+        state.clear()
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        d = distill_leg(args, dev, world, rank)
+        if rank == 0:
+            result["distill"] = d
+    if rank == 0:
         print(json.dumps(result), flush=True)
     du.finish()
+
+
+GF_DISTILL_PER_SAMPLE = 4200.0   # 4 teacher + 1 target + 1 student fwd + 1 student bwd (~2 fwd)
+
+
+def distill_leg(args, dev, world, rank):
+    """BASELINE.json configs[3] (SURVEY.md §8d "Config 4"): one consistency-distillation optimisation step
+    per GPU micro-batch of 9 latents -- 2 CFG teacher queries (batch 18 each) + Heun, target-network
+    forward, student forward + backward, SUM all-reduce of the 559 M fp32 gradients over RCCL, fused
+    AdamW (lr 1e-5, wd 1e-4), two-shadow EMA (0.95 / 0.999).  All four U-Nets use the light config and
+    random-init weights; z0 ~ N(0,1)*0.9, text states as in the generation leg.  Weak scaling: the
+    per-GPU batch is fixed, every rank takes the same number of optimizer steps."""
+    import torch
+
+    from consistencytta_amd import _native as N
+    from consistencytta_amd import dist_util as du
+    from consistencytta_amd import spec
+    from consistencytta_amd.models import AudioLCM
+    from consistencytta_amd.optim import WarmupSchedule
+
+    B, L = args.distill_batch, args.text_len
+    t_build = time.perf_counter()
+    m = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                 unet_model_config_path="tango_diffusion_light.json", unet_config=spec.LIGHT_UNET_CONFIG, snr_gamma=5.0,
+                 use_edm=True, teacher_guidance_scale=-1, num_diffusion_steps=18, vae=None, loss_type="mse",
+                 target_ema_decay=0.95, ema_decay=0.999)
+    m.to(dev)
+    m.teacher_unet.init_random_(seed=10)
+    m.student_unet.init_random_(seed=11)
+    with torch.no_grad():   # load_state_dict_from_tango starts target / EMA from the student's weights
+        for dst in (m.student_target_unet, m.student_ema_unet):
+            for p, q in zip(dst.parameters(), m.student_unet.parameters()):
+                p.copy_(q)
+    m.train()
+    opt = m.prepare_training(lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-4, broadcast=True)
+    sched = WarmupSchedule(opt, "linear", num_warmup_steps=1000, num_training_steps=100000)
+    g = torch.Generator(device="cpu").manual_seed(5 + rank)
+    z0 = (torch.randn(B, 8, 256, 16, generator=g) * 0.9).to(dev)
+    enc = (torch.randn(B, L, 1024, generator=g) * 0.25).to(dev)
+    lens = torch.randint(6, L + 1, (B,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(dev)
+    unc = torch.zeros_like(enc)
+    umask = torch.zeros_like(mask)
+    umask[:, 0] = True
+    P = {"embeds_cf": torch.cat([unc, enc]), "mask_cf": torch.cat([umask, mask]), "embeds": enc, "mask": mask}
+    torch.manual_seed(100 + rank)       # per-rank timestep / guidance / noise streams
+    build_s = time.perf_counter() - t_build
+
+    losses = []
+    for _ in range(max(1, args.warmup)):
+        losses.append(m.train_step(z0, P, opt, sched))
+    du.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        losses.append(m.train_step(z0, P, opt, sched))
+    du.barrier(dev)
+    dt = du.max_over_ranks(time.perf_counter() - t0, dev)
+    assert all(v == v for v in losses), "NaN distillation loss"
+    out = {
+        "metric": "distillation_steps_per_sec", "value": round(args.steps / dt, 4), "unit": "optimizer steps/s",
+        "samples_per_s": round(world * B * args.steps / dt, 3), "ms_per_step": round(dt / args.steps * 1e3, 3),
+        "n_gpus": world, "scaling": "weak", "dtype": "bf16 (fp32 master weights, gradients, AdamW moments)",
+        "config": {"workload": "configs[3]: consistency distillation step, light U-Net x4 (teacher, student, target, EMA), "
+                               "2 CFG teacher queries + Heun, SNR-MSE loss, backward, AdamW, EMA 0.95/0.999",
+                   "batch_per_gpu": B, "global_batch": B * world, "text_len": L, "latent": [8, 256, 16],
+                   "grad_accum": 1, "gradient_allreduce": "fp32 SUM over RCCL, %d MiB buckets" % 256 if world > 1 else "none (1 GPU)",
+                   "parallelism": "dp%d" % world},
+        "loss_first_last": [round(losses[0], 6), round(losses[-1], 6)], "build_s": round(build_s, 1),
+    }
+    if rank == 0:
+        import ctypes
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        L_ = N.lib()
+        L_.ctta_prof_enable(1)
+        ev[0].record()
+        m.train_step(z0, P, opt, sched)
+        ev[1].record()
+        torch.cuda.synchronize()
+        L_.ctta_prof_enable(0)
+        ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        csv = (args.profile_csv + ".distill").encode() if args.profile_csv else None
+        N.check(L_.ctta_prof_collect(0, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt), csv))
+        algo = GF_DISTILL_PER_SAMPLE * 1e9 * B
+        out["roofline"] = {
+            "kernel": "conv_gemm_kernel (forward, data-gradient, weight-gradient and attention-backward GEMMs)",
+            "bound": "mfma", "achieved": round(algo / (ms.value * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(algo / (ms.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "algorithmic_gflop_per_sample": GF_DISTILL_PER_SAMPLE, "launches_per_step": int(cnt.value),
+            "kernel_ms_per_step": round(ms.value, 3),
+            "executed_tflops_incl_padding": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
+            "share_of_step_time": round(ms.value / ev[0].elapsed_time(ev[1]), 3),
+        }
+    del m, opt
+    return out
 
 
 def host_cores():
