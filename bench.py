@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("both", "gen", "distill"), default="both",
-                    help="gen: configs[1] only; distill: configs[3] leg only (value stays the generation metric)")
+                    help="both (default): configs[1] generation line + a `distill` object for configs[3]; "
+                         "gen / distill: only that leg (profiling aids)")
     ap.add_argument("--distill-batch", type=int, default=9, help="per-GPU micro-batch of the distillation leg (train.sh)")
     ap.add_argument("--profile-csv", default=None, help="append one line per MFMA launch (tuning aid)")
     return ap.parse_args()
@@ -70,7 +71,15 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    du.init("nccl", dev)   # "nccl" is RCCL on ROCm; only used for the timing barrier / max-reduce
+    du.init("nccl", dev)   # "nccl" is RCCL on ROCm: timing barrier / max-reduce, gradient all-reduce of the distill leg
+    if args.mode == "distill":   # profiling aid: only the distillation leg, printed as the JSON line
+        d = distill_leg(args, dev, world, rank)
+        if rank == 0:
+            d.update({"steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+                      "data": "synthetic"})
+            print(json.dumps(d), flush=True)
+        du.finish()
+        return
 
     B, L = args.batch, args.text_len
     # ---- models: light U-Net + AudioLDM-s VAE/vocoder architecture, random init (no checkpoints offline)

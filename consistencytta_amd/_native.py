@@ -81,6 +81,8 @@ SIGNATURES = {
     "ctta_unet_destroy": (None, [c_void_p]),
     "ctta_unet_load_weights": (c_int, [c_void_p, POINTER(Tensor), c_int, c_void_p]),
     "ctta_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_pack_weight_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "ctta_copy_segments_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "ctta_unet_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ctta_unet_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ctta_unet_arena_bytes": (c_size_t, [c_void_p]),

@@ -65,7 +65,9 @@ extern "C" ctta_status ctta_transpose_bf16(const void* src, int64_t src_group_st
   return CTTA_OK;
 }
 
-// Q[(t*C + c)][m] = X[pixel(m, tap t)][c] (0 outside the image), m = (b, oh, ow); rows padded to m_pad.
+// Q[(c*T + t)][m] = X[pixel(m, tap t)][c] (0 outside the image), m = (b, oh, ow), T = kh*kw taps; rows padded
+// to m_pad.  Channel-major rows = the (cin, kh, kw) order of a conv weight row, so the weight-gradient slab
+// scatters back with an identity column map.
 struct Im2colParams {
   const bf16_t* x; int C, B, hi, wi, hs, ws, ups, ho, wo, kh, kw, sh, sw, ph, pw, dh, dw, M, m_pad;
   bf16_t* dst;
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(Im2colParams p) {
       uint32_t w[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[rr + 2 * e][c] | ((uint32_t)tile[rr + 2 * e + 1][c] << 16);
-      *reinterpret_cast<uint4*>(p.dst + ((size_t)t * p.C + c0 + c) * p.m_pad + m0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
+      *reinterpret_cast<uint4*>(p.dst + ((size_t)(c0 + c) * (p.kh * p.kw) + t) * p.m_pad + m0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
     }
   }
 }
@@ -162,6 +164,40 @@ __global__ void wgrad_scatter_kernel(const float* __restrict__ slabs, int S, lon
     *g = accumulate ? *g + v : v;
   }
 }
+// Same contraction for the common case (no aux maps), tiled through LDS so that BOTH sides are coalesced:
+// the slab is read along n, the gradient is written along k (a weight row is k-contiguous in the state dict).
+// col_off == NULL means the identity map.
+__global__ __launch_bounds__(256) void wgrad_scatter_tiled_kernel(const float* __restrict__ slabs, int S,
+                                                                  long long slab_stride, int ldn, int k_rows, int n_cols,
+                                                                  const int* __restrict__ row_off,
+                                                                  const int* __restrict__ col_off,
+                                                                  float* __restrict__ grad, int accumulate) {
+  __shared__ float tile[64][65];
+  const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int idx = tid + i * 256;
+    const int kk = idx >> 6, nn = idx & 63;
+    float v = 0.f;
+    if (k0 + kk < k_rows && n0 + nn < n_cols) {
+      const float* p = slabs + (size_t)(k0 + kk) * ldn + n0 + nn;
+      for (int s = 0; s < S; ++s) v += p[(size_t)s * slab_stride];
+    }
+    tile[kk][nn] = v;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = 0; i < 16; ++i) {
+    const int idx = tid + i * 256;
+    const int nn = idx >> 6, kk = idx & 63;
+    if (k0 + kk >= k_rows || n0 + nn >= n_cols) continue;
+    const int ro = row_off[n0 + nn];
+    const int co = col_off ? col_off[k0 + kk] : k0 + kk;
+    if (ro < 0 || co < 0) continue;
+    float* g = grad + (size_t)ro + (size_t)co;
+    *g = accumulate ? *g + tile[kk][nn] : tile[kk][nn];
+  }
+}
 // vector grad (bias / per-sample rows): dst[idx[n]] (+)= sum_s slab[s][row][n]  (idx[n] < 0 skipped; idx NULL = identity)
 __global__ void row_scatter_kernel(const float* __restrict__ slabs, int S, long long slab_stride, int ldn, int row,
                                    int n_cols, const int* __restrict__ idx, float* __restrict__ dst, int accumulate) {
@@ -178,7 +214,14 @@ extern "C" ctta_status ctta_wgrad_scatter(const float* slabs, int n_slabs, int64
                                           int n_cols, const int32_t* row_off, const int32_t* col_off,
                                           const int32_t* row_aux, const int32_t* col_aux, int aux_limit, float* grad,
                                           int accumulate, void* stream) {
-  CTTA_REQUIRE(slabs && row_off && col_off && grad && n_slabs >= 1, "wgrad_scatter: bad arguments");
+  CTTA_REQUIRE(slabs && row_off && grad && n_slabs >= 1 && (col_off || aux_limit <= 0), "wgrad_scatter: bad arguments");
+  if (aux_limit <= 0) {
+    hipLaunchKernelGGL(wgrad_scatter_tiled_kernel, dim3((k_rows + 63) / 64, (n_cols + 63) / 64), dim3(256), 0,
+                       (hipStream_t)stream, slabs, n_slabs, (long long)slab_stride, ldn, k_rows, n_cols, row_off, col_off,
+                       grad, accumulate);
+    CTTA_LAUNCH_CHECK();
+    return CTTA_OK;
+  }
   const long long total = (long long)k_rows * n_cols;
   hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs,
                      (long long)slab_stride, ldn, k_rows, n_cols, row_off, col_off, row_aux, col_aux, aux_limit, grad,
@@ -703,20 +746,26 @@ extern "C" ctta_status ctta_softmax_bwd_rows(const void* p, const float* dp, int
 // ------------------------------------------------------------------------------ fp32 embedding-MLP backward
 // y = x W^T + b (W [N][K]);  given dy [M][N]:  dx[m][k] = sum_n dy[m][n] W[n][k] (* silu'(xpre) when xpre given),
 // dW[n][k] (+)= sum_m dy[m][n] x[m][k], db[n] (+)= sum_m dy[m][n]
-__global__ void linear_f32_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                         const float* __restrict__ xpre, float* __restrict__ dx, int M, int N, int K,
-                                         int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= M * K) return;
-  const int m = i / K, k = i - m * K;
+// grid (K/64, M, n-chunks): 64 k-columns x 4 n-lanes per block, partial sums land with one atomicAdd per (m, k)
+__global__ __launch_bounds__(256) void linear_f32_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                                float* __restrict__ dx, int N, int K, int n_chunk) {
+  __shared__ float red[4][64];
+  const int kk = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + kk, m = blockIdx.y;
+  const int n0 = blockIdx.z * n_chunk, n1 = min(N, n0 + n_chunk);
   float acc = 0.f;
-  for (int n = 0; n < N; ++n) acc += dy[(size_t)m * N + n] * w[(size_t)n * K + k];
-  if (xpre) {
-    const float z = xpre[i];
-    const float s = 1.0f / (1.0f + expf(-z));
-    acc *= s * (1.0f + z * (1.0f - s));
-  }
-  dx[i] = accumulate ? dx[i] + acc : acc;
+  if (k < K)
+    for (int n = n0 + part; n < n1; n += 4) acc += dy[(size_t)m * N + n] * w[(size_t)n * K + k];
+  red[part][kk] = acc;
+  __syncthreads();
+  if (part == 0 && k < K) atomicAdd(&dx[(size_t)m * K + k], red[0][kk] + red[1][kk] + red[2][kk] + red[3][kk]);
+}
+__global__ void silu_grad_scale_kernel(float* __restrict__ dx, const float* __restrict__ xpre, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float z = xpre[i];
+  const float s = 1.0f / (1.0f + expf(-z));
+  dx[i] *= s * (1.0f + z * (1.0f - s));
 }
 __global__ void linear_f32_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                          float* __restrict__ dw, float* __restrict__ db, int M, int N, int K,
@@ -739,9 +788,17 @@ extern "C" ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const
   CTTA_REQUIRE(x && w && dy, "linear_f32_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
   if (dx) {
-    hipLaunchKernelGGL(linear_f32_bwd_dx_kernel, dim3((m * k + 255) / 256), dim3(256), 0, s, dy, w, xpre_silu, dx, m, n, k,
-                       accumulate_dx);
+    CTTA_REQUIRE(!(accumulate_dx && xpre_silu), "linear_f32_bwd: accumulate_dx with a SiLU pre-activation is not supported");
+    if (!accumulate_dx) CTTA_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)m * k * sizeof(float), s));
+    int chunks = (n + 255) / 256;
+    if (chunks > 64) chunks = 64;
+    const int n_chunk = (n + chunks - 1) / chunks;
+    hipLaunchKernelGGL(linear_f32_bwd_dx_kernel, dim3((k + 63) / 64, m, chunks), dim3(256), 0, s, dy, w, dx, n, k, n_chunk);
     CTTA_LAUNCH_CHECK();
+    if (xpre_silu) {
+      hipLaunchKernelGGL(silu_grad_scale_kernel, dim3((m * k + 255) / 256), dim3(256), 0, s, dx, xpre_silu, m * k);
+      CTTA_LAUNCH_CHECK();
+    }
   }
   if (dw) {
     const long long total = (long long)n * k;

@@ -73,25 +73,130 @@ struct PackMap {
   int32_t* bidx = nullptr;                // bias placement (NULL = identity over n_bias entries)
   int n = 0;                              // packed rows (GEMM N, padding included)
   int n_bias = 0;
+  int k_ident = 0;                        // conv: weight rows are (cin, kh, kw)-contiguous = the row order of
+                                          // ctta_im2col_t, so the gradient scatters with the identity column map
+                                          // over the first k_ident slab rows
 };
 
 // Persistent device storage for packed weights / fp32 copies / index maps.
+// (Re)loading a state dict = two table-driven launches: every bf16 pack job in one kernel, every fp32
+// vector / table copy in another (ctta_pack_weight_multi / ctta_copy_segments_multi).  The job tables
+// live on the device and are only re-uploaded when a source pointer changed -- in training the
+// parameters sit in one flat buffer, so the per-step re-pack after AdamW / EMA costs two launches.
 struct WeightStore {
   Arena arena;
-  std::vector<std::function<ctta_status(const WeightTable&, hipStream_t)>> jobs;
+  std::vector<std::function<ctta_status(const WeightTable&, hipStream_t)>> jobs;   // irregular one-offs
+
+  struct PackSpec {
+    std::string key;
+    std::vector<int64_t> shape;
+    const int32_t *ro, *co, *ra, *ca;
+    int aux_limit, n_rows, k_pad;
+    bf16_t* dst;
+  };
+  struct CopySpec {
+    std::string key;
+    int64_t numel;      // expected element count of the source tensor
+    int src_start, count;
+    float* dst;
+  };
+  std::vector<PackSpec> packs;
+  std::vector<CopySpec> copies;
+  std::vector<ctta_pack_job> h_pack, h_pack_prev;
+  std::vector<ctta_copy_seg> h_copy, h_copy_prev;
+  ctta_pack_job* d_pack = nullptr;
+  ctta_copy_seg* d_copy = nullptr;
+  size_t d_pack_cap = 0, d_copy_cap = 0;
+  int pack_blocks = 0;
 
   ctta_status init(size_t bytes) {
     arena.dry = false;
     arena.cap = bytes;
     CTTA_CHECK_HIP(hipMalloc((void**)&arena.base, bytes));
+    CTTA_CHECK_HIP(hipMemset(arena.base, 0, bytes));   // padding of the fp32 vectors stays zero for good
     return CTTA_OK;
   }
   void destroy() {
     if (arena.base) (void)hipFree(arena.base);
-    arena.base = nullptr;
+    if (d_pack) (void)hipFree(d_pack);
+    if (d_copy) (void)hipFree(d_copy);
+    arena.base = nullptr; d_pack = nullptr; d_copy = nullptr;
   }
+
+  static ctta_status find_checked(const WeightTable& wt, const std::string& key, const ctta_tensor** out) {
+    const ctta_tensor* t = wt.find(key);
+    if (!t) { ctta_set_error("missing state-dict key '%s'", key.c_str()); return CTTA_ERR_MISSING_KEY; }
+    *out = t;
+    return CTTA_OK;
+  }
+
   ctta_status run_all(const WeightTable& wt, hipStream_t s) {
+    // ---- bf16 packs
+    h_pack.clear();
+    int blk = 0;
+    for (const PackSpec& p : packs) {
+      const ctta_tensor* t;
+      CTTA_TRY(find_checked(wt, p.key, &t));
+      if (t->ndim != (int)p.shape.size()) {
+        ctta_set_error("key '%s': rank %d, expected %d", p.key.c_str(), t->ndim, (int)p.shape.size());
+        return CTTA_ERR_INVALID;
+      }
+      for (int i = 0; i < t->ndim; ++i)
+        if (t->shape[i] != p.shape[i]) {
+          ctta_set_error("size mismatch for '%s' dim %d: %lld vs expected %lld", p.key.c_str(), i,
+                         (long long)t->shape[i], (long long)p.shape[i]);
+          return CTTA_ERR_INVALID;
+        }
+      ctta_pack_job j;
+      j.src = t->data; j.row_off = p.ro; j.col_off = p.co; j.row_aux = p.ra; j.col_aux = p.ca;
+      j.aux_limit = p.aux_limit; j.n_rows = p.n_rows; j.k_pad = p.k_pad; j.dst = p.dst; j.block0 = blk;
+      blk += (int)(((int64_t)p.n_rows * p.k_pad + CTTA_PACK_ELEMS_PER_BLOCK - 1) / CTTA_PACK_ELEMS_PER_BLOCK);
+      h_pack.push_back(j);
+    }
+    pack_blocks = blk;
+    // ---- fp32 copies, chunked so that one block moves at most CTTA_COPY_ELEMS_PER_BLOCK elements
+    h_copy.clear();
+    for (const CopySpec& c : copies) {
+      const ctta_tensor* t;
+      CTTA_TRY(find_checked(wt, c.key, &t));
+      if (tensor_numel(t) != c.numel) {
+        ctta_set_error("size mismatch for '%s': %lld elements, expected %lld", c.key.c_str(),
+                       (long long)tensor_numel(t), (long long)c.numel);
+        return CTTA_ERR_INVALID;
+      }
+      for (int off = 0; off < c.count; off += CTTA_COPY_ELEMS_PER_BLOCK) {
+        ctta_copy_seg g;
+        g.src = t->data + c.src_start + off; g.dst = c.dst + off;
+        g.count = c.count - off < CTTA_COPY_ELEMS_PER_BLOCK ? c.count - off : CTTA_COPY_ELEMS_PER_BLOCK;
+        h_copy.push_back(g);
+      }
+    }
+    CTTA_TRY(sync_table(h_pack, h_pack_prev, (void**)&d_pack, &d_pack_cap, sizeof(ctta_pack_job)));
+    CTTA_TRY(sync_table(h_copy, h_copy_prev, (void**)&d_copy, &d_copy_cap, sizeof(ctta_copy_seg)));
+    if (!h_pack.empty()) CTTA_TRY(ctta_pack_weight_multi(d_pack, (int)h_pack.size(), pack_blocks, s));
+    if (!h_copy.empty()) CTTA_TRY(ctta_copy_segments_multi(d_copy, (int)h_copy.size(), s));
     for (auto& j : jobs) CTTA_TRY(j(wt, s));
+    return CTTA_OK;
+  }
+
+  // uploads a job table when it differs from what the device already holds (blocking copy: tables are a
+  // few hundred KB and change only when the caller hands over different tensors)
+  template <typename T>
+  static ctta_status sync_table(const std::vector<T>& cur, std::vector<T>& prev, void** dev, size_t* cap, size_t elem) {
+    if (cur.empty()) return CTTA_OK;
+    const size_t bytes = cur.size() * elem;
+    if (*dev && prev.size() == cur.size() && memcmp(prev.data(), cur.data(), bytes) == 0) return CTTA_OK;
+    if (bytes > *cap) {
+      CTTA_CHECK_HIP(hipDeviceSynchronize());
+      if (*dev) (void)hipFree(*dev);
+      *dev = nullptr;
+      CTTA_CHECK_HIP(hipMalloc(dev, bytes));
+      *cap = bytes;
+    } else {
+      CTTA_CHECK_HIP(hipDeviceSynchronize());   // an earlier launch may still be reading the old table
+    }
+    CTTA_CHECK_HIP(hipMemcpy(*dev, cur.data(), bytes, hipMemcpyHostToDevice));
+    prev = cur;
     return CTTA_OK;
   }
 
@@ -119,46 +224,19 @@ struct WeightStore {
     if (aux_limit > 0) { CTTA_TRY(upload(*row_aux, &dra)); CTTA_TRY(upload(*col_aux, &dca)); }
     *out = dst;
     if (pm) { pm->wkey = key; pm->ro = dro; pm->co = dco; pm->n = n_rows; }
-    jobs.push_back([=](const WeightTable& wt, hipStream_t s) -> ctta_status {
-      const ctta_tensor* t = wt.find(key);
-      if (!t) { ctta_set_error("missing state-dict key '%s'", key.c_str()); return CTTA_ERR_MISSING_KEY; }
-      if (t->ndim != (int)expect_shape.size()) {
-        ctta_set_error("key '%s': rank %d, expected %d", key.c_str(), t->ndim, (int)expect_shape.size());
-        return CTTA_ERR_INVALID;
-      }
-      for (int i = 0; i < t->ndim; ++i)
-        if (t->shape[i] != expect_shape[i]) {
-          ctta_set_error("size mismatch for '%s' dim %d: %lld vs expected %lld", key.c_str(), i,
-                         (long long)t->shape[i], (long long)expect_shape[i]);
-          return CTTA_ERR_INVALID;
-        }
-      return ctta_pack_weight(t->data, dro, dco, dra, dca, aux_limit, n_rows, k_pad, dst, s);
-    });
+    packs.push_back({key, expect_shape, dro, dco, dra, dca, aux_limit, n_rows, k_pad, dst});
     return CTTA_OK;
   }
 
   // fp32 vector copy with optional placement: dst has n_pad entries, src[i] lands at dst_pos(i)
-  // given as (count, dst_start) segments; the rest stays zero.
+  // given as (count, dst_start) segments; the rest stays zero (the store is zero-filled at init).
   struct Seg { int src_start, dst_start, count; };
   ctta_status add_vector(const std::string& key, int src_len, int n_pad, const std::vector<Seg>& segs,
                          float** out) {
     float* dst = arena.get<float>((size_t)n_pad);
     if (!dst) { ctta_set_error("weight store exhausted at %s", key.c_str()); return CTTA_ERR_NOMEM; }
     *out = dst;
-    jobs.push_back([=](const WeightTable& wt, hipStream_t s) -> ctta_status {
-      const ctta_tensor* t = wt.find(key);
-      if (!t) { ctta_set_error("missing state-dict key '%s'", key.c_str()); return CTTA_ERR_MISSING_KEY; }
-      if (tensor_numel(t) != src_len) {
-        ctta_set_error("size mismatch for '%s': %lld elements, expected %d", key.c_str(),
-                       (long long)tensor_numel(t), src_len);
-        return CTTA_ERR_INVALID;
-      }
-      CTTA_CHECK_HIP(hipMemsetAsync(dst, 0, (size_t)n_pad * sizeof(float), s));
-      for (const Seg& g : segs)
-        CTTA_CHECK_HIP(hipMemcpyAsync(dst + g.dst_start, t->data + g.src_start, (size_t)g.count * sizeof(float),
-                                      hipMemcpyDeviceToDevice, s));
-      return CTTA_OK;
-    });
+    for (const Seg& g : segs) copies.push_back({key, (int64_t)src_len, g.src_start, g.count, dst + g.dst_start});
     return CTTA_OK;
   }
   ctta_status add_vector(const std::string& key, int len, float** out) {
@@ -166,17 +244,7 @@ struct WeightStore {
   }
   // copies into a caller-chosen place of a bigger owned fp32 buffer (concatenated tables)
   ctta_status add_copy_into(const std::string& key, int64_t numel, float* dst) {
-    jobs.push_back([=](const WeightTable& wt, hipStream_t s) -> ctta_status {
-      const ctta_tensor* t = wt.find(key);
-      if (!t) { ctta_set_error("missing state-dict key '%s'", key.c_str()); return CTTA_ERR_MISSING_KEY; }
-      if (tensor_numel(t) != numel) {
-        ctta_set_error("size mismatch for '%s': %lld elements, expected %lld", key.c_str(),
-                       (long long)tensor_numel(t), (long long)numel);
-        return CTTA_ERR_INVALID;
-      }
-      CTTA_CHECK_HIP(hipMemcpyAsync(dst, t->data, (size_t)numel * sizeof(float), hipMemcpyDeviceToDevice, s));
-      return CTTA_OK;
-    });
+    copies.push_back({key, numel, 0, (int)numel, dst});
     return CTTA_OK;
   }
 };
@@ -206,6 +274,7 @@ static inline ctta_status make_conv(WeightStore& ws, const std::string& prefix, 
   CTTA_TRY(ws.add_matrix(prefix + "weight", shape, ro, co, nullptr, nullptr, 0, &L->p.w, nullptr, pm));
   if (with_bias) CTTA_TRY(ws.add_vector(prefix + "bias", cout, n_pad, {{0, 0, cout}}, &L->p.bias));
   if (pm && with_bias) { pm->bkey = prefix + "bias"; pm->n_bias = cout; }
+  if (pm) pm->k_ident = cin * kh * kw;
   L->p.n = n_pad; L->p.k_pad = k_pad;
   L->cin_pad = cin_pad; L->cout = cout; L->kh = kh; L->kw = kw; L->stride = stride; L->pad = pad;
   return CTTA_OK;

@@ -649,14 +649,12 @@ static ctta_status unet_build(ctta_unet* U) {
     if (tr) {   // conv_out runs on the direct small-N kernel in the forward; the backward uses conv_gemm
       CTTA_REQUIRE(co <= 8, "unet_create: training supports out_channels <= 8");
       CTTA_TRY(make_conv_dgrad(ws, "conv_out.", co, ci, 3, 3, 1, &U->t_conv_out.d, 8));
-      std::vector<int32_t> ro(8, -1), cmap((size_t)9 * ci);
+      std::vector<int32_t> ro(8, -1);
       for (int r = 0; r < co; ++r) ro[r] = r * ci * 9;
-      for (int t = 0; t < 9; ++t)
-        for (int cc = 0; cc < ci; ++cc) cmap[(size_t)t * ci + cc] = cc * 9 + t;
       PackMap& m = U->t_conv_out.m;
       m.wkey = "conv_out.weight"; m.bkey = "conv_out.bias"; m.n = 8; m.n_bias = co; m.bidx = nullptr;
+      m.k_ident = ci * 9;
       CTTA_TRY(ws.upload(ro, &m.ro));
-      CTTA_TRY(ws.upload(cmap, &m.co));
     }
   }
   return CTTA_OK;

@@ -81,7 +81,10 @@ static ctta_status scatter_wgrad(BCtx& c, const Slabs& sl, int k_rows, const Pac
   const int64_t stride = (int64_t)sl.R * sl.N;
   float* gw;
   CTTA_TRY(grad_ptr(c, m.wkey, &gw));
-  RUN(c, ctta_wgrad_scatter(sl.p + col0, sl.S, stride, sl.N, k_rows, m.n, m.ro, m.co, nullptr, nullptr, 0, gw, 1, c.stream));
+  if (m.k_ident > 0)
+    RUN(c, ctta_wgrad_scatter(sl.p + col0, sl.S, stride, sl.N, m.k_ident, m.n, m.ro, nullptr, nullptr, nullptr, 0, gw, 1, c.stream));
+  else
+    RUN(c, ctta_wgrad_scatter(sl.p + col0, sl.S, stride, sl.N, k_rows, m.n, m.ro, m.co, nullptr, nullptr, 0, gw, 1, c.stream));
   if (!m.bkey.empty()) {
     float* gb;
     CTTA_TRY(grad_ptr(c, m.bkey, &gb));

@@ -87,6 +87,46 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, const int* __r
   }
 }
 
+// All pack jobs of a state dict in one launch: a block finds its job by bisection over block0.
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const ctta_pack_job* __restrict__ jobs, int n_jobs) {
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ctta_pack_job j = jobs[lo];
+  const long long total = (long long)j.n_rows * j.k_pad;
+  const long long base = (long long)(blockIdx.x - j.block0) * CTTA_PACK_ELEMS_PER_BLOCK;
+  bf16_t* dst = (bf16_t*)j.dst;
+#pragma unroll
+  for (int i = 0; i < CTTA_PACK_ELEMS_PER_BLOCK / 256; ++i) {
+    const long long idx = base + i * 256 + threadIdx.x;
+    if (idx >= total) break;
+    const int k = (int)(idx % j.k_pad);
+    const int r = (int)(idx / j.k_pad);
+    const int ro = j.row_off[r], co = j.col_off[k];
+    bool ok = ro >= 0 && co >= 0;
+    if (ok && j.aux_limit > 0) ok = j.row_aux[r] + j.col_aux[k] < j.aux_limit;
+    dst[idx] = ok ? f2bf(j.src[(size_t)ro + (size_t)co]) : (bf16_t)0;
+  }
+}
+__global__ __launch_bounds__(256) void copy_segments_multi_kernel(const ctta_copy_seg* __restrict__ segs) {
+  const ctta_copy_seg g = segs[blockIdx.x];
+  for (int i = threadIdx.x; i < g.count; i += 256) g.dst[i] = g.src[i];
+}
+extern "C" ctta_status ctta_pack_weight_multi(const ctta_pack_job* jobs, int n_jobs, int total_blocks, void* stream) {
+  CTTA_REQUIRE(jobs && n_jobs >= 1 && total_blocks >= 1, "pack_weight_multi: bad arguments");
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+extern "C" ctta_status ctta_copy_segments_multi(const ctta_copy_seg* segs, int n_segs, void* stream) {
+  CTTA_REQUIRE(segs && n_segs >= 1, "copy_segments_multi: bad arguments");
+  hipLaunchKernelGGL(copy_segments_multi_kernel, dim3(n_segs), dim3(256), 0, (hipStream_t)stream, segs);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
 // ------------------------------------------------------------------------------ GroupNorm
 // Pass 1: per (batch, pixel-chunk) partial sums per group.  A thread owns one 8-channel
 // vector column (tid % VC) and strides over the chunk's pixels; per-channel partials meet in

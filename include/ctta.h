@@ -246,6 +246,25 @@ ctta_status ctta_pack_weight(const float* src, const int32_t* row_off, const int
                              const int32_t* row_aux, const int32_t* col_aux, int aux_limit,
                              int n_rows, int k_pad, void* dst, void* stream);
 
+/* Table-driven variants used by the engines' (re)load path: all pack jobs / all fp32 copies of a
+ * state dict in ONE launch each.  `jobs` / `segs` are DEVICE arrays; jobs must be sorted by block0
+ * (block0 = first thread block of the job, CTTA_PACK_ELEMS_PER_BLOCK outputs per block). */
+#define CTTA_PACK_ELEMS_PER_BLOCK 2048
+#define CTTA_COPY_ELEMS_PER_BLOCK 16384
+typedef struct {
+  const float* src;
+  const int32_t *row_off, *col_off, *row_aux, *col_aux;
+  int aux_limit, n_rows, k_pad, block0;
+  void* dst;
+} ctta_pack_job;
+typedef struct {
+  const float* src;
+  float* dst;
+  int count;
+} ctta_copy_seg;
+ctta_status ctta_pack_weight_multi(const ctta_pack_job* jobs, int n_jobs, int total_blocks, void* stream);
+ctta_status ctta_copy_segments_multi(const ctta_copy_seg* segs, int n_segs, void* stream);
+
 ctta_status ctta_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int batch, int c, int h,
                                        int w, int c_pad, float scale, void* stream);
 ctta_status ctta_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int batch, int c, int h,
@@ -297,12 +316,14 @@ ctta_status ctta_fourier_features(const double* w, const float* weight, int half
 ctta_status ctta_transpose_bf16(const void* src, int64_t src_group_stride, int rows, int cols, int src_ld,
                                 int col0, void* dst, int64_t dst_group_stride, int dst_ld, int groups,
                                 void* stream);
-/* Q[(tap*c + ch)][m] = X[pixel(m, tap)][ch] (transposed im2col, rows padded to m_pad); when
+/* Q[(ch*taps + tap)][m] = X[pixel(m, tap)][ch] (transposed im2col, channel-major rows = the (cin,kh,kw) order
+ * of a conv weight row; rows padded to m_pad); when
  * indicator_batches >= 0 appends 1 + indicator_batches rows: all-ones, then per-sample indicators. */
 ctta_status ctta_im2col_t(const void* x, int c, int batch, int hi, int wi, int upsample, int ho, int wo,
                           int kh, int kw, int stride, int pad_h, int pad_w, int dil_w, void* dst, int m_pad,
                           int indicator_batches, void* stream);
-/* grad_w[row_off[n] + col_off[k]] (+)= sum_s slabs[s][k][n]: inverse of ctta_pack_weight */
+/* grad_w[row_off[n] + col_off[k]] (+)= sum_s slabs[s][k][n]: inverse of ctta_pack_weight
+ * (col_off NULL = identity; negative offsets are skipped) */
 ctta_status ctta_wgrad_scatter(const float* slabs, int n_slabs, int64_t slab_stride, int ldn, int k_rows,
                                int n_cols, const int32_t* row_off, const int32_t* col_off,
                                const int32_t* row_aux, const int32_t* col_aux, int aux_limit, float* grad,

@@ -45,14 +45,9 @@ def wgrad(x_nhwc, dy_nhwc, B, H, W, Cin, Cout, k, stride, pad, ups, Ho, Wo, spli
                        ldc=Cout, out_f32=1, groups=splits, x_group_stride=seg, w_group_stride=seg,
                        out_group_stride=R * Cout))
     ro = (torch.arange(Cout, dtype=torch.int32) * (Cin * k * k)).to(DEV)
-    co = torch.empty(K, dtype=torch.int32)
-    for y in range(k):
-        for xx in range(k):
-            for c in range(Cin):
-                co[(y * k + xx) * Cin + c] = c * k * k + y * k + xx
-    co = co.to(DEV)
+    # im2col_t rows are (cin, kh, kw)-ordered like a conv weight row: identity column map (NULL)
     dw = torch.zeros(Cout, Cin, k, k, device=DEV)
-    N.check(L.ctta_wgrad_scatter(N.ptr(slabs), splits, R * Cout, Cout, K, Cout, N.ptr(ro), N.ptr(co), None, None, 0,
+    N.check(L.ctta_wgrad_scatter(N.ptr(slabs), splits, R * Cout, Cout, K, Cout, N.ptr(ro), None, None, None, 0,
                                  N.ptr(dw), 0, st))
     db = torch.zeros(Cout, device=DEV)
     N.check(L.ctta_row_scatter(N.ptr(slabs), splits, R * Cout, Cout, K, Cout, None, N.ptr(db), 0, st))
