@@ -81,6 +81,12 @@ SIGNATURES = {
     "ctta_unet_destroy": (None, [c_void_p]),
     "ctta_unet_load_weights": (c_int, [c_void_p, POINTER(Tensor), c_int, c_void_p]),
     "ctta_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_attention_lse": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                   c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "ctta_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                   c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                   c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
+                                   c_int, c_float, c_void_p]),
     "ctta_pack_weight_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ctta_copy_segments_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "ctta_unet_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -25,7 +25,7 @@
 __global__ __launch_bounds__(256, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int q_ld, const bf16_t* __restrict__ k, int k_ld, int k_rows,
     const bf16_t* __restrict__ vt, int vt_ld, const float* __restrict__ bias,
-    bf16_t* __restrict__ out, int out_ld, int heads, int nq, int nk, float scale_log2e) {
+    bf16_t* __restrict__ out, int out_ld, int heads, int nq, int nk, float scale_log2e, float* __restrict__ lse) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[ATT_KT * ATT_LDK];   // [key][d]
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * ATT_LDV];       // [d][key]
 
@@ -182,6 +182,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
     const int qi = q0 + jq * 16 + lq;
+    // training: log2-domain log-sum-exp per query, so the backward pass can rebuild P = exp2(s - lse)
+    if (lse && qi < nq && lg == 0) lse[((size_t)b * heads + h) * nq + qi] = mrun[jq] + log2f(l);
     if (qi < nq) {
       bf16_t* orow = out + ((size_t)b * nq + qi) * out_ld + h * 64;
 #pragma unroll
@@ -198,6 +200,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 extern "C" ctta_status ctta_attention(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
                                       int vt_ld, const float* bias, void* out, int out_ld, int batch,
                                       int heads, int nq, int nk, float scale, void* stream) {
+  return ctta_attention_lse(q, q_ld, k, k_ld, k_rows, vt, vt_ld, bias, out, out_ld, batch, heads, nq, nk, scale, nullptr,
+                            stream);
+}
+
+extern "C" ctta_status ctta_attention_lse(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
+                                          int vt_ld, const float* bias, void* out, int out_ld, int batch, int heads,
+                                          int nq, int nk, float scale, float* lse, void* stream) {
   CTTA_REQUIRE(q && k && vt && out, "attention: null pointer");
   CTTA_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vt_ld % 8 == 0 && out_ld % 4 == 0,
                "attention: row strides must be multiples of 8");
@@ -208,8 +217,352 @@ extern "C" ctta_status ctta_attention(const void* q, int q_ld, const void* k, in
   if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
   hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
                      (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, bias, (bf16_t*)out, out_ld, heads,
-                     nq, nk, scale * 1.4426950408889634f);
+                     nq, nk, scale * 1.4426950408889634f, lse);
   if (prof) ctta_prof_end((hipStream_t)stream);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// ====================================================================================== backward
+// Flash-style attention backward (torch autograd of F.scaled_dot_product_attention,
+// attention_processor.py:1127-1129).  Probabilities are rebuilt from the forward's log-sum-exp:
+//     P = exp2(s * scale*log2e + bias*log2e - lse),   dS = P * (dP - D) * scale,   D[q] = sum_d dO[q][d] O[q][d]
+// Two kernels, no atomics:
+//   * dq kernel : a workgroup owns 128 queries (32 per wave) and walks the keys -- the forward's structure:
+//        S^T = K Q^T,  dP^T = V dO^T  (queries = MFMA columns, Q / dO rows held in registers as B operands),
+//        dQ^T += K^T dS^T  (A = K^T tile from LDS, B = dS^T re-used from the accumulators).
+//   * dkv kernel: a workgroup owns 128 keys (32 per wave) and walks the queries:
+//        S = Q K^T,  dP = dO V^T  (keys = MFMA columns, K / V rows in registers),
+//        dV^T += dO^T P,  dK^T += Q^T dS   (A = dO^T / Q^T tiles from LDS, B = P / dS from the accumulators).
+// Operands that are needed with the contraction index contiguous (K^T, Q^T, dO^T, and V in natural
+// layout) are produced once per call by ctta_transpose_bf16 over all heads.
+struct AttnBwdParams {
+  const bf16_t *q, *k, *vn, *kt, *qt, *dot, *dO;
+  int q_ld, k_ld, k_rows, vn_ld, vn_rows, kt_ld, qt_ld, do_ld;
+  const float *bias, *lse, *dsum;
+  bf16_t *dq, *dk, *dv;
+  int dq_ld, dk_ld, dv_ld;
+  int heads, nq, nk;
+  float scale, scale_log2e;
+};
+
+// stages a [64 rows][64 cols] bf16 tile (row stride ld in LDS); rows >= rows_valid are zero
+__device__ __forceinline__ void stage_rows(bf16_t* lds, int ld, const bf16_t* src, size_t src_ld, int rows_valid, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int chunk = tid + i * 256;
+    const int r = chunk >> 3, cc = (chunk & 7) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < rows_valid) v = *reinterpret_cast<const uint4*>(src + (size_t)r * src_ld + cc);
+    *reinterpret_cast<uint4*>(lds + r * ld + cc) = v;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * ATT_LDK];    // [key][d]
+  __shared__ __attribute__((aligned(16))) bf16_t Vn[64 * ATT_LDK];    // [key][d]
+  __shared__ __attribute__((aligned(16))) bf16_t KTs[64 * ATT_LDV];   // [d][key]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int lq = lane & 15, lg = lane >> 4;
+  const bf16_t* qb = p.q + (size_t)b * p.nq * p.q_ld + h * 64;
+  const bf16_t* dob = p.dO + (size_t)b * p.nq * p.do_ld + h * 64;
+  const bf16_t* kb = p.k + (size_t)b * p.k_rows * p.k_ld + h * 64;
+  const bf16_t* vb = p.vn + (size_t)b * p.vn_rows * p.vn_ld + h * 64;
+  const bf16_t* ktb = p.kt + ((size_t)b * p.heads + h) * 64 * p.kt_ld;
+  const float* bb = p.bias ? p.bias + (size_t)b * p.nk : nullptr;
+
+  bf16x8_t qf[2][2], dof[2][2];
+  float lse_q[2], d_q[2];
+#pragma unroll
+  for (int jq = 0; jq < 2; ++jq) {
+    int qi = q0 + jq * 16 + lq;
+    if (qi >= p.nq) qi = p.nq - 1;   // clamp (never stored)
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      qf[jq][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qb + (size_t)qi * p.q_ld + ds * 32 + lg * 8));
+      dof[jq][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(dob + (size_t)qi * p.do_ld + ds * 32 + lg * 8));
+    }
+    lse_q[jq] = p.lse[((size_t)b * p.heads + h) * p.nq + qi];
+    d_q[jq] = p.dsum[((size_t)b * p.heads + h) * p.nq + qi];
+  }
+  f32x4_t o[4][2];   // dQ^T accumulators [d block][q block]
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) o[jd][jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (p.nk + 63) / 64;
+  for (int t = 0; t < ntiles; ++t) {
+    const int key0 = t * 64;
+    __syncthreads();
+    stage_rows(Ks, ATT_LDK, kb + (size_t)key0 * p.k_ld, p.k_ld, p.nk - key0, tid);
+    stage_rows(Vn, ATT_LDK, vb + (size_t)key0 * p.vn_ld, p.vn_ld, p.nk - key0, tid);
+    stage_rows(KTs, ATT_LDV, ktb + key0, p.kt_ld, 64, tid);   // zero beyond nk by construction of K^T
+    __syncthreads();
+    f32x4_t s[4][2], dp[4][2];
+#pragma unroll
+    for (int ik = 0; ik < 4; ++ik) {
+#pragma unroll
+      for (int jq = 0; jq < 2; ++jq) { s[ik][jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[ik][jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ks + (ik * 16 + lq) * ATT_LDK + ds * 32 + lg * 8));
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Vn + (ik * 16 + lq) * ATT_LDK + ds * 32 + lg * 8));
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) {
+          s[ik][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[jq][ds], s[ik][jq], 0, 0, 0);
+          dp[ik][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, dof[jq][ds], dp[ik][jq], 0, 0, 0);
+        }
+      }
+    }
+    // dS^T = P^T * (dP^T - D) * scale, lane holds keys key0 + ik*16 + lg*4 + r for query column lq
+#pragma unroll
+    for (int ik = 0; ik < 4; ++ik)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = key0 + ik * 16 + lg * 4 + r;
+        float add = 0.f;
+        if (key >= p.nk) add = -INFINITY;
+        else if (bb) add = bb[key] * 1.4426950408889634f;
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) {
+          const float pv = exp2f(s[ik][jq][r] * p.scale_log2e + add - lse_q[jq]);
+          s[ik][jq][r] = pv * (dp[ik][jq][r] - d_q[jq]) * p.scale;
+        }
+      }
+    // dQ^T += K^T dS^T
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t sf[2];
+#pragma unroll
+      for (int jq = 0; jq < 2; ++jq) {
+        uint4 pk;
+        pk.x = pack2bf(s[2 * kk][jq][0], s[2 * kk][jq][1]);
+        pk.y = pack2bf(s[2 * kk][jq][2], s[2 * kk][jq][3]);
+        pk.z = pack2bf(s[2 * kk + 1][jq][0], s[2 * kk + 1][jq][1]);
+        pk.w = pack2bf(s[2 * kk + 1][jq][2], s[2 * kk + 1][jq][3]);
+        sf[jq] = __builtin_bit_cast(bf16x8_t, pk);
+      }
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) {
+        const bf16_t* kr = KTs + (jd * 16 + lq) * ATT_LDV + kk * 32 + lg * 4;
+        const uint2 lo = *reinterpret_cast<const uint2*>(kr);
+        const uint2 hi = *reinterpret_cast<const uint2*>(kr + 16);
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) o[jd][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, sf[jq], o[jd][jq], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int jq = 0; jq < 2; ++jq) {
+    const int qi = q0 + jq * 16 + lq;
+    if (qi < p.nq) {
+      bf16_t* orow = p.dq + ((size_t)b * p.nq + qi) * p.dq_ld + h * 64;
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) {
+        uint2 pk;
+        pk.x = pack2bf(o[jd][jq][0], o[jd][jq][1]);
+        pk.y = pack2bf(o[jd][jq][2], o[jd][jq][3]);
+        *reinterpret_cast<uint2*>(orow + jd * 16 + lg * 4) = pk;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
+  __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * ATT_LDK];     // [query][d]
+  __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * ATT_LDK];    // [query][d]
+  __shared__ __attribute__((aligned(16))) bf16_t QTs[64 * ATT_LDV];    // [d][query]
+  __shared__ __attribute__((aligned(16))) bf16_t dOTs[64 * ATT_LDV];   // [d][query]
+  __shared__ __attribute__((aligned(16))) float lse_s[64];
+  __shared__ __attribute__((aligned(16))) float d_s[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int bh = blockIdx.y;
+  const int b = bh / p.heads, h = bh - b * p.heads;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int lq = lane & 15, lg = lane >> 4;
+  const bf16_t* qb = p.q + (size_t)b * p.nq * p.q_ld + h * 64;
+  const bf16_t* dob = p.dO + (size_t)b * p.nq * p.do_ld + h * 64;
+  const bf16_t* kb = p.k + (size_t)b * p.k_rows * p.k_ld + h * 64;
+  const bf16_t* vb = p.vn + (size_t)b * p.vn_rows * p.vn_ld + h * 64;
+  const bf16_t* qtb = p.qt + ((size_t)b * p.heads + h) * 64 * p.qt_ld;
+  const bf16_t* dotb = p.dot + ((size_t)b * p.heads + h) * 64 * p.qt_ld;
+  const float* lseb = p.lse + ((size_t)b * p.heads + h) * p.nq;
+  const float* dsb = p.dsum + ((size_t)b * p.heads + h) * p.nq;
+
+  bf16x8_t kf[2][2], vf[2][2];   // B operands: lane = key column, 8 consecutive d
+  float kb2[2];
+#pragma unroll
+  for (int jk = 0; jk < 2; ++jk) {
+    const int key = k0 + jk * 16 + lq;
+    const int kc = key < p.nk ? key : p.nk - 1;
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds) {
+      kf[jk][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(kb + (size_t)kc * p.k_ld + ds * 32 + lg * 8));
+      vf[jk][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(vb + (size_t)kc * p.vn_ld + ds * 32 + lg * 8));
+    }
+    kb2[jk] = key < p.nk ? (p.bias ? p.bias[(size_t)b * p.nk + key] * 1.4426950408889634f : 0.f) : -INFINITY;
+  }
+  f32x4_t dv[4][2], dk[4][2];   // dV^T / dK^T accumulators [d block][key block]
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+    for (int jk = 0; jk < 2; ++jk) { dv[jd][jk] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dk[jd][jk] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+
+  const int ntiles = (p.nq + 63) / 64;
+  for (int t = 0; t < ntiles; ++t) {
+    const int q0 = t * 64;
+    __syncthreads();
+    stage_rows(Qs, ATT_LDK, qb + (size_t)q0 * p.q_ld, p.q_ld, p.nq - q0, tid);
+    stage_rows(dOs, ATT_LDK, dob + (size_t)q0 * p.do_ld, p.do_ld, p.nq - q0, tid);
+    stage_rows(QTs, ATT_LDV, qtb + q0, p.qt_ld, 64, tid);     // zero beyond nq by construction
+    stage_rows(dOTs, ATT_LDV, dotb + q0, p.qt_ld, 64, tid);
+    if (tid < 64) {
+      const bool ok = q0 + tid < p.nq;
+      lse_s[tid] = ok ? lseb[q0 + tid] : INFINITY;   // exp2(-inf) = 0 for padded queries
+      d_s[tid] = ok ? dsb[q0 + tid] : 0.f;
+    }
+    __syncthreads();
+    f32x4_t s[4][2], dp[4][2];
+#pragma unroll
+    for (int iq = 0; iq < 4; ++iq) {
+#pragma unroll
+      for (int jk = 0; jk < 2; ++jk) { s[iq][jk] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dp[iq][jk] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        const bf16x8_t qa = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Qs + (iq * 16 + lq) * ATT_LDK + ds * 32 + lg * 8));
+        const bf16x8_t da = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(dOs + (iq * 16 + lq) * ATT_LDK + ds * 32 + lg * 8));
+#pragma unroll
+        for (int jk = 0; jk < 2; ++jk) {
+          s[iq][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qa, kf[jk][ds], s[iq][jk], 0, 0, 0);
+          dp[iq][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(da, vf[jk][ds], dp[iq][jk], 0, 0, 0);
+        }
+      }
+    }
+    // lane holds queries q0 + iq*16 + lg*4 + r for key column lq:  s -> P,  dp -> dS
+#pragma unroll
+    for (int iq = 0; iq < 4; ++iq) {
+      const float4 l4 = *reinterpret_cast<const float4*>(lse_s + iq * 16 + lg * 4);
+      const float4 d4 = *reinterpret_cast<const float4*>(d_s + iq * 16 + lg * 4);
+      const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
+      const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int jk = 0; jk < 2; ++jk) {
+          const float pv = exp2f(s[iq][jk][r] * p.scale_log2e + kb2[jk] - lv[r]);
+          s[iq][jk][r] = pv;
+          dp[iq][jk][r] = pv * (dp[iq][jk][r] - dd[r]) * p.scale;
+        }
+    }
+    // dV^T += dO^T P ,  dK^T += Q^T dS : k-slot (lg, e): e<4 -> query block 2kk, row lg*4+e ; e>=4 -> block 2kk+1
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      bf16x8_t pf[2], sf[2];
+#pragma unroll
+      for (int jk = 0; jk < 2; ++jk) {
+        uint4 a, c;
+        a.x = pack2bf(s[2 * kk][jk][0], s[2 * kk][jk][1]);
+        a.y = pack2bf(s[2 * kk][jk][2], s[2 * kk][jk][3]);
+        a.z = pack2bf(s[2 * kk + 1][jk][0], s[2 * kk + 1][jk][1]);
+        a.w = pack2bf(s[2 * kk + 1][jk][2], s[2 * kk + 1][jk][3]);
+        c.x = pack2bf(dp[2 * kk][jk][0], dp[2 * kk][jk][1]);
+        c.y = pack2bf(dp[2 * kk][jk][2], dp[2 * kk][jk][3]);
+        c.z = pack2bf(dp[2 * kk + 1][jk][0], dp[2 * kk + 1][jk][1]);
+        c.w = pack2bf(dp[2 * kk + 1][jk][2], dp[2 * kk + 1][jk][3]);
+        pf[jk] = __builtin_bit_cast(bf16x8_t, a);
+        sf[jk] = __builtin_bit_cast(bf16x8_t, c);
+      }
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) {
+        const bf16_t* dr = dOTs + (jd * 16 + lq) * ATT_LDV + kk * 32 + lg * 4;
+        const bf16_t* qr = QTs + (jd * 16 + lq) * ATT_LDV + kk * 32 + lg * 4;
+        const uint2 dlo = *reinterpret_cast<const uint2*>(dr), dhi = *reinterpret_cast<const uint2*>(dr + 16);
+        const uint2 qlo = *reinterpret_cast<const uint2*>(qr), qhi = *reinterpret_cast<const uint2*>(qr + 16);
+        const bf16x8_t daf = __builtin_bit_cast(bf16x8_t, make_uint4(dlo.x, dlo.y, dhi.x, dhi.y));
+        const bf16x8_t qaf = __builtin_bit_cast(bf16x8_t, make_uint4(qlo.x, qlo.y, qhi.x, qhi.y));
+#pragma unroll
+        for (int jk = 0; jk < 2; ++jk) {
+          dv[jd][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(daf, pf[jk], dv[jd][jk], 0, 0, 0);
+          dk[jd][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qaf, sf[jk], dk[jd][jk], 0, 0, 0);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int jk = 0; jk < 2; ++jk) {
+    const int key = k0 + jk * 16 + lq;
+    if (key < p.nk) {
+      bf16_t* vrow = p.dv + ((size_t)b * p.k_rows + key) * p.dv_ld + h * 64;
+      bf16_t* krow = p.dk + ((size_t)b * p.k_rows + key) * p.dk_ld + h * 64;
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) {
+        uint2 a, c;
+        a.x = pack2bf(dv[jd][jk][0], dv[jd][jk][1]);
+        a.y = pack2bf(dv[jd][jk][2], dv[jd][jk][3]);
+        c.x = pack2bf(dk[jd][jk][0], dk[jd][jk][1]);
+        c.y = pack2bf(dk[jd][jk][2], dk[jd][jk][3]);
+        *reinterpret_cast<uint2*>(vrow + jd * 16 + lg * 4) = a;
+        *reinterpret_cast<uint2*>(krow + jd * 16 + lg * 4) = c;
+      }
+    }
+  }
+}
+
+// D[b][h][q] = sum_d dO[q][h*64+d] * O[q][h*64+d]: one wave per query row, 8 lanes per head
+__global__ __launch_bounds__(256) void attn_rowdot_kernel(const bf16_t* __restrict__ dO, int do_ld,
+                                                          const bf16_t* __restrict__ o, int o_ld, float* __restrict__ dsum,
+                                                          int batch, int heads, int nq) {
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (long long)batch * nq) return;
+  const int b = (int)(row / nq), qi = (int)(row - (long long)b * nq);
+  for (int c8 = lane; c8 < heads * 8; c8 += 64) {
+    float a[8], g[8];
+    unpack8(*reinterpret_cast<const uint4*>(dO + (size_t)row * do_ld + c8 * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(o + (size_t)row * o_ld + c8 * 8), g);
+    float acc = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc += a[e] * g[e];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if ((lane & 7) == 0) dsum[((size_t)b * heads + (c8 >> 3)) * nq + qi] = acc;
+  }
+}
+
+extern "C" ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vn,
+                                          int vn_ld, int vn_rows, const void* kt, int kt_ld, const void* qt,
+                                          const void* dot, int qt_ld, const float* bias, const void* out, int out_ld,
+                                          const void* dout, int do_ld, const float* lse, float* dsum, void* dq, int dq_ld,
+                                          void* dk, int dk_ld, void* dv, int dv_ld, int batch, int heads, int nq, int nk,
+                                          float scale, void* stream) {
+  CTTA_REQUIRE(q && k && vn && kt && qt && dot && out && dout && lse && dsum && dq && dk && dv, "attention_bwd: null pointer");
+  CTTA_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vn_ld % 8 == 0 && kt_ld % 64 == 0 && qt_ld % 64 == 0 && do_ld % 8 == 0 &&
+                   out_ld % 8 == 0 && dq_ld % 4 == 0 && dk_ld % 4 == 0 && dv_ld % 4 == 0,
+               "attention_bwd: row strides (transposed operands need 64-multiples)");
+  CTTA_REQUIRE(nq > 0 && nk > 0 && k_rows >= nk && vn_rows >= nk && kt_ld >= nk && qt_ld >= nq, "attention_bwd: bad lengths");
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)(((long long)batch * nq + 3) / 4)), dim3(256), 0, s,
+                     (const bf16_t*)dout, do_ld, (const bf16_t*)out, out_ld, dsum, batch, heads, nq);
+  CTTA_LAUNCH_CHECK();
+  AttnBwdParams p;
+  p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vn = (const bf16_t*)vn; p.kt = (const bf16_t*)kt;
+  p.qt = (const bf16_t*)qt; p.dot = (const bf16_t*)dot; p.dO = (const bf16_t*)dout;
+  p.q_ld = q_ld; p.k_ld = k_ld; p.k_rows = k_rows; p.vn_ld = vn_ld; p.vn_rows = vn_rows; p.kt_ld = kt_ld; p.qt_ld = qt_ld;
+  p.do_ld = do_ld; p.bias = bias; p.lse = lse; p.dsum = dsum;
+  p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.dq_ld = dq_ld; p.dk_ld = dk_ld; p.dv_ld = dv_ld;
+  p.heads = heads; p.nq = nq; p.nk = nk; p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
+  const bool prof = ctta_prof_active();
+  // executed flops: 7 products of 2*nq*nk*64 per head (S and dP are computed by both kernels)
+  if (prof) ctta_prof_begin(1, 1, nq, nk, 448, (long long)batch * heads, s);
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((nk + 127) / 128, batch * heads), dim3(256), 0, s, p);
+  if (prof) ctta_prof_end(s);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

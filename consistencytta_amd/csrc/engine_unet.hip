@@ -80,7 +80,7 @@ struct Transformer {
     const bf16_t *x = nullptr, *g = nullptr, *s0 = nullptr, *n1 = nullptr, *qk = nullptr, *vt = nullptr, *att1 = nullptr,
                  *s1 = nullptr, *n2 = nullptr, *q2 = nullptr, *k2 = nullptr, *vt2 = nullptr, *att2 = nullptr, *s2 = nullptr,
                  *n3 = nullptr, *f = nullptr, *gg = nullptr, *s3 = nullptr;
-    float* st = nullptr;
+    float *st = nullptr, *lse1 = nullptr, *lse2 = nullptr;   // GroupNorm stats, attention log-sum-exps
     int H = 0, W = 0;
   } sv;
 };
@@ -278,9 +278,14 @@ static ctta_status run_resnet(UCtx& c, Resnet& R, const bf16_t* x, int H, int W,
 
 static ctta_status run_attention(UCtx& c, const bf16_t* q, int q_ld, const bf16_t* k, int k_ld, int k_rows,
                                  const bf16_t* vt, int vt_ld, const float* bias, bf16_t* out, int out_ld,
-                                 int heads, int nq, int nk, int dh) {
-  RUN(c, ctta_attention(q, q_ld, k, k_ld, k_rows, vt, vt_ld, bias, out, out_ld, c.B, heads, nq, nk,
-                        1.0f / sqrtf((float)dh), c.stream));
+                                 int heads, int nq, int nk, int dh, float** lse_out = nullptr) {
+  float* lse = nullptr;
+  if (c.train && lse_out) {   // the backward pass rebuilds the probabilities from the row log-sum-exp
+    lse = c.arena->get<float>((size_t)c.B * heads * nq); ALLOC_OR_FAIL(lse);
+    *lse_out = lse;
+  }
+  RUN(c, ctta_attention_lse(q, q_ld, k, k_ld, k_rows, vt, vt_ld, bias, out, out_ld, c.B, heads, nq, nk,
+                            1.0f / sqrtf((float)dh), lse, c.stream));
   return CTTA_OK;
 }
 
@@ -305,7 +310,7 @@ static ctta_status run_transformer(UCtx& c, Transformer& T, const bf16_t* x, int
   bf16_t* vt = A.get<bf16_t>((size_t)c.B * hp * vt_ld); ALLOC_OR_FAIL(vt);
   CTTA_TRY(run_vt(c, T.v1, n, c.B, N, N, vt, vt_ld));
   bf16_t* att = A.get<bf16_t>(M * hp); ALLOC_OR_FAIL(att);
-  CTTA_TRY(run_attention(c, qk, 2 * hp, qk + hp, 2 * hp, N, vt, vt_ld, nullptr, att, hp, T.heads, N, N, T.dh));
+  CTTA_TRY(run_attention(c, qk, 2 * hp, qk + hp, 2 * hp, N, vt, vt_ld, nullptr, att, hp, T.heads, N, N, T.dh, &T.sv.lse1));
   bf16_t* s1 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s1);
   CTTA_TRY(run_linear(c, T.out1, att, hp, M, s1, cp, s0, cp));
   // --- cross-attention against the text states
@@ -323,7 +328,7 @@ static ctta_status run_transformer(UCtx& c, Transformer& T, const bf16_t* x, int
   CTTA_TRY(run_linear(c, T.k2, c.enc_bf, c.U->xp, (int64_t)c.B * c.Lp, k2, hp, nullptr, 0));
   bf16_t* vt2 = A.get<bf16_t>((size_t)c.B * hp * c.Lp); ALLOC_OR_FAIL(vt2);
   CTTA_TRY(run_vt(c, T.v2, c.enc_bf, c.B, c.Lp, c.Lp, vt2, c.Lp));
-  CTTA_TRY(run_attention(c, q2, hp, k2, hp, c.Lp, vt2, c.Lp, c.mask_bias, att, hp, T.heads, N, c.L, T.dh));
+  CTTA_TRY(run_attention(c, q2, hp, k2, hp, c.Lp, vt2, c.Lp, c.mask_bias, att, hp, T.heads, N, c.L, T.dh, &T.sv.lse2));
   bf16_t* s2 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s2);
   CTTA_TRY(run_linear(c, T.out2, att, hp, M, s2, cp, s1, cp));
   // --- GEGLU feed-forward

@@ -6,8 +6,8 @@
 //   * weight gradients : one split-M GEMM  dW[k][n] = sum_m Q[k][m] * dY^T[n][m]  per layer, where
 //                        Q = im2col(X)^T plus an all-ones row (bias gradient) and, for the resnets'
 //                        conv1, one indicator row per sample (time-embedding gradient),
-//   * attention        : probabilities recomputed per head (S = QK^T materialised in fp32), then
-//                        dV = P^T dO, dP = dO V^T, dS = softmax'(P, dP), dQ = dS K, dK = dS^T Q,
+//   * attention        : flash-style backward (ctta_attention_bwd): probabilities rebuilt from the forward's
+//                        log-sum-exp, dV = P^T dO, dP = dO V^T, dS = P (dP - D) scale, dQ = dS K, dK = dS^T Q,
 //   * norms / GEGLU / embedding MLP: the kernels in backward.hip.
 // Gradients are ACCUMULATED into the caller's fp32 tensors (same names / shapes as the state dict),
 // i.e. `.grad` semantics; the caller zeroes them.  Activation gradients travel in bf16.
@@ -203,73 +203,29 @@ static ctta_status bwd_resnet(BCtx& c, Resnet& R, const bf16_t* dout, bf16_t** d
 }
 
 // ------------------------------------------------------------------------------ attention
-// q [B][nq][ldq], k [B][krows][ldk] (head h at columns h*64), vt [B][hp][vt_ld]; dO [B*nq][hp].
-// Writes dq [B*nq][lddq], dk [B*krows][lddk], dv [B*krows][hp] (head-padded lanes come out zero).
+// q [B][nq][ldq], k [B][krows][ldk] (head h at columns h*64), vt [B][hp][vt_ld]; out / dO [B*nq][hp].
+// Writes dq [B*nq][lddq], dk [B*krows][lddk], dv [B*krows][hp] for keys < nk (head-padded lanes come
+// out zero).  Flash-style: four whole-tensor transposes feed ctta_attention_bwd (no score matrix).
 static ctta_status bwd_attention(BCtx& c, int heads, int dh, const bf16_t* q, int ldq, const bf16_t* k, int ldk, int krows,
-                                 const bf16_t* vt, int vt_ld, const float* bias, int nq, int nk, const bf16_t* dO, int hp,
-                                 bf16_t* dq, int lddq, bf16_t* dk, int lddk, bf16_t* dv) {
+                                 const bf16_t* vt, int vt_ld, const float* bias, int nq, int nk, const bf16_t* out,
+                                 const bf16_t* dO, int hp, const float* lse, bf16_t* dq, int lddq, bf16_t* dk, int lddk,
+                                 bf16_t* dv) {
   Arena& A = *c.arena;
   const int B = c.B;
-  const int nk64 = round_up(krows > nk ? krows : nk, 64), nq64 = round_up(nq, 64);
-  const int ncols = krows;   // GEMM N for the score products (rows of k beyond nk are zero text rows)
-  const float scale = 1.0f / sqrtf((float)dh);
-  const size_t rows = (size_t)B * nq;
-  for (int h = 0; h < heads; ++h) {
-    const size_t mk = A.mark();
-    float* S = A.get<float>(rows * nk64); ALLOC_OR_FAIL(S);
-    bf16_t* P = A.get<bf16_t>(rows * nk64); ALLOC_OR_FAIL(P);
-    bf16_t* Vh = A.get<bf16_t>((size_t)B * nk64 * 64); ALLOC_OR_FAIL(Vh);
-    bf16_t* KhT = A.get<bf16_t>((size_t)B * 64 * nk64); ALLOC_OR_FAIL(KhT);
-    bf16_t* QhT = A.get<bf16_t>((size_t)B * 64 * nq64); ALLOC_OR_FAIL(QhT);
-    bf16_t* dOhT = A.get<bf16_t>((size_t)B * 64 * nq64); ALLOC_OR_FAIL(dOhT);
-    bf16_t* T1 = A.get<bf16_t>((size_t)B * nk64 * nq64); ALLOC_OR_FAIL(T1);   // P^T, then dS^T
-    ctta_conv_desc d;
-    // S = Q_h K_h^T
-    desc_init(&d);
-    d.x0 = q + h * 64; d.c0 = 64; d.x_stride = ldq; d.batch = 1; d.hi = nq; d.wi = 1; d.ho = nq; d.wo = 1;
-    d.w = k + h * 64; d.k_pad = ldk; d.n = ncols; d.out = S; d.ldc = nk64; d.out_f32 = 1;
-    d.groups = B; d.x_group_stride = (int64_t)nq * ldq; d.w_group_stride = (int64_t)krows * ldk;
-    d.out_group_stride = (int64_t)nq * nk64;
-    RUN(c, ctta_conv_gemm(&d, c.stream));
-    RUN(c, ctta_softmax_bias_rows(S, nk64, bias, nq, P, (int64_t)rows, nk, nk64, scale, c.stream));
-    // dV_h = P^T dO_h
-    RUN(c, ctta_transpose_bf16(P, (int64_t)nq * nk64, nq, nk64, nk64, 0, T1, (int64_t)nk64 * nq64, nq64, B, c.stream));
-    RUN(c, ctta_transpose_bf16(dO + h * 64, (int64_t)nq * hp, nq, 64, hp, 0, dOhT, (int64_t)64 * nq64, nq64, B, c.stream));
-    desc_init(&d);
-    d.x0 = T1; d.c0 = nq64; d.batch = 1; d.hi = nk; d.wi = 1; d.ho = nk; d.wo = 1;
-    d.w = dOhT; d.k_pad = nq64; d.n = 64; d.out = dv + h * 64; d.ldc = hp;
-    d.groups = B; d.x_group_stride = (int64_t)nk64 * nq64; d.w_group_stride = (int64_t)64 * nq64;
-    d.out_group_stride = (int64_t)krows * hp;
-    RUN(c, ctta_conv_gemm(&d, c.stream));
-    // dP = dO_h V_h^T  (into the score buffer), dS = softmax'(P, dP) (into P)
-    RUN(c, ctta_transpose_bf16(vt + (size_t)h * 64 * vt_ld, (int64_t)hp * vt_ld, 64, vt_ld, vt_ld, 0, Vh, (int64_t)nk64 * 64,
-                               64, B, c.stream));
-    desc_init(&d);
-    d.x0 = dO + h * 64; d.c0 = 64; d.x_stride = hp; d.batch = 1; d.hi = nq; d.wi = 1; d.ho = nq; d.wo = 1;
-    d.w = Vh; d.k_pad = 64; d.n = ncols; d.out = S; d.ldc = nk64; d.out_f32 = 1;
-    d.groups = B; d.x_group_stride = (int64_t)nq * hp; d.w_group_stride = (int64_t)nk64 * 64;
-    d.out_group_stride = (int64_t)nq * nk64;
-    RUN(c, ctta_conv_gemm(&d, c.stream));
-    RUN(c, ctta_softmax_bwd_rows(P, S, nk64, P, (int64_t)rows, nk, nk64, scale, c.stream));
-    // dQ_h = dS K_h
-    RUN(c, ctta_transpose_bf16(k + h * 64, (int64_t)krows * ldk, nk, 64, ldk, 0, KhT, (int64_t)64 * nk64, nk64, B, c.stream));
-    desc_init(&d);
-    d.x0 = P; d.c0 = nk64; d.batch = 1; d.hi = nq; d.wi = 1; d.ho = nq; d.wo = 1;
-    d.w = KhT; d.k_pad = nk64; d.n = 64; d.out = dq + h * 64; d.ldc = lddq;
-    d.groups = B; d.x_group_stride = (int64_t)nq * nk64; d.w_group_stride = (int64_t)64 * nk64;
-    d.out_group_stride = (int64_t)nq * lddq;
-    RUN(c, ctta_conv_gemm(&d, c.stream));
-    // dK_h = dS^T Q_h
-    RUN(c, ctta_transpose_bf16(P, (int64_t)nq * nk64, nq, nk64, nk64, 0, T1, (int64_t)nk64 * nq64, nq64, B, c.stream));
-    RUN(c, ctta_transpose_bf16(q + h * 64, (int64_t)nq * ldq, nq, 64, ldq, 0, QhT, (int64_t)64 * nq64, nq64, B, c.stream));
-    desc_init(&d);
-    d.x0 = T1; d.c0 = nq64; d.batch = 1; d.hi = nk; d.wi = 1; d.ho = nk; d.wo = 1;
-    d.w = QhT; d.k_pad = nq64; d.n = 64; d.out = dk + h * 64; d.ldc = lddk;
-    d.groups = B; d.x_group_stride = (int64_t)nk64 * nq64; d.w_group_stride = (int64_t)64 * nq64;
-    d.out_group_stride = (int64_t)krows * lddk;
-    RUN(c, ctta_conv_gemm(&d, c.stream));
-    A.release(mk);
-  }
+  const int nk64 = round_up(nk, 64), nq64 = round_up(nq, 64);
+  const size_t mk = A.mark();
+  bf16_t* vn = A.get<bf16_t>((size_t)B * vt_ld * hp); ALLOC_OR_FAIL(vn);      // V   [B][vt_ld][hp]
+  bf16_t* kt = A.get<bf16_t>((size_t)B * hp * nk64); ALLOC_OR_FAIL(kt);       // K^T [B][hp][nk64]
+  bf16_t* qt = A.get<bf16_t>((size_t)B * hp * nq64); ALLOC_OR_FAIL(qt);       // Q^T
+  bf16_t* dot = A.get<bf16_t>((size_t)B * hp * nq64); ALLOC_OR_FAIL(dot);     // dO^T
+  float* dsum = A.get<float>((size_t)B * heads * nq); ALLOC_OR_FAIL(dsum);
+  RUN(c, ctta_transpose_bf16(vt, (int64_t)hp * vt_ld, hp, vt_ld, vt_ld, 0, vn, (int64_t)vt_ld * hp, hp, B, c.stream));
+  RUN(c, ctta_transpose_bf16(k, (int64_t)krows * ldk, nk, hp, ldk, 0, kt, (int64_t)hp * nk64, nk64, B, c.stream));
+  RUN(c, ctta_transpose_bf16(q, (int64_t)nq * ldq, nq, hp, ldq, 0, qt, (int64_t)hp * nq64, nq64, B, c.stream));
+  RUN(c, ctta_transpose_bf16(dO, (int64_t)nq * hp, nq, hp, hp, 0, dot, (int64_t)hp * nq64, nq64, B, c.stream));
+  RUN(c, ctta_attention_bwd(q, ldq, k, ldk, krows, vn, hp, vt_ld, kt, nk64, qt, dot, nq64, bias, out, hp, dO, hp, lse, dsum,
+                            dq, lddq, dk, lddk, dv, hp, B, heads, nq, nk, 1.0f / sqrtf((float)dh), c.stream));
+  A.release(mk);
   return CTTA_OK;
 }
 
@@ -315,8 +271,8 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
       CTTA_CHECK_HIP(hipMemsetAsync(dk, 0, kv * sizeof(bf16_t), c.stream));
       CTTA_CHECK_HIP(hipMemsetAsync(dv, 0, kv * sizeof(bf16_t), c.stream));
     }
-    CTTA_TRY(bwd_attention(c, T.heads, T.dh, S.q2, hp, S.k2, hp, Lp, S.vt2, Lp, c.mask_bias, N, c.L, datt, hp, dq, hp, dk,
-                           hp, dv));
+    CTTA_TRY(bwd_attention(c, T.heads, T.dh, S.q2, hp, S.k2, hp, Lp, S.vt2, Lp, c.mask_bias, N, c.L, S.att2, datt, hp, S.lse2,
+                           dq, hp, dk, hp, dv));
     bf16_t* dn = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(dn);
     CTTA_TRY(linear_dgrad(c, T.t_q2.d, dq, hp, hp, M, dn, cp, cp, false));
     CTTA_TRY(linear_wgrad(c, T.t_q2.m, nullptr, S.n2, cp, M, dq, hp));
@@ -332,8 +288,8 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
     CTTA_TRY(linear_wgrad(c, T.t_out1.m, nullptr, S.att1, hp, M, ds, cp));
     bf16_t* dqk = A.get<bf16_t>((size_t)M * 2 * hp); ALLOC_OR_FAIL(dqk);
     bf16_t* dv = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(dv);
-    CTTA_TRY(bwd_attention(c, T.heads, T.dh, S.qk, 2 * hp, S.qk + hp, 2 * hp, N, S.vt, vt_ld, nullptr, N, N, datt, hp, dqk,
-                           2 * hp, dqk + hp, 2 * hp, dv));
+    CTTA_TRY(bwd_attention(c, T.heads, T.dh, S.qk, 2 * hp, S.qk + hp, 2 * hp, N, S.vt, vt_ld, nullptr, N, N, S.att1, datt, hp,
+                           S.lse1, dqk, 2 * hp, dqk + hp, 2 * hp, dv));
     bf16_t* dn = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(dn);
     CTTA_TRY(linear_dgrad(c, T.t_q1.d, dqk, hp, 2 * hp, M, dn, cp, cp, false));
     CTTA_TRY(linear_dgrad(c, T.t_k1.d, dqk + hp, hp, 2 * hp, M, dn, cp, cp, true));

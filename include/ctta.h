@@ -296,6 +296,27 @@ ctta_status ctta_softmax_rows(const float* s, void* p, int64_t rows, int cols, f
 ctta_status ctta_attention(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
                            int vt_ld, const float* bias, void* out, int out_ld, int batch,
                            int heads, int nq, int nk, float scale, void* stream);
+/* Same, and (when lse != NULL) also writes the log2-domain log-sum-exp of every query row,
+ * lse[b][head][q] = log2(sum_k exp2(s*scale*log2e + bias*log2e)), which ctta_attention_bwd needs. */
+ctta_status ctta_attention_lse(const void* q, int q_ld, const void* k, int k_ld, int k_rows,
+                               const void* vt, int vt_ld, const float* bias, void* out, int out_ld,
+                               int batch, int heads, int nq, int nk, float scale, float* lse,
+                               void* stream);
+/* Backward of the attention above (autograd of F.scaled_dot_product_attention,
+ * attention_processor.py:1127-1129) without materialising the scores.  Operands:
+ *   q, k            as in the forward;  out / dout: forward output and its gradient [B*nq][*_ld]
+ *   vn [B][vn_rows][vn_ld]   V in natural layout (head h at columns h*64)
+ *   kt [B][heads*64][kt_ld]  K^T (keys contiguous, zero beyond nk; kt_ld multiple of 64)
+ *   qt, dot [B][heads*64][qt_ld]  Q^T and dout^T (queries contiguous, zero beyond nq)
+ *   lse  from ctta_attention_lse;  dsum [B][heads][nq] fp32 scratch (D = rowsum(dout*out))
+ * Writes dq [B*nq][dq_ld], dk / dv [B*k_rows][*_ld] for keys < nk (head h at columns h*64). */
+ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k, int k_ld, int k_rows,
+                               const void* vn, int vn_ld, int vn_rows, const void* kt, int kt_ld,
+                               const void* qt, const void* dot, int qt_ld, const float* bias,
+                               const void* out, int out_ld, const void* dout, int do_ld,
+                               const float* lse, float* dsum, void* dq, int dq_ld, void* dk, int dk_ld,
+                               void* dv, int dv_ld, int batch, int heads, int nq, int nk, float scale,
+                               void* stream);
 
 /* Small fp32 linear: y[m][n] = act_out(sum_k act_in(x[m][k]) * w[n][k] + b[n]); m <= 1024.
  * act: 0 none, 1 silu. */

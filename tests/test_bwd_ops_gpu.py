@@ -244,3 +244,78 @@ def test_embedding_mlp_backward_loss_grad_and_adamw():
         N.check(L.ctta_adamw_step(N.ptr(pd), N.ptr(gd), N.ptr(m), N.ptr(v), 1000, 1e-3, 0.9, 0.999, 1e-8, 1e-2, i + 1, 1.0, st))
     sync()
     assert rel_err(pd.cpu(), pt.detach()) < 2e-6
+
+
+@pytest.mark.parametrize("B,heads,dh,nq,nk,krows,use_bias", [(2, 3, 51, 200, 200, 200, False), (2, 2, 64, 256, 256, 256, False),
+                                                            (3, 3, 13, 70, 7, 8, True), (1, 5, 51, 130, 31, 32, True),
+                                                            (2, 6, 40, 4, 4, 4, False)])
+def test_flash_attention_backward(B, heads, dh, nq, nk, krows, use_bias):
+    """ctta_attention_lse + ctta_attention_bwd vs autograd of softmax(q k^T * scale + bias) v (fp32 on the
+    bf16-rounded operands); heads padded to 64 lanes as in the engine."""
+    L = lib()
+    st = N.stream_ptr()
+    hp = heads * 64
+    scale = 1.0 / math.sqrt(dh)
+    q = bf16_round(det("fa.q", (B, heads, nq, dh), 1)).requires_grad_(True)
+    k = bf16_round(det("fa.k", (B, heads, nk, dh), 2)).requires_grad_(True)
+    v = bf16_round(det("fa.v", (B, heads, nk, dh), 3)).requires_grad_(True)
+    bias = None
+    if use_bias:
+        keep = (det("fa.m", (B, nk), 4) > -0.3).float()
+        keep[:, 0] = 1.0
+        bias = (1.0 - keep) * -10000.0
+    s = torch.einsum("bhqd,bhkd->bhqk", q, k) * scale
+    if bias is not None:
+        s = s + bias[:, None, None, :]
+    o = torch.einsum("bhqk,bhkd->bhqd", torch.softmax(s, dim=-1), v)
+    do = bf16_round(det("fa.do", (B, heads, nq, dh), 5))
+    o.backward(do)
+
+    def pad_heads(x, rows):          # (B, heads, n, dh) -> [B][rows][hp] bf16
+        out = torch.zeros(B, rows, hp)
+        for h in range(heads):
+            out[:, :x.shape[2], h * 64:h * 64 + dh] = x[:, h]
+        return out.to(torch.bfloat16).to(DEV)
+
+    qd, kd, vd, dod = pad_heads(q.detach(), nq), pad_heads(k.detach(), krows), pad_heads(v.detach(), krows), pad_heads(do, nq)
+    vt_ld = rup(krows, 8)
+    vt = torch.zeros(B, hp, vt_ld, dtype=torch.bfloat16, device=DEV)
+    vt[:, :, :krows] = vd.transpose(1, 2)
+    bd = bias.to(DEV).contiguous() if bias is not None else None
+    out = torch.empty(B, nq, hp, dtype=torch.bfloat16, device=DEV)
+    lse = torch.empty(B, heads, nq, device=DEV)
+    N.check(L.ctta_attention_lse(N.ptr(qd), hp, N.ptr(kd), hp, krows, N.ptr(vt), vt_ld, N.ptr(bd), N.ptr(out), hp, B, heads,
+                                 nq, nk, scale, N.ptr(lse), st))
+    # transposed operands, as the engine builds them
+    nk64, nq64 = rup(nk, 64), rup(nq, 64)
+    vn = torch.empty(B, vt_ld, hp, dtype=torch.bfloat16, device=DEV)
+    kt = torch.empty(B, hp, nk64, dtype=torch.bfloat16, device=DEV)
+    qt = torch.empty(B, hp, nq64, dtype=torch.bfloat16, device=DEV)
+    dot = torch.empty(B, hp, nq64, dtype=torch.bfloat16, device=DEV)
+    N.check(L.ctta_transpose_bf16(N.ptr(vt), hp * vt_ld, hp, vt_ld, vt_ld, 0, N.ptr(vn), vt_ld * hp, hp, B, st))
+    N.check(L.ctta_transpose_bf16(N.ptr(kd), krows * hp, nk, hp, hp, 0, N.ptr(kt), hp * nk64, nk64, B, st))
+    N.check(L.ctta_transpose_bf16(N.ptr(qd), nq * hp, nq, hp, hp, 0, N.ptr(qt), hp * nq64, nq64, B, st))
+    N.check(L.ctta_transpose_bf16(N.ptr(dod), nq * hp, nq, hp, hp, 0, N.ptr(dot), hp * nq64, nq64, B, st))
+    dsum = torch.empty(B, heads, nq, device=DEV)
+    dq = torch.full((B, nq, hp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dk = torch.zeros(B, krows, hp, dtype=torch.bfloat16, device=DEV)
+    dv = torch.zeros(B, krows, hp, dtype=torch.bfloat16, device=DEV)
+    N.check(L.ctta_attention_bwd(N.ptr(qd), hp, N.ptr(kd), hp, krows, N.ptr(vn), hp, vt_ld, N.ptr(kt), nk64, N.ptr(qt),
+                                 N.ptr(dot), nq64, N.ptr(bd), N.ptr(out), hp, N.ptr(dod), hp, N.ptr(lse), N.ptr(dsum),
+                                 N.ptr(dq), hp, N.ptr(dk), hp, N.ptr(dv), hp, B, heads, nq, nk, scale, st))
+    sync()
+
+    def unpad(x, n):
+        return torch.stack([x[:, :n, h * 64:h * 64 + dh].float().cpu() for h in range(heads)], dim=1)
+
+    # log-sum-exp of the forward (log2 domain) and the forward output
+    ref_lse = torch.logsumexp(s.detach(), dim=-1) * math.log2(math.e)
+    assert float((lse.cpu() - ref_lse).abs().max()) < 2e-2
+    assert rel_err(unpad(out, nq), o.detach()) < 2 * BF16_TOL
+    for name, got, ref in (("dq", unpad(dq, nq), q.grad), ("dk", unpad(dk, nk), k.grad), ("dv", unpad(dv, nk), v.grad)):
+        e = rel_err(got, ref)
+        print("%s rel err %.3e" % (name, e))
+        assert e < 3 * BF16_TOL, (name, e)
+    # head-padding lanes stay exactly zero (they feed the projection data-gradient GEMMs)
+    if dh < 64:
+        assert float(dq[:, :, dh:64].float().abs().max()) == 0.0 and float(dk[:, :nk, dh:64].float().abs().max()) == 0.0
