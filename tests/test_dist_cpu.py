@@ -27,7 +27,13 @@ def _worker(rank, world, port, q):
     mine = du.shard_clips(7, w, r)
     wav = torch.linspace(-0.5 - 0.1 * rank, 0.3 + 0.2 * rank, 11)
     mx, mn = du.global_wav_extrema(float(wav.max()), float(wav.min()), dev)
-    q.put((rank, t, mine, mx, mn))
+    # data-parallel distillation step: SUM all-reduce of the flat gradient in several buckets, 1/world folded
+    # into the optimizer; rank-0 parameters broadcast at start-up
+    grad = torch.arange(11, dtype=torch.float32) * (rank + 1)
+    w_ = du.allreduce_sum_(grad, bucket_elems=4)
+    params = torch.full((5,), float(rank + 7))
+    du.broadcast_(params)
+    q.put((rank, t, mine, mx, mn, w_, grad.tolist(), params.tolist()))
     du.finish()
 
 
@@ -47,3 +53,11 @@ def test_two_rank_protocol():
     assert sorted(res[0][2] + res[1][2]) == list(range(7))       # every clip owned exactly once
     for r in res:
         assert abs(r[3] - 0.5) < 1e-6 and abs(r[4] + 0.6) < 1e-6  # extrema agree on all ranks
+        assert r[5] == 2 and r[6] == [3.0 * i for i in range(11)]   # (1 + 2) * i summed over both ranks, all buckets
+        assert r[7] == [7.0] * 5                                    # everyone holds rank 0's parameters
+
+
+def test_allreduce_is_identity_without_a_process_group():
+    from consistencytta_amd import dist_util as du
+    g = torch.arange(6, dtype=torch.float32)
+    assert du.allreduce_sum_(g) == 1 and g.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
