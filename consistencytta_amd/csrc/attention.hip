@@ -244,6 +244,10 @@ struct AttnBwdParams {
   int dq_ld, dk_ld, dv_ld;
   int heads, nq, nk;
   float scale, scale_log2e;
+  // dkv kernel with few keys (cross-attention): the query range is split over blockIdx.z and every split
+  // writes fp32 partial sums part[z][dk|dv][B][k_rows][hp], folded by attn_bwd_fold_kernel
+  float* part;
+  int q_tiles_per_split, batch, hp;
 };
 
 // stages a [64 rows][64 cols] bf16 tile (row stride ld in LDS); rows >= rows_valid are zero
@@ -414,7 +418,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     for (int jk = 0; jk < 2; ++jk) { dv[jd][jk] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; dk[jd][jk] = (f32x4_t){0.f, 0.f, 0.f, 0.f}; }
 
   const int ntiles = (p.nq + 63) / 64;
-  for (int t = 0; t < ntiles; ++t) {
+  const int t_begin = blockIdx.z * p.q_tiles_per_split;
+  const int t_end = min(ntiles, t_begin + p.q_tiles_per_split);
+  for (int t = t_begin; t < t_end; ++t) {
     const int q0 = t * 64;
     __syncthreads();
     stage_rows(Qs, ATT_LDK, qb + (size_t)q0 * p.q_ld, p.q_ld, p.nq - q0, tid);
@@ -493,6 +499,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
       }
     }
   }
+  if (p.part) {   // split over queries: fp32 partials
+    const size_t plane = (size_t)p.batch * p.k_rows * p.hp;
+    float* pk = p.part + (size_t)blockIdx.z * 2 * plane;
+#pragma unroll
+    for (int jk = 0; jk < 2; ++jk) {
+      const int key = k0 + jk * 16 + lq;
+      if (key < p.nk) {
+        float* krow = pk + ((size_t)b * p.k_rows + key) * p.hp + h * 64;
+        float* vrow = krow + plane;
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) {
+          *reinterpret_cast<float4*>(krow + jd * 16 + lg * 4) = make_float4(dk[jd][jk][0], dk[jd][jk][1], dk[jd][jk][2], dk[jd][jk][3]);
+          *reinterpret_cast<float4*>(vrow + jd * 16 + lg * 4) = make_float4(dv[jd][jk][0], dv[jd][jk][1], dv[jd][jk][2], dv[jd][jk][3]);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int jk = 0; jk < 2; ++jk) {
     const int key = k0 + jk * 16 + lq;
@@ -510,6 +534,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
         *reinterpret_cast<uint2*>(krow + jd * 16 + lg * 4) = c;
       }
     }
+  }
+}
+
+// folds the query splits of the dkv kernel: dk/dv[b][key][c] = sum_z part[z][.][b][key][c]  (keys < nk)
+__global__ void attn_bwd_fold_kernel(const float* __restrict__ part, int nz, int batch, int k_rows, int nk, int hp,
+                                     bf16_t* __restrict__ dk, int dk_ld, bf16_t* __restrict__ dv, int dv_ld) {
+  const size_t plane = (size_t)batch * k_rows * hp;
+  const long long total = (long long)batch * nk * hp;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % hp);
+    const long long r = i / hp;
+    const int key = (int)(r % nk), b = (int)(r / nk);
+    const size_t off = ((size_t)b * k_rows + key) * hp + c;
+    float a = 0.f, v = 0.f;
+    for (int z = 0; z < nz; ++z) { a += part[(size_t)z * 2 * plane + off]; v += part[(size_t)z * 2 * plane + plane + off]; }
+    dk[((size_t)b * k_rows + key) * dk_ld + c] = f2bf(a);
+    dv[((size_t)b * k_rows + key) * dv_ld + c] = f2bf(v);
   }
 }
 
@@ -540,7 +581,7 @@ extern "C" ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k
                                           const void* dot, int qt_ld, const float* bias, const void* out, int out_ld,
                                           const void* dout, int do_ld, const float* lse, float* dsum, void* dq, int dq_ld,
                                           void* dk, int dk_ld, void* dv, int dv_ld, int batch, int heads, int nq, int nk,
-                                          float scale, void* stream) {
+                                          float scale, float* partial, int64_t partial_floats, void* stream) {
   CTTA_REQUIRE(q && k && vn && kt && qt && dot && out && dout && lse && dsum && dq && dk && dv, "attention_bwd: null pointer");
   CTTA_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vn_ld % 8 == 0 && kt_ld % 64 == 0 && qt_ld % 64 == 0 && do_ld % 8 == 0 &&
                    out_ld % 8 == 0 && dq_ld % 4 == 0 && dk_ld % 4 == 0 && dv_ld % 4 == 0,
@@ -561,7 +602,23 @@ extern "C" ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k
   // executed flops: 7 products of 2*nq*nk*64 per head (S and dP are computed by both kernels)
   if (prof) ctta_prof_begin(1, 1, nq, nk, 448, (long long)batch * heads, s);
   hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((nk + 127) / 128, batch * heads), dim3(256), 0, s, p);
+  // few keys (cross-attention): split the query walk so that the launch still fills the chip
+  const int ntiles = (nq + 63) / 64, kblocks = (nk + 127) / 128, hp = heads * 64;
+  int nz = 1;
+  if (partial) {
+    while (nz < 32 && (long long)kblocks * batch * heads * nz < 512 && ntiles / (nz * 2) >= 4) nz *= 2;
+    while (nz > 1 && (int64_t)nz * 2 * batch * k_rows * hp > partial_floats) nz /= 2;
+  }
+  p.q_tiles_per_split = (ntiles + nz - 1) / nz;
+  p.part = nz > 1 ? partial : nullptr;
+  p.batch = batch; p.hp = hp;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
+  if (nz > 1) {
+    CTTA_REQUIRE(dk_ld >= hp && dv_ld >= hp, "attention_bwd: split path needs dk/dv rows of at least heads*64");
+    const long long total = (long long)batch * nk * hp;
+    hipLaunchKernelGGL(attn_bwd_fold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, partial, nz, batch,
+                       k_rows, nk, hp, (bf16_t*)dk, dk_ld, (bf16_t*)dv, dv_ld);
+  }
   if (prof) ctta_prof_end(s);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;

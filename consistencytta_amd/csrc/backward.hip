@@ -198,6 +198,26 @@ __global__ __launch_bounds__(256) void wgrad_scatter_tiled_kernel(const float* _
     *g = accumulate ? *g + tile[kk][nn] : tile[kk][nn];
   }
 }
+// Row-major slabs [S][n_rows][ldk] (one slab row per weight row, k contiguous): a streaming add with a row remap,
+// coalesced on both sides with no staging.  grad_w[row_off[n] + col_off[k]] (+)= sum_s slab[s][n][k].
+__global__ __launch_bounds__(256) void wgrad_scatter_rows_kernel(const float* __restrict__ slabs, int S,
+                                                                 long long slab_stride, int ldk, int k_cols, int n_rows,
+                                                                 const int* __restrict__ row_off,
+                                                                 const int* __restrict__ col_off,
+                                                                 float* __restrict__ grad, int accumulate) {
+  const int n = blockIdx.y;
+  const int ro = row_off[n];
+  if (ro < 0) return;
+  const float* src = slabs + (size_t)n * ldk;
+  float* dst = grad + (size_t)ro;
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < k_cols; k += gridDim.x * 256) {
+    const int co = col_off ? col_off[k] : k;
+    if (co < 0) continue;
+    float v = 0.f;
+    for (int s = 0; s < S; ++s) v += src[(size_t)s * slab_stride + k];
+    dst[co] = accumulate ? dst[co] + v : v;
+  }
+}
 // vector grad (bias / per-sample rows): dst[idx[n]] (+)= sum_s slab[s][row][n]  (idx[n] < 0 skipped; idx NULL = identity)
 __global__ void row_scatter_kernel(const float* __restrict__ slabs, int S, long long slab_stride, int ldn, int row,
                                    int n_cols, const int* __restrict__ idx, float* __restrict__ dst, int accumulate) {
@@ -226,6 +246,40 @@ extern "C" ctta_status ctta_wgrad_scatter(const float* slabs, int n_slabs, int64
   hipLaunchKernelGGL(wgrad_scatter_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs,
                      (long long)slab_stride, ldn, k_rows, n_cols, row_off, col_off, row_aux, col_aux, aux_limit, grad,
                      accumulate);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+// dst[j * dst_stride + idx[n]] (+)= sum_s slab[s][n][col + j]   (row-major slabs; bias column, per-sample columns)
+__global__ void col_scatter_kernel(const float* __restrict__ slabs, int S, long long slab_stride, int ldk, int col,
+                                   int n_rows, const int* __restrict__ idx, float* __restrict__ dst, long long dst_stride,
+                                   int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_rows) return;
+  const int j = blockIdx.y;
+  const int t = idx ? idx[n] : n;
+  if (t < 0) return;
+  float v = 0.f;
+  for (int s = 0; s < S; ++s) v += slabs[(size_t)s * slab_stride + (size_t)n * ldk + col + j];
+  float* d = dst + (size_t)j * dst_stride + t;
+  *d = accumulate ? *d + v : v;
+}
+extern "C" ctta_status ctta_col_scatter(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int col, int n_cols,
+                                        int n_rows, const int32_t* idx, float* dst, int64_t dst_stride, int accumulate,
+                                        void* stream) {
+  CTTA_REQUIRE(slabs && dst && n_slabs >= 1 && n_cols >= 1 && n_rows >= 1, "col_scatter: bad arguments");
+  hipLaunchKernelGGL(col_scatter_kernel, dim3((n_rows + 255) / 256, n_cols), dim3(256), 0, (hipStream_t)stream, slabs,
+                     n_slabs, (long long)slab_stride, ldk, col, n_rows, idx, dst, (long long)dst_stride, accumulate);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+extern "C" ctta_status ctta_wgrad_scatter_rows(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int k_cols,
+                                               int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad,
+                                               int accumulate, void* stream) {
+  CTTA_REQUIRE(slabs && row_off && grad && n_slabs >= 1 && n_rows >= 1 && k_cols >= 1, "wgrad_scatter_rows: bad arguments");
+  int gx = (k_cols + 255) / 256;
+  if (gx > 8) gx = 8;
+  hipLaunchKernelGGL(wgrad_scatter_rows_kernel, dim3(gx, n_rows), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs,
+                     (long long)slab_stride, ldk, k_cols, n_rows, row_off, col_off, grad, accumulate);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

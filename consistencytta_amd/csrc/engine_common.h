@@ -148,9 +148,11 @@ struct WeightStore {
           return CTTA_ERR_INVALID;
         }
       ctta_pack_job j;
+      memset(&j, 0, sizeof(j));   // tables are compared bytewise: no indeterminate padding
       j.src = t->data; j.row_off = p.ro; j.col_off = p.co; j.row_aux = p.ra; j.col_aux = p.ca;
       j.aux_limit = p.aux_limit; j.n_rows = p.n_rows; j.k_pad = p.k_pad; j.dst = p.dst; j.block0 = blk;
-      blk += (int)(((int64_t)p.n_rows * p.k_pad + CTTA_PACK_ELEMS_PER_BLOCK - 1) / CTTA_PACK_ELEMS_PER_BLOCK);
+      j.rows_per_block = p.k_pad >= CTTA_PACK_ELEMS_PER_BLOCK ? 1 : CTTA_PACK_ELEMS_PER_BLOCK / p.k_pad;
+      blk += (p.n_rows + j.rows_per_block - 1) / j.rows_per_block;
       h_pack.push_back(j);
     }
     pack_blocks = blk;
@@ -166,6 +168,7 @@ struct WeightStore {
       }
       for (int off = 0; off < c.count; off += CTTA_COPY_ELEMS_PER_BLOCK) {
         ctta_copy_seg g;
+        memset(&g, 0, sizeof(g));
         g.src = t->data + c.src_start + off; g.dst = c.dst + off;
         g.count = c.count - off < CTTA_COPY_ELEMS_PER_BLOCK ? c.count - off : CTTA_COPY_ELEMS_PER_BLOCK;
         h_copy.push_back(g);

@@ -38,7 +38,9 @@ static ctta_status grad_ptr(BCtx& c, const std::string& key, float** out) {
 }
 
 // ------------------------------------------------------------------------------ weight gradients
-struct Slabs { float* p = nullptr; int S = 1, R = 0, N = 0; };
+// slabs[s][n][r]: one row per OUTPUT channel n, r = (cin, kh, kw) index of the weight row (then the bias column,
+// then per-sample columns) -- the state dict's own row layout, so the scatter is a coalesced streaming add.
+struct Slabs { float* p = nullptr; int S = 1, R = 0, ld = 0, N = 0; };
 
 static int pick_splits(int64_t M, int R, int N) {
   const int64_t tiles = (int64_t)((R + 127) / 128) * ((N + 127) / 128);
@@ -47,48 +49,50 @@ static int pick_splits(int64_t M, int R, int N) {
   return S;
 }
 
-// slabs[s][r][n] = sum_{m in segment s} Q[r][m] * dY[m][n];  x is the layer input in NHWC (a linear
-// is the 1x1 case with batch=1, hi=rows), dy [M][N] contiguous.  Rows of Q: (tap, channel) then
-// the all-ones row, then `nb` per-sample indicator rows.
+// slabs[s][n][r] = sum_{m in segment s} dY[m][n] * Q[r][m];  x is the layer input in NHWC (a linear is the 1x1 case
+// with batch=1, hi=rows), dy [M][N] contiguous.  Rows of Q: (channel, tap) then the all-ones row, then `nb`
+// per-sample indicator rows.  Both GEMM operands are made m-contiguous (dY^T, im2col^T).
 static ctta_status wgrad_slabs(BCtx& c, const bf16_t* x, int C, int B, int hi, int wi, bool ups, int ho, int wo, int kh,
                                int kw, int stride, int pad, const bf16_t* dy, int N, int nb, Slabs* out) {
   Arena& A = *c.arena;
   const int64_t M = (int64_t)B * ho * wo;
   const int K = kh * kw * C;
   const int R = K + 1 + nb;
+  const int ld = round_up(R, 4);
   const int S = pick_splits(M, R, N);
   const int mp = (int)round_up64(M, 64 * S);
   const int seg = mp / S;
   bf16_t* q = A.get<bf16_t>((size_t)R * mp); ALLOC_OR_FAIL(q);
   bf16_t* pt = A.get<bf16_t>((size_t)N * mp); ALLOC_OR_FAIL(pt);
-  float* slabs = A.get<float>((size_t)S * R * N); ALLOC_OR_FAIL(slabs);
+  float* slabs = A.get<float>((size_t)S * N * ld); ALLOC_OR_FAIL(slabs);
   RUN(c, ctta_im2col_t(x, C, B, hi, wi, ups ? 1 : 0, ho, wo, kh, kw, stride, pad, pad, 1, q, mp, nb, c.stream));
   RUN(c, ctta_transpose_bf16(dy, 0, (int)M, N, N, 0, pt, 0, mp, 1, c.stream));
   ctta_conv_desc d;
   desc_init(&d);
-  d.x0 = q; d.c0 = seg; d.x_stride = mp;
-  d.batch = 1; d.hi = R; d.wi = 1; d.ho = R; d.wo = 1;
-  d.w = pt; d.k_pad = mp; d.n = N;
-  d.out = slabs; d.ldc = N; d.out_f32 = 1;
-  d.groups = S; d.x_group_stride = seg; d.w_group_stride = seg; d.out_group_stride = (int64_t)R * N;
+  d.x0 = pt; d.c0 = seg; d.x_stride = mp;
+  d.batch = 1; d.hi = N; d.wi = 1; d.ho = N; d.wo = 1;
+  d.w = q; d.k_pad = mp; d.n = R;
+  d.out = slabs; d.ldc = ld; d.out_f32 = 1;
+  d.groups = S; d.x_group_stride = seg; d.w_group_stride = seg; d.out_group_stride = (int64_t)N * ld;
   RUN(c, ctta_conv_gemm(&d, c.stream));
-  out->p = slabs; out->S = S; out->R = R; out->N = N;
+  out->p = slabs; out->S = S; out->R = R; out->ld = ld; out->N = N;
   return CTTA_OK;
 }
 
-// slab columns [col0, col0 + m.n) -> weight / bias gradients of the layer described by `m`
-static ctta_status scatter_wgrad(BCtx& c, const Slabs& sl, int k_rows, const PackMap& m, int col0 = 0) {
-  const int64_t stride = (int64_t)sl.R * sl.N;
+// slab rows [row0, row0 + m.n) -> weight / bias gradients of the layer described by `m`
+static ctta_status scatter_wgrad(BCtx& c, const Slabs& sl, int k_rows, const PackMap& m, int row0 = 0) {
+  const int64_t stride = (int64_t)sl.N * sl.ld;
+  const float* base = sl.p + (size_t)row0 * sl.ld;
   float* gw;
   CTTA_TRY(grad_ptr(c, m.wkey, &gw));
   if (m.k_ident > 0)
-    RUN(c, ctta_wgrad_scatter(sl.p + col0, sl.S, stride, sl.N, m.k_ident, m.n, m.ro, nullptr, nullptr, nullptr, 0, gw, 1, c.stream));
+    RUN(c, ctta_wgrad_scatter_rows(base, sl.S, stride, sl.ld, m.k_ident, m.n, m.ro, nullptr, gw, 1, c.stream));
   else
-    RUN(c, ctta_wgrad_scatter(sl.p + col0, sl.S, stride, sl.N, k_rows, m.n, m.ro, m.co, nullptr, nullptr, 0, gw, 1, c.stream));
+    RUN(c, ctta_wgrad_scatter_rows(base, sl.S, stride, sl.ld, k_rows, m.n, m.ro, m.co, gw, 1, c.stream));
   if (!m.bkey.empty()) {
     float* gb;
     CTTA_TRY(grad_ptr(c, m.bkey, &gb));
-    RUN(c, ctta_row_scatter(sl.p + col0, sl.S, stride, sl.N, k_rows, m.n_bias, m.bidx, gb, 1, c.stream));
+    RUN(c, ctta_col_scatter(base, sl.S, stride, sl.ld, k_rows, 1, m.n_bias, m.bidx, gb, 0, 1, c.stream));
   }
   return CTTA_OK;
 }
@@ -104,9 +108,9 @@ static ctta_status conv_wgrad(BCtx& c, const ConvLayer& L, const PackMap& m, con
   CTTA_TRY(wgrad_slabs(c, x, L.cin_pad, c.B, hi, wi, ups, ho, wo, L.kh, L.kw, L.stride, L.pad, dy, L.p.n, nb, &sl));
   const int K = L.kh * L.kw * L.cin_pad;
   CTTA_TRY(scatter_wgrad(c, sl, K, m));
-  for (int b = 0; b < nb; ++b)   // d temb[b][off + n] = sum over the sample's pixels of dY
-    RUN(c, ctta_row_scatter(sl.p, sl.S, (int64_t)sl.R * sl.N, sl.N, K + 1 + b, L.cout, nullptr,
-                            c.dtemb_all + (size_t)b * c.U->temb_total + temb_off, 0, c.stream));
+  if (nb > 0)   // d temb[b][off + n] = sum over the sample's pixels of dY: columns K+1 .. K+B of the slab
+    RUN(c, ctta_col_scatter(sl.p, sl.S, (int64_t)sl.N * sl.ld, sl.ld, K + 1, nb, L.cout, nullptr,
+                            c.dtemb_all + temb_off, c.U->temb_total, 0, c.stream));
   A.release(mk);
   return CTTA_OK;
 }
@@ -219,12 +223,18 @@ static ctta_status bwd_attention(BCtx& c, int heads, int dh, const bf16_t* q, in
   bf16_t* qt = A.get<bf16_t>((size_t)B * hp * nq64); ALLOC_OR_FAIL(qt);       // Q^T
   bf16_t* dot = A.get<bf16_t>((size_t)B * hp * nq64); ALLOC_OR_FAIL(dot);     // dO^T
   float* dsum = A.get<float>((size_t)B * heads * nq); ALLOC_OR_FAIL(dsum);
+  float* part = nullptr;
+  int64_t part_floats = 0;
+  if (nk <= 128) {   // cross-attention: room for 32 query splits of the dk/dv kernel
+    part_floats = (int64_t)32 * 2 * B * krows * hp;
+    part = A.get<float>((size_t)part_floats); ALLOC_OR_FAIL(part);
+  }
   RUN(c, ctta_transpose_bf16(vt, (int64_t)hp * vt_ld, hp, vt_ld, vt_ld, 0, vn, (int64_t)vt_ld * hp, hp, B, c.stream));
   RUN(c, ctta_transpose_bf16(k, (int64_t)krows * ldk, nk, hp, ldk, 0, kt, (int64_t)hp * nk64, nk64, B, c.stream));
   RUN(c, ctta_transpose_bf16(q, (int64_t)nq * ldq, nq, hp, ldq, 0, qt, (int64_t)hp * nq64, nq64, B, c.stream));
   RUN(c, ctta_transpose_bf16(dO, (int64_t)nq * hp, nq, hp, hp, 0, dot, (int64_t)hp * nq64, nq64, B, c.stream));
   RUN(c, ctta_attention_bwd(q, ldq, k, ldk, krows, vn, hp, vt_ld, kt, nk64, qt, dot, nq64, bias, out, hp, dO, hp, lse, dsum,
-                            dq, lddq, dk, lddk, dv, hp, B, heads, nq, nk, 1.0f / sqrtf((float)dh), c.stream));
+                            dq, lddq, dk, lddk, dv, hp, B, heads, nq, nk, 1.0f / sqrtf((float)dh), part, part_floats, c.stream));
   A.release(mk);
   return CTTA_OK;
 }

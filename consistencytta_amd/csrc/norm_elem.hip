@@ -87,7 +87,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, const int* __r
   }
 }
 
-// All pack jobs of a state dict in one launch: a block finds its job by bisection over block0.
+// All pack jobs of a state dict in one launch: a block finds its job by bisection over block0 and packs
+// `rows_per_block` complete destination rows, so the strided source reads of one row (a conv row gathers
+// (cin, kh, kw) -> (kh, kw, cin)) stay inside one block's cache footprint instead of being re-fetched by 9 blocks.
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const ctta_pack_job* __restrict__ jobs, int n_jobs) {
   int lo = 0, hi = n_jobs - 1;
   while (lo < hi) {
@@ -95,19 +97,19 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const ctta_pack_
     if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const ctta_pack_job j = jobs[lo];
-  const long long total = (long long)j.n_rows * j.k_pad;
-  const long long base = (long long)(blockIdx.x - j.block0) * CTTA_PACK_ELEMS_PER_BLOCK;
+  const int r0 = (int)(blockIdx.x - j.block0) * j.rows_per_block;
+  const int r1 = min(j.n_rows, r0 + j.rows_per_block);
   bf16_t* dst = (bf16_t*)j.dst;
-#pragma unroll
-  for (int i = 0; i < CTTA_PACK_ELEMS_PER_BLOCK / 256; ++i) {
-    const long long idx = base + i * 256 + threadIdx.x;
-    if (idx >= total) break;
-    const int k = (int)(idx % j.k_pad);
-    const int r = (int)(idx / j.k_pad);
-    const int ro = j.row_off[r], co = j.col_off[k];
-    bool ok = ro >= 0 && co >= 0;
-    if (ok && j.aux_limit > 0) ok = j.row_aux[r] + j.col_aux[k] < j.aux_limit;
-    dst[idx] = ok ? f2bf(j.src[(size_t)ro + (size_t)co]) : (bf16_t)0;
+  for (int r = r0; r < r1; ++r) {
+    const int ro = j.row_off[r];
+    const int ra = j.aux_limit > 0 ? j.row_aux[r] : 0;
+    bf16_t* drow = dst + (size_t)r * j.k_pad;
+    for (int k = threadIdx.x; k < j.k_pad; k += 256) {
+      const int co = j.col_off[k];
+      bool ok = ro >= 0 && co >= 0;
+      if (ok && j.aux_limit > 0) ok = ra + j.col_aux[k] < j.aux_limit;
+      drow[k] = ok ? f2bf(j.src[(size_t)ro + (size_t)co]) : (bf16_t)0;
+    }
   }
 }
 __global__ __launch_bounds__(256) void copy_segments_multi_kernel(const ctta_copy_seg* __restrict__ segs) {
@@ -335,15 +337,76 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
   }
 }
 
+// Narrow rows (ld <= 512): GL lanes per row (32 or 64), 4 rows per lane group in flight, affine parameters
+// of the lane's 8 columns held in registers.  The one-wave-per-row kernel above leaves half the lanes idle and a
+// single load in flight at ld = 256 (the level-0 transformer width).
+template <int GL>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                             long long rows, int d, int ld,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps) {
+  constexpr int RPB = 256 / GL, PASSES = 4;
+  const int sub = threadIdx.x % GL, slot = threadIdx.x / GL;
+  const bool act = sub < ld / 8;
+  float g[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = sub * 8 + e;
+    g[e] = (act && c < d) ? gamma[c] : 0.f;
+    bt[e] = (act && c < d) ? beta[c] : 0.f;
+  }
+  const long long row0 = (long long)blockIdx.x * (RPB * PASSES) + slot;
+  uint4 raw[PASSES];
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const long long row = row0 + p * RPB;
+    raw[p] = make_uint4(0, 0, 0, 0);
+    if (act && row < rows) raw[p] = *reinterpret_cast<const uint4*>(x + (size_t)row * ld + sub * 8);
+  }
+  const float inv_d = 1.0f / (float)d;
+#pragma unroll
+  for (int p = 0; p < PASSES; ++p) {
+    const long long row = row0 + p * RPB;
+    float f[8];
+    unpack8(raw[p], f);
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      if (sub * 8 + e >= d) f[e] = 0.f;
+      s += f[e];
+    }
+#pragma unroll
+    for (int o = 1; o < GL; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      if (sub * 8 + e < d) { const float t = f[e] - mean; q += t * t; }
+#pragma unroll
+    for (int o = 1; o < GL; o <<= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q * inv_d + eps);
+    if (act && row < rows) {
+      float o8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o8[e] = sub * 8 + e < d ? (f[e] - mean) * rstd * g[e] + bt[e] : 0.f;
+      *reinterpret_cast<uint4*>(y + (size_t)row * ld + sub * 8) = pack8(o8);
+    }
+  }
+}
+
 extern "C" ctta_status ctta_layernorm(const void* x, void* y, int64_t rows, int d, int ld,
                                       const float* gamma, const float* beta, float eps, void* stream) {
   CTTA_REQUIRE(x && y && gamma && beta, "layernorm: null pointer");
   CTTA_REQUIRE(ld % 8 == 0 && d <= ld && d > 0 && ld <= 2048, "layernorm: d=%d ld=%d unsupported", d, ld);
   const dim3 grid((unsigned)cdiv64(rows, 4));
   hipStream_t s = (hipStream_t)stream;
-  if (ld <= 512)
-    hipLaunchKernelGGL(layernorm_kernel<1>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
-  else if (ld <= 1024)
+  if (ld <= 256) {
+    hipLaunchKernelGGL(layernorm_rows_kernel<32>, dim3((unsigned)cdiv64(rows, 32)), dim3(256), 0, s, (const bf16_t*)x,
+                       (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
+  } else if (ld <= 512) {
+    hipLaunchKernelGGL(layernorm_rows_kernel<64>, dim3((unsigned)cdiv64(rows, 16)), dim3(256), 0, s, (const bf16_t*)x,
+                       (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
+  } else if (ld <= 1024)
     hipLaunchKernelGGL(layernorm_kernel<2>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
   else
     hipLaunchKernelGGL(layernorm_kernel<4>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);

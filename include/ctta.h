@@ -248,13 +248,13 @@ ctta_status ctta_pack_weight(const float* src, const int32_t* row_off, const int
 
 /* Table-driven variants used by the engines' (re)load path: all pack jobs / all fp32 copies of a
  * state dict in ONE launch each.  `jobs` / `segs` are DEVICE arrays; jobs must be sorted by block0
- * (block0 = first thread block of the job, CTTA_PACK_ELEMS_PER_BLOCK outputs per block). */
+ * (block0 = first thread block of the job; a block packs rows_per_block complete rows). */
 #define CTTA_PACK_ELEMS_PER_BLOCK 2048
 #define CTTA_COPY_ELEMS_PER_BLOCK 16384
 typedef struct {
   const float* src;
   const int32_t *row_off, *col_off, *row_aux, *col_aux;
-  int aux_limit, n_rows, k_pad, block0;
+  int aux_limit, n_rows, k_pad, block0, rows_per_block;
   void* dst;
 } ctta_pack_job;
 typedef struct {
@@ -309,14 +309,17 @@ ctta_status ctta_attention_lse(const void* q, int q_ld, const void* k, int k_ld,
  *   kt [B][heads*64][kt_ld]  K^T (keys contiguous, zero beyond nk; kt_ld multiple of 64)
  *   qt, dot [B][heads*64][qt_ld]  Q^T and dout^T (queries contiguous, zero beyond nq)
  *   lse  from ctta_attention_lse;  dsum [B][heads][nq] fp32 scratch (D = rowsum(dout*out))
- * Writes dq [B*nq][dq_ld], dk / dv [B*k_rows][*_ld] for keys < nk (head h at columns h*64). */
+ * Writes dq [B*nq][dq_ld], dk / dv [B*k_rows][*_ld] for keys < nk (head h at columns h*64).
+ * partial (optional fp32 scratch of partial_floats): with few keys (cross-attention) the query walk of
+ * the dk/dv kernel is split over up to 32 workgroups whose fp32 partial sums are folded afterwards;
+ * needs 2 * splits * batch * k_rows * heads*64 floats, fewer splits are used if it is smaller. */
 ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k, int k_ld, int k_rows,
                                const void* vn, int vn_ld, int vn_rows, const void* kt, int kt_ld,
                                const void* qt, const void* dot, int qt_ld, const float* bias,
                                const void* out, int out_ld, const void* dout, int do_ld,
                                const float* lse, float* dsum, void* dq, int dq_ld, void* dk, int dk_ld,
                                void* dv, int dv_ld, int batch, int heads, int nq, int nk, float scale,
-                               void* stream);
+                               float* partial, int64_t partial_floats, void* stream);
 
 /* Small fp32 linear: y[m][n] = act_out(sum_k act_in(x[m][k]) * w[n][k] + b[n]); m <= 1024.
  * act: 0 none, 1 silu. */
@@ -349,6 +352,15 @@ ctta_status ctta_wgrad_scatter(const float* slabs, int n_slabs, int64_t slab_str
                                int n_cols, const int32_t* row_off, const int32_t* col_off,
                                const int32_t* row_aux, const int32_t* col_aux, int aux_limit, float* grad,
                                int accumulate, void* stream);
+/* same contraction for row-major slabs [S][n_rows][ldk] (k contiguous):
+ * grad_w[row_off[n] + col_off[k]] (+)= sum_s slabs[s][n][k] */
+ctta_status ctta_wgrad_scatter_rows(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int k_cols,
+                                    int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad,
+                                    int accumulate, void* stream);
+/* dst[j*dst_stride + idx[n]] (+)= sum_s slabs[s][n][col + j], j < n_cols (bias / per-sample columns) */
+ctta_status ctta_col_scatter(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int col, int n_cols,
+                             int n_rows, const int32_t* idx, float* dst, int64_t dst_stride, int accumulate,
+                             void* stream);
 ctta_status ctta_row_scatter(const float* slabs, int n_slabs, int64_t slab_stride, int ldn, int row,
                              int n_cols, const int32_t* idx, float* dst, int accumulate, void* stream);
 /* GroupNorm(+SiLU) backward; stats [B][G][2] = (mean, rstd) from ctta_groupnorm_stats */

@@ -39,21 +39,21 @@ def wgrad(x_nhwc, dy_nhwc, B, H, W, Cin, Cout, k, stride, pad, ups, Ho, Wo, spli
                             stride, pad, pad, 1, N.ptr(q), mp, B, st))
     pt = torch.empty(Cout, mp, dtype=torch.bfloat16, device=DEV)
     N.check(L.ctta_transpose_bf16(N.ptr(dy_nhwc), 0, M, Cout, Cout, 0, N.ptr(pt), 0, mp, 1, st))
-    slabs = torch.empty(splits, R, Cout, dtype=torch.float32, device=DEV)
+    ld = rup(R, 4)
+    slabs = torch.empty(splits, Cout, ld, dtype=torch.float32, device=DEV)
     seg = mp // splits
-    run_conv(conv_desc(x0=q, c0=seg, x_stride=mp, batch=1, hi=R, wi=1, ho=R, wo=1, w=pt, k_pad=mp, n=Cout, out=slabs,
-                       ldc=Cout, out_f32=1, groups=splits, x_group_stride=seg, w_group_stride=seg,
-                       out_group_stride=R * Cout))
+    # slabs[s][n][r] = sum_m dY^T[n][m] Q[r][m]: one slab row per weight row, k contiguous
+    run_conv(conv_desc(x0=pt, c0=seg, x_stride=mp, batch=1, hi=Cout, wi=1, ho=Cout, wo=1, w=q, k_pad=mp, n=R, out=slabs,
+                       ldc=ld, out_f32=1, groups=splits, x_group_stride=seg, w_group_stride=seg,
+                       out_group_stride=Cout * ld))
     ro = (torch.arange(Cout, dtype=torch.int32) * (Cin * k * k)).to(DEV)
     # im2col_t rows are (cin, kh, kw)-ordered like a conv weight row: identity column map (NULL)
     dw = torch.zeros(Cout, Cin, k, k, device=DEV)
-    N.check(L.ctta_wgrad_scatter(N.ptr(slabs), splits, R * Cout, Cout, K, Cout, N.ptr(ro), None, None, None, 0,
-                                 N.ptr(dw), 0, st))
+    N.check(L.ctta_wgrad_scatter_rows(N.ptr(slabs), splits, Cout * ld, ld, K, Cout, N.ptr(ro), None, N.ptr(dw), 0, st))
     db = torch.zeros(Cout, device=DEV)
-    N.check(L.ctta_row_scatter(N.ptr(slabs), splits, R * Cout, Cout, K, Cout, None, N.ptr(db), 0, st))
+    N.check(L.ctta_col_scatter(N.ptr(slabs), splits, Cout * ld, ld, K, 1, Cout, None, N.ptr(db), 0, 0, st))
     ps = torch.zeros(B, Cout, device=DEV)
-    for b in range(B):
-        N.check(L.ctta_row_scatter(N.ptr(slabs), splits, R * Cout, Cout, K + 1 + b, Cout, None, N.ptr(ps[b]), 0, st))
+    N.check(L.ctta_col_scatter(N.ptr(slabs), splits, Cout * ld, ld, K + 1, B, Cout, None, N.ptr(ps), Cout, 0, st))
     sync()
     return dw.cpu(), db.cpu(), ps.cpu()
 
@@ -248,6 +248,7 @@ def test_embedding_mlp_backward_loss_grad_and_adamw():
 
 @pytest.mark.parametrize("B,heads,dh,nq,nk,krows,use_bias", [(2, 3, 51, 200, 200, 200, False), (2, 2, 64, 256, 256, 256, False),
                                                             (3, 3, 13, 70, 7, 8, True), (1, 5, 51, 130, 31, 32, True),
+                                                            (1, 2, 51, 2100, 20, 24, True),
                                                             (2, 6, 40, 4, 4, 4, False)])
 def test_flash_attention_backward(B, heads, dh, nq, nk, krows, use_bias):
     """ctta_attention_lse + ctta_attention_bwd vs autograd of softmax(q k^T * scale + bias) v (fp32 on the
@@ -300,9 +301,11 @@ def test_flash_attention_backward(B, heads, dh, nq, nk, krows, use_bias):
     dq = torch.full((B, nq, hp), float("nan"), dtype=torch.bfloat16, device=DEV)
     dk = torch.zeros(B, krows, hp, dtype=torch.bfloat16, device=DEV)
     dv = torch.zeros(B, krows, hp, dtype=torch.bfloat16, device=DEV)
+    part = torch.empty(32 * 2 * B * krows * hp, device=DEV) if nk <= 128 else None   # query-split scratch (few keys)
     N.check(L.ctta_attention_bwd(N.ptr(qd), hp, N.ptr(kd), hp, krows, N.ptr(vn), hp, vt_ld, N.ptr(kt), nk64, N.ptr(qt),
                                  N.ptr(dot), nq64, N.ptr(bd), N.ptr(out), hp, N.ptr(dod), hp, N.ptr(lse), N.ptr(dsum),
-                                 N.ptr(dq), hp, N.ptr(dk), hp, N.ptr(dv), hp, B, heads, nq, nk, scale, st))
+                                 N.ptr(dq), hp, N.ptr(dk), hp, N.ptr(dv), hp, B, heads, nq, nk, scale, N.ptr(part),
+                                 part.numel() if part is not None else 0, st))
     sync()
 
     def unpad(x, n):
