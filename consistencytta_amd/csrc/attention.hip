@@ -62,17 +62,17 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   float lrun[2] = {0.f, 0.f};   // per-lane partial row sums (reduced over lane groups at the end)
 
   const int ntiles = (nk + ATT_KT - 1) / ATT_KT;
-  for (int t = 0; t < ntiles; ++t) {
-    const int key0 = t * ATT_KT;
-    __syncthreads();   // previous tile fully consumed
-    // stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys]: 512 16-byte chunks each
+  // K / V^T tiles travel global -> registers one tile ahead of the MFMAs, registers -> LDS at the top of the
+  // iteration: the global latency of tile t+1 hides behind the compute of tile t.
+  uint4 kreg[2], vreg[2];
+  auto fetch = [&](int key0) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int chunk = tid + i * 256;
       const int r = chunk >> 3, cc = (chunk & 7) * 8;
       uint4 kv = make_uint4(0, 0, 0, 0);
       if (key0 + r < nk) kv = *reinterpret_cast<const uint4*>(kb + (size_t)(key0 + r) * k_ld + cc);
-      *reinterpret_cast<uint4*>(Ks + r * ATT_LDK + cc) = kv;
+      kreg[i] = kv;
       uint4 vv = make_uint4(0, 0, 0, 0);
       const int valid = nk - (key0 + cc);   // keys of this chunk that exist
       if (valid > 0) {
@@ -85,9 +85,22 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
           vv = make_uint4(wv[0], wv[1], wv[2], wv[3]);
         }
       }
-      *reinterpret_cast<uint4*>(Vs + r * ATT_LDV + cc) = vv;
+      vreg[i] = vv;
+    }
+  };
+  fetch(0);
+  for (int t = 0; t < ntiles; ++t) {
+    const int key0 = t * ATT_KT;
+    __syncthreads();   // previous tile fully consumed
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int chunk = tid + i * 256;
+      const int r = chunk >> 3, cc = (chunk & 7) * 8;
+      *reinterpret_cast<uint4*>(Ks + r * ATT_LDK + cc) = kreg[i];
+      *reinterpret_cast<uint4*>(Vs + r * ATT_LDV + cc) = vreg[i];
     }
     __syncthreads();
+    if (t + 1 < ntiles) fetch(key0 + ATT_KT);
 
     // ---- S^T = K Q^T : 4 key blocks x 2 query blocks
     f32x4_t s[4][2];

@@ -111,6 +111,37 @@ def test_conv1d_dilated_lrelu_and_accumulate():
     assert rel_err(got, ref) < 2 * BF16_TOL   # `old` is itself bf16 and re-rounded
 
 
+@pytest.mark.parametrize("C,k,d,L", [(32, 11, 5, 777), (32, 3, 1, 256), (32, 7, 3, 1300), (32, 11, 1, 90), (64, 7, 3, 500)])
+def test_conv1d_halo_kernel(C, k, d, L):
+    """Stride-1 1-D convs with 32 channels (last HiFi-GAN stage) take the LDS-halo kernel automatically (C=64 stays on
+    the generic path); same epilogue options as the generic implicit GEMM (forced with tile=13), both checked against
+    F.conv1d."""
+    B = 2
+    x = bf16_round(det("halo.x", (B, C, L), 1))
+    w = bf16_round(det("halo.w", (C, C, k), 2) * (1.0 / math.sqrt(C * k)))
+    b = det("halo.b", (C,), 3) * 0.1
+    res = bf16_round(det("halo.r", (B, C, L), 4))
+    old = bf16_round(det("halo.o", (B, C, L), 5))
+    pad = (k * d - d) // 2
+    ref = F.leaky_relu((F.conv1d(x, w, b, dilation=d, padding=pad) + res + old) * 0.5, 0.1)
+    wp, k_pad = pack_conv_weight(w[:, :, None, :])
+    xa = x.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    rs = res.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    bd = b.to(DEV)
+    outs = []
+    for tile in (0, 13):
+        out = old.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+        out2 = torch.empty_like(out)
+        run_conv(conv_desc(x0=xa, c0=C, batch=B, hi=1, wi=L, ho=1, wo=L, kh=1, kw=k, pad_w=pad, dil_w=d, w=wp, k_pad=k_pad,
+                           n=C, bias=bd, res=rs, res_ld=C, accumulate=1, alpha=0.5, out_act=3, out_slope=0.1, out=out, ldc=C,
+                           out2=out2, out2_slope=0.1, tile=tile))
+        got = out.to(torch.float32).permute(0, 2, 1).cpu()
+        assert rel_err(got, ref) < 2 * BF16_TOL, tile
+        assert torch.equal(out2.float().cpu(), bf16_round(F.leaky_relu(out.float().cpu(), 0.1)))
+        outs.append(got)
+    assert rel_err(outs[0], outs[1]) < BF16_TOL      # halo kernel vs generic kernel
+
+
 def test_conv_fused_output_activations_and_scalar_store():
     """out_act=leaky_relu, the second (activated) output, and element-wise stores for Cout=1."""
     B, C, L, k = 2, 64, 150, 3
