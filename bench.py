@@ -45,9 +45,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=("both", "gen", "distill"), default="both",
-                    help="both (default): configs[1] generation line + a `distill` object for configs[3]; "
-                         "gen / distill: only that leg (profiling aids)")
+    ap.add_argument("--mode", choices=("both", "gen", "distill", "teacher"), default="both",
+                    help="both (default): configs[1] generation line + `distill` (configs[3]) and `teacher` (configs[2]) "
+                         "objects; gen / distill / teacher: only that leg (profiling aids)")
+    ap.add_argument("--teacher-steps", type=int, default=200, help="Heun steps of the teacher leg (2N-1 U-Net queries)")
+    ap.add_argument("--teacher-batch", type=int, default=8)
     ap.add_argument("--distill-batch", type=int, default=9, help="per-GPU micro-batch of the distillation leg (train.sh)")
     ap.add_argument("--profile-csv", default=None, help="append one line per MFMA launch (tuning aid)")
     return ap.parse_args()
@@ -72,6 +74,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     du.init("nccl", dev)   # "nccl" is RCCL on ROCm: timing barrier / max-reduce, gradient all-reduce of the distill leg
+    if args.mode == "teacher":
+        d = teacher_leg(args, dev, world, rank)
+        if rank == 0:
+            print(json.dumps(d), flush=True)
+        du.finish()
+        return
     if args.mode == "distill":   # profiling aid: only the distillation leg, printed as the JSON line
         d = distill_leg(args, dev, world, rank)
         if rank == 0:
@@ -201,9 +209,69 @@ def main():
         d = distill_leg(args, dev, world, rank)
         if rank == 0:
             result["distill"] = d
+        gc.collect()
+        torch.cuda.empty_cache()
+        t = teacher_leg(args, dev, world, rank)
+        if rank == 0:
+            result["teacher"] = t
     if rank == 0:
         print(json.dumps(result), flush=True)
     du.finish()
+
+
+def teacher_leg(args, dev, world, rank):
+    """BASELINE.json configs[2] (SURVEY.md §8d "Config 3"): the multi-step Heun teacher of AudioLCM.inference,
+    B clips per GPU (2B with CFG), N Heun steps = 2N-1 U-Net queries, w = 3, the loop replayed from one captured
+    hipGraph (models._teacher_loop_graphed).  Light U-Net, random-init weights.  Clips are independent: N GPUs
+    run N replicas.  Rank 0 also times the eager (uncaptured) loop for comparison."""
+    import torch
+
+    from consistencytta_amd import dist_util as du
+    from consistencytta_amd import scheduler as sched_mod
+    from consistencytta_amd import spec
+    from consistencytta_amd.models import AudioLCM
+
+    B, L, nsteps = args.teacher_batch, args.text_len, args.teacher_steps
+    m = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                 unet_model_config_path="tango_diffusion_light.json", unet_config=spec.LIGHT_UNET_CONFIG, snr_gamma=5.0,
+                 use_edm=True, teacher_guidance_scale=-1, num_diffusion_steps=18, vae=None, loss_type="mse")
+    m.to(dev)
+    m.teacher_unet.init_random_(seed=10)
+    m.student_ema_unet.init_random_(seed=11)
+    m.eval()
+    g = torch.Generator(device="cpu").manual_seed(7 + rank)
+    enc = (torch.randn(B, L, 1024, generator=g) * 0.25).to(dev)
+    lens = torch.randint(6, L + 1, (B,), generator=g)
+    mask = (torch.arange(L)[None, :] < lens[:, None]).to(dev)
+    umask = torch.zeros_like(mask)
+    umask[:, 0] = True
+    P = {"embeds_cf": torch.cat([torch.zeros_like(enc), enc]), "mask_cf": torch.cat([umask, mask]), "embeds": enc,
+         "mask": mask}
+    noise = torch.randn(B, 8, 256, 16, generator=g).to(dev)
+    sch = sched_mod.HeunDiscreteScheduler.from_pretrained("stabilityai/stable-diffusion-2-1", subfolder="scheduler")
+    kw = dict(guidance_scale_input=3.0, guidance_scale_post=1.0, num_steps=1, use_edm=True, use_ema=True,
+              query_teacher=True, return_all=True, noise=noise)
+    m.inference(P, sch, num_teacher_steps=2, graph_teacher=True, **kw)      # warm-up: handles, capture machinery
+    du.barrier(dev)
+    t0 = time.perf_counter()
+    _, lat, _, _ = m.inference(P, sch, num_teacher_steps=nsteps, graph_teacher=True, **kw)
+    du.barrier(dev)
+    dt = du.max_over_ranks(time.perf_counter() - t0, dev)
+    assert bool(torch.isfinite(lat).all()), "non-finite teacher latent"
+    evals = 2 * nsteps - 1
+    out = {"metric": "heun_teacher_clips_per_sec", "value": round(world * B / dt, 4), "unit": "clips/s",
+           "unet_queries_per_s": round(world * evals / dt, 2), "seconds_per_batch": round(dt, 3), "n_gpus": world,
+           "config": {"workload": "configs[2]: %d-step Heun teacher (%d CFG U-Net queries at batch %d), w=3, light U-Net, "
+                                  "hipGraph-replayed loop (includes the 1-step student query and graph capture)"
+                                  % (nsteps, evals, 2 * B), "batch_per_gpu": B, "text_len": L}}
+    if rank == 0:
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.inference(P, sch, num_teacher_steps=nsteps, **kw)
+        torch.cuda.synchronize()
+        out["eager_loop_seconds_per_batch"] = round(time.perf_counter() - t0, 3)
+    del m
+    return out
 
 
 GF_DISTILL_PER_SAMPLE = 4200.0   # SURVEY.md §3.3: 4 teacher + 1 target + 1 student fwd + 1 student bwd (~2 fwd)

@@ -420,7 +420,9 @@ class AudioLCM(AudioDistilledModel):
     @torch.no_grad()
     def inference(self, prompt, inference_scheduler, guidance_scale_input=3, guidance_scale_post=1, num_steps=20,
                   use_edm=False, num_samples=1, use_ema=True, query_teacher=False, num_teacher_steps=18,
-                  return_all=False, noise=None):
+                  return_all=False, noise=None, graph_teacher=False):
+        """`graph_teacher=True` runs the Heun teacher loop as replays of ONE captured hipGraph (a full 2nd-order
+        step = 2 CFG teacher queries); results are identical to the eager loop."""
         self.check_eval_mode()
         sch = inference_scheduler
         use_cf = guidance_scale_post > 1.
@@ -460,15 +462,89 @@ class AudioLCM(AudioDistilledModel):
             t2 = time()
             sch.set_timesteps(num_teacher_steps, device=dev)
             zhat_tea = noise * sch.init_noise_sigma
-            for t in sch._timesteps_host:
-                z_in = sch.scale_model_input(zhat_tea, float(t))
-                pred = self._query_teacher(z_in, float(t), enc_tea, mask_tea, guidance_scale_input)
-                zhat_tea = sch.step(pred, float(t), zhat_tea).prev_sample
+            if graph_teacher:
+                zhat_tea = self._teacher_loop_graphed(sch, zhat_tea, enc_tea, mask_tea, guidance_scale_input)
+            else:
+                for t in sch._timesteps_host:
+                    z_in = sch.scale_model_input(zhat_tea, float(t))
+                    pred = self._query_teacher(z_in, float(t), enc_tea, mask_tea, guidance_scale_input)
+                    zhat_tea = sch.step(pred, float(t), zhat_tea).prev_sample
             sch.prev_derivative = sch.dt = sch.sample = None
             time_tea = time() - t2 + time_embed
         if return_all:
             return zhat_0, zhat_tea, time_stu + time_embed, time_tea
         return zhat_0
+
+
+def _teacher_loop_graphed(self, sch, z, enc, mask, guidance_scale):
+    """The teacher loop of `inference` (audio_consistency_model.py:513-531) with its launch sequence captured
+    once: timesteps and sigmas live in device tables indexed by a device-side counter, the Heun state
+    (sample, derivative) in static buffers, so one graph = one full 2nd-order Heun step (scale, CFG teacher
+    query, 1st-order half, scale, CFG teacher query, 2nd-order half) and the loop is N-1 replays plus the
+    final 1st-order half.  No host sync, no per-iteration Python work beyond `replay()`."""
+    dev = z.device
+    B = z.shape[0]
+    n = z[0].numel()
+    ts_host, sig_host = sch._timesteps_host, sch._sigmas_host
+    nt = len(ts_host)                                   # 2N - 1
+    ts_dev = torch.tensor(ts_host, dtype=torch.float32, device=dev)
+    sig_dev = torch.tensor(sig_host, dtype=torch.float32, device=dev)
+    L_ = N.lib()
+    w = torch.full((B,), float(guidance_scale), dtype=torch.float32, device=dev)
+    x = z.clone().contiguous()
+    idx = torch.zeros(1, dtype=torch.int64, device=dev)
+    bufs = {k: torch.empty_like(x) for k in ("zin", "xhat", "deriv", "xnew")}
+    pred = torch.empty_like(x)
+
+    def query(zin, t_b):
+        out = self.teacher_unet(torch.cat([zin] * 2), torch.cat([t_b] * 2), enc, encoder_attention_mask=mask).sample
+        N.check(L_.ctta_cfg_combine(N.ptr(out[:B]), N.ptr(out[B:]), N.ptr(w), N.ptr(pred), B, n, N.stream_ptr()))
+        return pred
+
+    def half_first():
+        s_a = sig_dev.index_select(0, idx).expand(B).contiguous()
+        s_n = sig_dev.index_select(0, idx + 1).expand(B).contiguous()
+        t_a = ts_dev.index_select(0, idx).expand(B).contiguous()
+        N.check(L_.ctta_heun_scale_model_input(N.ptr(x), N.ptr(s_a), N.ptr(bufs["zin"]), B, n, N.stream_ptr()))
+        v = query(bufs["zin"], t_a)
+        N.check(L_.ctta_heun_step_first(N.ptr(v), N.ptr(x), N.ptr(s_a), N.ptr(s_n), N.ptr(bufs["xhat"]),
+                                        N.ptr(bufs["deriv"]), B, n, N.stream_ptr()))
+        return s_a, s_n
+
+    def pair():
+        s_a, s_n = half_first()
+        t_b = ts_dev.index_select(0, idx + 1).expand(B).contiguous()
+        N.check(L_.ctta_heun_scale_model_input(N.ptr(bufs["xhat"]), N.ptr(s_n), N.ptr(bufs["zin"]), B, n, N.stream_ptr()))
+        v = query(bufs["zin"], t_b)
+        N.check(L_.ctta_heun_step_second(N.ptr(v), N.ptr(bufs["xhat"]), N.ptr(x), N.ptr(bufs["deriv"]), N.ptr(s_a),
+                                         N.ptr(s_n), N.ptr(bufs["xnew"]), B, n, N.stream_ptr()))
+        x.copy_(bufs["xnew"])
+        idx.add_(2)
+
+    n_pairs = (nt - 1) // 2
+    if n_pairs > 0:
+        # one eager pair on a side stream first: handles, kernel attributes and the allocator pool must exist
+        # before capture; then rewind the state and capture
+        x0 = x.clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            pair()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        x.copy_(x0)
+        idx.zero_()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            pair()
+        x.copy_(x0)
+        idx.zero_()
+        for _ in range(n_pairs):
+            graph.replay()
+    half_first()                # last timestep: sigma_next = 0, a plain 1st-order (Euler) step
+    return bufs["xhat"].clone()
+
+
+AudioLCM._teacher_loop_graphed = _teacher_loop_graphed
 
 
 class ConsistencyTTA(nn.Module):

@@ -99,3 +99,24 @@ def test_update_ema_matches_reference_and_resyncs_engines(golden):
     m.eval()
     with pytest.raises(AssertionError):
         m.update_ema()                         # "EMA update should only be called during training"
+
+
+def test_teacher_loop_hipgraph_matches_eager(golden):
+    """Config 3: the Heun teacher loop replayed from one captured hipGraph gives the eager loop's result exactly,
+    and that result matches the reference's own AudioLCM.inference (3 Heun steps = 5 CFG teacher queries)."""
+    g = golden("distill_tiny")
+    m, P, _ = _model()
+    m.eval()
+    sched = scheduler.HeunDiscreteScheduler.from_pretrained("stabilityai/stable-diffusion-2-1", subfolder="scheduler")
+    noise = (cases.t(spec.det_uniform("distill.inf_noise", (3, 8, 256, 16), 16)) * np.float32(np.sqrt(3.0))).to(DEV)
+    kw = dict(guidance_scale_input=4.0, guidance_scale_post=1.0, num_steps=1, use_edm=True, use_ema=True,
+              query_teacher=True, return_all=True, noise=noise)
+    _, eager, _, _ = m.inference(P, sched, num_teacher_steps=3, **kw)
+    _, graphed, _, _ = m.inference(P, sched, num_teacher_steps=3, graph_teacher=True, **kw)
+    assert torch.equal(eager, graphed)
+    assert rel_l2(graphed, torch.from_numpy(g["inf_teacher_3steps"])) <= 2 * REL_L2
+    assert sched.state_in_first_order
+    # a longer schedule (more replays of the same graph) and a second call (new capture) stay consistent
+    _, e2, _, _ = m.inference(P, sched, num_teacher_steps=6, **kw)
+    _, g2, _, _ = m.inference(P, sched, num_teacher_steps=6, graph_teacher=True, **kw)
+    assert torch.equal(e2, g2)
