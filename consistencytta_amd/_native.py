@@ -6,6 +6,7 @@ library is missing or a call fails, a RuntimeError is raised (the reference rais
 exceptions at the same places -- shape asserts, load_state_dict key errors).
 """
 import ctypes
+from ctypes import byref  # noqa: F401  (re-exported for callers of out-parameter entry points)
 import os
 import subprocess
 from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int16, c_int32,
@@ -93,6 +94,8 @@ SIGNATURES = {
     "ctta_copy_segments_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "ctta_unet_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ctta_unet_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ctta_unet_backward_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ctta_unet_backward_next": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ctta_unet_arena_bytes": (c_size_t, [c_void_p]),
     "ctta_unet_num_taps": (c_int, [c_void_p]),
     "ctta_unet_tap_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
@@ -152,7 +155,7 @@ SIGNATURES = {
     "ctta_pool2_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_softmax_bias_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "ctta_softmax_bwd_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
-    "ctta_linear_f32_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ctta_linear_f32_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_snr_mse_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "ctta_prof_enable": (None, [c_int]),

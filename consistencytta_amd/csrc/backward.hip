@@ -801,15 +801,16 @@ extern "C" ctta_status ctta_softmax_bwd_rows(const void* p, const float* dp, int
 // y = x W^T + b (W [N][K]);  given dy [M][N]:  dx[m][k] = sum_n dy[m][n] W[n][k] (* silu'(xpre) when xpre given),
 // dW[n][k] (+)= sum_m dy[m][n] x[m][k], db[n] (+)= sum_m dy[m][n]
 // grid (K/64, M, n-chunks): 64 k-columns x 4 n-lanes per block, partial sums land with one atomicAdd per (m, k)
-__global__ __launch_bounds__(256) void linear_f32_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                                float* __restrict__ dx, int N, int K, int n_chunk) {
+__global__ __launch_bounds__(256) void linear_f32_bwd_dx_kernel(const float* __restrict__ dy, int ldy,
+                                                                const float* __restrict__ w, float* __restrict__ dx, int N,
+                                                                int K, int n_chunk) {
   __shared__ float red[4][64];
   const int kk = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int k = blockIdx.x * 64 + kk, m = blockIdx.y;
   const int n0 = blockIdx.z * n_chunk, n1 = min(N, n0 + n_chunk);
   float acc = 0.f;
   if (k < K)
-    for (int n = n0 + part; n < n1; n += 4) acc += dy[(size_t)m * N + n] * w[(size_t)n * K + k];
+    for (int n = n0 + part; n < n1; n += 4) acc += dy[(size_t)m * ldy + n] * w[(size_t)n * K + k];
   red[part][kk] = acc;
   __syncthreads();
   if (part == 0 && k < K) atomicAdd(&dx[(size_t)m * K + k], red[0][kk] + red[1][kk] + red[2][kk] + red[3][kk]);
@@ -821,7 +822,7 @@ __global__ void silu_grad_scale_kernel(float* __restrict__ dx, const float* __re
   const float s = 1.0f / (1.0f + expf(-z));
   dx[i] *= s * (1.0f + z * (1.0f - s));
 }
-__global__ void linear_f32_bwd_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+__global__ void linear_f32_bwd_dw_kernel(const float* __restrict__ dy, int ldy, const float* __restrict__ x,
                                          float* __restrict__ dw, float* __restrict__ db, int M, int N, int K,
                                          int accumulate) {
   const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
@@ -829,17 +830,17 @@ __global__ void linear_f32_bwd_dw_kernel(const float* __restrict__ dy, const flo
   const int n = (int)(i / K), k = (int)(i - (long long)n * K);
   float acc = 0.f, bs = 0.f;
   for (int m = 0; m < M; ++m) {
-    const float d = dy[(size_t)m * N + n];
+    const float d = dy[(size_t)m * ldy + n];
     acc += d * x[(size_t)m * K + k];
     bs += d;
   }
   dw[i] = accumulate ? dw[i] + acc : acc;
   if (db && k == 0) db[n] = accumulate ? db[n] + bs : bs;
 }
-extern "C" ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const float* dy, const float* xpre_silu,
-                                           float* dx, float* dw, float* db, int m, int n, int k, int accumulate_dx,
-                                           int accumulate_param, void* stream) {
-  CTTA_REQUIRE(x && w && dy, "linear_f32_bwd: null pointer");
+extern "C" ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const float* dy, int dy_ld,
+                                           const float* xpre_silu, float* dx, float* dw, float* db, int m, int n, int k,
+                                           int accumulate_dx, int accumulate_param, void* stream) {
+  CTTA_REQUIRE(x && w && dy && dy_ld >= n, "linear_f32_bwd: bad arguments");
   hipStream_t s = (hipStream_t)stream;
   if (dx) {
     CTTA_REQUIRE(!(accumulate_dx && xpre_silu), "linear_f32_bwd: accumulate_dx with a SiLU pre-activation is not supported");
@@ -847,7 +848,8 @@ extern "C" ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const
     int chunks = (n + 255) / 256;
     if (chunks > 64) chunks = 64;
     const int n_chunk = (n + chunks - 1) / chunks;
-    hipLaunchKernelGGL(linear_f32_bwd_dx_kernel, dim3((k + 63) / 64, m, chunks), dim3(256), 0, s, dy, w, dx, n, k, n_chunk);
+    hipLaunchKernelGGL(linear_f32_bwd_dx_kernel, dim3((k + 63) / 64, m, chunks), dim3(256), 0, s, dy, dy_ld, w, dx, n, k,
+                       n_chunk);
     CTTA_LAUNCH_CHECK();
     if (xpre_silu) {
       hipLaunchKernelGGL(silu_grad_scale_kernel, dim3((m * k + 255) / 256), dim3(256), 0, s, dx, xpre_silu, m * k);
@@ -856,8 +858,8 @@ extern "C" ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const
   }
   if (dw) {
     const long long total = (long long)n * k;
-    hipLaunchKernelGGL(linear_f32_bwd_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dy, x, dw, db, m,
-                       n, k, accumulate_param);
+    hipLaunchKernelGGL(linear_f32_bwd_dw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dy, dy_ld, x, dw,
+                       db, m, n, k, accumulate_param);
     CTTA_LAUNCH_CHECK();
   }
   return CTTA_OK;

@@ -101,6 +101,7 @@ struct TapeOp {
   Level* Lv = nullptr;
   const bf16_t* x = nullptr;   // layer input (samplers, conv_in)
   int H = 0, W = 0, ch = 0, skc = 0, skip_idx = -1;
+  int block = 0;   // 0 conv_in (+ embeddings), 1..n down blocks, n+1 mid, n+2.. up blocks
 };
 
 struct ctta_unet {
@@ -134,6 +135,13 @@ struct ctta_unet {
     const bf16_t *enc_bf = nullptr, *xin = nullptr, *h_last = nullptr, *a_out = nullptr;
     const float *mask_bias = nullptr, *st_out = nullptr;
   } ts;
+  struct BackwardState {   // between ctta_unet_backward_begin / _next calls
+    bool active = false;
+    bf16_t* dh = nullptr;
+    std::vector<bf16_t*> dskip;
+    float* dtemb_all = nullptr;
+    size_t pos = 0;
+  } bw;
 };
 
 struct UCtx : RunCtx {
@@ -431,7 +439,8 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   }
   c.enc_bf = enc_bf; c.mask_bias = mbias;
   U->ts.enc_bf = enc_bf; U->ts.mask_bias = mbias;
-  auto tape = [&](TapeOp op) { if (train) U->tape.push_back(op); };
+  int cur_block = 0;
+  auto tape = [&](TapeOp op) { op.block = cur_block; if (train) U->tape.push_back(op); };
 
   // ---- 2. conv_in
   bf16_t* xin = A.get<bf16_t>((size_t)B * H * W * U->cin_pad); ALLOC_OR_FAIL(xin);
@@ -455,6 +464,7 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   // ---- 3. down
   for (int i = 0; i < cfg.n_levels; ++i) {
     Level& Lv = U->down[i];
+    cur_block = 1 + i;
     const std::string p = "down_blocks." + std::to_string(i) + ".";
     for (size_t j = 0; j < Lv.res.size(); ++j) {
       CTTA_TRY(run_resnet(c, Lv.res[j], h, hh, ww, &h));
@@ -479,6 +489,7 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
     }
   }
   // ---- 4. mid
+  cur_block = 1 + cfg.n_levels;
   CTTA_TRY(run_resnet(c, U->mid_r0, h, hh, ww, &h));
   tape_res(U->mid_r0);
   CTTA_TRY(run_transformer(c, U->mid_att, h, hh, ww, &h));
@@ -489,6 +500,7 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   // ---- 5. up
   for (int i = 0; i < cfg.n_levels; ++i) {
     Level& Lv = U->up[i];
+    cur_block = 2 + cfg.n_levels + i;
     const std::string p = "up_blocks." + std::to_string(i) + ".";
     for (size_t j = 0; j < Lv.res.size(); ++j) {
       const Skip sk = skips.back();

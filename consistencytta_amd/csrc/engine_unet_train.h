@@ -192,6 +192,13 @@ static ctta_status bwd_resnet(BCtx& c, Resnet& R, const bf16_t* dout, bf16_t** d
   bf16_t* dt1 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(dt1);
   CTTA_TRY(gn_backward(c, R.n2, S.t1, da2, dt1, H * W, S.st2, true, false));
   CTTA_TRY(conv_wgrad(c, R.c1, R.t1.m, S.a, H, W, false, dt1, R.temb_off));
+  {  // temb = time_emb_proj(SiLU(emb)): its weight / bias gradients need only this resnet's rows of d temb
+    float *gw, *gb;
+    CTTA_TRY(grad_ptr(c, R.key + "time_emb_proj.weight", &gw));
+    CTTA_TRY(grad_ptr(c, R.key + "time_emb_proj.bias", &gb));
+    RUN(c, ctta_linear_f32_bwd(c.U->ts.emb_silu, c.U->temb_w, c.dtemb_all + R.temb_off, c.U->temb_total, nullptr, nullptr,
+                               gw, gb, c.B, R.cout, c.U->temb_dim, 0, 1, c.stream));
+  }
   bf16_t* da = A.get<bf16_t>(M * R.cin); ALLOC_OR_FAIL(da);
   CTTA_TRY(conv_dgrad(c, R.t1.d, dt1, H, W, da, H, W, false));
   if (R.has_sc) {
@@ -321,39 +328,15 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
 }
 
 // ------------------------------------------------------------------------------ embeddings
-__global__ void add_rows_f32_kernel(float* __restrict__ dst, const float* __restrict__ src, long long n) {
-  const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (i < n) dst[i] += src[i];
-}
-
 static ctta_status bwd_embeddings(BCtx& c) {
   ctta_unet* U = c.U;
   Arena& A = *c.arena;
   const ctta_unet::TrainSaved& S = U->ts;
   const int B = c.B, T = U->temb_dim, total = U->temb_total, c0 = U->cfg.block_out_channels[0];
-  // temb_all = Linear(SiLU(emb)) over the concatenated time_emb_proj table
-  float* dw = A.get<float>((size_t)total * T); ALLOC_OR_FAIL(dw);
-  float* db = A.get<float>((size_t)total); ALLOC_OR_FAIL(db);
+  // temb_all = Linear(SiLU(emb)) over the concatenated time_emb_proj table (its weight gradients were taken per resnet)
   float* demb = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(demb);
-  RUN(c, ctta_linear_f32_bwd(S.emb_silu, U->temb_w, c.dtemb_all, S.emb, demb, dw, db, B, total, T, 0, 0, c.stream));
-  auto scatter_res = [&](Resnet& R) -> ctta_status {
-    float *gw, *gb;
-    CTTA_TRY(grad_ptr(c, R.key + "time_emb_proj.weight", &gw));
-    CTTA_TRY(grad_ptr(c, R.key + "time_emb_proj.bias", &gb));
-    if (!c.dry) {
-      const long long n = (long long)R.cout * T;
-      hipLaunchKernelGGL(add_rows_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, gw,
-                         dw + (size_t)R.temb_off * T, n);
-      hipLaunchKernelGGL(add_rows_f32_kernel, dim3((R.cout + 255) / 256), dim3(256), 0, c.stream, gb, db + R.temb_off,
-                         (long long)R.cout);
-      CTTA_LAUNCH_CHECK();
-    }
-    return CTTA_OK;
-  };
-  for (auto& Lv : U->down) for (auto& R : Lv.res) CTTA_TRY(scatter_res(R));
-  for (auto& Lv : U->up) for (auto& R : Lv.res) CTTA_TRY(scatter_res(R));
-  CTTA_TRY(scatter_res(U->mid_r0));
-  CTTA_TRY(scatter_res(U->mid_r1));
+  RUN(c, ctta_linear_f32_bwd(S.emb_silu, U->temb_w, c.dtemb_all, total, S.emb, demb, nullptr, nullptr, B, total, T, 0, 0,
+                             c.stream));
   // emb = linear_2(SiLU(linear_1(feat)))  for the time (and guidance) branch; d emb feeds both
   auto mlp = [&](const std::string& name, const float* feat, int k, const float* hpre, const float* hid, const float* w1,
                  const float* w2) -> ctta_status {
@@ -363,8 +346,8 @@ static ctta_status bwd_embeddings(BCtx& c) {
     CTTA_TRY(grad_ptr(c, name + "linear_2.weight", &gw2));
     CTTA_TRY(grad_ptr(c, name + "linear_2.bias", &gb2));
     float* dh = A.get<float>((size_t)B * T); ALLOC_OR_FAIL(dh);
-    RUN(c, ctta_linear_f32_bwd(hid, w2, demb, hpre, dh, gw2, gb2, B, T, T, 0, 1, c.stream));
-    RUN(c, ctta_linear_f32_bwd(feat, w1, dh, nullptr, nullptr, gw1, gb1, B, T, k, 0, 1, c.stream));
+    RUN(c, ctta_linear_f32_bwd(hid, w2, demb, T, hpre, dh, gw2, gb2, B, T, T, 0, 1, c.stream));
+    RUN(c, ctta_linear_f32_bwd(feat, w1, dh, T, nullptr, nullptr, gw1, gb1, B, T, k, 0, 1, c.stream));
     return CTTA_OK;
   };
   CTTA_TRY(mlp("time_embedding.", S.tfeat, c0, S.t_h1pre, S.t_h1, U->t_w1, U->t_w2));
@@ -373,38 +356,62 @@ static ctta_status bwd_embeddings(BCtx& c) {
 }
 
 // ------------------------------------------------------------------------------ whole network
-static ctta_status unet_backward_impl(ctta_unet* U, bool dry, const bf16_t* dpred, const GradTable* grads,
-                                      hipStream_t stream, size_t* gn_need) {
-  const ctta_unet_config& cfg = U->cfg;
+// The backward pass is resumable block by block (out head, up blocks, mid block, down blocks, then conv_in + the
+// embedding MLPs): after each step all parameter gradients of that block are final, so the caller can start the
+// data-parallel all-reduce of that block's slice of the flat gradient buffer while the next block computes.
+static void bctx_init(BCtx& c, ctta_unet* U, bool dry, const GradTable* grads, hipStream_t stream) {
   const ctta_unet::TrainSaved& S = U->ts;
-  BCtx c;
   c.arena = &U->arena; c.stream = stream; c.dry = dry; c.taps = nullptr;
   c.gn_scratch = U->gn_scratch; c.gn_scratch_floats = U->gn_scratch_floats;
   c.U = U; c.B = S.B; c.L = S.L; c.Lp = S.Lp; c.train = true;
   c.enc_bf = S.enc_bf; c.mask_bias = S.mask_bias; c.grads = grads;
+  c.dtemb_all = U->bw.dtemb_all;
+}
+
+static ctta_status unet_backward_begin_impl(ctta_unet* U, bool dry, const bf16_t* dpred, const GradTable* grads,
+                                            hipStream_t stream) {
+  const ctta_unet_config& cfg = U->cfg;
+  const ctta_unet::TrainSaved& S = U->ts;
   Arena& A = U->arena;
   A.off = S.arena_off;
   A.no_release = false;
   const int B = S.B, H = cfg.height, W = cfg.width, c0 = cfg.block_out_channels[0];
-  c.dtemb_all = A.get<float>((size_t)B * U->temb_total); ALLOC_OR_FAIL(c.dtemb_all);
-  std::vector<bf16_t*> dskip((size_t)S.n_skips, nullptr);
-
+  U->bw.dtemb_all = A.get<float>((size_t)B * U->temb_total); ALLOC_OR_FAIL(U->bw.dtemb_all);
+  U->bw.dskip.assign((size_t)S.n_skips, nullptr);
+  U->bw.pos = U->tape.size();
+  BCtx c;
+  bctx_init(c, U, dry, grads, stream);
   // ---- conv_out, conv_norm_out
   const size_t M0 = (size_t)B * H * W;
   bf16_t* dh = A.get<bf16_t>(M0 * c0); ALLOC_OR_FAIL(dh);
-  {
-    const size_t mk = A.mark();
-    bf16_t* da = A.get<bf16_t>(M0 * c0); ALLOC_OR_FAIL(da);
-    CTTA_TRY(conv_dgrad(c, U->t_conv_out.d, dpred, H, W, da, H, W, false));
-    ConvLayer co;   // geometry of conv_out for the weight gradient (the forward runs it on the small-N kernel)
-    co.cin_pad = c0; co.cout = cfg.out_channels; co.kh = co.kw = 3; co.stride = 1; co.pad = 1; co.p.n = 8;
-    CTTA_TRY(conv_wgrad(c, co, U->t_conv_out.m, S.a_out, H, W, false, dpred));
-    CTTA_TRY(gn_backward(c, U->norm_out, S.h_last, da, dh, H * W, S.st_out, true, false));
-    A.release(mk);
-  }
-  // ---- the tape in reverse
-  for (size_t i = U->tape.size(); i-- > 0;) {
-    TapeOp& op = U->tape[i];
+  const size_t mk = A.mark();
+  bf16_t* da = A.get<bf16_t>(M0 * c0); ALLOC_OR_FAIL(da);
+  CTTA_TRY(conv_dgrad(c, U->t_conv_out.d, dpred, H, W, da, H, W, false));
+  ConvLayer co;   // geometry of conv_out for the weight gradient (the forward runs it on the small-N kernel)
+  co.cin_pad = c0; co.cout = cfg.out_channels; co.kh = co.kw = 3; co.stride = 1; co.pad = 1; co.p.n = 8;
+  CTTA_TRY(conv_wgrad(c, co, U->t_conv_out.m, S.a_out, H, W, false, dpred));
+  CTTA_TRY(gn_backward(c, U->norm_out, S.h_last, da, dh, H * W, S.st_out, true, false));
+  A.release(mk);
+  U->bw.dh = dh;
+  U->bw.active = true;
+  return CTTA_OK;
+}
+
+// replays the tape entries of ONE block (all entries at the current position that share its block id); the last
+// step also runs the embedding MLPs.  *block_done = id of the finished block, *finished = 1 after the last step.
+static ctta_status unet_backward_next_impl(ctta_unet* U, bool dry, const GradTable* grads, hipStream_t stream,
+                                           int* block_done, int* finished) {
+  const ctta_unet::TrainSaved& S = U->ts;
+  Arena& A = U->arena;
+  BCtx c;
+  bctx_init(c, U, dry, grads, stream);
+  const int B = S.B;
+  bf16_t* dh = U->bw.dh;
+  std::vector<bf16_t*>& dskip = U->bw.dskip;
+  CTTA_REQUIRE(U->bw.pos > 0, "unet_backward_next: nothing left to replay");
+  const int block = U->tape[U->bw.pos - 1].block;
+  while (U->bw.pos > 0 && U->tape[U->bw.pos - 1].block == block) {
+    TapeOp& op = U->tape[--U->bw.pos];
     const size_t M = (size_t)B * op.H * op.W;
     switch (op.kind) {
       case TapeOp::RESNET: CTTA_TRY(bwd_resnet(c, *op.R, dh, &dh)); break;
@@ -453,8 +460,23 @@ static ctta_status unet_backward_impl(ctta_unet* U, bool dry, const bf16_t* dpre
         break;
     }
   }
-  CTTA_TRY(bwd_embeddings(c));
-  if (gn_need) *gn_need = c.gn_need;
+  U->bw.dh = dh;
+  *block_done = block;
+  *finished = 0;
+  if (U->bw.pos == 0) {
+    CTTA_TRY(bwd_embeddings(c));
+    *finished = 1;
+    U->bw.active = false;
+  }
+  return CTTA_OK;
+}
+
+static ctta_status unet_backward_impl(ctta_unet* U, bool dry, const bf16_t* dpred, const GradTable* grads,
+                                      hipStream_t stream, size_t* gn_need) {
+  CTTA_TRY(unet_backward_begin_impl(U, dry, dpred, grads, stream));
+  int block = 0, fin = 0;
+  while (!fin) CTTA_TRY(unet_backward_next_impl(U, dry, grads, stream, &block, &fin));
+  if (gn_need) *gn_need = 0;
   return CTTA_OK;
 }
 
@@ -479,6 +501,28 @@ extern "C" ctta_status ctta_unet_backward(ctta_unet* U, const void* dout_nhwc, c
   GradTable gt;
   gt.build(grads, n_grads);
   const ctta_status st = unet_backward_impl(U, false, (const bf16_t*)dout_nhwc, &gt, (hipStream_t)stream, nullptr);
-  U->ts.valid = false;   // the saved activations have been overwritten by backward temporaries
+  U->ts.valid = false;   // one backward per training forward
   return st;
+}
+
+// Block-wise variant for overlapping the data-parallel gradient all-reduce with the backward pass:
+//   begin (out head) -> next ... next until *finished.  Block ids: 0 = conv_in + embedding MLPs, 1..n = down blocks,
+//   n+1 = mid block, n+2..2n+1 = up blocks, 2n+2 = conv_norm_out + conv_out (final after `begin`).
+extern "C" ctta_status ctta_unet_backward_begin(ctta_unet* U, const void* dout_nhwc, const ctta_tensor* grads, int n_grads,
+                                                void* stream) {
+  CTTA_REQUIRE(U && dout_nhwc && grads, "unet_backward_begin: null pointer");
+  CTTA_REQUIRE(U->cfg.enable_training, "unet_backward_begin: handle was created without enable_training");
+  CTTA_REQUIRE(U->ts.valid, "unet_backward_begin: no training forward to differentiate (call ctta_unet_forward_train first)");
+  GradTable gt;
+  gt.build(grads, n_grads);
+  U->ts.valid = false;
+  return unet_backward_begin_impl(U, false, (const bf16_t*)dout_nhwc, &gt, (hipStream_t)stream);
+}
+extern "C" ctta_status ctta_unet_backward_next(ctta_unet* U, const ctta_tensor* grads, int n_grads, void* stream,
+                                               int* block_done, int* finished) {
+  CTTA_REQUIRE(U && grads && block_done && finished, "unet_backward_next: null pointer");
+  CTTA_REQUIRE(U->bw.active, "unet_backward_next: call ctta_unet_backward_begin first");
+  GradTable gt;
+  gt.build(grads, n_grads);
+  return unet_backward_next_impl(U, false, &gt, (hipStream_t)stream, block_done, finished);
 }

@@ -70,6 +70,55 @@ def allreduce_sum_(flat, bucket_elems=64 << 20):
     return dist.get_world_size()
 
 
+class GradientBuckets:
+    """Overlaps the data-parallel gradient all-reduce with the backward pass: the engine finishes the U-Net's
+    blocks in reverse order (out head, up blocks, mid, down blocks, conv_in + embeddings) and reports each one;
+    `ready(block)` immediately issues the asynchronous SUM all-reduce of that block's contiguous slice of the flat
+    gradient buffer (RCCL runs it on its own stream behind the kernels already enqueued), `wait()` joins them
+    before the optimizer.  Blocks are merged until a bucket holds at least `min_elems` elements so that the small
+    level-0 blocks do not become many tiny collectives on the per-link-bound xGMI rings."""
+
+    def __init__(self, flat_grad, ranges, min_elems=16 << 20):
+        self.flat, self.ranges, self.min_elems = flat_grad, dict(ranges), int(min_elems)
+        self.works, self.pending = [], []
+        # CTTA_FORCE_COLLECTIVES=1 keeps the block-wise path on with a single rank (tests / profiling of the overlap)
+        force = os.environ.get("CTTA_FORCE_COLLECTIVES", "0") == "1"
+        self.enabled = dist.is_initialized() and (dist.get_world_size() > 1 or force)
+        self.world = dist.get_world_size() if self.enabled else 1
+
+    def _flush(self):
+        # merge adjacent ranges, one collective per contiguous run
+        for lo, hi in _merge(self.pending):
+            self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        self.pending = []
+
+    def ready(self, block):
+        if not self.enabled or block not in self.ranges:
+            return
+        self.pending.append(self.ranges[block])
+        if sum(hi - lo for lo, hi in self.pending) >= self.min_elems:
+            self._flush()
+
+    def wait(self):
+        """Joins all collectives; returns the world size (the 1/world factor goes into the optimizer kernel)."""
+        if self.enabled:
+            self._flush()
+            for w in self.works:
+                w.wait()
+        self.works = []
+        return self.world
+
+
+def _merge(ranges):
+    out = []
+    for lo, hi in sorted(ranges):
+        if out and out[-1][1] == lo:
+            out[-1] = (out[-1][0], hi)
+        else:
+            out.append((lo, hi))
+    return out
+
+
 def broadcast_(flat, src=0):
     """Rank `src`'s parameters to every rank (what DDP does at wrap time)."""
     if dist.is_initialized() and dist.get_world_size() > 1:

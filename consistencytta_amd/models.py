@@ -299,14 +299,14 @@ class AudioLCM(AudioDistilledModel):
             a = self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         return a
 
-    def _student_backward(self, pred, target, sig, gamma, loss_scale=1.0):
+    def _student_backward(self, pred, target, sig, gamma, loss_scale=1.0, on_block_done=None):
         """d loss / d pred of get_loss (audio_consistency_model.py:250-266) -> engine backward."""
         B, C, H, W = pred.shape
         d = torch.empty(B, H * W, 8, dtype=torch.bfloat16, device=pred.device)
         with torch.cuda.device(pred.device):
             N.check(N.lib().ctta_snr_mse_grad(N.ptr(pred), N.ptr(target.contiguous()), N.ptr(sig), float(gamma),
                                               float(loss_scale), B, C, H * W, 8, N.ptr(d), N.stream_ptr()))
-        self.student_unet.backward(grad_output_nhwc=d)
+        self.student_unet.backward(grad_output_nhwc=d, on_block_done=on_block_done)
 
     def prepare_training(self, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, broadcast=True):
         """Flat parameter buffers for the student family, rank-0 weights on every rank (DDP's wrap-time
@@ -329,8 +329,10 @@ class AudioLCM(AudioDistilledModel):
             loss, pred, target, sig, gamma = self._forward_impl(
                 z_0, gt_wav, prompt, False, True, fw.pop("time_inds", None), fw.pop("gaussian_noise", None),
                 fw.pop("guidance_scale", None), True)
-            self._student_backward(pred, target, sig, gamma, 1.0)
-            world = dist_util.allreduce_sum_(optimizer.grad[:optimizer.n])
+            # gradient all-reduce (RCCL) overlapped with the backward pass, block by block
+            buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges())
+            self._student_backward(pred, target, sig, gamma, 1.0, buckets.ready if buckets.enabled else None)
+            world = buckets.wait()
             value = float(loss.item())
             if not (skip_nan and value != value):      # train_utils.py:167-172: a NaN loss skips the update
                 optimizer.step(grad_scale=1.0 / world)

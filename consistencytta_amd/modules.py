@@ -296,7 +296,7 @@ class _UNetBase(_ParamTree):
         return self._forward(sample, timestep, guidance if self._guided else None, encoder_hidden_states,
                              encoder_attention_mask, train=True)
 
-    def backward(self, grad_output=None, grad_output_nhwc=None):
+    def backward(self, grad_output=None, grad_output_nhwc=None, on_block_done=None):
         """Accumulates dL/d(param) of the last `forward_train` into `p.grad` (fp32, allocated on first
         use).  `grad_output`: dL/d(prediction) (B,C,H,W) fp32, or `grad_output_nhwc`: the same as the
         (B, H*W, 8) bf16 tensor ctta_snr_mse_grad writes."""
@@ -314,9 +314,50 @@ class _UNetBase(_ParamTree):
                 p.grad = torch.zeros_like(p.data)
             table[k] = p.grad
         tab, keep = N.tensor_table(table)
+        g = grad_output_nhwc.contiguous()
         with torch.cuda.device(dev):
-            N.check(N.lib().ctta_unet_backward(self._h_unet, N.ptr(grad_output_nhwc.contiguous()), tab, len(tab),
-                                               N.stream_ptr()))
+            if on_block_done is None:
+                N.check(N.lib().ctta_unet_backward(self._h_unet, N.ptr(g), tab, len(tab), N.stream_ptr()))
+                return
+            # block-wise: after each step the gradients of one block are final; the callback typically starts
+            # the all-reduce of that block's slice of the flat gradient buffer (dist_util.GradientBuckets)
+            L_ = N.lib()
+            n_levels = len(self._cfg["block_out_channels"])
+            N.check(L_.ctta_unet_backward_begin(self._h_unet, N.ptr(g), tab, len(tab), N.stream_ptr()))
+            on_block_done(2 * n_levels + 2)
+            blk, fin = N.c_int(0), N.c_int(0)
+            while not fin.value:
+                N.check(L_.ctta_unet_backward_next(self._h_unet, tab, len(tab), N.stream_ptr(), N.byref(blk), N.byref(fin)))
+                on_block_done(blk.value)
+
+    def block_ranges(self):
+        """block id (see ctta_unet_backward_next) -> (start, end) element range of that block's parameters in the
+        flat parameter / gradient buffers (trainable parameters only; state-dict order keeps blocks contiguous)."""
+        n_levels = len(self._cfg["block_out_channels"])
+
+        def block_of(key):
+            head, _, rest = key.partition(".")
+            if head == "down_blocks":
+                return 1 + int(rest.split(".")[0])
+            if head == "mid_block":
+                return 1 + n_levels
+            if head == "up_blocks":
+                return 2 + n_levels + int(rest.split(".")[0])
+            if head in ("conv_norm_out", "conv_out"):
+                return 2 * n_levels + 2
+            return 0   # conv_in, time_embedding, guidance_embedding
+        frozen = set(getattr(self, "_frozen_keys", ()))
+        ranges, off = {}, 0
+        for k, p in self.named_parameters():
+            if k in frozen:
+                continue
+            b = block_of(k)
+            lo, hi = ranges.get(b, (off, off))
+            if hi != off:
+                raise RuntimeError("parameters of block %d are not contiguous in the flat buffer" % b)
+            ranges[b] = (lo, off + p.numel())
+            off += p.numel()
+        return ranges
 
     def read_taps(self):
         """name -> NCHW fp32 tensor of every recorded intermediate (debug_taps=True only)."""

@@ -93,6 +93,15 @@ ctta_status ctta_unet_forward_train(ctta_unet* h, const float* sample, const flo
                                     int batch, int text_len, float* out, void* stream);
 ctta_status ctta_unet_backward(ctta_unet* h, const void* dout_nhwc, const ctta_tensor* grads,
                                int n_grads, void* stream);
+/* The same backward pass, resumable block by block, so that the data-parallel all-reduce of a finished
+ * block's gradients (accelerate/DDP's bucketed all-reduce, train.py:377-379) overlaps with the remaining
+ * backward work: `begin` finishes block 2n+2 (conv_norm_out, conv_out); every `next` finishes one more
+ * block and reports its id -- n+2+i = up_blocks.i, n+1 = mid_block, 1+i = down_blocks.i, 0 = conv_in +
+ * time/guidance embedding MLPs (last, *finished = 1). */
+ctta_status ctta_unet_backward_begin(ctta_unet* h, const void* dout_nhwc, const ctta_tensor* grads,
+                                     int n_grads, void* stream);
+ctta_status ctta_unet_backward_next(ctta_unet* h, const ctta_tensor* grads, int n_grads, void* stream,
+                                    int* block_done, int* finished);
 /* Debug taps (only when cfg.debug_taps): named NCHW fp32 copies of intermediates. */
 int ctta_unet_num_taps(const ctta_unet* h);
 ctta_status ctta_unet_tap_info(const ctta_unet* h, int i, const char** name, int dims[4]);
@@ -386,9 +395,9 @@ ctta_status ctta_softmax_bias_rows(const float* s, int lds, const float* bias, i
                                    int64_t rows, int cols, int ldp, float scale, void* stream);
 ctta_status ctta_softmax_bwd_rows(const void* p, const float* dp, int lddp, void* ds, int64_t rows, int cols,
                                   int ldp, float scale, void* stream);
-ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const float* dy, const float* xpre_silu,
-                                float* dx, float* dw, float* db, int m, int n, int k, int accumulate_dx,
-                                int accumulate_param, void* stream);
+ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const float* dy, int dy_ld,
+                                const float* xpre_silu, float* dx, float* dw, float* db, int m, int n, int k,
+                                int accumulate_dx, int accumulate_param, void* stream);
 /* d/dpred of get_loss (MSE 'instance' x SNR clamp, models/audio_consistency_model.py:250-266) as NHWC bf16 */
 ctta_status ctta_snr_mse_grad(const float* pred, const float* target, const float* sigma, float gamma,
                               float loss_scale, int batch, int c, int hw, int c_pad, void* dpred_nhwc,

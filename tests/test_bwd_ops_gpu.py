@@ -214,10 +214,18 @@ def test_embedding_mlp_backward_loss_grad_and_adamw():
     xs = F.silu(x.detach()).to(DEV)
     dx, dw, db = torch.empty(M, Kd, device=DEV), torch.empty(Nn, Kd, device=DEV), torch.empty(Nn, device=DEV)
     xpre, wd, dyd = x.detach().to(DEV), w.detach().to(DEV), dy.to(DEV)
-    N.check(L.ctta_linear_f32_bwd(N.ptr(xs), N.ptr(wd), N.ptr(dyd), N.ptr(xpre), N.ptr(dx), N.ptr(dw), N.ptr(db), M, Nn,
+    N.check(L.ctta_linear_f32_bwd(N.ptr(xs), N.ptr(wd), N.ptr(dyd), Nn, N.ptr(xpre), N.ptr(dx), N.ptr(dw), N.ptr(db), M, Nn,
                                   Kd, 0, 0, st))
     sync()
     assert rel_err(dx.cpu(), x.grad) < 1e-5 and rel_err(dw.cpu(), w.grad) < 1e-5 and rel_err(db.cpu(), b.grad) < 1e-5
+    # a column slice of a wider dY (the per-resnet rows of the concatenated time_emb_proj table)
+    wide = torch.zeros(M, Nn + 11, device=DEV)
+    wide[:, 7:7 + Nn] = dyd
+    dw2, db2 = torch.zeros_like(dw), torch.zeros_like(db)
+    N.check(L.ctta_linear_f32_bwd(N.ptr(xs), N.ptr(wd), N.ptr(wide[:, 7:]), Nn + 11, None, None, N.ptr(dw2), N.ptr(db2), M,
+                                  Nn, Kd, 0, 1, st))
+    sync()
+    assert rel_err(dw2.cpu(), w.grad) < 1e-5 and rel_err(db2.cpu(), b.grad) < 1e-5
     # loss gradient
     B, C, H, W = 3, 8, 6, 4
     pred = det("lg.p", (B, C, H, W), 5).requires_grad_(True)

@@ -33,6 +33,13 @@ def _worker(rank, world, port, q):
     w_ = du.allreduce_sum_(grad, bucket_elems=4)
     params = torch.full((5,), float(rank + 7))
     du.broadcast_(params)
+    # block-wise buckets as the backward pass reports them (last block first); small blocks merge
+    g2 = torch.arange(11, dtype=torch.float32) * (rank + 1)
+    buckets = du.GradientBuckets(g2, {0: (0, 3), 1: (3, 7), 2: (7, 11)}, min_elems=5)
+    assert buckets.enabled
+    for blk in (2, 1, 0):
+        buckets.ready(blk)
+    assert buckets.wait() == 2 and g2.tolist() == [3.0 * i for i in range(11)]
     q.put((rank, t, mine, mx, mn, w_, grad.tolist(), params.tolist()))
     du.finish()
 

@@ -217,3 +217,54 @@ def test_train_step_adamw_and_ema_match_torch(golden):
     assert torch.equal(m.student_unet.get_parameter(k).detach().cpu(), cases.unet_weights(cases.TINY_UNET, True, 1)[k])
     # the engines picked the new weights up: the next loss differs from the first one
     assert abs(m.train_step(z0, P, opt, sched, **kw) - float(g["train_loss"])) > 1e-6
+
+
+def test_blockwise_backward_with_rccl_buckets_equals_monolithic(golden):
+    """The overlapped data-parallel path on one GPU: a 1-rank RCCL process group with CTTA_FORCE_COLLECTIVES=1 makes
+    train_step run the block-wise backward and issue the bucketed all-reduces; the parameters after one optimisation
+    step must equal those of the plain (monolithic backward, no collective) step.  (Only one step is compared
+    element-wise: the bf16 re-pack of the updated weights is discontinuous, so the last-bit noise of the LayerNorm
+    atomics can flip a rounding and, through AdamW's normalisation, move a near-zero-gradient element by ~lr in the
+    next step; the second step is checked through its loss.)"""
+    import os
+    import torch.distributed as dist
+    from consistencytta_amd import dist_util as du
+    g = golden("distill_tiny")
+    kw = dict(time_inds=torch.from_numpy(g["time_inds"]) * 2, gaussian_noise=torch.from_numpy(g["noise"]).to(DEV),
+              guidance_scale=torch.from_numpy(g["guidance"]))
+
+    def run(force):
+        m, P, z0 = _lcm()
+        m.train()
+        opt = m.prepare_training(lr=1e-3, weight_decay=1e-2, broadcast=False)
+        os.environ["CTTA_FORCE_COLLECTIVES"] = "1" if force else "0"
+        try:
+            losses = [m.train_step(z0, P, opt, None, **kw)]
+            torch.cuda.synchronize()
+            flat1 = opt.flat.detach().clone()
+            losses.append(m.train_step(z0, P, opt, None, **kw))
+        finally:
+            os.environ["CTTA_FORCE_COLLECTIVES"] = "0"
+        torch.cuda.synchronize()
+        return losses, flat1, m.student_unet.block_ranges(), opt.n
+
+    ref_losses, ref_flat, ranges, n = run(False)
+    # block ranges tile the trainable prefix of the flat buffer exactly
+    spans = sorted(ranges.values())
+    assert spans[0][0] == 0 and spans[-1][1] == n and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert set(ranges) == set(range(0, 2 * 4 + 3))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29581")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    try:
+        losses, flat, _, _ = run(True)
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert abs(losses[0] - ref_losses[0]) <= 1e-6 * abs(ref_losses[0])
+    assert abs(losses[1] - ref_losses[1]) <= 2e-3 * abs(ref_losses[1])
+    worst = float((flat - ref_flat).abs().max() / ref_flat.abs().max())
+    print("block-wise + RCCL vs monolithic: max relative parameter difference after one step %.3e" % worst)
+    assert worst <= 5e-6      # LayerNorm gamma/beta gradients use fp32 atomics: last-bit run-to-run differences
