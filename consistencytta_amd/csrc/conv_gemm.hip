@@ -38,6 +38,10 @@ struct ConvParams {
   const bf16_t* zero;   // >= 16 bytes of zeros: source of out-of-range chunks in the direct-to-LDS path
   unsigned x_bytes, w_bytes;   // buffer extents for the descriptor (MODE 2) path
   int xs0;                     // row stride (elements) of source 0: c0 unless a wider matrix is sliced
+  // split-K (groups == 1 only): blockIdx.z = split index, each split walks nk_split K-tiles and writes raw fp32
+  // partial sums to slab `split` of a workspace (out / ldc / ogs are redirected by the host); the fused epilogue
+  // runs afterwards in splitk_finish_kernel
+  int ksplit, nk_split;
 };
 
 // GLDS = true: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
@@ -173,7 +177,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   const int wm = wave / WN, wn = wave % WN;
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int g = blockIdx.z;
+  const int zs = blockIdx.z;
+  const int g = p.ksplit > 1 ? 0 : zs;                    // group index (pointer offsets)
+  const int kt_begin = p.ksplit > 1 ? zs * p.nk_split : 0;
+  const int nk = p.ksplit > 1 ? min(p.nk - kt_begin, p.nk_split) : p.nk;
 
   const bf16_t* x0 = p.x0 + (size_t)g * p.xgs;
   const bf16_t* x1 = p.x1;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   // per-thread K state (shared by all of this thread's rows)
   int c, tap, kh, kw;
   {
-    int kk = kc * 8;
+    int kk = kc * 8 + kt_begin * BK;
     tap = kk / p.ct;
     c = kk - tap * p.ct;
     kh = tap / p.kw;
@@ -322,6 +329,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   int ftap = 0, fkh = 0, fkw = 0, fcb = 0;   // wave-uniform K state (tap index, its (kh,kw), channel base)
   __amdgpu_buffer_rsrc_t rsx, rsw;
   if constexpr (MODE == 2) {
+    if (kt_begin > 0) {   // split-K: start inside the K range (ct is a multiple of BK on this path)
+      const int kk0 = kt_begin * BK;
+      ftap = kk0 / p.ct;
+      fcb = kk0 - ftap * p.ct;
+      fkh = ftap / p.kw;
+      fkw = ftap - fkh * p.kw;
+    }
     rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, p.x_bytes, 0x00020000);
     rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
 #pragma unroll
@@ -426,16 +440,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     constexpr int LPT = XP + WP;                 // LDS-DMA instructions per wave per tile
     constexpr int INFLIGHT = (STAGES - 2) * LPT; // what may stay outstanding while tile kt is consumed
     int issued = 0;
-    for (; issued < STAGES - 1 && issued < p.nk; ++issued) {
-      if constexpr (MODE == 2) issue_fast(issued, issued); else issue_tile(issued, issued);
+    for (; issued < STAGES - 1 && issued < nk; ++issued) {
+      if constexpr (MODE == 2) issue_fast(kt_begin + issued, issued); else issue_tile(kt_begin + issued, issued);
     }
     int slot = 0, fill = issued % STAGES;
-    for (int kt = 0; kt < p.nk; ++kt) {
+    for (int kt = 0; kt < nk; ++kt) {
       if (issued - kt - 1 >= STAGES - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(INFLIGHT) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();              // tile kt landed for every wave; slot `fill` is free
-      if (issued < p.nk) {
-        if constexpr (MODE == 2) issue_fast(issued, fill); else issue_tile(issued, fill);
+      if (issued < nk) {
+        if constexpr (MODE == 2) issue_fast(kt_begin + issued, fill); else issue_tile(kt_begin + issued, fill);
         ++issued;
         fill = (fill + 1 == STAGES) ? 0 : fill + 1;
       }
@@ -444,24 +458,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     }
   } else {
     if constexpr (MODE == 2) {
-      issue_fast(0, 0);
+      issue_fast(kt_begin, 0);
     } else if constexpr (MODE == 1) {
-      issue_tile(0, 0);
+      issue_tile(kt_begin, 0);
     } else {
-      load_tile(0);
+      load_tile(kt_begin);
       store_tile(0);
     }
     __syncthreads();
-    for (int kt = 0; kt < p.nk; ++kt) {
+    for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
-      if (kt + 1 < p.nk) {
-        if constexpr (MODE == 2) issue_fast(kt + 1, buf ^ 1);
-        else if constexpr (MODE == 1) issue_tile(kt + 1, buf ^ 1);
-        else load_tile(kt + 1);
+      if (kt + 1 < nk) {
+        if constexpr (MODE == 2) issue_fast(kt_begin + kt + 1, buf ^ 1);
+        else if constexpr (MODE == 1) issue_tile(kt_begin + kt + 1, buf ^ 1);
+        else load_tile(kt_begin + kt + 1);
       }
       compute_tile(buf);
       if constexpr (!GLDS) {
-        if (kt + 1 < p.nk) store_tile(buf ^ 1);
+        if (kt + 1 < nk) store_tile(buf ^ 1);
       }
       __syncthreads();
     }
@@ -479,7 +493,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
         const int n = n0 + wn * TN + i * 16 + nsub;
-        if (m_ok && n < p.n) epilogue_store(p, acc[i][j], m, n, b, mrem, g);
+        if (m_ok && n < p.n) epilogue_store(p, acc[i][j], m, n, b, mrem, zs);
       }
     }
   } else {
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         const int n = n0 + wn * TN + i * 16 + nsub;
         if (m < p.M && n < p.n) {
           const int b = m / p.howo;
-          epilogue_store(p, (f32x4_t){q.x, q.y, q.z, q.w}, m, n, b, m - (long long)b * p.howo, g);
+          epilogue_store(p, (f32x4_t){q.x, q.y, q.z, q.w}, m, n, b, m - (long long)b * p.howo, zs);
         }
       }
     }
@@ -607,6 +621,31 @@ static bool halo_eligible(const ctta_conv_desc* d, const ConvParams& p, int grou
 }
 
 // ------------------------------------------------------------------------------------------
+// split-K second pass: sums the fp32 partial slabs [S][M][ld] and runs the fused epilogue of the original launch
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvParams p, const float* __restrict__ slabs, int S,
+                                                            long long slab_stride, int ld) {
+  const int n4 = (p.n + 3) / 4;
+  const long long total = (long long)p.M * n4;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
+    const float* src = slabs + (size_t)m * ld + n;
+    float4 a = *reinterpret_cast<const float4*>(src);
+    for (int s2 = 1; s2 < S; ++s2) {
+      const float4 q = *reinterpret_cast<const float4*>(src + (size_t)s2 * slab_stride);
+      a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
+    }
+    const int b = m / p.howo;
+    epilogue_store(p, (f32x4_t){a.x, a.y, a.z, a.w}, m, n, b, m - (long long)b * p.howo, 0);
+  }
+}
+static const size_t kSplitWsBytes = (size_t)192 << 20;
+static float* splitk_workspace() {   // one workspace per process: split-K launches are serialised on their stream
+  static float* ws = nullptr;
+  if (!ws && hipMalloc((void**)&ws, kSplitWsBytes) != hipSuccess) ws = nullptr;
+  return ws;
+}
+
+// ------------------------------------------------------------------------------------------
 struct Variant {
   const char* name;
   int bm, bn, bk;
@@ -689,6 +728,11 @@ static const bf16_t* zero_page() {
   return z;
 }
 
+static bool splitk_default() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
 static bool glds_default() {
   static int v = -1;
   if (v < 0) {
@@ -786,6 +830,12 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       vid = kBigTile;
     } else {
       vid = pick_variant(M, d->n, K, groups);
+      // deep and narrow (few 128x128 tiles, long K): the 128x128 tile with split-K beats small tiles that only
+      // exist to create workgroups (measured: M=1152, N=1024, K=9216 at 176 TFLOP/s on 64x64 tiles)
+      const long long t128 = ((M + 127) / 128) * ((d->n + 127) / 128);
+      if (splitk_default() && groups == 1 && K >= 4096 && d->n >= 256 && t128 < 192 && !scalar_store &&
+          d->out_limit == 0 && d->out_offset == 0)
+        vid = 1;
       if (!d->in_act && glds_default()) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
     }
   }
@@ -800,9 +850,40 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   CTTA_REQUIRE((long long)p.nk * v.bk <= d->k_pad, "conv_gemm: k_pad too small for BK");
   CTTA_TRY(v.prepare());
   dim3 grid((unsigned)((M + v.bm - 1) / v.bm), (unsigned)((d->n + v.bn - 1) / v.bn), (unsigned)groups);
+  p.ksplit = 1; p.nk_split = p.nk;
+  // split-K: deep, narrow problems (the 1024-channel levels at small batch: M <= 2304, K = 9216 / 18432) launch
+  // too few workgroups to fill 256 CUs; split the K walk over blockIdx.z and reduce in a second pass
+  float* ws = splitk_workspace();
+  const long long tiles = (long long)grid.x * grid.y;
+  int splits = 1;
+  if (splitk_default() && ws && groups == 1 && !scalar_store && d->out_limit == 0 && d->out_offset == 0 && tiles < 192 &&
+      p.nk >= 32) {
+    splits = (int)(512 / tiles);
+    if (splits > 8) splits = 8;
+    if (splits > p.nk / 8) splits = p.nk / 8;
+    const int ld = (d->n + 3) / 4 * 4;
+    if ((long long)splits * M * ld * 4 > (long long)kSplitWsBytes) splits = 1;
+  }
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, vid, M, d->n, K, groups, (hipStream_t)stream);
-  v.launch(p, grid, (hipStream_t)stream);
+  if (splits > 1) {
+    const int ld = (d->n + 3) / 4 * 4;
+    ConvParams q = p;   // first pass: raw partial sums
+    q.nk_split = (p.nk + splits - 1) / splits;
+    splits = (p.nk + q.nk_split - 1) / q.nk_split;   // every split owns at least one K-tile
+    q.ksplit = splits;
+    q.bias = nullptr; q.bias_m = nullptr; q.rowvec = nullptr; q.res = nullptr; q.out_act = 0; q.alpha = 1.0f;
+    q.accumulate = 0; q.out2 = nullptr; q.out = ws; q.ldc = ld; q.out_f32 = 1; q.obs = (long long)p.howo * ld;
+    q.ogs = (long long)M * ld;
+    grid.z = (unsigned)splits;
+    v.launch(q, grid, (hipStream_t)stream);
+    const long long total = M * (ld / 4);
+    int fb = (int)((total + 255) / 256);
+    if (fb > 4096) fb = 4096;
+    splitk_finish_kernel<<<dim3(fb), dim3(256), 0, (hipStream_t)stream>>>(p, ws, splits, M * ld, ld);
+  } else {
+    v.launch(p, grid, (hipStream_t)stream);
+  }
   if (prof) ctta_prof_end((hipStream_t)stream);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;

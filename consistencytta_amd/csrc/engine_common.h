@@ -151,8 +151,7 @@ struct WeightStore {
       memset(&j, 0, sizeof(j));   // tables are compared bytewise: no indeterminate padding
       j.src = t->data; j.row_off = p.ro; j.col_off = p.co; j.row_aux = p.ra; j.col_aux = p.ca;
       j.aux_limit = p.aux_limit; j.n_rows = p.n_rows; j.k_pad = p.k_pad; j.dst = p.dst; j.block0 = blk;
-      j.rows_per_block = p.k_pad >= CTTA_PACK_ELEMS_PER_BLOCK ? 1 : CTTA_PACK_ELEMS_PER_BLOCK / p.k_pad;
-      blk += (p.n_rows + j.rows_per_block - 1) / j.rows_per_block;
+      blk += (int)(((int64_t)p.n_rows * p.k_pad + CTTA_PACK_ELEMS_PER_BLOCK - 1) / CTTA_PACK_ELEMS_PER_BLOCK);
       h_pack.push_back(j);
     }
     pack_blocks = blk;

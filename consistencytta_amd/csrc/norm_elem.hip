@@ -88,8 +88,9 @@ __global__ void pack_weight_kernel(const float* __restrict__ src, const int* __r
 }
 
 // All pack jobs of a state dict in one launch: a block finds its job by bisection over block0 and packs
-// `rows_per_block` complete destination rows, so the strided source reads of one row (a conv row gathers
-// (cin, kh, kw) -> (kh, kw, cin)) stay inside one block's cache footprint instead of being re-fetched by 9 blocks.
+// CTTA_PACK_ELEMS_PER_BLOCK consecutive destination elements (consecutive blocks walk the same destination row, so
+// the strided source reads of a conv row -- (cin, kh, kw) -> (kh, kw, cin) -- are served by L2 after the first tap;
+// one-row-per-block variants measured slower: too few blocks in flight for the 1024 x 9216 layers).
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const ctta_pack_job* __restrict__ jobs, int n_jobs) {
   int lo = 0, hi = n_jobs - 1;
   while (lo < hi) {
@@ -97,19 +98,19 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const ctta_pack_
     if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
   }
   const ctta_pack_job j = jobs[lo];
-  const int r0 = (int)(blockIdx.x - j.block0) * j.rows_per_block;
-  const int r1 = min(j.n_rows, r0 + j.rows_per_block);
+  const long long total = (long long)j.n_rows * j.k_pad;
+  const long long base = (long long)(blockIdx.x - j.block0) * CTTA_PACK_ELEMS_PER_BLOCK;
   bf16_t* dst = (bf16_t*)j.dst;
-  for (int r = r0; r < r1; ++r) {
-    const int ro = j.row_off[r];
-    const int ra = j.aux_limit > 0 ? j.row_aux[r] : 0;
-    bf16_t* drow = dst + (size_t)r * j.k_pad;
-    for (int k = threadIdx.x; k < j.k_pad; k += 256) {
-      const int co = j.col_off[k];
-      bool ok = ro >= 0 && co >= 0;
-      if (ok && j.aux_limit > 0) ok = ra + j.col_aux[k] < j.aux_limit;
-      drow[k] = ok ? f2bf(j.src[(size_t)ro + (size_t)co]) : (bf16_t)0;
-    }
+#pragma unroll
+  for (int i = 0; i < CTTA_PACK_ELEMS_PER_BLOCK / 256; ++i) {
+    const long long idx = base + i * 256 + threadIdx.x;
+    if (idx >= total) break;
+    const int k = (int)(idx % j.k_pad);
+    const int r = (int)(idx / j.k_pad);
+    const int ro = j.row_off[r], co = j.col_off[k];
+    bool ok = ro >= 0 && co >= 0;
+    if (ok && j.aux_limit > 0) ok = j.row_aux[r] + j.col_aux[k] < j.aux_limit;
+    dst[idx] = ok ? f2bf(j.src[(size_t)ro + (size_t)co]) : (bf16_t)0;
   }
 }
 __global__ __launch_bounds__(256) void copy_segments_multi_kernel(const ctta_copy_seg* __restrict__ segs) {

@@ -257,13 +257,13 @@ ctta_status ctta_pack_weight(const float* src, const int32_t* row_off, const int
 
 /* Table-driven variants used by the engines' (re)load path: all pack jobs / all fp32 copies of a
  * state dict in ONE launch each.  `jobs` / `segs` are DEVICE arrays; jobs must be sorted by block0
- * (block0 = first thread block of the job; a block packs rows_per_block complete rows). */
+ * (block0 = first thread block of the job, CTTA_PACK_ELEMS_PER_BLOCK outputs per block). */
 #define CTTA_PACK_ELEMS_PER_BLOCK 2048
 #define CTTA_COPY_ELEMS_PER_BLOCK 16384
 typedef struct {
   const float* src;
   const int32_t *row_off, *col_off, *row_aux, *col_aux;
-  int aux_limit, n_rows, k_pad, block0, rows_per_block;
+  int aux_limit, n_rows, k_pad, block0;
   void* dst;
 } ctta_pack_job;
 typedef struct {

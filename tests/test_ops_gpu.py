@@ -90,6 +90,25 @@ def test_conv_geometries_on_direct_to_lds_paths(tile):
     assert _conv_case(2, 64, 8, 8, 64, 3, 1, 1, epilogue=True, tile=tile, tag="g_epi") < BF16_TOL
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 256, 128, 8, 8), (9, 512, 256, 8, 2), (1, 1024, 64, 4, 4)])
+def test_conv_split_k(B, Cin, Cout, H, W):
+    """Deep, narrow problems (few output tiles, K >= 2048) are split over K automatically: partial slabs + a second
+    pass that runs the fused epilogue (bias, per-sample row vector, residual, SiLU) -- checked against F.conv2d."""
+    x = bf16_round(det("sk.x", (B, Cin, H, W), 1))
+    w = bf16_round(det("sk.w", (Cout, Cin, 3, 3), 2) * (1.0 / math.sqrt(Cin * 9)))
+    b = det("sk.b", (Cout,), 3) * 0.1
+    rv = det("sk.rv", (B, Cout), 4) * 0.2
+    res = bf16_round(det("sk.r", (B, Cout, H, W), 5))
+    ref = F.silu(F.conv2d(x, w, b, padding=1) + rv[:, :, None, None] + res)
+    wp, k_pad = pack_conv_weight(w)
+    xa, ra = nhwc_bf16(x), nhwc_bf16(res)
+    bd, rvd = b.to(DEV), rv.to(DEV).contiguous()
+    out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+    run_conv(conv_desc(x0=xa, c0=Cin, batch=B, hi=H, wi=W, ho=H, wo=W, kh=3, kw=3, pad_h=1, pad_w=1, w=wp, k_pad=k_pad,
+                       n=Cout, bias=bd, rowvec=rvd, rowvec_ld=Cout, res=ra, res_ld=Cout, out_act=1, out=out, ldc=Cout))
+    assert rel_err(from_nhwc(out), ref) < 2 * BF16_TOL
+
+
 def test_conv1d_dilated_lrelu_and_accumulate():
     B, C, L, k, d = 2, 32, 200, 7, 3
     x = bf16_round(det("c1d.x", (B, C, L), 1))
