@@ -90,6 +90,7 @@ SIGNATURES = {
                                    c_int, c_float, c_void_p, c_int64, c_void_p]),
     "ctta_wgrad_scatter_rows": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ctta_col_scatter": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ctta_transpose_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ctta_pack_weight_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ctta_copy_segments_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "ctta_unet_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -65,6 +65,48 @@ extern "C" ctta_status ctta_transpose_bf16(const void* src, int64_t src_group_st
   return CTTA_OK;
 }
 
+// many small transposes in one launch (job table on the device, one 64x64 tile per block)
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const ctta_tpose_job* __restrict__ jobs, int n_jobs) {
+  __shared__ bf16_t tile[64][72];
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ctta_tpose_job j = jobs[lo];
+  const int local = (int)blockIdx.x - j.block0;
+  const int r0 = (local % j.tiles_r) * 64, c0 = (local / j.tiles_r) * 64;
+  const bf16_t* s = (const bf16_t*)j.src;
+  bf16_t* d = (bf16_t*)j.dst;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = tid + i * 256;
+    const int r = ch >> 3, cc = (ch & 7) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r0 + r < j.rows && c0 + cc < j.cols) v = *reinterpret_cast<const uint4*>(s + (size_t)(r0 + r) * j.src_ld + c0 + cc);
+    *reinterpret_cast<uint4*>(&tile[r][cc]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ch = tid + i * 256;
+    const int c = ch >> 3, rr = (ch & 7) * 8;
+    if (c0 + c < j.cols && r0 + rr < j.wcols) {
+      uint32_t w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[rr + 2 * e][c] | ((uint32_t)tile[rr + 2 * e + 1][c] << 16);
+      *reinterpret_cast<uint4*>(d + (size_t)(c0 + c) * j.dst_ld + r0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+  }
+}
+extern "C" ctta_status ctta_transpose_multi(const ctta_tpose_job* jobs, int n_jobs, int total_blocks, void* stream) {
+  CTTA_REQUIRE(jobs && n_jobs >= 1 && total_blocks >= 1, "transpose_multi: bad arguments");
+  hipLaunchKernelGGL(transpose_multi_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, jobs, n_jobs);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
 // Q[(c*T + t)][m] = X[pixel(m, tap t)][c] (0 outside the image), m = (b, oh, ow), T = kh*kw taps; rows padded
 // to m_pad.  Channel-major rows = the (cin, kh, kw) order of a conv weight row, so the weight-gradient slab
 // scatters back with an identity column map.

@@ -102,6 +102,10 @@ struct WeightStore {
   };
   std::vector<PackSpec> packs;
   std::vector<CopySpec> copies;
+  std::vector<ctta_tpose_job> tposes;   // bf16 -> bf16 derivations (data-gradient operands); static pointers
+  ctta_tpose_job* d_tpose = nullptr;
+  int tpose_blocks = 0;
+  bool tpose_uploaded = false;
   std::vector<ctta_pack_job> h_pack, h_pack_prev;
   std::vector<ctta_copy_seg> h_copy, h_copy_prev;
   ctta_pack_job* d_pack = nullptr;
@@ -120,7 +124,8 @@ struct WeightStore {
     if (arena.base) (void)hipFree(arena.base);
     if (d_pack) (void)hipFree(d_pack);
     if (d_copy) (void)hipFree(d_copy);
-    arena.base = nullptr; d_pack = nullptr; d_copy = nullptr;
+    if (d_tpose) (void)hipFree(d_tpose);
+    arena.base = nullptr; d_pack = nullptr; d_copy = nullptr; d_tpose = nullptr;
   }
 
   static ctta_status find_checked(const WeightTable& wt, const std::string& key, const ctta_tensor** out) {
@@ -177,8 +182,26 @@ struct WeightStore {
     CTTA_TRY(sync_table(h_copy, h_copy_prev, (void**)&d_copy, &d_copy_cap, sizeof(ctta_copy_seg)));
     if (!h_pack.empty()) CTTA_TRY(ctta_pack_weight_multi(d_pack, (int)h_pack.size(), pack_blocks, s));
     if (!h_copy.empty()) CTTA_TRY(ctta_copy_segments_multi(d_copy, (int)h_copy.size(), s));
+    if (!tposes.empty()) {   // after the forward packs: their transposes / tap rotations
+      if (!tpose_uploaded) {
+        CTTA_CHECK_HIP(hipMalloc((void**)&d_tpose, tposes.size() * sizeof(ctta_tpose_job)));
+        CTTA_CHECK_HIP(hipMemcpy(d_tpose, tposes.data(), tposes.size() * sizeof(ctta_tpose_job), hipMemcpyHostToDevice));
+        tpose_uploaded = true;
+      }
+      CTTA_TRY(ctta_transpose_multi(d_tpose, (int)tposes.size(), tpose_blocks, s));
+    }
     for (auto& j : jobs) CTTA_TRY(j(wt, s));
     return CTTA_OK;
+  }
+
+  // dst[c][r] = src[r][c] (r < rows, c < cols), columns [rows, wcols) of each dst row zero; runs after the packs
+  void add_transpose(const bf16_t* src, bf16_t* dst, int rows, int cols, int src_ld, int dst_ld, int wcols) {
+    ctta_tpose_job j;
+    memset(&j, 0, sizeof(j));
+    j.src = src; j.dst = dst; j.rows = rows; j.cols = cols; j.src_ld = src_ld; j.dst_ld = dst_ld; j.wcols = wcols;
+    j.block0 = tpose_blocks; j.tiles_r = (wcols + 63) / 64;
+    tpose_blocks += j.tiles_r * ((cols + 63) / 64);
+    tposes.push_back(j);
   }
 
   // uploads a job table when it differs from what the device already holds (blocking copy: tables are a
@@ -316,6 +339,10 @@ static inline ctta_status make_linear(WeightStore& ws, const std::string& wkey, 
 
 // Data-gradient operands.  conv: dX = conv(dY, W rotated 180 deg, in/out channels swapped), so the
 // packed rows are the forward INPUT channels and K = (kh, kw, cout); linear: W^T.
+// Two ways to fill them: from the fp32 state dict with a pack job (make_conv_dgrad, used where no bf16 forward
+// operand exists), or -- cheaper, no fp32 re-read -- as bf16 transposes of the forward operand that the same
+// load just packed (make_*_dgrad_from): tap t of the forward pack, a [cout][cin] matrix, becomes the
+// [cin][cout] block of tap T-1-t.
 static inline ctta_status make_conv_dgrad(WeightStore& ws, const std::string& prefix, int cout, int cin, int kh,
                                           int kw, int pad, ConvLayer* D, int cout_pad = 0) {
   if (cout_pad < cout) cout_pad = cout;   // channel stride of the dY operand
@@ -332,16 +359,25 @@ static inline ctta_status make_conv_dgrad(WeightStore& ws, const std::string& pr
   D->cin_pad = cout_pad; D->cout = cin; D->kh = kh; D->kw = kw; D->stride = 1; D->pad = kh - 1 - pad;
   return CTTA_OK;
 }
-static inline ctta_status make_linear_dgrad(WeightStore& ws, const std::string& wkey, int n_src, int k_src,
-                                            const std::vector<int32_t>& row_map, const std::vector<int32_t>& col_map,
-                                            PackedW* D) {
-  const int n_pad = (int)row_map.size(), k_pad = (int)col_map.size();
-  const int kd = round_up(n_pad, 64);
-  std::vector<int32_t> ro(k_pad), co(kd, -1);
-  for (int k = 0; k < k_pad; ++k) ro[k] = col_map[k];
-  for (int n = 0; n < n_pad; ++n) co[n] = row_map[n] < 0 ? -1 : row_map[n] * k_src;
-  CTTA_TRY(ws.add_matrix(wkey, {n_src, k_src}, ro, co, nullptr, nullptr, 0, &D->w));
-  D->bias = nullptr; D->n = k_pad; D->k_pad = kd;
+static inline ctta_status make_conv_dgrad_from(WeightStore& ws, const ConvLayer& F, int cout, int cin, ConvLayer* D) {
+  CTTA_REQUIRE(cout % 8 == 0 && cin % 8 == 0, "data-gradient pack: channel counts must be multiples of 8");
+  const int T = F.kh * F.kw;
+  const int k_pad = round_up(T * cout, 64), n_pad = round_up(cin, 4);
+  bf16_t* dst = ws.arena.get<bf16_t>((size_t)n_pad * k_pad);   // zero-initialised store: padding stays zero
+  if (!dst) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
+  for (int t = 0; t < T; ++t)
+    ws.add_transpose(F.p.w + (size_t)t * F.cin_pad, dst + (size_t)(T - 1 - t) * cout, cout, cin, F.p.k_pad, k_pad, cout);
+  D->p.w = dst; D->p.bias = nullptr; D->p.n = n_pad; D->p.k_pad = k_pad;
+  D->cin_pad = cout; D->cout = cin; D->kh = F.kh; D->kw = F.kw; D->stride = 1; D->pad = F.kh - 1 - F.pad;
+  return CTTA_OK;
+}
+// W^T of a packed linear operand F ([n_rows][k_pad], rows may be a slice of a fused operand)
+static inline ctta_status make_linear_dgrad_from(WeightStore& ws, const bf16_t* fw, int n_rows, int k_pad, PackedW* D) {
+  const int kd = round_up(n_rows, 64);
+  bf16_t* dst = ws.arena.get<bf16_t>((size_t)k_pad * kd);
+  if (!dst) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
+  ws.add_transpose(fw, dst, n_rows, k_pad, k_pad, kd, kd);
+  D->w = dst; D->bias = nullptr; D->n = k_pad; D->k_pad = kd;
   return CTTA_OK;
 }
 

@@ -165,9 +165,9 @@ static ctta_status make_resnet(ctta_unet* U, const std::string& p, int cin, int 
   R->has_sc = cin != cout;
   if (R->has_sc) CTTA_TRY(make_conv(ws, p + "conv_shortcut.", cout, cin, cin, 1, 1, 1, 0, &R->sc, true, tr ? &R->tsc.m : nullptr));
   if (tr) {
-    CTTA_TRY(make_conv_dgrad(ws, p + "conv1.", cout, cin, 3, 3, 1, &R->t1.d));
-    CTTA_TRY(make_conv_dgrad(ws, p + "conv2.", cout, cout, 3, 3, 1, &R->t2.d));
-    if (R->has_sc) CTTA_TRY(make_conv_dgrad(ws, p + "conv_shortcut.", cout, cin, 1, 1, 0, &R->tsc.d));
+    CTTA_TRY(make_conv_dgrad_from(ws, R->c1, cout, cin, &R->t1.d));
+    CTTA_TRY(make_conv_dgrad_from(ws, R->c2, cout, cout, &R->t2.d));
+    if (R->has_sc) CTTA_TRY(make_conv_dgrad_from(ws, R->sc, cout, cin, &R->tsc.d));
   }
   // time_emb_proj rows live in one concatenated fp32 table -> one small GEMM per forward
   R->temb_off = U->temb_total;
@@ -203,7 +203,7 @@ static ctta_status make_transformer(ctta_unet* U, const std::string& p, int c, i
                  const std::vector<int32_t>& rows, const std::vector<int32_t>& cols, PackedW* P, LinTrain* LT,
                  bf16_t* pre = nullptr, bool need_dgrad = true) -> ctta_status {
     CTTA_TRY(make_linear(ws, wkey, bkey, n_src, k_src, rows, cols, P, pre, tr ? &LT->m : nullptr));
-    if (tr && need_dgrad) CTTA_TRY(make_linear_dgrad(ws, wkey, n_src, k_src, rows, cols, &LT->d));
+    if (tr && need_dgrad) CTTA_TRY(make_linear_dgrad_from(ws, P->w, P->n, P->k_pad, &LT->d));
     return CTTA_OK;
   };
   CTTA_TRY(lin(p + "proj_in.weight", p + "proj_in.bias", inner, c, identity_map(inner, cp),
@@ -613,7 +613,7 @@ static ctta_status unet_build(ctta_unet* U) {
       Lv.has_sampler = true;
       CTTA_TRY(make_conv(ws, p + "downsamplers.0.conv.", out_c, out_c, out_c, 3, 3, 2, 1, &Lv.sampler, true,
                          tr ? &Lv.tsampler.m : nullptr));
-      if (tr) CTTA_TRY(make_conv_dgrad(ws, p + "downsamplers.0.conv.", out_c, out_c, 3, 3, 1, &Lv.tsampler.d));
+      if (tr) CTTA_TRY(make_conv_dgrad_from(ws, Lv.sampler, out_c, out_c, &Lv.tsampler.d));
     }
   }
   U->up.resize(n);
@@ -640,7 +640,7 @@ static ctta_status unet_build(ctta_unet* U) {
       Lv.has_sampler = true;
       CTTA_TRY(make_conv(ws, p + "upsamplers.0.conv.", out_c, out_c, out_c, 3, 3, 1, 1, &Lv.sampler, true,
                          tr ? &Lv.tsampler.m : nullptr));
-      if (tr) CTTA_TRY(make_conv_dgrad(ws, p + "upsamplers.0.conv.", out_c, out_c, 3, 3, 1, &Lv.tsampler.d));
+      if (tr) CTTA_TRY(make_conv_dgrad_from(ws, Lv.sampler, out_c, out_c, &Lv.tsampler.d));
     }
   }
   CTTA_TRY(make_transformer(U, "mid_block.attentions.0.", boc[n - 1], cfg.heads[n - 1], &U->mid_att));

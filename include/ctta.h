@@ -272,6 +272,15 @@ typedef struct {
   int count;
 } ctta_copy_seg;
 ctta_status ctta_pack_weight_multi(const ctta_pack_job* jobs, int n_jobs, int total_blocks, void* stream);
+/* Table-driven bf16 transposes (one 64x64 tile per block): dst[c][r] = src[r][c] for r < rows, c < cols, zero for
+ * rows <= r < wcols; only the first wcols columns of a dst row are written.  Used to derive the data-gradient
+ * operands (W^T, rotated conv taps) from the freshly packed forward operands without re-reading fp32 weights. */
+typedef struct {
+  const void* src;
+  void* dst;
+  int rows, cols, src_ld, dst_ld, wcols, block0, tiles_r;
+} ctta_tpose_job;
+ctta_status ctta_transpose_multi(const ctta_tpose_job* jobs, int n_jobs, int total_blocks, void* stream);
 ctta_status ctta_copy_segments_multi(const ctta_copy_seg* segs, int n_segs, void* stream);
 
 ctta_status ctta_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int batch, int c, int h,
