@@ -135,6 +135,7 @@ SIGNATURES = {
     "ctta_concat_channels": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
     "ctta_groupnorm_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ctta_groupnorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
+    "ctta_groupnorm_stats_out": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "ctta_layernorm": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p]),
     "ctta_geglu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ctta_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),

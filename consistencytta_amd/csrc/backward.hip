@@ -391,45 +391,45 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const bf16_t* __res
     o[c] = a; o[C + c] = bb;
   }
 }
-// pass 2: fold chunks; coef[b][g] = (S1/n, S2/n) with S1 = sum_c gamma*A, S2 = sum_c gamma*Bc;
-// dgamma[c] (+)= sum_b Bc, dbeta[c] (+)= sum_b A.  One block.
-__global__ void gn_bwd_finalize_kernel(const float* __restrict__ part, int B, int nchunk, int G, int C, int HW,
-                                       const float* __restrict__ gamma, float* __restrict__ coef,
-                                       float* __restrict__ red, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                       int accumulate) {
-  // red: [B][2][C] folded per-channel sums (scratch)
+// pass 2a: one block per sample folds the chunks; coef[b][g] = (S1/n, S2/n) with S1 = sum_c gamma*A,
+// S2 = sum_c gamma*Bc; red[b][2][C] keeps the folded per-channel sums for pass 2b.
+__global__ __launch_bounds__(1024) void gn_bwd_fold_kernel(const float* __restrict__ part, int nchunk, int G, int C, int HW,
+                                                           const float* __restrict__ gamma, float* __restrict__ coef,
+                                                           float* __restrict__ red) {
+  const int b = blockIdx.x;
   const int cpg = C / G;
-  for (int i = threadIdx.x; i < B * C; i += blockDim.x) {
-    const int b = i / C, c = i - b * C;
+  float* rb = red + (size_t)b * 2 * C;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
     double a = 0.0, bb = 0.0;
     for (int ch = 0; ch < nchunk; ++ch) {
       const float* o = part + ((size_t)b * nchunk + ch) * 2 * C;
       a += (double)o[c]; bb += (double)o[C + c];
     }
-    red[((size_t)b * 2) * C + c] = (float)a;
-    red[((size_t)b * 2 + 1) * C + c] = (float)bb;
+    rb[c] = (float)a;
+    rb[C + c] = (float)bb;
   }
   __syncthreads();
   const double n = (double)HW * cpg;
-  for (int i = threadIdx.x; i < B * G; i += blockDim.x) {
-    const int b = i / G, g = i - b * G;
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
     double s1 = 0.0, s2 = 0.0;
     for (int cc = 0; cc < cpg; ++cc) {
       const int c = g * cpg + cc;
-      s1 += (double)gamma[c] * red[((size_t)b * 2) * C + c];
-      s2 += (double)gamma[c] * red[((size_t)b * 2 + 1) * C + c];
+      s1 += (double)gamma[c] * rb[c];
+      s2 += (double)gamma[c] * rb[C + c];
     }
-    coef[(size_t)i * 2] = (float)(s1 / n);
-    coef[(size_t)i * 2 + 1] = (float)(s2 / n);
+    coef[((size_t)b * G + g) * 2] = (float)(s1 / n);
+    coef[((size_t)b * G + g) * 2 + 1] = (float)(s2 / n);
   }
-  if (dgamma) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-      double a = 0.0, bb = 0.0;
-      for (int b = 0; b < B; ++b) { a += red[((size_t)b * 2) * C + c]; bb += red[((size_t)b * 2 + 1) * C + c]; }
-      dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-      dgamma[c] = accumulate ? dgamma[c] + (float)bb : (float)bb;
-    }
-  }
+}
+// pass 2b: dgamma[c] (+)= sum_b Bc, dbeta[c] (+)= sum_b A   (fixed summation order: deterministic)
+__global__ void gn_bwd_param_kernel(const float* __restrict__ red, int B, int C, float* __restrict__ dgamma,
+                                    float* __restrict__ dbeta, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, bb = 0.0;
+  for (int b = 0; b < B; ++b) { a += red[((size_t)b * 2) * C + c]; bb += red[((size_t)b * 2 + 1) * C + c]; }
+  dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+  dgamma[c] = accumulate ? dgamma[c] + (float)bb : (float)bb;
 }
 // pass 3: dx = rstd * (dz*gamma - S1/n - xhat*S2/n)   (+ existing dx when acc_dx)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
@@ -493,9 +493,14 @@ extern "C" ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* d
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, batch), dim3(256), (size_t)2 * PL * c * sizeof(float), s,
                      (const bf16_t*)x, (const bf16_t*)dy, hw, c, groups, ppc, nchunk, stats, gamma, beta, silu, part);
   CTTA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, part, batch, nchunk, groups, c, hw, gamma, coef,
-                     red, dgamma, dbeta, accumulate_param);
+  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(batch), dim3(1024), 0, s, part, nchunk, groups, c, hw, gamma, coef, red);
   CTTA_LAUNCH_CHECK();
+  if (dgamma) {
+    CTTA_REQUIRE(dbeta, "groupnorm_bwd: dgamma without dbeta");
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, s, red, batch, c, dgamma, dbeta,
+                       accumulate_param);
+    CTTA_LAUNCH_CHECK();
+  }
   const long long total_vec = (long long)batch * hw * VC;
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid1d(total_vec, 256, 8192)), dim3(256), 0, s, (const bf16_t*)x,
                      (const bf16_t*)dy, (bf16_t*)dx, hw, c, groups, stats, coef, gamma, beta, silu, accumulate_dx,

@@ -486,12 +486,13 @@ static inline ctta_status make_gn(WeightStore& ws, const std::string& prefix, in
   return CTTA_OK;
 }
 static inline ctta_status run_gn(RunCtx& c, const GNLayer& g, const bf16_t* x, bf16_t* y, int B, int hw,
-                                 int groups, float eps, bool silu) {
+                                 int groups, float eps, bool silu, float* stats = nullptr) {
   if (!c.dry && ctta_groupnorm_scratch_floats(B, hw, g.c, groups) > c.gn_scratch_floats) {
     ctta_set_error("groupnorm scratch too small");
     return CTTA_ERR_INVALID;
   }
-  RUN(c, ctta_groupnorm(x, y, B, hw, g.c, groups, g.gamma, g.beta, eps, silu ? 1 : 0, c.gn_scratch, c.stream));
+  RUN(c, ctta_groupnorm_stats_out(x, y, B, hw, g.c, groups, g.gamma, g.beta, eps, silu ? 1 : 0, c.gn_scratch, stats,
+                                  c.stream));
   return CTTA_OK;
 }
 

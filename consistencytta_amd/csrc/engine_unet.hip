@@ -251,13 +251,12 @@ static ctta_status gn(UCtx& c, const GNLayer& g, const bf16_t* x, bf16_t* y, int
     if (nb > need) need = nb;
   }
   if (need > c.gn_need) c.gn_need = need;
-  CTTA_TRY(run_gn(c, g, x, y, c.B, hw, groups, eps, silu));
-  if (c.train && stats_out) {
-    float* st = c.arena->get<float>((size_t)c.B * groups * 2); ALLOC_OR_FAIL(st);
-    RUN(c, ctta_groupnorm_stats(x, c.B, hw, g.c, groups, eps, st, c.stream));
+  float* st = nullptr;
+  if (c.train && stats_out) {   // (mean, rstd) per (sample, group), emitted by the forward's own fold
+    st = c.arena->get<float>((size_t)c.B * groups * 2); ALLOC_OR_FAIL(st);
     *stats_out = st;
   }
-  return CTTA_OK;
+  return run_gn(c, g, x, y, c.B, hw, groups, eps, silu, st);
 }
 
 static ctta_status run_resnet(UCtx& c, Resnet& R, const bf16_t* x, int H, int W, bf16_t** out_p) {

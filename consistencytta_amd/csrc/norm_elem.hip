@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 //   y = x*scale + shift,  scale = rstd*gamma, shift = beta - mean*rstd*gamma.
 __global__ void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int G, int C, int HW,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float* __restrict__ scale_shift) {
+                                   float eps, float* __restrict__ scale_shift, float* __restrict__ stats) {
   const int b = blockIdx.x;
   const int cpg = C / G;
   for (int g = threadIdx.x; g < G; g += blockDim.x) {
@@ -203,6 +203,10 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, int nchunk, i
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float meanf = (float)mean;
+    if (stats) {   // training forward: (mean, rstd) per (sample, group) for the backward pass
+      stats[((size_t)b * G + g) * 2] = meanf;
+      stats[((size_t)b * G + g) * 2 + 1] = rstd;
+    }
     for (int cc = 0; cc < cpg; ++cc) {
       const int c = g * cpg + cc;
       const float sc = rstd * gamma[c];
@@ -260,6 +264,12 @@ extern "C" size_t ctta_groupnorm_scratch_floats(int batch, int hw, int c, int gr
 extern "C" ctta_status ctta_groupnorm(const void* x, void* y, int batch, int hw, int c, int groups,
                                       const float* gamma, const float* beta, float eps, int silu,
                                       float* scratch, void* stream) {
+  return ctta_groupnorm_stats_out(x, y, batch, hw, c, groups, gamma, beta, eps, silu, scratch, nullptr, stream);
+}
+
+extern "C" ctta_status ctta_groupnorm_stats_out(const void* x, void* y, int batch, int hw, int c, int groups,
+                                                const float* gamma, const float* beta, float eps, int silu,
+                                                float* scratch, float* stats, void* stream) {
   CTTA_REQUIRE(x && y && gamma && beta && scratch, "groupnorm: null pointer");
   CTTA_REQUIRE(c % 8 == 0 && groups > 0 && c % groups == 0, "groupnorm: C=%d groups=%d unsupported", c, groups);
   CTTA_REQUIRE(groups <= 256 * 64, "groupnorm: too many groups");
@@ -275,7 +285,7 @@ extern "C" ctta_status ctta_groupnorm(const void* x, void* y, int batch, int hw,
                      c, groups, ppc, nchunk, part);
   CTTA_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(64), 0, s, part, nchunk, groups, c, hw,
-                     gamma, beta, eps, ss);
+                     gamma, beta, eps, ss, stats);
   CTTA_LAUNCH_CHECK();
   const long long total_vec = (long long)batch * hw * VC;
   const int blocks = (int)fmin((double)cdiv64(total_vec, 256), 8192.0);

@@ -298,6 +298,11 @@ size_t ctta_groupnorm_scratch_floats(int batch, int hw, int c, int groups);
 ctta_status ctta_groupnorm(const void* x, void* y, int batch, int hw, int c, int groups,
                            const float* gamma, const float* beta, float eps, int silu,
                            float* scratch, void* stream);
+/* Same, and also writes (mean, rstd) per (sample, group) to stats [B][G][2] when stats != NULL: what
+ * ctta_groupnorm_bwd needs, for free from the forward's own fp64 fold. */
+ctta_status ctta_groupnorm_stats_out(const void* x, void* y, int batch, int hw, int c, int groups,
+                                     const float* gamma, const float* beta, float eps, int silu,
+                                     float* scratch, float* stats, void* stream);
 /* LayerNorm over rows of a padded bf16 matrix: dims [rows][ld], true width d (pad -> 0). */
 ctta_status ctta_layernorm(const void* x, void* y, int64_t rows, int d, int ld,
                            const float* gamma, const float* beta, float eps, void* stream);
