@@ -659,16 +659,18 @@ extern "C" ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* d
 // ------------------------------------------------------------------------------ GEGLU / SiLU / adds
 // f = [value | gate] (rows x 2hp), dout (rows x hp) -> df (rows x 2hp)
 __global__ void geglu_bwd_kernel(const bf16_t* __restrict__ f, const bf16_t* __restrict__ dout, bf16_t* __restrict__ df,
-                                 long long rows, int hp) {
+                                 long long rows, int hp, int interleaved) {
   const int vc = hp / 8;
   const long long total = rows * vc;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int v = (int)(idx % vc);
     const long long r = idx / vc;
+    const int va = interleaved ? (v >> 1) * 32 + (v & 1) * 8 : v * 8;   // layouts: see geglu_kernel
+    const int vg = interleaved ? va + 16 : hp + v * 8;
     float a[8], g[8], dd[8], da[8], dg[8];
-    unpack8(*reinterpret_cast<const uint4*>(f + (size_t)r * 2 * hp + v * 8), a);
-    unpack8(*reinterpret_cast<const uint4*>(f + (size_t)r * 2 * hp + hp + v * 8), g);
+    unpack8(*reinterpret_cast<const uint4*>(f + (size_t)r * 2 * hp + va), a);
+    unpack8(*reinterpret_cast<const uint4*>(f + (size_t)r * 2 * hp + vg), g);
     unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * hp + v * 8), dd);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -677,14 +679,15 @@ __global__ void geglu_bwd_kernel(const bf16_t* __restrict__ f, const bf16_t* __r
       da[e] = dd[e] * g[e] * cdf;
       dg[e] = dd[e] * a[e] * (cdf + g[e] * pdf);
     }
-    *reinterpret_cast<uint4*>(df + (size_t)r * 2 * hp + v * 8) = pack8(da);
-    *reinterpret_cast<uint4*>(df + (size_t)r * 2 * hp + hp + v * 8) = pack8(dg);
+    *reinterpret_cast<uint4*>(df + (size_t)r * 2 * hp + va) = pack8(da);
+    *reinterpret_cast<uint4*>(df + (size_t)r * 2 * hp + vg) = pack8(dg);
   }
 }
-extern "C" ctta_status ctta_geglu_bwd(const void* f, const void* dout, void* df, int64_t rows, int hp, void* stream) {
-  CTTA_REQUIRE(f && dout && df && hp % 8 == 0, "geglu_bwd: bad arguments");
+extern "C" ctta_status ctta_geglu_bwd(const void* f, const void* dout, void* df, int64_t rows, int hp, int interleaved,
+                                      void* stream) {
+  CTTA_REQUIRE(f && dout && df && hp % 8 == 0 && (!interleaved || hp % 16 == 0), "geglu_bwd: bad arguments");
   hipLaunchKernelGGL(geglu_bwd_kernel, dim3(grid1d(rows * (hp / 8), 256, 8192)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)f, (const bf16_t*)dout, (bf16_t*)df, (long long)rows, hp);
+                     (const bf16_t*)f, (const bf16_t*)dout, (bf16_t*)df, (long long)rows, hp, interleaved);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

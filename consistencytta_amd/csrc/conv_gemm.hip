@@ -483,6 +483,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 
   // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3} (rows of D), m = mb + (lane&15)
   const int nsub = (lane >> 4) * 4;
+  // fused GEGLU: only compiled into the small-fragment tiles (a longer epilogue on the 16-fragment tiles
+  // pushes their accumulators into scratch)
+  if constexpr (FM * FN <= 8 && FN % 2 == 0) {
+    if (p.out_act == 4) {
+#pragma unroll
+      for (int j = 0; j < FM; ++j) {
+        const int m = m0 + wm * TM + j * 16 + frow;
+#pragma unroll
+        for (int i = 0; i < FN; i += 2) {
+          const int n = n0 + wn * TN + i * 16 + nsub;
+          if (m < p.M && n < p.n) epilogue_geglu(p, acc[i][j], acc[i + 1][j], m, n);
+        }
+      }
+      return;
+    }
+  }
   if constexpr (FM * FN <= 16) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
@@ -525,6 +541,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       }
     }
   }
+}
+
+// Fused GEGLU epilogue (out_act 4): the weight rows are packed in 16-row blocks [16 value][16 gate], so fragment
+// i (even) holds the values and fragment i+1 the gates of the same 16 hidden units for the same lane positions:
+// out[m][h] = (val + bias_v) * gelu(gate + bias_g), h = (n / 32) * 16 + n % 16, written to a matrix of HALF the
+// GEMM width.  Replaces attention.py:430-432 (proj -> chunk(2) -> value * gelu(gate)) without the round trip.
+__device__ __forceinline__ void epilogue_geglu(const ConvParams& p, const f32x4_t av, const f32x4_t ag, int m, int n) {
+  float v[4] = {av[0], av[1], av[2], av[3]}, g[4] = {ag[0], ag[1], ag[2], ag[3]};
+  if (p.bias) {
+    const float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+    const float4 bg = *reinterpret_cast<const float4*>(p.bias + n + 16);
+    v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w;
+    g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
+  }
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = v[r] * (0.5f * g[r] * (1.0f + erff(g[r] * 0.70710678118654752f)));
+  const int h = (n >> 5) * 16 + (n & 15);
+  uint2 pk;
+  pk.x = pack2bf(o[0], o[1]);
+  pk.y = pack2bf(o[2], o[3]);
+  *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.out) + (size_t)m * p.ldc + h) = pk;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -781,6 +819,11 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   CTTA_REQUIRE(d->out_offset % 4 == 0, "conv_gemm: out_offset must be a multiple of 4");
   CTTA_REQUIRE(!d->res || d->res_ld % 4 == 0, "conv_gemm: res_ld must be a multiple of 4");
   CTTA_REQUIRE(!d->rowvec || d->rowvec_ld % 4 == 0, "conv_gemm: rowvec_ld must be a multiple of 4");
+  const bool geglu = d->out_act == 4;
+  CTTA_REQUIRE(!geglu || (d->n % 32 == 0 && !d->rowvec && !d->res && !d->accumulate && !d->out2 && !d->out_f32 &&
+                          d->groups <= 1 && d->out_limit == 0 && d->out_offset == 0 && d->bias_m == nullptr &&
+                          d->alpha == 1.0f && d->ldc % 4 == 0 && d->ldc >= d->n / 2),
+               "conv_gemm: the fused GEGLU epilogue takes bias only, n %% 32 == 0 and an output of half the width");
   ConvParams p;
   memset(&p, 0, sizeof(p));
   p.x0 = (const bf16_t*)d->x0; p.x1 = (const bf16_t*)d->x1;
@@ -826,20 +869,27 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     return CTTA_OK;
   }
   if (vid <= 0 || vid > kNumVariants) {
-    if (!d->in_act && glds_default() && want_big_tile(M, d->n, K, groups) && fast_ok(kVariants[kBigTile - 1].bk)) {
+    if (!d->in_act && !geglu && glds_default() && want_big_tile(M, d->n, K, groups) && fast_ok(kVariants[kBigTile - 1].bk)) {
       vid = kBigTile;
     } else {
       vid = pick_variant(M, d->n, K, groups);
+      if (geglu) vid = 6;   // 64x128x64: the measured choice for the short-K feed-forward projections
       // deep and narrow (few 128x128 tiles, long K): the 128x128 tile with split-K beats small tiles that only
       // exist to create workgroups (measured: M=1152, N=1024, K=9216 at 176 TFLOP/s on 64x64 tiles)
       const long long t128 = ((M + 127) / 128) * ((d->n + 127) / 128);
-      if (splitk_default() && groups == 1 && K >= 4096 && d->n >= 256 && t128 < 192 && !scalar_store &&
+      if (splitk_default() && groups == 1 && K >= 4096 && d->n >= 256 && t128 < 192 && !scalar_store && !geglu &&
           d->out_limit == 0 && d->out_offset == 0)
         vid = 1;
       if (!d->in_act && glds_default()) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
     }
   }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
+  if (geglu) {   // compiled into the <= 8-fragment tiles only: 64x64, 64x128, 128x64, 256x32 (all staging modes)
+    const int base = (vid - 1) % 8 + 1;
+    CTTA_REQUIRE(vid <= 24 && (base == 4 || base == 5 || base == 6 || base == 8),
+                 "conv_gemm: the fused GEGLU epilogue needs a 64x64 / 64x128 / 128x64 / 256x32 tile (got %s)",
+                 kVariants[vid - 1].name);
+  }
   CTTA_REQUIRE(kVariants[vid - 1].mode != 2 || fast_ok(kVariants[vid - 1].bk),
                "conv_gemm: variant %s needs (c0+c1) %% BK == 0, one source and <= 32 taps", kVariants[vid - 1].name);
   const Variant& v = kVariants[vid - 1];
@@ -856,8 +906,8 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   float* ws = splitk_workspace();
   const long long tiles = (long long)grid.x * grid.y;
   int splits = 1;
-  if (splitk_default() && ws && groups == 1 && !scalar_store && d->out_limit == 0 && d->out_offset == 0 && tiles < 192 &&
-      p.nk >= 32) {
+  if (splitk_default() && ws && groups == 1 && !scalar_store && !geglu && d->out_limit == 0 && d->out_offset == 0 &&
+      tiles < 192 && p.nk >= 32) {
     splits = (int)(512 / tiles);
     if (splits > 8) splits = 8;
     if (splits > p.nk / 8) splits = p.nk / 8;

@@ -225,9 +225,10 @@ static ctta_status make_transformer(ctta_unet* U, const std::string& p, int c, i
   CTTA_TRY(lin(t + "attn2.to_v.weight", "", inner, X, hmap, identity_map(X, xp), &T->v2, &T->t_v2, nullptr, false));
   CTTA_TRY(lin(t + "attn2.to_out.0.weight", t + "attn2.to_out.0.bias", inner, inner, identity_map(inner, cp), hmap,
                &T->out2, &T->t_out2));
-  {  // GEGLU projection: value rows -> [0, ffp), gate rows -> [ffp, 2*ffp)  (attention.py:430-432)
+  {  // GEGLU projection (attention.py:430-432), rows interleaved in 16-blocks [16 value][16 gate] so that the fused
+     // GEMM epilogue finds value and gate of a hidden unit in adjacent accumulator fragments
     std::vector<int32_t> rows(2 * ffp, -1);
-    for (int i = 0; i < ffh; ++i) { rows[i] = i; rows[ffp + i] = ffh + i; }
+    for (int i = 0; i < ffh; ++i) { rows[(i / 16) * 32 + i % 16] = i; rows[(i / 16) * 32 + 16 + i % 16] = ffh + i; }
     CTTA_TRY(lin(t + "ff.net.0.proj.weight", t + "ff.net.0.proj.bias", 2 * ffh, inner, rows, in_cols, &T->ff1, &T->t_ff1));
   }
   CTTA_TRY(lin(t + "ff.net.2.weight", t + "ff.net.2.bias", inner, ffh, identity_map(inner, cp), identity_map(ffh, ffp),
@@ -341,10 +342,23 @@ static ctta_status run_transformer(UCtx& c, Transformer& T, const bf16_t* x, int
   // --- GEGLU feed-forward
   if (c.train) { n = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(n); }
   RUN(c, ctta_layernorm(s2, n, M, T.inner, cp, T.ln3.gamma, T.ln3.beta, 1e-5f, c.stream));
-  bf16_t* f = A.get<bf16_t>(M * 2 * T.ffp); ALLOC_OR_FAIL(f);
-  CTTA_TRY(run_linear(c, T.ff1, n, cp, M, f, 2 * T.ffp, nullptr, 0));
-  bf16_t* gg = A.get<bf16_t>(M * T.ffp); ALLOC_OR_FAIL(gg);
-  RUN(c, ctta_geglu(f, gg, M, T.ffp, c.stream));
+  bf16_t* f = nullptr;
+  bf16_t* gg = nullptr;
+  if (c.train) {   // the backward pass needs the pre-activation: unfused
+    f = A.get<bf16_t>(M * 2 * T.ffp); ALLOC_OR_FAIL(f);
+    CTTA_TRY(run_linear(c, T.ff1, n, cp, M, f, 2 * T.ffp, nullptr, 0));
+    gg = A.get<bf16_t>(M * T.ffp); ALLOC_OR_FAIL(gg);
+    RUN(c, ctta_geglu(f, gg, M, T.ffp, 1, c.stream));
+  } else {         // value * gelu(gate) in the GEMM epilogue: the (M, 2*ffp) projection never reaches HBM
+    gg = A.get<bf16_t>(M * T.ffp); ALLOC_OR_FAIL(gg);
+    ctta_conv_desc d;
+    desc_init(&d);
+    d.x0 = n; d.c0 = cp;
+    d.batch = 1; d.hi = (int)M; d.wi = 1; d.ho = (int)M; d.wo = 1;
+    d.w = T.ff1.w; d.k_pad = T.ff1.k_pad; d.n = T.ff1.n; d.bias = T.ff1.bias;
+    d.out = gg; d.ldc = T.ffp; d.out_act = 4;
+    RUN(c, ctta_conv_gemm(&d, c.stream));
+  }
   bf16_t* s3 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s3);
   CTTA_TRY(run_linear(c, T.ff2, gg, T.ffp, M, s3, cp, s2, cp));
   CTTA_TRY(run_linear(c, T.proj_out, s3, cp, M, out, T.c, x, T.c));

@@ -267,7 +267,7 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
     CTTA_TRY(linear_dgrad(c, T.t_ff2.d, ds, cp, cp, M, dgg, ffp, ffp, false));
     CTTA_TRY(linear_wgrad(c, T.t_ff2.m, nullptr, S.gg, ffp, M, ds, cp));
     bf16_t* df = A.get<bf16_t>((size_t)M * 2 * ffp); ALLOC_OR_FAIL(df);
-    RUN(c, ctta_geglu_bwd(S.f, dgg, df, M, ffp, c.stream));
+    RUN(c, ctta_geglu_bwd(S.f, dgg, df, M, ffp, 1, c.stream));
     bf16_t* dn = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(dn);
     CTTA_TRY(linear_dgrad(c, T.t_ff1.d, df, 2 * ffp, 2 * ffp, M, dn, cp, cp, false));
     CTTA_TRY(linear_wgrad(c, T.t_ff1.m, nullptr, S.n3, cp, M, df, 2 * ffp));

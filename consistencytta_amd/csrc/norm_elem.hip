@@ -426,17 +426,21 @@ extern "C" ctta_status ctta_layernorm(const void* x, void* y, int64_t rows, int 
 }
 
 // ------------------------------------------------------------------------------ GEGLU
+// layout 0: [value | gate] halves (torch chunk(2), attention.py:430-432); layout 1: 16-column blocks
+// [v0..15][g0..15][v16..31][g16..31]... (what the fused GEMM epilogue and the U-Net engine use)
 __global__ void geglu_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, long long rows,
-                             int hp) {
+                             int hp, int interleaved) {
   const int vc = hp / 8;
   const long long total = rows * vc;
   for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
     const int v = (int)(idx % vc);
     const long long r = idx / vc;
+    const int va = interleaved ? (v >> 1) * 32 + (v & 1) * 8 : v * 8;
+    const int vg = interleaved ? va + 16 : hp + v * 8;
     float a[8], g[8];
-    unpack8(*reinterpret_cast<const uint4*>(in + (size_t)r * 2 * hp + v * 8), a);
-    unpack8(*reinterpret_cast<const uint4*>(in + (size_t)r * 2 * hp + hp + v * 8), g);
+    unpack8(*reinterpret_cast<const uint4*>(in + (size_t)r * 2 * hp + va), a);
+    unpack8(*reinterpret_cast<const uint4*>(in + (size_t)r * 2 * hp + vg), g);
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       a[e] = a[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f)));
@@ -444,12 +448,12 @@ __global__ void geglu_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__
   }
 }
 
-extern "C" ctta_status ctta_geglu(const void* in, void* out, int64_t rows, int hp, void* stream) {
-  CTTA_REQUIRE(in && out && hp % 8 == 0, "geglu: bad arguments");
+extern "C" ctta_status ctta_geglu(const void* in, void* out, int64_t rows, int hp, int interleaved, void* stream) {
+  CTTA_REQUIRE(in && out && hp % 8 == 0 && (!interleaved || hp % 16 == 0), "geglu: bad arguments");
   const long long total = rows * (hp / 8);
   const int blocks = (int)fmin((double)cdiv64(total, 256), 8192.0);
   hipLaunchKernelGGL(geglu_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
-                     (bf16_t*)out, (long long)rows, hp);
+                     (bf16_t*)out, (long long)rows, hp, interleaved);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

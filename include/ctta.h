@@ -307,7 +307,7 @@ ctta_status ctta_groupnorm_stats_out(const void* x, void* y, int batch, int hw, 
 ctta_status ctta_layernorm(const void* x, void* y, int64_t rows, int d, int ld,
                            const float* gamma, const float* beta, float eps, void* stream);
 /* GEGLU: in [rows][2*hp] = [value | gate] -> out [rows][hp] = value * gelu_erf(gate) */
-ctta_status ctta_geglu(const void* in, void* out, int64_t rows, int hp, void* stream);
+ctta_status ctta_geglu(const void* in, void* out, int64_t rows, int hp, int interleaved, void* stream);
 /* Row softmax: fp32 scores [rows][cols] * scale -> bf16 probabilities [rows][cols] */
 ctta_status ctta_softmax_rows(const float* s, void* p, int64_t rows, int cols, float scale,
                               void* stream);
@@ -398,7 +398,8 @@ ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* dx, int batc
 ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t rows, int d, int ld,
                                const float* gamma, float eps, int accumulate_dx, float* dgamma, float* dbeta,
                                void* stream);
-ctta_status ctta_geglu_bwd(const void* f, const void* dout, void* df, int64_t rows, int hp, void* stream);
+ctta_status ctta_geglu_bwd(const void* f, const void* dout, void* df, int64_t rows, int hp, int interleaved,
+                           void* stream);
 ctta_status ctta_add_slices(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows,
                             int cols, void* stream);
 ctta_status ctta_zero_insert2(const void* dy, void* dz, int batch, int ho, int wo, int hz, int wz, int c,

@@ -158,9 +158,18 @@ def test_layernorm_geglu_backward(rows, d, ld):
     out.backward(do)
     fd, dod = f.detach().to(torch.bfloat16).to(DEV), do.to(torch.bfloat16).to(DEV)
     df = torch.empty_like(fd)
-    N.check(lib().ctta_geglu_bwd(N.ptr(fd), N.ptr(dod), N.ptr(df), rows, hp, N.stream_ptr()))
+    N.check(lib().ctta_geglu_bwd(N.ptr(fd), N.ptr(dod), N.ptr(df), rows, hp, 0, N.stream_ptr()))
     sync()
     assert rel_err(df.float().cpu(), f.grad) < 2 * BF16_TOL
+    # interleaved 16-blocks (engine layout): same numbers at permuted columns
+    perm = torch.empty(2 * hp, dtype=torch.long)
+    for j in range(hp):
+        perm[(j // 16) * 32 + j % 16], perm[(j // 16) * 32 + 16 + j % 16] = j, hp + j
+    fi = fd[:, perm.to(DEV)].contiguous()
+    dfi = torch.empty_like(fi)
+    N.check(lib().ctta_geglu_bwd(N.ptr(fi), N.ptr(dod), N.ptr(dfi), rows, hp, 1, N.stream_ptr()))
+    sync()
+    assert torch.equal(dfi.cpu(), df[:, perm.to(DEV)].cpu())
 
 
 def test_softmax_forward_bias_and_backward():

@@ -109,6 +109,31 @@ def test_conv_split_k(B, Cin, Cout, H, W):
     assert rel_err(from_nhwc(out), ref) < 2 * BF16_TOL
 
 
+@pytest.mark.parametrize("rows,k,hid,tile", [(300, 256, 1024, 0), (70, 512, 2048, 0), (129, 64, 96, 0), (300, 256, 1024, 21),
+                                             (300, 256, 1024, 24), (300, 256, 1024, 12)])
+def test_linear_with_fused_geglu_epilogue(rows, k, hid, tile):
+    """out_act=4: rows of the packed weight interleaved in 16-blocks [16 value][16 gate]; the epilogue writes
+    value * gelu(gate) at half the GEMM width (GEGLU, attention.py:430-432)."""
+    x = bf16_round(det("fg.x", (rows, k), 1))
+    w = bf16_round(det("fg.w", (2 * hid, k), 2) * (1.5 / math.sqrt(k)))
+    b = det("fg.b", (2 * hid,), 3) * 0.2
+    proj = F.linear(x, w, b)
+    ref = proj[:, :hid] * F.gelu(proj[:, hid:])
+    hidp = (hid + 15) // 16 * 16
+    wi, bi = torch.zeros(2 * hidp, k), torch.zeros(2 * hidp)
+    for j in range(hid):
+        wi[(j // 16) * 32 + j % 16], wi[(j // 16) * 32 + 16 + j % 16] = w[j], w[hid + j]
+        bi[(j // 16) * 32 + j % 16], bi[(j // 16) * 32 + 16 + j % 16] = b[j], b[hid + j]
+    wp, k_pad = pack_conv_weight(wi[:, :, None, None])
+    xd = x.to(torch.bfloat16).to(DEV)
+    out = torch.empty(rows, hidp, dtype=torch.bfloat16, device=DEV)
+    run_conv(conv_desc(x0=xd, c0=k, batch=1, hi=rows, wi=1, ho=rows, wo=1, w=wp, k_pad=k_pad, n=2 * hidp, bias=bi.to(DEV),
+                       out=out, ldc=hidp, out_act=4, tile=tile))
+    got = out.float().cpu()
+    assert rel_err(got[:, :hid], ref) < 2 * BF16_TOL
+    assert float(got[:, hid:].abs().max()) == 0.0 if hidp > hid else True
+
+
 def test_conv1d_dilated_lrelu_and_accumulate():
     B, C, L, k, d = 2, 32, 200, 7, 3
     x = bf16_round(det("c1d.x", (B, C, L), 1))
@@ -323,7 +348,15 @@ def test_geglu_and_softmax():
     ref = x[:, :hp] * F.gelu(x[:, hp:])
     xd = x.to(torch.bfloat16).to(DEV)
     y = torch.empty(rows, hp, dtype=torch.bfloat16, device=DEV)
-    N.check(lib().ctta_geglu(N.ptr(xd), N.ptr(y), rows, hp, N.stream_ptr()))
+    N.check(lib().ctta_geglu(N.ptr(xd), N.ptr(y), rows, hp, 0, N.stream_ptr()))
+    sync()
+    assert rel_err(y.to(torch.float32).cpu(), ref) < BF16_TOL
+    # the engine's layout: 16-column blocks [16 value][16 gate]
+    xi = torch.empty_like(x)
+    for j in range(hp):
+        xi[:, (j // 16) * 32 + j % 16] = x[:, j]
+        xi[:, (j // 16) * 32 + 16 + j % 16] = x[:, hp + j]
+    N.check(lib().ctta_geglu(N.ptr(xi.to(torch.bfloat16).to(DEV)), N.ptr(y), rows, hp, 1, N.stream_ptr()))
     sync()
     assert rel_err(y.to(torch.float32).cpu(), ref) < BF16_TOL
     s = det("sm.s", (19, 4096), 2) * 30

@@ -83,7 +83,9 @@ def test_unet_parameter_gradients_match_autograd(B, H, W, L):
     with torch.no_grad():
         out2 = m(x.to(DEV), ts.to(DEV), guidance=gs.to(DEV), encoder_hidden_states=enc.to(DEV),
                  encoder_attention_mask=mask.to(DEV)).sample
-    assert float((out2 - out).abs().max()) == 0.0
+    # (not bit-equal: the inference forward fuses GEGLU into the GEMM epilogue, the training forward keeps the
+    # pre-activation for the backward pass)
+    assert float((out2 - out).norm() / out.norm()) < 2.5e-2      # two bf16 evaluation orders: the engines' stated tolerance
 
 
 def test_backward_requires_a_training_forward():
