@@ -329,10 +329,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   int ftap = 0, fkh = 0, fkw = 0, fcb = 0;   // wave-uniform K state (tap index, its (kh,kw), channel base)
   __amdgpu_buffer_rsrc_t rsx, rsw;
   if constexpr (MODE == 2) {
-    if (kt_begin > 0) {   // split-K: start inside the K range (ct is a multiple of BK on this path)
-      const int kk0 = kt_begin * BK;
-      ftap = kk0 / p.ct;
-      fcb = kk0 - ftap * p.ct;
+    // K order on this path: taps INNERMOST -- K-step s = (channel chunk s / taps, tap s % taps).  All taps of one
+    // 64-channel chunk re-read the same (BM + halo) x BK footprint (tens of KB: L1/L2 resident); with channels
+    // innermost the whole (BM + halo) x C footprint of every resident workgroup has to survive between taps, which
+    // overflows the 4 MB L2 of an XCD (measured with FETCH_SIZE: 10-26x the input tensor per launch on the
+    // 256/512-channel convs, i.e. fabric-bound at 3.5 TB/s).
+    if (kt_begin > 0) {   // split-K: start inside the K range
+      const int chunk = kt_begin / p.taps;
+      ftap = kt_begin - chunk * p.taps;
+      fcb = chunk * BK;
       fkh = ftap / p.kw;
       fkw = ftap - fkh * p.kw;
     }
@@ -392,17 +397,14 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(xs + i * RPP * LDK), 16,
                                                (int)v, 0, 0, 0);
     }
-    const int soff = kt * BK * 2;
+    const int soff = (ftap * p.ct + fcb) * 2;   // weight columns stay (tap, channel)-ordered; only the walk changes
 #pragma unroll
     for (int j = 0; j < WP; ++j)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ws + j * RPP * LDK), 16,
                                                (int)fwoff[j], soff, 0, 0);
-    fcb += BK;
-    if (fcb >= p.ct) {
-      fcb = 0;
-      ++ftap;
-      if (++fkw == p.kw) { fkw = 0; ++fkh; }
-    }
+    ++ftap;
+    if (++fkw == p.kw) { fkw = 0; ++fkh; }
+    if (ftap == p.taps) { ftap = 0; fkh = 0; fkw = 0; fcb += BK; }
   };
 
   f32x4_t acc[FN][FM];

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""HBM traffic of the bench's kernel families from two rocprofv3 PMC passes (MI355X_MICROARCH.md, "HBM" and
+"rocprofv3 PMC slots": FETCH_SIZE and WRITE_SIZE do not fit one pass).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o p -- python3 bench.py ...
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o p -- python3 bench.py ...
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/pmc_traffic_r01.json
+
+Units and the gfx950 correction as the guide prescribes: FETCH_SIZE / WRITE_SIZE are reported in KiB
+(TCC_EA0_RDREQ x 64 B / 1024); on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) coalesced
+reads at 64 B, i.e. HALF the bytes -- all loads of these kernels are 16 B/lane, so the read figure is doubled.
+WRITE_SIZE is uncalibrated on this part and reported as is.  Steps are counted by the dispatches of
+conv_small_n_kernel<1> (exactly one per generation step)."""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    for key in ("conv_gemm_kernel", "conv1d_halo_kernel", "attention_kernel", "gn_", "layernorm", "geglu", "softmax_rows",
+                "conv_small_n_kernel", "splitk_finish"):
+        if key in name:
+            return key.rstrip("_")
+    return "other"
+
+
+def load(directory, counter):
+    path = glob.glob(directory + "/**/*counter_collection.csv", recursive=True)[0]
+    tot, steps = defaultdict(float), 0
+    seen = set()
+    for row in csv.DictReader(open(path)):
+        if row["Counter_Name"] != counter:
+            continue
+        tot[family(row["Kernel_Name"])] += float(row["Counter_Value"])
+        if "conv_small_n_kernel<1>" in row["Kernel_Name"] and row["Dispatch_Id"] not in seen:
+            seen.add(row["Dispatch_Id"])
+            steps += 1
+    return tot, max(1, steps)
+
+
+def main():
+    fetch, fs = load(sys.argv[1], "FETCH_SIZE")
+    write, wsteps = load(sys.argv[2], "WRITE_SIZE")
+    out = {"unit": "GB per generation step (batch 32)", "steps_fetch_pass": fs, "steps_write_pass": wsteps,
+           "fetch_correction": "x2 (gfx950: 128-B requests of 16 B/lane reads tallied at 64 B)", "families": {}}
+    for fam in sorted(set(fetch) | set(write), key=lambda f: -(fetch.get(f, 0) + write.get(f, 0))):
+        rd = fetch.get(fam, 0.0) * 1024 * 2 / fs / 1e9
+        wr = write.get(fam, 0.0) * 1024 / wsteps / 1e9
+        out["families"][fam] = {"read_GB": round(rd, 3), "write_GB": round(wr, 3), "total_GB": round(rd + wr, 3)}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
