@@ -183,7 +183,7 @@ def main():
         result["roofline"] = {
             "kernel": "conv_gemm_kernel (implicit-GEMM conv / linear / bmm, v_mfma_f32_16x16x32_bf16)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(B),
             "algorithmic_gflop_per_clip": round(gf_clip, 1), "launches_per_step": int(conv_cnt),
             "kernel_ms_per_step": round(conv_ms, 3), "avg_launch_ms": round(conv_ms / max(1, conv_cnt), 4),
             "executed_tflops_incl_padding": round(conv_exec_fl / (conv_ms * 1e-3) / 1e12, 2),
@@ -366,6 +366,21 @@ def distill_leg(args, dev, world, rank):
         }
     del m, opt
     return out
+
+
+def pmc_traffic(batch):
+    """HBM-side bytes per step of the conv_gemm family (GB): PMC counters cannot be collected inside the timed run, so
+    this is the committed result of the two separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this
+    same command (tools/pmc_traffic.py; units and the gfx950 x2 read correction per MI355X_MICROARCH.md).  None when
+    the file is absent or was taken at another batch size."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")))
+        if "batch 32" not in d.get("unit", "") or batch != 32:
+            return None
+        f = d["families"]["conv_gemm_kernel"]
+        return {"read_GB_per_step": f["read_GB"], "write_GB_per_step": f["write_GB"], "source": "profiles/pmc_traffic_r01.json"}
+    except Exception:
+        return None
 
 
 def host_cores():
