@@ -42,6 +42,10 @@ struct ConvParams {
   // partial sums to slab `split` of a workspace (out / ldc / ogs are redirected by the host); the fused epilogue
   // runs afterwards in splitk_finish_kernel
   int ksplit, nk_split;
+  // XCD-aware tile order (1-D grid): block id b runs on XCD b % 8; XCD x owns the contiguous M-tile range
+  // [x * xcd_per, (x + 1) * xcd_per) and walks it with the N tiles innermost, so the tiles that share input rows
+  // (neighbouring image rows, all N tiles of one M tile) meet in the same 4 MB L2 close in time.  0 = plain 2-D grid.
+  int xcd_per, m_tiles, n_tiles, n_inner;   // n_inner = 0: M tiles innermost (many N tiles: keep the weight slice hot)
 };
 
 // GLDS = true: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
@@ -175,8 +179,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  int mt = blockIdx.x, nt = blockIdx.y;
+  if (p.xcd_per > 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    if (p.n_inner) { nt = local % p.n_tiles; mt = xcd * p.xcd_per + local / p.n_tiles; }
+    else { nt = local / p.xcd_per; mt = xcd * p.xcd_per + local % p.xcd_per; }
+    if (mt >= p.m_tiles) return;   // padding blocks of the last XCD range (whole workgroup, before any barrier)
+  }
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
   const int zs = blockIdx.z;
   const int g = p.ksplit > 1 ? 0 : zs;                    // group index (pointer offsets)
   const int kt_begin = p.ksplit > 1 ? zs * p.nk_split : 0;
@@ -768,6 +779,11 @@ static const bf16_t* zero_page() {
   return z;
 }
 
+static bool xcd_default() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_XCD"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
 static bool splitk_default() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("CTTA_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -918,6 +934,14 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   }
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, vid, M, d->n, K, groups, (hipStream_t)stream);
+  if (splits == 1 && groups == 1 && xcd_default() && grid.x >= 64) {
+    p.m_tiles = (int)grid.x; p.n_tiles = (int)grid.y;
+    p.xcd_per = (p.m_tiles + 7) / 8;
+    // few N tiles: visit them back to back per M tile (the input tile is read once per XCD); many N tiles (wide
+    // linears: the weight matrix is far larger than L2): keep one weight slice hot and walk the XCD's M range
+    p.n_inner = (p.n_tiles <= 4 || w_bytes <= (2LL << 20)) ? 1 : 0;   // a <= 2 MB weight matrix stays L2-resident anyway
+    grid = dim3((unsigned)(8 * p.xcd_per * p.n_tiles), 1, 1);
+  }
   if (splits > 1) {
     const int ld = (d->n + 3) / 4 * 4;
     ConvParams q = p;   // first pass: raw partial sums
