@@ -185,6 +185,10 @@ def lib():
         raise RuntimeError(
             "libctta_hip.so is missing (%s). Build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or consistencytta_amd/csrc/build.sh; there is no non-HIP fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own libamdhip64; import torch first so that this library binds to the SAME HIP runtime
+    # instance (loading ours first pulls in /opt/rocm's copy: two runtimes in one process, device memory of one is
+    # invisible to the other -- observed as "no ROCm-capable device is detected" from the second one)
+    import torch  # noqa: F401
     L = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the .so does not export a declared symbol

@@ -320,18 +320,31 @@ class AudioLCM(AudioDistilledModel):
                 m.mark_weights_changed()
         return FusedAdamW(self.student_unet, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
 
-    def train_step(self, z_0, prompt, optimizer, lr_scheduler=None, gt_wav=None, skip_nan=True, **fw):
-        """One optimisation step of tools/train_utils.py:150-190 (gradient_accumulation_steps=1):
-        loss -> backward -> gradient all-reduce (RCCL) -> AdamW -> lr schedule -> zero_grad -> EMA.
-        Returns the loss as a Python float (the reference reads `loss.item()` every step too)."""
+    def train_step(self, z_0, prompt, optimizer, lr_scheduler=None, gt_wav=None, skip_nan=True,
+                   accumulation_steps=1, **fw):
+        """One micro-step of tools/train_utils.py:150-190: loss -> backward, and on every `accumulation_steps`-th
+        call (accelerator.accumulate / sync_gradients, train.py:269) gradient all-reduce (RCCL, overlapped with
+        that backward) -> AdamW -> lr schedule -> zero_grad -> EMA.  In between, gradients only accumulate locally
+        (DDP's no_sync).  The loss of every micro-step is scaled by 1/accumulation_steps like accelerate does.
+        Returns the (unscaled) loss as a Python float (the reference reads `loss.item()` every step too)."""
         assert self.training, "train_step needs model.train()"
+        self._micro = getattr(self, "_micro", 0) + 1
+        boundary = self._micro % max(1, int(accumulation_steps)) == 0
+        if not boundary:
+            with torch.no_grad():
+                loss, pred, target, sig, gamma = self._forward_impl(
+                    z_0, gt_wav, prompt, False, True, fw.pop("time_inds", None), fw.pop("gaussian_noise", None),
+                    fw.pop("guidance_scale", None), True)
+                self._student_backward(pred, target, sig, gamma, 1.0 / accumulation_steps)
+            return float(loss.item())
         with torch.no_grad():
             loss, pred, target, sig, gamma = self._forward_impl(
                 z_0, gt_wav, prompt, False, True, fw.pop("time_inds", None), fw.pop("gaussian_noise", None),
                 fw.pop("guidance_scale", None), True)
             # gradient all-reduce (RCCL) overlapped with the backward pass, block by block
             buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges())
-            self._student_backward(pred, target, sig, gamma, 1.0, buckets.ready if buckets.enabled else None)
+            self._student_backward(pred, target, sig, gamma, 1.0 / max(1, int(accumulation_steps)),
+                                   buckets.ready if buckets.enabled else None)
             world = buckets.wait()
             value = float(loss.item())
             if not (skip_nan and value != value):      # train_utils.py:167-172: a NaN loss skips the update

@@ -270,3 +270,31 @@ def test_blockwise_backward_with_rccl_buckets_equals_monolithic(golden):
     worst = float((flat - ref_flat).abs().max() / ref_flat.abs().max())
     print("block-wise + RCCL vs monolithic: max relative parameter difference after one step %.3e" % worst)
     assert worst <= 5e-6      # LayerNorm gamma/beta gradients use fp32 atomics: last-bit run-to-run differences
+
+
+def test_gradient_accumulation_matches_one_big_step(golden):
+    """accumulation_steps=2 with the same micro-batch twice: the accumulated, 1/2-scaled gradient equals the single
+    micro-step gradient, so the parameters after the boundary step equal those of a plain step (up to bf16 rounding of
+    the scaled loss gradient), and nothing moves before the boundary."""
+    g = golden("distill_tiny")
+    kw = dict(time_inds=torch.from_numpy(g["time_inds"]) * 2, gaussian_noise=torch.from_numpy(g["noise"]).to(DEV),
+              guidance_scale=torch.from_numpy(g["guidance"]))
+    m1, P, z0 = _lcm()
+    m1.train()
+    o1 = m1.prepare_training(lr=1e-4, weight_decay=0.0, broadcast=False)
+    before = o1.flat.detach().clone()
+    m1.train_step(z0, P, o1, None, **kw)
+    m2, _, _ = _lcm()
+    m2.train()
+    o2 = m2.prepare_training(lr=1e-4, weight_decay=0.0, broadcast=False)
+    m2.train_step(z0, P, o2, None, accumulation_steps=2, **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(o2.flat, before) and float(o2.grad.abs().max()) > 0      # no update, gradients kept
+    ema_before = m2.student_ema_unet._flat.detach().clone()
+    m2.train_step(z0, P, o2, None, accumulation_steps=2, **kw)
+    torch.cuda.synchronize()
+    assert float(o2.grad.abs().max()) == 0.0 and not torch.equal(m2.student_ema_unet._flat, ema_before)
+    d1, d2 = (o1.flat - before), (o2.flat - before)
+    rel = float((d1 - d2).norm() / d1.norm())
+    print("accumulated (2 x 1/2) vs single step: relative difference of the parameter update %.3e" % rel)
+    assert rel < 5e-2        # AdamW's first step is lr*sign-like: tiny gradient differences flip a few near-zero elements
