@@ -91,6 +91,13 @@ SIGNATURES = {
     "ctta_wgrad_scatter_rows": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ctta_col_scatter": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ctta_transpose_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "ctta_vae_encoder_create": (c_int, [POINTER(VAEConfig), POINTER(Tensor), c_int, c_void_p, POINTER(c_void_p)]),
+    "ctta_vae_encoder_destroy": (None, [c_void_p]),
+    "ctta_vae_encoder_load_weights": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "ctta_vae_encode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ctta_vae_encoder_num_taps": (c_int, [c_void_p]),
+    "ctta_vae_encoder_tap_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
+    "ctta_vae_encoder_tap_read": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "ctta_pack_weight_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ctta_copy_segments_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "ctta_unet_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

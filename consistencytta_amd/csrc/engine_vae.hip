@@ -66,6 +66,12 @@ struct VaeRes {
   bool has_sc = false;
 };
 
+struct VaeAttn {   // AttnBlock (modules.py:178-230): single head over H*W tokens, d = C
+  GNLayer norm;
+  ConvLayer q, k, v, proj;
+  int C = 0;
+};
+
 struct ctta_vae {
   ctta_vae_config cfg;
   WeightStore store;
@@ -74,8 +80,7 @@ struct ctta_vae {
   float *pq_w = nullptr, *pq_b = nullptr;
   ConvLayer conv_in;
   VaeRes mid1, mid2;
-  GNLayer attn_norm;
-  ConvLayer aq, ak, av, aproj;
+  VaeAttn attn;
   std::vector<std::vector<VaeRes>> up;     // [level][block]
   std::vector<ConvLayer> upsample;         // [level] (level 0 unused)
   GNLayer norm_out;
@@ -136,27 +141,37 @@ static ctta_status run_vae_res(VCtx& c, const VaeRes& R, const bf16_t* x, int H,
 // AttnBlock: single head over N = H*W tokens, d = C.  Scores are materialised in fp32
 // (B x N x N; 2 GiB at B=32, N=4096 -- 288 GB of HBM makes this the simple choice), softmaxed
 // to bf16, and multiplied by V^T; all three products run on conv_gemm.
-static ctta_status run_vae_attn(VCtx& c, ctta_vae* V, const bf16_t* x, int H, int W, bf16_t** out_p) {
+static ctta_status make_vae_attn(WeightStore& ws, const std::string& p, int C, VaeAttn* T) {
+  T->C = C;
+  CTTA_TRY(make_gn(ws, p + "norm.", C, &T->norm));
+  CTTA_TRY(make_conv(ws, p + "q.", C, C, C, 1, 1, 1, 0, &T->q));
+  CTTA_TRY(make_conv(ws, p + "k.", C, C, C, 1, 1, 1, 0, &T->k));
+  CTTA_TRY(make_conv(ws, p + "v.", C, C, C, 1, 1, 1, 0, &T->v));
+  CTTA_TRY(make_conv(ws, p + "proj_out.", C, C, C, 1, 1, 1, 0, &T->proj));
+  return CTTA_OK;
+}
+
+static ctta_status run_vae_attn(VCtx& c, const VaeAttn* V, const bf16_t* x, int H, int W, bf16_t** out_p) {
   Arena& A = *c.arena;
-  const int N = H * W, C = V->block_in, B = c.B;
+  const int N = H * W, C = V->C, B = c.B;
   CTTA_REQUIRE(N % 64 == 0 && C % 64 == 0, "vae attention: tokens=%d and channels=%d must be multiples of 64", N, C);
   const size_t M = (size_t)B * N;
   bf16_t* out = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(out);
   const size_t mk = A.mark();
   bf16_t* g = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(g);
-  CTTA_TRY(vgn(c, V->attn_norm, x, g, N, false));
+  CTTA_TRY(vgn(c, V->norm, x, g, N, false));
   bf16_t* q = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(q);
   bf16_t* k = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(k);
-  CTTA_TRY(run_conv2d(c, V->aq, g, B, H, W, false, q, nullptr, 0, nullptr, 0));
-  CTTA_TRY(run_conv2d(c, V->ak, g, B, H, W, false, k, nullptr, 0, nullptr, 0));
+  CTTA_TRY(run_conv2d(c, V->q, g, B, H, W, false, q, nullptr, 0, nullptr, 0));
+  CTTA_TRY(run_conv2d(c, V->k, g, B, H, W, false, k, nullptr, 0, nullptr, 0));
   bf16_t* vt = A.get<bf16_t>((size_t)B * C * N); ALLOC_OR_FAIL(vt);
   {
     ctta_conv_desc d;
     desc_init(&d);
-    d.x0 = V->av.p.w; d.c0 = V->av.p.k_pad;
+    d.x0 = V->v.p.w; d.c0 = V->v.p.k_pad;
     d.batch = 1; d.hi = C; d.wi = 1; d.ho = C; d.wo = 1;
     d.w = g; d.k_pad = C; d.n = N;
-    d.bias_m = V->av.p.bias;
+    d.bias_m = V->v.p.bias;
     d.out = vt; d.ldc = N;
     d.groups = B; d.w_group_stride = (int64_t)N * C; d.out_group_stride = (int64_t)C * N;
     RUN(c, ctta_conv_gemm(&d, c.stream));
@@ -187,7 +202,7 @@ static ctta_status run_vae_attn(VCtx& c, ctta_vae* V, const bf16_t* x, int H, in
     d.out_group_stride = (int64_t)N * C;
     RUN(c, ctta_conv_gemm(&d, c.stream));
   }
-  CTTA_TRY(run_conv2d(c, V->aproj, o, B, H, W, false, out, nullptr, 0, x, C));
+  CTTA_TRY(run_conv2d(c, V->proj, o, B, H, W, false, out, nullptr, 0, x, C));
   A.release(mk);
   *out_p = out;
   return CTTA_OK;
@@ -218,7 +233,7 @@ static ctta_status vae_forward_impl(ctta_vae* V, bool dry, const float* z, int B
   add_tap(c, "conv_in", h, B, ch, H, W, ch);
   CTTA_TRY(run_vae_res(c, V->mid1, h, H, W, &h));
   add_tap(c, "mid.block_1", h, B, ch, H, W, ch);
-  CTTA_TRY(run_vae_attn(c, V, h, H, W, &h));
+  CTTA_TRY(run_vae_attn(c, &V->attn, h, H, W, &h));
   add_tap(c, "mid.attn_1", h, B, ch, H, W, ch);
   CTTA_TRY(run_vae_res(c, V->mid2, h, H, W, &h));
   add_tap(c, "mid.block_2", h, B, ch, H, W, ch);
@@ -262,11 +277,7 @@ static ctta_status vae_build(ctta_vae* V) {
   const std::string p = "decoder.";
   CTTA_TRY(make_conv(ws, p + "conv_in.", block_in, cfg.z_channels, 32, 3, 3, 1, 1, &V->conv_in));
   CTTA_TRY(make_vae_res(ws, p + "mid.block_1.", block_in, block_in, &V->mid1));
-  CTTA_TRY(make_gn(ws, p + "mid.attn_1.norm.", block_in, &V->attn_norm));
-  CTTA_TRY(make_conv(ws, p + "mid.attn_1.q.", block_in, block_in, block_in, 1, 1, 1, 0, &V->aq));
-  CTTA_TRY(make_conv(ws, p + "mid.attn_1.k.", block_in, block_in, block_in, 1, 1, 1, 0, &V->ak));
-  CTTA_TRY(make_conv(ws, p + "mid.attn_1.v.", block_in, block_in, block_in, 1, 1, 1, 0, &V->av));
-  CTTA_TRY(make_conv(ws, p + "mid.attn_1.proj_out.", block_in, block_in, block_in, 1, 1, 1, 0, &V->aproj));
+  CTTA_TRY(make_vae_attn(ws, p + "mid.attn_1.", block_in, &V->attn));
   CTTA_TRY(make_vae_res(ws, p + "mid.block_2.", block_in, block_in, &V->mid2));
   V->up.resize(nres);
   V->upsample.resize(nres);
@@ -355,6 +366,212 @@ extern "C" ctta_status ctta_vae_tap_info(const ctta_vae* V, int i, const char** 
 extern "C" ctta_status ctta_vae_tap_read(ctta_vae* V, int i, float* dst, void* stream) {
   CTTA_REQUIRE(V && i >= 0 && i < (int)V->taps.size() && dst, "tap index out of range");
   const Tap& t = V->taps[i];
+  CTTA_REQUIRE(t.ptr, "tap '%s' has not been produced yet", t.name.c_str());
+  return ctta_nhwc_bf16_to_nchw_f32(t.ptr, dst, t.b, t.c, t.h, t.w, t.c_stride, stream);
+}
+
+// ====================================================================================== VAE encoder
+// AutoencoderKL.encode (autoencoder.py:80-85): Encoder.forward (modules.py:519-543) + quant_conv, the training-side
+// latent encoder (tools/train_utils.py:155-162 encodes every batch).  Same blocks as the decoder; Downsample
+// (modules.py:87-92) = zero-pad right/bottom by one + 3x3 stride-2 conv, which is conv_gemm with pad 0 and the
+// output extent H/2 x W/2 (the out-of-image tap reads zeros).
+struct ctta_vae_encoder {
+  ctta_vae_config cfg;
+  WeightStore store;
+  Arena arena;
+  std::vector<Tap> taps;
+  ConvLayer conv_in;
+  std::vector<std::vector<VaeRes>> down;   // [level][block]
+  std::vector<ConvLayer> downsample;       // [level] (last level unused)
+  VaeRes mid1, mid2;
+  VaeAttn attn;
+  GNLayer norm_out;
+  ConvLayer conv_out;
+  float *q_w = nullptr, *q_b = nullptr;    // quant_conv (1x1) in fp32
+  int block_in = 0, zc2 = 0;
+  float* gn_scratch = nullptr;
+  size_t gn_scratch_floats = 0;
+};
+
+// moments[b][o][hw] = quant_conv(h)[o] per pixel, h = conv_out result [M][zc2] bf16 -> NCHW fp32
+__global__ void quant_moments_kernel(const bf16_t* __restrict__ h, const float* __restrict__ w, const float* __restrict__ b,
+                                     int B, int cin, int cout, int HW, float* __restrict__ out) {
+  const long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (pix >= (long long)B * HW) return;
+  const int bb = (int)(pix / HW), hw = (int)(pix - (long long)bb * HW);
+  float in[32];
+  for (int c = 0; c < cin; ++c) in[c] = bf2f(h[(size_t)pix * cin + c]);
+  for (int o = 0; o < cout; ++o) {
+    float acc = b[o];
+    for (int c = 0; c < cin; ++c) acc += w[o * cin + c] * in[c];
+    out[((size_t)bb * cout + o) * HW + hw] = acc;
+  }
+}
+
+static ctta_status vae_encode_impl(ctta_vae_encoder* E, bool dry, const float* mel, int B, float* moments,
+                                   hipStream_t stream, size_t* gn_need) {
+  const ctta_vae_config& cfg = E->cfg;
+  VCtx c;
+  c.arena = &E->arena; c.stream = stream; c.dry = dry;
+  c.taps = cfg.debug_taps ? &E->taps : nullptr;
+  c.gn_scratch = E->gn_scratch; c.gn_scratch_floats = E->gn_scratch_floats;
+  c.B = B;
+  Arena& A = E->arena;
+  A.reset();
+  const int scale = 1 << (cfg.n_levels - 1);
+  int H = cfg.latent_h * scale, W = cfg.latent_w * scale;
+  const int cpad = 8;
+  bf16_t* xin = A.get<bf16_t>((size_t)B * H * W * cpad); ALLOC_OR_FAIL(xin);
+  RUN(c, ctta_nchw_f32_to_nhwc_bf16(mel, xin, B, 1, H, W, cpad, 1.0f, stream));
+  int ch = cfg.ch;
+  bf16_t* h = A.get<bf16_t>((size_t)B * H * W * ch); ALLOC_OR_FAIL(h);
+  CTTA_TRY(run_conv2d(c, E->conv_in, xin, B, H, W, false, h, nullptr, 0, nullptr, 0));
+  add_tap(c, "conv_in", h, B, ch, H, W, ch);
+  for (int lvl = 0; lvl < cfg.n_levels; ++lvl) {
+    for (size_t b = 0; b < E->down[lvl].size(); ++b) {
+      CTTA_TRY(run_vae_res(c, E->down[lvl][b], h, H, W, &h));
+      ch = E->down[lvl][b].cout;
+      add_tap(c, "down." + std::to_string(lvl) + ".block." + std::to_string(b), h, B, ch, H, W, ch);
+    }
+    if (lvl != cfg.n_levels - 1) {
+      const int ho = H / 2, wo = W / 2;
+      bf16_t* d_ = A.get<bf16_t>((size_t)B * ho * wo * ch); ALLOC_OR_FAIL(d_);
+      const ConvLayer& L = E->downsample[lvl];
+      ctta_conv_desc d;
+      desc_init(&d);
+      d.x0 = h; d.c0 = L.cin_pad;
+      d.batch = B; d.hi = H; d.wi = W; d.ho = ho; d.wo = wo;
+      d.kh = 3; d.kw = 3; d.stride_h = d.stride_w = 2; d.pad_h = d.pad_w = 0;
+      d.w = L.p.w; d.k_pad = L.p.k_pad; d.n = L.p.n; d.bias = L.p.bias;
+      d.out = d_; d.ldc = L.p.n;
+      RUN(c, ctta_conv_gemm(&d, c.stream));
+      h = d_; H = ho; W = wo;
+      add_tap(c, "down." + std::to_string(lvl) + ".downsample", h, B, ch, H, W, ch);
+    }
+  }
+  CTTA_TRY(run_vae_res(c, E->mid1, h, H, W, &h));
+  CTTA_TRY(run_vae_attn(c, &E->attn, h, H, W, &h));
+  CTTA_TRY(run_vae_res(c, E->mid2, h, H, W, &h));
+  add_tap(c, "mid.block_2", h, B, ch, H, W, ch);
+  bf16_t* a = A.get<bf16_t>((size_t)B * H * W * ch); ALLOC_OR_FAIL(a);
+  CTTA_TRY(vgn(c, E->norm_out, h, a, H * W, true));
+  bf16_t* co = A.get<bf16_t>((size_t)B * H * W * E->zc2); ALLOC_OR_FAIL(co);
+  CTTA_TRY(run_conv2d(c, E->conv_out, a, B, H, W, false, co, nullptr, 0, nullptr, 0));
+  if (!dry) {
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(quant_moments_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, co, E->q_w,
+                       E->q_b, B, E->zc2, 2 * cfg.embed_dim, H * W, moments);
+    CTTA_LAUNCH_CHECK();
+  }
+  if (gn_need) *gn_need = c.gn_need;
+  return CTTA_OK;
+}
+
+static ctta_status vae_encoder_build(ctta_vae_encoder* E) {
+  const ctta_vae_config& cfg = E->cfg;
+  WeightStore& ws = E->store;
+  const int nres = cfg.n_levels;
+  const std::string p = "encoder.";
+  CTTA_TRY(make_conv(ws, p + "conv_in.", cfg.ch, 1, 8, 3, 3, 1, 1, &E->conv_in));
+  int block_in = cfg.ch;
+  E->down.resize(nres);
+  E->downsample.resize(nres);
+  for (int lvl = 0; lvl < nres; ++lvl) {
+    const int block_out = cfg.ch * cfg.ch_mult[lvl];
+    E->down[lvl].resize(cfg.num_res_blocks);
+    for (int b = 0; b < cfg.num_res_blocks; ++b) {
+      CTTA_TRY(make_vae_res(ws, p + "down." + std::to_string(lvl) + ".block." + std::to_string(b) + ".", block_in,
+                            block_out, &E->down[lvl][b]));
+      block_in = block_out;
+    }
+    if (lvl != nres - 1)
+      CTTA_TRY(make_conv(ws, p + "down." + std::to_string(lvl) + ".downsample.conv.", block_in, block_in, block_in, 3, 3,
+                         2, 0, &E->downsample[lvl]));
+  }
+  E->block_in = block_in;
+  CTTA_TRY(make_vae_res(ws, p + "mid.block_1.", block_in, block_in, &E->mid1));
+  CTTA_TRY(make_vae_attn(ws, p + "mid.attn_1.", block_in, &E->attn));
+  CTTA_TRY(make_vae_res(ws, p + "mid.block_2.", block_in, block_in, &E->mid2));
+  CTTA_TRY(make_gn(ws, p + "norm_out.", block_in, &E->norm_out));
+  E->zc2 = 2 * cfg.z_channels;
+  CTTA_TRY(make_conv(ws, p + "conv_out.", E->zc2, block_in, block_in, 3, 3, 1, 1, &E->conv_out));
+  CTTA_TRY(ws.add_vector("quant_conv.weight", 2 * cfg.embed_dim * E->zc2, &E->q_w));
+  CTTA_TRY(ws.add_vector("quant_conv.bias", 2 * cfg.embed_dim, &E->q_b));
+  return CTTA_OK;
+}
+
+extern "C" void ctta_vae_encoder_destroy(ctta_vae_encoder* E) {
+  if (!E) return;
+  E->store.destroy();
+  if (E->arena.base) (void)hipFree(E->arena.base);
+  if (E->gn_scratch) (void)hipFree(E->gn_scratch);
+  delete E;
+}
+
+extern "C" ctta_status ctta_vae_encoder_create(const ctta_vae_config* cfg, const ctta_tensor* weights, int n_weights,
+                                               void* stream, ctta_vae_encoder** out) {
+  CTTA_REQUIRE(cfg && weights && out, "vae_encoder_create: null pointer");
+  CTTA_REQUIRE(cfg->n_levels >= 1 && cfg->n_levels <= CTTA_MAX_LEVELS, "vae_encoder_create: n_levels=%d", cfg->n_levels);
+  CTTA_REQUIRE(cfg->z_channels * 2 <= 32 && cfg->z_channels * 2 % 4 == 0 && cfg->embed_dim * 2 <= 32,
+               "vae_encoder_create: z_channels/embed_dim unsupported");
+  CTTA_REQUIRE(cfg->out_ch == 1, "vae_encoder_create: in_channels=%d (only the 1-channel mel encoder is built)", cfg->out_ch);
+  CTTA_REQUIRE(cfg->ch % 32 == 0, "vae_encoder_create: ch=%d must be a multiple of 32 (GroupNorm(32))", cfg->ch);
+  hipStream_t s = (hipStream_t)stream;
+  ctta_vae_encoder* E = new ctta_vae_encoder();
+  E->cfg = *cfg;
+  ctta_status st = E->store.init(estimate_store_bytes(weights, n_weights));
+  if (st != CTTA_OK) { delete E; return st; }
+  WeightTable wt;
+  wt.build(weights, n_weights);
+  st = vae_encoder_build(E);
+  if (st == CTTA_OK) st = E->store.run_all(wt, s);
+  size_t gn_need = 0;
+  if (st == CTTA_OK) {
+    E->arena.dry = true;
+    E->arena.no_release = cfg->debug_taps != 0;
+    st = vae_encode_impl(E, true, nullptr, cfg->max_batch, nullptr, s, &gn_need);
+  }
+  if (st == CTTA_OK) {
+    const size_t bytes = E->arena.peak + (1 << 20);
+    E->arena.dry = false;
+    E->arena.cap = bytes;
+    if (hipMalloc((void**)&E->arena.base, bytes) != hipSuccess ||
+        hipMalloc((void**)&E->gn_scratch, (gn_need + 64) * sizeof(float)) != hipSuccess) {
+      ctta_set_error("vae_encoder_create: hipMalloc of %zu-byte activation arena failed", bytes);
+      st = CTTA_ERR_NOMEM;
+    } else {
+      E->gn_scratch_floats = gn_need + 64;
+    }
+  }
+  if (st == CTTA_OK && hipStreamSynchronize(s) != hipSuccess) { ctta_set_error("vae_encoder_create: stream sync failed"); st = CTTA_ERR_HIP; }
+  if (st != CTTA_OK) { ctta_vae_encoder_destroy(E); return st; }
+  *out = E;
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_vae_encode(ctta_vae_encoder* E, const float* mel, int batch, float* moments, void* stream) {
+  CTTA_REQUIRE(E && mel && moments, "vae_encode: null pointer");
+  CTTA_REQUIRE(batch >= 1 && batch <= E->cfg.max_batch, "vae_encode: batch %d outside [1,%d]", batch, E->cfg.max_batch);
+  return vae_encode_impl(E, false, mel, batch, moments, (hipStream_t)stream, nullptr);
+}
+extern "C" ctta_status ctta_vae_encoder_load_weights(ctta_vae_encoder* E, const ctta_tensor* weights, int n_weights,
+                                                     void* stream) {
+  CTTA_REQUIRE(E && weights, "vae_encoder_load_weights: null pointer");
+  WeightTable wt;
+  wt.build(weights, n_weights);
+  return E->store.run_all(wt, (hipStream_t)stream);
+}
+extern "C" int ctta_vae_encoder_num_taps(const ctta_vae_encoder* E) { return E ? (int)E->taps.size() : 0; }
+extern "C" ctta_status ctta_vae_encoder_tap_info(const ctta_vae_encoder* E, int i, const char** name, int dims[4]) {
+  CTTA_REQUIRE(E && i >= 0 && i < (int)E->taps.size(), "tap index out of range");
+  const Tap& t = E->taps[i];
+  *name = t.name.c_str();
+  dims[0] = t.b; dims[1] = t.c; dims[2] = t.h; dims[3] = t.w;
+  return CTTA_OK;
+}
+extern "C" ctta_status ctta_vae_encoder_tap_read(ctta_vae_encoder* E, int i, float* dst, void* stream) {
+  CTTA_REQUIRE(E && i >= 0 && i < (int)E->taps.size() && dst, "tap index out of range");
+  const Tap& t = E->taps[i];
   CTTA_REQUIRE(t.ptr, "tap '%s' has not been produced yet", t.name.c_str());
   return ctta_nhwc_bf16_to_nchw_f32(t.ptr, dst, t.b, t.c, t.h, t.w, t.c_stride, stream);
 }

@@ -405,6 +405,35 @@ class UNet2DConditionModel(_UNetBase):
 
 
 # ------------------------------------------------------------------------------------------
+class DiagonalGaussianDistribution(object):
+    """audioldm/variational_autoencoder/distributions.py:24-74 (elementwise torch ops on the moments the HIP
+    encoder produced; sampling draws from the global RNG exactly like the reference)."""
+
+    def __init__(self, parameters, deterministic=False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if self.deterministic:
+            self.var = self.std = torch.zeros_like(self.mean).to(device=self.parameters.device)
+
+    def sample(self):
+        return self.mean + self.std * torch.randn(self.mean.shape).to(device=self.parameters.device)
+
+    def kl(self, other=None):
+        if self.deterministic:
+            return torch.Tensor([0.0])
+        if other is None:
+            return 0.5 * torch.mean(torch.pow(self.mean, 2) + self.var - 1.0 - self.logvar, dim=[1, 2, 3])
+        return 0.5 * torch.mean(torch.pow(self.mean - other.mean, 2) / other.var + self.var / other.var - 1.0
+                                - self.logvar + other.logvar, dim=[1, 2, 3])
+
+    def mode(self):
+        return self.mean
+
+
 class Generator(_ParamTree):
     """HiFi-GAN parameter holder (weight_norm already removed, hifigan/utilities.py:71)."""
 
@@ -415,8 +444,8 @@ class Generator(_ParamTree):
 
 
 class AutoencoderKL(_ParamTree):
-    """decode_first_stage / decode_to_waveform of the AudioLDM VAE (autoencoder.py:91-111).
-    The encoder half (training-side) is not built yet: `encode*` raise."""
+    """AudioLDM VAE (autoencoder.py:10-132): `decode_first_stage` / `decode_to_waveform` (generation) and
+    `encode_first_stage` / `get_first_stage_encoding` (the training-side latent encoder, tools/train_utils.py:155-162)."""
 
     def __init__(self, ddconfig=None, lossconfig=None, image_key="fbank", embed_dim=None, time_shuffle=1,
                  subband=1, ckpt_path=None, reload_from_ckpt=None, ignore_keys=(), colorize_nlabels=None,
@@ -431,8 +460,16 @@ class AutoencoderKL(_ParamTree):
         self.subband = 1
         self.image_key = image_key
         self.scale_factor = scale_factor
-        self._register(spec.vae_decoder_param_spec(self.ddconfig, self.embed_dim))
+        # reference state-dict order: encoder.*, decoder.*, quant_conv.*, post_quant_conv.*, vocoder.*
+        enc = spec.vae_encoder_param_spec(self.ddconfig, self.embed_dim)
+        dec = spec.vae_decoder_param_spec(self.ddconfig, self.embed_dim)
+        table = OrderedDict((k, v) for k, v in enc.items() if k.startswith("encoder."))
+        table.update((k, v) for k, v in dec.items() if k.startswith("decoder."))
+        table.update((k, v) for k, v in enc.items() if k.startswith("quant_conv."))
+        table.update((k, v) for k, v in dec.items() if k.startswith("post_quant_conv."))
+        self._register(table)
         self.vocoder = Generator(hifigan_config)
+        self._h_enc = self._h_enc_key = self._h_enc_ver = None
         self.ema_decoder = None
         self._h_vae = self._h_voc = None
         self._h_vae_key = self._h_voc_key = None
@@ -444,24 +481,106 @@ class AutoencoderKL(_ParamTree):
         return next(self.parameters()).device
 
     def load_state_dict(self, state_dict, strict=True):
-        """Reference checkpoints also carry encoder.* / quant_conv.* (and loss.*) keys; they
-        belong to the training-side encoder and are skipped until that row is built."""
-        own = {k: v for k, v in state_dict.items()
-               if not k.startswith(("encoder.", "quant_conv.", "loss.", "ema_"))}
+        """Reference checkpoints also carry loss.* (discriminator) and ema_* keys, which this path never uses.
+        A decoder-only state dict (generation checkpoints without the encoder) loads too: missing encoder.* /
+        quant_conv.* keys are tolerated and `encode*` then raises until they are provided."""
+        own = {k: v for k, v in state_dict.items() if not k.startswith(("loss.", "ema_"))}
+        has_enc = any(k.startswith("encoder.") for k in own)
+        self._encoder_loaded = has_enc or getattr(self, "_encoder_loaded", False)
+        if not has_enc:
+            mine = self.state_dict()
+            own.update({k: v for k, v in mine.items() if k.startswith(("encoder.", "quant_conv."))})
         return super().load_state_dict(own, strict=strict)
 
+    def init_deterministic(self, seed=0, prefix=""):
+        self._encoder_loaded = True
+        return super().init_deterministic(seed, prefix)
+
+    def init_random_(self, seed=0, prefix=""):
+        self._encoder_loaded = True
+        return super().init_random_(seed, prefix)
+
+    # ---- encoder, autoencoder.py:80-89,123-132
+    def _ensure_enc(self, B, T, F):
+        L_ = N.lib()
+        nres = len(self.ddconfig["ch_mult"])
+        s = 1 << (nres - 1)
+        if T % s or F % s:
+            raise ValueError("mel extent %dx%d must be a multiple of %d" % (T, F, s))
+        key = (T, F, self.debug_taps, self.device)
+        ver = sum(p._version for k, p in self.named_parameters() if k.startswith(("encoder.", "quant_conv.")))
+        if self._h_enc is None or self._h_enc_key[1:] != key or B > self._h_enc_key[0] or ver != self._h_enc_ver:
+            if self._h_enc is not None:
+                L_.ctta_vae_encoder_destroy(self._h_enc)
+                self._h_enc = None
+            dd = self.ddconfig
+            c = N.VAEConfig()
+            c.z_channels, c.embed_dim, c.ch, c.out_ch = dd["z_channels"], self.embed_dim, dd["ch"], dd["in_channels"]
+            c.n_levels, c.num_res_blocks = nres, dd["num_res_blocks"]
+            for i, m in enumerate(dd["ch_mult"]):
+                c.ch_mult[i] = m
+            c.scale_factor = float(self.scale_factor)
+            c.max_batch, c.latent_h, c.latent_w = B, T // s, F // s
+            c.debug_taps = int(self.debug_taps)
+            sd = OrderedDict((k, p.detach()) for k, p in self.named_parameters()
+                             if k.startswith(("encoder.", "quant_conv.")))
+            for k, p in sd.items():
+                if not p.is_cuda:
+                    raise N.CttaError("parameter '%s' is on %s: the HIP engine has no CPU path" % (k, p.device))
+            table, keep = N.tensor_table(sd)
+            h = N.c_void_p()
+            with torch.cuda.device(self.device):
+                N.check(L_.ctta_vae_encoder_create(c, table, len(table), N.stream_ptr(), h))
+            self._h_enc, self._h_enc_key, self._h_enc_ver = h, (B,) + key, ver
+        return self._h_enc
+
+    @torch.no_grad()
     def encode(self, x):
-        raise NotImplementedError("VAE encoder is the next hot-path row (SURVEY.md §8f rank 1)")
+        """mel (B,1,T,F) -> DiagonalGaussianDistribution over the latent (B, embed_dim, T/4, F/4)."""
+        if not getattr(self, "_encoder_loaded", False):
+            raise RuntimeError("this AutoencoderKL was loaded from a decoder-only state dict: no encoder weights")
+        if x.ndim != 4 or x.shape[1] != self.ddconfig["in_channels"]:
+            raise ValueError("mel must be (batch, %d, T, F), got %s" % (self.ddconfig["in_channels"], tuple(x.shape)))
+        if not x.is_cuda:
+            raise N.CttaError("mel is on %s: the HIP engine has no CPU path" % x.device)
+        B, _, T, F = x.shape
+        h = self._ensure_enc(B, T, F)
+        s = 1 << (len(self.ddconfig["ch_mult"]) - 1)
+        mel = x.detach().to(device=self.device, dtype=torch.float32).contiguous()
+        moments = torch.empty((B, 2 * self.embed_dim, T // s, F // s), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ctta_vae_encode(h, N.ptr(mel), B, N.ptr(moments), N.stream_ptr()))
+        return DiagonalGaussianDistribution(moments)
 
     encode_first_stage = encode
 
     def get_first_stage_encoding(self, encoder_posterior):
-        if isinstance(encoder_posterior, torch.Tensor):
-            return self.scale_factor * encoder_posterior
-        raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+        if isinstance(encoder_posterior, DiagonalGaussianDistribution):
+            z = encoder_posterior.sample()
+        elif isinstance(encoder_posterior, torch.Tensor):
+            z = encoder_posterior
+        else:
+            raise NotImplementedError(f"encoder_posterior of type '{type(encoder_posterior)}' not yet implemented")
+        return self.scale_factor * z
+
+    def read_encoder_taps(self):
+        L_ = N.lib()
+        out = OrderedDict()
+        for i in range(L_.ctta_vae_encoder_num_taps(self._h_enc)):
+            name = N.c_char_p()
+            dims = (N.c_int * 4)()
+            N.check(L_.ctta_vae_encoder_tap_info(self._h_enc, i, name, dims))
+            t = torch.empty(tuple(dims), dtype=torch.float32, device=self.device)
+            N.check(L_.ctta_vae_encoder_tap_read(self._h_enc, i, N.ptr(t), N.stream_ptr()))
+            out[name.value.decode()] = t
+        return out
 
     def _release(self):
-        L_ = N.lib() if (getattr(self, "_h_vae", None) or getattr(self, "_h_voc", None)) else None
+        L_ = N.lib() if (getattr(self, "_h_vae", None) or getattr(self, "_h_voc", None)
+                         or getattr(self, "_h_enc", None)) else None
+        if getattr(self, "_h_enc", None):
+            L_.ctta_vae_encoder_destroy(self._h_enc)
+            self._h_enc = None
         if getattr(self, "_h_vae", None):
             L_.ctta_vae_destroy(self._h_vae)
         if getattr(self, "_h_voc", None):
@@ -475,7 +594,7 @@ class AutoencoderKL(_ParamTree):
             pass
 
     def _decoder_version(self):
-        return sum(p._version for k, p in self.named_parameters() if not k.startswith("vocoder."))
+        return sum(p._version for k, p in self.named_parameters() if k.startswith(("decoder.", "post_quant_conv.")))
 
     def _ensure_vae(self, B, T, F):
         L_ = N.lib()
@@ -496,7 +615,8 @@ class AutoencoderKL(_ParamTree):
             c.scale_factor = sf
             c.max_batch, c.latent_h, c.latent_w = B, T, F
             c.debug_taps = int(self.debug_taps)
-            sd = OrderedDict((k, p.detach()) for k, p in self.named_parameters() if not k.startswith("vocoder."))
+            sd = OrderedDict((k, p.detach()) for k, p in self.named_parameters()
+                             if k.startswith(("decoder.", "post_quant_conv.")))
             for k, p in sd.items():
                 if not p.is_cuda:
                     raise N.CttaError("parameter '%s' is on %s: the HIP engine has no CPU path" % (k, p.device))

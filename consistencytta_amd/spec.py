@@ -227,6 +227,42 @@ def vae_decoder_param_spec(dd=VAE_DDCONFIG, embed_dim=8):
     return sd
 
 
+def vae_encoder_param_spec(dd=VAE_DDCONFIG, embed_dim=8):
+    """encoder.* and quant_conv.* keys of AutoencoderKL (modules.py:419-543, autoencoder.py:37), reference order:
+    conv_in, down.{lvl}.block.{b} (+ downsample.conv), mid, norm_out, conv_out; attn_resolutions is empty in the
+    AudioLDM config, so only the mid block carries attention."""
+    ch, mult, nrb = dd["ch"], list(dd["ch_mult"]), dd["num_res_blocks"]
+    nres = len(mult)
+    sd = OrderedDict()
+    sd["encoder.conv_in.weight"] = (ch, dd["in_channels"], 3, 3)
+    sd["encoder.conv_in.bias"] = (ch,)
+    block_in = ch
+    for lvl in range(nres):
+        block_out = ch * mult[lvl]
+        for b in range(nrb):
+            _vae_resblock(sd, "encoder.down.%d.block.%d." % (lvl, b), block_in, block_out)
+            block_in = block_out
+        if lvl != nres - 1:
+            sd["encoder.down.%d.downsample.conv.weight" % lvl] = (block_in, block_in, 3, 3)
+            sd["encoder.down.%d.downsample.conv.bias" % lvl] = (block_in,)
+    _vae_resblock(sd, "encoder.mid.block_1.", block_in, block_in)
+    a = "encoder.mid.attn_1."
+    sd[a + "norm.weight"] = (block_in,)
+    sd[a + "norm.bias"] = (block_in,)
+    for k in ("q", "k", "v", "proj_out"):
+        sd[a + k + ".weight"] = (block_in, block_in, 1, 1)
+        sd[a + k + ".bias"] = (block_in,)
+    _vae_resblock(sd, "encoder.mid.block_2.", block_in, block_in)
+    sd["encoder.norm_out.weight"] = (block_in,)
+    sd["encoder.norm_out.bias"] = (block_in,)
+    zc2 = 2 * dd["z_channels"] if dd.get("double_z", True) else dd["z_channels"]
+    sd["encoder.conv_out.weight"] = (zc2, block_in, 3, 3)
+    sd["encoder.conv_out.bias"] = (zc2,)
+    sd["quant_conv.weight"] = (2 * embed_dim, 2 * dd["z_channels"], 1, 1)
+    sd["quant_conv.bias"] = (2 * embed_dim,)
+    return sd
+
+
 def hifigan_param_spec(h=HIFIGAN_16K_64, prefix="vocoder."):
     """Generator keys after remove_weight_norm (bias registered before weight)."""
     sd = OrderedDict()

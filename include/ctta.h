@@ -133,6 +133,22 @@ ctta_status ctta_vae_tap_info(const ctta_vae* h, int i, const char** name, int d
 ctta_status ctta_vae_tap_read(ctta_vae* h, int i, float* dst_nchw, void* stream);
 
 #define CTTA_MAX_UPS 8
+/* VAE encoder: AutoencoderKL.encode_first_stage (autoencoder.py:80-89 -> Encoder.forward modules.py:519-543 +
+ * quant_conv), the training-side latent encoder of tools/train_utils.py:155-162.  Same ctta_vae_config as the decoder
+ * (out_ch = the mel's channel count 1; latent_h/_w = the LATENT extent, the mel is 2^(n_levels-1) times larger).
+ * mel (B,1,T,F) f32 -> moments (B, 2*embed_dim, T/s, F/s) f32 = [mean | logvar] of the diagonal Gaussian posterior;
+ * sampling (DiagonalGaussianDistribution.sample, distributions.py:37-41) stays with the caller's RNG. */
+typedef struct ctta_vae_encoder ctta_vae_encoder;
+ctta_status ctta_vae_encoder_create(const ctta_vae_config* cfg, const ctta_tensor* weights, int n_weights,
+                                    void* stream, ctta_vae_encoder** out);
+void ctta_vae_encoder_destroy(ctta_vae_encoder* h);
+ctta_status ctta_vae_encoder_load_weights(ctta_vae_encoder* h, const ctta_tensor* weights, int n_weights,
+                                          void* stream);
+ctta_status ctta_vae_encode(ctta_vae_encoder* h, const float* mel, int batch, float* moments, void* stream);
+int ctta_vae_encoder_num_taps(const ctta_vae_encoder* h);
+ctta_status ctta_vae_encoder_tap_info(const ctta_vae_encoder* h, int i, const char** name, int dims[4]);
+ctta_status ctta_vae_encoder_tap_read(ctta_vae_encoder* h, int i, float* dst_nchw, void* stream);
+
 typedef struct {
   int num_mels, upsample_initial_channel, n_ups, n_kernels;
   int upsample_rates[CTTA_MAX_UPS], upsample_kernel_sizes[CTTA_MAX_UPS];

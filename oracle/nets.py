@@ -259,6 +259,45 @@ def vae_decode(dd, sd, z, scale_factor, taps=None, groups=32):
     return h
 
 
+def vae_encode(dd, sd, mel, taps=None, groups=32):
+    """AutoencoderKL.encode (autoencoder.py:80-85) = Encoder.forward (modules.py:519-543) + quant_conv.
+    mel (B,1,T,F) -> moments (B, 2*embed_dim, T/2^(L-1), F/2^(L-1)) = [mean | logvar] of the diagonal posterior.
+    Downsample.forward (modules.py:87-92): zero-pad right/bottom by one, 3x3 conv stride 2, no padding."""
+    def tap(name, t):
+        if taps is not None:
+            taps[name] = t.detach().clone()
+
+    nres = len(dd["ch_mult"])
+    p = "encoder."
+    h = F.conv2d(mel.float(), sd[p + "conv_in.weight"], sd[p + "conv_in.bias"], padding=1)
+    tap("conv_in", h)
+    for lvl in range(nres):
+        for b in range(dd["num_res_blocks"]):
+            h = vae_resblock(sd, p + "down.%d.block.%d." % (lvl, b), h, groups)
+            tap("down.%d.block.%d" % (lvl, b), h)
+        if lvl != nres - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = F.conv2d(h, sd[p + "down.%d.downsample.conv.weight" % lvl], sd[p + "down.%d.downsample.conv.bias" % lvl],
+                         stride=2, padding=0)
+            tap("down.%d.downsample" % lvl, h)
+    h = vae_resblock(sd, p + "mid.block_1.", h, groups)
+    h = vae_attn(sd, p + "mid.attn_1.", h, groups)
+    h = vae_resblock(sd, p + "mid.block_2.", h, groups)
+    tap("mid.block_2", h)
+    h = _vae_norm(sd, p + "norm_out.", h, groups)
+    h = h * torch.sigmoid(h)
+    h = F.conv2d(h, sd[p + "conv_out.weight"], sd[p + "conv_out.bias"], padding=1)
+    return F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+
+
+def posterior_sample(moments, noise, scale_factor):
+    """DiagonalGaussianDistribution (distributions.py:24-41) + get_first_stage_encoding (autoencoder.py:123-132):
+    z = scale_factor * (mean + exp(0.5 * clamp(logvar, -30, 20)) * noise)."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    return scale_factor * (mean + torch.exp(0.5 * logvar) * noise)
+
+
 # ----------------------------------------------------------------------------- HiFi-GAN
 def hifigan_forward(hcfg, sd, mel, prefix="vocoder.", taps=None):
     """Generator.forward, hifigan/models.py:101-117; ResBlock.forward :56-63.

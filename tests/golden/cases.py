@@ -40,6 +40,11 @@ def vae_weights(dd, seed=0):
     return {k: t(v) for k, v in spec.det_state_dict(sp, seed, prefix="vae.").items()}
 
 
+def vae_encoder_weights(dd, seed=0):
+    sp = spec.vae_encoder_param_spec(dd)
+    return {k: t(v) for k, v in spec.det_state_dict(sp, seed, prefix="vae.").items()}
+
+
 def hifigan_weights(h, seed=0):
     sp = spec.hifigan_param_spec(h)
     return {k: t(v) for k, v in spec.det_state_dict(sp, seed, prefix="vae.").items()}

@@ -86,9 +86,14 @@ def ref_vae(ns, dd, hcfg, seed=0):
     assert dec_keys == list(spec.vae_decoder_param_spec(dd).keys())
     voc_keys = [k for k in ref_sd if k.startswith("vocoder.")]
     assert voc_keys == list(spec.hifigan_param_spec(hcfg).keys())
+    esd = cases.vae_encoder_weights(dd, seed)
+    enc_keys = [k for k in ref_sd if k.startswith(("encoder.", "quant_conv."))]
+    assert enc_keys == list(spec.vae_encoder_param_spec(dd).keys()), "encoder key order"
+    for k, v in esd.items():
+        assert tuple(ref_sd[k].shape) == tuple(v.shape), k
+    sd.update(esd)
     missing, unexpected = vae.load_state_dict(sd, strict=False)
-    assert not unexpected
-    assert all(k.startswith(("encoder.", "quant_conv.")) for k in missing), missing
+    assert not unexpected and not missing, (missing, unexpected)
     return vae.eval().requires_grad_(False), vc["scale_factor"]
 
 
@@ -108,6 +113,26 @@ def golden_vae(ns):
         mel_in = cases.mel_inputs(1, 64, 64, "hifigan_full")
         wav = vae.vocoder(mel_in.squeeze(1).permute(0, 2, 1)).squeeze(1).float()
         save("vae_full", mel=mel.numpy(), wav=wav.numpy(), scale_factor=sf)
+
+
+def golden_vae_encoder(ns):
+    """AutoencoderKL.encode_first_stage / get_first_stage_encoding of the reference (the training-side latent
+    encoder, tools/train_utils.py:155-162): posterior moments for a tiny and the full-width encoder, and one sampled
+    latent with the reference's noise draw recorded."""
+    with torch.no_grad():
+        vae, sf = ref_vae(ns, cases.TINY_VAE_DD, cases.TINY_HIFIGAN)
+        mel = cases.mel_inputs(2, 64, 16, "vaeenc_tiny") * 2.0 - 4.0
+        post = vae.encode_first_stage(mel)
+        torch.manual_seed(11)
+        noise = torch.randn(post.mean.shape)
+        torch.manual_seed(11)
+        z = vae.get_first_stage_encoding(post)
+        save("vae_encoder_tiny", moments=post.parameters.numpy(), noise=noise.numpy(), z=z.numpy(), scale_factor=sf)
+
+        vae, sf = ref_vae(ns, spec.VAE_DDCONFIG, spec.HIFIGAN_16K_64)
+        mel = cases.mel_inputs(1, 128, 64, "vaeenc_full") * 2.0 - 4.0   # full widths, 1/8 of the 1024 frames
+        post = vae.encode_first_stage(mel)
+        save("vae_encoder_full", moments=post.parameters.numpy(), scale_factor=sf)
 
 
 def golden_heun(ns):
@@ -173,5 +198,7 @@ if __name__ == "__main__":
         golden_unet(ns)
     if "vae" in which:
         golden_vae(ns)
+    if "vae_encoder" in which:
+        golden_vae_encoder(ns)
     if "pipeline" in which:
         golden_pipeline(ns)

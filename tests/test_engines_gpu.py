@@ -204,3 +204,57 @@ def test_pipeline_config1_end_to_end(golden):
     ref_head = torch.from_numpy(g["wav_head"])
     _report("pipeline waveform head", wav[:, :ref_head.shape[1]], ref_head)
     assert bool(torch.isfinite(wav).all()) and float(wav.abs().max()) <= 1.0
+
+
+def test_vae_encoder_against_reference_golden_and_oracle_taps(golden):
+    """AutoencoderKL.encode_first_stage / get_first_stage_encoding on the HIP encoder: posterior
+    moments vs the reference's own fixture, layer by layer vs the oracle, and the sampled, scaled latent."""
+    g = golden("vae_encoder_tiny")
+    dd = cases.TINY_VAE_DD
+    sd = dict(cases.vae_weights(dd))
+    sd.update(cases.vae_encoder_weights(dd))
+    sd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
+    v = modules.AutoencoderKL(ddconfig=dd, embed_dim=8, scale_factor=float(g["scale_factor"]),
+                              hifigan_config=cases.TINY_HIFIGAN)
+    v.debug_taps = True
+    _load(v, sd)
+    mel = cases.mel_inputs(2, 64, 16, "vaeenc_tiny") * 2.0 - 4.0
+    post = v.encode_first_stage(mel.to(DEV))
+    taps = {}
+    with torch.no_grad():
+        ref = onets.vae_encode(dd, sd, mel, taps=taps)
+    worst = 0.0
+    for name, t in v.read_encoder_taps().items():
+        l2, _ = _report("enc tap " + name, t, taps[name])
+        worst = max(worst, l2)
+    assert worst <= REL_L2
+    _check("vae encoder moments vs oracle", post.parameters, ref)
+    _check("vae encoder moments vs reference golden", post.parameters, torch.from_numpy(g["moments"]))
+    # sampling: the reference draws torch.randn(mean.shape) on the CPU and moves it; replay the recorded draw
+    noise = torch.from_numpy(g["noise"])
+    orig = torch.randn
+    torch.randn = lambda *a, **k: noise.clone()
+    try:
+        z = v.get_first_stage_encoding(post)
+    finally:
+        torch.randn = orig
+    _check("scaled posterior sample vs reference golden", z, torch.from_numpy(g["z"]))
+    assert tuple(z.shape) == (2, 8, 16, 4)
+    # round trip through the decoder stays finite and has the mel's shape
+    rec = v.decode_first_stage(z)
+    assert tuple(rec.shape) == tuple(mel.shape) and bool(torch.isfinite(rec).all())
+
+
+def test_vae_encoder_full_width_against_reference_golden(golden):
+    g = golden("vae_encoder_full")
+    dd = spec.VAE_DDCONFIG
+    v = modules.AutoencoderKL(ddconfig=dd, embed_dim=8, scale_factor=float(g["scale_factor"]))
+    sd = dict(cases.vae_weights(dd))
+    sd.update(cases.vae_encoder_weights(dd))
+    sd.update(cases.hifigan_weights(spec.HIFIGAN_16K_64))
+    _load(v, sd)
+    mel = cases.mel_inputs(1, 128, 64, "vaeenc_full") * 2.0 - 4.0
+    post = v.encode_first_stage(mel.to(DEV))
+    _check("full-width vae encoder moments vs reference golden", post.parameters, torch.from_numpy(g["moments"]))
+    with pytest.raises(ValueError):
+        v.encode_first_stage(torch.zeros(1, 1, 30, 64, device=DEV))     # extent not a multiple of 4

@@ -150,3 +150,26 @@ def test_inference_student_and_teacher_loops(golden):
         close(distill.inference_student(n, n.target, P, noise, 3.0, 2.0, 2, torch.from_numpy(g["inf_renoise"])),
               g["inf_student_2step_cfg"])
         close(distill.inference_teacher(n, P, noise, 4.0, 3), g["inf_teacher_3steps"], 5e-4, 5e-5)
+
+
+def test_vae_encoder_tiny(golden):
+    """oracle.nets.vae_encode / posterior_sample vs the reference's AutoencoderKL.encode_first_stage and
+    get_first_stage_encoding (recorded noise draw)."""
+    g = golden("vae_encoder_tiny")
+    with torch.no_grad():
+        sd = cases.vae_encoder_weights(cases.TINY_VAE_DD)
+        assert list(sd.keys()) == list(spec.vae_encoder_param_spec(cases.TINY_VAE_DD).keys())
+        mel = cases.mel_inputs(2, 64, 16, "vaeenc_tiny") * 2.0 - 4.0
+        mom = nets.vae_encode(cases.TINY_VAE_DD, sd, mel)
+        close(mom, g["moments"])
+        z = nets.posterior_sample(mom, torch.from_numpy(g["noise"]), float(g["scale_factor"]))
+        close(z, g["z"])
+
+
+@pytest.mark.slow
+def test_vae_encoder_full_width(golden):
+    g = golden("vae_encoder_full")
+    with torch.no_grad():
+        sd = cases.vae_encoder_weights(spec.VAE_DDCONFIG)
+        mel = cases.mel_inputs(1, 128, 64, "vaeenc_full") * 2.0 - 4.0
+        close(nets.vae_encode(spec.VAE_DDCONFIG, sd, mel), g["moments"])
