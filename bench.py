@@ -364,6 +364,26 @@ def distill_leg(args, dev, world, rank):
             "executed_tflops_incl_padding": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
             "share_of_step_time": round(ms.value / ev[0].elapsed_time(ev[1]), 3),
         }
+    if rank == 0:   # the adjacent front half of the real training step (train_utils.py:155-162): wav -> log-mel -> latent
+        from consistencytta_amd import audio, modules
+        stft = audio.TacotronSTFT(1024, 160, 1024, 64, 16000, 0, 8000).to(dev)
+        vae = modules.AutoencoderKL(ddconfig=spec.VAE_DDCONFIG, embed_dim=8, scale_factor=0.9227914214134216)
+        vae.to(dev)
+        vae.init_random_(seed=12)
+        vae.eval().requires_grad_(False)
+        wav = (torch.rand(B, 163840, generator=torch.Generator().manual_seed(9)) * 2 - 1).to(dev) * 0.5
+        for _ in range(2):
+            mel, _ = audio.wav_to_fbank(wav, 1024, stft)
+            z = vae.get_first_stage_encoding(vae.encode_first_stage(mel.unsqueeze(1)))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            mel, _ = audio.wav_to_fbank(wav, 1024, stft)
+            z = vae.get_first_stage_encoding(vae.encode_first_stage(mel.unsqueeze(1)))
+        torch.cuda.synchronize()
+        assert bool(torch.isfinite(z).all()) and tuple(z.shape) == (B, 8, 256, 16)
+        out["wav_to_latent_ms"] = round((time.perf_counter() - t0) / 3 * 1e3, 3)
+        del vae, stft
     del m, opt
     return out
 

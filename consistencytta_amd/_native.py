@@ -98,6 +98,9 @@ SIGNATURES = {
     "ctta_vae_encoder_num_taps": (c_int, [c_void_p]),
     "ctta_vae_encoder_tap_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
     "ctta_vae_encoder_tap_read": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "ctta_mel_frontend_create": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, POINTER(c_void_p)]),
+    "ctta_mel_frontend_destroy": (None, [c_void_p]),
+    "ctta_wav_to_fbank": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ctta_pack_weight_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ctta_copy_segments_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "ctta_unet_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

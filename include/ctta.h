@@ -149,6 +149,20 @@ int ctta_vae_encoder_num_taps(const ctta_vae_encoder* h);
 ctta_status ctta_vae_encoder_tap_info(const ctta_vae_encoder* h, int i, const char** name, int dims[4]);
 ctta_status ctta_vae_encoder_tap_read(ctta_vae_encoder* h, int i, float* dst_nchw, void* stream);
 
+/* Waveform -> log-mel front-end of the training step: tools/torch_tools.py:126-135 (wav_to_fbank) with
+ * audioldm/audio/stft.py:132-186 (TacotronSTFT: reflect pad, conv1d STFT at hop `hop_length`, magnitude, mel
+ * filterbank (librosa.filters.mel, Slaney scale / area norm), log(clamp(x, 1e-5))) and torch_tools.py:38-51 (_pad_spec).
+ * wav (B, n_samples) f32 (clipped to [-1, 1], NaN -> 0 like get_mel_from_wav) -> fbank (B, target_length, n_mels) f32
+ * and, when logmag != NULL, the log-magnitude spectrogram (B, target_length, filter_length/2) f32.  Frames past
+ * n_samples/hop + 1 are zero (not log(1e-5)), exactly as the reference pads. */
+typedef struct ctta_mel_frontend ctta_mel_frontend;
+ctta_status ctta_mel_frontend_create(int filter_length, int hop_length, int win_length, int n_mels,
+                                     int sampling_rate, float mel_fmin, float mel_fmax, int max_batch,
+                                     int max_samples, ctta_mel_frontend** out);
+void ctta_mel_frontend_destroy(ctta_mel_frontend* h);
+ctta_status ctta_wav_to_fbank(ctta_mel_frontend* h, const float* wav, int batch, int n_samples,
+                              int target_length, float* fbank, float* logmag, void* stream);
+
 typedef struct {
   int num_mels, upsample_initial_channel, n_ups, n_kernels;
   int upsample_rates[CTTA_MAX_UPS], upsample_kernel_sizes[CTTA_MAX_UPS];

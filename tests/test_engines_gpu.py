@@ -17,7 +17,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 import cases  # noqa: E402
-from consistencytta_amd import modules, scheduler, spec  # noqa: E402
+from consistencytta_amd import _native as N, modules, scheduler, spec  # noqa: E402
 from gpu_util import DEV, rel_err, rel_l2  # noqa: E402
 from oracle import nets as onets  # noqa: E402
 
@@ -258,3 +258,28 @@ def test_vae_encoder_full_width_against_reference_golden(golden):
     _check("full-width vae encoder moments vs reference golden", post.parameters, torch.from_numpy(g["moments"]))
     with pytest.raises(ValueError):
         v.encode_first_stage(torch.zeros(1, 1, 30, 64, device=DEV))     # extent not a multiple of 4
+
+
+def test_mel_frontend_against_reference_golden(golden):
+    """wav_to_fbank on the HIP front-end vs the reference's TacotronSTFT + tools.torch_tools.wav_to_fbank fixture.
+    Tolerance: the log-mel is compared in ABSOLUTE terms (it is a logarithm; 0.005 = 0.5 % in linear mel energy); the
+    three-way split-bf16 STFT (fp32-grade products) keeps even near-silent bins within it."""
+    import make_golden_mel as mg
+    from consistencytta_amd import audio
+    g = golden("mel_frontend")
+    stft = audio.TacotronSTFT(1024, 160, 1024, 64, 16000, 0, 8000).to(DEV)
+    fb, lm = audio.wav_to_fbank(mg.test_wave(2, 40000, "mel").to(DEV), 256, stft)
+    ref = torch.from_numpy(g["fbank"])
+    err = float((fb.cpu() - ref).abs().max())
+    print("log-mel max abs error %.3e (range %.1f .. %.1f)" % (err, float(ref.min()), float(ref.max())))
+    assert tuple(fb.shape) == (2, 256, 64) and err < 5e-3
+    assert float(fb[:, 251:].abs().max()) == 0.0                       # zero padding past the last frame
+    assert float((lm.cpu()[:, ::8, ::8] - torch.from_numpy(g["logmag_sub"])).abs().max()) < 5e-2
+    fb2, _ = audio.wav_to_fbank(mg.test_wave(1, 163840, "mel_full"), 1024, stft)     # CPU waveform (dataloader) is moved
+    err2 = float((fb2.cpu() - torch.from_numpy(g["fbank_full"])).abs().max())
+    print("10.24 s clip: log-mel max abs error %.3e" % err2)
+    assert tuple(fb2.shape) == (1, 1024, 64) and err2 < 5e-3
+    mel, logm, _ = stft.mel_spectrogram(mg.test_wave(1, 16000, "mel_s").nan_to_num().clip(-1, 1).to(DEV))
+    assert tuple(mel.shape) == (1, 64, 101) and tuple(logm.shape) == (1, 512, 101)
+    with pytest.raises(N.CttaError):
+        audio.TacotronSTFT().fbank(torch.zeros(1, 16000))            # module on the CPU: no fallback

@@ -173,3 +173,40 @@ def test_vae_encoder_full_width(golden):
         sd = cases.vae_encoder_weights(spec.VAE_DDCONFIG)
         mel = cases.mel_inputs(1, 128, 64, "vaeenc_full") * 2.0 - 4.0
         close(nets.vae_encode(spec.VAE_DDCONFIG, sd, mel), g["moments"])
+
+
+def test_mel_filterbank_known_answers():
+    """librosa.filters.mel (absent here) restated in oracle/mel.py: published constants of the Slaney mel scale and the
+    structural properties of the area-normalised triangular filterbank."""
+    from oracle import mel as omel
+    assert abs(float(omel.hz_to_mel(1000.0)) - 15.0) < 1e-12 and abs(float(omel.mel_to_hz(15.0)) - 1000.0) < 1e-9
+    assert abs(float(omel.hz_to_mel(8000.0)) - (15.0 + 27.0 * np.log(8.0) / np.log(6.4))) < 1e-9
+    assert abs(float(omel.hz_to_mel(500.0)) - 7.5) < 1e-12                    # linear region: 200/3 Hz per mel
+    w = omel.mel_filterbank(16000, 1024, 64, 0.0, 8000.0)
+    assert w.shape == (64, 513) and w.dtype == np.float32 and float(w.min()) >= 0.0
+    # slaney normalisation: every triangle has unit area in Hz (bin width 15.625 Hz), up to bin sampling
+    area = w.sum(1) * (16000.0 / 1024)
+    assert np.all(np.abs(area[8:] - 1.0) < 0.05), area
+    # filters are ordered, overlap only with neighbours, and tile the band edge to edge
+    peaks = w.argmax(1)
+    assert np.all(np.diff(peaks) > 0) and peaks[0] >= 1 and peaks[-1] <= 512
+    assert float((w[:-2] * w[2:]).sum()) == 0.0
+    assert float(w[:, 0].sum()) == 0.0 and float(w[:, 512].sum()) == 0.0
+
+
+def test_mel_frontend(golden):
+    """oracle.mel.wav_to_fbank vs the reference's TacotronSTFT + tools.torch_tools.wav_to_fbank."""
+    import make_golden_mel as mg
+    from oracle import mel as omel
+    g = golden("mel_frontend")
+    basis = omel.stft_basis(1024)
+    close(basis[[0, 1, 7, 512, 513, 520, 1025]], g["basis_rows"], 1e-6, 1e-7)
+    close(omel.mel_filterbank().sum(1), g["mel_basis_sum"], 1e-6, 1e-8)
+    with torch.no_grad():
+        fb, lm = omel.wav_to_fbank(mg.test_wave(2, 40000, "mel"), 256)
+        assert tuple(fb.shape) == (2, 256, 64) and tuple(lm.shape) == (2, 256, 512)
+        close(fb, g["fbank"], 1e-5, 2e-4)          # log domain: absolute tolerance
+        close(lm[:, ::8, ::8], g["logmag_sub"], 1e-5, 2e-4)
+        assert float(fb[:, 251:].abs().max()) == 0.0                 # _pad_spec pads with zeros, not log(1e-5)
+        fb2, _ = omel.wav_to_fbank(mg.test_wave(1, 163840, "mel_full"), 1024)
+        close(fb2, g["fbank_full"], 1e-5, 2e-4)

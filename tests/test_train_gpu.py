@@ -298,3 +298,30 @@ def test_gradient_accumulation_matches_one_big_step(golden):
     rel = float((d1 - d2).norm() / d1.norm())
     print("accumulated (2 x 1/2) vs single step: relative difference of the parameter update %.3e" % rel)
     assert rel < 5e-2        # AdamW's first step is lr*sign-like: tiny gradient differences flip a few near-zero elements
+
+
+def test_real_training_step_from_waveforms(golden):
+    """The reference's inner loop end to end (tools/train_utils.py:150-183): waveforms -> wav_to_fbank -> VAE
+    encode_first_stage -> get_first_stage_encoding -> distillation step, all on the HIP path."""
+    import make_golden_mel as mg
+    from consistencytta_amd import audio
+    m, P, _ = _lcm()
+    dd = cases.TINY_VAE_DD
+    vae = modules.AutoencoderKL(ddconfig=dd, embed_dim=8, scale_factor=0.9227914214134216,
+                                hifigan_config=cases.TINY_HIFIGAN)
+    sd = dict(cases.vae_weights(dd))
+    sd.update(cases.vae_encoder_weights(dd))
+    sd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
+    vae.load_state_dict(sd)
+    vae.to(DEV).eval().requires_grad_(False)
+    stft = audio.TacotronSTFT(1024, 160, 1024, 32, 16000, 0, 8000).to(DEV)     # 32 mel bins -> latent (B, 8, 32, 8)
+    wav = mg.test_wave(3, 20320, "train_wav").nan_to_num().clip(-1, 1)
+    with torch.no_grad():
+        mel, _ = audio.wav_to_fbank(wav, 128, stft)
+        z0 = vae.get_first_stage_encoding(vae.encode_first_stage(mel.unsqueeze(1)))
+    assert tuple(z0.shape) == (3, 8, 32, 8) and bool(torch.isfinite(z0).all())
+    m.train()
+    opt = m.prepare_training(lr=1e-5, weight_decay=1e-4, broadcast=False)
+    before = opt.flat.detach().clone()
+    loss = m.train_step(z0, P, opt, None)
+    assert loss == loss and loss > 0 and not torch.equal(opt.flat, before)
