@@ -127,7 +127,8 @@ def golden_vae_encoder(ns):
         noise = torch.randn(post.mean.shape)
         torch.manual_seed(11)
         z = vae.get_first_stage_encoding(post)
-        save("vae_encoder_tiny", moments=post.parameters.numpy(), noise=noise.numpy(), z=z.numpy(), scale_factor=sf)
+        save("vae_encoder_tiny", moments=post.parameters.numpy(), noise=noise.numpy(), z=z.numpy(), scale_factor=sf,
+             keys=np.array(list(vae.state_dict().keys())))
 
         vae, sf = ref_vae(ns, spec.VAE_DDCONFIG, spec.HIFIGAN_16K_64)
         mel = cases.mel_inputs(1, 128, 64, "vaeenc_full") * 2.0 - 4.0   # full widths, 1/8 of the 1024 frames

@@ -64,13 +64,17 @@ def test_mirror_state_dict_keys_are_the_references(golden):
     assert all(not k.startswith("guidance") for k in t.state_dict())
     v = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, hifigan_config=cases.TINY_HIFIGAN)
     keys = list(v.state_dict().keys())
-    assert keys[:2] == ["decoder.conv_in.weight", "decoder.conv_in.bias"]
+    # the reference AutoencoderKL's own key list and order (encoder, decoder, quant convs, vocoder)
+    assert keys == [str(k) for k in golden("vae_encoder_tiny")["keys"]]
+    assert keys[:2] == ["encoder.conv_in.weight", "encoder.conv_in.bias"]
     assert "vocoder.resblocks.14.convs2.2.weight" in keys and "post_quant_conv.bias" in keys
-    # checkpoints with encoder keys load (encoder is a later row), unknown keys still raise
+    # decoder-only checkpoints (generation) load; the encoder then refuses to run; unknown keys still raise
     sd = dict(cases.vae_weights(cases.TINY_VAE_DD))
     sd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
-    sd["encoder.conv_in.weight"] = torch.zeros(1)
     v.load_state_dict(sd)
+    with pytest.raises(RuntimeError, match="decoder-only"):
+        v.encode_first_stage(torch.zeros(1, 1, 8, 8))
+    v.load_state_dict(dict(sd, **cases.vae_encoder_weights(cases.TINY_VAE_DD)))
     with pytest.raises(RuntimeError):
         v.load_state_dict(dict(sd, bogus=torch.zeros(1)))
     import copy
