@@ -57,7 +57,7 @@ struct ConvParams {
 // in flight across the barrier (a __syncthreads() would drain them: its release carries vmcnt(0)).
 // One accumulator fragment (4 consecutive output channels of one pixel) through the fused epilogue.
 __device__ __forceinline__ void epilogue_store(const ConvParams& p, const f32x4_t a, int m, int n, int b,
-                                               long long mrem, int g) {
+                                               long long mrem, int g, const uint2* res_pre = nullptr) {
   const long long inb = mrem * p.ldc + n + p.out_offset;
   if (p.out_limit > 0 && (inb < 0 || inb >= p.out_limit)) return;
   const size_t oidx = (size_t)((long long)g * p.ogs + (long long)b * p.obs + inb);
@@ -79,8 +79,8 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, const f32x4_
     const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_ld + n);
     v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
   }
-  if (p.res) {
-    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
+  if (p.res) {   // res_pre: the caller already fetched the residual (rolled epilogues prefetch a whole chunk)
+    const uint2 rr = res_pre ? *res_pre : *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
     v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
     v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
   }
@@ -529,27 +529,40 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     // Large wave tiles: unrolling the generic epilogue once per fragment would blow the code size (and
     // a rolled loop cannot index registers), so fragments bounce through thread-private LDS slots in
     // chunks of 8 and a ROLLED loop runs the epilogue on them.  The ring is dead by now.
-    constexpr int CH = 8;
-    static_assert((FM * FN) % CH == 0 && (size_t)CH * NT * 16 <= (size_t)STAGES * (BM + BN) * BK * 2, "stage size");
+    constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
+    constexpr int CH = (size_t)8 * NT * 24 <= RING ? 8 : 4;
+    static_assert((FM * FN) % CH == 0 && (size_t)CH * NT * 24 <= RING, "stage size");
     __syncthreads();
     float4* stage = reinterpret_cast<float4*>(smem_raw);
+    uint2* rstage = reinterpret_cast<uint2*>(stage + CH * NT);
 #pragma unroll
     for (int c0_ = 0; c0_ < FM * FN; c0_ += CH) {
+      // unrolled: park the fragments AND issue all residual loads of the chunk back to back -- inside the rolled
+      // loop below each load would expose its full latency (measured: -40 % on the 256-wide tiles with a residual)
 #pragma unroll
       for (int f = 0; f < CH; ++f) {
-        const f32x4_t a = acc[(c0_ + f) / FM][(c0_ + f) % FM];
+        const int idx = c0_ + f;
+        const f32x4_t a = acc[idx / FM][idx % FM];
         stage[f * NT + tid] = make_float4(a[0], a[1], a[2], a[3]);
+        if (p.res) {
+          const int m = m0 + wm * TM + (idx % FM) * 16 + frow;
+          const int n = n0 + wn * TN + (idx / FM) * 16 + nsub;
+          uint2 rr = make_uint2(0, 0);
+          if (m < p.M && n < p.n) rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
+          rstage[f * NT + tid] = rr;
+        }
       }
 #pragma unroll 1
       for (int f = 0; f < CH; ++f) {
         const int idx = c0_ + f;
         const int i = idx / FM, j = idx % FM;
         const float4 q = stage[f * NT + tid];
+        const uint2 rr = p.res ? rstage[f * NT + tid] : make_uint2(0, 0);
         const int m = m0 + wm * TM + j * 16 + frow;
         const int n = n0 + wn * TN + i * 16 + nsub;
         if (m < p.M && n < p.n) {
           const int b = m / p.howo;
-          epilogue_store(p, (f32x4_t){q.x, q.y, q.z, q.w}, m, n, b, m - (long long)b * p.howo, zs);
+          epilogue_store(p, (f32x4_t){q.x, q.y, q.z, q.w}, m, n, b, m - (long long)b * p.howo, zs, &rr);
         }
       }
     }
@@ -889,6 +902,10 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   if (vid <= 0 || vid > kNumVariants) {
     if (!d->in_act && !geglu && glds_default() && want_big_tile(M, d->n, K, groups) && fast_ok(kVariants[kBigTile - 1].bk)) {
       vid = kBigTile;
+      // short K with a heavy epilogue (residual read / second output / accumulate): the 256x256 tile holds one
+      // workgroup per CU (128 KB ring), so its epilogue cannot hide behind another workgroup's main loop; the
+      // 256x128x32 tile (48 KB, 3 workgroups per CU) wins there (sweep with SWEEP_EPI=1: 363 vs 284 TFLOP/s at K=768)
+      if (K < 2048 && (d->res || d->out2 || d->accumulate)) vid = 28;
     } else {
       vid = pick_variant(M, d->n, K, groups);
       if (geglu) vid = 6;   // 64x128x64: the measured choice for the short-K feed-forward projections

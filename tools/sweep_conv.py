@@ -53,12 +53,19 @@ SHAPES = [
 
 
 def main():
+    # SWEEP_FILTER=substring restricts the shapes; SWEEP_VARIANTS=17,18,... the variants; SWEEP_EPI=1 adds the
+    # HiFi-GAN ResBlock epilogue (residual read + second, LeakyReLU'd output) to every launch
     L = N.lib()
     nvar = L.ctta_conv_gemm_num_variants()
     names = [L.ctta_conv_gemm_variant_name(i + 1).decode() for i in range(nvar)]
-    print("variants:", names)
+    flt = os.environ.get("SWEEP_FILTER", "")
+    only = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "").split(",") if v]
+    epi = os.environ.get("SWEEP_EPI", "0") == "1"
+    print("variants:", names if not only else [names[v - 1] for v in only])
     results = []
     for (tag, B, H, W, Cin, Cout, kh, kw, dil) in SHAPES:
+        if flt and flt not in tag:
+            continue
         x = (torch.randn(B, H, W, Cin, device=DEV) * 0.5).to(torch.bfloat16)
         K = kh * kw * Cin
         k_pad = (K + 63) // 64 * 64
@@ -68,7 +75,9 @@ def main():
         M = B * H * W
         flops = 2.0 * M * Cout * K
         row = {"tag": tag, "M": M, "N": Cout, "K": K, "tflops": {}}
-        for v in range(1, nvar + 1):
+        res = torch.randn(B, H, W, Cout, device=DEV).to(torch.bfloat16) if epi else None
+        out2 = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV) if epi else None
+        for v in ([0] + only if only else range(1, nvar + 1)):
             d = N.ConvDesc()
             d.x0, d.c0 = x.data_ptr(), Cin
             d.batch, d.hi, d.wi, d.ho, d.wo = B, H, W, H, W
@@ -78,10 +87,13 @@ def main():
             d.w, d.k_pad, d.n = w.data_ptr(), k_pad, Cout
             d.bias = bias.data_ptr()
             d.alpha, d.groups = 1.0, 1
+            if epi:
+                d.res, d.res_ld, d.out2, d.out2_slope = res.data_ptr(), Cout, out2.data_ptr(), 0.1
             d.out, d.ldc, d.tile = out.data_ptr(), Cout, v
             st = N.stream_ptr()
+            vname = names[v - 1] if v > 0 else "auto"
             if L.ctta_conv_gemm(ctypes.byref(d), st) != 0:   # variant not eligible for this shape
-                row["tflops"][names[v - 1]] = 0.0
+                row["tflops"][vname] = 0.0
                 continue
             N.check(L.ctta_conv_gemm(ctypes.byref(d), st))
             torch.cuda.synchronize()
@@ -93,12 +105,12 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
-            row["tflops"][names[v - 1]] = round(flops / (ms * 1e-3) / 1e12, 1)
+            row["tflops"][vname] = round(flops / (ms * 1e-3) / 1e12, 1)
         best = max(row["tflops"], key=row["tflops"].get)
         row["best"] = best
         results.append(row)
         print("%-24s M=%8d N=%5d K=%6d  best %-22s %s" % (tag, M, Cout, K, best,
-              " ".join("%6.0f" % row["tflops"][n] for n in names)), flush=True)
+              " ".join("%6.0f" % t for t in row["tflops"].values())), flush=True)
         del x, w, out
     if len(sys.argv) > 1:
         json.dump({"variants": names, "shapes": results}, open(sys.argv[1], "w"), indent=1)
