@@ -283,3 +283,40 @@ def test_mel_frontend_against_reference_golden(golden):
     assert tuple(mel.shape) == (1, 64, 101) and tuple(logm.shape) == (1, 512, 101)
     with pytest.raises(N.CttaError):
         audio.TacotronSTFT().fbank(torch.zeros(1, 16000))            # module on the CPU: no fallback
+
+
+@pytest.mark.parametrize("B,H,W,L,mask_mode", [(1, 8, 8, 1, "none"), (2, 16, 8, 3, "row_all_masked"), (3, 8, 16, 9, "ragged"),
+                                               (1, 40, 8, 33, "ragged")])
+def test_unet_edge_cases_against_oracle(B, H, W, L, mask_mode):
+    """Smallest extent the 4-level U-Net accepts, a single text token, a row whose mask keeps nothing (the reference adds
+    -10000 to every key of that row: a uniform softmax), ragged masks, odd text lengths beyond the 32-token arena
+    default, batch 1 -- all vs the CPU oracle."""
+    cfg = cases.TINY_UNET
+    sd = cases.unet_weights(cfg, True)
+    m = _load(modules.UNet2DConditionGuidedModel.from_config(cfg), sd)
+    x, ts, gs, enc, mask = cases.unet_inputs(cfg, B, H, W, L, "edge_%s_%d" % (mask_mode, L))
+    if mask_mode == "none":
+        mask = None
+    elif mask_mode == "row_all_masked":
+        mask = mask.clone()
+        mask[-1] = False
+    out = m(x.to(DEV), ts.to(DEV), guidance=gs.to(DEV), encoder_hidden_states=enc.to(DEV),
+            encoder_attention_mask=None if mask is None else mask.to(DEV)).sample
+    with torch.no_grad():
+        ref = onets.unet_forward(cfg, sd, x, ts, gs, enc, mask)
+    _check("unet edge %s B=%d %dx%d L=%d" % (mask_mode, B, H, W, L), out, ref)
+
+
+def test_unet_rejects_bad_extents_and_shapes():
+    cfg = cases.TINY_UNET
+    m = _load(modules.UNet2DConditionGuidedModel.from_config(cfg), cases.unet_weights(cfg, True))
+    x, ts, gs, enc, mask = cases.unet_inputs(cfg, 1, 12, 8, 4, "edge_bad")          # 12 is not a multiple of 8
+    with pytest.raises(N.CttaError, match="multiple of 8"):
+        m(x.to(DEV), ts.to(DEV), guidance=gs.to(DEV), encoder_hidden_states=enc.to(DEV))
+    x, ts, gs, enc, mask = cases.unet_inputs(cfg, 1, 16, 8, 4, "edge_bad2")
+    with pytest.raises(ValueError):
+        m(x.to(DEV), ts.to(DEV), guidance=gs.to(DEV), encoder_hidden_states=enc[:, :, :-1].to(DEV))   # wrong feature dim
+    with pytest.raises(ValueError):
+        m(x[:, :4].to(DEV), ts.to(DEV), guidance=gs.to(DEV), encoder_hidden_states=enc.to(DEV))        # wrong channels
+    with pytest.raises(N.CttaError, match="no CPU path"):
+        m(x, ts, guidance=gs, encoder_hidden_states=enc)                                                # CPU tensors
