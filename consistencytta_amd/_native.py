@@ -101,6 +101,9 @@ SIGNATURES = {
     "ctta_mel_frontend_create": (c_int, [c_int, c_int, c_int, c_int, c_int, c_float, c_float, c_int, c_int, POINTER(c_void_p)]),
     "ctta_mel_frontend_destroy": (None, [c_void_p]),
     "ctta_wav_to_fbank": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "ctta_lincomb2_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_float, c_void_p]),
+    "ctta_weighted_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "ctta_weighted_mse_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_pack_weight_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ctta_copy_segments_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "ctta_unet_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -949,6 +949,37 @@ extern "C" ctta_status ctta_snr_mse_grad(const float* pred, const float* target,
   return CTTA_OK;
 }
 
+// loss = mean_b( w_b * mean((pred-target)^2) ) with explicit per-instance weights (NULL = 1): stage-1 guided distillation
+// (models/audio_guided_model.py:92-117, min-SNR weights computed by the caller)
+__global__ void weighted_mse_grad_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                         const float* __restrict__ w, float loss_scale, int B, int C, int HW, int cpad,
+                                         bf16_t* __restrict__ out) {
+  const long long total = (long long)B * HW * cpad;
+  const float n = (float)C * (float)HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % cpad);
+    const long long pix = i / cpad;
+    const int b = (int)(pix / HW);
+    const int hw = (int)(pix - (long long)b * HW);
+    float g = 0.f;
+    if (c < C) {
+      const size_t j = ((size_t)b * C + c) * HW + hw;
+      g = 2.0f * (w ? w[b] : 1.0f) / (n * (float)B) * (pred[j] - target[j]) * loss_scale;
+    }
+    out[i] = f2bf(g);
+  }
+}
+extern "C" ctta_status ctta_weighted_mse_grad(const float* pred, const float* target, const float* weights,
+                                              float loss_scale, int batch, int c, int hw, int c_pad, void* dpred_nhwc,
+                                              void* stream) {
+  CTTA_REQUIRE(pred && target && dpred_nhwc && c_pad >= c, "weighted_mse_grad: bad arguments");
+  const long long total = (long long)batch * hw * c_pad;
+  hipLaunchKernelGGL(weighted_mse_grad_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, pred, target,
+                     weights, loss_scale, batch, c, hw, c_pad, (bf16_t*)dpred_nhwc);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
 // ------------------------------------------------------------------------------ AdamW (torch.optim.AdamW, no amsgrad)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, long long n, float lr, float beta1, float beta2, float eps, float wd,

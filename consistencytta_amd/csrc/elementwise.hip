@@ -101,6 +101,31 @@ __global__ void cfg_combine_kernel(const float4* __restrict__ u, const float4* _
   }
 }
 
+// out = a[b]*x + b_[b]*y per sample (optionally clamped): DDPM/DDIM add_noise and the v-prediction step pieces
+__global__ void lincomb2_kernel(const float4* __restrict__ x, const float4* __restrict__ y, const float* __restrict__ a,
+                                const float* __restrict__ b_, float4* __restrict__ out, long long nvec_per, long long total,
+                                float clamp) {
+  VEC_LOOP(total) {
+    const int s = (int)(i / nvec_per);
+    const float ca = a[s], cb = b_[s];
+    const float4 xx = x[i], yy = y[i];
+    float4 o = make_float4(ca * xx.x + cb * yy.x, ca * xx.y + cb * yy.y, ca * xx.z + cb * yy.z, ca * xx.w + cb * yy.w);
+    if (clamp > 0.f) {
+      o.x = fminf(fmaxf(o.x, -clamp), clamp); o.y = fminf(fmaxf(o.y, -clamp), clamp);
+      o.z = fminf(fmaxf(o.z, -clamp), clamp); o.w = fminf(fmaxf(o.w, -clamp), clamp);
+    }
+    out[i] = o;
+  }
+}
+// loss = mean_b(w[b] * inst[b])  (w NULL = 1)
+__global__ void weighted_mean_kernel(const float* __restrict__ inst, const float* __restrict__ w, int B,
+                                     float* __restrict__ loss) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s += inst[b] * (w ? w[b] : 1.0f);
+  loss[0] = s / (float)B;
+}
+
 // per-instance mean squared error (one workgroup per instance), then the SNR-clamped mean
 __global__ __launch_bounds__(256) void inst_mse_kernel(const float4* __restrict__ a,
                                                        const float4* __restrict__ t,
@@ -344,6 +369,30 @@ extern "C" ctta_status ctta_snr_mse_loss(const float* pred, const float* target,
   CTTA_LAUNCH_CHECK();
   hipLaunchKernelGGL(snr_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, per_instance, sigma,
                      gamma, batch, loss);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_lincomb2_rows(const float* x, const float* y, const float* a, const float* b, float* out,
+                                          int batch, int64_t n_per_sample, float clamp, void* stream) {
+  CTTA_REQUIRE(x && y && a && b && out, "lincomb2_rows: null pointer");
+  REQ_VEC(n_per_sample);
+  const long long nv = n_per_sample / 4, total = nv * batch;
+  hipLaunchKernelGGL(lincomb2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     (const float4*)y, a, b, (float4*)out, nv, total, clamp);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_weighted_mse_loss(const float* pred, const float* target, const float* weights,
+                                              float* per_instance, float* loss, int batch, int64_t n_per_sample,
+                                              void* stream) {
+  CTTA_REQUIRE(pred && target && per_instance && loss, "weighted_mse_loss: null pointer");
+  REQ_VEC(n_per_sample);
+  hipLaunchKernelGGL(inst_mse_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const float4*)pred,
+                     (const float4*)target, (long long)(n_per_sample / 4), per_instance);
+  CTTA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(weighted_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, per_instance, weights, batch, loss);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

@@ -25,7 +25,7 @@ from torch import nn
 from . import _native as N
 from . import dist_util
 from .modules import AutoencoderKL, UNet2DConditionGuidedModel, UNet2DConditionModel
-from .scheduler import HeunDiscreteScheduler
+from .scheduler import DDPMScheduler, HeunDiscreteScheduler
 
 
 def randn_tensor(shape, generator=None, device=None, dtype=None):
@@ -489,6 +489,190 @@ class AudioLCM(AudioDistilledModel):
         if return_all:
             return zhat_0, zhat_tea, time_stu + time_embed, time_tea
         return zhat_0
+
+
+class _WeightedMSELoss(torch.autograd.Function):
+    """grad_fn of AudioGDM's loss: backward = d(weighted MSE)/d(pred) -> the student engine's backward pass."""
+
+    @staticmethod
+    def forward(ctx, anchor, loss, model, pred, target, weights):
+        ctx.model, ctx.saved = model, (pred, target, weights)
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pred, target, weights = ctx.saved
+        ctx.model._student_backward(pred, target, weights, float(grad_out))
+        return (None,) * 6
+
+
+class AudioGDM(AudioDistilledModel):
+    """Stage-1 guided distillation (models/audio_guided_model.py:16-244): the CFG teacher is
+    distilled into the guidance-conditioned student at DDPM noise levels; loss = MSE to the teacher's prediction with
+    min-SNR-gamma weights.  `forward` returns a loss with a grad_fn (engine backward), `train_step` is the fused
+    data-parallel step, `inference` runs the reference's DDIM loop."""
+
+    def __init__(self, text_encoder_name, scheduler_name, unet_model_name=None, unet_model_config_path=None,
+                 snr_gamma=None, freeze_text_encoder=True, use_lora=False, ema_decay=.999, teacher_guidance_scale=3,
+                 **kwargs):
+        super().__init__(text_encoder_name=text_encoder_name, scheduler_name=scheduler_name,
+                         unet_model_name=unet_model_name, unet_model_config_path=unet_model_config_path,
+                         snr_gamma=snr_gamma, freeze_text_encoder=freeze_text_encoder, use_lora=use_lora,
+                         ema_decay=ema_decay, teacher_guidance_scale=teacher_guidance_scale, **kwargs)
+        self.noise_scheduler = DDPMScheduler.from_pretrained(self.scheduler_name, subfolder="scheduler")
+
+    def train(self, mode=True):
+        """audio_distilled_model.py:154-163: the frozen teacher / EMA / text encoder stay in eval mode."""
+        super().train(mode)
+        self.teacher_unet.eval()
+        self.student_ema_unet.eval()
+        if self.text_encoder is not None:
+            self.text_encoder.eval()
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def compute_snr(self, timesteps):
+        """alpha^2 / sigma^2 with alpha = sqrt(alphas_cumprod[t]) (audio_distilled_model.py:165-191), host side."""
+        ac = self.noise_scheduler.alphas_cumprod[torch.as_tensor(timesteps).reshape(-1).to("cpu", torch.int64)]
+        return ((ac ** 0.5) / ((1.0 - ac) ** 0.5)) ** 2
+
+    def update_ema(self):
+        assert self.training, "EMA update should only be called during training"
+        do_ema_update(self.student_unet, [self.student_ema_unet], [self.ema_decay])
+
+    def _grad_anchor(self):
+        a = getattr(self, "_anchor", None)
+        if a is None or a.device != self.device:
+            a = self._anchor = torch.zeros((), device=self.device, requires_grad=True)
+        return a
+
+    def _loss_weights(self, t_n, dev):
+        if self.snr_gamma is None:
+            return None
+        snr = self.compute_snr(t_n).reshape(-1)
+        trunc = torch.clamp(snr, max=self.snr_gamma)
+        if self.noise_scheduler.config.prediction_type == "v_prediction":
+            w = trunc / (snr + 1)
+        elif self.noise_scheduler.config.prediction_type == "epsilon":
+            w = trunc / snr
+        else:
+            raise ValueError("Unknown prediction type.")
+        return w.to(device=dev, dtype=torch.float32).contiguous()
+
+    def _student_backward(self, pred, target, weights, loss_scale=1.0, on_block_done=None):
+        B, C, H, W = pred.shape
+        d = torch.empty(B, H * W, 8, dtype=torch.bfloat16, device=pred.device)
+        with torch.cuda.device(pred.device):
+            N.check(N.lib().ctta_weighted_mse_grad(N.ptr(pred), N.ptr(target.contiguous()), N.ptr(weights),
+                                                   float(loss_scale), B, C, H * W, 8, N.ptr(d), N.stream_ptr()))
+        self.student_unet.backward(grad_output_nhwc=d, on_block_done=on_block_done)
+
+    def _forward_impl(self, z_0, prompt, want_grad, time_inds=None, gaussian_noise=None, guidance_scale=None):
+        self.check_eval_mode()
+        sch = self.noise_scheduler
+        dev = z_0.device
+        B = z_0.shape[0]
+        embeds_cf, mask_cf, embeds, mask = self.get_prompt_embeds(prompt, self.use_teacher_cf_guidance, 1)
+        avail = sch.timesteps                                               # host int64, 999..0
+        inds = time_inds.to("cpu", torch.int64) if time_inds is not None else torch.randint(0, len(avail), (B,))
+        t_n = avail[inds]
+        noise = gaussian_noise if gaussian_noise is not None else torch.randn_like(z_0)
+        z_noisy = sch.add_noise(z_0, noise, t_n)
+        z_gauss = noise * sch.init_noise_sigma
+        last = (t_n == int(avail.max())).reshape(-1, 1, 1, 1).to(dev)
+        z_n = torch.where(last, z_gauss, z_noisy)
+        z_n_scaled = sch.scale_model_input(z_n, t_n)
+        if self.teacher_guidance_scale == -1:
+            if guidance_scale is None:
+                guidance_scale = torch.rand(B) * self.max_rand_guidance_scale
+            guidance_scale = guidance_scale.to(dev)
+        else:
+            guidance_scale = None
+        t_f = t_n.to(torch.float32)
+        teacher = self._query_teacher(z_n_scaled, t_f, embeds_cf, mask_cf, guidance_scale)
+        w = guidance_scale if guidance_scale is not None else float(self.teacher_guidance_scale)
+        if want_grad:
+            pred = self.student_unet.forward_train(z_n_scaled, t_f, w, embeds, mask)
+        else:
+            pred = self.student_unet(z_n_scaled, t_f, guidance=w, encoder_hidden_states=embeds,
+                                     encoder_attention_mask=mask).sample
+        weights = self._loss_weights(t_n, dev)
+        inst = torch.empty(B, dtype=torch.float32, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        N.check(N.lib().ctta_weighted_mse_loss(N.ptr(pred.contiguous()), N.ptr(teacher.contiguous()), N.ptr(weights),
+                                               N.ptr(inst), N.ptr(out), B, pred[0].numel(), N.stream_ptr()))
+        return out[0], pred, teacher.contiguous(), weights
+
+    def forward(self, z_0, prompt, time_inds=None, gaussian_noise=None, guidance_scale=None, **kwargs):
+        want_grad = (self.training and torch.is_grad_enabled()
+                     and any(p.requires_grad for p in self.student_unet.parameters()))
+        with torch.no_grad():
+            loss, pred, target, weights = self._forward_impl(z_0, prompt, want_grad, time_inds, gaussian_noise,
+                                                             guidance_scale)
+        if not want_grad:
+            return loss
+        return _WeightedMSELoss.apply(self._grad_anchor(), loss, self, pred, target, weights)
+
+    def prepare_training(self, lr=3e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, broadcast=True):
+        from .optim import FusedAdamW
+        self.student_unet.enable_training = True
+        for m in (self.student_unet, self.student_ema_unet):
+            flat = m.flatten_parameters_()
+            if broadcast:
+                dist_util.broadcast_(flat)
+                m.mark_weights_changed()
+        return FusedAdamW(self.student_unet, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+
+    def train_step(self, z_0, prompt, optimizer, lr_scheduler=None, skip_nan=True, **fw):
+        """loss -> backward (+ overlapped RCCL gradient all-reduce) -> AdamW -> schedule -> zero_grad -> EMA."""
+        assert self.training, "train_step needs model.train()"
+        with torch.no_grad():
+            loss, pred, target, weights = self._forward_impl(z_0, prompt, True, fw.pop("time_inds", None),
+                                                             fw.pop("gaussian_noise", None), fw.pop("guidance_scale", None))
+            buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges())
+            self._student_backward(pred, target, weights, 1.0, buckets.ready if buckets.enabled else None)
+            world = buckets.wait()
+            value = float(loss.item())
+            if not (skip_nan and value != value):
+                optimizer.step(grad_scale=1.0 / world)
+                if lr_scheduler is not None:
+                    lr_scheduler.step()
+            optimizer.zero_grad()
+            self.update_ema()
+        return value
+
+    @torch.no_grad()
+    def inference(self, prompt, inference_scheduler, guidance_scale_input=3, guidance_scale_post=1, num_steps=20,
+                  use_edm=False, num_samples=1, use_ema=True, query_teacher=False, noise=None, **kwargs):
+        self.check_eval_mode()
+        sch = inference_scheduler
+        use_cf = guidance_scale_post > 1.
+        embeds_cf, mask_cf, embeds, mask = self.get_prompt_embeds(prompt, True, num_samples)
+        enc_stu, mask_stu = (embeds_cf, mask_cf) if use_cf else (embeds, mask)
+        enc_tea, mask_tea = (embeds_cf, mask_cf) if self.use_teacher_cf_guidance else (embeds, mask)
+        dev = embeds.device
+        B = embeds.shape[0]
+        sch.set_timesteps(num_steps, device=dev)
+        tea_sch = deepcopy(sch) if query_teacher else None
+        if noise is None:
+            noise = randn_tensor((B, self.student_unet.config.in_channels, 256, 16), device=dev, dtype=torch.float32)
+        z_stu = z_tea = noise * sch.init_noise_sigma
+        unet = self.student_ema_unet if use_ema else self.student_unet
+        for t in [float(v) for v in sch.timesteps]:
+            z_in = torch.cat([z_stu] * 2) if use_cf else z_stu
+            z_in = sch.scale_model_input(z_in, t)
+            v = unet(z_in, t, guidance=guidance_scale_input, encoder_hidden_states=enc_stu,
+                     encoder_attention_mask=mask_stu).sample
+            if use_cf:
+                u, c = v.chunk(2)
+                v = u + guidance_scale_post * (c - u)
+            z_stu = sch.step(v, int(t), z_stu).prev_sample
+            if query_teacher:
+                vt = self._query_teacher(sch.scale_model_input(z_tea, t), t, enc_tea, mask_tea, guidance_scale_input)
+                z_tea = tea_sch.step(vt, int(t), z_tea).prev_sample
+        return z_stu
 
 
 def _teacher_loop_graphed(self, sch, z, enc, mask, guidance_scale):

@@ -160,3 +160,149 @@ class HeunDiscreteScheduler:
 
     def __len__(self):
         return self.config.num_train_timesteps
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Stage-1 guided distillation: the reference's batched-timestep DDPM / DDIM schedulers
+# (diffusers/schedulers/scheduling_ddpm.py, scheduling_ddim.py).  Coefficient tables live on the host; the per-sample
+# linear combinations run on the HIP elementwise kernel ctta_lincomb2_rows.
+SD21_DDIM_EXTRA = dict(clip_sample=False, set_alpha_to_one=False)
+
+
+def _scaled_linear_alphas_cumprod(num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas):
+    if trained_betas is not None:
+        betas = torch.tensor(trained_betas, dtype=torch.float32)
+    elif beta_schedule == "linear":
+        betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+    elif beta_schedule == "scaled_linear":
+        betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+    else:
+        raise NotImplementedError(f"{beta_schedule} does is not implemented for this scheduler")
+    return betas, torch.cumprod(1.0 - betas, dim=0)
+
+
+class _LinCombMixin:
+    @staticmethod
+    def _lincomb(x, y, a, b, clamp=0.0):
+        """out = a[b]*x + b[b]*y with per-sample coefficients given as host tensors / arrays."""
+        if not x.is_cuda:
+            raise N.CttaError("scheduler inputs are on %s: the HIP kernels have no CPU path" % x.device)
+        x = x.detach().to(torch.float32).contiguous()
+        y = y.detach().to(device=x.device, dtype=torch.float32).contiguous()
+        B = x.shape[0]
+        ad = torch.as_tensor(np.asarray(a, dtype=np.float32)).reshape(-1).expand(B).contiguous().to(x.device)
+        bd = torch.as_tensor(np.asarray(b, dtype=np.float32)).reshape(-1).expand(B).contiguous().to(x.device)
+        out = torch.empty_like(x)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().ctta_lincomb2_rows(N.ptr(x), N.ptr(y), N.ptr(ad), N.ptr(bd), N.ptr(out), B, x[0].numel(),
+                                               float(clamp), N.stream_ptr()))
+        return out
+
+    def _t_index(self, timesteps, B):
+        """(B,) int64 host indices from a Python int / CPU tensor (no device sync) or a CUDA tensor (one sync)."""
+        t = torch.as_tensor(timesteps).detach().reshape(-1).to("cpu", torch.int64)
+        return t.expand(B).contiguous() if t.numel() == 1 else t
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def add_noise(self, original_samples, noise, timesteps):
+        """sqrt(ac[t]) * x0 + sqrt(1 - ac[t]) * noise  (scheduling_ddpm.py:420-443, scheduling_ddim.py:372-393)."""
+        t = self._t_index(timesteps, original_samples.shape[0])
+        ac = self.alphas_cumprod[t]
+        return self._lincomb(original_samples, noise, (ac ** 0.5).numpy(), ((1 - ac) ** 0.5).numpy())
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+
+class DDPMScheduler(_LinCombMixin):
+    """Training-side noising schedule of AudioGDM (models/audio_guided_model.py:43-47): timesteps 999..0, add_noise,
+    init_noise_sigma = 1, identity scale_model_input, alphas_cumprod for compute_snr.  The ancestral `step` is not used
+    by any script of the reference (inference runs DDIM or Heun) and is not built."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 trained_betas=None, variance_type="fixed_small", clip_sample=True, prediction_type="epsilon", **kw):
+        self.betas, self.alphas_cumprod = _scaled_linear_alphas_cumprod(num_train_timesteps, beta_start, beta_end,
+                                                                       beta_schedule, trained_betas)
+        self.alphas = 1.0 - self.betas
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                      beta_schedule=beta_schedule, prediction_type=prediction_type,
+                                      clip_sample=clip_sample, variance_type=variance_type)
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy())
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, subfolder=None, **kwargs):
+        return cls(**dict(SD21_SCHEDULER_CONFIG, clip_sample=False, **kwargs))
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        if num_inference_steps > self.config.num_train_timesteps:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                             f"`self.config.train_timesteps`: {self.config.num_train_timesteps}")
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        self.timesteps = torch.from_numpy((np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64))
+
+    def step(self, *a, **k):
+        raise NotImplementedError("DDPMScheduler.step (ancestral sampling) is unused by the reference's scripts and not built; "
+                                  "use DDIMScheduler or HeunDiscreteScheduler for inference")
+
+
+class DDIMScheduler(_LinCombMixin):
+    """scheduling_ddim.py in the reference's batched-timestep version: set_timesteps (:218-241, the steps_offset line is
+    commented out upstream), step (:243-370) for v_prediction / epsilon with eta = 0, add_noise."""
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 trained_betas=None, clip_sample=True, set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon",
+                 clip_sample_range=1.0, **kw):
+        self.betas, self.alphas_cumprod = _scaled_linear_alphas_cumprod(num_train_timesteps, beta_start, beta_end,
+                                                                       beta_schedule, trained_betas)
+        self.alphas = 1.0 - self.betas
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        if prediction_type not in ("v_prediction", "epsilon"):
+            raise ValueError(f"prediction_type given as {prediction_type} must be one of `epsilon` or `v_prediction`")
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                      beta_schedule=beta_schedule, prediction_type=prediction_type,
+                                      clip_sample=clip_sample, clip_sample_range=clip_sample_range,
+                                      set_alpha_to_one=set_alpha_to_one, steps_offset=steps_offset)
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path=None, subfolder=None, **kwargs):
+        return cls(**dict(SD21_SCHEDULER_CONFIG, **SD21_DDIM_EXTRA, **kwargs))
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        if num_inference_steps > self.config.num_train_timesteps:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                             f"`self.config.train_timesteps`: {self.config.num_train_timesteps}")
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        self.timesteps = torch.from_numpy((np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64))
+
+    def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None,
+             variance_noise=None, return_dict=True):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if eta != 0.0:
+            raise NotImplementedError("only the deterministic DDIM step (eta = 0) the reference uses is built")
+        B = sample.shape[0]
+        t = self._t_index(timestep, B)
+        prev = t - self.config.num_train_timesteps // self.num_inference_steps
+        a_t = self.alphas_cumprod[t]
+        a_prev = torch.where(prev >= 0, self.alphas_cumprod[prev.clamp(min=0)], self.final_alpha_cumprod)
+        sa, sb = a_t ** 0.5, (1 - a_t) ** 0.5
+        clamp = float(self.config.clip_sample_range) if self.config.clip_sample else 0.0
+        if self.config.prediction_type == "v_prediction":
+            x0 = self._lincomb(sample, model_output, sa.numpy(), (-sb).numpy(), clamp)
+            eps = self._lincomb(model_output, sample, sa.numpy(), sb.numpy())
+        else:  # epsilon
+            x0 = self._lincomb(sample, model_output, (1.0 / sa).numpy(), (-sb / sa).numpy(), clamp)
+            eps = model_output
+        prev_sample = self._lincomb(x0, eps, (a_prev ** 0.5).numpy(), ((1 - a_prev) ** 0.5).numpy())
+        if not return_dict:
+            return (prev_sample,)
+        return SimpleNamespace(prev_sample=prev_sample, pred_original_sample=x0)

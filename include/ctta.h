@@ -220,6 +220,17 @@ ctta_status ctta_cfg_combine(const float* uncond, const float* cond, const float
 ctta_status ctta_snr_mse_loss(const float* pred, const float* target, const float* sigma,
                               float gamma, float* per_instance, float* loss, int batch,
                               int64_t n_per_sample, void* stream);
+/* Stage-1 guided distillation pieces: per-sample linear combination out = a[b]*x + b[b]*y
+ * (optionally clamped to [-clamp, clamp]) -- DDPMScheduler/DDIMScheduler.add_noise (scheduling_ddpm.py:420-443) and the
+ * v-prediction terms of DDIMScheduler.step (scheduling_ddim.py:243-370) -- and the MSE with explicit per-instance weights
+ * of AudioGDM.forward's get_loss (models/audio_guided_model.py:92-117). */
+ctta_status ctta_lincomb2_rows(const float* x, const float* y, const float* a, const float* b, float* out,
+                               int batch, int64_t n_per_sample, float clamp, void* stream);
+ctta_status ctta_weighted_mse_loss(const float* pred, const float* target, const float* weights,
+                                   float* per_instance, float* loss, int batch, int64_t n_per_sample,
+                                   void* stream);
+ctta_status ctta_weighted_mse_grad(const float* pred, const float* target, const float* weights, float loss_scale,
+                                   int batch, int c, int hw, int c_pad, void* dpred_nhwc, void* stream);
 
 /* ------------------------------------------------------------------------------------ *
  * Fused two-shadow EMA.  Replaces do_ema_update (tools/train_utils.py:255-282) as called by

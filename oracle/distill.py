@@ -135,3 +135,32 @@ def inference_teacher(n, P, noise, w, num_teacher_steps):
             z = heun.step_second(v, z, sj1, x0, d, dt)
         first = not first
     return z
+
+
+# ----------------------------------------------------------------------------------- stage 1 (AudioGDM)
+def gdm_loss(n, P, z0, noise, time_inds, w, snr_gamma=5.0):
+    """AudioGDM.forward (models/audio_guided_model.py:87-164): DDPM noising at t = timesteps[time_inds], one CFG teacher
+    query, the guided student's prediction, MSE weighted by min(snr, gamma) / (snr + 1) per instance."""
+    from . import ddim
+    ac = ddim.alphas_cumprod()
+    ts = ddim.ddpm_timesteps()
+    t_n = ts[time_inds]
+    z_noisy = ddim.add_noise(z0, noise, t_n, ac)
+    last = (t_n == ts.max()).reshape(-1, 1, 1, 1)
+    z_n = torch.where(last, noise * 1.0, z_noisy)                 # init_noise_sigma = 1; scale_model_input = identity
+    teacher = query_teacher(n, z_n, t_n, P["embeds_cf"], P["mask_cf"], w)
+    student = unet_forward(n.cfg, n.student, z_n, t_n, w, P["embeds"], P["mask"])
+    inst = ((student - teacher) ** 2).mean(dim=(1, 2, 3))
+    return (inst * ddim.gdm_loss_weights(t_n, snr_gamma, ac)).mean()
+
+
+def gdm_inference(n, sd, P, noise, w_in, num_steps):
+    """AudioGDM.inference (:166-244) with guidance_scale_post = 1: num_steps DDIM steps of the guided student."""
+    from . import ddim
+    ac = ddim.alphas_cumprod()
+    z = noise * 1.0
+    B = noise.shape[0]
+    for t in ddim.ddim_timesteps(num_steps):
+        v = unet_forward(n.cfg, sd, z, float(t), float(w_in), P["embeds"], P["mask"])
+        z = ddim.ddim_step(v, torch.full((B,), int(t)), z, num_steps, ac)
+    return z

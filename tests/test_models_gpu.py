@@ -120,3 +120,95 @@ def test_teacher_loop_hipgraph_matches_eager(golden):
     _, e2, _, _ = m.inference(P, sched, num_teacher_steps=6, **kw)
     _, g2, _, _ = m.inference(P, sched, num_teacher_steps=6, graph_teacher=True, **kw)
     assert torch.equal(e2, g2)
+
+
+# ------------------------------------------------------------------------------------------------
+# Stage-1 guided distillation: DDPM / DDIM schedulers and models.AudioGDM
+def _gdm():
+    from consistencytta_amd.models import AudioGDM
+    cfg = cases.TINY_UNET
+    m = AudioGDM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                 unet_model_config_path="tiny_light.json", unet_config=cfg, snr_gamma=5.0, teacher_guidance_scale=-1,
+                 ema_decay=0.999)
+    m.teacher_unet.load_state_dict(cases.unet_weights(cfg, False, 0))
+    m.student_unet.load_state_dict(cases.unet_weights(cfg, True, 1))
+    m.student_ema_unet.load_state_dict(cases.unet_weights(cfg, True, 3))
+    m.to(DEV)
+    P = {k: v.to(DEV) for k, v in cases.prompt_states(cfg, 3, 6, "distill").items()}
+    z0 = (cases.t(spec.det_uniform("distill.z0", (3, 8, 32, 8), 14)) * 0.9).to(DEV)
+    return m, P, z0
+
+
+def test_ddpm_ddim_schedulers_against_reference_golden(golden):
+    g = golden("gdm_tiny")
+    x = (cases.t(spec.det_uniform("gdm.x", (3, 8, 16, 4), 1)) * 2).to(DEV)
+    noise = cases.t(spec.det_uniform("gdm.n", (3, 8, 16, 4), 2)).to(DEV)
+    v = cases.t(spec.det_uniform("gdm.v", (3, 8, 16, 4), 3)).to(DEV)
+    ddpm = scheduler.DDPMScheduler.from_pretrained("stabilityai/stable-diffusion-2-1", subfolder="scheduler")
+    np.testing.assert_array_equal(ddpm.timesteps[:5].numpy(), g["ddpm_timesteps_head"])
+    np.testing.assert_allclose(ddpm.alphas_cumprod.numpy(), g["alphas_cumprod"], rtol=1e-6)
+    t_train = torch.tensor([999, 400, 0])
+    assert rel_err(ddpm.add_noise(x, noise, t_train), torch.from_numpy(g["ddpm_add_noise"])) < 1e-6
+    assert ddpm.init_noise_sigma == 1.0 and ddpm.scale_model_input(x, 5) is x
+    ddim = scheduler.DDIMScheduler.from_pretrained("stabilityai/stable-diffusion-2-1", subfolder="scheduler")
+    for n in (50, 5):
+        ddim.set_timesteps(n)
+        np.testing.assert_array_equal(ddim.timesteps.numpy(), g["ddim_timesteps_%d" % n])
+    assert rel_err(ddim.step(v, torch.from_numpy(g["ddim_t"]), x).prev_sample, torch.from_numpy(g["ddim_step"])) < 1e-6
+    assert rel_err(ddim.step(v, 600, x).prev_sample, torch.from_numpy(g["ddim_step_scalar_t"])) < 1e-6
+    assert rel_err(ddim.add_noise(x, noise, t_train.to(DEV)), torch.from_numpy(g["ddim_add_noise"])) < 1e-6
+    with pytest.raises(NotImplementedError):
+        ddpm.step(v, 5, x)
+    with pytest.raises(ValueError):
+        scheduler.DDIMScheduler().step(v, 5, x)          # set_timesteps not called
+
+
+def test_stage1_guided_distillation_loss_backward_and_inference(golden):
+    """AudioGDM.forward vs the reference's own AudioGDM (recorded random draws), its gradients vs torch autograd over
+    the oracle, one fused train_step, and the 4-step DDIM inference vs the reference."""
+    from oracle import distill
+    g = golden("gdm_tiny")
+    m, P, z0 = _gdm()
+    m.train()
+    kw = dict(time_inds=torch.from_numpy(g["gdm_time_inds"]), gaussian_noise=torch.from_numpy(g["gdm_noise"]).to(DEV),
+              guidance_scale=torch.from_numpy(g["gdm_guidance"]))
+    loss = m(z0, P, **kw)
+    ref = float(g["gdm_loss"])
+    print("stage-1 loss hip %.6f ref %.6f" % (float(loss), ref))
+    assert loss.requires_grad and abs(float(loss) - ref) <= 5e-2 * ref
+    loss.backward()
+    torch.cuda.synchronize()
+    # oracle gradients
+    cfg = cases.TINY_UNET
+    student = {k: v.clone().requires_grad_(k != "guidance_proj.weight") for k, v in cases.unet_weights(cfg, True, 1).items()}
+    n = distill.Nets(cfg, cases.unet_weights(cfg, False, 0), student, None, cases.unet_weights(cfg, True, 3))
+    Pc = cases.prompt_states(cfg, 3, 6, "distill")
+    z0c = cases.t(spec.det_uniform("distill.z0", (3, 8, 32, 8), 14)) * 0.9
+    distill.gdm_loss(n, Pc, z0c, torch.from_numpy(g["gdm_noise"]), torch.from_numpy(g["gdm_time_inds"]),
+                     torch.from_numpy(g["gdm_guidance"])).backward()
+    num = den = 0.0
+    for k, p in m.student_unet.named_parameters():
+        if p.requires_grad:
+            num += float((p.grad.cpu() - student[k].grad).norm()) ** 2
+            den += float(student[k].grad.norm()) ** 2
+    rel = (num / den) ** 0.5
+    print("stage-1 gradients vs oracle autograd: rel_l2 %.3e" % rel)
+    assert rel <= 4e-2
+    # fused step
+    for p in m.student_unet.parameters():
+        p.grad = None
+    opt = m.prepare_training(lr=1e-4, weight_decay=1e-2, broadcast=False)
+    before = opt.flat.detach().clone()
+    ema_before = m.student_ema_unet._flat.detach().clone()
+    val = m.train_step(z0, P, opt, None, **kw)
+    assert abs(val - float(loss)) <= 1e-5 * abs(val) and not torch.equal(opt.flat, before)
+    assert not torch.equal(m.student_ema_unet._flat, ema_before) and float(opt.grad.abs().max()) == 0.0
+    # inference (fresh model: the step above changed the weights)
+    m2, P2, _ = _gdm()
+    m2.eval()
+    sched = scheduler.DDIMScheduler.from_pretrained("stabilityai/stable-diffusion-2-1", subfolder="scheduler")
+    lat = (cases.t(spec.det_uniform("gdm.inf_noise", (3, 8, 256, 16), 16)) * np.float32(np.sqrt(3.0))).to(DEV)
+    z = m2.inference(P2, sched, guidance_scale_input=3.0, guidance_scale_post=1.0, num_steps=4, use_ema=True, noise=lat)
+    l2 = rel_l2(z, torch.from_numpy(g["gdm_inference_4steps"]))
+    print("stage-1 4-step DDIM inference rel_l2 %.3e" % l2)
+    assert l2 <= 2 * REL_L2

@@ -210,3 +210,45 @@ def test_mel_frontend(golden):
         assert float(fb[:, 251:].abs().max()) == 0.0                 # _pad_spec pads with zeros, not log(1e-5)
         fb2, _ = omel.wav_to_fbank(mg.test_wave(1, 163840, "mel_full"), 1024)
         close(fb2, g["fbank_full"], 1e-5, 2e-4)
+
+
+def test_stage1_schedulers_and_guided_distillation(golden):
+    """oracle.ddim / oracle.distill.gdm_* vs the reference's DDPMScheduler, DDIMScheduler and AudioGDM.forward
+    (SURVEY §8f rank 3)."""
+    from oracle import ddim, distill
+    g = golden("gdm_tiny")
+    ac = ddim.alphas_cumprod()
+    np.testing.assert_allclose(ac.numpy(), g["alphas_cumprod"], rtol=1e-6)
+    np.testing.assert_array_equal(ddim.ddpm_timesteps()[:5].numpy(), g["ddpm_timesteps_head"])
+    for n in (5, 50):
+        np.testing.assert_array_equal(ddim.ddim_timesteps(n).numpy(), g["ddim_timesteps_%d" % n])
+    x = cases.t(spec.det_uniform("gdm.x", (3, 8, 16, 4), 1)) * 2
+    noise = cases.t(spec.det_uniform("gdm.n", (3, 8, 16, 4), 2))
+    v = cases.t(spec.det_uniform("gdm.v", (3, 8, 16, 4), 3))
+    t_train = torch.tensor([999, 400, 0])
+    close(ddim.add_noise(x, noise, t_train, ac), g["ddpm_add_noise"], 1e-6, 1e-7)
+    close(ddim.add_noise(x, noise, t_train, ac), g["ddim_add_noise"], 1e-6, 1e-7)
+    close(ddim.ddim_step(v, torch.from_numpy(g["ddim_t"]), x, 5, ac), g["ddim_step"], 1e-6, 1e-7)
+    close(ddim.ddim_step(v, torch.full((3,), 600), x, 5, ac), g["ddim_step_scalar_t"], 1e-6, 1e-7)
+    cfg = cases.TINY_UNET
+    n = distill.Nets(cfg, cases.unet_weights(cfg, False, 0), cases.unet_weights(cfg, True, 1), None,
+                     cases.unet_weights(cfg, True, 3))
+    P = cases.prompt_states(cfg, 3, 6, "distill")
+    z0 = cases.t(spec.det_uniform("distill.z0", (3, 8, 32, 8), 14)) * 0.9
+    with torch.no_grad():
+        loss = distill.gdm_loss(n, P, z0, torch.from_numpy(g["gdm_noise"]), torch.from_numpy(g["gdm_time_inds"]),
+                                torch.from_numpy(g["gdm_guidance"]))
+    assert abs(float(loss) - float(g["gdm_loss"])) <= 2e-4 * float(g["gdm_loss"])
+
+
+@pytest.mark.slow
+def test_stage1_inference(golden):
+    from oracle import distill
+    g = golden("gdm_tiny")
+    cfg = cases.TINY_UNET
+    n = distill.Nets(cfg, cases.unet_weights(cfg, False, 0), cases.unet_weights(cfg, True, 1), None,
+                     cases.unet_weights(cfg, True, 3))
+    P = cases.prompt_states(cfg, 3, 6, "distill")
+    lat = cases.t(spec.det_uniform("gdm.inf_noise", (3, 8, 256, 16), 16)) * np.float32(np.sqrt(3.0))
+    with torch.no_grad():
+        close(distill.gdm_inference(n, n.ema, P, lat, 3.0, 4), g["gdm_inference_4steps"], 5e-4, 5e-5)
