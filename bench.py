@@ -198,6 +198,35 @@ def main():
         torch.cuda.synchronize()
         result["pcie_inclusive_clips_per_s"] = round(2 * B / (time.perf_counter() - t1), 3)
 
+        # ---- single-clip latency (configs[0] shape: one prompt, L=16), eager launches vs one hipGraph replay
+        try:
+            e1, m1, n1 = enc[:1, :16].contiguous(), mask[:1, :16].contiguous(), noise[:1].contiguous()
+            m1[:] = True
+            gen1 = pipe.capture_graph(1, 16, cfg_scale_input=4.0)
+
+            def eager1():
+                lat_ = pipe.generate_latent(e1, m1, n1, cfg_scale_input=4.0, cfg_scale_post=1.0, num_steps=1)
+                w_ = vae.vocode(vae.decode_first_stage(lat_))
+                p_ = torch.empty(w_.shape, dtype=torch.int16, device=dev)
+                N.check(N.lib().ctta_wav_finalize(N.ptr(w_), w_.numel(), N.ptr(scratch), None, N.ptr(p_), N.stream_ptr()))
+                return p_
+
+            lat_ms = {}
+            for name, fn in (("eager", eager1), ("hipgraph", lambda: gen1(e1, m1, n1))):
+                for _ in range(3):
+                    fn()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    fn()
+                torch.cuda.synchronize()
+                lat_ms[name] = round((time.perf_counter() - t1) / 10 * 1e3, 3)
+            assert torch.equal(eager1(), gen1(e1, m1, n1))
+            result["single_clip_latency_ms"] = lat_ms
+            del gen1
+        except Exception as exc:   # a failed capture must not cost the headline line
+            result["single_clip_latency_ms"] = {"error": str(exc)[:200]}
+
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(pipe, vae, enc, mask, noise)
     if args.mode != "gen":

@@ -796,6 +796,47 @@ class ConsistencyTTA(nn.Module):
         return zhat_0
 
     @torch.no_grad()
+    def capture_graph(self, batch, text_len, cfg_scale_input=3., cross_attention_dim=1024, latent=(8, 256, 16)):
+        """Captures the whole single-step pipeline (U-Net query -> VAE decoder -> HiFi-GAN -> int16) for a fixed
+        (batch, text_len) into ONE hipGraph and returns a callable `(encoder_states, encoder_mask, noise) -> pcm` that
+        copies its arguments into the graph's static inputs and replays it.  The ~1500 kernel launches of a clip cost
+        more host time than GPU time at batch 1 (demo.py / easy_inference latency); a replay is a single launch.
+        Results are identical to `forward_from_embeds(..., cfg_scale_post=1, num_steps=1)`."""
+        self.check_eval_mode()
+        dev = self.unet.device
+        st = {"enc": torch.zeros(batch, text_len, cross_attention_dim, device=dev),
+              "mask": torch.ones(batch, text_len, dtype=torch.bool, device=dev),
+              "noise": torch.zeros((batch,) + tuple(latent), device=dev)}
+        scratch = torch.empty(4, dtype=torch.float32, device=dev)
+
+        def run():
+            lat = self.generate_latent(st["enc"], st["mask"], st["noise"], cfg_scale_input, 1.0, 1)
+            mel = self.vae.decode_first_stage(lat)
+            wav = self.vae.vocode(mel)
+            pcm = torch.empty(wav.shape, dtype=torch.int16, device=dev)
+            N.check(N.lib().ctta_wav_finalize(N.ptr(wav), wav.numel(), N.ptr(scratch), None, N.ptr(pcm), N.stream_ptr()))
+            return lat, mel, pcm
+
+        side = torch.cuda.Stream(device=dev)        # eager warm-up: engine handles, kernel attributes, allocator pool
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = run()
+
+        def replay(encoder_states, encoder_mask, noise):
+            st["enc"].copy_(encoder_states)
+            st["mask"].copy_(encoder_mask)
+            st["noise"].copy_(noise)
+            graph.replay()
+            return out[2]
+
+        replay.graph, replay.outputs = graph, out
+        return replay
+
+    @torch.no_grad()
     def forward_from_embeds(self, encoder_states, encoder_mask, noise, cfg_scale_input=3., cfg_scale_post=1.,
                             num_steps=1, sr=16000, **kw):
         self.check_eval_mode()

@@ -76,6 +76,8 @@ class HeunDiscreteScheduler:
         ts = np.concatenate([timesteps[:1], np.repeat(timesteps[1:], 2)])
         self._sigmas_host = sig
         self._timesteps_host = ts
+        if device is not None and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            device = None   # inside hipGraph capture: no host->device copies; the kernels use the host tables anyway
         self.sigmas = torch.from_numpy(sig).to(device=device)
         self.init_noise_sigma = self.sigmas.max()
         self.timesteps = torch.from_numpy(ts).to(device=device)
@@ -100,10 +102,11 @@ class HeunDiscreteScheduler:
         return idx if self.state_in_first_order else idx - 1
 
     def _sigma_dev(self, idx, B, device):
-        s = self._sigmas_host[idx]
-        if s.shape[0] == 1 and B > 1:
-            s = np.repeat(s, B)
-        return torch.from_numpy(np.ascontiguousarray(s, dtype=np.float32)).to(device, non_blocking=True)
+        s = np.asarray(self._sigmas_host[idx], dtype=np.float32).reshape(-1)
+        if s.shape[0] == 1 or bool((s == s[0]).all()):
+            # one sigma for the whole batch: a device-side fill (no host->device copy, safe inside hipGraph capture)
+            return torch.full((B,), float(s[0]), dtype=torch.float32, device=device)
+        return torch.from_numpy(np.ascontiguousarray(s)).to(device, non_blocking=True)
 
     @staticmethod
     def _check(x):

@@ -212,3 +212,27 @@ def test_stage1_guided_distillation_loss_backward_and_inference(golden):
     l2 = rel_l2(z, torch.from_numpy(g["gdm_inference_4steps"]))
     print("stage-1 4-step DDIM inference rel_l2 %.3e" % l2)
     assert l2 <= 2 * REL_L2
+
+
+def test_whole_pipeline_hipgraph_matches_eager():
+    """ConsistencyTTA.capture_graph: one hipGraph for U-Net -> VAE decoder -> HiFi-GAN -> int16; replays with new inputs
+    must equal the eager pipeline bit for bit."""
+    from consistencytta_amd import modules
+    from consistencytta_amd.models import ConsistencyTTA
+    cfg = cases.TINY_UNET
+    vae = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, scale_factor=0.9, hifigan_config=cases.TINY_HIFIGAN)
+    pipe = ConsistencyTTA(unet_config=cfg, vae=vae)
+    pipe.to(DEV)
+    pipe.unet.init_deterministic(1)
+    vae.init_deterministic(2)
+    pipe.eval().requires_grad_(False)
+    B, L = 2, 7
+    gen = pipe.capture_graph(B, L, cfg_scale_input=4.0, cross_attention_dim=cfg["cross_attention_dim"], latent=(8, 32, 16))
+    for seed in (1, 2):
+        x, _, _, enc, mask = cases.unet_inputs(cfg, B, 32, 16, L, "graph%d" % seed)
+        pcm = gen(enc.to(DEV), mask.to(DEV), x.to(DEV)).clone()
+        lat = pipe.generate_latent(enc.to(DEV), mask.to(DEV), x.to(DEV), 4.0, 1.0, 1)
+        mel = vae.decode_first_stage(lat)
+        ref = vae.decode_to_waveform(mel)
+        assert torch.equal(gen.outputs[0], lat) and torch.equal(gen.outputs[1], mel)
+        assert np.array_equal(pcm.cpu().numpy(), ref)
