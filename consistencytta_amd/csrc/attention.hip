@@ -18,6 +18,10 @@
 
 #include <math.h>
 
+// v_exp_f32 directly: exp2f() wraps it in a denormal-range fix-up (compare, select, add, ldexp: 6 instructions per
+// element in a VALU-bound loop); probabilities below 2^-126 flushing to zero is immaterial here
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 #define ATT_KT 64          // keys per tile
 #define ATT_LDK 80         // K tile row stride (bf16): 160 B rows are conflict-free for ds_read_b128
 #define ATT_LDV 72         // V^T tile row stride: 144 B rows are conflict-free for the paired ds_read_b64
@@ -143,22 +147,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun[jq], mx);
-      const float alpha = exp2f(mrun[jq] - mnew);   // first tile: exp2(-inf) = 0
+      const float alpha = fast_exp2(mrun[jq] - mnew);   // first tile: exp2(-inf) = 0
       mrun[jq] = mnew;
       float ps = 0.f;
 #pragma unroll
       for (int ik = 0; ik < 4; ++ik)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = exp2f(s[ik][jq][r] - mnew);
+          const float pv = fast_exp2(s[ik][jq][r] - mnew);
           s[ik][jq][r] = pv;
           ps += pv;
         }
       lrun[jq] = lrun[jq] * alpha + ps;
+      if (__any(alpha != 1.0f)) {   // wave-uniform: after the first tiles the running maxima rarely move
 #pragma unroll
-      for (int jd = 0; jd < 4; ++jd) {
-        o[jd][jq][0] *= alpha; o[jd][jq][1] *= alpha;
-        o[jd][jq][2] *= alpha; o[jd][jq][3] *= alpha;
+        for (int jd = 0; jd < 4; ++jd) {
+          o[jd][jq][0] *= alpha; o[jd][jq][1] *= alpha;
+          o[jd][jq][2] *= alpha; o[jd][jq][3] *= alpha;
+        }
       }
     }
     // ---- O^T += V^T P^T : k-slot (lg, e): e<4 -> key block 2kk, row lg*4+e ; e>=4 -> block 2kk+1
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
         else if (bb) add = bb[key] * 1.4426950408889634f;
 #pragma unroll
         for (int jq = 0; jq < 2; ++jq) {
-          const float pv = exp2f(s[ik][jq][r] * p.scale_log2e + add - lse_q[jq]);
+          const float pv = fast_exp2(s[ik][jq][r] * p.scale_log2e + add - lse_q[jq]);
           s[ik][jq][r] = pv * (dp[ik][jq][r] - d_q[jq]) * p.scale;
         }
       }
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int jk = 0; jk < 2; ++jk) {
-          const float pv = exp2f(s[iq][jk][r] * p.scale_log2e + kb2[jk] - lv[r]);
+          const float pv = fast_exp2(s[iq][jk][r] * p.scale_log2e + kb2[jk] - lv[r]);
           s[iq][jk][r] = pv;
           dp[iq][jk][r] = pv * (dp[iq][jk][r] - dd[r]) * p.scale;
         }
