@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--teacher-steps", type=int, default=200, help="Heun steps of the teacher leg (2N-1 U-Net queries)")
     ap.add_argument("--teacher-batch", type=int, default=8)
     ap.add_argument("--distill-batch", type=int, default=9, help="per-GPU micro-batch of the distillation leg (train.sh)")
+    ap.add_argument("--no-latency", action="store_true",
+                    help="skip the single-clip eager/hipGraph latency leg (graph replay hangs under rocprofv3 --pmc)")
     ap.add_argument("--profile-csv", default=None, help="append one line per MFMA launch (tuning aid)")
     return ap.parse_args()
 
@@ -200,6 +202,8 @@ def main():
 
         # ---- single-clip latency (configs[0] shape: one prompt, L=16), eager launches vs one hipGraph replay
         try:
+            if args.no_latency:
+                raise RuntimeError("skipped (--no-latency)")
             e1, m1, n1 = enc[:1, :16].contiguous(), mask[:1, :16].contiguous(), noise[:1].contiguous()
             m1[:] = True
             gen1 = pipe.capture_graph(1, 16, cfg_scale_input=4.0)

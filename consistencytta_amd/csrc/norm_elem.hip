@@ -185,29 +185,42 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 
 // Pass 2: fold chunks in double, emit per-(batch, channel) scale/shift:
 //   y = x*scale + shift,  scale = rstd*gamma, shift = beta - mean*rstd*gamma.
-__global__ void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int G, int C, int HW,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   float eps, float* __restrict__ scale_shift, float* __restrict__ stats) {
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int G, int C,
+                                                          int HW, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ scale_shift, float* __restrict__ stats) {
   const int b = blockIdx.x;
   const int cpg = C / G;
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+  // LPG lanes share a group: each folds every LPG-th chunk, then a butterfly (fixed order, so the
+  // result does not depend on the launch) leaves the total in all of them.
+  int LPG = 1;
+  if (G <= 128 && 256 % G == 0) LPG = min(64, 256 / G);
+  const int per_pass = 256 / LPG;
+  for (int g0 = 0; g0 < G; g0 += per_pass) {
+    const int g = g0 + (int)threadIdx.x / LPG, l = (int)threadIdx.x % LPG;
     double s = 0.0, q = 0.0;
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const float* pp = part + (((size_t)b * nchunk + ch) * G + g) * 2;
-      s += (double)pp[0];
-      q += (double)pp[1];
+    if (g < G)
+      for (int ch = l; ch < nchunk; ch += LPG) {
+        const float2 pp = *reinterpret_cast<const float2*>(part + (((size_t)b * nchunk + ch) * G + g) * 2);
+        s += (double)pp.x;
+        q += (double)pp.y;
+      }
+    for (int off = 1; off < LPG; off <<= 1) {
+      s += __shfl_xor(s, off);
+      q += __shfl_xor(q, off);
     }
+    if (g >= G) continue;
     const double n = (double)HW * cpg;
     const double mean = s / n;
     double var = q / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
     const float meanf = (float)mean;
-    if (stats) {   // training forward: (mean, rstd) per (sample, group) for the backward pass
+    if (stats && l == 0) {   // training forward: (mean, rstd) per (sample, group) for the backward pass
       stats[((size_t)b * G + g) * 2] = meanf;
       stats[((size_t)b * G + g) * 2 + 1] = rstd;
     }
-    for (int cc = 0; cc < cpg; ++cc) {
+    for (int cc = l; cc < cpg; cc += LPG) {
       const int c = g * cpg + cc;
       const float sc = rstd * gamma[c];
       scale_shift[((size_t)b * 2 + 0) * C + c] = sc;
@@ -284,7 +297,7 @@ extern "C" ctta_status ctta_groupnorm_stats_out(const void* x, void* y, int batc
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, batch), dim3(256), smem, s, (const bf16_t*)x, hw,
                      c, groups, ppc, nchunk, part);
   CTTA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(64), 0, s, part, nchunk, groups, c, hw,
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, part, nchunk, groups, c, hw,
                      gamma, beta, eps, ss, stats);
   CTTA_LAUNCH_CHECK();
   const long long total_vec = (long long)batch * hw * VC;

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Regenerates everything under profiles/ that a round's numbers come from.  Run on the GPU box from the repo root:
+#   gpurun --timeout 1500 -- 'bash tools/refresh_profiles.sh'
+# then copy gpurun_out/refresh/* into profiles/ (see profiles/README.md).
+set -u
+R=$PWD
+O=$R/gpurun_out/refresh
+rm -rf $O; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+python3 $R/bench.py > $O/bench.json 2> $O/bench.err
+rocprofv3 --kernel-trace --stats -d $O/prof_gen -o p -- python3 $R/bench.py --mode gen --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_gen.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/prof_distill -o p -- python3 $R/bench.py --mode distill --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_distill.log 2>&1
+for m in gen distill; do
+  db=$(find $O/prof_$m -name '*.db' | head -1)
+  [ -n "$db" ] && python3 $R/tools/rocpd_stats.py $db $O/rocprof_stats_$m.md > /dev/null
+done
+python3 $R/bench.py --mode gen --steps 3 --warmup 1 --no-cpu-baseline --profile-csv $O/launch_gen.csv > /dev/null 2>&1
+python3 $R/tools/launch_table.py $O/launch_gen.csv 60 2 > $O/launch_table_gen.txt 2>&1
+python3 $R/bench.py --mode distill --steps 3 --warmup 1 --no-cpu-baseline --profile-csv $O/launch_distill.csv > /dev/null 2>&1
+python3 $R/tools/launch_table.py $O/launch_distill.csv.distill 60 1 > $O/launch_table_distill.txt 2>&1
+timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_fetch.log 2>&1
+timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_write.log 2>&1
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/pmc_traffic.json 2> $O/pmc_traffic.err
+rm -rf $O/prof_gen $O/prof_distill $O/launch_gen.csv $O/launch_distill.csv $O/launch_distill.csv.distill
+find $O/pmc_fetch $O/pmc_write -type f ! -name '*counter_collection.csv' -delete 2>/dev/null
+du -sh $O
