@@ -41,7 +41,7 @@ class VAEConfig(Structure):
         ("z_channels", c_int), ("embed_dim", c_int), ("ch", c_int), ("out_ch", c_int),
         ("n_levels", c_int), ("num_res_blocks", c_int), ("ch_mult", c_int * MAX_LEVELS),
         ("scale_factor", c_float), ("max_batch", c_int), ("latent_h", c_int),
-        ("latent_w", c_int), ("debug_taps", c_int),
+        ("latent_w", c_int), ("debug_taps", c_int), ("enable_grad", c_int),
     ]
 
 
@@ -51,7 +51,7 @@ class HifiganConfig(Structure):
         ("n_kernels", c_int), ("upsample_rates", c_int * MAX_UPS),
         ("upsample_kernel_sizes", c_int * MAX_UPS), ("resblock_kernel_sizes", c_int * 4),
         ("resblock_dilations", (c_int * 3) * 4), ("max_batch", c_int), ("max_frames", c_int),
-        ("debug_taps", c_int),
+        ("debug_taps", c_int), ("enable_grad", c_int),
     ]
 
 
@@ -117,6 +117,8 @@ SIGNATURES = {
     "ctta_vae_create": (c_int, [POINTER(VAEConfig), POINTER(Tensor), c_int, c_void_p, POINTER(c_void_p)]),
     "ctta_vae_destroy": (None, [c_void_p]),
     "ctta_vae_decode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ctta_vae_decode_with_grad": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
+    "ctta_vae_decode_backward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "ctta_vae_arena_bytes": (c_size_t, [c_void_p]),
     "ctta_vae_num_taps": (c_int, [c_void_p]),
     "ctta_vae_tap_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),
@@ -125,6 +127,8 @@ SIGNATURES = {
     "ctta_hifigan_destroy": (None, [c_void_p]),
     "ctta_hifigan_out_len": (c_int64, [c_void_p, c_int]),
     "ctta_hifigan_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_hifigan_forward_with_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_hifigan_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ctta_wav_finalize": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ctta_hifigan_arena_bytes": (c_size_t, [c_void_p]),
     "ctta_hifigan_num_taps": (c_int, [c_void_p]),
@@ -167,6 +171,9 @@ SIGNATURES = {
     "ctta_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ctta_add_slices": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "ctta_zero_insert2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "ctta_lrelu_bwd": (c_int, [c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "ctta_conv_cout1_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                      c_void_p, c_float, c_void_p, c_void_p]),
     "ctta_pool2_sum": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_softmax_bias_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "ctta_softmax_bwd_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),

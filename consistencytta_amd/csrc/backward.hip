@@ -980,6 +980,95 @@ extern "C" ctta_status ctta_weighted_mse_grad(const float* pred, const float* ta
   return CTTA_OK;
 }
 
+// ------------------------------------------------------------------------------ vocoder / decoder input gradients
+// LeakyReLU backward with the residual stream folded in (ResBlock.forward, hifigan/models.py:56-63, in reverse):
+//   out (+)= res + alpha * g * (act > 0 ? 1 : slope)
+// `act` is the SAVED leaky_relu output (same sign as its argument since slope > 0).
+__global__ void lrelu_bwd_kernel(const uint4* __restrict__ g, const uint4* __restrict__ act, float slope, float alpha,
+                                 const uint4* __restrict__ res, uint4* __restrict__ out, long long nvec, int accumulate) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < nvec; i += (long long)gridDim.x * blockDim.x) {
+    float fg[8], fa[8], fo[8];
+    unpack8(g[i], fg);
+    unpack8(act[i], fa);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fo[e] = alpha * fg[e] * (fa[e] > 0.f ? 1.0f : slope);
+    if (res) {
+      float fr[8];
+      unpack8(res[i], fr);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fo[e] += fr[e];
+    }
+    if (accumulate) {
+      float fp[8];
+      unpack8(out[i], fp);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fo[e] += fp[e];
+    }
+    out[i] = pack8(fo);
+  }
+}
+extern "C" ctta_status ctta_lrelu_bwd(const void* g, const void* act, float slope, float alpha, const void* res, void* out,
+                                      int64_t n, int accumulate, void* stream) {
+  CTTA_REQUIRE(g && act && out && n % 8 == 0, "lrelu_bwd: bad arguments");
+  hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid1d(n / 8, 256, 8192)), dim3(256), 0, (hipStream_t)stream, (const uint4*)g,
+                     (const uint4*)act, slope, alpha, (const uint4*)res, (uint4*)out, (long long)(n / 8), accumulate);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// Data gradient of a single-output-channel convolution (the decoder's conv_out and the vocoder's conv_post):
+//   dx[b][y][x][c] = mask * sum_taps w[tap][c] * gy'[b][y - (a - pad_h)][x - (bq - pad_w)],
+// gy' = gy * (1 - yt^2) when yt (the tanh output) is given; mask = leaky_relu'(act) when act is given.
+__global__ void conv_cout1_dgrad_kernel(const float* __restrict__ gy, const float* __restrict__ yt,
+                                        const float* __restrict__ w, int B, int H, int W, int kh, int kw, int pad_h,
+                                        int pad_w, int C, const bf16_t* __restrict__ act, float slope,
+                                        bf16_t* __restrict__ dx) {
+  const int vc = C / 8;
+  const long long total = (long long)B * H * W * vc;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int v = (int)(idx % vc);
+    long long p = idx / vc;
+    const int x = (int)(p % W); p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int a = 0; a < kh; ++a) {
+      const int yy = y - (a - pad_h);
+      if (yy < 0 || yy >= H) continue;
+      for (int q = 0; q < kw; ++q) {
+        const int xx = x - (q - pad_w);
+        if (xx < 0 || xx >= W) continue;
+        const size_t o = ((size_t)b * H + yy) * W + xx;
+        float gv = gy[o];
+        if (yt) { const float t = yt[o]; gv *= 1.0f - t * t; }
+        const float* wr = w + (size_t)(a * kw + q) * C + v * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += wr[e] * gv;
+      }
+    }
+    if (act) {
+      float fa[8];
+      unpack8(*reinterpret_cast<const uint4*>(act + (size_t)idx * 8), fa);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] *= fa[e] > 0.f ? 1.0f : slope;
+    }
+    *reinterpret_cast<uint4*>(dx + (size_t)idx * 8) = pack8(acc);
+  }
+}
+extern "C" ctta_status ctta_conv_cout1_dgrad(const float* gy, const float* y_tanh, const float* w, int batch, int h, int wd,
+                                             int kh, int kw, int pad_h, int pad_w, int c, const void* act, float slope,
+                                             void* dx, void* stream) {
+  CTTA_REQUIRE(gy && w && dx && c % 8 == 0 && kh >= 1 && kw >= 1, "conv_cout1_dgrad: bad arguments");
+  const long long total = (long long)batch * h * wd * (c / 8);
+  hipLaunchKernelGGL(conv_cout1_dgrad_kernel, dim3(grid1d(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, gy,
+                     y_tanh, w, batch, h, wd, kh, kw, pad_h, pad_w, c, (const bf16_t*)act, slope, (bf16_t*)dx);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
 // ------------------------------------------------------------------------------ AdamW (torch.optim.AdamW, no amsgrad)
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, long long n, float lr, float beta1, float beta2, float eps, float wd,

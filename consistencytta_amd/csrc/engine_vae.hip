@@ -64,12 +64,22 @@ struct VaeRes {
   GNLayer n1, n2;
   ConvLayer c1, c2, sc;
   bool has_sc = false;
+  // enable_grad: data-gradient operands and what the differentiable forward keeps for the backward
+  ConvLayer d1, d2, dsc;
+  struct Saved { const bf16_t* x = nullptr; bf16_t* t1 = nullptr; float *st1 = nullptr, *st2 = nullptr; int H = 0, W = 0; } sv;
 };
 
 struct VaeAttn {   // AttnBlock (modules.py:178-230): single head over H*W tokens, d = C
   GNLayer norm;
   ConvLayer q, k, v, proj;
   int C = 0;
+  ConvLayer dq, dk, dv, dproj;
+  struct Saved {
+    const bf16_t* x = nullptr;
+    bf16_t *q = nullptr, *k = nullptr, *vt = nullptr, *p = nullptr;
+    float* st = nullptr;
+    int H = 0, W = 0;
+  } sv;
 };
 
 struct ctta_vae {
@@ -88,23 +98,31 @@ struct ctta_vae {
   int block_in = 0, c_last = 0;
   float* gn_scratch = nullptr;
   size_t gn_scratch_floats = 0;
+  // enable_grad (CLAPLoss's differentiable decode, tools/losses.py:294-296)
+  ConvLayer d_conv_in;
+  std::vector<ConvLayer> d_upsample;
+  float* out_w = nullptr;                  // conv_out weight as fp32 [tap][C]
+  struct Saved { const bf16_t* h_last = nullptr; float* st_out = nullptr; int B = 0; } sv;
 };
 
 struct VCtx : RunCtx {
   int B;
   size_t gn_need = 0;
+  bool grad = false;   // differentiable forward: keep what vae_backward_impl reads
 };
 
 static const int kVaeGroups = 32;    // Normalize(): GroupNorm(32, eps=1e-6)  modules.py:38-41
 static const float kVaeEps = 1e-6f;
 
-static ctta_status vgn(VCtx& c, const GNLayer& g, const bf16_t* x, bf16_t* y, int hw, bool silu) {
+static ctta_status vgn(VCtx& c, const GNLayer& g, const bf16_t* x, bf16_t* y, int hw, bool silu, float* stats = nullptr) {
   const size_t need = ctta_groupnorm_scratch_floats(c.B, hw, g.c, kVaeGroups);
   if (need > c.gn_need) c.gn_need = need;
-  return run_gn(c, g, x, y, c.B, hw, kVaeGroups, kVaeEps, silu);
+  return run_gn(c, g, x, y, c.B, hw, kVaeGroups, kVaeEps, silu, stats);
 }
+// (mean, rstd) per (sample, group) kept for the backward
+static float* stats_buf(VCtx& c) { return c.grad ? c.arena->get<float>((size_t)c.B * kVaeGroups * 2) : nullptr; }
 
-static ctta_status make_vae_res(WeightStore& ws, const std::string& p, int cin, int cout, VaeRes* R) {
+static ctta_status make_vae_res(WeightStore& ws, const std::string& p, int cin, int cout, VaeRes* R, bool grad = false) {
   R->cin = cin; R->cout = cout;
   CTTA_TRY(make_gn(ws, p + "norm1.", cin, &R->n1));
   CTTA_TRY(make_conv(ws, p + "conv1.", cout, cin, cin, 3, 3, 1, 1, &R->c1));
@@ -112,20 +130,33 @@ static ctta_status make_vae_res(WeightStore& ws, const std::string& p, int cin, 
   CTTA_TRY(make_conv(ws, p + "conv2.", cout, cout, cout, 3, 3, 1, 1, &R->c2));
   R->has_sc = cin != cout;
   if (R->has_sc) CTTA_TRY(make_conv(ws, p + "nin_shortcut.", cout, cin, cin, 1, 1, 1, 0, &R->sc));
+  if (grad) {
+    CTTA_TRY(make_conv_dgrad_from(ws, R->c1, cout, cin, &R->d1));
+    CTTA_TRY(make_conv_dgrad_from(ws, R->c2, cout, cout, &R->d2));
+    if (R->has_sc) CTTA_TRY(make_conv_dgrad_from(ws, R->sc, cout, cin, &R->dsc));
+  }
   return CTTA_OK;
 }
 
-static ctta_status run_vae_res(VCtx& c, const VaeRes& R, const bf16_t* x, int H, int W, bf16_t** out_p) {
+static ctta_status run_vae_res(VCtx& c, VaeRes& R, const bf16_t* x, int H, int W, bf16_t** out_p) {
   Arena& A = *c.arena;
   const size_t M = (size_t)c.B * H * W;
   bf16_t* out = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(out);
+  bf16_t* t1 = nullptr;
+  float *st1 = nullptr, *st2 = nullptr;
+  if (c.grad) {   // conv1's output and both norms' statistics outlive the block
+    t1 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(t1);
+    st1 = stats_buf(c); ALLOC_OR_FAIL(st1);
+    st2 = stats_buf(c); ALLOC_OR_FAIL(st2);
+    R.sv.x = x; R.sv.t1 = t1; R.sv.st1 = st1; R.sv.st2 = st2; R.sv.H = H; R.sv.W = W;
+  }
   const size_t mk = A.mark();
   bf16_t* a = A.get<bf16_t>(M * R.cin); ALLOC_OR_FAIL(a);
-  CTTA_TRY(vgn(c, R.n1, x, a, H * W, true));
-  bf16_t* t1 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(t1);
+  CTTA_TRY(vgn(c, R.n1, x, a, H * W, true, st1));
+  if (!t1) { t1 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(t1); }
   CTTA_TRY(run_conv2d(c, R.c1, a, c.B, H, W, false, t1, nullptr, 0, nullptr, 0));
   bf16_t* a2 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(a2);
-  CTTA_TRY(vgn(c, R.n2, t1, a2, H * W, true));
+  CTTA_TRY(vgn(c, R.n2, t1, a2, H * W, true, st2));
   const bf16_t* res = x;
   if (R.has_sc) {
     bf16_t* r = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(r);
@@ -141,30 +172,46 @@ static ctta_status run_vae_res(VCtx& c, const VaeRes& R, const bf16_t* x, int H,
 // AttnBlock: single head over N = H*W tokens, d = C.  Scores are materialised in fp32
 // (B x N x N; 2 GiB at B=32, N=4096 -- 288 GB of HBM makes this the simple choice), softmaxed
 // to bf16, and multiplied by V^T; all three products run on conv_gemm.
-static ctta_status make_vae_attn(WeightStore& ws, const std::string& p, int C, VaeAttn* T) {
+static ctta_status make_vae_attn(WeightStore& ws, const std::string& p, int C, VaeAttn* T, bool grad = false) {
   T->C = C;
   CTTA_TRY(make_gn(ws, p + "norm.", C, &T->norm));
   CTTA_TRY(make_conv(ws, p + "q.", C, C, C, 1, 1, 1, 0, &T->q));
   CTTA_TRY(make_conv(ws, p + "k.", C, C, C, 1, 1, 1, 0, &T->k));
   CTTA_TRY(make_conv(ws, p + "v.", C, C, C, 1, 1, 1, 0, &T->v));
   CTTA_TRY(make_conv(ws, p + "proj_out.", C, C, C, 1, 1, 1, 0, &T->proj));
+  if (grad) {
+    CTTA_TRY(make_conv_dgrad_from(ws, T->q, C, C, &T->dq));
+    CTTA_TRY(make_conv_dgrad_from(ws, T->k, C, C, &T->dk));
+    CTTA_TRY(make_conv_dgrad_from(ws, T->v, C, C, &T->dv));
+    CTTA_TRY(make_conv_dgrad_from(ws, T->proj, C, C, &T->dproj));
+  }
   return CTTA_OK;
 }
 
-static ctta_status run_vae_attn(VCtx& c, const VaeAttn* V, const bf16_t* x, int H, int W, bf16_t** out_p) {
+static ctta_status run_vae_attn(VCtx& c, VaeAttn* V, const bf16_t* x, int H, int W, bf16_t** out_p) {
   Arena& A = *c.arena;
   const int N = H * W, C = V->C, B = c.B;
   CTTA_REQUIRE(N % 64 == 0 && C % 64 == 0, "vae attention: tokens=%d and channels=%d must be multiples of 64", N, C);
   const size_t M = (size_t)B * N;
   bf16_t* out = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(out);
+  bf16_t *q = nullptr, *k = nullptr, *vt = nullptr, *p = nullptr;
+  float* st = nullptr;
+  if (c.grad) {   // q, k, V^T, the probabilities and the norm statistics outlive the block
+    q = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(q);
+    k = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(k);
+    vt = A.get<bf16_t>((size_t)B * C * N); ALLOC_OR_FAIL(vt);
+    p = A.get<bf16_t>((size_t)B * N * N); ALLOC_OR_FAIL(p);
+    st = stats_buf(c); ALLOC_OR_FAIL(st);
+    V->sv.x = x; V->sv.q = q; V->sv.k = k; V->sv.vt = vt; V->sv.p = p; V->sv.st = st; V->sv.H = H; V->sv.W = W;
+  }
   const size_t mk = A.mark();
   bf16_t* g = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(g);
-  CTTA_TRY(vgn(c, V->norm, x, g, N, false));
-  bf16_t* q = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(q);
-  bf16_t* k = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(k);
+  CTTA_TRY(vgn(c, V->norm, x, g, N, false, st));
+  if (!q) { q = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(q); }
+  if (!k) { k = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(k); }
   CTTA_TRY(run_conv2d(c, V->q, g, B, H, W, false, q, nullptr, 0, nullptr, 0));
   CTTA_TRY(run_conv2d(c, V->k, g, B, H, W, false, k, nullptr, 0, nullptr, 0));
-  bf16_t* vt = A.get<bf16_t>((size_t)B * C * N); ALLOC_OR_FAIL(vt);
+  if (!vt) { vt = A.get<bf16_t>((size_t)B * C * N); ALLOC_OR_FAIL(vt); }
   {
     ctta_conv_desc d;
     desc_init(&d);
@@ -188,7 +235,7 @@ static ctta_status run_vae_attn(VCtx& c, const VaeAttn* V, const bf16_t* x, int 
     d.out_group_stride = (int64_t)N * N;
     RUN(c, ctta_conv_gemm(&d, c.stream));
   }
-  bf16_t* p = A.get<bf16_t>((size_t)B * N * N); ALLOC_OR_FAIL(p);
+  if (!p) { p = A.get<bf16_t>((size_t)B * N * N); ALLOC_OR_FAIL(p); }
   RUN(c, ctta_softmax_rows(s, p, (int64_t)B * N, N, 1.0f / sqrtf((float)C), c.stream));
   bf16_t* o = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(o);
   {
@@ -209,13 +256,15 @@ static ctta_status run_vae_attn(VCtx& c, const VaeAttn* V, const bf16_t* x, int 
 }
 
 static ctta_status vae_forward_impl(ctta_vae* V, bool dry, const float* z, int B, float* mel, hipStream_t stream,
-                                    size_t* gn_need) {
+                                    size_t* gn_need, bool grad = false) {
   const ctta_vae_config& cfg = V->cfg;
   VCtx c;
   c.arena = &V->arena; c.stream = stream; c.dry = dry;
   c.taps = cfg.debug_taps ? &V->taps : nullptr;
   c.gn_scratch = V->gn_scratch; c.gn_scratch_floats = V->gn_scratch_floats;
   c.B = B;
+  c.grad = grad;
+  V->sv.B = grad ? B : 0;
   Arena& A = V->arena;
   A.reset();
   int H = cfg.latent_h, W = cfg.latent_w;
@@ -250,8 +299,9 @@ static ctta_status vae_forward_impl(ctta_vae* V, bool dry, const float* z, int B
       add_tap(c, "up." + std::to_string(lvl) + ".upsample", h, B, ch, H, W, ch);
     }
   }
+  if (grad) { V->sv.h_last = h; V->sv.st_out = stats_buf(c); ALLOC_OR_FAIL(V->sv.st_out); }
   bf16_t* a = A.get<bf16_t>((size_t)B * H * W * ch); ALLOC_OR_FAIL(a);
-  CTTA_TRY(vgn(c, V->norm_out, h, a, H * W, true));
+  CTTA_TRY(vgn(c, V->norm_out, h, a, H * W, true, grad ? V->sv.st_out : nullptr));
   {  // conv_out (Cout = out_ch = 1): MFMA kernel with element-wise fp32 stores; NCHW with C=1 == [m]
     ctta_conv_desc d;
     desc_init(&d);
@@ -266,6 +316,172 @@ static ctta_status vae_forward_impl(ctta_vae* V, bool dry, const float* z, int B
   return CTTA_OK;
 }
 
+// ------------------------------------------------------------------------------ decoder input gradient
+// d mel / d z for a frozen decoder (CLAPLoss back-propagates the waveform loss into the student's latent,
+// tools/losses.py:294-298): the differentiable forward's saved tensors are replayed in reverse with data-gradient
+// convolutions (conv_gemm against the rotated / transposed packs) and the GroupNorm / softmax backward kernels.
+__global__ void post_quant_bwd_kernel(const bf16_t* __restrict__ dzin, int ld, const float* __restrict__ w,
+                                      float inv_scale, int B, int zin, int zout, int HW, float* __restrict__ gz) {
+  const long long total = (long long)B * HW;
+  const long long pix = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (pix >= total) return;
+  const int bb = (int)(pix / HW);
+  const int hw = (int)(pix - (long long)bb * HW);
+  float d[32];
+  for (int o = 0; o < zout; ++o) d[o] = bf2f(dzin[(size_t)pix * ld + o]);
+  for (int e = 0; e < zin; ++e) {
+    float acc = 0.f;
+    for (int o = 0; o < zout; ++o) acc += w[o * zin + e] * d[o];
+    gz[((size_t)bb * zin + e) * HW + hw] = acc * inv_scale;
+  }
+}
+
+static ctta_status vconv_dgrad(VCtx& c, const ConvLayer& D, const bf16_t* dy, int H, int W, bf16_t* dx, bool accumulate) {
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = dy; d.c0 = D.cin_pad;
+  d.batch = c.B; d.hi = H; d.wi = W; d.ho = H; d.wo = W;
+  d.kh = D.kh; d.kw = D.kw; d.pad_h = d.pad_w = D.pad;
+  d.w = D.p.w; d.k_pad = D.p.k_pad; d.n = D.p.n;
+  d.out = dx; d.ldc = D.cout; d.accumulate = accumulate ? 1 : 0;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  return CTTA_OK;
+}
+
+static ctta_status vgn_bwd(VCtx& c, const GNLayer& g, const bf16_t* x, const bf16_t* dy, bf16_t* dx, int hw,
+                           const float* stats, bool silu, bool accumulate_dx) {
+  const size_t need = ctta_groupnorm_bwd_scratch_floats(c.B, hw, g.c, kVaeGroups);
+  if (need > c.gn_need) c.gn_need = need;
+  if (!c.dry && need > c.gn_scratch_floats) { ctta_set_error("groupnorm backward scratch too small"); return CTTA_ERR_INVALID; }
+  RUN(c, ctta_groupnorm_bwd(x, dy, dx, c.B, hw, g.c, kVaeGroups, stats, g.gamma, g.beta, silu ? 1 : 0,
+                            accumulate_dx ? 1 : 0, nullptr, nullptr, 0, c.gn_scratch, c.stream));
+  return CTTA_OK;
+}
+
+// out = conv2(silu(gn2(t1))) + shortcut(x), t1 = conv1(silu(gn1(x)))   (ResnetBlock.forward modules.py:155-175)
+static ctta_status bwd_vae_res(VCtx& c, const VaeRes& R, const bf16_t* dout, bf16_t** dx_p) {
+  Arena& A = *c.arena;
+  const int H = R.sv.H, W = R.sv.W;
+  const size_t M = (size_t)c.B * H * W;
+  bf16_t* dx = A.get<bf16_t>(M * R.cin); ALLOC_OR_FAIL(dx);
+  const size_t mk = A.mark();
+  bf16_t* da2 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(da2);
+  CTTA_TRY(vconv_dgrad(c, R.d2, dout, H, W, da2, false));
+  bf16_t* dt1 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(dt1);
+  CTTA_TRY(vgn_bwd(c, R.n2, R.sv.t1, da2, dt1, H * W, R.sv.st2, true, false));
+  bf16_t* da = A.get<bf16_t>(M * R.cin); ALLOC_OR_FAIL(da);
+  CTTA_TRY(vconv_dgrad(c, R.d1, dt1, H, W, da, false));
+  if (R.has_sc) CTTA_TRY(vconv_dgrad(c, R.dsc, dout, H, W, dx, false));
+  else RUN(c, ctta_add_slices(dout, R.cout, nullptr, 0, dx, R.cin, (int64_t)M, R.cin, c.stream));
+  CTTA_TRY(vgn_bwd(c, R.n1, R.sv.x, da, dx, H * W, R.sv.st1, true, true));
+  A.release(mk);
+  *dx_p = dx;
+  return CTTA_OK;
+}
+
+// batched GEMM helper: out[g][m][n] = sum_k X[g][m][k] * Wt[g][n][k]
+static ctta_status bgemm(VCtx& c, const bf16_t* x, int64_t xs, const bf16_t* w, int64_t wst, int Mr, int Nn, int K,
+                         void* out, int64_t os, int ldc, bool f32) {
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = x; d.c0 = K;
+  d.batch = 1; d.hi = Mr; d.wi = 1; d.ho = Mr; d.wo = 1;
+  d.w = w; d.k_pad = K; d.n = Nn;
+  d.out = out; d.ldc = ldc; d.out_f32 = f32 ? 1 : 0;
+  d.groups = c.B; d.x_group_stride = xs; d.w_group_stride = wst; d.out_group_stride = os;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  return CTTA_OK;
+}
+
+// AttnBlock.forward (modules.py:204-230) in reverse.  With P = softmax(q k^T / sqrt(C)) saved:
+//   dO = proj^T dout;  dP = dO V^T;  dS = P (dP - rowsum(P dP)) / sqrt(C);  dq = dS k;  dk = dS^T q;  dV = P^T dO;
+//   d norm(x) = Wq^T dq + Wk^T dk + Wv^T dV;  dx = dout + GroupNorm backward.
+static ctta_status bwd_vae_attn(VCtx& c, const VaeAttn& T, const bf16_t* dout, bf16_t** dx_p) {
+  Arena& A = *c.arena;
+  const int H = T.sv.H, W = T.sv.W, N = H * W, C = T.C, B = c.B;
+  const size_t M = (size_t)B * N;
+  const int64_t NC = (int64_t)N * C, NN = (int64_t)N * N;
+  bf16_t* dx = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(dx);
+  const size_t mk = A.mark();
+  bf16_t* dO = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(dO);
+  CTTA_TRY(vconv_dgrad(c, T.dproj, dout, H, W, dO, false));
+  bf16_t* vn = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(vn);     // V   [B][N][C]
+  bf16_t* kt = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(kt);     // K^T [B][C][N]
+  bf16_t* qt = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(qt);     // Q^T
+  bf16_t* dOt = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(dOt);   // dO^T
+  RUN(c, ctta_transpose_bf16(T.sv.vt, NC, C, N, N, 0, vn, NC, C, B, c.stream));
+  RUN(c, ctta_transpose_bf16(T.sv.k, NC, N, C, C, 0, kt, NC, N, B, c.stream));
+  RUN(c, ctta_transpose_bf16(T.sv.q, NC, N, C, C, 0, qt, NC, N, B, c.stream));
+  RUN(c, ctta_transpose_bf16(dO, NC, N, C, C, 0, dOt, NC, N, B, c.stream));
+  float* dP = A.get<float>((size_t)B * NN); ALLOC_OR_FAIL(dP);
+  CTTA_TRY(bgemm(c, dO, NC, vn, NC, N, N, C, dP, NN, N, true));
+  bf16_t* dS = A.get<bf16_t>((size_t)B * NN); ALLOC_OR_FAIL(dS);
+  RUN(c, ctta_softmax_bwd_rows(T.sv.p, dP, N, dS, (int64_t)B * N, N, N, 1.0f / sqrtf((float)C), c.stream));
+  bf16_t* dq = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(dq);
+  bf16_t* dk = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(dk);
+  bf16_t* dv = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(dv);
+  CTTA_TRY(bgemm(c, dS, NN, kt, NC, N, C, N, dq, NC, C, false));
+  bf16_t* tt = reinterpret_cast<bf16_t*>(dP);               // dP is dead: its space holds dS^T, then P^T
+  RUN(c, ctta_transpose_bf16(dS, NN, N, N, N, 0, tt, NN, N, B, c.stream));
+  CTTA_TRY(bgemm(c, tt, NN, qt, NC, N, C, N, dk, NC, C, false));
+  RUN(c, ctta_transpose_bf16(T.sv.p, NN, N, N, N, 0, tt, NN, N, B, c.stream));
+  CTTA_TRY(bgemm(c, tt, NN, dOt, NC, N, C, N, dv, NC, C, false));
+  bf16_t* dg = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(dg);
+  CTTA_TRY(vconv_dgrad(c, T.dq, dq, H, W, dg, false));
+  CTTA_TRY(vconv_dgrad(c, T.dk, dk, H, W, dg, true));
+  CTTA_TRY(vconv_dgrad(c, T.dv, dv, H, W, dg, true));
+  RUN(c, ctta_add_slices(dout, C, nullptr, 0, dx, C, (int64_t)M, C, c.stream));
+  CTTA_TRY(vgn_bwd(c, T.norm, T.sv.x, dg, dx, N, T.sv.st, false, true));
+  A.release(mk);
+  *dx_p = dx;
+  return CTTA_OK;
+}
+
+static ctta_status vae_backward_impl(ctta_vae* V, bool dry, const float* gmel, int B, float* gz, hipStream_t stream,
+                                     size_t* gn_need) {
+  const ctta_vae_config& cfg = V->cfg;
+  VCtx c;
+  c.arena = &V->arena; c.stream = stream; c.dry = dry;
+  c.taps = nullptr;
+  c.gn_scratch = V->gn_scratch; c.gn_scratch_floats = V->gn_scratch_floats;
+  c.B = B;
+  Arena& A = V->arena;   // continues above the differentiable forward's saved tensors
+  const int up = 1 << (cfg.n_levels - 1);
+  int H = cfg.latent_h * up, W = cfg.latent_w * up, ch = V->c_last;
+  bf16_t* da = A.get<bf16_t>((size_t)B * H * W * ch); ALLOC_OR_FAIL(da);
+  RUN(c, ctta_conv_cout1_dgrad(gmel, nullptr, V->out_w, B, H, W, 3, 3, 1, 1, ch, nullptr, 0.f, da, stream));
+  bf16_t* dh = A.get<bf16_t>((size_t)B * H * W * ch); ALLOC_OR_FAIL(dh);
+  CTTA_TRY(vgn_bwd(c, V->norm_out, V->sv.h_last, da, dh, H * W, V->sv.st_out, true, false));
+  for (int lvl = 0; lvl < cfg.n_levels; ++lvl) {
+    if (lvl != 0) {   // u = conv(nearest x2 (h)): data gradient at the fine resolution, then the 2x2 sum
+      bf16_t* du = A.get<bf16_t>((size_t)B * H * W * ch); ALLOC_OR_FAIL(du);
+      CTTA_TRY(vconv_dgrad(c, V->d_upsample[lvl], dh, H, W, du, false));
+      H /= 2; W /= 2;
+      bf16_t* dl = A.get<bf16_t>((size_t)B * H * W * ch); ALLOC_OR_FAIL(dl);
+      RUN(c, ctta_pool2_sum(du, dl, B, H, W, ch, 0, stream));
+      dh = dl;
+    }
+    for (int b = (int)V->up[lvl].size() - 1; b >= 0; --b) {
+      CTTA_TRY(bwd_vae_res(c, V->up[lvl][b], dh, &dh));
+      ch = V->up[lvl][b].cin;
+    }
+  }
+  CTTA_TRY(bwd_vae_res(c, V->mid2, dh, &dh));
+  CTTA_TRY(bwd_vae_attn(c, V->attn, dh, &dh));
+  CTTA_TRY(bwd_vae_res(c, V->mid1, dh, &dh));
+  const int zc = V->d_conv_in.cout;
+  bf16_t* dzin = A.get<bf16_t>((size_t)B * H * W * zc); ALLOC_OR_FAIL(dzin);
+  CTTA_TRY(vconv_dgrad(c, V->d_conv_in, dh, H, W, dzin, false));
+  if (!dry) {
+    const long long total = (long long)B * H * W;
+    hipLaunchKernelGGL(post_quant_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, dzin, zc,
+                       V->pq_w, 1.0f / cfg.scale_factor, B, cfg.embed_dim, cfg.z_channels, H * W, gz);
+    CTTA_LAUNCH_CHECK();
+  }
+  if (gn_need && c.gn_need > *gn_need) *gn_need = c.gn_need;
+  return CTTA_OK;
+}
+
 static ctta_status vae_build(ctta_vae* V) {
   const ctta_vae_config& cfg = V->cfg;
   WeightStore& ws = V->store;
@@ -275,27 +491,33 @@ static ctta_status vae_build(ctta_vae* V) {
   CTTA_TRY(ws.add_vector("post_quant_conv.weight", cfg.z_channels * cfg.embed_dim, &V->pq_w));
   CTTA_TRY(ws.add_vector("post_quant_conv.bias", cfg.z_channels, &V->pq_b));
   const std::string p = "decoder.";
+  const bool grad = cfg.enable_grad != 0;
   CTTA_TRY(make_conv(ws, p + "conv_in.", block_in, cfg.z_channels, 32, 3, 3, 1, 1, &V->conv_in));
-  CTTA_TRY(make_vae_res(ws, p + "mid.block_1.", block_in, block_in, &V->mid1));
-  CTTA_TRY(make_vae_attn(ws, p + "mid.attn_1.", block_in, &V->attn));
-  CTTA_TRY(make_vae_res(ws, p + "mid.block_2.", block_in, block_in, &V->mid2));
+  if (grad) CTTA_TRY(make_conv_dgrad_from(ws, V->conv_in, block_in, cfg.z_channels, &V->d_conv_in));
+  CTTA_TRY(make_vae_res(ws, p + "mid.block_1.", block_in, block_in, &V->mid1, grad));
+  CTTA_TRY(make_vae_attn(ws, p + "mid.attn_1.", block_in, &V->attn, grad));
+  CTTA_TRY(make_vae_res(ws, p + "mid.block_2.", block_in, block_in, &V->mid2, grad));
   V->up.resize(nres);
   V->upsample.resize(nres);
+  V->d_upsample.resize(nres);
   for (int lvl = nres - 1; lvl >= 0; --lvl) {
     const int block_out = cfg.ch * cfg.ch_mult[lvl];
     V->up[lvl].resize(cfg.num_res_blocks + 1);
     for (int b = 0; b <= cfg.num_res_blocks; ++b) {
       CTTA_TRY(make_vae_res(ws, p + "up." + std::to_string(lvl) + ".block." + std::to_string(b) + ".", block_in,
-                            block_out, &V->up[lvl][b]));
+                            block_out, &V->up[lvl][b], grad));
       block_in = block_out;
     }
-    if (lvl != 0)
+    if (lvl != 0) {
       CTTA_TRY(make_conv(ws, p + "up." + std::to_string(lvl) + ".upsample.conv.", block_in, block_in, block_in, 3, 3, 1,
                          1, &V->upsample[lvl]));
+      if (grad) CTTA_TRY(make_conv_dgrad_from(ws, V->upsample[lvl], block_in, block_in, &V->d_upsample[lvl]));
+    }
   }
   V->c_last = block_in;
   CTTA_TRY(make_gn(ws, p + "norm_out.", block_in, &V->norm_out));
   CTTA_TRY(make_conv(ws, p + "conv_out.", cfg.out_ch, block_in, block_in, 3, 3, 1, 1, &V->conv_out));
+  if (grad) CTTA_TRY(add_small_conv_w(ws, p + "conv_out.weight", 1, block_in, 9, &V->out_w));
   return CTTA_OK;
 }
 
@@ -310,7 +532,9 @@ extern "C" ctta_status ctta_vae_create(const ctta_vae_config* cfg, const ctta_te
   hipStream_t s = (hipStream_t)stream;
   ctta_vae* V = new ctta_vae();
   V->cfg = *cfg;
-  ctta_status st = V->store.init(estimate_store_bytes(weights, n_weights));
+  CTTA_REQUIRE(!cfg->enable_grad || cfg->z_channels % 8 == 0, "vae_create: enable_grad needs z_channels %% 8 == 0");
+  ctta_status st = V->store.init(cfg->enable_grad ? estimate_store_bytes_training(weights, n_weights)
+                                                  : estimate_store_bytes(weights, n_weights));
   if (st != CTTA_OK) { delete V; return st; }
   WeightTable wt;
   wt.build(weights, n_weights);
@@ -321,6 +545,10 @@ extern "C" ctta_status ctta_vae_create(const ctta_vae_config* cfg, const ctta_te
     V->arena.dry = true;
     V->arena.no_release = cfg->debug_taps != 0;
     st = vae_forward_impl(V, true, nullptr, cfg->max_batch, nullptr, s, &gn_need);
+    if (st == CTTA_OK && cfg->enable_grad) {   // the differentiable forward keeps more, and the backward runs on top
+      st = vae_forward_impl(V, true, nullptr, cfg->max_batch, nullptr, s, &gn_need, true);
+      if (st == CTTA_OK) st = vae_backward_impl(V, true, nullptr, cfg->max_batch, nullptr, s, &gn_need);
+    }
   }
   if (st == CTTA_OK) {
     const size_t bytes = V->arena.peak + (1 << 20);
@@ -352,6 +580,22 @@ extern "C" ctta_status ctta_vae_decode(ctta_vae* V, const float* z, int batch, f
   CTTA_REQUIRE(V && z && mel, "vae_decode: null pointer");
   CTTA_REQUIRE(batch >= 1 && batch <= V->cfg.max_batch, "vae_decode: batch %d outside [1,%d]", batch, V->cfg.max_batch);
   return vae_forward_impl(V, false, z, batch, mel, (hipStream_t)stream, nullptr);
+}
+
+extern "C" ctta_status ctta_vae_decode_with_grad(ctta_vae* V, const float* z, int batch, float* mel, void* stream) {
+  CTTA_REQUIRE(V && z && mel, "vae_decode_with_grad: null pointer");
+  CTTA_REQUIRE(V->cfg.enable_grad, "vae_decode_with_grad: the handle was created without enable_grad");
+  CTTA_REQUIRE(batch >= 1 && batch <= V->cfg.max_batch, "vae_decode_with_grad: batch %d outside [1,%d]", batch,
+               V->cfg.max_batch);
+  return vae_forward_impl(V, false, z, batch, mel, (hipStream_t)stream, nullptr, true);
+}
+extern "C" ctta_status ctta_vae_decode_backward(ctta_vae* V, const float* grad_mel, int batch, float* grad_z, void* stream) {
+  CTTA_REQUIRE(V && grad_mel && grad_z, "vae_decode_backward: null pointer");
+  CTTA_REQUIRE(V->cfg.enable_grad && V->sv.B == batch,
+               "vae_decode_backward: no differentiable forward of batch %d is pending on this handle", batch);
+  const ctta_status st = vae_backward_impl(V, false, grad_mel, batch, grad_z, (hipStream_t)stream, nullptr);
+  V->sv.B = 0;   // the saved tensors are consumed (the backward's temporaries overwrote the arena above them)
+  return st;
 }
 
 extern "C" size_t ctta_vae_arena_bytes(const ctta_vae* V) { return V ? V->arena.cap + V->store.arena.cap : 0; }
@@ -587,6 +831,9 @@ struct ConvT1d {
 };
 struct HResBlock {
   Conv1d c1[3], c2[3];
+  Conv1d d1[3], d2[3];                       // enable_grad: data-gradient operands
+  const bf16_t* sv_xt[3] = {nullptr, nullptr, nullptr};    // leaky_relu(convs1[m](.)) of the differentiable forward
+  const bf16_t* sv_ract[3] = {nullptr, nullptr, nullptr};  // leaky_relu of the residual stream entering unit m
 };
 
 struct ctta_hifigan {
@@ -599,6 +846,15 @@ struct ctta_hifigan {
   std::vector<HResBlock> res;   // [n_ups * n_kernels]
   float *post_w = nullptr, *post_b = nullptr;
   int c_last = 0;
+  // enable_grad (decode_to_waveform(allow_grad=True), hifigan/utilities.py:79-81)
+  Conv1d d_pre;
+  std::vector<Conv1d> d_ups;                 // strided convolutions: the ConvTranspose1d data gradients
+  struct Saved {
+    const bf16_t* xa0 = nullptr;             // leaky_relu(conv_pre(mel))
+    std::vector<const bf16_t*> xa_out;       // per stage: leaky_relu(sum_j resblock_j / n_kernels)
+    std::vector<int> len;                    // per stage: output length
+    int B = 0, frames = 0;
+  } sv;
 };
 
 static ctta_status make_conv1d(WeightStore& ws, const std::string& p, int cout, int cin, int k, int dil, Conv1d* L) {
@@ -634,6 +890,28 @@ static ctta_status make_convt1d(WeightStore& ws, const std::string& p, int cin, 
   CTTA_TRY(ws.add_vector(p + "bias", cout, n, segs, &L->p.bias));
   L->p.n = n; L->p.k_pad = k_pad;
   L->cin = cin; L->cout = cout; L->k = k; L->u = u; L->pad = (k - u) / 2; L->taps = taps;
+  return CTTA_OK;
+}
+
+// Data-gradient operands.  Conv1d ("same" padding, dilation d): dX = conv(dY, taps reversed, channels swapped), same
+// dilation, padding (k-1)d - pad = pad; built as bf16 transposes of the forward pack.  ConvTranspose1d(stride u):
+// dX[q][ci] = sum_{k,co} dY[q*u - pad + k][co] W[ci][co][k], a stride-u convolution over dY.
+static ctta_status make_conv1d_dgrad(WeightStore& ws, const Conv1d& F, Conv1d* D) {
+  ConvLayer f, d;
+  f.p = F.p; f.cin_pad = F.cin; f.cout = F.cout; f.kh = 1; f.kw = F.k; f.pad = 0;
+  CTTA_TRY(make_conv_dgrad_from(ws, f, F.cout, F.cin, &d));
+  D->p = d.p; D->cin = F.cout; D->cout = F.cin; D->k = F.k; D->dil = F.dil; D->pad = (F.k - 1) * F.dil - F.pad;
+  return CTTA_OK;
+}
+static ctta_status make_convt1d_dgrad(WeightStore& ws, const std::string& p, const ConvT1d& F, Conv1d* D) {
+  const int K = F.k * F.cout, k_pad = round_up(K, 64), n_pad = round_up(F.cin, 4);
+  std::vector<int32_t> ro(n_pad, -1), co(k_pad, -1);
+  for (int ci = 0; ci < F.cin; ++ci) ro[ci] = ci * F.cout * F.k;
+  for (int kk = 0; kk < F.k; ++kk)
+    for (int o = 0; o < F.cout; ++o) co[kk * F.cout + o] = o * F.k + kk;
+  CTTA_TRY(ws.add_matrix(p + "weight", {F.cin, F.cout, F.k}, ro, co, nullptr, nullptr, 0, &D->p.w));
+  D->p.bias = nullptr; D->p.n = n_pad; D->p.k_pad = k_pad;
+  D->cin = F.cout; D->cout = F.cin; D->k = F.k; D->dil = F.u /* stride */; D->pad = F.pad;
   return CTTA_OK;
 }
 
@@ -693,7 +971,7 @@ extern "C" int64_t ctta_hifigan_out_len(const ctta_hifigan* G, int frames) {
 }
 
 static ctta_status hifigan_forward_impl(ctta_hifigan* G, bool dry, const float* mel, int B, int frames, float* wav,
-                                        hipStream_t stream) {
+                                        hipStream_t stream, bool grad = false) {
   const ctta_hifigan_config& cfg = G->cfg;
   RunCtx c;
   c.arena = &G->arena; c.stream = stream; c.dry = dry;
@@ -712,6 +990,12 @@ static ctta_status hifigan_forward_impl(ctta_hifigan* G, bool dry, const float* 
     CTTA_TRY(run_conv1d(c, G->conv_pre, m, B, len, xa, nullptr, false, 1.0f, oa));
   }
   add_tap(c, "lrelu.conv_pre", xa, B, ch, 1, len, ch);
+  G->sv.B = 0;
+  if (grad) {
+    G->sv.B = B; G->sv.frames = frames; G->sv.xa0 = xa;
+    G->sv.xa_out.assign(cfg.n_ups, nullptr);
+    G->sv.len.assign(cfg.n_ups, 0);
+  }
   for (int i = 0; i < cfg.n_ups; ++i) {
     const ConvT1d& U = G->ups[i];
     const int lout = convt_out_len(U, len);
@@ -733,16 +1017,26 @@ static ctta_status hifigan_forward_impl(ctta_hifigan* G, bool dry, const float* 
     bf16_t* ab = A.get<bf16_t>(elems); ALLOC_OR_FAIL(ab);
     const bool last_stage = i == cfg.n_ups - 1;
     for (int j = 0; j < nk; ++j) {
-      const HResBlock& R = G->res[i * nk + j];
+      HResBlock& R = G->res[i * nk + j];
       const bf16_t* r = y;       // residual stream (raw)
       const bf16_t* ract = ya;   // leaky_relu(r, 0.1)
       for (int mth = 0; mth < 3; ++mth) {
+        if (grad) {   // every activated tensor is a LeakyReLU mask of the backward: no buffer reuse
+          xt = A.get<bf16_t>(elems); ALLOC_OR_FAIL(xt);
+          R.sv_xt[mth] = xt; R.sv_ract[mth] = ract;
+        }
         OutAct o1; o1.out_slope = 0.1f;                 // xt is only ever consumed through leaky_relu
         CTTA_TRY(run_conv1d(c, R.c1[mth], ract, B, len, xt, nullptr, false, 1.0f, o1));
+        if (grad) {   // the backward's LeakyReLU masks, readable by the parity tests
+          const std::string tn = "mask.res." + std::to_string(i) + "." + std::to_string(j) + "." + std::to_string(mth);
+          add_tap(c, tn + ".a", ract, B, ch, 1, len, ch);
+          add_tap(c, tn + ".b", xt, B, ch, 1, len, ch);
+        }
         const bool last = mth == 2;
         if (!last) {
           bf16_t* dst = (r == ra) ? rb : ra;
           bf16_t* dact = (ract == aa) ? ab : aa;
+          if (grad) { dact = A.get<bf16_t>(elems); ALLOC_OR_FAIL(dact); }
           OutAct o2; o2.out2 = dact; o2.out2_slope = 0.1f;
           CTTA_TRY(run_conv1d(c, R.c2[mth], xt, B, len, dst, r, false, 1.0f, o2));
           r = dst; ract = dact;
@@ -756,12 +1050,87 @@ static ctta_status hifigan_forward_impl(ctta_hifigan* G, bool dry, const float* 
         }
       }
     }
-    A.release(mk);
+    if (!grad) A.release(mk);
     xa = xs;
+    if (grad) { G->sv.xa_out[i] = xa; G->sv.len[i] = len; }
     add_tap(c, "lrelu.stage." + std::to_string(i), xa, B, ch, 1, len, ch);
   }
   // x = tanh(conv_post(leaky_relu(x)))  -- the leaky_relu (default slope 0.01, models.py:113) is already in xa
   RUN(c, ctta_conv_small_n(xa, ch, B, 1, len, 1, 7, 0, 3, G->post_w, G->post_b, 1, 0, 0.f, 2, wav, nullptr, stream));
+  return CTTA_OK;
+}
+
+// ------------------------------------------------------------------------------ vocoder input gradient
+// d wav / d mel of the frozen Generator (Generator.forward hifigan/models.py:101-117 in reverse): tanh and conv_post
+// in one small kernel, then per stage the three ResBlocks (two data-gradient convolutions + two LeakyReLU masks per
+// unit, residual stream folded into the mask kernel), the ConvTranspose1d data gradient as a strided convolution,
+// and conv_pre's data gradient written as the fp32 (B, frames, num_mels) mel gradient.
+static ctta_status run_conv1d_dgrad(RunCtx& c, const Conv1d& D, const bf16_t* dy, int B, int len_in, int len_out,
+                                    int stride, void* out, bool f32) {
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = dy; d.c0 = D.cin;
+  d.batch = B; d.hi = 1; d.wi = len_in; d.ho = 1; d.wo = len_out;
+  d.kh = 1; d.kw = D.k; d.pad_w = D.pad;
+  if (stride > 0) d.stride_w = stride; else d.dil_w = D.dil;
+  d.w = D.p.w; d.k_pad = D.p.k_pad; d.n = D.p.n;
+  d.out = out; d.ldc = D.cout; d.out_f32 = f32 ? 1 : 0;
+  RUN(c, ctta_conv_gemm(&d, c.stream));
+  return CTTA_OK;
+}
+
+static ctta_status hifigan_backward_impl(ctta_hifigan* G, bool dry, const float* gwav, const float* wav, int B, float* gmel,
+                                         hipStream_t stream) {
+  const ctta_hifigan_config& cfg = G->cfg;
+  RunCtx c;
+  c.arena = &G->arena; c.stream = stream; c.dry = dry;
+  c.taps = cfg.debug_taps ? &G->taps : nullptr; c.gn_scratch = nullptr; c.gn_scratch_floats = 0;
+  Arena& A = G->arena;   // continues above the differentiable forward's saved tensors
+  const int nk = cfg.n_kernels, last = cfg.n_ups - 1;
+  int len = G->sv.len[last], ch = G->c_last;
+  bf16_t* g = A.get<bf16_t>((size_t)B * len * ch); ALLOC_OR_FAIL(g);    // gradient w.r.t. the stage's activated output
+  RUN(c, ctta_conv_cout1_dgrad(gwav, wav, G->post_w, B, 1, len, 1, 7, 0, 3, ch, nullptr, 0.f, g, stream));
+  for (int i = last; i >= 0; --i) {
+    add_tap(c, "grad.lrelu.stage." + std::to_string(i), g, B, ch, 1, len, ch);
+    const ConvT1d& U = G->ups[i];
+    const int len_prev = i > 0 ? G->sv.len[i - 1] : G->sv.frames;
+    const size_t elems = (size_t)B * len * ch;
+    bf16_t* gs = A.get<bf16_t>(elems); ALLOC_OR_FAIL(gs);             // d / d(resblock output), 1/n_kernels folded in
+    RUN(c, ctta_lrelu_bwd(g, G->sv.xa_out[i], i == last ? 0.01f : 0.1f, 1.0f / (float)nk, nullptr, gs, (int64_t)elems, 0,
+                          stream));
+    bf16_t* gy = A.get<bf16_t>(elems); ALLOC_OR_FAIL(gy);             // d / d(ups[i] output), summed over the blocks
+    bf16_t* gprev = A.get<bf16_t>((size_t)B * len_prev * U.cin); ALLOC_OR_FAIL(gprev);
+    const size_t mk = A.mark();
+    bf16_t* gxt = A.get<bf16_t>(elems); ALLOC_OR_FAIL(gxt);
+    bf16_t* gu = A.get<bf16_t>(elems); ALLOC_OR_FAIL(gu);
+    bf16_t* gra = A.get<bf16_t>(elems); ALLOC_OR_FAIL(gra);
+    bf16_t* ra = A.get<bf16_t>(elems); ALLOC_OR_FAIL(ra);
+    bf16_t* rb = A.get<bf16_t>(elems); ALLOC_OR_FAIL(rb);
+    for (int j = 0; j < nk; ++j) {
+      const HResBlock& R = G->res[i * nk + j];
+      const bf16_t* gr = gs;
+      for (int m = 2; m >= 0; --m) {   // r' = convs2(leaky_relu(convs1(leaky_relu(r)))) + r
+        CTTA_TRY(run_conv1d_dgrad(c, R.d2[m], gr, B, len, len, 0, gxt, false));
+        RUN(c, ctta_lrelu_bwd(gxt, R.sv_xt[m], 0.1f, 1.0f, nullptr, gu, (int64_t)elems, 0, stream));
+        CTTA_TRY(run_conv1d_dgrad(c, R.d1[m], gu, B, len, len, 0, gra, false));
+        if (m > 0) {
+          bf16_t* dst = (gr == ra) ? rb : ra;
+          RUN(c, ctta_lrelu_bwd(gra, R.sv_ract[m], 0.1f, 1.0f, gr, dst, (int64_t)elems, 0, stream));
+          gr = dst;
+        } else {
+          RUN(c, ctta_lrelu_bwd(gra, R.sv_ract[0], 0.1f, 1.0f, gr, gy, (int64_t)elems, j > 0 ? 1 : 0, stream));
+        }
+      }
+    }
+    add_tap(c, "grad.ups." + std::to_string(i), gy, B, ch, 1, len, ch);
+    CTTA_TRY(run_conv1d_dgrad(c, G->d_ups[i], gy, B, len, len_prev, U.u, gprev, false));
+    A.release(mk);
+    g = gprev; len = len_prev; ch = U.cin;
+  }
+  const size_t elems = (size_t)B * len * ch;
+  bf16_t* gpre = A.get<bf16_t>(elems); ALLOC_OR_FAIL(gpre);
+  RUN(c, ctta_lrelu_bwd(g, G->sv.xa0, 0.1f, 1.0f, nullptr, gpre, (int64_t)elems, 0, stream));
+  CTTA_TRY(run_conv1d_dgrad(c, G->d_pre, gpre, B, len, len, 0, gmel, true));
   return CTTA_OK;
 }
 
@@ -770,8 +1139,11 @@ static ctta_status hifigan_build(ctta_hifigan* G) {
   WeightStore& ws = G->store;
   const std::string P = "vocoder.";
   const int c0 = cfg.upsample_initial_channel;
+  const bool grad = cfg.enable_grad != 0;
   CTTA_TRY(make_conv1d(ws, P + "conv_pre.", c0, cfg.num_mels, 7, 1, &G->conv_pre));
+  if (grad) CTTA_TRY(make_conv1d_dgrad(ws, G->conv_pre, &G->d_pre));
   G->ups.resize(cfg.n_ups);
+  G->d_ups.resize(cfg.n_ups);
   G->res.resize((size_t)cfg.n_ups * cfg.n_kernels);
   int ch = c0;
   for (int i = 0; i < cfg.n_ups; ++i) {
@@ -779,6 +1151,7 @@ static ctta_status hifigan_build(ctta_hifigan* G) {
     CTTA_REQUIRE(cout % 8 == 0, "hifigan: channel count %d not a multiple of 8", cout);
     CTTA_TRY(make_convt1d(ws, P + "ups." + std::to_string(i) + ".", cin, cout, cfg.upsample_kernel_sizes[i],
                           cfg.upsample_rates[i], &G->ups[i]));
+    if (grad) CTTA_TRY(make_convt1d_dgrad(ws, P + "ups." + std::to_string(i) + ".", G->ups[i], &G->d_ups[i]));
     ch = cout;
     for (int j = 0; j < cfg.n_kernels; ++j) {
       HResBlock& R = G->res[(size_t)i * cfg.n_kernels + j];
@@ -787,6 +1160,10 @@ static ctta_status hifigan_build(ctta_hifigan* G) {
       for (int m = 0; m < 3; ++m) {
         CTTA_TRY(make_conv1d(ws, rp + "convs1." + std::to_string(m) + ".", ch, ch, k, cfg.resblock_dilations[j][m], &R.c1[m]));
         CTTA_TRY(make_conv1d(ws, rp + "convs2." + std::to_string(m) + ".", ch, ch, k, 1, &R.c2[m]));
+        if (grad) {
+          CTTA_TRY(make_conv1d_dgrad(ws, R.c1[m], &R.d1[m]));
+          CTTA_TRY(make_conv1d_dgrad(ws, R.c2[m], &R.d2[m]));
+        }
       }
     }
   }
@@ -805,7 +1182,8 @@ extern "C" ctta_status ctta_hifigan_create(const ctta_hifigan_config* cfg, const
   hipStream_t s = (hipStream_t)stream;
   ctta_hifigan* G = new ctta_hifigan();
   G->cfg = *cfg;
-  ctta_status st = G->store.init(estimate_store_bytes(weights, n_weights));
+  ctta_status st = G->store.init(cfg->enable_grad ? estimate_store_bytes_training(weights, n_weights)
+                                                  : estimate_store_bytes(weights, n_weights));
   if (st != CTTA_OK) { delete G; return st; }
   WeightTable wt;
   wt.build(weights, n_weights);
@@ -815,6 +1193,11 @@ extern "C" ctta_status ctta_hifigan_create(const ctta_hifigan_config* cfg, const
     G->arena.dry = true;
     G->arena.no_release = cfg->debug_taps != 0;
     st = hifigan_forward_impl(G, true, nullptr, cfg->max_batch, cfg->max_frames, nullptr, s);
+    if (st == CTTA_OK && cfg->enable_grad) {
+      st = hifigan_forward_impl(G, true, nullptr, cfg->max_batch, cfg->max_frames, nullptr, s, true);
+      if (st == CTTA_OK) st = hifigan_backward_impl(G, true, nullptr, nullptr, cfg->max_batch, nullptr, s);
+      G->sv.B = 0;
+    }
   }
   if (st == CTTA_OK) {
     const size_t bytes = G->arena.peak + (1 << 20);
@@ -845,6 +1228,25 @@ extern "C" ctta_status ctta_hifigan_forward(ctta_hifigan* G, const float* mel, i
                "hifigan_forward: batch %d / frames %d outside the handle's limits (%d, %d)", batch, frames,
                G->cfg.max_batch, G->cfg.max_frames);
   return hifigan_forward_impl(G, false, mel, batch, frames, wav, (hipStream_t)stream);
+}
+
+extern "C" ctta_status ctta_hifigan_forward_with_grad(ctta_hifigan* G, const float* mel, int batch, int frames, float* wav,
+                                                      void* stream) {
+  CTTA_REQUIRE(G && mel && wav, "hifigan_forward_with_grad: null pointer");
+  CTTA_REQUIRE(G->cfg.enable_grad, "hifigan_forward_with_grad: the handle was created without enable_grad");
+  CTTA_REQUIRE(batch >= 1 && batch <= G->cfg.max_batch && frames >= 1 && frames <= G->cfg.max_frames,
+               "hifigan_forward_with_grad: batch %d / frames %d outside the handle's limits (%d, %d)", batch, frames,
+               G->cfg.max_batch, G->cfg.max_frames);
+  return hifigan_forward_impl(G, false, mel, batch, frames, wav, (hipStream_t)stream, true);
+}
+extern "C" ctta_status ctta_hifigan_backward(ctta_hifigan* G, const float* grad_wav, const float* wav, int batch, int frames,
+                                             float* grad_mel, void* stream) {
+  CTTA_REQUIRE(G && grad_wav && wav && grad_mel, "hifigan_backward: null pointer");
+  CTTA_REQUIRE(G->cfg.enable_grad && G->sv.B == batch && G->sv.frames == frames,
+               "hifigan_backward: no differentiable forward of batch %d x %d frames is pending on this handle", batch, frames);
+  const ctta_status st = hifigan_backward_impl(G, false, grad_wav, wav, batch, grad_mel, (hipStream_t)stream);
+  G->sv.B = 0;
+  return st;
 }
 
 extern "C" size_t ctta_hifigan_arena_bytes(const ctta_hifigan* G) { return G ? G->arena.cap + G->store.arena.cap : 0; }

@@ -434,6 +434,74 @@ class DiagonalGaussianDistribution(object):
         return self.mean
 
 
+class _VaeDecodeWithGrad(torch.autograd.Function):
+    """decode_first_stage under torch.set_grad_enabled(True) (autoencoder.py:103-106) for a frozen decoder: the HIP
+    engine keeps its own saved tensors between the two calls; one forward may be pending per AutoencoderKL."""
+
+    @staticmethod
+    def forward(ctx, z, vae):
+        B, _, T, F = z.shape
+        h = vae._ensure_vae(B, T, F, grad=True)
+        zz = z.detach().to(device=vae.device, dtype=torch.float32).contiguous()
+        up = 2 ** (len(vae.ddconfig["ch_mult"]) - 1)
+        mel = torch.empty((B, vae.ddconfig["out_ch"], T * up, F * up), dtype=torch.float32, device=vae.device)
+        with torch.cuda.device(vae.device):
+            N.check(N.lib().ctta_vae_decode_with_grad(h, N.ptr(zz), B, N.ptr(mel), N.stream_ptr()))
+        ctx.vae, ctx.shape, ctx.dtype = vae, tuple(z.shape), z.dtype
+        ctx.token = vae._vae_pending = object()
+        return mel
+
+    @staticmethod
+    def backward(ctx, grad_mel):
+        vae = ctx.vae
+        if vae._vae_pending is not ctx.token:
+            raise N.CttaError("decode_first_stage(allow_grad=True): the decoder ran again (or its handle was rebuilt) "
+                              "before this backward -- only the latest differentiable decode can be back-propagated")
+        g = grad_mel.to(device=vae.device, dtype=torch.float32).contiguous()
+        gz = torch.empty(ctx.shape, dtype=torch.float32, device=vae.device)
+        with torch.cuda.device(vae.device):
+            N.check(N.lib().ctta_vae_decode_backward(vae._h_vae, N.ptr(g), ctx.shape[0], N.ptr(gz), N.stream_ptr()))
+        vae._vae_pending = None
+        return gz.to(ctx.dtype), None
+
+
+class _VocodeWithGrad(torch.autograd.Function):
+    """vocoder(mels) of vocoder_infer(allow_grad=True) (hifigan/utilities.py:79-80) for the frozen generator."""
+
+    @staticmethod
+    def forward(ctx, mel, vae):
+        if mel.ndim != 4 or mel.shape[1] != 1 or mel.shape[3] != vae.vocoder.h["num_mels"]:
+            raise ValueError("mel must be (batch, 1, T, %d), got %s" % (vae.vocoder.h["num_mels"], tuple(mel.shape)))
+        if not mel.is_cuda:
+            raise N.CttaError("mel is on %s: the HIP engine has no CPU path" % mel.device)
+        B, _, T, F = mel.shape
+        h = vae._ensure_voc(B, T, grad=True)
+        m = mel.detach().to(device=vae.device, dtype=torch.float32).contiguous()
+        n = N.lib().ctta_hifigan_out_len(h, T)
+        wav = torch.empty((B, n), dtype=torch.float32, device=vae.device)
+        with torch.cuda.device(vae.device):
+            N.check(N.lib().ctta_hifigan_forward_with_grad(h, N.ptr(m), B, T, N.ptr(wav), N.stream_ptr()))
+        ctx.vae, ctx.shape, ctx.dtype = vae, tuple(mel.shape), mel.dtype
+        ctx.token = vae._voc_pending = object()
+        ctx.save_for_backward(wav)
+        return wav
+
+    @staticmethod
+    def backward(ctx, grad_wav):
+        vae = ctx.vae
+        if vae._voc_pending is not ctx.token:
+            raise N.CttaError("decode_to_waveform(allow_grad=True): the vocoder ran again (or its handle was rebuilt) "
+                              "before this backward -- only the latest differentiable call can be back-propagated")
+        (wav,) = ctx.saved_tensors
+        B, _, T, F = ctx.shape
+        g = grad_wav.to(device=vae.device, dtype=torch.float32).contiguous()
+        gm = torch.empty(ctx.shape, dtype=torch.float32, device=vae.device)
+        with torch.cuda.device(vae.device):
+            N.check(N.lib().ctta_hifigan_backward(vae._h_voc, N.ptr(g), N.ptr(wav), B, T, N.ptr(gm), N.stream_ptr()))
+        vae._voc_pending = None
+        return gm.to(ctx.dtype), None
+
+
 class Generator(_ParamTree):
     """HiFi-GAN parameter holder (weight_norm already removed, hifigan/utilities.py:71)."""
 
@@ -472,6 +540,8 @@ class AutoencoderKL(_ParamTree):
         self._h_enc = self._h_enc_key = self._h_enc_ver = None
         self.ema_decoder = None
         self._h_vae = self._h_voc = None
+        self._h_vae_grad = self._h_voc_grad = False
+        self._vae_pending = self._voc_pending = None
         self._h_vae_key = self._h_voc_key = None
         self._h_vae_ver = self._h_voc_ver = None
         self.debug_taps = False
@@ -596,13 +666,14 @@ class AutoencoderKL(_ParamTree):
     def _decoder_version(self):
         return sum(p._version for k, p in self.named_parameters() if k.startswith(("decoder.", "post_quant_conv.")))
 
-    def _ensure_vae(self, B, T, F):
+    def _ensure_vae(self, B, T, F, grad=False):
         L_ = N.lib()
         sf = float(self.scale_factor)
         key = (T, F, sf, self.debug_taps, self.device)
         ver = self._decoder_version()
+        grad = grad or (self._h_vae is not None and getattr(self, "_h_vae_grad", False))
         if (self._h_vae is None or self._h_vae_key[1:] != key or B > self._h_vae_key[0]
-                or ver != self._h_vae_ver):
+                or ver != self._h_vae_ver or grad != getattr(self, "_h_vae_grad", False)):
             if self._h_vae is not None:
                 L_.ctta_vae_destroy(self._h_vae)
                 self._h_vae = None
@@ -615,6 +686,8 @@ class AutoencoderKL(_ParamTree):
             c.scale_factor = sf
             c.max_batch, c.latent_h, c.latent_w = B, T, F
             c.debug_taps = int(self.debug_taps)
+            c.enable_grad = int(grad)
+            self._h_vae_grad, self._vae_pending = grad, None
             sd = OrderedDict((k, p.detach()) for k, p in self.named_parameters()
                              if k.startswith(("decoder.", "post_quant_conv.")))
             for k, p in sd.items():
@@ -627,12 +700,13 @@ class AutoencoderKL(_ParamTree):
             self._h_vae, self._h_vae_key, self._h_vae_ver = h, (B,) + key, ver
         return self._h_vae
 
-    def _ensure_voc(self, B, frames):
+    def _ensure_voc(self, B, frames, grad=False):
         L_ = N.lib()
         ver = sum(p._version for p in self.vocoder.parameters())
         key = (self.debug_taps, self.device)
+        grad = grad or (self._h_voc is not None and getattr(self, "_h_voc_grad", False))
         if (self._h_voc is None or self._h_voc_key[2:] != key or B > self._h_voc_key[0]
-                or frames > self._h_voc_key[1] or ver != self._h_voc_ver):
+                or frames > self._h_voc_key[1] or ver != self._h_voc_ver or grad != getattr(self, "_h_voc_grad", False)):
             if self._h_voc is not None:
                 L_.ctta_hifigan_destroy(self._h_voc)
                 self._h_voc = None
@@ -647,6 +721,8 @@ class AutoencoderKL(_ParamTree):
                 for m in range(3):
                     c.resblock_dilations[j][m] = dil[m]
             c.max_batch, c.max_frames, c.debug_taps = B, frames, int(self.debug_taps)
+            c.enable_grad = int(grad)
+            self._h_voc_grad, self._voc_pending = grad, None
             sd = OrderedDict(("vocoder." + k, p.detach()) for k, p in self.vocoder.named_parameters())
             for k, p in sd.items():
                 if not p.is_cuda:
@@ -663,20 +739,23 @@ class AutoencoderKL(_ParamTree):
         return self.decode_first_stage(z * self.scale_factor, use_ema=use_ema)
 
     def decode_first_stage(self, z, allow_grad=False, use_ema=False):
-        """z (B,8,T,F) -> mel (B,1,4T,4F); z is divided by scale_factor first (autoencoder.py:105)."""
-        if allow_grad:
-            raise NotImplementedError("allow_grad=True (CLAP fine-tuning, SURVEY §8f rank 2) is not built yet")
+        """z (B,8,T,F) -> mel (B,1,4T,4F); z is divided by scale_factor first (autoencoder.py:105).
+        allow_grad=True (CLAPLoss, tools/losses.py:294-296) returns a mel that back-propagates into z through the
+        frozen decoder (ctta_vae_decode_with_grad / ctta_vae_decode_backward)."""
         if use_ema and self.ema_decoder is None:
             print("VAE does not have EMA modules, but specified use_ema. Using the none-EMA modules instead.")
         if z.ndim != 4 or z.shape[1] != self.embed_dim:
             raise ValueError("z must be (batch, %d, T, F), got %s" % (self.embed_dim, tuple(z.shape)))
         if not z.is_cuda:
             raise N.CttaError("z is on %s: the HIP engine has no CPU path" % z.device)
+        if allow_grad:
+            return _VaeDecodeWithGrad.apply(z, self)
         B, _, T, F = z.shape
         h = self._ensure_vae(B, T, F)
         zz = z.detach().to(device=self.device, dtype=torch.float32).contiguous()
         up = 2 ** (len(self.ddconfig["ch_mult"]) - 1)
         mel = torch.empty((B, self.ddconfig["out_ch"], T * up, F * up), dtype=torch.float32, device=self.device)
+        self._vae_pending = None
         with torch.cuda.device(self.device):
             N.check(N.lib().ctta_vae_decode(h, N.ptr(zz), B, N.ptr(mel), N.stream_ptr()))
         return mel
@@ -692,6 +771,7 @@ class AutoencoderKL(_ParamTree):
         m = mel.detach().to(device=self.device, dtype=torch.float32).contiguous()
         n = N.lib().ctta_hifigan_out_len(h, T)
         wav = torch.empty((B, n), dtype=torch.float32, device=self.device)
+        self._voc_pending = None
         with torch.cuda.device(self.device):
             N.check(N.lib().ctta_hifigan_forward(h, N.ptr(m), B, T, N.ptr(wav), N.stream_ptr()))
         return wav
@@ -699,9 +779,11 @@ class AutoencoderKL(_ParamTree):
     def decode_to_waveform(self, dec, allow_grad=False, return_float=False):
         """vocoder_infer (hifigan/utilities.py:76-91): batch-global (max+min)/2 centring, then
         int16 numpy on the host (the reference's return type); return_float keeps the centred
-        float tensor on the device."""
+        float tensor on the device.  allow_grad=True returns the centred float waveform with a graph back to `dec`
+        (utilities.py:79-81; the centring's max/min run as torch ops on the vocoder's differentiable output)."""
         if allow_grad:
-            raise NotImplementedError("allow_grad=True (CLAP fine-tuning) is not built yet")
+            wavs = _VocodeWithGrad.apply(dec, self).float()
+            return wavs - (wavs.max() + wavs.min()) / 2
         wav = self.vocode(dec)
         scratch = torch.empty(4, dtype=torch.float32, device=wav.device)
         centred = torch.empty_like(wav) if return_float else None

@@ -119,6 +119,8 @@ typedef struct {
   float scale_factor;
   int max_batch, latent_h, latent_w;
   int debug_taps;
+  int enable_grad;   /* 1: also build the data-gradient packs and size the arena for
+                        ctta_vae_decode_with_grad + ctta_vae_decode_backward (decoder only) */
 } ctta_vae_config;
 
 typedef struct ctta_vae ctta_vae;
@@ -127,6 +129,12 @@ ctta_status ctta_vae_create(const ctta_vae_config* cfg, const ctta_tensor* weigh
 void ctta_vae_destroy(ctta_vae* h);
 /* z (B,zc,T,F) f32 -> mel (B,out_ch,4T,4F) f32 */
 ctta_status ctta_vae_decode(ctta_vae* h, const float* z, int batch, float* mel, void* stream);
+/* decode_first_stage(z, allow_grad=True) (autoencoder.py:103-106 as called by CLAPLoss, tools/losses.py:294-296):
+ * the same decode, keeping what the input gradient needs; ctta_vae_decode_backward then turns d loss / d mel
+ * (B,1,4T,4F) f32 into d loss / d z (B,zc,T,F) f32 -- the decoder is frozen, no parameter gradients.  One forward
+ * may be pending per handle; the backward consumes it.  Requires cfg.enable_grad. */
+ctta_status ctta_vae_decode_with_grad(ctta_vae* h, const float* z, int batch, float* mel, void* stream);
+ctta_status ctta_vae_decode_backward(ctta_vae* h, const float* grad_mel, int batch, float* grad_z, void* stream);
 size_t ctta_vae_arena_bytes(const ctta_vae* h);
 int ctta_vae_num_taps(const ctta_vae* h);
 ctta_status ctta_vae_tap_info(const ctta_vae* h, int i, const char** name, int dims[4]);
@@ -170,6 +178,7 @@ typedef struct {
   int resblock_dilations[4][3];
   int max_batch, max_frames;
   int debug_taps;
+  int enable_grad;   /* 1: ctta_hifigan_forward_with_grad + ctta_hifigan_backward are available */
 } ctta_hifigan_config;
 
 typedef struct ctta_hifigan ctta_hifigan;
@@ -181,6 +190,13 @@ int64_t ctta_hifigan_out_len(const ctta_hifigan* h, int frames);
  * BEFORE the reference's batch-global centring. */
 ctta_status ctta_hifigan_forward(ctta_hifigan* h, const float* mel, int batch, int frames,
                                  float* wav, void* stream);
+/* vocoder_infer(..., allow_grad=True) (hifigan/utilities.py:79-81): the same forward keeping every LeakyReLU mask;
+ * ctta_hifigan_backward turns d loss / d wav (B,out_len) f32 (`wav` = the forward's output, for tanh') into
+ * d loss / d mel (B,frames,num_mels) f32.  The generator is frozen.  Requires cfg.enable_grad. */
+ctta_status ctta_hifigan_forward_with_grad(ctta_hifigan* h, const float* mel, int batch, int frames, float* wav,
+                                           void* stream);
+ctta_status ctta_hifigan_backward(ctta_hifigan* h, const float* grad_wav, const float* wav, int batch, int frames,
+                                  float* grad_mel, void* stream);
 /* vocoder_infer post-processing (utilities.py:83-86): wav -= (max+min)/2 over the WHOLE
  * batch, *32768, truncation to int16.  `scratch` >= 2 floats of device memory.
  * centred (float, may be NULL) and pcm (int16, may be NULL) receive the results. */
@@ -427,6 +443,14 @@ ctta_status ctta_col_scatter(const float* slabs, int n_slabs, int64_t slab_strid
                              void* stream);
 ctta_status ctta_row_scatter(const float* slabs, int n_slabs, int64_t slab_stride, int ldn, int row,
                              int n_cols, const int32_t* idx, float* dst, int accumulate, void* stream);
+/* out (+)= res + alpha * g * (act > 0 ? 1 : slope): LeakyReLU backward on the saved activation, residual folded in */
+ctta_status ctta_lrelu_bwd(const void* g, const void* act, float slope, float alpha, const void* res, void* out,
+                           int64_t n, int accumulate, void* stream);
+/* data gradient of a 1-output-channel conv (w fp32 [tap][c]); gy is scaled by (1 - y_tanh^2) when y_tanh != NULL and
+ * the result by leaky_relu'(act) when act != NULL; dx NHWC bf16 */
+ctta_status ctta_conv_cout1_dgrad(const float* gy, const float* y_tanh, const float* w, int batch, int h, int wd,
+                                  int kh, int kw, int pad_h, int pad_w, int c, const void* act, float slope,
+                                  void* dx, void* stream);
 /* GroupNorm(+SiLU) backward; stats [B][G][2] = (mean, rstd) from ctta_groupnorm_stats */
 size_t ctta_groupnorm_bwd_scratch_floats(int batch, int hw, int c, int groups);
 ctta_status ctta_groupnorm_stats(const void* x, int batch, int hw, int c, int groups, float eps, float* stats,

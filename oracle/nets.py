@@ -299,19 +299,45 @@ def posterior_sample(moments, noise, scale_factor):
 
 
 # ----------------------------------------------------------------------------- HiFi-GAN
-def hifigan_forward(hcfg, sd, mel, prefix="vocoder.", taps=None):
+class _LeakyReluPrescribedMask(torch.autograd.Function):
+    """leaky_relu whose BACKWARD uses the sign pattern of a given tensor instead of its own input's.  The vocoder is
+    piecewise linear, so its input gradient is a discontinuous function of the activations: a bf16 engine and this
+    fp32 restatement disagree on the sign of activations that are ~0, and each disagreement moves one gradient entry
+    by 90 % of its value.  Prescribing the engine's own masks checks the engine's backward operator exactly (it is
+    linear once the masks are fixed) instead of comparing two different linearisations."""
+
+    @staticmethod
+    def forward(ctx, x, slope, mask_src):
+        ctx.slope = slope
+        ctx.save_for_backward(mask_src)
+        return F.leaky_relu(x, slope)
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        return g * torch.where(m > 0, torch.ones_like(g), torch.full_like(g, ctx.slope)), None, None
+
+
+def hifigan_forward(hcfg, sd, mel, prefix="vocoder.", taps=None, lrelu_masks=None):
     """Generator.forward, hifigan/models.py:101-117; ResBlock.forward :56-63.
-    mel (B, num_mels, T) -> (B, 1, T * prod(upsample_rates) [+ tails])."""
+    mel (B, num_mels, T) -> (B, 1, T * prod(upsample_rates) [+ tails]).
+    lrelu_masks (tests only): {site: tensor} sign patterns for the backward of the LeakyReLU at that site
+    ("conv_pre", "stage.i", "res.i.j.m.a" / ".b"); sites not listed keep the true derivative."""
     def tap(name, t):
         if taps is not None:
             taps[name] = t.detach().clone()
+
+    def lrelu(x, slope, site):
+        if lrelu_masks is not None and site in lrelu_masks:
+            return _LeakyReluPrescribedMask.apply(x, slope, lrelu_masks[site])
+        return F.leaky_relu(x, slope)
 
     P = prefix
     nk = len(hcfg["resblock_kernel_sizes"])
     x = F.conv1d(mel, sd[P + "conv_pre.weight"], sd[P + "conv_pre.bias"], padding=3)
     tap("conv_pre", x)
     for i, (u, k) in enumerate(zip(hcfg["upsample_rates"], hcfg["upsample_kernel_sizes"])):
-        x = F.leaky_relu(x, 0.1)
+        x = lrelu(x, 0.1, "conv_pre" if i == 0 else "stage.%d" % (i - 1))
         x = F.conv_transpose1d(x, sd[P + "ups.%d.weight" % i], sd[P + "ups.%d.bias" % i],
                                stride=u, padding=(k - u) // 2)
         tap("ups.%d" % i, x)
@@ -321,17 +347,17 @@ def hifigan_forward(hcfg, sd, mel, prefix="vocoder.", taps=None):
             rp = P + "resblocks.%d." % (i * nk + j)
             r = x
             for m, d in enumerate(dil):
-                xt = F.leaky_relu(r, 0.1)
+                xt = lrelu(r, 0.1, "res.%d.%d.%d.a" % (i, j, m))
                 xt = F.conv1d(xt, sd[rp + "convs1.%d.weight" % m], sd[rp + "convs1.%d.bias" % m],
                               dilation=d, padding=(rk * d - d) // 2)
-                xt = F.leaky_relu(xt, 0.1)
+                xt = lrelu(xt, 0.1, "res.%d.%d.%d.b" % (i, j, m))
                 xt = F.conv1d(xt, sd[rp + "convs2.%d.weight" % m], sd[rp + "convs2.%d.bias" % m],
                               padding=(rk - 1) // 2)
                 r = xt + r
             xs = r if xs is None else xs + r
         x = xs / nk
         tap("stage.%d" % i, x)
-    x = F.leaky_relu(x)  # default slope 0.01, models.py:113
+    x = lrelu(x, 0.01, "stage.%d" % (len(hcfg["upsample_rates"]) - 1))  # default slope 0.01, models.py:113
     x = F.conv1d(x, sd[P + "conv_post.weight"], sd[P + "conv_post.bias"], padding=3)
     return torch.tanh(x)
 
@@ -343,5 +369,5 @@ def mel_to_waveform(hcfg, sd, mel_b1tf, prefix="vocoder."):
     dec = mel_b1tf.squeeze(1).permute(0, 2, 1)
     wav = hifigan_forward(hcfg, sd, dec, prefix).squeeze(1).float()
     centred = wav - (wav.max() + wav.min()) / 2
-    pcm = (centred.cpu().numpy() * 32768).astype("int16")
+    pcm = (centred.detach().cpu().numpy() * 32768).astype("int16")
     return wav, centred, pcm

@@ -136,6 +136,21 @@ def golden_vae_encoder(ns):
         save("vae_encoder_full", moments=post.parameters.numpy(), scale_factor=sf)
 
 
+def golden_vae_grad(ns):
+    """CLAPLoss's differentiable waveform (tools/losses.py:294-298): decode_first_stage(allow_grad=True) ->
+    decode_to_waveform(allow_grad=True), and the latent / mel gradients of sum(wav * direction) from the reference's
+    own autograd graph (VAE and vocoder frozen, as in the CLAP fine-tuning stage)."""
+    vae, sf = ref_vae(ns, cases.TINY_VAE_DD, cases.TINY_HIFIGAN)
+    z = cases.vae_inputs(2, 16, 16, "vae_grad").clone().requires_grad_(True)
+    mel = vae.decode_first_stage(z, allow_grad=True)
+    mel.retain_grad()
+    wav = vae.decode_to_waveform(mel, allow_grad=True)
+    direction = cases.t(spec.det_uniform("vae_grad.direction", tuple(wav.shape), 21))
+    (wav * direction).sum().backward()
+    save("vae_grad_tiny", mel=mel.detach().numpy(), wav=wav.detach().numpy(), grad_mel=mel.grad.numpy(),
+         grad_z=z.grad.numpy(), scale_factor=sf)
+
+
 def golden_heun(ns):
     out = {}
     for n in (1, 2, 18, 200):
@@ -201,5 +216,7 @@ if __name__ == "__main__":
         golden_vae(ns)
     if "vae_encoder" in which:
         golden_vae_encoder(ns)
+    if "vae_grad" in which:
+        golden_vae_grad(ns)
     if "pipeline" in which:
         golden_pipeline(ns)

@@ -96,6 +96,24 @@ def test_vae_hifigan_tiny(golden):
         assert np.abs(pcm.astype(np.int64) - g["pcm"].astype(np.int64)).max() <= 1
 
 
+def test_differentiable_decode_gradients(golden):
+    """decode_first_stage / decode_to_waveform with allow_grad=True (tools/losses.py:294-298): waveform, mel and the
+    latent / mel gradients of the reference's autograd graph."""
+    g = golden("vae_grad_tiny")
+    sd = dict(cases.vae_weights(cases.TINY_VAE_DD))
+    sd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
+    z = cases.vae_inputs(2, 16, 16, "vae_grad").clone().requires_grad_(True)
+    mel = nets.vae_decode(cases.TINY_VAE_DD, sd, z, float(g["scale_factor"]))
+    mel.retain_grad()
+    _, centred, _ = nets.mel_to_waveform(cases.TINY_HIFIGAN, sd, mel)
+    direction = cases.t(spec.det_uniform("vae_grad.direction", tuple(centred.shape), 21))
+    (centred * direction).sum().backward()
+    close(mel.detach(), g["mel"])
+    close(centred.detach(), g["wav"])
+    close(mel.grad, g["grad_mel"], rtol=1e-4, atol=1e-6)
+    close(z.grad, g["grad_z"], rtol=1e-4, atol=1e-6)
+
+
 @pytest.mark.slow
 def test_vae_hifigan_full_width(golden):
     g = golden("vae_full")
