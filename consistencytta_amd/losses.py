@@ -1,0 +1,111 @@
+"""Training losses of tools/losses.py on top of the HIP engines.
+
+The latent MSE ('mse', train.sh's setting) never goes through this module: AudioLCM computes it and its gradient with
+ctta_snr_mse_loss / ctta_snr_mse_grad.  The perceptual variants decode the predicted latent with
+AutoencoderKL.decode_first_stage / decode_to_waveform(allow_grad=True) -- ctta_vae_decode_with_grad and
+ctta_hifigan_forward_with_grad on the device -- and only the few reductions after that run as torch ops:
+
+  MelLoss                  tools/losses.py:36-64    0.3 * mse(mel(input), mel(target)) + 0.7 * mse(input, target)
+  MultiResolutionSTFTLoss  tools/losses.py:187-256  spectral convergence + log-magnitude over 3 STFT resolutions
+  CLAPLoss                 tools/losses.py:259-316  needs the laion_clap package and its checkpoint: not available
+                                                    offline, construction fails loudly
+All return one value per instance for reduction='instance' (the only mode AudioLCM uses, audio_consistency_model.py:93-102).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+
+def reduce(loss, reduction):
+    if reduction == "instance":
+        return loss
+    if reduction == "mean":
+        return loss.mean()
+    if reduction == "sum":
+        return loss.sum()
+    raise ValueError("Unknown loss reduction option.")
+
+
+def _instance_mse(a, b):
+    d = (a.float() - b.float()) ** 2
+    return d.reshape(d.shape[0], -1).mean(dim=1)
+
+
+class MSELoss(nn.Module):
+    def __init__(self, reduction="instance"):
+        super().__init__()
+        self.reduction = reduction
+
+    def forward(self, input, target, gt_wav=None, gt_text=None):
+        return reduce(_instance_mse(input, target), self.reduction)
+
+
+class MelLoss(nn.Module):
+    def __init__(self, vae, reduction="instance", mse_weight=.7, mel_weight=.3):
+        super().__init__()
+        object.__setattr__(self, "vae", vae)   # not a submodule: the VAE belongs to the model (and stays frozen)
+        self.reduction = reduction
+        self.mse_weight, self.mel_weight = mse_weight, mel_weight
+
+    def forward(self, input, target, gt_wav=None, gt_text=None):
+        input_mel = self.vae.decode_first_stage(input.float(), allow_grad=True)
+        target_mel = self.vae.decode_first_stage(target.float(), allow_grad=True)
+        inst = _instance_mse(input_mel, target_mel) * self.mel_weight + _instance_mse(input, target) * self.mse_weight
+        return reduce(inst, self.reduction)
+
+
+class _STFTMagnitude(nn.Module):
+    """|STFT| in float64 like the reference (tools/losses.py:146-169): (B, frames, fft_size // 2 + 1) float32."""
+
+    def __init__(self, fft_size, shift_size, win_length, window):
+        super().__init__()
+        self.fft_size, self.shift_size, self.win_length = fft_size, shift_size, win_length
+        self.register_buffer("window", getattr(torch, window)(win_length))
+
+    def forward(self, x):
+        spec = torch.stft(x.double(), self.fft_size, self.shift_size, self.win_length, self.window.to(x.device),
+                          return_complex=True)
+        power = spec.real ** 2 + spec.imag ** 2
+        return torch.clamp(power, min=1e-8).sqrt().transpose(2, 1).float()
+
+
+class MultiResolutionSTFTLoss(nn.Module):
+    """factor_mse * mse(latents) + factor_mag * mean_r log-magnitude L1 + factor_sc * mean_r spectral convergence.
+    The reference reads an undefined `self.sr` (tools/losses.py:241); 16 kHz -- CLAPLoss's value and the vocoder's
+    rate -- is used here so that the loss is usable."""
+
+    def __init__(self, vae, reduction="instance", fft_sizes=(1024, 2048, 512), hop_sizes=(120, 240, 50),
+                 win_lengths=(600, 1200, 240), window="hann_window", factor_sc=0.2, factor_mag=0.2, factor_mse=1):
+        super().__init__()
+        assert len(fft_sizes) == len(hop_sizes) == len(win_lengths)
+        object.__setattr__(self, "vae", vae)
+        self.reduction = reduction
+        self.sr = 16000
+        self.stfts = nn.ModuleList(_STFTMagnitude(f, h, w, window) for f, h, w in zip(fft_sizes, hop_sizes, win_lengths))
+        self.factor_sc, self.factor_mag, self.factor_mse = factor_sc, factor_mag, factor_mse
+
+    def _wav(self, latent):
+        mel = self.vae.decode_first_stage(latent.float(), allow_grad=True)
+        return self.vae.decode_to_waveform(mel.float(), allow_grad=True)[:, :int(self.sr * 10)]
+
+    def forward(self, input, target, gt_wav=None, gt_text=None):
+        mse = reduce(_instance_mse(input, target), self.reduction)
+        x, y = self._wav(input), self._wav(target)
+        sc = mag = 0.
+        for stft in self.stfts:
+            xm, ym = stft(x), stft(y)
+            diff = (ym - xm).reshape(xm.shape[0], -1)
+            sc = sc + reduce(diff.norm(dim=1) / ym.reshape(ym.shape[0], -1).norm(dim=1), self.reduction)
+            l1 = (torch.log(ym) - torch.log(xm)).abs()
+            mag = mag + reduce(l1.reshape(l1.shape[0], -1).mean(dim=1), self.reduction)
+        n = len(self.stfts)
+        return self.factor_mse * mse + self.factor_mag * (mag / n) + self.factor_sc * (sc / n)
+
+
+class CLAPLoss(nn.Module):
+    def __init__(self, vae, reduction="instance", mse_weight=1., clap_weight=1.):
+        super().__init__()
+        raise RuntimeError(
+            "CLAPLoss needs laion_clap (HTSAT-base + RoBERTa) and ckpt/music_audioset_epoch_15_esc_90.14.pt "
+            "(tools/losses.py:270-273); neither is available offline.  The differentiable half it sits on -- "
+            "decode_first_stage / decode_to_waveform with allow_grad=True -- is built: see MelLoss / MultiResolutionSTFTLoss.")

@@ -210,7 +210,7 @@ class AudioLCM(AudioDistilledModel):
                          ema_decay=ema_decay, teacher_guidance_scale=teacher_guidance_scale, **kwargs)
         assert use_edm, "only the Heun/EDM path (use_edm, train.sh:33) is built; DDIM is §8f rank 3"
         assert not use_karras, "Karras sigmas are unused by the shipped scripts and not built"
-        assert loss_type == "mse", "only the stage-2 latent MSE loss is built (mel/stft/clap: out of scope / next)"
+        assert loss_type in ("mse", "mel", "stft", "clap"), "unknown loss_type %r" % (loss_type,)
         self.uncondition = uncondition
         self.use_edm = use_edm
         self.target_ema_decay = target_ema_decay
@@ -222,6 +222,29 @@ class AudioLCM(AudioDistilledModel):
         self.noise_scheduler.set_timesteps(self.num_diffusion_steps)
         self.vae = vae
         self.loss_type = loss_type
+        # audio_consistency_model.py:92-105.  'mse' stays on the fused kernels (ctta_snr_mse_loss / _grad); the
+        # perceptual losses run through the differentiable decode (losses.py).
+        from . import losses as L
+        if loss_type == "mel":
+            self.loss = L.MelLoss(vae=self.vae, reduction="instance")
+        elif loss_type == "stft":
+            self.loss = L.MultiResolutionSTFTLoss(vae=self.vae, reduction="instance", fft_sizes=[1024, 2048, 512],
+                                                  hop_sizes=[120, 240, 50], win_lengths=[600, 1200, 240],
+                                                  window="hann_window", factor_sc=0.1, factor_mag=0.1, factor_mse=.8)
+        elif loss_type == "clap":
+            self.loss = L.CLAPLoss(vae=self.vae, reduction="instance", mse_weight=1., clap_weight=.1)
+        else:
+            self.loss = None
+        if self.loss is not None and self.vae is None:
+            raise ValueError("loss_type=%r decodes latents: pass vae=" % (loss_type,))
+
+    def _perceptual_loss(self, pred, target, gt_wav, prompt, sig, gamma):
+        """get_loss (audio_consistency_model.py:250-266) for loss_type != 'mse': instance losses through the
+        differentiable decode, SNR weights clamp(sigma^-2, max=snr_gamma), batch mean."""
+        inst = self.loss(pred, target, gt_wav, prompt)
+        if gamma and gamma > 0:
+            inst = inst * torch.clamp(sig.to(inst.device, torch.float32) ** -2, max=float(gamma))
+        return inst.mean()
 
     def train(self, mode=True):
         super().train(mode)
@@ -301,6 +324,12 @@ class AudioLCM(AudioDistilledModel):
 
     def _student_backward(self, pred, target, sig, gamma, loss_scale=1.0, on_block_done=None):
         """d loss / d pred of get_loss (audio_consistency_model.py:250-266) -> engine backward."""
+        if isinstance(target, tuple):   # perceptual loss: torch differentiates loss(pred) down to the latent
+            leaf, graph = target
+            with torch.enable_grad():
+                (g,) = torch.autograd.grad(graph, leaf, torch.full_like(graph, float(loss_scale)))
+            self.student_unet.backward(grad_output=g, on_block_done=on_block_done)
+            return
         B, C, H, W = pred.shape
         d = torch.empty(B, H * W, 8, dtype=torch.bfloat16, device=pred.device)
         with torch.cuda.device(pred.device):
@@ -401,6 +430,9 @@ class AudioLCM(AudioDistilledModel):
         sig = torch.from_numpy(sch._sigmas_host[inds.numpy()]).to(dev)
 
         def mse(a, b, sigma=None, gamma=0.0):
+            if self.loss is not None and sigma is not None:   # the consistency loss proper (get_loss); plain MSEs stay MSE
+                with torch.no_grad():
+                    return self._perceptual_loss(a, b, gt_wav, prompt, sigma, gamma)
             inst = torch.empty(B, dtype=torch.float32, device=dev)
             out = torch.empty(1, dtype=torch.float32, device=dev)
             N.check(N.lib().ctta_snr_mse_loss(N.ptr(a.contiguous()), N.ptr(b.contiguous()), N.ptr(sigma), float(gamma),
@@ -426,6 +458,11 @@ class AudioLCM(AudioDistilledModel):
         if want_grad:
             pred = self.student_unet.forward_train(z_np1_scaled, t_np1, w, embeds, mask)
             gamma = self.snr_gamma or 0.0
+            if self.loss is not None:   # keep the graph from pred to the loss; _student_backward differentiates it
+                leaf = pred.detach().requires_grad_(True)
+                with torch.enable_grad():
+                    graph = self._perceptual_loss(leaf, target, gt_wav, prompt, sig, gamma)
+                return graph.detach(), pred, (leaf, graph), sig, gamma
             return mse(pred, target, sig, gamma), pred, target.contiguous(), sig, gamma
         pred = self.student_unet(z_np1_scaled, t_np1, guidance=w, encoder_hidden_states=embeds,
                                  encoder_attention_mask=mask).sample

@@ -135,6 +135,9 @@ class _ParamTree(nn.Module):
         for k in list(d):
             if k.startswith("_h_"):
                 d[k] = None
+        if "_eng" in d:
+            d["_eng"] = {"vae": [None, None], "voc": [None, None]}
+            d["_vae_pending"] = d["_voc_pending"] = None
         return d
 
     def __deepcopy__(self, memo):
@@ -143,7 +146,12 @@ class _ParamTree(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            new.__dict__[k] = None if k.startswith(("_h_", "_flat")) else copy.deepcopy(v, memo)
+            if k == "_eng":
+                new.__dict__[k] = {"vae": [None, None], "voc": [None, None]}
+            elif k in ("_vae_pending", "_voc_pending"):
+                new.__dict__[k] = None
+            else:
+                new.__dict__[k] = None if k.startswith(("_h_", "_flat")) else copy.deepcopy(v, memo)
         return new
 
 
@@ -460,7 +468,7 @@ class _VaeDecodeWithGrad(torch.autograd.Function):
         g = grad_mel.to(device=vae.device, dtype=torch.float32).contiguous()
         gz = torch.empty(ctx.shape, dtype=torch.float32, device=vae.device)
         with torch.cuda.device(vae.device):
-            N.check(N.lib().ctta_vae_decode_backward(vae._h_vae, N.ptr(g), ctx.shape[0], N.ptr(gz), N.stream_ptr()))
+            N.check(N.lib().ctta_vae_decode_backward(vae._eng["vae"][1]["h"], N.ptr(g), ctx.shape[0], N.ptr(gz), N.stream_ptr()))
         vae._vae_pending = None
         return gz.to(ctx.dtype), None
 
@@ -497,7 +505,7 @@ class _VocodeWithGrad(torch.autograd.Function):
         g = grad_wav.to(device=vae.device, dtype=torch.float32).contiguous()
         gm = torch.empty(ctx.shape, dtype=torch.float32, device=vae.device)
         with torch.cuda.device(vae.device):
-            N.check(N.lib().ctta_hifigan_backward(vae._h_voc, N.ptr(g), N.ptr(wav), B, T, N.ptr(gm), N.stream_ptr()))
+            N.check(N.lib().ctta_hifigan_backward(vae._eng["voc"][1]["h"], N.ptr(g), N.ptr(wav), B, T, N.ptr(gm), N.stream_ptr()))
         vae._voc_pending = None
         return gm.to(ctx.dtype), None
 
@@ -539,11 +547,11 @@ class AutoencoderKL(_ParamTree):
         self.vocoder = Generator(hifigan_config)
         self._h_enc = self._h_enc_key = self._h_enc_ver = None
         self.ema_decoder = None
-        self._h_vae = self._h_voc = None
-        self._h_vae_grad = self._h_voc_grad = False
+        # engine handles: [plain, differentiable] per stage -- separate handles, so that a plain decode (e.g. of the
+        # target latent in MelLoss) never disturbs the tensors a pending differentiable decode saved for its backward
+        self._eng = {"vae": [None, None], "voc": [None, None]}
+        self._h_vae = self._h_voc = None     # the handle each stage used last (debug taps)
         self._vae_pending = self._voc_pending = None
-        self._h_vae_key = self._h_voc_key = None
-        self._h_vae_ver = self._h_voc_ver = None
         self.debug_taps = False
 
     @property
@@ -646,16 +654,19 @@ class AutoencoderKL(_ParamTree):
         return out
 
     def _release(self):
-        L_ = N.lib() if (getattr(self, "_h_vae", None) or getattr(self, "_h_voc", None)
-                         or getattr(self, "_h_enc", None)) else None
+        eng = getattr(self, "_eng", None) or {"vae": [], "voc": []}
+        live = [e for v in eng.values() for e in v if e]
+        L_ = N.lib() if (live or getattr(self, "_h_enc", None)) else None
         if getattr(self, "_h_enc", None):
             L_.ctta_vae_encoder_destroy(self._h_enc)
             self._h_enc = None
-        if getattr(self, "_h_vae", None):
-            L_.ctta_vae_destroy(self._h_vae)
-        if getattr(self, "_h_voc", None):
-            L_.ctta_hifigan_destroy(self._h_voc)
+        for which, destroy in (("vae", "ctta_vae_destroy"), ("voc", "ctta_hifigan_destroy")):
+            for i, e in enumerate(eng[which]):
+                if e:
+                    getattr(L_, destroy)(e["h"])
+                    eng[which][i] = None
         self._h_vae = self._h_voc = None
+        self._vae_pending = self._voc_pending = None
 
     def __del__(self):
         try:
@@ -671,12 +682,11 @@ class AutoencoderKL(_ParamTree):
         sf = float(self.scale_factor)
         key = (T, F, sf, self.debug_taps, self.device)
         ver = self._decoder_version()
-        grad = grad or (self._h_vae is not None and getattr(self, "_h_vae_grad", False))
-        if (self._h_vae is None or self._h_vae_key[1:] != key or B > self._h_vae_key[0]
-                or ver != self._h_vae_ver or grad != getattr(self, "_h_vae_grad", False)):
-            if self._h_vae is not None:
-                L_.ctta_vae_destroy(self._h_vae)
-                self._h_vae = None
+        e = self._eng["vae"][int(grad)]
+        if e is None or e["key"] != key or B > e["B"] or ver != e["ver"]:
+            if e is not None:
+                L_.ctta_vae_destroy(e["h"])
+                self._eng["vae"][int(grad)] = None
             dd = self.ddconfig
             c = N.VAEConfig()
             c.z_channels, c.embed_dim, c.ch, c.out_ch = dd["z_channels"], self.embed_dim, dd["ch"], dd["out_ch"]
@@ -687,7 +697,8 @@ class AutoencoderKL(_ParamTree):
             c.max_batch, c.latent_h, c.latent_w = B, T, F
             c.debug_taps = int(self.debug_taps)
             c.enable_grad = int(grad)
-            self._h_vae_grad, self._vae_pending = grad, None
+            if grad:
+                self._vae_pending = None
             sd = OrderedDict((k, p.detach()) for k, p in self.named_parameters()
                              if k.startswith(("decoder.", "post_quant_conv.")))
             for k, p in sd.items():
@@ -697,19 +708,19 @@ class AutoencoderKL(_ParamTree):
             h = N.c_void_p()
             with torch.cuda.device(self.device):
                 N.check(L_.ctta_vae_create(c, table, len(table), N.stream_ptr(), h))
-            self._h_vae, self._h_vae_key, self._h_vae_ver = h, (B,) + key, ver
-        return self._h_vae
+            e = self._eng["vae"][int(grad)] = {"h": h, "key": key, "B": B, "ver": ver}
+        self._h_vae = e["h"]
+        return e["h"]
 
     def _ensure_voc(self, B, frames, grad=False):
         L_ = N.lib()
         ver = sum(p._version for p in self.vocoder.parameters())
         key = (self.debug_taps, self.device)
-        grad = grad or (self._h_voc is not None and getattr(self, "_h_voc_grad", False))
-        if (self._h_voc is None or self._h_voc_key[2:] != key or B > self._h_voc_key[0]
-                or frames > self._h_voc_key[1] or ver != self._h_voc_ver or grad != getattr(self, "_h_voc_grad", False)):
-            if self._h_voc is not None:
-                L_.ctta_hifigan_destroy(self._h_voc)
-                self._h_voc = None
+        e = self._eng["voc"][int(grad)]
+        if e is None or e["key"] != key or B > e["B"] or frames > e["frames"] or ver != e["ver"]:
+            if e is not None:
+                L_.ctta_hifigan_destroy(e["h"])
+                self._eng["voc"][int(grad)] = None
             h_ = self.vocoder.h
             c = N.HifiganConfig()
             c.num_mels, c.upsample_initial_channel = h_["num_mels"], h_["upsample_initial_channel"]
@@ -722,7 +733,8 @@ class AutoencoderKL(_ParamTree):
                     c.resblock_dilations[j][m] = dil[m]
             c.max_batch, c.max_frames, c.debug_taps = B, frames, int(self.debug_taps)
             c.enable_grad = int(grad)
-            self._h_voc_grad, self._voc_pending = grad, None
+            if grad:
+                self._voc_pending = None
             sd = OrderedDict(("vocoder." + k, p.detach()) for k, p in self.vocoder.named_parameters())
             for k, p in sd.items():
                 if not p.is_cuda:
@@ -731,8 +743,9 @@ class AutoencoderKL(_ParamTree):
             h = N.c_void_p()
             with torch.cuda.device(self.device):
                 N.check(L_.ctta_hifigan_create(c, table, len(table), N.stream_ptr(), h))
-            self._h_voc, self._h_voc_key, self._h_voc_ver = h, (B, frames) + key, ver
-        return self._h_voc
+            e = self._eng["voc"][int(grad)] = {"h": h, "key": key, "B": B, "frames": frames, "ver": ver}
+        self._h_voc = e["h"]
+        return e["h"]
 
     # ---- reference API
     def decode(self, z, use_ema=False):
@@ -748,14 +761,13 @@ class AutoencoderKL(_ParamTree):
             raise ValueError("z must be (batch, %d, T, F), got %s" % (self.embed_dim, tuple(z.shape)))
         if not z.is_cuda:
             raise N.CttaError("z is on %s: the HIP engine has no CPU path" % z.device)
-        if allow_grad:
+        if allow_grad and torch.is_grad_enabled() and z.requires_grad:
             return _VaeDecodeWithGrad.apply(z, self)
         B, _, T, F = z.shape
         h = self._ensure_vae(B, T, F)
         zz = z.detach().to(device=self.device, dtype=torch.float32).contiguous()
         up = 2 ** (len(self.ddconfig["ch_mult"]) - 1)
         mel = torch.empty((B, self.ddconfig["out_ch"], T * up, F * up), dtype=torch.float32, device=self.device)
-        self._vae_pending = None
         with torch.cuda.device(self.device):
             N.check(N.lib().ctta_vae_decode(h, N.ptr(zz), B, N.ptr(mel), N.stream_ptr()))
         return mel
@@ -771,7 +783,6 @@ class AutoencoderKL(_ParamTree):
         m = mel.detach().to(device=self.device, dtype=torch.float32).contiguous()
         n = N.lib().ctta_hifigan_out_len(h, T)
         wav = torch.empty((B, n), dtype=torch.float32, device=self.device)
-        self._voc_pending = None
         with torch.cuda.device(self.device):
             N.check(N.lib().ctta_hifigan_forward(h, N.ptr(m), B, T, N.ptr(wav), N.stream_ptr()))
         return wav
@@ -782,7 +793,8 @@ class AutoencoderKL(_ParamTree):
         float tensor on the device.  allow_grad=True returns the centred float waveform with a graph back to `dec`
         (utilities.py:79-81; the centring's max/min run as torch ops on the vocoder's differentiable output)."""
         if allow_grad:
-            wavs = _VocodeWithGrad.apply(dec, self).float()
+            need_graph = torch.is_grad_enabled() and dec.requires_grad
+            wavs = (_VocodeWithGrad.apply(dec, self) if need_graph else self.vocode(dec)).float()
             return wavs - (wavs.max() + wavs.min()) / 2
         wav = self.vocode(dec)
         scratch = torch.empty(4, dtype=torch.float32, device=wav.device)

@@ -164,3 +164,14 @@ def gdm_inference(n, sd, P, noise, w_in, num_steps):
         v = unet_forward(n.cfg, sd, z, float(t), float(w_in), P["embeds"], P["mask"])
         z = ddim.ddim_step(v, torch.full((B,), int(t)), z, num_steps, ac)
     return z
+
+
+def mel_loss_instances(dd, sd, pred, target, scale_factor, mse_weight=.7, mel_weight=.3):
+    """MelLoss.forward (tools/losses.py:47-64), reduction='instance': 0.3 * mse(decode(pred), decode(target)) +
+    0.7 * mse(pred, target), each a mean over everything but the batch axis.  Differentiable in `pred`."""
+    from .nets import vae_decode
+    mel_p = vae_decode(dd, sd, pred.float(), scale_factor)
+    mel_t = vae_decode(dd, sd, target.float(), scale_factor)
+    l_mel = ((mel_p - mel_t) ** 2).reshape(pred.shape[0], -1).mean(dim=1) * mel_weight
+    l_lat = ((pred.float() - target.float()) ** 2).reshape(pred.shape[0], -1).mean(dim=1) * mse_weight
+    return l_mel + l_lat

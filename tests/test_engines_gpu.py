@@ -390,8 +390,15 @@ def test_differentiable_decode_gradients_against_reference_golden(golden):
     (mel2 * dirm.to(DEV)).sum().backward()
     _check("decoder d/d z vs oracle autograd", z2.grad, zo.grad)
 
-    # a plain decode in between invalidates the pending differentiable forward: loud error, not stale gradients
-    mel3 = v.decode_first_stage(z.to(DEV).requires_grad_(True), allow_grad=True)
-    v.decode_first_stage(z.to(DEV))
+    # plain decodes (own handle) do not disturb a pending differentiable one -- MelLoss decodes input AND target;
+    # a second differentiable decode does: loud error on the stale graph, not stale gradients
+    z3 = z.to(DEV).requires_grad_(True)
+    mel3 = v.decode_first_stage(z3, allow_grad=True)
+    plain = v.decode_first_stage(z.to(DEV), allow_grad=True)      # no grad wanted -> plain path
+    assert not plain.requires_grad
+    (mel3 * dirm.to(DEV)).sum().backward()
+    _check("decoder d/d z with a plain decode in between", z3.grad, zo.grad)
+    mel4 = v.decode_first_stage(z.to(DEV).requires_grad_(True), allow_grad=True)
+    v.decode_first_stage(z.to(DEV).requires_grad_(True), allow_grad=True)
     with pytest.raises(N.CttaError):
-        mel3.sum().backward()
+        mel4.sum().backward()

@@ -114,6 +114,19 @@ def test_differentiable_decode_gradients(golden):
     close(z.grad, g["grad_z"], rtol=1e-4, atol=1e-6)
 
 
+def test_mel_loss_and_its_latent_gradient(golden):
+    """tools.losses.MelLoss over the reference VAE: instance losses and d(weighted mean)/d(predicted latent)."""
+    from oracle import distill
+    g = golden("melloss_tiny")
+    sd = dict(cases.vae_weights(cases.TINY_VAE_DD))
+    pred = (cases.vae_inputs(2, 16, 16, "melloss.pred") * 0.5).requires_grad_(True)
+    target = cases.vae_inputs(2, 16, 16, "melloss.target") * 0.5
+    inst = distill.mel_loss_instances(cases.TINY_VAE_DD, sd, pred, target, float(g["scale_factor"]))
+    (inst * torch.from_numpy(g["weights"])).mean().backward()
+    close(inst.detach(), g["instance_loss"])
+    close(pred.grad, g["grad_pred"], rtol=1e-4, atol=1e-7)
+
+
 @pytest.mark.slow
 def test_vae_hifigan_full_width(golden):
     g = golden("vae_full")

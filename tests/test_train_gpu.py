@@ -325,3 +325,95 @@ def test_real_training_step_from_waveforms(golden):
     before = opt.flat.detach().clone()
     loss = m.train_step(z0, P, opt, None)
     assert loss == loss and loss > 0 and not torch.equal(opt.flat, before)
+
+
+# ------------------------------------------------------------------------------------------------
+# Perceptual losses on the differentiable decode (tools/losses.py MelLoss / CLAPLoss path).
+def _tiny_vae(scale_factor):
+    from consistencytta_amd import modules
+    v = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, scale_factor=scale_factor,
+                              hifigan_config=cases.TINY_HIFIGAN)
+    sd = dict(cases.vae_weights(cases.TINY_VAE_DD))
+    sd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
+    v.load_state_dict(sd)
+    return v.to(DEV).eval().requires_grad_(False), sd
+
+
+def test_mel_loss_against_reference_golden(golden):
+    from consistencytta_amd import losses
+    g = golden("melloss_tiny")
+    vae, _ = _tiny_vae(float(g["scale_factor"]))
+    pred = (cases.vae_inputs(2, 16, 16, "melloss.pred") * 0.5).to(DEV).requires_grad_(True)
+    target = (cases.vae_inputs(2, 16, 16, "melloss.target") * 0.5).to(DEV)
+    inst = losses.MelLoss(vae=vae, reduction="instance")(pred, target, None, None)
+    (inst * torch.from_numpy(g["weights"]).to(DEV)).mean().backward()
+    ref = torch.from_numpy(g["instance_loss"])
+    assert float((inst.detach().cpu() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+    gr = torch.from_numpy(g["grad_pred"])
+    rel = float((pred.grad.cpu() - gr).norm() / gr.norm())
+    print("MelLoss d/d latent vs the reference's autograd: rel_l2 %.3e" % rel)
+    assert rel <= 2.5e-2
+    with pytest.raises(RuntimeError):
+        losses.CLAPLoss(vae=vae)
+
+
+def test_distillation_with_mel_loss_backward_matches_oracle_autograd(golden):
+    """AudioLCM(loss_type='mel'): the loss graph runs student U-Net -> frozen VAE decoder (HIP backward) -> MelLoss;
+    parameter gradients against torch autograd over the oracle with the reference's recorded random draws."""
+    from consistencytta_amd.models import AudioLCM
+    from oracle import distill
+    g = golden("distill_tiny")
+    sf = 0.9227914214134216
+    vae, vsd = _tiny_vae(sf)
+    cfg = cases.TINY_UNET
+    m = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                 unet_model_config_path="tiny_light.json", unet_config=cfg, snr_gamma=5.0, use_edm=True,
+                 teacher_guidance_scale=-1, num_diffusion_steps=18, vae=vae, loss_type="mel",
+                 target_ema_decay=0.95, ema_decay=0.999)
+    m.teacher_unet.load_state_dict(cases.unet_weights(cfg, False, 0))
+    m.student_unet.load_state_dict(cases.unet_weights(cfg, True, 1))
+    m.student_target_unet.load_state_dict(cases.unet_weights(cfg, True, 2))
+    m.student_ema_unet.load_state_dict(cases.unet_weights(cfg, True, 3))
+    m.to(DEV)
+    P = {k: v.to(DEV) for k, v in cases.prompt_states(cfg, 3, 6, "distill").items()}
+    z0 = (cases.t(spec.det_uniform("distill.z0", (3, 8, 32, 8), 14)) * 0.9).to(DEV)
+    m.train()
+    draws = dict(time_inds=torch.from_numpy(g["time_inds"]) * 2, gaussian_noise=torch.from_numpy(g["noise"]).to(DEV),
+                 guidance_scale=torch.from_numpy(g["guidance"]))
+    loss = m(z0, None, P, **draws)
+    assert loss.requires_grad
+    loss.backward()
+    torch.cuda.synchronize()
+    grads = {k: p.grad for k, p in m.student_unet.named_parameters() if p.requires_grad}
+    assert all(p.grad is None for p in vae.parameters())
+
+    # oracle
+    student = {k: v.clone().requires_grad_(k != "guidance_proj.weight") for k, v in cases.unet_weights(cfg, True, 1).items()}
+    n = distill.Nets(cfg, cases.unet_weights(cfg, False, 0), student, cases.unet_weights(cfg, True, 2),
+                     cases.unet_weights(cfg, True, 3))
+    Pc = cases.prompt_states(cfg, 3, 6, "distill")
+    z0c = z0.cpu()
+    noise, inds, w = torch.from_numpy(g["noise"]), torch.from_numpy(g["time_inds"]) * 2, torch.from_numpy(g["guidance"])
+    with torch.no_grad():
+        ts, sig = distill._tables()
+        z_np1_scaled, t_np1, zhat, zhat_scaled, t_n, s_np1 = distill._teacher_two_queries(n, Pc, z0c, noise, inds, w, ts, sig)
+        target = onets.unet_forward(cfg, n.target, zhat_scaled, t_n, w, Pc["embeds"], Pc["mask"])
+        target = torch.where((t_n == 0).reshape(-1, 1, 1, 1), z0c, target)
+    pred = onets.unet_forward(cfg, student, z_np1_scaled, t_np1, w, Pc["embeds"], Pc["mask"])
+    inst = distill.mel_loss_instances(cases.TINY_VAE_DD, vsd, pred, target, sf)
+    ref_loss = (inst * torch.clamp(s_np1.float() ** -2, max=5.0)).mean()
+    ref_loss.backward()
+    ref = {k: p.grad for k, p in student.items() if p.requires_grad}
+    print("mel-loss distillation: loss %.6f (oracle %.6f)" % (float(loss), float(ref_loss)))
+    assert abs(float(loss) - float(ref_loss)) <= 5e-2 * float(ref_loss)
+    total, worst = _compare(grads, ref)
+    assert np.isfinite(total) and total <= 1.5 * GRAD_REL_L2_ALL
+
+    # one full optimizer step through the same path
+    for p in m.student_unet.parameters():
+        p.grad = None
+    opt = m.prepare_training(lr=1e-5, weight_decay=1e-4, broadcast=False)
+    before = m.student_unet.flatten_parameters_().clone()
+    value = m.train_step(z0, P, opt, **draws)
+    assert abs(value - float(ref_loss)) <= 5e-2 * float(ref_loss)
+    assert float((m.student_unet.flatten_parameters_() - before).abs().max()) > 0
