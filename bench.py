@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--text-len", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", choices=("both", "gen", "distill", "teacher"), default="both",
+    ap.add_argument("--mode", choices=("both", "gen", "distill", "teacher", "perceptual"), default="both",
                     help="both (default): configs[1] generation line + `distill` (configs[3]) and `teacher` (configs[2]) "
                          "objects; gen / distill / teacher: only that leg (profiling aids)")
     ap.add_argument("--teacher-steps", type=int, default=200, help="Heun steps of the teacher leg (2N-1 U-Net queries)")
@@ -53,13 +53,15 @@ def parse():
     ap.add_argument("--distill-batch", type=int, default=9, help="per-GPU micro-batch of the distillation leg (train.sh)")
     ap.add_argument("--no-latency", action="store_true",
                     help="skip the single-clip eager/hipGraph latency leg (graph replay hangs under rocprofv3 --pmc)")
+    ap.add_argument("--perceptual-batch", type=int, default=4,
+                    help="per-GPU micro-batch of the perceptual-loss leg (configs[4] without CLAP)")
     ap.add_argument("--profile-csv", default=None, help="append one line per MFMA launch (tuning aid)")
     return ap.parse_args()
 
 
 def main():
     args = parse()
-    if args.mode == "distill":
+    if args.mode in ("distill", "perceptual"):
         args.no_cpu_baseline = True
     import torch
 
@@ -82,8 +84,8 @@ def main():
             print(json.dumps(d), flush=True)
         du.finish()
         return
-    if args.mode == "distill":   # profiling aid: only the distillation leg, printed as the JSON line
-        d = distill_leg(args, dev, world, rank)
+    if args.mode in ("distill", "perceptual"):   # profiling aid: only that leg, printed as the JSON line
+        d = distill_leg(args, dev, world, rank, perceptual=args.mode == "perceptual")
         if rank == 0:
             d.update({"steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
                       "data": "synthetic"})
@@ -247,6 +249,14 @@ def main():
         t = teacher_leg(args, dev, world, rank)
         if rank == 0:
             result["teacher"] = t
+        gc.collect()
+        torch.cuda.empty_cache()
+        try:
+            pd_ = distill_leg(args, dev, world, rank, perceptual=True)
+        except Exception as exc:   # the newest leg must not cost the headline line
+            pd_ = {"error": str(exc)[:300]}
+        if rank == 0:
+            result["perceptual_distill"] = pd_
     if rank == 0:
         print(json.dumps(result), flush=True)
     du.finish()
@@ -310,8 +320,13 @@ def teacher_leg(args, dev, world, rank):
 GF_DISTILL_PER_SAMPLE = 4200.0   # 4 teacher + 1 target + 1 student fwd + 1 student bwd (~2 fwd)
 
 
-def distill_leg(args, dev, world, rank):
-    """BASELINE.json configs[3] (SURVEY.md §8d "Config 4"): one consistency-distillation optimisation step
+def distill_leg(args, dev, world, rank, perceptual=False):
+    """perceptual=True: BASELINE.json configs[4] as far as it can be built offline -- the same distillation step with
+    the waveform-domain loss path of the CLAP fine-tuning stage (tools/losses.py:294-298): student latent -> VAE
+    decode -> HiFi-GAN with allow_grad=True, loss on the waveform (multi-resolution STFT; CLAP itself needs weights
+    that are not available), gradient back through vocoder and decoder (frozen) into the student U-Net.
+
+    Otherwise BASELINE.json configs[3] (SURVEY.md §8d "Config 4"): one consistency-distillation optimisation step
     per GPU micro-batch of 9 latents -- 2 CFG teacher queries (batch 18 each) + Heun, target-network
     forward, student forward + backward, SUM all-reduce of the 559 M fp32 gradients over RCCL, fused
     AdamW (lr 1e-5, wd 1e-4), two-shadow EMA (0.95 / 0.999).  All four U-Nets use the light config and
@@ -325,12 +340,19 @@ def distill_leg(args, dev, world, rank):
     from consistencytta_amd.models import AudioLCM
     from consistencytta_amd.optim import WarmupSchedule
 
-    B, L = args.distill_batch, args.text_len
+    B, L = (args.perceptual_batch if perceptual else args.distill_batch), args.text_len
     t_build = time.perf_counter()
+    vae = None
+    if perceptual:
+        from consistencytta_amd import modules
+        vae = modules.AutoencoderKL(ddconfig=spec.VAE_DDCONFIG, embed_dim=8, scale_factor=0.9227914214134216)
+        vae.to(dev)
+        vae.init_random_(seed=12)
+        vae.eval().requires_grad_(False)
     m = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
                  unet_model_config_path="tango_diffusion_light.json", unet_config=spec.LIGHT_UNET_CONFIG, snr_gamma=5.0,
-                 use_edm=True, teacher_guidance_scale=-1, num_diffusion_steps=18, vae=None, loss_type="mse",
-                 target_ema_decay=0.95, ema_decay=0.999)
+                 use_edm=True, teacher_guidance_scale=-1, num_diffusion_steps=18, vae=vae,
+                 loss_type="stft" if perceptual else "mse", target_ema_decay=0.95, ema_decay=0.999)
     m.to(dev)
     m.teacher_unet.init_random_(seed=10)
     m.student_unet.init_random_(seed=11)
@@ -374,6 +396,14 @@ def distill_leg(args, dev, world, rank):
                    "parallelism": "dp%d" % world},
         "loss_first_last": [round(losses[0], 6), round(losses[-1], 6)], "build_s": round(build_s, 1),
     }
+    if perceptual:
+        out["metric"] = "perceptual_distillation_steps_per_sec"
+        out["config"]["workload"] = ("configs[4] without CLAP (weights unavailable offline): distillation step whose loss "
+                                     "decodes the student latent to a waveform with allow_grad=True (VAE decoder + HiFi-GAN "
+                                     "forward and input-gradient passes on HIP), multi-resolution STFT loss, U-Net backward, "
+                                     "AdamW, EMA")
+        del m, opt, vae
+        return out
     if rank == 0:
         import ctypes
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

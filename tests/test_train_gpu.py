@@ -417,3 +417,32 @@ def test_distillation_with_mel_loss_backward_matches_oracle_autograd(golden):
     value = m.train_step(z0, P, opt, **draws)
     assert abs(value - float(ref_loss)) <= 5e-2 * float(ref_loss)
     assert float((m.student_unet.flatten_parameters_() - before).abs().max()) > 0
+
+
+def test_multi_resolution_stft_loss_runs_through_the_differentiable_vocoder():
+    """MultiResolutionSTFTLoss (tools/losses.py:187-256): latent -> mel -> waveform with allow_grad=True on the HIP
+    engines, three STFT resolutions in torch.  Value against the same formula over the oracle's fp32 waveforms; the
+    latent gradient must exist and be finite (its LeakyReLU-mask sensitivity is covered in test_engines_gpu.py)."""
+    from consistencytta_amd import losses
+    from oracle import nets
+    sf = 0.9227914214134216
+    vae, sd = _tiny_vae(sf)
+    pred = (cases.vae_inputs(2, 16, 16, "stftloss.pred") * 0.5).to(DEV).requires_grad_(True)
+    target = (cases.vae_inputs(2, 16, 16, "stftloss.target") * 0.5).to(DEV)
+    crit = losses.MultiResolutionSTFTLoss(vae=vae, reduction="instance", factor_sc=0.1, factor_mag=0.1, factor_mse=.8).to(DEV)
+    inst = crit(pred, target, None, None)
+    inst.mean().backward()
+    assert inst.shape == (2,) and torch.isfinite(inst).all()
+    assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().max()) > 0
+
+    class _CpuVae:   # the oracle behind the two methods the loss calls
+        def decode_first_stage(self, z, allow_grad=False):
+            return nets.vae_decode(cases.TINY_VAE_DD, sd, z, sf)
+
+        def decode_to_waveform(self, mel, allow_grad=False):
+            return nets.mel_to_waveform(cases.TINY_HIFIGAN, sd, mel)[1]
+    with torch.no_grad():
+        ref = losses.MultiResolutionSTFTLoss(vae=_CpuVae(), reduction="instance", factor_sc=0.1, factor_mag=0.1,
+                                             factor_mse=.8)(pred.detach().cpu(), target.cpu(), None, None)
+    print("stft loss", inst.detach().cpu().numpy(), "oracle", ref.numpy())
+    assert float((inst.detach().cpu() - ref).abs().max()) <= 5e-2 * float(ref.abs().max())
