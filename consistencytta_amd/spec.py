@@ -287,6 +287,38 @@ def hifigan_param_spec(h=HIFIGAN_16K_64, prefix="vocoder."):
     return sd
 
 
+# FLAN-T5-large encoder (google/flan-t5-large config.json; the reference's text encoder,
+# models/audio_distilled_model.py:97-98).  Weights are not available offline: shapes and key order only.
+T5_LARGE_CONFIG = {
+    "vocab_size": 32128, "d_model": 1024, "d_kv": 64, "d_ff": 2816, "num_layers": 24, "num_heads": 16,
+    "relative_attention_num_buckets": 32, "relative_attention_max_distance": 128, "layer_norm_epsilon": 1e-6,
+    "feed_forward_proj": "gated-gelu", "tie_word_embeddings": False,
+}
+
+
+def t5_encoder_param_spec(cfg=T5_LARGE_CONFIG):
+    """transformers.T5EncoderModel.state_dict() keys in order (`encoder.embed_tokens.weight` is the same tensor as
+    `shared.weight`)."""
+    sd = OrderedDict()
+    d, inner, ff = cfg["d_model"], cfg["num_heads"] * cfg["d_kv"], cfg["d_ff"]
+    sd["shared.weight"] = (cfg["vocab_size"], d)
+    sd["encoder.embed_tokens.weight"] = (cfg["vocab_size"], d)
+    for i in range(cfg["num_layers"]):
+        p = "encoder.block.%d.layer." % i
+        for n in ("q", "k", "v"):
+            sd[p + "0.SelfAttention.%s.weight" % n] = (inner, d)
+        sd[p + "0.SelfAttention.o.weight"] = (d, inner)
+        if i == 0:
+            sd[p + "0.SelfAttention.relative_attention_bias.weight"] = (cfg["relative_attention_num_buckets"], cfg["num_heads"])
+        sd[p + "0.layer_norm.weight"] = (d,)
+        sd[p + "1.DenseReluDense.wi_0.weight"] = (ff, d)
+        sd[p + "1.DenseReluDense.wi_1.weight"] = (ff, d)
+        sd[p + "1.DenseReluDense.wo.weight"] = (d, ff)
+        sd[p + "1.layer_norm.weight"] = (d,)
+    sd["encoder.final_layer_norm.weight"] = (d,)
+    return sd
+
+
 # ----------------------------------------------------------------------------------------
 # Deterministic generator: value i of tensor `name` is a pure function of (seed, name, i).
 # splitmix64 counter stream -> 24-bit uniform -> float32; only IEEE basic ops, so the

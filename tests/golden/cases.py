@@ -86,3 +86,23 @@ def prompt_states(cfg, B, L, tag):
     umask = torch.zeros(B, L, dtype=torch.bool)
     umask[:, 0] = True        # "" pads to the cond length: one valid token (audio_distilled_model.py:230-233)
     return dict(embeds_cf=torch.cat([uncond, cond]), mask_cf=torch.cat([umask, cmask]), embeds=cond, mask=cmask)
+
+
+# Text encoder: a small T5 (d_kv stays 64 like every T5 size) and FLAN-T5-large's widths at 2 layers.
+TINY_T5 = dict(spec.T5_LARGE_CONFIG, vocab_size=512, d_model=256, d_ff=512, num_layers=3, num_heads=4)
+WIDE_T5 = dict(spec.T5_LARGE_CONFIG, vocab_size=1024, num_layers=2)
+
+
+def t5_weights(cfg, seed=0):
+    sp = spec.t5_encoder_param_spec(cfg)
+    sd = {k: t(v) for k, v in spec.det_state_dict(sp, seed, prefix="t5.").items() if k != "encoder.embed_tokens.weight"}
+    sd["encoder.embed_tokens.weight"] = sd["shared.weight"]
+    return sd
+
+
+def t5_inputs(cfg, B, L, tag):
+    ids = (np.abs(spec.det_uniform(tag + ".ids", (B, L), 31)) * (cfg["vocab_size"] - 1)).astype(np.int64)
+    lens = (np.abs(spec.det_uniform(tag + ".len", (B,), 32)) * (L - 1)).astype(np.int64) + 1
+    lens[0] = L
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    return t(ids), t(mask)

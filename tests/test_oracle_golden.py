@@ -127,6 +127,22 @@ def test_mel_loss_and_its_latent_gradient(golden):
     close(pred.grad, g["grad_pred"], rtol=1e-4, atol=1e-7)
 
 
+def test_t5_encoder_restatement_against_transformers(golden):
+    """oracle.t5 vs transformers.T5EncoderModel (the reference's text encoder, audio_distilled_model.py:97-98,208-214):
+    padded batches, a sequence longer than max_distance (all 32 relative-position buckets), FLAN-T5-large's widths."""
+    from oracle import t5
+    g = golden("t5_encoder")
+    for name, cfg, B, L, tag in (("tiny", cases.TINY_T5, 3, 13, "t5_tiny"), ("tiny_long", cases.TINY_T5, 2, 150, "t5_long"),
+                                 ("wide", cases.WIDE_T5, 2, 16, "t5_wide")):
+        ids, mask = cases.t5_inputs(cfg, B, L, tag)
+        with torch.no_grad():
+            out = t5.t5_encode(cfg, cases.t5_weights(cfg), ids, mask)
+        close(out, g[name])
+    # known answers of the bucket function (modeling_t5.py _relative_position_bucket, bidirectional, 32 / 128)
+    rp = torch.tensor([0, 1, -1, 7, 8, -8, 15, 16, 64, 127, 128, 1000, -1000])
+    assert t5.relative_position_bucket(rp).tolist() == [0, 17, 1, 23, 24, 8, 25, 26, 30, 31, 31, 31, 15]
+
+
 @pytest.mark.slow
 def test_vae_hifigan_full_width(golden):
     g = golden("vae_full")
