@@ -45,6 +45,14 @@ class VAEConfig(Structure):
     ]
 
 
+class T5Config(Structure):
+    _fields_ = [
+        ("vocab_size", c_int), ("d_model", c_int), ("d_kv", c_int), ("d_ff", c_int), ("num_layers", c_int),
+        ("num_heads", c_int), ("rel_buckets", c_int), ("rel_max_distance", c_int), ("eps", c_float),
+        ("max_batch", c_int), ("max_len", c_int),
+    ]
+
+
 class HifiganConfig(Structure):
     _fields_ = [
         ("num_mels", c_int), ("upsample_initial_channel", c_int), ("n_ups", c_int),
@@ -116,6 +124,12 @@ SIGNATURES = {
     "ctta_unet_tap_read": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "ctta_vae_create": (c_int, [POINTER(VAEConfig), POINTER(Tensor), c_int, c_void_p, POINTER(c_void_p)]),
     "ctta_vae_destroy": (None, [c_void_p]),
+    "ctta_t5_create": (c_int, [POINTER(T5Config), POINTER(Tensor), c_int, c_void_p, POINTER(c_void_p)]),
+    "ctta_t5_destroy": (None, [c_void_p]),
+    "ctta_t5_encode": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_t5_arena_bytes": (c_size_t, [c_void_p]),
+    "ctta_attention_rel": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p,
+                                   c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "ctta_vae_decode": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "ctta_vae_decode_with_grad": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "ctta_vae_decode_backward": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

@@ -26,10 +26,14 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 #define ATT_LDK 80         // K tile row stride (bf16): 160 B rows are conflict-free for ds_read_b128
 #define ATT_LDV 72         // V^T tile row stride: 144 B rows are conflict-free for the paired ds_read_b64
 
+// REL: additionally adds rel_bias[h][key - query + nq - 1] (already in the log2 domain) -- T5's relative position bias
+// (one table per head over the nq + nk - 1 possible offsets); q / out batches are then q_rows rows apart.
+template <bool REL>
 __global__ __launch_bounds__(256, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int q_ld, const bf16_t* __restrict__ k, int k_ld, int k_rows,
     const bf16_t* __restrict__ vt, int vt_ld, const float* __restrict__ bias,
-    bf16_t* __restrict__ out, int out_ld, int heads, int nq, int nk, float scale_log2e, float* __restrict__ lse) {
+    bf16_t* __restrict__ out, int out_ld, int heads, int nq, int nk, float scale_log2e, float* __restrict__ lse,
+    int q_rows, const float* __restrict__ rel_bias) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[ATT_KT * ATT_LDK];   // [key][d]
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * ATT_LDV];       // [d][key]
 
@@ -40,10 +44,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   const int lq = lane & 15;        // query column within a 16-block
   const int lg = lane >> 4;        // lane group 0..3
 
-  const bf16_t* qb = q + (size_t)b * nq * q_ld + h * 64;
+  const bf16_t* qb = q + (size_t)b * q_rows * q_ld + h * 64;
   const bf16_t* kb = k + (size_t)b * k_rows * k_ld + h * 64;
   const bf16_t* vb = vt + ((size_t)b * heads + h) * 64 * vt_ld;
   const float* bb = bias ? bias + (size_t)b * nk : nullptr;
+  const float* rb = REL ? rel_bias + (size_t)h * (nq + nk - 1) + (nq - 1) : nullptr;
 
   // Q^T fragments: B operand, lane j = query, 8 consecutive d at (ds*32 + lg*8)
   bf16x8_t qf[2][2];
@@ -136,11 +141,13 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 #pragma unroll
     for (int jq = 0; jq < 2; ++jq) {
       float mx = -INFINITY;
+      const int qrel = min(q0 + jq * 16 + lq, nq - 1);
 #pragma unroll
       for (int ik = 0; ik < 4; ++ik)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = s[ik][jq][r] * scale_log2e + kbias[ik][r];
+          float v = s[ik][jq][r] * scale_log2e + kbias[ik][r];
+          if (REL) v += rb[min(key0 + ik * 16 + lg * 4 + r, nk - 1) - qrel];
           s[ik][jq][r] = v;
           mx = fmaxf(mx, v);
         }
@@ -204,7 +211,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     // training: log2-domain log-sum-exp per query, so the backward pass can rebuild P = exp2(s - lse)
     if (lse && qi < nq && lg == 0) lse[((size_t)b * heads + h) * nq + qi] = mrun[jq] + log2f(l);
     if (qi < nq) {
-      bf16_t* orow = out + ((size_t)b * nq + qi) * out_ld + h * 64;
+      bf16_t* orow = out + ((size_t)b * q_rows + qi) * out_ld + h * 64;
 #pragma unroll
       for (int jd = 0; jd < 4; ++jd) {
         uint2 pk;
@@ -234,9 +241,29 @@ extern "C" ctta_status ctta_attention_lse(const void* q, int q_ld, const void* k
   const bool prof = ctta_prof_active();
   // executed flops: QK^T and PV over the padded head dim (2 * 2*nq*nk*64 per head)
   if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
+  hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
                      (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, bias, (bf16_t*)out, out_ld, heads,
-                     nq, nk, scale * 1.4426950408889634f, lse);
+                     nq, nk, scale * 1.4426950408889634f, lse, nq, (const float*)nullptr);
+  if (prof) ctta_prof_end((hipStream_t)stream);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_attention_rel(const void* q, int q_ld, int q_rows, const void* k, int k_ld, int k_rows,
+                                          const void* vt, int vt_ld, const float* key_bias, const float* rel_bias_log2,
+                                          void* out, int out_ld, int batch, int heads, int nq, int nk, float scale,
+                                          void* stream) {
+  CTTA_REQUIRE(q && k && vt && out && rel_bias_log2, "attention_rel: null pointer");
+  CTTA_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vt_ld % 8 == 0 && out_ld % 4 == 0,
+               "attention_rel: row strides must be multiples of 8");
+  CTTA_REQUIRE(nq > 0 && nk > 0 && q_rows >= nq && k_rows >= nk && vt_ld >= ((nk + 7) / 8) * 8,
+               "attention_rel: bad lengths nq=%d nk=%d vt_ld=%d", nq, nk, vt_ld);
+  dim3 grid((nq + 127) / 128, batch * heads);
+  const bool prof = ctta_prof_active();
+  if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
+  hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
+                     (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, key_bias, (bf16_t*)out, out_ld, heads,
+                     nq, nk, scale * 1.4426950408889634f, (float*)nullptr, q_rows, rel_bias_log2);
   if (prof) ctta_prof_end((hipStream_t)stream);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;

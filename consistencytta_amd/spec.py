@@ -370,6 +370,8 @@ def weight_rule(name, shape):
     gain = 1.0
     if any(t in name for t in ("conv2.", "to_out.0.", "ff.net.2.", "proj_out.", "convs2.")):
         gain = 0.5  # residual-branch outputs
+    if "SelfAttention.q." in name:
+        gain = 0.125  # T5 folds the missing 1/sqrt(d_kv) score scaling into q's init: std (d_model * d_kv)^-0.5
     return 0.0, float(gain * np.sqrt(3.0 / fan_in))
 
 

@@ -171,6 +171,29 @@ void ctta_mel_frontend_destroy(ctta_mel_frontend* h);
 ctta_status ctta_wav_to_fbank(ctta_mel_frontend* h, const float* wav, int batch, int n_samples,
                               int target_length, float* fbank, float* logmag, void* stream);
 
+/* ------------------------------------------------------------------------------------ *
+ * Text encoder.  Replaces `self.text_encoder(input_ids=, attention_mask=)[0]` of
+ * models/audio_distilled_model.py:208-214 (transformers T5EncoderModel, FLAN-T5-large; weights in the
+ * T5EncoderModel state-dict layout: shared.weight, encoder.block.N.layer.{0.SelfAttention.{q,k,v,o},
+ * 0.layer_norm, 1.DenseReluDense.{wi_0,wi_1,wo}, 1.layer_norm}.weight, block 0's relative_attention_bias,
+ * encoder.final_layer_norm.weight).  gated-gelu feed-forward, d_kv = 64.
+ * ------------------------------------------------------------------------------------ */
+typedef struct {
+  int vocab_size, d_model, d_kv, d_ff, num_layers, num_heads;
+  int rel_buckets, rel_max_distance;   /* relative_attention_num_buckets / _max_distance */
+  float eps;                           /* layer_norm_epsilon */
+  int max_batch, max_len;              /* arena sizing */
+} ctta_t5_config;
+typedef struct ctta_t5 ctta_t5;
+ctta_status ctta_t5_create(const ctta_t5_config* cfg, const ctta_tensor* weights, int n_weights, void* stream,
+                           ctta_t5** out);
+void ctta_t5_destroy(ctta_t5* h);
+/* input_ids (B, L) int64, attention_mask (B, L) uint8 (1 = token, 0 = padding; every row needs one token)
+ * -> last_hidden_state (B, L, d_model) f32 */
+ctta_status ctta_t5_encode(ctta_t5* h, const int64_t* input_ids, const uint8_t* attention_mask, int batch, int len,
+                           float* last_hidden_state, void* stream);
+size_t ctta_t5_arena_bytes(const ctta_t5* h);
+
 typedef struct {
   int num_mels, upsample_initial_channel, n_ups, n_kernels;
   int upsample_rates[CTTA_MAX_UPS], upsample_kernel_sizes[CTTA_MAX_UPS];
@@ -373,6 +396,11 @@ ctta_status ctta_softmax_rows(const float* s, void* p, int64_t rows, int cols, f
  * q [B][nq][..] row stride q_ld, head h at column h*64; k [B][k_rows >= nk][..] likewise; vt is V
  * TRANSPOSED: [B][heads*64][vt_ld] (keys contiguous).  bias (B, nk) f32 additive per key or NULL.
  * softmax(q k^T * scale + bias) v  ->  out [B][nq][out_ld], head h at column h*64. */
+/* Same with a relative-position table added to the scores: rel_bias_log2 [heads][nq+nk-1], entry
+ * (key - query + nq - 1), ALREADY multiplied by log2(e); q / out batches are q_rows rows apart (T5 self-attention). */
+ctta_status ctta_attention_rel(const void* q, int q_ld, int q_rows, const void* k, int k_ld, int k_rows,
+                               const void* vt, int vt_ld, const float* key_bias, const float* rel_bias_log2,
+                               void* out, int out_ld, int batch, int heads, int nq, int nk, float scale, void* stream);
 ctta_status ctta_attention(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
                            int vt_ld, const float* bias, void* out, int out_ld, int batch,
                            int heads, int nq, int nk, float scale, void* stream);

@@ -402,3 +402,40 @@ def test_differentiable_decode_gradients_against_reference_golden(golden):
     v.decode_first_stage(z.to(DEV).requires_grad_(True), allow_grad=True)
     with pytest.raises(N.CttaError):
         mel4.sum().backward()
+
+
+def test_t5_encoder_against_transformers_golden_and_oracle(golden):
+    """The text encoder (models/audio_distilled_model.py:97-98,208-214) on the HIP engine vs the
+    installed transformers' own T5EncoderModel (fixture) and the oracle: ragged masks, a length that is not a multiple
+    of 8, a sequence spanning every relative-position bucket, FLAN-T5-large's widths; key order; error behaviour."""
+    from consistencytta_amd import text_encoder
+    from oracle import t5 as ot5
+    g = golden("t5_encoder")
+    for name, cfg, B, L, tag in (("tiny", cases.TINY_T5, 3, 13, "t5_tiny"), ("tiny_long", cases.TINY_T5, 2, 150, "t5_long"),
+                                 ("wide", cases.WIDE_T5, 2, 16, "t5_wide")):
+        m = text_encoder.T5EncoderModel(cfg)
+        assert list(m.state_dict().keys()) == list(spec.t5_encoder_param_spec(cfg).keys())
+        sd = cases.t5_weights(cfg)
+        m.load_state_dict(sd)
+        m.to(DEV).eval()
+        ids, mask = cases.t5_inputs(cfg, B, L, tag)
+        out = m(input_ids=ids.to(DEV), attention_mask=mask.to(DEV))
+        assert out[0] is out.last_hidden_state and tuple(out[0].shape) == (B, L, cfg["d_model"])
+        with torch.no_grad():
+            ref = ot5.t5_encode(cfg, sd, ids, mask)
+        valid = mask.bool()
+        # padded positions are computed by the reference too (and consumed nowhere): compared as well
+        _check("t5 %s vs oracle" % name, out[0], ref)
+        _check("t5 %s vs transformers" % name, out[0], torch.from_numpy(g[name]))
+        _check("t5 %s valid tokens vs transformers" % name, out[0].cpu()[valid], torch.from_numpy(g[name])[valid])
+        # smaller batch / shorter length on the same handle; batch independence
+        out1 = m(input_ids=ids[:1, :L - 3].to(DEV), attention_mask=torch.ones(1, L - 3, dtype=torch.long, device=DEV))
+        with torch.no_grad():
+            ref1 = ot5.t5_encode(cfg, sd, ids[:1, :L - 3], torch.ones(1, L - 3, dtype=torch.long))
+        _check("t5 %s shorter call vs oracle" % name, out1[0], ref1)
+    with pytest.raises(N.CttaError):
+        m(input_ids=ids, attention_mask=mask)                       # CPU tensors: no CPU path
+    with pytest.raises(IndexError):
+        m(input_ids=torch.full((1, 4), cfg["vocab_size"], device=DEV), attention_mask=torch.ones(1, 4, device=DEV))
+    with pytest.raises(ValueError):
+        m(input_ids=ids.to(DEV), attention_mask=torch.zeros_like(mask).to(DEV))
