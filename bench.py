@@ -202,6 +202,30 @@ def main():
         torch.cuda.synchronize()
         result["pcie_inclusive_clips_per_s"] = round(2 * B / (time.perf_counter() - t1), 3)
 
+        # ---- the text encoder in front of the clip (FLAN-T5-large shape, random init): cond + uncond batches of
+        # encode_text_classifier_free (audio_distilled_model.py:236-248) on the HIP engine
+        try:
+            from consistencytta_amd import text_encoder
+            te = text_encoder.T5EncoderModel(spec.T5_LARGE_CONFIG).to(dev)
+            te.init_random_(seed=7)
+            ids = torch.randint(2, 32000, (B, L), generator=torch.Generator().manual_seed(8)).to(dev)
+            am = mask.to(torch.int64)
+            for _ in range(2):
+                te(input_ids=ids, attention_mask=am)
+                te(input_ids=torch.ones_like(ids), attention_mask=am)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                te(input_ids=ids, attention_mask=am)
+                te(input_ids=torch.ones_like(ids), attention_mask=am)
+            torch.cuda.synchronize()
+            te_ms = (time.perf_counter() - t1) / 5 * 1e3
+            result["text_encoder_ms"] = round(te_ms, 3)
+            result["clips_per_s_incl_text_encoder"] = round(B / (B / result["value"] + te_ms * 1e-3), 3)
+            del te
+        except Exception as exc:
+            result["text_encoder_ms"] = {"error": str(exc)[:200]}
+
         # ---- single-clip latency (configs[0] shape: one prompt, L=16), eager launches vs one hipGraph replay
         try:
             if args.no_latency:

@@ -126,7 +126,8 @@ class AudioDistilledModel(nn.Module):
     def _require_text_encoder(self):
         if self.text_encoder is None or self.tokenizer is None:
             try:
-                from transformers import AutoTokenizer, T5EncoderModel
+                from transformers import AutoTokenizer
+                from .text_encoder import T5EncoderModel   # HIP engine behind transformers' T5EncoderModel interface
                 self.tokenizer = AutoTokenizer.from_pretrained(self.text_encoder_name)
                 self.text_encoder = T5EncoderModel.from_pretrained(self.text_encoder_name).to(self.device)
                 self.text_encoder.eval().requires_grad_(False)
@@ -872,6 +873,27 @@ class ConsistencyTTA(nn.Module):
 
         replay.graph, replay.outputs = graph, out
         return replay
+
+    # ---- text side, easy_inference/consistencytta.py:82-132 (FLAN-T5 on the HIP engine, tokenizer on the host)
+    @property
+    def device(self):
+        return self.unet.device
+
+    _require_text_encoder = AudioDistilledModel._require_text_encoder
+    encode_text = AudioDistilledModel.encode_text
+    encode_text_classifier_free = AudioDistilledModel.encode_text_classifier_free
+
+    @torch.no_grad()
+    def forward(self, prompt, cfg_scale_input=3., cfg_scale_post=1., num_steps=1, num_samples=1, sr=16000):
+        """easy_inference/consistencytta.py:135-200: prompts -> int16 waveforms (numpy), truncated to 9.5 s."""
+        self.check_eval_mode()
+        embeds_cf, mask_cf, embeds, mask = self.encode_text_classifier_free(prompt, num_samples)
+        B = embeds.shape[0]
+        noise = randn_tensor((B, self.unet.config.in_channels, 256, 16), device=embeds.device, dtype=torch.float32)
+        kw = {}
+        if cfg_scale_post > 1.:
+            kw = dict(uncond_states=embeds_cf[:B], uncond_mask=mask_cf[:B])
+        return self.forward_from_embeds(embeds, mask, noise, cfg_scale_input, cfg_scale_post, num_steps, sr, **kw)
 
     @torch.no_grad()
     def forward_from_embeds(self, encoder_states, encoder_mask, noise, cfg_scale_input=3., cfg_scale_post=1.,

@@ -236,3 +236,54 @@ def test_whole_pipeline_hipgraph_matches_eager():
         ref = vae.decode_to_waveform(mel)
         assert torch.equal(gen.outputs[0], lat) and torch.equal(gen.outputs[1], mel)
         assert np.array_equal(pcm.cpu().numpy(), ref)
+
+
+class _FakeTokenizer:
+    """Whitespace tokenizer with T5's calling convention (the sentencepiece model is not available offline)."""
+    model_max_length = 512
+
+    def __call__(self, prompt, max_length=None, padding=True, truncation=True, return_tensors="pt"):
+        max_length = max_length or self.model_max_length
+        rows = [[(sum(map(ord, w)) % 500) + 2 for w in p.split()][:max_length - 1] + [1] for p in prompt]
+        width = max_length if padding == "max_length" else max(len(r) for r in rows)
+        ids = torch.zeros(len(rows), width, dtype=torch.long)
+        mask = torch.zeros(len(rows), width, dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, :len(r)] = torch.tensor(r)
+            mask[i, :len(r)] = 1
+        return type("Batch", (), {"input_ids": ids, "attention_mask": mask})()
+
+
+def test_prompt_to_waveform_with_the_hip_text_encoder():
+    """easy_inference ConsistencyTTA.forward (consistencytta.py:135-200) end to end on the HIP engines: tokenizer (host)
+    -> T5 encoder -> CFG batch -> U-Net -> VAE -> HiFi-GAN; equals the embedding-level entry point fed with the oracle's
+    T5 states within the path tolerance, for cfg_scale_post = 1 and > 1."""
+    from consistencytta_amd import modules, text_encoder
+    from consistencytta_amd.models import ConsistencyTTA
+    from oracle import t5 as ot5
+    cfg = dict(cases.TINY_UNET, cross_attention_dim=cases.TINY_T5["d_model"])
+    vae = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, scale_factor=0.9, hifigan_config=cases.TINY_HIFIGAN)
+    te = text_encoder.T5EncoderModel(cases.TINY_T5)
+    tsd = cases.t5_weights(cases.TINY_T5)
+    te.load_state_dict(tsd)
+    pipe = ConsistencyTTA(unet_config=cfg, vae=vae, text_encoder=te, tokenizer=_FakeTokenizer())
+    pipe.to(DEV)
+    pipe.unet.init_deterministic(1)
+    vae.init_deterministic(2)
+    pipe.eval().requires_grad_(False)
+    prompts = ["a dog barks twice", "rain"]
+    emb_cf, mask_cf, emb, mask = pipe.encode_text_classifier_free(prompts, 1)
+    assert emb.shape == (2, 5, 256) and emb_cf.shape == (4, 5, 256) and mask.dtype == torch.bool
+    tok = _FakeTokenizer()(prompts)
+    with torch.no_grad():
+        ref = ot5.t5_encode(cases.TINY_T5, tsd, tok.input_ids, tok.attention_mask)
+    assert rel_l2(emb, ref) <= REL_L2
+    for post in (1.0, 2.0):
+        torch.manual_seed(5)
+        pcm = pipe(prompts, cfg_scale_input=4.0, cfg_scale_post=post, num_steps=1)
+        assert pcm.dtype == np.int16 and pcm.shape[0] == 2
+        torch.manual_seed(5)
+        noise = torch.randn((2, 8, 256, 16), device=DEV)
+        kw = dict(uncond_states=emb_cf[:2], uncond_mask=mask_cf[:2]) if post > 1 else {}
+        again = pipe.forward_from_embeds(emb, mask, noise, 4.0, post, 1, **kw)
+        assert np.array_equal(pcm, again)
