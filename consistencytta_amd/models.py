@@ -798,6 +798,22 @@ class ConsistencyTTA(nn.Module):
         self.unet.eval().requires_grad_(False)
         self.vae.eval().requires_grad_(False)
 
+    @classmethod
+    def from_checkpoint_dir(cls, ckpt_dir="consistencytta_clapft_ckpt", unet_config=None, text_encoder=None,
+                            tokenizer=None, device=None):
+        """The reference's released layout (easy_inference/consistencytta.py:22-42): `unet_state_dict.pt` (the guided
+        U-Net's state dict) and `vae_state_dict.pt` = {"state_dict": AutoencoderKL incl. vocoder, "scale_factor"}."""
+        import os
+        unet_sd = torch.load(os.path.join(ckpt_dir, "unet_state_dict.pt"), map_location="cpu")
+        raw = torch.load(os.path.join(ckpt_dir, "vae_state_dict.pt"), map_location="cpu")
+        vae = AutoencoderKL(embed_dim=8, scale_factor=float(raw["scale_factor"]))
+        vae.load_state_dict(raw["state_dict"])
+        pipe = cls(unet_config=unet_config, vae=vae, text_encoder=text_encoder, tokenizer=tokenizer)
+        pipe.unet.load_state_dict(unet_sd)
+        if device is not None:
+            pipe.to(device)
+        return pipe.eval().requires_grad_(False)
+
     def check_eval_mode(self):
         for model, name in ((self.vae, "vae"), (self.unet, "unet")):
             assert model.training is False, f"The {name} is not in eval mode."

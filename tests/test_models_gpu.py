@@ -287,3 +287,24 @@ def test_prompt_to_waveform_with_the_hip_text_encoder():
         kw = dict(uncond_states=emb_cf[:2], uncond_mask=mask_cf[:2]) if post > 1 else {}
         again = pipe.forward_from_embeds(emb, mask, noise, 4.0, post, 1, **kw)
         assert np.array_equal(pcm, again)
+
+
+def test_released_checkpoint_layout_round_trip(tmp_path):
+    """`unet_state_dict.pt` + `vae_state_dict.pt` ({"state_dict", "scale_factor"}) as easy_inference/consistencytta.py:22-42
+    reads them: written from one pipeline with torch.save, loaded by from_checkpoint_dir, same waveform bit for bit."""
+    from consistencytta_amd import modules
+    from consistencytta_amd.models import ConsistencyTTA
+    cfg = cases.TINY_UNET
+    vae = modules.AutoencoderKL(embed_dim=8, scale_factor=0.9227914214134216)
+    a = ConsistencyTTA(unet_config=cfg, vae=vae)
+    a.unet.init_deterministic(1)
+    vae.init_deterministic(2)
+    torch.save(a.unet.state_dict(), tmp_path / "unet_state_dict.pt")
+    torch.save({"state_dict": vae.state_dict(), "scale_factor": vae.scale_factor}, tmp_path / "vae_state_dict.pt")
+    b = ConsistencyTTA.from_checkpoint_dir(str(tmp_path), unet_config=cfg, device=DEV)
+    a.to(DEV).eval().requires_grad_(False)
+    assert list(b.vae.state_dict().keys()) == list(vae.state_dict().keys()) and b.vae.scale_factor == vae.scale_factor
+    x, _, _, enc, mask = cases.unet_inputs(cfg, 1, 32, 16, 5, "ckpt")
+    wa = a.forward_from_embeds(enc.to(DEV), mask.to(DEV), x.to(DEV), 4.0, 1.0, 1)
+    wb = b.forward_from_embeds(enc.to(DEV), mask.to(DEV), x.to(DEV), 4.0, 1.0, 1)
+    assert wa.dtype == np.int16 and np.array_equal(wa, wb)
