@@ -275,11 +275,11 @@ def main():
             result["teacher"] = t
         gc.collect()
         torch.cuda.empty_cache()
-        try:
-            pd_ = distill_leg(args, dev, world, rank, perceptual=True)
-        except Exception as exc:   # the newest leg must not cost the headline line
-            pd_ = {"error": str(exc)[:300]}
-        if rank == 0:
+        if world == 1:   # single-GPU extra: a one-sided failure inside a collective would hang the scaling runs
+            try:
+                pd_ = distill_leg(args, dev, world, rank, perceptual=True)
+            except Exception as exc:   # the newest leg must not cost the headline line
+                pd_ = {"error": str(exc)[:300]}
             result["perceptual_distill"] = pd_
     if rank == 0:
         print(json.dumps(result), flush=True)
