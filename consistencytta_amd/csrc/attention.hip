@@ -126,8 +126,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
           s[ik][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[jq][ds], s[ik][jq], 0, 0, 0);
       }
     }
-    // ---- scale, bias, key mask; lane holds keys key0 + ik*16 + lg*4 + r for query column lq
-    float kbias[4][4];
+    // ---- scale, bias, key mask; lane holds keys key0 + ik*16 + lg*4 + r for query column lq.
+    // Written on 4-vectors so that the scale/bias FMA, the max subtraction and the row sums compile to the packed
+    // fp32 instructions (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per issue) -- the softmax VALU work, not the
+    // MFMAs, bounds this kernel.
+    f32x4_t kbias[4];
 #pragma unroll
     for (int ik = 0; ik < 4; ++ik)
 #pragma unroll
@@ -143,35 +146,35 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
       float mx = -INFINITY;
       const int qrel = min(q0 + jq * 16 + lq, nq - 1);
 #pragma unroll
-      for (int ik = 0; ik < 4; ++ik)
+      for (int ik = 0; ik < 4; ++ik) {
+        f32x4_t v = s[ik][jq] * scale_log2e + kbias[ik];
+        if (REL) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s[ik][jq][r] * scale_log2e + kbias[ik][r];
-          if (REL) v += rb[min(key0 + ik * 16 + lg * 4 + r, nk - 1) - qrel];
-          s[ik][jq][r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; ++r) v[r] += rb[min(key0 + ik * 16 + lg * 4 + r, nk - 1) - qrel];
         }
+        s[ik][jq] = v;
+        mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float mnew = fmaxf(mrun[jq], mx);
       const float alpha = fast_exp2(mrun[jq] - mnew);   // first tile: exp2(-inf) = 0
       mrun[jq] = mnew;
-      float ps = 0.f;
+      f32x4_t ps4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4_t neg_m = {-mnew, -mnew, -mnew, -mnew};
 #pragma unroll
-      for (int ik = 0; ik < 4; ++ik)
+      for (int ik = 0; ik < 4; ++ik) {
+        const f32x4_t d = s[ik][jq] + neg_m;
+        f32x4_t pv;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pv = fast_exp2(s[ik][jq][r] - mnew);
-          s[ik][jq][r] = pv;
-          ps += pv;
-        }
-      lrun[jq] = lrun[jq] * alpha + ps;
+        for (int r = 0; r < 4; ++r) pv[r] = fast_exp2(d[r]);
+        s[ik][jq] = pv;
+        ps4 += pv;
+      }
+      lrun[jq] = lrun[jq] * alpha + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
       if (__any(alpha != 1.0f)) {   // wave-uniform: after the first tiles the running maxima rarely move
 #pragma unroll
-        for (int jd = 0; jd < 4; ++jd) {
-          o[jd][jq][0] *= alpha; o[jd][jq][1] *= alpha;
-          o[jd][jq][2] *= alpha; o[jd][jq][3] *= alpha;
-        }
+        for (int jd = 0; jd < 4; ++jd) o[jd][jq] *= alpha;
       }
     }
     // ---- O^T += V^T P^T : k-slot (lg, e): e<4 -> key block 2kk, row lg*4+e ; e>=4 -> block 2kk+1
