@@ -337,7 +337,7 @@ extern "C" ctta_status ctta_row_scatter(const float* slabs, int n_slabs, int64_t
 // ------------------------------------------------------------------------------ GroupNorm backward
 // y = silu?(xhat*gamma + beta), xhat = (x - mean)*rstd.  stats: [B][G][2] = (mean, rstd).
 __device__ __forceinline__ float silu_grad(float z) {
-  const float s = 1.0f / (1.0f + __expf(-z));
+  const float s = sigmoid_f(z);
   return s * (1.0f + z * (1.0f - s));
 }
 // pass 1: per (b, chunk) per-channel sums  A = sum dz, Bc = sum dz*xhat     part: [B][nchunk][2][C]
