@@ -77,7 +77,7 @@ def main():
         row = {"tag": tag, "M": M, "N": Cout, "K": K, "tflops": {}}
         res = torch.randn(B, H, W, Cout, device=DEV).to(torch.bfloat16) if epi else None
         out2 = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV) if epi else None
-        for v in ([0] + only if only else range(1, nvar + 1)):
+        for v in ([0] + only if only else range(0, nvar + 1)):
             d = N.ConvDesc()
             d.x0, d.c0 = x.data_ptr(), Cin
             d.batch, d.hi, d.wi, d.ho, d.wo = B, H, W, H, W
@@ -109,8 +109,12 @@ def main():
         best = max(row["tflops"], key=row["tflops"].get)
         row["best"] = best
         results.append(row)
-        print("%-24s M=%8d N=%5d K=%6d  best %-22s %s" % (tag, M, Cout, K, best,
-              " ".join("%6.0f" % t for t in row["tflops"].values())), flush=True)
+        if os.environ.get("SWEEP_BRIEF", "0") == "1":
+            print("%-24s M=%8d N=%5d K=%6d  auto %6.0f  best %-22s %6.0f" % (tag, M, Cout, K, row["tflops"].get("auto", 0.0),
+                  best, row["tflops"][best]), flush=True)
+        else:
+            print("%-24s M=%8d N=%5d K=%6d  best %-22s %s" % (tag, M, Cout, K, best,
+                  " ".join("%6.0f" % t for t in row["tflops"].values())), flush=True)
         del x, w, out
     if len(sys.argv) > 1:
         json.dump({"variants": names, "shapes": results}, open(sys.argv[1], "w"), indent=1)
