@@ -221,7 +221,8 @@ def main():
             torch.cuda.synchronize()
             te_ms = (time.perf_counter() - t1) / 5 * 1e3
             result["text_encoder_ms"] = round(te_ms, 3)
-            result["clips_per_s_incl_text_encoder"] = round(B / (B / result["value"] + te_ms * 1e-3), 3)
+            per_rank = result["value"] / world
+            result["clips_per_s_incl_text_encoder"] = round(world * B / (B / per_rank + te_ms * 1e-3), 3)
             del te
         except Exception as exc:
             result["text_encoder_ms"] = {"error": str(exc)[:200]}
