@@ -46,6 +46,8 @@ struct ConvParams {
   // [x * xcd_per, (x + 1) * xcd_per) and walks it with the N tiles innermost, so the tiles that share input rows
   // (neighbouring image rows, all N tiles of one M tile) meet in the same 4 MB L2 close in time.  0 = plain 2-D grid.
   int xcd_per, m_tiles, n_tiles, n_inner;   // n_inner = 0: M tiles innermost (many N tiles: keep the weight slice hot)
+  // 1: the tile is transposed through LDS and leaves as whole 64..256-byte row segments (see the kernel's epilogue)
+  int wide_store;
 };
 
 // GLDS = true: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
@@ -496,6 +498,87 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 
   // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3} (rows of D), m = mb + (lane&15)
   const int nsub = (lane >> 4) * 4;
+  // Wide-store epilogue (bf16 output, plain row-major destination).  In the MFMA layout a store instruction writes
+  // 16 rows x 32 bytes; measured, a launch then pays ~0.5 us per MB of output on top of its main loop (335 MB outputs:
+  // 180 of 300 us of K-independent time) because workgroups cannot retire before their scattered stores drain.  Here
+  // every wave transposes its tile through the (dead) LDS ring in fp32, CHR rows at a time, and reads it back with
+  // TN/4 consecutive lanes per output row: stores -- and the residual reads -- are whole TN*2-byte row segments, the
+  // bias sits in registers because a lane keeps its 4 channels, and the arithmetic runs in one rolled loop.
+  if (p.wide_store) {
+    constexpr int NW = WM * WN;
+    constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
+    constexpr int RSF = TN * 4 + 16;                       // staging row stride (bytes): +16 keeps 16-byte accesses conflict-free
+    constexpr int CHR = (FM % 2 == 0 && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;   // rows per chunk
+    static_assert((size_t)NW * CHR * RSF <= RING, "wide-store staging does not fit the ring");
+    constexpr int CJ = CHR / 16;
+    constexpr int LPR = TN / 4;                            // lanes per output row (4 channels each)
+    constexpr int RPW = 64 / LPR;                          // rows per pass of the wave
+    unsigned char* stg = smem_raw + (size_t)wave * CHR * RSF;
+    const int col4 = lane % LPR, prow = lane / LPR;
+    const int n_lane = n0 + wn * TN + col4 * 4;
+    const bool n_ok = n_lane < p.n;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + n_lane);
+    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out) + (size_t)g * p.ogs + n_lane;
+    bf16_t* out2p = p.out2 ? p.out2 + (size_t)g * p.ogs + n_lane : nullptr;
+    const bf16_t* resp = p.res ? p.res + n_lane : nullptr;
+    __syncthreads();   // every wave is done with the ring
+#pragma unroll
+    for (int j0 = 0; j0 < FM; j0 += CJ) {
+#pragma unroll
+      for (int jj = 0; jj < CJ; ++jj)
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          const f32x4_t a = acc[i][j0 + jj];
+          *reinterpret_cast<float4*>(stg + (jj * 16 + frow) * RSF + (i * 16 + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+      __syncthreads();
+#pragma unroll 2
+      for (int r = prow; r < CHR; r += RPW) {
+        const int m = m0 + wm * TM + j0 * 16 + r;
+        if (m < p.M && n_ok) {
+          const float4 q = *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16);
+          float v[4] = {q.x + bias4.x, q.y + bias4.y, q.z + bias4.z, q.w + bias4.w};
+          if (p.bias_m) {
+            const float bm = p.bias_m[m];
+            v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+          }
+          if (p.rowvec) {
+            const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.howo) * p.rowvec_ld + n_lane);
+            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+          }
+          if (resp) {
+            const uint2 rr = *reinterpret_cast<const uint2*>(resp + (size_t)m * p.res_ld);
+            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[e] *= p.alpha;
+            if (p.out_act == 1) v[e] = silu_f(v[e]);
+            else if (p.out_act == 2) v[e] = tanhf(v[e]);
+            else if (p.out_act == 3) v[e] = v[e] > 0.f ? v[e] : v[e] * p.out_slope;
+          }
+          uint2 pk;
+          pk.x = pack2bf(v[0], v[1]);
+          pk.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(outp + (size_t)m * p.ldc) = pk;
+          if (out2p) {   // leaky_relu of the SAME (bf16-rounded) values
+            float w2[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
+                           __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w2[e] = w2[e] > 0.f ? w2[e] : w2[e] * p.out2_slope;
+            uint2 pk2;
+            pk2.x = pack2bf(w2[0], w2[1]);
+            pk2.y = pack2bf(w2[2], w2[3]);
+            *reinterpret_cast<uint2*>(out2p + (size_t)m * p.ldc) = pk2;
+          }
+        }
+      }
+      if (j0 + CJ < FM) __syncthreads();
+    }
+    return;
+  }
   // fused GEGLU: only compiled into the small-fragment tiles (a longer epilogue on the 16-fragment tiles
   // pushes their accumulators into scratch)
   if constexpr (FM * FN <= 8 && FN % 2 == 0) {
@@ -797,6 +880,11 @@ static bool xcd_default() {
   if (v < 0) { const char* e = getenv("CTTA_XCD"); v = (e && e[0] == '0') ? 0 : 1; }
   return v != 0;
 }
+static bool wide_store_default() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_WIDE_STORE"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
 static bool splitk_default() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("CTTA_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -930,6 +1018,10 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   const Variant& v = kVariants[vid - 1];
   p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;
   p.zero = zero_page();
+  p.wide_store = (wide_store_default() && !d->out_f32 && !scalar_store && !geglu && !d->accumulate && d->out_limit == 0 &&
+                  d->out_offset == 0 && p.obs == (long long)p.howo * d->ldc && d->ldc % 4 == 0 && d->n % 4 == 0 &&
+                  (!d->res || d->res_ld % 4 == 0) && (!d->rowvec || d->rowvec_ld % 4 == 0))
+                     ? 1 : 0;
   CTTA_REQUIRE(p.zero, "conv_gemm: could not allocate the zero page");
   p.nk = (int)((K + v.bk - 1) / v.bk);
   CTTA_REQUIRE((long long)p.nk * v.bk <= d->k_pad, "conv_gemm: k_pad too small for BK");
@@ -967,6 +1059,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     q.ksplit = splits;
     q.bias = nullptr; q.bias_m = nullptr; q.rowvec = nullptr; q.res = nullptr; q.out_act = 0; q.alpha = 1.0f;
     q.accumulate = 0; q.out2 = nullptr; q.out = ws; q.ldc = ld; q.out_f32 = 1; q.obs = (long long)p.howo * ld;
+    q.wide_store = 0;
     q.ogs = (long long)M * ld;
     grid.z = (unsigned)splits;
     v.launch(q, grid, (hipStream_t)stream);
