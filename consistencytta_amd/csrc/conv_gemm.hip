@@ -523,6 +523,51 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     bf16_t* out2p = p.out2 ? p.out2 + (size_t)g * p.ogs + n_lane : nullptr;
     const bf16_t* resp = p.res ? p.res + n_lane : nullptr;
     __syncthreads();   // every wave is done with the ring
+    if constexpr (FM * FN <= 8 && FN % 2 == 0) {
+      if (p.out_act == 4) {   // fused GEGLU: hidden unit hl of the wave's row = value column (hl/16)*32 + hl%16, gate 16 further
+        constexpr int LPG = TN / 8, RPG = 64 / LPG;          // lanes per output row (4 hidden units each), rows per pass
+        const int h4 = lane % LPG, grow = lane / LPG;
+        const int vcol = (h4 / 4) * 32 + (h4 % 4) * 4;       // value columns of this lane within the wave tile
+        const int n_val = n0 + wn * TN + vcol;
+        const bool g_ok = n_val < p.n;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+        if (p.bias && g_ok) {
+          bv = *reinterpret_cast<const float4*>(p.bias + n_val);
+          bg = *reinterpret_cast<const float4*>(p.bias + n_val + 16);
+        }
+        bf16_t* og = reinterpret_cast<bf16_t*>(p.out) + (size_t)g * p.ogs + ((n0 + wn * TN) >> 1) + h4 * 4;
+#pragma unroll
+        for (int j0 = 0; j0 < FM; j0 += CJ) {
+#pragma unroll
+          for (int jj = 0; jj < CJ; ++jj)
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+              const f32x4_t a = acc[i][j0 + jj];
+              *reinterpret_cast<float4*>(stg + (jj * 16 + frow) * RSF + (i * 16 + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+            }
+          __syncthreads();
+#pragma unroll 2
+          for (int r = grow; r < CHR; r += RPG) {
+            const int m = m0 + wm * TM + j0 * 16 + r;
+            if (m < p.M && g_ok) {
+              const float4 qv = *reinterpret_cast<const float4*>(stg + r * RSF + vcol * 4);
+              const float4 qg = *reinterpret_cast<const float4*>(stg + r * RSF + (vcol + 16) * 4);
+              const float vv[4] = {qv.x + bv.x, qv.y + bv.y, qv.z + bv.z, qv.w + bv.w};
+              const float gg[4] = {qg.x + bg.x, qg.y + bg.y, qg.z + bg.z, qg.w + bg.w};
+              float o[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = vv[e] * (0.5f * gg[e] * (1.0f + erff(gg[e] * 0.70710678118654752f)));
+              uint2 pk;
+              pk.x = pack2bf(o[0], o[1]);
+              pk.y = pack2bf(o[2], o[3]);
+              *reinterpret_cast<uint2*>(og + (size_t)m * p.ldc) = pk;
+            }
+          }
+          if (j0 + CJ < FM) __syncthreads();
+        }
+        return;
+      }
+    }
 #pragma unroll
     for (int j0 = 0; j0 < FM; j0 += CJ) {
 #pragma unroll
@@ -551,6 +596,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
             const uint2 rr = *reinterpret_cast<const uint2*>(resp + (size_t)m * p.res_ld);
             v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
             v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+          }
+          if (p.accumulate) {
+            const uint2 old = *reinterpret_cast<const uint2*>(outp + (size_t)m * p.ldc);
+            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -1018,7 +1068,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   const Variant& v = kVariants[vid - 1];
   p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;
   p.zero = zero_page();
-  p.wide_store = (wide_store_default() && !d->out_f32 && !scalar_store && !geglu && !d->accumulate && d->out_limit == 0 &&
+  p.wide_store = (wide_store_default() && !d->out_f32 && !scalar_store && d->out_limit == 0 &&
                   d->out_offset == 0 && p.obs == (long long)p.howo * d->ldc && d->ldc % 4 == 0 && d->n % 4 == 0 &&
                   (!d->res || d->res_ld % 4 == 0) && (!d->rowvec || d->rowvec_ld % 4 == 0))
                      ? 1 : 0;
