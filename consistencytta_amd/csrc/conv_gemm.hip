@@ -50,6 +50,53 @@ struct ConvParams {
   int wide_store;
 };
 
+// The fused epilogue on 4 consecutive channels of one output row, for the wide-store paths (plain row-major bf16
+// destination: element (m, n) at m*ldc + n): same operation order as epilogue_store.
+__device__ __forceinline__ void epilogue_wide4(const ConvParams& p, const float4 q, const float4 bias4, int m, int n,
+                                               size_t gofs) {
+  float v[4] = {q.x + bias4.x, q.y + bias4.y, q.z + bias4.z, q.w + bias4.w};
+  if (p.bias_m) {
+    const float bm = p.bias_m[m];
+    v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+  }
+  if (p.rowvec) {
+    const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.howo) * p.rowvec_ld + n);
+    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+  }
+  if (p.res) {
+    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
+    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+  }
+  bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + gofs + (size_t)m * p.ldc + n;
+  if (p.accumulate) {
+    const uint2 old = *reinterpret_cast<const uint2*>(o);
+    v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+    v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[e] *= p.alpha;
+    if (p.out_act == 1) v[e] = silu_f(v[e]);
+    else if (p.out_act == 2) v[e] = tanhf(v[e]);
+    else if (p.out_act == 3) v[e] = v[e] > 0.f ? v[e] : v[e] * p.out_slope;
+  }
+  uint2 pk;
+  pk.x = pack2bf(v[0], v[1]);
+  pk.y = pack2bf(v[2], v[3]);
+  *reinterpret_cast<uint2*>(o) = pk;
+  if (p.out2) {   // leaky_relu of the SAME (bf16-rounded) values
+    float w2[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),
+                   __uint_as_float(pk.y & 0xffff0000u)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w2[e] = w2[e] > 0.f ? w2[e] : w2[e] * p.out2_slope;
+    uint2 pk2;
+    pk2.x = pack2bf(w2[0], w2[1]);
+    pk2.y = pack2bf(w2[2], w2[3]);
+    *reinterpret_cast<uint2*>(p.out2 + gofs + (size_t)m * p.ldc + n) = pk2;
+  }
+}
+
 // GLDS = true: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
 // ds_write): the LDS image is lane-linear per wave instruction (8 rows x 128 B for BK = 64), so the
 // XOR swizzle is applied to the per-lane SOURCE chunk instead of the destination; padding / tail
@@ -519,9 +566,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     const bool n_ok = n_lane < p.n;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + n_lane);
-    bf16_t* outp = reinterpret_cast<bf16_t*>(p.out) + (size_t)g * p.ogs + n_lane;
-    bf16_t* out2p = p.out2 ? p.out2 + (size_t)g * p.ogs + n_lane : nullptr;
-    const bf16_t* resp = p.res ? p.res + n_lane : nullptr;
     __syncthreads();   // every wave is done with the ring
     if constexpr (FM * FN <= 8 && FN % 2 == 0) {
       if (p.out_act == 4) {   // fused GEGLU: hidden unit hl of the wave's row = value column (hl/16)*32 + hl%16, gate 16 further
@@ -581,49 +625,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 #pragma unroll 2
       for (int r = prow; r < CHR; r += RPW) {
         const int m = m0 + wm * TM + j0 * 16 + r;
-        if (m < p.M && n_ok) {
-          const float4 q = *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16);
-          float v[4] = {q.x + bias4.x, q.y + bias4.y, q.z + bias4.z, q.w + bias4.w};
-          if (p.bias_m) {
-            const float bm = p.bias_m[m];
-            v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
-          }
-          if (p.rowvec) {
-            const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.howo) * p.rowvec_ld + n_lane);
-            v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
-          }
-          if (resp) {
-            const uint2 rr = *reinterpret_cast<const uint2*>(resp + (size_t)m * p.res_ld);
-            v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
-            v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
-          }
-          if (p.accumulate) {
-            const uint2 old = *reinterpret_cast<const uint2*>(outp + (size_t)m * p.ldc);
-            v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
-            v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
-          }
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            v[e] *= p.alpha;
-            if (p.out_act == 1) v[e] = silu_f(v[e]);
-            else if (p.out_act == 2) v[e] = tanhf(v[e]);
-            else if (p.out_act == 3) v[e] = v[e] > 0.f ? v[e] : v[e] * p.out_slope;
-          }
-          uint2 pk;
-          pk.x = pack2bf(v[0], v[1]);
-          pk.y = pack2bf(v[2], v[3]);
-          *reinterpret_cast<uint2*>(outp + (size_t)m * p.ldc) = pk;
-          if (out2p) {   // leaky_relu of the SAME (bf16-rounded) values
-            float w2[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u),
-                           __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xffff0000u)};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) w2[e] = w2[e] > 0.f ? w2[e] : w2[e] * p.out2_slope;
-            uint2 pk2;
-            pk2.x = pack2bf(w2[0], w2[1]);
-            pk2.y = pack2bf(w2[2], w2[3]);
-            *reinterpret_cast<uint2*>(out2p + (size_t)m * p.ldc) = pk2;
-          }
-        }
+        if (m < p.M && n_ok)
+          epilogue_wide4(p, *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16), bias4, m, n_lane, (size_t)g * p.ogs);
       }
       if (j0 + CJ < FM) __syncthreads();
     }
@@ -784,6 +787,31 @@ __global__ __launch_bounds__(256) void conv1d_halo_kernel(const ConvParams p) {
     }
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) a_cur[cb] = a_nxt[cb];
+  }
+  if (p.wide_store) {   // same transposed store as conv_gemm_kernel: 16 positions x C channels per wave at a time
+    constexpr int RSF = C * 4 + 16;
+    constexpr int LPR = C / 4, RPW = 64 / LPR;
+    unsigned char* stg = smem_raw + (size_t)wave * 16 * RSF;
+    const int col4 = lane % LPR, prow = lane / LPR;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bias4 = *reinterpret_cast<const float4*>(p.bias + col4 * 4);
+    __syncthreads();   // the input tile is dead
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const f32x4_t a = acc[cb][pb];
+        *reinterpret_cast<float4*>(stg + lq * RSF + (cb * 16 + lg * 4) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = prow; r < 16; r += RPW) {
+        const int l = l0 + wave * (BL / 4) + pb * 16 + r;
+        if (l < L) epilogue_wide4(p, *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16), bias4, b * L + l, col4 * 4, 0);
+      }
+      if (pb + 1 < PB) __syncthreads();
+    }
+    return;
   }
 #pragma unroll
   for (int pb = 0; pb < PB; ++pb) {
@@ -1028,6 +1056,10 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
            (!p.ups || (d->kh == 3 && d->kw == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 &&
                        d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1));
   };
+  p.wide_store = (wide_store_default() && !d->out_f32 && !scalar_store && d->out_limit == 0 &&
+                  d->out_offset == 0 && p.obs == (long long)p.howo * d->ldc && d->ldc % 4 == 0 && d->n % 4 == 0 &&
+                  (!d->res || d->res_ld % 4 == 0) && (!d->rowvec || d->rowvec_ld % 4 == 0))
+                     ? 1 : 0;
   int vid = d->tile;
   if (vid <= 0 && halo_eligible(d, p, groups)) {
     const bool prof = ctta_prof_active();
@@ -1068,10 +1100,6 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   const Variant& v = kVariants[vid - 1];
   p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;
   p.zero = zero_page();
-  p.wide_store = (wide_store_default() && !d->out_f32 && !scalar_store && d->out_limit == 0 &&
-                  d->out_offset == 0 && p.obs == (long long)p.howo * d->ldc && d->ldc % 4 == 0 && d->n % 4 == 0 &&
-                  (!d->res || d->res_ld % 4 == 0) && (!d->rowvec || d->rowvec_ld % 4 == 0))
-                     ? 1 : 0;
   CTTA_REQUIRE(p.zero, "conv_gemm: could not allocate the zero page");
   p.nk = (int)((K + v.bk - 1) / v.bk);
   CTTA_REQUIRE((long long)p.nk * v.bk <= d->k_pad, "conv_gemm: k_pad too small for BK");
