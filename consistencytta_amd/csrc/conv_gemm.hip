@@ -48,6 +48,7 @@ struct ConvParams {
   int xcd_per, m_tiles, n_tiles, n_inner;   // n_inner = 0: M tiles innermost (many N tiles: keep the weight slice hot)
   // 1: the tile is transposed through LDS and leaves as whole 64..256-byte row segments (see the kernel's epilogue)
   int wide_store;
+  int plain_out;   // destination element (m, n) sits at m*ldc + n (no per-batch stride, offset or limit)
 };
 
 // The fused epilogue on 4 consecutive channels of one output row, for the wide-store paths (plain row-major bf16
@@ -68,7 +69,14 @@ __device__ __forceinline__ void epilogue_wide4(const ConvParams& p, const float4
     v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
     v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
   }
-  bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + gofs + (size_t)m * p.ldc + n;
+  size_t oidx = gofs + (size_t)m * p.ldc + n;
+  if (!p.plain_out) {   // ConvTranspose phases: per-batch stride, shifted and clipped rows (same rule as epilogue_store)
+    const int b = m / p.howo;
+    const long long inb = (long long)(m - b * p.howo) * p.ldc + n + p.out_offset;
+    if (p.out_limit > 0 && (inb < 0 || inb >= p.out_limit)) return;
+    oidx = gofs + (size_t)((long long)b * p.obs + inb);
+  }
+  bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + oidx;
   if (p.accumulate) {
     const uint2 old = *reinterpret_cast<const uint2*>(o);
     v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
@@ -93,7 +101,7 @@ __device__ __forceinline__ void epilogue_wide4(const ConvParams& p, const float4
     uint2 pk2;
     pk2.x = pack2bf(w2[0], w2[1]);
     pk2.y = pack2bf(w2[2], w2[3]);
-    *reinterpret_cast<uint2*>(p.out2 + gofs + (size_t)m * p.ldc + n) = pk2;
+    *reinterpret_cast<uint2*>(p.out2 + oidx) = pk2;
   }
 }
 
@@ -1056,8 +1064,9 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
            (!p.ups || (d->kh == 3 && d->kw == 3 && d->pad_h == 1 && d->pad_w == 1 && d->stride_h == 1 &&
                        d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1));
   };
-  p.wide_store = (wide_store_default() && !d->out_f32 && !scalar_store && d->out_limit == 0 &&
-                  d->out_offset == 0 && p.obs == (long long)p.howo * d->ldc && d->ldc % 4 == 0 && d->n % 4 == 0 &&
+  p.plain_out = (d->out_limit == 0 && d->out_offset == 0 && p.obs == (long long)p.howo * d->ldc) ? 1 : 0;
+  p.wide_store = (wide_store_default() && !d->out_f32 && !scalar_store && d->ldc % 4 == 0 && d->n % 4 == 0 &&
+                  (p.plain_out || (!geglu && p.obs % 4 == 0 && d->out_offset % 4 == 0 && d->out_limit % 4 == 0)) &&
                   (!d->res || d->res_ld % 4 == 0) && (!d->rowvec || d->rowvec_ld % 4 == 0))
                      ? 1 : 0;
   int vid = d->tile;
