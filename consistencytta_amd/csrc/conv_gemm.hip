@@ -575,7 +575,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + n_lane);
     __syncthreads();   // every wave is done with the ring
-    if constexpr (FM * FN <= 8 && FN % 2 == 0) {
+    if constexpr (FM * FN <= 16 && FN % 2 == 0) {
       if (p.out_act == 4) {   // fused GEGLU: hidden unit hl of the wave's row = value column (hl/16)*32 + hl%16, gate 16 further
         constexpr int LPG = TN / 8, RPG = 64 / LPG;          // lanes per output row (4 hidden units each), rows per pass
         const int h4 = lane % LPG, grow = lane / LPG;
@@ -992,7 +992,7 @@ static bool glds_default() {
 static const int kBigTile = 29;
 static bool want_big_tile(long long M, int N, long long K, int groups) {
   const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * groups;
-  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= 768 && t256 >= 192;
+  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= 1024 && t256 >= 192;
 }
 static int pick_variant(long long M, int N, long long K, int groups) {
   if (N <= 32) return 4;                                   // 256x32
@@ -1001,8 +1001,7 @@ static int pick_variant(long long M, int N, long long K, int groups) {
   if (t128 < 200) return 5;                                // too few 128x128 tiles to fill 256 CUs
   if (K >= 4096) return N >= 256 ? 1 : 6;                  // 128x128x64 / 64x128x64
   if (K > 1536) return M >= 400000 ? 6 : 2;                // 64x128x64 / 128x128x32
-  if (K > 512) return N >= 256 ? 2 : 6;                    // 128x128x32 / 64x128x64
-  return 6;                                                // short K: 64x128x64
+  return N >= 256 ? 2 : 6;                                 // 128x128x32 / 64x128x64 (re-swept with the wide-store epilogue)
 }
 
 extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
@@ -1087,7 +1086,9 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       if (K < 2048 && (d->res || d->out2 || d->accumulate)) vid = 28;
     } else {
       vid = pick_variant(M, d->n, K, groups);
-      if (geglu) vid = 6;   // 64x128x64: the measured choice for the short-K feed-forward projections
+      // fused GEGLU: 128x128x32 through the wide-store epilogue (its read-back loop is rolled, so the 16-fragment tile
+      // keeps its accumulators in registers); the direct epilogue only exists in the <= 8-fragment tiles (64x128x64)
+      if (geglu) vid = p.wide_store ? 2 : 6;
       // deep and narrow (few 128x128 tiles, long K): the 128x128 tile with split-K beats small tiles that only
       // exist to create workgroups (measured: M=1152, N=1024, K=9216 at 176 TFLOP/s on 64x64 tiles)
       const long long t128 = ((M + 127) / 128) * ((d->n + 127) / 128);
@@ -1095,13 +1096,19 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
           d->out_limit == 0 && d->out_offset == 0)
         vid = 1;
       if (!d->in_act && glds_default()) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
+      // 64 < N <= 128 with enough rows: the 256x128x32 tile (8 waves of 64x64) stages 25 % fewer bytes per FLOP than
+      // 128x128 / 64x128 and, with the wide-store epilogue, wins from K = 384 up (sweep: +12..22 %)
+      const long long t28 = ((M + 255) / 256) * groups;
+      if (!geglu && !d->in_act && glds_default() && d->n > 64 && d->n <= 128 && K >= 384 && t28 >= 512 && fast_ok(32) &&
+          vid != 1 + 16)
+        vid = 28;
     }
   }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
-  if (geglu) {   // compiled into the <= 8-fragment tiles only: 64x64, 64x128, 128x64, 256x32 (all staging modes)
+  if (geglu) {   // direct epilogue: <= 8-fragment tiles (64x64, 64x128, 128x64, 256x32); wide-store: also the 128x128 tiles
     const int base = (vid - 1) % 8 + 1;
-    CTTA_REQUIRE(vid <= 24 && (base == 4 || base == 5 || base == 6 || base == 8),
-                 "conv_gemm: the fused GEGLU epilogue needs a 64x64 / 64x128 / 128x64 / 256x32 tile (got %s)",
+    CTTA_REQUIRE(vid <= 24 && (base == 4 || base == 5 || base == 6 || base == 8 || (p.wide_store && (base == 1 || base == 2))),
+                 "conv_gemm: the fused GEGLU epilogue needs a 64x64 / 64x128 / 128x64 / 256x32 (or, wide-store, 128x128) tile (got %s)",
                  kVariants[vid - 1].name);
   }
   CTTA_REQUIRE(kVariants[vid - 1].mode != 2 || fast_ok(kVariants[vid - 1].bk),
