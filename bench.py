@@ -255,6 +255,18 @@ def main():
             assert torch.equal(eager1(), gen1(e1, m1, n1))
             result["single_clip_latency_ms"] = lat_ms
             del gen1
+            if world == 1:   # the whole batch-32 step as ONE hipGraph replay (information; `value` stays the eager loop)
+                genB = pipe.capture_graph(B, L, cfg_scale_input=4.0)
+                for _ in range(2):
+                    genB(enc, mask, noise)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(args.steps):
+                    pg = genB(enc, mask, noise)
+                torch.cuda.synchronize()
+                result["hipgraph_clips_per_s"] = round(B * args.steps / (time.perf_counter() - t1), 3)
+                assert torch.equal(pg, step()[3])
+                del genB
         except Exception as exc:   # a failed capture must not cost the headline line
             result["single_clip_latency_ms"] = {"error": str(exc)[:200]}
 
