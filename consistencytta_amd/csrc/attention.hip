@@ -311,6 +311,26 @@ __device__ __forceinline__ void stage_rows(bf16_t* lds, int ld, const bf16_t* sr
   }
 }
 
+// stage_rows in two halves, so a tile's global loads can be issued one tile ahead of the MFMAs that consume it
+__device__ __forceinline__ void fetch_rows(uint4 (&reg)[2], const bf16_t* src, size_t src_ld, int rows_valid, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int chunk = tid + i * 256;
+    const int r = chunk >> 3, cc = (chunk & 7) * 8;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < rows_valid) v = *reinterpret_cast<const uint4*>(src + (size_t)r * src_ld + cc);
+    reg[i] = v;
+  }
+}
+__device__ __forceinline__ void put_rows(bf16_t* lds, int ld, const uint4 (&reg)[2], int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int chunk = tid + i * 256;
+    const int r = chunk >> 3, cc = (chunk & 7) * 8;
+    *reinterpret_cast<uint4*>(lds + r * ld + cc) = reg[i];
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * ATT_LDK];    // [key][d]
   __shared__ __attribute__((aligned(16))) bf16_t Vn[64 * ATT_LDK];    // [key][d]
@@ -348,13 +368,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     for (int jq = 0; jq < 2; ++jq) o[jd][jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = (p.nk + 63) / 64;
+  uint4 rk[2], rv[2], rkt[2];
+  auto fetch = [&](int key0) {
+    fetch_rows(rk, kb + (size_t)key0 * p.k_ld, p.k_ld, p.nk - key0, tid);
+    fetch_rows(rv, vb + (size_t)key0 * p.vn_ld, p.vn_ld, p.nk - key0, tid);
+    fetch_rows(rkt, ktb + key0, p.kt_ld, 64, tid);   // zero beyond nk by construction of K^T
+  };
+  fetch(0);
   for (int t = 0; t < ntiles; ++t) {
     const int key0 = t * 64;
     __syncthreads();
-    stage_rows(Ks, ATT_LDK, kb + (size_t)key0 * p.k_ld, p.k_ld, p.nk - key0, tid);
-    stage_rows(Vn, ATT_LDK, vb + (size_t)key0 * p.vn_ld, p.vn_ld, p.nk - key0, tid);
-    stage_rows(KTs, ATT_LDV, ktb + key0, p.kt_ld, 64, tid);   // zero beyond nk by construction of K^T
+    put_rows(Ks, ATT_LDK, rk, tid);
+    put_rows(Vn, ATT_LDK, rv, tid);
+    put_rows(KTs, ATT_LDV, rkt, tid);
     __syncthreads();
+    if (t + 1 < ntiles) fetch(key0 + 64);
     f32x4_t s[4][2], dp[4][2];
 #pragma unroll
     for (int ik = 0; ik < 4; ++ik) {
@@ -469,19 +497,33 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   const int ntiles = (p.nq + 63) / 64;
   const int t_begin = blockIdx.z * p.q_tiles_per_split;
   const int t_end = min(ntiles, t_begin + p.q_tiles_per_split);
+  uint4 rq[2], rdo[2], rqt[2], rdot[2];
+  float r_lse = INFINITY, r_d = 0.f;
+  auto fetch = [&](int q0) {
+    fetch_rows(rq, qb + (size_t)q0 * p.q_ld, p.q_ld, p.nq - q0, tid);
+    fetch_rows(rdo, dob + (size_t)q0 * p.do_ld, p.do_ld, p.nq - q0, tid);
+    fetch_rows(rqt, qtb + q0, p.qt_ld, 64, tid);     // zero beyond nq by construction
+    fetch_rows(rdot, dotb + q0, p.qt_ld, 64, tid);
+    if (tid < 64) {
+      const bool ok = q0 + tid < p.nq;
+      r_lse = ok ? lseb[q0 + tid] : INFINITY;   // exp2(-inf) = 0 for padded queries
+      r_d = ok ? dsb[q0 + tid] : 0.f;
+    }
+  };
+  if (t_begin < t_end) fetch(t_begin * 64);
   for (int t = t_begin; t < t_end; ++t) {
     const int q0 = t * 64;
     __syncthreads();
-    stage_rows(Qs, ATT_LDK, qb + (size_t)q0 * p.q_ld, p.q_ld, p.nq - q0, tid);
-    stage_rows(dOs, ATT_LDK, dob + (size_t)q0 * p.do_ld, p.do_ld, p.nq - q0, tid);
-    stage_rows(QTs, ATT_LDV, qtb + q0, p.qt_ld, 64, tid);     // zero beyond nq by construction
-    stage_rows(dOTs, ATT_LDV, dotb + q0, p.qt_ld, 64, tid);
+    put_rows(Qs, ATT_LDK, rq, tid);
+    put_rows(dOs, ATT_LDK, rdo, tid);
+    put_rows(QTs, ATT_LDV, rqt, tid);
+    put_rows(dOTs, ATT_LDV, rdot, tid);
     if (tid < 64) {
-      const bool ok = q0 + tid < p.nq;
-      lse_s[tid] = ok ? lseb[q0 + tid] : INFINITY;   // exp2(-inf) = 0 for padded queries
-      d_s[tid] = ok ? dsb[q0 + tid] : 0.f;
+      lse_s[tid] = r_lse;
+      d_s[tid] = r_d;
     }
     __syncthreads();
+    if (t + 1 < t_end) fetch(q0 + 64);
     f32x4_t s[4][2], dp[4][2];
 #pragma unroll
     for (int iq = 0; iq < 4; ++iq) {
