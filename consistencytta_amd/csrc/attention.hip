@@ -497,13 +497,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   const int ntiles = (p.nq + 63) / 64;
   const int t_begin = blockIdx.z * p.q_tiles_per_split;
   const int t_end = min(ntiles, t_begin + p.q_tiles_per_split);
-  uint4 rq[2], rdo[2], rqt[2], rdot[2];
+  uint4 rq[2], rdo[2], rqt[2];
   float r_lse = INFINITY, r_d = 0.f;
-  auto fetch = [&](int q0) {
+  auto fetch = [&](int q0) {   // dO^T stays a synchronous stage: a fourth register tile spills the accumulators
     fetch_rows(rq, qb + (size_t)q0 * p.q_ld, p.q_ld, p.nq - q0, tid);
     fetch_rows(rdo, dob + (size_t)q0 * p.do_ld, p.do_ld, p.nq - q0, tid);
     fetch_rows(rqt, qtb + q0, p.qt_ld, 64, tid);     // zero beyond nq by construction
-    fetch_rows(rdot, dotb + q0, p.qt_ld, 64, tid);
     if (tid < 64) {
       const bool ok = q0 + tid < p.nq;
       r_lse = ok ? lseb[q0 + tid] : INFINITY;   // exp2(-inf) = 0 for padded queries
@@ -517,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     put_rows(Qs, ATT_LDK, rq, tid);
     put_rows(dOs, ATT_LDK, rdo, tid);
     put_rows(QTs, ATT_LDV, rqt, tid);
-    put_rows(dOTs, ATT_LDV, rdot, tid);
+    stage_rows(dOTs, ATT_LDV, dotb + q0, p.qt_ld, 64, tid);
     if (tid < 64) {
       lse_s[tid] = r_lse;
       d_s[tid] = r_d;
