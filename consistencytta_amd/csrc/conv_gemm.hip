@@ -999,6 +999,7 @@ static int pick_variant(long long M, int N, long long K, int groups) {
   if (N <= 64) return K >= 512 ? 8 : 5;                    // 128x64 / 64x64
   const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * groups;
   if (t128 < 200) return 5;                                // too few 128x128 tiles to fill 256 CUs
+  if (t128 < 1024 && (K < 4096 || t128 < 400 || N <= 512)) return 6;                    // thin grids (distillation micro-batch): 64x128x64 doubles the workgroups
   if (K >= 4096) return N >= 256 ? 1 : 6;                  // 128x128x64 / 64x128x64
   if (K > 1536) return M >= 400000 ? 6 : 2;                // 64x128x64 / 128x128x32
   return N >= 256 ? 2 : 6;                                 // 128x128x32 / 64x128x64 (re-swept with the wide-store epilogue)

@@ -49,6 +49,18 @@ SHAPES = [
     ("lin M8192 1024>8192", 32, 256, 1, 1024, 8192, 1, 1, 1),
     ("lin M8192 4096>1024", 32, 256, 1, 4096, 1024, 1, 1, 1),
     ("lin M2048 1024>8192", 32, 64, 1, 1024, 8192, 1, 1, 1),
+    # distillation micro-batch (B = 9 student / 18 teacher-CFG): SWEEP_FILTER=d9
+    ("d9 conv 128x8 512>512", 9, 128, 8, 512, 512, 3, 3, 1),
+    ("d9 conv 256x16 256>256", 9, 256, 16, 256, 256, 3, 3, 1),
+    ("d9 conv 64x4 1024>1024", 9, 64, 4, 1024, 1024, 3, 3, 1),
+    ("d9 lin M9216 640>512", 9, 1024, 1, 640, 512, 1, 1, 1),
+    ("d9 lin M36864 320>256", 9, 4096, 1, 320, 256, 1, 1, 1),
+    ("d9 lin M36864 256>256", 9, 4096, 1, 256, 256, 1, 1, 1),
+    ("d9 lin M9216 512>512", 9, 1024, 1, 512, 512, 1, 1, 1),
+    ("d9 lin M2304 1280>1024", 9, 256, 1, 1280, 1024, 1, 1, 1),
+    ("d9 lin M4608 1024>1024", 18, 256, 1, 1024, 1024, 1, 1, 1),
+    ("d9 lin M36864 256>2048", 9, 4096, 1, 256, 2048, 1, 1, 1),
+    ("d9 lin M9216 2048>512", 9, 1024, 1, 2048, 512, 1, 1, 1),
 ]
 
 
