@@ -113,6 +113,7 @@ SIGNATURES = {
     "ctta_weighted_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "ctta_weighted_mse_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_pack_weight_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "ctta_pack_weight_rows_multi": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_copy_segments_multi": (c_int, [c_void_p, c_int, c_void_p]),
     "ctta_unet_forward_train": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ctta_unet_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

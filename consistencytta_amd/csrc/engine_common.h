@@ -93,6 +93,7 @@ struct WeightStore {
     const int32_t *ro, *co, *ra, *ca;
     int aux_limit, n_rows, k_pad;
     bf16_t* dst;
+    int src_row_len;   // > 0: rows are contiguous source ranges (row-staged pack kernel), 0: generic gather
   };
   struct CopySpec {
     std::string key;
@@ -107,6 +108,15 @@ struct WeightStore {
   int tpose_blocks = 0;
   bool tpose_uploaded = false;
   std::vector<ctta_pack_job> h_pack, h_pack_prev;
+  // jobs of the row-staged kernel, one table per LDS class: [0] rows of <= 9216 floats (36 KB: four 256-thread
+  // blocks per CU), [1] longer rows (one 1024-thread block per CU)
+  static constexpr int kRowsLdsSmall = 9216, kRowsLdsLarge = 36 * 1024;
+  struct RowClass {
+    std::vector<ctta_pack_job> h, h_prev;
+    ctta_pack_job* d = nullptr;
+    size_t cap = 0;
+    int blocks = 0, lds_floats = 0;
+  } rowc[2];
   std::vector<ctta_copy_seg> h_copy, h_copy_prev;
   ctta_pack_job* d_pack = nullptr;
   ctta_copy_seg* d_copy = nullptr;
@@ -123,6 +133,7 @@ struct WeightStore {
   void destroy() {
     if (arena.base) (void)hipFree(arena.base);
     if (d_pack) (void)hipFree(d_pack);
+    for (RowClass& c : rowc) { if (c.d) (void)hipFree(c.d); c.d = nullptr; c.cap = 0; }
     if (d_copy) (void)hipFree(d_copy);
     if (d_tpose) (void)hipFree(d_tpose);
     arena.base = nullptr; d_pack = nullptr; d_copy = nullptr; d_tpose = nullptr;
@@ -138,6 +149,7 @@ struct WeightStore {
   ctta_status run_all(const WeightTable& wt, hipStream_t s) {
     // ---- bf16 packs
     h_pack.clear();
+    for (RowClass& c : rowc) { c.h.clear(); c.blocks = 0; c.lds_floats = 0; }
     int blk = 0;
     for (const PackSpec& p : packs) {
       const ctta_tensor* t;
@@ -155,7 +167,22 @@ struct WeightStore {
       ctta_pack_job j;
       memset(&j, 0, sizeof(j));   // tables are compared bytewise: no indeterminate padding
       j.src = t->data; j.row_off = p.ro; j.col_off = p.co; j.row_aux = p.ra; j.col_aux = p.ca;
-      j.aux_limit = p.aux_limit; j.n_rows = p.n_rows; j.k_pad = p.k_pad; j.dst = p.dst; j.block0 = blk;
+      j.aux_limit = p.aux_limit; j.n_rows = p.n_rows; j.k_pad = p.k_pad; j.dst = p.dst;
+      j.src_row_len = p.src_row_len;
+      if (p.src_row_len > 0 && p.src_row_len <= kRowsLdsLarge) {   // source rows staged in LDS
+        RowClass& c = rowc[p.src_row_len <= kRowsLdsSmall ? 0 : 1];
+        const int cap = p.src_row_len <= kRowsLdsSmall ? kRowsLdsSmall : kRowsLdsLarge;
+        int rpb = cap / p.src_row_len;
+        if (rpb > 64) rpb = 64;
+        if (rpb > p.n_rows) rpb = p.n_rows;
+        j.rows_per_block = rpb;
+        j.block0 = c.blocks;
+        c.blocks += (p.n_rows + rpb - 1) / rpb;
+        if (rpb * p.src_row_len > c.lds_floats) c.lds_floats = rpb * p.src_row_len;
+        c.h.push_back(j);
+        continue;
+      }
+      j.block0 = blk;
       blk += (int)(((int64_t)p.n_rows * p.k_pad + CTTA_PACK_ELEMS_PER_BLOCK - 1) / CTTA_PACK_ELEMS_PER_BLOCK);
       h_pack.push_back(j);
     }
@@ -179,6 +206,12 @@ struct WeightStore {
       }
     }
     CTTA_TRY(sync_table(h_pack, h_pack_prev, (void**)&d_pack, &d_pack_cap, sizeof(ctta_pack_job)));
+    for (int ci = 0; ci < 2; ++ci) {
+      RowClass& c = rowc[ci];
+      CTTA_TRY(sync_table(c.h, c.h_prev, (void**)&c.d, &c.cap, sizeof(ctta_pack_job)));
+      if (!c.h.empty())
+        CTTA_TRY(ctta_pack_weight_rows_multi(c.d, (int)c.h.size(), c.blocks, c.lds_floats, ci == 0 ? 256 : 1024, s));
+    }
     CTTA_TRY(sync_table(h_copy, h_copy_prev, (void**)&d_copy, &d_copy_cap, sizeof(ctta_copy_seg)));
     if (!h_pack.empty()) CTTA_TRY(ctta_pack_weight_multi(d_pack, (int)h_pack.size(), pack_blocks, s));
     if (!h_copy.empty()) CTTA_TRY(ctta_copy_segments_multi(d_copy, (int)h_copy.size(), s));
@@ -249,7 +282,19 @@ struct WeightStore {
     if (aux_limit > 0) { CTTA_TRY(upload(*row_aux, &dra)); CTTA_TRY(upload(*col_aux, &dca)); }
     *out = dst;
     if (pm) { pm->wkey = key; pm->ro = dro; pm->co = dco; pm->n = n_rows; }
-    packs.push_back({key, expect_shape, dro, dco, dra, dca, aux_limit, n_rows, k_pad, dst});
+    // rows that are contiguous source ranges (every plain conv / linear weight: row r = src[r * rowlen ...]) take the
+    // row-staged kernel; anything else (the ConvTranspose phase packs) the generic gather
+    int src_row_len = 0;
+    if (!expect_shape.empty() && expect_shape[0] > 0 && k_pad % 8 == 0) {
+      int64_t numel = 1;
+      for (int64_t d : expect_shape) numel *= d;
+      const int64_t rowlen = numel / expect_shape[0];
+      bool ok = rowlen > 0 && rowlen < (1 << 30);
+      for (int32_t c : col_off) ok = ok && c < rowlen;
+      for (int32_t r : row_off) ok = ok && (r < 0 || (r % rowlen == 0 && r + rowlen <= numel));
+      if (ok) src_row_len = (int)rowlen;
+    }
+    packs.push_back({key, expect_shape, dro, dco, dra, dca, aux_limit, n_rows, k_pad, dst, src_row_len});
     return CTTA_OK;
   }
 

@@ -101,17 +101,112 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const ctta_pack_
   const long long total = (long long)j.n_rows * j.k_pad;
   const long long base = (long long)(blockIdx.x - j.block0) * CTTA_PACK_ELEMS_PER_BLOCK;
   bf16_t* dst = (bf16_t*)j.dst;
+  static_assert(CTTA_PACK_ELEMS_PER_BLOCK == 256 * 8, "one 8-element group per thread");
+  // a thread packs 8 consecutive destination elements (k_pad is a multiple of 64: they share the row), so the
+  // row / column split is one division per 16-byte store instead of two 64-bit divisions per element
+  const long long idx = base + (long long)threadIdx.x * 8;
+  if (idx >= total) return;
+  const int r = (int)(idx / j.k_pad);
+  const int k = (int)(idx - (long long)r * j.k_pad);
+  const int ro = j.row_off[r];
+  const int4 c0 = *reinterpret_cast<const int4*>(j.col_off + k);
+  const int4 c1 = *reinterpret_cast<const int4*>(j.col_off + k + 4);
+  const int co[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+  float f[8];
 #pragma unroll
-  for (int i = 0; i < CTTA_PACK_ELEMS_PER_BLOCK / 256; ++i) {
-    const long long idx = base + i * 256 + threadIdx.x;
-    if (idx >= total) break;
-    const int k = (int)(idx % j.k_pad);
-    const int r = (int)(idx / j.k_pad);
-    const int ro = j.row_off[r], co = j.col_off[k];
-    bool ok = ro >= 0 && co >= 0;
-    if (ok && j.aux_limit > 0) ok = j.row_aux[r] + j.col_aux[k] < j.aux_limit;
-    dst[idx] = ok ? f2bf(j.src[(size_t)ro + (size_t)co]) : (bf16_t)0;
+  for (int e = 0; e < 8; ++e) {
+    bool ok = ro >= 0 && co[e] >= 0;
+    if (ok && j.aux_limit > 0) ok = j.row_aux[r] + j.col_aux[k + e] < j.aux_limit;
+    f[e] = ok ? j.src[(size_t)ro + (size_t)co[e]] : 0.f;
   }
+  *reinterpret_cast<uint4*>(dst + idx) = pack8(f);
+}
+// Row-staged pack: a block owns rows_per_block whole destination rows of one job.  Their source rows (contiguous
+// fp32 ranges) are read once, coalesced, into LDS; the (cin, kh, kw) -> (kh, kw, cin) permutation is then an LDS
+// gather with a destination pair per lane (lane stride 2 * kh * kw floats: at most 2-way bank conflicts for 3x3
+// taps) and a coalesced 4-byte store.  HBM traffic is the algorithmic 4 + 2 bytes per element; the column table
+// (4 bytes per element, shared by all rows of a job) is served by the L2.
+#define CTTA_PACK_ROWS_MAX_RPB 64
+__global__ __launch_bounds__(1024) void pack_weight_rows_multi_kernel(const ctta_pack_job* __restrict__ jobs, int n_jobs) {
+  extern __shared__ float srow[];
+  __shared__ int s_ro[CTTA_PACK_ROWS_MAX_RPB];
+  int lo = 0, hi = n_jobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block0 <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const ctta_pack_job j = jobs[lo];
+  const int r0 = ((int)blockIdx.x - j.block0) * j.rows_per_block;
+  const int nr = min(j.rows_per_block, j.n_rows - r0);
+  const int L = j.src_row_len, kp = j.k_pad;
+  const int nt = blockDim.x;
+  if ((int)threadIdx.x < nr) s_ro[threadIdx.x] = j.row_off[r0 + threadIdx.x];
+  __syncthreads();
+  if ((L & 3) == 0 && (reinterpret_cast<uintptr_t>(j.src) & 15) == 0) {   // row_off is a multiple of L: 16-byte rows
+    const int L4 = L >> 2, n4 = nr * L4;
+    float4* s4 = reinterpret_cast<float4*>(srow);
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n4; i += nt) {
+      const int r = i / L4, c = i - r * L4;
+      const int ro = s_ro[r];
+      if (ro >= 0) s4[i] = *reinterpret_cast<const float4*>(j.src + ro + 4 * c);
+    }
+  } else {
+    const int n = nr * L;
+#pragma unroll 4
+    for (int i = threadIdx.x; i < n; i += nt) {
+      const int r = i / L, c = i - r * L;
+      const int ro = s_ro[r];
+      if (ro >= 0) srow[i] = j.src[(size_t)ro + c];
+    }
+  }
+  __syncthreads();
+  bf16_t* dst = (bf16_t*)j.dst + (size_t)r0 * kp;
+  const int total = nr * kp;   // k_pad is a multiple of 64: a pair never straddles rows
+  for (int base = threadIdx.x * 2; base < total; base += nt * 8) {
+    int2 c[4];
+    int rr[4], kk[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * nt * 2;
+      const int r = idx < total ? idx / kp : 0;
+      rr[u] = r; kk[u] = idx < total ? idx - r * kp : 0;
+      c[u] = *reinterpret_cast<const int2*>(j.col_off + kk[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * nt * 2;
+      if (idx >= total) break;
+      const int ro = s_ro[rr[u]];
+      bool ok0 = ro >= 0 && c[u].x >= 0, ok1 = ro >= 0 && c[u].y >= 0;
+      if (j.aux_limit > 0 && ro >= 0) {
+        const int ra = j.row_aux[r0 + rr[u]];
+        ok0 = ok0 && ra + j.col_aux[kk[u]] < j.aux_limit;
+        ok1 = ok1 && ra + j.col_aux[kk[u] + 1] < j.aux_limit;
+      }
+      const float* sr = srow + rr[u] * L;
+      const float f0 = ok0 ? sr[c[u].x] : 0.f;
+      const float f1 = ok1 ? sr[c[u].y] : 0.f;
+      *reinterpret_cast<uint32_t*>(dst + idx) = pack2bf(f0, f1);
+    }
+  }
+}
+extern "C" ctta_status ctta_pack_weight_rows_multi(const ctta_pack_job* jobs, int n_jobs, int total_blocks,
+                                                   int lds_floats, int threads, void* stream) {
+  CTTA_REQUIRE(jobs && n_jobs >= 1 && total_blocks >= 1 && lds_floats >= 1, "pack_weight_rows_multi: bad arguments");
+  CTTA_REQUIRE(threads == 256 || threads == 512 || threads == 1024, "pack_weight_rows_multi: threads must be 256, 512 or 1024");
+  const size_t smem = (size_t)lds_floats * sizeof(float);
+  CTTA_REQUIRE(smem + sizeof(int) * CTTA_PACK_ROWS_MAX_RPB <= 160 * 1024,
+               "pack_weight_rows_multi: %d staged floats do not fit the LDS", lds_floats);
+  static size_t configured = 0;
+  if (smem > configured) {
+    CTTA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&pack_weight_rows_multi_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    configured = smem;
+  }
+  hipLaunchKernelGGL(pack_weight_rows_multi_kernel, dim3(total_blocks), dim3(threads), smem, (hipStream_t)stream, jobs, n_jobs);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
 }
 __global__ __launch_bounds__(256) void copy_segments_multi_kernel(const ctta_copy_seg* __restrict__ segs) {
   const ctta_copy_seg g = segs[blockIdx.x];

@@ -345,6 +345,9 @@ typedef struct {
   const int32_t *row_off, *col_off, *row_aux, *col_aux;
   int aux_limit, n_rows, k_pad, block0;
   void* dst;
+  int src_row_len;     /* > 0: every source row is the contiguous range [row_off[r], row_off[r] + src_row_len) and
+                          all col_off < src_row_len: eligible for ctta_pack_weight_rows_multi */
+  int rows_per_block;  /* ctta_pack_weight_rows_multi only: rows a block stages (<= 64; block0 counts such blocks) */
 } ctta_pack_job;
 typedef struct {
   const float* src;
@@ -352,6 +355,13 @@ typedef struct {
   int count;
 } ctta_copy_seg;
 ctta_status ctta_pack_weight_multi(const ctta_pack_job* jobs, int n_jobs, int total_blocks, void* stream);
+/* Same result for jobs with src_row_len > 0.  A block of `threads` (256 / 512 / 1024) threads stages
+ * rows_per_block source rows (rows_per_block * src_row_len <= lds_floats floats of dynamic shared memory), read once
+ * and coalesced, and permutes them from LDS -- the strided (cin, kh, kw) -> (kh, kw, cin) gather of a conv weight
+ * otherwise touches every cache line kh*kw times.  Callers launch one table per LDS class so that short rows keep
+ * several blocks per CU. */
+ctta_status ctta_pack_weight_rows_multi(const ctta_pack_job* jobs, int n_jobs, int total_blocks, int lds_floats,
+                                        int threads, void* stream);
 /* Table-driven bf16 transposes (one 64x64 tile per block): dst[c][r] = src[r][c] for r < rows, c < cols, zero for
  * rows <= r < wcols; only the first wcols columns of a dst row are written.  Used to derive the data-gradient
  * operands (W^T, rotated conv taps) from the freshly packed forward operands without re-reading fp32 weights. */
