@@ -517,3 +517,85 @@ def test_errors_are_loud():
     d = conv_desc()
     with pytest.raises(N.CttaError):
         N.check(lib().ctta_conv_gemm(ctypes.byref(d), N.stream_ptr()))
+
+
+class _PackJob(ctypes.Structure):
+    """ctta_pack_job of include/ctta.h."""
+    _fields_ = [("src", ctypes.c_void_p), ("row_off", ctypes.c_void_p), ("col_off", ctypes.c_void_p),
+                ("row_aux", ctypes.c_void_p), ("col_aux", ctypes.c_void_p), ("aux_limit", ctypes.c_int),
+                ("n_rows", ctypes.c_int), ("k_pad", ctypes.c_int), ("block0", ctypes.c_int),
+                ("dst", ctypes.c_void_p), ("src_row_len", ctypes.c_int), ("rows_per_block", ctypes.c_int)]
+
+
+def _pack_case(name, cout, cin, taps, n_rows, aux_limit, seed):
+    """A conv-weight-like job: src (cout, cin, taps) fp32 -> dst [n_rows][k_pad] with k = (tap, cin); some rows
+    are zero rows (row_off < 0), the K tail is padding (col_off < 0), optional aux masking."""
+    g = torch.Generator().manual_seed(seed)
+    L = cin * taps
+    K = taps * cin
+    k_pad = (K + 63) // 64 * 64
+    src = det(name, (cout, cin, taps), seed)
+    ro = torch.full((n_rows,), -1, dtype=torch.int32)
+    perm = torch.randperm(cout, generator=g)
+    for r in range(min(n_rows, cout)):
+        if r % 7 != 5:
+            ro[r] = int(perm[r]) * L
+    co = torch.full((k_pad,), -1, dtype=torch.int32)
+    for t in range(taps):
+        for c in range(cin):
+            co[t * cin + c] = c * taps + t
+    ra = torch.randint(0, 3, (n_rows,), generator=g, dtype=torch.int32)
+    ca = torch.randint(0, 3, (k_pad,), generator=g, dtype=torch.int32)
+    flat = src.reshape(-1)
+    want = torch.zeros(n_rows, k_pad)
+    for r in range(n_rows):
+        if ro[r] < 0:
+            continue
+        ok = co >= 0
+        if aux_limit > 0:
+            ok = ok & ((ra[r] + ca) < aux_limit)
+        idx = (ro[r] + co.clamp(min=0)).long()
+        want[r] = torch.where(ok, flat[idx], torch.zeros(()))
+    return dict(src=src, ro=ro, co=co, ra=ra, ca=ca, aux_limit=aux_limit, n_rows=n_rows, k_pad=k_pad, L=L,
+                want=want.to(torch.bfloat16))
+
+
+@pytest.mark.parametrize("threads,lds_floats", [(256, 9216), (1024, 36 * 1024)])
+def test_pack_weight_tables_match_gather(threads, lds_floats):
+    """ctta_pack_weight_multi (generic gather) and ctta_pack_weight_rows_multi (LDS-staged rows) against a host
+    gather, bit-exact (round-to-nearest-even bf16): several rows per block, a ragged last block, zero rows, K padding,
+    aux masking, a row length that is not a multiple of 4 (scalar staging), a row that fills the LDS class."""
+    cases = [_pack_case("pk.a", 40, 32, 9, 37, 0, 1),      # 3x3 conv, rows of 288 floats, many rows per block
+             _pack_case("pk.b", 70, 51, 1, 70, 0, 2),      # linear with odd width: scalar staging
+             _pack_case("pk.c", 16, 24, 4, 20, 4, 3),      # aux masking, more destination rows than source rows
+             _pack_case("pk.d", 3, lds_floats // 9, 9, 3, 0, 4)]   # one row per block, LDS filled
+    keep = []
+    for variant in ("rows", "generic"):
+        jobs = (_PackJob * len(cases))()
+        blocks = 0
+        outs = []
+        for i, c in enumerate(cases):
+            dev = {k: c[k].contiguous().to(DEV) for k in ("src", "ro", "co", "ra", "ca")}
+            out = torch.full((c["n_rows"], c["k_pad"]), 7.0, dtype=torch.bfloat16, device=DEV)
+            keep.append(dev)
+            outs.append(out)
+            j = jobs[i]
+            j.src, j.row_off, j.col_off = N.ptr(dev["src"]), N.ptr(dev["ro"]), N.ptr(dev["co"])
+            j.row_aux, j.col_aux = N.ptr(dev["ra"]), N.ptr(dev["ca"])
+            j.aux_limit, j.n_rows, j.k_pad, j.dst = c["aux_limit"], c["n_rows"], c["k_pad"], N.ptr(out)
+            j.src_row_len, j.block0 = c["L"], blocks
+            if variant == "rows":
+                rpb = max(1, min(64, lds_floats // c["L"], c["n_rows"]))
+                j.rows_per_block = rpb
+                blocks += (c["n_rows"] + rpb - 1) // rpb
+            else:
+                blocks += (c["n_rows"] * c["k_pad"] + 2047) // 2048
+        table = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(DEV)
+        if variant == "rows":
+            N.check(lib().ctta_pack_weight_rows_multi(N.ptr(table), len(cases), blocks, lds_floats, threads,
+                                                      N.stream_ptr()))
+        else:
+            N.check(lib().ctta_pack_weight_multi(N.ptr(table), len(cases), blocks, N.stream_ptr()))
+        torch.cuda.synchronize()
+        for c, out in zip(cases, outs):
+            assert torch.equal(out.cpu().view(torch.int16), c["want"].view(torch.int16)), variant
