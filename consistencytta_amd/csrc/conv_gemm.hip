@@ -995,7 +995,10 @@ static bool want_big_tile(long long M, int N, long long K, int groups) {
   return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= 1024 && t256 >= 192;
 }
 static int pick_variant(long long M, int N, long long K, int groups) {
-  if (N <= 32) return 4;                                   // 256x32
+  if (N <= 32) {                                           // 256x32; few row tiles (the per-sample cross-attention
+    const long long t256 = ((M + 255) / 256) * groups;     // K / V^T projections: 18..180 workgroups walking K = 1024
+    return t256 >= 512 ? 4 : 5;                            // one latency-bound tile at a time): 64x64 quadruples them
+  }
   if (N <= 64) return K >= 512 ? 8 : 5;                    // 128x64 / 64x64
   const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * groups;
   if (t128 < 200) return 5;                                // too few 128x128 tiles to fill 256 CUs
@@ -1130,8 +1133,11 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   int splits = 1;
   if (splitk_default() && ws && groups == 1 && !scalar_store && !geglu && d->out_limit == 0 && d->out_offset == 0 &&
       tiles < 192 && p.nk >= 32) {
-    splits = (int)(512 / tiles);
-    if (splits > 8) splits = 8;
+    static int target = -1, cap = -1;   // tuning knobs: workgroups aimed for / most splits
+    if (target < 0) { const char* e = getenv("CTTA_SPLITK_TARGET"); target = e ? atoi(e) : 512; }
+    if (cap < 0) { const char* e = getenv("CTTA_SPLITK_MAX"); cap = e ? atoi(e) : 8; }
+    splits = (int)(target / tiles);
+    if (splits > cap) splits = cap;
     if (splits > p.nk / 8) splits = p.nk / 8;
     const int ld = (d->n + 3) / 4 * 4;
     if ((long long)splits * M * ld * 4 > (long long)kSplitWsBytes) splits = 1;
