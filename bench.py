@@ -35,6 +35,7 @@ GF_VAE_CONV, GF_VAE_ATTN = 636.1, 34.4
 GF_HIFIGAN = 1027.0
 GF_SMALL_N = 0.15 + 0.15 + 0.07          # conv_out (U-Net, VAE) and conv_post run on the direct kernel
 PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA peak, MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0                    # HBM3E peak, MI355X_MICROARCH.md
 
 
 def parse():
@@ -464,6 +465,30 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             "executed_tflops_incl_padding": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
             "share_of_step_time": round(ms.value / ev[0].elapsed_time(ev[1]), 3),
         }
+    if rank == 0:   # the HBM-bound kernel class of the step: fused training-state passes over 559 M fp32
+        def timed(fn, reps=5):
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()   # the launches go to torch's current stream (N.stream_ptr()), the one these events see
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        n_tr, n_all = opt.n, opt.flat.numel()
+        passes = [
+            ("adamw_kernel", "read p, g, m, v; write p, m, v (fp32)", 28 * n_tr, lambda: opt.step(grad_scale=1.0)),
+            ("ema2_kernel", "read student, 2 shadows; write 2 shadows (fp32)", 20 * n_all, m.update_ema),
+            ("zero_grad (fill)", "write g (fp32)", 4 * opt.grad.numel(), opt.zero_grad),
+        ]
+        rows = []
+        for name, what, nbytes, fn in passes:
+            ms_ = timed(fn)
+            gbps = nbytes / (ms_ * 1e-3) / 1e9
+            rows.append({"kernel": name, "streams": what, "algorithmic_GB_per_launch": round(nbytes / 1e9, 3),
+                         "ms": round(ms_, 3), "achieved_GBps": round(gbps, 1), "frac": round(gbps / PEAK_HBM_GBPS, 4)})
+        out["hbm_kernels"] = {"bound": "hbm", "peak": PEAK_HBM_GBPS, "unit": "GB/s", "parameters": int(n_all),
+                              "passes": rows}
     if rank == 0:   # the adjacent front half of the real training step (train_utils.py:155-162): wav -> log-mel -> latent
         from consistencytta_amd import audio, modules
         stft = audio.TacotronSTFT(1024, 160, 1024, 64, 16000, 0, 8000).to(dev)
