@@ -195,6 +195,34 @@ def main():
             "share_of_step_time": round(conv_ms / (dt / args.steps * 1e3), 3),
             "mfma_launch_ms_per_step_all_kinds": round(all_ms, 3),
         }
+        # ---- the HBM-bound kernel class of the clip: GroupNorm + SiLU at the two largest layer shapes,
+        # priced on the layer-boundary bytes (read x once, write y once; the statistics pass re-reads x)
+        def gn_pass(tag, HW, C):
+            Lb = N.lib()
+            x = torch.randn(B, HW, C, device=dev).to(torch.bfloat16)
+            y = torch.empty_like(x)
+            ga, be = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+            scr = torch.empty(int(Lb.ctta_groupnorm_scratch_floats(B, HW, C, 32)), dtype=torch.float32, device=dev)
+
+            def fn():
+                N.check(Lb.ctta_groupnorm(N.ptr(x), N.ptr(y), B, HW, C, 32, N.ptr(ga), N.ptr(be), 1e-5, 1, N.ptr(scr),
+                                          N.stream_ptr()))
+            fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms_ = e0.elapsed_time(e1) / 5
+            nbytes = 2 * x.numel() * 2
+            gbps = nbytes / (ms_ * 1e-3) / 1e9
+            return {"kernel": "groupnorm+silu (gn_partial / gn_finalize / gn_apply)", "shape": tag,
+                    "algorithmic_GB_per_launch": round(nbytes / 1e9, 3), "ms": round(ms_, 3),
+                    "achieved_GBps": round(gbps, 1), "frac": round(gbps / PEAK_HBM_GBPS, 4)}
+        result["hbm_kernels"] = {"bound": "hbm", "peak": PEAK_HBM_GBPS, "unit": "GB/s", "passes": [
+            gn_pass("VAE decoder last level (%d, 1024x64, 128)" % B, 65536, 128),
+            gn_pass("U-Net level 0 (%d, 256x16, 256)" % B, 4096, 256)]}
         # ---- PCIe-inclusive variant (the reference's decode_to_waveform ends on the host)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
