@@ -206,6 +206,48 @@ def test_pipeline_config1_end_to_end(golden):
     assert bool(torch.isfinite(wav).all()) and float(wav.abs().max()) <= 1.0
 
 
+def test_pipeline_batch32_shards_into_single_clip_runs(golden):
+    """BASELINE.json configs[1] at its full size (batch 32, light U-Net + VAE decoder + HiFi-GAN, L=32 with ragged
+    masks) through a size-independent property: every clip of the batch equals the same clip run alone (the shape
+    the config-1 golden pins against the reference) -- clips are independent, so a batch shards over ranks with no
+    data-path collective.  Tile shapes and split-K differ between M = 32 x 4096 and M = 4096, so the
+    fp32 accumulation ORDER differs; on this random-init network any such change (split-K off, another tile, another
+    batch size -- tools/order_noise.py) moves the bf16 result by the same 9.2e-3 relative L2 in the latent (1.9e-2
+    mel, 1.6e-2 waveform): the bf16 rounding-noise floor, below the 1.2e-2 / 1.9e-2 distance to the fp32 reference.
+    The tolerances are that floor with 2x margin; a replay of the batch itself is bit-exact."""
+    from consistencytta_amd.models import ConsistencyTTA
+    g = golden("pipeline_light")
+    cfg = spec.LIGHT_UNET_CONFIG
+    v, _ = _vae(spec.VAE_DDCONFIG, spec.HIFIGAN_16K_64)
+    v.scale_factor = float(g["scale_factor"])
+    pipe = ConsistencyTTA(unet_config=cfg, vae=v)
+    _load(pipe.unet, cases.unet_weights(cfg, True))
+    B, L = 32, 32
+    gen = torch.Generator().manual_seed(3)
+    enc = torch.randn(B, L, 1024, generator=gen) * 0.25
+    lens = torch.randint(6, L + 1, (B,), generator=gen)
+    mask = torch.arange(L)[None, :] < lens[:, None]
+    noise = torch.randn(B, 8, 256, 16, generator=gen)
+
+    def run(sel):
+        lat = pipe.generate_latent(enc[sel].to(DEV), mask[sel].to(DEV), noise[sel].to(DEV), cfg_scale_input=4.0,
+                                   cfg_scale_post=1.0, num_steps=1)
+        mel = v.decode_first_stage(lat)
+        return lat, mel, v.vocode(mel)
+    full = run(slice(0, B))
+    again = run(slice(0, B))
+    for a, b in zip(full, again):
+        assert torch.equal(a, b)
+    assert full[2].shape == (B, 163872) and bool(torch.isfinite(full[2]).all())
+    for i in (0, 17, 31):
+        one = run(slice(i, i + 1))
+        for tag, a, b, tol in (("latent", full[0][i:i + 1], one[0], 2e-2), ("mel", full[1][i:i + 1], one[1], 3e-2),
+                               ("waveform", full[2][i:i + 1], one[2], 3e-2)):
+            err = rel_l2(a.float().cpu(), b.float().cpu())
+            print("clip %d %s: batch-32 vs alone rel_l2 %.2e" % (i, tag, err))
+            assert err < tol, (i, tag, err)
+
+
 def test_vae_encoder_against_reference_golden_and_oracle_taps(golden):
     """AutoencoderKL.encode_first_stage / get_first_stage_encoding on the HIP encoder: posterior
     moments vs the reference's own fixture, layer by layer vs the oracle, and the sampled, scaled latent."""
