@@ -60,6 +60,26 @@ def parse():
     return ap.parse_args()
 
 
+def flush_c_stdio():
+    """RCCL prints its banner (ROCm version / hostname / library path) with C stdio; on a pipe that buffer is only
+    flushed at exit, i.e. AFTER the JSON line.  Flushing it here keeps the JSON line the last line on stdout."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
+def emit(result, rank, dev):
+    """Every rank drains its stdio, then rank 0 prints the ONE JSON line."""
+    from consistencytta_amd import dist_util as du
+    flush_c_stdio()
+    du.barrier(dev)
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
 def main():
     args = parse()
     if args.mode in ("distill", "perceptual"):
@@ -76,13 +96,18 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    du.init("nccl", dev)   # "nccl" is RCCL on ROCm: timing barrier / max-reduce, gradient all-reduce of the distill leg
+    # CTTA_BENCH_BACKEND=gloo rehearses the multi-rank flow (same collective sequence on every rank) on a box with
+    # fewer GPUs than ranks: ranks share devices round-robin and the collectives go through the host
+    backend = os.environ.get("CTTA_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    du.init(backend, dev)   # "nccl" is RCCL on ROCm: timing barrier / max-reduce, gradient all-reduce of the distill leg
+    du.barrier(dev)         # first collective: the communicator (and its banner) exists from here on
+    flush_c_stdio()
     if args.mode == "teacher":
         d = teacher_leg(args, dev, world, rank)
-        if rank == 0:
-            print(json.dumps(d), flush=True)
+        emit(d, rank, dev)
         du.finish()
         return
     if args.mode in ("distill", "perceptual"):   # profiling aid: only that leg, printed as the JSON line
@@ -90,7 +115,7 @@ def main():
         if rank == 0:
             d.update({"steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
                       "data": "synthetic"})
-            print(json.dumps(d), flush=True)
+        emit(d, rank, dev)
         du.finish()
         return
 
@@ -323,8 +348,7 @@ def main():
             except Exception as exc:   # the newest leg must not cost the headline line
                 pd_ = {"error": str(exc)[:300]}
             result["perceptual_distill"] = pd_
-    if rank == 0:
-        print(json.dumps(result), flush=True)
+    emit(result if rank == 0 else None, rank, dev)
     du.finish()
 
 
@@ -470,15 +494,19 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                                      "AdamW, EMA")
         del m, opt, vae
         return out
+    # one more step with the in-library launch profiler on rank 0.  EVERY rank takes the step: at world > 1 it issues
+    # the gradient all-reduces, and a collective entered by rank 0 alone would pair up with the other ranks' next
+    # barrier and hang the job
+    import ctypes
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    L_ = N.lib()
     if rank == 0:
-        import ctypes
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        L_ = N.lib()
         L_.ctta_prof_enable(1)
-        ev[0].record()
-        m.train_step(z0, P, opt, sched)
-        ev[1].record()
-        torch.cuda.synchronize()
+    ev[0].record()
+    m.train_step(z0, P, opt, sched)
+    ev[1].record()
+    torch.cuda.synchronize()
+    if rank == 0:
         L_.ctta_prof_enable(0)
         ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         csv = (args.profile_csv + ".distill").encode() if args.profile_csv else None

@@ -771,7 +771,9 @@ def _teacher_loop_graphed(self, sch, z, enc, mask, guidance_scale):
         x.copy_(x0)
         idx.zero_()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # thread-local capture mode: with a process group alive, RCCL's watchdog thread may touch the HIP runtime
+        # during the capture; only this thread's calls belong to it
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             pair()
         x.copy_(x0)
         idx.zero_()
@@ -877,7 +879,7 @@ class ConsistencyTTA(nn.Module):
             run()
         torch.cuda.current_stream(dev).wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             out = run()
 
         def replay(encoder_states, encoder_mask, noise):
