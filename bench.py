@@ -53,7 +53,8 @@ def parse():
     ap.add_argument("--teacher-batch", type=int, default=8)
     ap.add_argument("--distill-batch", type=int, default=9, help="per-GPU micro-batch of the distillation leg (train.sh)")
     ap.add_argument("--no-latency", action="store_true",
-                    help="skip the single-clip eager/hipGraph latency leg (graph replay hangs under rocprofv3 --pmc)")
+                    help="skip the single-clip eager/hipGraph latency leg (graph replay hangs under rocprofv3 --pmc) and, "
+                         "in --mode distill, the AdamW / EMA timing passes and the wav -> latent leg (PMC passes)")
     ap.add_argument("--perceptual-batch", type=int, default=4,
                     help="per-GPU micro-batch of the perceptual-loss leg (configs[4] without CLAP)")
     ap.add_argument("--profile-csv", default=None, help="append one line per MFMA launch (tuning aid)")
@@ -515,13 +516,14 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         out["roofline"] = {
             "kernel": "conv_gemm_kernel (forward, data-gradient, weight-gradient and attention-backward GEMMs)",
             "bound": "mfma", "achieved": round(algo / (ms.value * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS,
-            "unit": "TFLOP/s", "frac": round(algo / (ms.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "unit": "TFLOP/s", "frac": round(algo / (ms.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+            "traffic": pmc_traffic_distill(B),
             "algorithmic_gflop_per_sample": GF_DISTILL_PER_SAMPLE, "launches_per_step": int(cnt.value),
             "kernel_ms_per_step": round(ms.value, 3),
             "executed_tflops_incl_padding": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
             "share_of_step_time": round(ms.value / ev[0].elapsed_time(ev[1]), 3),
         }
-    if rank == 0:   # the HBM-bound kernel class of the step: fused training-state passes over 559 M fp32
+    if rank == 0 and not args.no_latency:   # the HBM-bound kernel class of the step: fused training-state passes over 559 M fp32
         def timed(fn, reps=5):
             fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -545,7 +547,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                          "ms": round(ms_, 3), "achieved_GBps": round(gbps, 1), "frac": round(gbps / PEAK_HBM_GBPS, 4)})
         out["hbm_kernels"] = {"bound": "hbm", "peak": PEAK_HBM_GBPS, "unit": "GB/s", "parameters": int(n_all),
                               "passes": rows}
-    if rank == 0:   # the adjacent front half of the real training step (train_utils.py:155-162): wav -> log-mel -> latent
+    if rank == 0 and not args.no_latency:   # the adjacent front half of the real training step (train_utils.py:155-162): wav -> log-mel -> latent
         from consistencytta_amd import audio, modules
         stft = audio.TacotronSTFT(1024, 160, 1024, 64, 16000, 0, 8000).to(dev)
         vae = modules.AutoencoderKL(ddconfig=spec.VAE_DDCONFIG, embed_dim=8, scale_factor=0.9227914214134216)
@@ -567,6 +569,19 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         del vae, stft
     del m, opt
     return out
+
+
+def pmc_traffic_distill(batch):
+    """Same for the distillation leg: profiles/pmc_traffic_distill_r01.json (conv_gemm family, GB per step at batch 9)."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_distill_r01.json")))
+        if "batch 9" not in d.get("unit", "") or batch != 9:
+            return None
+        f = d["families"]["conv_gemm_kernel"]
+        return {"read_GB_per_step": f["read_GB"], "write_GB_per_step": f["write_GB"],   # read: None (pass hangs)
+                "source": "profiles/pmc_traffic_distill_r01.json"}
+    except Exception:
+        return None
 
 
 def pmc_traffic(batch):

@@ -10,7 +10,12 @@ Units and the gfx950 correction as the guide prescribes: FETCH_SIZE / WRITE_SIZE
 (TCC_EA0_RDREQ x 64 B / 1024); on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) coalesced
 reads at 64 B, i.e. HALF the bytes -- all loads of these kernels are 16 B/lane, so the read figure is doubled.
 WRITE_SIZE is uncalibrated on this part and reported as is.  Steps are counted by the dispatches of
-conv_small_n_kernel<1> (exactly one per generation step)."""
+conv_small_n_kernel<1> (exactly one per generation step).
+
+    python tools/pmc_traffic.py <fetch dir> <write dir> distill <train steps in the profiled run>
+
+does the same for `bench.py --mode distill` (per distillation step; the step count is given: warmup + steps + the
+one profiled step; run the bench with --no-latency so that only training steps are in the trace)."""
 import csv
 import glob
 import json
@@ -19,8 +24,9 @@ from collections import defaultdict
 
 
 def family(name):
-    for key in ("conv_gemm_kernel", "conv1d_halo_kernel", "attention_kernel", "gn_", "layernorm", "geglu", "softmax_rows",
-                "conv_small_n_kernel", "splitk_finish"):
+    for key in ("conv_gemm_kernel", "conv1d_halo_kernel", "attention_kernel", "attn_bwd", "gn_", "layernorm", "ln_bwd", "geglu",
+                "softmax_rows", "conv_small_n_kernel", "splitk_finish", "adamw_kernel", "ema2_kernel", "pack_weight",
+                "wgrad_scatter", "im2col_t", "transpose"):
         if key in name:
             return key.rstrip("_")
     return "other"
@@ -43,7 +49,11 @@ def load(directory, counter):
 def main():
     fetch, fs = load(sys.argv[1], "FETCH_SIZE")
     write, wsteps = load(sys.argv[2], "WRITE_SIZE")
-    out = {"unit": "GB per generation step (batch 32)", "steps_fetch_pass": fs, "steps_write_pass": wsteps,
+    unit = "GB per generation step (batch 32)"
+    if len(sys.argv) > 4 and sys.argv[3] == "distill":
+        fs = wsteps = int(sys.argv[4])
+        unit = "GB per distillation step (batch 9)"
+    out = {"unit": unit, "steps_fetch_pass": fs, "steps_write_pass": wsteps,
            "fetch_correction": "x2 (gfx950: 128-B requests of 16 B/lane reads tallied at 64 B)", "families": {}}
     for fam in sorted(set(fetch) | set(write), key=lambda f: -(fetch.get(f, 0) + write.get(f, 0))):
         rd = fetch.get(fam, 0.0) * 1024 * 2 / fs / 1e9
