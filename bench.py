@@ -35,6 +35,7 @@ GF_VAE_CONV, GF_VAE_ATTN = 636.1, 34.4
 GF_HIFIGAN = 1027.0
 GF_SMALL_N = 0.15 + 0.15 + 0.07          # conv_out (U-Net, VAE) and conv_post run on the direct kernel
 PEAK_BF16_TFLOPS = 2500.0                 # dense MFMA peak, MI355X_MICROARCH.md
+GB_CLIP_FUSED = 3.15                       # operand bytes per clip, every conv / linear / attention operand once
 PEAK_HBM_GBPS = 8000.0                    # HBM3E peak, MI355X_MICROARCH.md
 
 
@@ -214,13 +215,19 @@ def main():
         result["roofline"] = {
             "kernel": "conv_gemm_kernel (implicit-GEMM conv / linear / bmm, v_mfma_f32_16x16x32_bf16)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": pmc_traffic(B),
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "traffic_detail": pmc_traffic(B),
             "algorithmic_gflop_per_clip": round(gf_clip, 1), "launches_per_step": int(conv_cnt),
             "kernel_ms_per_step": round(conv_ms, 3), "avg_launch_ms": round(conv_ms / max(1, conv_cnt), 4),
             "executed_tflops_incl_padding": round(conv_exec_fl / (conv_ms * 1e-3) / 1e12, 2),
             "share_of_step_time": round(conv_ms / (dt / args.steps * 1e3), 3),
             "mfma_launch_ms_per_step_all_kinds": round(all_ms, 3),
         }
+        td = result["roofline"]["traffic_detail"]
+        if td and conv_cnt:   # per launch like `achieved`: HBM-side bytes of the family per step / its launches per step
+            result["roofline"]["traffic"] = int((td["read_GB_per_step"] + td["write_GB_per_step"]) * 1e9 / conv_cnt)
+            result["roofline"]["traffic_unit"] = ("bytes per conv_gemm launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the family "
+                                                  "per step / launches per step); algorithmic operand bytes per launch: %d"
+                                                  % int(GB_CLIP_FUSED * 1e9 * B / conv_cnt))
         # ---- the HBM-bound kernel class of the clip: GroupNorm + SiLU at the two largest layer shapes,
         # priced on the layer-boundary bytes (read x once, write y once; the statistics pass re-reads x)
         def gn_pass(tag, HW, C):
@@ -517,7 +524,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             "kernel": "conv_gemm_kernel (forward, data-gradient, weight-gradient and attention-backward GEMMs)",
             "bound": "mfma", "achieved": round(algo / (ms.value * 1e-3) / 1e12, 2), "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s", "frac": round(algo / (ms.value * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "traffic": pmc_traffic_distill(B),
+            "traffic": None, "traffic_detail": pmc_traffic_distill(B),   # reads unavailable (the FETCH_SIZE pass hangs)
             "algorithmic_gflop_per_sample": GF_DISTILL_PER_SAMPLE, "launches_per_step": int(cnt.value),
             "kernel_ms_per_step": round(ms.value, 3),
             "executed_tflops_incl_padding": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
