@@ -113,6 +113,7 @@ extern "C" ctta_status ctta_transpose_multi(const ctta_tpose_job* jobs, int n_jo
 struct Im2colParams {
   const bf16_t* x; int C, B, hi, wi, hs, ws, ups, ho, wo, kh, kw, sh, sw, ph, pw, dh, dw, M, m_pad;
   bf16_t* dst;
+  int ind_rows;   // > 0: indicator rows behind the kh*kw*C im2col rows ([0] = 1 for m < M, [1 + b] = pixels of sample b)
 };
 __global__ __launch_bounds__(256) void im2col_t_kernel(Im2colParams p) {
   __shared__ bf16_t tile[64][72];
@@ -151,18 +152,19 @@ __global__ __launch_bounds__(256) void im2col_t_kernel(Im2colParams p) {
       *reinterpret_cast<uint4*>(p.dst + ((size_t)(c0 + c) * (p.kh * p.kw) + t) * p.m_pad + m0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
     }
   }
-}
-// rows: [0] = 1 for m < M ; [1 + b] = 1 for pixels of sample b (n_batch rows; 0 disables)
-__global__ void indicator_rows_kernel(bf16_t* __restrict__ dst, int M, int m_pad, int per_batch, int n_batch) {
-  const long long total = (long long)(1 + n_batch) * m_pad;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const int m = (int)(i % m_pad);
-    const int r = (int)(i / m_pad);
-    bool one = m < M && (r == 0 || m / per_batch == r - 1);
-    dst[i] = one ? (bf16_t)0x3F80 : (bf16_t)0;
+  // the indicator rows ride in the same launch: the (channel tile 0, tap 0) block of every 64-column slice writes them
+  if (p.ind_rows > 0 && blockIdx.y == 0 && t == 0) {
+    bf16_t* rows = p.dst + (size_t)p.kh * p.kw * p.C * p.m_pad;
+    const int per_batch = p.ho * p.wo;
+    for (int i = tid; i < p.ind_rows * 64; i += 256) {
+      const int r = i >> 6, m = m0 + (i & 63);
+      if (m < p.m_pad) {
+        const bool one = m < p.M && (r == 0 || m / per_batch == r - 1);
+        rows[(size_t)r * p.m_pad + m] = one ? (bf16_t)0x3F80 : (bf16_t)0;
+      }
+    }
   }
 }
-
 extern "C" ctta_status ctta_im2col_t(const void* x, int c, int batch, int hi, int wi, int upsample, int ho, int wo,
                                      int kh, int kw, int stride, int pad_h, int pad_w, int dil_w, void* dst, int m_pad,
                                      int indicator_batches, void* stream) {
@@ -173,16 +175,10 @@ extern "C" ctta_status ctta_im2col_t(const void* x, int c, int batch, int hi, in
   p.sh = p.sw = stride; p.ph = pad_h; p.pw = pad_w; p.dh = 1; p.dw = dil_w;
   p.M = batch * ho * wo; p.m_pad = m_pad; p.dst = (bf16_t*)dst;
   CTTA_REQUIRE(m_pad >= p.M, "im2col_t: m_pad < M");
+  p.ind_rows = indicator_batches >= 0 ? 1 + indicator_batches : 0;
   dim3 grid((m_pad + 63) / 64, (c + 63) / 64, kh * kw);
   hipLaunchKernelGGL(im2col_t_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
   CTTA_LAUNCH_CHECK();
-  if (indicator_batches >= 0) {
-    bf16_t* rows = (bf16_t*)dst + (size_t)kh * kw * c * m_pad;
-    const long long total = (long long)(1 + indicator_batches) * m_pad;
-    hipLaunchKernelGGL(indicator_rows_kernel, dim3(grid1d(total)), dim3(256), 0, (hipStream_t)stream, rows, p.M, m_pad,
-                       ho * wo, indicator_batches);
-    CTTA_LAUNCH_CHECK();
-  }
   return CTTA_OK;
 }
 
