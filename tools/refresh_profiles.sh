@@ -21,9 +21,11 @@ python3 $R/tools/launch_table.py $O/launch_distill.csv.distill 60 1 > $O/launch_
 timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_fetch.log 2>&1
 timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_write.log 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/pmc_traffic.json 2> $O/pmc_traffic.err
-# distillation leg: only the WRITE_SIZE pass -- the FETCH_SIZE pass of --mode distill hangs under --pmc on this pool (twice,
-# killed by its timeout); tools/pmc_traffic.py <fetch> <write> distill 4 handles both when it works
-timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmcd_write -o p -- python3 $R/bench.py --mode distill --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmcd_write.log 2>&1
+# No PMC pass for --mode distill here: under rocprofv3 --pmc that mode hangs intermittently on this pool (FETCH_SIZE twice,
+# WRITE_SIZE once out of two runs; each costs its 420 s timeout).  profiles/pmc_traffic_distill_r01.json is the one
+# WRITE_SIZE pass that completed:
+#   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d D -o p -- python3 bench.py --mode distill --steps 2 --warmup 1 --no-cpu-baseline --no-latency
+#   (tools/pmc_traffic.py <fetch dir> <write dir> distill 4 handles the pair when both complete)
 rm -rf $O/prof_gen $O/prof_distill $O/launch_gen.csv $O/launch_distill.csv $O/launch_distill.csv.distill
-find $O/pmc_fetch $O/pmc_write $O/pmcd_write -type f ! -name '*counter_collection.csv' -delete 2>/dev/null
+find $O/pmc_fetch $O/pmc_write -type f ! -name '*counter_collection.csv' -delete 2>/dev/null
 du -sh $O
