@@ -78,9 +78,14 @@ class GradientBuckets:
     before the optimizer.  Blocks are merged until a bucket holds at least `min_elems` elements so that the small
     level-0 blocks do not become many tiny collectives on the per-link-bound xGMI rings."""
 
-    def __init__(self, flat_grad, ranges, min_elems=16 << 20):
+    def __init__(self, flat_grad, ranges, min_elems=16 << 20, compress=None):
+        """`compress=torch.bfloat16` sends every bucket as bf16 (half the xGMI bytes: 1.12 GB instead of 2.24 GB per
+        step) and adds the reduced values back into the fp32 buffer; default fp32 = DDP's exact sum."""
         self.flat, self.ranges, self.min_elems = flat_grad, dict(ranges), int(min_elems)
         self.works, self.pending = [], []
+        if compress is not None and compress not in (torch.bfloat16, torch.float16):
+            raise ValueError("gradient all-reduce dtype must be None (fp32), torch.bfloat16 or torch.float16")
+        self.compress = compress
         # CTTA_FORCE_COLLECTIVES=1 keeps the block-wise path on with a single rank (tests / profiling of the overlap)
         force = os.environ.get("CTTA_FORCE_COLLECTIVES", "0") == "1"
         self.enabled = dist.is_initialized() and (dist.get_world_size() > 1 or force)
@@ -89,7 +94,11 @@ class GradientBuckets:
     def _flush(self):
         # merge adjacent ranges, one collective per contiguous run
         for lo, hi in _merge(self.pending):
-            self.works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            if self.compress is None:
+                self.works.append((dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True), None, lo, hi))
+            else:
+                tmp = self.flat[lo:hi].to(self.compress)
+                self.works.append((dist.all_reduce(tmp, op=dist.ReduceOp.SUM, async_op=True), tmp, lo, hi))
         self.pending = []
 
     def ready(self, block):
@@ -103,8 +112,10 @@ class GradientBuckets:
         """Joins all collectives; returns the world size (the 1/world factor goes into the optimizer kernel)."""
         if self.enabled:
             self._flush()
-            for w in self.works:
+            for w, tmp, lo, hi in self.works:
                 w.wait()
+                if tmp is not None:
+                    self.flat[lo:hi].copy_(tmp)
         self.works = []
         return self.world
 
@@ -117,6 +128,24 @@ def _merge(ranges):
         else:
             out.append((lo, hi))
     return out
+
+
+class AnyRankFlag:
+    """`flag` (a 0-dim / 1-element bool-like device tensor) OR-ed over all ranks, asynchronously: issued before the
+    backward pass, read after it.  Used for the NaN-loss skip of the training step (tools/train_utils.py:167-172):
+    the SUM all-reduce spreads one rank's NaN gradients to every rank, so every rank must skip the update together
+    or the replicas diverge."""
+
+    def __init__(self, flag):
+        self.t = flag.reshape(1).to(torch.float32)
+        self.work = None
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            self.work = dist.all_reduce(self.t, op=dist.ReduceOp.MAX, async_op=True)
+
+    def result(self):
+        if self.work is not None:
+            self.work.wait()
+        return bool(self.t.item() > 0)
 
 
 def broadcast_(flat, src=0):

@@ -44,8 +44,11 @@ def do_ema_update(source_model, shadow_models, decay_consts):
         assert 0 <= d <= 1
         assert src.keys() == sh.keys()
     L_ = N.lib()
-    flats = [getattr(m, "_flat", None) for m in [source_model] + list(shadow_models)]
-    if all(f is not None and f.numel() == flats[0].numel() for f in flats):
+    nets = [source_model] + list(shadow_models)
+    flats = [getattr(m, "_flat", None) for m in nets]
+    # the one-launch path needs every network to STILL live in its flat buffer (a `.to()` / `.float()` after
+    # flatten_parameters_ re-homes p.data and would leave the kernel updating stale memory)
+    if all(f is not None and f.numel() == flats[0].numel() for f in flats) and all(m.flat_is_current() for m in nets):
         # every network lives in one flat buffer with the same layout: one launch for the whole model
         fa = flats[1]
         fb = flats[2] if len(flats) > 2 else None
@@ -131,6 +134,10 @@ class AudioDistilledModel(nn.Module):
                 self.tokenizer = AutoTokenizer.from_pretrained(self.text_encoder_name)
                 self.text_encoder = T5EncoderModel.from_pretrained(self.text_encoder_name).to(self.device)
                 self.text_encoder.eval().requires_grad_(False)
+                pending = getattr(self, "_pending_text_encoder_sd", None)
+                if pending:         # text_encoder.* entries a checkpoint brought before the encoder existed
+                    self.text_encoder.load_state_dict(pending)
+                    self._pending_text_encoder_sd = None
             except Exception as e:  # no network / no cache
                 raise RuntimeError(
                     "FLAN-T5 (%s) is not available offline; pass text_encoder= and tokenizer= "
@@ -275,32 +282,76 @@ class AudioLCM(AudioDistilledModel):
         for p in self.student_target_unet.parameters():
             assert p.requires_grad is False, "The student_target_unet is not frozen."
 
-    def load_pretrained(self, state_dict):
-        """audio_consistency_model.py:160-204: legacy key renames, then a strict load."""
-        sd = {}
-        for k, v in state_dict.items():
-            k = k.replace("consistency_ema_unet", "student_target_unet").replace(
-                "consistency_unet", "student_unet").replace("diffusion_unet", "teacher_unet")
-            sd[k] = v
-        own = self.state_dict()
-        return self.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=False)
+    def _load_converted(self, new_sd):
+        """Tail shared by both loaders (audio_consistency_model.py:129-147,187-204): a strict load first; when it
+        fails, a non-strict one that prints the keys it could not fill and refuses unknown ones (vae / loss keys
+        exempt).  FLAN-T5 is constructed lazily here (`_require_text_encoder`), so `text_encoder.*` entries of a
+        checkpoint are parked until the encoder exists instead of being reported as redundant."""
+        if self.text_encoder is None:
+            parked = {k[len("text_encoder."):]: v for k, v in new_sd.items() if k.startswith("text_encoder.")}
+            if parked:
+                self._pending_text_encoder_sd = parked
+                new_sd = {k: v for k, v in new_sd.items() if not k.startswith("text_encoder.")}
+        try:
+            return self.load_state_dict(new_sd, strict=True)
+        except Exception:
+            print("Strict loading failed. The loaded state_dict may not match the target model. "
+                  "This is okay if 'Keys that are not loaded' is an empty list.")
+            info = self.load_state_dict(new_sd, strict=False)
+            missing = [k for k in info.missing_keys if "vae" not in k and "loss." not in k]
+            redundant = [k for k in info.unexpected_keys if "vae" not in k and "loss." not in k]
+            print(f"Keys that are not loaded: {missing}")
+            assert len(redundant) == 0, f"Redundant keys in state_dict: {info.unexpected_keys}"
+            return info
+
+    def load_pretrained(self, state_dict, strict=True):
+        """audio_consistency_model.py:160-204: checkpoints written by older implementations name the networks
+        consistency_unet / consistency_ema_* / consistency_slow_ema_* / diffusion_unet and the STFT loss `loss.*`;
+        the fast EMA (`consistency_ema_`) also seeds `student_ema_*` unless the checkpoint brings its own slow EMA;
+        `vae.*` entries are never loaded.  (`strict` is accepted and, as in the reference, not consulted.)"""
+        new_sd = {}
+        for key, val in state_dict.items():
+            if "consistency_unet" in key:
+                new_sd["student_unet" + key.split("consistency_unet")[-1]] = val
+            elif "consistency_ema_" in key:
+                aft = key.split("consistency_ema_")[-1]
+                new_sd["student_target_" + aft] = val
+                new_sd.setdefault("student_ema_" + aft, val)
+            elif "consistency_slow_ema_" in key:
+                new_sd["student_ema_" + key.split("consistency_slow_ema_")[-1]] = val
+            elif "diffusion_unet" in key:
+                new_sd["teacher_unet" + key.split("diffusion_unet")[-1]] = val
+            elif "loss." in key and "vae." not in key:
+                new_sd["stft_loss." + key.split("loss.")[-1]] = val
+            elif "vae." not in key:
+                new_sd[key] = val
+        return self._load_converted(new_sd)
 
     def load_state_dict_from_tango(self, tango_state_dict, stage1_state_dict=None):
-        """audio_consistency_model.py:107-158: fan TANGO's `unet.*` keys out to the four U-Nets."""
+        """audio_consistency_model.py:107-158: TANGO's `unet.*` becomes the teacher; the three students start from
+        the teacher when there is no stage-1 checkpoint, otherwise all three start from stage 1's `student_ema_*`
+        weights.  Every other TANGO key (text encoder, ...) passes through under its own name."""
+        students = ("student", "student_target", "student_ema")
         new_sd = {}
-        gkeys = {k for k in self.student_unet.state_dict() if k.startswith(("guidance_proj", "guidance_embedding"))}
-        for k, v in tango_state_dict.items():
-            if not k.startswith("unet."):
-                continue
-            kk = k[len("unet."):]
-            for name in ("teacher_unet", "student_unet", "student_target_unet", "student_ema_unet"):
-                new_sd[name + "." + kk] = v
-        own = self.state_dict()
-        for k in own:
-            if k not in new_sd:
-                sub = k.split(".", 1)[1] if "." in k else k
-                assert sub in gkeys or not k.startswith(("teacher_unet", "student")), f"missing key {k}"
-        return self.load_state_dict(new_sd, strict=False)
+        for key, val in tango_state_dict.items():
+            if "unet" in key and "_unet" not in key:
+                new_sd["teacher_" + key] = val
+                if stage1_state_dict is None:
+                    for m in students:
+                        new_sd[m + "_" + key] = val
+            else:
+                new_sd[key] = val
+        if stage1_state_dict is not None:
+            for key, val in stage1_state_dict.items():
+                if "student_ema" in key:
+                    aft = key.split("student_ema_")[-1]
+                    for m in students:
+                        new_sd[m + "_" + aft] = val
+        info = self._load_converted(new_sd)
+        self.student_target_unet.requires_grad_(False)
+        self.student_ema_unet.requires_grad_(False)
+        self.teacher_unet.requires_grad_(False)
+        return info
 
     # ---- distillation loss, audio_consistency_model.py:239-427
     def forward(self, z_0, gt_wav, prompt, validation_mode=False, run_teacher=True, time_inds=None,
@@ -372,12 +423,14 @@ class AudioLCM(AudioDistilledModel):
                 z_0, gt_wav, prompt, False, True, fw.pop("time_inds", None), fw.pop("gaussian_noise", None),
                 fw.pop("guidance_scale", None), True)
             # gradient all-reduce (RCCL) overlapped with the backward pass, block by block
-            buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges())
+            buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges(),
+                                                compress=getattr(self, "allreduce_dtype", None))
+            nan_any = dist_util.AnyRankFlag(torch.isnan(loss))     # all ranks skip together (or none)
             self._student_backward(pred, target, sig, gamma, 1.0 / max(1, int(accumulation_steps)),
                                    buckets.ready if buckets.enabled else None)
             world = buckets.wait()
             value = float(loss.item())
-            if not (skip_nan and value != value):      # train_utils.py:167-172: a NaN loss skips the update
+            if not (skip_nan and nan_any.result()):    # train_utils.py:167-172: a NaN loss skips the update
                 optimizer.step(grad_scale=1.0 / world)
                 if lr_scheduler is not None:
                     lr_scheduler.step()
@@ -669,11 +722,13 @@ class AudioGDM(AudioDistilledModel):
         with torch.no_grad():
             loss, pred, target, weights = self._forward_impl(z_0, prompt, True, fw.pop("time_inds", None),
                                                              fw.pop("gaussian_noise", None), fw.pop("guidance_scale", None))
-            buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges())
+            buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges(),
+                                                compress=getattr(self, "allreduce_dtype", None))
+            nan_any = dist_util.AnyRankFlag(torch.isnan(loss))
             self._student_backward(pred, target, weights, 1.0, buckets.ready if buckets.enabled else None)
             world = buckets.wait()
             value = float(loss.item())
-            if not (skip_nan and value != value):
+            if not (skip_nan and nan_any.result()):
                 optimizer.step(grad_scale=1.0 / world)
                 if lr_scheduler is not None:
                     lr_scheduler.step()

@@ -92,6 +92,36 @@ class _ParamTree(nn.Module):
         self._flat_grad = None
         return flat
 
+    def flat_is_current(self):
+        """True while every parameter still aliases `_flat` (a later `.to()`, `.float()`, `load_state_dict(assign=True)`
+        ... re-homes `p.data` and would leave the fused optimizer / EMA kernels updating a stale buffer)."""
+        flat = getattr(self, "_flat", None)
+        if flat is None:
+            return False
+        lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
+        return all(lo <= p.data_ptr() < hi for p in self.parameters())
+
+    def grads_alias_flat(self):
+        """True while every trainable parameter's `.grad` is a view of `_flat_grad` (`zero_grad(set_to_none=True)`
+        followed by a backward that allocates fresh gradients would break this)."""
+        g = getattr(self, "_flat_grad", None)
+        if g is None:
+            return False
+        lo, hi = g.data_ptr(), g.data_ptr() + g.numel() * 4
+        return all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.parameters() if p.requires_grad)
+
+    def realias_grads_(self):
+        """Points every trainable `p.grad` back at its slice of the flat gradient buffer (after set_to_none)."""
+        g = getattr(self, "_flat_grad", None)
+        if g is None:
+            return
+        off = 0
+        for p in self._flat_order():
+            n = p.numel()
+            if p.requires_grad and (p.grad is None or p.grad.data_ptr() != g.data_ptr() + off * 4):
+                p.grad = g[off:off + n].view(p.shape)
+            off += n
+
     def flat_grad_(self):
         """Flat fp32 gradient buffer aliased by every `p.grad` (zero-initialised on first use)."""
         flat = self.flatten_parameters_()
@@ -315,6 +345,8 @@ class _UNetBase(_ParamTree):
             g[:, :, :C] = grad_output.detach().to(dev).permute(0, 2, 3, 1).reshape(B, H * W, C).to(torch.bfloat16)
             grad_output_nhwc = g
         table = OrderedDict()
+        if getattr(self, "_flat_grad", None) is not None and not self.grads_alias_flat():
+            self.realias_grads_()    # e.g. after zero_grad(set_to_none=True): the fused optimizer reads the flat buffer
         for k, p in self.named_parameters():
             if not p.requires_grad:
                 continue

@@ -33,6 +33,13 @@ class FusedAdamW:
         """One update; `grad_scale` multiplies the gradient inside the kernel (1/world_size after a
         SUM all-reduce, 1/accumulation_steps, ...)."""
         g = self.param_groups[0]
+        if not self.module.flat_is_current() or self.module._flat is not self.flat:
+            raise N.CttaError("FusedAdamW: the module's parameters no longer alias the flat buffer this optimizer "
+                              "was built on (model.to()/.float() after prepare_training?) -- build a new optimizer")
+        if not self.module.grads_alias_flat():
+            self.module.realias_grads_()
+            raise N.CttaError("FusedAdamW: parameter gradients were not views of the flat gradient buffer (zero_grad("
+                              "set_to_none=True) + a foreign backward?); they have been re-aliased -- redo the backward")
         self.step_count += 1
         with torch.cuda.device(self.flat.device):
             N.check(N.lib().ctta_adamw_step(N.ptr(self.flat), N.ptr(self.grad), N.ptr(self.exp_avg),
@@ -84,3 +91,13 @@ class WarmupSchedule:
 
     def get_last_lr(self):
         return [self.opt.param_groups[0]["lr"]]
+
+    # resume (accelerator.save_state stores the scheduler too, train.py:497-505)
+    def state_dict(self):
+        return {"name": self.name, "num_warmup_steps": self.warm, "num_training_steps": self.total,
+                "base_lr": self.base_lr, "last_step": self.last_step}
+
+    def load_state_dict(self, sd):
+        self.name, self.warm, self.total = sd["name"], int(sd["num_warmup_steps"]), sd["num_training_steps"]
+        self.base_lr, self.last_step = float(sd["base_lr"]), int(sd["last_step"])
+        self._apply()

@@ -1,0 +1,108 @@
+"""Fixture pinning the distillation step at the REAL widths:
+the reference's own `models.AudioLCM` at `configs/tango_diffusion_light.json` (559 M-parameter
+U-Nets), B=2 latents of the real (8, 256, 16) shape, its internal random draws recorded, loss
+AND the student's gradients from torch autograd (build container only, ≈3 min of CPU):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden_distill_light.py
+
+The full gradient is 2.2 GB, so the fixture keeps, for every parameter tensor of the student,
+its L2 norm and a deterministic strided sample of up to 512 entries (`sample_index`): a
+per-block relative L2 over the samples is an unbiased estimate of the block's relative L2.
+Follows `models/audio_consistency_model.py:239-427` and `tools/train_utils.py:166`.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import cases  # noqa: E402
+from consistencytta_amd import spec  # noqa: E402
+from make_golden_distill import load_reference_audiolcm  # noqa: E402
+
+B, H, W, L = 2, 256, 16, 16
+N_SAMPLE = 512
+
+
+def sample_index(numel, n=N_SAMPLE):
+    """Deterministic strided sample positions inside a flattened tensor (shared with the test)."""
+    n = min(n, numel)
+    return (np.arange(n, dtype=np.int64) * numel) // n
+
+
+def main():
+    ns, AudioLCM, TU = load_reference_audiolcm()
+    cfg = spec.LIGHT_UNET_CONFIG
+    torch.manual_seed(0)
+    model = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                     unet_model_config_path=ns.light_config_path, snr_gamma=5.0, use_edm=True,
+                     teacher_guidance_scale=-1, num_diffusion_steps=18, vae=torch.nn.Identity(), loss_type="mse",
+                     target_ema_decay=0.95, ema_decay=0.999)
+    model.teacher_unet.load_state_dict(cases.unet_weights(cfg, False, 0))
+    model.student_unet.load_state_dict(cases.unet_weights(cfg, True, 1))
+    model.student_target_unet.load_state_dict(cases.unet_weights(cfg, True, 2))
+    model.student_ema_unet.load_state_dict(cases.unet_weights(cfg, True, 3))
+    P = cases.prompt_states(cfg, B, L, "distill_light")
+    model.get_prompt_embeds = lambda prompt, use_cf, num_samples_per_prompt=1: (
+        P["embeds_cf"], P["mask_cf"], P["embeds"], P["mask"])
+    model.encode_text_classifier_free = lambda prompt, n: (P["embeds_cf"], P["mask_cf"], P["embeds"], P["mask"])
+    z0 = cases.t(spec.det_uniform("distill_light.z0", (B, 8, H, W), 14)) * 0.9
+
+    rec = {}
+    o_randint, o_randn_like, o_rand = torch.randint, torch.randn_like, torch.rand
+
+    def randint(*a, **k):
+        v = o_randint(*a, **k)
+        rec.setdefault("randint", v.clone())
+        return v
+
+    def randn_like(x, *a, **k):
+        v = o_randn_like(x, *a, **k)
+        rec.setdefault("randn_like", v.clone())
+        return v
+
+    def rand(*a, **k):
+        v = o_rand(*a, **k)
+        rec.setdefault("rand", v.clone())
+        return v
+
+    model.train()
+    torch.manual_seed(4321)
+    torch.randint, torch.randn_like, torch.rand = randint, randn_like, rand
+    try:
+        loss = model(z0, None, ["a"] * B)
+    finally:
+        torch.randint, torch.randn_like, torch.rand = o_randint, o_randn_like, o_rand
+    loss.backward()          # accelerator.backward(loss) on one process (tools/train_utils.py:166)
+
+    out = dict(train_loss=np.float64(float(loss)), time_inds=rec["randint"].numpy(),
+               noise=rec["randn_like"].numpy(), guidance=rec["rand"].numpy() * 6)
+    names, norms, samples, offsets = [], [], [], [0]
+    for k, p in model.student_unet.named_parameters():
+        if p.grad is None:
+            assert not p.requires_grad, k
+            continue
+        g = p.grad.detach().reshape(-1)
+        names.append(k)
+        norms.append(float(g.double().norm()))
+        samples.append(g[torch.from_numpy(sample_index(g.numel()))].numpy())
+        offsets.append(offsets[-1] + samples[-1].size)
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms, dtype=np.float64)
+    out["grad_samples"] = np.concatenate(samples).astype(np.float32)
+    out["grad_offsets"] = np.array(offsets, dtype=np.int64)
+    for p in model.teacher_unet.parameters():
+        assert p.grad is None
+    path = os.path.join(HERE, "distill_light.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; loss", float(loss), "tensors", len(names),
+          "time_inds", out["time_inds"], "guidance", out["guidance"])
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(os.cpu_count())
+    main()

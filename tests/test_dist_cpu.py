@@ -40,6 +40,16 @@ def _worker(rank, world, port, q):
     for blk in (2, 1, 0):
         buckets.ready(blk)
     assert buckets.wait() == 2 and g2.tolist() == [3.0 * i for i in range(11)]
+    # bf16-compressed buckets: half the bytes on the wire, result added back into the fp32 buffer
+    g3 = torch.arange(11, dtype=torch.float32) * (rank + 1)
+    b3 = du.GradientBuckets(g3, {0: (0, 3), 1: (3, 7), 2: (7, 11)}, min_elems=5, compress=torch.bfloat16)
+    for blk in (2, 1, 0):
+        b3.ready(blk)
+    assert b3.wait() == 2 and g3.tolist() == [3.0 * i for i in range(11)] and g3.dtype == torch.float32
+    # NaN-loss skip: one rank's flag reaches every rank (all skip the update together)
+    flag_any = du.AnyRankFlag(torch.tensor(rank == 1)).result()
+    flag_none = du.AnyRankFlag(torch.tensor(False)).result()
+    assert flag_any is True and flag_none is False
     q.put((rank, t, mine, mx, mn, w_, grad.tolist(), params.tolist()))
     du.finish()
 

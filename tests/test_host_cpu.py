@@ -135,3 +135,103 @@ def test_det_generator_is_stable():
     assert not np.array_equal(a, spec.det_uniform("some.key", (4, 3), seed=8))
     # frozen values: a change here invalidates every committed fixture
     np.testing.assert_allclose(spec.det_uniform("x", (3,), 0), [-0.597583532333374, 0.6170535087585449, 0.2866472005844116], rtol=0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------
+# checkpoint loaders of AudioLCM (audio_consistency_model.py:107-204) -- host logic only, CPU tensors
+def _lcm():
+    from consistencytta_amd.models import AudioLCM
+    return AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                    unet_model_config_path="tiny_light.json", unet_config=cases.TINY_UNET, snr_gamma=5.0, use_edm=True,
+                    teacher_guidance_scale=-1, num_diffusion_steps=18, vae=None, loss_type="mse")
+
+
+def _fill(m, value):
+    with torch.no_grad():
+        for p in m.parameters():
+            p.fill_(value)
+
+
+def test_load_state_dict_from_tango_with_and_without_stage1(capsys):
+    m = _lcm()
+    _fill(m, -1.0)
+    tango = {"unet." + k: torch.full_like(v, 2.0) for k, v in m.teacher_unet.state_dict().items()}
+    tango["text_encoder.shared.weight"] = torch.zeros(3)            # parked: FLAN-T5 is built lazily
+    info = m.load_state_dict_from_tango(tango)
+    # the teacher has no guidance branch: those student keys are reported as not loaded, nothing is redundant
+    printed = capsys.readouterr().out
+    assert "Keys that are not loaded" in printed and "guidance_embedding.linear_1.weight" in printed
+    assert all("guidance" in k for k in info.missing_keys)
+    assert m._pending_text_encoder_sd.keys() == {"shared.weight"}
+    for net in (m.teacher_unet, m.student_unet, m.student_target_unet, m.student_ema_unet):
+        for k, p in net.named_parameters():
+            assert float(p.flatten()[0]) == (-1.0 if k.startswith("guidance") else 2.0), k
+    assert not any(p.requires_grad for p in m.student_target_unet.parameters())
+    # stage 1 given: teacher from TANGO, all three students from stage 1's student_ema_* (guidance branch included)
+    _fill(m, -1.0)
+    stage1 = {"student_ema_unet." + k: torch.full_like(v, 5.0) for k, v in m.student_unet.state_dict().items()}
+    stage1.update({"student_unet." + k: torch.full_like(v, 9.0) for k, v in m.student_unet.state_dict().items()})
+    m.load_state_dict_from_tango({k: v for k, v in tango.items() if k.startswith("unet.")}, stage1)
+    assert all(float(p.flatten()[0]) == 2.0 for p in m.teacher_unet.parameters())
+    for net in (m.student_unet, m.student_target_unet, m.student_ema_unet):
+        assert all(float(p.flatten()[0]) == 5.0 for p in net.parameters())
+    # an unknown key is refused like in the reference
+    with pytest.raises(AssertionError, match="Redundant keys"):
+        m.load_state_dict_from_tango(dict(tango, **{"unet.bogus.weight": torch.zeros(1)}))
+
+
+def test_load_pretrained_converts_legacy_names():
+    m = _lcm()
+    _fill(m, -1.0)
+    stu = m.student_unet.state_dict()
+    legacy = {"consistency_unet." + k: torch.full_like(v, 1.0) for k, v in stu.items()}
+    legacy.update({"consistency_ema_unet." + k: torch.full_like(v, 2.0) for k, v in stu.items()})
+    legacy.update({"diffusion_unet." + k: torch.full_like(v, 4.0) for k, v in m.teacher_unet.state_dict().items()})
+    legacy["vae.decoder.conv_in.weight"] = torch.zeros(1)             # never loaded
+    m.load_pretrained(legacy)
+    val = lambda net: {float(p.flatten()[0]) for p in net.parameters()}
+    # no slow EMA in the checkpoint: the fast EMA seeds BOTH shadows; every student_ema tensor was overwritten
+    assert val(m.student_unet) == {1.0} and val(m.student_target_unet) == {2.0} and val(m.student_ema_unet) == {2.0}
+    assert val(m.teacher_unet) == {4.0}
+    # with a slow EMA, it wins for student_ema_* whatever the key order
+    _fill(m, -1.0)
+    slow = {"consistency_slow_ema_unet." + k: torch.full_like(v, 3.0) for k, v in stu.items()}
+    m.load_pretrained(dict(legacy, **slow))
+    assert val(m.student_ema_unet) == {3.0} and val(m.student_target_unet) == {2.0}
+    _fill(m, -1.0)
+    m.load_pretrained(dict(slow, **legacy))
+    assert val(m.student_ema_unet) == {3.0}
+    # current names pass through; unknown names are refused
+    m.load_pretrained({k: torch.full_like(v, 6.0) for k, v in m.state_dict().items()})
+    assert val(m.student_ema_unet) == {6.0}
+    with pytest.raises(AssertionError, match="Redundant keys"):
+        m.load_pretrained(dict(legacy, **{"consistency_unet.nope": torch.zeros(1)}))
+
+
+def test_flat_alias_checks_and_schedule_state():
+    from consistencytta_amd import optim
+    m = modules.UNet2DConditionGuidedModel.from_config(cases.TINY_UNET).init_deterministic()
+    flat = m.flatten_parameters_()
+    g = m.flat_grad_()
+    assert m.flat_is_current() and m.grads_alias_flat()
+    for p in m.parameters():
+        p.grad = None                              # torch's default zero_grad(set_to_none=True)
+    assert not m.grads_alias_flat()
+    m.realias_grads_()
+    assert m.grads_alias_flat() and m._flat_grad is g
+    m.double().float()                             # re-homes p.data: the flat buffer is stale now
+    assert not m.flat_is_current()
+    assert m.flatten_parameters_() is not flat and m.flat_is_current()
+
+    class _Opt:
+        param_groups = [dict(lr=1e-3)]
+    sch = optim.WarmupSchedule(_Opt(), "linear", num_warmup_steps=4, num_training_steps=20)
+    for _ in range(7):
+        sch.step()
+    o2 = _Opt()
+    o2.param_groups = [dict(lr=1e-3)]
+    s2 = optim.WarmupSchedule(o2, "constant")
+    s2.load_state_dict(sch.state_dict())
+    assert s2.get_last_lr() == sch.get_last_lr() and s2.last_step == 7
+    s2.step(), sch.step()
+    assert s2.get_last_lr() == sch.get_last_lr()
