@@ -88,6 +88,13 @@ def prompt_states(cfg, B, L, tag):
     return dict(embeds_cf=torch.cat([uncond, cond]), mask_cf=torch.cat([umask, cmask]), embeds=cond, mask=cmask)
 
 
+def sample_index(numel, n=512):
+    """Deterministic strided sample positions inside a flattened tensor: what `distill_light.npz` keeps of every
+    gradient tensor (the full gradient is 2.2 GB)."""
+    n = min(n, numel)
+    return (np.arange(n, dtype=np.int64) * numel) // n
+
+
 # Text encoder: a small T5 (d_kv stays 64 like every T5 size) and FLAN-T5-large's widths at 2 layers.
 TINY_T5 = dict(spec.T5_LARGE_CONFIG, vocab_size=512, d_model=256, d_ff=512, num_layers=3, num_heads=4)
 WIDE_T5 = dict(spec.T5_LARGE_CONFIG, vocab_size=1024, num_layers=2)

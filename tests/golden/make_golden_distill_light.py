@@ -25,13 +25,9 @@ from consistencytta_amd import spec  # noqa: E402
 from make_golden_distill import load_reference_audiolcm  # noqa: E402
 
 B, H, W, L = 2, 256, 16, 16
-N_SAMPLE = 512
 
 
-def sample_index(numel, n=N_SAMPLE):
-    """Deterministic strided sample positions inside a flattened tensor (shared with the test)."""
-    n = min(n, numel)
-    return (np.arange(n, dtype=np.int64) * numel) // n
+sample_index = cases.sample_index
 
 
 def main():

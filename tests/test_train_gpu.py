@@ -478,7 +478,7 @@ def test_distillation_step_at_light_widths_matches_reference(golden):
     bench times: split-K deep-level GEMMs, wgrad scatter, 64x64 K/V tiles) vs the reference's loss and autograd
     gradients.  The fixture holds every tensor's gradient norm and a strided 512-entry sample of it; tolerances:
     loss 5e-2 relative, per-block sampled-gradient relative L2 4e-2, per-tensor norm 8e-2."""
-    from make_golden_distill_light import sample_index
+    sample_index = cases.sample_index
     g = golden("distill_light")
     m, P, z0 = _lcm_light(2, 16, "distill_light")
     m.train()
