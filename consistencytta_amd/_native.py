@@ -157,6 +157,8 @@ SIGNATURES = {
     "ctta_snr_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "ctta_ema_update2": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_double, c_int64, c_void_p]),
     "ctta_conv_gemm": (c_int, [POINTER(ConvDesc), c_void_p]),
+    "ctta_conv_bind_workspace": (None, [c_void_p, c_size_t]),
+    "ctta_conv_workspace_bytes": (c_size_t, []),
     "ctta_conv_gemm_num_variants": (c_int, []),
     "ctta_conv_gemm_variant_name": (c_char_p, [c_int]),
     "ctta_conv_small_n": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),

@@ -871,11 +871,26 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvParams p, 
     epilogue_store(p, (f32x4_t){a.x, a.y, a.z, a.w}, m, n, b, m - (long long)b * p.howo, 0);
   }
 }
+// Split-K workspace.  Every engine handle owns one (SplitWs in engine_common.h) and binds it to the calling host
+// thread for the duration of each entry point (ctta_conv_bind_workspace), so handles running on different streams
+// or host threads never share partial-sum slabs.  Raw ctta_conv_gemm callers that bound nothing get a lazily
+// allocated workspace PER DEVICE (mutex-guarded); launches that share it must be ordered on one stream.
 static const size_t kSplitWsBytes = (size_t)192 << 20;
-static float* splitk_workspace() {   // one workspace per process: split-K launches are serialised on their stream
-  static float* ws = nullptr;
-  if (!ws && hipMalloc((void**)&ws, kSplitWsBytes) != hipSuccess) ws = nullptr;
-  return ws;
+static thread_local float* t_ws = nullptr;
+static thread_local size_t t_ws_bytes = 0;
+extern "C" void ctta_conv_bind_workspace(void* ws, size_t bytes) { t_ws = (float*)ws; t_ws_bytes = ws ? bytes : 0; }
+extern "C" size_t ctta_conv_workspace_bytes(void) { return kSplitWsBytes; }
+#include <mutex>
+static float* splitk_workspace(size_t* bytes) {
+  if (t_ws) { *bytes = t_ws_bytes; return t_ws; }
+  static std::mutex mu;
+  static float* per_dev[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!per_dev[dev] && hipMalloc((void**)&per_dev[dev], kSplitWsBytes) != hipSuccess) per_dev[dev] = nullptr;
+  *bytes = kSplitWsBytes;
+  return per_dev[dev];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -952,13 +967,19 @@ extern "C" const char* ctta_conv_gemm_variant_name(int id) {
   return (id >= 1 && id <= kNumVariants) ? kVariants[id - 1].name : "auto";
 }
 
-static const bf16_t* zero_page() {
-  static bf16_t* z = nullptr;
-  if (!z) {
+static const bf16_t* zero_page() {   // 256 zero bytes per device (source of out-of-range chunks in the LDS-direct paths)
+  static std::mutex mu;
+  static bf16_t* per_dev[64] = {nullptr};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!per_dev[dev]) {
+    bf16_t* z = nullptr;
     if (hipMalloc((void**)&z, 256) != hipSuccess) return nullptr;
-    if (hipMemset(z, 0, 256) != hipSuccess) return nullptr;
+    if (hipMemset(z, 0, 256) != hipSuccess) { (void)hipFree(z); return nullptr; }
+    per_dev[dev] = z;
   }
-  return z;
+  return per_dev[dev];
 }
 
 static bool xcd_default() {
@@ -1128,11 +1149,12 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   p.ksplit = 1; p.nk_split = p.nk;
   // split-K: deep, narrow problems (the 1024-channel levels at small batch: M <= 2304, K = 9216 / 18432) launch
   // too few workgroups to fill 256 CUs; split the K walk over blockIdx.z and reduce in a second pass
-  float* ws = splitk_workspace();
   const long long tiles = (long long)grid.x * grid.y;
   int splits = 1;
-  if (splitk_default() && ws && groups == 1 && !scalar_store && !geglu && d->out_limit == 0 && d->out_offset == 0 &&
-      tiles < 192 && p.nk >= 32) {
+  float* ws = nullptr;
+  size_t ws_bytes = 0;
+  if (splitk_default() && groups == 1 && !scalar_store && !geglu && d->out_limit == 0 && d->out_offset == 0 &&
+      tiles < 192 && p.nk >= 32 && (ws = splitk_workspace(&ws_bytes)) != nullptr) {
     static int target = -1, cap = -1;   // tuning knobs: workgroups aimed for / most splits
     if (target < 0) { const char* e = getenv("CTTA_SPLITK_TARGET"); target = e ? atoi(e) : 512; }
     if (cap < 0) { const char* e = getenv("CTTA_SPLITK_MAX"); cap = e ? atoi(e) : 8; }
@@ -1140,7 +1162,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     if (splits > cap) splits = cap;
     if (splits > p.nk / 8) splits = p.nk / 8;
     const int ld = (d->n + 3) / 4 * 4;
-    if ((long long)splits * M * ld * 4 > (long long)kSplitWsBytes) splits = 1;
+    if ((long long)splits * M * ld * 4 > (long long)ws_bytes) splits = 1;
   }
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, vid, M, d->n, K, groups, (hipStream_t)stream);

@@ -31,6 +31,25 @@ struct Arena {
   void reset() { off = 0; }
 };
 
+// Per-handle split-K workspace of conv_gemm: allocated with the handle, bound to the calling host thread while one of
+// the handle's entry points enqueues work (WsBind), so two handles on two streams never share partial-sum slabs.
+struct SplitWs {
+  void* p = nullptr;
+  size_t bytes = 0;
+  ctta_status init() {
+    bytes = ctta_conv_workspace_bytes();
+    if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; ctta_set_error("hipMalloc of the split-K workspace failed"); return CTTA_ERR_NOMEM; }
+    return CTTA_OK;
+  }
+  void destroy() { if (p) (void)hipFree(p); p = nullptr; }
+};
+struct WsBind {
+  explicit WsBind(const SplitWs& w) { ctta_conv_bind_workspace(w.p, w.bytes); }
+  ~WsBind() { ctta_conv_bind_workspace(nullptr, 0); }
+  WsBind(const WsBind&) = delete;
+  WsBind& operator=(const WsBind&) = delete;
+};
+
 struct Tap {
   std::string name;
   const void* ptr;

@@ -112,6 +112,7 @@ struct ctta_t5 {
   ctta_t5_config cfg;
   WeightStore store;
   Arena arena;
+  SplitWs splitws;
   float* embed = nullptr;        // fp32 [vocab][d_model]
   float* rel_emb = nullptr;      // fp32 [buckets][heads]
   float* ln_f = nullptr;
@@ -254,6 +255,7 @@ extern "C" void ctta_t5_destroy(ctta_t5* T) {
   if (!T) return;
   T->store.destroy();
   if (T->arena.base) (void)hipFree(T->arena.base);
+  T->splitws.destroy();
   delete T;
 }
 
@@ -287,6 +289,8 @@ extern "C" ctta_status ctta_t5_create(const ctta_t5_config* cfg, const ctta_tens
     if (hipMalloc((void**)&T->arena.base, bytes) != hipSuccess) {
       ctta_set_error("t5_create: hipMalloc of %zu-byte activation arena failed", bytes);
       st = CTTA_ERR_NOMEM;
+    } else {
+      st = T->splitws.init();
     }
   }
   if (st == CTTA_OK && hipStreamSynchronize(s) != hipSuccess) { ctta_set_error("t5_create: stream sync failed"); st = CTTA_ERR_HIP; }
@@ -301,6 +305,7 @@ extern "C" ctta_status ctta_t5_encode(ctta_t5* T, const int64_t* input_ids, cons
   CTTA_REQUIRE(batch >= 1 && batch <= T->cfg.max_batch && len >= 1 && len <= T->cfg.max_len,
                "t5_encode: batch %d / length %d outside the handle's limits (%d, %d)", batch, len, T->cfg.max_batch,
                T->cfg.max_len);
+  WsBind bind(T->splitws);
   return t5_forward_impl(T, false, input_ids, attention_mask, batch, len, last_hidden_state, (hipStream_t)stream);
 }
 

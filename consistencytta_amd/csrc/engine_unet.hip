@@ -123,6 +123,7 @@ struct ctta_unet {
   int temb_dim = 0, temb_total = 0, cin_pad = 0, xp = 0;
   float* gn_scratch = nullptr;
   size_t gn_scratch_floats = 0;
+  SplitWs splitws;   // this handle's split-K workspace (bound per entry point)
   // ---- training state (cfg.enable_training)
   ConvTrain t_conv_in, t_conv_out;
   std::vector<TapeOp> tape;
@@ -742,6 +743,7 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
     } else {
       U->gn_scratch_floats = gn_need + 64;
       if (hipMemsetAsync(U->arena.base, 0, bytes, s) != hipSuccess) st = CTTA_ERR_HIP;
+      if (st == CTTA_OK) st = U->splitws.init();
     }
   }
   if (st == CTTA_OK && hipStreamSynchronize(s) != hipSuccess) { ctta_set_error("unet_create: stream sync failed"); st = CTTA_ERR_HIP; }
@@ -755,6 +757,7 @@ extern "C" void ctta_unet_destroy(ctta_unet* U) {
   U->store.destroy();
   if (U->arena.base) (void)hipFree(U->arena.base);
   if (U->gn_scratch) (void)hipFree(U->gn_scratch);
+  U->splitws.destroy();
   delete U;
 }
 
@@ -773,6 +776,7 @@ extern "C" ctta_status ctta_unet_forward(ctta_unet* U, const float* sample, cons
   CTTA_REQUIRE(batch >= 1 && batch <= U->cfg.max_batch, "unet_forward: batch %d outside [1,%d]", batch, U->cfg.max_batch);
   CTTA_REQUIRE(text_len >= 1 && text_len <= U->cfg.max_text_len, "unet_forward: text_len %d outside [1,%d]", text_len,
                U->cfg.max_text_len);
+  WsBind bind(U->splitws);
   return unet_forward_impl(U, false, sample, timesteps, guidance, enc, mask, batch, text_len, out, (hipStream_t)stream,
                            nullptr);
 }

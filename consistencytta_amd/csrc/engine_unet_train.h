@@ -489,6 +489,7 @@ extern "C" ctta_status ctta_unet_forward_train(ctta_unet* U, const float* sample
   CTTA_REQUIRE(batch >= 1 && batch <= U->cfg.max_batch, "unet_forward_train: batch %d outside [1,%d]", batch, U->cfg.max_batch);
   CTTA_REQUIRE(text_len >= 1 && text_len <= U->cfg.max_text_len, "unet_forward_train: text_len %d outside [1,%d]", text_len,
                U->cfg.max_text_len);
+  WsBind bind(U->splitws);
   return unet_forward_impl(U, false, sample, timesteps, guidance, enc, mask, batch, text_len, out, (hipStream_t)stream,
                            nullptr, true);
 }
@@ -500,6 +501,7 @@ extern "C" ctta_status ctta_unet_backward(ctta_unet* U, const void* dout_nhwc, c
   CTTA_REQUIRE(U->ts.valid, "unet_backward: no training forward to differentiate (call ctta_unet_forward_train first)");
   GradTable gt;
   gt.build(grads, n_grads);
+  WsBind bind(U->splitws);
   const ctta_status st = unet_backward_impl(U, false, (const bf16_t*)dout_nhwc, &gt, (hipStream_t)stream, nullptr);
   U->ts.valid = false;   // one backward per training forward
   return st;
@@ -516,6 +518,7 @@ extern "C" ctta_status ctta_unet_backward_begin(ctta_unet* U, const void* dout_n
   GradTable gt;
   gt.build(grads, n_grads);
   U->ts.valid = false;
+  WsBind bind(U->splitws);
   return unet_backward_begin_impl(U, false, (const bf16_t*)dout_nhwc, &gt, (hipStream_t)stream);
 }
 extern "C" ctta_status ctta_unet_backward_next(ctta_unet* U, const ctta_tensor* grads, int n_grads, void* stream,
@@ -524,5 +527,6 @@ extern "C" ctta_status ctta_unet_backward_next(ctta_unet* U, const ctta_tensor* 
   CTTA_REQUIRE(U->bw.active, "unet_backward_next: call ctta_unet_backward_begin first");
   GradTable gt;
   gt.build(grads, n_grads);
+  WsBind bind(U->splitws);
   return unet_backward_next_impl(U, false, &gt, (hipStream_t)stream, block_done, finished);
 }

@@ -98,6 +98,7 @@ struct ctta_vae {
   int block_in = 0, c_last = 0;
   float* gn_scratch = nullptr;
   size_t gn_scratch_floats = 0;
+  SplitWs splitws;
   // enable_grad (CLAPLoss's differentiable decode, tools/losses.py:294-296)
   ConvLayer d_conv_in;
   std::vector<ConvLayer> d_upsample;
@@ -560,6 +561,7 @@ extern "C" ctta_status ctta_vae_create(const ctta_vae_config* cfg, const ctta_te
       st = CTTA_ERR_NOMEM;
     } else {
       V->gn_scratch_floats = gn_need + 64;
+      st = V->splitws.init();
     }
   }
   if (st == CTTA_OK && hipStreamSynchronize(s) != hipSuccess) { ctta_set_error("vae_create: stream sync failed"); st = CTTA_ERR_HIP; }
@@ -573,12 +575,14 @@ extern "C" void ctta_vae_destroy(ctta_vae* V) {
   V->store.destroy();
   if (V->arena.base) (void)hipFree(V->arena.base);
   if (V->gn_scratch) (void)hipFree(V->gn_scratch);
+  V->splitws.destroy();
   delete V;
 }
 
 extern "C" ctta_status ctta_vae_decode(ctta_vae* V, const float* z, int batch, float* mel, void* stream) {
   CTTA_REQUIRE(V && z && mel, "vae_decode: null pointer");
   CTTA_REQUIRE(batch >= 1 && batch <= V->cfg.max_batch, "vae_decode: batch %d outside [1,%d]", batch, V->cfg.max_batch);
+  WsBind bind(V->splitws);
   return vae_forward_impl(V, false, z, batch, mel, (hipStream_t)stream, nullptr);
 }
 
@@ -587,12 +591,14 @@ extern "C" ctta_status ctta_vae_decode_with_grad(ctta_vae* V, const float* z, in
   CTTA_REQUIRE(V->cfg.enable_grad, "vae_decode_with_grad: the handle was created without enable_grad");
   CTTA_REQUIRE(batch >= 1 && batch <= V->cfg.max_batch, "vae_decode_with_grad: batch %d outside [1,%d]", batch,
                V->cfg.max_batch);
+  WsBind bind(V->splitws);
   return vae_forward_impl(V, false, z, batch, mel, (hipStream_t)stream, nullptr, true);
 }
 extern "C" ctta_status ctta_vae_decode_backward(ctta_vae* V, const float* grad_mel, int batch, float* grad_z, void* stream) {
   CTTA_REQUIRE(V && grad_mel && grad_z, "vae_decode_backward: null pointer");
   CTTA_REQUIRE(V->cfg.enable_grad && V->sv.B == batch,
                "vae_decode_backward: no differentiable forward of batch %d is pending on this handle", batch);
+  WsBind bind(V->splitws);
   const ctta_status st = vae_backward_impl(V, false, grad_mel, batch, grad_z, (hipStream_t)stream, nullptr);
   V->sv.B = 0;   // the saved tensors are consumed (the backward's temporaries overwrote the arena above them)
   return st;
@@ -635,6 +641,7 @@ struct ctta_vae_encoder {
   int block_in = 0, zc2 = 0;
   float* gn_scratch = nullptr;
   size_t gn_scratch_floats = 0;
+  SplitWs splitws;
 };
 
 // moments[b][o][hw] = quant_conv(h)[o] per pixel, h = conv_out result [M][zc2] bf16 -> NCHW fp32
@@ -749,6 +756,7 @@ extern "C" void ctta_vae_encoder_destroy(ctta_vae_encoder* E) {
   E->store.destroy();
   if (E->arena.base) (void)hipFree(E->arena.base);
   if (E->gn_scratch) (void)hipFree(E->gn_scratch);
+  E->splitws.destroy();
   delete E;
 }
 
@@ -785,6 +793,7 @@ extern "C" ctta_status ctta_vae_encoder_create(const ctta_vae_config* cfg, const
       st = CTTA_ERR_NOMEM;
     } else {
       E->gn_scratch_floats = gn_need + 64;
+      st = E->splitws.init();
     }
   }
   if (st == CTTA_OK && hipStreamSynchronize(s) != hipSuccess) { ctta_set_error("vae_encoder_create: stream sync failed"); st = CTTA_ERR_HIP; }
@@ -796,6 +805,7 @@ extern "C" ctta_status ctta_vae_encoder_create(const ctta_vae_config* cfg, const
 extern "C" ctta_status ctta_vae_encode(ctta_vae_encoder* E, const float* mel, int batch, float* moments, void* stream) {
   CTTA_REQUIRE(E && mel && moments, "vae_encode: null pointer");
   CTTA_REQUIRE(batch >= 1 && batch <= E->cfg.max_batch, "vae_encode: batch %d outside [1,%d]", batch, E->cfg.max_batch);
+  WsBind bind(E->splitws);
   return vae_encode_impl(E, false, mel, batch, moments, (hipStream_t)stream, nullptr);
 }
 extern "C" ctta_status ctta_vae_encoder_load_weights(ctta_vae_encoder* E, const ctta_tensor* weights, int n_weights,
@@ -840,6 +850,7 @@ struct ctta_hifigan {
   ctta_hifigan_config cfg;
   WeightStore store;
   Arena arena;
+  SplitWs splitws;
   std::vector<Tap> taps;
   Conv1d conv_pre;
   std::vector<ConvT1d> ups;
@@ -1206,6 +1217,8 @@ extern "C" ctta_status ctta_hifigan_create(const ctta_hifigan_config* cfg, const
     if (hipMalloc((void**)&G->arena.base, bytes) != hipSuccess) {
       ctta_set_error("hifigan_create: hipMalloc of %zu-byte activation arena failed", bytes);
       st = CTTA_ERR_NOMEM;
+    } else {
+      st = G->splitws.init();
     }
   }
   if (st == CTTA_OK && hipStreamSynchronize(s) != hipSuccess) { ctta_set_error("hifigan_create: stream sync failed"); st = CTTA_ERR_HIP; }
@@ -1218,6 +1231,7 @@ extern "C" void ctta_hifigan_destroy(ctta_hifigan* G) {
   if (!G) return;
   G->store.destroy();
   if (G->arena.base) (void)hipFree(G->arena.base);
+  G->splitws.destroy();
   delete G;
 }
 
@@ -1227,6 +1241,7 @@ extern "C" ctta_status ctta_hifigan_forward(ctta_hifigan* G, const float* mel, i
   CTTA_REQUIRE(batch >= 1 && batch <= G->cfg.max_batch && frames >= 1 && frames <= G->cfg.max_frames,
                "hifigan_forward: batch %d / frames %d outside the handle's limits (%d, %d)", batch, frames,
                G->cfg.max_batch, G->cfg.max_frames);
+  WsBind bind(G->splitws);
   return hifigan_forward_impl(G, false, mel, batch, frames, wav, (hipStream_t)stream);
 }
 
@@ -1237,6 +1252,7 @@ extern "C" ctta_status ctta_hifigan_forward_with_grad(ctta_hifigan* G, const flo
   CTTA_REQUIRE(batch >= 1 && batch <= G->cfg.max_batch && frames >= 1 && frames <= G->cfg.max_frames,
                "hifigan_forward_with_grad: batch %d / frames %d outside the handle's limits (%d, %d)", batch, frames,
                G->cfg.max_batch, G->cfg.max_frames);
+  WsBind bind(G->splitws);
   return hifigan_forward_impl(G, false, mel, batch, frames, wav, (hipStream_t)stream, true);
 }
 extern "C" ctta_status ctta_hifigan_backward(ctta_hifigan* G, const float* grad_wav, const float* wav, int batch, int frames,
@@ -1244,6 +1260,7 @@ extern "C" ctta_status ctta_hifigan_backward(ctta_hifigan* G, const float* grad_
   CTTA_REQUIRE(G && grad_wav && wav && grad_mel, "hifigan_backward: null pointer");
   CTTA_REQUIRE(G->cfg.enable_grad && G->sv.B == batch && G->sv.frames == frames,
                "hifigan_backward: no differentiable forward of batch %d x %d frames is pending on this handle", batch, frames);
+  WsBind bind(G->splitws);
   const ctta_status st = hifigan_backward_impl(G, false, grad_wav, wav, batch, grad_mel, (hipStream_t)stream);
   G->sv.B = 0;
   return st;

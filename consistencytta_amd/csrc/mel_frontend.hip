@@ -20,6 +20,7 @@ struct ctta_mel_frontend {
   bf16_t* x[3] = {nullptr, nullptr, nullptr};   // waveform parts [B][lp]
   float* ft = nullptr;                       // [B * frames][n_rows]
   size_t lp_max = 0, frames_max = 0;
+  SplitWs splitws;
 };
 
 // clip to [-1, 1], nan_to_num, reflect-pad n_fft/2 on both sides, split into bf16 hi + lo
@@ -94,6 +95,7 @@ extern "C" void ctta_mel_frontend_destroy(ctta_mel_frontend* M) {
   for (void* p : {(void*)M->b[0], (void*)M->b[1], (void*)M->b[2], (void*)M->mel_w, (void*)M->x[0], (void*)M->x[1],
                   (void*)M->x[2], (void*)M->ft})
     if (p) (void)hipFree(p);
+  M->splitws.destroy();
   delete M;
 }
 
@@ -162,6 +164,7 @@ extern "C" ctta_status ctta_mel_frontend_create(int filter_length, int hop_lengt
          hipMalloc((void**)&M->x[part], (size_t)max_batch * lp * 2) == hipSuccess &&
          hipMemcpy(M->b[part], parts[part].data(), parts[part].size() * 2, hipMemcpyHostToDevice) == hipSuccess;
   if (ok) ok = hipMemcpy(M->mel_w, w.data(), w.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+  if (ok) ok = M->splitws.init() == CTTA_OK;
   if (!ok) {
     ctta_set_error("mel_frontend_create: device allocation / upload failed");
     ctta_mel_frontend_destroy(M);
@@ -179,6 +182,7 @@ extern "C" ctta_status ctta_wav_to_fbank(ctta_mel_frontend* M, const float* wav,
                "wav_to_fbank: batch %d / samples %d outside the handle's limits (%d, %d)", batch, n_samples, M->max_batch,
                M->max_samples);
   hipStream_t s = (hipStream_t)stream;
+  WsBind bind(M->splitws);
   const int N = M->n_fft, half = N / 2;
   const int lp = round_up(n_samples + N, 8);
   const int frames_all = n_samples / M->hop + 1;                  // (T + 2*half - N) / hop + 1

@@ -318,6 +318,14 @@ typedef struct {
 } ctta_conv_desc;
 
 ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream);
+/* Split-K partial sums (deep, narrow problems: < 192 output tiles and K >= 1024) go through a device workspace.
+ * Threading contract: every engine handle (ctta_unet / ctta_vae / ctta_hifigan / ctta_t5 ...) owns its own workspace
+ * and binds it to the calling host thread inside each of its entry points, so different handles may run on different
+ * streams or host threads concurrently.  A RAW ctta_conv_gemm caller is served from one lazily allocated workspace per
+ * device: launches that share it must be ordered on ONE stream -- or the caller binds its own buffer of
+ * ctta_conv_workspace_bytes() bytes for the calling thread (NULL unbinds). */
+void ctta_conv_bind_workspace(void* ws, size_t bytes);
+size_t ctta_conv_workspace_bytes(void);
 int ctta_conv_gemm_num_variants(void);
 const char* ctta_conv_gemm_variant_name(int id);
 
