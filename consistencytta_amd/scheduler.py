@@ -221,17 +221,22 @@ class _LinCombMixin:
 
 class DDPMScheduler(_LinCombMixin):
     """Training-side noising schedule of AudioGDM (models/audio_guided_model.py:43-47): timesteps 999..0, add_noise,
-    init_noise_sigma = 1, identity scale_model_input, alphas_cumprod for compute_snr.  The ancestral `step` is not used
-    by any script of the reference (inference runs DDIM or Heun) and is not built."""
+    init_noise_sigma = 1, identity scale_model_input, alphas_cumprod for compute_snr, and the ancestral `step`
+    (scheduling_ddpm.py:285-418; unused by the reference's scripts -- inference runs DDIM or Heun -- kept for parity)."""
 
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
-                 trained_betas=None, variance_type="fixed_small", clip_sample=True, prediction_type="epsilon", **kw):
+                 trained_betas=None, variance_type="fixed_small", clip_sample=True, prediction_type="epsilon",
+                 thresholding=False, clip_sample_range=1.0, **kw):
+        if thresholding:
+            raise NotImplementedError("dynamic thresholding is unused by ConsistencyTTA and not built")
         self.betas, self.alphas_cumprod = _scaled_linear_alphas_cumprod(num_train_timesteps, beta_start, beta_end,
                                                                        beta_schedule, trained_betas)
         self.alphas = 1.0 - self.betas
         self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                                       beta_schedule=beta_schedule, prediction_type=prediction_type,
-                                      clip_sample=clip_sample, variance_type=variance_type)
+                                      clip_sample=clip_sample, clip_sample_range=clip_sample_range,
+                                      variance_type=variance_type, thresholding=False)
+        self.variance_type = variance_type
         self.init_noise_sigma = 1.0
         self.num_inference_steps = None
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy())
@@ -248,9 +253,67 @@ class DDPMScheduler(_LinCombMixin):
         ratio = self.config.num_train_timesteps // num_inference_steps
         self.timesteps = torch.from_numpy((np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64))
 
-    def step(self, *a, **k):
-        raise NotImplementedError("DDPMScheduler.step (ancestral sampling) is unused by the reference's scripts and not built; "
-                                  "use DDIMScheduler or HeunDiscreteScheduler for inference")
+    def _coeffs(self, t):
+        """Host-side per-sample tables of `step` (scheduling_ddpm.py:319-333,232-265): x0 / x_t coefficients of the
+        posterior mean and the posterior variance, float32 like the reference's tensor arithmetic."""
+        n_inf = self.num_inference_steps if self.num_inference_steps else self.config.num_train_timesteps
+        prev = t - self.config.num_train_timesteps // n_inf
+        one = torch.tensor(1.0)
+        a_t = self.alphas_cumprod[t]
+        a_prev = torch.where(prev >= 0, self.alphas_cumprod[prev.clamp(min=0)], one)
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        cur_a = a_t / a_prev
+        cur_b = 1 - cur_a
+        c_x0 = (a_prev ** 0.5 * cur_b) / b_t
+        c_xt = cur_a ** 0.5 * b_prev / b_t
+        var = b_prev / b_t * cur_b
+        vt = self.config.variance_type
+        if vt == "fixed_small":
+            std = torch.clamp(var, min=1e-20) ** 0.5
+        elif vt == "fixed_small_log":
+            std = torch.exp(0.5 * torch.log(torch.clamp(var, min=1e-20)))
+        elif vt == "fixed_large":
+            std = cur_b ** 0.5
+        else:
+            raise NotImplementedError("variance_type %r: only the fixed variances are built (the ConsistencyTTA U-Nets "
+                                      "predict no variance)" % (vt,))
+        return a_t, b_t, c_x0, c_xt, std
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True, variance_noise=None):
+        """Ancestral sampling step in the reference's batched-timestep form (scheduling_ddpm.py:285-418): x0 from the
+        prediction, posterior mean (formula 7 of Ho et al.), plus sqrt(variance) * noise for the samples with t > 0.
+        Noise is drawn like the reference (one randn of the t > 0 sub-batch's shape on the sample's device) unless
+        `variance_noise` (full batch shape; rows with t == 0 ignored) is given."""
+        B = sample.shape[0]
+        t = self._t_index(timestep, B)
+        a_t, b_t, c_x0, c_xt, std = self._coeffs(t)
+        clamp = float(getattr(self.config, "clip_sample_range", 1.0)) if self.config.clip_sample else 0.0
+        pt = self.config.prediction_type
+        if pt == "epsilon":
+            x0 = self._lincomb(sample, model_output, (a_t ** -0.5).numpy(), (-(b_t ** 0.5) / a_t ** 0.5).numpy(), clamp)
+        elif pt == "sample":
+            x0 = self._lincomb(model_output, sample, np.ones(B, np.float32), np.zeros(B, np.float32), clamp)
+        elif pt == "v_prediction":
+            x0 = self._lincomb(sample, model_output, (a_t ** 0.5).numpy(), (-(b_t ** 0.5)).numpy(), clamp)
+        else:
+            raise ValueError(f"prediction_type given as {pt} must be one of `epsilon`, `sample` or `v_prediction` "
+                             "for the DDPMScheduler.")
+        mean = self._lincomb(x0, sample, c_x0.numpy(), c_xt.numpy())
+        # reference quirk kept for parity (:381-407): the noise rows are picked by indexing the batch with
+        # (timestep > 0).nonzero() of the UN-expanded timestep, so a shared scalar timestep perturbs batch row 0 only
+        t_raw = torch.as_tensor(timestep).detach().reshape(-1).to("cpu", torch.int64)
+        pos = (t_raw > 0).nonzero().reshape(-1)
+        if variance_noise is None:
+            variance_noise = torch.zeros_like(mean)
+            if pos.numel():
+                variance_noise[pos.to(mean.device)] = torch.randn((pos.numel(),) + tuple(mean.shape[1:]), generator=generator,
+                                                                  device=mean.device, dtype=mean.dtype)
+        scale = torch.zeros_like(std)
+        scale[pos] = std[pos]
+        prev = self._lincomb(mean, variance_noise, np.ones(B, np.float32), scale.numpy())
+        if not return_dict:
+            return (prev,)
+        return SimpleNamespace(prev_sample=prev, pred_original_sample=x0)
 
 
 class DDIMScheduler(_LinCombMixin):

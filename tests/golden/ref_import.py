@@ -1,10 +1,10 @@
 """Import harness for the *reference* (Bai-YT/ConsistencyTTA) numerical modules.
 
 Only usable in the build container, where the read-only reference tree is mounted at
-/root/reference.  It is used by `make_golden.py` to produce the committed fixtures in this
-directory and by `tests/test_oracle_vs_reference.py` (skipped when the tree is absent) to
-check the CPU oracle against the reference's own modules.  Nothing on the GPU box imports
-this file's targets: /root/reference does not exist there.
+/root/reference.  It is used by the `make_golden*.py` scripts to produce the committed fixtures
+in this directory; the CPU oracle is then checked against those fixtures
+(`tests/test_oracle_golden.py`).  Nothing on the GPU box imports this file's targets:
+/root/reference does not exist there.
 
 Recipe follows SURVEY.md §8(c): the trimmed `easy_inference` copy of diffusers/audioldm is
 arithmetically identical to the full vendored tree (diff = import lines) and imports under

@@ -235,3 +235,32 @@ def test_flat_alias_checks_and_schedule_state():
     assert s2.get_last_lr() == sch.get_last_lr() and s2.last_step == 7
     s2.step(), sch.step()
     assert s2.get_last_lr() == sch.get_last_lr()
+
+
+def test_ddpm_step_host_tables_match_reference(golden):
+    """DDPMScheduler.step's per-sample coefficient tables (scheduling_ddpm.py:232-265,319-333) vs the reference's own
+    step outputs: the HIP kernel only evaluates a*x + b*y with these numbers (GPU twin: test_models_gpu.py)."""
+    g = golden("ddpm_step")
+    x = cases.t(spec.det_uniform("ddpm.x", (4, 8, 16, 4), 1)) * 2
+    v = cases.t(spec.det_uniform("ddpm.v", (4, 8, 16, 4), 3))
+    sd21 = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                prediction_type="v_prediction", clip_sample=False)
+    for tag, kw, steps in (("v_full", sd21, None), ("v_50", sd21, 50),
+                           ("eps_clip", dict(sd21, prediction_type="epsilon", clip_sample=True), 20),
+                           ("v_large", dict(sd21, variance_type="fixed_large"), 10)):
+        s = scheduler.DDPMScheduler(**kw)
+        if steps:
+            s.set_timesteps(steps)
+        t = torch.from_numpy(g[tag + "_t"])
+        a_t, b_t, c_x0, c_xt, std = (q.reshape(-1, 1, 1, 1) for q in s._coeffs(t))
+        if kw["prediction_type"] == "epsilon":
+            x0 = ((x - b_t ** 0.5 * v) / a_t ** 0.5).clamp(-1, 1)
+        else:
+            x0 = a_t ** 0.5 * x - b_t ** 0.5 * v
+        prev = c_x0 * x0 + c_xt * x + std * torch.from_numpy(g[tag + "_noise"])     # the fixture's noise is 0 where none is added
+        np.testing.assert_allclose(x0.numpy(), g[tag + "_x0"], rtol=2e-5, atol=2e-6)
+        np.testing.assert_allclose(prev.numpy(), g[tag + "_prev"], rtol=2e-5, atol=2e-6)
+    with pytest.raises(NotImplementedError):
+        scheduler.DDPMScheduler(**dict(sd21, variance_type="learned_range"))._coeffs(torch.tensor([5]))
+    with pytest.raises(RuntimeError):
+        scheduler.DDPMScheduler(**sd21).step(v, 3, x)                       # CPU tensors: no CPU path

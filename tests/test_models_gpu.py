@@ -157,10 +157,37 @@ def test_ddpm_ddim_schedulers_against_reference_golden(golden):
     assert rel_err(ddim.step(v, torch.from_numpy(g["ddim_t"]), x).prev_sample, torch.from_numpy(g["ddim_step"])) < 1e-6
     assert rel_err(ddim.step(v, 600, x).prev_sample, torch.from_numpy(g["ddim_step_scalar_t"])) < 1e-6
     assert rel_err(ddim.add_noise(x, noise, t_train.to(DEV)), torch.from_numpy(g["ddim_add_noise"])) < 1e-6
-    with pytest.raises(NotImplementedError):
-        ddpm.step(v, 5, x)
     with pytest.raises(ValueError):
         scheduler.DDIMScheduler().step(v, 5, x)          # set_timesteps not called
+
+
+def test_ddpm_ancestral_step_against_reference_golden(golden):
+    """DDPMScheduler.step (scheduling_ddpm.py:285-418) on the HIP elementwise kernel vs the reference's own step with
+    its recorded noise: full 1000-step schedule, 50/20/10-step schedules, epsilon + clipping, fixed_large variance,
+    rows with t == 0 (no noise) and prev_t < 0 (alpha_prev = 1)."""
+    g = golden("ddpm_step")
+    x = (cases.t(spec.det_uniform("ddpm.x", (4, 8, 16, 4), 1)) * 2).to(DEV)
+    v = cases.t(spec.det_uniform("ddpm.v", (4, 8, 16, 4), 3)).to(DEV)
+    sd21 = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                prediction_type="v_prediction", clip_sample=False)
+    for tag, kw, steps in (("v_full", sd21, None), ("v_50", sd21, 50),
+                           ("eps_clip", dict(sd21, prediction_type="epsilon", clip_sample=True), 20),
+                           ("v_large", dict(sd21, variance_type="fixed_large"), 10)):
+        s = scheduler.DDPMScheduler(**kw)
+        if steps:
+            s.set_timesteps(steps)
+        r = s.step(v, torch.from_numpy(g[tag + "_t"]), x, variance_noise=torch.from_numpy(g[tag + "_noise"]).to(DEV))
+        assert rel_err(r.prev_sample, torch.from_numpy(g[tag + "_prev"])) < 2e-6, tag
+        assert rel_err(r.pred_original_sample, torch.from_numpy(g[tag + "_x0"])) < 2e-6, tag
+    s = scheduler.DDPMScheduler(**sd21)
+    s.set_timesteps(50)
+    assert rel_err(s.step(v, 0, x).prev_sample, torch.from_numpy(g["scalar_t_prev"])) < 2e-6
+    # own noise: drawn for the t > 0 rows only, reproducible through the generator
+    gen = torch.Generator(device=DEV).manual_seed(3)
+    a = s.step(v, torch.tensor([980, 0, 20, 500]), x, generator=gen).prev_sample
+    gen.manual_seed(3)
+    b = s.step(v, torch.tensor([980, 0, 20, 500]), x, generator=gen).prev_sample
+    assert torch.equal(a, b) and not torch.equal(a[0], s.step(v, torch.tensor([980, 0, 20, 500]), x).prev_sample[0])
 
 
 def test_stage1_guided_distillation_loss_backward_and_inference(golden):
