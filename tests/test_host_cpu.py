@@ -264,3 +264,72 @@ def test_ddpm_step_host_tables_match_reference(golden):
         scheduler.DDPMScheduler(**dict(sd21, variance_type="learned_range"))._coeffs(torch.tensor([5]))
     with pytest.raises(RuntimeError):
         scheduler.DDPMScheduler(**sd21).step(v, 3, x)                       # CPU tensors: no CPU path
+
+
+def test_run_directory_formats_round_trip(tmp_path):
+    """summary.jsonl (train.py:304-305, tools/train_utils.py:240-241, inference.py:114) and the accelerate
+    `save_state` layout with the distilled model in pytorch_model_2.bin (train.py:380,498-505; inference.py:152-153)."""
+    import argparse
+    import json
+    from consistencytta_amd import checkpoint as ck
+    from consistencytta_amd import audio, optim
+    run = str(tmp_path / "run")
+    args = argparse.Namespace(stage=2, text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                              unet_model_name=None, unet_model_config="tiny_light.json", snr_gamma=5.0,
+                              freeze_text_encoder=True, uncondition=False, use_edm=True, use_karras=False, use_lora=False,
+                              target_ema_decay=0.95, ema_decay=0.999, num_diffusion_steps=18, teacher_guidance_scale=-1,
+                              loss_type="mse", finetune_vae=False, output_dir=run)
+    ck.write_args_summary(run, args)
+    ck.append_summary(run, {"epoch": 1, "step": 10, "validation_loss": 0.5, "train_loss": 0.25})
+    text = open(os.path.join(run, "summary.jsonl")).read()
+    assert text.split("\n")[0] == json.dumps(dict(vars(args))) and text.endswith("}\n\n")
+    assert os.path.isdir(os.path.join(run, "outputs"))
+    ta = ck.read_original_args(os.path.join(run, "summary.jsonl"))
+    assert ta.stage == 2 and ta.hf_model is None and ta.unet_model_config == "tiny_light.json" and ta.nonexistent is None
+    assert ck.read_summary(os.path.join(run, "summary.jsonl"))[1]["validation_loss"] == 0.5
+
+    m = _lcm()
+    for i, net in enumerate((m.teacher_unet, m.student_unet, m.student_target_unet, m.student_ema_unet)):
+        net.init_deterministic(seed=10 + i)
+    vae = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, hifigan_config=cases.TINY_HIFIGAN).init_deterministic(3)
+    stft = audio.TacotronSTFT()
+    opt = optim.FusedAdamW(m.student_unet, lr=1e-5)
+    opt.step_count = 7
+    opt.exp_avg.fill_(0.5)
+    sch = optim.WarmupSchedule(opt, "linear", num_warmup_steps=3, num_training_steps=30)
+    for _ in range(5):
+        sch.step()
+    ckdir = ck.save_state(os.path.join(run, "epoch_1"), (vae, stft, m), opt, sch)
+    assert sorted(os.listdir(ckdir)) == ["optimizer.bin", "pytorch_model.bin", "pytorch_model_1.bin", "pytorch_model_2.bin",
+                                         "random_states_0.pkl", "scheduler.bin"]
+    saved = torch.load(os.path.join(ckdir, "pytorch_model_2.bin"))
+    assert list(saved.keys()) == list(m.state_dict().keys())          # plain state dict, the model's own key order
+    assert list(saved)[0].startswith("teacher_unet.") and any(k.startswith("student_target_unet.") for k in saved)
+
+    # inference.py's path: arguments from summary.jsonl + pytorch_model_2.bin through load_pretrained
+    m2, ta2 = ck.build_model_from_run(os.path.join(ckdir, "pytorch_model_2.bin"), os.path.join(run, "summary.jsonl"),
+                                      vae=None, stage=2, unet_config=cases.TINY_UNET)
+    assert not m2.training and ta2.loss_type == "mse"
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+    with pytest.raises(AssertionError, match="Stage mismatch"):
+        ck.build_model_from_run(os.path.join(ckdir, "pytorch_model_2.bin"), os.path.join(run, "summary.jsonl"), stage=1,
+                                unet_config=cases.TINY_UNET)
+
+    # train.py --resume_from_checkpoint: everything comes back, RNG streams included
+    m3 = _lcm()
+    vae3 = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, hifigan_config=cases.TINY_HIFIGAN)
+    opt3 = optim.FusedAdamW(m3.student_unet, lr=3e-5)
+    sch3 = optim.WarmupSchedule(opt3, "constant")
+    ck.load_state(ckdir, (vae3, audio.TacotronSTFT(), m3), opt3, sch3)
+    assert opt3.step_count == 7 and float(opt3.exp_avg[0]) == 0.5 and sch3.last_step == 5
+    assert sch3.get_last_lr() == sch.get_last_lr()
+    for (k, a), (_, b) in zip(vae.state_dict().items(), vae3.state_dict().items()):
+        assert torch.equal(a, b), k
+    assert torch.equal(m3.student_ema_unet.state_dict()["conv_in.weight"], m.student_ema_unet.state_dict()["conv_in.weight"])
+    torch.manual_seed(5)
+    ck.save_state(os.path.join(run, "rng"), ())
+    want = torch.rand(4)
+    torch.manual_seed(6)
+    ck.load_state(os.path.join(run, "rng"), ())
+    assert torch.equal(torch.rand(4), want)
