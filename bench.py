@@ -502,6 +502,23 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                                      "AdamW, EMA")
         del m, opt, vae
         return out
+    # train.sh:33's recipe accumulates 5 micro-batches per optimizer step (SURVEY 8d "grad-accum 1 and 5"): 4 local
+    # micro-steps (loss + backward, DDP no_sync) and a 5th that also all-reduces, steps AdamW and updates the EMAs
+    acc, n_opt = 5, max(2, args.steps // 5)
+    m._micro = 0
+    for _ in range(acc):
+        m.train_step(z0, P, opt, sched, accumulation_steps=acc)
+    du.barrier(dev)
+    t0 = time.perf_counter()
+    for _ in range(acc * n_opt):
+        losses.append(m.train_step(z0, P, opt, sched, accumulation_steps=acc))
+    du.barrier(dev)
+    dt5 = du.max_over_ranks(time.perf_counter() - t0, dev)
+    m._micro = 0
+    assert all(v == v for v in losses), "NaN distillation loss"
+    out["grad_accum_5"] = {"value": round(n_opt / dt5, 4), "unit": "optimizer steps/s", "optimizer_steps": n_opt,
+                           "micro_steps_per_s": round(acc * n_opt / dt5, 3), "samples_per_s": round(world * B * acc * n_opt / dt5, 3),
+                           "ms_per_optimizer_step": round(dt5 / n_opt * 1e3, 3), "global_batch": B * world * acc}
     # one more step with the in-library launch profiler on rank 0.  EVERY rank takes the step: at world > 1 it issues
     # the gradient all-reduces, and a collective entered by rank 0 alone would pair up with the other ranks' next
     # barrier and hang the job

@@ -224,31 +224,42 @@ static ctta_status run_vae_attn(VCtx& c, VaeAttn* V, const bf16_t* x, int H, int
     d.groups = B; d.w_group_stride = (int64_t)N * C; d.out_group_stride = (int64_t)C * N;
     RUN(c, ctta_conv_gemm(&d, c.stream));
   }
-  float* s = A.get<float>((size_t)B * N * N); ALLOC_OR_FAIL(s);
-  {
-    ctta_conv_desc d;
-    desc_init(&d);
-    d.x0 = q; d.c0 = C;
-    d.batch = 1; d.hi = N; d.wi = 1; d.ho = N; d.wo = 1;
-    d.w = k; d.k_pad = C; d.n = N;
-    d.out = s; d.ldc = N; d.out_f32 = 1;
-    d.groups = B; d.x_group_stride = (int64_t)N * C; d.w_group_stride = (int64_t)N * C;
-    d.out_group_stride = (int64_t)N * N;
-    RUN(c, ctta_conv_gemm(&d, c.stream));
-  }
-  if (!p) { p = A.get<bf16_t>((size_t)B * N * N); ALLOC_OR_FAIL(p); }
-  RUN(c, ctta_softmax_rows(s, p, (int64_t)B * N, N, 1.0f / sqrtf((float)C), c.stream));
+  // scores / probabilities in sample chunks small enough to stay in the 256 MB Infinity Cache between the three
+  // launches (QK^T -> softmax -> PV): the (N x N) fp32 score matrix of one sample is 64 MB at N = 4096, the whole batch
+  // at B = 32 would be 2 GiB of arena and 6 GB of HBM traffic per decode (modules.py:204-230 materialises it too)
+  int gb = (int)(((size_t)100 << 20) / ((size_t)N * N * 6));
+  if (gb < 1) gb = 1;
+  if (gb > B) gb = B;
+  float* s = A.get<float>((size_t)gb * N * N); ALLOC_OR_FAIL(s);
+  if (!p) { p = A.get<bf16_t>((size_t)gb * N * N); ALLOC_OR_FAIL(p); }
+  const bool p_full = c.grad;   // the differentiable forward keeps every sample's probabilities
   bf16_t* o = A.get<bf16_t>(M * C); ALLOC_OR_FAIL(o);
-  {
-    ctta_conv_desc d;
-    desc_init(&d);
-    d.x0 = p; d.c0 = N;
-    d.batch = 1; d.hi = N; d.wi = 1; d.ho = N; d.wo = 1;
-    d.w = vt; d.k_pad = N; d.n = C;
-    d.out = o; d.ldc = C;
-    d.groups = B; d.x_group_stride = (int64_t)N * N; d.w_group_stride = (int64_t)C * N;
-    d.out_group_stride = (int64_t)N * C;
-    RUN(c, ctta_conv_gemm(&d, c.stream));
+  for (int b0 = 0; b0 < B; b0 += gb) {
+    const int nb = B - b0 < gb ? B - b0 : gb;
+    bf16_t* pc = p_full ? p + (size_t)b0 * N * N : p;
+    {
+      ctta_conv_desc d;
+      desc_init(&d);
+      d.x0 = q + (size_t)b0 * N * C; d.c0 = C;
+      d.batch = 1; d.hi = N; d.wi = 1; d.ho = N; d.wo = 1;
+      d.w = k + (size_t)b0 * N * C; d.k_pad = C; d.n = N;
+      d.out = s; d.ldc = N; d.out_f32 = 1;
+      d.groups = nb; d.x_group_stride = (int64_t)N * C; d.w_group_stride = (int64_t)N * C;
+      d.out_group_stride = (int64_t)N * N;
+      RUN(c, ctta_conv_gemm(&d, c.stream));
+    }
+    RUN(c, ctta_softmax_rows(s, pc, (int64_t)nb * N, N, 1.0f / sqrtf((float)C), c.stream));
+    {
+      ctta_conv_desc d;
+      desc_init(&d);
+      d.x0 = pc; d.c0 = N;
+      d.batch = 1; d.hi = N; d.wi = 1; d.ho = N; d.wo = 1;
+      d.w = vt + (size_t)b0 * C * N; d.k_pad = N; d.n = C;
+      d.out = o + (size_t)b0 * N * C; d.ldc = C;
+      d.groups = nb; d.x_group_stride = (int64_t)N * N; d.w_group_stride = (int64_t)C * N;
+      d.out_group_stride = (int64_t)N * C;
+      RUN(c, ctta_conv_gemm(&d, c.stream));
+    }
   }
   CTTA_TRY(run_conv2d(c, V->proj, o, B, H, W, false, out, nullptr, 0, x, C));
   A.release(mk);

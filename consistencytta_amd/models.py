@@ -16,6 +16,7 @@ runs the HIP engine's own backward pass and fills `student_unet` `.grad`s, so th
 buffer, fused AdamW, two-shadow EMA) that replaces accelerate's DDP wrapper (train.py:377-379),
 whose autograd hooks cannot see gradients produced outside autograd.
 """
+import os
 from copy import deepcopy
 from time import time
 
@@ -374,6 +375,12 @@ class AudioLCM(AudioDistilledModel):
             a = self._anchor = torch.zeros((), device=self.device, requires_grad=True)
         return a
 
+    def _side_stream(self, dev):
+        st = getattr(self, "_side", None)
+        if st is None or st.device != torch.device(dev):
+            st = self._side = torch.cuda.Stream(device=dev)
+        return st
+
     def _student_backward(self, pred, target, sig, gamma, loss_scale=1.0, on_block_done=None):
         """d loss / d pred of get_loss (audio_consistency_model.py:250-266) -> engine backward."""
         if isinstance(target, tuple):   # perceptual loss: torch differentiates loss(pred) down to the latent
@@ -471,6 +478,19 @@ class AudioLCM(AudioDistilledModel):
             guidance_scale = guidance_scale.to(dev)
         else:
             guidance_scale = None
+        # The student's training forward depends only on the noised input, not on the teacher: enqueue it on a second
+        # HIP stream so that it runs beside the two teacher queries and the target network (the thin deep-level
+        # launches of a batch-9/18 forward leave CUs idle).  Every engine handle owns its arena and split-K workspace,
+        # so the two streams share no scratch memory.  CTTA_TWO_STREAM=0 keeps everything on one stream.
+        side_pred = None
+        if (want_grad and validation_mode == 0 and z_0.is_cuda and os.environ.get("CTTA_TWO_STREAM", "1") != "0"):
+            cur = torch.cuda.current_stream(dev)
+            side = self._side_stream(dev)
+            w_stu = guidance_scale if guidance_scale is not None else float(self.teacher_guidance_scale)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                side_pred = self.student_unet.forward_train(z_np1_scaled, t_np1, w_stu, embeds, mask)
+            side_pred.record_stream(cur)
         v1 = self._query_teacher(z_np1_scaled, t_np1, embeds_cf, mask_cf, guidance_scale)
         zhat_n = sch.step(v1, t_np1, z_np1).prev_sample
         zhat_n_scaled = sch.scale_model_input(zhat_n, t_n)
@@ -510,7 +530,11 @@ class AudioLCM(AudioDistilledModel):
             return loss_w_gt, loss_w_teacher, loss_consis, loss_teacher
         target = torch.where((t_n == 0).reshape(-1, 1, 1, 1).to(dev), z_0, target)
         if want_grad:
-            pred = self.student_unet.forward_train(z_np1_scaled, t_np1, w, embeds, mask)
+            if side_pred is not None:
+                torch.cuda.current_stream(dev).wait_stream(self._side_stream(dev))
+                pred = side_pred
+            else:
+                pred = self.student_unet.forward_train(z_np1_scaled, t_np1, w, embeds, mask)
             gamma = self.snr_gamma or 0.0
             if self.loss is not None:   # keep the graph from pred to the loss; _student_backward differentiates it
                 leaf = pred.detach().requires_grad_(True)
