@@ -527,10 +527,18 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     L_ = N.lib()
     if rank == 0:
         L_.ctta_prof_enable(1)
+    # the profiled step keeps every launch on ONE stream: with the student forward on its side stream the bracketed
+    # launch times of concurrent kernels overlap and their sum is not a duration any more
+    two_stream = os.environ.get("CTTA_TWO_STREAM")
+    os.environ["CTTA_TWO_STREAM"] = "0"
     ev[0].record()
     m.train_step(z0, P, opt, sched)
     ev[1].record()
     torch.cuda.synchronize()
+    if two_stream is None:
+        del os.environ["CTTA_TWO_STREAM"]
+    else:
+        os.environ["CTTA_TWO_STREAM"] = two_stream
     if rank == 0:
         L_.ctta_prof_enable(0)
         ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()

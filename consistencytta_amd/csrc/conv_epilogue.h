@@ -1,0 +1,184 @@
+// ConvParams and the fused output epilogues shared by the implicit-GEMM kernels (conv_gemm.hip) and the fused
+// HiFi-GAN ResBlock unit (resunit.hip).
+#pragma once
+#include "common.h"
+
+struct ConvParams {
+  const bf16_t* x0; const bf16_t* x1; int c0, c1, ct;
+  int M, hi, wi, hs, ws, ups, ho, wo, howo;
+  int kh, kw, taps, sh, sw, ph, pw, dh, dw;
+  const bf16_t* w; int k_pad, n, nk;
+  const float* bias; const float* bias_m; const float* rowvec; int rowvec_ld;
+  const bf16_t* res; int res_ld;
+  int in_act; float in_slope; int out_act; float out_slope; float alpha; int accumulate;
+  void* out; int ldc; int out_f32; bf16_t* out2; float out2_slope; int scalar_store;
+  long long obs, out_offset, out_limit;
+  long long xgs, wgs, ogs;
+  const bf16_t* zero;   // >= 16 bytes of zeros: source of out-of-range chunks in the direct-to-LDS path
+  unsigned x_bytes, w_bytes;   // buffer extents for the descriptor (MODE 2) path
+  int xs0;                     // row stride (elements) of source 0: c0 unless a wider matrix is sliced
+  // split-K (groups == 1 only): blockIdx.z = split index, each split walks nk_split K-tiles and writes raw fp32
+  // partial sums to slab `split` of a workspace (out / ldc / ogs are redirected by the host); the fused epilogue
+  // runs afterwards in splitk_finish_kernel
+  int ksplit, nk_split;
+  // XCD-aware tile order (1-D grid): block id b runs on XCD b % 8; XCD x owns the contiguous M-tile range
+  // [x * xcd_per, (x + 1) * xcd_per) and walks it with the N tiles innermost, so the tiles that share input rows
+  // (neighbouring image rows, all N tiles of one M tile) meet in the same 4 MB L2 close in time.  0 = plain 2-D grid.
+  int xcd_per, m_tiles, n_tiles, n_inner;   // n_inner = 0: M tiles innermost (many N tiles: keep the weight slice hot)
+  // 1: the tile is transposed through LDS and leaves as whole 64..256-byte row segments (see the kernel's epilogue)
+  int wide_store;
+  int plain_out;   // destination element (m, n) sits at m*ldc + n (no per-batch stride, offset or limit)
+};
+
+// The fused epilogue on 4 consecutive channels of one output row, for the wide-store paths (plain row-major bf16
+// destination: element (m, n) at m*ldc + n): same operation order as epilogue_store.
+__device__ __forceinline__ void epilogue_wide4(const ConvParams& p, const float4 q, const float4 bias4, int m, int n,
+                                               size_t gofs) {
+  float v[4] = {q.x + bias4.x, q.y + bias4.y, q.z + bias4.z, q.w + bias4.w};
+  if (p.bias_m) {
+    const float bm = p.bias_m[m];
+    v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+  }
+  if (p.rowvec) {
+    const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.howo) * p.rowvec_ld + n);
+    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+  }
+  if (p.res) {
+    const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
+    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+  }
+  size_t oidx = gofs + (size_t)m * p.ldc + n;
+  if (!p.plain_out) {   // ConvTranspose phases: per-batch stride, shifted and clipped rows (same rule as epilogue_store)
+    const int b = m / p.howo;
+    const long long inb = (long long)(m - b * p.howo) * p.ldc + n + p.out_offset;
+    if (p.out_limit > 0 && (inb < 0 || inb >= p.out_limit)) return;
+    oidx = gofs + (size_t)((long long)b * p.obs + inb);
+  }
+  bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + oidx;
+  if (p.accumulate) {
+    const uint2 old = *reinterpret_cast<const uint2*>(o);
+    v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+    v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    v[e] *= p.alpha;
+    if (p.out_act == 1) v[e] = silu_f(v[e]);
+    else if (p.out_act == 2) v[e] = tanhf(v[e]);
+    else if (p.out_act == 3) v[e] = v[e] > 0.f ? v[e] : v[e] * p.out_slope;
+  }
+  uint2 pk;
+  pk.x = pack2bf(v[0], v[1]);
+  pk.y = pack2bf(v[2], v[3]);
+  *reinterpret_cast<uint2*>(o) = pk;
+  if (p.out2) {   // leaky_relu of the SAME (bf16-rounded) values
+    float w2[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),
+                   __uint_as_float(pk.y & 0xffff0000u)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w2[e] = w2[e] > 0.f ? w2[e] : w2[e] * p.out2_slope;
+    uint2 pk2;
+    pk2.x = pack2bf(w2[0], w2[1]);
+    pk2.y = pack2bf(w2[2], w2[3]);
+    *reinterpret_cast<uint2*>(p.out2 + oidx) = pk2;
+  }
+}
+
+// GLDS = true: tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no
+// ds_write): the LDS image is lane-linear per wave instruction (8 rows x 128 B for BK = 64), so the
+// XOR swizzle is applied to the per-lane SOURCE chunk instead of the destination; padding / tail
+// chunks read a zero page.  GLDS = false stages through registers (needed for in_act).
+// STAGES > 2 (GLDS only): an S-slot LDS ring with S-1 tiles in flight; the wait for tile kt is a
+// COUNTED s_waitcnt vmcnt((S-2) * loads_per_tile) followed by a raw s_barrier, so younger tiles stay
+// in flight across the barrier (a __syncthreads() would drain them: its release carries vmcnt(0)).
+// One accumulator fragment (4 consecutive output channels of one pixel) through the fused epilogue.
+__device__ __forceinline__ void epilogue_store(const ConvParams& p, const f32x4_t a, int m, int n, int b,
+                                               long long mrem, int g, const uint2* res_pre = nullptr) {
+  const long long inb = mrem * p.ldc + n + p.out_offset;
+  if (p.out_limit > 0 && (inb < 0 || inb >= p.out_limit)) return;
+  const size_t oidx = (size_t)((long long)g * p.ogs + (long long)b * p.obs + inb);
+  float v[4] = {a[0], a[1], a[2], a[3]};
+  if (p.bias) {
+    if (p.scalar_store) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (n + r < p.n) v[r] += p.bias[n + r];
+    } else {
+      const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+      v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+    }
+  }
+  if (p.bias_m) {
+    const float bm = p.bias_m[m];
+    v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
+  }
+  if (p.rowvec) {
+    const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_ld + n);
+    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
+  }
+  if (p.res) {   // res_pre: the caller already fetched the residual (rolled epilogues prefetch a whole chunk)
+    const uint2 rr = res_pre ? *res_pre : *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
+    v[0] += __uint_as_float(rr.x << 16); v[1] += __uint_as_float(rr.x & 0xffff0000u);
+    v[2] += __uint_as_float(rr.y << 16); v[3] += __uint_as_float(rr.y & 0xffff0000u);
+  }
+  if (p.scalar_store) {
+    // tiny Cout (ldc not a multiple of 4): element-wise fp32 / bf16 stores of the valid channels
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n + r < p.n) {
+        float t = v[r] * p.alpha;
+        if (p.out_act == 1) t = silu_f(t);
+        else if (p.out_act == 2) t = tanhf(t);
+        else if (p.out_act == 3) t = t > 0.f ? t : t * p.out_slope;
+        if (p.out_f32) reinterpret_cast<float*>(p.out)[oidx + r] = t;
+        else reinterpret_cast<bf16_t*>(p.out)[oidx + r] = f2bf(t);
+      }
+    }
+    return;
+  }
+  if (p.out_f32) {
+    float* o = reinterpret_cast<float*>(p.out) + oidx;
+    if (p.accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(o);
+      v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] *= p.alpha;
+      if (p.out_act == 1) v[r] = silu_f(v[r]);
+      else if (p.out_act == 2) v[r] = tanhf(v[r]);
+      else if (p.out_act == 3) v[r] = v[r] > 0.f ? v[r] : v[r] * p.out_slope;
+    }
+    *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    return;
+  }
+  bf16_t* o = reinterpret_cast<bf16_t*>(p.out) + oidx;
+  if (p.accumulate) {
+    const uint2 old = *reinterpret_cast<const uint2*>(o);
+    v[0] += __uint_as_float(old.x << 16); v[1] += __uint_as_float(old.x & 0xffff0000u);
+    v[2] += __uint_as_float(old.y << 16); v[3] += __uint_as_float(old.y & 0xffff0000u);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    v[r] *= p.alpha;
+    if (p.out_act == 1) v[r] = silu_f(v[r]);
+    else if (p.out_act == 2) v[r] = tanhf(v[r]);
+    else if (p.out_act == 3) v[r] = v[r] > 0.f ? v[r] : v[r] * p.out_slope;
+  }
+  uint2 pk;
+  pk.x = pack2bf(v[0], v[1]);
+  pk.y = pack2bf(v[2], v[3]);
+  *reinterpret_cast<uint2*>(o) = pk;
+  if (p.out2) {   // second output: leaky_relu of the SAME (bf16-rounded) values, for the next conv's input
+    float w[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float q = bf2f(f2bf(v[r]));
+      w[r] = q > 0.f ? q : q * p.out2_slope;
+    }
+    uint2 pk2;
+    pk2.x = pack2bf(w[0], w[1]);
+    pk2.y = pack2bf(w[2], w[3]);
+    *reinterpret_cast<uint2*>(p.out2 + oidx) = pk2;
+  }
+}
+

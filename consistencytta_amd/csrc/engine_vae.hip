@@ -7,6 +7,8 @@
 // (B,1,T,F) mel IS the vocoder's (B, T, F=num_mels) input, autoencoder.py:109).
 #include "engine_common.h"
 
+#include <stdlib.h>
+
 #include <math.h>
 
 // z (B,zc,H,W) f32 -> post_quant_conv(z / scale) as NHWC bf16 with channels padded to cpad.
@@ -227,7 +229,9 @@ static ctta_status run_vae_attn(VCtx& c, VaeAttn* V, const bf16_t* x, int H, int
   // scores / probabilities in sample chunks small enough to stay in the 256 MB Infinity Cache between the three
   // launches (QK^T -> softmax -> PV): the (N x N) fp32 score matrix of one sample is 64 MB at N = 4096, the whole batch
   // at B = 32 would be 2 GiB of arena and 6 GB of HBM traffic per decode (modules.py:204-230 materialises it too)
-  int gb = (int)(((size_t)100 << 20) / ((size_t)N * N * 6));
+  static int chunk_mb = -1;
+  if (chunk_mb < 0) { const char* e = getenv("CTTA_VAE_ATTN_MB"); chunk_mb = e ? atoi(e) : 100; }
+  int gb = (int)(((size_t)chunk_mb << 20) / ((size_t)N * N * 6));
   if (gb < 1) gb = 1;
   if (gb > B) gb = B;
   float* s = A.get<float>((size_t)gb * N * N); ALLOC_OR_FAIL(s);
@@ -852,6 +856,9 @@ struct ConvT1d {
 };
 struct HResBlock {
   Conv1d c1[3], c2[3];
+  bf16_t* f1[3] = {nullptr, nullptr, nullptr};   // fragment-major copies of c1 / c2 for the fused unit kernel (resunit.hip)
+  bf16_t* f2[3] = {nullptr, nullptr, nullptr};
+  bool fused = false;
   Conv1d d1[3], d2[3];                       // enable_grad: data-gradient operands
   const bf16_t* sv_xt[3] = {nullptr, nullptr, nullptr};    // leaky_relu(convs1[m](.)) of the differentiable forward
   const bf16_t* sv_ract[3] = {nullptr, nullptr, nullptr};  // leaky_relu of the residual stream entering unit m
@@ -1025,7 +1032,10 @@ static ctta_status hifigan_forward_impl(ctta_hifigan* G, bool dry, const float* 
     bf16_t* y = A.get<bf16_t>(elems); ALLOC_OR_FAIL(y);        // x = ups[i](leaky_relu(x, 0.1))
     bf16_t* ya = A.get<bf16_t>(elems); ALLOC_OR_FAIL(ya);      // leaky_relu(x, 0.1) for the 3 resblocks
     {
-      OutAct oa; oa.out2 = ya; oa.out2_slope = 0.1f;
+      bool all_fused = !grad;
+      for (int j = 0; j < nk; ++j) all_fused = all_fused && G->res[i * nk + j].fused;
+      OutAct oa;
+      if (!all_fused) { oa.out2 = ya; oa.out2_slope = 0.1f; }   // the fused units apply leaky_relu themselves
       CTTA_TRY(run_convt1d(c, U, xa, B, len, y, oa));
     }
     len = lout; ch = U.cout;
@@ -1042,6 +1052,18 @@ static ctta_status hifigan_forward_impl(ctta_hifigan* G, bool dry, const float* 
       HResBlock& R = G->res[i * nk + j];
       const bf16_t* r = y;       // residual stream (raw)
       const bf16_t* ract = ya;   // leaky_relu(r, 0.1)
+      if (R.fused && !grad) {    // one launch per unit: x -> x + conv2(lrelu(conv1(lrelu(x)))), intermediate kept in LDS
+        for (int mth = 0; mth < 3; ++mth) {
+          const bool last = mth == 2, fin = j == nk - 1;
+          bf16_t* dst = last ? xs : ((r == ra) ? rb : ra);
+          const float out_slope = (last && fin) ? (last_stage ? 0.01f : 0.1f) : 0.f;
+          RUN(c, ctta_resunit_conv1d(r, B, len, ch, R.c1[mth].k, R.c1[mth].dil, R.f1[mth], R.c1[mth].p.bias, R.f2[mth],
+                                     R.c2[mth].p.bias, 0.1f, dst, (last && j > 0) ? 1 : 0,
+                                     (last && fin) ? 1.0f / (float)nk : 1.0f, out_slope, c.stream));
+          r = dst;
+        }
+        continue;
+      }
       for (int mth = 0; mth < 3; ++mth) {
         if (grad) {   // every activated tensor is a LeakyReLU mask of the backward: no buffer reuse
           xt = A.get<bf16_t>(elems); ALLOC_OR_FAIL(xt);
@@ -1186,6 +1208,26 @@ static ctta_status hifigan_build(ctta_hifigan* G) {
           CTTA_TRY(make_conv1d_dgrad(ws, R.c1[m], &R.d1[m]));
           CTTA_TRY(make_conv1d_dgrad(ws, R.c2[m], &R.d2[m]));
         }
+      }
+      // narrow stages: the plain forward runs each unit (conv1 -> lrelu -> conv2 -> + x) as ONE fused launch that reads
+      // its weights fragment-major; the copies are re-derived from the packed operands after every (re)load
+      R.fused = !grad;
+      for (int m = 0; m < 3; ++m) R.fused = R.fused && ctta_resunit_supported(ch, k, cfg.resblock_dilations[j][m]) != 0;
+      if (R.fused) {
+        for (int m = 0; m < 3; ++m) {
+          R.f1[m] = ws.arena.get<bf16_t>((size_t)ch * k * ch);
+          R.f2[m] = ws.arena.get<bf16_t>((size_t)ch * k * ch);
+          if (!R.f1[m] || !R.f2[m]) { ctta_set_error("weight store exhausted (fragment-major vocoder weights)"); return CTTA_ERR_NOMEM; }
+        }
+        HResBlock* Rp = &R;
+        const int chc = ch;
+        ws.jobs.push_back([Rp, chc, k](const WeightTable&, hipStream_t s) -> ctta_status {
+          for (int m = 0; m < 3; ++m) {
+            CTTA_TRY(ctta_frag_pack(Rp->c1[m].p.w, chc, Rp->c1[m].p.k_pad, k * chc, Rp->f1[m], s));
+            CTTA_TRY(ctta_frag_pack(Rp->c2[m].p.w, chc, Rp->c2[m].p.k_pad, k * chc, Rp->f2[m], s));
+          }
+          return CTTA_OK;
+        });
       }
     }
   }

@@ -1,0 +1,304 @@
+// Fused HiFi-GAN ResBlock unit for the narrow vocoder stages (C = 32 / 64 / 128 channels):
+//
+//   out = x + conv2( leaky_relu( conv1( leaky_relu(x, 0.1) ) + b1, 0.1 ) ) + b2        hifigan/models.py:56-63
+//   (conv1: k taps, dilation d; conv2: k taps, dilation 1; both "same"-padded, stride 1)
+//
+// As two implicit-GEMM launches each unit moves x, lrelu(x), the intermediate and the output through HBM and
+// re-gathers every input row k times from L2 while producing only C channels per row (the generic kernel runs these
+// stages at 107-725 TFLOP/s).  Here one workgroup owns T output positions of one sample:
+//   1. stages leaky_relu(x) for its T positions plus the (k-1)(d+1)/2 halo on each side ONCE in LDS,
+//   2. conv1 over T + (k-1) positions, taps = row offsets into that tile; the result (bias, leaky_relu, bf16) is
+//      written back into the same LDS buffer (the input tile is dead by then),
+//   3. conv2 over the T positions from that intermediate, then the fused epilogue (bias, residual x re-read from
+//      L2, optional accumulate / scale / leaky_relu of the stage fold) through an LDS transpose, so that whole
+//      C-channel rows leave as 64..256-byte segments.
+// HBM sees x once and the output once.
+//
+// MFMA mapping (v_mfma_f32_16x16x32_bf16, weights = A operand, positions = B operand, as in conv_gemm): the
+// workgroup's 4 waves are split WC x WP; wave (wc, wp) owns a slice of C / WC output channels (NCB = 2 blocks of 16)
+// for the positions of part wp.  WEIGHT-STATIONARY: a wave streams its own rows of the weight matrix straight from
+// L2 into registers (fragment-major packing: one contiguous 1 KB load per 16x32 fragment, two K-steps ahead of the
+// MFMAs) and reads every position block of the LDS tile; no barrier inside a convolution's K loop.  The weight
+// traffic per workgroup is C*k*C*2 bytes per conv = 1 byte per T flops: T = 128 (C = 128) keeps L2 -> CU below
+// 32 B/clk/CU at the MFMA peak; a position-split design with every wave reading all weights needs 4x that and is
+// L2-bound (measured in round 1: 2x slower than the generic kernel at C = 128).
+#include "conv_epilogue.h"
+
+#include <stdlib.h>
+
+struct ResUnitParams {
+  const bf16_t* x;       // [B][L][C] raw residual stream
+  const bf16_t* w1f;     // conv1 weights, fragment-major [C/16][k*C/32][64][8]
+  const bf16_t* w2f;
+  const float* b1;
+  int L, k, dil;
+  float slope;
+  ConvParams epi;        // conv2's epilogue: bias = b2, res = x, out, accumulate, alpha, out_act / out_slope
+};
+
+template <int C, int WC, int WP, int T>
+__global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) {
+  static_assert(WC * WP == 4, "four waves per workgroup");
+  constexpr int RS = C + 8;                  // LDS row stride (bf16): 16 B of padding spreads ds_read_b128 over banks
+  constexpr int NCB = C / 16 / WC;           // cout blocks per wave
+  constexpr int NCH = C / 32;                // 32-channel chunks per tap
+  constexpr int OB = T / 16 / WP;            // conv2 position blocks per wave
+  constexpr int MBW = OB + 1;                // conv1 position blocks per wave (T + k - 1 <= T + 16 rows in total)
+  static_assert(NCB >= 1 && T % (16 * WP) == 0, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* tile = reinterpret_cast<bf16_t*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int wc = wave % WC, wp = wave / WC;
+  const int b = blockIdx.y, l0 = blockIdx.x * T;
+  const int L = p.L, k = p.k, dil = p.dil;
+  const int H1 = dil * (k - 1) / 2, H2 = (k - 1) / 2;
+  const int MT = T + 2 * H2;                 // rows of the intermediate (conv1 outputs) this tile needs
+  const int MB = (MT + 15) / 16;             // ... in blocks of 16
+  const int rows_in = MB * 16 + 2 * H1;      // staged input rows (a multiple-of-16 body + the conv1 halo)
+  const bf16_t* xb = p.x + (size_t)b * L * C;
+
+  // ---- 1. leaky_relu(x) tile -> LDS (zero outside the sequence: F.conv1d pads the ACTIVATED signal with zeros)
+  for (int idx = tid; idx < rows_in * (C / 8); idx += 256) {
+    const int r = idx / (C / 8), cc = idx - r * (C / 8);
+    const int pos = l0 - H1 - H2 + r;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if ((unsigned)pos < (unsigned)L) {
+      v = *reinterpret_cast<const uint4*>(xb + (size_t)pos * C + cc * 8);
+      float f[8];
+      unpack8(v, f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = f[e] > 0.f ? f[e] : f[e] * p.slope;
+      v = pack8(f);
+    }
+    *reinterpret_cast<uint4*>(tile + r * RS + cc * 8) = v;
+  }
+
+  // ---- 2. conv1: rows [mb0*16, (mb0 + nmb)*16) of the intermediate, couts [cout0, cout0 + 16*NCB)
+  const int cb0 = wc * NCB;
+  const int mb_per = (MB + WP - 1) / WP;
+  const int mb0 = wp * mb_per;
+  int nmb = MB - mb0;
+  if (nmb > mb_per) nmb = mb_per;
+  if (nmb < 0) nmb = 0;
+  f32x4_t acc[NCB][MBW];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i)
+#pragma unroll
+    for (int j = 0; j < MBW; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  const int nsteps = k * NCH;
+  {
+    const uint4* wf = reinterpret_cast<const uint4*>(p.w1f) + (size_t)cb0 * nsteps * 64 + lane;
+    bf16x8_t a0[NCB], a1[NCB], a2[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      a0[cb] = __builtin_bit_cast(bf16x8_t, wf[(size_t)(cb * nsteps) * 64]);
+      a1[cb] = __builtin_bit_cast(bf16x8_t, wf[(size_t)(cb * nsteps + (nsteps > 1 ? 1 : 0)) * 64]);
+    }
+    __syncthreads();
+    const bf16_t* xw = tile + (mb0 * 16 + lq) * RS + lg * 8;
+    int st = 0;
+    for (int tap = 0; tap < k; ++tap) {
+      const bf16_t* xt = xw + tap * dil * RS;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch, ++st) {
+        const int nx = st + 2 < nsteps ? st + 2 : nsteps - 1;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) a2[cb] = __builtin_bit_cast(bf16x8_t, wf[(size_t)(cb * nsteps + nx) * 64]);
+#pragma unroll
+        for (int pb = 0; pb < MBW; ++pb) {
+          if (pb < nmb) {
+            const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xt + ch * 32 + pb * 16 * RS));
+#pragma unroll
+            for (int cb = 0; cb < NCB; ++cb)
+              acc[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[cb], bf, acc[cb][pb], 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) { a0[cb] = a1[cb]; a1[cb] = a2[cb]; }
+      }
+    }
+  }
+  __syncthreads();   // every wave is done with the input tile: the intermediate takes its place
+  {
+#pragma unroll
+    for (int pb = 0; pb < MBW; ++pb) {
+      if (pb < nmb) {
+        const int m = (mb0 + pb) * 16 + lq;          // intermediate row <-> sequence position l0 - H2 + m
+        const int pos = l0 - H2 + m;
+        const bool live = m < MT && (unsigned)pos < (unsigned)L;   // conv2 zero-pads the activated intermediate
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          const int n = (cb0 + cb) * 16 + lg * 4;
+          const float4 bb = *reinterpret_cast<const float4*>(p.b1 + n);
+          float v[4] = {acc[cb][pb][0] + bb.x, acc[cb][pb][1] + bb.y, acc[cb][pb][2] + bb.z, acc[cb][pb][3] + bb.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = live ? (v[e] > 0.f ? v[e] : v[e] * p.slope) : 0.f;
+          uint2 pk;
+          pk.x = pack2bf(v[0], v[1]);
+          pk.y = pack2bf(v[2], v[3]);
+          *reinterpret_cast<uint2*>(tile + m * RS + n) = pk;
+        }
+      }
+    }
+  }
+
+  // ---- 3. conv2 over the T output positions: rows [ob0*16, (ob0 + OB)*16), taps = consecutive intermediate rows
+  const int ob0 = wp * OB;
+  f32x4_t acc2[NCB][OB];
+#pragma unroll
+  for (int i = 0; i < NCB; ++i)
+#pragma unroll
+    for (int j = 0; j < OB; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  {
+    const uint4* wf = reinterpret_cast<const uint4*>(p.w2f) + (size_t)cb0 * nsteps * 64 + lane;
+    bf16x8_t a0[NCB], a1[NCB], a2[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      a0[cb] = __builtin_bit_cast(bf16x8_t, wf[(size_t)(cb * nsteps) * 64]);
+      a1[cb] = __builtin_bit_cast(bf16x8_t, wf[(size_t)(cb * nsteps + (nsteps > 1 ? 1 : 0)) * 64]);
+    }
+    __syncthreads();
+    const bf16_t* xw = tile + (ob0 * 16 + lq) * RS + lg * 8;
+    int st = 0;
+    for (int tap = 0; tap < k; ++tap) {
+      const bf16_t* xt = xw + tap * RS;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch, ++st) {
+        const int nx = st + 2 < nsteps ? st + 2 : nsteps - 1;
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) a2[cb] = __builtin_bit_cast(bf16x8_t, wf[(size_t)(cb * nsteps + nx) * 64]);
+#pragma unroll
+        for (int pb = 0; pb < OB; ++pb) {
+          const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xt + ch * 32 + pb * 16 * RS));
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb)
+            acc2[cb][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[cb], bf, acc2[cb][pb], 0, 0, 0);
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) { a0[cb] = a1[cb]; a1[cb] = a2[cb]; }
+      }
+    }
+  }
+
+  // ---- epilogue: two position blocks per part at a time through an fp32 LDS transpose; a row of C channels is then
+  //      finished (bias, residual, accumulate, scale, activation) and stored by C/4 consecutive lanes
+  constexpr int RSF = C * 4 + 16;            // staging row stride (bytes)
+  constexpr int CH_ROWS = 32;                // rows per part and pass
+  constexpr int LPR = C / 4;                 // lanes per output row
+  constexpr int RPP = 256 / LPR;             // rows finished per sweep of the workgroup
+  const int col4 = tid % LPR, prow = tid / LPR;
+  const float4 bias4 = p.epi.bias ? *reinterpret_cast<const float4*>(p.epi.bias + col4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int pass = 0; pass < OB / 2; ++pass) {
+    __syncthreads();   // the intermediate (first pass) / the previous pass's staging rows are dead
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int pb = pass * 2 + h;
+      unsigned char* row = smem_raw + (size_t)(wp * CH_ROWS + h * 16 + lq) * RSF;
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        const f32x4_t a = acc2[cb][pb];
+        *reinterpret_cast<float4*>(row + ((cb0 + cb) * 16 + lg * 4) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    }
+    __syncthreads();
+    for (int r = prow; r < WP * CH_ROWS; r += RPP) {
+      const int part = r / CH_ROWS, rr = r - part * CH_ROWS;
+      const int l = l0 + (part * OB + pass * 2) * 16 + rr;
+      if (l < L)
+        epilogue_wide4(p.epi, *reinterpret_cast<const float4*>(smem_raw + (size_t)r * RSF + col4 * 16), bias4, b * L + l,
+                       col4 * 4, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// packed [n][k_pad] (K contiguous, conv_gemm's layout) -> fragment-major [n/16][nsteps][64 lanes][8]: lane (lq, lg) of
+// fragment (cb, st) holds W[cb*16 + lq][st*32 + lg*8 .. +7], so an A operand is one contiguous 1 KB wave load
+__global__ void frag_pack_kernel(const bf16_t* __restrict__ src, int k_pad, int n_cb, int nsteps, bf16_t* __restrict__ dst) {
+  const long long total = (long long)n_cb * nsteps * 64;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int lane = (int)(i & 63);
+    const long long f = i >> 6;
+    const int st = (int)(f % nsteps), cb = (int)(f / nsteps);
+    const uint4 v = *reinterpret_cast<const uint4*>(src + (size_t)(cb * 16 + (lane & 15)) * k_pad + st * 32 + (lane >> 4) * 8);
+    reinterpret_cast<uint4*>(dst)[i] = v;
+  }
+}
+
+extern "C" ctta_status ctta_frag_pack(const void* packed, int n, int k_pad, int k_valid, void* dst, void* stream) {
+  CTTA_REQUIRE(packed && dst, "frag_pack: null pointer");
+  CTTA_REQUIRE(n > 0 && n % 16 == 0 && k_valid > 0 && k_valid % 32 == 0 && k_valid <= k_pad && k_pad % 8 == 0,
+               "frag_pack: n=%d must be a multiple of 16 and k_valid=%d a multiple of 32 within k_pad=%d", n, k_valid, k_pad);
+  const int n_cb = n / 16, nsteps = k_valid / 32;
+  const long long total = (long long)n_cb * nsteps * 64;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(frag_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)packed, k_pad, n_cb,
+                     nsteps, (bf16_t*)dst);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+template <int C, int WC, int WP, int T>
+static ctta_status launch_resunit(const ResUnitParams& p, int batch, hipStream_t s) {
+  const int H1 = p.dil * (p.k - 1) / 2, H2 = (p.k - 1) / 2;
+  const int MB = (T + 2 * H2 + 15) / 16;
+  size_t smem = (size_t)(MB * 16 + 2 * H1) * (C + 8) * 2;
+  const size_t stage = (size_t)WP * 32 * (C * 4 + 16);
+  if (stage > smem) smem = stage;
+  static size_t configured = 0;
+  if (smem > configured) {
+    CTTA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&resunit_kernel<C, WC, WP, T>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    configured = smem;
+  }
+  dim3 grid((unsigned)((p.L + T - 1) / T), (unsigned)batch);
+  resunit_kernel<C, WC, WP, T><<<grid, dim3(256), smem, s>>>(p);
+  return CTTA_OK;
+}
+
+extern "C" int ctta_resunit_supported(int channels, int k, int dil) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("CTTA_FUSED_RES"); env = (e && e[0] == '0') ? 0 : 1; }
+  if (!env) return 0;
+  if (channels != 32 && channels != 64 && channels != 128) return 0;
+  if (k < 1 || k > 11 || (k & 1) == 0 || dil < 1) return 0;
+  const int T = channels == 128 ? 128 : channels == 64 ? 256 : 512;
+  const int H1 = dil * (k - 1) / 2, H2 = (k - 1) / 2;
+  const size_t smem = (size_t)((T + 2 * H2 + 15) / 16 * 16 + 2 * H1) * (channels + 8) * 2;
+  return smem <= (size_t)64 * 1024 ? 1 : 0;
+}
+
+extern "C" ctta_status ctta_resunit_conv1d(const void* x, int batch, int len, int channels, int k, int dil,
+                                           const void* w1_frag, const float* b1, const void* w2_frag, const float* b2,
+                                           float slope, void* out, int accumulate, float alpha, float out_slope,
+                                           void* stream) {
+  CTTA_REQUIRE(x && w1_frag && w2_frag && b1 && b2 && out, "resunit_conv1d: null pointer");
+  CTTA_REQUIRE(batch >= 1 && len >= 1 && (long long)batch * len < (1LL << 31), "resunit_conv1d: bad extent");
+  CTTA_REQUIRE(ctta_resunit_supported(channels, k, dil),
+               "resunit_conv1d: channels=%d k=%d dilation=%d is outside the fused kernel's range (C in {32,64,128}, odd k <= 11, "
+               "tile <= 64 KB of LDS)", channels, k, dil);
+  ResUnitParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const bf16_t*)x; p.w1f = (const bf16_t*)w1_frag; p.w2f = (const bf16_t*)w2_frag; p.b1 = b1;
+  p.L = len; p.k = k; p.dil = dil; p.slope = slope;
+  ConvParams& e = p.epi;
+  e.bias = b2; e.res = (const bf16_t*)x; e.res_ld = channels;
+  e.out = out; e.ldc = channels; e.plain_out = 1; e.wide_store = 1;
+  e.accumulate = accumulate ? 1 : 0; e.alpha = alpha;
+  if (out_slope > 0.f) { e.out_act = 3; e.out_slope = out_slope; }
+  e.howo = len; e.n = channels; e.M = batch * len;
+  hipStream_t s = (hipStream_t)stream;
+  const bool prof = ctta_prof_active();
+  if (prof) ctta_prof_begin(0, 40, (long long)batch * len, channels, 2LL * k * channels, 1, s);
+  ctta_status st;
+  if (channels == 128) st = launch_resunit<128, 4, 1, 128>(p, batch, s);
+  else if (channels == 64) st = launch_resunit<64, 2, 2, 256>(p, batch, s);
+  else st = launch_resunit<32, 1, 4, 512>(p, batch, s);
+  if (prof) ctta_prof_end(s);
+  CTTA_TRY(st);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}

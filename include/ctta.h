@@ -329,6 +329,18 @@ size_t ctta_conv_workspace_bytes(void);
 int ctta_conv_gemm_num_variants(void);
 const char* ctta_conv_gemm_variant_name(int id);
 
+/* Fused HiFi-GAN ResBlock unit (hifigan/models.py:56-63) for C = 32 / 64 / 128 channels, odd k <= 11:
+ *   out = act( alpha * ( [old out +] x + conv2(leaky_relu(conv1(leaky_relu(x, slope)) + b1, slope)) + b2 ) )
+ * conv1: k taps, dilation `dil`; conv2: k taps, dilation 1; "same" zero padding; x / out bf16 [batch][len][channels].
+ * The intermediate never leaves LDS.  Weights are FRAGMENT-MAJOR copies ([n/16][k*channels/32][64][8] bf16) of the
+ * packed [n][k_pad] operands, made by ctta_frag_pack (k_valid = k * channels).  out_slope > 0 applies a final
+ * leaky_relu.  ctta_resunit_supported reports whether a (channels, k, dil) combination fits the kernel. */
+int ctta_resunit_supported(int channels, int k, int dil);
+ctta_status ctta_frag_pack(const void* packed, int n, int k_pad, int k_valid, void* dst, void* stream);
+ctta_status ctta_resunit_conv1d(const void* x, int batch, int len, int channels, int k, int dil,
+                                const void* w1_frag, const float* b1, const void* w2_frag, const float* b2,
+                                float slope, void* out, int accumulate, float alpha, float out_slope, void* stream);
+
 /* Direct convolution for tiny Cout (<= 8): bf16 NHWC in, fp32 weights [n][kh][kw][c],
  * fp32 planar (NCHW) out, optional input leaky-relu and output tanh. */
 ctta_status ctta_conv_small_n(const void* x, int c, int batch, int hi, int wi, int kh, int kw,

@@ -66,11 +66,11 @@ def test_two_rank_train_step_equals_one_process_on_the_global_batch(tmp_path):
     g = grad.cpu()
     rel = float((r0["grad"] - g).norm() / g.norm())
     print("2 ranks x B=2 vs 1 process x B=4: averaged gradient rel_l2 %.3e" % rel)
-    assert rel <= 2e-2           # different batch shapes -> different tile / split-K paths: bf16 round-off only
+    assert rel <= 1e-5           # a sample's result does not depend on its batch mates: only the summation order differs
     d_ref, d_two = after.cpu() - before.cpu(), r0["after"] - r0["before"]
     upd = float((d_ref - d_two).norm() / d_ref.norm())
     print("parameter update rel diff %.3e" % upd)
-    assert upd <= 0.15           # AdamW's first step is sign-like: near-zero gradient entries flip
+    assert upd <= 1e-3
 
 
 def test_nan_on_one_rank_skips_the_update_on_every_rank(tmp_path):

@@ -186,6 +186,60 @@ def test_conv1d_halo_kernel(C, k, d, L):
     assert rel_err(outs[0], outs[1]) < BF16_TOL      # halo kernel vs generic kernel
 
 
+@pytest.mark.parametrize("C,k,d,L,B", [(128, 11, 5, 700, 2), (128, 3, 1, 129, 1), (128, 7, 3, 128, 2), (64, 11, 5, 1000, 2),
+                                       (64, 3, 3, 255, 1), (64, 7, 1, 513, 2), (32, 11, 5, 1500, 2), (32, 3, 1, 40, 3),
+                                       (32, 7, 5, 1025, 1), (128, 11, 1, 50, 1)])
+def test_fused_resblock_unit(C, k, d, L, B):
+    """hifigan/models.py:56-63 as ONE launch (resunit.hip): x + conv2(lrelu(conv1(lrelu(x)))) with the intermediate in
+    LDS, vs F.conv1d on the same bf16-rounded operands (intermediate rounded to bf16 like the two-launch path), for
+    every channel width the kernel serves, sequence ends inside / on / beyond tile borders, and the stage-fold epilogue
+    (accumulate, scale, final leaky_relu).  Also checked against the two generic conv_gemm launches it replaces."""
+    L_ = lib()
+    assert L_.ctta_resunit_supported(C, k, d) == 1
+    x = bf16_round(det("ru.x", (B, C, L), 1))
+    w1 = bf16_round(det("ru.w1", (C, C, k), 2) * (1.0 / math.sqrt(C * k)))
+    w2 = bf16_round(det("ru.w2", (C, C, k), 3) * (1.0 / math.sqrt(C * k)))
+    b1, b2 = det("ru.b1", (C,), 4) * 0.1, det("ru.b2", (C,), 5) * 0.1
+    old = bf16_round(det("ru.o", (B, C, L), 6))
+    mid = bf16_round(F.leaky_relu(F.conv1d(F.leaky_relu(x, 0.1), w1, b1, dilation=d, padding=(k * d - d) // 2), 0.1))
+    unit = x + F.conv1d(mid, w2, b2, padding=(k - 1) // 2)
+    xa = x.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    frags = []
+    for w in (w1, w2):
+        wp, k_pad = pack_conv_weight(w[:, :, None, :])
+        f = torch.empty(C * k * C, dtype=torch.bfloat16, device=DEV)
+        N.check(L_.ctta_frag_pack(N.ptr(wp), C, k_pad, k * C, N.ptr(f), N.stream_ptr()))
+        frags.append((f, wp, k_pad))
+    b1d, b2d = b1.to(DEV), b2.to(DEV)
+    # plain unit
+    out = torch.empty_like(xa)
+    N.check(L_.ctta_resunit_conv1d(N.ptr(xa), B, L, C, k, d, N.ptr(frags[0][0]), N.ptr(b1d), N.ptr(frags[1][0]), N.ptr(b2d),
+                                   0.1, N.ptr(out), 0, 1.0, 0.0, N.stream_ptr()))
+    sync()
+    got = out.float().permute(0, 2, 1).cpu()
+    assert rel_err(got, unit) < 2 * BF16_TOL
+    # the two generic launches it replaces (activated input, activated bf16 intermediate, residual epilogue)
+    xact = bf16_round(F.leaky_relu(x, 0.1)).permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    t1, t2 = torch.empty_like(xa), torch.empty_like(xa)
+    run_conv(conv_desc(x0=xact, c0=C, batch=B, hi=1, wi=L, ho=1, wo=L, kh=1, kw=k, pad_w=(k * d - d) // 2, dil_w=d,
+                       w=frags[0][1], k_pad=frags[0][2], n=C, bias=b1d, out_act=3, out_slope=0.1, out=t1, ldc=C, tile=13))
+    run_conv(conv_desc(x0=t1, c0=C, batch=B, hi=1, wi=L, ho=1, wo=L, kh=1, kw=k, pad_w=(k - 1) // 2, w=frags[1][1],
+                       k_pad=frags[1][2], n=C, bias=b2d, res=xa, res_ld=C, out=t2, ldc=C, tile=13))
+    assert rel_err(got, t2.float().permute(0, 2, 1).cpu()) < BF16_TOL
+    # stage fold: (old + unit) / 3 then leaky_relu(0.01), accumulated in place
+    out = old.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    N.check(L_.ctta_resunit_conv1d(N.ptr(xa), B, L, C, k, d, N.ptr(frags[0][0]), N.ptr(b1d), N.ptr(frags[1][0]), N.ptr(b2d),
+                                   0.1, N.ptr(out), 1, 1.0 / 3.0, 0.01, N.stream_ptr()))
+    sync()
+    ref = F.leaky_relu((old + unit) / 3.0, 0.01)
+    assert rel_err(out.float().permute(0, 2, 1).cpu(), ref) < 2 * BF16_TOL
+    # unsupported shapes are refused loudly
+    assert L_.ctta_resunit_supported(256, 3, 1) == 0 and L_.ctta_resunit_supported(64, 4, 1) == 0
+    with pytest.raises(RuntimeError):
+        N.check(L_.ctta_resunit_conv1d(N.ptr(xa), B, L, 256, k, d, N.ptr(frags[0][0]), N.ptr(b1d), N.ptr(frags[1][0]),
+                                       N.ptr(b2d), 0.1, N.ptr(out), 0, 1.0, 0.0, N.stream_ptr()))
+
+
 def test_conv_fused_output_activations_and_scalar_store():
     """out_act=leaky_relu, the second (activated) output, and element-wise stores for Cout=1."""
     B, C, L, k = 2, 64, 150, 3
