@@ -230,7 +230,8 @@ static ctta_status run_vae_attn(VCtx& c, VaeAttn* V, const bf16_t* x, int H, int
   // launches (QK^T -> softmax -> PV): the (N x N) fp32 score matrix of one sample is 64 MB at N = 4096, the whole batch
   // at B = 32 would be 2 GiB of arena and 6 GB of HBM traffic per decode (modules.py:204-230 materialises it too)
   static int chunk_mb = -1;
-  if (chunk_mb < 0) { const char* e = getenv("CTTA_VAE_ATTN_MB"); chunk_mb = e ? atoi(e) : 100; }
+  if (chunk_mb < 0) { const char* e = getenv("CTTA_VAE_ATTN_MB"); chunk_mb = e ? atoi(e) : 0; }
+  if (chunk_mb <= 0) chunk_mb = 1 << 20;   // default: the whole batch in one go (measured fastest; the chunks exist for memory-tight boxes)
   int gb = (int)(((size_t)chunk_mb << 20) / ((size_t)N * N * 6));
   if (gb < 1) gb = 1;
   if (gb > B) gb = B;
