@@ -161,6 +161,26 @@ SIGNATURES = {
     "ctta_conv_workspace_bytes": (c_size_t, []),
     "ctta_conv_gemm_num_variants": (c_int, []),
     "ctta_conv_gemm_variant_name": (c_char_p, [c_int]),
+    "ctta_attention_fullbias": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                        c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "ctta_attention_fullbias_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
+                                            c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int,
+                                            c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int,
+                                            c_int, c_int, c_int, c_float, c_void_p]),
+    "ctta_resample_poly": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "ctta_resample_poly_bwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                       c_void_p]),
+    "ctta_wav_to_logmel_db": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "ctta_wav_to_logmel_db_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "ctta_htsat_image": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                 c_void_p, c_void_p]),
+    "ctta_htsat_image_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_int, c_void_p, c_void_p]),
+    "ctta_gather_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p]),
+    "ctta_gelu": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "ctta_gelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "ctta_mean_tokens": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_mean_tokens_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_resunit_supported": (c_int, [c_int, c_int, c_int]),
     "ctta_frag_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_resunit_conv1d": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

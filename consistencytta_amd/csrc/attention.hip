@@ -28,12 +28,15 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 // REL: additionally adds rel_bias[h][key - query + nq - 1] (already in the log2 domain) -- T5's relative position bias
 // (one table per head over the nq + nk - 1 possible offsets); q / out batches are then q_rows rows apart.
-template <bool REL>
+// BMODE 2 (FULL): adds full_bias[(b % full_nb)][h][query][key] (log2 domain) -- Swin window attention: relative-position
+// bias per head plus the shifted-window mask, one table per window position (htsat.py:336-361).
+template <int BMODE>
 __global__ __launch_bounds__(256, 2) void attention_kernel(
     const bf16_t* __restrict__ q, int q_ld, const bf16_t* __restrict__ k, int k_ld, int k_rows,
     const bf16_t* __restrict__ vt, int vt_ld, const float* __restrict__ bias,
     bf16_t* __restrict__ out, int out_ld, int heads, int nq, int nk, float scale_log2e, float* __restrict__ lse,
-    int q_rows, const float* __restrict__ rel_bias) {
+    int q_rows, const float* __restrict__ rel_bias, int full_nb) {
+  constexpr bool REL = BMODE == 1, FULL = BMODE == 2;
   __shared__ __attribute__((aligned(16))) bf16_t Ks[ATT_KT * ATT_LDK];   // [key][d]
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * ATT_LDV];       // [d][key]
 
@@ -49,6 +52,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   const bf16_t* vb = vt + ((size_t)b * heads + h) * 64 * vt_ld;
   const float* bb = bias ? bias + (size_t)b * nk : nullptr;
   const float* rb = REL ? rel_bias + (size_t)h * (nq + nk - 1) + (nq - 1) : nullptr;
+  const float* fb = FULL ? rel_bias + ((size_t)(b % full_nb) * heads + h) * nq * nk : nullptr;
 
   // Q^T fragments: B operand, lane j = query, 8 consecutive d at (ds*32 + lg*8)
   bf16x8_t qf[2][2];
@@ -152,6 +156,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] += rb[min(key0 + ik * 16 + lg * 4 + r, nk - 1) - qrel];
         }
+        if (FULL) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += fb[(size_t)qrel * nk + min(key0 + ik * 16 + lg * 4 + r, nk - 1)];
+        }
         s[ik][jq] = v;
         mx = fmaxf(mx, fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
       }
@@ -244,9 +252,9 @@ extern "C" ctta_status ctta_attention_lse(const void* q, int q_ld, const void* k
   const bool prof = ctta_prof_active();
   // executed flops: QK^T and PV over the padded head dim (2 * 2*nq*nk*64 per head)
   if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
-  hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
+  hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
                      (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, bias, (bf16_t*)out, out_ld, heads,
-                     nq, nk, scale * 1.4426950408889634f, lse, nq, (const float*)nullptr);
+                     nq, nk, scale * 1.4426950408889634f, lse, nq, (const float*)nullptr, 1);
   if (prof) ctta_prof_end((hipStream_t)stream);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
@@ -264,9 +272,29 @@ extern "C" ctta_status ctta_attention_rel(const void* q, int q_ld, int q_rows, c
   dim3 grid((nq + 127) / 128, batch * heads);
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
-  hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
+  hipLaunchKernelGGL(attention_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
                      (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, key_bias, (bf16_t*)out, out_ld, heads,
-                     nq, nk, scale * 1.4426950408889634f, (float*)nullptr, q_rows, rel_bias_log2);
+                     nq, nk, scale * 1.4426950408889634f, (float*)nullptr, q_rows, rel_bias_log2, 1);
+  if (prof) ctta_prof_end((hipStream_t)stream);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_attention_fullbias(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
+                                               int vt_ld, const float* full_bias_log2, int n_bias_batches, void* out,
+                                               int out_ld, int batch, int heads, int nq, int nk, float scale, float* lse,
+                                               void* stream) {
+  CTTA_REQUIRE(q && k && vt && out && full_bias_log2 && n_bias_batches >= 1, "attention_fullbias: null pointer");
+  CTTA_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vt_ld % 8 == 0 && out_ld % 4 == 0,
+               "attention_fullbias: row strides must be multiples of 8");
+  CTTA_REQUIRE(nq > 0 && nk > 0 && k_rows >= nk && vt_ld >= ((nk + 7) / 8) * 8,
+               "attention_fullbias: bad lengths nq=%d nk=%d vt_ld=%d", nq, nk, vt_ld);
+  dim3 grid((nq + 127) / 128, batch * heads);
+  const bool prof = ctta_prof_active();
+  if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
+  hipLaunchKernelGGL(attention_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
+                     (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, (const float*)nullptr, (bf16_t*)out, out_ld,
+                     heads, nq, nk, scale * 1.4426950408889634f, lse, nq, full_bias_log2, n_bias_batches);
   if (prof) ctta_prof_end((hipStream_t)stream);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
@@ -297,6 +325,8 @@ struct AttnBwdParams {
   // writes fp32 partial sums part[z][dk|dv][B][k_rows][hp], folded by attn_bwd_fold_kernel
   float* part;
   int q_tiles_per_split, batch, hp;
+  const float* full_bias;   // FULL kernels: [full_nb][heads][nq][nk], log2 domain (window attention)
+  int full_nb;
 };
 
 // stages a [64 rows][64 cols] bf16 tile (row stride ld in LDS); rows >= rows_valid are zero
@@ -331,6 +361,7 @@ __device__ __forceinline__ void put_rows(bf16_t* lds, int ld, const uint4 (&reg)
   }
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * ATT_LDK];    // [key][d]
   __shared__ __attribute__((aligned(16))) bf16_t Vn[64 * ATT_LDK];    // [key][d]
@@ -346,13 +377,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   const bf16_t* vb = p.vn + (size_t)b * p.vn_rows * p.vn_ld + h * 64;
   const bf16_t* ktb = p.kt + ((size_t)b * p.heads + h) * 64 * p.kt_ld;
   const float* bb = p.bias ? p.bias + (size_t)b * p.nk : nullptr;
+  const float* fb = FULL ? p.full_bias + ((size_t)(b % p.full_nb) * p.heads + h) * p.nq * p.nk : nullptr;
 
   bf16x8_t qf[2][2], dof[2][2];
   float lse_q[2], d_q[2];
+  int q_row[2];
 #pragma unroll
   for (int jq = 0; jq < 2; ++jq) {
     int qi = q0 + jq * 16 + lq;
     if (qi >= p.nq) qi = p.nq - 1;   // clamp (never stored)
+    q_row[jq] = qi;
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) {
       qf[jq][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qb + (size_t)qi * p.q_ld + ds * 32 + lg * 8));
@@ -410,7 +444,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
         else if (bb) add = bb[key] * 1.4426950408889634f;
 #pragma unroll
         for (int jq = 0; jq < 2; ++jq) {
-          const float pv = fast_exp2(s[ik][jq][r] * p.scale_log2e + add - lse_q[jq]);
+          float addq = add;
+          if (FULL) addq += fb[(size_t)q_row[jq] * p.nk + min(key, p.nk - 1)];
+          const float pv = fast_exp2(s[ik][jq][r] * p.scale_log2e + addq - lse_q[jq]);
           s[ik][jq][r] = pv * (dp[ik][jq][r] - d_q[jq]) * p.scale;
         }
       }
@@ -454,6 +490,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   }
 }
 
+template <bool FULL>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * ATT_LDK];     // [query][d]
   __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * ATT_LDK];    // [query][d]
@@ -474,6 +511,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   const bf16_t* dotb = p.dot + ((size_t)b * p.heads + h) * 64 * p.qt_ld;
   const float* lseb = p.lse + ((size_t)b * p.heads + h) * p.nq;
   const float* dsb = p.dsum + ((size_t)b * p.heads + h) * p.nq;
+  const float* fb = FULL ? p.full_bias + ((size_t)(b % p.full_nb) * p.heads + h) * p.nq * p.nk : nullptr;
 
   bf16x8_t kf[2][2], vf[2][2];   // B operands: lane = key column, 8 consecutive d
   float kb2[2];
@@ -550,7 +588,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
       for (int r = 0; r < 4; ++r)
 #pragma unroll
         for (int jk = 0; jk < 2; ++jk) {
-          const float pv = fast_exp2(s[iq][jk][r] * p.scale_log2e + kb2[jk] - lv[r]);
+          float addk = kb2[jk];
+          if (FULL) addk += fb[(size_t)min(q0 + iq * 16 + lg * 4 + r, p.nq - 1) * p.nk + min(k0 + jk * 16 + lq, p.nk - 1)];
+          const float pv = fast_exp2(s[iq][jk][r] * p.scale_log2e + addk - lv[r]);
           s[iq][jk][r] = pv;
           dp[iq][jk][r] = pv * (dp[iq][jk][r] - dd[r]) * p.scale;
         }
@@ -666,12 +706,13 @@ __global__ __launch_bounds__(256) void attn_rowdot_kernel(const bf16_t* __restri
   }
 }
 
-extern "C" ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vn,
-                                          int vn_ld, int vn_rows, const void* kt, int kt_ld, const void* qt,
-                                          const void* dot, int qt_ld, const float* bias, const void* out, int out_ld,
-                                          const void* dout, int do_ld, const float* lse, float* dsum, void* dq, int dq_ld,
-                                          void* dk, int dk_ld, void* dv, int dv_ld, int batch, int heads, int nq, int nk,
-                                          float scale, float* partial, int64_t partial_floats, void* stream) {
+static ctta_status attention_bwd_impl(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vn,
+                                      int vn_ld, int vn_rows, const void* kt, int kt_ld, const void* qt,
+                                      const void* dot, int qt_ld, const float* bias, const void* out, int out_ld,
+                                      const void* dout, int do_ld, const float* lse, float* dsum, void* dq, int dq_ld,
+                                      void* dk, int dk_ld, void* dv, int dv_ld, int batch, int heads, int nq, int nk,
+                                      float scale, float* partial, int64_t partial_floats, void* stream,
+                                      const float* full_bias, int full_nb) {
   CTTA_REQUIRE(q && k && vn && kt && qt && dot && out && dout && lse && dsum && dq && dk && dv, "attention_bwd: null pointer");
   CTTA_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vn_ld % 8 == 0 && kt_ld % 64 == 0 && qt_ld % 64 == 0 && do_ld % 8 == 0 &&
                    out_ld % 8 == 0 && dq_ld % 4 == 0 && dk_ld % 4 == 0 && dv_ld % 4 == 0,
@@ -688,10 +729,12 @@ extern "C" ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k
   p.do_ld = do_ld; p.bias = bias; p.lse = lse; p.dsum = dsum;
   p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.dq_ld = dq_ld; p.dk_ld = dk_ld; p.dv_ld = dv_ld;
   p.heads = heads; p.nq = nq; p.nk = nk; p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
+  p.full_bias = full_bias; p.full_nb = full_nb > 0 ? full_nb : 1;
   const bool prof = ctta_prof_active();
   // executed flops: 7 products of 2*nq*nk*64 per head (S and dP are computed by both kernels)
   if (prof) ctta_prof_begin(1, 1, nq, nk, 448, (long long)batch * heads, s);
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
+  if (full_bias) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
   // few keys (cross-attention): split the query walk so that the launch still fills the chip
   const int ntiles = (nq + 63) / 64, kblocks = (nk + 127) / 128, hp = heads * 64;
   int nz = 1;
@@ -702,7 +745,8 @@ extern "C" ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k
   p.q_tiles_per_split = (ntiles + nz - 1) / nz;
   p.part = nz > 1 ? partial : nullptr;
   p.batch = batch; p.hp = hp;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
+  if (full_bias) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
   if (nz > 1) {
     CTTA_REQUIRE(dk_ld >= hp && dv_ld >= hp, "attention_bwd: split path needs dk/dv rows of at least heads*64");
     const long long total = (long long)batch * nk * hp;
@@ -712,4 +756,28 @@ extern "C" ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k
   if (prof) ctta_prof_end(s);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vn,
+                                          int vn_ld, int vn_rows, const void* kt, int kt_ld, const void* qt,
+                                          const void* dot, int qt_ld, const float* bias, const void* out, int out_ld,
+                                          const void* dout, int do_ld, const float* lse, float* dsum, void* dq, int dq_ld,
+                                          void* dk, int dk_ld, void* dv, int dv_ld, int batch, int heads, int nq, int nk,
+                                          float scale, float* partial, int64_t partial_floats, void* stream) {
+  return attention_bwd_impl(q, q_ld, k, k_ld, k_rows, vn, vn_ld, vn_rows, kt, kt_ld, qt, dot, qt_ld, bias, out, out_ld, dout,
+                            do_ld, lse, dsum, dq, dq_ld, dk, dk_ld, dv, dv_ld, batch, heads, nq, nk, scale, partial,
+                            partial_floats, stream, nullptr, 1);
+}
+// Backward of ctta_attention_fullbias (same operands as ctta_attention_bwd; no per-key bias, no split path)
+extern "C" ctta_status ctta_attention_fullbias_bwd(const void* q, int q_ld, const void* k, int k_ld, int k_rows,
+                                                   const void* vn, int vn_ld, int vn_rows, const void* kt, int kt_ld,
+                                                   const void* qt, const void* dot, int qt_ld,
+                                                   const float* full_bias_log2, int n_bias_batches, const void* out,
+                                                   int out_ld, const void* dout, int do_ld, const float* lse, float* dsum,
+                                                   void* dq, int dq_ld, void* dk, int dk_ld, void* dv, int dv_ld, int batch,
+                                                   int heads, int nq, int nk, float scale, void* stream) {
+  CTTA_REQUIRE(full_bias_log2 && n_bias_batches >= 1, "attention_fullbias_bwd: null bias table");
+  return attention_bwd_impl(q, q_ld, k, k_ld, k_rows, vn, vn_ld, vn_rows, kt, kt_ld, qt, dot, qt_ld, nullptr, out, out_ld,
+                            dout, do_ld, lse, dsum, dq, dq_ld, dk, dk_ld, dv, dv_ld, batch, heads, nq, nk, scale, nullptr, 0,
+                            stream, full_bias_log2, n_bias_batches);
 }

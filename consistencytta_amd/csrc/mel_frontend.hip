@@ -21,11 +21,17 @@ struct ctta_mel_frontend {
   float* ft = nullptr;                       // [B * frames][n_rows]
   size_t lp_max = 0, frames_max = 0;
   SplitWs splitws;
+  // power / dB mode with input gradient (CLAP audio tower): d(re, im) in bf16, the basis as a [n_fft][kpad] operand
+  // (re / im rows contiguous along K), and the per-frame sample gradients; allocated on first use
+  bf16_t* dft = nullptr;
+  bf16_t* basis_t = nullptr;
+  float* dframes = nullptr;
+  int kpad = 0;
 };
 
 // clip to [-1, 1], nan_to_num, reflect-pad n_fft/2 on both sides, split into bf16 hi + lo
 __global__ void mel_prepare_kernel(const float* __restrict__ wav, int T, int lp, int half, bf16_t* __restrict__ p0,
-                                   bf16_t* __restrict__ p1, bf16_t* __restrict__ p2) {
+                                   bf16_t* __restrict__ p1, bf16_t* __restrict__ p2, int clip) {
   const int b = blockIdx.y;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < lp; i += gridDim.x * blockDim.x) {
     float v = 0.f;
@@ -34,8 +40,10 @@ __global__ void mel_prepare_kernel(const float* __restrict__ wav, int T, int lp,
       if (j < 0) j = -j;
       if (j >= T) j = 2 * (T - 1) - j;
       v = wav[(size_t)b * T + j];
-      if (v != v) v = 0.f;                                       // nan_to_num after clip: NaN -> 0
-      v = fminf(fmaxf(v, -1.0f), 1.0f);                          // also maps +-inf to +-1 (clip happens first)
+      if (clip) {
+        if (v != v) v = 0.f;                                     // nan_to_num after clip: NaN -> 0
+        v = fminf(fmaxf(v, -1.0f), 1.0f);                        // also maps +-inf to +-1 (clip happens first)
+      }
     }
     const bf16_t h0 = f2bf(v);
     const float r1 = v - bf2f(h0);
@@ -94,6 +102,8 @@ extern "C" void ctta_mel_frontend_destroy(ctta_mel_frontend* M) {
   if (!M) return;
   for (void* p : {(void*)M->b[0], (void*)M->b[1], (void*)M->b[2], (void*)M->mel_w, (void*)M->x[0], (void*)M->x[1],
                   (void*)M->x[2], (void*)M->ft})
+    if (p) (void)hipFree(p);
+  for (void* p : {(void*)M->dft, (void*)M->basis_t, (void*)M->dframes})
     if (p) (void)hipFree(p);
   M->splitws.destroy();
   delete M;
@@ -188,7 +198,7 @@ extern "C" ctta_status ctta_wav_to_fbank(ctta_mel_frontend* M, const float* wav,
   const int frames_all = n_samples / M->hop + 1;                  // (T + 2*half - N) / hop + 1
   const int frames = frames_all < target_length ? frames_all : target_length;   // later frames are cut by _pad_spec
   hipLaunchKernelGGL(mel_prepare_kernel, dim3((lp + 255) / 256 > 1024 ? 1024 : (lp + 255) / 256, batch), dim3(256), 0, s, wav,
-                     n_samples, lp, half, M->x[0], M->x[1], M->x[2]);
+                     n_samples, lp, half, M->x[0], M->x[1], M->x[2], 1);
   CTTA_LAUNCH_CHECK();
   // x_i * b_j for i + j <= 2, smallest terms first so that they are not absorbed by the large one
   const int xi[6] = {2, 1, 0, 1, 0, 0}, bj[6] = {0, 1, 2, 0, 1, 0};
@@ -204,6 +214,163 @@ extern "C" ctta_status ctta_wav_to_fbank(ctta_mel_frontend* M, const float* wav,
   }
   hipLaunchKernelGGL(mel_kernel, dim3(target_length, batch), dim3(256), (size_t)M->cutoff * sizeof(float), s, M->ft, frames,
                      M->n_rows, M->cutoff, M->mel_w, M->n_mels, target_length, fbank, logmag);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Power / dB variant for the CLAP audio tower (torchlibrosa Spectrogram(power=2) + LogmelFilterBank as configured at
+// laion_clap/clap_module/htsat.py:684-697): out[b][f][m] = 10 log10(max(sum_k W[m][k] (re^2 + im^2), amin)), no
+// clipping of the waveform, every frame of the centred STFT (n_samples / hop + 1).  The STFT itself is the same
+// split-bf16 GEMM as above; `ft` stays in the handle for the backward call.
+__global__ __launch_bounds__(256) void mel_power_db_kernel(const float* __restrict__ ft, int frames, int n_rows, int cutoff,
+                                                           const float* __restrict__ mel_w, int n_mels, float amin,
+                                                           float* __restrict__ out) {
+  extern __shared__ float pw[];
+  const int f = blockIdx.x, b = blockIdx.y;
+  const float* row = ft + ((size_t)b * frames + f) * n_rows;
+  for (int k = threadIdx.x; k < cutoff; k += 256) {
+    const float re = row[k], im = row[cutoff + k];
+    pw[k] = re * re + im * im;
+  }
+  __syncthreads();
+  const int j = threadIdx.x >> 2, part = threadIdx.x & 3;
+  if (j < n_mels) {
+    const float* w = mel_w + (size_t)j * cutoff;
+    float acc = 0.f;
+    for (int k = part; k < cutoff; k += 4) acc += w[k] * pw[k];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0) out[((size_t)b * frames + f) * n_mels + j] = 10.0f * log10f(fmaxf(acc, amin));
+  }
+}
+// one block per frame: g_mel[m] = dout[m] * (10 / ln 10) / mel[m] (0 where mel <= amin), dP[k] = sum_m W[m][k] g_mel[m],
+// d re = 2 re dP, d im = 2 im dP  ->  bf16 [B*frames][kpad] (re block, then im block, zero padded)
+__global__ __launch_bounds__(256) void mel_power_db_bwd_kernel(const float* __restrict__ ft, int frames, int n_rows, int cutoff,
+                                                               const float* __restrict__ mel_w, int n_mels, float amin,
+                                                               const float* __restrict__ dout, bf16_t* __restrict__ dft,
+                                                               int kpad) {
+  extern __shared__ float sm[];
+  float* pw = sm;               // [cutoff]
+  float* gm = sm + cutoff;      // [n_mels]
+  const int f = blockIdx.x, b = blockIdx.y;
+  const float* row = ft + ((size_t)b * frames + f) * n_rows;
+  for (int k = threadIdx.x; k < cutoff; k += 256) {
+    const float re = row[k], im = row[cutoff + k];
+    pw[k] = re * re + im * im;
+  }
+  __syncthreads();
+  const int j = threadIdx.x >> 2, part = threadIdx.x & 3;
+  if (j < n_mels) {
+    const float* w = mel_w + (size_t)j * cutoff;
+    float acc = 0.f;
+    for (int k = part; k < cutoff; k += 4) acc += w[k] * pw[k];
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    if (part == 0)
+      gm[j] = acc > amin ? dout[((size_t)b * frames + f) * n_mels + j] * 4.3429448190325175f / acc : 0.f;
+  }
+  __syncthreads();
+  bf16_t* o = dft + ((size_t)b * frames + f) * kpad;
+  for (int k = threadIdx.x; k < kpad; k += 256) {
+    float v = 0.f;
+    if (k < 2 * cutoff) {
+      const int kk = k < cutoff ? k : k - cutoff;
+      float dp = 0.f;
+      for (int m = 0; m < n_mels; ++m) dp += mel_w[(size_t)m * cutoff + kk] * gm[m];
+      v = 2.0f * row[k] * dp;
+    }
+    o[k] = f2bf(v);
+  }
+}
+// overlap-add of the per-frame sample gradients plus the adjoint of the reflect padding:
+// val[i] = sum_f dframes[f][i - f*hop] over the padded axis, dwav[j] = val[j + half] (+ the mirrored halo entries)
+__global__ __launch_bounds__(256) void stft_overlap_add_kernel(const float* __restrict__ dframes, int frames, int N, int hop,
+                                                               int T, float* __restrict__ dwav) {
+  const int b = blockIdx.y, half = N / 2;
+  const float* df = dframes + (size_t)b * frames * N;
+  auto val = [&](int i) {
+    float acc = 0.f;
+    int f_hi = i / hop;
+    if (f_hi > frames - 1) f_hi = frames - 1;
+    for (int f = f_hi; f >= 0 && i - f * hop < N; --f) acc += df[(size_t)f * N + (i - f * hop)];
+    return acc;
+  };
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < T; j += gridDim.x * blockDim.x) {
+    float acc = val(j + half);
+    if (j >= 1 && j <= half) acc += val(half - j);                          // left halo: padded i = half - j
+    const int r = half + 2 * (T - 1) - j;                                   // right halo: padded i = half + 2(T-1) - j
+    if (j <= T - 2 && r >= half + T && r < T + 2 * half) acc += val(r);
+    dwav[(size_t)b * T + j] = acc;
+  }
+}
+
+extern "C" ctta_status ctta_wav_to_logmel_db(ctta_mel_frontend* M, const float* wav, int batch, int n_samples, float amin,
+                                             float* logmel, void* stream) {
+  CTTA_REQUIRE(M && wav && logmel, "wav_to_logmel_db: null pointer");
+  CTTA_REQUIRE(batch >= 1 && batch <= M->max_batch && n_samples > M->n_fft / 2 && n_samples <= M->max_samples,
+               "wav_to_logmel_db: batch %d / samples %d outside the handle's limits (%d, %d)", batch, n_samples, M->max_batch,
+               M->max_samples);
+  hipStream_t s = (hipStream_t)stream;
+  WsBind bind(M->splitws);
+  const int N = M->n_fft, half = N / 2;
+  const int lp = round_up(n_samples + N, 8);
+  const int frames = n_samples / M->hop + 1;
+  hipLaunchKernelGGL(mel_prepare_kernel, dim3((lp + 255) / 256 > 1024 ? 1024 : (lp + 255) / 256, batch), dim3(256), 0, s, wav,
+                     n_samples, lp, half, M->x[0], M->x[1], M->x[2], 0);
+  CTTA_LAUNCH_CHECK();
+  const int xi[6] = {2, 1, 0, 1, 0, 0}, bj[6] = {0, 1, 2, 0, 1, 0};
+  for (int pass = 0; pass < 6; ++pass) {
+    ctta_conv_desc d;
+    desc_init(&d);
+    d.x0 = M->x[xi[pass]]; d.c0 = 8;
+    d.batch = batch; d.hi = 1; d.wi = lp / 8; d.ho = 1; d.wo = frames;
+    d.kh = 1; d.kw = N / 8; d.stride_w = M->hop / 8;
+    d.w = M->b[bj[pass]]; d.k_pad = N; d.n = M->n_rows;
+    d.out = M->ft; d.ldc = M->n_rows; d.out_f32 = 1; d.accumulate = pass > 0 ? 1 : 0;
+    CTTA_TRY(ctta_conv_gemm(&d, s));
+  }
+  hipLaunchKernelGGL(mel_power_db_kernel, dim3(frames, batch), dim3(256), (size_t)M->cutoff * sizeof(float), s, M->ft, frames,
+                     M->n_rows, M->cutoff, M->mel_w, M->n_mels, amin, logmel);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// d logmel -> d wav for the LAST ctta_wav_to_logmel_db call on this handle (same batch / n_samples / amin)
+extern "C" ctta_status ctta_wav_to_logmel_db_bwd(ctta_mel_frontend* M, const float* dlogmel, int batch, int n_samples,
+                                                 float amin, float* dwav, void* stream) {
+  CTTA_REQUIRE(M && dlogmel && dwav, "wav_to_logmel_db_bwd: null pointer");
+  CTTA_REQUIRE(batch >= 1 && batch <= M->max_batch && n_samples > M->n_fft / 2 && n_samples <= M->max_samples,
+               "wav_to_logmel_db_bwd: batch %d / samples %d outside the handle's limits", batch, n_samples);
+  hipStream_t s = (hipStream_t)stream;
+  WsBind bind(M->splitws);
+  const int N = M->n_fft, cutoff = M->cutoff;
+  const int frames = n_samples / M->hop + 1;
+  if (!M->dft) {   // first backward: the gradient-side buffers and the transposed basis
+    M->kpad = round_up(2 * cutoff, 64);
+    const size_t rows = (size_t)M->max_batch * M->frames_max;
+    CTTA_CHECK_HIP(hipMalloc((void**)&M->dft, rows * M->kpad * 2));
+    CTTA_CHECK_HIP(hipMalloc((void**)&M->dframes, rows * N * 4));
+    CTTA_CHECK_HIP(hipMalloc((void**)&M->basis_t, (size_t)N * M->kpad * 2));
+    CTTA_CHECK_HIP(hipMemsetAsync(M->basis_t, 0, (size_t)N * M->kpad * 2, s));
+    // basis_t[n][r] = basis[r][n] (leading bf16 part), r < 2*cutoff
+    CTTA_TRY(ctta_transpose_bf16(M->b[0], 0, 2 * cutoff, N, N, 0, M->basis_t, 0, M->kpad, 1, s));
+  }
+  hipLaunchKernelGGL(mel_power_db_bwd_kernel, dim3(frames, batch), dim3(256), (size_t)(cutoff + M->n_mels) * sizeof(float), s,
+                     M->ft, frames, M->n_rows, cutoff, M->mel_w, M->n_mels, amin, dlogmel, M->dft, M->kpad);
+  CTTA_LAUNCH_CHECK();
+  ctta_conv_desc d;
+  desc_init(&d);
+  d.x0 = M->dft; d.c0 = M->kpad;
+  d.batch = 1; d.hi = batch * frames; d.wi = 1; d.ho = batch * frames; d.wo = 1;
+  d.w = M->basis_t; d.k_pad = M->kpad; d.n = N;
+  d.out = M->dframes; d.ldc = N; d.out_f32 = 1;
+  CTTA_TRY(ctta_conv_gemm(&d, s));
+  int blocks = (n_samples + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(stft_overlap_add_kernel, dim3(blocks, batch), dim3(256), 0, s, M->dframes, frames, N, M->hop, n_samples,
+                     dwav);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

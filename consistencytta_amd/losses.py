@@ -7,8 +7,8 @@ ctta_hifigan_forward_with_grad on the device -- and only the few reductions afte
 
   MelLoss                  tools/losses.py:36-64    0.3 * mse(mel(input), mel(target)) + 0.7 * mse(input, target)
   MultiResolutionSTFTLoss  tools/losses.py:187-256  spectral convergence + log-magnitude over 3 STFT resolutions
-  CLAPLoss                 tools/losses.py:259-316  needs the laion_clap package and its checkpoint: not available
-                                                    offline, construction fails loudly
+  CLAPLoss                 tools/losses.py:259-316  mse + cosine terms of CLAP embeddings of the decoded waveform (clap.py:
+                                                    resampler, HTSAT-base audio tower with input gradient, RoBERTa)
 All return one value per instance for reduction='instance' (the only mode AudioLCM uses, audio_consistency_model.py:93-102).
 """
 import torch
@@ -103,9 +103,50 @@ class MultiResolutionSTFTLoss(nn.Module):
 
 
 class CLAPLoss(nn.Module):
-    def __init__(self, vae, reduction="instance", mse_weight=1., clap_weight=1.):
+    """tools/losses.py:259-316: mse_weight * mse(latents) + clap_weight * (2 - cos(audio(input), text) - cos(audio(input),
+    audio(gt))).  The predicted latent is decoded to a waveform with allow_grad=True, cut to 10 s, resampled 16 -> 48 kHz
+    (Kaiser-windowed sinc, `clap.Resampler`) and embedded by the frozen CLAP towers (`clap.CLAP_Module`: HTSAT-base audio
+    tower with input gradient, RoBERTa text tower) -- every stage on the HIP kernels.
+
+    The reference loads `ckpt/music_audioset_epoch_15_esc_90.14.pt` in its constructor; pass `clap=` (a ready
+    `clap.CLAP_Module`) or `ckpt=` here, there is no download path offline.  `tokenizer=` may replace the RoBERTa
+    tokenizer (host-side string work, stays transformers')."""
+
+    def __init__(self, vae, reduction="instance", mse_weight=1., clap_weight=1., clap=None, ckpt="ckpt/music_audioset_epoch_15_esc_90.14.pt",
+                 tokenizer=None):
         super().__init__()
-        raise RuntimeError(
-            "CLAPLoss needs laion_clap (HTSAT-base + RoBERTa) and ckpt/music_audioset_epoch_15_esc_90.14.pt "
-            "(tools/losses.py:270-273); neither is available offline.  The differentiable half it sits on -- "
-            "decode_first_stage / decode_to_waveform with allow_grad=True -- is built: see MelLoss / MultiResolutionSTFTLoss.")
+        from . import clap as C
+        object.__setattr__(self, "vae", vae)
+        self.reduction = reduction
+        self.sr = 16000
+        if clap is None:
+            import os
+            if not os.path.exists(ckpt):
+                raise RuntimeError("CLAPLoss: the CLAP checkpoint %r is not on this box (tools/losses.py:271 loads it in the "
+                                   "constructor); pass clap=<clap.CLAP_Module with weights> or ckpt=<path>" % ckpt)
+            clap = C.CLAP_Module(enable_fusion=False, amodel="HTSAT-base", tokenizer=tokenizer)
+            clap.load_ckpt(ckpt)
+        self.clap = clap
+        self.clap.eval()
+        self.clap.requires_grad_(False)
+        self.resample = C.Resampler(16000, 48000, lowpass_filter_width=64, rolloff=0.9475937167399596,
+                                    beta=14.769656459379492)
+        self.mse_weight, self.clap_weight = mse_weight, clap_weight
+
+    def forward(self, input, target, gt_wav, captions, use_ema=False):
+        mse_loss = reduce(_instance_mse(input, target), self.reduction)
+        input_mel = self.vae.decode_first_stage(input.float(), allow_grad=True, use_ema=use_ema)
+        input_wav = self.vae.decode_to_waveform(input_mel.float(), allow_grad=True)
+        input_wav = input_wav[:, :int(self.sr * 10)]
+        input_wav, gt48 = (self.resample(w[:, :int(self.sr * 10)].float()) for w in (input_wav, gt_wav.to(input_wav.device)))
+        input_feat = self.clap.get_audio_embedding_from_data(input_wav, use_tensor=True)
+        with torch.no_grad():
+            gt_wav_feat = self.clap.get_audio_embedding_from_data(gt48, use_tensor=True)
+            if isinstance(captions, dict):                  # pre-computed prompt states (benchmarks / tests): CLAP text
+                captions = captions["clap_text_features"]    # features ride along under this key
+            caption_feat = (captions if torch.is_tensor(captions)     # (offline boxes have no tokenizer files)
+                            else self.clap.get_text_embedding(captions, use_tensor=True))
+        gen_text_similarity = F.cosine_similarity(input_feat, caption_feat, dim=1)
+        gen_gt_similarity = F.cosine_similarity(input_feat, gt_wav_feat, dim=1)
+        instance_loss = self.mse_weight * mse_loss + self.clap_weight * (2 - gen_text_similarity - gen_gt_similarity)
+        return reduce(instance_loss, self.reduction)

@@ -212,7 +212,7 @@ class AudioLCM(AudioDistilledModel):
     def __init__(self, text_encoder_name, scheduler_name, unet_model_name=None, unet_model_config_path=None,
                  snr_gamma=None, freeze_text_encoder=True, uncondition=False, use_edm=False, use_karras=False,
                  use_lora=False, target_ema_decay=.95, ema_decay=.999, num_diffusion_steps=18,
-                 teacher_guidance_scale=1, vae=None, loss_type="mse", **kwargs):
+                 teacher_guidance_scale=1, vae=None, loss_type="mse", clap_module=None, **kwargs):
         super().__init__(text_encoder_name=text_encoder_name, scheduler_name=scheduler_name,
                          unet_model_name=unet_model_name, unet_model_config_path=unet_model_config_path,
                          snr_gamma=snr_gamma, freeze_text_encoder=freeze_text_encoder, use_lora=use_lora,
@@ -241,7 +241,8 @@ class AudioLCM(AudioDistilledModel):
                                                   hop_sizes=[120, 240, 50], win_lengths=[600, 1200, 240],
                                                   window="hann_window", factor_sc=0.1, factor_mag=0.1, factor_mse=.8)
         elif loss_type == "clap":
-            self.loss = L.CLAPLoss(vae=self.vae, reduction="instance", mse_weight=1., clap_weight=.1)
+            # the reference loads ckpt/music_audioset_epoch_15_esc_90.14.pt here; `clap_module=` supplies ready towers
+            self.loss = L.CLAPLoss(vae=self.vae, reduction="instance", mse_weight=1., clap_weight=.1, clap=clap_module)
         else:
             self.loss = None
         if self.loss is not None and self.vae is None:

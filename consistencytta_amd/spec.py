@@ -385,3 +385,129 @@ def det_weight(name, shape, seed=0):
 def det_state_dict(spec, seed=0, prefix=""):
     """name -> float32 numpy array for every entry of a spec table."""
     return OrderedDict((k, det_weight(prefix + k, s, seed)) for k, s in spec.items())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CLAP (CLAP fine-tuning stage, tools/losses.py:259-316): laion_clap.CLAP_Module(amodel='HTSAT-base', tmodel='roberta')
+HTSAT_BASE_CONFIG = dict(spec_size=256, patch_size=4, patch_stride=4, embed_dim=128, depths=[2, 2, 12, 2],
+                         num_heads=[4, 8, 16, 32], window_size=8, mlp_ratio=4.0, mel_bins=64, sample_rate=48000,
+                         n_fft=1024, hop=480, fmin=50, fmax=14000, num_classes=527)
+ROBERTA_BASE_CONFIG = dict(vocab_size=50265, hidden_size=768, num_hidden_layers=12, num_attention_heads=12,
+                           intermediate_size=3072, max_position_embeddings=514, type_vocab_size=1, layer_norm_eps=1e-5,
+                           pad_token_id=1)
+CLAP_JOINT_DIM = 512
+
+
+def htsat_param_spec(cfg=HTSAT_BASE_CONFIG):
+    """State-dict keys / shapes of `HTSAT_Swin_Transformer` (laion_clap/clap_module/htsat.py:615-775) in the module's
+    own registration order, floating-point entries only (the integer buffers relative_position_index /
+    num_batches_tracked and the constant shift masks are structural).  torchlibrosa's frozen STFT / mel matrices are
+    listed too so that a released checkpoint loads; the engine derives them itself."""
+    sd = OrderedDict()
+    n_fft, F = cfg["n_fft"], cfg["n_fft"] // 2 + 1
+    sd["spectrogram_extractor.stft.conv_real.weight"] = (F, 1, n_fft)
+    sd["spectrogram_extractor.stft.conv_imag.weight"] = (F, 1, n_fft)
+    sd["logmel_extractor.melW"] = (F, cfg["mel_bins"])
+    for k in ("weight", "bias", "running_mean", "running_var"):
+        sd["bn0." + k] = (cfg["mel_bins"],)
+    C, ps = cfg["embed_dim"], cfg["patch_size"]
+    sd["patch_embed.proj.weight"] = (C, 1, ps, ps)
+    sd["patch_embed.proj.bias"] = (C,)
+    sd["patch_embed.norm.weight"] = (C,)
+    sd["patch_embed.norm.bias"] = (C,)
+    res = cfg["spec_size"] // cfg["patch_stride"]
+    n_layers = len(cfg["depths"])
+    for i, (depth, heads) in enumerate(zip(cfg["depths"], cfg["num_heads"])):
+        dim = C * 2 ** i
+        ws = min(cfg["window_size"], res)
+        hidden = int(dim * cfg["mlp_ratio"])
+        for j in range(depth):
+            p = "layers.%d.blocks.%d." % (i, j)
+            sd[p + "norm1.weight"] = (dim,)
+            sd[p + "norm1.bias"] = (dim,)
+            sd[p + "attn.relative_position_bias_table"] = ((2 * ws - 1) ** 2, heads)
+            sd[p + "attn.qkv.weight"] = (3 * dim, dim)
+            sd[p + "attn.qkv.bias"] = (3 * dim,)
+            sd[p + "attn.proj.weight"] = (dim, dim)
+            sd[p + "attn.proj.bias"] = (dim,)
+            sd[p + "norm2.weight"] = (dim,)
+            sd[p + "norm2.bias"] = (dim,)
+            sd[p + "mlp.fc1.weight"] = (hidden, dim)
+            sd[p + "mlp.fc1.bias"] = (hidden,)
+            sd[p + "mlp.fc2.weight"] = (dim, hidden)
+            sd[p + "mlp.fc2.bias"] = (dim,)
+        if i < n_layers - 1:
+            p = "layers.%d.downsample." % i
+            sd[p + "reduction.weight"] = (2 * dim, 4 * dim)
+            sd[p + "norm.weight"] = (4 * dim,)
+            sd[p + "norm.bias"] = (4 * dim,)
+            res //= 2
+    nf = C * 2 ** (n_layers - 1)
+    sd["norm.weight"] = (nf,)
+    sd["norm.bias"] = (nf,)
+    sf = cfg["spec_size"] // (2 ** (n_layers - 1)) // cfg["patch_stride"] // (cfg["spec_size"] // cfg["mel_bins"])
+    sd["tscam_conv.weight"] = (cfg["num_classes"], nf, sf, 3)
+    sd["tscam_conv.bias"] = (cfg["num_classes"],)
+    sd["head.weight"] = (cfg["num_classes"], cfg["num_classes"])
+    sd["head.bias"] = (cfg["num_classes"],)
+    return sd
+
+
+def roberta_param_spec(cfg=ROBERTA_BASE_CONFIG):
+    """transformers.RobertaModel(add_pooling_layer=True) parameters in its own order."""
+    H, I = cfg["hidden_size"], cfg["intermediate_size"]
+    sd = OrderedDict()
+    sd["embeddings.word_embeddings.weight"] = (cfg["vocab_size"], H)
+    sd["embeddings.position_embeddings.weight"] = (cfg["max_position_embeddings"], H)
+    sd["embeddings.token_type_embeddings.weight"] = (cfg["type_vocab_size"], H)
+    sd["embeddings.LayerNorm.weight"] = (H,)
+    sd["embeddings.LayerNorm.bias"] = (H,)
+    for i in range(cfg["num_hidden_layers"]):
+        p = "encoder.layer.%d." % i
+        for t in ("query", "key", "value"):
+            sd[p + "attention.self.%s.weight" % t] = (H, H)
+            sd[p + "attention.self.%s.bias" % t] = (H,)
+        sd[p + "attention.output.dense.weight"] = (H, H)
+        sd[p + "attention.output.dense.bias"] = (H,)
+        sd[p + "attention.output.LayerNorm.weight"] = (H,)
+        sd[p + "attention.output.LayerNorm.bias"] = (H,)
+        sd[p + "intermediate.dense.weight"] = (I, H)
+        sd[p + "intermediate.dense.bias"] = (I,)
+        sd[p + "output.dense.weight"] = (H, I)
+        sd[p + "output.dense.bias"] = (H,)
+        sd[p + "output.LayerNorm.weight"] = (H,)
+        sd[p + "output.LayerNorm.bias"] = (H,)
+    sd["pooler.dense.weight"] = (H, H)
+    sd["pooler.dense.bias"] = (H,)
+    return sd
+
+
+def clap_param_spec(audio_cfg=HTSAT_BASE_CONFIG, text_cfg=ROBERTA_BASE_CONFIG, joint=CLAP_JOINT_DIM):
+    """`clap_module.model.CLAP` (model.py:420-560) with an HTSAT audio branch and a RoBERTa text branch: the entries the
+    embedding paths read (`get_audio_embedding` / `get_text_embedding`, model.py:688-744), reference key names."""
+    sd = OrderedDict()
+    for k, s in htsat_param_spec(audio_cfg).items():
+        sd["audio_branch." + k] = s
+    for k, s in roberta_param_spec(text_cfg).items():
+        sd["text_branch." + k] = s
+    nf = audio_cfg["embed_dim"] * 2 ** (len(audio_cfg["depths"]) - 1)
+    for name, width in (("text_projection", text_cfg["hidden_size"]), ("audio_projection", nf)):
+        sd[name + ".0.weight"] = (joint, width)
+        sd[name + ".0.bias"] = (joint,)
+        sd[name + ".2.weight"] = (joint, joint)
+        sd[name + ".2.bias"] = (joint,)
+    return sd
+
+
+def clap_det_weight(name, shape, seed=0):
+    """Deterministic CLAP test weights: det_weight with the few distribution tweaks the tower needs to stay well
+    conditioned at random init (positive BatchNorm variances, O(1) relative-position biases, a bn0 gain that brings the
+    dB-scaled log-mel values back to O(1))."""
+    shape = tuple(shape)
+    if name.endswith("running_var"):
+        return (1.0 + 0.5 * np.abs(det_uniform(name, shape, seed))).astype(np.float32)
+    if name.endswith("relative_position_bias_table"):
+        return (0.5 * det_uniform(name, shape, seed)).astype(np.float32)
+    if name.endswith("bn0.weight"):
+        return (0.1 + 0.02 * det_uniform(name, shape, seed)).astype(np.float32)
+    return det_weight(name, shape, seed)

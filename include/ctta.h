@@ -459,6 +459,57 @@ ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k, int k_ld,
                                void* dv, int dv_ld, int batch, int heads, int nq, int nk, float scale,
                                float* partial, int64_t partial_floats, void* stream);
 
+/* Window attention of the CLAP audio tower (Swin, laion_clap/clap_module/htsat.py:336-361): the flash kernels above with a
+ * FULL additive bias table full_bias_log2 [n_bias_batches][heads][nq][nk] (already multiplied by log2 e; relative-position
+ * bias per head plus the shifted-window mask, one table per window position); batch item b reads table b % n_bias_batches.
+ * Heads are padded to 64 lanes like everywhere else.  lse may be NULL in the forward. */
+ctta_status ctta_attention_fullbias(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
+                                    int vt_ld, const float* full_bias_log2, int n_bias_batches, void* out, int out_ld,
+                                    int batch, int heads, int nq, int nk, float scale, float* lse, void* stream);
+ctta_status ctta_attention_fullbias_bwd(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vn,
+                                        int vn_ld, int vn_rows, const void* kt, int kt_ld, const void* qt,
+                                        const void* dot, int qt_ld, const float* full_bias_log2, int n_bias_batches,
+                                        const void* out, int out_ld, const void* dout, int do_ld, const float* lse,
+                                        float* dsum, void* dq, int dq_ld, void* dk, int dk_ld, void* dv, int dv_ld,
+                                        int batch, int heads, int nq, int nk, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------ *
+ * CLAP fine-tuning stage (tools/losses.py:259-316): glue kernels of the audio tower.
+ * ------------------------------------------------------------------------------------ */
+/* torchaudio.functional.resample(sinc_interp_kaiser) as a polyphase FIR (tools/losses.py:299-303):
+ * y[b][n*up + p] = sum_j kernels[p][j] * x[b][n*down + j - width], zero outside [0, len); kernels fp32 [up][taps] built by
+ * the host from the published window formula; out_len = ceil(up * len / down).  _bwd is the adjoint (d y -> d x). */
+ctta_status ctta_resample_poly(const float* x, int batch, int len, const float* kernels, int up, int down, int width,
+                               int taps, float* y, int64_t out_len, void* stream);
+ctta_status ctta_resample_poly_bwd(const float* dy, int batch, int64_t out_len, const float* kernels, int up, int down,
+                                   int width, int taps, float* dx, int len, void* stream);
+/* Spectrogram(power 2) + LogmelFilterBank (dB, amin) of htsat.py:684-697 on a ctta_mel_frontend handle: (batch, n_samples)
+ * fp32 -> logmel [batch][n_samples / hop + 1][n_mels] fp32; _bwd maps d logmel to d wav for the last forward call. */
+ctta_status ctta_wav_to_logmel_db(ctta_mel_frontend* h, const float* wav, int batch, int n_samples, float amin,
+                                  float* logmel, void* stream);
+ctta_status ctta_wav_to_logmel_db_bwd(ctta_mel_frontend* h, const float* dlogmel, int batch, int n_samples, float amin,
+                                      float* dwav, void* stream);
+/* bn0 (eval: per-mel-bin scale / shift) + bicubic stretch of the frame axis (tap tables [out_frames][4] from the host) +
+ * fold into the (spec_size x spec_size) image, htsat.py:913-925,856-878 -> NHWC bf16 [batch][S][S][cpad] (channel 0).
+ * _bwd: gradient of the patch-embedding conv in token layout [batch][(S/patch)^2][ld >= patch^2] fp32 -> d logmel, with the
+ * transposed tap list in CSR form (rt_ptr [frames + 1], rt_tt, rt_w). */
+ctta_status ctta_htsat_image(const float* logmel, int batch, int frames, int mel_bins, const float* bn_scale,
+                             const float* bn_shift, const int32_t* tap_idx, const float* tap_w, int out_frames,
+                             int spec_size, int cpad, void* image_nhwc, void* stream);
+ctta_status ctta_htsat_image_bwd(const float* dtokens, int dtokens_ld, int patch, int batch, int frames, int mel_bins,
+                                 const float* bn_scale, const int32_t* rt_ptr, const int32_t* rt_tt, const float* rt_w,
+                                 int spec_size, float* dlogmel, void* stream);
+/* dst[r][:] = src[idx[r]][:] over bf16 rows (idx < 0: zeros): window partition / cyclic shift / patch merging and their
+ * inverses are all row permutations of the token matrix (htsat.py:259-287,471-492,517-537). */
+ctta_status ctta_gather_rows(const void* src, int src_ld, const int32_t* idx, void* dst, int dst_ld, int64_t n_rows,
+                             int row_elems, void* stream);
+/* nn.GELU (erf) on bf16 and its backward from the pre-activation (htsat.py:156-174) */
+ctta_status ctta_gelu(const void* x, void* y, int64_t n, void* stream);
+ctta_status ctta_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+/* mean over the token axis: bf16 [batch][tokens][ld] -> fp32 [batch][channels], and its backward (htsat.py:818-819) */
+ctta_status ctta_mean_tokens(const void* x, int batch, int tokens, int channels, int ld, float* y, void* stream);
+ctta_status ctta_mean_tokens_bwd(const float* dy, int batch, int tokens, int channels, int ld, void* dx, void* stream);
+
 /* Small fp32 linear: y[m][n] = act_out(sum_k act_in(x[m][k]) * w[n][k] + b[n]); m <= 1024.
  * act: 0 none, 1 silu. */
 ctta_status ctta_linear_f32(const float* x, const float* w, const float* b, float* y, int m,

@@ -113,3 +113,44 @@ def t5_inputs(cfg, B, L, tag):
     lens[0] = L
     mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
     return t(ids), t(mask)
+
+
+# CLAP text tower: a small RoBERTa and roberta-base's widths at one layer (head width 64 like every released size)
+TINY_ROBERTA = dict(spec.ROBERTA_BASE_CONFIG, vocab_size=1000, hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                    intermediate_size=256, max_position_embeddings=90)
+WIDE_ROBERTA = dict(spec.ROBERTA_BASE_CONFIG, vocab_size=2000, num_hidden_layers=1, max_position_embeddings=90)
+
+
+def roberta_weights(cfg, seed=0):
+    sd = {}
+    for k, s in spec.roberta_param_spec(cfg).items():
+        if k.endswith("LayerNorm.weight"):
+            sd[k] = t(1.0 + 0.2 * spec.det_uniform("roberta." + k, s, seed))
+        elif "embeddings" in k and k.endswith("weight"):
+            sd[k] = t(spec.det_uniform("roberta." + k, s, seed))          # O(1) embedding tables
+        else:
+            sd[k] = t(spec.clap_det_weight("roberta." + k, s, seed))
+    return sd
+
+
+def roberta_inputs(cfg, B, L, tag):
+    ids = (np.abs(spec.det_uniform(tag + ".rids", (B, L), 41)) * (cfg["vocab_size"] - 3)).astype(np.int64) + 2
+    lens = (np.abs(spec.det_uniform(tag + ".rlen", (B,), 42)) * (L - 2)).astype(np.int64) + 2
+    lens[0] = L
+    mask = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    ids = np.where(mask == 1, ids, cfg["pad_token_id"])
+    return t(ids), t(mask)
+
+
+def clap_weights(keys, shapes, tag, seed):
+    """HTSAT weights of the `clap_htsat.npz` cases: the reference module's own key / shape lists (fixture data) through
+    the deterministic generator."""
+    sd = {}
+    for k, s in zip(keys, shapes):
+        shape = tuple(int(x) for x in str(s).split(",")) if str(s) else ()
+        sd[str(k)] = t(spec.clap_det_weight(tag + "." + str(k), shape, seed))
+    return sd
+
+
+TINY_HTSAT = dict(spec.HTSAT_BASE_CONFIG, spec_size=64, embed_dim=64, depths=[2, 2, 2, 2], num_heads=[2, 4, 8, 16],
+                  num_classes=11)

@@ -13,7 +13,7 @@ the fixture as data, so that the GPU box can rebuild them without the reference)
 (music_audioset_epoch_15_esc_90.14.pt) is not available offline.
 
 Two cases: HTSAT-base (`create_htsat_model` "base": embed 128, depths 2/2/12/2, heads 4/8/16/32, window 8) on 10 s of
-48 kHz audio -- embedding in full, the input gradient as norm + strided sample -- and a small tower (spec 64, embed 32,
+48 kHz audio -- embedding in full, the input gradient as norm + strided sample -- and a small tower (spec 64, embed 64,
 depths 2/2/2/2) whose stages cover shifted 8x8 windows, one full window, and windows shrunk to 4x4 and 2x2, with every
 tensor stored in full.
 """
@@ -102,13 +102,7 @@ def det_weights(model, tag, seed):
             continue
         keys.append(k)
         shapes.append(list(v.shape))
-        w = torch.from_numpy(spec.det_weight(tag + k, tuple(v.shape), seed))
-        if k.endswith("running_var"):
-            w = 1.0 + 0.5 * torch.from_numpy(spec.det_uniform(tag + k, tuple(v.shape), seed)).abs()
-        elif k.endswith("relative_position_bias_table"):
-            w = torch.from_numpy(spec.det_uniform(tag + k, tuple(v.shape), seed)) * 0.5
-        elif k.endswith("bn0.weight"):
-            w = 0.1 + 0.02 * torch.from_numpy(spec.det_uniform(tag + k, tuple(v.shape), seed))   # log-mel dB values are O(50)
+        w = torch.from_numpy(spec.clap_det_weight(tag + k, tuple(v.shape), seed))
         new[k] = w
     model.load_state_dict(new, strict=False)
     return new, keys, shapes
@@ -144,7 +138,7 @@ def main():
     # ---- small tower, every tensor in full
     B, L = 2, 28800
     wav = cases.t(spec.det_uniform("clap.tiny.wav", (B, L), 3)) * 0.4
-    tiny_kw = dict(spec_size=64, patch_size=4, patch_stride=(4, 4), num_classes=11, embed_dim=32, depths=[2, 2, 2, 2],
+    tiny_kw = dict(spec_size=64, patch_size=4, patch_stride=(4, 4), num_classes=11, embed_dim=64, depths=[2, 2, 2, 2],
                    num_heads=[2, 4, 8, 16], window_size=8)
     m, sd = run_case(H, base, tiny_kw, wav, "tiny", 5, out, full=True)
     with torch.no_grad():   # the oracle's own front half against the reference's (bn0 + bicubic + fold)

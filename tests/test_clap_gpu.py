@@ -1,0 +1,256 @@
+"""CLAP fine-tuning stage on the HIP path (tools/losses.py:259-316): operator parity of the new
+kernels against the CPU oracle, the HTSAT audio tower (forward AND input gradient) against fixtures produced by the
+reference's own laion_clap/clap_module/htsat.py, the RoBERTa text tower against transformers' RobertaModel, and the
+CLAP loss end to end (latent -> VAE decoder -> HiFi-GAN -> resampler -> tower -> cosine terms) against the oracle.
+
+Tolerances: bf16 activations with fp32 accumulation against fp32 references -- relative L2 2.5e-2 on embeddings,
+5e-2 on input gradients (24 residual blocks deep); fp32 kernels (resampler, front end) a few 1e-4."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import cases  # noqa: E402
+from consistencytta_amd import _native as N  # noqa: E402
+from consistencytta_amd import clap as C  # noqa: E402
+from consistencytta_amd import spec  # noqa: E402
+from gpu_util import DEV, bf16_round, det, rel_err, rel_l2, sync  # noqa: E402
+from oracle import clap as oclap  # noqa: E402
+
+KAISER = dict(lowpass_filter_width=64, rolloff=0.9475937167399596, beta=14.769656459379492)
+
+
+# ------------------------------------------------------------------------------------------------ operators
+@pytest.mark.parametrize("orig,new,L", [(16000, 48000, 5000), (16000, 48000, 333), (48000, 16000, 4001), (2, 3, 1000)])
+def test_resampler_forward_and_adjoint(orig, new, L):
+    x = (det("rs.x", (2, L), 1) * 0.8).requires_grad_(True)
+    ref = oclap.resample(x, orig, new, **KAISER)
+    g = det("rs.g", tuple(ref.shape), 2)
+    (ref * g).sum().backward()
+    rs = C.Resampler(orig, new, **KAISER)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    y = rs(xd)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < 2e-5
+    (y * g.to(DEV)).sum().backward()
+    assert rel_err(xd.grad, x.grad) < 2e-5
+    with pytest.raises(RuntimeError):
+        rs(x.detach())                                     # CPU tensor: no CPU path
+
+
+def test_gather_gelu_mean_tokens():
+    L_ = N.lib()
+    x = bf16_round(det("g.x", (37, 64), 1) * 3).to(torch.bfloat16).to(DEV)
+    idx = torch.randperm(37, generator=torch.Generator().manual_seed(1)).to(torch.int32)
+    idx[5] = -1
+    out = C._gather(x, idx.to(DEV))
+    ref = x.cpu()[idx.clamp(min=0).long()]
+    ref[5] = 0
+    assert torch.equal(out.cpu(), ref)
+    xf = x.float().cpu().requires_grad_(True)
+    yr = F.gelu(xf)
+    gy = bf16_round(det("g.gy", (37, 64), 2))
+    (yr * gy).sum().backward()
+    xg = x.clone().requires_grad_(True)
+    y = C._Gelu.apply(xg)
+    assert rel_err(y, yr) < 2.0 ** -8
+    (y.float() * gy.to(DEV)).sum().backward()
+    assert rel_err(xg.grad, xf.grad) < 2 * 2.0 ** -8
+    t = bf16_round(det("g.t", (3 * 16, 128), 3)).to(torch.bfloat16).to(DEV).requires_grad_(True)
+    m = C._MeanTokens.apply(t, 3, 16, 128)
+    assert rel_err(m, t.detach().float().cpu().view(3, 16, 128).mean(1)) < 1e-6
+    m.sum().backward()
+    assert rel_err(t.grad, torch.full((48, 128), 1.0 / 16)) < 2.0 ** -8
+
+
+@pytest.mark.parametrize("L", [28800, 9000])
+def test_htsat_front_end_against_oracle(L):
+    """wav -> power STFT -> dB log-mel -> bn0 -> bicubic frame stretch -> fold, and its input gradient, vs the oracle
+    restatement (itself bit-identical to the reference module's own front half, tests/test_oracle_golden.py)."""
+    cfg = cases.TINY_HTSAT
+    m = C.HTSAT(cfg)
+    g = np.load(cases.__file__.replace("cases.py", "clap_htsat.npz"))
+    sd = cases.clap_weights(g["tiny_keys"], g["tiny_shapes"], "tiny", 5)
+    m.load_state_dict(sd, strict=False)
+    m.to(DEV)
+    wav = (det("fe.wav", (2, L), 7) * 0.4)
+    with torch.no_grad():
+        ref = oclap.wav_to_image(cfg, sd, wav, prefix="")                 # (B, 1, 64, 64)
+    P = m._pack()
+    wd = wav.to(DEV).requires_grad_(True)
+    tok = C._Frontend.apply(wd, m._fe, P["patch"], P["patch_t"])
+    img = m._fe.last_image[..., 0].float().cpu()
+    assert rel_err(img, ref[:, 0]) < 3 * 2.0 ** -8                       # bf16 image of O(1) values
+    # patch tokens vs conv2d on the bf16 image
+    tref = F.conv2d(bf16_round(ref.detach()), bf16_round(sd["patch_embed.proj.weight"]), sd["patch_embed.proj.bias"], stride=4)
+    assert rel_err(tok.float().cpu().view(2, 16, 16, -1).permute(0, 3, 1, 2), tref) < 3 * 2.0 ** -8
+    (tok.float() * 0).sum().backward()                                     # exercises the plumbing (zero gradient)
+    assert float(wd.grad.abs().max()) == 0.0
+
+
+def test_window_attention_fullbias_forward_backward():
+    """Swin window attention (htsat.py:336-361) on the flash kernels with a full bias table vs plain torch."""
+    heads, hd, n, nw, nbb = 4, 32, 64, 8, 4
+    hp = heads * 64
+    qkv = torch.zeros(nw * n, 3 * hp)
+    raw = bf16_round(det("wa.qkv", (nw * n, 3, heads, hd), 1) * 1.5)
+    for part in range(3):
+        for h in range(heads):
+            qkv[:, part * hp + h * 64: part * hp + h * 64 + hd] = raw[:, part, h]
+    bias = det("wa.bias", (nbb, heads, n, n), 2) * 2.0
+    bias[1, :, :, 40:] = -100.0                                              # a shifted-window style mask
+    scale = hd ** -0.5
+    q, k, v = (raw[:, i].view(nw, n, heads, hd).permute(0, 2, 1, 3).clone().requires_grad_(True) for i in range(3))
+    att = (q * scale) @ k.transpose(-1, -2) + bias[torch.arange(nw) % nbb]
+    o_ref = att.softmax(-1) @ v                                              # (nw, heads, n, hd)
+    go = bf16_round(det("wa.go", tuple(o_ref.shape), 3))
+    (o_ref * go).sum().backward()
+    qd = qkv.to(torch.bfloat16).to(DEV).requires_grad_(True)
+    out = C._WindowAttention.apply(qd, (bias * C.LOG2E).contiguous().to(DEV), nbb, heads, n, scale)
+    got = out.float().cpu().view(nw, n, heads, 64)[..., :hd].permute(0, 2, 1, 3)
+    assert rel_err(got, o_ref) < 3 * 2.0 ** -8
+    assert float(out.float().cpu().view(nw, n, heads, 64)[..., hd:].abs().max()) == 0.0     # pad lanes stay zero
+    gpad = torch.zeros(nw * n, hp)
+    gp = go.permute(0, 2, 1, 3).reshape(nw * n, heads, hd)
+    for h in range(heads):
+        gpad[:, h * 64: h * 64 + hd] = gp[:, h]
+    out.backward(gpad.to(torch.bfloat16).to(DEV))
+    dq = qd.grad.float().cpu()
+    for part, ref in enumerate((q.grad, k.grad, v.grad)):
+        got = dq[:, part * hp:(part + 1) * hp].view(nw, n, heads, 64)[..., :hd].permute(0, 2, 1, 3)
+        assert rel_l2(got, ref) < 2e-2, part
+
+
+# ------------------------------------------------------------------------------------------------ towers
+def _tower(cfg, keys, shapes, tag, seed):
+    m = C.HTSAT(cfg)
+    sd = cases.clap_weights(keys, shapes, tag, seed)
+    missing = m.load_state_dict(sd, strict=False)
+    assert all(k.startswith(("spectrogram_extractor", "logmel_extractor")) for k in missing.missing_keys), missing
+    assert not missing.unexpected_keys
+    return m.to(DEV).eval(), sd
+
+
+def test_htsat_tiny_tower_embedding_taps_and_input_gradient(golden):
+    g = golden("clap_htsat")
+    cfg = cases.TINY_HTSAT
+    m, sd = _tower(cfg, g["tiny_keys"], g["tiny_shapes"], "tiny", 5)
+    wav = cases.t(spec.det_uniform("clap.tiny.wav", (2, 28800), 3)) * 0.4
+    otaps = {}
+    with torch.no_grad():
+        oclap.htsat_embedding(cfg, sd, wav, prefix="", taps=otaps)
+    wd = wav.to(DEV).requires_grad_(True)
+    taps = {}
+    emb = m(wd, taps=taps)
+    assert rel_err(taps["image"], torch.from_numpy(g["tiny_image"])[:, 0]) < 3 * 2.0 ** -8
+    for i in range(4):
+        l2 = rel_l2(taps["layer%d" % i], otaps["layer%d" % i])
+        print("tiny tower layer %d rel_l2 %.3e" % (i, l2))
+        assert l2 < 2.5e-2
+    l2 = rel_l2(emb, torch.from_numpy(g["tiny_embedding"]))
+    print("tiny tower embedding rel_l2 %.3e" % l2)
+    assert l2 < 2.5e-2
+    direction = cases.t(spec.det_uniform("tiny.dir", tuple(emb.shape), 9)).to(DEV)
+    (emb * direction).sum().backward()
+    gl2 = rel_l2(wd.grad, torch.from_numpy(g["tiny_grad"]))
+    print("tiny tower d/d wav rel_l2 %.3e" % gl2)
+    assert gl2 < 5e-2
+    # a plain (no-grad) pass between a differentiable forward and its backward must not disturb it
+    wd2 = wav.to(DEV).requires_grad_(True)
+    e2 = m(wd2)
+    with torch.no_grad():
+        m(wav.to(DEV) * 0.5)
+    (e2 * direction).sum().backward()
+    assert torch.equal(wd2.grad, wd.grad)
+
+
+def test_htsat_base_tower_on_ten_seconds(golden):
+    """HTSAT-base (72 M parameters, 24 Swin blocks) on 10 s at 48 kHz: the shape CLAPLoss runs (tools/losses.py:305)."""
+    g = golden("clap_htsat")
+    m, sd = _tower(spec.HTSAT_BASE_CONFIG, g["base_keys"], g["base_shapes"], "base", 6)
+    wav = cases.t(spec.det_uniform("clap.base.wav", (2, 480000), 4)) * 0.4
+    wd = wav.to(DEV).requires_grad_(True)
+    emb = m(wd)
+    l2 = rel_l2(emb, torch.from_numpy(g["base_embedding"]))
+    print("HTSAT-base embedding rel_l2 %.3e" % l2)
+    assert l2 < 2.5e-2
+    direction = cases.t(spec.det_uniform("base.dir", tuple(emb.shape), 9)).to(DEV)
+    (emb * direction).sum().backward()
+    gn = float(wd.grad.double().norm())
+    idx = torch.from_numpy(cases.sample_index(480000, 4096)).to(DEV)
+    gs = rel_l2(wd.grad[:, idx], torch.from_numpy(g["base_grad_sample"]))
+    print("HTSAT-base d/d wav: norm %.4e (ref %.4e), sampled rel_l2 %.3e" % (gn, float(g["base_grad_norm"]), gs))
+    assert abs(gn - float(g["base_grad_norm"])) <= 5e-2 * float(g["base_grad_norm"]) and gs < 6e-2
+
+
+@pytest.mark.parametrize("tag,cfg", [("tiny", cases.TINY_ROBERTA), ("wide", cases.WIDE_ROBERTA)])
+def test_roberta_text_tower_matches_transformers(golden, tag, cfg):
+    g = golden("roberta")
+    m = C.RobertaModel(cfg)
+    m.load_state_dict(cases.roberta_weights(cfg))
+    m.to(DEV).eval()
+    ids, mask = cases.roberta_inputs(cfg, 3, 20, tag)
+    out = m(input_ids=ids.to(DEV), attention_mask=mask.to(DEV))
+    valid = mask.bool()
+    l2 = rel_l2(out["last_hidden_state"].cpu()[valid], torch.from_numpy(g[tag + "_last"])[valid])
+    p2 = rel_l2(out["pooler_output"], torch.from_numpy(g[tag + "_pooler"]))
+    print("RoBERTa %s: last_hidden_state rel_l2 %.3e, pooler_output rel_l2 %.3e" % (tag, l2, p2))
+    assert l2 < 2.5e-2 and p2 < 2.5e-2
+
+
+def test_clap_loss_end_to_end_matches_oracle():
+    """CLAPLoss (tools/losses.py:276-316): latent -> VAE decoder -> HiFi-GAN (allow_grad) -> 16 -> 48 kHz -> CLAP audio
+    embedding; cosine terms against text / ground-truth-audio embeddings; value and latent gradient vs the oracle chain
+    (oracle VAE / vocoder / resampler / tower under torch autograd)."""
+    from consistencytta_amd import losses, modules
+    from oracle import nets as onets
+    g = np.load(cases.__file__.replace("cases.py", "clap_htsat.npz"))
+    cfg = cases.TINY_HTSAT
+    clap = C.CLAP_Module(audio_cfg=cfg, text_cfg=cases.TINY_ROBERTA)
+    hsd = cases.clap_weights(g["tiny_keys"], g["tiny_shapes"], "tiny", 5)
+    clap.model.audio_branch.load_state_dict(hsd, strict=False)
+    proj = {k: cases.t(spec.clap_det_weight("clap." + k, tuple(v.shape), 1)) for k, v in clap.model.state_dict().items()
+            if k.startswith("audio_projection")}
+    clap.model.load_state_dict(proj)
+    vsd = dict(cases.vae_weights(cases.TINY_VAE_DD))
+    vsd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
+    vae = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, scale_factor=0.9, hifigan_config=cases.TINY_HIFIGAN)
+    vae.load_state_dict(vsd)
+    vae.to(DEV).eval().requires_grad_(False)
+    loss = losses.CLAPLoss(vae, reduction="instance", mse_weight=1.0, clap_weight=0.1, clap=clap).to(DEV)
+    B = 2
+    z = (cases.vae_inputs(B, 15, 16, "claploss") * 0.5)
+    zt = z + 0.1 * cases.vae_inputs(B, 15, 16, "claploss.t")
+    gt = det("claploss.gt", (B, 7000), 3) * 0.3                 # shorter than the clip: repeat-padded
+    text = F.normalize(det("claploss.text", (B, 512), 4), dim=-1)
+    # ---- oracle chain
+    zo = z.clone().requires_grad_(True)
+    mel = onets.vae_decode(cases.TINY_VAE_DD, vsd, zo, 0.9)
+    wav = onets.hifigan_forward(cases.TINY_HIFIGAN, vsd, mel[:, 0].transpose(1, 2))[:, 0]
+    wav = wav - (wav.max() + wav.min()) / 2
+    clap.clip_samples = 3 * wav.shape[1]          # the small tower's clip length stands in for the 480 000 of HTSAT-base
+    zd = z.to(DEV).requires_grad_(True)
+    inst = loss(zd, zt.to(DEV), gt.to(DEV), text.to(DEV))
+    inst.sum().backward()
+    sd = dict(hsd)
+    sd.update(proj)
+    kw = KAISER
+
+    fin48 = oclap.resample(wav[:, :160000], 16000, 48000, **kw)
+    gt48 = C.CLAP_Module._fit(oclap.resample(gt, 16000, 48000, **kw), fin48.shape[1])
+    osd = {("audio_branch." + k if not k.startswith("audio_projection") else k): v for k, v in sd.items()}
+    e_in = oclap.audio_features(cfg, osd, fin48)
+    with torch.no_grad():
+        e_gt = oclap.audio_features(cfg, osd, gt48)
+    mse = ((zo - zt) ** 2).reshape(B, -1).mean(1)
+    ref = 1.0 * mse + 0.1 * (2 - F.cosine_similarity(e_in, text, dim=1) - F.cosine_similarity(e_in, e_gt, dim=1))
+    ref.sum().backward()
+    print("CLAP loss hip", inst.detach().cpu().numpy(), "oracle", ref.detach().numpy())
+    np.testing.assert_allclose(inst.detach().cpu().numpy(), ref.detach().numpy(), rtol=3e-2)
+    gl2 = rel_l2(zd.grad, zo.grad)
+    print("CLAP loss d/d latent rel_l2 %.3e" % gl2)
+    assert gl2 < 0.3      # dominated by the piecewise-linear vocoder's mask flips; the tower alone: 5e-2

@@ -299,3 +299,60 @@ def test_stage1_inference(golden):
     lat = cases.t(spec.det_uniform("gdm.inf_noise", (3, 8, 256, 16), 16)) * np.float32(np.sqrt(3.0))
     with torch.no_grad():
         close(distill.gdm_inference(n, n.ema, P, lat, 3.0, 4), g["gdm_inference_4steps"], 5e-4, 5e-5)
+
+
+# ------------------------------------------------------------------------------------------------ CLAP audio tower
+def test_clap_oracle_matches_reference_htsat(golden):
+    """oracle/clap.py (resampler-free part: log-mel front end + HTSAT Swin tower) against the fixtures the reference's
+    own laion_clap/clap_module/htsat.py produced (tests/golden/make_golden_clap.py): image, embedding, input gradient."""
+    from oracle import clap as oclap
+    g = golden("clap_htsat")
+    cfg = cases.TINY_HTSAT
+    sd = cases.clap_weights(g["tiny_keys"], g["tiny_shapes"], "tiny", 5)
+    wav = (cases.t(spec.det_uniform("clap.tiny.wav", (2, 28800), 3)) * 0.4).requires_grad_(True)
+    taps = {}
+    emb = oclap.htsat_embedding(cfg, sd, wav, prefix="", taps=taps)
+    np.testing.assert_allclose(taps["image"].detach().numpy(), g["tiny_image"], rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(emb.detach().numpy(), g["tiny_embedding"], rtol=2e-4, atol=2e-4)
+    (emb * cases.t(spec.det_uniform("tiny.dir", tuple(emb.shape), 9))).sum().backward()
+    ref = torch.from_numpy(g["tiny_grad"])
+    assert float((wav.grad - ref).norm() / ref.norm()) < 2e-4
+    # the build's own parameter table reproduces the reference module's key list (order included)
+    mine = [k for k in spec.htsat_param_spec(spec.HTSAT_BASE_CONFIG) if not k.startswith(("spectrogram_extractor", "logmel_extractor"))]
+    assert mine == [str(k) for k in g["base_keys"]]
+    assert [",".join(str(d) for d in spec.htsat_param_spec()[k]) for k in mine] == [str(s) for s in g["base_shapes"]]
+
+
+@pytest.mark.slow
+def test_clap_oracle_htsat_base_embedding(golden):
+    from oracle import clap as oclap
+    g = golden("clap_htsat")
+    sd = cases.clap_weights(g["base_keys"], g["base_shapes"], "base", 6)
+    wav = cases.t(spec.det_uniform("clap.base.wav", (2, 480000), 4)) * 0.4
+    with torch.no_grad():
+        emb = oclap.htsat_embedding(spec.HTSAT_BASE_CONFIG, sd, wav, prefix="")
+    np.testing.assert_allclose(emb.numpy(), g["base_embedding"], rtol=2e-4, atol=2e-4)
+
+
+def test_kaiser_sinc_resampler_known_answers():
+    """torchaudio's published sinc_interp_kaiser algorithm (absent here) restated in oracle/clap.py: properties any correct
+    implementation has -- unit DC gain per phase, a band-limited sine is reproduced on the new grid, the output length is
+    ceil(new * len / orig), up then down returns the signal -- plus the host table of the product path being identical."""
+    from consistencytta_amd import clap as C
+    from oracle import clap as oclap
+    kw = dict(lowpass_filter_width=64, rolloff=0.9475937167399596, beta=14.769656459379492)
+    k, width, orig, new = oclap.sinc_resample_kernel(16000, 48000, **kw)
+    assert (orig, new, width) == (1, 3, 68) and tuple(k.shape) == (3, 1, 137)
+    np.testing.assert_allclose(k.sum(-1).numpy().ravel(), 1.0, atol=2e-6)            # DC gain of every phase filter
+    kp, wp, op, npp = C.sinc_resample_kernel(16000, 48000, **kw)
+    assert (wp, op, npp) == (68, 1, 3) and np.array_equal(kp, k[:, 0].numpy())
+    t16 = torch.arange(4000, dtype=torch.float64) / 16000
+    x = torch.sin(2 * np.pi * 1000.0 * t16).float()[None]
+    y = oclap.resample(x, 16000, 48000, **kw)
+    assert y.shape == (1, 12000)
+    t48 = torch.arange(12000, dtype=torch.float64) / 48000
+    ref = torch.sin(2 * np.pi * 1000.0 * t48).float()
+    assert float((y[0, 300:-300] - ref[300:-300]).abs().max()) < 2e-3
+    back = oclap.resample(y, 48000, 16000, **kw)
+    assert back.shape == x.shape and float((back[0, 300:-300] - x[0, 300:-300]).abs().max()) < 3e-3
+    assert oclap.resample(torch.zeros(2, 333), 16000, 48000, **kw).shape == (2, 999)
