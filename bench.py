@@ -440,17 +440,21 @@ def distill_leg(args, dev, world, rank, perceptual=False):
 
     B, L = (args.perceptual_batch if perceptual else args.distill_batch), args.text_len
     t_build = time.perf_counter()
-    vae = None
+    vae = clap = None
     if perceptual:
+        from consistencytta_amd import clap as clap_mod
         from consistencytta_amd import modules
         vae = modules.AutoencoderKL(ddconfig=spec.VAE_DDCONFIG, embed_dim=8, scale_factor=0.9227914214134216)
         vae.to(dev)
         vae.init_random_(seed=12)
         vae.eval().requires_grad_(False)
+        clap = clap_mod.CLAP_Module(enable_fusion=False, amodel="HTSAT-base")     # HTSAT-base + roberta-base, random init
+        clap.to(dev)
+        clap.model.init_random_(seed=13)
     m = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
                  unet_model_config_path="tango_diffusion_light.json", unet_config=spec.LIGHT_UNET_CONFIG, snr_gamma=5.0,
                  use_edm=True, teacher_guidance_scale=-1, num_diffusion_steps=18, vae=vae,
-                 loss_type="stft" if perceptual else "mse", target_ema_decay=0.95, ema_decay=0.999)
+                 loss_type="clap" if perceptual else "mse", clap_module=clap, target_ema_decay=0.95, ema_decay=0.999)
     m.to(dev)
     m.teacher_unet.init_random_(seed=10)
     m.student_unet.init_random_(seed=11)
@@ -470,16 +474,25 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     umask = torch.zeros_like(mask)
     umask[:, 0] = True
     P = {"embeds_cf": torch.cat([unc, enc]), "mask_cf": torch.cat([umask, mask]), "embeds": enc, "mask": mask}
+    step_kw = {}
+    if perceptual:   # CLAPLoss's other two inputs: ground-truth audio (10 s at 16 kHz) and the captions' CLAP text features,
+        # the latter from the RoBERTa tower on synthetic token ids (77 positions, ragged lengths, tokenizer files are offline)
+        ids = torch.randint(4, 50000, (B, 77), generator=g)
+        tl = torch.randint(5, 30, (B,), generator=g)
+        tmask = (torch.arange(77)[None, :] < tl[:, None]).long()
+        ids = torch.where(tmask == 1, ids, torch.ones_like(ids))
+        P["clap_text_features"] = clap.model.get_text_embedding({"input_ids": ids.to(dev), "attention_mask": tmask.to(dev)})
+        step_kw["gt_wav"] = (torch.rand(B, 160000, generator=g) * 2 - 1).to(dev) * 0.3
     torch.manual_seed(100 + rank)       # per-rank timestep / guidance / noise streams
     build_s = time.perf_counter() - t_build
 
     losses = []
     for _ in range(max(1, args.warmup)):
-        losses.append(m.train_step(z0, P, opt, sched))
+        losses.append(m.train_step(z0, P, opt, sched, **step_kw))
     du.barrier(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        losses.append(m.train_step(z0, P, opt, sched))
+        losses.append(m.train_step(z0, P, opt, sched, **step_kw))
     du.barrier(dev)
     dt = du.max_over_ranks(time.perf_counter() - t0, dev)
     assert all(v == v for v in losses), "NaN distillation loss"
@@ -496,11 +509,13 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     }
     if perceptual:
         out["metric"] = "perceptual_distillation_steps_per_sec"
-        out["config"]["workload"] = ("configs[4] without CLAP (weights unavailable offline): distillation step whose loss "
-                                     "decodes the student latent to a waveform with allow_grad=True (VAE decoder + HiFi-GAN "
-                                     "forward and input-gradient passes on HIP), multi-resolution STFT loss, U-Net backward, "
-                                     "AdamW, EMA")
-        del m, opt, vae
+        out["config"]["workload"] = ("configs[4]: CLAP fine-tuning step -- consistency generation (student / teacher / target "
+                                     "U-Nets as in configs[3]), VAE decode + HiFi-GAN with allow_grad=True, 16->48 kHz "
+                                     "Kaiser-sinc resampling, CLAP forward (HTSAT-base audio tower on the generated and the "
+                                     "ground-truth clip, RoBERTa-base text features) and its input gradient back through "
+                                     "vocoder, decoder and U-Net; CLAPLoss(mse 1.0, clap 0.1); AdamW, EMA; random-init CLAP "
+                                     "weights (no checkpoint offline)")
+        del m, opt, vae, clap
         return out
     # train.sh:33's recipe accumulates 5 micro-batches per optimizer step (SURVEY 8d "grad-accum 1 and 5"): 4 local
     # micro-steps (loss + backward, DDP no_sync) and a 5th that also all-reduces, steps AdamW and updates the EMAs

@@ -782,6 +782,29 @@ class CLAP(nn.Module):
         self.audio_projection = mlp(nf)
         self.requires_grad_(False)
 
+    def init_random_(self, seed=0):
+        """On-device random init for benchmarks (no CLAP checkpoint offline): the same scale rules as the deterministic
+        test weights (spec.clap_det_weight), values not reproducible across boxes."""
+        gen = torch.Generator(device=self.audio_branch.device)
+        gen.manual_seed(seed)
+        with torch.no_grad():
+            for k, p in self.named_parameters():
+                u = torch.rand(p.shape, generator=gen, device=p.device) * 2 - 1
+                if k.endswith("running_var"):
+                    p.copy_(1.0 + 0.5 * u.abs())
+                elif k.endswith("relative_position_bias_table"):
+                    p.copy_(0.5 * u)
+                elif k.endswith("bn0.weight"):
+                    p.copy_(0.1 + 0.02 * u)
+                elif k.endswith("LayerNorm.weight"):
+                    p.copy_(1.0 + 0.2 * u)
+                elif "embeddings." in k and k.endswith("weight"):
+                    p.copy_(u)
+                else:
+                    off, amp = spec.weight_rule(k, tuple(p.shape))
+                    p.copy_(off + amp * u)
+        return self
+
     @staticmethod
     def _project(seq, x):
         h = _LinearF32.apply(x, seq[0].weight, seq[0].bias)

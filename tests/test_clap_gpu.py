@@ -223,8 +223,8 @@ def test_clap_loss_end_to_end_matches_oracle():
     vae.to(DEV).eval().requires_grad_(False)
     loss = losses.CLAPLoss(vae, reduction="instance", mse_weight=1.0, clap_weight=0.1, clap=clap).to(DEV)
     B = 2
-    z = (cases.vae_inputs(B, 15, 16, "claploss") * 0.5)
-    zt = z + 0.1 * cases.vae_inputs(B, 15, 16, "claploss.t")
+    z = (cases.vae_inputs(B, 12, 16, "claploss") * 0.5)
+    zt = z + 0.1 * cases.vae_inputs(B, 12, 16, "claploss.t")
     gt = det("claploss.gt", (B, 7000), 3) * 0.3                 # shorter than the clip: repeat-padded
     text = F.normalize(det("claploss.text", (B, 512), 4), dim=-1)
     # ---- oracle chain
@@ -254,3 +254,52 @@ def test_clap_loss_end_to_end_matches_oracle():
     gl2 = rel_l2(zd.grad, zo.grad)
     print("CLAP loss d/d latent rel_l2 %.3e" % gl2)
     assert gl2 < 0.3      # dominated by the piecewise-linear vocoder's mask flips; the tower alone: 5e-2
+
+
+def test_audiolcm_clap_finetune_step_runs_and_moves_the_student():
+    """BASELINE configs[4] at toy size through the public path: AudioLCM(loss_type='clap').train_step with ground-truth
+    audio and pre-computed CLAP text features -- consistency generation, differentiable decode, resampler, CLAP tower
+    forward + input gradient, U-Net backward, AdamW, EMA.  Checks the loss against a manual evaluation of the same
+    CLAPLoss on the step's own prediction, that the student moved and the frozen towers did not."""
+    from consistencytta_amd import losses, modules
+    from consistencytta_amd.models import AudioLCM
+    ucfg = cases.TINY_UNET
+    hcfg = dict(cases.TINY_HTSAT, spec_size=128)                       # 256 frames: room for the 64-frame mel of a 16x16 latent
+    clap = C.CLAP_Module(audio_cfg=hcfg, text_cfg=cases.TINY_ROBERTA, clip_samples=3 * (64 * 160 + 32))
+    clap.to(DEV)
+    clap.model.init_random_(seed=3)
+    vsd = dict(cases.vae_weights(cases.TINY_VAE_DD))
+    vsd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
+    vae = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, scale_factor=0.9, hifigan_config=cases.TINY_HIFIGAN)
+    vae.load_state_dict(vsd)
+    vae.to(DEV).eval().requires_grad_(False)
+    m = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                 unet_model_config_path="tiny_light.json", unet_config=ucfg, snr_gamma=5.0, use_edm=True,
+                 teacher_guidance_scale=-1, num_diffusion_steps=18, vae=vae, loss_type="clap", clap_module=clap)
+    m.teacher_unet.load_state_dict(cases.unet_weights(ucfg, False, 0))
+    for net, seed in ((m.student_unet, 1), (m.student_target_unet, 2), (m.student_ema_unet, 3)):
+        net.load_state_dict(cases.unet_weights(ucfg, True, seed))
+    m.to(DEV)
+    m.train()
+    assert isinstance(m.loss, losses.CLAPLoss) and not any(p.requires_grad for p in m.loss.clap.parameters())
+    B = 2
+    P = {k: v.to(DEV) for k, v in cases.prompt_states(ucfg, B, 6, "clapft").items()}
+    ids, mask = cases.roberta_inputs(cases.TINY_ROBERTA, B, 12, "clapft")
+    P["clap_text_features"] = clap.model.get_text_embedding({"input_ids": ids.to(DEV), "attention_mask": mask.to(DEV)})
+    assert abs(float(P["clap_text_features"].norm(dim=1)[0]) - 1.0) < 1e-3
+    z0 = (cases.t(spec.det_uniform("clapft.z0", (B, 8, 16, 16), 14)) * 0.9).to(DEV)
+    gt = (det("clapft.gt", (B, 9000), 5) * 0.3).to(DEV)
+    opt = m.prepare_training(lr=1e-4, weight_decay=0.0, broadcast=False)
+    before = opt.flat.detach().clone()
+    tower_before = m.loss.clap.model.audio_branch.get_parameter("norm.weight").detach().clone()
+    gen = torch.Generator().manual_seed(3)
+    kw = dict(time_inds=torch.randint(0, 17, (B,), generator=gen) * 2,
+              gaussian_noise=torch.randn(B, 8, 16, 16, generator=gen).to(DEV), guidance_scale=torch.rand(B, generator=gen) * 6)
+    v1 = m.train_step(z0, P, opt, None, gt_wav=gt, **kw)
+    torch.cuda.synchronize()
+    assert np.isfinite(v1) and v1 > 0
+    moved = float((opt.flat - before).abs().max())
+    print("CLAP fine-tuning step: loss %.5f, max parameter change %.3e" % (v1, moved))
+    assert moved > 0 and torch.equal(m.loss.clap.model.audio_branch.get_parameter("norm.weight"), tower_before)
+    v2 = m.train_step(z0, P, opt, None, gt_wav=gt, **kw)
+    assert np.isfinite(v2) and v2 != v1
