@@ -815,10 +815,12 @@ static bool wide_store_default() {
   if (v < 0) { const char* e = getenv("CTTA_WIDE_STORE"); v = (e && e[0] == '0') ? 0 : 1; }
   return v != 0;
 }
+static thread_local int t_no_splitk = 0;
+extern "C" void ctta_conv_suppress_splitk(int on) { t_no_splitk = on ? 1 : 0; }
 static bool splitk_default() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("CTTA_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
+  return v != 0 && !t_no_splitk;
 }
 static bool glds_default() {
   static int v = -1;

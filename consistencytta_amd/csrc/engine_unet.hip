@@ -12,6 +12,8 @@
 // columns placed at weight-packing time, so no kernel ever sees an odd width.
 #include "engine_common.h"
 
+#include <stdlib.h>
+
 #include <math.h>
 
 __global__ void add_silu_kernel(const float* __restrict__ a, const float* __restrict__ b,
@@ -136,6 +138,22 @@ struct ctta_unet {
     const bf16_t *enc_bf = nullptr, *xin = nullptr, *h_last = nullptr, *a_out = nullptr;
     const float *mask_bias = nullptr, *st_out = nullptr;
   } ts;
+  // Weight-gradient jobs (transposed im2col, the split-M GEMM, the scatter into the caller's gradient tensors) run on a
+  // SECOND stream: the data-gradient chain on the caller's stream is the critical path of the backward pass, its thin
+  // batch-9 launches leave CUs idle, and a layer's weight gradient depends on nothing that comes after it.  Each job
+  // owns one of NS scratch slots (dY^T is written by the main stream, everything else by the side stream); events
+  // order slot reuse and the joins at block boundaries.  CTTA_WGRAD_STREAM=0 keeps everything on one stream.
+  struct WgradSide {
+    static constexpr int NS = 2;
+    hipStream_t stream = nullptr;
+    Arena slot[NS];
+    char* base = nullptr;
+    hipEvent_t ready[NS] = {nullptr, nullptr}, freed[NS] = {nullptr, nullptr}, joined = nullptr;
+    bool in_use[NS] = {false, false};
+    bool dirty = false;     // side stream has work the main stream has not joined yet
+    int next = 0;
+    bool enabled = false;
+  } wg;
   struct BackwardState {   // between ctta_unet_backward_begin / _next calls
     bool active = false;
     bf16_t* dh = nullptr;
@@ -728,8 +746,30 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
       st = unet_forward_impl(U, true, nullptr, nullptr, nullptr, nullptr, (const uint8_t*)1, cfg->max_batch,
                              cfg->max_text_len, nullptr, s, &gn2, true);
       if (gn2 > gn_need) gn_need = gn2;
+      for (Arena& a : U->wg.slot) { a.dry = true; a.reset(); a.peak = 0; }
       if (st == CTTA_OK) st = unet_backward_impl(U, true, nullptr, nullptr, s, nullptr);
       U->ts.valid = false;
+    }
+  }
+  if (st == CTTA_OK && cfg->enable_training) {   // scratch slots + stream + events of the weight-gradient side stream
+    ctta_unet::WgradSide& W = U->wg;
+    size_t slot_bytes = 0;
+    for (Arena& a : W.slot) if (a.peak > slot_bytes) slot_bytes = a.peak;
+    slot_bytes = (slot_bytes + 4095) & ~(size_t)4095;
+    const char* e = getenv("CTTA_WGRAD_STREAM");
+    W.enabled = !(e && e[0] == '0');
+    if (hipMalloc((void**)&W.base, slot_bytes * ctta_unet::WgradSide::NS + 4096) != hipSuccess) {
+      ctta_set_error("unet_create: hipMalloc of the weight-gradient scratch (%zu bytes) failed", slot_bytes * 2);
+      st = CTTA_ERR_NOMEM;
+    } else {
+      for (int i = 0; i < ctta_unet::WgradSide::NS; ++i) {
+        W.slot[i].dry = false; W.slot[i].base = W.base + (size_t)i * slot_bytes; W.slot[i].cap = slot_bytes; W.slot[i].reset();
+        if (hipEventCreateWithFlags(&W.ready[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&W.freed[i], hipEventDisableTiming) != hipSuccess) st = CTTA_ERR_HIP;
+      }
+      if (hipEventCreateWithFlags(&W.joined, hipEventDisableTiming) != hipSuccess ||
+          hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking) != hipSuccess) st = CTTA_ERR_HIP;
+      if (st != CTTA_OK) ctta_set_error("unet_create: could not create the weight-gradient stream / events");
     }
   }
   if (st == CTTA_OK) {
@@ -758,6 +798,13 @@ extern "C" void ctta_unet_destroy(ctta_unet* U) {
   if (U->arena.base) (void)hipFree(U->arena.base);
   if (U->gn_scratch) (void)hipFree(U->gn_scratch);
   U->splitws.destroy();
+  if (U->wg.stream) { (void)hipStreamSynchronize(U->wg.stream); (void)hipStreamDestroy(U->wg.stream); }
+  for (int i = 0; i < ctta_unet::WgradSide::NS; ++i) {
+    if (U->wg.ready[i]) (void)hipEventDestroy(U->wg.ready[i]);
+    if (U->wg.freed[i]) (void)hipEventDestroy(U->wg.freed[i]);
+  }
+  if (U->wg.joined) (void)hipEventDestroy(U->wg.joined);
+  if (U->wg.base) (void)hipFree(U->wg.base);
   delete U;
 }
 

@@ -25,6 +25,54 @@ struct BCtx : UCtx {
   float* dtemb_all = nullptr;   // [B][temb_total] fp32, filled from the conv1 indicator rows
 };
 
+// One weight-gradient job: `w` is the context its launches use (scratch slot as arena; side stream when enabled).
+struct WgJob {
+  BCtx w;
+  int slot = 0;
+  bool async = false;
+};
+static ctta_status wg_begin(BCtx& c, WgJob* j) {
+  ctta_unet::WgradSide& W = c.U->wg;
+  j->slot = W.next;
+  W.next = (W.next + 1) % ctta_unet::WgradSide::NS;
+  j->async = !c.dry && W.enabled && W.stream != nullptr;
+  j->w = c;
+  j->w.arena = &W.slot[j->slot];
+  W.slot[j->slot].reset();
+  if (j->async) {
+    j->w.stream = W.stream;
+    // the slot's previous job must have drained before the main stream writes dY^T into it
+    if (W.in_use[j->slot]) CTTA_CHECK_HIP(hipStreamWaitEvent(c.stream, W.freed[j->slot], 0));
+  }
+  return CTTA_OK;
+}
+// dY^T is in the slot (written on the main stream): hand over to the side stream
+static ctta_status wg_handoff(BCtx& c, WgJob& j) {
+  if (!j.async) return CTTA_OK;
+  ctta_unet::WgradSide& W = c.U->wg;
+  CTTA_CHECK_HIP(hipEventRecord(W.ready[j.slot], c.stream));
+  CTTA_CHECK_HIP(hipStreamWaitEvent(W.stream, W.ready[j.slot], 0));
+  return CTTA_OK;
+}
+static ctta_status wg_end(BCtx& c, WgJob& j) {
+  if (!j.async) return CTTA_OK;
+  ctta_unet::WgradSide& W = c.U->wg;
+  CTTA_CHECK_HIP(hipEventRecord(W.freed[j.slot], W.stream));
+  W.in_use[j.slot] = true;
+  W.dirty = true;
+  return CTTA_OK;
+}
+// the main stream waits for every weight-gradient job issued so far (block boundaries: the caller may start the
+// all-reduce of the block's gradients; before the embedding MLPs, which read d temb)
+static ctta_status wg_join(BCtx& c) {
+  ctta_unet::WgradSide& W = c.U->wg;
+  if (c.dry || !W.dirty) return CTTA_OK;
+  CTTA_CHECK_HIP(hipEventRecord(W.joined, W.stream));
+  CTTA_CHECK_HIP(hipStreamWaitEvent(c.stream, W.joined, 0));
+  W.dirty = false;
+  return CTTA_OK;
+}
+
 static ctta_status grad_ptr(BCtx& c, const std::string& key, float** out) {
   *out = nullptr;
   if (c.dry) return CTTA_OK;
@@ -52,8 +100,9 @@ static int pick_splits(int64_t M, int R, int N) {
 // slabs[s][n][r] = sum_{m in segment s} dY[m][n] * Q[r][m];  x is the layer input in NHWC (a linear is the 1x1 case
 // with batch=1, hi=rows), dy [M][N] contiguous.  Rows of Q: (channel, tap) then the all-ones row, then `nb`
 // per-sample indicator rows.  Both GEMM operands are made m-contiguous (dY^T, im2col^T).
-static ctta_status wgrad_slabs(BCtx& c, const bf16_t* x, int C, int B, int hi, int wi, bool ups, int ho, int wo, int kh,
-                               int kw, int stride, int pad, const bf16_t* dy, int N, int nb, Slabs* out) {
+static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int B, int hi, int wi, bool ups, int ho, int wo,
+                               int kh, int kw, int stride, int pad, const bf16_t* dy, int N, int nb, Slabs* out) {
+  BCtx& c = job.w;
   Arena& A = *c.arena;
   const int64_t M = (int64_t)B * ho * wo;
   const int K = kh * kw * C;
@@ -65,8 +114,9 @@ static ctta_status wgrad_slabs(BCtx& c, const bf16_t* x, int C, int B, int hi, i
   bf16_t* q = A.get<bf16_t>((size_t)R * mp); ALLOC_OR_FAIL(q);
   bf16_t* pt = A.get<bf16_t>((size_t)N * mp); ALLOC_OR_FAIL(pt);
   float* slabs = A.get<float>((size_t)S * N * ld); ALLOC_OR_FAIL(slabs);
+  RUN(cm, ctta_transpose_bf16(dy, 0, (int)M, N, N, 0, pt, 0, mp, 1, cm.stream));   // dY lives in the main stream's arena
+  if (!cm.dry) CTTA_TRY(wg_handoff(cm, job));
   RUN(c, ctta_im2col_t(x, C, B, hi, wi, ups ? 1 : 0, ho, wo, kh, kw, stride, pad, pad, 1, q, mp, nb, c.stream));
-  RUN(c, ctta_transpose_bf16(dy, 0, (int)M, N, N, 0, pt, 0, mp, 1, c.stream));
   ctta_conv_desc d;
   desc_init(&d);
   d.x0 = pt; d.c0 = seg; d.x_stride = mp;
@@ -74,7 +124,10 @@ static ctta_status wgrad_slabs(BCtx& c, const bf16_t* x, int C, int B, int hi, i
   d.w = q; d.k_pad = mp; d.n = R;
   d.out = slabs; d.ldc = ld; d.out_f32 = 1;
   d.groups = S; d.x_group_stride = seg; d.w_group_stride = seg; d.out_group_stride = (int64_t)N * ld;
-  RUN(c, ctta_conv_gemm(&d, c.stream));
+  if (job.async) ctta_conv_suppress_splitk(1);   // the handle's split-K slabs belong to the main stream's launches
+  const ctta_status gst = c.dry ? CTTA_OK : ctta_conv_gemm(&d, c.stream);
+  if (job.async) ctta_conv_suppress_splitk(0);
+  CTTA_TRY(gst);
   out->p = slabs; out->S = S; out->R = R; out->ld = ld; out->N = N;
   return CTTA_OK;
 }
@@ -98,33 +151,42 @@ static ctta_status scatter_wgrad(BCtx& c, const Slabs& sl, int k_rows, const Pac
 }
 
 static ctta_status conv_wgrad(BCtx& c, const ConvLayer& L, const PackMap& m, const bf16_t* x, int H, int W, bool ups,
-                              const bf16_t* dy, int temb_off = -1) {
-  Arena& A = *c.arena;
-  const size_t mk = A.mark();
+                              const bf16_t* dy, int temb_off = -1, const Resnet* temb_of = nullptr) {
+  WgJob job;
+  CTTA_TRY(wg_begin(c, &job));
+  BCtx& w = job.w;
   const int hi = ups ? 2 * H : H, wi = ups ? 2 * W : W;
   const int ho = (hi + 2 * L.pad - L.kh) / L.stride + 1, wo = (wi + 2 * L.pad - L.kw) / L.stride + 1;
   const int nb = temb_off >= 0 ? c.B : 0;
   Slabs sl;
-  CTTA_TRY(wgrad_slabs(c, x, L.cin_pad, c.B, hi, wi, ups, ho, wo, L.kh, L.kw, L.stride, L.pad, dy, L.p.n, nb, &sl));
+  CTTA_TRY(wgrad_slabs(c, job, x, L.cin_pad, c.B, hi, wi, ups, ho, wo, L.kh, L.kw, L.stride, L.pad, dy, L.p.n, nb, &sl));
   const int K = L.kh * L.kw * L.cin_pad;
-  CTTA_TRY(scatter_wgrad(c, sl, K, m));
+  CTTA_TRY(scatter_wgrad(w, sl, K, m));
   if (nb > 0)   // d temb[b][off + n] = sum over the sample's pixels of dY: columns K+1 .. K+B of the slab
-    RUN(c, ctta_col_scatter(sl.p, sl.S, (int64_t)sl.N * sl.ld, sl.ld, K + 1, nb, L.cout, nullptr,
-                            c.dtemb_all + temb_off, c.U->temb_total, 0, c.stream));
-  A.release(mk);
+    RUN(w, ctta_col_scatter(sl.p, sl.S, (int64_t)sl.N * sl.ld, sl.ld, K + 1, nb, L.cout, nullptr,
+                            c.dtemb_all + temb_off, c.U->temb_total, 0, w.stream));
+  if (temb_of) {  // temb = time_emb_proj(SiLU(emb)): its weight / bias gradients need only this resnet's rows of d temb,
+                  // which the scatter above just produced (same stream, in order)
+    float *gw, *gb;
+    CTTA_TRY(grad_ptr(w, temb_of->key + "time_emb_proj.weight", &gw));
+    CTTA_TRY(grad_ptr(w, temb_of->key + "time_emb_proj.bias", &gb));
+    RUN(w, ctta_linear_f32_bwd(c.U->ts.emb_silu, c.U->temb_w, c.dtemb_all + temb_of->temb_off, c.U->temb_total, nullptr,
+                               nullptr, gw, gb, c.B, temb_of->cout, c.U->temb_dim, 0, 1, w.stream));
+  }
+  if (!c.dry) CTTA_TRY(wg_end(c, job));
   return CTTA_OK;
 }
 
 // linear y = x W^T (+b): x [rows][x_ld] (the first k_rows columns are the GEMM K), dy [rows][N]
 static ctta_status linear_wgrad(BCtx& c, const PackMap& m, const PackMap* m2, const bf16_t* x, int x_ld, int64_t rows,
                                 const bf16_t* dy, int N) {
-  Arena& A = *c.arena;
-  const size_t mk = A.mark();
+  WgJob job;
+  CTTA_TRY(wg_begin(c, &job));
   Slabs sl;
-  CTTA_TRY(wgrad_slabs(c, x, x_ld, 1, (int)rows, 1, false, (int)rows, 1, 1, 1, 1, 0, dy, N, 0, &sl));
-  CTTA_TRY(scatter_wgrad(c, sl, x_ld, m, 0));
-  if (m2) CTTA_TRY(scatter_wgrad(c, sl, x_ld, *m2, m.n));   // fused [q | k]
-  A.release(mk);
+  CTTA_TRY(wgrad_slabs(c, job, x, x_ld, 1, (int)rows, 1, false, (int)rows, 1, 1, 1, 1, 0, dy, N, 0, &sl));
+  CTTA_TRY(scatter_wgrad(job.w, sl, x_ld, m, 0));
+  if (m2) CTTA_TRY(scatter_wgrad(job.w, sl, x_ld, *m2, m.n));   // fused [q | k]
+  if (!c.dry) CTTA_TRY(wg_end(c, job));
   return CTTA_OK;
 }
 
@@ -191,14 +253,7 @@ static ctta_status bwd_resnet(BCtx& c, Resnet& R, const bf16_t* dout, bf16_t** d
   CTTA_TRY(conv_wgrad(c, R.c2, R.t2.m, S.a2, H, W, false, dout));
   bf16_t* dt1 = A.get<bf16_t>(M * R.cout); ALLOC_OR_FAIL(dt1);
   CTTA_TRY(gn_backward(c, R.n2, S.t1, da2, dt1, H * W, S.st2, true, false));
-  CTTA_TRY(conv_wgrad(c, R.c1, R.t1.m, S.a, H, W, false, dt1, R.temb_off));
-  {  // temb = time_emb_proj(SiLU(emb)): its weight / bias gradients need only this resnet's rows of d temb
-    float *gw, *gb;
-    CTTA_TRY(grad_ptr(c, R.key + "time_emb_proj.weight", &gw));
-    CTTA_TRY(grad_ptr(c, R.key + "time_emb_proj.bias", &gb));
-    RUN(c, ctta_linear_f32_bwd(c.U->ts.emb_silu, c.U->temb_w, c.dtemb_all + R.temb_off, c.U->temb_total, nullptr, nullptr,
-                               gw, gb, c.B, R.cout, c.U->temb_dim, 0, 1, c.stream));
-  }
+  CTTA_TRY(conv_wgrad(c, R.c1, R.t1.m, S.a, H, W, false, dt1, R.temb_off, &R));   // + time_emb_proj weight / bias gradients
   bf16_t* da = A.get<bf16_t>(M * R.cin); ALLOC_OR_FAIL(da);
   CTTA_TRY(conv_dgrad(c, R.t1.d, dt1, H, W, da, H, W, false));
   if (R.has_sc) {
@@ -392,6 +447,7 @@ static ctta_status unet_backward_begin_impl(ctta_unet* U, bool dry, const bf16_t
   CTTA_TRY(conv_wgrad(c, co, U->t_conv_out.m, S.a_out, H, W, false, dpred));
   CTTA_TRY(gn_backward(c, U->norm_out, S.h_last, da, dh, H * W, S.st_out, true, false));
   A.release(mk);
+  CTTA_TRY(wg_join(c));   // the out head's gradients are final when this call returns
   U->bw.dh = dh;
   U->bw.active = true;
   return CTTA_OK;
@@ -463,6 +519,7 @@ static ctta_status unet_backward_next_impl(ctta_unet* U, bool dry, const GradTab
   U->bw.dh = dh;
   *block_done = block;
   *finished = 0;
+  CTTA_TRY(wg_join(c));     // this block's weight gradients (and d temb rows) are complete
   if (U->bw.pos == 0) {
     CTTA_TRY(bwd_embeddings(c));
     *finished = 1;

@@ -325,6 +325,9 @@ ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream);
  * device: launches that share it must be ordered on ONE stream -- or the caller binds its own buffer of
  * ctta_conv_workspace_bytes() bytes for the calling thread (NULL unbinds). */
 void ctta_conv_bind_workspace(void* ws, size_t bytes);
+/* on != 0: launches issued by the calling host thread take no split-K path until switched off again (used for GEMMs that
+ * an engine enqueues on a second stream of the same handle, which must not share the handle's partial-sum slabs) */
+void ctta_conv_suppress_splitk(int on);
 size_t ctta_conv_workspace_bytes(void);
 int ctta_conv_gemm_num_variants(void);
 const char* ctta_conv_gemm_variant_name(int id);
