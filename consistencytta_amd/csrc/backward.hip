@@ -640,7 +640,10 @@ extern "C" ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* d
                                           void* stream) {
   CTTA_REQUIRE(x && dy && dx && gamma && dgamma && dbeta, "layernorm_bwd: null pointer (dgamma/dbeta must be zeroed or hold the running sum)");
   CTTA_REQUIRE(ld % 8 == 0 && d <= ld && ld <= 2048, "layernorm_bwd: d=%d ld=%d", d, ld);
-  const int rpb = 64;
+  // rows per block: 64 amortises the per-block dgamma / dbeta atomics on long matrices, but the distillation step's
+  // token matrices are short (9 216 .. 36 864 rows): aim for >= ~2000 blocks so that every CU holds several
+  int rpb = (int)(rows / 2048);
+  rpb = rpb < 8 ? 8 : (rpb > 64 ? 64 : (rpb + 3) / 4 * 4);
   const dim3 grid((unsigned)cdiv64(rows, rpb));
   const size_t smem = (size_t)2 * ld * sizeof(float);
   hipStream_t s = (hipStream_t)stream;

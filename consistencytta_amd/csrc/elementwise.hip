@@ -221,21 +221,28 @@ __global__ void wav_finalize_kernel(const float* __restrict__ x, long long n,
 }
 
 // ------------------------------------------------------------------------------ direct conv
-// Cout <= 8, stride 1, dilation 1.  One thread per output pixel; weights fp32 [n][kh][kw][c].
-template <int N>
+// Cout <= 8, stride 1, dilation 1; weights fp32 [n][kh][kw][c].  LPP lanes share one output pixel: lane `sub` takes the
+// 8-channel chunks sub, sub + LPP, ... of every tap (neighbouring lanes read neighbouring 16-byte chunks) and the partial
+// sums meet in a shuffle reduction.  LPP = 1 is the plain one-thread-per-pixel walk (millions of pixels: enough threads
+// anyway); LPP = 8 serves the U-Net's conv_out, whose 36 864 .. 131 072 pixels x 2304-long dot products would otherwise
+// run as a few hundred long serial loops per CU.
+template <int N, int LPP>
 __global__ __launch_bounds__(256) void conv_small_n_kernel(
     const bf16_t* __restrict__ x, int C, int B, int H, int W, int KH, int KW, int ph, int pw,
     const float* __restrict__ w, const float* __restrict__ bias, int in_act, float in_slope,
     int out_act, float* __restrict__ out, bf16_t* __restrict__ out_bf) {
   const long long total = (long long)B * H * W;
-  const long long m = blockIdx.x * (long long)blockDim.x + threadIdx.x;
-  if (m >= total) return;
-  const int b = (int)(m / ((long long)H * W));
-  const int rem = (int)(m - (long long)b * H * W);
+  const long long gid = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  const long long m = gid / LPP;
+  const int sub = (int)(gid % LPP);
+  const bool live = m < total;
+  const long long mm = live ? m : total - 1;      // idle lanes of the last block still take part in the shuffles
+  const int b = (int)(mm / ((long long)H * W));
+  const int rem = (int)(mm - (long long)b * H * W);
   const int oh = rem / W, ow = rem - oh * W;
   float acc[N];
 #pragma unroll
-  for (int n = 0; n < N; ++n) acc[n] = bias ? bias[n] : 0.f;
+  for (int n = 0; n < N; ++n) acc[n] = (bias && sub == 0) ? bias[n] : 0.f;
   const int K = KH * KW * C;
   for (int kh = 0; kh < KH; ++kh) {
     const int ih = oh - ph + kh;
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256) void conv_small_n_kernel(
       if ((unsigned)iw >= (unsigned)W) continue;
       const bf16_t* xp = x + ((size_t)((size_t)b * H + ih) * W + iw) * C;
       const float* wp = w + (size_t)(kh * KW + kw) * C;
-      for (int c = 0; c < C; c += 8) {
+      for (int c = sub * 8; c < C; c += 8 * LPP) {
         float f[8];
         unpack8(*reinterpret_cast<const uint4*>(xp + c), f);
         if (in_act == 1) {
@@ -262,6 +269,13 @@ __global__ __launch_bounds__(256) void conv_small_n_kernel(
       }
     }
   }
+  if (LPP > 1) {
+#pragma unroll
+    for (int n = 0; n < N; ++n)
+#pragma unroll
+      for (int o = 1; o < LPP; o <<= 1) acc[n] += __shfl_xor(acc[n], o, 64);
+  }
+  if (!live || sub != 0) return;
 #pragma unroll
   for (int n = 0; n < N; ++n) {
     float v = acc[n];
@@ -278,12 +292,15 @@ extern "C" ctta_status ctta_conv_small_n(const void* x, int c, int batch, int hi
   CTTA_REQUIRE(x && w && (out_nchw || out_bf16_nhwc), "conv_small_n: null pointer");
   CTTA_REQUIRE(c % 8 == 0, "conv_small_n: C=%d must be a multiple of 8", c);
   const long long total = (long long)batch * hi * wi;
-  const dim3 grid((unsigned)((total + 255) / 256));
   hipStream_t s = (hipStream_t)stream;
-#define LAUNCH_N(NN)                                                                              \
-  hipLaunchKernelGGL(conv_small_n_kernel<NN>, grid, dim3(256), 0, s, (const bf16_t*)x, c, batch, hi, \
-                     wi, kh, kw, pad_h, pad_w, w, bias, in_act, in_slope, out_act, out_nchw,      \
+  // few pixels with long dot products: 8 lanes per pixel (see the kernel)
+  const int lpp = (total <= (1 << 18) && c >= 64) ? 8 : 1;
+  const dim3 grid((unsigned)((total * lpp + 255) / 256));
+#define LAUNCH_NL(NN, LL)                                                                                 \
+  hipLaunchKernelGGL((conv_small_n_kernel<NN, LL>), grid, dim3(256), 0, s, (const bf16_t*)x, c, batch, hi, \
+                     wi, kh, kw, pad_h, pad_w, w, bias, in_act, in_slope, out_act, out_nchw,              \
                      (bf16_t*)out_bf16_nhwc)
+#define LAUNCH_N(NN) do { if (lpp == 8) LAUNCH_NL(NN, 8); else LAUNCH_NL(NN, 1); } while (0)
   switch (n) {
     case 1: LAUNCH_N(1); break;
     case 2: LAUNCH_N(2); break;
@@ -291,6 +308,7 @@ extern "C" ctta_status ctta_conv_small_n(const void* x, int c, int batch, int hi
     case 8: LAUNCH_N(8); break;
     default: CTTA_REQUIRE(false, "conv_small_n: n=%d unsupported (1,2,4,8)", n);
   }
+#undef LAUNCH_NL
 #undef LAUNCH_N
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
