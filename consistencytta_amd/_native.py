@@ -79,6 +79,7 @@ class ConvDesc(Structure):
         ("out_batch_stride", c_int64), ("out_offset", c_int64), ("out_limit", c_int64),
         ("groups", c_int), ("x_group_stride", c_int64), ("w_group_stride", c_int64),
         ("out_group_stride", c_int64), ("tile", c_int), ("x_stride", c_int),
+        ("gn_part", c_void_p), ("gn_groups", c_int), ("gn_hw", c_int),
     ]
 
 
@@ -157,6 +158,7 @@ SIGNATURES = {
     "ctta_snr_mse_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int64, c_void_p]),
     "ctta_ema_update2": (c_int, [c_void_p, c_void_p, c_double, c_void_p, c_double, c_int64, c_void_p]),
     "ctta_conv_gemm": (c_int, [POINTER(ConvDesc), c_void_p]),
+    "ctta_conv_last_gn_chunks": (c_int, []),
     "ctta_conv_bind_workspace": (None, [c_void_p, c_size_t]),
     "ctta_conv_workspace_bytes": (c_size_t, []),
     "ctta_conv_suppress_splitk": (None, [c_int]),
@@ -195,6 +197,8 @@ SIGNATURES = {
     "ctta_groupnorm_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ctta_groupnorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     "ctta_groupnorm_stats_out": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
+    "ctta_groupnorm_from_partials": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int,
+                                             c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ctta_layernorm": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_void_p, c_float, c_void_p]),
     "ctta_geglu": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ctta_softmax_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),

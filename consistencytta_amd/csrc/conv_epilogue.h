@@ -28,12 +28,17 @@ struct ConvParams {
   // 1: the tile is transposed through LDS and leaves as whole 64..256-byte row segments (see the kernel's epilogue)
   int wide_store;
   int plain_out;   // destination element (m, n) sits at m*ldc + n (no per-batch stride, offset or limit)
+  // GroupNorm statistics of the OUTPUT tensor from the epilogue (wide-store path only): every workgroup writes
+  // (sum, sum of squares) of its BM x BN tile per channel group to gn_part[((b * gn_nchunk + chunk) * gn_G + g) * 2],
+  // chunk = row-tile index inside sample b (gn_hw rows per sample, a multiple of BM) -- the layout gn_finalize_kernel folds.
+  float* gn_part;
+  int gn_cpg, gn_G, gn_hw, gn_nchunk;
 };
 
 // The fused epilogue on 4 consecutive channels of one output row, for the wide-store paths (plain row-major bf16
 // destination: element (m, n) at m*ldc + n): same operation order as epilogue_store.
 __device__ __forceinline__ void epilogue_wide4(const ConvParams& p, const float4 q, const float4 bias4, int m, int n,
-                                               size_t gofs) {
+                                               size_t gofs, float* gn_acc = nullptr) {
   float v[4] = {q.x + bias4.x, q.y + bias4.y, q.z + bias4.z, q.w + bias4.w};
   if (p.bias_m) {
     const float bm = p.bias_m[m];
@@ -72,6 +77,12 @@ __device__ __forceinline__ void epilogue_wide4(const ConvParams& p, const float4
   pk.x = pack2bf(v[0], v[1]);
   pk.y = pack2bf(v[2], v[3]);
   *reinterpret_cast<uint2*>(o) = pk;
+  if (gn_acc) {   // statistics of the values as stored (bf16-rounded), like a separate pass over the tensor would see them
+    const float r0 = __uint_as_float(pk.x << 16), r1 = __uint_as_float(pk.x & 0xffff0000u);
+    const float r2 = __uint_as_float(pk.y << 16), r3 = __uint_as_float(pk.y & 0xffff0000u);
+    gn_acc[0] += (r0 + r1) + (r2 + r3);
+    gn_acc[1] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+  }
   if (p.out2) {   // leaky_relu of the SAME (bf16-rounded) values
     float w2[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),
                    __uint_as_float(pk.y & 0xffff0000u)};

@@ -443,6 +443,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         return;
       }
     }
+    float gacc[2] = {0.f, 0.f};
+    float* const gn_acc = p.gn_part ? gacc : nullptr;
 #pragma unroll
     for (int j0 = 0; j0 < FM; j0 += CJ) {
 #pragma unroll
@@ -457,9 +459,38 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       for (int r = prow; r < CHR; r += RPW) {
         const int m = m0 + wm * TM + j0 * 16 + r;
         if (m < p.M && n_ok)
-          epilogue_wide4(p, *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16), bias4, m, n_lane, (size_t)g * p.ogs);
+          epilogue_wide4(p, *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16), bias4, m, n_lane, (size_t)g * p.ogs,
+                         gn_acc);
       }
       if (j0 + CJ < FM) __syncthreads();
+    }
+    if (p.gn_part) {
+      // GroupNorm statistics of this tile: every lane parks the (sum, sum of squares) of its 4 channels over the rows it
+      // finished, then one thread per channel group adds the entries of its group in a FIXED order (no atomics: the
+      // statistics are bit-reproducible) and writes the tile's partial in gn_finalize_kernel's layout.
+      __syncthreads();   // staging rows are dead
+      float* gl = reinterpret_cast<float*>(smem_raw);   // [NW][64][2]
+      gl[(wave * 64 + lane) * 2] = gacc[0];
+      gl[(wave * 64 + lane) * 2 + 1] = gacc[1];
+      __syncthreads();
+      const int cpg = p.gn_cpg;
+      const int gpt = BN / cpg;                 // groups per tile (host guarantees BN % cpg == 0, cpg % 4 == 0)
+      if (tid < gpt && n0 + tid * cpg < p.n) {
+        const int c_lo = tid * cpg, c_hi = c_lo + cpg;          // tile-local channel range of this group
+        float s1 = 0.f, s2 = 0.f;
+        for (int w = 0; w < NW; ++w) {
+          const int wcol0 = (w % WN) * TN;                      // wave w covers tile-local channels [wcol0, wcol0 + TN)
+          if (wcol0 + TN <= c_lo || wcol0 >= c_hi) continue;
+          for (int l = 0; l < 64; ++l) {
+            const int ch = wcol0 + (l % LPR) * 4;
+            if (ch >= c_lo && ch < c_hi) { s1 += gl[(w * 64 + l) * 2]; s2 += gl[(w * 64 + l) * 2 + 1]; }
+          }
+        }
+        const int b = m0 / p.gn_hw, chunk = (m0 - b * p.gn_hw) / BM;
+        float* dst = p.gn_part + (((size_t)b * p.gn_nchunk + chunk) * p.gn_G + (n0 + c_lo) / cpg) * 2;
+        dst[0] = s1;
+        dst[1] = s2;
+      }
     }
     return;
   }
@@ -854,7 +885,11 @@ static int pick_variant(long long M, int N, long long K, int groups) {
   return N >= 256 ? 2 : 6;                                 // 128x128x32 / 64x128x64 (re-swept with the wide-store epilogue)
 }
 
+static thread_local int t_last_gn_chunks = 0;
+extern "C" int ctta_conv_last_gn_chunks(void) { return t_last_gn_chunks; }
+
 extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
+  t_last_gn_chunks = 0;
   CTTA_REQUIRE(d && d->x0 && d->w && d->out, "conv_gemm: null pointer");
   CTTA_REQUIRE(d->c0 > 0 && d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->c1 >= 0,
                "conv_gemm: channel counts must be multiples of 8 (c0=%d c1=%d)", d->c0, d->c1);
@@ -998,6 +1033,15 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     // linears: the weight matrix is far larger than L2): keep one weight slice hot and walk the XCD's M range
     p.n_inner = (p.n_tiles <= 4 || w_bytes <= (2LL << 20)) ? 1 : 0;   // a <= 2 MB weight matrix stays L2-resident anyway
     grid = dim3((unsigned)(8 * p.xcd_per * p.n_tiles), 1, 1);
+  }
+  if (d->gn_part && d->gn_groups > 0 && d->gn_hw > 0 && splits == 1 && groups == 1 && p.wide_store && !geglu) {
+    // GroupNorm partials from the epilogue: whole tiles per sample and whole channel groups per tile
+    const int cpg = d->n % d->gn_groups == 0 ? d->n / d->gn_groups : 0;
+    if (cpg >= 4 && cpg % 4 == 0 && v.bn % cpg == 0 && d->gn_hw % v.bm == 0 && M % d->gn_hw == 0) {
+      p.gn_part = (float*)d->gn_part; p.gn_cpg = cpg; p.gn_G = d->gn_groups; p.gn_hw = d->gn_hw;
+      p.gn_nchunk = d->gn_hw / v.bm;
+      t_last_gn_chunks = p.gn_nchunk;
+    }
   }
   if (splits > 1) {
     const int ld = (d->n + 3) / 4 * 4;

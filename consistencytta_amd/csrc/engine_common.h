@@ -1,6 +1,8 @@
 // Host-side runtime shared by the three engines: device arenas, the state-dict weight table,
 // weight packing into the conv_gemm layouts, and thin layer launchers.
 #pragma once
+#include <stdlib.h>
+
 #include <functional>
 #include <string>
 #include <unordered_map>
@@ -466,7 +468,36 @@ struct RunCtx {
   std::vector<Tap>* taps;   // non-null when debug taps are recorded
   float* gn_scratch;        // groupnorm scratch (sized for the largest call)
   size_t gn_scratch_floats;
+  // GroupNorm statistics from the producing convolution's epilogue: convolutions / linears whose output may feed a
+  // GroupNorm write per-tile partial sums to gn_fpart; the GroupNorm that consumes exactly that tensor next skips its own
+  // statistics pass (ctta_groupnorm_from_partials).  gn_ready_* describe the tensor the partials in gn_fpart belong to.
+  float* gn_fpart = nullptr;
+  size_t gn_fpart_floats = 0;
+  int gn_groups = 0;
+  const void* gn_ready_x = nullptr;
+  int gn_ready_chunks = 0, gn_ready_c = 0;
 };
+
+static inline void gn_emit_setup(RunCtx& c, ctta_conv_desc* d, int64_t rows_per_sample, int64_t samples) {
+  c.gn_ready_x = nullptr;
+  c.gn_ready_chunks = 0;
+  if (c.dry || !c.gn_fpart || c.gn_groups <= 0 || d->n % c.gn_groups || rows_per_sample < 64) return;
+  if ((size_t)samples * (size_t)(rows_per_sample / 64) * c.gn_groups * 2 > c.gn_fpart_floats) return;   // tiles have >= 64 rows
+  d->gn_part = c.gn_fpart; d->gn_groups = c.gn_groups; d->gn_hw = (int)rows_per_sample;
+}
+static inline void gn_emit_done(RunCtx& c, const ctta_conv_desc& d) {
+  if (c.dry || !d.gn_part) return;
+  const int chunks = ctta_conv_last_gn_chunks();
+  if (chunks > 0) { c.gn_ready_x = d.out; c.gn_ready_chunks = chunks; c.gn_ready_c = d.n; }
+}
+
+
+// fused GroupNorm statistics (engine_common.h: gn_emit_setup): partial-sum buffer appended to the GroupNorm scratch
+static inline bool gn_fuse_enabled() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_GN_FUSE"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
 
 #define RUN(ctx, expr)                 \
   do {                                 \
@@ -502,7 +533,9 @@ static inline ctta_status run_conv2d(RunCtx& c, const ConvLayer& L, const bf16_t
   d.w = L.p.w; d.k_pad = L.p.k_pad; d.n = L.p.n; d.bias = L.p.bias;
   d.rowvec = rowvec; d.rowvec_ld = rowvec_ld; d.res = res; d.res_ld = res_ld;
   d.out = out; d.ldc = L.p.n;
+  gn_emit_setup(c, &d, (int64_t)d.ho * d.wo, B);
   RUN(c, ctta_conv_gemm(&d, c.stream));
+  gn_emit_done(c, d);
   return CTTA_OK;
 }
 
@@ -516,6 +549,7 @@ static inline ctta_status run_linear(RunCtx& c, const PackedW& P, const bf16_t* 
   d.w = P.w; d.k_pad = P.k_pad; d.n = P.n; d.bias = P.bias;
   d.res = res; d.res_ld = res_ld;
   d.out = out; d.ldc = ldc;
+  c.gn_ready_x = nullptr;      // a linear overwrites nothing the partials describe, but ends the producer -> GroupNorm adjacency
   RUN(c, ctta_conv_gemm(&d, c.stream));
   return CTTA_OK;
 }
@@ -554,6 +588,15 @@ static inline ctta_status run_gn(RunCtx& c, const GNLayer& g, const bf16_t* x, b
   if (!c.dry && ctta_groupnorm_scratch_floats(B, hw, g.c, groups) > c.gn_scratch_floats) {
     ctta_set_error("groupnorm scratch too small");
     return CTTA_ERR_INVALID;
+  }
+  if (!c.dry && c.gn_ready_x == (const void*)x && c.gn_ready_chunks > 0 && c.gn_ready_c == g.c && groups == c.gn_groups) {
+    // the convolution that produced x already summed it per (sample, row tile, group)
+    const int chunks = c.gn_ready_chunks;
+    c.gn_ready_x = nullptr;
+    c.gn_ready_chunks = 0;
+    CTTA_TRY(ctta_groupnorm_from_partials(x, y, B, hw, g.c, groups, g.gamma, g.beta, eps, silu ? 1 : 0, c.gn_fpart, chunks,
+                                          c.gn_scratch, stats, c.stream));
+    return CTTA_OK;
   }
   RUN(c, ctta_groupnorm_stats_out(x, y, B, hw, g.c, groups, g.gamma, g.beta, eps, silu ? 1 : 0, c.gn_scratch, stats,
                                   c.stream));

@@ -125,6 +125,7 @@ struct ctta_unet {
   int temb_dim = 0, temb_total = 0, cin_pad = 0, xp = 0;
   float* gn_scratch = nullptr;
   size_t gn_scratch_floats = 0;
+  size_t gn_fpart_floats = 0;   // fused-statistics partials, stored behind the gn_scratch_floats of scratch
   SplitWs splitws;   // this handle's split-K workspace (bound per entry point)
   // ---- training state (cfg.enable_training)
   ConvTrain t_conv_in, t_conv_out;
@@ -404,6 +405,8 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   c.arena = &U->arena; c.stream = stream; c.dry = dry;
   c.taps = cfg.debug_taps ? &U->taps : nullptr;
   c.gn_scratch = U->gn_scratch; c.gn_scratch_floats = U->gn_scratch_floats;
+  if (U->gn_scratch && gn_fuse_enabled()) { c.gn_fpart = U->gn_scratch + U->gn_scratch_floats; c.gn_fpart_floats = U->gn_fpart_floats; }
+  c.gn_groups = cfg.norm_num_groups;
   c.U = U; c.B = B; c.L = L; c.Lp = round_up(L, 8);
   Arena& A = U->arena;
   A.reset();
@@ -777,7 +780,8 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
     U->arena.dry = false;
     U->arena.cap = bytes;
     if (hipMalloc((void**)&U->arena.base, bytes) != hipSuccess ||
-        hipMalloc((void**)&U->gn_scratch, (gn_need + 64) * sizeof(float)) != hipSuccess) {
+        hipMalloc((void**)&U->gn_scratch, (gn_need + 64 + (U->gn_fpart_floats = (size_t)cfg->max_batch * (cfg->height * cfg->width / 64 + 1) *
+                                                            cfg->norm_num_groups * 2)) * sizeof(float)) != hipSuccess) {
       ctta_set_error("unet_create: hipMalloc of %zu-byte activation arena failed", bytes);
       st = CTTA_ERR_NOMEM;
     } else {

@@ -100,6 +100,7 @@ struct ctta_vae {
   int block_in = 0, c_last = 0;
   float* gn_scratch = nullptr;
   size_t gn_scratch_floats = 0;
+  size_t gn_fpart_floats = 0;
   SplitWs splitws;
   // enable_grad (CLAPLoss's differentiable decode, tools/losses.py:294-296)
   ConvLayer d_conv_in;
@@ -279,6 +280,8 @@ static ctta_status vae_forward_impl(ctta_vae* V, bool dry, const float* z, int B
   c.arena = &V->arena; c.stream = stream; c.dry = dry;
   c.taps = cfg.debug_taps ? &V->taps : nullptr;
   c.gn_scratch = V->gn_scratch; c.gn_scratch_floats = V->gn_scratch_floats;
+  if (V->gn_scratch && gn_fuse_enabled()) { c.gn_fpart = V->gn_scratch + V->gn_scratch_floats; c.gn_fpart_floats = V->gn_fpart_floats; }
+  c.gn_groups = 32;
   c.B = B;
   c.grad = grad;
   V->sv.B = grad ? B : 0;
@@ -461,6 +464,8 @@ static ctta_status vae_backward_impl(ctta_vae* V, bool dry, const float* gmel, i
   c.arena = &V->arena; c.stream = stream; c.dry = dry;
   c.taps = nullptr;
   c.gn_scratch = V->gn_scratch; c.gn_scratch_floats = V->gn_scratch_floats;
+  if (V->gn_scratch && gn_fuse_enabled()) { c.gn_fpart = V->gn_scratch + V->gn_scratch_floats; c.gn_fpart_floats = V->gn_fpart_floats; }
+  c.gn_groups = 32;
   c.B = B;
   Arena& A = V->arena;   // continues above the differentiable forward's saved tensors
   const int up = 1 << (cfg.n_levels - 1);
@@ -572,7 +577,8 @@ extern "C" ctta_status ctta_vae_create(const ctta_vae_config* cfg, const ctta_te
     V->arena.dry = false;
     V->arena.cap = bytes;
     if (hipMalloc((void**)&V->arena.base, bytes) != hipSuccess ||
-        hipMalloc((void**)&V->gn_scratch, (gn_need + 64) * sizeof(float)) != hipSuccess) {
+        hipMalloc((void**)&V->gn_scratch, (gn_need + 64 + (V->gn_fpart_floats = (size_t)cfg->max_batch *
+                                                            ((size_t)cfg->latent_h * cfg->latent_w * 16 / 64 + 1) * 32 * 2)) * sizeof(float)) != hipSuccess) {
       ctta_set_error("vae_create: hipMalloc of %zu-byte activation arena failed", bytes);
       st = CTTA_ERR_NOMEM;
     } else {
@@ -657,6 +663,7 @@ struct ctta_vae_encoder {
   int block_in = 0, zc2 = 0;
   float* gn_scratch = nullptr;
   size_t gn_scratch_floats = 0;
+  size_t gn_fpart_floats = 0;
   SplitWs splitws;
 };
 
@@ -682,6 +689,8 @@ static ctta_status vae_encode_impl(ctta_vae_encoder* E, bool dry, const float* m
   c.arena = &E->arena; c.stream = stream; c.dry = dry;
   c.taps = cfg.debug_taps ? &E->taps : nullptr;
   c.gn_scratch = E->gn_scratch; c.gn_scratch_floats = E->gn_scratch_floats;
+  if (E->gn_scratch && gn_fuse_enabled()) { c.gn_fpart = E->gn_scratch + E->gn_scratch_floats; c.gn_fpart_floats = E->gn_fpart_floats; }
+  c.gn_groups = 32;
   c.B = B;
   Arena& A = E->arena;
   A.reset();
@@ -804,7 +813,8 @@ extern "C" ctta_status ctta_vae_encoder_create(const ctta_vae_config* cfg, const
     E->arena.dry = false;
     E->arena.cap = bytes;
     if (hipMalloc((void**)&E->arena.base, bytes) != hipSuccess ||
-        hipMalloc((void**)&E->gn_scratch, (gn_need + 64) * sizeof(float)) != hipSuccess) {
+        hipMalloc((void**)&E->gn_scratch, (gn_need + 64 + (E->gn_fpart_floats = (size_t)cfg->max_batch *
+                                                            ((size_t)cfg->latent_h * cfg->latent_w * 16 / 64 + 1) * 32 * 2)) * sizeof(float)) != hipSuccess) {
       ctta_set_error("vae_encoder_create: hipMalloc of %zu-byte activation arena failed", bytes);
       st = CTTA_ERR_NOMEM;
     } else {

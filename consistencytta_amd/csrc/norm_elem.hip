@@ -403,6 +403,28 @@ extern "C" ctta_status ctta_groupnorm_stats_out(const void* x, void* y, int batc
   return CTTA_OK;
 }
 
+// GroupNorm(+SiLU) whose (sum, sum of squares) partials already exist -- written by the producing convolution's epilogue
+// (ctta_conv_desc.gn_part) in the [batch][nchunk][groups][2] layout: finalize + apply only, one read of x instead of two.
+// scratch: >= batch * 2 * c floats (scale / shift).
+extern "C" ctta_status ctta_groupnorm_from_partials(const void* x, void* y, int batch, int hw, int c, int groups,
+                                                    const float* gamma, const float* beta, float eps, int silu,
+                                                    const float* partials, int nchunk, float* scratch, float* stats,
+                                                    void* stream) {
+  CTTA_REQUIRE(x && y && gamma && beta && partials && scratch && nchunk >= 1, "groupnorm_from_partials: null pointer");
+  CTTA_REQUIRE(c % 8 == 0 && groups > 0 && c % groups == 0, "groupnorm_from_partials: C=%d groups=%d unsupported", c, groups);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, partials, nchunk, groups, c, hw, gamma, beta, eps,
+                     scratch, stats);
+  CTTA_LAUNCH_CHECK();
+  const int VC = c / 8;
+  const long long total_vec = (long long)batch * hw * VC;
+  const int blocks = (int)fmin((double)cdiv64(total_vec, 256), 8192.0);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, hw, c, scratch, silu,
+                     total_vec);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
 // ------------------------------------------------------------------------------ LayerNorm
 // One wave per row; the row (<= 2048 padded columns) lives in registers: two-pass variance.
 template <int MAXV>

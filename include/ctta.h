@@ -315,9 +315,17 @@ typedef struct {
   int groups; int64_t x_group_stride, w_group_stride, out_group_stride;
   int tile;                   /* 0 = auto; else force a kernel variant id (tuning) */
   int x_stride;               /* 0 -> c0; else row stride of x0 in elements (column slice of a wider matrix) */
+  /* GroupNorm statistics of the output from the epilogue (saves GroupNorm's own read pass over the tensor): when
+   * gn_part != NULL, gn_groups divides n and gn_hw (rows per sample) divides the row count, every workgroup writes
+   * (sum, sum of squares) per channel group of its tile to gn_part [batch][chunks][gn_groups][2] fp32, chunks = gn_hw /
+   * tile rows.  Only some launches can do it (plain bf16 output through the wide-store epilogue, whole tiles per sample,
+   * no split-K): ctta_conv_last_gn_chunks() tells the caller whether -- and with how many chunks -- it happened. */
+  void* gn_part; int gn_groups; int gn_hw;
 } ctta_conv_desc;
 
 ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream);
+/* chunks per sample of the GroupNorm partials the calling thread's LAST ctta_conv_gemm wrote (0: none were written) */
+int ctta_conv_last_gn_chunks(void);
 /* Split-K partial sums (deep, narrow problems: < 192 output tiles and K >= 1024) go through a device workspace.
  * Threading contract: every engine handle (ctta_unet / ctta_vae / ctta_hifigan / ctta_t5 ...) owns its own workspace
  * and binds it to the calling host thread inside each of its entry points, so different handles may run on different
@@ -416,6 +424,11 @@ ctta_status ctta_groupnorm(const void* x, void* y, int batch, int hw, int c, int
 ctta_status ctta_groupnorm_stats_out(const void* x, void* y, int batch, int hw, int c, int groups,
                                      const float* gamma, const float* beta, float eps, int silu,
                                      float* scratch, float* stats, void* stream);
+/* Same normalisation from partial sums that a convolution's epilogue already wrote (ctta_conv_desc.gn_part, `nchunk` =
+ * ctta_conv_last_gn_chunks()): finalize + apply, no statistics pass over x.  scratch: >= batch * 2 * c floats. */
+ctta_status ctta_groupnorm_from_partials(const void* x, void* y, int batch, int hw, int c, int groups,
+                                         const float* gamma, const float* beta, float eps, int silu,
+                                         const float* partials, int nchunk, float* scratch, float* stats, void* stream);
 /* LayerNorm over rows of a padded bf16 matrix: dims [rows][ld], true width d (pad -> 0). */
 ctta_status ctta_layernorm(const void* x, void* y, int64_t rows, int d, int ld,
                            const float* gamma, const float* beta, float eps, void* stream);
