@@ -465,31 +465,39 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       if (j0 + CJ < FM) __syncthreads();
     }
     if (p.gn_part) {
-      // GroupNorm statistics of this tile: every lane parks the (sum, sum of squares) of its 4 channels over the rows it
-      // finished, then one thread per channel group adds the entries of its group in a FIXED order (no atomics: the
-      // statistics are bit-reproducible) and writes the tile's partial in gn_finalize_kernel's layout.
-      __syncthreads();   // staging rows are dead
-      float* gl = reinterpret_cast<float*>(smem_raw);   // [NW][64][2]
-      gl[(wave * 64 + lane) * 2] = gacc[0];
-      gl[(wave * 64 + lane) * 2 + 1] = gacc[1];
-      __syncthreads();
+      // GroupNorm statistics of this tile.  Inside a wave the lanes of one channel group (cw / 4 neighbouring column
+      // lanes x all row lanes) fold their (sum, sum of squares) with a fixed butterfly; one lane per group parks the wave's
+      // value in LDS and one thread per group adds the waves in a FIXED order (no atomics: bit-reproducible) and writes the
+      // tile's partial in gn_finalize_kernel's layout.
       const int cpg = p.gn_cpg;
-      const int gpt = BN / cpg;                 // groups per tile (host guarantees BN % cpg == 0, cpg % 4 == 0)
+      const int cw = cpg < TN ? cpg : TN;        // channels of one group inside a wave's TN columns
+      const int LG = cw / 4;                     // column lanes per group (power of two)
+      float s1 = gacc[0], s2 = gacc[1];
+      for (int o = 1; o < LG; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
+      __syncthreads();   // staging rows are dead
+      float* gl = reinterpret_cast<float*>(smem_raw);   // [NW][TN / 4][2] (one slot per column lane, only group leaders write)
+      if (prow == 0 && col4 % LG == 0) {
+        gl[(wave * LPR + col4 / LG) * 2] = s1;
+        gl[(wave * LPR + col4 / LG) * 2 + 1] = s2;
+      }
+      __syncthreads();
+      const int gpt = BN / cpg;                  // groups per tile (host guarantees BN % cpg == 0, cpg % 4 == 0)
       if (tid < gpt && n0 + tid * cpg < p.n) {
         const int c_lo = tid * cpg, c_hi = c_lo + cpg;          // tile-local channel range of this group
-        float s1 = 0.f, s2 = 0.f;
-        for (int w = 0; w < NW; ++w) {
-          const int wcol0 = (w % WN) * TN;                      // wave w covers tile-local channels [wcol0, wcol0 + TN)
-          if (wcol0 + TN <= c_lo || wcol0 >= c_hi) continue;
-          for (int l = 0; l < 64; ++l) {
-            const int ch = wcol0 + (l % LPR) * 4;
-            if (ch >= c_lo && ch < c_hi) { s1 += gl[(w * 64 + l) * 2]; s2 += gl[(w * 64 + l) * 2 + 1]; }
+        float t1 = 0.f, t2 = 0.f;
+        for (int wr = 0; wr < WM; ++wr)
+          for (int wc = c_lo / TN; wc * TN < c_hi; ++wc) {
+            const int w = wr * WN + wc;
+            const int lo = c_lo > wc * TN ? c_lo - wc * TN : 0;    // first channel of the group inside this wave's columns
+            t1 += gl[(w * LPR + lo / cw) * 2];
+            t2 += gl[(w * LPR + lo / cw) * 2 + 1];
           }
-        }
         const int b = m0 / p.gn_hw, chunk = (m0 - b * p.gn_hw) / BM;
         float* dst = p.gn_part + (((size_t)b * p.gn_nchunk + chunk) * p.gn_G + (n0 + c_lo) / cpg) * 2;
-        dst[0] = s1;
-        dst[1] = s2;
+        dst[0] = t1;
+        dst[1] = t2;
       }
     }
     return;

@@ -256,19 +256,21 @@ def test_groupnorm_statistics_from_the_conv_epilogue(B, C, H, W, Cout, tile):
     wp, k_pad = pack_conv_weight(w)
     out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
     part = torch.full((B * (H * W // 64 + 1) * G * 2,), float("nan"), dtype=torch.float32, device=DEV)
-    d = conv_desc(x0=nhwc_bf16(x), c0=C, batch=B, hi=H, wi=W, ho=H, wo=W, kh=3, kw=3, pad_h=1, pad_w=1, w=wp, k_pad=k_pad,
-                  n=Cout, bias=b.to(DEV), res=nhwc_bf16(res), res_ld=Cout, out=out, ldc=Cout, tile=tile, gn_part=part,
+    xd, bdev, resd = nhwc_bf16(x), b.to(DEV), nhwc_bf16(res)
+    d = conv_desc(x0=xd, c0=C, batch=B, hi=H, wi=W, ho=H, wo=W, kh=3, kw=3, pad_h=1, pad_w=1, w=wp, k_pad=k_pad,
+                  n=Cout, bias=bdev, res=resd, res_ld=Cout, out=out, ldc=Cout, tile=tile, gn_part=part,
                   gn_groups=G, gn_hw=H * W)
     run_conv(d)
     chunks = L_.ctta_conv_last_gn_chunks()
     assert chunks >= 1 and (H * W) % chunks == 0, "this launch should have produced GroupNorm partials"
     assert bool(torch.isfinite(part[:B * chunks * G * 2]).all())
+    gd, bd = gamma.to(DEV), beta.to(DEV)
     scratch = torch.empty(L_.ctta_groupnorm_scratch_floats(B, H * W, Cout, G) + B * 2 * Cout, dtype=torch.float32, device=DEV)
     y_f, y_s = torch.empty_like(out), torch.empty_like(out)
     st_f, st_s = (torch.empty(B, G, 2, dtype=torch.float32, device=DEV) for _ in range(2))
-    N.check(L_.ctta_groupnorm_from_partials(N.ptr(out), N.ptr(y_f), B, H * W, Cout, G, N.ptr(gamma.to(DEV)), N.ptr(beta.to(DEV)),
+    N.check(L_.ctta_groupnorm_from_partials(N.ptr(out), N.ptr(y_f), B, H * W, Cout, G, N.ptr(gd), N.ptr(bd),
                                             1e-5, 1, N.ptr(part), chunks, N.ptr(scratch), N.ptr(st_f), N.stream_ptr()))
-    N.check(L_.ctta_groupnorm_stats_out(N.ptr(out), N.ptr(y_s), B, H * W, Cout, G, N.ptr(gamma.to(DEV)), N.ptr(beta.to(DEV)),
+    N.check(L_.ctta_groupnorm_stats_out(N.ptr(out), N.ptr(y_s), B, H * W, Cout, G, N.ptr(gd), N.ptr(bd),
                                         1e-5, 1, N.ptr(scratch), N.ptr(st_s), N.stream_ptr()))
     sync()
     assert rel_err(st_f[..., 0], st_s[..., 0]) < 1e-5 and rel_err(st_f[..., 1], st_s[..., 1]) < 1e-5     # mean, rstd
@@ -276,10 +278,10 @@ def test_groupnorm_statistics_from_the_conv_epilogue(B, C, H, W, Cout, tile):
     ref = F.silu(F.group_norm(from_nhwc(out), G, gamma, beta, 1e-5))
     assert rel_err(from_nhwc(y_f), ref) < BF16_TOL
     # launches that cannot provide the statistics say so instead of writing garbage: split-K (deep and narrow) ...
-    d2 = conv_desc(x0=nhwc_bf16(bf16_round(det("gnf.x2", (1, 1024, 4, 4), 7))), c0=1024, batch=1, hi=4, wi=4, ho=4, wo=4, kh=3,
-                   kw=3, pad_h=1, pad_w=1, w=pack_conv_weight(bf16_round(det("gnf.w2", (256, 1024, 3, 3), 8) * 0.01))[0],
-                   k_pad=9216, n=256, out=torch.empty(1, 4, 4, 256, dtype=torch.bfloat16, device=DEV), ldc=256, gn_part=part,
-                   gn_groups=G, gn_hw=16)
+    x2, w2 = nhwc_bf16(bf16_round(det("gnf.x2", (1, 1024, 4, 4), 7))), pack_conv_weight(bf16_round(det("gnf.w2", (256, 1024, 3, 3), 8) * 0.01))[0]
+    o2 = torch.empty(1, 4, 4, 256, dtype=torch.bfloat16, device=DEV)
+    d2 = conv_desc(x0=x2, c0=1024, batch=1, hi=4, wi=4, ho=4, wo=4, kh=3, kw=3, pad_h=1, pad_w=1, w=w2, k_pad=9216, n=256,
+                   out=o2, ldc=256, gn_part=part, gn_groups=G, gn_hw=16)
     run_conv(d2)
     assert L_.ctta_conv_last_gn_chunks() == 0
 
