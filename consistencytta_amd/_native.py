@@ -79,7 +79,7 @@ class ConvDesc(Structure):
         ("out_batch_stride", c_int64), ("out_offset", c_int64), ("out_limit", c_int64),
         ("groups", c_int), ("x_group_stride", c_int64), ("w_group_stride", c_int64),
         ("out_group_stride", c_int64), ("tile", c_int), ("x_stride", c_int),
-        ("gn_part", c_void_p), ("gn_groups", c_int), ("gn_hw", c_int),
+        ("gn_part", c_void_p), ("gn_groups", c_int), ("gn_hw", c_int), ("gn_part_floats", c_int64),
     ]
 
 

@@ -465,39 +465,24 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       if (j0 + CJ < FM) __syncthreads();
     }
     if (p.gn_part) {
-      // GroupNorm statistics of this tile.  Inside a wave the lanes of one channel group (cw / 4 neighbouring column
-      // lanes x all row lanes) fold their (sum, sum of squares) with a fixed butterfly; one lane per group parks the wave's
-      // value in LDS and one thread per group adds the waves in a FIXED order (no atomics: bit-reproducible) and writes the
-      // tile's partial in gn_finalize_kernel's layout.
+      // GroupNorm statistics.  Inside a wave the lanes of one channel group (cw / 4 neighbouring column lanes x all row
+      // lanes) fold their (sum, sum of squares) with a fixed butterfly, and the group's leader lane writes the WAVE's
+      // partial straight to global memory: one "chunk" per (row tile, wave row, column slice of a group wider than the
+      // wave), no LDS, no barrier, no atomics (bit-reproducible).  gn_finalize_kernel adds the chunks.
       const int cpg = p.gn_cpg;
       const int cw = cpg < TN ? cpg : TN;        // channels of one group inside a wave's TN columns
       const int LG = cw / 4;                     // column lanes per group (power of two)
+      const int SUB = cpg / cw;                  // wave columns a group spans (1 unless cpg > TN)
       float s1 = gacc[0], s2 = gacc[1];
       for (int o = 1; o < LG; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
-      __syncthreads();   // staging rows are dead
-      float* gl = reinterpret_cast<float*>(smem_raw);   // [NW][TN / 4][2] (one slot per column lane, only group leaders write)
-      if (prow == 0 && col4 % LG == 0) {
-        gl[(wave * LPR + col4 / LG) * 2] = s1;
-        gl[(wave * LPR + col4 / LG) * 2 + 1] = s2;
-      }
-      __syncthreads();
-      const int gpt = BN / cpg;                  // groups per tile (host guarantees BN % cpg == 0, cpg % 4 == 0)
-      if (tid < gpt && n0 + tid * cpg < p.n) {
-        const int c_lo = tid * cpg, c_hi = c_lo + cpg;          // tile-local channel range of this group
-        float t1 = 0.f, t2 = 0.f;
-        for (int wr = 0; wr < WM; ++wr)
-          for (int wc = c_lo / TN; wc * TN < c_hi; ++wc) {
-            const int w = wr * WN + wc;
-            const int lo = c_lo > wc * TN ? c_lo - wc * TN : 0;    // first channel of the group inside this wave's columns
-            t1 += gl[(w * LPR + lo / cw) * 2];
-            t2 += gl[(w * LPR + lo / cw) * 2 + 1];
-          }
-        const int b = m0 / p.gn_hw, chunk = (m0 - b * p.gn_hw) / BM;
-        float* dst = p.gn_part + (((size_t)b * p.gn_nchunk + chunk) * p.gn_G + (n0 + c_lo) / cpg) * 2;
-        dst[0] = t1;
-        dst[1] = t2;
+      if (prow == 0 && col4 % LG == 0 && n_ok) {
+        const int b = m0 / p.gn_hw;
+        const int chunk = (((m0 - b * p.gn_hw) / BM) * WM + wm) * SUB + (wn % SUB);
+        const int grp = n_lane / cpg;
+        float* dst = p.gn_part + (((size_t)b * p.gn_nchunk + chunk) * p.gn_G + grp) * 2;
+        *reinterpret_cast<float2*>(dst) = make_float2(s1, s2);
       }
     }
     return;
@@ -759,6 +744,7 @@ static float* splitk_workspace(size_t* bytes) {
 struct Variant {
   const char* name;
   int bm, bn, bk;
+  int wm, wn;
   int mode;
   void (*launch)(const ConvParams&, dim3, hipStream_t);
   ctta_status (*prepare)();
@@ -785,7 +771,7 @@ static ctta_status prepare_variant() {
 }
 
 #define VARIANT(BM, BN, BK, WM, WN, G, S) \
-  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN "_m" #G "_s" #S, BM, BN, BK, G, \
+  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN "_m" #G "_s" #S, BM, BN, BK, WM, WN, G, \
    launch_variant<BM, BN, BK, WM, WN, G, S>, prepare_variant<BM, BN, BK, WM, WN, G, S>}
 
 static const Variant kVariants[] = {
@@ -1043,12 +1029,17 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     grid = dim3((unsigned)(8 * p.xcd_per * p.n_tiles), 1, 1);
   }
   if (d->gn_part && d->gn_groups > 0 && d->gn_hw > 0 && splits == 1 && groups == 1 && p.wide_store && !geglu) {
-    // GroupNorm partials from the epilogue: whole tiles per sample and whole channel groups per tile
+    // GroupNorm partials from the epilogue: whole tiles per sample, whole groups per tile, a lane's 4 channels in one group
     const int cpg = d->n % d->gn_groups == 0 ? d->n / d->gn_groups : 0;
-    if (cpg >= 4 && cpg % 4 == 0 && v.bn % cpg == 0 && d->gn_hw % v.bm == 0 && M % d->gn_hw == 0) {
-      p.gn_part = (float*)d->gn_part; p.gn_cpg = cpg; p.gn_G = d->gn_groups; p.gn_hw = d->gn_hw;
-      p.gn_nchunk = d->gn_hw / v.bm;
-      t_last_gn_chunks = p.gn_nchunk;
+    const int tn = v.bn / v.wn;
+    if (cpg >= 4 && (cpg & (cpg - 1)) == 0 && v.bn % cpg == 0 && d->gn_hw % v.bm == 0 && M % d->gn_hw == 0) {
+      const int sub = cpg > tn ? cpg / tn : 1;
+      const int nchunk = d->gn_hw / v.bm * v.wm * sub;
+      if ((long long)(M / d->gn_hw) * nchunk * d->gn_groups * 2 <= (long long)d->gn_part_floats) {
+        p.gn_part = (float*)d->gn_part; p.gn_cpg = cpg; p.gn_G = d->gn_groups; p.gn_hw = d->gn_hw;
+        p.gn_nchunk = nchunk;
+        t_last_gn_chunks = nchunk;
+      }
     }
   }
   if (splits > 1) {

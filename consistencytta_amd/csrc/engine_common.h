@@ -482,8 +482,9 @@ static inline void gn_emit_setup(RunCtx& c, ctta_conv_desc* d, int64_t rows_per_
   c.gn_ready_x = nullptr;
   c.gn_ready_chunks = 0;
   if (c.dry || !c.gn_fpart || c.gn_groups <= 0 || d->n % c.gn_groups || rows_per_sample < 64) return;
-  if ((size_t)samples * (size_t)(rows_per_sample / 64) * c.gn_groups * 2 > c.gn_fpart_floats) return;   // tiles have >= 64 rows
+  (void)samples;
   d->gn_part = c.gn_fpart; d->gn_groups = c.gn_groups; d->gn_hw = (int)rows_per_sample;
+  d->gn_part_floats = (int64_t)c.gn_fpart_floats;
 }
 static inline void gn_emit_done(RunCtx& c, const ctta_conv_desc& d) {
   if (c.dry || !d.gn_part) return;

@@ -780,7 +780,7 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
     U->arena.dry = false;
     U->arena.cap = bytes;
     if (hipMalloc((void**)&U->arena.base, bytes) != hipSuccess ||
-        hipMalloc((void**)&U->gn_scratch, (gn_need + 64 + (U->gn_fpart_floats = (size_t)cfg->max_batch * (cfg->height * cfg->width / 64 + 1) *
+        hipMalloc((void**)&U->gn_scratch, (gn_need + 64 + (U->gn_fpart_floats = (size_t)cfg->max_batch * (cfg->height * cfg->width / 16 + 1) *
                                                             cfg->norm_num_groups * 2)) * sizeof(float)) != hipSuccess) {
       ctta_set_error("unet_create: hipMalloc of %zu-byte activation arena failed", bytes);
       st = CTTA_ERR_NOMEM;

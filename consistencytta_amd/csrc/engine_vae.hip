@@ -578,7 +578,7 @@ extern "C" ctta_status ctta_vae_create(const ctta_vae_config* cfg, const ctta_te
     V->arena.cap = bytes;
     if (hipMalloc((void**)&V->arena.base, bytes) != hipSuccess ||
         hipMalloc((void**)&V->gn_scratch, (gn_need + 64 + (V->gn_fpart_floats = (size_t)cfg->max_batch *
-                                                            ((size_t)cfg->latent_h * cfg->latent_w * 16 / 64 + 1) * 32 * 2)) * sizeof(float)) != hipSuccess) {
+                                                            ((size_t)cfg->latent_h * cfg->latent_w * 16 / 16 + 1) * 32 * 2)) * sizeof(float)) != hipSuccess) {
       ctta_set_error("vae_create: hipMalloc of %zu-byte activation arena failed", bytes);
       st = CTTA_ERR_NOMEM;
     } else {
@@ -814,7 +814,7 @@ extern "C" ctta_status ctta_vae_encoder_create(const ctta_vae_config* cfg, const
     E->arena.cap = bytes;
     if (hipMalloc((void**)&E->arena.base, bytes) != hipSuccess ||
         hipMalloc((void**)&E->gn_scratch, (gn_need + 64 + (E->gn_fpart_floats = (size_t)cfg->max_batch *
-                                                            ((size_t)cfg->latent_h * cfg->latent_w * 16 / 64 + 1) * 32 * 2)) * sizeof(float)) != hipSuccess) {
+                                                            ((size_t)cfg->latent_h * cfg->latent_w * 16 / 16 + 1) * 32 * 2)) * sizeof(float)) != hipSuccess) {
       ctta_set_error("vae_encoder_create: hipMalloc of %zu-byte activation arena failed", bytes);
       st = CTTA_ERR_NOMEM;
     } else {

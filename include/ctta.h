@@ -321,6 +321,7 @@ typedef struct {
    * tile rows.  Only some launches can do it (plain bf16 output through the wide-store epilogue, whole tiles per sample,
    * no split-K): ctta_conv_last_gn_chunks() tells the caller whether -- and with how many chunks -- it happened. */
   void* gn_part; int gn_groups; int gn_hw;
+  int64_t gn_part_floats;     /* capacity of gn_part; launches whose partials would not fit write none */
 } ctta_conv_desc;
 
 ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream);

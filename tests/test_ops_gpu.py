@@ -240,7 +240,7 @@ def test_fused_resblock_unit(C, k, d, L, B):
                                        N.ptr(b2d), 0.1, N.ptr(out), 0, 1.0, 0.0, N.stream_ptr()))
 
 
-@pytest.mark.parametrize("B,C,H,W,Cout,tile", [(2, 64, 16, 16, 128, 0), (3, 128, 32, 8, 256, 0), (2, 256, 16, 16, 512, 0),
+@pytest.mark.parametrize("B,C,H,W,Cout,tile", [(2, 64, 16, 16, 128, 0), (3, 128, 32, 8, 256, 0), (4, 256, 64, 64, 512, 0),
                                                (1, 64, 64, 64, 128, 0), (2, 64, 16, 16, 128, 17), (2, 128, 16, 16, 256, 29)])
 def test_groupnorm_statistics_from_the_conv_epilogue(B, C, H, W, Cout, tile):
     """ctta_conv_desc.gn_part: the convolution's wide-store epilogue writes per-tile (sum, sum of squares) of its OUTPUT per
@@ -255,11 +255,11 @@ def test_groupnorm_statistics_from_the_conv_epilogue(B, C, H, W, Cout, tile):
     gamma, beta = 1.0 + 0.2 * det("gnf.g", (Cout,), 5), 0.1 * det("gnf.be", (Cout,), 6)
     wp, k_pad = pack_conv_weight(w)
     out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
-    part = torch.full((B * (H * W // 64 + 1) * G * 2,), float("nan"), dtype=torch.float32, device=DEV)
+    part = torch.full((B * (H * W // 16 + 1) * G * 2,), float("nan"), dtype=torch.float32, device=DEV)
     xd, bdev, resd = nhwc_bf16(x), b.to(DEV), nhwc_bf16(res)
     d = conv_desc(x0=xd, c0=C, batch=B, hi=H, wi=W, ho=H, wo=W, kh=3, kw=3, pad_h=1, pad_w=1, w=wp, k_pad=k_pad,
                   n=Cout, bias=bdev, res=resd, res_ld=Cout, out=out, ldc=Cout, tile=tile, gn_part=part,
-                  gn_groups=G, gn_hw=H * W)
+                  gn_groups=G, gn_hw=H * W, gn_part_floats=part.numel())
     run_conv(d)
     chunks = L_.ctta_conv_last_gn_chunks()
     assert chunks >= 1 and (H * W) % chunks == 0, "this launch should have produced GroupNorm partials"
@@ -281,7 +281,7 @@ def test_groupnorm_statistics_from_the_conv_epilogue(B, C, H, W, Cout, tile):
     x2, w2 = nhwc_bf16(bf16_round(det("gnf.x2", (1, 1024, 4, 4), 7))), pack_conv_weight(bf16_round(det("gnf.w2", (256, 1024, 3, 3), 8) * 0.01))[0]
     o2 = torch.empty(1, 4, 4, 256, dtype=torch.bfloat16, device=DEV)
     d2 = conv_desc(x0=x2, c0=1024, batch=1, hi=4, wi=4, ho=4, wo=4, kh=3, kw=3, pad_h=1, pad_w=1, w=w2, k_pad=9216, n=256,
-                   out=o2, ldc=256, gn_part=part, gn_groups=G, gn_hw=16)
+                   out=o2, ldc=256, gn_part=part, gn_groups=G, gn_hw=16, gn_part_floats=part.numel())
     run_conv(d2)
     assert L_.ctta_conv_last_gn_chunks() == 0
 
