@@ -496,7 +496,10 @@ static inline void gn_emit_done(RunCtx& c, const ctta_conv_desc& d) {
 // fused GroupNorm statistics (engine_common.h: gn_emit_setup): partial-sum buffer appended to the GroupNorm scratch
 static inline bool gn_fuse_enabled() {
   static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_GN_FUSE"); v = (e && e[0] == '0') ? 0 : 1; }
+  // Off by default: measured on MI355X (round 2, profiles/README.md) the fused statistics save GroupNorm's first read pass
+  // but the apply pass then misses the Infinity-Cache lines that pass used to leave behind -- generation 300.5 -> 299.7
+  // clips/s, distillation 124.1 -> 123.5 ms: a wash.  CTTA_GN_FUSE=1 turns it on.
+  if (v < 0) { const char* e = getenv("CTTA_GN_FUSE"); v = (e && e[0] == '1') ? 1 : 0; }
   return v != 0;
 }
 
