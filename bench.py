@@ -213,7 +213,7 @@ def main():
         algo_flops = gf_clip * 1e9 * B
         achieved = algo_flops / (conv_ms * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "conv_gemm_kernel (implicit-GEMM conv / linear / bmm, v_mfma_f32_16x16x32_bf16)",
+            "kernel": "conv_gemm_kernel family (implicit-GEMM conv / linear / bmm + the fused vocoder ResBlock units, v_mfma_f32_16x16x32_bf16)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "traffic_detail": pmc_traffic(B),
             "algorithmic_gflop_per_clip": round(gf_clip, 1), "launches_per_step": int(conv_cnt),
@@ -573,6 +573,11 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             "executed_tflops_incl_padding": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
             "share_of_step_time": round(ms.value / ev[0].elapsed_time(ev[1]), 3),
         }
+        td = out["roofline"]["traffic_detail"]
+        if td and td.get("read_GB_per_step") is not None and td.get("write_GB_per_step") is not None and cnt.value:
+            # the PMC families of tools/pmc_traffic.py that hold the MFMA kernels of the step, per launch like `achieved`
+            out["roofline"]["traffic"] = int((td["read_GB_per_step"] + td["write_GB_per_step"]) * 1e9 / cnt.value)
+            out["roofline"]["traffic_unit"] = "bytes per MFMA launch (PMC FETCH_SIZE x2 + WRITE_SIZE of conv_gemm + attention families per step / launches per step)"
     if rank == 0 and not args.no_latency:   # the HBM-bound kernel class of the step: fused training-state passes over 559 M fp32
         def timed(fn, reps=5):
             fn()
@@ -621,15 +626,25 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     return out
 
 
+def _profile(stem):
+    """Newest committed profiles/<stem>_rNN.json (PMC summaries are named per round)."""
+    import glob
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", stem + "_r[0-9][0-9].json")))
+    return found[-1] if found else os.path.join(ROOT, "profiles", stem + "_r01.json")
+
+
 def pmc_traffic_distill(batch):
-    """Same for the distillation leg: profiles/pmc_traffic_distill_r01.json (conv_gemm family, GB per step at batch 9)."""
+    """Same for the distillation leg: profiles/pmc_traffic_distill_r02.json (conv_gemm family, GB per step at batch 9)."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_distill_r01.json")))
+        d = json.load(open(_profile("pmc_traffic_distill")))
         if "batch 9" not in d.get("unit", "") or batch != 9:
             return None
-        f = d["families"]["conv_gemm_kernel"]
-        return {"read_GB_per_step": f["read_GB"], "write_GB_per_step": f["write_GB"],   # read: None (pass hangs)
-                "source": "profiles/pmc_traffic_distill_r01.json"}
+        fams = [d["families"][k] for k in ("conv_gemm_kernel", "attention_kernel", "attn_bwd") if k in d["families"]]
+        rd = [f["read_GB"] for f in fams]
+        f = {"read_GB": None if any(v is None for v in rd) else round(sum(rd), 3),
+             "write_GB": round(sum(f["write_GB"] or 0.0 for f in fams), 3)}
+        return {"read_GB_per_step": f["read_GB"], "write_GB_per_step": f["write_GB"],   # read: None when that pass hung
+                "source": "profiles/" + os.path.basename(_profile("pmc_traffic_distill"))}
     except Exception:
         return None
 
@@ -640,11 +655,11 @@ def pmc_traffic(batch):
     same command (tools/pmc_traffic.py; units and the gfx950 x2 read correction per MI355X_MICROARCH.md).  None when
     the file is absent or was taken at another batch size."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_r01.json")))
+        d = json.load(open(_profile("pmc_traffic")))
         if "batch 32" not in d.get("unit", "") or batch != 32:
             return None
         f = d["families"]["conv_gemm_kernel"]
-        return {"read_GB_per_step": f["read_GB"], "write_GB_per_step": f["write_GB"], "source": "profiles/pmc_traffic_r01.json"}
+        return {"read_GB_per_step": f["read_GB"], "write_GB_per_step": f["write_GB"], "source": "profiles/" + os.path.basename(_profile("pmc_traffic"))}
     except Exception:
         return None
 

@@ -20,6 +20,8 @@ SIMDS, CLOCK_HZ, PEAK_TFLOPS = 256 * 4, 2.4e9, 2500.0
 
 
 def family(name):
+    if "resunit_kernel" in name:
+        return "conv_gemm_kernel"
     for key in ("conv_gemm_kernel", "conv1d_halo_kernel", "attention_kernel", "conv_small_n_kernel"):
         if key in name:
             return key

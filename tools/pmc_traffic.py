@@ -24,6 +24,8 @@ from collections import defaultdict
 
 
 def family(name):
+    if "resunit_kernel" in name:       # the fused vocoder ResBlock units are convolutions of the conv_gemm family
+        return "conv_gemm_kernel"
     for key in ("conv_gemm_kernel", "conv1d_halo_kernel", "attention_kernel", "attn_bwd", "gn_", "layernorm", "ln_bwd", "geglu",
                 "softmax_rows", "conv_small_n_kernel", "splitk_finish", "adamw_kernel", "ema2_kernel", "pack_weight",
                 "wgrad_scatter", "im2col_t", "transpose"):

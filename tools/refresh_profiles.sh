@@ -21,11 +21,14 @@ python3 $R/tools/launch_table.py $O/launch_distill.csv.distill 60 1 > $O/launch_
 timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_fetch.log 2>&1
 timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_write.log 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/pmc_traffic.json 2> $O/pmc_traffic.err
-# No PMC pass for --mode distill here: under rocprofv3 --pmc that mode hangs intermittently on this pool (FETCH_SIZE twice,
-# WRITE_SIZE once out of two runs; each costs its 420 s timeout).  profiles/pmc_traffic_distill_r01.json is the one
-# WRITE_SIZE pass that completed:
-#   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d D -o p -- python3 bench.py --mode distill --steps 2 --warmup 1 --no-cpu-baseline --no-latency
-#   (tools/pmc_traffic.py <fetch dir> <write dir> distill 4 handles the pair when both complete)
+# Distillation leg: the PMC passes of that mode hung intermittently in round 1; one step, no warm-up, no latency legs
+# keeps each pass short, and a 300 s timeout bounds the loss when one hangs (tools/pmc_traffic.py ... distill <steps>;
+# steps = 1 timed + 1 warm-up minimum + 10 accumulation micro-steps + 1 profiled = see the script's own count)
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_d -o p -- python3 $R/bench.py --mode distill --steps 1 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_fetch_d.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_d -o p -- python3 $R/bench.py --mode distill --steps 1 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_write_d.log 2>&1
+python3 $R/tools/pmc_traffic.py $O/pmc_fetch_d $O/pmc_write_d distill 18 > $O/pmc_traffic_distill.json 2> $O/pmc_traffic_distill.err
+timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_mfma.log 2>&1
+python3 $R/tools/pmc_mfma_util.py $O/pmc_mfma > $O/pmc_mfma_util.json 2> $O/pmc_mfma_util.err
 rm -rf $O/prof_gen $O/prof_distill $O/launch_gen.csv $O/launch_distill.csv $O/launch_distill.csv.distill
-find $O/pmc_fetch $O/pmc_write -type f ! -name '*counter_collection.csv' -delete 2>/dev/null
+find $O/pmc_fetch $O/pmc_write $O/pmc_fetch_d $O/pmc_write_d $O/pmc_mfma -type f ! -name '*counter_collection.csv' -delete 2>/dev/null
 du -sh $O
