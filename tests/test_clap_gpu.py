@@ -303,3 +303,46 @@ def test_audiolcm_clap_finetune_step_runs_and_moves_the_student():
     assert moved > 0 and torch.equal(m.loss.clap.model.audio_branch.get_parameter("norm.weight"), tower_before)
     v2 = m.train_step(z0, P, opt, None, gt_wav=gt, **kw)
     assert np.isfinite(v2) and v2 != v1
+
+
+@pytest.mark.parametrize("loss_type", ["mel", "stft", "clap"])
+def test_perceptual_losses_decrease_over_twenty_fixed_draw_steps(loss_type):
+    """with the random draws of AudioLCM.forward held fixed (timestep indices, noise, guidance), twenty
+    optimizer steps on the waveform- / mel-domain losses must lower the loss -- the bench's `loss_first_last` draws a new
+    timestep every step and cannot show this."""
+    from consistencytta_amd import modules
+    from consistencytta_amd.models import AudioLCM
+    ucfg = cases.TINY_UNET
+    vsd = dict(cases.vae_weights(cases.TINY_VAE_DD))
+    vsd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
+    vae = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, scale_factor=0.9, hifigan_config=cases.TINY_HIFIGAN)
+    vae.load_state_dict(vsd)
+    vae.to(DEV).eval().requires_grad_(False)
+    kw_model = {}
+    B = 2
+    P = {k: v.to(DEV) for k, v in cases.prompt_states(ucfg, B, 6, "decr").items()}
+    if loss_type == "clap":
+        clap = C.CLAP_Module(audio_cfg=dict(cases.TINY_HTSAT, spec_size=128), text_cfg=cases.TINY_ROBERTA,
+                             clip_samples=3 * (64 * 160 + 32))
+        clap.to(DEV)
+        clap.model.init_random_(seed=3)
+        kw_model["clap_module"] = clap
+        P["clap_text_features"] = F.normalize(det("decr.text", (B, 512), 4), dim=-1).to(DEV)
+    m = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                 unet_model_config_path="tiny_light.json", unet_config=ucfg, snr_gamma=5.0, use_edm=True,
+                 teacher_guidance_scale=-1, num_diffusion_steps=18, vae=vae, loss_type=loss_type, **kw_model)
+    m.teacher_unet.load_state_dict(cases.unet_weights(ucfg, False, 0))
+    for net, seed in ((m.student_unet, 1), (m.student_target_unet, 1), (m.student_ema_unet, 1)):
+        net.load_state_dict(cases.unet_weights(ucfg, True, seed))     # target = EMA = student, as after load_state_dict_from_tango
+    m.to(DEV)
+    m.train()
+    z0 = (cases.t(spec.det_uniform("decr.z0", (B, 8, 16, 16), 14)) * 0.9).to(DEV)
+    gt = (det("decr.gt", (B, 9000), 5) * 0.3).to(DEV)
+    opt = m.prepare_training(lr=2e-4, weight_decay=0.0, broadcast=False)
+    gen = torch.Generator().manual_seed(11)
+    kw = dict(time_inds=torch.randint(2, 15, (B,), generator=gen) * 2,
+              gaussian_noise=torch.randn(B, 8, 16, 16, generator=gen).to(DEV), guidance_scale=torch.rand(B, generator=gen) * 6)
+    losses = [m.train_step(z0, P, opt, None, gt_wav=gt, **kw) for _ in range(20)]
+    print("%s loss over 20 fixed-draw steps: %.5f -> %.5f (min %.5f)" % (loss_type, losses[0], losses[-1], min(losses)))
+    assert all(np.isfinite(v) for v in losses)
+    assert np.mean(losses[-3:]) < 0.9 * np.mean(losses[:3])
