@@ -10,7 +10,7 @@ Units and the gfx950 correction as the guide prescribes: FETCH_SIZE / WRITE_SIZE
 (TCC_EA0_RDREQ x 64 B / 1024); on gfx950 FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane) coalesced
 reads at 64 B, i.e. HALF the bytes -- all loads of these kernels are 16 B/lane, so the read figure is doubled.
 WRITE_SIZE is uncalibrated on this part and reported as is.  Steps are counted by the dispatches of
-conv_small_n_kernel<1> (exactly one per generation step).
+conv_small_n_kernel<1, *> (the vocoder's conv_post: exactly one per generation step).
 
     python tools/pmc_traffic.py <fetch dir> <write dir> distill <train steps in the profiled run>
 
@@ -19,6 +19,7 @@ one profiled step; run the bench with --no-latency so that only training steps a
 import csv
 import glob
 import json
+import re
 import sys
 from collections import defaultdict
 
@@ -42,7 +43,7 @@ def load(directory, counter):
         if row["Counter_Name"] != counter:
             continue
         tot[family(row["Kernel_Name"])] += float(row["Counter_Value"])
-        if "conv_small_n_kernel<1>" in row["Kernel_Name"] and row["Dispatch_Id"] not in seen:
+        if re.search(r"conv_small_n_kernel<1[,>]", row["Kernel_Name"]) and row["Dispatch_Id"] not in seen:
             seen.add(row["Dispatch_Id"])
             steps += 1
     return tot, max(1, steps)

@@ -30,5 +30,6 @@ python3 $R/tools/pmc_traffic.py $O/pmc_fetch_d $O/pmc_write_d distill 18 > $O/pm
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_mfma.log 2>&1
 python3 $R/tools/pmc_mfma_util.py $O/pmc_mfma > $O/pmc_mfma_util.json 2> $O/pmc_mfma_util.err
 rm -rf $O/prof_gen $O/prof_distill $O/launch_gen.csv $O/launch_distill.csv $O/launch_distill.csv.distill
-find $O/pmc_fetch $O/pmc_write $O/pmc_fetch_d $O/pmc_write_d $O/pmc_mfma -type f ! -name '*counter_collection.csv' -delete 2>/dev/null
+# the raw counter CSVs are ~85 MB together and gpurun copies back at most 64 MiB: only the summaries travel
+rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_fetch_d $O/pmc_write_d $O/pmc_mfma
 du -sh $O
