@@ -27,6 +27,9 @@ struct ConvParams {
   int xcd_per, m_tiles, n_tiles, n_inner;   // n_inner = 0: M tiles innermost (many N tiles: keep the weight slice hot)
   // 1: the tile is transposed through LDS and leaves as whole 64..256-byte row segments (see the kernel's epilogue)
   int wide_store;
+  unsigned long long* stamps;   // diagnostic (ctta_conv_debug_stamps): per workgroup {hw id, t_begin, t_first_tile, t_main_done, t_epilogue_done}
+  int epi_fast;      // straight-line wide-store epilogue (bias / rowvec / residual / LeakyReLU / second output)
+  int epi_barrier;   // debug: workgroup barriers between the staging write and read-back of the wide-store epilogue
   int plain_out;   // destination element (m, n) sits at m*ldc + n (no per-batch stride, offset or limit)
   // GroupNorm statistics of the OUTPUT tensor from the epilogue (wide-store path only): every workgroup writes
   // (sum, sum of squares) of its BM x BN tile per channel group to gn_part[((b * gn_nchunk + chunk) * gn_G + g) * 2],
@@ -38,7 +41,7 @@ struct ConvParams {
 // The fused epilogue on 4 consecutive channels of one output row, for the wide-store paths (plain row-major bf16
 // destination: element (m, n) at m*ldc + n): same operation order as epilogue_store.
 __device__ __forceinline__ void epilogue_wide4(const ConvParams& p, const float4 q, const float4 bias4, int m, int n,
-                                               size_t gofs, float* gn_acc = nullptr) {
+                                               size_t gofs, float2* gn_acc = nullptr) {
   float v[4] = {q.x + bias4.x, q.y + bias4.y, q.z + bias4.z, q.w + bias4.w};
   if (p.bias_m) {
     const float bm = p.bias_m[m];
@@ -80,8 +83,8 @@ __device__ __forceinline__ void epilogue_wide4(const ConvParams& p, const float4
   if (gn_acc) {   // statistics of the values as stored (bf16-rounded), like a separate pass over the tensor would see them
     const float r0 = __uint_as_float(pk.x << 16), r1 = __uint_as_float(pk.x & 0xffff0000u);
     const float r2 = __uint_as_float(pk.y << 16), r3 = __uint_as_float(pk.y & 0xffff0000u);
-    gn_acc[0] += (r0 + r1) + (r2 + r3);
-    gn_acc[1] += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
+    gn_acc->x += (r0 + r1) + (r2 + r3);
+    gn_acc->y += (r0 * r0 + r1 * r1) + (r2 * r2 + r3 * r3);
   }
   if (p.out2) {   // leaky_relu of the SAME (bf16-rounded) values
     float w2[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),

@@ -32,6 +32,104 @@
 // channel base are wave-uniform scalars), <= 32 taps and one source; per row only a pixel base and
 // a tap-validity bitmask are kept, padding chunks are sent out of range (hardware returns zeros),
 // weight rows >= n fall outside the descriptor, and the per-step K advance rides in soffset.
+// ---- wide-store epilogue, fast path -------------------------------------------------------------------------
+struct WideCtx {
+  unsigned char* stg;      // this wave's staging rows in the (dead) LDS ring
+  int rsf;                 // staging row stride in bytes
+  int frow, nsub;          // MFMA accumulator coordinates of the lane (row within a 16-row fragment, first of its 4 channels)
+  int prow, col4;          // read-back coordinates: row within a pass, 4-channel column
+  int m_first;             // output row of (chunk 0, pass 0) for this lane
+  size_t gofs;             // group offset (elements) into out / out2
+  int n_lane;
+  float4 bias4, rv4;
+};
+#define WAVE_LDS_FENCE_() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// out = act((acc + bias + rowvec + res) * alpha) for one wave tile of FM x FN fragments, CJ fragments (CHR rows) per
+// staging chunk, RPW rows per read-back pass.  Everything is unrolled and free of divergent control flow, so the waits
+// the compiler inserts are exact counts.  Stores and residual loads go through buffer descriptors sized to the M valid
+// rows: one VGPR offset per lane, the row advance rides in the scalar offset, rows past M are dropped / read as zero by
+// the bounds check.  The residual row of (chunk c + 1, pass i) is requested right after that of (chunk c, pass i) was
+// consumed (same registers), i.e. a chunk ahead of its use and before the younger half of chunk c's stores.
+// Same operation order as epilogue_wide4.
+template <int FM, int FN, int CJ, int CHR, int RPW, bool RES, bool OUT2>
+__device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t (&acc)[FN][FM], const WideCtx& w) {
+  constexpr int IT = CHR / RPW;          // read-back passes per chunk
+  constexpr int NCH = FM / CJ;           // chunks
+  constexpr int QB = RES ? 2 : 4;        // passes read back from LDS at a time
+  const float slope = p.out_act == 3 ? p.out_slope : 1.0f;      // max(v, v * 1) == v
+  const float alpha = p.alpha, slope2 = p.out2_slope;
+  const unsigned rows_bytes = (unsigned)(((long long)(p.M - 1) * p.ldc + p.n) * 2);
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<bf16_t*>(p.out) + w.gofs), 0, rows_bytes, 0x00020000);
+  __amdgpu_buffer_rsrc_t rs2 = rso, rsr = rso;
+  if constexpr (OUT2) rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out2 + w.gofs), 0, rows_bytes, 0x00020000);
+  if constexpr (RES)
+    rsr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (unsigned)(((long long)(p.M - 1) * p.res_ld + p.n) * 2), 0x00020000);
+  const int voff = (w.m_first * p.ldc + w.n_lane) * 2;          // byte offset of the lane's (chunk 0, pass 0) element
+  const int roff = RES ? (w.m_first * p.res_ld + w.n_lane) * 2 : 0;
+  const int ostep = RPW * p.ldc * 2, rstep = RPW * p.res_ld * 2;   // bytes per read-back pass (wave-uniform)
+  u32x2_t rr[RES ? IT : 1];
+  if constexpr (RES) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b64(rsr, roff, it * rstep, 0);
+  }
+#pragma unroll
+  for (int ch = 0; ch < NCH; ++ch) {
+#pragma unroll
+    for (int jj = 0; jj < CJ; ++jj)
+#pragma unroll
+      for (int i = 0; i < FN; ++i) {
+        const f32x4_t a = acc[i][ch * CJ + jj];
+        *reinterpret_cast<float4*>(w.stg + (jj * 16 + w.frow) * w.rsf + (i * 16 + w.nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    WAVE_LDS_FENCE_();
+#pragma unroll
+    for (int h = 0; h < IT; h += QB) {
+      float4 q[QB];
+#pragma unroll
+      for (int e = 0; e < QB; ++e)
+        if (h + e < IT) q[e] = *reinterpret_cast<const float4*>(w.stg + (w.prow + (h + e) * RPW) * w.rsf + w.col4 * 16);
+#pragma unroll
+      for (int e = 0; e < QB; ++e) {
+        if (h + e < IT) {
+          const int it = h + e;
+          const int pass = ch * IT + it;       // rows advance by RPW per pass: CHR == IT * RPW
+          float v[4] = {q[e].x + w.bias4.x, q[e].y + w.bias4.y, q[e].z + w.bias4.z, q[e].w + w.bias4.w};
+          v[0] += w.rv4.x; v[1] += w.rv4.y; v[2] += w.rv4.z; v[3] += w.rv4.w;
+          if constexpr (RES) {
+            const u32x2_t r2 = rr[it];
+            if (ch + 1 < NCH) rr[it] = __builtin_amdgcn_raw_buffer_load_b64(rsr, roff, (pass + IT) * rstep, 0);
+            v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+            v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { v[c] *= alpha; v[c] = fmaxf(v[c], v[c] * slope); }
+          u32x2_t pk;
+          pk.x = pack2bf(v[0], v[1]);
+          pk.y = pack2bf(v[2], v[3]);
+          __builtin_amdgcn_raw_buffer_store_b64(pk, rso, voff, pass * ostep, 0);
+          if constexpr (OUT2) {
+            float w2[4] = {__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xffff0000u), __uint_as_float(pk.y << 16),
+                           __uint_as_float(pk.y & 0xffff0000u)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w2[c] = fmaxf(w2[c], w2[c] * slope2);
+            u32x2_t pk2;
+            pk2.x = pack2bf(w2[0], w2[1]);
+            pk2.y = pack2bf(w2[2], w2[3]);
+            __builtin_amdgcn_raw_buffer_store_b64(pk2, rs2, voff, pass * ostep, 0);
+          }
+        }
+      }
+    }
+    if (ch + 1 < NCH) WAVE_LDS_FENCE_();     // the staging rows are rewritten by the next chunk
+  }
+}
+
+// orders a wave's own LDS writes before its LDS reads (other lanes of the SAME wave) without a workgroup barrier
+#define WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                              __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p) {
   constexpr bool GLDS = MODE != 0;
@@ -54,6 +152,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_raw);               // [STAGES][BM][LDK]
   bf16_t* Ws = Xs + STAGES * BM * LDK;                             // [STAGES][BN][LDK]
+  unsigned long long* stamp = nullptr;
+  if (p.stamps) {
+    stamp = p.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 6;
+    if (threadIdx.x == 0) { stamp[0] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32); stamp[1] = __builtin_amdgcn_s_memtime(); }
+  }
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -350,6 +453,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       slot = (slot + 1 == STAGES) ? 0 : slot + 1;
     }
   } else {
+    if (stamp && threadIdx.x == 0) stamp[5] = __builtin_amdgcn_s_memtime();
     if constexpr (MODE == 2) {
       issue_fast(kt_begin, 0);
     } else if constexpr (MODE == 1) {
@@ -359,6 +463,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       store_tile(0);
     }
     __syncthreads();
+    if (stamp && threadIdx.x == 0) stamp[2] = __builtin_amdgcn_s_memtime();
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < nk) {
@@ -374,6 +479,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     }
   }
 
+  if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
   // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3} (rows of D), m = mb + (lane&15)
   const int nsub = (lane >> 4) * 4;
   // Wide-store epilogue (bf16 output, plain row-major destination).  In the MFMA layout a store instruction writes
@@ -443,8 +549,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         return;
       }
     }
-    float gacc[2] = {0.f, 0.f};
-    float* const gn_acc = p.gn_part ? gacc : nullptr;
+    // Fast path (bias [+ per-sample row vector] [+ residual] [+ LeakyReLU] [+ second LeakyReLU output], plain destination):
+    // straight-line code so that the waits the compiler inserts are exact -- inside the rolled generic loop below every
+    // iteration waits for all but one outstanding store (vmcnt counts stores too, and the back edge makes the count
+    // conservative), which serialises the epilogue on the store round trip: 16.7 us per 256x256 tile measured with
+    // s_memtime stamps (tools/tile_timeline.py) against 76 us of main loop at K = 2816.
+    // (per wave: its TN columns must lie inside the matrix -- no predicates, no divergent control flow, which would also
+    // make the compiler's wait counts conservative; rows past M fall to the buffer bounds check; edge waves take the
+    // generic loop, there is no barrier)
+    if (p.epi_fast && n0 + wn * TN + TN <= p.n) {
+      const bool one_sample = m0 / p.howo == (min(m0 + BM, p.M) - 1) / p.howo;
+      if (!p.rowvec || one_sample) {
+        float4 rv4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.rowvec) rv4 = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m0 / p.howo) * p.rowvec_ld + n_lane);
+        const WideCtx wc = {stg, RSF, frow, nsub, prow, col4, m0 + wm * TM + prow, (size_t)g * p.ogs, n_lane, bias4, rv4};
+        if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false>(p, acc, wc);
+        else if (!p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false>(p, acc, wc);
+        else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, true>(p, acc, wc);
+        if (stamp && threadIdx.x == 0) stamp[4] = __builtin_amdgcn_s_memtime();
+        return;
+      }
+    }
+    float2 gacc = make_float2(0.f, 0.f);   // always passed (a conditional pointer would force it into scratch)
 #pragma unroll
     for (int j0 = 0; j0 < FM; j0 += CJ) {
 #pragma unroll
@@ -454,16 +580,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
           const f32x4_t a = acc[i][j0 + jj];
           *reinterpret_cast<float4*>(stg + (jj * 16 + frow) * RSF + (i * 16 + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
-      __syncthreads();
+      // the staging rows are private to the wave and a wave's LDS operations execute in order: no workgroup barrier
+      if (p.epi_barrier) __syncthreads(); else WAVE_LDS_FENCE();
 #pragma unroll 2
       for (int r = prow; r < CHR; r += RPW) {
         const int m = m0 + wm * TM + j0 * 16 + r;
         if (m < p.M && n_ok)
           epilogue_wide4(p, *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16), bias4, m, n_lane, (size_t)g * p.ogs,
-                         gn_acc);
+                         &gacc);
       }
-      if (j0 + CJ < FM) __syncthreads();
+      if (j0 + CJ < FM) { if (p.epi_barrier) __syncthreads(); else WAVE_LDS_FENCE(); }
     }
+    if (stamp && threadIdx.x == 0) stamp[4] = __builtin_amdgcn_s_memtime();
     if (p.gn_part) {
       // GroupNorm statistics.  Inside a wave the lanes of one channel group (cw / 4 neighbouring column lanes x all row
       // lanes) fold their (sum, sum of squares) with a fixed butterfly, and the group's leader lane writes the WAVE's
@@ -473,7 +601,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       const int cw = cpg < TN ? cpg : TN;        // channels of one group inside a wave's TN columns
       const int LG = cw / 4;                     // column lanes per group (power of two)
       const int SUB = cpg / cw;                  // wave columns a group spans (1 unless cpg > TN)
-      float s1 = gacc[0], s2 = gacc[1];
+      float s1 = gacc.x, s2 = gacc.y;
       for (int o = 1; o < LG; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }
@@ -840,12 +968,24 @@ static bool wide_store_default() {
   if (v < 0) { const char* e = getenv("CTTA_WIDE_STORE"); v = (e && e[0] == '0') ? 0 : 1; }
   return v != 0;
 }
+static thread_local unsigned long long* t_stamps = nullptr;
+extern "C" void ctta_conv_debug_stamps(void* buf) { t_stamps = (unsigned long long*)buf; }
 static thread_local int t_no_splitk = 0;
 extern "C" void ctta_conv_suppress_splitk(int on) { t_no_splitk = on ? 1 : 0; }
 static bool splitk_default() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("CTTA_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
   return v != 0 && !t_no_splitk;
+}
+static bool epi_fast_default() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_EPI_FAST"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
+static bool epi_barrier_default() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_EPI_BARRIER"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v != 0;
 }
 static bool glds_default() {
   static int v = -1;
@@ -947,6 +1087,12 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
                   (p.plain_out || (!geglu && p.obs % 4 == 0 && d->out_offset % 4 == 0 && d->out_limit % 4 == 0)) &&
                   (!d->res || d->res_ld % 4 == 0) && (!d->rowvec || d->rowvec_ld % 4 == 0))
                      ? 1 : 0;
+  p.epi_barrier = epi_barrier_default() ? 1 : 0;
+  p.epi_fast = (epi_fast_default() && !p.epi_barrier && p.wide_store && M * (long long)d->ldc * 2 < 0x7FFFFF00LL &&
+                (!d->res || M * (long long)d->res_ld * 2 < 0x7FFFFF00LL) && p.plain_out && !geglu && !d->bias_m && !d->accumulate && !d->gn_part &&
+                (d->out_act == 0 || (d->out_act == 3 && d->out_slope >= 0.f && d->out_slope <= 1.f)) &&
+                (!d->out2 || (d->res && d->out2_slope >= 0.f && d->out2_slope <= 1.f))) ? 1 : 0;
+  p.stamps = t_stamps;
   int vid = d->tile;
   if (vid <= 0 && halo_eligible(d, p, groups)) {
     const bool prof = ctta_prof_active();

@@ -337,6 +337,10 @@ void ctta_conv_bind_workspace(void* ws, size_t bytes);
 /* on != 0: launches issued by the calling host thread take no split-K path until switched off again (used for GEMMs that
  * an engine enqueues on a second stream of the same handle, which must not share the handle's partial-sum slabs) */
 void ctta_conv_suppress_splitk(int on);
+/* Diagnostic: while `buf` is non-NULL every conv_gemm workgroup launched from this host thread writes six 64-bit words
+ * {HW_ID register, s_memtime at entry, after the first K-tile landed, after the main loop, after the epilogue's last
+ * store was issued, before the first K-tile request} to buf[6 * linear workgroup index] (tools/tile_timeline.py).  buf: >= 48 bytes per workgroup. */
+void ctta_conv_debug_stamps(void* buf);
 size_t ctta_conv_workspace_bytes(void);
 int ctta_conv_gemm_num_variants(void);
 const char* ctta_conv_gemm_variant_name(int id);
