@@ -28,6 +28,7 @@ struct ConvParams {
   // 1: the tile is transposed through LDS and leaves as whole 64..256-byte row segments (see the kernel's epilogue)
   int wide_store;
   unsigned long long* stamps;   // diagnostic (ctta_conv_debug_stamps): per workgroup {hw id, t_begin, t_first_tile, t_main_done, t_epilogue_done}
+  unsigned howo_inv, wo_inv;   // floor(2^32 / howo), floor(2^32 / wo) for fast_div
   int epi_fast;      // straight-line wide-store epilogue (bias / rowvec / residual / LeakyReLU / second output)
   int epi_barrier;   // debug: workgroup barriers between the staging write and read-back of the wide-store epilogue
   int plain_out;   // destination element (m, n) sits at m*ldc + n (no per-batch stride, offset or limit)

@@ -32,6 +32,12 @@
 // channel base are wave-uniform scalars), <= 32 taps and one source; per row only a pixel base and
 // a tap-validity bitmask are kept, padding chunks are sent out of range (hardware returns zeros),
 // weight rows >= n fall outside the descriptor, and the per-step K advance rides in soffset.
+// n / d for 0 <= n < 2^31 with inv = floor(2^32 / d) (0xFFFFFFFF for d == 1): the estimate is q or q - 1
+__device__ __forceinline__ int fast_div(int n, int d, unsigned inv) {
+  unsigned q = __umulhi((unsigned)n, inv);
+  if ((unsigned)n - q * (unsigned)d >= (unsigned)d) ++q;
+  return (int)q;
+}
 // ---- wide-store epilogue, fast path -------------------------------------------------------------------------
 struct WideCtx {
   unsigned char* stg;      // this wave's staging rows in the (dead) LDS ring
@@ -343,17 +349,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       unsigned mask = 0;
       int pix = 0, ph = 0, pw = 0;
       if (m < p.M) {
-        const int b = m / p.howo;
+        const int b = fast_div(m, p.howo, p.howo_inv);
         const int rem = m - b * p.howo;
-        const int oh = rem / p.wo;
+        const int oh = fast_div(rem, p.wo, p.wo_inv);
         const int ow = rem - oh * p.wo;
         const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
-        int t = 0;
-        for (int a = 0; a < p.kh; ++a)
-          for (int bq = 0; bq < p.kw; ++bq, ++t) {
-            const int ih = ih0 + a * p.dh, iw = iw0 + bq * p.dw;
-            if ((unsigned)ih < (unsigned)p.hi && (unsigned)iw < (unsigned)p.wi) mask |= 1u << t;
-          }
+        // valid taps are a rectangle: rows a with 0 <= ih0 + a*dh < hi  x  columns bq with 0 <= iw0 + bq*dw < wi.
+        // Undilated axes get their bit range by arithmetic, dilated ones by a loop over that axis only (this block runs
+        // once per tile and was 2.8-4.1 us of it with a compare pair per tap, tools/tile_timeline.py)
+        unsigned hm = 0, wmk = 0;
+        if (p.dh == 1) {
+          const int lo = max(0, -ih0), hi_ = min(p.kh - 1, p.hi - 1 - ih0);
+          if (hi_ >= lo) hm = (2u << hi_) - (1u << lo);
+        } else {
+          for (int a = 0; a < p.kh; ++a) if ((unsigned)(ih0 + a * p.dh) < (unsigned)p.hi) hm |= 1u << a;
+        }
+        if (p.dw == 1) {
+          const int lo = max(0, -iw0), hi_ = min(p.kw - 1, p.wi - 1 - iw0);
+          if (hi_ >= lo) wmk = (2u << hi_) - (1u << lo);
+        } else {
+          for (int bq = 0; bq < p.kw; ++bq) if ((unsigned)(iw0 + bq * p.dw) < (unsigned)p.wi) wmk |= 1u << bq;
+        }
+        for (int a = 0; a < p.kh; ++a) if ((hm >> a) & 1u) mask |= wmk << (a * p.kw);
         if (p.ups) {   // 3x3 / pad 1 / stride 1 on a x2 nearest-upsampled source: base = (oh>>1, ow>>1)
           pix = (b * p.hs + (oh >> 1)) * p.ws + (ow >> 1);
           ph = oh & 1; pw = ow & 1;
@@ -1003,7 +1020,7 @@ static bool glds_default() {
 static const int kBigTile = 29;
 static bool want_big_tile(long long M, int N, long long K, int groups) {
   const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * groups;
-  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= 1024 && t256 >= 192;
+  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= 512 && t256 >= 192;   // (K >= 512 since the straight-line epilogue, profiles/sweep_r02*.json)
 }
 static int pick_variant(long long M, int N, long long K, int groups) {
   if (N <= 32) {                                           // 256x32; few row tiles (the per-sample cross-attention
@@ -1058,6 +1075,8 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   p.M = (int)M; p.hi = d->hi; p.wi = d->wi; p.ups = d->upsample ? 1 : 0;
   p.hs = p.ups ? d->hi / 2 : d->hi; p.ws = p.ups ? d->wi / 2 : d->wi;
   p.ho = d->ho; p.wo = d->wo; p.howo = d->ho * d->wo;
+  p.howo_inv = p.howo == 1 ? 0xFFFFFFFFu : (unsigned)((1ULL << 32) / (unsigned)p.howo);
+  p.wo_inv = p.wo == 1 ? 0xFFFFFFFFu : (unsigned)((1ULL << 32) / (unsigned)p.wo);
   p.kh = d->kh; p.kw = d->kw; p.taps = d->kh * d->kw;
   p.sh = d->stride_h; p.sw = d->stride_w; p.ph = d->pad_h; p.pw = d->pad_w;
   p.dh = d->dil_h; p.dw = d->dil_w;
@@ -1108,7 +1127,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       // short K with a heavy epilogue (residual read / second output / accumulate): the 256x256 tile holds one
       // workgroup per CU (128 KB ring), so its epilogue cannot hide behind another workgroup's main loop; the
       // 256x128x32 tile (48 KB, 3 workgroups per CU) wins there (sweep with SWEEP_EPI=1: 363 vs 284 TFLOP/s at K=768)
-      if (K < 2048 && (d->res || d->out2 || d->accumulate)) vid = 28;
+      if (K < 2048 && d->accumulate) vid = 28;   // (residual / second output ride in the straight-line epilogue now: sweep_r02_epi)
     } else {
       vid = pick_variant(M, d->n, K, groups);
       // fused GEGLU: 128x128x32 through the wide-store epilogue (its read-back loop is rolled, so the 16-fragment tile
@@ -1165,7 +1184,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     if ((long long)splits * M * ld * 4 > (long long)ws_bytes) splits = 1;
   }
   const bool prof = ctta_prof_active();
-  if (prof) ctta_prof_begin(0, vid, M, d->n, K, groups, (hipStream_t)stream);
+  if (prof) ctta_prof_begin(0, vid + (p.epi_fast ? 0 : 100), M, d->n, K, groups, (hipStream_t)stream);   // +100: generic epilogue
   if (splits == 1 && groups == 1 && xcd_default() && grid.x >= 64) {
     p.m_tiles = (int)grid.x; p.n_tiles = (int)grid.y;
     p.xcd_per = (p.m_tiles + 7) / 8;
