@@ -36,6 +36,10 @@ struct ResUnitParams {
   ConvParams epi;        // conv2's epilogue: bias = b2, res = x, out, accumulate, alpha, out_act / out_slope
 };
 
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// workgroup barrier that orders LDS traffic only (leaves global loads / stores in flight)
+#define LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
 template <int C, int WC, int WP, int T>
 __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) {
   static_assert(WC * WP == 4, "four waves per workgroup");
@@ -182,16 +186,44 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
   }
 
   // ---- epilogue: two position blocks per part at a time through an fp32 LDS transpose; a row of C channels is then
-  //      finished (bias, residual, accumulate, scale, activation) and stored by C/4 consecutive lanes
+  //      finished (bias, residual, accumulate, scale, LeakyReLU) and stored by C/4 consecutive lanes.
+  // Straight-line code (4 passes x 4 row sweeps), buffer descriptors bounded to this sample's L rows (rows past the
+  // sequence end are dropped / read as zero by the bounds check, so nothing is predicated), the row advance in the
+  // scalar offset, raw LDS barriers (a __syncthreads() would also drain the stores and the prefetched residual rows):
+  // the residual -- and, when accumulating, the old output -- of pass p + 1 is requested while pass p is finished.
+  // A rolled loop over epilogue_wide4 made every sweep wait for its own residual load and for all but one of the
+  // stores issued before it (the compiler's wait counts are conservative across a back edge).
   constexpr int RSF = C * 4 + 16;            // staging row stride (bytes)
   constexpr int CH_ROWS = 32;                // rows per part and pass
   constexpr int LPR = C / 4;                 // lanes per output row
   constexpr int RPP = 256 / LPR;             // rows finished per sweep of the workgroup
+  constexpr int NSW = WP * CH_ROWS / RPP;    // sweeps per pass
+  constexpr int NP = OB / 2;                 // passes
   const int col4 = tid % LPR, prow = tid / LPR;
-  const float4 bias4 = p.epi.bias ? *reinterpret_cast<const float4*>(p.epi.bias + col4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const ConvParams& e = p.epi;
+  const float4 bias4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + col4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float oslope = e.out_act == 3 ? e.out_slope : 1.0f, alpha = e.alpha;
+  const bool acc_old = e.accumulate != 0;
+  const unsigned sample_bytes = (unsigned)L * C * 2;
+  const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<bf16_t*>(e.out) + (size_t)b * L * C), 0, sample_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, sample_bytes, 0x00020000);
+  const int voff = ((l0 + prow) * C + col4 * 4) * 2;
+  // sequence position of (pass, sweep) relative to l0 + prow: part = sweep * RPP / 32 rows of 32, OB blocks per part
+  auto rel = [](int pass, int sw) { return (((sw * RPP) / CH_ROWS) * OB + pass * 2) * 16 + (sw * RPP) % CH_ROWS; };
+  u32x2_t rx[NSW], ro[NSW];
 #pragma unroll
-  for (int pass = 0; pass < OB / 2; ++pass) {
-    __syncthreads();   // the intermediate (first pass) / the previous pass's staging rows are dead
+  for (int sw = 0; sw < NSW; ++sw) {
+    rx[sw] = __builtin_amdgcn_raw_buffer_load_b64(rsx, voff, rel(0, sw) * C * 2, 0);
+    ro[sw] = (u32x2_t){0u, 0u};
+  }
+  if (acc_old) {
+#pragma unroll
+    for (int sw = 0; sw < NSW; ++sw) ro[sw] = __builtin_amdgcn_raw_buffer_load_b64(rso, voff, rel(0, sw) * C * 2, 0);
+  }
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+    LDS_BARRIER();     // the intermediate (first pass) / the previous pass's staging rows are dead
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int pb = pass * 2 + h;
@@ -202,13 +234,29 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
         *reinterpret_cast<float4*>(row + ((cb0 + cb) * 16 + lg * 4) * 4) = make_float4(a[0], a[1], a[2], a[3]);
       }
     }
-    __syncthreads();
-    for (int r = prow; r < WP * CH_ROWS; r += RPP) {
-      const int part = r / CH_ROWS, rr = r - part * CH_ROWS;
-      const int l = l0 + (part * OB + pass * 2) * 16 + rr;
-      if (l < L)
-        epilogue_wide4(p.epi, *reinterpret_cast<const float4*>(smem_raw + (size_t)r * RSF + col4 * 16), bias4, b * L + l,
-                       col4 * 4, 0);
+    LDS_BARRIER();
+    float4 q[NSW];
+#pragma unroll
+    for (int sw = 0; sw < NSW; ++sw)
+      q[sw] = *reinterpret_cast<const float4*>(smem_raw + (size_t)(prow + sw * RPP) * RSF + col4 * 16);
+#pragma unroll
+    for (int sw = 0; sw < NSW; ++sw) {
+      float v[4] = {q[sw].x + bias4.x, q[sw].y + bias4.y, q[sw].z + bias4.z, q[sw].w + bias4.w};
+      const u32x2_t r2 = rx[sw], o2 = ro[sw];
+      if (pass + 1 < NP) {
+        rx[sw] = __builtin_amdgcn_raw_buffer_load_b64(rsx, voff, rel(pass + 1, sw) * C * 2, 0);
+        if (acc_old) ro[sw] = __builtin_amdgcn_raw_buffer_load_b64(rso, voff, rel(pass + 1, sw) * C * 2, 0);
+      }
+      v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+      v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+      v[0] += __uint_as_float(o2.x << 16); v[1] += __uint_as_float(o2.x & 0xffff0000u);      // + 0 unless accumulating
+      v[2] += __uint_as_float(o2.y << 16); v[3] += __uint_as_float(o2.y & 0xffff0000u);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { v[c] *= alpha; v[c] = fmaxf(v[c], v[c] * oslope); }
+      u32x2_t pk;
+      pk.x = pack2bf(v[0], v[1]);
+      pk.y = pack2bf(v[2], v[3]);
+      __builtin_amdgcn_raw_buffer_store_b64(pk, rso, voff, rel(pass, sw) * C * 2, 0);
     }
   }
 }
@@ -277,6 +325,7 @@ extern "C" ctta_status ctta_resunit_conv1d(const void* x, int batch, int len, in
                                            void* stream) {
   CTTA_REQUIRE(x && w1_frag && w2_frag && b1 && b2 && out, "resunit_conv1d: null pointer");
   CTTA_REQUIRE(batch >= 1 && len >= 1 && (long long)batch * len < (1LL << 31), "resunit_conv1d: bad extent");
+  CTTA_REQUIRE(out_slope >= 0.f && out_slope <= 1.f, "resunit_conv1d: out_slope=%g must lie in [0, 1]", (double)out_slope);
   CTTA_REQUIRE(ctta_resunit_supported(channels, k, dil),
                "resunit_conv1d: channels=%d k=%d dilation=%d is outside the fused kernel's range (C in {32,64,128}, odd k <= 11, "
                "tile <= 64 KB of LDS)", channels, k, dil);
