@@ -59,11 +59,11 @@ typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 // the bounds check.  The residual row of (chunk c + 1, pass i) is requested right after that of (chunk c, pass i) was
 // consumed (same registers), i.e. a chunk ahead of its use and before the younger half of chunk c's stores.
 // Same operation order as epilogue_wide4.
-template <int FM, int FN, int CJ, int CHR, int RPW, bool RES, bool OUT2>
+template <int FM, int FN, int CJ, int CHR, int RPW, bool RES, bool OUT2, bool ACC>
 __device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t (&acc)[FN][FM], const WideCtx& w) {
   constexpr int IT = CHR / RPW;          // read-back passes per chunk
   constexpr int NCH = FM / CJ;           // chunks
-  constexpr int QB = RES ? 2 : 4;        // passes read back from LDS at a time
+  constexpr int QB = (RES || ACC) ? 2 : 4;        // passes read back from LDS at a time
   const float slope = p.out_act == 3 ? p.out_slope : 1.0f;      // max(v, v * 1) == v
   const float alpha = p.alpha, slope2 = p.out2_slope;
   const unsigned rows_bytes = (unsigned)(((long long)(p.M - 1) * p.ldc + p.n) * 2);
@@ -76,10 +76,14 @@ __device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t 
   const int voff = (w.m_first * p.ldc + w.n_lane) * 2;          // byte offset of the lane's (chunk 0, pass 0) element
   const int roff = RES ? (w.m_first * p.res_ld + w.n_lane) * 2 : 0;
   const int ostep = RPW * p.ldc * 2, rstep = RPW * p.res_ld * 2;   // bytes per read-back pass (wave-uniform)
-  u32x2_t rr[RES ? IT : 1];
+  u32x2_t rr[RES ? IT : 1], oo[ACC ? IT : 1];      // residual / old-output rows, requested a chunk ahead
   if constexpr (RES) {
 #pragma unroll
     for (int it = 0; it < IT; ++it) rr[it] = __builtin_amdgcn_raw_buffer_load_b64(rsr, roff, it * rstep, 0);
+  }
+  if constexpr (ACC) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) oo[it] = __builtin_amdgcn_raw_buffer_load_b64(rso, voff, it * ostep, 0);
   }
 #pragma unroll
   for (int ch = 0; ch < NCH; ++ch) {
@@ -109,6 +113,12 @@ __device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t 
             if (ch + 1 < NCH) rr[it] = __builtin_amdgcn_raw_buffer_load_b64(rsr, roff, (pass + IT) * rstep, 0);
             v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
             v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+          }
+          if constexpr (ACC) {
+            const u32x2_t o2 = oo[it];
+            if (ch + 1 < NCH) oo[it] = __builtin_amdgcn_raw_buffer_load_b64(rso, voff, (pass + IT) * ostep, 0);
+            v[0] += __uint_as_float(o2.x << 16); v[1] += __uint_as_float(o2.x & 0xffff0000u);
+            v[2] += __uint_as_float(o2.y << 16); v[3] += __uint_as_float(o2.y & 0xffff0000u);
           }
 #pragma unroll
           for (int c = 0; c < 4; ++c) { v[c] *= alpha; v[c] = fmaxf(v[c], v[c] * slope); }
@@ -580,9 +590,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         float4 rv4 = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p.rowvec) rv4 = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m0 / p.howo) * p.rowvec_ld + n_lane);
         const WideCtx wc = {stg, RSF, frow, nsub, prow, col4, m0 + wm * TM + prow, (size_t)g * p.ogs, n_lane, bias4, rv4};
-        if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false>(p, acc, wc);
-        else if (!p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false>(p, acc, wc);
-        else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, true>(p, acc, wc);
+        if (p.accumulate) {
+          if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, true>(p, acc, wc);
+          else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, true>(p, acc, wc);
+        } else if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false>(p, acc, wc);
+        else if (!p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false>(p, acc, wc);
+        else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, true, false>(p, acc, wc);
         if (stamp && threadIdx.x == 0) stamp[4] = __builtin_amdgcn_s_memtime();
         return;
       }
@@ -1108,7 +1121,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
                      ? 1 : 0;
   p.epi_barrier = epi_barrier_default() ? 1 : 0;
   p.epi_fast = (epi_fast_default() && !p.epi_barrier && p.wide_store && M * (long long)d->ldc * 2 < 0x7FFFFF00LL &&
-                (!d->res || M * (long long)d->res_ld * 2 < 0x7FFFFF00LL) && p.plain_out && !geglu && !d->bias_m && !d->accumulate && !d->gn_part &&
+                (!d->res || M * (long long)d->res_ld * 2 < 0x7FFFFF00LL) && p.plain_out && !geglu && !d->bias_m && !d->gn_part && !(d->accumulate && d->out2) &&
                 (d->out_act == 0 || (d->out_act == 3 && d->out_slope >= 0.f && d->out_slope <= 1.f)) &&
                 (!d->out2 || (d->res && d->out2_slope >= 0.f && d->out2_slope <= 1.f))) ? 1 : 0;
   p.stamps = t_stamps;
@@ -1124,10 +1137,9 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   if (vid <= 0 || vid > kNumVariants) {
     if (!d->in_act && !geglu && glds_default() && want_big_tile(M, d->n, K, groups) && fast_ok(kVariants[kBigTile - 1].bk)) {
       vid = kBigTile;
-      // short K with a heavy epilogue (residual read / second output / accumulate): the 256x256 tile holds one
-      // workgroup per CU (128 KB ring), so its epilogue cannot hide behind another workgroup's main loop; the
-      // 256x128x32 tile (48 KB, 3 workgroups per CU) wins there (sweep with SWEEP_EPI=1: 363 vs 284 TFLOP/s at K=768)
-      if (K < 2048 && d->accumulate) vid = 28;   // (residual / second output ride in the straight-line epilogue now: sweep_r02_epi)
+      // (round 1 sent short-K launches with a residual / second output / accumulate to the 256x128x32 tile because the
+      // big tile's rolled epilogue could not hide behind another workgroup; with the straight-line epilogue the big tile
+      // wins there too: profiles/sweep_r02_epi.json, 670 vs 626 TFLOP/s at K = 768)
     } else {
       vid = pick_variant(M, d->n, K, groups);
       // fused GEGLU: 128x128x32 through the wide-store epilogue (its read-back loop is rolled, so the 16-fragment tile

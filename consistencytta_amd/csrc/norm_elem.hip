@@ -671,7 +671,12 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
         for (int f = 0; f < NF; ++f) {
           const float4 wv = n0 + f < N ? *reinterpret_cast<const float4*>(w + (size_t)(n0 + f) * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-          for (int r = 0; r < RM; ++r) acc[f][r] += xv[r].x * wv.x + xv[r].y * wv.y + xv[r].z * wv.z + xv[r].w * wv.w;
+          for (int r = 0; r < RM; ++r) {   // explicit fma chain: every (row, feature) sum rounds the same way whatever its
+            float a = acc[f][r];            // slot in the row chunk, so a sample's result never depends on its batch mates
+            a = __fmaf_rn(xv[r].x, wv.x, a); a = __fmaf_rn(xv[r].y, wv.y, a);
+            a = __fmaf_rn(xv[r].z, wv.z, a); a = __fmaf_rn(xv[r].w, wv.w, a);
+            acc[f][r] = a;
+          }
         }
       }
     } else {
@@ -686,7 +691,7 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
         for (int f = 0; f < NF; ++f) {
           const float wv = n0 + f < N ? w[(size_t)(n0 + f) * K + k] : 0.f;
 #pragma unroll
-          for (int r = 0; r < RM; ++r) acc[f][r] += xv[r] * wv;
+          for (int r = 0; r < RM; ++r) acc[f][r] = __fmaf_rn(xv[r], wv, acc[f][r]);
         }
       }
     }

@@ -481,3 +481,30 @@ def test_t5_encoder_against_transformers_golden_and_oracle(golden):
         m(input_ids=torch.full((1, 4), cfg["vocab_size"], device=DEV), attention_mask=torch.ones(1, 4, device=DEV))
     with pytest.raises(ValueError):
         m(input_ids=ids.to(DEV), attention_mask=torch.zeros_like(mask).to(DEV))
+
+
+@pytest.mark.parametrize("guided", [True, False])
+def test_unet_forward_is_bit_identical_whatever_the_batch_mates(guided):
+    """Data-parallel training shards a batch by sample, so a sample's activations must not depend on who shares its
+    launch: every sub-batch of an 8-sample forward reproduces those rows bit for bit (tile choice, split-K and the
+    small fp32 MLP kernels all change with the batch size; a 1-ulp difference in the time embedding once flipped bf16
+    roundings downstream and showed up as 1e-3 in the 2-rank gradient test)."""
+    cfg = cases.TINY_UNET
+    cls = modules.UNet2DConditionGuidedModel if guided else modules.UNet2DConditionModel
+    net = _load(cls.from_config(cfg), cases.unet_weights(cfg, guided, 1))
+    B, L = 8, 6
+    P = cases.prompt_states(cfg, B, L, "mates")
+    z = (cases.t(spec.det_uniform("mates.z", (B, 8, 32, 8), 14)) * 0.9).to(DEV)
+    t = torch.tensor([3.0, 400.0, 77.0, 950.0, 10.0, 500.0, 640.0, 999.0], device=DEV)
+    w = torch.tensor([1.0, 2.5, 4.0, 0.3, 0.7, 5.0, 3.3, 2.0], device=DEV)
+    enc, mask = P["embeds"].to(DEV), P["mask"].to(DEV)
+
+    def run(lo, hi):
+        kw = dict(encoder_hidden_states=enc[lo:hi], encoder_attention_mask=mask[lo:hi])
+        if guided:
+            kw["guidance"] = w[lo:hi]
+        with torch.no_grad():
+            return net(z[lo:hi], t[lo:hi], **kw).sample.clone()
+    full = run(0, B)
+    for lo, hi in [(0, 4), (4, 8), (2, 5), (0, 7)] + [(s, s + 1) for s in range(B)]:
+        assert torch.equal(run(lo, hi), full[lo:hi]), "samples %d..%d differ from their rows of the batch-8 forward" % (lo, hi - 1)
