@@ -544,6 +544,44 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
           bg = *reinterpret_cast<const float4*>(p.bias + n_val + 16);
         }
         bf16_t* og = reinterpret_cast<bf16_t*>(p.out) + (size_t)g * p.ogs + ((n0 + wn * TN) >> 1) + h4 * 4;
+        if (p.epi_fast_geglu && n0 + wn * TN + TN <= p.n) {
+          // straight-line variant (see wide_epilogue_fast): buffer stores bounded to the M valid rows, row advance in the
+          // scalar offset, nothing predicated, wave-local LDS ordering only
+          constexpr int ITG = CHR / RPG;
+          const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(reinterpret_cast<bf16_t*>(p.out) + (size_t)g * p.ogs), 0,
+              (unsigned)(((long long)(p.M - 1) * p.ldc + (p.n >> 1)) * 2), 0x00020000);
+          const int voff = ((m0 + wm * TM + grow) * p.ldc + ((n0 + wn * TN) >> 1) + h4 * 4) * 2;
+          const int ostep = RPG * p.ldc * 2;
+#pragma unroll
+          for (int j0 = 0; j0 < FM; j0 += CJ) {
+#pragma unroll
+            for (int jj = 0; jj < CJ; ++jj)
+#pragma unroll
+              for (int i = 0; i < FN; ++i) {
+                const f32x4_t a = acc[i][j0 + jj];
+                *reinterpret_cast<float4*>(stg + (jj * 16 + frow) * RSF + (i * 16 + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+              }
+            WAVE_LDS_FENCE();
+#pragma unroll
+            for (int it = 0; it < ITG; ++it) {
+              const int r = grow + it * RPG;
+              const float4 qv = *reinterpret_cast<const float4*>(stg + r * RSF + vcol * 4);
+              const float4 qg = *reinterpret_cast<const float4*>(stg + r * RSF + (vcol + 16) * 4);
+              const float vv[4] = {qv.x + bv.x, qv.y + bv.y, qv.z + bv.z, qv.w + bv.w};
+              const float gg[4] = {qg.x + bg.x, qg.y + bg.y, qg.z + bg.z, qg.w + bg.w};
+              float o[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = vv[e] * (0.5f * gg[e] * (1.0f + erff(gg[e] * 0.70710678118654752f)));
+              u32x2_t pk;
+              pk.x = pack2bf(o[0], o[1]);
+              pk.y = pack2bf(o[2], o[3]);
+              __builtin_amdgcn_raw_buffer_store_b64(pk, rso, voff, ((j0 / CJ) * ITG + it) * ostep, 0);
+            }
+            if (j0 + CJ < FM) WAVE_LDS_FENCE();
+          }
+          return;
+        }
 #pragma unroll
         for (int j0 = 0; j0 < FM; j0 += CJ) {
 #pragma unroll
@@ -553,7 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
               const f32x4_t a = acc[i][j0 + jj];
               *reinterpret_cast<float4*>(stg + (jj * 16 + frow) * RSF + (i * 16 + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
             }
-          __syncthreads();
+          if (p.epi_barrier) __syncthreads(); else WAVE_LDS_FENCE();   // wave-private staging rows
 #pragma unroll 2
           for (int r = grow; r < CHR; r += RPG) {
             const int m = m0 + wm * TM + j0 * 16 + r;
@@ -571,7 +609,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
               *reinterpret_cast<uint2*>(og + (size_t)m * p.ldc) = pk;
             }
           }
-          if (j0 + CJ < FM) __syncthreads();
+          if (j0 + CJ < FM) { if (p.epi_barrier) __syncthreads(); else WAVE_LDS_FENCE(); }
         }
         return;
       }
@@ -965,6 +1003,8 @@ static const Variant kVariants[] = {
     VARIANT(256, 256, 32, 2, 4, 2, 2),  // 30
     VARIANT(256, 128, 64, 2, 2, 2, 2),  // 31  4 waves, 128x64 per wave
     VARIANT(256, 128, 32, 2, 2, 2, 2),  // 32
+    VARIANT(256, 256, 32, 2, 4, 2, 3),  // 33  deeper rings for the big tile (96 / 128 KB)
+    VARIANT(256, 256, 32, 2, 4, 2, 4),  // 34
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -1120,6 +1160,8 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
                   (!d->res || d->res_ld % 4 == 0) && (!d->rowvec || d->rowvec_ld % 4 == 0))
                      ? 1 : 0;
   p.epi_barrier = epi_barrier_default() ? 1 : 0;
+  p.epi_fast_geglu = (epi_fast_default() && !p.epi_barrier && geglu && p.wide_store && p.plain_out &&
+                      M * (long long)d->ldc * 2 < 0x7FFFFF00LL) ? 1 : 0;
   p.epi_fast = (epi_fast_default() && !p.epi_barrier && p.wide_store && M * (long long)d->ldc * 2 < 0x7FFFFF00LL &&
                 (!d->res || M * (long long)d->res_ld * 2 < 0x7FFFFF00LL) && p.plain_out && !geglu && !d->bias_m && !d->gn_part && !(d->accumulate && d->out2) &&
                 (d->out_act == 0 || (d->out_act == 3 && d->out_slope >= 0.f && d->out_slope <= 1.f)) &&
@@ -1128,7 +1170,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   int vid = d->tile;
   if (vid <= 0 && halo_eligible(d, p, groups)) {
     const bool prof = ctta_prof_active();
-    if (prof) ctta_prof_begin(0, 33, M, d->n, K, groups, (hipStream_t)stream);
+    if (prof) ctta_prof_begin(0, 39, M, d->n, K, groups, (hipStream_t)stream);
     launch_halo<32, 256>(p, d->batch, (hipStream_t)stream);
     if (prof) ctta_prof_end((hipStream_t)stream);
     CTTA_LAUNCH_CHECK();
@@ -1196,7 +1238,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     if ((long long)splits * M * ld * 4 > (long long)ws_bytes) splits = 1;
   }
   const bool prof = ctta_prof_active();
-  if (prof) ctta_prof_begin(0, vid + (p.epi_fast ? 0 : 100), M, d->n, K, groups, (hipStream_t)stream);   // +100: generic epilogue
+  if (prof) ctta_prof_begin(0, vid + ((p.epi_fast || p.epi_fast_geglu) ? 0 : 100), M, d->n, K, groups, (hipStream_t)stream);   // +100: generic epilogue
   if (splits == 1 && groups == 1 && xcd_default() && grid.x >= 64) {
     p.m_tiles = (int)grid.x; p.n_tiles = (int)grid.y;
     p.xcd_per = (p.m_tiles + 7) / 8;
