@@ -175,6 +175,11 @@ SIGNATURES = {
     "ctta_resample_poly_bwd": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
                                        c_void_p]),
     "ctta_wav_to_logmel_db": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "ctta_stft_create": (c_int, [c_int, c_int, c_int, c_int, c_int, POINTER(c_void_p)]),
+    "ctta_stft_destroy": (None, [c_void_p]),
+    "ctta_stft_frames": (c_int, [c_void_p, c_int]),
+    "ctta_stft_magnitude": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_stft_magnitude_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ctta_wav_to_logmel_db_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p]),
     "ctta_htsat_image": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                  c_void_p, c_void_p]),

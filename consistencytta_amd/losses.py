@@ -6,7 +6,8 @@ AutoencoderKL.decode_first_stage / decode_to_waveform(allow_grad=True) -- ctta_v
 ctta_hifigan_forward_with_grad on the device -- and only the few reductions after that run as torch ops:
 
   MelLoss                  tools/losses.py:36-64    0.3 * mse(mel(input), mel(target)) + 0.7 * mse(input, target)
-  MultiResolutionSTFTLoss  tools/losses.py:187-256  spectral convergence + log-magnitude over 3 STFT resolutions
+  MultiResolutionSTFTLoss  tools/losses.py:187-256  spectral convergence + log-magnitude over 3 STFT resolutions (the
+                                                    magnitudes and their input gradient on csrc/stft_loss.hip)
   CLAPLoss                 tools/losses.py:259-316  mse + cosine terms of CLAP embeddings of the decoded waveform (clap.py:
                                                     resampler, HTSAT-base audio tower with input gradient, RoBERTa)
 All return one value per instance for reduction='instance' (the only mode AudioLCM uses, audio_consistency_model.py:93-102).
@@ -54,19 +55,84 @@ class MelLoss(nn.Module):
         return reduce(inst, self.reduction)
 
 
+class _STFTMagnitudeFn(torch.autograd.Function):
+    """(B, T) fp32 waveform -> |STFT| (B, frames, fft_size // 2 + 1) fp32 on ctta_stft_magnitude / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, owner):
+        from . import _native as N
+        B, T = x.shape
+        grad = bool(ctx.needs_input_grad[0])     # (grad mode is off inside forward)
+        h = owner._handle(B, T, x.device, grad)
+        xc = x.detach().contiguous().float()
+        frames = T // owner.shift_size + 1
+        mag = torch.empty(B, frames, owner.fft_size // 2 + 1, dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            N.check(N.lib().ctta_stft_magnitude(h, N.ptr(xc), B, T, N.ptr(mag), N.stream_ptr()))
+        ctx.owner, ctx.h, ctx.shape = owner, h, (B, T)
+        if grad:
+            owner._pending = ctx.token = object()   # the handle keeps (re, im) of this call until its backward
+        return mag
+
+    @staticmethod
+    def backward(ctx, dmag):
+        from . import _native as N
+        owner, (B, T) = ctx.owner, ctx.shape
+        if owner._pending is not ctx.token:
+            raise RuntimeError("_STFTMagnitude: another differentiable forward ran on this module before backward; use one "
+                               "module instance per differentiable input")
+        dwav = torch.empty(B, T, dtype=torch.float32, device=dmag.device)
+        g = dmag.contiguous().float()
+        with torch.cuda.device(dmag.device):
+            N.check(N.lib().ctta_stft_magnitude_bwd(ctx.h, N.ptr(g), B, T, N.ptr(dwav), N.stream_ptr()))
+        owner._pending = None
+        return dwav, None
+
+
 class _STFTMagnitude(nn.Module):
-    """|STFT| in float64 like the reference (tools/losses.py:146-169): (B, frames, fft_size // 2 + 1) float32."""
+    """|STFT| of tools/losses.py:146-169 (torch.stft in float64, periodic Hann window centred in fft_size, reflect padding,
+    sqrt(clamp(power, 1e-8)), transposed to (B, frames, bins), float32) on the HIP kernels of csrc/stft_loss.hip: split-bf16
+    GEMM against the windowed DFT basis (fp32-grade), bf16 GEMM + overlap-add for the input gradient.  Two native handles:
+    the differentiable call keeps its spectrum until the backward, a plain call (the target's) must not overwrite it."""
 
     def __init__(self, fft_size, shift_size, win_length, window):
         super().__init__()
+        if window != "hann_window":
+            raise ValueError("_STFTMagnitude: only hann_window (the reference's setting) is built")
         self.fft_size, self.shift_size, self.win_length = fft_size, shift_size, win_length
-        self.register_buffer("window", getattr(torch, window)(win_length))
+        self._h = {False: None, True: None}
+        self._key = {False: None, True: None}
+        self._pending = None
+
+    def _handle(self, B, T, dev, grad):
+        from . import _native as N
+        key = self._key[grad]
+        if self._h[grad] is None or key[0] < B or key[1] < T or key[2] != dev:
+            self._release(grad)
+            Bm, Tm = (max(B, key[0]), max(T, key[1])) if key and key[2] == dev else (B, T)
+            h = N.c_void_p()
+            with torch.cuda.device(dev):
+                N.check(N.lib().ctta_stft_create(self.fft_size, self.shift_size, self.win_length, Bm, Tm, h))
+            self._h[grad], self._key[grad] = h, (Bm, Tm, dev)
+        return self._h[grad]
+
+    def _release(self, grad):
+        if self._h[grad] is not None:
+            from . import _native as N
+            N.lib().ctta_stft_destroy(self._h[grad])
+            self._h[grad] = None
+
+    def __del__(self):
+        try:
+            self._release(False)
+            self._release(True)
+        except Exception:
+            pass
 
     def forward(self, x):
-        spec = torch.stft(x.double(), self.fft_size, self.shift_size, self.win_length, self.window.to(x.device),
-                          return_complex=True)
-        power = spec.real ** 2 + spec.imag ** 2
-        return torch.clamp(power, min=1e-8).sqrt().transpose(2, 1).float()
+        if not x.is_cuda:
+            raise RuntimeError("_STFTMagnitude runs on the HIP kernels: the waveform must be a CUDA(ROCm) tensor")
+        return _STFTMagnitudeFn.apply(x, self)
 
 
 class MultiResolutionSTFTLoss(nn.Module):

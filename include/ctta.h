@@ -504,6 +504,18 @@ ctta_status ctta_resample_poly(const float* x, int batch, int len, const float* 
                                int taps, float* y, int64_t out_len, void* stream);
 ctta_status ctta_resample_poly_bwd(const float* dy, int batch, int64_t out_len, const float* kernels, int up, int down,
                                    int width, int taps, float* dx, int len, void* stream);
+/* |STFT| with input gradient for MultiResolutionSTFTLoss (tools/losses.py:146-169 `stft`, :187-256): torch.stft(center,
+ * reflect padding, periodic Hann window of win_length centred in fft_size) -> sqrt(clamp(re^2 + im^2, 1e-8)), laid out
+ * (batch, frames, fft_size / 2 + 1) with frames = n_samples / hop_size + 1.  The reference computes in float64; here both
+ * GEMM operands are split into three bf16 parts (fp32-grade).  ctta_stft_magnitude_bwd maps d|STFT| of the LAST
+ * ctta_stft_magnitude call on the handle to d wav (batch, n_samples).  One handle per resolution; not thread-safe. */
+typedef struct ctta_stft ctta_stft;
+ctta_status ctta_stft_create(int fft_size, int hop_size, int win_length, int max_batch, int max_samples, ctta_stft** out);
+void ctta_stft_destroy(ctta_stft* h);
+int ctta_stft_frames(const ctta_stft* h, int n_samples);
+ctta_status ctta_stft_magnitude(ctta_stft* h, const float* wav, int batch, int n_samples, float* mag, void* stream);
+ctta_status ctta_stft_magnitude_bwd(ctta_stft* h, const float* dmag, int batch, int n_samples, float* dwav, void* stream);
+
 /* Spectrogram(power 2) + LogmelFilterBank (dB, amin) of htsat.py:684-697 on a ctta_mel_frontend handle: (batch, n_samples)
  * fp32 -> logmel [batch][n_samples / hop + 1][n_mels] fp32; _bwd maps d logmel to d wav for the last forward call. */
 ctta_status ctta_wav_to_logmel_db(ctta_mel_frontend* h, const float* wav, int batch, int n_samples, float amin,

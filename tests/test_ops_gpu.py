@@ -699,3 +699,29 @@ def test_pack_weight_tables_match_gather(threads, lds_floats):
         torch.cuda.synchronize()
         for c, out in zip(cases, outs):
             assert torch.equal(out.cpu().view(torch.int16), c["want"].view(torch.int16)), variant
+
+
+@pytest.mark.parametrize("fft,hop,win", [(1024, 120, 600), (2048, 240, 1200), (512, 50, 240)])
+def test_stft_magnitude_and_input_gradient_against_torch_stft_float64(fft, hop, win):
+    """losses._STFTMagnitude (csrc/stft_loss.hip) against the reference's own recipe, tools/losses.py:146-169:
+    torch.stft(x.double(), ...) -> sqrt(clamp(re^2 + im^2, 1e-8)) -> (B, frames, bins) float32, forward and d/dx."""
+    from consistencytta_amd import losses
+    B, T = 2, 9000
+    gen = torch.Generator().manual_seed(fft)
+    x = (torch.randn(B, T, generator=gen) * 0.2 * torch.linspace(0.05, 1.0, T)).float()
+    direction = torch.randn(B, T // hop + 1, fft // 2 + 1, generator=gen)
+    xr = x.clone().double().requires_grad_(True)
+    spec = torch.stft(xr, fft, hop, win, torch.hann_window(win).double(), return_complex=True)
+    ref = torch.clamp(spec.real ** 2 + spec.imag ** 2, min=1e-8).sqrt().transpose(2, 1)
+    (ref * direction.double()).sum().backward()
+    m = losses._STFTMagnitude(fft, hop, win, "hann_window")
+    xg = x.to(DEV).requires_grad_(True)
+    got = m(xg)
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    (got * direction.to(DEV)).sum().backward()
+    plain = m(x.to(DEV))                               # the no-grad handle gives the same numbers
+    assert torch.equal(plain, got.detach())
+    e_f = float((got.detach().cpu().double() - ref.detach()).norm() / ref.detach().norm())
+    e_b = float((xg.grad.cpu().double() - xr.grad).norm() / xr.grad.norm())
+    print("stft %d/%d/%d: magnitude rel_l2 %.2e, input gradient rel_l2 %.2e" % (fft, hop, win, e_f, e_b))
+    assert e_f <= 2e-6 and e_b <= 1e-2      # forward: three-way bf16 split = fp32-grade; backward: one bf16 GEMM

@@ -421,7 +421,8 @@ def test_distillation_with_mel_loss_backward_matches_oracle_autograd(golden):
 
 def test_multi_resolution_stft_loss_runs_through_the_differentiable_vocoder():
     """MultiResolutionSTFTLoss (tools/losses.py:187-256): latent -> mel -> waveform with allow_grad=True on the HIP
-    engines, three STFT resolutions in torch.  Value against the same formula over the oracle's fp32 waveforms; the
+    engines, three STFT resolutions on csrc/stft_loss.hip.  Value against oracle/losses.py (torch.stft in float64, the
+    reference's recipe) over the oracle's fp32 waveforms; the
     latent gradient must exist and be finite (its LeakyReLU-mask sensitivity is covered in test_engines_gpu.py)."""
     from consistencytta_amd import losses
     from oracle import nets
@@ -435,15 +436,12 @@ def test_multi_resolution_stft_loss_runs_through_the_differentiable_vocoder():
     assert inst.shape == (2,) and torch.isfinite(inst).all()
     assert torch.isfinite(pred.grad).all() and float(pred.grad.abs().max()) > 0
 
-    class _CpuVae:   # the oracle behind the two methods the loss calls
-        def decode_first_stage(self, z, allow_grad=False):
-            return nets.vae_decode(cases.TINY_VAE_DD, sd, z, sf)
-
-        def decode_to_waveform(self, mel, allow_grad=False):
-            return nets.mel_to_waveform(cases.TINY_HIFIGAN, sd, mel)[1]
-    with torch.no_grad():
-        ref = losses.MultiResolutionSTFTLoss(vae=_CpuVae(), reduction="instance", factor_sc=0.1, factor_mag=0.1,
-                                             factor_mse=.8)(pred.detach().cpu(), target.cpu(), None, None)
+    from oracle import losses as olosses
+    with torch.no_grad():   # the oracle's fp32 decode + vocoder, then the reference's own torch.stft recipe
+        wavs = [nets.mel_to_waveform(cases.TINY_HIFIGAN, sd, nets.vae_decode(cases.TINY_VAE_DD, sd, z.detach().cpu(), sf))[1]
+                for z in (pred, target)]
+        ref = olosses.multi_resolution_stft_loss(pred.detach().cpu(), target.cpu(), wavs[0], wavs[1], factor_sc=0.1,
+                                                 factor_mag=0.1, factor_mse=.8)
     print("stft loss", inst.detach().cpu().numpy(), "oracle", ref.numpy())
     assert float((inst.detach().cpu() - ref).abs().max()) <= 5e-2 * float(ref.abs().max())
 
