@@ -28,6 +28,8 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 
 // REL: additionally adds rel_bias[h][key - query + nq - 1] (already in the log2 domain) -- T5's relative position bias
 // (one table per head over the nq + nk - 1 possible offsets); q / out batches are then q_rows rows apart.
+// BMODE 3 (PLAIN): bias == nullptr and nk % 64 == 0 -- self-attention over whole key tiles, its own instantiation so that
+// the two softmax formulations do not share (and inflate) one register allocation.
 // BMODE 2 (FULL): adds full_bias[(b % full_nb)][h][query][key] (log2 domain) -- Swin window attention: relative-position
 // bias per head plus the shifted-window mask, one table per window position (htsat.py:336-361).
 template <int BMODE>
@@ -37,6 +39,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     bf16_t* __restrict__ out, int out_ld, int heads, int nq, int nk, float scale_log2e, float* __restrict__ lse,
     int q_rows, const float* __restrict__ rel_bias, int full_nb) {
   constexpr bool REL = BMODE == 1, FULL = BMODE == 2;
+  constexpr bool PLAIN = BMODE == 3;   // no additive term at all and nk a multiple of the key tile (host-checked)
   __shared__ __attribute__((aligned(16))) bf16_t Ks[ATT_KT * ATT_LDK];   // [key][d]
   __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * ATT_LDV];       // [d][key]
 
@@ -79,6 +82,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   // iteration: the global latency of tile t+1 hides behind the compute of tile t.
   uint4 kreg[2], vreg[2];
   auto fetch = [&](int key0) {
+    if (key0 + ATT_KT <= nk) {   // whole tile (wave-uniform): no per-lane predicates, no tail masking
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int chunk = tid + i * 256;
+        const int r = chunk >> 3, cc = (chunk & 7) * 8;
+        kreg[i] = *reinterpret_cast<const uint4*>(kb + (size_t)(key0 + r) * k_ld + cc);
+        vreg[i] = *reinterpret_cast<const uint4*>(vb + (size_t)r * vt_ld + key0 + cc);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int chunk = tid + i * 256;
@@ -134,6 +147,40 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
     // Written on 4-vectors so that the scale/bias FMA, the max subtraction and the row sums compile to the packed
     // fp32 instructions (v_pk_fma_f32 / v_pk_add_f32: two lanes' worth per issue) -- the softmax VALU work, not the
     // MFMAs, bounds this kernel.
+    if constexpr (PLAIN) {
+      // No additive term (self-attention over a whole key tile: the 4096-token case, 97 % of this kernel's time): the row
+      // maximum is taken on the raw products (scale > 0) and scale and -max fold into ONE packed FMA in front of the
+      // exponential -- this loop is bound by VALU issue, not by the MFMAs (34 v_exp + ~125 other VALU ops against 32 MFMAs
+      // per tile before; the separate subtraction was 32 of them).
+#pragma unroll
+      for (int jq = 0; jq < 2; ++jq) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int ik = 0; ik < 4; ++ik)
+          mx = fmaxf(mx, fmaxf(fmaxf(s[ik][jq][0], s[ik][jq][1]), fmaxf(s[ik][jq][2], s[ik][jq][3])));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mnew = fmaxf(mrun[jq], mx * scale_log2e);
+        const float alpha = fast_exp2(mrun[jq] - mnew);
+        mrun[jq] = mnew;
+        const f32x4_t neg_m = {-mnew, -mnew, -mnew, -mnew};
+        f32x4_t ps4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ik = 0; ik < 4; ++ik) {
+          const f32x4_t d = s[ik][jq] * scale_log2e + neg_m;
+          f32x4_t pv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = fast_exp2(d[r]);
+          s[ik][jq] = pv;
+          ps4 += pv;
+        }
+        lrun[jq] = lrun[jq] * alpha + ((ps4[0] + ps4[1]) + (ps4[2] + ps4[3]));
+        if (__any(alpha != 1.0f)) {
+#pragma unroll
+          for (int jd = 0; jd < 4; ++jd) o[jd][jq] *= alpha;
+        }
+      }
+    } else {
     f32x4_t kbias[4];
 #pragma unroll
     for (int ik = 0; ik < 4; ++ik)
@@ -185,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
         for (int jd = 0; jd < 4; ++jd) o[jd][jq] *= alpha;
       }
     }
+    }   // !plain
     // ---- O^T += V^T P^T : k-slot (lg, e): e<4 -> key block 2kk, row lg*4+e ; e>=4 -> block 2kk+1
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
@@ -252,9 +300,14 @@ extern "C" ctta_status ctta_attention_lse(const void* q, int q_ld, const void* k
   const bool prof = ctta_prof_active();
   // executed flops: QK^T and PV over the padded head dim (2 * 2*nq*nk*64 per head)
   if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
-  hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
-                     (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, bias, (bf16_t*)out, out_ld, heads,
-                     nq, nk, scale * 1.4426950408889634f, lse, nq, (const float*)nullptr, 1);
+  if (!bias && nk % ATT_KT == 0)   // self-attention over whole key tiles: the formulation without an additive term
+    hipLaunchKernelGGL(attention_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
+                       (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, bias, (bf16_t*)out, out_ld, heads,
+                       nq, nk, scale * 1.4426950408889634f, lse, nq, (const float*)nullptr, 1);
+  else
+    hipLaunchKernelGGL(attention_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
+                       (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, bias, (bf16_t*)out, out_ld, heads,
+                       nq, nk, scale * 1.4426950408889634f, lse, nq, (const float*)nullptr, 1);
   if (prof) ctta_prof_end((hipStream_t)stream);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
