@@ -414,7 +414,10 @@ __device__ __forceinline__ void put_rows(bf16_t* lds, int ld, const uint4 (&reg)
   }
 }
 
-template <bool FULL>
+// PLAIN: no additive term (bias == nullptr, no full table) and nk % 64 == 0 -- the softmax rebuild on 4-vectors: P =
+// exp2(s * scale - lse) and dS = P * (dP * scale - D * scale) are one packed FMA + exp, one packed FMA and one packed
+// multiply per pair of elements instead of seven scalar operations and a key-range test per element.
+template <bool FULL, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * ATT_LDK];    // [key][d]
   __shared__ __attribute__((aligned(16))) bf16_t Vn[64 * ATT_LDK];    // [key][d]
@@ -487,6 +490,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
       }
     }
     // dS^T = P^T * (dP^T - D) * scale, lane holds keys key0 + ik*16 + lg*4 + r for query column lq
+    if constexpr (PLAIN) {
+#pragma unroll
+      for (int jq = 0; jq < 2; ++jq) {
+        const float nl = -lse_q[jq], nd = -d_q[jq] * p.scale;
+        const f32x4_t nl4 = {nl, nl, nl, nl}, nd4 = {nd, nd, nd, nd};
+#pragma unroll
+        for (int ik = 0; ik < 4; ++ik) {
+          const f32x4_t e = s[ik][jq] * p.scale_log2e + nl4;
+          f32x4_t pv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = fast_exp2(e[r]);
+          s[ik][jq] = pv * (dp[ik][jq] * p.scale + nd4);
+        }
+      }
+    } else
 #pragma unroll
     for (int ik = 0; ik < 4; ++ik)
 #pragma unroll
@@ -543,7 +561,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   }
 }
 
-template <bool FULL>
+template <bool FULL, bool PLAIN>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * ATT_LDK];     // [query][d]
   __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * ATT_LDK];    // [query][d]
@@ -608,9 +626,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     put_rows(dOs, ATT_LDK, rdo, tid);
     put_rows(QTs, ATT_LDV, rqt, tid);
     stage_rows(dOTs, ATT_LDV, dotb + q0, p.qt_ld, 64, tid);
-    if (tid < 64) {
-      lse_s[tid] = r_lse;
-      d_s[tid] = r_d;
+    if (tid < 64) {   // PLAIN keeps them negated (and D pre-scaled): operands of the packed FMAs below
+      lse_s[tid] = PLAIN ? -r_lse : r_lse;
+      d_s[tid] = PLAIN ? -r_d * p.scale : r_d;
     }
     __syncthreads();
     if (t + 1 < t_end) fetch(q0 + 64);
@@ -637,6 +655,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
       const float4 d4 = *reinterpret_cast<const float4*>(d_s + iq * 16 + lg * 4);
       const float lv[4] = {l4.x, l4.y, l4.z, l4.w};
       const float dd[4] = {d4.x, d4.y, d4.z, d4.w};
+      if constexpr (PLAIN) {
+        const f32x4_t nl4 = {l4.x, l4.y, l4.z, l4.w}, nd4 = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int jk = 0; jk < 2; ++jk) {
+          const f32x4_t e = s[iq][jk] * p.scale_log2e + nl4;
+          f32x4_t pv;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pv[r] = fast_exp2(e[r]);
+          s[iq][jk] = pv;
+          dp[iq][jk] = pv * (dp[iq][jk] * p.scale + nd4);
+        }
+      } else
 #pragma unroll
       for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -786,8 +816,10 @@ static ctta_status attention_bwd_impl(const void* q, int q_ld, const void* k, in
   const bool prof = ctta_prof_active();
   // executed flops: 7 products of 2*nq*nk*64 per head (S and dP are computed by both kernels)
   if (prof) ctta_prof_begin(1, 1, nq, nk, 448, (long long)batch * heads, s);
-  if (full_bias) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
+  const bool plain = !full_bias && !p.bias && nk % 64 == 0 && nq % 64 == 0;   // self-attention over whole tiles
+  if (full_bias) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
+  else if (plain) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
   // few keys (cross-attention): split the query walk so that the launch still fills the chip
   const int ntiles = (nq + 63) / 64, kblocks = (nk + 127) / 128, hp = heads * 64;
   int nz = 1;
@@ -798,8 +830,9 @@ static ctta_status attention_bwd_impl(const void* q, int q_ld, const void* k, in
   p.q_tiles_per_split = (ntiles + nz - 1) / nz;
   p.part = nz > 1 ? partial : nullptr;
   p.batch = batch; p.hp = hp;
-  if (full_bias) hipLaunchKernelGGL(attn_bwd_dkv_kernel<true>, dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL(attn_bwd_dkv_kernel<false>, dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
+  if (full_bias) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
+  else if (plain) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
   if (nz > 1) {
     CTTA_REQUIRE(dk_ld >= hp && dv_ld >= hp, "attention_bwd: split path needs dk/dv rows of at least heads*64");
     const long long total = (long long)batch * nk * hp;
