@@ -22,6 +22,11 @@
 // element in a VALU-bound loop); probabilities below 2^-126 flushing to zero is immaterial here
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+static bool attn_plain_enabled() {   // CTTA_ATTN_PLAIN=0: always the general kernels (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_ATTN_PLAIN"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
 #define ATT_KT 64          // keys per tile
 #define ATT_LDK 80         // K tile row stride (bf16): 160 B rows are conflict-free for ds_read_b128
 #define ATT_LDV 72         // V^T tile row stride: 144 B rows are conflict-free for the paired ds_read_b64
@@ -300,7 +305,7 @@ extern "C" ctta_status ctta_attention_lse(const void* q, int q_ld, const void* k
   const bool prof = ctta_prof_active();
   // executed flops: QK^T and PV over the padded head dim (2 * 2*nq*nk*64 per head)
   if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
-  if (!bias && nk % ATT_KT == 0)   // self-attention over whole key tiles: the formulation without an additive term
+  if (!bias && nk % ATT_KT == 0 && attn_plain_enabled())   // self-attention over whole key tiles: no additive term
     hipLaunchKernelGGL(attention_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
                        (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, bias, (bf16_t*)out, out_ld, heads,
                        nq, nk, scale * 1.4426950408889634f, lse, nq, (const float*)nullptr, 1);
@@ -816,7 +821,7 @@ static ctta_status attention_bwd_impl(const void* q, int q_ld, const void* k, in
   const bool prof = ctta_prof_active();
   // executed flops: 7 products of 2*nq*nk*64 per head (S and dP are computed by both kernels)
   if (prof) ctta_prof_begin(1, 1, nq, nk, 448, (long long)batch * heads, s);
-  const bool plain = !full_bias && !p.bias && nk % 64 == 0 && nq % 64 == 0;   // self-attention over whole tiles
+  const bool plain = !full_bias && !p.bias && nk % 64 == 0 && nq % 64 == 0 && attn_plain_enabled();   // self-attention over whole tiles
   if (full_bias) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
   else if (plain) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
   else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
