@@ -41,6 +41,9 @@ d.w, d.k_pad, d.n, d.bias = ws.data_ptr(), 11 * C, C, bs.data_ptr()
 d.alpha, d.groups, d.out, d.ldc, d.tile = 1.0, 1, outs.data_ptr(), C, int(os.environ.get('TILE', '0'))
 xa = torch.randn(64, 1024, device=DEV); Wa = torch.randn(4096, 1024, device=DEV); ba = torch.randn(4096, device=DEV); ya = torch.empty(64, 4096, device=DEV)
 BIG = torch.randn(16384, 16384, device=DEV) if mode.startswith('bigtorch') else None; BIG2 = torch.randn(16384, 16384, device=DEV) if mode.startswith('bigtorch') else None
+if mode.startswith('gn'):
+    GX = torch.randn(32, 65536, 128, device=DEV).to(torch.bfloat16); GY = torch.empty_like(GX); GG = torch.ones(128, device=DEV); GB = torch.zeros(128, device=DEV)
+    GS = torch.empty(int(L.ctta_groupnorm_scratch_floats(32, 65536, 128, 32)), device=DEV)
 bad = 0
 for i in range(40):
     x = torch.randn(M, K, device=DEV)          # new values every iteration: a stale read cannot hide
@@ -55,6 +58,8 @@ for i in range(40):
             for _ in range(50): N.check(L.ctta_linear_f32(N.ptr(xa), N.ptr(Wa), N.ptr(ba), N.ptr(ya), 64, 4096, 1024, 0, 1, N.stream_ptr()))
         elif mode.startswith("torch"):
             for _ in range(20): _ = Wa @ Wa.t()
+        elif mode.startswith("gn"):          # a plain streaming kernel of this library as the co-runner
+            N.check(L.ctta_groupnorm(N.ptr(GX), N.ptr(GY), 32, 65536, 128, 32, N.ptr(GG), N.ptr(GB), 1e-5, 1, N.ptr(GS), N.stream_ptr()))
         elif mode.startswith("bigtorch"):
             _ = BIG @ BIG2                                  # one ~10 ms kernel on every CU
     if os.environ.get('MAIN2') == '1':
