@@ -4,7 +4,11 @@ set -euo pipefail
 cd "$(dirname "$0")"
 OUT=../libctta_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
+# -fno-slp-vectorize: clang's SLP vectoriser pairs scalar fp32 work into v_pk_*_f32 with op_sel source swizzles, and
+# `v_pk_fma_f32 ... op_sel:[0,1,0]` returns wrong low-lane results on these MI355X boxes while waves of ANOTHER kernel issue
+# MFMAs on the same CU (tools/pk_hazard.py) -- which is what two engine handles on two streams do.
+# tools/check_isa.py (also a test) verifies that the built library contains no such form.
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-variable ${CTTA_EXTRA_FLAGS:-}"
 mkdir -p build
 pids=()
 for f in api conv_gemm resunit clap_ops norm_elem attention backward engine_unet engine_vae engine_t5 mel_frontend stft_loss; do

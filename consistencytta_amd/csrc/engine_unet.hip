@@ -143,7 +143,7 @@ struct ctta_unet {
   // SECOND stream: the data-gradient chain on the caller's stream is the critical path of the backward pass, its thin
   // batch-9 launches leave CUs idle, and a layer's weight gradient depends on nothing that comes after it.  Each job
   // owns one of NS scratch slots (dY^T is written by the main stream, everything else by the side stream); events
-  // order slot reuse and the joins at block boundaries.  OFF unless CTTA_WGRAD_STREAM=1 (see ctta_unet_create).
+  // order slot reuse and the joins at block boundaries.  CTTA_WGRAD_STREAM=0 keeps everything on one stream.
   struct WgradSide {
     static constexpr int NS = 2;
     hipStream_t stream = nullptr;
@@ -759,12 +759,8 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
     size_t slot_bytes = 0;
     for (Arena& a : W.slot) if (a.peak > slot_bytes) slot_bytes = a.peak;
     slot_bytes = (slot_bytes + 4095) & ~(size_t)4095;
-    // OFF by default: with the weight-gradient jobs in a second hardware queue the full-batch gradients vary from run to
-    // run by 1.5e-7 .. 3.8e-7 relative instead of the 1.6e-8 of the LayerNorm atomics -- occasional stale reads in
-    // dependent kernel chains while another queue is busy (tools/two_queue_coherence.py).  CTTA_WGRAD_STREAM=1
-    // turns the overlap on (-2.4 % step time).
-    const char* e = getenv("CTTA_WGRAD_STREAM");
-    W.enabled = e && e[0] == '1';
+    const char* e = getenv("CTTA_WGRAD_STREAM");   // =0: one stream
+    W.enabled = !(e && e[0] == '0');
     if (hipMalloc((void**)&W.base, slot_bytes * ctta_unet::WgradSide::NS + 4096) != hipSuccess) {
       ctta_set_error("unet_create: hipMalloc of the weight-gradient scratch (%zu bytes) failed", slot_bytes * 2);
       st = CTTA_ERR_NOMEM;

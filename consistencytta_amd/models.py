@@ -479,18 +479,16 @@ class AudioLCM(AudioDistilledModel):
             guidance_scale = guidance_scale.to(dev)
         else:
             guidance_scale = None
-        # The student's training forward depends only on the noised input, not on the teacher, and can be enqueued on a
-        # second HIP stream beside the two teacher queries and the target network (every engine handle owns its arena and
-        # split-K workspace).  OFF by default (CTTA_TWO_STREAM=1 enables it): on this ROCm stack a chain of dependent
-        # kernels inside ONE stream reads stale cache lines while a second hardware queue keeps the CUs busy, unless an
-        # event-induced fence separates producer and consumer (tools/two_queue_coherence.py reproduces it with two
-        # ctta_linear_f32 launches: 40 of 40 iterations wrong beside a concurrent conv_gemm, 0 of 40 with
-        # GPU_MAX_HW_QUEUES=1 or with agent-scope loads).  The engines' kernel chains have no such fences, so overlapping
-        # two of them made the teacher's output -- and the loss -- vary from run to run (caught by
-        # test_distillation_step_full_batch_is_deterministic_and_blockwise_exact).  The weight-gradient side stream of
-        # the backward pass is different: every job starts behind an event wait and touches its scratch once.
+        # The student's training forward depends only on the noised input, not on the teacher: enqueue it on a second
+        # HIP stream so that it runs beside the two teacher queries and the target network (the thin deep-level
+        # launches of a batch-9/18 forward leave CUs idle).  Every engine handle owns its arena and split-K workspace,
+        # so the two streams share no scratch memory.  CTTA_TWO_STREAM=0 keeps everything on one stream.
+        # (Two kernels of different handles on one CU once made the teacher's output vary from run to run: an
+        # SLP-generated `v_pk_fma_f32 ... op_sel:[0,1,0]` in the fp32 MLP kernel reads a wrong dword beside another
+        # kernel's MFMA waves -- tools/pk_hazard.py.  The library is built without that instruction form and
+        # tools/check_isa.py keeps it out; test_distillation_step_full_batch_is_deterministic... guards the overlap.)
         side_pred = None
-        if (want_grad and validation_mode == 0 and z_0.is_cuda and os.environ.get("CTTA_TWO_STREAM", "0") == "1"):
+        if (want_grad and validation_mode == 0 and z_0.is_cuda and os.environ.get("CTTA_TWO_STREAM", "1") != "0"):
             cur = torch.cuda.current_stream(dev)
             side = self._side_stream(dev)
             w_stu = guidance_scale if guidance_scale is not None else float(self.teacher_guidance_scale)

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Scans the device code inside libctta_hip.so for instruction forms this build must not contain.
+
+`v_pk_*_f32 ... op_sel:[...]` -- a packed fp32 operation whose LOW lane takes the HIGH dword of a source pair.  On the
+MI355X boxes of this pool `v_pk_fma_f32 vD, vA, vB, vC op_sel:[0,1,0]` returns wrong low-lane results while waves of another
+kernel issue MFMAs on the same CU (tools/pk_hazard.py: 11 904 wrong lanes in 20 launches beside ctta_conv_gemm, 0 alone, 0
+for the scalar twin, 0 for the plain and the op_sel_hi forms).  clang's SLP vectoriser emits that form (8 sites in the
+round-2 build, all in the small fp32 MLP kernel); it is the reason two engine handles on two streams gave run-to-run
+different results.  build.sh therefore compiles with -fno-slp-vectorize, and this scan (also run by tests/) keeps the
+form from coming back through hand-written vector code.
+
+    python tools/check_isa.py [path/to/libctta_hip.so]      exit status 1 if a forbidden form is present"""
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+FORBIDDEN = re.compile(r"\bv_pk_\w*f32\b.*\bop_sel:\[")
+
+
+def code_objects(path):
+    data = open(path, "rb").read()
+    pos = 0
+    while True:
+        i = data.find(MAGIC, pos)
+        if i < 0:
+            return
+        n, = struct.unpack_from("<Q", data, i + len(MAGIC))
+        off = i + len(MAGIC) + 8
+        for _ in range(n):
+            o, size, tl = struct.unpack_from("<QQQ", data, off)
+            triple = data[off + 24:off + 24 + tl].decode()
+            off += 24 + tl
+            if "gfx" in triple and size > 0:
+                yield triple, data[i + o:i + o + size]
+        pos = i + len(MAGIC)
+
+
+def scan(path):
+    hits, n_insn, n_obj = [], 0, 0
+    for triple, blob in code_objects(path):
+        n_obj += 1
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob)
+            f.flush()
+            out = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], capture_output=True, text=True, check=True).stdout
+        kernel = "?"
+        for line in out.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                kernel = m.group(1)
+                continue
+            if "v_" in line or "s_" in line:
+                n_insn += 1
+            if FORBIDDEN.search(line):
+                hits.append((kernel, line.strip()))
+    return hits, n_insn, n_obj
+
+
+if __name__ == "__main__":
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                             "consistencytta_amd", "libctta_hip.so")
+    hits, n_insn, n_obj = scan(lib)
+    print("%s: %d code objects, %d instructions scanned, %d forbidden packed-fp32 op_sel forms" % (lib, n_obj, n_insn, len(hits)))
+    for k, l in hits[:20]:
+        print("  %s: %s" % (k[:60], l))
+    sys.exit(1 if hits else 0)

@@ -7,8 +7,9 @@ Main stream: y = W2 silu(W x + b) + b as two ctta_linear_f32 launches on fresh r
 torch.  Side stream (non-blocking), concurrently: nothing / three big-tile ctta_conv_gemm launches / fifty ctta_linear_f32
 launches / twenty torch matmuls.  Measured on MI355X, ROCm 7.0 runtime of the PyTorch wheel: `conv` 40 of 40 iterations
 wrong (stale reads: the rerun without concurrency is right), `none` / `lin` / `torch` 0 of 40, GPU_MAX_HW_QUEUES=1 0 of 40,
-agent-scope atomic loads in the consumer 0 of 40.  This is why AudioLCM's two-stream forward (CTTA_TWO_STREAM=1) is off by
-default; MAIN2=1 runs the chain on an explicit stream instead of the null stream (38 of 40), TILE=n picks the conv variant."""
+agent-scope atomic loads in the consumer 0 of 40 (round-2 build WITH the SLP vectoriser).  The cause turned out to be an
+instruction form, not coherence: tools/pk_hazard.py; built with -fno-slp-vectorize this script reports 0 of 40
+in every mode.  MAIN2=1 runs the chain on an explicit stream instead of the null stream, TILE=n picks the conv variant."""
 import os, sys, ctypes
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -21,6 +22,10 @@ M, K, Nn = 18, 256, 1024
 W = torch.randn(Nn, K, device=DEV) * 0.05; b = torch.randn(Nn, device=DEV); W2 = torch.randn(Nn, Nn, device=DEV) * 0.03
 def chain(x):
     h = torch.empty(M, Nn, device=DEV); y = torch.empty(M, Nn, device=DEV)
+    if mode.endswith("torcheltmain"):      # torch elementwise chain through fresh buffers (returned as (h, y) lookalikes)
+        a1 = x * 2.0; a2 = a1 + 1.0; a3 = a2.sin(); a4 = a3 * 3.0; a5 = a4.cos(); got = a5 + x
+        refc = ((x * 2.0 + 1.0).sin() * 3.0).cos() + x if False else None
+        return got, got
     if mode.endswith("torchmain"):
         h = torch.nn.functional.silu(x @ W.t() + b); y = h @ W2.t() + b
         return h, y
@@ -49,6 +54,7 @@ for i in range(40):
     x = torch.randn(M, K, device=DEV)          # new values every iteration: a stale read cannot hide
     torch.cuda.synchronize()
     ref_h = torch.nn.functional.silu(x @ W.t() + b); ref_y = ref_h @ W2.t() + b
+    if mode.endswith('torcheltmain'): ref_h = ref_y = ((x * 2.0 + 1.0).sin() * 3.0).cos() + x
     torch.cuda.synchronize()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
