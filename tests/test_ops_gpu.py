@@ -725,3 +725,46 @@ def test_stft_magnitude_and_input_gradient_against_torch_stft_float64(fft, hop, 
     e_b = float((xg.grad.cpu().double() - xr.grad).norm() / xr.grad.norm())
     print("stft %d/%d/%d: magnitude rel_l2 %.2e, input gradient rel_l2 %.2e" % (fft, hop, win, e_f, e_b))
     assert e_f <= 2e-6 and e_b <= 1e-2      # forward: three-way bf16 split = fp32-grade; backward: one bf16 GEMM
+
+
+def test_fp32_mlp_kernel_is_exact_beside_a_concurrent_conv_gemm():
+    """Two engine handles on two streams put kernels of different kinds on one CU.  The fp32 MLP kernel once returned wrong
+    rows there: an SLP-generated `v_pk_fma_f32 ... op_sel:[0,1,0]` reads a wrong dword beside another kernel's MFMA waves
+    (tools/pk_hazard.py, DESIGN.md 5).  The library is built without that form (tools/check_isa.py is the static guard);
+    this is the dynamic one: a dependent pair of ctta_linear_f32 launches on fresh inputs beside three big conv_gemm
+    launches on a second stream must match torch every time."""
+    L = N.lib()
+    M, K, Nn, C = 18, 256, 1024, 256
+    W = torch.randn(Nn, K, device=DEV) * 0.05
+    b = torch.randn(Nn, device=DEV)
+    W2 = torch.randn(Nn, Nn, device=DEV) * 0.03
+    xs = (torch.randn(16, 1, 20484, C, device=DEV) * 0.5).to(torch.bfloat16)
+    outs = torch.empty_like(xs)
+    ws = (torch.randn(C, 11 * C, device=DEV) * 0.05).to(torch.bfloat16)
+    bs = torch.randn(C, device=DEV)
+    d = N.ConvDesc()
+    d.x0, d.c0 = xs.data_ptr(), C
+    d.batch, d.hi, d.wi, d.ho, d.wo = 16, 1, 20484, 1, 20484
+    d.kh, d.kw, d.stride_h, d.stride_w, d.dil_h, d.dil_w = 1, 11, 1, 1, 1, 1
+    d.pad_h, d.pad_w = 0, 5
+    d.w, d.k_pad, d.n, d.bias = ws.data_ptr(), 11 * C, C, bs.data_ptr()
+    d.alpha, d.groups, d.out, d.ldc = 1.0, 1, outs.data_ptr(), C
+    side = torch.cuda.Stream()
+    worst = 0.0
+    for _ in range(12):
+        x = torch.randn(M, K, device=DEV)
+        ref_h = F.silu(x @ W.t() + b)
+        ref_y = ref_h @ W2.t() + b
+        torch.cuda.synchronize()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                N.check(L.ctta_conv_gemm(ctypes.byref(d), N.stream_ptr()))
+        h = torch.empty(M, Nn, device=DEV)
+        y = torch.empty(M, Nn, device=DEV)
+        N.check(L.ctta_linear_f32(N.ptr(x), N.ptr(W), N.ptr(b), N.ptr(h), M, Nn, K, 0, 1, N.stream_ptr()))
+        N.check(L.ctta_linear_f32(N.ptr(h), N.ptr(W2), N.ptr(b), N.ptr(y), M, Nn, Nn, 0, 0, N.stream_ptr()))
+        torch.cuda.synchronize()
+        worst = max(worst, float((h - ref_h).abs().max()), float((y - ref_y).abs().max()))
+    print("linear_f32 chain beside conv_gemm: worst abs error %.2e" % worst)
+    assert worst <= 2e-4
