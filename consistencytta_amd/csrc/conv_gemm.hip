@@ -336,6 +336,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 
   // ---------------- MODE 2: descriptor path, K-loop-invariant address work hoisted
   unsigned fvoff[XP], fmask[XP], fph[XP], fpw[XP], fwoff[WP];
+  int fih0[XP], fiw0[XP];
   int ftap = 0, fkh = 0, fkw = 0, fcb = 0;   // wave-uniform K state (tap index, its (kh,kw), channel base)
   __amdgpu_buffer_rsrc_t rsx, rsw;
   if constexpr (MODE == 2) {
@@ -353,34 +354,21 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     }
     rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, p.x_bytes, 0x00020000);
     rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
+    // Only what the FIRST K tile needs is computed here (pixel offsets and the validity of its one tap); the tap-validity
+    // masks of all taps follow in full_masks(), called right after that tile's loads are in flight, so that this ALU
+    // work (1.85 us per tile, tools/tile_timeline.py) runs inside the first load's latency instead of in front of it.
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
       const int m = m0 + r0 + i * RPP;
       unsigned mask = 0;
-      int pix = 0, ph = 0, pw = 0;
+      int pix = 0, ph = 0, pw = 0, ih0 = -(1 << 28), iw0 = 0;
       if (m < p.M) {
         const int b = fast_div(m, p.howo, p.howo_inv);
         const int rem = m - b * p.howo;
         const int oh = fast_div(rem, p.wo, p.wo_inv);
         const int ow = rem - oh * p.wo;
-        const int ih0 = oh * p.sh - p.ph, iw0 = ow * p.sw - p.pw;
-        // valid taps are a rectangle: rows a with 0 <= ih0 + a*dh < hi  x  columns bq with 0 <= iw0 + bq*dw < wi.
-        // Undilated axes get their bit range by arithmetic, dilated ones by a loop over that axis only (this block runs
-        // once per tile and was 2.8-4.1 us of it with a compare pair per tap, tools/tile_timeline.py)
-        unsigned hm = 0, wmk = 0;
-        if (p.dh == 1) {
-          const int lo = max(0, -ih0), hi_ = min(p.kh - 1, p.hi - 1 - ih0);
-          if (hi_ >= lo) hm = (2u << hi_) - (1u << lo);
-        } else {
-          for (int a = 0; a < p.kh; ++a) if ((unsigned)(ih0 + a * p.dh) < (unsigned)p.hi) hm |= 1u << a;
-        }
-        if (p.dw == 1) {
-          const int lo = max(0, -iw0), hi_ = min(p.kw - 1, p.wi - 1 - iw0);
-          if (hi_ >= lo) wmk = (2u << hi_) - (1u << lo);
-        } else {
-          for (int bq = 0; bq < p.kw; ++bq) if ((unsigned)(iw0 + bq * p.dw) < (unsigned)p.wi) wmk |= 1u << bq;
-        }
-        for (int a = 0; a < p.kh; ++a) if ((hm >> a) & 1u) mask |= wmk << (a * p.kw);
+        ih0 = oh * p.sh - p.ph; iw0 = ow * p.sw - p.pw;
+        if ((unsigned)(ih0 + fkh * p.dh) < (unsigned)p.hi && (unsigned)(iw0 + fkw * p.dw) < (unsigned)p.wi) mask = 1u << ftap;
         if (p.ups) {   // 3x3 / pad 1 / stride 1 on a x2 nearest-upsampled source: base = (oh>>1, ow>>1)
           pix = (b * p.hs + (oh >> 1)) * p.ws + (ow >> 1);
           ph = oh & 1; pw = ow & 1;
@@ -388,6 +376,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
           pix = (b * p.hs + ih0) * p.ws + iw0;
         }
       }
+      fih0[i] = ih0; fiw0[i] = iw0;
       fmask[i] = mask;
       fvoff[i] = (unsigned)(pix * p.xs0 + kc * 8) * 2u;      // bytes; wraps correctly for border rows
       fph[i] = ph ? (unsigned)(p.ws * p.xs0) * 2u : 0u;
@@ -396,6 +385,30 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 #pragma unroll
     for (int j = 0; j < WP; ++j) fwoff[j] = (unsigned)((n0 + r0 + j * RPP) * p.k_pad + kc * 8) * 2u;
   }
+  // valid taps are a rectangle: rows a with 0 <= ih0 + a*dh < hi  x  columns bq with 0 <= iw0 + bq*dw < wi.  Undilated
+  // axes get their bit range by arithmetic, dilated ones by a loop over that axis only (rows past M carry ih0 = -2^28:
+  // empty ranges).
+  auto full_masks = [&]() {
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int ih0 = fih0[i], iw0 = fiw0[i];
+      unsigned hm = 0, wmk = 0, mask = 0;
+      if (p.dh == 1) {
+        const int lo = max(0, -ih0), hi_ = min(p.kh - 1, p.hi - 1 - ih0);
+        if (hi_ >= lo) hm = (2u << hi_) - (1u << lo);
+      } else {
+        for (int a = 0; a < p.kh; ++a) if ((unsigned)(ih0 + a * p.dh) < (unsigned)p.hi) hm |= 1u << a;
+      }
+      if (p.dw == 1) {
+        const int lo = max(0, -iw0), hi_ = min(p.kw - 1, p.wi - 1 - iw0);
+        if (hi_ >= lo) wmk = (2u << hi_) - (1u << lo);
+      } else {
+        for (int bq = 0; bq < p.kw; ++bq) if ((unsigned)(iw0 + bq * p.dw) < (unsigned)p.wi) wmk |= 1u << bq;
+      }
+      for (int a = 0; a < p.kh; ++a) if ((hm >> a) & 1u) mask |= wmk << (a * p.kw);
+      fmask[i] = mask;
+    }
+  };
   auto issue_fast = [&](int kt, int buf) {
     bf16_t* xs = Xs + buf * BM * LDK + wave_u * ROWS_PER_INSTR * LDK;
     bf16_t* ws = Ws + buf * BN * LDK + wave_u * ROWS_PER_INSTR * LDK;
@@ -464,7 +477,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     constexpr int INFLIGHT = (STAGES - 2) * LPT; // what may stay outstanding while tile kt is consumed
     int issued = 0;
     for (; issued < STAGES - 1 && issued < nk; ++issued) {
-      if constexpr (MODE == 2) issue_fast(kt_begin + issued, issued); else issue_tile(kt_begin + issued, issued);
+      if constexpr (MODE == 2) { issue_fast(kt_begin + issued, issued); if (issued == 0) full_masks(); }
+      else issue_tile(kt_begin + issued, issued);
     }
     int slot = 0, fill = issued % STAGES;
     for (int kt = 0; kt < nk; ++kt) {
@@ -483,6 +497,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     if (stamp && threadIdx.x == 0) stamp[5] = __builtin_amdgcn_s_memtime();
     if constexpr (MODE == 2) {
       issue_fast(kt_begin, 0);
+      full_masks();
     } else if constexpr (MODE == 1) {
       issue_tile(kt_begin, 0);
     } else {
