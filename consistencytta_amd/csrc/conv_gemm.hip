@@ -187,6 +187,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   }
   const int m0 = mt * BM;
   const int n0 = nt * BN;
+  // a wave whose TM rows all lie past M (the last row tile of M = k * BM + a few rows) skips its MFMAs: its SIMD partner
+  // then runs at full matrix-pipe rate and the tail tile of a one-workgroup-per-CU launch takes about half a tile time
+  const bool wave_live = m0 + (wave / WN) * TM < p.M;
   const int zs = blockIdx.z;
   const int g = p.ksplit > 1 ? 0 : zs;                    // group index (pointer offsets)
   const int kt_begin = p.ksplit > 1 ? zs * p.nk_split : 0;
@@ -490,7 +493,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         ++issued;
         fill = (fill + 1 == STAGES) ? 0 : fill + 1;
       }
-      compute_tile(slot);
+      if (wave_live) compute_tile(slot);
       slot = (slot + 1 == STAGES) ? 0 : slot + 1;
     }
   } else {
@@ -513,7 +516,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         else if constexpr (MODE == 1) issue_tile(kt_begin + kt + 1, buf ^ 1);
         else load_tile(kt_begin + kt + 1);
       }
-      compute_tile(buf);
+      if (wave_live) compute_tile(buf);
       if constexpr (!GLDS) {
         if (kt + 1 < nk) store_tile(buf ^ 1);
       }
