@@ -768,3 +768,52 @@ def test_fp32_mlp_kernel_is_exact_beside_a_concurrent_conv_gemm():
         worst = max(worst, float((h - ref_h).abs().max()), float((y - ref_y).abs().max()))
     print("linear_f32 chain beside conv_gemm: worst abs error %.2e" % worst)
     assert worst <= 2e-4
+
+
+@pytest.mark.parametrize("tile", [0, 17, 18, 21, 22, 24, 28, 29, 32])
+@pytest.mark.parametrize("mode", ["bias", "res", "res_out2", "acc", "res_acc_lrelu", "rowvec_res"])
+def test_straight_line_epilogue_classes(tile, mode):
+    """Every class of the straight-line wide-store epilogue (wide_epilogue_fast<RES, OUT2, ACC>: bias / per-sample row vector /
+    residual / second LeakyReLU output / accumulate + scale + LeakyReLU) on 1-D convolutions whose row count is NOT a multiple
+    of any tile (the last row tile is partial: rows past M must be dropped by the buffer bounds, and on the 256-row tiles whole
+    waves lie past M and skip their MFMAs) and whose length is not a multiple of the tile either, so that with a row vector
+    some tiles straddle two samples (generic path) and others do not (fast path)."""
+    B, C, L, k = 3, 256, 1111, 3
+    x = bf16_round(det("sle.x", (B, C, L), 1))
+    w = bf16_round(det("sle.w", (C, C, k), 2) * (1.0 / math.sqrt(C * k)))
+    b = det("sle.b", (C,), 3) * 0.1
+    res = bf16_round(det("sle.r", (B, C, L), 4))
+    old = bf16_round(det("sle.o", (B, C, L), 5))
+    rv = det("sle.rv", (B, C), 6)
+    ref = F.conv1d(x, w, b, padding=1)
+    nlc = lambda t: t.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)     # noqa: E731
+    wp, k_pad = pack_conv_weight(w[:, :, None, :])
+    out = nlc(old)
+    kw = dict(x0=nlc(x), c0=C, batch=B, hi=1, wi=L, ho=1, wo=L, kh=1, kw=k, pad_w=1, w=wp, k_pad=k_pad, n=C, bias=b.to(DEV),
+              out=out, ldc=C, tile=tile)
+    keep, ref2, out2 = [wp, kw["x0"], kw["bias"]], None, None
+    if mode in ("res", "res_out2", "res_acc_lrelu", "rowvec_res"):
+        rs = nlc(res)
+        kw.update(res=rs, res_ld=C)
+        keep.append(rs)
+        ref = ref + res
+    if mode == "rowvec_res":
+        rvd = rv.to(DEV)
+        kw.update(rowvec=rvd, rowvec_ld=C)
+        keep.append(rvd)
+        ref = ref + rv[:, :, None]
+    if mode in ("acc", "res_acc_lrelu"):
+        kw.update(accumulate=1)
+        ref = ref + old
+    if mode == "res_acc_lrelu":
+        kw.update(alpha=1.0 / 3.0, out_act=3, out_slope=0.1)
+        ref = F.leaky_relu(ref / 3.0, 0.1)
+    if mode == "res_out2":
+        out2 = torch.zeros_like(out)
+        kw.update(out2=out2, out2_slope=0.1)
+        ref2 = F.leaky_relu(bf16_round(ref), 0.1)
+    run_conv(conv_desc(**kw))
+    got = out.to(torch.float32).permute(0, 2, 1).cpu()
+    assert rel_err(got, ref) < 2 * BF16_TOL
+    if ref2 is not None:
+        assert rel_err(out2.to(torch.float32).permute(0, 2, 1).cpu(), ref2) < 2 * BF16_TOL
