@@ -3,7 +3,8 @@
 
 `v_pk_*_f32 ... op_sel:[...]` -- a packed fp32 operation whose LOW lane takes the HIGH dword of a source pair.  On the
 MI355X boxes of this pool `v_pk_fma_f32 vD, vA, vB, vC op_sel:[0,1,0]` returns wrong low-lane results while waves of another
-kernel issue MFMAs on the same CU (tools/pk_hazard.py: 11 904 wrong lanes in 20 launches beside ctta_conv_gemm, 0 alone, 0
+kernel issue MFMAs on the same CU (tools/pk_hazard.py: 11 904 wrong lanes in 20 launches beside ctta_conv_gemm, 701 568
+beside a kernel that only issues v_mfma_f32_16x16x32_bf16, 0 beside an HBM-copy or a plain fp32-VALU kernel, 0 alone, 0
 for the scalar twin, 0 for the plain and the op_sel_hi forms).  clang's SLP vectoriser emits that form (8 sites in the
 round-2 build, all in the small fp32 MLP kernel); it is the reason two engine handles on two streams gave run-to-run
 different results.  build.sh therefore compiles with -fno-slp-vectorize, and this scan (also run by tests/) keeps the

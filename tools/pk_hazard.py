@@ -26,7 +26,10 @@ inp = torch.tensor([0.999, 0.001, 0.5, -0.25], device=DEV)
 blocks, iters = 1024, 2000
 n = blocks * 256 * 2
 side = torch.cuda.Stream()
-for mode, variant in [(m, v) for v in (0, 1, 2) for m in ("alone", "beside conv_gemm")]:
+PK.co_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
+co_out = torch.empty(2048 * 256, device=DEV); co_a = torch.randn(64 << 20, device=DEV); co_b = torch.empty_like(co_a)
+MODES = [(m, v) for v in (0, 1, 2) for m in ("alone", "beside conv_gemm")] + [(m, 2) for m in ("beside MFMA-only kernel", "beside HBM-copy kernel", "beside fp32-VALU kernel")]
+for mode, variant in MODES:
     bad_pk = bad_sc = 0
     big = torch.randn(8192, 8192, device=DEV) if "torch" in mode else None
     for it in range(20):
@@ -37,10 +40,16 @@ for mode, variant in [(m, v) for v in (0, 1, 2) for m in ("alone", "beside conv_
             with torch.cuda.stream(side):
                 if "conv" in mode:
                     for _ in range(3): N.check(L.ctta_conv_gemm(ctypes.byref(d), N.stream_ptr()))
+                elif "MFMA-only" in mode:
+                    PK.co_launch(0, co_out.data_ptr(), None, 0, 40000, torch.cuda.current_stream().cuda_stream)
+                elif "HBM-copy" in mode:
+                    for _ in range(3): PK.co_launch(1, co_a.data_ptr(), co_b.data_ptr(), co_a.numel() // 4, 0, torch.cuda.current_stream().cuda_stream)
+                elif "VALU" in mode:
+                    PK.co_launch(2, co_out.data_ptr(), None, 0, 400000, torch.cuda.current_stream().cuda_stream)
                 else:
                     _ = big @ big
         PK.pk_launch(inp.data_ptr(), o_pk.data_ptr(), o_sc.data_ptr(), blocks, iters, variant, torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         if it == 0 and mode == "alone" and variant == 0: ref = o_sc.clone()
         bad_pk += int((o_pk != ref).sum()); bad_sc += int((o_sc != ref).sum())
-    print("variant %d %-18s wrong packed results %d, wrong scalar results %d (of %d per launch x 20)" % (variant, mode, bad_pk, bad_sc, n))
+    print("variant %d %-26s wrong packed results %d, wrong scalar results %d (of %d per launch x 20)" % (variant, mode, bad_pk, bad_sc, n))
