@@ -28,7 +28,7 @@ n = blocks * 256 * 2
 side = torch.cuda.Stream()
 PK.co_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int, ctypes.c_void_p]
 co_out = torch.empty(2048 * 256, device=DEV); co_a = torch.randn(64 << 20, device=DEV); co_b = torch.empty_like(co_a)
-MODES = [(m, v) for v in (0, 1, 2) for m in ("alone", "beside conv_gemm")] + [(m, 2) for m in ("beside MFMA-only kernel", "beside HBM-copy kernel", "beside fp32-VALU kernel")]
+MODES = [(m, v) for v in (0, 1, 2) for m in ("alone", "beside conv_gemm")] + [(m, 2) for m in ("beside MFMA-only kernel", "beside HBM-copy kernel", "beside fp32-VALU kernel")] + [("beside MFMA-only kernel", 0), ("beside MFMA-only kernel", 1)]
 for mode, variant in MODES:
     bad_pk = bad_sc = 0
     big = torch.randn(8192, 8192, device=DEV) if "torch" in mode else None
