@@ -149,14 +149,36 @@ def main():
         N.check(N.lib().ctta_wav_finalize(N.ptr(wav), wav.numel(), N.ptr(scratch), None, N.ptr(pcm), N.stream_ptr()))
         return lat, mel, wav, pcm
 
-    for _ in range(args.warmup):
-        step()
-    du.barrier(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    du.barrier(dev)
-    dt = du.max_over_ranks(time.perf_counter() - t0, dev)
+    # The step as the product runs it for fixed shapes: ONE hipGraph replay of U-Net query -> VAE decoder -> HiFi-GAN -> int16
+    # (ConsistencyTTA.capture_graph: handles never allocate or synchronise inside *_forward, so the ~370 launches of a
+    # batch-32 step replay as one submission; bit-identical to the eager launches, asserted here).  CTTA_BENCH_GRAPH=0, or a
+    # failed capture, times the eager launches instead; both rates are reported.
+    timed, launch_mode, genB = step, "eager launches", None
+    if os.environ.get("CTTA_BENCH_GRAPH", "1") != "0":
+        try:
+            genB = pipe.capture_graph(B, L, cfg_scale_input=4.0)
+            pg = genB(enc, mask, noise)
+            torch.cuda.synchronize()
+            assert torch.equal(pg, step()[3]), "hipGraph replay differs from the eager step"
+            timed, launch_mode = (lambda: genB(enc, mask, noise)), "one hipGraph replay per step"
+        except Exception as exc:   # a failed capture must not cost the headline line
+            launch_mode = "eager launches (graph capture failed: %s)" % str(exc)[:120]
+            timed, genB = step, None
+
+    def time_loop(fn):
+        for _ in range(args.warmup):
+            fn()
+        du.barrier(dev)
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        du.barrier(dev)
+        return du.max_over_ranks(time.perf_counter() - t0_, dev)
+
+    dt = time_loop(timed)
+    dt_eager = time_loop(step)      # always, on every rank: the collective sequence must not depend on a rank's capture
+    del timed, genB
+    out = step()
     lat, mel, wav, pcm = out
     assert bool(torch.isfinite(wav).all()), "non-finite waveform"
     clips_per_s = world * B * args.steps / dt
@@ -170,7 +192,9 @@ def main():
                                "AudioLDM VAE decoder + HiFi-GAN, 10 s clips, L=32 text tokens, w=4, T5 excluded",
                    "batch_per_gpu": B, "global_batch": B * world, "text_len": L, "latent": [8, 256, 16],
                    "waveform_samples": int(wav.shape[1]), "weights": "random-init (no checkpoints offline)",
-                   "parallelism": "replicas x%d (clips sharded, no data-path collective)" % world},
+                   "parallelism": "replicas x%d (clips sharded, no data-path collective)" % world,
+                   "launch": launch_mode},
+        "eager_clips_per_s": round(world * B * args.steps / dt_eager, 3),
     }
 
     if rank == 0:
@@ -317,18 +341,6 @@ def main():
             assert torch.equal(eager1(), gen1(e1, m1, n1))
             result["single_clip_latency_ms"] = lat_ms
             del gen1
-            if world == 1:   # the whole batch-32 step as ONE hipGraph replay (information; `value` stays the eager loop)
-                genB = pipe.capture_graph(B, L, cfg_scale_input=4.0)
-                for _ in range(2):
-                    genB(enc, mask, noise)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(args.steps):
-                    pg = genB(enc, mask, noise)
-                torch.cuda.synchronize()
-                result["hipgraph_clips_per_s"] = round(B * args.steps / (time.perf_counter() - t1), 3)
-                assert torch.equal(pg, step()[3])
-                del genB
         except Exception as exc:   # a failed capture must not cost the headline line
             result["single_clip_latency_ms"] = {"error": str(exc)[:200]}
 
