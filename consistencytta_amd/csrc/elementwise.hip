@@ -185,16 +185,29 @@ __global__ void ema2_tail_kernel(const float* __restrict__ p, float* __restrict_
 // vocoder_infer centring: batch-global max / min  (utilities.py:85)
 __global__ __launch_bounds__(256) void minmax_kernel(const float* __restrict__ x, long long n,
                                                      unsigned int* __restrict__ mm) {
+  // one atomic pair per BLOCK of a capped grid (every wave of 5 121 blocks hammering the same two words cost 0.47 ms at
+  // batch 32: 40 000 serialised L2 atomics); float4 loads over the 16-byte-aligned body, scalars for the tail
+  __shared__ float smx[4], smn[4];
   float mx = -INFINITY, mn = INFINITY;
-  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n;
-       i += (long long)gridDim.x * blockDim.x) {
+  const long long n4 = (reinterpret_cast<size_t>(x) & 15) == 0 ? n >> 2 : 0;   // unaligned base: everything is "tail"
+  const float4* x4 = reinterpret_cast<const float4*>(x);
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = x4[i];
+    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+    mn = fminf(fminf(mn, fminf(v.x, v.y)), fminf(v.z, v.w));
+  }
+  for (long long i = (n4 << 2) + blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const float v = x[i];
     mx = fmaxf(mx, v);
     mn = fminf(mn, v);
   }
   mx = wave_max(mx);
   mn = -wave_max(-mn);
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; smn[threadIdx.x >> 6] = mn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
     // order-preserving float <-> uint encoding so integer atomics give float max/min
     auto enc = [](float f) { unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
     atomicMax(&mm[0], enc(mx));
@@ -445,7 +458,12 @@ extern "C" ctta_status ctta_wav_finalize(const float* wav, int64_t n, float* scr
   hipStream_t s = (hipStream_t)stream;
   unsigned int* mm = reinterpret_cast<unsigned int*>(scratch);
   hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, mm);
-  hipLaunchKernelGGL(minmax_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, wav, (long long)n, mm);
+  {
+    long long mb = (n / 4 + 255) / 256;
+    if (mb > 1024) mb = 1024;
+    if (mb < 1) mb = 1;
+    hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)mb), dim3(256), 0, s, wav, (long long)n, mm);
+  }
   CTTA_LAUNCH_CHECK();
   hipLaunchKernelGGL(wav_finalize_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, wav, (long long)n,
                      mm, centred, pcm);
