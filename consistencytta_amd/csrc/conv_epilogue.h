@@ -30,6 +30,7 @@ struct ConvParams {
   unsigned long long* stamps;   // diagnostic (ctta_conv_debug_stamps): per workgroup {hw id, t_begin, t_first_tile, t_main_done, t_epilogue_done}
   unsigned howo_inv, wo_inv;   // floor(2^32 / howo), floor(2^32 / wo) for fast_div
   int epi_fast;      // straight-line wide-store epilogue (bias / rowvec / residual / LeakyReLU / second output)
+  int epi_act;       // ... with alpha != 1 or a LeakyReLU (the ACT instantiations)
   int epi_fast_geglu;
   int epi_barrier;   // debug: workgroup barriers between the staging write and read-back of the wide-store epilogue
   int plain_out;   // destination element (m, n) sits at m*ldc + n (no per-batch stride, offset or limit)

@@ -4,6 +4,7 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 // ------------------------------------------------------------------------------ layout packs
 // (B,C,H,W) f32 -> (B,H,W,Cp) bf16, channels >= C zero.  One thread per (pixel, 8-ch group).
@@ -324,34 +325,112 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
-// Pass 3: apply (+SiLU).
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x,
-                                                       bf16_t* __restrict__ y, int HW, int C,
-                                                       const float* __restrict__ scale_shift,
-                                                       int silu, long long total_vec) {
+// Pass 3: apply (+SiLU).  grid = (blocks per sample, batch): a block stays inside one sample, and because its stride
+// (gridDim.x * 256 vectors) is a multiple of the C / 8 vector columns whenever C / 8 divides 256, a thread keeps ONE
+// channel vector for its whole walk -- its 8 scales and 8 shifts are loaded once into registers instead of 64 bytes of
+// (cached) table per 16 bytes of x (round 2's kernel: 4.0 TB/s on the 537 MB tensors of the VAE decoder).  Four vectors
+// are requested before the first is used.
+// FUSED: passes 2 + 3 in one launch for partials that are cheap to fold (the conv epilogue's per-tile partials: <= 2048
+// (chunk, group) pairs per sample): every block of sample b folds that sample's partials itself (fp64, the same fixed
+// order as gn_finalize_kernel -> the same scale / shift in every block and in the two-launch path), parks them in LDS.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int HW, int C,
+                                                       const float* __restrict__ scale_shift, int silu, int G,
+                                                       const float* __restrict__ part, int nchunk,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       float eps) {
+  extern __shared__ float ss[];   // FUSED: [2][C] scale, shift
+  const int b = blockIdx.y;
+  const float* tab = scale_shift + (size_t)b * 2 * C;
+  if constexpr (FUSED) {
+    const int cpg = C / G;
+    int LPG = 1;
+    if (G <= 128 && 256 % G == 0) LPG = min(64, 256 / G);
+    const int per_pass = 256 / LPG;
+    for (int g0 = 0; g0 < G; g0 += per_pass) {
+      const int g = g0 + (int)threadIdx.x / LPG, l = (int)threadIdx.x % LPG;
+      double s = 0.0, q = 0.0;
+      if (g < G)
+        for (int ch = l; ch < nchunk; ch += LPG) {
+          const float2 pp = *reinterpret_cast<const float2*>(part + (((size_t)b * nchunk + ch) * G + g) * 2);
+          s += (double)pp.x;
+          q += (double)pp.y;
+        }
+      for (int off = 1; off < LPG; off <<= 1) {
+        s += __shfl_xor(s, off);
+        q += __shfl_xor(q, off);
+      }
+      if (g >= G) continue;
+      const double n = (double)HW * cpg;
+      const double mean = s / n;
+      double var = q / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+      const float meanf = (float)mean;
+      for (int cc = l; cc < cpg; cc += LPG) {
+        const int c = g * cpg + cc;
+        const float sc = rstd * gamma[c];
+        ss[c] = sc;
+        ss[C + c] = beta[c] - meanf * sc;
+      }
+    }
+    __syncthreads();
+    tab = ss;
+  }
   const int VC = C / 8;
-  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total_vec;
-       idx += (long long)gridDim.x * blockDim.x) {
-    const int v = (int)(idx % VC);
-    const long long pix = idx / VC;
-    const int b = (int)(pix / HW);
-    const float* sc = scale_shift + ((size_t)b * 2) * C + v * 8;
-    const float* sh = sc + C;
-    const float4 s0 = *reinterpret_cast<const float4*>(sc);
-    const float4 s1 = *reinterpret_cast<const float4*>(sc + 4);
-    const float4 h0 = *reinterpret_cast<const float4*>(sh);
-    const float4 h1 = *reinterpret_cast<const float4*>(sh + 4);
-    const float scl[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-    const float shf[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+  const long long total = (long long)HW * VC;
+  const uint4* xb = reinterpret_cast<const uint4*>(x + (size_t)b * HW * C);
+  uint4* yb = reinterpret_cast<uint4*>(y + (size_t)b * HW * C);
+  const long long stride = (long long)gridDim.x * 256;
+  long long idx = blockIdx.x * 256LL + threadIdx.x;
+  auto apply8 = [&](const uint4 raw, const float* scl, const float* shf) {
     float f[8];
-    unpack8(*reinterpret_cast<const uint4*>(x + (size_t)idx * 8), f);
+    unpack8(raw, f);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float t = f[e] * scl[e] + shf[e];
+      const float t = f[e] * scl[e] + shf[e];
       f[e] = silu ? silu_f(t) : t;
     }
-    *reinterpret_cast<uint4*>(y + (size_t)idx * 8) = pack8(f);
+    return pack8(f);
+  };
+  if (256 % VC == 0) {   // the thread's channel vector never changes
+    const int v = (int)(idx % VC);
+    float scl[8], shf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { scl[e] = tab[v * 8 + e]; shf[e] = tab[C + v * 8 + e]; }
+    for (; idx + 3 * stride < total; idx += 4 * stride) {
+      uint4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = xb[idx + u * stride];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) yb[idx + u * stride] = apply8(r[u], scl, shf);
+    }
+    for (; idx < total; idx += stride) yb[idx] = apply8(xb[idx], scl, shf);
+    return;
   }
+  for (; idx < total; idx += stride) {
+    const int v = (int)(idx % VC);
+    float scl[8], shf[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { scl[e] = tab[v * 8 + e]; shf[e] = tab[C + v * 8 + e]; }
+    yb[idx] = apply8(xb[idx], scl, shf);
+  }
+}
+static void gn_launch_apply(const void* x, void* y, int batch, int hw, int c, const float* scale_shift, int silu, bool fused,
+                            int groups, const float* part, int nchunk, const float* gamma, const float* beta, float eps,
+                            hipStream_t s) {
+  const long long per_sample = (long long)hw * (c / 8);
+  long long bps = cdiv64(per_sample, 256 * 8);          // >= 8 vectors per thread
+  const long long cap = cdiv64(8192, batch);
+  if (bps > cap) bps = cap;
+  if (bps < 1) bps = 1;
+  const dim3 grid((unsigned)bps, (unsigned)batch);
+  if (fused)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, grid, dim3(256), (size_t)2 * c * sizeof(float), s, (const bf16_t*)x, (bf16_t*)y,
+                       hw, c, scale_shift, silu, groups, part, nchunk, gamma, beta, eps);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, grid, dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, hw, c, scale_shift, silu,
+                       groups, part, nchunk, gamma, beta, eps);
 }
 
 static void gn_geometry(int hw, int c, int* pix_per_chunk, int* nchunk) {
@@ -395,10 +474,7 @@ extern "C" ctta_status ctta_groupnorm_stats_out(const void* x, void* y, int batc
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, part, nchunk, groups, c, hw,
                      gamma, beta, eps, ss, stats);
   CTTA_LAUNCH_CHECK();
-  const long long total_vec = (long long)batch * hw * VC;
-  const int blocks = (int)fmin((double)cdiv64(total_vec, 256), 8192.0);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, hw,
-                     c, ss, silu, total_vec);
+  gn_launch_apply(x, y, batch, hw, c, ss, silu, false, groups, nullptr, 0, gamma, beta, eps, s);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }
@@ -413,14 +489,18 @@ extern "C" ctta_status ctta_groupnorm_from_partials(const void* x, void* y, int 
   CTTA_REQUIRE(x && y && gamma && beta && partials && scratch && nchunk >= 1, "groupnorm_from_partials: null pointer");
   CTTA_REQUIRE(c % 8 == 0 && groups > 0 && c % groups == 0, "groupnorm_from_partials: C=%d groups=%d unsupported", c, groups);
   hipStream_t s = (hipStream_t)stream;
+  const int VC = c / 8;
+  static int fused = -1;   // CTTA_GN_APPLY_FUSED=0: always the two-launch form (A/B switch)
+  if (fused < 0) { const char* e = getenv("CTTA_GN_APPLY_FUSED"); fused = (e && e[0] == '0') ? 0 : 1; }
+  if (fused && !stats && (long long)nchunk * groups <= 2048 && c <= 4096) {
+    gn_launch_apply(x, y, batch, hw, c, scratch, silu, true, groups, partials, nchunk, gamma, beta, eps, s);
+    CTTA_LAUNCH_CHECK();
+    return CTTA_OK;
+  }
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, partials, nchunk, groups, c, hw, gamma, beta, eps,
                      scratch, stats);
   CTTA_LAUNCH_CHECK();
-  const int VC = c / 8;
-  const long long total_vec = (long long)batch * hw * VC;
-  const int blocks = (int)fmin((double)cdiv64(total_vec, 256), 8192.0);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(blocks), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, hw, c, scratch, silu,
-                     total_vec);
+  gn_launch_apply(x, y, batch, hw, c, scratch, silu, false, groups, nullptr, 0, gamma, beta, eps, s);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

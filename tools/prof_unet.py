@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--guided", type=int, default=1)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--text-len", type=int, default=32)
+    ap.add_argument("--profile-csv", default=None, help="one line per MFMA launch of ONE forward (in-library HIP-event profiler)")
     a = ap.parse_args()
     dev = "cuda:0"
     cls = modules.UNet2DConditionGuidedModel if a.guided else modules.UNet2DConditionModel
@@ -45,6 +46,17 @@ def main():
     e1.record()
     torch.cuda.synchronize()
     print("unet batch %d: %.3f ms per forward" % (a.batch, e0.elapsed_time(e1) / a.iters))
+    if a.profile_csv:
+        import ctypes
+        from consistencytta_amd import _native as N
+        L_ = N.lib()
+        L_.ctta_prof_enable(1)
+        fwd()
+        torch.cuda.synchronize()
+        L_.ctta_prof_enable(0)
+        ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        N.check(L_.ctta_prof_collect(-1, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt), a.profile_csv.encode()))
+        print("profiled forward: %.3f ms in %d MFMA launches, %.1f TF/s executed" % (ms.value, cnt.value, fl.value / ms.value / 1e9))
 
 
 if __name__ == "__main__":
