@@ -160,6 +160,7 @@ SIGNATURES = {
     "ctta_conv_gemm": (c_int, [POINTER(ConvDesc), c_void_p]),
     "ctta_conv_last_gn_chunks": (c_int, []),
     "ctta_conv_bind_workspace": (None, [c_void_p, c_size_t]),
+    "ctta_conv_bound_workspace": (None, [POINTER(c_void_p), POINTER(c_size_t)]),
     "ctta_conv_workspace_bytes": (c_size_t, []),
     "ctta_conv_suppress_splitk": (None, [c_int]),
     "ctta_conv_debug_stamps": (None, [c_void_p]),
@@ -233,6 +234,8 @@ SIGNATURES = {
     "ctta_snr_mse_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "ctta_prof_enable": (None, [c_int]),
+    "ctta_set_gn_fuse": (None, [c_int]),
+    "ctta_get_gn_fuse": (c_int, []),
     "ctta_prof_collect": (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_char_p]),
 }
 

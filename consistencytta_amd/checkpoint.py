@@ -10,7 +10,10 @@
   order (train.py:380), so the distilled model is `pytorch_model_2.bin` -- the file `inference.py --model` and
   `demo.py` load with `torch.load(...)` + `model.load_pretrained(...)` (inference.py:152-153); `optimizer.bin`,
   `scheduler.bin` and `random_states_0.pkl` sit beside it and are read back by `accelerator.load_state`
-  (train.py:424-427).
+  (train.py:424-427).  `optimizer.bin` holds `torch.optim.AdamW.state_dict()` over `student_unet.parameters()` and
+  `scheduler.bin` `LambdaLR.state_dict()` (optim.FusedAdamW / WarmupSchedule emit and accept exactly those layouts:
+  tests/test_host_cpu.py::test_optimizer_and_scheduler_files_are_torch_layout loads files written by the torch
+  classes and the other way round), so a reference run resumes here and vice versa.
 
 Host-side file plumbing only: tensors are moved to the CPU for writing and land on each module's own device when read.
 """

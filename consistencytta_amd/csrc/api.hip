@@ -3,6 +3,8 @@
 
 #include "common.h"
 
+#include <stdlib.h>
+
 static thread_local char g_err[1024] = "";
 
 void ctta_set_error(const char* fmt, ...) {
@@ -44,6 +46,15 @@ void ctta_prof_end(hipStream_t s) {
 }
 
 extern "C" void ctta_prof_enable(int on) { g_prof_on = on != 0; }
+
+// GroupNorm statistics from the producing convolution's epilogue (engine_common.h: gn_fuse_enabled)
+static int g_gn_fuse = -1;
+bool ctta_gn_fuse_on() {
+  if (g_gn_fuse < 0) { const char* e = getenv("CTTA_GN_FUSE"); g_gn_fuse = (e && e[0] == '0') ? 0 : 1; }
+  return g_gn_fuse != 0;
+}
+extern "C" void ctta_set_gn_fuse(int on) { g_gn_fuse = on ? 1 : 0; }
+extern "C" int ctta_get_gn_fuse(void) { return ctta_gn_fuse_on() ? 1 : 0; }
 
 // Synchronises, sums the records of `kind` (0 conv_gemm, 1 attention, -1 all), optionally appends
 // one CSV line per launch to `csv_path`, and clears the log.

@@ -17,10 +17,46 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 // v_exp_f32 directly: exp2f() wraps it in a denormal-range fix-up (compare, select, add, ldexp: 6 instructions per
 // element in a VALU-bound loop); probabilities below 2^-126 flushing to zero is immaterial here
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// max without the canonicalising v_max_f32 x, x that clang puts in front of fmaxf() on MFMA results (one extra VALU op per
+// operand in a VALU-bound loop), and three-input max; NaNs cannot occur here (finite products of finite operands)
+__device__ __forceinline__ float vmax2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+// butterfly steps across the four 16-lane rows of a wave on the VALU (gfx950 v_permlane16_swap / v_permlane32_swap) instead
+// of ds_bpermute_b32: no LDS round trip, and no s_waitcnt lgkmcnt(0) that would also wait for the K / V fragment reads
+__device__ __forceinline__ float xrow16(float x, float& other) {   // rows (0,1) and (2,3) exchanged: returns own-side, other-side
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  other = __uint_as_float(r[1]);
+  return __uint_as_float(r[0]);
+}
+__device__ __forceinline__ float xhalf32(float x, float& other) {
+  const unsigned u = __float_as_uint(x);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  other = __uint_as_float(r[1]);
+  return __uint_as_float(r[0]);
+}
+__device__ __forceinline__ float rows_max(float x) {   // max over lanes l, l^16, l^32, l^48
+  float o;
+  float a = xrow16(x, o);
+  a = vmax2(a, o);
+  float b = xhalf32(a, o);
+  return vmax2(b, o);
+}
+__device__ __forceinline__ float rows_sum(float x) {
+  float o;
+  float a = xrow16(x, o);
+  a += o;
+  float b = xhalf32(a, o);
+  return b + o;
+}
 
 static bool attn_plain_enabled() {   // CTTA_ATTN_PLAIN=0: always the general kernels (A/B switch)
   static int v = -1;
@@ -287,6 +323,222 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
   }
 }
 
+// ---- self-attention over whole key tiles, round 3 --------------------------------------------------------------------
+// Same mapping as attention_kernel<3> (S^T = K Q^T, O^T += V^T P^T, a wave owns 32 queries, 64-key tiles), different
+// schedule.  Round 2's loop ran QK^T -> softmax -> PV strictly in sequence inside a wave, with two workgroup barriers and
+// a register -> LDS copy per tile: 31 % of the matrix-pipe peak with NEITHER the MFMA nor the VALU pipe saturated (32
+// MFMAs = 512 cycles against ~520 cycles of softmax VALU per wave and tile).  Here
+//   * the raw scores of tile t+1 (16 MFMAs, independent of everything the softmax touches) are issued BEFORE the softmax
+//     of tile t, so the matrix pipe works while the wave's VALU does max / exp / sum (two score register sets);
+//   * K / V^T tiles travel global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write), K two
+//     tiles ahead and V^T one, into two-slot rings; the 16-byte chunks are XOR-swizzled on the SOURCE side
+//     (chunk c of row r sits at c ^ ((r >> 1) & 7): conflict-free for the ds_read_b128 K fragments and the paired
+//     ds_read_b64 V^T fragments, rows are 128 bytes, no padding);
+//   * ONE workgroup barrier per tile: at the top of iteration t every wave has finished tile t-1, so K slot t & 1 (read by
+//     the scores of tile t, computed during iteration t-1) and V slot (t+1) & 1 (read by PV of tile t-1) are free, and the
+//     DMA issued an iteration ago has landed (s_waitcnt vmcnt(0) in front of the barrier).
+__global__ __launch_bounds__(256, 2) void attention_plain2_kernel(
+    const bf16_t* __restrict__ q, int q_ld, const bf16_t* __restrict__ k, int k_ld, int k_rows,
+    const bf16_t* __restrict__ vt, int vt_ld, bf16_t* __restrict__ out, int out_ld, int heads, int nq, int nk,
+    float scale_log2e, float* __restrict__ lse) {
+  // ONE LDS object: with two, hipcc waits vmcnt(0) (all LDS-DMA landed) in front of every ds_read of the other array
+  __shared__ __attribute__((aligned(16))) bf16_t smem[4 * ATT_KT * 64];
+  bf16_t (*Ks)[ATT_KT * 64] = reinterpret_cast<bf16_t (*)[ATT_KT * 64]>(smem);                    // [slot][key][d], swizzled chunks
+  bf16_t (*Vs)[ATT_KT * 64] = reinterpret_cast<bf16_t (*)[ATT_KT * 64]>(smem + 2 * ATT_KT * 64);  // [slot][d][key], swizzled chunks
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bh = blockIdx.y;
+  const int b = bh / heads, h = bh - b * heads;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int lq = lane & 15, lg = lane >> 4;
+  const bf16_t* qb = q + (size_t)b * nq * q_ld + h * 64;
+  const bf16_t* kb = k + (size_t)b * k_rows * k_ld + h * 64;
+  const bf16_t* vb = vt + ((size_t)b * heads + h) * 64 * vt_ld;
+
+  bf16x8_t qf[2][2];
+#pragma unroll
+  for (int jq = 0; jq < 2; ++jq) {
+    int qi = q0 + jq * 16 + lq;
+    if (qi >= nq) qi = nq - 1;   // clamp (never stored)
+#pragma unroll
+    for (int ds = 0; ds < 2; ++ds)
+      qf[jq][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qb + (size_t)qi * q_ld + ds * 32 + lg * 8));
+  }
+  // LDS-DMA: a wave instruction covers 8 rows x 128 bytes; lane -> (row = lane / 8, chunk position = lane % 8), which
+  // receives the logical chunk (lane % 8) ^ ((row >> 1) & 7) of that row.  A tile is 8 instructions: 2 per wave.
+  // Through buffer descriptors (as conv_gemm does): the per-lane byte offsets are loop invariant, the tile advance rides
+  // in the scalar offset -- and, unlike __builtin_amdgcn_global_load_lds, hipcc does not put s_waitcnt vmcnt(0) in front
+  // of later ds_reads of the OTHER ring slot.
+  const int drow = wave * 16 + (lane >> 3);          // + 8 for the wave's second instruction
+  const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)kb, 0, (unsigned)(((long long)(nk - 1) * k_ld + 64) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)vb, 0, (unsigned)(((long long)63 * vt_ld + nk) * 2), 0x00020000);
+  int koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = drow + i * 8;
+    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    koff[i] = (r * k_ld + c * 8) * 2;
+    voff[i] = (r * vt_ld + c * 8) * 2;
+  }
+  auto issue_k = [&](int key0, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(&Ks[slot][(wave * 16 + i * 8) * 64]), 16,
+                                               koff[i], key0 * k_ld * 2, 0, 0);
+  };
+  auto issue_v = [&](int key0, int slot) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(&Vs[slot][(wave * 16 + i * 8) * 64]), 16,
+                                               voff[i], key0 * 2, 0, 0);
+  };
+  const int fsw = (lq >> 1) & 7;                      // swizzle of the fragment rows this lane reads (row % 16 == lq)
+  auto scores = [&](int slot, f32x4_t (&s)[4][2]) {
+#pragma unroll
+    for (int ik = 0; ik < 4; ++ik) {
+#pragma unroll
+      for (int jq = 0; jq < 2; ++jq) s[ik][jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        const bf16x8_t kf = __builtin_bit_cast(
+            bf16x8_t, *reinterpret_cast<const uint4*>(&Ks[slot][(ik * 16 + lq) * 64 + (((ds * 4 + lg) ^ fsw) * 8)]));
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) s[ik][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[jq][ds], s[ik][jq], 0, 0, 0);
+      }
+    }
+  };
+
+  // V^T fragment byte offsets inside a slot, loop invariant: row d = jd*16 + lq (+ jd * 2048 bytes), keys kk*32 + lg*4 .. +3
+  // = chunk kk*4 + lg/2, half lg & 1; the +16 keys of the second half-fragment = chunk + 2.
+  unsigned vbase[2][2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      vbase[kk][hh] = (unsigned)(lq * 128 + (((kk * 4 + hh * 2 + (lg >> 1)) ^ fsw) * 16) + (lg & 1) * 8);
+    }
+  const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+  f32x4_t o[4][2];
+#pragma unroll
+  for (int jd = 0; jd < 4; ++jd)
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) o[jd][jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  float mrun[2] = {-INFINITY, -INFINITY};
+  float lrun[2] = {0.f, 0.f};
+
+  const int ntiles = nk / ATT_KT;
+  issue_k(0, 0);
+  issue_v(0, 0);
+  if (ntiles > 1) issue_k(ATT_KT, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  f32x4_t sc[4][2], sn[4][2];
+  scores(0, sc);
+  for (int t = 0; t < ntiles; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of K(t+1) / V(t) has landed ...
+    __builtin_amdgcn_s_barrier();                        // ... and so has everybody else's; tile t-1 is finished everywhere
+    if (t + 2 < ntiles) issue_k((t + 2) * ATT_KT, t & 1);
+    if (t + 1 < ntiles) issue_v((t + 1) * ATT_KT, (t + 1) & 1);
+    if (t + 1 < ntiles) scores((t + 1) & 1, sn);
+    // ---- softmax of tile t on the raw products (scale > 0): max, then scale and -max folded into one FMA before exp2
+#pragma unroll
+    for (int jq = 0; jq < 2; ++jq) {
+      float mx = vmax2(sc[0][jq][0], sc[0][jq][1]);
+      mx = vmax3(mx, sc[0][jq][2], sc[0][jq][3]);
+#pragma unroll
+      for (int ik = 1; ik < 4; ++ik) {
+        mx = vmax3(mx, sc[ik][jq][0], sc[ik][jq][1]);
+        mx = vmax3(mx, sc[ik][jq][2], sc[ik][jq][3]);
+      }
+      mx = rows_max(mx);
+      const float mnew = vmax2(mrun[jq], mx * scale_log2e);
+      const float alpha = fast_exp2(mrun[jq] - mnew);
+      mrun[jq] = mnew;
+      float ps = 0.f;
+#pragma unroll
+      for (int ik = 0; ik < 4; ++ik)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = fast_exp2(fmaf(sc[ik][jq][r], scale_log2e, -mnew));
+          sc[ik][jq][r] = pv;
+          ps += pv;
+        }
+      lrun[jq] = lrun[jq] * alpha + ps;
+      if (__any(alpha != 1.0f)) {
+#pragma unroll
+        for (int jd = 0; jd < 4; ++jd) o[jd][jq] *= alpha;
+      }
+    }
+    // ---- O^T += V^T P^T.  The V^T fragments are read with inline-asm ds_read_b64: hipcc merges the compiler-visible
+    // form into ds_read2st64_b64 and then waits vmcnt(0) -- i.e. for the LDS-DMA of the NEXT tiles, issued a few hundred
+    // cycles earlier -- in front of it (the K fragments' ds_read_b128 get no such wait).  LDS operations return in
+    // order, so the compiler's own counted lgkmcnt waits stay correct (at worst they wait for more); the values read
+    // here are consumed behind an explicit lgkmcnt(0).
+    // (Measured alternatives, tools/attn_bench.py at B=32, 5 heads, 4096 tokens: all 16 reads up front + PV per query
+    // block behind its half of the softmax: 192 VGPRs = 2 waves per SIMD, 727 TFLOP/s; this form: 164 VGPRs = 3 waves per
+    // SIMD, 790; round 2's kernel 717.)
+    const unsigned vs_off = (unsigned)(2 * ATT_KT * 64 * 2 + (t & 1) * (ATT_KT * 64 * 2));   // byte offset of V slot t & 1 in smem
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint2 lo[4], hi[4];
+      const unsigned a0 = lds_base + vs_off + vbase[kk][0], a1 = lds_base + vs_off + vbase[kk][1];
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) {
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo[jd]) : "v"(a0), "n"(jd * 2048));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi[jd]) : "v"(a1), "n"(jd * 2048));
+      }
+      bf16x8_t pf[2];
+#pragma unroll
+      for (int jq = 0; jq < 2; ++jq) {
+        uint4 pk;
+        pk.x = pack2bf(sc[2 * kk][jq][0], sc[2 * kk][jq][1]);
+        pk.y = pack2bf(sc[2 * kk][jq][2], sc[2 * kk][jq][3]);
+        pk.z = pack2bf(sc[2 * kk + 1][jq][0], sc[2 * kk + 1][jq][1]);
+        pk.w = pack2bf(sc[2 * kk + 1][jq][2], sc[2 * kk + 1][jq][3]);
+        pf[jq] = __builtin_bit_cast(bf16x8_t, pk);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) {
+        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(lo[jd].x, lo[jd].y, hi[jd].x, hi[jd].y));
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) o[jd][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[jq], o[jd][jq], 0, 0, 0);
+      }
+    }
+    if (t + 1 < ntiles) {
+#pragma unroll
+      for (int ik = 0; ik < 4; ++ik)
+#pragma unroll
+        for (int jq = 0; jq < 2; ++jq) sc[ik][jq] = sn[ik][jq];
+    }
+  }
+#pragma unroll
+  for (int jq = 0; jq < 2; ++jq) {
+    const float l = rows_sum(lrun[jq]);
+    const float inv = 1.0f / l;
+    const int qi = q0 + jq * 16 + lq;
+    if (lse && qi < nq && lg == 0) lse[((size_t)b * heads + h) * nq + qi] = mrun[jq] + log2f(l);
+    if (qi < nq) {
+      bf16_t* orow = out + ((size_t)b * nq + qi) * out_ld + h * 64;
+#pragma unroll
+      for (int jd = 0; jd < 4; ++jd) {
+        uint2 pk;
+        pk.x = pack2bf(o[jd][jq][0] * inv, o[jd][jq][1] * inv);
+        pk.y = pack2bf(o[jd][jq][2] * inv, o[jd][jq][3] * inv);
+        *reinterpret_cast<uint2*>(orow + jd * 16 + lg * 4) = pk;
+      }
+    }
+  }
+}
+static int attn_v2_mode() {   // CTTA_ATTN_V2=0: round 2's kernel for self-attention (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_ATTN_V2"); v = e ? atoi(e) : 1; }
+  return v;
+}
+
 extern "C" ctta_status ctta_attention(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
                                       int vt_ld, const float* bias, void* out, int out_ld, int batch,
                                       int heads, int nq, int nk, float scale, void* stream) {
@@ -305,7 +557,11 @@ extern "C" ctta_status ctta_attention_lse(const void* q, int q_ld, const void* k
   const bool prof = ctta_prof_active();
   // executed flops: QK^T and PV over the padded head dim (2 * 2*nq*nk*64 per head)
   if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
-  if (!bias && nk % ATT_KT == 0 && attn_plain_enabled())   // self-attention over whole key tiles: no additive term
+  if (!bias && nk % ATT_KT == 0 && attn_plain_enabled() && attn_v2_mode() && nk >= 2 * ATT_KT)
+    hipLaunchKernelGGL(attention_plain2_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
+                       (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, (bf16_t*)out, out_ld, heads, nq, nk,
+                       scale * 1.4426950408889634f, lse);
+  else if (!bias && nk % ATT_KT == 0 && attn_plain_enabled())   // self-attention over whole key tiles: no additive term
     hipLaunchKernelGGL(attention_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
                        (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, bias, (bf16_t*)out, out_ld, heads,
                        nq, nk, scale * 1.4426950408889634f, lse, nq, (const float*)nullptr, 1);

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void gelu_kernel(const uint4* __restrict__ x, 
     float f[8];
     unpack8(x[i], f);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) f[e] = 0.5f * f[e] * (1.0f + erff(f[e] * 0.70710678118654752f));
+    for (int e = 0; e < 8; ++e) f[e] = gelu_erf_f(f[e]);
     y[i] = pack8(f);
   }
 }

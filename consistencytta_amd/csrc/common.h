@@ -44,6 +44,24 @@ __device__ __forceinline__ uint4 pack8(const float f[8]) {
 __device__ __forceinline__ float sigmoid_f(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoid_f(x); }
 
+// Exact-GELU gate g * Phi(g), Phi(g) = 0.5 * (1 + erf(g / sqrt 2)) (F.gelu as attention.py:430-432 / nn.GELU call it) with
+// Abramowitz-Stegun 7.1.26 for the error function (|error| <= 1.5e-7: four orders below the bf16 rounding of the result):
+// h = 0.5 * erfc(|g| / sqrt 2) = poly(t) * exp(-g^2 / 2), t = 1 / (1 + p |g| / sqrt 2); Phi = h for g < 0 (no
+// cancellation in the tail), 1 - h otherwise.  One v_rcp, one v_exp and a dozen FMA-class operations, branch-free.
+// ocml's erff is a two-branch polynomial (~35 instructions under exec masks per element), which made the GEGLU epilogue
+// of the K = 256 ff1 GEMM as long as its main loop.
+__device__ __forceinline__ float gelu_erf_f(float g) {
+  const float ax = fabsf(g);
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));
+  float poly = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+  poly = fmaf(poly, t, 0.5f * 1.421413741f);
+  poly = fmaf(poly, t, 0.5f * -0.284496736f);
+  poly = fmaf(poly, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(g * g * (-0.5f * 1.4426950408889634f));
+  const float h = poly * t * e;
+  return g * (g > 0.f ? 1.0f - h : h);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -58,6 +76,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // ---- host side ---------------------------------------------------------------------------
 void ctta_set_error(const char* fmt, ...);
 bool ctta_prof_active();
+bool ctta_gn_fuse_on();
 void ctta_prof_begin(int kind, int variant, long long m, long long n, long long k, long long groups, hipStream_t s);
 void ctta_prof_end(hipStream_t s);
 

@@ -25,6 +25,10 @@ struct ConvParams {
   // [x * xcd_per, (x + 1) * xcd_per) and walks it with the N tiles innermost, so the tiles that share input rows
   // (neighbouring image rows, all N tiles of one M tile) meet in the same 4 MB L2 close in time.  0 = plain 2-D grid.
   int xcd_per, m_tiles, n_tiles, n_inner;   // n_inner = 0: M tiles innermost (many N tiles: keep the weight slice hot)
+  // first output row of this launch (a multiple of 4; normally 0).  The host splits the ragged last row tile of a
+  // 256-row-tile launch off into a second launch with small tiles when that tile alone would open another round of the
+  // 256 CUs (HiFi-GAN: M = 32 * 5121 = 640 * 256 + 32 rows x 2 column tiles = 5.008 rounds).
+  int m_off;
   // 1: the tile is transposed through LDS and leaves as whole 64..256-byte row segments (see the kernel's epilogue)
   int wide_store;
   unsigned long long* stamps;   // diagnostic (ctta_conv_debug_stamps): per workgroup {hw id, t_begin, t_first_tile, t_main_done, t_epilogue_done}
@@ -45,14 +49,16 @@ struct ConvParams {
 // destination: element (m, n) at m*ldc + n): same operation order as epilogue_store.
 __device__ __forceinline__ void epilogue_wide4(const ConvParams& p, const float4 q, const float4 bias4, int m, int n,
                                                size_t gofs, float2* gn_acc = nullptr) {
-  float v[4] = {q.x + bias4.x, q.y + bias4.y, q.z + bias4.z, q.w + bias4.w};
+  // one order for every epilogue of the library: acc + (bias + rowvec), then the per-row bias, then the residual
+  float4 c4 = bias4;
+  if (p.rowvec) {
+    const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.howo) * p.rowvec_ld + n);
+    c4.x += rv.x; c4.y += rv.y; c4.z += rv.z; c4.w += rv.w;
+  }
+  float v[4] = {q.x + c4.x, q.y + c4.y, q.z + c4.z, q.w + c4.w};
   if (p.bias_m) {
     const float bm = p.bias_m[m];
     v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
-  }
-  if (p.rowvec) {
-    const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m / p.howo) * p.rowvec_ld + n);
-    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
   }
   if (p.res) {
     const uint2 rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
@@ -115,22 +121,26 @@ __device__ __forceinline__ void epilogue_store(const ConvParams& p, const f32x4_
   if (p.out_limit > 0 && (inb < 0 || inb >= p.out_limit)) return;
   const size_t oidx = (size_t)((long long)g * p.ogs + (long long)b * p.obs + inb);
   float v[4] = {a[0], a[1], a[2], a[3]};
-  if (p.bias) {
-    if (p.scalar_store) {
+  {   // acc + (bias + rowvec): the order of epilogue_wide4 / wide_epilogue_fast
+    float c[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) {
+      if (p.scalar_store) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) if (n + r < p.n) v[r] += p.bias[n + r];
-    } else {
-      const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
-      v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        for (int r = 0; r < 4; ++r) if (n + r < p.n) c[r] = p.bias[n + r];
+      } else {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+        c[0] = bb.x; c[1] = bb.y; c[2] = bb.z; c[3] = bb.w;
+      }
     }
+    if (p.rowvec) {
+      const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_ld + n);
+      c[0] += rv.x; c[1] += rv.y; c[2] += rv.z; c[3] += rv.w;
+    }
+    v[0] += c[0]; v[1] += c[1]; v[2] += c[2]; v[3] += c[3];
   }
   if (p.bias_m) {
     const float bm = p.bias_m[m];
     v[0] += bm; v[1] += bm; v[2] += bm; v[3] += bm;
-  }
-  if (p.rowvec) {
-    const float4 rv = *reinterpret_cast<const float4*>(p.rowvec + (size_t)b * p.rowvec_ld + n);
-    v[0] += rv.x; v[1] += rv.y; v[2] += rv.z; v[3] += rv.w;
   }
   if (p.res) {   // res_pre: the caller already fetched the residual (rolled epilogues prefetch a whole chunk)
     const uint2 rr = res_pre ? *res_pre : *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);

@@ -170,6 +170,7 @@ static const size_t kSplitWsBytes = (size_t)192 << 20;
 static thread_local float* t_ws = nullptr;
 static thread_local size_t t_ws_bytes = 0;
 extern "C" void ctta_conv_bind_workspace(void* ws, size_t bytes) { t_ws = (float*)ws; t_ws_bytes = ws ? bytes : 0; }
+extern "C" void ctta_conv_bound_workspace(void** ws, size_t* bytes) { if (ws) *ws = t_ws; if (bytes) *bytes = t_ws_bytes; }
 extern "C" size_t ctta_conv_workspace_bytes(void) { return kSplitWsBytes; }
 #include <mutex>
 static float* splitk_workspace(size_t* bytes) {
@@ -469,6 +470,22 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   }
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, vid + ((p.epi_fast || p.epi_fast_geglu) ? 0 : 100), M, d->n, K, groups, (hipStream_t)stream);   // +100: generic epilogue
+  // Ragged last row tile of a 256-row-tile launch: when it alone opens another round of the CUs, it leaves this launch
+  // (one row tile fewer) and runs as a second launch with 64x64 tiles behind it (the same rows, the same epilogue; rows
+  // are independent, so this is exact).  M = 163872, N = 512: 1282 -> 1280 big tiles = 5 rounds instead of 5 + a round
+  // of two half-idle workgroups, plus ~16 small workgroups.
+  int tail_rows = 0;
+  {
+    static int tail_env = -1;
+    if (tail_env < 0) { const char* e = getenv("CTTA_TAIL_SPLIT"); tail_env = (e && e[0] == '0') ? 0 : 1; }
+    const long long slots = 256LL * (vid == 28 ? 2 : 1);
+    const long long t_all = (long long)grid.x * grid.y, t_cut = (long long)(grid.x - 1) * grid.y;
+    if (tail_env && d->tile <= 0 && v.bm == 256 && v.mode != 0 && splits == 1 && groups == 1 && M % 256 != 0 && grid.x > 1 &&
+        !geglu && !d->gn_part && !t_stamps && (t_all + slots - 1) / slots > (t_cut + slots - 1) / slots) {
+      tail_rows = (int)(M % 256);
+      grid.x -= 1;
+    }
+  }
   if (splits == 1 && groups == 1 && xcd_default() && grid.x >= 64) {
     p.m_tiles = (int)grid.x; p.n_tiles = (int)grid.y;
     p.xcd_per = (p.m_tiles + 7) / 8;
@@ -509,6 +526,17 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     splitk_finish_kernel<<<dim3(fb), dim3(256), 0, (hipStream_t)stream>>>(p, ws, splits, M * ld, ld);
   } else {
     v.launch(p, grid, (hipStream_t)stream);
+    if (tail_rows > 0) {
+      const int tid_ = 5 + ((v.mode == 2 && fast_ok(64)) ? 16 : 8);   // 64x64x64, descriptor staging where a K tile never straddles a tap
+      const Variant& tv = kVariants[tid_ - 1];
+      CTTA_TRY(tv.prepare());
+      ConvParams t = p;
+      t.m_off = (int)(M - tail_rows);
+      t.xcd_per = 0; t.m_tiles = 0; t.n_tiles = 0; t.n_inner = 0;
+      t.nk = (int)((K + tv.bk - 1) / tv.bk);
+      t.nk_split = t.nk;
+      tv.launch(t, dim3((unsigned)((tail_rows + tv.bm - 1) / tv.bm), (unsigned)((d->n + tv.bn - 1) / tv.bn), 1), (hipStream_t)stream);
+    }
   }
   if (prof) ctta_prof_end((hipStream_t)stream);
   CTTA_LAUNCH_CHECK();

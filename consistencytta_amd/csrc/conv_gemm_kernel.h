@@ -48,17 +48,19 @@ struct WideCtx {
   int m_first;             // output row of (chunk 0, pass 0) for this lane
   size_t gofs;             // group offset (elements) into out / out2
   int n_lane;
+  float4 c4;               // bias + the sample's row vector for the lane's 4 channels (loop invariant on this path)
   int m0, wm, wn;          // tile origin row and the wave's coordinates in the workgroup (GroupNorm partials)
 };
 #define WAVE_LDS_FENCE_() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-// out = act((acc + res [+ old]) * alpha) for one wave tile of FM x FN fragments, CJ fragments (CHR rows) per staging
-// chunk, RPW rows per read-back pass.  bias + the per-sample row vector are ALREADY in acc: the waves that take this path
-// start their accumulators from them (see the kernel), so the epilogue carries no per-row additions for them.  ACT =
-// false (alpha == 1 and no LeakyReLU, the U-Net / VAE case) drops the scale and the max as well: per 4 outputs the
-// arithmetic is 2 conversions (+ 8 operations with a residual) instead of 22 (30) -- round 2's epilogue spent about half
-// of its 4.1 us per 256x256 tile issuing VALU work.  Everything is unrolled and free of divergent control flow, so the waits
+// out = act((acc + (bias + rowvec) + res [+ old]) * alpha) for one wave tile of FM x FN fragments, CJ fragments (CHR rows)
+// per staging chunk, RPW rows per read-back pass.  (bias + rowvec) is one per-lane constant here (a tile on this path
+// lies inside one sample); every epilogue of the library adds in this order -- acc + (bias + rowvec), then the residual --
+// so that a sample's numbers do not depend on which path its tile took.  ACT = false (alpha == 1 and no LeakyReLU, the
+// U-Net / VAE case) drops the scale and the max: per 4 outputs the arithmetic is 4 additions + 2 conversions (+ 8
+// operations with a residual) instead of 22 (30) -- round 2's epilogue spent about half of its 4.1 us per 256x256 tile
+// issuing VALU work.  Everything is unrolled and free of divergent control flow, so the waits
 // the compiler inserts are exact counts.  Stores and residual loads go through buffer descriptors sized to the M valid
 // rows: one VGPR offset per lane, the row advance rides in the scalar offset, rows past M are dropped / read as zero by
 // the bounds check.  The residual row of (chunk c + 1, pass i) is requested right after that of (chunk c, pass i) was
@@ -139,7 +141,7 @@ __device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t 
         if (h + e < IT) {
           const int it = h + e;
           const int pass = ch * IT + it;       // rows advance by RPW per pass: CHR == IT * RPW
-          float v[4] = {q[e].x, q[e].y, q[e].z, q[e].w};
+          float v[4] = {q[e].x + w.c4.x, q[e].y + w.c4.y, q[e].z + w.c4.z, q[e].w + w.c4.w};
           if constexpr (RES) {
             const u32x2_t r2 = rr[it];
             if (ch + 1 < NCH) rr[it] = __builtin_amdgcn_raw_buffer_load_b64(rsr, roff, (pass + IT) * rstep, 0);
@@ -197,7 +199,7 @@ __device__ __forceinline__ void epilogue_geglu(const ConvParams& p, const f32x4_
   }
   float o[4];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) o[r] = v[r] * (0.5f * g[r] * (1.0f + erff(g[r] * 0.70710678118654752f)));
+  for (int r = 0; r < 4; ++r) o[r] = v[r] * gelu_erf_f(g[r]);
   const int h = (n >> 5) * 16 + (n & 15);
   uint2 pk;
   pk.x = pack2bf(o[0], o[1]);
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     else { nt = local / p.xcd_per; mt = xcd * p.xcd_per + local % p.xcd_per; }
     if (mt >= p.m_tiles) return;   // padding blocks of the last XCD range (whole workgroup, before any barrier)
   }
-  const int m0 = mt * BM;
+  const int m0 = p.m_off + mt * BM;
   const int n0 = nt * BN;
   // a wave whose TM rows all lie past M (the last row tile of M = k * BM + a few rows) skips its MFMAs: its SIMD partner
   // then runs at full matrix-pipe rate and the tail tile of a one-workgroup-per-CU launch takes about half a tile time
@@ -506,28 +508,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     if (ftap == p.taps) { ftap = 0; fkh = 0; fkw = 0; fcb += BK; }
   };
 
-  // Waves that will take the straight-line wide-store epilogue (decided here: every input of the decision is known) start
-  // their accumulators from bias + the sample's row vector instead of zero -- 8 fewer additions per 4 outputs there.
-  bool fast_wave = false;
-  if (p.wide_store && p.epi_fast && n0 + wn * TN + TN <= p.n) {
-    const bool one_sample = m0 / p.howo == (min(m0 + BM, p.M) - 1) / p.howo;
-    fast_wave = !p.rowvec || one_sample;
-  }
   f32x4_t acc[FN][FM];
 #pragma unroll
-  for (int i = 0; i < FN; ++i) {
-    f32x4_t init = {0.f, 0.f, 0.f, 0.f};
-    if (fast_wave) {   // lane's channels of fragment column i: n0 + wn*TN + i*16 + (lane >> 4)*4 + {0..3}
-      const int nb = n0 + wn * TN + i * 16 + (lane >> 4) * 4;
-      if (p.bias) { const float4 b4 = *reinterpret_cast<const float4*>(p.bias + nb); init = (f32x4_t){b4.x, b4.y, b4.z, b4.w}; }
-      if (p.rowvec) {
-        const float4 r4 = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m0 / p.howo) * p.rowvec_ld + nb);
-        init[0] += r4.x; init[1] += r4.y; init[2] += r4.z; init[3] += r4.w;
-      }
-    }
+  for (int i = 0; i < FN; ++i)
 #pragma unroll
-    for (int j = 0; j < FM; ++j) acc[i][j] = init;
-  }
+    for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15;
   const int fchunk = lane >> 4;                       // logical 16-byte chunk within a 32-wide k-slab
@@ -669,7 +654,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
               const float gg[4] = {qg.x + bg.x, qg.y + bg.y, qg.z + bg.z, qg.w + bg.w};
               float o[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = vv[e] * (0.5f * gg[e] * (1.0f + erff(gg[e] * 0.70710678118654752f)));
+              for (int e = 0; e < 4; ++e) o[e] = vv[e] * gelu_erf_f(gg[e]);
               u32x2_t pk;
               pk.x = pack2bf(o[0], o[1]);
               pk.y = pack2bf(o[2], o[3]);
@@ -699,7 +684,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
               const float gg[4] = {qg.x + bg.x, qg.y + bg.y, qg.z + bg.z, qg.w + bg.w};
               float o[4];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) o[e] = vv[e] * (0.5f * gg[e] * (1.0f + erff(gg[e] * 0.70710678118654752f)));
+              for (int e = 0; e < 4; ++e) o[e] = vv[e] * gelu_erf_f(gg[e]);
               uint2 pk;
               pk.x = pack2bf(o[0], o[1]);
               pk.y = pack2bf(o[2], o[3]);
@@ -719,8 +704,18 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     // (per wave: its TN columns must lie inside the matrix -- no predicates, no divergent control flow, which would also
     // make the compiler's wait counts conservative; rows past M fall to the buffer bounds check; edge waves take the
     // generic loop, there is no barrier)
+    bool fast_wave = false;
+    if (p.epi_fast && n0 + wn * TN + TN <= p.n) {
+      const bool one_sample = m0 / p.howo == (min(m0 + BM, p.M) - 1) / p.howo;
+      fast_wave = !p.rowvec || one_sample;
+    }
     if (fast_wave) {
-      const WideCtx wc = {stg, RSF, frow, nsub, prow, col4, m0 + wm * TM + prow, (size_t)g * p.ogs, n_lane, m0, wm, wn};
+      float4 c4 = bias4;
+      if (p.rowvec) {
+        const float4 rv4 = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m0 / p.howo) * p.rowvec_ld + n_lane);
+        c4.x += rv4.x; c4.y += rv4.y; c4.z += rv4.z; c4.w += rv4.w;
+      }
+      const WideCtx wc = {stg, RSF, frow, nsub, prow, col4, m0 + wm * TM + prow, (size_t)g * p.ogs, n_lane, c4, m0, wm, wn};
       if (p.gn_part) {       // host: no accumulate, no second output, alpha == 1, no activation on this path
         if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, false, true, BM, WM>(p, acc, wc);
         else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false, false, true, BM, WM>(p, acc, wc);

@@ -45,9 +45,11 @@ struct SplitWs {
   }
   void destroy() { if (p) (void)hipFree(p); p = nullptr; }
 };
-struct WsBind {
-  explicit WsBind(const SplitWs& w) { ctta_conv_bind_workspace(w.p, w.bytes); }
-  ~WsBind() { ctta_conv_bind_workspace(nullptr, 0); }
+struct WsBind {   // re-entrant: the previous binding of the thread (a raw caller's, or an outer handle's) comes back
+  void* prev = nullptr;
+  size_t prev_bytes = 0;
+  explicit WsBind(const SplitWs& w) { ctta_conv_bound_workspace(&prev, &prev_bytes); ctta_conv_bind_workspace(w.p, w.bytes); }
+  ~WsBind() { ctta_conv_bind_workspace(prev, prev_bytes); }
   WsBind(const WsBind&) = delete;
   WsBind& operator=(const WsBind&) = delete;
 };
@@ -494,14 +496,17 @@ static inline void gn_emit_done(RunCtx& c, const ctta_conv_desc& d) {
 
 
 // fused GroupNorm statistics (engine_common.h: gn_emit_setup): partial-sum buffer appended to the GroupNorm scratch
-static inline bool gn_fuse_enabled() {
-  static int v = -1;
-  // Off by default: measured on MI355X (round 2, profiles/README.md) the fused statistics save GroupNorm's first read pass
-  // but the apply pass then misses the Infinity-Cache lines that pass used to leave behind -- generation 300.5 -> 299.7
-  // clips/s, distillation 124.1 -> 123.5 ms: a wash.  CTTA_GN_FUSE=1 turns it on.
-  if (v < 0) { const char* e = getenv("CTTA_GN_FUSE"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v != 0;
-}
+// On by default since round 3 (ctta_set_gn_fuse / CTTA_GN_FUSE=0 turn it off).  Round 2 measured it neutral (the
+// statistics then rode in the ROLLED wide-store epilogue, 16.7 us per 256x256 tile); in the straight-line epilogue they
+// cost two packed adds and two packed FMAs per 4 outputs (+1..7 us per launch, +4 % on the 128-channel VAE layers) and
+// save GroupNorm's statistics pass: conv + GroupNorm 193 -> 177 us (U-Net level 0), 683 -> 632 us (VAE 256 ch), 1005 ->
+// 948 us (VAE 128 ch), generation 364 -> 369 clips/s (tools/gn_fuse_ab.py, profiles/README.md).
+// Trade-off, stated: the per-tile partial sums make a sample's (mean, rstd) depend -- in the last fp32 bits -- on the
+// TILE SHAPE its convolution ran with, which is chosen from the batch size.  A sample's result is still bit-independent
+// of its batch mates and of its position at a FIXED batch size (what data-parallel sharding needs); across batch sizes
+// it now agrees to bf16 round-off instead of bit for bit (tests/test_engines_gpu.py, both properties; with the fusion
+// off the old bit-for-bit property across sizes is asserted too).
+static inline bool gn_fuse_enabled() { return ctta_gn_fuse_on(); }
 
 #define RUN(ctx, expr)                 \
   do {                                 \

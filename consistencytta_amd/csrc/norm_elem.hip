@@ -653,7 +653,7 @@ __global__ void geglu_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__
     unpack8(*reinterpret_cast<const uint4*>(in + (size_t)r * 2 * hp + vg), g);
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      a[e] = a[e] * (0.5f * g[e] * (1.0f + erff(g[e] * 0.70710678118654752f)));
+      a[e] = a[e] * gelu_erf_f(g[e]);
     *reinterpret_cast<uint4*>(out + (size_t)r * hp + v * 8) = pack8(a);
   }
 }

@@ -48,16 +48,86 @@ class FusedAdamW:
                                             N.stream_ptr()))
         self.module.mark_weights_changed()
 
-    # checkpoint / resume (accelerator.save_state stores the optimizer state, train.py:497-505)
+    # checkpoint / resume (accelerator.save_state stores the optimizer state, train.py:497-505): the layout is
+    # torch.optim.AdamW.state_dict() over `student_unet.parameters()` (tools/train_utils.py:38-39,59-63), so that
+    # optimizer.bin written here resumes a reference run and vice versa:
+    #   {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [{..., 'params': [0..n_params)}]}
+    # with i the parameter's position in `parameters()` order; parameters without a gradient (guidance_proj.weight)
+    # have no state entry, exactly as torch leaves them.
+    def _segments(self):
+        """[(index in parameters() order, parameter, offset in the flat moment buffers)] of the trainable parameters."""
+        frozen = set(getattr(self.module, "_frozen_keys", ()))
+        segs, off = [], 0
+        for i, (k, p) in enumerate(self.module.named_parameters()):
+            if k in frozen:
+                continue
+            segs.append((i, p, off))
+            off += p.numel()
+        assert off == self.n
+        return segs
+
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
-                "param_groups": [dict(g) for g in self.param_groups]}
+        step = torch.tensor(float(self.step_count))
+        state = {}
+        if self.step_count > 0:   # torch creates a parameter's state at its first update
+            for i, p, off in self._segments():
+                n = p.numel()
+                state[i] = {"step": step.clone(), "exp_avg": self.exp_avg[off:off + n].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[off:off + n].view(p.shape).clone()}
+        n_params = sum(1 for _ in self.module.parameters())
+        groups = []
+        for g in self.param_groups:
+            t = dict(g)
+            t.setdefault("amsgrad", False)
+            t.setdefault("maximize", False)
+            t.setdefault("foreach", None)
+            t.setdefault("capturable", False)
+            t.setdefault("differentiable", False)
+            t.setdefault("fused", None)
+            t["params"] = list(range(n_params))
+            groups.append(t)
+        return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
-        self.param_groups = [dict(g) for g in sd["param_groups"]]
+        if "state" not in sd:   # rounds 1-2 private layout {step, exp_avg, exp_avg_sq, param_groups} over the flat buffer
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            self.param_groups = [dict(g) for g in sd["param_groups"]]
+            return
+        if len(sd["param_groups"]) != 1:
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        n_params = sum(1 for _ in self.module.parameters())
+        if len(sd["param_groups"][0]["params"]) != n_params:
+            raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+        segs = {i: (p, off) for i, p, off in self._segments()}
+        state = sd["state"]
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for i, st in state.items():
+            i = int(i)
+            if i not in segs:
+                raise ValueError("optimizer state for parameter %d, which this model does not train" % i)
+            p, off = segs[i]
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("optimizer state %d: shape %s, parameter %s" % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
+            n = p.numel()
+            self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if state and len(state) != len(segs):
+            raise ValueError("optimizer state covers %d of %d trainable parameters" % (len(state), len(segs)))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ (%s): the fused update keeps one" % sorted(steps))
+        self.step_count = steps.pop() if steps else 0
+        g = dict(sd["param_groups"][0])
+        g.pop("params", None)
+        g["betas"] = tuple(g["betas"])
+        for k in ("amsgrad", "maximize"):
+            if g.get(k):
+                raise ValueError("FusedAdamW does not implement %s=True" % k)
+        self.param_groups = [g]
 
 
 class WarmupSchedule:
@@ -92,12 +162,20 @@ class WarmupSchedule:
     def get_last_lr(self):
         return [self.opt.param_groups[0]["lr"]]
 
-    # resume (accelerator.save_state stores the scheduler too, train.py:497-505)
+    # resume (accelerator.save_state stores the scheduler too, train.py:497-505): torch.optim.lr_scheduler.LambdaLR's
+    # own keys (what transformers.get_scheduler returns), so scheduler.bin is interchangeable with the reference's;
+    # the schedule's shape (name / warm-up / total) is a constructor argument there too and rides along as extra keys.
     def state_dict(self):
-        return {"name": self.name, "num_warmup_steps": self.warm, "num_training_steps": self.total,
-                "base_lr": self.base_lr, "last_step": self.last_step}
+        return {"base_lrs": [self.base_lr], "last_epoch": self.last_step, "_step_count": self.last_step + 1,
+                "_get_lr_called_within_step": False, "_last_lr": self.get_last_lr(), "lr_lambdas": [None],
+                "name": self.name, "num_warmup_steps": self.warm, "num_training_steps": self.total}
 
     def load_state_dict(self, sd):
-        self.name, self.warm, self.total = sd["name"], int(sd["num_warmup_steps"]), sd["num_training_steps"]
-        self.base_lr, self.last_step = float(sd["base_lr"]), int(sd["last_step"])
+        if "last_epoch" in sd:
+            self.base_lr, self.last_step = float(sd["base_lrs"][0]), int(sd["last_epoch"])
+            if "name" in sd:
+                self.name, self.warm, self.total = sd["name"], int(sd["num_warmup_steps"]), sd["num_training_steps"]
+        else:   # rounds 1-2 private layout
+            self.name, self.warm, self.total = sd["name"], int(sd["num_warmup_steps"]), sd["num_training_steps"]
+            self.base_lr, self.last_step = float(sd["base_lr"]), int(sd["last_step"])
         self._apply()

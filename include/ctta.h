@@ -334,6 +334,10 @@ int ctta_conv_last_gn_chunks(void);
  * device: launches that share it must be ordered on ONE stream -- or the caller binds its own buffer of
  * ctta_conv_workspace_bytes() bytes for the calling thread (NULL unbinds). */
 void ctta_conv_bind_workspace(void* ws, size_t bytes);
+/* The calling thread's current binding (NULL / 0 when none).  Engine / STFT / mel / T5 entry points bind their own
+ * handle's workspace while they enqueue work and RESTORE the caller's binding on return (round 3; before, they left the
+ * thread unbound and later raw launches silently fell back to the shared per-device workspace). */
+void ctta_conv_bound_workspace(void** ws, size_t* bytes);
 /* on != 0: launches issued by the calling host thread take no split-K path until switched off again (used for GEMMs that
  * an engine enqueues on a second stream of the same handle, which must not share the handle's partial-sum slabs) */
 void ctta_conv_suppress_splitk(int on);
@@ -633,6 +637,11 @@ ctta_status ctta_adamw_step(float* param, const float* grad, float* exp_avg, flo
  * and attention (kind 1) launch is bracketed by hipEvents on its own stream.  collect() waits
  * for the recorded launches, returns their summed duration / executed FLOPs / count, optionally
  * appends one CSV line per launch (kind,variant,m,n,k,groups,ms,tflops) and clears the log. */
+/* GroupNorm statistics from the producing convolution's epilogue (default on; CTTA_GN_FUSE=0 in the environment or
+ * ctta_set_gn_fuse(0) turn it off, process-wide, taking effect at the next engine call).  Off: a sample's result is
+ * bit-identical at every batch size; on: at a fixed batch size. */
+void ctta_set_gn_fuse(int on);
+int ctta_get_gn_fuse(void);
 void ctta_prof_enable(int on);
 ctta_status ctta_prof_collect(int kind, double* total_ms, double* total_flops, int64_t* launches,
                               const char* csv_path);

@@ -237,6 +237,73 @@ def test_flat_alias_checks_and_schedule_state():
     assert s2.get_last_lr() == sch.get_last_lr()
 
 
+def test_optimizer_and_scheduler_files_are_torch_layout(tmp_path):
+    """optimizer.bin / scheduler.bin must be what the reference writes -- torch.optim.AdamW.state_dict()
+    over student_unet.parameters() (tools/train_utils.py:38-39,59-63) and LambdaLR.state_dict() (get_scheduler, :77-81) --
+    so that a reference run resumes here and the other way round.  Both directions against the real torch classes."""
+    from transformers import get_scheduler
+    from consistencytta_amd import optim
+    m = _lcm()
+    net = m.student_unet
+    net.init_deterministic(seed=3)
+    params = list(net.parameters())
+    names = [k for k, _ in net.named_parameters()]
+    frozen = set(net._frozen_keys)
+    assert frozen and all(not p.requires_grad for k, p in net.named_parameters() if k in frozen)
+    # --- a reference-side optimizer after two updates (parameters without a gradient get no state, as in the reference)
+    ref = torch.optim.AdamW(params, lr=1e-5, betas=(0.9, 0.999), weight_decay=1e-4, eps=1e-8)
+    rs = get_scheduler(name="linear", optimizer=ref, num_warmup_steps=2, num_training_steps=40)
+    g = torch.Generator().manual_seed(0)
+    for _ in range(2):
+        for k, p in zip(names, params):
+            p.grad = None if k in frozen else torch.randn(p.shape, generator=g) * 1e-2
+        ref.step()
+        rs.step()
+    torch.save(ref.state_dict(), tmp_path / "optimizer.bin")
+    torch.save(rs.state_dict(), tmp_path / "scheduler.bin")
+    for p in params:
+        p.grad = None
+    ours = optim.FusedAdamW(net, lr=3e-5)
+    sch = optim.WarmupSchedule(ours, "linear", num_warmup_steps=2, num_training_steps=40)
+    ours.load_state_dict(torch.load(tmp_path / "optimizer.bin"))
+    sch.load_state_dict(torch.load(tmp_path / "scheduler.bin"))
+    assert ours.step_count == 2 and sch.last_step == 2 and sch.get_last_lr() == rs.get_last_lr()
+    assert ours.param_groups[0]["weight_decay"] == 1e-4 and ours.param_groups[0]["betas"] == (0.9, 0.999)
+    off = 0
+    for i, (k, p) in enumerate(net.named_parameters()):   # the flat moments are the per-parameter ones, trainable order
+        if k in frozen:
+            continue
+        st = ref.state_dict()["state"][i]
+        assert torch.equal(ours.exp_avg[off:off + p.numel()].view(p.shape), st["exp_avg"]), k
+        assert torch.equal(ours.exp_avg_sq[off:off + p.numel()].view(p.shape), st["exp_avg_sq"]), k
+        off += p.numel()
+    assert off == ours.n
+    # --- and back: our files load into the torch classes and continue identically
+    torch.save(ours.state_dict(), tmp_path / "optimizer2.bin")
+    torch.save(sch.state_dict(), tmp_path / "scheduler2.bin")
+    ref2 = torch.optim.AdamW(params, lr=7e-5)
+    rs2 = get_scheduler(name="linear", optimizer=ref2, num_warmup_steps=2, num_training_steps=40)
+    ref2.load_state_dict(torch.load(tmp_path / "optimizer2.bin"))
+    rs2.load_state_dict(torch.load(tmp_path / "scheduler2.bin"))
+    a, b = ref.state_dict(), ref2.state_dict()
+    assert sorted(a["state"]) == sorted(b["state"]) and a["param_groups"][0]["params"] == b["param_groups"][0]["params"]
+    for i in a["state"]:
+        for key in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.equal(torch.as_tensor(a["state"][i][key]), torch.as_tensor(b["state"][i][key])), (i, key)
+    assert rs2.last_epoch == 2 and rs2.get_last_lr() == rs.get_last_lr()
+    rs.step(), rs2.step(), sch.step()
+    assert rs2.get_last_lr() == rs.get_last_lr() == sch.get_last_lr()
+    # a state dict for a different model is refused like torch refuses it
+    bad = ours.state_dict()
+    bad["param_groups"][0]["params"] = bad["param_groups"][0]["params"][:-1]
+    with pytest.raises(ValueError, match="doesn't match the size"):
+        ours.load_state_dict(bad)
+    # the private layout of rounds 1-2 still loads
+    ours.load_state_dict({"step": 5, "exp_avg": torch.zeros(ours.n), "exp_avg_sq": torch.ones(ours.n),
+                          "param_groups": [dict(lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0)]})
+    assert ours.step_count == 5 and float(ours.exp_avg_sq[3]) == 1.0
+
+
 def test_ddpm_step_host_tables_match_reference(golden):
     """DDPMScheduler.step's per-sample coefficient tables (scheduling_ddpm.py:232-265,319-333) vs the reference's own
     step outputs: the HIP kernel only evaluates a*x + b*y with these numbers (GPU twin: test_models_gpu.py)."""

@@ -282,7 +282,8 @@ def test_groupnorm_statistics_from_the_conv_epilogue(B, C, H, W, Cout, tile, wit
     sync()
     # (mean, rstd): the epilogue sums the fp32 values BEFORE their bf16 rounding (what the reference's fp32 GroupNorm sees),
     # the three-pass kernel the stored bf16 values: zero-mean rounding noise, 2^-9 relative per element
-    assert rel_err(st_f[..., 0], st_s[..., 0]) < 1e-4 and rel_err(st_f[..., 1], st_s[..., 1]) < 1e-4
+    # -> the means agree to a thousandth of a standard deviation, the reciprocal deviations to 1e-3 (1024-element groups in the smallest case)
+    assert float(((st_f[..., 0] - st_s[..., 0]) * st_s[..., 1]).abs().max()) < 1e-3 and rel_err(st_f[..., 1], st_s[..., 1]) < 1e-3
     assert rel_err(y_f.float(), y_s.float()) <= 2.0 ** -7                                                 # at most an ulp apart
     # no statistics table -> one launch folds the partials in every block: bit-identical to the two-launch form
     y_1 = torch.empty_like(out)
@@ -299,6 +300,33 @@ def test_groupnorm_statistics_from_the_conv_epilogue(B, C, H, W, Cout, tile, wit
                    out=o2, ldc=256, gn_part=part, gn_groups=G, gn_hw=16, gn_part_floats=part.numel())
     run_conv(d2)
     assert L_.ctta_conv_last_gn_chunks() == 0
+
+
+@pytest.mark.parametrize("with_res", [False, True])
+def test_ragged_last_row_tile_runs_as_a_second_launch(with_res):
+    """M = 256 * 256 + 40 rows, one column tile: 257 workgroups of the 256x256 tile = two rounds of the 256 CUs for 40 rows.
+    The host cuts the last row tile off and runs it with 64x64 tiles through ConvParams.m_off (round 3; HiFi-GAN's
+    M = 32 * 5121).  Same numbers as one launch with a forced tile, and as F.conv1d."""
+    B, C, Co, L, k = 1, 64, 256, 256 * 256 + 40, 11
+    x = bf16_round(det("tail.x", (B, C, L), 1))
+    w = bf16_round(det("tail.w", (Co, C, k), 2) * (1.0 / math.sqrt(C * k)))
+    b = det("tail.b", (Co,), 3) * 0.1
+    res = bf16_round(det("tail.r", (B, Co, L), 4))
+    ref = F.conv1d(x, w, b, padding=k // 2) + (res if with_res else 0.0)
+    wp, k_pad = pack_conv_weight(w[:, :, None, :])
+    xa = x.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    ra = res.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    bd = b.to(DEV)
+    outs = []
+    for tile in (0, 29):
+        out = torch.full((B, L, Co), float("nan"), dtype=torch.bfloat16, device=DEV)
+        run_conv(conv_desc(x0=xa, c0=C, batch=B, hi=1, wi=L, ho=1, wo=L, kh=1, kw=k, pad_w=k // 2, w=wp, k_pad=k_pad, n=Co,
+                           bias=bd, out=out, ldc=Co, tile=tile, **(dict(res=ra, res_ld=Co) if with_res else {})))
+        assert bool(torch.isfinite(out.float()).all())
+        outs.append(out.float().permute(0, 2, 1).cpu())
+    assert rel_err(outs[0], ref) < BF16_TOL and rel_err(outs[1], ref) < BF16_TOL
+    assert torch.equal(outs[0][:, :, :256 * 256], outs[1][:, :, :256 * 256])     # the big tiles are the same launch
+    assert rel_err(outs[0][:, :, 256 * 256:], outs[1][:, :, 256 * 256:]) <= 2.0 ** -7
 
 
 def test_conv_fused_output_activations_and_scalar_store():
@@ -731,7 +759,15 @@ def test_stft_magnitude_and_input_gradient_against_torch_stft_float64(fft, hop, 
     (ref * direction.double()).sum().backward()
     m = losses._STFTMagnitude(fft, hop, win, "hann_window")
     xg = x.to(DEV).requires_grad_(True)
+    # a raw ctta_conv_gemm caller's split-K workspace binding survives the entry point (WsBind used to unbind)
+    L_ = lib()
+    mine = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    L_.ctta_conv_bind_workspace(N.ptr(mine), mine.numel())
     got = m(xg)
+    ws, nb = ctypes.c_void_p(), ctypes.c_size_t()
+    L_.ctta_conv_bound_workspace(ctypes.byref(ws), ctypes.byref(nb))
+    L_.ctta_conv_bind_workspace(None, 0)
+    assert ws.value == mine.data_ptr() and nb.value == mine.numel()
     assert got.shape == ref.shape and got.dtype == torch.float32
     (got * direction.to(DEV)).sum().backward()
     plain = m(x.to(DEV))                               # the no-grad handle gives the same numbers
