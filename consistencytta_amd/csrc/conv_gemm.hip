@@ -312,6 +312,9 @@ static int pick_variant(long long M, int N, long long K, int groups) {
   if (N <= 64) return K >= 512 ? 8 : 5;                    // 128x64 / 64x64
   const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * groups;
   if (t128 < 200) return 5;                                // too few 128x128 tiles to fill 256 CUs
+  // the batch-32 level-2 linears (M = 8192, N = 1024..2560, K = 1024 / 1280): 128x128x64 at 736-824 TFLOP/s against 588-682
+  // on the thin-grid tile below (profiles/sweep_r03.txt); batch-9 shapes (t128 < 400) keep the thin-grid rule
+  if (t128 >= 400 && K >= 1024 && K < 4096 && N >= 1024 && M <= 16384) return 1;
   if (t128 < 1024 && (K < 4096 || t128 < 400 || N <= 512)) return 6;                    // thin grids (distillation micro-batch): 64x128x64 doubles the workgroups
   if (K >= 4096) return N >= 256 ? 1 : 6;                  // 128x128x64 / 64x128x64
   if (K > 1536) return M >= 400000 ? 6 : 2;                // 64x128x64 / 128x128x32
@@ -417,14 +420,16 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       vid = pick_variant(M, d->n, K, groups);
       // fused GEGLU: 128x128x32 through the wide-store epilogue (its read-back loop is rolled, so the 16-fragment tile
       // keeps its accumulators in registers); the direct epilogue only exists in the <= 8-fragment tiles (64x128x64)
-      if (geglu) vid = p.wide_store ? 2 : 6;
+      // (round 3, after the GELU rewrite: 256x128x32 with 8 waves of 64x64 wins from K = 512 up and on the batch-9 / 16
+      // shapes -- 796 vs 727, 919 vs 795, 625 vs 591 TFLOP/s, profiles/sweep_r03.txt; the K = 256 batch-32 launch stays)
+      if (geglu) vid = !p.wide_store ? 6 : ((K >= 512 || M < 100000) && fast_ok(32) && glds_default()) ? 28 : 2;
       // deep and narrow (few 128x128 tiles, long K): the 128x128 tile with split-K beats small tiles that only
       // exist to create workgroups (measured: M=1152, N=1024, K=9216 at 176 TFLOP/s on 64x64 tiles)
       const long long t128 = ((M + 127) / 128) * ((d->n + 127) / 128);
       if (splitk_default() && groups == 1 && K >= 4096 && d->n >= 256 && t128 < 192 && !scalar_store && !geglu &&
           d->out_limit == 0 && d->out_offset == 0)
         vid = 1;
-      if (!d->in_act && glds_default()) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
+      if (!d->in_act && glds_default() && vid <= 8) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
       // 64 < N <= 128 with enough rows: the 256x128x32 tile (8 waves of 64x64) stages 25 % fewer bytes per FLOP than
       // 128x128 / 64x128 and, with the wide-store epilogue, wins from K = 384 up (sweep: +12..22 %)
       const long long t28 = ((M + 255) / 256) * groups;
@@ -435,10 +440,11 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
   if (geglu) {   // direct epilogue: <= 8-fragment tiles (64x64, 64x128, 128x64, 256x32); wide-store: also the 128x128 tiles
-    const int base = (vid - 1) % 8 + 1;
-    CTTA_REQUIRE(vid <= 24 && (base == 4 || base == 5 || base == 6 || base == 8 || (p.wide_store && (base == 1 || base == 2))),
-                 "conv_gemm: the fused GEGLU epilogue needs a 64x64 / 64x128 / 128x64 / 256x32 (or, wide-store, 128x128) tile (got %s)",
-                 kVariants[vid - 1].name);
+    const Variant& gv = kVariants[vid - 1];
+    const int frags = (gv.bm / gv.wm / 16) * (gv.bn / gv.wn / 16);     // accumulator fragments per wave
+    CTTA_REQUIRE(frags <= 8 || (p.wide_store && frags <= 16),
+                 "conv_gemm: the fused GEGLU epilogue needs a tile with <= 8 fragments per wave (or, wide-store, <= 16): got %s",
+                 gv.name);
   }
   CTTA_REQUIRE(kVariants[vid - 1].mode != 2 || fast_ok(kVariants[vid - 1].bk),
                "conv_gemm: variant %s needs (c0+c1) %% BK == 0, one source and <= 32 taps", kVariants[vid - 1].name);

@@ -49,6 +49,23 @@ SHAPES = [
     ("lin M8192 1024>8192", 32, 256, 1, 1024, 8192, 1, 1, 1),
     ("lin M8192 4096>1024", 32, 256, 1, 4096, 1024, 1, 1, 1),
     ("lin M2048 1024>8192", 32, 64, 1, 1024, 8192, 1, 1, 1),
+    # round 3: the transformer linears of the batch-32 U-Net that the first list lacked (SWEEP_FILTER=u32)
+    ("u32 M131072 320>256", 32, 4096, 1, 320, 256, 1, 1, 1),
+    ("u32 M131072 256>320", 32, 4096, 1, 256, 320, 1, 1, 1),
+    ("u32 M32768 512>512", 32, 1024, 1, 512, 512, 1, 1, 1),
+    ("u32 M32768 640>512", 32, 1024, 1, 640, 512, 1, 1, 1),
+    ("u32 M32768 512>1280", 32, 1024, 1, 512, 1280, 1, 1, 1),
+    ("u32 M8192 1024>1024", 32, 256, 1, 1024, 1024, 1, 1, 1),
+    ("u32 M8192 1280>1024", 32, 256, 1, 1280, 1024, 1, 1, 1),
+    ("u32 M8192 1024>2560", 32, 256, 1, 1024, 2560, 1, 1, 1),
+    ("u32 conv 64x4 1024>1024", 32, 64, 4, 1024, 1024, 3, 3, 1),
+    ("u32 conv 32x2 1024>1024", 32, 32, 2, 1024, 1024, 3, 3, 1),
+    # fused GEGLU (SWEEP_GEGLU=1 SWEEP_FILTER=ff1): N counts value + gate columns
+    ("ff1 M131072 256>2048", 32, 4096, 1, 256, 2048, 1, 1, 1),
+    ("ff1 M32768 512>4096", 32, 1024, 1, 512, 4096, 1, 1, 1),
+    ("ff1 M8192 1024>8192", 32, 256, 1, 1024, 8192, 1, 1, 1),
+    ("ff1 M36864 256>2048", 9, 4096, 1, 256, 2048, 1, 1, 1),
+    ("ff1 M65536 256>2048", 16, 4096, 1, 256, 2048, 1, 1, 1),
     # distillation micro-batch (B = 9 student / 18 teacher-CFG): SWEEP_FILTER=d9
     ("d9 conv 128x8 512>512", 9, 128, 8, 512, 512, 3, 3, 1),
     ("d9 conv 256x16 256>256", 9, 256, 16, 256, 256, 3, 3, 1),
@@ -73,6 +90,7 @@ def main():
     flt = os.environ.get("SWEEP_FILTER", "")
     only = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "").split(",") if v]
     epi = os.environ.get("SWEEP_EPI", "0") == "1"
+    geglu = os.environ.get("SWEEP_GEGLU", "0") == "1"
     print("variants:", names if not only else [names[v - 1] for v in only])
     results = []
     for (tag, B, H, W, Cin, Cout, kh, kw, dil) in SHAPES:
@@ -83,7 +101,7 @@ def main():
         k_pad = (K + 63) // 64 * 64
         w = (torch.randn(Cout, k_pad, device=DEV) * 0.05).to(torch.bfloat16)
         bias = torch.randn(Cout, device=DEV)
-        out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+        out = torch.empty(B, H, W, Cout // 2 if geglu else Cout, dtype=torch.bfloat16, device=DEV)
         M = B * H * W
         flops = 2.0 * M * Cout * K
         row = {"tag": tag, "M": M, "N": Cout, "K": K, "tflops": {}}
@@ -101,7 +119,9 @@ def main():
             d.alpha, d.groups = 1.0, 1
             if epi:
                 d.res, d.res_ld, d.out2, d.out2_slope = res.data_ptr(), Cout, out2.data_ptr(), 0.1
-            d.out, d.ldc, d.tile = out.data_ptr(), Cout, v
+            d.out, d.ldc, d.tile = out.data_ptr(), (Cout // 2 if geglu else Cout), v
+            if geglu:
+                d.out_act = 4
             st = N.stream_ptr()
             vname = names[v - 1] if v > 0 else "auto"
             if L.ctta_conv_gemm(ctypes.byref(d), st) != 0:   # variant not eligible for this shape
