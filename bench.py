@@ -54,8 +54,9 @@ def parse():
     ap.add_argument("--teacher-batch", type=int, default=8)
     ap.add_argument("--distill-batch", type=int, default=9, help="per-GPU micro-batch of the distillation leg (train.sh)")
     ap.add_argument("--no-latency", action="store_true",
-                    help="skip the single-clip eager/hipGraph latency leg (graph replay hangs under rocprofv3 --pmc) and, "
-                         "in --mode distill, the AdamW / EMA timing passes and the wav -> latent leg (PMC passes)")
+                    help="for the rocprofv3 --pmc passes: no hipGraph anywhere (the headline loop times eager launches, the "
+                         "single-clip eager/hipGraph latency leg is skipped -- a graph replay under --pmc hung on this pool in "
+                         "round 1) and, in --mode distill, no AdamW / EMA timing passes and no wav -> latent leg")
     ap.add_argument("--perceptual-batch", type=int, default=4,
                     help="per-GPU micro-batch of the perceptual-loss leg (configs[4] without CLAP)")
     ap.add_argument("--profile-csv", default=None, help="append one line per MFMA launch (tuning aid)")
@@ -154,7 +155,9 @@ def main():
     # batch-32 step replay as one submission; bit-identical to the eager launches, asserted here).  CTTA_BENCH_GRAPH=0, or a
     # failed capture, times the eager launches instead; both rates are reported.
     timed, launch_mode, genB = step, "eager launches", None
-    if os.environ.get("CTTA_BENCH_GRAPH", "1") != "0":
+    # --no-latency (the PMC passes of tools/refresh_profiles.sh) times eager launches only: graph replays under
+    # `rocprofv3 --pmc` hung on this pool in round 1, and counters should not mix replayed and eager steps
+    if os.environ.get("CTTA_BENCH_GRAPH", "1") != "0" and not args.no_latency:
         try:
             genB = pipe.capture_graph(B, L, cfg_scale_input=4.0)
             pg = genB(enc, mask, noise)
@@ -210,6 +213,11 @@ def main():
         torch.cuda.synchronize()
         result["stage_ms"] = {"unet": round(ev[0].elapsed_time(ev[1]), 3), "vae_decoder": round(ev[1].elapsed_time(ev[2]), 3),
                               "hifigan": round(ev[2].elapsed_time(ev[3]), 3)}
+        # whole-stage fraction of the dense bf16 peak: ALL algorithmic FLOPs of the stage (convs, linears, attention) over
+        # the stage's wall time (eager launches, every kernel of the stage included) -- the weakest stage at a glance
+        gf_stage = {"unet": GF_UNET_CONV + GF_UNET_LINEAR_L16 + GF_UNET_LINEAR_PER_16TOK * max(0, (L - 16) / 16.0) + GF_UNET_SELF_ATTN + GF_UNET_CROSS_ATTN_L16 * L / 16.0,
+                    "vae_decoder": GF_VAE_CONV + GF_VAE_ATTN, "hifigan": GF_HIFIGAN}
+        stage_frac = {k: round(gf_stage[k] * 1e9 * B / (result["stage_ms"][k] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4) for k in gf_stage}
         # ---- roofline of the dominant kernel family, measured live with HIP events per launch
         import ctypes
         L_ = N.lib()
@@ -245,6 +253,7 @@ def main():
             "executed_tflops_incl_padding": round(conv_exec_fl / (conv_ms * 1e-3) / 1e12, 2),
             "share_of_step_time": round(conv_ms / (dt / args.steps * 1e3), 3),
             "mfma_launch_ms_per_step_all_kinds": round(all_ms, 3),
+            "stage_frac": stage_frac,
         }
         td = result["roofline"]["traffic_detail"]
         if td and conv_cnt:   # per launch like `achieved`: HBM-side bytes of the family per step / its launches per step
@@ -603,7 +612,8 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         n_tr, n_all = opt.n, opt.flat.numel()
         passes = [
             ("adamw_kernel", "read p, g, m, v; write p, m, v (fp32)", 28 * n_tr, lambda: opt.step(grad_scale=1.0)),
-            ("ema2_kernel", "read student, 2 shadows; write 2 shadows (fp32)", 20 * n_all, m.update_ema),
+            ("ema2_kernel (AudioLCM.update_ema: the launch + its O(1) host checks)", "read student, 2 shadows; write 2 shadows (fp32)",
+             20 * n_all, m.update_ema),
             ("zero_grad (fill)", "write g (fp32)", 4 * opt.grad.numel(), opt.zero_grad),
         ]
         rows = []

@@ -198,6 +198,7 @@ SIGNATURES = {
     "ctta_conv_small_n": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "ctta_pack_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "ctta_nhwc_f32_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_rows_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ctta_concat_channels": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),

@@ -851,7 +851,7 @@ class CLAP_Module(nn.Module):
     def load_ckpt(self, ckpt=None, model_id=-1, verbose=False):
         if ckpt is None:
             raise RuntimeError("downloading CLAP checkpoints needs network access; pass ckpt=<path>")
-        sd = torch.load(ckpt, map_location="cpu")
+        sd = torch.load(ckpt, map_location="cpu", weights_only=False)   # a full training checkpoint dict (epoch, optimizer, ...), as laion_clap loads it
         sd = sd.get("state_dict", sd)
         sd = OrderedDict((k[7:] if k.startswith("module.") else k, v) for k, v in sd.items())
         sd.pop("text_branch.embeddings.position_ids", None)
@@ -869,9 +869,10 @@ class CLAP_Module(nn.Module):
         """get_audio_features(data_truncating='rand_trunc', data_filling='repeatpad') (training/data.py:402-492) for a
         batch of equal-length clips: repeat-and-zero-pad short clips, randomly crop long ones."""
         L = wav.shape[-1]
-        if L > max_len:
-            i = int(np.random.randint(0, L - max_len + 1))
-            return wav[..., i:i + max_len]
+        if L > max_len:   # one offset PER CLIP, like the reference's loop over waveforms (hook.py:174-186)
+            flat = wav.reshape(-1, L)
+            offs = [int(np.random.randint(0, L - max_len + 1)) for _ in range(flat.shape[0])]
+            return torch.stack([flat[j, i:i + max_len] for j, i in enumerate(offs)]).reshape(*wav.shape[:-1], max_len)
         if L < max_len:
             rep = wav.repeat(1, max_len // L)
             return torch.nn.functional.pad(rep, (0, max_len - rep.shape[-1]))

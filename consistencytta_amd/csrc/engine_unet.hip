@@ -116,7 +116,8 @@ struct ctta_unet {
   Transformer mid_att;
   ConvLayer conv_in;
   GNLayer norm_out;
-  float* conv_out_w = nullptr;   // fp32 [cout][3][3][c0] for the direct small-N kernel
+  ConvLayer conv_out;            // bf16 pack for conv_gemm (round 3: 256x32 MFMA tile, ~4x the direct kernel at batch 32)
+  float* conv_out_w = nullptr;   // fp32 [cout][3][3][c0] for the direct small-N kernel (CTTA_CONV_OUT_DIRECT=1)
   float* conv_out_b = nullptr;
   // embeddings (fp32)
   float *freqs = nullptr, *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
@@ -568,8 +569,23 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   bf16_t* a = A.get<bf16_t>((size_t)B * H * W * c0); ALLOC_OR_FAIL(a);
   float* st_out = nullptr;
   CTTA_TRY(gn(c, U->norm_out, h, a, H * W, cfg.norm_eps, true, &st_out));
-  RUN(c, ctta_conv_small_n(a, c0, B, H, W, 3, 3, 1, 1, U->conv_out_w, U->conv_out_b, cfg.out_channels, 0,
-                           0.f, 0, out, nullptr, stream));
+  static int co_direct = -1;   // CTTA_CONV_OUT_DIRECT=1: round 2's direct fp32-weight kernel (290 us at batch 32)
+  if (co_direct < 0) { const char* e = getenv("CTTA_CONV_OUT_DIRECT"); co_direct = (e && e[0] == '1') ? 1 : 0; }
+  if (co_direct || cfg.out_channels % 4 != 0) {
+    RUN(c, ctta_conv_small_n(a, c0, B, H, W, 3, 3, 1, 1, U->conv_out_w, U->conv_out_b, cfg.out_channels, 0,
+                             0.f, 0, out, nullptr, stream));
+  } else {   // conv_gemm on the matrix pipe (N = 8 of a 32-wide tile), fp32 [pixel][channel] result, then the NCHW hop
+    float* o_nhwc = A.get<float>((size_t)B * H * W * U->conv_out.p.n); ALLOC_OR_FAIL(o_nhwc);
+    ctta_conv_desc d;
+    desc_init(&d);
+    d.x0 = a; d.c0 = c0;
+    d.batch = B; d.hi = H; d.wi = W; d.ho = H; d.wo = W;
+    d.kh = 3; d.kw = 3; d.pad_h = d.pad_w = 1;
+    d.w = U->conv_out.p.w; d.k_pad = U->conv_out.p.k_pad; d.n = U->conv_out.p.n; d.bias = U->conv_out.p.bias;
+    d.out = o_nhwc; d.ldc = U->conv_out.p.n; d.out_f32 = 1;
+    RUN(c, ctta_conv_gemm(&d, stream));
+    RUN(c, ctta_nhwc_f32_to_nchw_f32(o_nhwc, out, B, cfg.out_channels, H * W, U->conv_out.p.n, stream));
+  }
   if (train) {
     U->ts.h_last = h; U->ts.a_out = a; U->ts.st_out = st_out;
     U->ts.B = B; U->ts.L = L; U->ts.Lp = c.Lp; U->ts.n_skips = n_skips; U->ts.arena_off = A.off;
@@ -685,6 +701,7 @@ static ctta_status unet_build(ctta_unet* U) {
   CTTA_TRY(make_gn(ws, "conv_norm_out.", boc[0], &U->norm_out));
   {
     const int co = cfg.out_channels, ci = boc[0];
+    CTTA_TRY(make_conv(ws, "conv_out.", co, ci, ci, 3, 3, 1, 1, &U->conv_out, true, nullptr));
     U->conv_out_w = ws.arena.get<float>((size_t)co * ci * 9);
     if (!U->conv_out_w) { ctta_set_error("weight store exhausted"); return CTTA_ERR_NOMEM; }
     float* dst = U->conv_out_w;

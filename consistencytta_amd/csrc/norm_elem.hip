@@ -42,6 +42,28 @@ __global__ void nhwc_to_nchw_kernel(const bf16_t* __restrict__ src, float* __res
   }
 }
 
+// (B,HW,Cs) f32 -> (B,C,HW) f32 (the U-Net's conv_out result, written [pixel][8] by conv_gemm, to the caller's NCHW)
+__global__ void nhwc_f32_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int HW, int Cs) {
+  const long long total = (long long)B * C * HW;
+  for (long long idx = blockIdx.x * (long long)blockDim.x + threadIdx.x; idx < total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    const int hw = (int)(idx % HW);
+    const long long bc = idx / HW;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    dst[idx] = src[((size_t)b * HW + hw) * Cs + c];
+  }
+}
+extern "C" ctta_status ctta_nhwc_f32_to_nchw_f32(const float* src, float* dst, int batch, int c, int hw, int c_stride, void* stream) {
+  CTTA_REQUIRE(src && dst && batch > 0 && c > 0 && hw > 0 && c_stride >= c, "nhwc_f32_to_nchw_f32: bad arguments");
+  const long long total = (long long)batch * c * hw;
+  int blocks = (int)((total + 255) / 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(nhwc_f32_to_nchw_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, dst, batch, c, hw, c_stride);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
 __global__ void rows_f32_to_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
                                         long long rows, int cols, int cols_pad) {
   const int vc = cols_pad / 8;
@@ -433,6 +455,77 @@ static void gn_launch_apply(const void* x, void* y, int batch, int hw, int c, co
                        groups, part, nchunk, gamma, beta, eps);
 }
 
+// The whole GroupNorm(+SiLU) in ONE launch when a (sample, group) slab is small (HW * C/G <= 16384 elements: the deep
+// U-Net levels, whose split-K convolutions emit no statistics): one block per (group, sample) keeps its slab in registers
+// (<= 8 vectors of 8 channels per thread), reduces (sum, sum of squares) through LDS in a fixed order, normalises from the
+// registers and stores -- one read, one write, no scratch, instead of three launches of 5..16 us each on a 4 MB tensor.
+__global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int HW, int C,
+                                                       int G, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, int silu,
+                                                       float* __restrict__ stats) {
+  constexpr int MAXV = 8;
+  __shared__ double red[2][4];
+  const int g = blockIdx.x, b = blockIdx.y;
+  const int cpg = C / G, vpr = cpg / 8;            // vectors per pixel row of this group
+  const int nvec = HW * vpr;
+  const bf16_t* xb = x + (size_t)b * HW * C + (size_t)g * cpg;
+  bf16_t* yb = y + (size_t)b * HW * C + (size_t)g * cpg;
+  uint4 v[MAXV];
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    v[i] = make_uint4(0, 0, 0, 0);
+    if (idx < nvec) {
+      const int pix = idx / vpr, cv = idx - pix * vpr;
+      v[i] = *reinterpret_cast<const uint4*>(xb + (size_t)pix * C + cv * 8);
+      float f[8];
+      unpack8(v[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s += f[e]; q += f[e] * f[e]; }
+    }
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = (double)s; red[1][threadIdx.x >> 6] = (double)q; }
+  __syncthreads();
+  const double ts = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+  const double tq = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  const double n = (double)HW * cpg;
+  const double mean = ts / n;
+  double var = tq / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  if (stats && threadIdx.x == 0) {
+    stats[((size_t)b * G + g) * 2] = meanf;
+    stats[((size_t)b * G + g) * 2 + 1] = rstd;
+  }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = threadIdx.x + i * 256;
+    if (idx < nvec) {
+      const int pix = idx / vpr, cv = idx - pix * vpr;
+      const int c0 = g * cpg + cv * 8;
+      float f[8];
+      unpack8(v[i], f);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float sc = rstd * gamma[c0 + e];
+        const float t = f[e] * sc + (beta[c0 + e] - meanf * sc);
+        f[e] = silu ? silu_f(t) : t;
+      }
+      *reinterpret_cast<uint4*>(yb + (size_t)pix * C + cv * 8) = pack8(f);
+    }
+  }
+}
+static bool gn_small_ok(int hw, int c, int groups) {
+  static int env = -1;
+  if (env < 0) { const char* e = getenv("CTTA_GN_SMALL"); env = (e && e[0] == '0') ? 0 : 1; }
+  const int cpg = c / groups;
+  return env && cpg % 8 == 0 && (long long)hw * cpg <= 16384 && groups <= 65535;
+}
+
 static void gn_geometry(int hw, int c, int* pix_per_chunk, int* nchunk) {
   int ppc = 32768 / c;
   if (ppc < 16) ppc = 16;
@@ -461,6 +554,12 @@ extern "C" ctta_status ctta_groupnorm_stats_out(const void* x, void* y, int batc
   CTTA_REQUIRE(c % 8 == 0 && groups > 0 && c % groups == 0, "groupnorm: C=%d groups=%d unsupported", c, groups);
   CTTA_REQUIRE(groups <= 256 * 64, "groupnorm: too many groups");
   hipStream_t s = (hipStream_t)stream;
+  if (gn_small_ok(hw, c, groups)) {
+    hipLaunchKernelGGL(gn_small_kernel, dim3(groups, batch), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, hw, c, groups, gamma,
+                       beta, eps, silu, stats);
+    CTTA_LAUNCH_CHECK();
+    return CTTA_OK;
+  }
   int ppc, nchunk;
   gn_geometry(hw, c, &ppc, &nchunk);
   float* part = scratch;

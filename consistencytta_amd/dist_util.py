@@ -96,8 +96,10 @@ class GradientBuckets:
         for lo, hi in _merge(self.pending):
             if self.compress is None:
                 self.works.append((dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True), None, lo, hi))
-            else:
-                tmp = self.flat[lo:hi].to(self.compress)
+            else:   # a persistent low-precision twin of the flat buffer (allocated once per gradient buffer and dtype,
+                # not one temporary per bucket and step)
+                tmp = _twin(self.flat, self.compress)[lo:hi]
+                tmp.copy_(self.flat[lo:hi])
                 self.works.append((dist.all_reduce(tmp, op=dist.ReduceOp.SUM, async_op=True), tmp, lo, hi))
         self.pending = []
 
@@ -118,6 +120,18 @@ class GradientBuckets:
                     self.flat[lo:hi].copy_(tmp)
         self.works = []
         return self.world
+
+
+_TWINS = {}
+
+
+def _twin(flat, dtype):
+    key = (flat.data_ptr(), flat.numel(), dtype)
+    t = _TWINS.get(key)
+    if t is None or t.device != flat.device:
+        _TWINS.clear()          # one training buffer per process: do not keep stale 1 GB twins alive
+        t = _TWINS[key] = torch.empty(flat.numel(), dtype=dtype, device=flat.device)
+    return t
 
 
 def _merge(ranges):

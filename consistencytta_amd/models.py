@@ -39,14 +39,29 @@ def do_ema_update(source_model, shadow_models, decay_consts):
     shadow += (1 - decay) * (param - shadow).  Buffers: the U-Net mirrors have none."""
     assert len(shadow_models) == len(decay_consts)
     assert 1 <= len(shadow_models) <= 2, "the fused kernel updates one or two shadows"
+    L_ = N.lib()
+    nets = [source_model] + list(shadow_models)
+    flats = [getattr(m, "_flat", None) for m in nets]
+    # steady state of the training loop: the same networks, still living in their flat buffers (O(1) checks: the key
+    # comparison below ran when this tuple was recorded, and flat_is_current() only walks after a re-homing event)
+    sig = tuple((id(m), getattr(m, "_rehome_count", 0)) for m in nets)
+    if (getattr(source_model, "_ema_validated", None) == sig and all(f is not None for f in flats)
+            and all(m.flat_is_current() for m in nets)):
+        for d in decay_consts:
+            assert 0 <= d <= 1
+        with torch.cuda.device(flats[0].device):
+            N.check(L_.ctta_ema_update2(N.ptr(flats[0]), N.ptr(flats[1]), float(decay_consts[0]),
+                                        N.ptr(flats[2]) if len(flats) > 2 else N.c_void_p(0),
+                                        float(decay_consts[1]) if len(flats) > 2 else 0.0, flats[0].numel(),
+                                        N.stream_ptr()))
+        for m in shadow_models:
+            m.mark_weights_changed()
+        return
     src = dict(source_model.named_parameters())
     shadows = [dict(m.named_parameters()) for m in shadow_models]
     for sh, d in zip(shadows, decay_consts):
         assert 0 <= d <= 1
         assert src.keys() == sh.keys()
-    L_ = N.lib()
-    nets = [source_model] + list(shadow_models)
-    flats = [getattr(m, "_flat", None) for m in nets]
     # the one-launch path needs every network to STILL live in its flat buffer (a `.to()` / `.float()` after
     # flatten_parameters_ re-homes p.data and would leave the kernel updating stale memory)
     if all(f is not None and f.numel() == flats[0].numel() for f in flats) and all(m.flat_is_current() for m in nets):
@@ -60,6 +75,7 @@ def do_ema_update(source_model, shadow_models, decay_consts):
                                         N.stream_ptr()))
         for m in shadow_models:
             m.mark_weights_changed()
+        source_model._ema_validated = sig
         return
     for name, p in src.items():
         a = shadows[0][name]

@@ -90,16 +90,36 @@ class _ParamTree(nn.Module):
             off += n
         self._flat = flat
         self._flat_grad = None
+        self._flat_checked_at = getattr(self, "_rehome_count", 0)
         return flat
+
+    # Everything that re-homes `p.data` through the nn.Module protocol (.to() / .float() / .cuda() / ... and
+    # load_state_dict(assign=True)) bumps a counter, so `flat_is_current()` is O(1) on the steady-state training step
+    # instead of a walk over 690 parameters per network (0.9 ms of host time per EMA update in round 2's bench).
+    def _apply(self, fn, recurse=True):
+        self._rehome_count = getattr(self, "_rehome_count", 0) + 1
+        return super()._apply(fn, recurse)
+
+    def load_state_dict(self, state_dict, strict=True, assign=False):
+        if assign:
+            self._rehome_count = getattr(self, "_rehome_count", 0) + 1
+        return super().load_state_dict(state_dict, strict=strict, assign=assign)
 
     def flat_is_current(self):
         """True while every parameter still aliases `_flat` (a later `.to()`, `.float()`, `load_state_dict(assign=True)`
-        ... re-homes `p.data` and would leave the fused optimizer / EMA kernels updating a stale buffer)."""
+        ... re-homes `p.data` and would leave the fused optimizer / EMA kernels updating a stale buffer).  The walk over
+        the parameters runs once per re-homing event (see `_apply`); assigning `p.data` by hand is not tracked."""
         flat = getattr(self, "_flat", None)
         if flat is None:
             return False
+        epoch = getattr(self, "_rehome_count", 0)
+        if getattr(self, "_flat_checked_at", None) == epoch:
+            return True
         lo, hi = flat.data_ptr(), flat.data_ptr() + flat.numel() * 4
-        return all(lo <= p.data_ptr() < hi for p in self.parameters())
+        ok = all(lo <= p.data_ptr() < hi for p in self.parameters())
+        if ok:
+            self._flat_checked_at = epoch
+        return ok
 
     def grads_alias_flat(self):
         """True while every trainable parameter's `.grad` is a view of `_flat_grad` (`zero_grad(set_to_none=True)`

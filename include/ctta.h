@@ -415,6 +415,9 @@ ctta_status ctta_copy_segments_multi(const ctta_copy_seg* segs, int n_segs, void
 
 ctta_status ctta_nchw_f32_to_nhwc_bf16(const float* src, void* dst, int batch, int c, int h,
                                        int w, int c_pad, float scale, void* stream);
+/* (B, HW, c_stride) fp32 rows -> (B, C, HW) fp32: the last hop of UNet2DCondition*Model.forward's `sample` (conv_out's
+ * [pixel][channel] result of ctta_conv_gemm to the reference's NCHW, unet_2d_condition_guided.py:940-945) */
+ctta_status ctta_nhwc_f32_to_nchw_f32(const float* src, float* dst, int batch, int c, int hw, int c_stride, void* stream);
 ctta_status ctta_nhwc_bf16_to_nchw_f32(const void* src, float* dst, int batch, int c, int h,
                                        int w, int c_stride, void* stream);
 ctta_status ctta_rows_f32_to_bf16(const float* src, void* dst, int64_t rows, int cols,

@@ -105,7 +105,11 @@ def test_conv_backward(B, Cin, Cout, H, W, k, stride, ups):
 
 
 @pytest.mark.parametrize("B,C,H,W,G,silu,eps", [(2, 40, 16, 8, 8, True, 1e-5), (3, 256, 8, 8, 32, False, 1e-6),
-                                                (2, 120, 4, 2, 8, True, 1e-5)])
+                                                (2, 120, 4, 2, 8, True, 1e-5),
+                                                # many chunks per sample: the chunk walk of gn_bwd_fold split over the block's
+                                                # threads (C <= 512), with C not dividing 1024 and C = 512
+                                                (2, 320, 64, 16, 32, True, 1e-5), (2, 512, 32, 16, 32, True, 1e-5),
+                                                (1, 1024, 16, 16, 32, False, 1e-5)])
 def test_groupnorm_backward(B, C, H, W, G, silu, eps):
     x = bf16_round(det("gb.x", (B, C, H, W), 1) * 2 + 0.3).requires_grad_(True)
     gamma = (1 + 0.2 * det("gb.g", (C,), 2)).requires_grad_(True)

@@ -654,6 +654,20 @@ def test_heun_cfg_loss_ema_wav(golden):
     ref = wav - (wav.max() + wav.min()) / 2
     assert torch.equal(cen.cpu(), ref)
     assert np.array_equal(pcm.cpu().numpy(), (ref.numpy() * 32768).astype("int16"))
+    # the float4 min / max walk: a base pointer 4 bytes off 16-byte alignment and a length that is not a multiple of 4, with
+    # the extrema placed in the unaligned head and in the tail
+    for n, lo_at, hi_at in [(9999, 0, 9998), (4097, 4096, 1), (5, 4, 0), (3, 1, 2)]:
+        w2 = torch.tanh(det("wav2.%d" % n, (n + 1,), 6)) * 0.5
+        w2[1 + lo_at], w2[1 + hi_at] = -0.97, 0.91
+        buf = w2.to(DEV)
+        view = buf[1:]                      # 4-byte offset
+        assert view.data_ptr() % 16 == 4
+        cen2 = torch.empty(n, device=DEV)
+        pcm2 = torch.empty(n, dtype=torch.int16, device=DEV)
+        N.check(L.ctta_wav_finalize(N.ptr(view), n, N.ptr(scratch), N.ptr(cen2), N.ptr(pcm2), st)); sync()
+        r2 = w2[1:] - (w2[1:].max() + w2[1:].min()) / 2
+        assert torch.equal(cen2.cpu(), r2), n
+        assert np.array_equal(pcm2.cpu().numpy(), (r2.numpy() * 32768).astype("int16")), n
 
 
 def test_errors_are_loud():
