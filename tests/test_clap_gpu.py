@@ -22,11 +22,11 @@ from gpu_util import DEV, bf16_round, det, rel_err, rel_l2, sync  # noqa: E402
 from oracle import clap as oclap  # noqa: E402
 
 KAISER = dict(lowpass_filter_width=64, rolloff=0.9475937167399596, beta=14.769656459379492)
-# Sampled-gradient budget of the real-size CLAP fine-tuning step (per block and overall): the CLAP term reaches the latent
-# through the vocoder's 46 LeakyReLUs, whose masks differ between bf16 and fp32 activations (0.13 .. 0.19 on the
-# input gradient of the vocoder alone); the MSE term, which dominates the gradient, has no such path.  Set from the
-# measured value with margin (printed by the test).
-CLAPFT_GRAD_REL_L2 = 0.15
+# Sampled-gradient budget of the real-size CLAP fine-tuning step (per block and overall).  Measured on MI355X: loss 0.547995
+# vs the reference's 0.547909, sampled gradient rel-L2 5.1e-3 over all blocks, worst block 9.0e-3, worst per-tensor norm
+# deviation 2.2e-3 -- the MSE term dominates the gradient at this size, so the vocoder's mask flips (0.13..0.19 on
+# the vocoder's own input gradient) stay below the bf16 noise of the U-Net backward.  Budget = the distillation step's.
+CLAPFT_GRAD_REL_L2 = 4e-2
 
 
 # ------------------------------------------------------------------------------------------------ operators
@@ -401,13 +401,12 @@ def _block_of(key):
 
 def test_clap_finetune_step_at_light_widths_matches_reference(golden):
     """configs[4] end to end at the real widths vs the reference: loss within 5e-2; the student's gradient, block by
-    block on the fixture's strided samples, within the vocoder-flip budget (the CLAP term reaches the latent
-    through 46 LeakyReLUs whose masks differ between bf16 and fp32 activations; the MSE term has no such path)."""
+    block on the fixture's strided samples, within the budget of the plain distillation step (4e-2; measured 5e-3)."""
     g, m, P, z0, gt, kw = _clapft_light(golden)
     loss = m(z0, gt, P, **kw)
     ref_loss = float(g["train_loss"])
     print("light-width CLAP fine-tuning loss hip %.6f ref %.6f (instance %s, mse part %s)"
-          % (float(loss), ref_loss, g["instance_loss"], g["instance_mse"]))
+          % (float(loss.detach()), ref_loss, g["instance_loss"], g["instance_mse"]))
     assert abs(float(loss) - ref_loss) <= 5e-2 * abs(ref_loss)
     loss.backward()
     torch.cuda.synchronize()
