@@ -20,6 +20,7 @@ import os
 from copy import deepcopy
 from time import time
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -884,6 +885,190 @@ def _teacher_loop_graphed(self, sch, z, enc, mask, guidance_scale):
 
 
 AudioLCM._teacher_loop_graphed = _teacher_loop_graphed
+
+
+class _DistillStepGraph:
+    """The distillation micro-step of `AudioLCM.train_step` (tools/train_utils.py:150-183) with its launch sequence
+    captured ONCE into a hipGraph: noising, the two CFG teacher queries + Heun, the target network, the student's training
+    forward (on its side stream) and backward, and the loss -- about 5 600 launches -- replay as one submission.  AdamW,
+    the LR schedule, zero_grad and the EMA stay eager behind the replay (3 launches; their scalars -- lr, step count --
+    are kernel arguments and change every step).
+
+    What makes the sequence replayable: every per-step quantity lives in a STATIC device tensor that the host refreshes
+    before the replay -- the latents, the noise, the guidance scales, the two timestep vectors and the eight per-sample
+    sigma vectors the Heun scheduler's methods look up (computed by the scheduler's own host logic, `_sigma_plan`, in the
+    order `_forward_impl` calls them) -- and the networks whose weights change every step (student after AdamW, target after
+    the EMA) have their bf16 re-pack captured at the head of their forward.  Single-process only: with a process group
+    the block-wise gradient all-reduce must interleave with the backward (`train_step`), which a replay cannot do.
+    Results are bit-identical to the eager `train_step` (same kernels, same arguments; asserted by
+    tests/test_train_gpu.py and by bench.py before it times the replays)."""
+
+    def __init__(self, model, optimizer, z_shape, P):
+        assert model.loss is None, "the captured step covers the latent-space loss (loss_type='mse')"
+        assert model.training and model.use_teacher_cf_guidance
+        self.m, self.opt = model, optimizer
+        dev = model.device
+        B = z_shape[0]
+        self.B, self.dev = B, dev
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.z0 = torch.zeros(z_shape, **f32)
+        self.noise = torch.zeros(z_shape, **f32)
+        self.w = torch.zeros(B, **f32)
+        self.t_np1 = torch.zeros(B, **f32)
+        self.t_n = torch.zeros(B, **f32)
+        self.sig = [torch.zeros(B, **f32) for _ in range(8)]
+        self.P = {k: v.detach().clone() for k, v in P.items()}
+        self.loss = None
+        self.graph = None
+        self._pinned = torch.zeros(11, B, dtype=torch.float32).pin_memory()
+
+    # -- host side: what the Heun scheduler would look up for this draw, in `_forward_impl`'s call order
+    def _sigma_plan(self, inds):
+        sch = self.m.noise_scheduler
+        avail, sig = sch._timesteps_host, sch._sigmas_host
+        t_np1, t_n = avail[inds], avail[inds + 2]
+
+        def idx(t, first_order):
+            saved = sch.dt
+            sch.dt = None if first_order else (0, 0)
+            try:
+                return sch.index_for_timestep(t)
+            finally:
+                sch.dt = saved
+        i1 = idx(t_np1, True)         # add_noise, scale_model_input, step (1st order) at t_{n+1}
+        i2 = idx(t_n, False)          # scale_model_input and step (2nd order) at t_n
+        i3 = idx(t_n, True)           # scale_model_input at t_n, back in first-order state
+        plan = [sig[i1], sig[i1 + 1], sig[i2], sig[i2 - 1], sig[i2], sig[i3], sig[inds]]
+        return t_np1, t_n, plan
+
+    def _refresh(self, z_0, time_inds, gaussian_noise, guidance_scale):
+        m, B = self.m, self.B
+        avail = m.noise_scheduler._timesteps_host
+        order = 2
+        if time_inds is not None:
+            inds = time_inds.to("cpu", torch.int64)
+        else:
+            inds = torch.randint(0, (len(avail) - 1) // order, (B,)) * order
+        noise = gaussian_noise if gaussian_noise is not None else torch.randn_like(z_0)
+        if guidance_scale is None:
+            guidance_scale = torch.rand(B) * m.max_rand_guidance_scale
+        t_np1, t_n, plan = self._sigma_plan(inds.numpy())
+        host = self._pinned
+        host[0].copy_(torch.from_numpy(np.asarray(t_np1, dtype=np.float32)))
+        host[1].copy_(torch.from_numpy(np.asarray(t_n, dtype=np.float32)))
+        host[2].copy_(guidance_scale.detach().to("cpu", torch.float32).reshape(-1).expand(B))
+        for i, s_ in enumerate(plan):
+            host[3 + i].copy_(torch.from_numpy(np.asarray(s_, dtype=np.float32).reshape(-1)))
+        self.t_np1.copy_(host[0], non_blocking=True)
+        self.t_n.copy_(host[1], non_blocking=True)
+        self.w.copy_(host[2], non_blocking=True)
+        for i in range(len(plan)):
+            self.sig[i].copy_(host[3 + i], non_blocking=True)
+        self.z0.copy_(z_0)
+        self.noise.copy_(noise)
+
+    # -- device side: `_forward_impl` (training branch) + `_student_backward`, on static tensors only
+    def _body(self):
+        m, B, dev = self.m, self.B, self.dev
+        sch = m.noise_scheduler
+        L_ = N.lib()
+        z0, noise, w = self.z0, self.noise, self.w
+        n = z0[0].numel()
+        s_add, s_next1, s_scale2, s_prev2, s_cur2, s_scale3, s_loss = self.sig[:7]
+        embeds_cf, mask_cf, embeds, mask = m.get_prompt_embeds(self.P, m.use_teacher_cf_guidance, 1)
+
+        def scale(x, sg):
+            out = torch.empty_like(x)
+            N.check(L_.ctta_heun_scale_model_input(N.ptr(x), N.ptr(sg), N.ptr(out), B, n, N.stream_ptr()))
+            return out
+        z_noisy = torch.empty_like(z0)
+        N.check(L_.ctta_heun_add_noise(N.ptr(z0), N.ptr(noise), N.ptr(s_add), N.ptr(z_noisy), B, n, N.stream_ptr()))
+        z_gauss = noise * float(sch.init_noise_sigma)
+        t_max = float(sch._timesteps_host.max())
+        z_np1 = torch.where((self.t_np1 == t_max).reshape(-1, 1, 1, 1), z_gauss, z_noisy)
+        z_np1_scaled = scale(z_np1, s_add)
+        side_pred = None
+        two_stream = os.environ.get("CTTA_TWO_STREAM", "1") != "0"
+        if two_stream:
+            cur = torch.cuda.current_stream(dev)
+            side = m._side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                side_pred = m.student_unet.forward_train(z_np1_scaled, self.t_np1, w, embeds, mask)
+        v1 = m._query_teacher(z_np1_scaled, self.t_np1, embeds_cf, mask_cf, w)
+        zhat = torch.empty_like(z0)
+        deriv = torch.empty_like(z0)
+        N.check(L_.ctta_heun_step_first(N.ptr(v1.contiguous()), N.ptr(z_np1), N.ptr(s_add), N.ptr(s_next1), N.ptr(zhat),
+                                        N.ptr(deriv), B, n, N.stream_ptr()))
+        v2 = m._query_teacher(scale(zhat, s_scale2), self.t_n, embeds_cf, mask_cf, w)
+        zhat2 = torch.empty_like(z0)
+        N.check(L_.ctta_heun_step_second(N.ptr(v2.contiguous()), N.ptr(zhat), N.ptr(z_np1), N.ptr(deriv), N.ptr(s_prev2),
+                                         N.ptr(s_cur2), N.ptr(zhat2), B, n, N.stream_ptr()))
+        target = m.student_target_unet(scale(zhat2, s_scale3), self.t_n, guidance=w, encoder_hidden_states=embeds,
+                                       encoder_attention_mask=mask).sample
+        target = torch.where((self.t_n == 0).reshape(-1, 1, 1, 1), z0, target).contiguous()
+        if side_pred is not None:
+            torch.cuda.current_stream(dev).wait_stream(m._side_stream(dev))
+            pred = side_pred
+        else:
+            pred = m.student_unet.forward_train(z_np1_scaled, self.t_np1, w, embeds, mask)
+        gamma = m.snr_gamma or 0.0
+        inst = torch.empty(B, dtype=torch.float32, device=dev)
+        out = torch.empty(1, dtype=torch.float32, device=dev)
+        N.check(L_.ctta_snr_mse_loss(N.ptr(pred.contiguous()), N.ptr(target), N.ptr(s_loss), float(gamma), N.ptr(inst),
+                                     N.ptr(out), B, pred[0].numel(), N.stream_ptr()))
+        m._student_backward(pred, target, s_loss, gamma, 1.0, None)
+        return out
+
+    def capture(self, z_0, time_inds=None, gaussian_noise=None, guidance_scale=None):
+        """One eager pass on a side stream (handles, kernel attributes, allocator pool), then the capture.  Both passes
+        ACCUMULATE into the gradient buffer like any backward; the caller zeroes it (train_step does after its update)."""
+        m = self.m
+        self._refresh(z_0, time_inds, gaussian_noise, guidance_scale)
+        with torch.no_grad():
+            warm = torch.cuda.Stream(device=self.dev)
+            warm.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(warm):
+                self._body()
+            torch.cuda.current_stream(self.dev).wait_stream(warm)
+            torch.cuda.synchronize(self.dev)
+            for net in (m.student_unet, m.student_target_unet):   # their bf16 re-pack belongs to every replay
+                net._h_version = None
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                self.loss = self._body()
+        self.opt.zero_grad()
+        return self
+
+    def step(self, z_0, lr_scheduler=None, time_inds=None, gaussian_noise=None, guidance_scale=None, skip_nan=True):
+        """`AudioLCM.train_step` with accumulation_steps = 1 on one process: refresh the static inputs, ONE replay, then the
+        eager tail (AdamW, LR schedule, zero_grad, EMA).  Returns the loss as a Python float."""
+        m = self.m
+        self._refresh(z_0, time_inds, gaussian_noise, guidance_scale)
+        self.graph.replay()
+        value = float(self.loss.item())
+        if not (skip_nan and value != value):
+            self.opt.step(grad_scale=1.0)
+            if lr_scheduler is not None:
+                lr_scheduler.step()
+        self.opt.zero_grad()
+        m.update_ema()
+        return value
+
+
+def _capture_train_graph(self, optimizer, z_0, prompt, **draws):
+    """hipGraph-captured distillation step (single process, loss_type='mse'): returns a `_DistillStepGraph` whose
+    `.step(z_0, lr_scheduler, ...)` replaces `train_step(z_0, prompt, optimizer, lr_scheduler, ...)` for fixed shapes and a
+    fixed prompt batch (`prompt` must be the dict of pre-computed text states; refresh `graph.P[...]` in place to change them)."""
+    if dist_util.dist.is_initialized() and dist_util.dist.get_world_size() > 1:
+        raise N.CttaError("capture_train_graph is single-process: the data-parallel step overlaps its gradient all-reduce "
+                          "with the backward pass block by block (train_step), which a graph replay cannot do")
+    if not isinstance(prompt, dict):
+        raise N.CttaError("capture_train_graph needs the pre-computed text states (dict), not prompt strings")
+    return _DistillStepGraph(self, optimizer, tuple(z_0.shape), prompt).capture(z_0, **draws)
+
+
+AudioLCM.capture_train_graph = _capture_train_graph
 
 
 class ConsistencyTTA(nn.Module):
