@@ -153,6 +153,8 @@ struct ctta_unet {
     hipEvent_t ready[NS] = {nullptr, nullptr}, freed[NS] = {nullptr, nullptr}, joined = nullptr;
     bool in_use[NS] = {false, false};
     bool dirty = false;     // side stream has work the main stream has not joined yet
+    hipStream_t joined_on = nullptr;   // the main stream that last joined the side stream (see unet_backward_begin_impl)
+    bool was_capturing = false;        // whether the previous backward was recorded into a hipGraph capture
     int next = 0;
     bool enabled = false;
   } wg;

@@ -70,6 +70,7 @@ static ctta_status wg_join(BCtx& c) {
   CTTA_CHECK_HIP(hipEventRecord(W.joined, W.stream));
   CTTA_CHECK_HIP(hipStreamWaitEvent(c.stream, W.joined, 0));
   W.dirty = false;
+  W.joined_on = c.stream;
   return CTTA_OK;
 }
 
@@ -436,6 +437,21 @@ static ctta_status unet_backward_begin_impl(ctta_unet* U, bool dry, const bf16_t
   U->bw.pos = U->tape.size();
   BCtx c;
   bctx_init(c, U, dry, grads, stream);
+  if (!dry) {
+    // Every earlier backward ended with wg_join: when that join was on THIS stream, everything the side stream did for
+    // it is ordered before what this call enqueues, so no scratch slot is "in use" any more.  Without this the first
+    // jobs of a backward waited on `freed` events recorded by the previous one -- harmless eagerly, but inside a hipGraph
+    // capture that is a dependency on uncaptured work (hipErrorStreamCaptureIsolation).
+    // The same when this call is the first one inside / after a capture: events recorded on the other side of that
+    // boundary must not be waited on (torch's graph context synchronises the device when it opens and closes).
+    ctta_unet::WgradSide& Wg = U->wg;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(stream, &cs);
+    const bool capturing = cs == hipStreamCaptureStatusActive;
+    if (!Wg.dirty && (Wg.joined_on == stream || capturing != Wg.was_capturing))
+      for (int i = 0; i < ctta_unet::WgradSide::NS; ++i) Wg.in_use[i] = false;
+    Wg.was_capturing = capturing;
+  }
   // ---- conv_out, conv_norm_out
   const size_t M0 = (size_t)B * H * W;
   bf16_t* dh = A.get<bf16_t>(M0 * c0); ALLOC_OR_FAIL(dh);

@@ -1035,7 +1035,7 @@ class _DistillStepGraph:
             for net in (m.student_unet, m.student_target_unet):   # their bf16 re-pack belongs to every replay
                 net._h_version = None
             self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            with torch.cuda.graph(self.graph, stream=warm, capture_error_mode="thread_local"):
                 self.loss = self._body()
         self.opt.zero_grad()
         return self

@@ -277,9 +277,9 @@ def test_graph_captured_distillation_step_equals_eager_train_step(golden):
     """VERDICT r2 missing #2: the distillation micro-step captured into ONE hipGraph (AudioLCM.capture_train_graph: noising,
     two CFG teacher queries + Heun, target network, student training forward on its side stream and backward with the
     weight-gradient side stream, loss; AdamW / EMA eager behind it) against the eager `train_step`: same draws -> the same
-    loss bit for bit on every step (the loss of step k depends on the parameters after k-1 updates), and the same
-    parameters up to the LayerNorm-atomics round-off.  Three steps with DIFFERENT draws per step: the static timestep /
-    sigma / guidance tensors must really be refreshed before each replay."""
+    loss bit for bit and the same gradient up to the LayerNorm-atomics round-off (1e-7), from identical parameters, for
+    three DIFFERENT draws (the static timestep / sigma / guidance tensors must really be refreshed before each replay;
+    one draw takes the pure-noise branch of the noising step, one has t_n = 0 where the target becomes z_0)."""
     g = golden("distill_tiny")
     gen = torch.Generator().manual_seed(7)
     draws = [dict(time_inds=torch.from_numpy(g["time_inds"]) * 2, gaussian_noise=torch.from_numpy(g["noise"]).to(DEV),
@@ -293,23 +293,41 @@ def test_graph_captured_distillation_step_equals_eager_train_step(golden):
     m1, P, z0 = _lcm()
     m1.train()
     o1 = m1.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)
-    l1 = [m1.train_step(z0, P, o1, None, **kw) for kw in draws]
     m2, _, _ = _lcm()
     m2.train()
     o2 = m2.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)
     gs = m2.capture_train_graph(o2, z0, P, **draws[0])
     assert float(o2.grad.abs().max()) == 0.0 and o2.step_count == 0          # capturing moved nothing
     assert torch.equal(o2.flat, m2.student_unet._flat)
-    l2 = [gs.step(z0, None, **kw) for kw in draws]
-    torch.cuda.synchronize()
-    print("eager losses", l1, "graph losses", l2)
-    assert l1[0] == l2[0]
-    assert all(abs(a - b) <= 1e-6 * abs(a) for a, b in zip(l1, l2))
-    for a, b, name in ((o1.flat, o2.flat, "student"), (m1.student_target_unet._flat, m2.student_target_unet._flat, "target"),
-                       (m1.student_ema_unet._flat, m2.student_ema_unet._flat, "ema")):
-        worst = float((a - b).abs().max() / a.abs().max())
-        print("  %s parameters after 3 steps: max relative difference %.3e" % (name, worst))
-        assert worst <= 5e-6, name
+    nets = ("student_unet", "student_target_unet", "student_ema_unet")
+    for it, kw in enumerate(draws):
+        # same parameters on both sides (one AdamW step amplifies the 1e-8 LayerNorm-atomics noise of a gradient through
+        # its sign-like first update, so free-running copies drift apart chaotically: 2e-6 in the loss after one step,
+        # 4e-4 after two -- measured, eager vs eager behaves the same)
+        for name in nets:
+            getattr(m2, name)._flat.copy_(getattr(m1, name)._flat)
+            getattr(m2, name).mark_weights_changed()
+        with torch.no_grad():
+            loss, pred, target, sig, gamma = m1._forward_impl(z0, None, P, False, True, kw["time_inds"], kw["gaussian_noise"],
+                                                              kw["guidance_scale"], True)
+            m1._student_backward(pred, target, sig, gamma, 1.0, None)
+        gs._refresh(z0, kw["time_inds"], kw["gaussian_noise"], kw["guidance_scale"])
+        gs.graph.replay()
+        torch.cuda.synchronize()
+        l_e, l_g = float(loss), float(gs.loss.item())
+        rel = float((o1.grad - o2.grad).norm() / o1.grad.norm())
+        print("draw %d: eager loss %.9g graph loss %.9g, gradient rel diff %.2e" % (it, l_e, l_g, rel))
+        assert l_e == l_g and np.isfinite(l_e)
+        assert float(o1.grad.norm()) > 0 and rel <= 1e-7
+        for o, m in ((o1, m1), (o2, m2)):      # the eager tail of the step, identically on both sides
+            o.step(grad_scale=1.0)
+            o.zero_grad()
+            m.update_ema()
+    # the public entry points end to end: one more step each from (nearly) equal states
+    v1 = m1.train_step(z0, P, o1, None, **draws[0])
+    v2 = gs.step(z0, None, **draws[0])
+    assert np.isfinite(v1) and abs(v1 - v2) <= 1e-3 * abs(v1) and o2.step_count == o1.step_count == 4
+    assert float(o2.grad.abs().max()) == 0.0
     with pytest.raises(N.CttaError, match="pre-computed text states"):
         m2.capture_train_graph(o2, z0, ["a", "b", "c"])
 
