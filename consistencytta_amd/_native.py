@@ -90,6 +90,7 @@ SIGNATURES = {
     "ctta_unet_create": (c_int, [POINTER(UNetConfig), POINTER(Tensor), c_int, c_void_p, POINTER(c_void_p)]),
     "ctta_unet_destroy": (None, [c_void_p]),
     "ctta_unet_load_weights": (c_int, [c_void_p, POINTER(Tensor), c_int, c_void_p]),
+    "ctta_unet_reuse_text": (c_int, [c_void_p, c_int]),
     "ctta_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ctta_attention_lse": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                    c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),

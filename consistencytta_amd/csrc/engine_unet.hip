@@ -77,6 +77,7 @@ struct Transformer {
   GNLayer norm;
   PackedW proj_in, qk1, v1, out1, q2, k2, v2, out2, ff1, ff2, proj_out;
   LNLayer ln1, ln2, ln3;
+  bf16_t *k2c = nullptr, *vt2c = nullptr;   // persistent cross-attention K / V^T of the text states (text cache)
   LinTrain t_proj_in, t_q1, t_k1, t_v1, t_out1, t_q2, t_k2, t_v2, t_out2, t_ff1, t_ff2, t_proj_out;
   struct Saved {
     const bf16_t *x = nullptr, *g = nullptr, *s0 = nullptr, *n1 = nullptr, *qk = nullptr, *vt = nullptr, *att1 = nullptr,
@@ -128,6 +129,13 @@ struct ctta_unet {
   size_t gn_scratch_floats = 0;
   size_t gn_fpart_floats = 0;   // fused-statistics partials, stored behind the gn_scratch_floats of scratch
   SplitWs splitws;   // this handle's split-K workspace (bound per entry point)
+  // Text cache: the cross-attention K / V^T projections of the text states (32 small GEMMs per forward) live in
+  // persistent buffers; a caller that queries the same handle again with the SAME text states and mask (the second CFG
+  // teacher query of a distillation step, every query of the Heun teacher loop) says so with ctta_unet_reuse_text and
+  // the forward skips them.  Invalidated by ctta_unet_load_weights.
+  char* tc_base = nullptr;
+  bool tc_valid = false, tc_reuse_next = false;
+  int tc_B = 0, tc_L = 0;
   // ---- training state (cfg.enable_training)
   ConvTrain t_conv_in, t_conv_out;
   std::vector<TapeOp> tape;
@@ -169,6 +177,7 @@ struct ctta_unet {
 
 struct UCtx : RunCtx {
   ctta_unet* U;
+  bool reuse_text = false;
   int B, L, Lp;
   const float* temb_all;
   const bf16_t* enc_bf;
@@ -355,10 +364,16 @@ static ctta_status run_transformer(UCtx& c, Transformer& T, const bf16_t* x, int
   bf16_t* const n2 = n;
   bf16_t* q2 = A.get<bf16_t>(M * hp); ALLOC_OR_FAIL(q2);
   CTTA_TRY(run_linear(c, T.q2, n, cp, M, q2, hp, nullptr, 0));
-  bf16_t* k2 = A.get<bf16_t>((size_t)c.B * c.Lp * hp); ALLOC_OR_FAIL(k2);
-  CTTA_TRY(run_linear(c, T.k2, c.enc_bf, c.U->xp, (int64_t)c.B * c.Lp, k2, hp, nullptr, 0));
-  bf16_t* vt2 = A.get<bf16_t>((size_t)c.B * hp * c.Lp); ALLOC_OR_FAIL(vt2);
-  CTTA_TRY(run_vt(c, T.v2, c.enc_bf, c.B, c.Lp, c.Lp, vt2, c.Lp));
+  bf16_t* k2 = T.k2c;
+  bf16_t* vt2 = T.vt2c;
+  if (!k2 || c.dry) {   // sizing pass / no text cache: arena buffers
+    k2 = A.get<bf16_t>((size_t)c.B * c.Lp * hp); ALLOC_OR_FAIL(k2);
+    vt2 = A.get<bf16_t>((size_t)c.B * hp * c.Lp); ALLOC_OR_FAIL(vt2);
+  }
+  if (!c.reuse_text) {
+    CTTA_TRY(run_linear(c, T.k2, c.enc_bf, c.U->xp, (int64_t)c.B * c.Lp, k2, hp, nullptr, 0));
+    CTTA_TRY(run_vt(c, T.v2, c.enc_bf, c.B, c.Lp, c.Lp, vt2, c.Lp));
+  }
   CTTA_TRY(run_attention(c, q2, hp, k2, hp, c.Lp, vt2, c.Lp, c.mask_bias, att, hp, T.heads, N, c.L, T.dh, &T.sv.lse2));
   bf16_t* s2 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s2);
   CTTA_TRY(run_linear(c, T.out2, att, hp, M, s2, cp, s1, cp));
@@ -411,6 +426,8 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   if (U->gn_scratch && gn_fuse_enabled()) { c.gn_fpart = U->gn_scratch + U->gn_scratch_floats; c.gn_fpart_floats = U->gn_fpart_floats; }
   c.gn_groups = cfg.norm_num_groups;
   c.U = U; c.B = B; c.L = L; c.Lp = round_up(L, 8);
+  c.reuse_text = !dry && !train && U->tc_reuse_next && U->tc_valid && U->tc_base && U->tc_B == B && U->tc_L == L;
+  U->tc_reuse_next = false;
   Arena& A = U->arena;
   A.reset();
   A.no_release = cfg.debug_taps != 0 || train;   // the backward pass reads every intermediate
@@ -467,9 +484,11 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   if (mask) { mbias = A.get<float>((size_t)B * L); ALLOC_OR_FAIL(mbias); }
   if (!dry) {
     const long long total = (long long)B * c.Lp * U->xp;
-    hipLaunchKernelGGL(pack_enc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, enc, enc_bf, B,
-                       L, cfg.cross_attention_dim, c.Lp, U->xp);
-    CTTA_LAUNCH_CHECK();
+    if (!c.reuse_text) {   // only the K / V^T projections read the packed text states
+      hipLaunchKernelGGL(pack_enc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, enc, enc_bf, B,
+                         L, cfg.cross_attention_dim, c.Lp, U->xp);
+      CTTA_LAUNCH_CHECK();
+    }
     if (mask) {
       hipLaunchKernelGGL(mask_bias_kernel, dim3((B * L + 255) / 256), dim3(256), 0, stream, mask, mbias, B * L);
       CTTA_LAUNCH_CHECK();
@@ -594,6 +613,7 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
     U->ts.valid = !dry;
   }
   if (gn_need) *gn_need = c.gn_need;
+  if (!dry && U->tc_base) { U->tc_valid = true; U->tc_B = B; U->tc_L = L; }
   return CTTA_OK;
 }
 
@@ -809,6 +829,25 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
       if (st == CTTA_OK) st = U->splitws.init();
     }
   }
+  if (st == CTTA_OK) {   // text cache: K [B][Lp][hp] + V^T [B][hp][Lp] per transformer block
+    std::vector<Transformer*> ts;
+    for (Level& Lv : U->down) for (Transformer& T : Lv.att) ts.push_back(&T);
+    ts.push_back(&U->mid_att);
+    for (Level& Lv : U->up) for (Transformer& T : Lv.att) ts.push_back(&T);
+    const size_t lp = (size_t)round_up(cfg->max_text_len, 8);
+    size_t total = 0;
+    for (Transformer* T : ts) total += 2 * (((size_t)cfg->max_batch * lp * T->hp * sizeof(bf16_t) + 255) & ~(size_t)255);
+    if (hipMalloc((void**)&U->tc_base, total + 256) != hipSuccess) {
+      U->tc_base = nullptr;   // no cache: the forward falls back to arena buffers (sized by the dry run either way)
+    } else {
+      char* q = U->tc_base;
+      for (Transformer* T : ts) {
+        const size_t one = ((size_t)cfg->max_batch * lp * T->hp * sizeof(bf16_t) + 255) & ~(size_t)255;
+        T->k2c = reinterpret_cast<bf16_t*>(q); q += one;
+        T->vt2c = reinterpret_cast<bf16_t*>(q); q += one;
+      }
+    }
+  }
   if (st == CTTA_OK && hipStreamSynchronize(s) != hipSuccess) { ctta_set_error("unet_create: stream sync failed"); st = CTTA_ERR_HIP; }
   if (st != CTTA_OK) { ctta_unet_destroy(U); return st; }
   *out = U;
@@ -820,6 +859,7 @@ extern "C" void ctta_unet_destroy(ctta_unet* U) {
   U->store.destroy();
   if (U->arena.base) (void)hipFree(U->arena.base);
   if (U->gn_scratch) (void)hipFree(U->gn_scratch);
+  if (U->tc_base) (void)hipFree(U->tc_base);
   U->splitws.destroy();
   if (U->wg.stream) { (void)hipStreamSynchronize(U->wg.stream); (void)hipStreamDestroy(U->wg.stream); }
   for (int i = 0; i < ctta_unet::WgradSide::NS; ++i) {
@@ -835,7 +875,14 @@ extern "C" ctta_status ctta_unet_load_weights(ctta_unet* U, const ctta_tensor* w
   CTTA_REQUIRE(U && weights, "unet_load_weights: null pointer");
   WeightTable wt;
   wt.build(weights, n_weights);
+  U->tc_valid = false;   // the cached K / V^T were projected with the old weights
   return U->store.run_all(wt, (hipStream_t)stream);
+}
+
+extern "C" ctta_status ctta_unet_reuse_text(ctta_unet* U, int reuse) {
+  CTTA_REQUIRE(U, "unet_reuse_text: null handle");
+  U->tc_reuse_next = reuse != 0;
+  return CTTA_OK;
 }
 
 extern "C" ctta_status ctta_unet_forward(ctta_unet* U, const float* sample, const float* timesteps,

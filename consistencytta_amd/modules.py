@@ -316,7 +316,24 @@ class _UNetBase(_ParamTree):
             v = v[None]
         return v.expand(B).contiguous()
 
-    def _forward(self, sample, timestep, guidance, encoder_hidden_states, encoder_attention_mask, train=False):
+    def _text_unchanged(self, enc, mask, B, reuse_text):
+        """Whether this forward may take the cross-attention K / V projections of the text states from the handle's text
+        cache (ctta_unet_reuse_text): the SAME tensor objects as in the previous forward on this module, unmodified since
+        (identity + version counters; the module keeps a reference, so the storage cannot have been recycled).  Inside a
+        hipGraph capture only on the caller's explicit word (`reuse_text=True`): a replay cannot re-decide."""
+        key = (enc, enc._version, mask, None if mask is None else mask._version, B)
+        prev = getattr(self, "_text_key", None)
+        same = (prev is not None and prev[0] is key[0] and prev[1] == key[1] and prev[2] is key[2] and prev[3] == key[3]
+                and prev[4] == key[4])
+        self._text_key = key
+        if reuse_text is False or not same:
+            return False
+        if reuse_text is True:
+            return True
+        return not torch.cuda.is_current_stream_capturing()
+
+    def _forward(self, sample, timestep, guidance, encoder_hidden_states, encoder_attention_mask, train=False,
+                 reuse_text=None):
         if sample.ndim != 4 or sample.shape[1] != self._cfg["in_channels"]:
             raise ValueError("sample must be (batch, %d, height, width), got %s"
                              % (self._cfg["in_channels"], tuple(sample.shape)))
@@ -330,7 +347,10 @@ class _UNetBase(_ParamTree):
         dev = self.device
         if not sample.is_cuda:
             raise N.CttaError("sample is on %s: the HIP engine has no CPU path" % sample.device)
+        had_handle, ver0 = self._h_unet is not None, self._h_version
         self._ensure(B, H, W, L)
+        reuse = self._text_unchanged(encoder_hidden_states, encoder_attention_mask, B, reuse_text)
+        reuse = reuse and not train and had_handle and ver0 == self._h_version       # same handle, same packed weights
         x = sample.detach().to(device=dev, dtype=torch.float32).contiguous()
         enc = encoder_hidden_states.detach().to(device=dev, dtype=torch.float32).contiguous()
         t = self._per_sample(timestep, B, dev, torch.float32)  # get_timestep_embedding casts to fp32
@@ -341,6 +361,8 @@ class _UNetBase(_ParamTree):
         out = torch.empty((B, self._cfg["out_channels"], H, W), dtype=torch.float32, device=dev)
         fn = N.lib().ctta_unet_forward_train if train else N.lib().ctta_unet_forward
         with torch.cuda.device(dev):
+            if reuse:
+                N.check(N.lib().ctta_unet_reuse_text(self._h_unet, 1))
             N.check(fn(self._h_unet, N.ptr(x), N.ptr(t), N.ptr(g), N.ptr(enc), N.ptr(m), B, L, N.ptr(out),
                        N.stream_ptr()))
         return out
@@ -447,7 +469,8 @@ class UNet2DConditionGuidedModel(_UNetBase):
                         ("mid_block_additional_residual", mid_block_additional_residual)):
             if v is not None:
                 raise NotImplementedError("%s is not used on the ConsistencyTTA path and is not supported" % name)
-        out = self._forward(sample, timestep, guidance, encoder_hidden_states, encoder_attention_mask)
+        out = self._forward(sample, timestep, guidance, encoder_hidden_states, encoder_attention_mask,
+                            reuse_text=kwargs.get("reuse_text"))
         return UNet2DConditionOutput(sample=out) if return_dict else (out,)
 
 
@@ -460,7 +483,8 @@ class UNet2DConditionModel(_UNetBase):
                 attention_mask=None, cross_attention_kwargs=None, added_cond_kwargs=None,
                 down_block_additional_residuals=None, mid_block_additional_residual=None,
                 encoder_attention_mask=None, return_dict=True, **kwargs):
-        out = self._forward(sample, timestep, None, encoder_hidden_states, encoder_attention_mask)
+        out = self._forward(sample, timestep, None, encoder_hidden_states, encoder_attention_mask,
+                            reuse_text=kwargs.get("reuse_text"))
         return UNet2DConditionOutput(sample=out) if return_dict else (out,)
 
 

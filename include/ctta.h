@@ -79,6 +79,13 @@ ctta_status ctta_unet_load_weights(ctta_unet* h, const ctta_tensor* weights, int
                                    void* stream);
 /* sample (B,C,H,W) f32; timesteps (B) f32; guidance (B) f64 or NULL when !guided;
  * enc (B,L,X) f32; mask (B,L) u8 (1 = keep) or NULL; out (B,Cout,H,W) f32. */
+/* One-shot hint for the NEXT ctta_unet_forward / _forward_train on this handle: reuse != 0 promises that its
+ * encoder_hidden_states and encoder_attention_mask (and batch / text_len) are those of the previous forward on the handle,
+ * so the cross-attention K / V projections of the text states (attention_processor.py:1107-1111: `to_k` / `to_v` of
+ * encoder_hidden_states, 32 small GEMMs per forward) are taken from the handle's text cache instead of recomputed -- the
+ * second CFG teacher query of a distillation step, every query of a Heun teacher loop.  Ignored when nothing valid is cached
+ * (first forward, other batch / length, after ctta_unet_load_weights).  Results are bit-identical either way. */
+ctta_status ctta_unet_reuse_text(ctta_unet* h, int reuse);
 ctta_status ctta_unet_forward(ctta_unet* h, const float* sample, const float* timesteps,
                               const double* guidance, const float* enc, const uint8_t* mask,
                               int batch, int text_len, float* out, void* stream);

@@ -539,6 +539,57 @@ def test_unet_forward_is_bit_identical_whatever_the_batch_mates(guided):
         L_.ctta_set_gn_fuse(1)
 
 
+def test_text_cache_reuses_cross_attention_kv_only_for_unchanged_text_states():
+    """ctta_unet_reuse_text (round 3): a second query with the SAME text-state tensors skips the 2 x (number of transformer
+    blocks) K / V projection GEMMs and is bit-identical to a cold module; an in-place change of the text states, a new
+    tensor object, other weights or a capture without the caller's word all recompute."""
+    import ctypes
+    from consistencytta_amd import _native as N_
+    cfg = cases.TINY_UNET
+    sd = cases.unet_weights(cfg, False, 1)
+    net = _load(modules.UNet2DConditionModel.from_config(cfg), sd)
+    cold = _load(modules.UNet2DConditionModel.from_config(cfg), sd)
+    B, L = 4, 6
+    P = cases.prompt_states(cfg, B, L, "tcache")
+    enc, mask = P["embeds"].to(DEV).contiguous(), P["mask"].to(DEV)
+    z = [(cases.t(spec.det_uniform("tcache.z%d" % i, (B, 8, 32, 8), 14 + i)) * 0.9).to(DEV) for i in range(3)]
+    t = [torch.tensor([3.0, 400.0, 77.0, 950.0], device=DEV) + i for i in range(3)]
+    L_ = N_.lib()
+
+    def launches(fn):
+        L_.ctta_prof_enable(1)
+        out = fn()
+        torch.cuda.synchronize()
+        L_.ctta_prof_enable(0)
+        ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        N_.check(L_.ctta_prof_collect(0, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt), None))
+        return out, cnt.value
+
+    def q(m, i, e=enc, **kw):
+        with torch.no_grad():
+            return m(z[i], t[i], e, encoder_attention_mask=mask, **kw).sample.clone()
+    o0, n0 = launches(lambda: q(net, 0))
+    o1, n1 = launches(lambda: q(net, 1))                       # same tensors: K / V from the cache
+    n_blocks = sum(1 for k in sd if k.endswith("attn2.to_k.weight"))
+    assert n_blocks >= 3 and n0 - n1 == 2 * n_blocks, (n0, n1, n_blocks)
+    assert torch.equal(o1, q(cold, 1, e=enc.clone()))
+    _, n1f = launches(lambda: q(net, 1, reuse_text=False))    # the caller can always refuse
+    assert n1f == n0
+    enc.mul_(1.25)                                             # in-place change: version counter moved -> recompute
+    o2, n2 = launches(lambda: q(net, 2))
+    assert n2 == n0 and torch.equal(o2, q(cold, 2, e=enc.clone()))
+    o2b, n2b = launches(lambda: q(net, 2, e=enc.clone()))      # equal content, other object -> recompute (and same numbers)
+    assert n2b == n0 and torch.equal(o2b, o2)
+    new_sd = {k: (v * 1.01 if k.endswith("attn2.to_k.weight") else v) for k, v in sd.items()}
+    net.load_state_dict(new_sd)
+    net.to(DEV)
+    e3 = enc.clone()
+    q(net, 0, e=e3)
+    cold2 = _load(modules.UNet2DConditionModel.from_config(cfg), new_sd)
+    o3, n3 = launches(lambda: q(net, 1, e=e3))
+    assert n3 == n1 and torch.equal(o3, q(cold2, 1, e=e3.clone()))     # new weights were re-projected once, then reused
+
+
 def test_vocoder_input_gradient_predicts_the_finite_difference_along_itself():
     """a finite-difference check of the vocoder's input gradient that does not depend on the reference's
     activation signs.  f(mel) = <vocode(mel), w> is piecewise linear; along d = g / |g| (g = the engine's gradient) the
