@@ -714,12 +714,114 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __res
   }
 }
 
+// Round 3: the transformer widths of the U-Net (ld = 256 / 512 / 1024) in one kernel.  GL lanes share a row (32 / 64 / 64),
+// VPL vectors of 8 channels per lane (1 / 1 / 2); a lane group walks RPG consecutive rows with the loads of ALL of them
+// issued before the first reduction (round 2's kernels had 4 rows, or ONE row per wave at ld = 1024: 1.1 TB/s on the
+// 17 MB level-2 tensor, a quarter of the launches' time was the launch itself); gamma / beta of the lane's columns sit in
+// registers; the row sums fold on the VALU -- DPP row rotations inside 16 lanes, v_permlane16/32_swap across them --
+// instead of ten ds_bpermute round trips per row.  Same two-pass variance as before.
+__device__ __forceinline__ float dpp_row_sum(float v) {   // total of the 16 lanes of a DPP row, in every lane
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+template <int GL>
+__device__ __forceinline__ float group_sum(float v) {
+  v = dpp_row_sum(v);
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  if constexpr (GL == 64) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  return v;
+}
+template <int GL, int VPL, int RPG>
+__global__ __launch_bounds__(256) void layernorm_fast_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                             long long rows, int d, int ld,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float eps) {
+  constexpr int GPB = 256 / GL;                       // lane groups per block
+  const int sub = threadIdx.x % GL, grp = threadIdx.x / GL;
+  float g[VPL][8], bt[VPL][8];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = (sub + i * GL) * 8 + e;
+      g[i][e] = c < d ? gamma[c] : 0.f;
+      bt[i][e] = c < d ? beta[c] : 0.f;
+    }
+  const long long row0 = ((long long)blockIdx.x * GPB + grp) * RPG;
+  uint4 raw[RPG][VPL];
+#pragma unroll
+  for (int r = 0; r < RPG; ++r)
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      raw[r][i] = make_uint4(0, 0, 0, 0);
+      if (row0 + r < rows) raw[r][i] = *reinterpret_cast<const uint4*>(x + (size_t)(row0 + r) * ld + (sub + i * GL) * 8);
+    }
+  const float inv_d = 1.0f / (float)d;
+#pragma unroll
+  for (int r = 0; r < RPG; ++r) {
+    float f[VPL][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      unpack8(raw[r][i], f[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        if ((sub + i * GL) * 8 + e >= d) f[i][e] = 0.f;
+        s += f[i][e];
+      }
+    }
+    const float mean = group_sum<GL>(s) * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if ((sub + i * GL) * 8 + e < d) { const float t = f[i][e] - mean; q += t * t; }
+    const float rstd = rsqrtf(group_sum<GL>(q) * inv_d + eps);
+    if (row0 + r < rows) {
+#pragma unroll
+      for (int i = 0; i < VPL; ++i) {
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = (sub + i * GL) * 8 + e < d ? (f[i][e] - mean) * rstd * g[i][e] + bt[i][e] : 0.f;
+        *reinterpret_cast<uint4*>(y + (size_t)(row0 + r) * ld + (sub + i * GL) * 8) = pack8(o8);
+      }
+    }
+  }
+}
+
 extern "C" ctta_status ctta_layernorm(const void* x, void* y, int64_t rows, int d, int ld,
                                       const float* gamma, const float* beta, float eps, void* stream) {
   CTTA_REQUIRE(x && y && gamma && beta, "layernorm: null pointer");
   CTTA_REQUIRE(ld % 8 == 0 && d <= ld && d > 0 && ld <= 2048, "layernorm: d=%d ld=%d unsupported", d, ld);
   const dim3 grid((unsigned)cdiv64(rows, 4));
   hipStream_t s = (hipStream_t)stream;
+  static int fast = -1;   // CTTA_LN_FAST=0: round 2's kernels (A/B switch)
+  if (fast < 0) { const char* e = getenv("CTTA_LN_FAST"); fast = (e && e[0] == '0') ? 0 : 1; }
+  if (fast && (ld == 256 || ld == 512 || ld == 1024)) {
+    if (ld == 256)
+      hipLaunchKernelGGL((layernorm_fast_kernel<32, 1, 8>), dim3((unsigned)cdiv64(rows, 8 * 8)), dim3(256), 0, s, (const bf16_t*)x,
+                         (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
+    else if (ld == 512)
+      hipLaunchKernelGGL((layernorm_fast_kernel<64, 1, 8>), dim3((unsigned)cdiv64(rows, 4 * 8)), dim3(256), 0, s, (const bf16_t*)x,
+                         (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
+    else
+      hipLaunchKernelGGL((layernorm_fast_kernel<64, 2, 4>), dim3((unsigned)cdiv64(rows, 4 * 4)), dim3(256), 0, s, (const bf16_t*)x,
+                         (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
+    CTTA_LAUNCH_CHECK();
+    return CTTA_OK;
+  }
   if (ld <= 256) {
     hipLaunchKernelGGL(layernorm_rows_kernel<32>, dim3((unsigned)cdiv64(rows, 32)), dim3(256), 0, s, (const bf16_t*)x,
                        (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);

@@ -468,7 +468,8 @@ def test_groupnorm(B, C, H, W, G, silu, eps):
     assert rel_err(from_nhwc(y), ref) < BF16_TOL
 
 
-@pytest.mark.parametrize("rows,d,ld", [(37, 39, 64), (64, 255, 256), (16, 1020, 1024), (5, 1275, 1280)])
+@pytest.mark.parametrize("rows,d,ld", [(37, 39, 64), (64, 255, 256), (16, 1020, 1024), (5, 1275, 1280), (131, 255, 256),
+                                        (70, 510, 512), (9, 1020, 1024), (33, 512, 512)])
 def test_layernorm(rows, d, ld):
     x = torch.zeros(rows, ld)
     x[:, :d] = bf16_round(det("ln.x", (rows, d), 1) * 3 + 0.5)
