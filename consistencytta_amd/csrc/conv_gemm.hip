@@ -300,9 +300,18 @@ static bool glds_default() {
 // direct-to-LDS twins.  kBigTile (256x256x64, 8 waves of 128x64) is chosen separately: it halves the
 // L1->LDS bytes per FLOP, which is what bounds the 128-wide tiles (64 B/clk/CU vs 512 MFMA-cycles).
 static const int kBigTile = 29;
+static bool tile_rules_r3() {   // CTTA_TILE_RULES=2: round 2's tile choice (A/B switch for the round-3 rules)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_TILE_RULES"); v = (e && e[0] == '2') ? 0 : 1; }
+  return v != 0;
+}
 static bool want_big_tile(long long M, int N, long long K, int groups) {
   const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * groups;
-  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= 512 && t256 >= 192;   // (K >= 512 since the straight-line epilogue, profiles/sweep_r02*.json)
+  // one workgroup per CU: 288 tiles (the distillation teacher's batch 18 at level 0) are two rounds of the 256 CUs with the
+  // second one 12 % full -- 659-741 TFLOP/s against 828-910 on the thin-grid tile (profiles/sweep_r03.txt, t18 rows)
+  const long long rounds = (t256 + 255) / 256;
+  const bool fills = !tile_rules_r3() || t256 >= 1024 || t256 * 10 >= rounds * 256 * 7;
+  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= 512 && t256 >= 192 && fills;   // (K >= 512 since the straight-line epilogue, profiles/sweep_r02*.json)
 }
 static int pick_variant(long long M, int N, long long K, int groups) {
   if (N <= 32) {                                           // 256x32; few row tiles (the per-sample cross-attention
@@ -312,10 +321,13 @@ static int pick_variant(long long M, int N, long long K, int groups) {
   if (N <= 64) return K >= 512 ? 8 : 5;                    // 128x64 / 64x64
   const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * groups;
   if (t128 < 200) return 5;                                // too few 128x128 tiles to fill 256 CUs
-  // the batch-32 level-2 linears (M = 8192, N = 1024..2560, K = 1024 / 1280): 128x128x64 at 736-824 TFLOP/s against 588-682
-  // on the thin-grid tile below (profiles/sweep_r03.txt); batch-9 shapes (t128 < 400) keep the thin-grid rule
-  if (t128 >= 400 && K >= 1024 && K < 4096 && N >= 1024 && M <= 16384) return 1;
+  // 128x128x64 when its tiles fill the CUs about evenly (two resident workgroups per CU: 512 slots).  The batch-32 level-2
+  // linears (M = 8192, t128 = 512: 736-824 vs 588-682 TFLOP/s on the thin-grid tile) and the Heun teacher's batch 16 at
+  // level 1 (t128 = 512: 1024 vs 740, 1109 vs 786, 928 vs 665) take it; batch 18 (t128 = 576 = 2.25 tiles per slot pair)
+  // and batch 9 (288) do NOT: 723 vs 866, 665 vs 768 -- profiles/sweep_r03.txt, u32 / t16 / t18 rows.
+  if (tile_rules_r3() && t128 >= 400 && t128 < 1024 && K >= 512 && t128 * 100 >= ((t128 + 511) / 512) * 512 * 85) return 1;
   if (t128 < 1024 && (K < 4096 || t128 < 400 || N <= 512)) return 6;                    // thin grids (distillation micro-batch): 64x128x64 doubles the workgroups
+  if (tile_rules_r3() && t128 < 1536 && K >= 1024 && N <= 512) return 6;      // batch 18 at level 0 (M = 73728, N = 256: 1152 tiles): 828-910 vs 730 on 128x128x32
   if (K >= 4096) return N >= 256 ? 1 : 6;                  // 128x128x64 / 64x128x64
   if (K > 1536) return M >= 400000 ? 6 : 2;                // 64x128x64 / 128x128x32
   return N >= 256 ? 2 : 6;                                 // 128x128x32 / 64x128x64 (re-swept with the wide-store epilogue)
@@ -422,13 +434,15 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       // keeps its accumulators in registers); the direct epilogue only exists in the <= 8-fragment tiles (64x128x64)
       // (round 3, after the GELU rewrite: 256x128x32 with 8 waves of 64x64 wins from K = 512 up and on the batch-9 / 16
       // shapes -- 796 vs 727, 919 vs 795, 625 vs 591 TFLOP/s, profiles/sweep_r03.txt; the K = 256 batch-32 launch stays)
-      if (geglu) vid = !p.wide_store ? 6 : ((K >= 512 || M < 100000) && fast_ok(32) && glds_default()) ? 28 : 2;
+      if (geglu) vid = !p.wide_store ? 6 : (tile_rules_r3() && (K >= 512 || M < 100000) && fast_ok(32) && glds_default()) ? 28 : 2;
       // deep and narrow (few 128x128 tiles, long K): the 128x128 tile with split-K beats small tiles that only
       // exist to create workgroups (measured: M=1152, N=1024, K=9216 at 176 TFLOP/s on 64x64 tiles)
       const long long t128 = ((M + 127) / 128) * ((d->n + 127) / 128);
       if (splitk_default() && groups == 1 && K >= 4096 && d->n >= 256 && t128 < 192 && !scalar_store && !geglu &&
           d->out_limit == 0 && d->out_offset == 0)
-        vid = 1;
+        // M = 1024 / 1152 (teacher batches, level 3): 64x128x64 + split-K 502-523 vs 414-450 TFLOP/s on 128x128x64;
+        // M = 576 (batch 9, level 3): 128x64x64 346 vs 295
+        vid = !tile_rules_r3() ? 1 : M <= 640 ? 8 : M <= 1280 ? 6 : 1;
       if (!d->in_act && glds_default() && vid <= 8) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
       // 64 < N <= 128 with enough rows: the 256x128x32 tile (8 waves of 64x64) stages 25 % fewer bytes per FLOP than
       // 128x128 / 64x128 and, with the wide-store epilogue, wins from K = 384 up (sweep: +12..22 %)

@@ -60,6 +60,37 @@ SHAPES = [
     ("u32 M8192 1024>2560", 32, 256, 1, 1024, 2560, 1, 1, 1),
     ("u32 conv 64x4 1024>1024", 32, 64, 4, 1024, 1024, 3, 3, 1),
     ("u32 conv 32x2 1024>1024", 32, 32, 2, 1024, 1024, 3, 3, 1),
+    # the Heun teacher's batch (8 clips x 2 CFG halves = 16): SWEEP_FILTER=t16
+    ("t16 conv 128x8 512>512", 16, 128, 8, 512, 512, 3, 3, 1),
+    ("t16 conv 128x8 1024>512", 16, 128, 8, 1024, 512, 3, 3, 1),
+    ("t16 conv 64x4 1024>1024", 16, 64, 4, 1024, 1024, 3, 3, 1),
+    ("t16 conv 64x4 2048>1024", 16, 64, 4, 2048, 1024, 3, 3, 1),
+    ("t16 conv 32x2 1024>1024", 16, 32, 2, 1024, 1024, 3, 3, 1),
+    ("t16 lin M16384 512>512", 16, 1024, 1, 512, 512, 1, 1, 1),
+    ("t16 lin M16384 2048>512", 16, 1024, 1, 2048, 512, 1, 1, 1),
+    ("t16 lin M16384 640>512", 16, 1024, 1, 640, 512, 1, 1, 1),
+    ("t16 lin M4096 1024>1024", 16, 256, 1, 1024, 1024, 1, 1, 1),
+    ("t16 lin M4096 4096>1024", 16, 256, 1, 4096, 1024, 1, 1, 1),
+    ("t16 lin M4096 1280>1024", 16, 256, 1, 1280, 1024, 1, 1, 1),
+    ("t16 lin M4096 1024>2560", 16, 256, 1, 1024, 2560, 1, 1, 1),
+    # the distillation teacher's batch (9 latents x 2 CFG halves = 18): SWEEP_FILTER=t18
+    ("t18 conv 256x16 256>256", 18, 256, 16, 256, 256, 3, 3, 1),
+    ("t18 conv 256x16 512>256", 18, 256, 16, 512, 256, 3, 3, 1),
+    ("t18 conv 128x8 512>512", 18, 128, 8, 512, 512, 3, 3, 1),
+    ("t18 conv 128x8 1024>512", 18, 128, 8, 1024, 512, 3, 3, 1),
+    ("t18 conv 64x4 1024>1024", 18, 64, 4, 1024, 1024, 3, 3, 1),
+    ("t18 conv 32x2 1024>1024", 18, 32, 2, 1024, 1024, 3, 3, 1),
+    ("t18 lin M73728 256>256", 18, 4096, 1, 256, 256, 1, 1, 1),
+    ("t18 lin M73728 256>640", 18, 4096, 1, 256, 640, 1, 1, 1),
+    ("t18 lin M73728 1024>256", 18, 4096, 1, 1024, 256, 1, 1, 1),
+    ("t18 lin M73728 320>256", 18, 4096, 1, 320, 256, 1, 1, 1),
+    ("t18 lin M18432 512>512", 18, 1024, 1, 512, 512, 1, 1, 1),
+    ("t18 lin M18432 2048>512", 18, 1024, 1, 2048, 512, 1, 1, 1),
+    ("t18 lin M4608 1024>1024", 18, 256, 1, 1024, 1024, 1, 1, 1),
+    ("t18 lin M4608 4096>1024", 18, 256, 1, 4096, 1024, 1, 1, 1),
+    ("t9 conv 32x2 1024>1024", 9, 32, 2, 1024, 1024, 3, 3, 1),
+    ("t9 conv 64x4 2048>1024", 9, 64, 4, 2048, 1024, 3, 3, 1),
+    ("t9 conv 256x16 512>256", 9, 256, 16, 512, 256, 3, 3, 1),
     # fused GEGLU (SWEEP_GEGLU=1 SWEEP_FILTER=ff1): N counts value + gate columns
     ("ff1 M131072 256>2048", 32, 4096, 1, 256, 2048, 1, 1, 1),
     ("ff1 M32768 512>4096", 32, 1024, 1, 512, 4096, 1, 1, 1),
