@@ -234,6 +234,8 @@ static const Variant kVariants[] = {
     VARIANT(256, 128, 32, 2, 2, 2, 2),  // 32
     VARIANT(256, 256, 32, 2, 4, 2, 3),  // 33  deeper rings for the big tile (96 / 128 KB)
     VARIANT(256, 256, 32, 2, 4, 2, 4),  // 34
+    VARIANT(512, 128, 32, 4, 2, 2, 2),  // 35  N = 128 layers: 8 waves of 128x64 (the big tile's wave shape) over 512 rows
+    VARIANT(512, 128, 64, 4, 2, 2, 2),  // 36  ... with BK = 64: the whole 160 KB of LDS
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -309,8 +311,12 @@ static bool want_big_tile(long long M, int N, long long K, int groups) {
   const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * groups;
   // one workgroup per CU: 288 tiles (the distillation teacher's batch 18 at level 0) are two rounds of the 256 CUs with the
   // second one 12 % full -- 659-741 TFLOP/s against 828-910 on the thin-grid tile (profiles/sweep_r03.txt, t18 rows)
-  const long long rounds = (t256 + 255) / 256;
-  const bool fills = !tile_rules_r3() || t256 >= 1024 || t256 * 10 >= rounds * 256 * 7;
+  // (a ragged last row tile that alone opens a round is cut off into its own small launch: judge the rest)
+  long long tq = t256;
+  const long long t_cut = (M / 256) * ((N + 255) / 256) * groups;
+  if (M % 256 != 0 && groups == 1 && t_cut >= 1 && (t_cut + 255) / 256 < (t256 + 255) / 256) tq = t_cut;
+  const long long rounds = (tq + 255) / 256;
+  const bool fills = !tile_rules_r3() || tq >= 1024 || tq * 10 >= rounds * 256 * 7;
   return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= 512 && t256 >= 192 && fills;   // (K >= 512 since the straight-line epilogue, profiles/sweep_r02*.json)
 }
 static int pick_variant(long long M, int N, long long K, int groups) {
@@ -448,8 +454,12 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       // 128x128 / 64x128 and, with the wide-store epilogue, wins from K = 384 up (sweep: +12..22 %)
       const long long t28 = ((M + 255) / 256) * groups;
       if (!geglu && !d->in_act && glds_default() && d->n > 64 && d->n <= 128 && K >= 384 && t28 >= 512 && fast_ok(32) &&
-          vid != 1 + 16)
+          vid != 1 + 16) {
         vid = 28;
+        // ... and from K = 1024 up with >= 2 rounds of 512-row tiles: 512x128x64 (8 waves of 128x64 = the big tile's wave
+        // shape, all 160 KB of LDS): 978 vs 937-959 (K = 1152), 1074 vs 961 (K = 2304), 895 vs 806 (k = 11 conv1d) TFLOP/s
+        if (tile_rules_r3() && K >= 1024 && (M + 511) / 512 * groups >= 512 && fast_ok(64)) vid = 36;
+      }
     }
   }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");

@@ -889,6 +889,9 @@ ctta_status prepare_variant() {
   X(128, 128, 32, 2, 2, 2, 2) \
   X(256, 64, 64, 4, 1, 2, 2) \
   X(256, 128, 64, 4, 2, 2, 2)
+#define CTTA_CONV_VARIANTS_7(X) \
+  X(512, 128, 32, 4, 2, 2, 2) \
+  X(512, 128, 64, 4, 2, 2, 2)
 #define CTTA_CONV_VARIANTS_6(X) \
   X(256, 32, 64, 4, 1, 2, 2) \
   X(64, 64, 64, 2, 2, 2, 2) \
@@ -898,7 +901,7 @@ ctta_status prepare_variant() {
   X(128, 128, 32, 2, 2, 2, 3) \
   X(64, 128, 64, 2, 2, 2, 3) \
   X(256, 128, 32, 4, 2, 2, 2)
-#define CTTA_CONV_VARIANTS_ALL(X) CTTA_CONV_VARIANTS_1(X) CTTA_CONV_VARIANTS_2(X) CTTA_CONV_VARIANTS_3(X) CTTA_CONV_VARIANTS_4(X) CTTA_CONV_VARIANTS_5(X) CTTA_CONV_VARIANTS_6(X)
+#define CTTA_CONV_VARIANTS_ALL(X) CTTA_CONV_VARIANTS_1(X) CTTA_CONV_VARIANTS_2(X) CTTA_CONV_VARIANTS_3(X) CTTA_CONV_VARIANTS_4(X) CTTA_CONV_VARIANTS_5(X) CTTA_CONV_VARIANTS_6(X) CTTA_CONV_VARIANTS_7(X)
 #define CTTA_CONV_INSTANTIATE(BM, BN, BK, WM, WN, G, S)                                      \
   template void launch_variant<BM, BN, BK, WM, WN, G, S>(const ConvParams&, dim3, hipStream_t); \
   template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S>();

@@ -65,7 +65,7 @@ def _conv_case(B, Cin, H, W, Cout, k, stride, pad, tile=0, upsample=False, c_spl
     return rel_err(from_nhwc(out), ref)
 
 
-@pytest.mark.parametrize("tile", list(range(0, 33)))
+@pytest.mark.parametrize("tile", list(range(0, 37)))
 def test_conv3x3_all_tiles(tile):
     assert _conv_case(2, 64, 24, 16, 96, 3, 1, 1, tile=tile, tag="t%d" % tile) < BF16_TOL
 
@@ -245,7 +245,7 @@ def test_fused_resblock_unit(C, k, d, L, B):
 @pytest.mark.parametrize("with_res", [True, False])
 @pytest.mark.parametrize("B,C,H,W,Cout,tile", [(2, 64, 16, 16, 128, 0), (3, 128, 32, 8, 256, 0), (4, 256, 64, 64, 512, 0),
                                                (1, 64, 64, 64, 128, 0), (2, 64, 16, 16, 128, 17), (2, 128, 16, 16, 256, 29),
-                                               (2, 128, 64, 16, 1024, 29), (2, 64, 64, 32, 128, 28)])
+                                               (2, 128, 64, 16, 1024, 29), (2, 64, 64, 32, 128, 28), (2, 64, 64, 32, 128, 36)])
 def test_groupnorm_statistics_from_the_conv_epilogue(B, C, H, W, Cout, tile, with_res):
     """ctta_conv_desc.gn_part: the convolution's wide-store epilogue writes per-tile (sum, sum of squares) of its OUTPUT per
     channel group; ctta_groupnorm_from_partials then normalises without its own statistics pass.  Must agree with the
@@ -836,7 +836,7 @@ def test_fp32_mlp_kernel_is_exact_beside_a_concurrent_conv_gemm():
     assert worst <= 2e-4
 
 
-@pytest.mark.parametrize("tile", [0, 17, 18, 21, 22, 24, 28, 29, 32])
+@pytest.mark.parametrize("tile", [0, 17, 18, 21, 22, 24, 28, 29, 32, 35, 36])
 @pytest.mark.parametrize("mode", ["bias", "res", "res_out2", "acc", "res_acc_lrelu", "rowvec_res"])
 def test_straight_line_epilogue_classes(tile, mode):
     """Every class of the straight-line wide-store epilogue (wide_epilogue_fast<RES, OUT2, ACC>: bias / per-sample row vector /
