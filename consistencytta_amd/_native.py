@@ -196,6 +196,9 @@ SIGNATURES = {
     "ctta_frag_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_resunit_conv1d": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_float, c_void_p, c_int, c_float, c_float, c_void_p]),
+    "ctta_reschain_supported": (c_int, [c_int, c_int, c_void_p]),
+    "ctta_reschain_conv1d": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                     c_float, c_void_p, c_int, c_float, c_float, c_void_p]),
     "ctta_conv_small_n": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "ctta_pack_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_nchw_f32_to_nhwc_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),

@@ -870,6 +870,7 @@ struct HResBlock {
   bf16_t* f1[3] = {nullptr, nullptr, nullptr};   // fragment-major copies of c1 / c2 for the fused unit kernel (resunit.hip)
   bf16_t* f2[3] = {nullptr, nullptr, nullptr};
   bool fused = false;
+  bool chained = false;                      // all three units in one launch (ctta_reschain_conv1d)
   Conv1d d1[3], d2[3];                       // enable_grad: data-gradient operands
   const bf16_t* sv_xt[3] = {nullptr, nullptr, nullptr};    // leaky_relu(convs1[m](.)) of the differentiable forward
   const bf16_t* sv_ract[3] = {nullptr, nullptr, nullptr};  // leaky_relu of the residual stream entering unit m
@@ -1063,6 +1064,17 @@ static ctta_status hifigan_forward_impl(ctta_hifigan* G, bool dry, const float* 
       HResBlock& R = G->res[i * nk + j];
       const bf16_t* r = y;       // residual stream (raw)
       const bf16_t* ract = ya;   // leaky_relu(r, 0.1)
+      if (R.chained && !grad) {  // one launch per ResBlock: residual stream and intermediates stay in LDS across the 3 units
+        const bool fin = j == nk - 1;
+        const int dils[3] = {R.c1[0].dil, R.c1[1].dil, R.c1[2].dil};
+        const void* w1[3] = {R.f1[0], R.f1[1], R.f1[2]};
+        const void* w2[3] = {R.f2[0], R.f2[1], R.f2[2]};
+        const float* b1[3] = {R.c1[0].p.bias, R.c1[1].p.bias, R.c1[2].p.bias};
+        const float* b2[3] = {R.c2[0].p.bias, R.c2[1].p.bias, R.c2[2].p.bias};
+        RUN(c, ctta_reschain_conv1d(y, B, len, ch, R.c1[0].k, dils, w1, b1, w2, b2, 0.1f, xs, j > 0 ? 1 : 0,
+                                    fin ? 1.0f / (float)nk : 1.0f, fin ? (last_stage ? 0.01f : 0.1f) : 0.f, c.stream));
+        continue;
+      }
       if (R.fused && !grad) {    // one launch per unit: x -> x + conv2(lrelu(conv1(lrelu(x)))), intermediate kept in LDS
         for (int mth = 0; mth < 3; ++mth) {
           const bool last = mth == 2, fin = j == nk - 1;
@@ -1224,6 +1236,13 @@ static ctta_status hifigan_build(ctta_hifigan* G) {
       // its weights fragment-major; the copies are re-derived from the packed operands after every (re)load
       R.fused = !grad;
       for (int m = 0; m < 3; ++m) R.fused = R.fused && ctta_resunit_supported(ch, k, cfg.resblock_dilations[j][m]) != 0;
+      // the chained form (one launch per ResBlock) is correct and tested, but measured SLOWER than three unit launches
+      // once those lost their serialised staging loads (round 3, B = 32: C = 32 k = 3 0.76 vs 0.63 ms, k = 7 1.34 vs 0.81 ms:
+      // the recomputed halo and two workgroups per CU cost more than the two saved HBM round trips): opt-in only
+      {
+        const char* e = getenv("CTTA_RES_CHAIN");
+        R.chained = e && e[0] == '1' && R.fused && ctta_reschain_supported(ch, k, cfg.resblock_dilations[j]) != 0;
+      }
       if (R.fused) {
         for (int m = 0; m < 3; ++m) {
           R.f1[m] = ws.arena.get<bf16_t>((size_t)ch * k * ch);

@@ -367,6 +367,15 @@ ctta_status ctta_frag_pack(const void* packed, int n, int k_pad, int k_valid, vo
 ctta_status ctta_resunit_conv1d(const void* x, int batch, int len, int channels, int k, int dil,
                                 const void* w1_frag, const float* b1, const void* w2_frag, const float* b2,
                                 float slope, void* out, int accumulate, float alpha, float out_slope, void* stream);
+/* The three units of one ResBlock chained in ONE launch (C = 32 / 64, k in {3, 5, 7}): x_{u+1} = x_u + unit_u(x_u) with the
+ * residual stream kept in LDS between units (rounded to bf16 after every unit, as ctta_resunit_conv1d stores it), the last
+ * unit finished by the same epilogue as ctta_resunit_conv1d.  Bit-identical to three ctta_resunit_conv1d calls.
+ * dils / w1_frag / b1 / w2_frag / b2: HOST arrays of three entries (device pointers inside).  out must not alias x. */
+int ctta_reschain_supported(int channels, int k, const int* dils);
+ctta_status ctta_reschain_conv1d(const void* x, int batch, int len, int channels, int k, const int* dils,
+                                 const void* const* w1_frag, const float* const* b1, const void* const* w2_frag,
+                                 const float* const* b2, float slope, void* out, int accumulate, float alpha,
+                                 float out_slope, void* stream);
 
 /* Direct convolution for tiny Cout (<= 8): bf16 NHWC in, fp32 weights [n][kh][kw][c],
  * fp32 planar (NCHW) out, optional input leaky-relu and output tanh. */

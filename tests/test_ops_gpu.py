@@ -242,6 +242,71 @@ def test_fused_resblock_unit(C, k, d, L, B):
                                        N.ptr(b2d), 0.1, N.ptr(out), 0, 1.0, 0.0, N.stream_ptr()))
 
 
+@pytest.mark.parametrize("C,k,dils,L,B", [(64, 3, (1, 3, 5), 1000, 2), (64, 7, (1, 3, 5), 513, 2), (64, 7, (1, 3, 5), 128, 1),
+                                          (64, 3, (1, 3, 5), 20, 3), (32, 3, (1, 3, 5), 1500, 2), (32, 7, (1, 3, 5), 1025, 1),
+                                          (32, 7, (1, 3, 5), 256, 2), (32, 5, (2, 1, 4), 700, 1), (64, 5, (1, 1, 1), 129, 2),
+                                          (32, 7, (1, 3, 5), 30, 1)])
+def test_chained_resblock(C, k, dils, L, B):
+    """hifigan/models.py:42-63, one whole ResBlock (three units, dilations `dils`) as ONE launch (resunit.hip:
+    reschain_kernel): the residual stream stays in LDS between units.  Must be BIT-identical to three
+    ctta_resunit_conv1d launches (same MFMA order, same bf16 rounding of the stream after every unit) -- plain, and with
+    the stage-fold epilogue -- and agree with F.conv1d on bf16-rounded operands; sequences shorter than, equal to and
+    ragged against the tile and its 12..36-row halo."""
+    L_ = lib()
+    dil_arr = (ctypes.c_int * 3)(*dils)
+    assert L_.ctta_reschain_supported(C, k, dil_arr) == 1
+    x = bf16_round(det("rc.x", (B, C, L), 1))
+    old = bf16_round(det("rc.o", (B, C, L), 6))
+    xa = x.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    units, ref = [], x
+    for u, d in enumerate(dils):
+        w1 = bf16_round(det("rc.w1.%d" % u, (C, C, k), 2) * (1.0 / math.sqrt(C * k)))
+        w2 = bf16_round(det("rc.w2.%d" % u, (C, C, k), 3) * (1.0 / math.sqrt(C * k)))
+        b1, b2 = det("rc.b1.%d" % u, (C,), 4) * 0.1, det("rc.b2.%d" % u, (C,), 5) * 0.1
+        mid = bf16_round(F.leaky_relu(F.conv1d(F.leaky_relu(ref, 0.1), w1, b1, dilation=d, padding=(k * d - d) // 2), 0.1))
+        ref = ref + F.conv1d(mid, w2, b2, padding=(k - 1) // 2)
+        if u < 2:
+            ref = bf16_round(ref)
+        fr = []
+        for w in (w1, w2):
+            wp, k_pad = pack_conv_weight(w[:, :, None, :])
+            f = torch.empty(C * k * C, dtype=torch.bfloat16, device=DEV)
+            N.check(L_.ctta_frag_pack(N.ptr(wp), C, k_pad, k * C, N.ptr(f), N.stream_ptr()))
+            fr.append(f)
+        units.append((fr[0], b1.to(DEV), fr[1], b2.to(DEV)))
+    vp = lambda ts: (ctypes.c_void_p * 3)(*[N.ptr(t) for t in ts])
+    args = (dil_arr, vp([u[0] for u in units]), vp([u[1] for u in units]), vp([u[2] for u in units]), vp([u[3] for u in units]))
+
+    def three_launches(dst, accumulate, alpha, out_slope):
+        cur = xa
+        for u, d in enumerate(dils):
+            last = u == 2
+            nxt = dst if last else torch.empty_like(xa)
+            N.check(L_.ctta_resunit_conv1d(N.ptr(cur), B, L, C, k, d, N.ptr(units[u][0]), N.ptr(units[u][1]),
+                                           N.ptr(units[u][2]), N.ptr(units[u][3]), 0.1, N.ptr(nxt), accumulate if last else 0,
+                                           alpha if last else 1.0, out_slope if last else 0.0, N.stream_ptr()))
+            cur = nxt
+        sync()
+        return dst
+
+    out = torch.empty_like(xa)
+    N.check(L_.ctta_reschain_conv1d(N.ptr(xa), B, L, C, k, *args, 0.1, N.ptr(out), 0, 1.0, 0.0, N.stream_ptr()))
+    sync()
+    assert rel_err(out.float().permute(0, 2, 1).cpu(), ref) < 3 * BF16_TOL
+    assert torch.equal(out, three_launches(torch.empty_like(xa), 0, 1.0, 0.0))
+    # stage fold: (old + block) / 3 then leaky_relu(0.1), accumulated in place
+    o1 = old.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    o2 = o1.clone()
+    N.check(L_.ctta_reschain_conv1d(N.ptr(xa), B, L, C, k, *args, 0.1, N.ptr(o1), 1, 1.0 / 3.0, 0.1, N.stream_ptr()))
+    sync()
+    assert torch.equal(o1, three_launches(o2, 1, 1.0 / 3.0, 0.1))
+    assert rel_err(o1.float().permute(0, 2, 1).cpu(), F.leaky_relu((old + ref) / 3.0, 0.1)) < 3 * BF16_TOL
+    # outside the kernel's range: refused loudly
+    assert L_.ctta_reschain_supported(128, 3, dil_arr) == 0 and L_.ctta_reschain_supported(64, 11, dil_arr) == 0
+    with pytest.raises(RuntimeError):
+        N.check(L_.ctta_reschain_conv1d(N.ptr(xa), B, L, C, k, *args, 0.1, N.ptr(xa), 0, 1.0, 0.0, N.stream_ptr()))
+
+
 @pytest.mark.parametrize("with_res", [True, False])
 @pytest.mark.parametrize("B,C,H,W,Cout,tile", [(2, 64, 16, 16, 128, 0), (3, 128, 32, 8, 256, 0), (4, 256, 64, 64, 512, 0),
                                                (1, 64, 64, 64, 128, 0), (2, 64, 16, 16, 128, 17), (2, 128, 16, 16, 256, 29),
