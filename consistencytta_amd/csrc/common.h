@@ -77,6 +77,7 @@ __device__ __forceinline__ float wave_max(float v) {
 void ctta_set_error(const char* fmt, ...);
 bool ctta_prof_active();
 bool ctta_gn_fuse_on();
+unsigned long long* ctta_debug_stamps_current();   // ctta_conv_debug_stamps' buffer of this host thread (or null)
 void ctta_prof_begin(int kind, int variant, long long m, long long n, long long k, long long groups, hipStream_t s);
 void ctta_prof_end(hipStream_t s);
 

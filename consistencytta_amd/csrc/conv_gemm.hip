@@ -271,6 +271,7 @@ static bool wide_store_default() {
 }
 static thread_local unsigned long long* t_stamps = nullptr;
 extern "C" void ctta_conv_debug_stamps(void* buf) { t_stamps = (unsigned long long*)buf; }
+unsigned long long* ctta_debug_stamps_current() { return t_stamps; }
 static thread_local int t_no_splitk = 0;
 extern "C" void ctta_conv_suppress_splitk(int on) { t_no_splitk = on ? 1 : 0; }
 static bool splitk_default() {

@@ -60,6 +60,17 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
   const int b = blockIdx.y, l0 = blockIdx.x * T;
   const int L = p.L, k = KT ? KT : p.k, dil = p.dil;
   const float slope = p.slope;
+  // diagnostic (ctta_conv_debug_stamps, tools/resunit_timeline.py): 8 words per workgroup {hw id, entry, tile staged, conv1
+  // done, intermediate written, conv2 done, last store issued}
+  unsigned long long* stamp = nullptr;
+  if (p.epi.stamps) {
+    stamp = p.epi.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    if (tid == 0) {
+      stamp[0] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |
+                 ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32);
+      stamp[1] = __builtin_amdgcn_s_memtime();
+    }
+  }
   const int H1 = dil * (k - 1) / 2, H2 = (k - 1) / 2;
   const int MT = T + 2 * H2;                 // rows of the intermediate (conv1 outputs) this tile needs
   // conv1 runs WP * MBW blocks of 16 rows -- T/16 + WP >= ceil(MT / 16) -- whatever k is: a part that would own fewer live
@@ -105,6 +116,8 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
     }
   }
 
+  if (stamp && tid == 0) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp[2] = __builtin_amdgcn_s_memtime(); }
+
   // ---- 2. conv1: rows [mb0*16, (mb0 + MBW)*16) of the intermediate, couts [cout0, cout0 + 16*NCB)
   const int cb0 = wc * NCB;
   const int mb0 = wp * MBW;
@@ -148,6 +161,7 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
       }
     }
   }
+  if (stamp && tid == 0) stamp[3] = __builtin_amdgcn_s_memtime();
   __syncthreads();   // every wave is done with the input tile: the intermediate takes its place
   {
 #pragma unroll
@@ -174,6 +188,8 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
       }
     }
   }
+
+  if (stamp && tid == 0) stamp[4] = __builtin_amdgcn_s_memtime();
 
   // ---- 3. conv2 over the T output positions: rows [ob0*16, (ob0 + OB)*16), taps = consecutive intermediate rows
   const int ob0 = wp * OB;
@@ -214,6 +230,13 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
     }
   }
 
+  if (stamp && tid == 0) stamp[5] = __builtin_amdgcn_s_memtime();
+
+  // (Round 3 also tried the epilogue straight from the accumulators -- 8-byte stores, 64-byte runs of 16 consecutive rows,
+  // no LDS pass, no barriers, the residual requested before conv2: within +-3 % of this one at C = 32 and 4-13 % slower at
+  // C = 64, where the extra live registers spill.  With every load and store disabled a C = 32, k = 3 launch still takes
+  // 125 of its 232 us: the kernel's own VALU work -- unpack / leaky_relu / pack of the staged tile, the two fused
+  // epilogues -- and the HBM time (89 us at 8 TB/s) add up rather than overlap at three workgroups per CU.)
   // ---- epilogue: two position blocks per part at a time through an fp32 LDS transpose; a row of C channels is then
   //      finished (bias, residual, accumulate, scale, LeakyReLU) and stored by C/4 consecutive lanes.
   // Straight-line code (4 passes x 4 row sweeps), buffer descriptors bounded to this sample's L rows (rows past the
@@ -286,6 +309,7 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
       __builtin_amdgcn_raw_buffer_store_b64(pk, rso, voff, rel(pass, sw) * C * 2, 0);
     }
   }
+  if (stamp && tid == 0) stamp[6] = __builtin_amdgcn_s_memtime();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -661,6 +685,7 @@ extern "C" ctta_status ctta_resunit_conv1d(const void* x, int batch, int len, in
   e.accumulate = accumulate ? 1 : 0; e.alpha = alpha;
   if (out_slope > 0.f) { e.out_act = 3; e.out_slope = out_slope; }
   e.howo = len; e.n = channels; e.M = batch * len;
+  e.stamps = ctta_debug_stamps_current();
   hipStream_t s = (hipStream_t)stream;
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, 40, (long long)batch * len, channels, 2LL * k * channels, 1, s);
