@@ -196,6 +196,9 @@ SIGNATURES = {
     "ctta_frag_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_resunit_conv1d": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_float, c_void_p, c_int, c_float, c_float, c_void_p]),
+    "ctta_logmel_to_image": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ctta_avgpool2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ctta_cnn14_head": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_reschain_supported": (c_int, [c_int, c_int, c_void_p]),
     "ctta_reschain_conv1d": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                      c_float, c_void_p, c_int, c_float, c_float, c_void_p]),

@@ -499,6 +499,64 @@ def clap_param_spec(audio_cfg=HTSAT_BASE_CONFIG, text_cfg=ROBERTA_BASE_CONFIG, j
     return sd
 
 
+# ---------------------------------------------------------------------------------------------- evaluation classifier
+# PANNs Cnn14 as audioldm_eval/eval.py:68-82 builds it for 16 kHz / 32 kHz audio
+CNN14_16K_CONFIG = dict(sample_rate=16000, n_fft=512, hop=160, mel_bins=64, fmin=50, fmax=8000, classes_num=527,
+                        widths=[64, 128, 256, 512, 1024, 2048])
+CNN14_32K_CONFIG = dict(sample_rate=32000, n_fft=1024, hop=320, mel_bins=64, fmin=50, fmax=14000, classes_num=527,
+                        widths=[64, 128, 256, 512, 1024, 2048])
+
+
+def cnn14_param_spec(cfg=CNN14_16K_CONFIG):
+    """State-dict keys / shapes of `Cnn14` (audioldm_eval/feature_extractors/panns/models.py:168-234) in the module's own
+    registration order, floating-point entries only (num_batches_tracked is structural).  torchlibrosa's frozen STFT / mel
+    matrices are listed too so that the released `Cnn14_16k_mAP=0.438.pth` loads; the engine derives them itself."""
+    sd = OrderedDict()
+    n_fft, F = cfg["n_fft"], cfg["n_fft"] // 2 + 1
+    sd["spectrogram_extractor.stft.conv_real.weight"] = (F, 1, n_fft)
+    sd["spectrogram_extractor.stft.conv_imag.weight"] = (F, 1, n_fft)
+    sd["logmel_extractor.melW"] = (F, cfg["mel_bins"])
+    for k in ("weight", "bias", "running_mean", "running_var"):
+        sd["bn0." + k] = (cfg["mel_bins"],)
+    cin = 1
+    for i, c in enumerate(cfg["widths"]):
+        p = "conv_block%d." % (i + 1)
+        sd[p + "conv1.weight"] = (c, cin, 3, 3)
+        sd[p + "conv2.weight"] = (c, c, 3, 3)
+        for bn in ("bn1.", "bn2."):
+            for k in ("weight", "bias", "running_mean", "running_var"):
+                sd[p + bn + k] = (c,)
+        cin = c
+    sd["fc1.weight"] = (cin, cin)
+    sd["fc1.bias"] = (cin,)
+    sd["fc_audioset.weight"] = (cfg["classes_num"], cin)
+    sd["fc_audioset.bias"] = (cfg["classes_num"],)
+    return sd
+
+
+CNN14_STRUCTURAL = ("spectrogram_extractor.stft.conv_real.weight", "spectrogram_extractor.stft.conv_imag.weight",
+                    "logmel_extractor.melW")
+
+
+def cnn14_det_weight(name, shape, seed=0):
+    """Deterministic Cnn14 test weights (no checkpoint exists offline): positive BatchNorm variances, BatchNorm gains around
+    1 (bn0: 0.1, which brings the dB-scaled log-mel back to O(1)), He-scaled convolutions so that twelve ReLU layers keep
+    their activations O(1)."""
+    shape = tuple(shape)
+    u = det_uniform(name, shape, seed)
+    leaf = name.rsplit(".", 1)[-1]
+    if leaf == "running_var":
+        return (1.0 + 0.5 * np.abs(u)).astype(np.float32)
+    if name.endswith("bn0.weight"):
+        return (0.1 + 0.02 * u).astype(np.float32)
+    if ".bn" in name and leaf == "weight":
+        return (1.0 + 0.2 * u).astype(np.float32)
+    if len(shape) == 1:
+        return (0.05 * u).astype(np.float32)
+    fan_in = int(np.prod(shape[1:]))
+    return (np.sqrt(6.0 / fan_in) * u).astype(np.float32)
+
+
 def clap_det_weight(name, shape, seed=0):
     """Deterministic CLAP test weights: det_weight with the few distribution tweaks the tower needs to stay well
     conditioned at random init (positive BatchNorm variances, O(1) relative-position biases, a bn0 gain that brings the

@@ -566,6 +566,19 @@ ctta_status ctta_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, vo
 ctta_status ctta_mean_tokens(const void* x, int batch, int tokens, int channels, int ld, float* y, void* stream);
 ctta_status ctta_mean_tokens_bwd(const float* dy, int batch, int tokens, int channels, int ld, void* dx, void* stream);
 
+/* Evaluation-suite classifier glue (PANNs Cnn14, audioldm_eval/feature_extractors/panns/models.py:168-323; the twelve 3x3
+ * convolutions run on ctta_conv_gemm with BatchNorm folded in, the front end on ctta_wav_to_logmel_db):
+ *   ctta_logmel_to_image  bn0 in eval mode (models.py:276-278: scale / shift per mel bin) of logmel fp32 [batch][frames][mel_bins]
+ *                         -> image bf16 [batch][frames][mel_bins][8], channel 0 live;
+ *   ctta_avgpool2         F.avg_pool2d(2) (models.py:71-72) on NHWC bf16 [batch][hi][wi][c] -> [batch][hi/2][wi/2][c], c % 8 == 0,
+ *                         a trailing odd row / column dropped as torch does;
+ *   ctta_cnn14_head       mean over frequency, then max over time + mean over time (models.py:305-309):
+ *                         bf16 [batch][frames][freq][c] -> fp32 [batch][c]. */
+ctta_status ctta_logmel_to_image(const float* logmel, int batch, int frames, int mel_bins, const float* scale,
+                                 const float* shift, void* image, void* stream);
+ctta_status ctta_avgpool2(const void* x, void* y, int batch, int hi, int wi, int c, void* stream);
+ctta_status ctta_cnn14_head(const void* x, int batch, int frames, int freq, int c, float* y, void* stream);
+
 /* Small fp32 linear: y[m][n] = act_out(sum_k act_in(x[m][k]) * w[n][k] + b[n]); m <= 1024.
  * act: 0 none, 1 silu. */
 ctta_status ctta_linear_f32(const float* x, const float* w, const float* b, float* y, int m,

@@ -154,3 +154,42 @@ def clap_weights(keys, shapes, tag, seed):
 
 TINY_HTSAT = dict(spec.HTSAT_BASE_CONFIG, spec_size=64, embed_dim=64, depths=[2, 2, 2, 2], num_heads=[2, 4, 8, 16],
                   num_classes=11)
+
+
+# ------------------------------------------------------------------------------------------------ evaluation suite
+def cnn14_weights(keys, shapes, seed=3):
+    """Deterministic Cnn14 weights over the reference module's own state-dict keys (stored in eval_suite.npz as data)."""
+    return {str(k): t(spec.cnn14_det_weight("cnn14." + str(k), tuple(int(d) for d in str(s).split(",")), seed))
+            for k, s in zip(keys, shapes)}
+
+
+def eval_waves(tag, B, L, sr=16000):
+    """Seeded test audio: band-limited noise plus two sines per clip, amplitude about 0.3."""
+    t = np.arange(L, dtype=np.float64) / sr
+    out = []
+    for b in range(B):
+        n = spec.det_uniform("%s.noise.%d" % (tag, b), (L,), 11).astype(np.float64)
+        n = np.convolve(n, np.ones(8) / 8.0, mode="same")
+        w = 0.25 * n + 0.15 * np.sin(2 * np.pi * (220.0 * (b + 1)) * t) + 0.1 * np.sin(2 * np.pi * (1330.0 + 517.0 * b) * t + 0.3)
+        out.append(w)
+    return torch.from_numpy(np.stack(out).astype(np.float32))
+
+
+def eval_metric_inputs():
+    """Seeded feature matrices, the same on both sides (tests rebuild them from spec.det_uniform)."""
+    u = lambda name, shape: spec.det_uniform("evalsuite." + name, shape, 21).astype(np.float64)
+    mix = u("fid.mix", (48, 48)) * 0.3 + np.eye(48)
+    fid1 = (u("fid.1", (200, 48)) * 1.7) @ mix + 0.2
+    fid2 = (u("fid.2", (180, 48)) * 1.4) @ mix.T - 0.1
+    isc = u("isc", (203, 527)) * 4.0
+    kid1 = np.maximum(u("kid.1", (120, 64)) * 2.0 + 0.5, 0.0)
+    kid2 = np.maximum(u("kid.2", (100, 64)) * 1.5 + 0.8, 0.0)
+    kl1, kl2 = u("kl.1", (50, 527)) * 3.0, u("kl.2", (50, 527)) * 3.0
+    f32 = lambda a: torch.from_numpy(a.astype(np.float32))
+    return dict(fid1=f32(fid1), fid2=f32(fid2), isc=f32(isc), kid1=f32(kid1), kid2=f32(kid2), kl1=f32(kl1), kl2=f32(kl2))
+
+
+def eval_kl_names(n):
+    names = ["clip_%03d.wav" % i for i in range(n)]
+    perm = np.random.RandomState(5).permutation(n)
+    return names, perm

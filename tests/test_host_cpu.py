@@ -415,3 +415,51 @@ def test_device_code_has_no_swizzled_packed_fp32():
     hits, n_insn, n_obj = mod.scan(os.path.join(root, "consistencytta_amd", "libctta_hip.so"))
     assert n_obj >= 10 and n_insn > 100000, "the scan did not find the device code (%d objects, %d instructions)" % (n_obj, n_insn)
     assert not hits, hits[:5]
+
+
+def test_eval_metrics_match_the_reference_functions(golden):
+    """consistencytta_amd.audioldm_eval.calculate_{fid,isc,kid,kl} (host arithmetic, as in the reference) against the values
+    the reference's own audioldm_eval/metrics/*.py returned on the same seeded features (tests/golden/make_golden_eval.py):
+    same dictionary keys, same random streams, KL pairing by base name whatever the directory order."""
+    from consistencytta_amd import audioldm_eval as E
+    g = golden("eval_suite")
+    X = cases.eval_metric_inputs()
+    fd = lambda f: {"f": f}
+    assert E.calculate_fid(fd(X["fid1"]), fd(X["fid2"]), "f") == {"frechet_distance": pytest.approx(float(g["fid"]), rel=1e-9)}
+    r = E.calculate_isc(fd(X["isc"]), "f", rng_seed=2020, samples_shuffle=True, splits=10)
+    assert [r["inception_score_mean"], r["inception_score_std"]] == pytest.approx(list(g["isc"]), rel=1e-12)
+    r = E.calculate_kid(fd(X["kid1"]), fd(X["kid2"]), subsets=100, subset_size=90, degree=3, gamma=None, coef0=1, rng_seed=2020,
+                        feat_layer_name="f")
+    assert [r["kernel_inception_distance_mean"], r["kernel_inception_distance_std"]] == pytest.approx(list(g["kid"]), rel=1e-12)
+    names, perm = cases.eval_kl_names(50)
+    d1 = {"f": X["kl1"], "file_path_": ["/gen/" + n for n in names]}
+    d2 = {"f": X["kl2"][perm], "file_path_": ["/gt/" + names[i] for i in perm]}
+    r, kl_ref, paths = E.calculate_kl(d1, d2, "f", True)
+    assert [r["kullback_leibler_divergence_sigmoid"], r["kullback_leibler_divergence_softmax"]] == pytest.approx(list(g["kl"]), rel=1e-6)
+    np.testing.assert_allclose(kl_ref.numpy(), g["kl_ref"], rtol=1e-5)
+    assert paths == names
+    r, a, b = E.calculate_kl(d1, d2, "f", same_name=False)      # unpaired directories: the reference reports -1
+    assert r == {"kullback_leibler_divergence_sigmoid": -1.0, "kullback_leibler_divergence_softmax": -1.0} and a is None
+    # subset larger than a set: clipped with a warning, like the reference
+    r = E.calculate_kid(fd(X["kid1"]), fd(X["kid2"]), subsets=3, subset_size=1000, degree=3, gamma=None, coef0=1, rng_seed=1,
+                        feat_layer_name="f")
+    assert np.isfinite(r["kernel_inception_distance_mean"])
+
+
+def test_eval_wav_reader(tmp_path):
+    """datasets/load_mel.py:17-29 with scipy.io.wavfile: int16 scaling, stereo mix-down, integer-ratio decimation by striding,
+    mean removal, the 2 s zero padding; a non-integer rate ratio (resampy in the reference) is refused."""
+    from scipy.io import wavfile
+    from consistencytta_amd import audioldm_eval as E
+    rng = np.random.RandomState(0)
+    x = (rng.rand(48000, 2) * 2 - 1) * 0.5
+    wavfile.write(str(tmp_path / "a.wav"), 48000, (x * 32767).astype(np.int16))
+    got = E.read_centered_wav(str(tmp_path / "a.wav"), 16000)
+    mono = ((x * 32767).astype(np.int16).astype(np.float64) / 32768.0).mean(1)[::3]
+    np.testing.assert_allclose(got, mono - mono.mean(), atol=1e-12)
+    wavfile.write(str(tmp_path / "b.wav"), 22050, (x[:, 0] * 32767).astype(np.int16))
+    with pytest.raises(RuntimeError):
+        E.read_centered_wav(str(tmp_path / "b.wav"), 16000)
+    ds = E.WaveDataset(str(tmp_path), sr=48000, target_length=50)
+    w, name = ds[0]
+    assert name == "a.wav" and tuple(w.shape) == (1, 32000) and float(w[0, 24000:].abs().max()) == 0.0

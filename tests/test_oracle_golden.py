@@ -356,3 +356,34 @@ def test_kaiser_sinc_resampler_known_answers():
     back = oclap.resample(y, 48000, 16000, **kw)
     assert back.shape == x.shape and float((back[0, 300:-300] - x[0, 300:-300]).abs().max()) < 3e-3
     assert oclap.resample(torch.zeros(2, 333), 16000, 48000, **kw).shape == (2, 999)
+
+
+# ------------------------------------------------------------------------------------------------ evaluation suite
+def test_eval_suite_oracle_matches_reference(golden):
+    """oracle/evalsuite.py against tests/golden/eval_suite.npz, which the reference's own `Cnn14.forward`
+    (audioldm_eval/feature_extractors/panns/models.py:269-323) and its own metric functions
+    (audioldm_eval/metrics/{fid,isc,kid,kl}.py) produced (tests/golden/make_golden_eval.py)."""
+    from oracle import evalsuite as oe
+    g = golden("eval_suite")
+    cfg = spec.CNN14_16K_CONFIG
+    # the build's parameter table reproduces the reference module's key list (order and shapes included)
+    mine = [k for k in spec.cnn14_param_spec(cfg) if k not in spec.CNN14_STRUCTURAL]
+    assert mine == [str(k) for k in g["cnn14_keys"]]
+    assert [",".join(str(d) for d in spec.cnn14_param_spec(cfg)[k]) for k in mine] == [str(s) for s in g["cnn14_shapes"]]
+    sd = cases.cnn14_weights(g["cnn14_keys"], g["cnn14_shapes"])
+    for tag, B, L in (("short", 2, 32000), ("clip", 1, 160000)):
+        taps = {}
+        with torch.no_grad():
+            out = oe.cnn14_forward(cfg, sd, cases.eval_waves("evalsuite." + tag, B, L), taps)
+        np.testing.assert_allclose(out["2048"].numpy(), g[tag + "_2048"], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(out["logits"].numpy(), g[tag + "_logits"], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(out["clipwise_output"].numpy(), g[tag + "_clipwise"], rtol=2e-4, atol=2e-4)
+        np.testing.assert_allclose(taps["block6"].numpy()[:, ::16], g[tag + "_block6"], rtol=2e-4, atol=2e-4)
+        rms = [float(taps["block%d" % i].double().pow(2).mean().sqrt()) for i in range(1, 7)]
+        np.testing.assert_allclose(rms, g[tag + "_block_rms"], rtol=1e-4)
+    X = {k: v.numpy() for k, v in cases.eval_metric_inputs().items()}
+    np.testing.assert_allclose(oe.fid(X["fid1"].astype(np.float32), X["fid2"].astype(np.float32)), float(g["fid"]), rtol=1e-6)
+    np.testing.assert_allclose(oe.isc(X["isc"]), g["isc"], rtol=1e-9)
+    np.testing.assert_allclose(oe.kid(X["kid1"], X["kid2"], subsets=100, subset_size=90), g["kid"], rtol=2e-5)   # float32 kernel sums, another order
+    names, perm = cases.eval_kl_names(50)
+    np.testing.assert_allclose(oe.kl(X["kl1"], X["kl2"]), g["kl"], rtol=2e-5)
