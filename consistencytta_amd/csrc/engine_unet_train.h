@@ -109,14 +109,31 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
   const int K = kh * kw * C;
   const int R = K + 1 + nb;
   const int ld = round_up(R, 4);
-  const int S = pick_splits(M, R, N);
+  // the layer input read in place through LDS transpose reads (wgrad_gemm.hip) wherever the geometry allows: every linear
+  // and every 3x3 stride-1 convolution of the U-Net except conv_in (8 channels); the stride-2 / upsampling samplers and
+  // conv_in keep the im2col^T route below
+  const int taps = kh * kw;
+  const bool implicit = !ups && stride == 1 && ho == hi && wo == wi && ((taps == 9 && kh == 3 && pad == 1) || (taps == 1 && pad == 0)) &&
+                        M < (1LL << 31) - 4096 && ctta_wgrad_implicit_supported(taps, C, hi, wi, C, N) != 0;
+  int S = pick_splits(M, R, N);
+  if (implicit) {   // 64 x 64 (x 9 taps) / 64 x 256 tiles, two workgroups per CU
+    const int64_t tiles = (int64_t)((N + 63) / 64) * ((C + (taps == 9 ? 63 : 255)) / (taps == 9 ? 64 : 256));
+    S = 1;
+    while (tiles * S < 512 && S < 64 && M / (2 * S) >= 256) S *= 2;   // few tiles = a small weight: its slabs are small too
+  }
   const int mp = (int)round_up64(M, 64 * S);
   const int seg = mp / S;
-  bf16_t* q = A.get<bf16_t>((size_t)R * mp); ALLOC_OR_FAIL(q);
+  bf16_t* q = nullptr;
+  if (!implicit) { q = A.get<bf16_t>((size_t)R * mp); ALLOC_OR_FAIL(q); }
   bf16_t* pt = A.get<bf16_t>((size_t)N * mp); ALLOC_OR_FAIL(pt);
   float* slabs = A.get<float>((size_t)S * N * ld); ALLOC_OR_FAIL(slabs);
   RUN(cm, ctta_transpose_bf16(dy, 0, (int)M, N, N, 0, pt, 0, mp, 1, cm.stream));   // dY lives in the main stream's arena
   if (!cm.dry) CTTA_TRY(wg_handoff(cm, job));
+  if (implicit) {
+    RUN(c, ctta_wgrad_implicit(pt, N, mp, x, C, C, B, hi, wi, taps, (int)M, S, K, nb, slabs, (int64_t)N * ld, ld, c.stream));
+    out->p = slabs; out->S = S; out->R = R; out->ld = ld; out->N = N;
+    return CTTA_OK;
+  }
   RUN(c, ctta_im2col_t(x, C, B, hi, wi, ups ? 1 : 0, ho, wo, kh, kw, stride, pad, pad, 1, q, mp, nb, c.stream));
   ctta_conv_desc d;
   desc_init(&d);

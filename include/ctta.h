@@ -612,6 +612,17 @@ ctta_status ctta_wgrad_scatter(const float* slabs, int n_slabs, int64_t slab_str
                                int accumulate, void* stream);
 /* same contraction for row-major slabs [S][n_rows][ldk] (k contiguous):
  * grad_w[row_off[n] + col_off[k]] (+)= sum_s slabs[s][n][k] */
+/* Implicit weight-gradient GEMM (csrc/wgrad_gemm.hip): slabs[s][n][c * taps + t] = sum over split s's positions m of
+ * dY^T[n][m] * X[pixel(m, tap t)][c] -- the product ctta_im2col_t + ctta_conv_gemm compute, without materialising im2col(X)^T.
+ * dyt: bf16 [n][mp] (ctta_transpose_bf16 of dY, zero beyond m_valid); x: bf16 NHWC (batch, h, w) with x_ld elements per
+ * pixel, c channels used; taps = 9: 3x3, stride 1, pad 1, columns in (cin, kh, kw) order; taps = 1: a linear layer
+ * (batch * h * w = rows).  bias_col >= 0 also writes the row sums of dY^T into column bias_col (bias gradient) and, for
+ * sample_cols > 0, per-sample sums into the columns behind it (d temb).  mp % (64 * splits) == 0.
+ * ctta_wgrad_implicit_supported: whether a geometry is inside the kernel's range (CTTA_WGRAD_IMPLICIT=0 turns it off). */
+int ctta_wgrad_implicit_supported(int taps, int c, int h, int w, int x_ld, int n);
+ctta_status ctta_wgrad_implicit(const void* dyt, int n, int mp, const void* x, int x_ld, int c, int batch, int h, int w,
+                                int taps, int m_valid, int splits, int bias_col, int sample_cols, float* slabs,
+                                int64_t slab_stride, int ld, void* stream);
 ctta_status ctta_wgrad_scatter_rows(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int k_cols,
                                     int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad,
                                     int accumulate, void* stream);

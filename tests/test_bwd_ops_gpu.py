@@ -104,6 +104,53 @@ def test_conv_backward(B, Cin, Cout, H, W, k, stride, ups):
     assert rel_err(from_nhwc(dx), x.grad) < (2.5 if ups else 1.0) * BF16_TOL
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,splits,nb", [(2, 64, 96, 8, 8, 3, 1, 2), (3, 40, 24, 32, 2, 3, 2, 3),
+                                                        (2, 128, 72, 16, 16, 3, 4, 0), (1, 320, 64, 8, 16, 3, 1, 1),
+                                                        (2, 64, 64, 8, 32, 3, 2, 2), (1, 256, 248, 200, 1, 1, 1, 0),
+                                                        (1, 1280, 40, 77, 1, 1, 2, 0), (4, 72, 520, 16, 4, 1, 4, 0)])
+def test_implicit_weight_gradient(B, Cin, Cout, H, W, k, splits, nb):
+    """ctta_wgrad_implicit (csrc/wgrad_gemm.hip): dW of F.conv2d(3x3, stride 1, pad 1) / F.linear read from the NHWC input
+    through LDS transpose reads, against torch autograd and against the im2col^T route it replaces: 3x3 at every width the
+    U-Net has (2 .. 32), ragged channel counts on both sides, split positions, bias and per-sample columns."""
+    L = lib()
+    st = N.stream_ptr()
+    pad = k // 2
+    x = bf16_round(det("wi.x", (B, Cin, H, W), 1)).requires_grad_(True)
+    w = bf16_round(det("wi.w", (Cout, Cin, k, k), 2) / math.sqrt(Cin * k * k)).requires_grad_(True)
+    b = (det("wi.b", (Cout,), 3) * 0.1).requires_grad_(True)
+    y = F.conv2d(x, w, b, padding=pad)
+    dy = bf16_round(det("wi.dy", tuple(y.shape), 4))
+    y.backward(dy)
+    xa, dya = nhwc_bf16(x.detach()), nhwc_bf16(dy)
+    M = B * H * W
+    taps = k * k
+    assert L.ctta_wgrad_implicit_supported(taps, Cin, H, W, Cin, Cout) == 1
+    mp = rup(M, 64 * splits)
+    pt = torch.empty(Cout, mp, dtype=torch.bfloat16, device=DEV)
+    N.check(L.ctta_transpose_bf16(N.ptr(dya), 0, M, Cout, Cout, 0, N.ptr(pt), 0, mp, 1, st))
+    K = taps * Cin
+    ld = rup(K + 1 + nb, 4)
+    slabs = torch.full((splits, Cout, ld), float("nan"), device=DEV)
+    N.check(L.ctta_wgrad_implicit(N.ptr(pt), Cout, mp, N.ptr(xa), Cin, Cin, B, H, W, taps, M, splits, K, nb, N.ptr(slabs),
+                                  Cout * ld, ld, st))
+    sync()
+    got = slabs[:, :, :K + 1 + nb].sum(0).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_err(got[:, :K].reshape(Cout, Cin, k, k), w.grad) < 2e-3
+    assert rel_err(got[:, K], b.grad) < 2e-3
+    if nb:
+        assert rel_err(got[:, K + 1:K + 1 + nb].t(), dy.sum(dim=(2, 3))[:nb]) < 2e-3
+    # the route it replaces gives the same numbers up to the fp32 summation order
+    dw_old, db_old, _ = wgrad(xa, dya, B, H, W, Cin, Cout, k, 1, pad, False, H, W)
+    assert rel_err(got[:, :K].reshape(Cout, Cin, k, k), dw_old) < 1e-4
+    # outside the kernel's range: refused loudly
+    assert L.ctta_wgrad_implicit_supported(9, 64, 8, 48, 64, 64) == 0 and L.ctta_wgrad_implicit_supported(9, 64, 6, 4, 64, 64) == 0
+    assert L.ctta_wgrad_implicit_supported(4, 64, 8, 8, 64, 64) == 0 and L.ctta_wgrad_implicit_supported(1, 8, 8, 8, 8, 64) == 0
+    with pytest.raises(RuntimeError):
+        N.check(L.ctta_wgrad_implicit(N.ptr(pt), Cout, mp, N.ptr(xa), Cin, Cin, B, H, W, 4, M, splits, K, nb, N.ptr(slabs),
+                                      Cout * ld, ld, st))
+
+
 @pytest.mark.parametrize("B,C,H,W,G,silu,eps", [(2, 40, 16, 8, 8, True, 1e-5), (3, 256, 8, 8, 32, False, 1e-6),
                                                 (2, 120, 4, 2, 8, True, 1e-5),
                                                 # many chunks per sample: the chunk walk of gn_bwd_fold split over the block's
