@@ -212,6 +212,8 @@ SIGNATURES = {
     "ctta_nhwc_bf16_to_nchw_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_rows_f32_to_bf16": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ctta_concat_channels": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int64, c_void_p]),
+    "ctta_concat_channels_gn": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_int64,
+                                        c_void_p, c_void_p]),
     "ctta_groupnorm_scratch_floats": (c_size_t, [c_int, c_int, c_int, c_int]),
     "ctta_groupnorm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p]),
     "ctta_groupnorm_stats_out": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),

@@ -564,7 +564,17 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
       skips.pop_back();
       const size_t M = (size_t)B * hh * ww;
       bf16_t* cat = A.get<bf16_t>(M * (ch + sk.c)); ALLOC_OR_FAIL(cat);
-      RUN(c, ctta_concat_channels(h, ch, sk.p, sk.c, cat, (int64_t)M, stream));   // torch.cat([h, skip], 1)
+      // torch.cat([h, skip], 1).  With the statistics fusion on, the pass that writes the concatenation also sums it for the
+      // resnet's norm1 (the one GroupNorm input no convolution epilogue produces): one read of the two sources instead of
+      // concat + a statistics pass over its output
+      if (!c.dry && c.gn_fpart && c.gn_groups > 0 && (ch + sk.c) % c.gn_groups == 0) {
+        int chunks = 0;
+        CTTA_TRY(ctta_concat_channels_gn(h, ch, sk.p, sk.c, cat, B, hh * ww, c.gn_groups, c.gn_fpart, (int64_t)c.gn_fpart_floats,
+                                         &chunks, stream));
+        c.gn_ready_x = cat; c.gn_ready_chunks = chunks; c.gn_ready_c = ch + sk.c;
+      } else {
+        RUN(c, ctta_concat_channels(h, ch, sk.p, sk.c, cat, (int64_t)M, stream));
+      }
       CTTA_REQUIRE(Lv.res[j].cin == ch + sk.c, "internal: skip width mismatch");
       { TapeOp op; op.kind = TapeOp::CONCAT; op.ch = ch; op.skc = sk.c; op.skip_idx = (int)skips.size(); op.H = hh; op.W = ww; tape(op); }
       CTTA_TRY(run_resnet(c, Lv.res[j], cat, hh, ww, &h));

@@ -253,9 +253,13 @@ extern "C" ctta_status ctta_copy_segments_multi(const ctta_copy_seg* segs, int n
 // vector column (tid % VC) and strides over the chunk's pixels; per-channel partials meet in
 // LDS and are folded per group -- deterministic (no atomics).
 // part layout: [B][nchunk][G][2] floats (sum, sumsq).
+// CAT: x is the channel concatenation [x (C1 channels) | x2 (C - C1 channels)] (torch.cat([h, skip], 1) of the up blocks),
+// which this pass also WRITES to y while it sums it: the separate concat launch and its re-read disappear.
+template <bool CAT>
 __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restrict__ x, int HW, int C,
                                                          int G, int pix_per_chunk, int nchunk,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, const bf16_t* __restrict__ x2, int C1,
+                                                         bf16_t* __restrict__ y) {
   extern __shared__ float sm[];  // [PL][C] sum, [PL][C] sumsq
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int VC = C / 8;
@@ -273,7 +277,14 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
       for (int pix = p_begin + tp; pix < p_end; pix += PL) {
-        const uint4 raw = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + pix) * C + v * 8);
+        uint4 raw;
+        if (CAT) {
+          raw = v * 8 < C1 ? *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + pix) * C1 + v * 8)
+                           : *reinterpret_cast<const uint4*>(x2 + ((size_t)b * HW + pix) * (C - C1) + v * 8 - C1);
+          *reinterpret_cast<uint4*>(y + ((size_t)b * HW + pix) * C + v * 8) = raw;
+        } else {
+          raw = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + pix) * C + v * 8);
+        }
         float f[8];
         unpack8(raw, f);
 #pragma unroll
@@ -579,14 +590,37 @@ extern "C" ctta_status ctta_groupnorm_stats_out(const void* x, void* y, int batc
   const int VC = c / 8;
   const int PL = VC <= 256 ? 256 / VC : 1;
   const size_t smem = (size_t)2 * PL * c * sizeof(float);
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nchunk, batch), dim3(256), smem, s, (const bf16_t*)x, hw,
-                     c, groups, ppc, nchunk, part);
+  hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(nchunk, batch), dim3(256), smem, s, (const bf16_t*)x, hw,
+                     c, groups, ppc, nchunk, part, (const bf16_t*)nullptr, 0, (bf16_t*)nullptr);
   CTTA_LAUNCH_CHECK();
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, part, nchunk, groups, c, hw,
                      gamma, beta, eps, ss, stats);
   CTTA_LAUNCH_CHECK();
   gn_launch_apply(x, y, batch, hw, c, ss, silu, false, groups, nullptr, 0, gamma, beta, eps, s);
   CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+// torch.cat([a, b], 1) of two NHWC tensors that also leaves the GroupNorm partial sums of the result in `partials`
+// ([batch][*nchunk][groups][2], the layout ctta_groupnorm_from_partials reads): same chunking and summation order as the
+// first pass of ctta_groupnorm, so the statistics -- and the normalised tensor -- are bit-identical to concat + GroupNorm.
+extern "C" ctta_status ctta_concat_channels_gn(const void* a, int ca, const void* b, int cb, void* dst, int batch, int hw,
+                                               int groups, float* partials, int64_t partials_floats, int* nchunk_out,
+                                               void* stream) {
+  CTTA_REQUIRE(a && b && dst && partials && nchunk_out && ca % 8 == 0 && cb % 8 == 0 && ca > 0 && cb > 0 && batch >= 1 && hw >= 1,
+               "concat_channels_gn: bad arguments");
+  const int c = ca + cb;
+  CTTA_REQUIRE(groups > 0 && c % groups == 0, "concat_channels_gn: C=%d groups=%d unsupported", c, groups);
+  int ppc = 0, nchunk = 0;
+  gn_geometry(hw, c, &ppc, &nchunk);
+  CTTA_REQUIRE((int64_t)batch * nchunk * groups * 2 <= partials_floats, "concat_channels_gn: partials buffer too small");
+  const int VC = c / 8;
+  const int PL = VC <= 256 ? 256 / VC : 1;
+  const size_t smem = (size_t)2 * PL * c * sizeof(float);
+  hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(nchunk, batch), dim3(256), smem, (hipStream_t)stream, (const bf16_t*)a, hw, c,
+                     groups, ppc, nchunk, partials, (const bf16_t*)b, ca, (bf16_t*)dst);
+  CTTA_LAUNCH_CHECK();
+  *nchunk_out = nchunk;
   return CTTA_OK;
 }
 

@@ -440,6 +440,11 @@ ctta_status ctta_rows_f32_to_bf16(const float* src, void* dst, int64_t rows, int
                                   int cols_pad, void* stream);
 ctta_status ctta_concat_channels(const void* a, int ca, const void* b, int cb, void* dst,
                                  int64_t pixels, void* stream);
+/* The same concatenation, also leaving the GroupNorm partial sums of the result ([batch][*nchunk][groups][2], what
+ * ctta_groupnorm_from_partials reads; chunking and summation order of ctta_groupnorm's own first pass, so the normalised tensor
+ * is bit-identical to concat + ctta_groupnorm): unet_2d_blocks.py:2053 + resnet.py:553 in one pass over the two sources. */
+ctta_status ctta_concat_channels_gn(const void* a, int ca, const void* b, int cb, void* dst, int batch, int hw, int groups,
+                                    float* partials, int64_t partials_floats, int* nchunk_out, void* stream);
 
 /* GroupNorm over NHWC bf16 (+ optional SiLU): F.group_norm semantics (biased variance).
  * scratch: fp32 device buffer of ctta_groupnorm_scratch_floats(...) floats. */

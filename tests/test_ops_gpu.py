@@ -533,6 +533,46 @@ def test_groupnorm(B, C, H, W, G, silu, eps):
     assert rel_err(from_nhwc(y), ref) < BF16_TOL
 
 
+@pytest.mark.parametrize("B,C1,C2,H,W,G,stats", [(2, 256, 256, 64, 16, 32, False), (3, 1024, 512, 16, 4, 32, False),
+                                                 (2, 512, 256, 32, 8, 32, True), (1, 1024, 1024, 8, 2, 32, False),
+                                                 (2, 40, 24, 9, 5, 8, False)])
+def test_concat_with_groupnorm_statistics(B, C1, C2, H, W, G, stats):
+    """ctta_concat_channels_gn: torch.cat([h, skip], 1) (unet_2d_blocks.py:2053) that also sums the result for the resnet's
+    norm1: the concatenation is exact, and ctta_groupnorm_from_partials on its partials is BIT-identical to
+    ctta_groupnorm on the concatenated tensor (same chunking and order) -- group boundaries that straddle the two
+    sources (1024 + 512 in 32 groups) included."""
+    L_ = lib()
+    s = N.stream_ptr()
+    C, hw = C1 + C2, H * W
+    a = nhwc_bf16(bf16_round(det("cg.a", (B, C1, H, W), 1) * 2 + 0.3))
+    b = nhwc_bf16(bf16_round(det("cg.b", (B, C2, H, W), 2) - 0.2))
+    gd, bd = (1 + 0.2 * det("cg.g", (C,), 3)).to(DEV), (0.1 * det("cg.be", (C,), 4)).to(DEV)
+    cat = torch.empty(B, H, W, C, dtype=torch.bfloat16, device=DEV)
+    part = torch.full((B * (hw // 16 + 1) * G * 2,), float("nan"), device=DEV)
+    nchunk = ctypes.c_int(0)
+    N.check(L_.ctta_concat_channels_gn(N.ptr(a), C1, N.ptr(b), C2, N.ptr(cat), B, hw, G, N.ptr(part), part.numel(),
+                                       ctypes.byref(nchunk), s))
+    sync()
+    assert torch.equal(cat, torch.cat([a, b], dim=3)) and nchunk.value >= 1
+    scratch = torch.empty(L_.ctta_groupnorm_scratch_floats(B, hw, C, G) + 16, dtype=torch.float32, device=DEV)
+    y_ref, y = torch.empty_like(cat), torch.empty_like(cat)
+    st_ref, st = torch.zeros(B, G, 2, device=DEV), torch.zeros(B, G, 2, device=DEV)
+    N.check(L_.ctta_groupnorm_stats_out(N.ptr(cat), N.ptr(y_ref), B, hw, C, G, N.ptr(gd), N.ptr(bd), 1e-5, 1, N.ptr(scratch),
+                                        N.ptr(st_ref) if stats else None, s))
+    scratch2 = torch.empty(B * 2 * C + 16, device=DEV)
+    N.check(L_.ctta_groupnorm_from_partials(N.ptr(cat), N.ptr(y), B, hw, C, G, N.ptr(gd), N.ptr(bd), 1e-5, 1, N.ptr(part),
+                                            nchunk.value, N.ptr(scratch2), N.ptr(st) if stats else None, s))
+    sync()
+    ref = F.silu(F.group_norm(from_nhwc(cat), G, gd.cpu(), bd.cpu(), 1e-5))
+    assert rel_err(from_nhwc(y), ref) < BF16_TOL
+    if hw * (C // G) > 16384:          # below that ctta_groupnorm takes its single-launch form (another summation order)
+        assert torch.equal(y, y_ref) and torch.equal(st, st_ref)
+    else:
+        assert rel_err(y.float().cpu(), y_ref.float().cpu()) < 2.0 ** -7
+    with pytest.raises(RuntimeError):   # a partials buffer that cannot hold the chunks is refused
+        N.check(L_.ctta_concat_channels_gn(N.ptr(a), C1, N.ptr(b), C2, N.ptr(cat), B, hw, G, N.ptr(part), 2, ctypes.byref(nchunk), s))
+
+
 @pytest.mark.parametrize("rows,d,ld", [(37, 39, 64), (64, 255, 256), (16, 1020, 1024), (5, 1275, 1280), (131, 255, 256),
                                         (70, 510, 512), (9, 1020, 1024), (33, 512, 512)])
 def test_layernorm(rows, d, ld):
