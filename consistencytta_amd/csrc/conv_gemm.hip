@@ -463,6 +463,11 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       }
     }
   }
+  {   // experiment switch: the 3-stage ring for the K-heavy thin launches (weights streamed cold from HBM inside the pipeline)
+    static int ring = -1;
+    if (ring < 0) { const char* e = getenv("CTTA_THIN_RING"); ring = e ? atoi(e) : 0; }
+    if (ring > 0 && d->tile <= 0 && vid == 22 && K >= ring && !geglu) vid = 27;
+  }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
   if (geglu) {   // direct epilogue: <= 8-fragment tiles (64x64, 64x128, 128x64, 256x32); wide-store: also the 128x128 tiles
     const Variant& gv = kVariants[vid - 1];

@@ -112,14 +112,20 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
   // the layer input read in place through LDS transpose reads (wgrad_gemm.hip) wherever the geometry allows: every linear
   // and every 3x3 stride-1 convolution of the U-Net except conv_in (8 channels); the stride-2 / upsampling samplers and
   // conv_in keep the im2col^T route below
+  // Linears (taps == 1) stay on the transposed-operand route by default: there the old Q is ONE transposed copy of X, not
+  // nine, and the implicit kernel's 1-tap tiling reads LDS once per MFMA (round-3 profile: 7.5 ms of side-stream kernel
+  // time per step against 3.9 ms for ALL gradient GEMMs before); CTTA_WGRAD_IMPLICIT_LINEAR=1 routes them through it too.
+  static int implicit_linear = -1;
+  if (implicit_linear < 0) { const char* e = getenv("CTTA_WGRAD_IMPLICIT_LINEAR"); implicit_linear = (e && e[0] == '1') ? 1 : 0; }
   const int taps = kh * kw;
-  const bool implicit = !ups && stride == 1 && ho == hi && wo == wi && ((taps == 9 && kh == 3 && pad == 1) || (taps == 1 && pad == 0)) &&
+  const bool implicit = !ups && stride == 1 && ho == hi && wo == wi &&
+                        ((taps == 9 && kh == 3 && pad == 1) || (taps == 1 && pad == 0 && implicit_linear)) &&
                         M < (1LL << 31) - 4096 && ctta_wgrad_implicit_supported(taps, C, hi, wi, C, N) != 0;
   int S = pick_splits(M, R, N);
   if (implicit) {   // 64 x 64 (x 9 taps) / 64 x 256 tiles, two workgroups per CU
     const int64_t tiles = (int64_t)((N + 63) / 64) * ((C + (taps == 9 ? 63 : 255)) / (taps == 9 ? 64 : 256));
     S = 1;
-    while (tiles * S < 512 && S < 64 && M / (2 * S) >= 256) S *= 2;   // few tiles = a small weight: its slabs are small too
+    while (tiles * S < 512 && S < 16 && M / (2 * S) >= 256) S *= 2;
   }
   const int mp = (int)round_up64(M, 64 * S);
   const int seg = mp / S;

@@ -186,6 +186,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
 
 // slab[s][n][col0]         = sum over split s's positions of dY^T[n][m]                         (bias gradient)
 // slab[s][n][col0 + 1 + b] = the same restricted to sample b = m / hw, b < nb                  (d temb of the resnets' conv1)
+// One wave per (output channel, split); 8 positions per lane and load (the row is contiguous and 16-byte aligned: mp % 8 == 0).
+// Sample boundaries are multiples of hw, which the host requires to be a multiple of 8 whenever nb > 0.
 __global__ __launch_bounds__(64) void wgrad_rowsum_kernel(const bf16_t* __restrict__ dyt, int mp, int M, int seg, int hw,
                                                           int nb, float* __restrict__ slabs, long long slab_stride, int ld,
                                                           int col0) {
@@ -198,7 +200,13 @@ __global__ __launch_bounds__(64) void wgrad_rowsum_kernel(const bf16_t* __restri
   for (int b = 0; b < nparts; ++b) {
     const int a = nb > 0 ? max(lo, b * hw) : lo, e = nb > 0 ? min(hi, (b + 1) * hw) : hi;
     float sum = 0.f;
-    for (int m = a + lane; m < e; m += 64) sum += __uint_as_float((unsigned)row[m] << 16);
+    int m = a + lane * 8;
+    for (; m + 8 <= e; m += 512) {
+      float f[8];
+      unpack8(*reinterpret_cast<const uint4*>(row + m), f);
+      sum += ((f[0] + f[1]) + (f[2] + f[3])) + ((f[4] + f[5]) + (f[6] + f[7]));
+    }
+    for (int t = m; t < e && t < m + 8; ++t) sum += __uint_as_float((unsigned)row[t] << 16);     // the ragged tail of M
     sum = wave_sum(sum);
     total += sum;
     if (nb > 0 && lane == 0) out[1 + b] = sum;
@@ -228,8 +236,9 @@ extern "C" ctta_status ctta_wgrad_implicit(const void* dyt, int n, int mp, const
   CTTA_REQUIRE(mp % (64 * splits) == 0 && mp % 8 == 0, "wgrad_implicit: mp=%d must be a multiple of 64 * splits=%d", mp, 64 * splits);
   CTTA_REQUIRE(ld % 4 == 0 && ld >= c * taps + (bias_col >= 0 ? 1 + sample_cols : 0) && slab_stride % 4 == 0 &&
                ((uintptr_t)slabs & 15) == 0, "wgrad_implicit: slab rows must be 16-byte aligned and hold c * taps (+ bias) columns");
-  CTTA_REQUIRE(taps == 1 ? (long long)batch * h * w == m_valid : (long long)batch * h * w == m_valid,
-               "wgrad_implicit: m_valid=%d is not batch * h * w", m_valid);
+  CTTA_REQUIRE((long long)batch * h * w == m_valid, "wgrad_implicit: m_valid=%d is not batch * h * w", m_valid);
+  CTTA_REQUIRE(bias_col < 0 || sample_cols == 0 || ((h * w) % 8 == 0 && sample_cols <= batch),
+               "wgrad_implicit: per-sample columns need h*w %% 8 == 0 and sample_cols <= batch");
   WgradParams p;
   p.dyt = (const bf16_t*)dyt; p.x = (const bf16_t*)x; p.slabs = slabs;
   p.N = n; p.C = c; p.xld = x_ld; p.mp = mp; p.ld = ld;

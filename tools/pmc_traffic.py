@@ -29,39 +29,51 @@ def family(name):
         return "conv_gemm_kernel"
     for key in ("conv_gemm_kernel", "conv1d_halo_kernel", "attention_kernel", "attn_bwd", "gn_", "layernorm", "ln_bwd", "geglu",
                 "softmax_rows", "conv_small_n_kernel", "splitk_finish", "adamw_kernel", "ema2_kernel", "pack_weight",
-                "wgrad_scatter", "im2col_t", "transpose"):
+                "wgrad_scatter", "wgrad_implicit", "wgrad_rowsum", "im2col_t", "transpose"):
         if key in name:
             return key.rstrip("_")
     return "other"
 
 
-def load(directory, counter):
-    path = glob.glob(directory + "/**/*counter_collection.csv", recursive=True)[0]
+def load(directory, counter, step_kernel=r"conv_small_n_kernel<1[,>]"):
+    """Sums `counter` by kernel family; a pass that left no CSV (the distillation-mode passes hang intermittently under
+    --pmc and are killed by `timeout`) gives (None, 0).  Steps = dispatches of the once-per-step kernel `step_kernel`."""
+    paths = glob.glob(directory + "/**/*counter_collection.csv", recursive=True)
+    if not paths:
+        return None, 0
     tot, steps = defaultdict(float), 0
     seen = set()
-    for row in csv.DictReader(open(path)):
+    for row in csv.DictReader(open(paths[0])):
         if row["Counter_Name"] != counter:
             continue
         tot[family(row["Kernel_Name"])] += float(row["Counter_Value"])
-        if re.search(r"conv_small_n_kernel<1[,>]", row["Kernel_Name"]) and row["Dispatch_Id"] not in seen:
+        if re.search(step_kernel, row["Kernel_Name"]) and row["Dispatch_Id"] not in seen:
             seen.add(row["Dispatch_Id"])
             steps += 1
     return tot, max(1, steps)
 
 
 def main():
-    fetch, fs = load(sys.argv[1], "FETCH_SIZE")
-    write, wsteps = load(sys.argv[2], "WRITE_SIZE")
-    unit = "GB per generation step (batch 32)"
-    if len(sys.argv) > 4 and sys.argv[3] == "distill":
-        fs = wsteps = int(sys.argv[4])
-        unit = "GB per distillation step (batch 9)"
+    distill = len(sys.argv) > 3 and sys.argv[3] == "distill"
+    # one micro-step = one launch of the loss-gradient kernel (every leg of `bench.py --mode distill` runs it once per micro-step)
+    sk = r"snr_mse_grad_kernel" if distill else r"conv_small_n_kernel<1[,>]"
+    fetch, fs = load(sys.argv[1], "FETCH_SIZE", sk)
+    write, wsteps = load(sys.argv[2], "WRITE_SIZE", sk)
+    unit = "GB per distillation micro-step (batch 9)" if distill else "GB per generation step (batch 32)"
     out = {"unit": unit, "steps_fetch_pass": fs, "steps_write_pass": wsteps,
            "fetch_correction": "x2 (gfx950: 128-B requests of 16 B/lane reads tallied at 64 B)", "families": {}}
-    for fam in sorted(set(fetch) | set(write), key=lambda f: -(fetch.get(f, 0) + write.get(f, 0))):
-        rd = fetch.get(fam, 0.0) * 1024 * 2 / fs / 1e9
-        wr = write.get(fam, 0.0) * 1024 / wsteps / 1e9
-        out["families"][fam] = {"read_GB": round(rd, 3), "write_GB": round(wr, 3), "total_GB": round(rd + wr, 3)}
+    if fetch is None or write is None:
+        out["missing_pass"] = "FETCH_SIZE" if fetch is None else "WRITE_SIZE"
+    fams = set(fetch or {}) | set(write or {})
+    key = lambda f: -((fetch or {}).get(f, 0) * 2 / max(fs, 1) + (write or {}).get(f, 0) / max(wsteps, 1))
+    tr = tw = 0.0
+    for fam in sorted(fams, key=key):
+        rd = None if fetch is None else round(fetch.get(fam, 0.0) * 1024 * 2 / fs / 1e9, 3)
+        wr = None if write is None else round(write.get(fam, 0.0) * 1024 / wsteps / 1e9, 3)
+        tr += rd or 0.0
+        tw += wr or 0.0
+        out["families"][fam] = {"read_GB": rd, "write_GB": wr, "total_GB": None if rd is None or wr is None else round(rd + wr, 3)}
+    out["all_kernels"] = {"read_GB": None if fetch is None else round(tr, 3), "write_GB": None if write is None else round(tw, 3)}
     json.dump(out, sys.stdout, indent=1)
     print()
 
