@@ -463,10 +463,19 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       }
     }
   }
-  {   // experiment switch: the 3-stage ring for the K-heavy thin launches (weights streamed cold from HBM inside the pipeline)
+  {   // K-heavy launches on the 64x128x64 tile whose workgroups fill whole rounds at TWO per CU: the 3-stage ring (72 KB of
+      // LDS instead of 48: two K tiles in flight while one is consumed -- inside the pipeline the weights of these layers
+      // arrive cold from HBM, 1.3 us per K step with one tile in flight).  Teacher loop at batch 16 (M = 4096 x N = 1024:
+      // 512 workgroups; M = 16384 x N = 512: 1024): 67.7 -> 70.1 U-Net queries/s.  Batch 9 / 18 (576, 1152 workgroups: 1.1 and
+      // 2.25 rounds of 512 slots where the 2-stage tile has 768) lose 2.3 ms of the distillation step with it, so the rule
+      // looks at the round fill, like the tile rules above (A/B of round 3: tools/r3_probe26.sh; CTTA_THIN_RING=0: off).
     static int ring = -1;
-    if (ring < 0) { const char* e = getenv("CTTA_THIN_RING"); ring = e ? atoi(e) : 0; }
-    if (ring > 0 && d->tile <= 0 && vid == 22 && K >= ring && !geglu) vid = 27;
+    if (ring < 0) { const char* e = getenv("CTTA_THIN_RING"); ring = (e && e[0] == '0') ? 0 : 1; }
+    if (ring && tile_rules_r3() && d->tile <= 0 && vid == 22 && K >= 4096 && !geglu) {
+      const long long wgs = ((M + 63) / 64) * ((d->n + 127) / 128) * groups;
+      const long long rounds = (wgs + 511) / 512;
+      if (wgs >= 512 && wgs * 100 >= rounds * 512 * 85) vid = 27;
+    }
   }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
   if (geglu) {   // direct epilogue: <= 8-fragment tiles (64x64, 64x128, 128x64, 256x32); wide-store: also the 128x128 tiles
