@@ -472,7 +472,14 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     static int ring = -1;
     if (ring < 0) { const char* e = getenv("CTTA_THIN_RING"); ring = (e && e[0] == '0') ? 0 : 1; }
     if (ring && tile_rules_r3() && d->tile <= 0 && vid == 22 && K >= 4096 && !geglu) {
-      const long long wgs = ((M + 63) / 64) * ((d->n + 127) / 128) * groups;
+      long long wgs = ((M + 63) / 64) * ((d->n + 127) / 128) * groups;
+      if (wgs < 192 && groups == 1 && splitk_default()) {     // the split-K factor the launch below will choose
+        const long long nk = (K + 63) / 64;
+        long long sp = 512 / wgs;
+        if (sp > 8) sp = 8;
+        if (sp > nk / 8) sp = nk / 8;
+        if (sp > 1) wgs *= sp;
+      }
       const long long rounds = (wgs + 511) / 512;
       if (wgs >= 512 && wgs * 100 >= rounds * 512 * 85) vid = 27;
     }
