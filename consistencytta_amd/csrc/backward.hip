@@ -10,6 +10,10 @@
 // attention_processor.py:1068-1147; optimizer tools/train_utils.py:59-63 (torch.optim.AdamW).
 #include "common.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include <math.h>
 
 static int grid1d(long long total, int per = 256, int cap = 16384) {
@@ -458,6 +462,46 @@ __global__ __launch_bounds__(1024) void gn_bwd_fold_kernel(const float* __restri
     coef[((size_t)b * G + g) * 2 + 1] = (float)(s2 / n);
   }
 }
+// pass 2a on a (group slices, batch) grid: a block owns the channels of `gpb` consecutive groups (64 channels for the U-Net's
+// group widths), its 1024 threads split the chunk walk 1024 / channels ways per channel and meet in LDS in a fixed order,
+// then the block's first threads turn the per-channel sums into the groups' coefficients.  (One block per SAMPLE -- nine
+// blocks at batch 9 -- walked up to 64 chunks per thread: 28-36 us per call, 1.7-2.2 ms of the distillation step.)
+__global__ __launch_bounds__(1024) void gn_bwd_fold_slices_kernel(const float* __restrict__ part, int nchunk, int G, int C, int HW,
+                                                                  const float* __restrict__ gamma, float* __restrict__ coef,
+                                                                  float* __restrict__ red, int gpb) {
+  __shared__ double sa[1024], sb[1024];
+  __shared__ float fa[1024], fb[1024];
+  const int b = blockIdx.y, g0 = blockIdx.x * gpb;
+  const int cpg = C / G, ng = min(gpb, G - g0), c_lo = g0 * cpg, nc = ng * cpg;      // nc <= 1024 (host)
+  const int parts = 1024 / nc;
+  const int c = threadIdx.x % nc, pt = threadIdx.x / nc;
+  double a = 0.0, bb = 0.0;
+  if (pt < parts) {
+    const float* pc = part + (size_t)b * nchunk * 2 * C + c_lo + c;
+    for (int ch = pt; ch < nchunk; ch += parts) { a += (double)pc[(size_t)ch * 2 * C]; bb += (double)pc[(size_t)ch * 2 * C + C]; }
+  }
+  sa[threadIdx.x] = a; sb[threadIdx.x] = bb;
+  __syncthreads();
+  if (pt == 0) {
+    for (int q = 1; q < parts; ++q) { a += sa[q * nc + c]; bb += sb[q * nc + c]; }
+    float* rb = red + (size_t)b * 2 * C;
+    rb[c_lo + c] = fa[c] = (float)a;
+    rb[C + c_lo + c] = fb[c] = (float)bb;
+  }
+  __syncthreads();
+  const double n = (double)HW * cpg;
+  if ((int)threadIdx.x < ng) {
+    const int g = threadIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int cc = 0; cc < cpg; ++cc) {
+      const double gm = (double)gamma[c_lo + g * cpg + cc];
+      s1 += gm * fa[g * cpg + cc];
+      s2 += gm * fb[g * cpg + cc];
+    }
+    coef[((size_t)b * G + g0 + g) * 2] = (float)(s1 / n);
+    coef[((size_t)b * G + g0 + g) * 2 + 1] = (float)(s2 / n);
+  }
+}
 // pass 2b: dgamma[c] (+)= sum_b Bc, dbeta[c] (+)= sum_b A   (fixed summation order: deterministic)
 __global__ void gn_bwd_param_kernel(const float* __restrict__ red, int B, int C, float* __restrict__ dgamma,
                                     float* __restrict__ dbeta, int accumulate) {
@@ -501,6 +545,55 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const bf16_t* __restr
   }
 }
 
+// The same pass with a block of (256 / VC) * VC threads, VC = C / 8 <= 256: grid (blocks per sample, batch); a thread keeps ONE
+// 8-channel vector column for the whole launch, so (mean, rstd, S1/n, S2/n) of its channels' groups, gamma and beta sit in
+// registers -- the kernel above re-loads six scalars per ELEMENT and divides per element -- and four vectors are in
+// flight per thread (round 3: 36-44 us per call at batch 9 against an HBM time of 11).
+__global__ __launch_bounds__(256) void gn_bwd_apply_cols_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                                bf16_t* __restrict__ dx, int HW, int C, int G,
+                                                                const float* __restrict__ stats,
+                                                                const float* __restrict__ coef,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, int silu, int acc_dx) {
+  const int VC = C / 8, cpg = C / G, b = blockIdx.y;
+  const long long total = (long long)HW * VC;
+  const long long stride = (long long)gridDim.x * blockDim.x;     // blockDim.x is a multiple of VC
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int v = (int)(idx % VC);
+  float mu[8], rs[8], c0[8], c1[8], gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int c = v * 8 + e, g = c / cpg;
+    mu[e] = stats[((size_t)b * G + g) * 2]; rs[e] = stats[((size_t)b * G + g) * 2 + 1];
+    c0[e] = coef[((size_t)b * G + g) * 2]; c1[e] = coef[((size_t)b * G + g) * 2 + 1];
+    gm[e] = gamma[c]; bt[e] = beta[c];
+  }
+  const uint4* xb = reinterpret_cast<const uint4*>(x + (size_t)b * HW * C);
+  const uint4* db = reinterpret_cast<const uint4*>(dy + (size_t)b * HW * C);
+  uint4* ob = reinterpret_cast<uint4*>(dx + (size_t)b * HW * C);
+  auto one = [&](const uint4 rx, const uint4 rd, const uint4 ro) {
+    float fx[8], fd[8], fo[8];
+    unpack8(rx, fx); unpack8(rd, fd); unpack8(ro, fo);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (fx[e] - mu[e]) * rs[e];
+      float dz = fd[e];
+      if (silu) dz *= silu_grad(xh * gm[e] + bt[e]);
+      const float r = rs[e] * (dz * gm[e] - c0[e] - xh * c1[e]);
+      fo[e] = acc_dx ? fo[e] + r : r;
+    }
+    return pack8(fo);
+  };
+  for (; idx + 3 * stride < total; idx += 4 * stride) {
+    uint4 rx[4], rd[4], ro[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { rx[u] = xb[idx + u * stride]; rd[u] = db[idx + u * stride]; ro[u] = acc_dx ? ob[idx + u * stride] : make_uint4(0, 0, 0, 0); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ob[idx + u * stride] = one(rx[u], rd[u], ro[u]);
+  }
+  for (; idx < total; idx += stride) ob[idx] = one(xb[idx], db[idx], acc_dx ? ob[idx] : make_uint4(0, 0, 0, 0));
+}
+
 static void gnb_geometry(int hw, int c, int* ppc, int* nchunk) {
   int p = 16384 / c;
   if (p < 16) p = 16;
@@ -530,7 +623,17 @@ extern "C" ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* d
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, batch), dim3(256), (size_t)2 * PL * c * sizeof(float), s,
                      (const bf16_t*)x, (const bf16_t*)dy, hw, c, groups, ppc, nchunk, stats, gamma, beta, silu, part);
   CTTA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(batch), dim3(1024), 0, s, part, nchunk, groups, c, hw, gamma, coef, red);
+  {
+    const int cpg = c / groups;
+    const int gpb = cpg >= 64 ? 1 : 64 / cpg;
+    static int slices = -1;
+    if (slices < 0) { const char* e = getenv("CTTA_GN_BWD_FOLD_SLICES"); slices = (e && e[0] == '0') ? 0 : 1; }
+    if (slices && cpg * gpb <= 1024)
+      hipLaunchKernelGGL(gn_bwd_fold_slices_kernel, dim3((groups + gpb - 1) / gpb, batch), dim3(1024), 0, s, part, nchunk, groups, c,
+                         hw, gamma, coef, red, gpb);
+    else
+      hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(batch), dim3(1024), 0, s, part, nchunk, groups, c, hw, gamma, coef, red);
+  }
   CTTA_LAUNCH_CHECK();
   if (dgamma) {
     CTTA_REQUIRE(dbeta, "groupnorm_bwd: dgamma without dbeta");
@@ -539,9 +642,22 @@ extern "C" ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* d
     CTTA_LAUNCH_CHECK();
   }
   const long long total_vec = (long long)batch * hw * VC;
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid1d(total_vec, 256, 8192)), dim3(256), 0, s, (const bf16_t*)x,
-                     (const bf16_t*)dy, (bf16_t*)dx, hw, c, groups, stats, coef, gamma, beta, silu, accumulate_dx,
-                     total_vec);
+  static int cols = -1;
+  if (cols < 0) { const char* e = getenv("CTTA_GN_BWD_COLS"); cols = (e && e[0] == '0') ? 0 : 1; }
+  if (cols && VC <= 256) {
+    const int bd = 256 / VC * VC;
+    const long long per_sample = (long long)hw * VC;
+    long long bps = (per_sample + bd * 8 - 1) / (bd * 8);               // >= 8 vectors per thread
+    const long long cap = (8192 + batch - 1) / batch;
+    if (bps > cap) bps = cap;
+    if (bps < 1) bps = 1;
+    hipLaunchKernelGGL(gn_bwd_apply_cols_kernel, dim3((unsigned)bps, (unsigned)batch), dim3(bd), 0, s, (const bf16_t*)x,
+                       (const bf16_t*)dy, (bf16_t*)dx, hw, c, groups, stats, coef, gamma, beta, silu, accumulate_dx);
+  } else {
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(grid1d(total_vec, 256, 8192)), dim3(256), 0, s, (const bf16_t*)x,
+                       (const bf16_t*)dy, (bf16_t*)dx, hw, c, groups, stats, coef, gamma, beta, silu, accumulate_dx,
+                       total_vec);
+  }
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }
@@ -599,19 +715,25 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                      bf16_t* __restrict__ dx, long long rows, int d, int ld,
                                                      const float* __restrict__ gamma, float eps, int acc_dx,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                     int rows_per_block) {
-  extern __shared__ float sm[];   // [2][ld]
+                                                     int rows_per_block, float* __restrict__ part) {
+  extern __shared__ float sm[];   // [row groups][2][ld]: one (d gamma, d beta) copy per row group of the block
   const int wave = threadIdx.x >> 6;
   const int lane = HALF ? (threadIdx.x & 31) : (threadIdx.x & 63);      // lane within the row's group
   constexpr int LW = HALF ? 32 : 64;                                      // lanes per row
   const int VC = ld / 8;
-  for (int i = threadIdx.x; i < 2 * ld; i += 256) sm[i] = 0.f;
-  __syncthreads();
   float gacc[MAXV][8], bacc[MAXV][8];
 #pragma unroll
   for (int i = 0; i < MAXV; ++i)
 #pragma unroll
     for (int e = 0; e < 8; ++e) { gacc[i][e] = 0.f; bacc[i][e] = 0.f; }
+  float gam[MAXV][8];             // this lane's columns of gamma (they do not change from row to row)
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = (lane + i * LW) * 8 + e;
+      gam[i][e] = c < d ? gamma[c] : 0.f;
+    }
   const long long r_begin = (long long)blockIdx.x * rows_per_block;
   const long long r_end = r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows;
   const int step = HALF ? 8 : 4;
@@ -660,7 +782,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         const int c = (lane + i * LW) * 8 + e;
         if (c < d) {
           const float xh = (fx[i][e] - mean) * rstd;
-          const float dg = fd[i][e] * gamma[c];
+          const float dg = fd[i][e] * gam[i][e];
           s1 += dg; s2 += dg * xh;
           gacc[i][e] += fd[i][e] * xh; bacc[i][e] += fd[i][e];
           fx[i][e] = xh; fd[i][e] = dg;
@@ -684,21 +806,95 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       }
     }
   }
+  // every row group parks its column sums in its own LDS copy (plain stores: a lane owns its columns), then the block
+  // folds the NG copies per column in a fixed order.  (The copies replace LDS float atomics on one shared copy, which cost
+  // ~25 us of a 58 us launch at 36864 x 256: tools/ln_bwd_bench.py with the epilogue ablated.)
+  constexpr int NG = HALF ? 8 : 4;
+  {
+    float* mine = sm + (size_t)(HALF ? threadIdx.x >> 5 : wave) * 2 * ld;
 #pragma unroll
-  for (int i = 0; i < MAXV; ++i) {
-    const int v = lane + i * LW;
-    if (v < VC)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        atomicAdd(&sm[v * 8 + e], gacc[i][e]);
-        atomicAdd(&sm[ld + v * 8 + e], bacc[i][e]);
+    for (int i = 0; i < MAXV; ++i) {
+      const int v = lane + i * LW;
+      if (v < VC) {
+        *reinterpret_cast<float4*>(mine + v * 8) = make_float4(gacc[i][0], gacc[i][1], gacc[i][2], gacc[i][3]);
+        *reinterpret_cast<float4*>(mine + v * 8 + 4) = make_float4(gacc[i][4], gacc[i][5], gacc[i][6], gacc[i][7]);
+        *reinterpret_cast<float4*>(mine + ld + v * 8) = make_float4(bacc[i][0], bacc[i][1], bacc[i][2], bacc[i][3]);
+        *reinterpret_cast<float4*>(mine + ld + v * 8 + 4) = make_float4(bacc[i][4], bacc[i][5], bacc[i][6], bacc[i][7]);
       }
+    }
   }
   __syncthreads();
+  for (int c = threadIdx.x; c < 2 * ld; c += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) t += sm[(size_t)g * 2 * ld + c];
+    sm[c] = t;                    // copy 0 now holds the block's sums (this thread is the only reader of column c)
+  }
+  __syncthreads();
+  if (part) {   // this block's (d gamma, d beta) row of the partial table; ln_bwd_reduce_kernel folds the table in a fixed order
+    float* o = part + (size_t)blockIdx.x * 2 * ld;
+    for (int c = threadIdx.x; c < 2 * ld; c += 256) o[c] = sm[c];
+    return;
+  }
   for (int c = threadIdx.x; c < d; c += 256) {
     atomicAdd(&dgamma[c], sm[c]);
     atomicAdd(&dbeta[c], sm[ld + c]);
   }
+}
+// dgamma[c] += sum_b part[b][0][c], dbeta[c] += sum_b part[b][1][c].  grid (column blocks of 64, row slices): a block folds
+// its slice of the table with 4 row lanes per column (8 loads in flight each), then adds ONE value per column and slice.
+// (Round 3: the kernel above used to add every block's 2 d partials straight into dgamma / dbeta -- 1536 blocks x 2 x 320
+// global atomics on 640 addresses per call, which the L2 serialises per address: 65-70 us per launch on a tensor whose
+// HBM time is 14, tools/ln_bwd_bench.py.  Now <= 32 atomics per address.)
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ part, int nblocks, int ld, int d,
+                                                            int rows_per_slice, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  __shared__ float red[2][4][64];
+  const int col = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r_lo = blockIdx.y * rows_per_slice, r_hi = min(nblocks, r_lo + rows_per_slice);
+  float g = 0.f, b = 0.f;
+  if (col < d) {
+    constexpr int U = 8;
+    for (int r = r_lo + rl; r < r_hi; r += 4 * U) {
+      float pg[U], pb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int rr = r + 4 * u;
+        pg[u] = rr < r_hi ? part[(size_t)rr * 2 * ld + col] : 0.f;
+        pb[u] = rr < r_hi ? part[(size_t)rr * 2 * ld + ld + col] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { g += pg[u]; b += pb[u]; }
+    }
+  }
+  red[0][rl][threadIdx.x & 63] = g;
+  red[1][rl][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (rl == 0 && col < d) {
+    const int t = threadIdx.x & 63;
+    atomicAdd(&dgamma[col], (red[0][0][t] + red[0][1][t]) + (red[0][2][t] + red[0][3][t]));
+    atomicAdd(&dbeta[col], (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]));
+  }
+}
+// per-stream partial table of ctta_layernorm_bwd (grown on demand; the first, eager pass of a step sees every size before
+// a graph capture replays them)
+static float* ln_bwd_workspace(hipStream_t s, size_t bytes) {
+  struct Ws { float* p = nullptr; size_t bytes = 0; };
+  static std::mutex mu;
+  static std::map<std::pair<int, hipStream_t>, Ws> table;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  Ws& w = table[std::make_pair(dev, s)];
+  if (w.bytes >= bytes) return w.p;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // no allocation while capturing
+  float* q = nullptr;
+  const size_t want = bytes < ((size_t)8 << 20) ? ((size_t)8 << 20) : bytes;
+  if (hipMalloc((void**)&q, want) != hipSuccess) return nullptr;
+  if (w.p) { (void)hipStreamSynchronize(s); (void)hipFree(w.p); }
+  w.p = q; w.bytes = want;
+  return w.p;
 }
 extern "C" ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t rows, int d, int ld,
                                           const float* gamma, float eps, int accumulate_dx, float* dgamma, float* dbeta,
@@ -710,13 +906,27 @@ extern "C" ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* d
   int rpb = (int)(rows / 2048);
   rpb = rpb < 8 ? 8 : (rpb > 64 ? 64 : (rpb + 7) / 8 * 8);
   const dim3 grid((unsigned)cdiv64(rows, rpb));
-  const size_t smem = (size_t)2 * ld * sizeof(float);
+  const size_t smem = (size_t)(ld <= 256 ? 8 : 4) * 2 * ld * sizeof(float);      // one copy per row group (<= 64 KB at ld = 2048)
   hipStream_t s = (hipStream_t)stream;
+  // d gamma / d beta: per-block partials + a sliced fold when a table of <= 64 MB holds them and the grid is large enough
+  // for the per-address atomics to hurt; a failed allocation falls back to one atomic per block and column
+  static int two_pass = -1;
+  if (two_pass < 0) { const char* e = getenv("CTTA_LN_BWD_TWO_PASS"); two_pass = (e && e[0] == '0') ? 0 : 1; }
+  float* part = nullptr;
+  const size_t part_bytes = (size_t)grid.x * 2 * ld * sizeof(float);
+  if (two_pass && grid.x >= 16 && part_bytes <= ((size_t)64 << 20)) part = ln_bwd_workspace(s, part_bytes);
 #define LNB(MV, HF) hipLaunchKernelGGL((ln_bwd_kernel<MV, HF>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, \
-                                       (bf16_t*)dx, (long long)rows, d, ld, gamma, eps, accumulate_dx, dgamma, dbeta, rpb)
+                                       (bf16_t*)dx, (long long)rows, d, ld, gamma, eps, accumulate_dx, dgamma, dbeta, rpb, part)
   if (ld <= 256) LNB(1, true); else if (ld <= 512) LNB(1, false); else if (ld <= 1024) LNB(2, false); else LNB(4, false);
 #undef LNB
   CTTA_LAUNCH_CHECK();
+  if (part) {
+    const int slices = (int)grid.x >= 32 * 8 ? 32 : ((int)grid.x + 7) / 8;          // >= 8 table rows per slice
+    const int rps = ((int)grid.x + slices - 1) / slices;
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3((d + 63) / 64, ((int)grid.x + rps - 1) / rps), dim3(256), 0, s, part,
+                       (int)grid.x, ld, d, rps, dgamma, dbeta);
+    CTTA_LAUNCH_CHECK();
+  }
   return CTTA_OK;
 }
 
