@@ -28,7 +28,7 @@ static int grid1d(long long total, int per = 256, int cap = 16384) {
 __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, long long sgs, int rows,
                                                         int cols, int src_ld, int col0, bf16_t* __restrict__ dst,
                                                         long long dgs, int dst_ld) {
-  __shared__ bf16_t tile[64][72];
+  __shared__ __attribute__((aligned(16))) bf16_t tile[64][72];
   const int g = blockIdx.z;
   const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
   const bf16_t* s = src + (size_t)g * sgs;
@@ -43,15 +43,21 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
     *reinterpret_cast<uint4*>(&tile[r][cc]) = v;
   }
   __syncthreads();
+  // columns out through the LDS transpose read (ds_read_b64_tr_b16: lane t of a 16-lane group names row k0 + t / 4, columns
+  // 4 (t % 4) .. + 3 and receives column t % 16, rows k0 .. k0 + 3): wave w owns columns 16 w .. + 15, group kg of pass i the
+  // eight rows (4 i + kg) * 8 .. + 7 -- two reads and one 16-byte store per lane, where the scalar form took eight 2-byte
+  // LDS reads and their packing
+  typedef short s16x4_t __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4_t* lds_ptr;
+  const int lane = tid & 63, wave = tid >> 6, t = lane & 15, kg = lane >> 4;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int ch = tid + i * 256;
-    const int c = ch >> 3, rr = (ch & 7) * 8;
+    const int rr = (i * 4 + kg) * 8, c = wave * 16 + t;
+    const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)&tile[rr + (t >> 2)][wave * 16 + (t & 3) * 4]);
+    const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)&tile[rr + 4 + (t >> 2)][wave * 16 + (t & 3) * 4]);
     if (c0 + c < cols && r0 + rr < dst_ld) {
-      uint32_t w[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = (uint32_t)tile[rr + 2 * e][c] | ((uint32_t)tile[rr + 2 * e + 1][c] << 16);
-      *reinterpret_cast<uint4*>(d + (size_t)(c0 + c) * dst_ld + r0 + rr) = make_uint4(w[0], w[1], w[2], w[3]);
+      const uint2 u0 = __builtin_bit_cast(uint2, a0), u1 = __builtin_bit_cast(uint2, a1);
+      *reinterpret_cast<uint4*>(d + (size_t)(c0 + c) * dst_ld + r0 + rr) = make_uint4(u0.x, u0.y, u1.x, u1.y);
     }
   }
 }
@@ -948,8 +954,8 @@ __global__ void geglu_bwd_kernel(const bf16_t* __restrict__ f, const bf16_t* __r
     unpack8(*reinterpret_cast<const uint4*>(dout + (size_t)r * hp + v * 8), dd);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float cdf = 0.5f * (1.0f + erff(g[e] * 0.70710678118654752f));
-      const float pdf = 0.3989422804014327f * __expf(-0.5f * g[e] * g[e]);
+      float cdf, pdf;
+      gelu_cdf_pdf(g[e], cdf, pdf);
       da[e] = dd[e] * g[e] * cdf;
       dg[e] = dd[e] * a[e] * (cdf + g[e] * pdf);
     }

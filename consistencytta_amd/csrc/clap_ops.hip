@@ -123,8 +123,8 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const uint4* __restrict__
     unpack8(dy[i], g);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float cdf = 0.5f * (1.0f + erff(f[e] * 0.70710678118654752f));
-      const float pdf = 0.3989422804014327f * __expf(-0.5f * f[e] * f[e]);
+      float cdf, pdf;
+      gelu_cdf_pdf(f[e], cdf, pdf);
       g[e] *= cdf + f[e] * pdf;
     }
     dx[i] = pack8(g);

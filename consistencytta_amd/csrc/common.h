@@ -62,6 +62,21 @@ __device__ __forceinline__ float gelu_erf_f(float g) {
   return g * (g > 0.f ? 1.0f - h : h);
 }
 
+// Phi(g) and phi(g) of the GELU derivative  d/dg [g Phi(g)] = Phi(g) + g phi(g)  from the same rational fit and the same
+// exponential as gelu_erf_f (the backward kernels used ocml's erff plus a second exponential per element).
+__device__ __forceinline__ void gelu_cdf_pdf(float g, float& cdf, float& pdf) {
+  const float ax = fabsf(g);
+  const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752f, 1.0f));
+  float poly = fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f);
+  poly = fmaf(poly, t, 0.5f * 1.421413741f);
+  poly = fmaf(poly, t, 0.5f * -0.284496736f);
+  poly = fmaf(poly, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(g * g * (-0.5f * 1.4426950408889634f));
+  const float h = poly * t * e;
+  cdf = g > 0.f ? 1.0f - h : h;
+  pdf = 0.3989422804014327f * e;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
