@@ -202,17 +202,21 @@ def main():
 
     if rank == 0:
         # ---- per-stage split (HIP events on the current stream)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-        ev[0].record()
-        l_ = pipe.generate_latent(enc, mask, noise, cfg_scale_input=4.0, cfg_scale_post=1.0, num_steps=1)
-        ev[1].record()
-        m_ = vae.decode_first_stage(l_)
-        ev[2].record()
-        vae.vocode(m_)
-        ev[3].record()
-        torch.cuda.synchronize()
-        result["stage_ms"] = {"unet": round(ev[0].elapsed_time(ev[1]), 3), "vae_decoder": round(ev[1].elapsed_time(ev[2]), 3),
-                              "hifigan": round(ev[2].elapsed_time(ev[3]), 3)}
+        # median of five eager passes (one pass is +-2 ms on the U-Net's ~500 launches; round 3 reported single passes)
+        passes = []
+        for _ in range(5):
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            ev[0].record()
+            l_ = pipe.generate_latent(enc, mask, noise, cfg_scale_input=4.0, cfg_scale_post=1.0, num_steps=1)
+            ev[1].record()
+            m_ = vae.decode_first_stage(l_)
+            ev[2].record()
+            vae.vocode(m_)
+            ev[3].record()
+            torch.cuda.synchronize()
+            passes.append([ev[i].elapsed_time(ev[i + 1]) for i in range(3)])
+        med = [sorted(p[i] for p in passes)[2] for i in range(3)]
+        result["stage_ms"] = {"unet": round(med[0], 3), "vae_decoder": round(med[1], 3), "hifigan": round(med[2], 3)}
         # whole-stage fraction of the dense bf16 peak: ALL algorithmic FLOPs of the stage (convs, linears, attention) over
         # the stage's wall time (eager launches, every kernel of the stage included) -- the weakest stage at a glance
         gf_stage = {"unet": GF_UNET_CONV + GF_UNET_LINEAR_L16 + GF_UNET_LINEAR_PER_16TOK * max(0, (L - 16) / 16.0) + GF_UNET_SELF_ATTN + GF_UNET_CROSS_ATTN_L16 * L / 16.0,

@@ -449,7 +449,11 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
           d->out_limit == 0 && d->out_offset == 0)
         // M = 1024 / 1152 (teacher batches, level 3): 64x128x64 + split-K 502-523 vs 414-450 TFLOP/s on 128x128x64;
         // M = 576 (batch 9, level 3): 128x64x64 346 vs 295
-        vid = !tile_rules_r3() ? 1 : M <= 640 ? 8 : M <= 1280 ? 6 : 1;
+      {
+        static int m64 = -1;     // rows up to which the 64x128x64 tile (+ split-K, + the 3-stage ring when it fills) is taken
+        if (m64 < 0) { const char* e = getenv("CTTA_SPLITK_M64"); m64 = e ? atoi(e) : 1280; }
+        vid = !tile_rules_r3() ? 1 : M <= 640 ? 8 : M <= m64 ? 6 : 1;
+      }
       if (!d->in_act && glds_default() && vid <= 8) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
       // 64 < N <= 128 with enough rows: the 256x128x32 tile (8 waves of 64x64) stages 25 % fewer bytes per FLOP than
       // 128x128 / 64x128 and, with the wide-store epilogue, wins from K = 384 up (sweep: +12..22 %)
