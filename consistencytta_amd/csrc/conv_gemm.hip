@@ -475,6 +475,8 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       // looks at the round fill, like the tile rules above (A/B of round 3: tools/r3_probe26.sh; CTTA_THIN_RING=0: off).
     static int ring = -1;
     if (ring < 0) { const char* e = getenv("CTTA_THIN_RING"); ring = (e && e[0] == '0') ? 0 : 1; }
+    // (the same move for the 128x128x64 tile -- 128x128x32 with a 3-stage ring, 48 KB -- measured slower at batch 32 and 16:
+    // 25.4 vs 24.8 ms and 14.7 vs 14.5 ms per U-Net forward, tools/r3_probe35.sh)
     if (ring && tile_rules_r3() && d->tile <= 0 && vid == 22 && K >= 4096 && !geglu) {
       long long wgs = ((M + 63) / 64) * ((d->n + 127) / 128) * groups;
       if (wgs < 192 && groups == 1 && splitk_default()) {     // the split-K factor the launch below will choose
