@@ -375,6 +375,47 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// Pass 2 for long chunk lists (nchunk * G > 2048: the VAE's top levels, 256 row tiles per sample): grid (G / 4, batch), 64 lanes
+// per group, so a lane folds nchunk / 64 chunks instead of nchunk / 8 (the one-block-per-sample form above spent 14 us per
+// call there, 0.8 ms of a batch-32 generation step).  The fused finalize + apply never sees these lists, so its "same order
+// as gn_finalize_kernel" contract is untouched.
+__global__ __launch_bounds__(256) void gn_finalize_wide_kernel(const float* __restrict__ part, int nchunk, int G, int C, int HW,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps,
+                                                               float* __restrict__ scale_shift, float* __restrict__ stats) {
+  const int b = blockIdx.y, g = blockIdx.x * 4 + (int)threadIdx.x / 64, l = (int)threadIdx.x % 64;
+  const int cpg = C / G;
+  double s = 0.0, q = 0.0;
+  if (g < G) gn_fold_chunks(part + ((size_t)b * nchunk * G + g) * 2, nchunk, G, l, 64, s, q);
+  for (int off = 1; off < 64; off <<= 1) {
+    s += __shfl_xor(s, off);
+    q += __shfl_xor(q, off);
+  }
+  if (g >= G) return;
+  const double n = (double)HW * cpg;
+  const double mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float meanf = (float)mean;
+  if (stats && l == 0) {
+    stats[((size_t)b * G + g) * 2] = meanf;
+    stats[((size_t)b * G + g) * 2 + 1] = rstd;
+  }
+  for (int cc = l; cc < cpg; cc += 64) {
+    const int c = g * cpg + cc;
+    const float sc = rstd * gamma[c];
+    scale_shift[((size_t)b * 2 + 0) * C + c] = sc;
+    scale_shift[((size_t)b * 2 + 1) * C + c] = beta[c] - meanf * sc;
+  }
+}
+
+static bool gn_finalize_wide_on() {   // CTTA_GN_FINALIZE_WIDE=0: the one-block-per-sample form everywhere (A/B)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_GN_FINALIZE_WIDE"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
+
 // Pass 3: apply (+SiLU).  grid = (blocks per sample, batch): a block stays inside one sample, and because its stride
 // (gridDim.x * 256 vectors) is a multiple of the C / 8 vector columns whenever C / 8 divides 256, a thread keeps ONE
 // channel vector for its whole walk -- its 8 scales and 8 shifts are loaded once into registers instead of 64 bytes of
@@ -593,8 +634,12 @@ extern "C" ctta_status ctta_groupnorm_stats_out(const void* x, void* y, int batc
   hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(nchunk, batch), dim3(256), smem, s, (const bf16_t*)x, hw,
                      c, groups, ppc, nchunk, part, (const bf16_t*)nullptr, 0, (bf16_t*)nullptr);
   CTTA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, part, nchunk, groups, c, hw,
-                     gamma, beta, eps, ss, stats);
+  if (gn_finalize_wide_on() && (long long)nchunk * groups > 2048)
+    hipLaunchKernelGGL(gn_finalize_wide_kernel, dim3((groups + 3) / 4, batch), dim3(256), 0, s, part, nchunk, groups, c, hw,
+                       gamma, beta, eps, ss, stats);
+  else
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, part, nchunk, groups, c, hw,
+                       gamma, beta, eps, ss, stats);
   CTTA_LAUNCH_CHECK();
   gn_launch_apply(x, y, batch, hw, c, ss, silu, false, groups, nullptr, 0, gamma, beta, eps, s);
   CTTA_LAUNCH_CHECK();
@@ -642,8 +687,12 @@ extern "C" ctta_status ctta_groupnorm_from_partials(const void* x, void* y, int 
     CTTA_LAUNCH_CHECK();
     return CTTA_OK;
   }
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, partials, nchunk, groups, c, hw, gamma, beta, eps,
-                     scratch, stats);
+  if (gn_finalize_wide_on() && (long long)nchunk * groups > 2048)
+    hipLaunchKernelGGL(gn_finalize_wide_kernel, dim3((groups + 3) / 4, batch), dim3(256), 0, s, partials, nchunk, groups, c, hw,
+                       gamma, beta, eps, scratch, stats);
+  else
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(batch), dim3(256), 0, s, partials, nchunk, groups, c, hw, gamma, beta, eps,
+                       scratch, stats);
   CTTA_LAUNCH_CHECK();
   gn_launch_apply(x, y, batch, hw, c, scratch, silu, false, groups, nullptr, 0, gamma, beta, eps, s);
   CTTA_LAUNCH_CHECK();
