@@ -217,6 +217,35 @@ def main():
             passes.append([ev[i].elapsed_time(ev[i + 1]) for i in range(3)])
         med = [sorted(p[i] for p in passes)[2] for i in range(3)]
         result["stage_ms"] = {"unet": round(med[0], 3), "vae_decoder": round(med[1], 3), "hifigan": round(med[2], 3)}
+        # the same three stages, each as its OWN hipGraph replay (what the headline's single graph is made of; the eager
+        # figures above carry the host's launch cadence of ~500 / ~130 / ~190 launches): median of five replays
+        try:
+            def graphed(fn):
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    out = fn()                      # warm pass on the capture stream
+                torch.cuda.current_stream(dev).wait_stream(side)
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=side):
+                    out = fn()
+                ts = []
+                for _ in range(5):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    gr.replay()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    ts.append(e0.elapsed_time(e1))
+                return out, sorted(ts)[2]
+            with torch.no_grad():
+                lg, t_u = graphed(lambda: pipe.generate_latent(enc, mask, noise, cfg_scale_input=4.0, cfg_scale_post=1.0, num_steps=1))
+                mg, t_v = graphed(lambda: vae.decode_first_stage(lg))
+                _, t_h = graphed(lambda: vae.vocode(mg))
+            result["stage_ms_graph"] = {"unet": round(t_u, 3), "vae_decoder": round(t_v, 3), "hifigan": round(t_h, 3)}
+        except Exception as exc:   # a stage that cannot be captured on this torch build: the eager split stays
+            result["stage_ms_graph"] = {"error": str(exc)[:200]}
         # whole-stage fraction of the dense bf16 peak: ALL algorithmic FLOPs of the stage (convs, linears, attention) over
         # the stage's wall time (eager launches, every kernel of the stage included) -- the weakest stage at a glance
         gf_stage = {"unet": GF_UNET_CONV + GF_UNET_LINEAR_L16 + GF_UNET_LINEAR_PER_16TOK * max(0, (L - 16) / 16.0) + GF_UNET_SELF_ATTN + GF_UNET_CROSS_ATTN_L16 * L / 16.0,
