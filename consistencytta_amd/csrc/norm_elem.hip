@@ -433,6 +433,20 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
   extern __shared__ float ss[];   // FUSED: [2][C] scale, shift
   const int b = blockIdx.y;
   const float* tab = scale_shift + (size_t)b * 2 * C;
+  const int VC = C / 8;
+  const uint4* xb = reinterpret_cast<const uint4*>(x + (size_t)b * HW * C);
+  uint4* yb = reinterpret_cast<uint4*>(y + (size_t)b * HW * C);
+  const long long total_end = (long long)HW * VC;
+  const long long stride = (long long)gridDim.x * 256;
+  long long idx = blockIdx.x * 256LL + threadIdx.x;
+  // FUSED: the first four vectors are requested BEFORE the fold of the partials (they do not depend on it), so the fold's
+  // two or three L2 round trips pass behind the first HBM round trip instead of in front of it
+  uint4 r0[4];
+  const bool pre = FUSED && 256 % VC == 0 && idx + 3 * stride < total_end;
+  if (pre) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) r0[u] = xb[idx + u * stride];
+  }
   if constexpr (FUSED) {
     const int cpg = C / G;
     int LPG = 1;
@@ -463,12 +477,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     __syncthreads();
     tab = ss;
   }
-  const int VC = C / 8;
-  const uint4* xb = reinterpret_cast<const uint4*>(x + (size_t)b * HW * C);
-  uint4* yb = reinterpret_cast<uint4*>(y + (size_t)b * HW * C);
-  const long long total_end = (long long)HW * VC;
-  const long long stride = (long long)gridDim.x * 256;
-  long long idx = blockIdx.x * 256LL + threadIdx.x;
   auto apply8 = [&](const uint4 raw, const float* scl, const float* shf) {
     float f[8];
     unpack8(raw, f);
@@ -484,6 +492,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16_t* __restrict_
     float scl[8], shf[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { scl[e] = tab[v * 8 + e]; shf[e] = tab[C + v * 8 + e]; }
+    if (pre) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) yb[idx + u * stride] = apply8(r0[u], scl, shf);
+      idx += 4 * stride;
+    }
     for (; idx + 3 * stride < total_end; idx += 4 * stride) {
       uint4 r[4];
 #pragma unroll
