@@ -463,3 +463,25 @@ def test_eval_wav_reader(tmp_path):
     ds = E.WaveDataset(str(tmp_path), sr=48000, target_length=50)
     w, name = ds[0]
     assert name == "a.wav" and tuple(w.shape) == (1, 32000) and float(w[0, 24000:].abs().max()) == 0.0
+
+
+def test_cnn14_loads_a_released_checkpoint_layout():
+    """`Cnn14.load_state_dict` takes the key set of the released `Cnn14_16k_mAP=0.438.pth` (`["model"]`): the module's own
+    parameters and BatchNorm buffers, torchlibrosa's frozen STFT / mel matrices, `num_batches_tracked` counters -- strictly,
+    with or without the structural front-end entries; an unknown key is refused."""
+    from consistencytta_amd import audioldm_eval as E
+    m = E.Cnn14(features_list=["2048", "logits"])
+    table = spec.cnn14_param_spec(spec.CNN14_16K_CONFIG)
+    assert list(k for k, _ in m.named_parameters()) == list(table)
+    sd = {k: torch.from_numpy(spec.cnn14_det_weight("ck." + k, shape, 1)) for k, shape in table.items()}
+    for k in list(sd):
+        if k.endswith("running_var"):
+            sd[k.replace("running_var", "num_batches_tracked")] = torch.tensor(7)
+    m.load_state_dict(sd, strict=True)
+    assert torch.equal(m.get_parameter("conv_block3.bn2.running_var"), sd["conv_block3.bn2.running_var"])
+    core = {k: v for k, v in sd.items() if k not in spec.CNN14_STRUCTURAL}
+    m.load_state_dict(core, strict=True)                       # a state dict without the frozen front-end matrices
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(dict(core, **{"conv_block7.conv1.weight": torch.zeros(1)}), strict=True)
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(1, 32000))                               # CPU tensors: there is no CPU path
