@@ -600,6 +600,98 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_cols_kernel(const bf16_t* __
   for (; idx < total; idx += stride) ob[idx] = one(xb[idx], db[idx], acc_dx ? ob[idx] : make_uint4(0, 0, 0, 0));
 }
 
+// The whole backward of one (sample, group) slab in ONE launch when the slab is small (HW * C / G <= 16384 elements: levels 1-3
+// of the batch-9 U-Net, 45 of its 61 GroupNorms): a block keeps x and dy of its slab in registers (<= 8 + 8 vectors per
+// thread), reduces the per-channel sums (A = sum dz, Bc = sum dz * xhat) through LDS in a fixed order, turns them into the
+// group's two coefficients and writes dx -- x and dy are read once instead of twice, and the partial / fold / apply
+// launches (5-20 us each plus their dependent-launch gaps on the step's main stream) become one.  red[b][2][C] receives
+// the per-channel sums for gn_bwd_param_kernel exactly like the fold kernels leave them.
+__global__ __launch_bounds__(256) void gn_bwd_small_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
+                                                           bf16_t* __restrict__ dx, int HW, int C, int G,
+                                                           const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, int silu, int acc_dx,
+                                                           float* __restrict__ red) {
+  constexpr int MAXV = 8;
+  __shared__ float sA[256][9], sB[256][9];          // [thread][8 channels], padded
+  __shared__ float chA[128], chB[128], coef[2];     // per-channel sums of the group (cpg <= 128), the two coefficients
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int cpg = C / G, vpr = cpg / 8;              // vectors per pixel row of this group; vpr divides 256 (host)
+  const int nvec = HW * vpr;
+  const int cv = tid % vpr;                          // this thread's channel vector inside the group: fixed (256 % vpr == 0)
+  const size_t base = (size_t)b * HW * C + (size_t)g * cpg;
+  const float mean = stats[((size_t)b * G + g) * 2], rstd = stats[((size_t)b * G + g) * 2 + 1];
+  float gm[8], bt[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { gm[e] = gamma[g * cpg + cv * 8 + e]; bt[e] = beta[g * cpg + cv * 8 + e]; }
+  float xh[MAXV][8], dz[MAXV][8];
+  float a[8], bb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a[e] = 0.f; bb[e] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < nvec) {
+      const int pix = idx / vpr;
+      float fx[8], fd[8];
+      unpack8(*reinterpret_cast<const uint4*>(x + base + (size_t)pix * C + cv * 8), fx);
+      unpack8(*reinterpret_cast<const uint4*>(dy + base + (size_t)pix * C + cv * 8), fd);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float h = (fx[e] - mean) * rstd;
+        float z = fd[e];
+        if (silu) z *= silu_grad(h * gm[e] + bt[e]);
+        xh[i][e] = h; dz[i][e] = z;
+        a[e] += z; bb[e] += z * h;
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { sA[tid][e] = a[e]; sB[tid][e] = bb[e]; }
+  __syncthreads();
+  if (tid < cpg) {                                   // channel tid of the group: threads cv, cv + vpr, ... hold its sums
+    const int v = tid / 8, e = tid % 8;
+    float ta = 0.f, tb = 0.f;
+    for (int t = v; t < 256; t += vpr) { ta += sA[t][e]; tb += sB[t][e]; }
+    chA[tid] = ta; chB[tid] = tb;
+    red[(size_t)b * 2 * C + g * cpg + tid] = ta;
+    red[(size_t)b * 2 * C + C + g * cpg + tid] = tb;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = 0; c < cpg; ++c) { s1 += (double)gamma[g * cpg + c] * chA[c]; s2 += (double)gamma[g * cpg + c] * chB[c]; }
+    const double n = (double)HW * cpg;
+    coef[0] = (float)(s1 / n); coef[1] = (float)(s2 / n);
+  }
+  __syncthreads();
+  const float c0 = coef[0], c1 = coef[1];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = tid + i * 256;
+    if (idx < nvec) {
+      const int pix = idx / vpr;
+      bf16_t* o = dx + base + (size_t)pix * C + cv * 8;
+      float fo[8];
+      if (acc_dx) unpack8(*reinterpret_cast<const uint4*>(o), fo);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float r = rstd * (dz[i][e] * gm[e] - c0 - xh[i][e] * c1);
+        fo[e] = acc_dx ? fo[e] + r : r;
+      }
+      *reinterpret_cast<uint4*>(o) = pack8(fo);
+    }
+  }
+}
+static bool gn_bwd_small_ok(int hw, int c, int groups) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CTTA_GN_BWD_SMALL"); on = (e && e[0] == '0') ? 0 : 1; }
+  if (!on || c % groups) return false;
+  const int cpg = c / groups;
+  if (cpg % 8 || cpg > 128) return false;
+  const int vpr = cpg / 8;
+  return 256 % vpr == 0 && (long long)hw * vpr <= 256 * 8;
+}
+
 static void gnb_geometry(int hw, int c, int* ppc, int* nchunk) {
   int p = 16384 / c;
   if (p < 16) p = 16;
@@ -625,6 +717,18 @@ extern "C" ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* d
   float* part = scratch;
   float* red = part + (size_t)batch * nchunk * 2 * c;
   float* coef = red + (size_t)batch * 2 * c;
+  if (gn_bwd_small_ok(hw, c, groups)) {
+    hipLaunchKernelGGL(gn_bwd_small_kernel, dim3(groups, batch), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy,
+                       (bf16_t*)dx, hw, c, groups, stats, gamma, beta, silu, accumulate_dx, red);
+    CTTA_LAUNCH_CHECK();
+    if (dgamma) {
+      CTTA_REQUIRE(dbeta, "groupnorm_bwd: dgamma without dbeta");
+      hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((c + 255) / 256), dim3(256), 0, s, red, batch, c, dgamma, dbeta,
+                         accumulate_param);
+      CTTA_LAUNCH_CHECK();
+    }
+    return CTTA_OK;
+  }
   const int VC = c / 8, PL = VC <= 256 ? 256 / VC : 1;
   hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(nchunk, batch), dim3(256), (size_t)2 * PL * c * sizeof(float), s,
                      (const bf16_t*)x, (const bf16_t*)dy, hw, c, groups, ppc, nchunk, stats, gamma, beta, silu, part);
