@@ -479,7 +479,9 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     // 25.4 vs 24.8 ms and 14.7 vs 14.5 ms per U-Net forward, tools/r3_probe35.sh)
     if (ring && tile_rules_r3() && d->tile <= 0 && vid == 22 && K >= 4096 && !geglu) {
       long long wgs = ((M + 63) / 64) * ((d->n + 127) / 128) * groups;
-      if (wgs < 192 && groups == 1 && splitk_default()) {     // the split-K factor the launch below will choose
+      static int tg = -1;
+      if (tg < 0) { const char* e = getenv("CTTA_SPLITK_TILES"); tg = e ? atoi(e) : 192; }
+      if (wgs < tg && groups == 1 && splitk_default()) {      // the split-K factor the launch below will choose
         const long long nk = (K + 63) / 64;
         long long sp = 512 / wgs;
         if (sp > 8) sp = 8;
@@ -515,8 +517,10 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   int splits = 1;
   float* ws = nullptr;
   size_t ws_bytes = 0;
+  static int tiles_gate = -1;   // launches with fewer tiles than this are split over K (CTTA_SPLITK_TILES, tuning knob)
+  if (tiles_gate < 0) { const char* e = getenv("CTTA_SPLITK_TILES"); tiles_gate = e ? atoi(e) : 192; }
   if (splitk_default() && groups == 1 && !scalar_store && !geglu && d->out_limit == 0 && d->out_offset == 0 &&
-      tiles < 192 && p.nk >= 32 && (ws = splitk_workspace(&ws_bytes)) != nullptr) {
+      tiles < tiles_gate && p.nk >= 32 && (ws = splitk_workspace(&ws_bytes)) != nullptr) {
     static int target = -1, cap = -1;   // tuning knobs: workgroups aimed for / most splits
     if (target < 0) { const char* e = getenv("CTTA_SPLITK_TARGET"); target = e ? atoi(e) : 512; }
     if (cap < 0) { const char* e = getenv("CTTA_SPLITK_MAX"); cap = e ? atoi(e) : 8; }
