@@ -394,12 +394,20 @@ def main():
         import gc
         gc.collect()
         torch.cuda.empty_cache()
-        d = distill_leg(args, dev, world, rank)
+        # a leg that fails the same way on every rank (an allocator or collective set-up error) must not cost the headline
+        # line; a ONE-sided failure inside a collective cannot be caught here (the other ranks wait in the all-reduce)
+        try:
+            d = distill_leg(args, dev, world, rank)
+        except Exception as exc:
+            d = {"error": str(exc)[:300]}
         if rank == 0:
             result["distill"] = d
         gc.collect()
         torch.cuda.empty_cache()
-        t = teacher_leg(args, dev, world, rank)
+        try:
+            t = teacher_leg(args, dev, world, rank)
+        except Exception as exc:
+            t = {"error": str(exc)[:300]}
         if rank == 0:
             result["teacher"] = t
         gc.collect()
