@@ -422,15 +422,32 @@ class EvaluationHelper:
         out.update(calculate_fid(featuresdict_1, featuresdict_2, feat_layer_name="2048"))
         return {key: round(out.get(key, float("nan")), 4) for key in self.KEYS}
 
-    def clap_scores(self, gt_items, gen_items, captions):
-        """eval.py:29-55,238-253: clamped cosine similarities of CLAP embeddings (16 kHz waveforms resampled to the
-        tower's 48 kHz by the caller's CLAP_Module), x 100."""
+    def _clap_wave(self, w, seconds=10.0):
+        """What `T2APairedDataset` hands the CLAP tower (tools/t2a_dataset.py:111-125 -> tools/torch_tools.py:54-75): the clip at
+        48 kHz, mean removed, scaled to peak 0.5, cut / zero-padded to the segment length, scaled again.  The reference
+        resamples with `resampy` (kaiser_best), which is not in its tree; here the Kaiser-windowed sinc resampler of the CLAP loss
+        (tools/losses.py:299-303 = `clap.Resampler`) does it -- a stated deviation of the filter, not of the pipeline."""
+        from .clap import Resampler
+        w = w.reshape(1, -1).float().to(self.device)
+        if self.sampling_rate != 48000:
+            if getattr(self, "_to48k", None) is None:
+                self._to48k = Resampler(orig_freq=self.sampling_rate, new_freq=48000)
+            w = self._to48k(w)
+        w = w - w.mean()
+        w = w / (w.abs().max() + 1e-8) / 2
+        seg = int(round(seconds * 48000))
+        w = w[:, :seg] if w.shape[1] >= seg else torch.nn.functional.pad(w, (0, seg - w.shape[1]))
+        return w / (w.abs().max() + 1e-8) / 2
+
+    def clap_scores(self, gt_items, gen_items, captions, seconds=10.0):
+        """eval.py:29-55,238-253: clamped cosine similarities of CLAP embeddings (audio at 48 kHz as `_clap_wave` prepares
+        it, captions through the text tower), x 100."""
         cos = torch.nn.functional.cosine_similarity
         sims = {"gt_text": [], "gen_text": [], "gen_gt": []}
         with torch.no_grad():
             for (gw, name), (xw, _) in zip(gt_items, gen_items):
-                g = self.clap_model.get_audio_embedding_from_data(x=gw.float().to(self.device), use_tensor=True)
-                x = self.clap_model.get_audio_embedding_from_data(x=xw.float().to(self.device), use_tensor=True)
+                g = self.clap_model.get_audio_embedding_from_data(x=self._clap_wave(gw, seconds), use_tensor=True)
+                x = self.clap_model.get_audio_embedding_from_data(x=self._clap_wave(xw, seconds), use_tensor=True)
                 t = self.clap_model.get_text_embedding([captions[name]], use_tensor=True)
                 sims["gt_text"].append(cos(g, t, dim=1).clamp(min=0))
                 sims["gen_text"].append(cos(x, t, dim=1).clamp(min=0))

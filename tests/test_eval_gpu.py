@@ -143,3 +143,42 @@ def test_evaluation_helper_end_to_end(golden, tmp_path):
     os.remove(str(gen_dir / "clip_00.wav"))
     with pytest.raises(ValueError):
         helper.main(str(gen_dir), str(gt_dir))
+
+
+def test_clap_scores_feed_the_tower_what_the_reference_dataset_does(golden):
+    """EvaluationHelper.clap_scores (eval.py:29-55,238-253): every clip reaches the CLAP tower as `read_wav_file` prepares it
+    (tools/torch_tools.py:54-75: 48 kHz, mean removed, peak 0.5, 10 s segment, peak 0.5 again) and the three scores are the
+    clamped cosines x 100; checked with a stand-in tower that records its inputs and embeds by simple statistics."""
+    m, _ = _model(golden("eval_suite"))
+    seen = []
+
+    class Tower:
+        def get_audio_embedding_from_data(self, x, use_tensor=False):
+            assert use_tensor and x.is_cuda
+            seen.append(x)
+            f = x.reshape(1, 100, -1)
+            return torch.nn.functional.normalize(f.abs().mean(2) + f.std(2), dim=-1)
+
+        def get_text_embedding(self, texts, use_tensor=False):
+            gen = torch.Generator().manual_seed(len(texts[0]))
+            return torch.nn.functional.normalize(torch.rand(1, 100, generator=gen), dim=-1).to(DEV)
+
+    helper = E.EvaluationHelper(16000, DEV, mel_model=m, clap_model=Tower())
+    gt = [(cases.eval_waves("evalsuite.cs.gt", 1, 32000)[0:1], "a.wav"), (cases.eval_waves("evalsuite.cs.gt2", 1, 200000)[0:1], "b.wav")]
+    gen = [(cases.eval_waves("evalsuite.cs.gen", 1, 32000)[0:1], "a.wav"), (cases.eval_waves("evalsuite.cs.gen2", 1, 160000)[0:1], "b.wav")]
+    res = helper.clap_scores(gt, gen, {"a.wav": "a dog barks", "b.wav": "rain on a roof"})
+    assert set(res) == {"gt_text_clap_score", "gen_text_clap_score", "gen_gt_clap_score"}
+    assert all(0.0 <= v <= 100.0 for v in res.values()) and res["gen_gt_clap_score"] > 50.0
+    assert len(seen) == 4
+    for x in seen:
+        assert tuple(x.shape) == (1, 480000) and abs(float(x.abs().max()) - 0.5) < 1e-4
+    # the 2 s clips are zero-padded behind 96 000 samples, the 12.5 s clip is cut at 10 s
+    assert float(seen[0][0, 96100:].abs().max()) == 0.0 and float(seen[2][0, -100:].abs().max()) > 0.0
+    # against a direct evaluation of the same recipe
+    w = helper._clap_wave(gen[0][0])
+    ref = torch.nn.functional.cosine_similarity(Tower().get_audio_embedding_from_data(w, True),
+                                                Tower().get_text_embedding(["a dog barks"], True), dim=1).clamp(min=0)
+    w2 = helper._clap_wave(gen[1][0])
+    ref2 = torch.nn.functional.cosine_similarity(Tower().get_audio_embedding_from_data(w2, True),
+                                                 Tower().get_text_embedding(["rain on a roof"], True), dim=1).clamp(min=0)
+    assert abs(res["gen_text_clap_score"] - float((ref + ref2) / 2) * 100.0) < 1e-3
