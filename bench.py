@@ -568,17 +568,21 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     # with the same draws).  With a process group the block-wise all-reduce must interleave with the backward, so the
     # data-parallel step stays eager; both rates are reported.
     dt_eager, launch_mode = dt, "eager launches (two streams + weight-gradient side stream)"
-    if world == 1 and not perceptual and os.environ.get("CTTA_BENCH_GRAPH", "1") != "0" and not args.no_latency:
-        try:
-            gdr = torch.Generator().manual_seed(77)
-            kw = dict(time_inds=torch.randint(0, 17, (B,), generator=gdr) * 2,
-                      gaussian_noise=torch.randn(B, 8, 256, 16, generator=gdr).to(dev), guidance_scale=torch.rand(B, generator=gdr) * 6)
-            gs = m.capture_train_graph(opt, z0, P, **kw)
+    dt_seg = None
+    if not perceptual and os.environ.get("CTTA_BENCH_GRAPH", "1") != "0" and not args.no_latency:
+        gdr = torch.Generator().manual_seed(77 + rank)
+        kw = dict(time_inds=torch.randint(0, 17, (B,), generator=gdr) * 2,
+                  gaussian_noise=torch.randn(B, 8, 256, 16, generator=gdr).to(dev), guidance_scale=torch.rand(B, generator=gdr) * 6)
+
+        def timed_graph(segmented):
+            """Capture, check one replay against an eager forward with the same draws, time n_steps public steps.  Every
+            rank runs the same sequence (the segmented step issues the bucket all-reduces between its replays)."""
+            gs = m.capture_train_graph(opt, z0, P, segmented=segmented, **kw)
             with torch.no_grad():
                 loss_e = float(m._forward_impl(z0, None, P, False, True, kw["time_inds"], kw["gaussian_noise"],
                                                kw["guidance_scale"], True)[0])
             gs._refresh(z0, kw["time_inds"], kw["gaussian_noise"], kw["guidance_scale"])
-            gs.graph.replay()
+            gs.replay()
             loss_g = float(gs.loss.item())
             opt.zero_grad()
             assert loss_g == loss_e, "hipGraph replay of the distillation step differs from the eager step (%r vs %r)" % (loss_g, loss_e)
@@ -589,23 +593,41 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             for _ in range(n_steps):
                 losses.append(gs.step(z0, sched))
             du.barrier(dev)
-            dt = du.max_over_ranks(time.perf_counter() - t0, dev)
-            launch_mode = "one hipGraph replay per micro-step (forward + backward + loss) + eager AdamW / zero_grad / EMA"
-            del gs
-        except Exception as exc:   # a failed capture must not cost the line
-            launch_mode = "eager launches (graph capture failed: %s)" % str(exc)[:160]
-            dt = dt_eager
+            return du.max_over_ranks(time.perf_counter() - t0, dev)
+        # a capture can fail on one rank only; the ranks then agree (MAX over an error flag) before anyone enters the
+        # collectives of the segmented step alone
+        def all_ok(ok):
+            return du.max_over_ranks(0.0 if ok else 1.0, dev) == 0.0
+        try:
+            dt_seg = timed_graph(True)
+            launch_seg = ("%d hipGraph replays per micro-step (forward + loss + out head | one graph per backward block, bucket "
+                          "all-reduce issued between replays) + eager AdamW / zero_grad / EMA" % 12)
+            if world > 1:
+                dt, launch_mode = dt_seg, launch_seg
+        except Exception as exc:
+            if world > 1:
+                raise       # the other ranks are inside the same collectives: failing loudly beats a hang
+            launch_mode = "eager launches (segmented graph capture failed: %s)" % str(exc)[:160]
+        if world == 1:
+            try:
+                dt = timed_graph(False)
+                launch_mode = "one hipGraph replay per micro-step (forward + backward + loss) + eager AdamW / zero_grad / EMA"
+            except Exception as exc:   # a failed capture must not cost the line
+                launch_mode = "eager launches (graph capture failed: %s)" % str(exc)[:160]
+                dt = dt_eager
     assert all(v == v for v in losses), "NaN distillation loss"
     out = {
         "metric": "distillation_steps_per_sec", "value": round(n_steps / dt, 4), "unit": "optimizer steps/s",
         "samples_per_s": round(world * B * n_steps / dt, 3), "ms_per_step": round(dt / n_steps * 1e3, 3),
         "steps": n_steps, "warmup": n_warm,
         "eager_ms_per_step": round(dt_eager / n_steps * 1e3, 3),
+        "segmented_ms_per_step": None if dt_seg is None else round(dt_seg / n_steps * 1e3, 3),
         "n_gpus": world, "scaling": "weak", "dtype": "bf16 (fp32 master weights, gradients, AdamW moments)",
         "config": {"workload": "configs[3]: consistency distillation step, light U-Net x4 (teacher, student, target, EMA), "
                                "2 CFG teacher queries + Heun, SNR-MSE loss, backward, AdamW, EMA 0.95/0.999",
                    "batch_per_gpu": B, "global_batch": B * world, "text_len": L, "latent": [8, 256, 16],
-                   "launch": launch_mode, "grad_accum": 1, "gradient_allreduce": "fp32 SUM over RCCL, %d MiB buckets" % 256 if world > 1 else "none (1 GPU)",
+                   "launch": launch_mode, "grad_accum": 1, "gradient_allreduce": ("fp32 SUM over RCCL, one asynchronous collective per finished backward block, blocks merged to >= 16 M "
+                                          "elements (64 MiB), overlapped with the rest of the backward") if world > 1 else "none (1 GPU)",
                    "parallelism": "dp%d" % world},
         "loss_first_last": [round(losses[0], 6), round(losses[-1], 6)], "build_s": round(build_s, 1),
     }

@@ -81,3 +81,31 @@ extern "C" ctta_status ctta_prof_collect(int kind, double* total_ms, double* tot
   if (launches) *launches = cnt;
   return CTTA_OK;
 }
+
+// Zero-fill as a KERNEL.  hipMemsetAsync becomes a memset node under stream capture, and on this ROCm (7.0 runtime) a
+// replayed memset node was observed to run out of order with its neighbour kernels in small graphs: the segmented
+// distillation-step capture got garbage in exactly the gradients behind memset + atomicAdd buffers (tools/dbg_seg.py).
+// Everything the engines zero on a capturable path goes through here.
+__global__ void ctta_zero_kernel(uint4* __restrict__ p, size_t n16, unsigned char* __restrict__ tail, int ntail) {
+  const uint4 z = {0u, 0u, 0u, 0u};
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
+  if (blockIdx.x == 0 && (int)threadIdx.x < ntail) tail[threadIdx.x] = 0;
+}
+hipError_t ctta_zero_async(void* ptr, size_t bytes, hipStream_t s) {
+  if (!bytes) return hipSuccess;
+  unsigned char* b = (unsigned char*)ptr;
+  const size_t head = (16 - ((uintptr_t)b & 15)) & 15;
+  if (head >= bytes || head) {                      // unaligned start (never the case for arena / tensor memory)
+    const size_t h = head < bytes ? head : bytes;
+    hipLaunchKernelGGL(ctta_zero_kernel, dim3(1), dim3(64), 0, s, (uint4*)nullptr, (size_t)0, b, (int)h);
+    b += h; bytes -= h;
+    if (!bytes) return hipGetLastError();
+  }
+  const size_t n16 = bytes / 16;
+  const int ntail = (int)(bytes - n16 * 16);
+  size_t blocks = (n16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(ctta_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (uint4*)b, n16, b + n16 * 16, ntail);
+  return hipGetLastError();
+}

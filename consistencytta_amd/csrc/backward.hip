@@ -11,6 +11,7 @@
 #include "common.h"
 
 #include <map>
+#include <vector>
 #include <mutex>
 #include <utility>
 
@@ -1002,7 +1003,11 @@ static float* ln_bwd_workspace(hipStream_t s, size_t bytes) {
   float* q = nullptr;
   const size_t want = bytes < ((size_t)8 << 20) ? ((size_t)8 << 20) : bytes;
   if (hipMalloc((void**)&q, want) != hipSuccess) return nullptr;
-  if (w.p) { (void)hipStreamSynchronize(s); (void)hipFree(w.p); }
+  // The outgrown block is RETIRED, never freed: a captured hipGraph may hold its address as ln_bwd_kernel's `part` table,
+  // and torch hands pooled stream handles out again, so "this stream's previous table" can belong to a graph that is
+  // still replayed.  Tables are <= 64 MB and grow a handful of times per process.
+  static std::vector<float*> retired;
+  if (w.p) retired.push_back(w.p);
   w.p = q; w.bytes = want;
   return w.p;
 }
@@ -1278,7 +1283,7 @@ extern "C" ctta_status ctta_linear_f32_bwd(const float* x, const float* w, const
   hipStream_t s = (hipStream_t)stream;
   if (dx) {
     CTTA_REQUIRE(!(accumulate_dx && xpre_silu), "linear_f32_bwd: accumulate_dx with a SiLU pre-activation is not supported");
-    if (!accumulate_dx) CTTA_CHECK_HIP(hipMemsetAsync(dx, 0, (size_t)m * k * sizeof(float), s));
+    if (!accumulate_dx) CTTA_CHECK_HIP(ctta_zero_async(dx, (size_t)m * k * sizeof(float), s));
     int chunks = (n + 255) / 256;
     if (chunks > 64) chunks = 64;
     const int n_chunk = (n + chunks - 1) / chunks;

@@ -95,6 +95,7 @@ bool ctta_gn_fuse_on();
 unsigned long long* ctta_debug_stamps_current();   // ctta_conv_debug_stamps' buffer of this host thread (or null)
 void ctta_prof_begin(int kind, int variant, long long m, long long n, long long k, long long groups, hipStream_t s);
 void ctta_prof_end(hipStream_t s);
+hipError_t ctta_zero_async(void* ptr, size_t bytes, hipStream_t s);   // zero-fill kernel (no memset nodes in hipGraphs)
 
 #define CTTA_CHECK_HIP(expr)                                                         \
   do {                                                                               \

@@ -215,7 +215,7 @@ static ctta_status t5_forward_impl(ctta_t5* T, bool dry, const int64_t* ids, con
     hipLaunchKernelGGL(t5_mask_bias_kernel, dim3((B * L + 255) / 256), dim3(256), 0, stream, mask, B * L, kbias);
     CTTA_LAUNCH_CHECK();
     // pad rows of att are never written by the attention kernel but are read (and ignored) by the o-projection
-    CTTA_CHECK_HIP(hipMemsetAsync(att, 0, (size_t)M * inner * sizeof(bf16_t), stream));
+    CTTA_CHECK_HIP(ctta_zero_async(att, (size_t)M * inner * sizeof(bf16_t), stream));
   }
   for (int i = 0; i < cfg.num_layers; ++i) {
     const T5Block& Bk = T->blocks[i];

@@ -835,7 +835,7 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
       st = CTTA_ERR_NOMEM;
     } else {
       U->gn_scratch_floats = gn_need + 64;
-      if (hipMemsetAsync(U->arena.base, 0, bytes, s) != hipSuccess) st = CTTA_ERR_HIP;
+      if (ctta_zero_async(U->arena.base, bytes, s) != hipSuccess) st = CTTA_ERR_HIP;
       if (st == CTTA_OK) st = U->splitws.init();
     }
   }

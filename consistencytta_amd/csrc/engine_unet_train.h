@@ -364,8 +364,8 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
     bf16_t* dk = A.get<bf16_t>(kv); ALLOC_OR_FAIL(dk);
     bf16_t* dv = A.get<bf16_t>(kv); ALLOC_OR_FAIL(dv);
     if (!c.dry) {   // rows of padded text positions are never written by the per-head GEMMs
-      CTTA_CHECK_HIP(hipMemsetAsync(dk, 0, kv * sizeof(bf16_t), c.stream));
-      CTTA_CHECK_HIP(hipMemsetAsync(dv, 0, kv * sizeof(bf16_t), c.stream));
+      CTTA_CHECK_HIP(ctta_zero_async(dk, kv * sizeof(bf16_t), c.stream));
+      CTTA_CHECK_HIP(ctta_zero_async(dv, kv * sizeof(bf16_t), c.stream));
     }
     CTTA_TRY(bwd_attention(c, T.heads, T.dh, S.q2, hp, S.k2, hp, Lp, S.vt2, Lp, c.mask_bias, N, c.L, S.att2, datt, hp, S.lse2,
                            dq, hp, dk, hp, dv));
@@ -500,6 +500,14 @@ static ctta_status unet_backward_next_impl(ctta_unet* U, bool dry, const GradTab
   Arena& A = U->arena;
   BCtx c;
   bctx_init(c, U, dry, grads, stream);
+  if (!dry) {
+    // begin / every earlier next ended with wg_join on this stream: no scratch slot is in use any more, and the `freed`
+    // events of the previous call must not be waited on when this call is captured into its OWN hipGraph (segmented
+    // capture of the data-parallel step: they were recorded in another capture).
+    ctta_unet::WgradSide& Wg = U->wg;
+    if (!Wg.dirty && Wg.joined_on == stream)
+      for (int i = 0; i < ctta_unet::WgradSide::NS; ++i) Wg.in_use[i] = false;
+  }
   const int B = S.B;
   bf16_t* dh = U->bw.dh;
   std::vector<bf16_t*>& dskip = U->bw.dskip;

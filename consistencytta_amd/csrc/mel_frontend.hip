@@ -353,7 +353,7 @@ extern "C" ctta_status ctta_wav_to_logmel_db_bwd(ctta_mel_frontend* M, const flo
     CTTA_CHECK_HIP(hipMalloc((void**)&M->dft, rows * M->kpad * 2));
     CTTA_CHECK_HIP(hipMalloc((void**)&M->dframes, rows * N * 4));
     CTTA_CHECK_HIP(hipMalloc((void**)&M->basis_t, (size_t)N * M->kpad * 2));
-    CTTA_CHECK_HIP(hipMemsetAsync(M->basis_t, 0, (size_t)N * M->kpad * 2, s));
+    CTTA_CHECK_HIP(ctta_zero_async(M->basis_t, (size_t)N * M->kpad * 2, s));
     // basis_t[n][r] = basis[r][n] (leading bf16 part), r < 2*cutoff
     CTTA_TRY(ctta_transpose_bf16(M->b[0], 0, 2 * cutoff, N, N, 0, M->basis_t, 0, M->kpad, 1, s));
   }

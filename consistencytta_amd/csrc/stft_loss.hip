@@ -219,7 +219,7 @@ extern "C" ctta_status ctta_stft_magnitude_bwd(ctta_stft* S, const float* dmag, 
     CTTA_CHECK_HIP(hipMalloc((void**)&S->dft, rmax * S->kpad * 2));
     CTTA_CHECK_HIP(hipMalloc((void**)&S->dframes, rmax * N * 4));
     CTTA_CHECK_HIP(hipMalloc((void**)&S->basis_t, (size_t)N * S->kpad * 2));
-    CTTA_CHECK_HIP(hipMemsetAsync(S->basis_t, 0, (size_t)N * S->kpad * 2, s));
+    CTTA_CHECK_HIP(ctta_zero_async(S->basis_t, (size_t)N * S->kpad * 2, s));
     CTTA_TRY(ctta_transpose_bf16(S->b[0], 0, 2 * cutoff, N, N, 0, S->basis_t, 0, S->kpad, 1, s));
   }
   const long long total = rows * S->kpad;

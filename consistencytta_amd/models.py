@@ -905,15 +905,26 @@ class _DistillStepGraph:
     before the replay -- the latents, the noise, the guidance scales, the two timestep vectors and the eight per-sample
     sigma vectors the Heun scheduler's methods look up (computed by the scheduler's own host logic, `_sigma_plan`, in the
     order `_forward_impl` calls them) -- and the networks whose weights change every step (student after AdamW, target after
-    the EMA) have their bf16 re-pack captured at the head of their forward.  Single-process only: with a process group
-    the block-wise gradient all-reduce must interleave with the backward (`train_step`), which a replay cannot do.
+    the EMA) have their bf16 re-pack captured at the head of their forward.
     Results are bit-identical to the eager `train_step` (same kernels, same arguments; asserted by
-    tests/test_train_gpu.py and by bench.py before it times the replays)."""
+    tests/test_train_gpu.py and by bench.py before it times the replays).
 
-    def __init__(self, model, optimizer, z_shape, P):
+    `segmented=True` is the form the DATA-PARALLEL step runs (tools/train_utils.py:152-183 under accelerate's DDP): the
+    sequence is captured as 1 + n hipGraphs -- forward, loss, d loss / d pred and the out head of the backward, then one
+    graph per remaining block of the block-wise backward (`ctta_unet_backward_next`: every call joins its weight-gradient
+    side stream before it returns, so each is a closed sub-sequence).  `step` replays them in order and hands every
+    finished block to `dist_util.GradientBuckets` between two replays, so the bucketed asynchronous all-reduce (RCCL on
+    its own stream) overlaps the blocks still to come exactly as in the eager `train_step`; the graphs share one memory
+    pool and the engine's arena, so the kernels and their arguments are those of the monolithic capture."""
+
+    def __init__(self, model, optimizer, z_shape, P, segmented=False, accumulation_steps=1):
         assert model.loss is None, "the captured step covers the latent-space loss (loss_type='mse')"
         assert model.training and model.use_teacher_cf_guidance
         self.m, self.opt = model, optimizer
+        self.segmented = bool(segmented)
+        self.accum = max(1, int(accumulation_steps))
+        self.segments = []       # [(graph, block id it completes)]
+        self._micro = 0
         dev = model.device
         B = z_shape[0]
         self.B, self.dev = B, dev
@@ -957,7 +968,11 @@ class _DistillStepGraph:
         else:
             inds = torch.randint(0, (len(avail) - 1) // order, (B,)) * order
         noise = gaussian_noise if gaussian_noise is not None else torch.randn_like(z_0)
-        if guidance_scale is None:
+        if m.teacher_guidance_scale != -1:
+            # a fixed teacher scale conditions student and target on that same w (`_forward_impl`: guidance_scale = None
+            # -> w = float(teacher_guidance_scale)); `_query_teacher` uses the fixed scale by itself
+            guidance_scale = torch.full((B,), float(m.teacher_guidance_scale))
+        elif guidance_scale is None:
             guidance_scale = torch.rand(B) * m.max_rand_guidance_scale
         t_np1, t_n, plan = self._sigma_plan(inds.numpy())
         host = self._pinned
@@ -976,6 +991,11 @@ class _DistillStepGraph:
 
     # -- device side: `_forward_impl` (training branch) + `_student_backward`, on static tensors only
     def _body(self):
+        out, pred, target, s_loss, gamma = self._forward_part()
+        self.m._student_backward(pred, target, s_loss, gamma, 1.0 / self.accum, None)
+        return out
+
+    def _forward_part(self):
         m, B, dev = self.m, self.B, self.dev
         sch = m.noise_scheduler
         L_ = N.lib()
@@ -1002,12 +1022,13 @@ class _DistillStepGraph:
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 side_pred = m.student_unet.forward_train(z_np1_scaled, self.t_np1, w, embeds, mask)
-        v1 = m._query_teacher(z_np1_scaled, self.t_np1, embeds_cf, mask_cf, w, reuse_text=False)
+        w_t = w if m.teacher_guidance_scale == -1 else None      # None: `_query_teacher` takes the model's fixed scale
+        v1 = m._query_teacher(z_np1_scaled, self.t_np1, embeds_cf, mask_cf, w_t, reuse_text=False)
         zhat = torch.empty_like(z0)
         deriv = torch.empty_like(z0)
         N.check(L_.ctta_heun_step_first(N.ptr(v1.contiguous()), N.ptr(z_np1), N.ptr(s_add), N.ptr(s_next1), N.ptr(zhat),
                                         N.ptr(deriv), B, n, N.stream_ptr()))
-        v2 = m._query_teacher(scale(zhat, s_scale2), self.t_n, embeds_cf, mask_cf, w, reuse_text=True)   # K / V of query 1
+        v2 = m._query_teacher(scale(zhat, s_scale2), self.t_n, embeds_cf, mask_cf, w_t, reuse_text=True)   # K / V of query 1
         zhat2 = torch.empty_like(z0)
         N.check(L_.ctta_heun_step_second(N.ptr(v2.contiguous()), N.ptr(zhat), N.ptr(z_np1), N.ptr(deriv), N.ptr(s_prev2),
                                          N.ptr(s_cur2), N.ptr(zhat2), B, n, N.stream_ptr()))
@@ -1024,7 +1045,30 @@ class _DistillStepGraph:
         out = torch.empty(1, dtype=torch.float32, device=dev)
         N.check(L_.ctta_snr_mse_loss(N.ptr(pred.contiguous()), N.ptr(target), N.ptr(s_loss), float(gamma), N.ptr(inst),
                                      N.ptr(out), B, pred[0].numel(), N.stream_ptr()))
-        m._student_backward(pred, target, s_loss, gamma, 1.0, None)
+        return out, pred, target, s_loss, gamma
+
+    def _capture_segments(self, warm):
+        """forward + loss + out head | one graph per backward block, all in one memory pool."""
+        m = self.m
+        unet = m.student_unet
+        pool = torch.cuda.graph_pool_handle()
+        kw = dict(pool=pool, stream=warm, capture_error_mode="thread_local")
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, **kw):
+            out, pred, target, s_loss, gamma = self._forward_part()
+            Bn, C, H, W = pred.shape
+            d = torch.empty(Bn, H * W, 8, dtype=torch.bfloat16, device=pred.device)
+            N.check(N.lib().ctta_snr_mse_grad(N.ptr(pred), N.ptr(target), N.ptr(s_loss), float(gamma), 1.0 / self.accum,
+                                              Bn, C, H * W, 8, N.ptr(d), N.stream_ptr()))
+            first = unet.backward_begin(d)
+        self._keep = (pred, target, d)        # read by the later graphs: their pool blocks must stay allocated
+        self.segments = [(self.graph, first)]
+        fin = False
+        while not fin:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, **kw):
+                blk, fin = unet.backward_next()
+            self.segments.append((g, blk))
         return out
 
     def capture(self, z_0, time_inds=None, gaussian_noise=None, guidance_scale=None):
@@ -1041,21 +1085,57 @@ class _DistillStepGraph:
             torch.cuda.synchronize(self.dev)
             for net in (m.student_unet, m.student_target_unet):   # their bf16 re-pack belongs to every replay
                 net._h_version = None
-            self.graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph, stream=warm, capture_error_mode="thread_local"):
-                self.loss = self._body()
+            if self.segmented:
+                self.loss = self._capture_segments(warm)
+            else:
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=warm, capture_error_mode="thread_local"):
+                    self.loss = self._body()
         self.opt.zero_grad()
         return self
 
+    def replay(self, on_block_done=None):
+        """The device work of one micro-step.  Segmented: `on_block_done(block id)` runs between two replays, when that
+        block's gradients are final on the stream (what `ctta_unet_backward_next` reports to `train_step`)."""
+        if not self.segmented:
+            self.graph.replay()
+            return
+        for g, blk in self.segments:
+            g.replay()
+            if on_block_done is not None:
+                on_block_done(blk)
+
     def step(self, z_0, lr_scheduler=None, time_inds=None, gaussian_noise=None, guidance_scale=None, skip_nan=True):
-        """`AudioLCM.train_step` with accumulation_steps = 1 on one process: refresh the static inputs, ONE replay, then the
-        eager tail (AdamW, LR schedule, zero_grad, EMA).  Returns the loss as a Python float."""
+        """`AudioLCM.train_step`: refresh the static inputs, replay, then -- on every `accumulation_steps`-th call -- the
+        eager tail (gradient all-reduce joined, AdamW, LR schedule, zero_grad, EMA).  With a process group the capture
+        must be `segmented` so that the all-reduce of a finished block is issued before the next block's replay.
+        Returns the (unscaled) loss as a Python float."""
         m = self.m
         self._refresh(z_0, time_inds, gaussian_noise, guidance_scale)
-        self.graph.replay()
+        self._micro += 1
+        if self._micro % self.accum != 0:      # DDP's no_sync: gradients only accumulate locally
+            self.replay()
+            return float(self.loss.item())
+        buckets = dist_util.GradientBuckets(self.opt.grad, m.student_unet.block_ranges(),
+                                            compress=getattr(m, "allreduce_dtype", None))
+        if buckets.enabled and not self.segmented:
+            raise N.CttaError("a monolithic step graph cannot interleave the gradient all-reduce with the backward pass: "
+                              "capture with segmented=True under a process group")
+        if not buckets.enabled:
+            self.replay()
+            nan_any = dist_util.AnyRankFlag(torch.isnan(self.loss))
+        else:
+            g0, first = self.segments[0]
+            g0.replay()
+            nan_any = dist_util.AnyRankFlag(torch.isnan(self.loss))     # all ranks skip together (or none)
+            buckets.ready(first)
+            for g, blk in self.segments[1:]:
+                g.replay()
+                buckets.ready(blk)
+        world = buckets.wait()
         value = float(self.loss.item())
-        if not (skip_nan and value != value):
-            self.opt.step(grad_scale=1.0)
+        if not (skip_nan and nan_any.result()):
+            self.opt.step(grad_scale=1.0 / world)
             if lr_scheduler is not None:
                 lr_scheduler.step()
         self.opt.zero_grad()
@@ -1063,16 +1143,19 @@ class _DistillStepGraph:
         return value
 
 
-def _capture_train_graph(self, optimizer, z_0, prompt, **draws):
-    """hipGraph-captured distillation step (single process, loss_type='mse'): returns a `_DistillStepGraph` whose
+def _capture_train_graph(self, optimizer, z_0, prompt, segmented=None, accumulation_steps=1, **draws):
+    """hipGraph-captured distillation step (loss_type='mse'): returns a `_DistillStepGraph` whose
     `.step(z_0, lr_scheduler, ...)` replaces `train_step(z_0, prompt, optimizer, lr_scheduler, ...)` for fixed shapes and a
-    fixed prompt batch (`prompt` must be the dict of pre-computed text states; refresh `graph.P[...]` in place to change them)."""
-    if dist_util.dist.is_initialized() and dist_util.dist.get_world_size() > 1:
-        raise N.CttaError("capture_train_graph is single-process: the data-parallel step overlaps its gradient all-reduce "
-                          "with the backward pass block by block (train_step), which a graph replay cannot do")
+    fixed prompt batch (`prompt` must be the dict of pre-computed text states; refresh `graph.P[...]` in place to change them).
+    `segmented` (default: whenever a process group with more than one rank exists) captures the backward block by block
+    so that the data-parallel gradient all-reduce overlaps it as in the eager `train_step`."""
+    if segmented is None:
+        segmented = (dist_util.dist.is_initialized() and dist_util.dist.get_world_size() > 1) or \
+            os.environ.get("CTTA_FORCE_COLLECTIVES", "0") == "1"
     if not isinstance(prompt, dict):
         raise N.CttaError("capture_train_graph needs the pre-computed text states (dict), not prompt strings")
-    return _DistillStepGraph(self, optimizer, tuple(z_0.shape), prompt).capture(z_0, **draws)
+    return _DistillStepGraph(self, optimizer, tuple(z_0.shape), prompt, segmented=segmented,
+                             accumulation_steps=accumulation_steps).capture(z_0, **draws)
 
 
 AudioLCM.capture_train_graph = _capture_train_graph

@@ -386,6 +386,21 @@ class _UNetBase(_ParamTree):
             g = torch.zeros(B, H * W, 8, dtype=torch.bfloat16, device=dev)
             g[:, :, :C] = grad_output.detach().to(dev).permute(0, 2, 3, 1).reshape(B, H * W, C).to(torch.bfloat16)
             grad_output_nhwc = g
+        tab, keep = self._grad_table()
+        g = grad_output_nhwc.contiguous()
+        with torch.cuda.device(dev):
+            if on_block_done is None:
+                N.check(N.lib().ctta_unet_backward(self._h_unet, N.ptr(g), tab, len(tab), N.stream_ptr()))
+                return
+        # block-wise: after each step the gradients of one block are final; the callback typically starts
+        # the all-reduce of that block's slice of the flat gradient buffer (dist_util.GradientBuckets)
+        on_block_done(self.backward_begin(g))
+        fin = False
+        while not fin:
+            blk, fin = self.backward_next()
+            on_block_done(blk)
+
+    def _grad_table(self):
         table = OrderedDict()
         if getattr(self, "_flat_grad", None) is not None and not self.grads_alias_flat():
             self.realias_grads_()    # e.g. after zero_grad(set_to_none=True): the fused optimizer reads the flat buffer
@@ -395,22 +410,24 @@ class _UNetBase(_ParamTree):
             if p.grad is None:
                 p.grad = torch.zeros_like(p.data)
             table[k] = p.grad
-        tab, keep = N.tensor_table(table)
-        g = grad_output_nhwc.contiguous()
-        with torch.cuda.device(dev):
-            if on_block_done is None:
-                N.check(N.lib().ctta_unet_backward(self._h_unet, N.ptr(g), tab, len(tab), N.stream_ptr()))
-                return
-            # block-wise: after each step the gradients of one block are final; the callback typically starts
-            # the all-reduce of that block's slice of the flat gradient buffer (dist_util.GradientBuckets)
-            L_ = N.lib()
-            n_levels = len(self._cfg["block_out_channels"])
-            N.check(L_.ctta_unet_backward_begin(self._h_unet, N.ptr(g), tab, len(tab), N.stream_ptr()))
-            on_block_done(2 * n_levels + 2)
-            blk, fin = N.c_int(0), N.c_int(0)
-            while not fin.value:
-                N.check(L_.ctta_unet_backward_next(self._h_unet, tab, len(tab), N.stream_ptr(), N.byref(blk), N.byref(fin)))
-                on_block_done(blk.value)
+        return N.tensor_table(table)
+
+    def backward_begin(self, grad_output_nhwc):
+        """First step of the block-wise backward (ctta_unet_backward_begin): the out head.  Returns its block id.  Each
+        begin / next call is self-contained on the calling stream (the weight-gradient side stream is joined before it
+        returns), so a caller may capture every call into its own hipGraph (`_DistillStepGraph(segmented=True)`)."""
+        tab, keep = self._grad_table()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ctta_unet_backward_begin(self._h_unet, N.ptr(grad_output_nhwc), tab, len(tab), N.stream_ptr()))
+        return 2 * len(self._cfg["block_out_channels"]) + 2
+
+    def backward_next(self):
+        """One more block (ctta_unet_backward_next) -> (block id, finished)."""
+        tab, keep = self._grad_table()
+        blk, fin = N.c_int(0), N.c_int(0)
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ctta_unet_backward_next(self._h_unet, tab, len(tab), N.stream_ptr(), N.byref(blk), N.byref(fin)))
+        return blk.value, bool(fin.value)
 
     def block_ranges(self):
         """block id (see ctta_unet_backward_next) -> (start, end) element range of that block's parameters in the

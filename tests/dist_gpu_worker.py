@@ -57,10 +57,18 @@ def shard(P, z0, draws, lo, hi, dev):
     return Ps, z0[lo:hi].to(dev), kw
 
 
-def run_step(m, Ps, z, kw, lr=1e-4, compress=None):
-    """One train_step; returns (loss, the all-reduced flat gradient AdamW consumed x 1/world, flat params after)."""
+def run_step(m, Ps, z, kw, lr=1e-4, compress=None, graph=False):
+    """One train_step (graph=True: the segmented hipGraph replay of it, `capture_train_graph`); returns (loss, the
+    all-reduced flat gradient AdamW consumed x 1/world, flat params after)."""
     opt = m.prepare_training(lr=lr, weight_decay=0.0, broadcast=True)
     m.allreduce_dtype = compress
+    gs = None
+    if graph:   # captured with OTHER draws than the step's: the replay must pick up the refreshed static tensors
+        g = torch.Generator().manual_seed(5)
+        gs = m.capture_train_graph(opt, z, Ps, time_inds=torch.randint(0, 17, (z.shape[0],), generator=g) * 2,
+                                   gaussian_noise=torch.randn(z.shape, generator=g).to(z.device),
+                                   guidance_scale=torch.rand(z.shape[0], generator=g) * 6)
+        assert gs.segmented and len(gs.segments) == 2 * len(cases.TINY_UNET["block_out_channels"]) + 3
     seen = {}
     orig = opt.step
 
@@ -69,7 +77,7 @@ def run_step(m, Ps, z, kw, lr=1e-4, compress=None):
         return orig(grad_scale=grad_scale)
     opt.step = step
     before = opt.flat.detach().clone()
-    loss = m.train_step(z, Ps, opt, None, **kw)
+    loss = gs.step(z, None, **kw) if gs is not None else m.train_step(z, Ps, opt, None, **kw)
     torch.cuda.synchronize()
     return loss, seen.get("grad"), opt.flat.detach().clone(), before, opt
 
@@ -89,7 +97,7 @@ def main():
         z = z.clone()
         z[0, 0, 0, 0] = float("nan")
     compress = torch.bfloat16 if mode == "bf16" else None
-    loss, grad, after, before, opt = run_step(m, Ps, z, kw, compress=compress)
+    loss, grad, after, before, opt = run_step(m, Ps, z, kw, compress=compress, graph=(mode == "graph"))
     res = {"loss": loss, "grad": None if grad is None else grad.cpu(), "after": after.cpu(), "before": before.cpu(),
            "target_after": m.student_target_unet._flat.detach().cpu(), "step_count": opt.step_count}
     torch.save(res, os.path.join(out, "rank%d.pt" % rank))

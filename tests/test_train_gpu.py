@@ -332,6 +332,112 @@ def test_graph_captured_distillation_step_equals_eager_train_step(golden):
         m2.capture_train_graph(o2, z0, ["a", "b", "c"])
 
 
+def test_segmented_step_graph_with_rccl_buckets_equals_monolithic_graph_and_eager(golden):
+    """the distillation micro-step captured as 1 + n hipGraphs (forward + loss + out head | one graph
+    per backward block) with the bucketed gradient all-reduce issued BETWEEN the replays -- the form the data-parallel
+    step runs (tools/train_utils.py:152-183 under DDP).  On one rank with a real RCCL process group
+    (CTTA_FORCE_COLLECTIVES=1: every block's slice of the flat gradient buffer goes through ncclAllReduce on RCCL's
+    stream) the segmented replay must reproduce the monolithic replay and the eager step: loss bit-identical, gradient
+    to the LayerNorm-atomics round-off, for two different draws; the public `step` then moves the parameters like the
+    eager `train_step`."""
+    import os
+    import torch.distributed as dist
+    g = golden("distill_tiny")
+    gen = torch.Generator().manual_seed(11)
+    draws = [dict(time_inds=torch.from_numpy(g["time_inds"]) * 2, gaussian_noise=torch.from_numpy(g["noise"]).to(DEV),
+                  guidance_scale=torch.from_numpy(g["guidance"])),
+             dict(time_inds=torch.randint(0, 17, (3,), generator=gen) * 2,
+                  gaussian_noise=torch.randn(3, 8, 32, 8, generator=gen).to(DEV), guidance_scale=torch.rand(3, generator=gen) * 6)]
+    models = []
+    for _ in range(3):
+        m, P, z0 = _lcm()
+        m.train()
+        models.append((m, m.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)))
+    (m_e, o_e), (m_g, o_g), (m_s, o_s) = models
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29583")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    os.environ["CTTA_FORCE_COLLECTIVES"] = "1"
+    try:
+        mono = m_g.capture_train_graph(o_g, z0, P, segmented=False, **draws[0])
+        seg = m_s.capture_train_graph(o_s, z0, P, **draws[0])          # default: segmented under (forced) collectives
+        assert seg.segmented and not mono.segmented
+        n_levels = len(cases.TINY_UNET["block_out_channels"])
+        blocks = [b for _, b in seg.segments]
+        assert blocks == [2 * n_levels + 2] + list(range(2 * n_levels + 1, -1, -1)), blocks
+        assert float(o_s.grad.abs().max()) == 0.0 and o_s.step_count == 0
+        from consistencytta_amd import dist_util as du
+        for it, kw in enumerate(draws):
+            with torch.no_grad():
+                loss, pred, target, sig, gamma = m_e._forward_impl(z0, None, P, False, True, kw["time_inds"],
+                                                                   kw["gaussian_noise"], kw["guidance_scale"], True)
+                m_e._student_backward(pred, target, sig, gamma, 1.0, None)
+            mono._refresh(z0, kw["time_inds"], kw["gaussian_noise"], kw["guidance_scale"])
+            mono.replay()
+            seg._refresh(z0, kw["time_inds"], kw["gaussian_noise"], kw["guidance_scale"])
+            buckets = du.GradientBuckets(o_s.grad, m_s.student_unet.block_ranges(), min_elems=1)
+            assert buckets.enabled
+            seen = []
+            seg.replay(lambda b: (seen.append(b), buckets.ready(b)))
+            assert buckets.wait() == 1 and seen == blocks
+            torch.cuda.synchronize()
+            l_e, l_g, l_s = float(loss), float(mono.loss.item()), float(seg.loss.item())
+            r_g = float((o_e.grad - o_g.grad).norm() / o_e.grad.norm())
+            r_s = float((o_e.grad - o_s.grad).norm() / o_e.grad.norm())
+            print("draw %d: loss eager %.9g mono %.9g segmented %.9g; gradient rel diff mono %.2e segmented %.2e"
+                  % (it, l_e, l_g, l_s, r_g, r_s))
+            assert l_e == l_g == l_s and np.isfinite(l_e)
+            assert float(o_e.grad.norm()) > 0 and r_g <= 1e-7 and r_s <= 1e-7
+            for o in (o_e, o_g, o_s):
+                o.zero_grad()
+        # the public entry point: same parameters in, one optimizer step each
+        before = o_e.flat.detach().clone()
+        v_e = m_e.train_step(z0, P, o_e, None, **draws[1])
+        v_s = seg.step(z0, None, **draws[1])
+        torch.cuda.synchronize()
+        assert v_e == v_s and o_s.step_count == o_e.step_count == 1
+        d_e, d_s = o_e.flat - before, o_s.flat - before
+        upd = float((d_e - d_s).norm() / d_e.norm())
+        print("segmented step vs eager train_step: parameter update rel diff %.3e" % upd)
+        assert upd <= 1e-3 and float(o_s.grad.abs().max()) == 0.0
+        assert torch.equal(m_s.student_unet._flat, o_s.flat)
+        with pytest.raises(N.CttaError, match="segmented=True"):
+            mono.step(z0, None, **draws[0])
+    finally:
+        os.environ["CTTA_FORCE_COLLECTIVES"] = "0"
+        if created:
+            dist.destroy_process_group()
+
+
+def test_step_graph_with_a_fixed_teacher_guidance_scale_equals_eager(golden):
+    """with teacher_guidance_scale = 3 the eager `_forward_impl` conditions student and target on
+    w = 3 (audio_consistency_model.py:300-311: the random draw exists only for scale -1); the captured step must do the
+    same whatever `guidance_scale` the caller passes."""
+    g = golden("distill_tiny")
+    kw = dict(time_inds=torch.from_numpy(g["time_inds"]) * 2, gaussian_noise=torch.from_numpy(g["noise"]).to(DEV))
+    pair = []
+    for _ in range(2):
+        m, P, z0 = _lcm()
+        m.teacher_guidance_scale = 3
+        m.train()
+        pair.append((m, m.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)))
+    (m1, o1), (m2, o2) = pair
+    gs = m2.capture_train_graph(o2, z0, P, segmented=False, guidance_scale=torch.from_numpy(g["guidance"]), **kw)
+    with torch.no_grad():
+        loss, pred, target, sig, gamma = m1._forward_impl(z0, None, P, False, True, kw["time_inds"], kw["gaussian_noise"],
+                                                          None, True)
+        m1._student_backward(pred, target, sig, gamma, 1.0, None)
+    gs._refresh(z0, kw["time_inds"], kw["gaussian_noise"], torch.from_numpy(g["guidance"]))   # a draw the model must ignore
+    gs.replay()
+    torch.cuda.synchronize()
+    assert float(gs.w.min()) == float(gs.w.max()) == 3.0
+    rel = float((o1.grad - o2.grad).norm() / o1.grad.norm())
+    print("fixed w = 3: eager loss %.9g graph loss %.9g, gradient rel diff %.2e" % (float(loss), float(gs.loss.item()), rel))
+    assert float(loss) == float(gs.loss.item()) and rel <= 1e-7
+
+
 def test_gradient_accumulation_matches_one_big_step(golden):
     """accumulation_steps=2 with the same micro-batch twice: the accumulated, 1/2-scaled gradient equals the single
     micro-step gradient, so the parameters after the boundary step equal those of a plain step (up to bf16 rounding of
@@ -612,3 +718,33 @@ def test_distillation_step_full_batch_is_deterministic_and_blockwise_exact():
     # (the default: CTTA_TWO_STREAM / CTTA_WGRAD_STREAM).  The 1.5e-7..3.8e-7 once seen with a second hardware queue were the
     # v_pk_fma_f32 op_sel hazard, gone since the library is built with -fno-slp-vectorize.
     assert d12 <= 1e-7 and d13 <= 1e-7
+    # the hipGraph-captured step at THIS size (what bench.py times) against the eager one -- loss bit
+    # for bit and the whole 559 M-element gradient, for the monolithic capture and for the segmented one (1 + 11 graphs,
+    # the data-parallel form); a second, different draw checks that the static tensors are really refreshed.
+    for segmented in (False, True):
+        gs = m.capture_train_graph(opt, z0, P, segmented=segmented, **kw)
+        assert float(opt.grad.abs().max()) == 0.0
+        gen2 = torch.Generator().manual_seed(6)
+        kw2 = dict(time_inds=torch.randint(0, 17, (9,), generator=gen2) * 2,
+                   gaussian_noise=torch.randn(9, 8, 256, 16, generator=gen2).to(DEV),
+                   guidance_scale=torch.rand(9, generator=gen2) * 6)
+        for draw in (kw, kw2):
+            opt.zero_grad()
+            with torch.no_grad():
+                loss, pred, target, sig, gamma = m._forward_impl(z0, None, P, False, True, draw["time_inds"],
+                                                                 draw["gaussian_noise"], draw["guidance_scale"], True)
+                m._student_backward(pred, target, sig, gamma, 1.0, None)
+            torch.cuda.synchronize()
+            g_e, l_e = opt.grad.detach().clone(), float(loss)
+            opt.zero_grad()
+            gs._refresh(z0, draw["time_inds"], draw["gaussian_noise"], draw["guidance_scale"])
+            seen = []
+            gs.replay(seen.append if segmented else None)
+            torch.cuda.synchronize()
+            d = float((opt.grad - g_e).norm() / g_e.norm())
+            print("B=9 light, %s graph: loss %.9g vs eager %.9g, gradient rel diff %.2e"
+                  % ("segmented" if segmented else "monolithic", float(gs.loss.item()), l_e, d))
+            assert float(gs.loss.item()) == l_e and d <= 1e-7
+            assert not segmented or (seen[0] == 10 and sorted(seen) == list(range(11)))
+        opt.zero_grad()
+        del gs
