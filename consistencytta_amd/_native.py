@@ -150,6 +150,8 @@ SIGNATURES = {
     "ctta_hifigan_forward_with_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ctta_hifigan_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ctta_wav_finalize": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ctta_wav_extrema": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p]),
+    "ctta_wav_center": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ctta_hifigan_arena_bytes": (c_size_t, [c_void_p]),
     "ctta_hifigan_num_taps": (c_int, [c_void_p]),
     "ctta_hifigan_tap_info": (c_int, [c_void_p, c_int, POINTER(c_char_p), POINTER(c_int * 4)]),

@@ -396,11 +396,25 @@ class EvaluationHelper:
         res["file_path_"] = [name for _, name in items]
         return res
 
-    def calculate_metrics(self, generate_files_path, groundtruth_path, same_name=True, target_length=1000, limit_num=None,
-                          captions=None, subset_size=None):
-        """eval.py:181-308 on two directories of identically named .wav files.  captions: {file name: text} for the CLAP
-        scores (the reference reads them from its dataset json).  Returns the reference's dictionary, rounded to 4 digits;
-        metrics whose third-party model is not rebuilt are NaN."""
+    @staticmethod
+    def captions_from_dataset_json(dataset_json_path):
+        """{generated file name: caption} as `T2APairedDataset` pairs them (tools/t2a_dataset.py:79-87,118-119): line i of the
+        json-lines file holds the caption of `output_<i>.wav`."""
+        import json
+        if not os.path.isfile(dataset_json_path):
+            raise AssertionError("%s is not a file." % dataset_json_path)
+        with open(dataset_json_path) as f:
+            rows = [json.loads(line) for line in f if line.strip()]
+        return {"output_%d.wav" % i: r["captions"] for i, r in enumerate(rows)}
+
+    def calculate_metrics(self, dataset_json_path, generate_files_path, groundtruth_path, mel_path=None, same_name=True,
+                          target_length=1000, limit_num=None, captions=None, subset_size=None):
+        """eval.py:181-308 (same positional order) on two directories of identically named .wav files.  The captions of the
+        CLAP scores come from `dataset_json_path` as in the reference (or from `captions`: {file name: text}); `mel_path`
+        (pre-computed generated mels for the reference's optional mel metrics) is accepted and unused.  Returns the
+        reference's dictionary, rounded to 4 digits; metrics whose third-party model is not rebuilt are NaN."""
+        if captions is None and dataset_json_path is not None:
+            captions = self.captions_from_dataset_json(dataset_json_path)
         gen_files = sorted(f for f in os.listdir(generate_files_path) if f.endswith(".wav"))
         gt_files = sorted(f for f in os.listdir(groundtruth_path) if f.endswith(".wav"))
         if gen_files != gt_files:
@@ -454,8 +468,12 @@ class EvaluationHelper:
                 sims["gen_gt"].append(cos(x, g, dim=1).clamp(min=0))
         return {k + "_clap_score": torch.cat(v).mean().item() * 100.0 for k, v in sims.items()}
 
-    def main(self, generated_files_path, groundtruth_path, target_length=1000, limit_num=None, captions=None):
+    def main(self, dataset_json_path, generated_files_path, groundtruth_path, mel_path=None, target_length=1000,
+             limit_num=None, captions=None):
+        """eval.py:336-349, keyword- and position-compatible with the reference's callers (inference.py:230,
+        evaluate_existing.py:54); `dataset_json_path=None` skips the CLAP scores unless `captions` is given."""
         self.file_init_check(generated_files_path)
         self.file_init_check(groundtruth_path)
         same_name = self.get_filename_intersection_ratio(generated_files_path, groundtruth_path, limit_num=limit_num)
-        return self.calculate_metrics(generated_files_path, groundtruth_path, same_name, target_length, limit_num, captions)
+        return self.calculate_metrics(dataset_json_path, generated_files_path, groundtruth_path, mel_path, same_name,
+                                      target_length, limit_num, captions)

@@ -452,6 +452,43 @@ extern "C" ctta_status ctta_ema_update2(const float* param, float* shadow_a, dou
   return CTTA_OK;
 }
 
+// The two halves of ctta_wav_finalize for a batch that is sharded over ranks (vocoder_infer centres with the extrema of
+// the WHOLE batch, hifigan/utilities.py:85): extrema -> (max, min) as floats on the device, which the caller MAX-reduces
+// over ranks, then centre with the reduced pair.  Same arithmetic as the one-call form: shift = (max + min) / 2.
+__global__ void minmax_decode_kernel(const unsigned int* __restrict__ mm, float* __restrict__ out) {
+  auto dec = [](unsigned u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); };
+  out[0] = dec(mm[0]);
+  out[1] = dec(mm[1]);
+}
+__global__ void minmax_encode_kernel(const float* __restrict__ in, unsigned int* __restrict__ mm) {
+  auto enc = [](float f) { const unsigned u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); };
+  mm[0] = enc(in[0]);
+  mm[1] = enc(in[1]);
+}
+extern "C" ctta_status ctta_wav_extrema(const float* wav, int64_t n, float* scratch, float* max_min, void* stream) {
+  CTTA_REQUIRE(wav && scratch && max_min && n > 0, "wav_extrema: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned int* mm = reinterpret_cast<unsigned int*>(scratch);
+  hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, s, mm);
+  long long mb = (n / 4 + 255) / 256;
+  if (mb > 1024) mb = 1024;
+  if (mb < 1) mb = 1;
+  hipLaunchKernelGGL(minmax_kernel, dim3((unsigned)mb), dim3(256), 0, s, wav, (long long)n, mm);
+  hipLaunchKernelGGL(minmax_decode_kernel, dim3(1), dim3(1), 0, s, mm, max_min);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+extern "C" ctta_status ctta_wav_center(const float* wav, int64_t n, const float* max_min, float* scratch, float* centred,
+                                       int16_t* pcm, void* stream) {
+  CTTA_REQUIRE(wav && max_min && scratch && n > 0, "wav_center: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned int* mm = reinterpret_cast<unsigned int*>(scratch);
+  hipLaunchKernelGGL(minmax_encode_kernel, dim3(1), dim3(1), 0, s, max_min, mm);
+  hipLaunchKernelGGL(wav_finalize_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, wav, (long long)n, mm, centred, pcm);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
 extern "C" ctta_status ctta_wav_finalize(const float* wav, int64_t n, float* scratch, float* centred,
                                          int16_t* pcm, void* stream) {
   CTTA_REQUIRE(wav && scratch && n > 0, "wav_finalize: null pointer");

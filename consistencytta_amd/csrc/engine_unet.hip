@@ -428,6 +428,9 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   c.U = U; c.B = B; c.L = L; c.Lp = round_up(L, 8);
   c.reuse_text = !dry && !train && U->tc_reuse_next && U->tc_valid && U->tc_base && U->tc_B == B && U->tc_L == L;
   U->tc_reuse_next = false;
+  // a forward that re-projects the text states overwrites the cache as it goes: the cache is valid again only when this
+  // call has finished (line `tc_valid = true` at the end), so a call that fails half way cannot leave mixed K / V behind
+  if (!dry && !c.reuse_text && !train) U->tc_valid = false;
   Arena& A = U->arena;
   A.reset();
   A.no_release = cfg.debug_taps != 0 || train;   // the backward pass reads every intermediate

@@ -1,8 +1,9 @@
 """One-process-per-GPU plumbing for the replicated (clip-sharded) inference path and the
 timing protocol of bench.py.  Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
 Generation shards by clip with NO data-path collective; the only collectives are
-the timing barrier, the MAX-reduce of the elapsed time and the optional 2-scalar (max, min)
-reduce that makes the vocoder's batch-global centring match a single-process run."""
+the timing barrier, the MAX-reduce of the elapsed time and the opt-in 2-scalar (max, min)
+reduce (`decode_to_waveform(world_extrema=True)`) that makes the vocoder's batch-global centring
+match a single-process run of the unsharded batch."""
 import os
 
 import torch
@@ -39,18 +40,16 @@ def max_over_ranks(seconds, device):
     return float(t.item())
 
 
-def shard_clips(n_clips, world, rank):
-    """Round-robin clip ownership: clip i belongs to rank i % world."""
-    return list(range(rank, n_clips, world))
-
-
-def global_wav_extrema(local_max, local_min, device):
-    """(max, min) over ALL ranks' waveforms: vocoder_infer centres with batch-global extrema
-    (hifigan/utilities.py:85), so a sharded batch needs these two scalars to match exactly."""
-    t = torch.tensor([local_max, -local_min], dtype=torch.float32, device=device)
-    if dist.is_initialized():
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t[0]), -float(t[1])
+def global_wav_extrema_(max_min):
+    """In place: `max_min` = [max, min] of this rank's waveforms (a 2-element float tensor, device or host) becomes the pair
+    over ALL ranks.  vocoder_infer centres with batch-global extrema (hifigan/utilities.py:85), so a clip-sharded batch
+    needs these two scalars to reproduce the single-process result exactly
+    (`AutoencoderKL.decode_to_waveform(..., world_extrema=True)`).  One MAX all-reduce of (max, -min)."""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        max_min[1].neg_()
+        dist.all_reduce(max_min, op=dist.ReduceOp.MAX)
+        max_min[1].neg_()
+    return max_min
 
 
 def allreduce_sum_(flat, bucket_elems=64 << 20):

@@ -325,7 +325,11 @@ class _UNetBase(_ParamTree):
         prev = getattr(self, "_text_key", None)
         same = (prev is not None and prev[0] is key[0] and prev[1] == key[1] and prev[2] is key[2] and prev[3] == key[3]
                 and prev[4] == key[4])
-        self._text_key = key
+        # the key of THIS forward is committed by `_forward` after the native call has returned OK (a failed forward must
+        # not leave its text states registered as "the cached ones").  Identity + `_version` cannot see writes through raw
+        # pointers (how this library's own kernels fill tensors): a caller that refills a persistent text-state buffer
+        # natively must pass reuse_text=False.
+        self._text_key_pending = key
         if reuse_text is False or not same:
             return False
         if reuse_text is True:
@@ -360,11 +364,13 @@ class _UNetBase(_ParamTree):
             m = encoder_attention_mask.to(device=dev).reshape(B, L).to(torch.uint8).contiguous()
         out = torch.empty((B, self._cfg["out_channels"], H, W), dtype=torch.float32, device=dev)
         fn = N.lib().ctta_unet_forward_train if train else N.lib().ctta_unet_forward
+        self._text_key = None
         with torch.cuda.device(dev):
             if reuse:
                 N.check(N.lib().ctta_unet_reuse_text(self._h_unet, 1))
             N.check(fn(self._h_unet, N.ptr(x), N.ptr(t), N.ptr(g), N.ptr(enc), N.ptr(m), B, L, N.ptr(out),
                        N.stream_ptr()))
+        self._text_key = self._text_key_pending
         return out
 
     # ---- distillation step: the reference differentiates `forward` with torch autograd
@@ -880,11 +886,14 @@ class AutoencoderKL(_ParamTree):
             N.check(N.lib().ctta_hifigan_forward(h, N.ptr(m), B, T, N.ptr(wav), N.stream_ptr()))
         return wav
 
-    def decode_to_waveform(self, dec, allow_grad=False, return_float=False):
+    def decode_to_waveform(self, dec, allow_grad=False, return_float=False, world_extrema=False):
         """vocoder_infer (hifigan/utilities.py:76-91): batch-global (max+min)/2 centring, then
         int16 numpy on the host (the reference's return type); return_float keeps the centred
         float tensor on the device.  allow_grad=True returns the centred float waveform with a graph back to `dec`
-        (utilities.py:79-81; the centring's max/min run as torch ops on the vocoder's differentiable output)."""
+        (utilities.py:79-81; the centring's max/min run as torch ops on the vocoder's differentiable output).
+        world_extrema=True (clip-sharded generation under a process group): the extrema are MAX-reduced over all ranks
+        first, so every rank centres with the whole batch's pair and the shards equal a single-process run of the
+        unsharded batch bit for bit; the default centres per shard (no data-path collective)."""
         if allow_grad:
             need_graph = torch.is_grad_enabled() and dec.requires_grad
             wavs = (_VocodeWithGrad.apply(dec, self) if need_graph else self.vocode(dec)).float()
@@ -894,8 +903,16 @@ class AutoencoderKL(_ParamTree):
         centred = torch.empty_like(wav) if return_float else None
         pcm = None if return_float else torch.empty(wav.shape, dtype=torch.int16, device=wav.device)
         with torch.cuda.device(self.device):
-            N.check(N.lib().ctta_wav_finalize(N.ptr(wav), wav.numel(), N.ptr(scratch), N.ptr(centred), N.ptr(pcm),
-                                              N.stream_ptr()))
+            if world_extrema:
+                from . import dist_util
+                mm = torch.empty(2, dtype=torch.float32, device=wav.device)
+                N.check(N.lib().ctta_wav_extrema(N.ptr(wav), wav.numel(), N.ptr(scratch), N.ptr(mm), N.stream_ptr()))
+                dist_util.global_wav_extrema_(mm)
+                N.check(N.lib().ctta_wav_center(N.ptr(wav), wav.numel(), N.ptr(mm), N.ptr(scratch), N.ptr(centred), N.ptr(pcm),
+                                                N.stream_ptr()))
+            else:
+                N.check(N.lib().ctta_wav_finalize(N.ptr(wav), wav.numel(), N.ptr(scratch), N.ptr(centred), N.ptr(pcm),
+                                                  N.stream_ptr()))
         return centred if return_float else pcm.cpu().numpy()
 
     def _read_taps(self, which):

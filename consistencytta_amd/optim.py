@@ -133,7 +133,13 @@ class FusedAdamW:
 class WarmupSchedule:
     """transformers.get_scheduler('linear' | 'constant' | 'constant_with_warmup') on a FusedAdamW."""
 
-    def __init__(self, optimizer, name="linear", num_warmup_steps=0, num_training_steps=None):
+    def __init__(self, optimizer, name="linear", num_warmup_steps=0, num_training_steps=None, steps_per_update=1):
+        """`steps_per_update`: accelerate's AcceleratedScheduler steps the wrapped LambdaLR `num_processes` times per
+        optimizer update (which is why tools/train_utils.py:77 multiplies the warm-up by `accelerator.num_processes`).  To
+        continue an N-GPU reference run -- its scheduler.bin holds last_epoch = N x updates and its warm-up / total counts
+        are in those units -- pass steps_per_update=N and the reference's (already multiplied) step counts; the default 1
+        is a single-process run, where the two conventions coincide."""
+        self.steps_per_update = max(1, int(steps_per_update))
         if name not in ("linear", "constant", "constant_with_warmup"):
             raise ValueError("lr schedule '%s' is not built (linear, constant, constant_with_warmup)" % name)
         if name == "linear" and not num_training_steps:
@@ -156,7 +162,7 @@ class WarmupSchedule:
         self.opt.param_groups[0]["lr"] = self.base_lr * self._factor(self.last_step)
 
     def step(self):
-        self.last_step += 1
+        self.last_step += self.steps_per_update
         self._apply()
 
     def get_last_lr(self):

@@ -232,6 +232,13 @@ ctta_status ctta_hifigan_backward(ctta_hifigan* h, const float* grad_wav, const 
  * centred (float, may be NULL) and pcm (int16, may be NULL) receive the results. */
 ctta_status ctta_wav_finalize(const float* wav, int64_t n, float* scratch, float* centred,
                               int16_t* pcm, void* stream);
+/* The same in two halves for a batch SHARDED over ranks: the centring uses the extrema of the whole batch
+ * (hifigan/utilities.py:85 `(wavs.max() + wavs.min()) / 2` on the full tensor), so every rank computes its local
+ * (max, min) -> max_min[2] (device floats), the caller MAX-reduces (max, -min) over ranks (dist_util.global_wav_extrema_),
+ * and ctta_wav_center applies the reduced pair.  scratch >= 2 floats. */
+ctta_status ctta_wav_extrema(const float* wav, int64_t n, float* scratch, float* max_min, void* stream);
+ctta_status ctta_wav_center(const float* wav, int64_t n, const float* max_min, float* scratch, float* centred,
+                            int16_t* pcm, void* stream);
 size_t ctta_hifigan_arena_bytes(const ctta_hifigan* h);
 int ctta_hifigan_num_taps(const ctta_hifigan* h);
 ctta_status ctta_hifigan_tap_info(const ctta_hifigan* h, int i, const char** name, int dims[4]);

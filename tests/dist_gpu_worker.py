@@ -82,12 +82,34 @@ def run_step(m, Ps, z, kw, lr=1e-4, compress=None, graph=False):
     return loss, seen.get("grad"), opt.flat.detach().clone(), before, opt
 
 
+def tiny_vocoder(dev):
+    from consistencytta_amd import modules
+    sd = dict(cases.vae_weights(cases.TINY_VAE_DD))
+    sd.update(cases.hifigan_weights(cases.TINY_HIFIGAN))
+    v = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, scale_factor=0.9, hifigan_config=cases.TINY_HIFIGAN)
+    v.load_state_dict(sd)
+    return v.to(dev).eval().requires_grad_(False)
+
+
+def wav_batch():
+    mel = cases.t(spec.det_uniform("dist.mel", (4, 1, 64, cases.TINY_HIFIGAN["num_mels"]), 33)) * 2.0 - 5.0
+    mel[3] += 1.5          # the loudest clip lives on rank 1: rank 0 cannot centre correctly without the exchange
+    return mel
+
+
 def main():
     mode, out = sys.argv[1], sys.argv[2]
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
     world, rank = du.init("gloo")
     assert world == 2
+    if mode == "wav":     # clip-sharded generation with the opt-in batch-global centring (hifigan/utilities.py:85)
+        v = tiny_vocoder(dev)
+        mel = wav_batch()[rank * 2:(rank + 1) * 2].to(dev)
+        res = {"world": v.decode_to_waveform(mel, world_extrema=True), "local": v.decode_to_waveform(mel)}
+        torch.save(res, os.path.join(out, "rank%d.pt" % rank))
+        du.finish()
+        return
     m = build(dev, seed_shift=10 * rank)
     m.train()
     P, z0, draws = global_batch()

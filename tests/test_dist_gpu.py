@@ -109,3 +109,17 @@ def test_two_rank_segmented_graph_step_equals_the_eager_two_rank_step(tmp_path):
     d_e, d_g = e0["after"] - e0["before"], g0["after"] - g0["before"]
     assert float((d_e - d_g).norm() / d_e.norm()) <= 1e-3
     assert g0["step_count"] == 1
+
+
+def test_sharded_vocoder_centring_with_world_extrema_equals_the_unsharded_batch(tmp_path):
+    """`decode_to_waveform(world_extrema=True)` -- two ranks hold two clips each, exchange (max, -min)
+    (dist_util.global_wav_extrema_) and centre with the WHOLE batch's pair: the int16 shards equal a single process on the
+    four clips bit for bit (hifigan/utilities.py:85 centres with batch-global extrema).  The default (per-shard centring,
+    no data-path collective) is the documented deviation and differs on the rank that does not hold the loudest clip."""
+    import numpy as np
+    import dist_gpu_worker as W
+    r0, r1 = _launch("wav", tmp_path)
+    v = W.tiny_vocoder(torch.device("cuda:0"))
+    ref = v.decode_to_waveform(W.wav_batch().to("cuda:0"))
+    assert np.array_equal(np.concatenate([r0["world"], r1["world"]]), ref)
+    assert not np.array_equal(np.concatenate([r0["local"], r1["local"]]), ref)

@@ -117,7 +117,7 @@ def test_evaluation_helper_end_to_end(golden, tmp_path):
         wavfile.write(str(gen_dir / ("clip_%02d.wav" % i)), 16000, (gen[i] * 32767).astype(np.int16))
         wavfile.write(str(gt_dir / ("clip_%02d.wav" % i)), 48000, (gt[i] * 32767).astype(np.int16))
     helper = E.EvaluationHelper(16000, DEV, mel_model=m)
-    res = helper.main(str(gen_dir), str(gt_dir))
+    res = helper.main(None, str(gen_dir), str(gt_dir))
     assert list(res) == E.EvaluationHelper.KEYS
     for k in ("frechet_audio_distance", "lsd", "psnr", "ssim", "ssim_stft", "gt_text_clap_score"):
         assert np.isnan(res[k]), k                        # third-party models the build does not have: reported like a missing key
@@ -142,7 +142,7 @@ def test_evaluation_helper_end_to_end(golden, tmp_path):
     # directories that do not hold the same files are refused like the reference (eval.py:196-204)
     os.remove(str(gen_dir / "clip_00.wav"))
     with pytest.raises(ValueError):
-        helper.main(str(gen_dir), str(gt_dir))
+        helper.main(None, str(gen_dir), str(gt_dir))
 
 
 def test_clap_scores_feed_the_tower_what_the_reference_dataset_does(golden):

@@ -485,3 +485,55 @@ def test_cnn14_loads_a_released_checkpoint_layout():
         m.load_state_dict(dict(core, **{"conv_block7.conv1.weight": torch.zeros(1)}), strict=True)
     with pytest.raises(RuntimeError):
         m(torch.zeros(1, 32000))                               # CPU tensors: there is no CPU path
+
+
+def test_scheduler_resumes_an_n_process_reference_run():
+    """accelerate's AcceleratedScheduler steps the LambdaLR `num_processes` times per optimizer update, and
+    tools/train_utils.py:77 multiplies the warm-up by num_processes for that reason; an N-GPU reference scheduler.bin
+    therefore holds last_epoch = N x updates.  WarmupSchedule(steps_per_update=N) continues exactly that curve."""
+    from transformers import get_scheduler
+    from consistencytta_amd import optim
+    N_PROC, warm, total = 4, 3, 50
+    p = torch.nn.Parameter(torch.zeros(2))
+    ref = torch.optim.AdamW([p], lr=3e-5)
+    rs = get_scheduler(name="linear", optimizer=ref, num_warmup_steps=warm * N_PROC, num_training_steps=total * N_PROC)
+    for _ in range(5):                       # 5 optimizer updates of the 4-process reference run
+        for _ in range(N_PROC):
+            rs.step()
+    sd = rs.state_dict()
+    assert sd["last_epoch"] == 5 * N_PROC
+
+    class _Opt:
+        param_groups = [{"lr": 3e-5}]
+    sch = optim.WarmupSchedule(_Opt(), "linear", num_warmup_steps=warm * N_PROC, num_training_steps=total * N_PROC,
+                               steps_per_update=N_PROC)
+    sch.load_state_dict(sd)
+    assert sch.last_step == 20 and sch.get_last_lr() == rs.get_last_lr()
+    for _ in range(7):                       # both continue: one update = N_PROC LambdaLR steps there, one step() here
+        for _ in range(N_PROC):
+            rs.step()
+        sch.step()
+        assert abs(sch.get_last_lr()[0] - rs.get_last_lr()[0]) <= 1e-12 * 3e-5 + 1e-18
+    assert sch.state_dict()["last_epoch"] == rs.state_dict()["last_epoch"] == 48
+
+
+def test_eval_captions_come_from_the_dataset_json_like_the_reference(tmp_path):
+    """`EvaluationHelper.main(dataset_json_path, generated_files_path, groundtruth_path, mel_path=...)` keeps the
+    reference's positional order (audioldm_eval/eval.py:336-349; callers inference.py:230, evaluate_existing.py:54) and reads
+    the captions itself: line i of the json-lines file belongs to output_<i>.wav (tools/t2a_dataset.py:79-87,118-119)."""
+    import inspect
+    import json
+    from consistencytta_amd import audioldm_eval as E
+    path = tmp_path / "test.json"
+    with open(path, "w") as f:
+        for i, c in enumerate(["a dog barks", "rain on a roof", "a car passes"]):
+            f.write(json.dumps({"captions": c, "location": "/data/%d.wav" % i, "dataset": "audiocaps"}) + "\n")
+    caps = E.EvaluationHelper.captions_from_dataset_json(str(path))
+    assert caps == {"output_0.wav": "a dog barks", "output_1.wav": "rain on a roof", "output_2.wav": "a car passes"}
+    assert list(inspect.signature(E.EvaluationHelper.main).parameters)[:7] == [
+        "self", "dataset_json_path", "generated_files_path", "groundtruth_path", "mel_path", "target_length", "limit_num"]
+    assert list(inspect.signature(E.EvaluationHelper.calculate_metrics).parameters)[:8] == [
+        "self", "dataset_json_path", "generate_files_path", "groundtruth_path", "mel_path", "same_name", "target_length",
+        "limit_num"]
+    with pytest.raises(AssertionError):
+        E.EvaluationHelper.captions_from_dataset_json(str(tmp_path / "missing.json"))

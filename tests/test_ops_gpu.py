@@ -760,6 +760,18 @@ def test_heun_cfg_loss_ema_wav(golden):
     ref = wav - (wav.max() + wav.min()) / 2
     assert torch.equal(cen.cpu(), ref)
     assert np.array_equal(pcm.cpu().numpy(), (ref.numpy() * 32768).astype("int16"))
+    # the two halves a clip-sharded batch uses (extrema -> all-reduce -> centre): shard A and shard B centred with the
+    # pair of the WHOLE batch reproduce the one-call result bit for bit (hifigan/utilities.py:85)
+    mmA, mmB = torch.empty(2, device=DEV), torch.empty(2, device=DEV)
+    N.check(L.ctta_wav_extrema(N.ptr(wd_[0]), 5000, N.ptr(scratch), N.ptr(mmA), st))
+    N.check(L.ctta_wav_extrema(N.ptr(wd_[1]), 5000, N.ptr(scratch), N.ptr(mmB), st)); sync()
+    assert mmA.tolist() == [float(wav[0].max()), float(wav[0].min())]
+    both = torch.stack([torch.maximum(mmA[0], mmB[0]), torch.minimum(mmA[1], mmB[1])]).contiguous()
+    cenS, pcmS = torch.empty_like(wd_), torch.empty_like(pcm)
+    for i in range(2):
+        N.check(L.ctta_wav_center(N.ptr(wd_[i]), 5000, N.ptr(both), N.ptr(scratch), N.ptr(cenS[i]), N.ptr(pcmS[i]), st))
+    sync()
+    assert torch.equal(cenS, cen) and torch.equal(pcmS, pcm)
     # the float4 min / max walk: a base pointer 4 bytes off 16-byte alignment and a length that is not a multiple of 4, with
     # the extrema placed in the unaligned head and in the tail
     for n, lo_at, hi_at in [(9999, 0, 9998), (4097, 4096, 1), (5, 4, 0), (3, 1, 2)]:
