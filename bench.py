@@ -568,20 +568,24 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     # with the same draws).  With a process group the block-wise all-reduce must interleave with the backward, so the
     # data-parallel step stays eager; both rates are reported.
     dt_eager, launch_mode = dt, "eager launches (two streams + weight-gradient side stream)"
-    dt_seg = None
+    dt_seg = dt_graph = dt_pipe = dt_seg_pipe = None
     if not perceptual and os.environ.get("CTTA_BENCH_GRAPH", "1") != "0" and not args.no_latency:
         gdr = torch.Generator().manual_seed(77 + rank)
         kw = dict(time_inds=torch.randint(0, 17, (B,), generator=gdr) * 2,
                   gaussian_noise=torch.randn(B, 8, 256, 16, generator=gdr).to(dev), guidance_scale=torch.rand(B, generator=gdr) * 6)
 
-        def timed_graph(segmented):
+        def timed_graph(segmented, pipelined=False):
             """Capture, check one replay against an eager forward with the same draws, time n_steps public steps.  Every
             rank runs the same sequence (the segmented step issues the bucket all-reduces between its replays)."""
-            gs = m.capture_train_graph(opt, z0, P, segmented=segmented, **kw)
+            gs = m.capture_train_graph(opt, z0, P, segmented=segmented, pipeline_teacher=pipelined, **kw)
             with torch.no_grad():
                 loss_e = float(m._forward_impl(z0, None, P, False, True, kw["time_inds"], kw["gaussian_noise"],
                                                kw["guidance_scale"], True)[0])
-            gs._refresh(z0, kw["time_inds"], kw["gaussian_noise"], kw["guidance_scale"])
+            if pipelined:
+                gs.feed(z0, **kw)       # the teacher phase of this batch on the teacher stream ...
+                gs.feed(z0, **kw)       # ... becomes the current set; the same batch queued again behind it
+            else:
+                gs._refresh(z0, kw["time_inds"], kw["gaussian_noise"], kw["guidance_scale"])
             gs.replay()
             loss_g = float(gs.loss.item())
             opt.zero_grad()
@@ -598,20 +602,35 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         # collectives of the segmented step alone
         def all_ok(ok):
             return du.max_over_ranks(0.0 if ok else 1.0, dev) == 0.0
+        pipe_on = os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0"
+        pipe_txt = ("; the frozen teacher's two CFG queries + Heun step run as their own hipGraph on a second stream for batch "
+                    "i + 1 beside the student / target / backward work of batch i (every timed step holds one teacher phase, "
+                    "one target forward, one student forward + backward, AdamW, EMA)")
         try:
             dt_seg = timed_graph(True)
             launch_seg = ("%d hipGraph replays per micro-step (forward + loss + out head | one graph per backward block, bucket "
                           "all-reduce issued between replays) + eager AdamW / zero_grad / EMA" % 12)
+            if pipe_on:      # what the data-parallel step runs: segmented (bucket all-reduce between replays) AND pipelined
+                dt_seg_pipe = timed_graph(True, True)
             if world > 1:
                 dt, launch_mode = dt_seg, launch_seg
+                if pipe_on and dt_seg_pipe < dt_seg:
+                    dt, launch_mode = dt_seg_pipe, launch_seg + pipe_txt
         except Exception as exc:
             if world > 1:
                 raise       # the other ranks are inside the same collectives: failing loudly beats a hang
             launch_mode = "eager launches (segmented graph capture failed: %s)" % str(exc)[:160]
         if world == 1:
             try:
-                dt = timed_graph(False)
+                dt = dt_graph = timed_graph(False)
                 launch_mode = "one hipGraph replay per micro-step (forward + backward + loss) + eager AdamW / zero_grad / EMA"
+                if pipe_on:
+                    try:
+                        dt_pipe = timed_graph(False, True)
+                        if dt_pipe < dt:
+                            dt, launch_mode = dt_pipe, launch_mode + pipe_txt
+                    except Exception as exc:
+                        launch_mode += " (pipelined capture failed: %s)" % str(exc)[:120]
             except Exception as exc:   # a failed capture must not cost the line
                 launch_mode = "eager launches (graph capture failed: %s)" % str(exc)[:160]
                 dt = dt_eager
@@ -622,6 +641,9 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         "steps": n_steps, "warmup": n_warm,
         "eager_ms_per_step": round(dt_eager / n_steps * 1e3, 3),
         "segmented_ms_per_step": None if dt_seg is None else round(dt_seg / n_steps * 1e3, 3),
+        "segmented_pipelined_ms_per_step": None if dt_seg_pipe is None else round(dt_seg_pipe / n_steps * 1e3, 3),
+        "graph_ms_per_step": None if dt_graph is None else round(dt_graph / n_steps * 1e3, 3),
+        "pipelined_ms_per_step": None if dt_pipe is None else round(dt_pipe / n_steps * 1e3, 3),
         "n_gpus": world, "scaling": "weak", "dtype": "bf16 (fp32 master weights, gradients, AdamW moments)",
         "config": {"workload": "configs[3]: consistency distillation step, light U-Net x4 (teacher, student, target, EMA), "
                                "2 CFG teacher queries + Heun, SNR-MSE loss, backward, AdamW, EMA 0.95/0.999",

@@ -917,28 +917,53 @@ class _DistillStepGraph:
     its own stream) overlaps the blocks still to come exactly as in the eager `train_step`; the graphs share one memory
     pool and the engine's arena, so the kernels and their arguments are those of the monolithic capture."""
 
-    def __init__(self, model, optimizer, z_shape, P, segmented=False, accumulation_steps=1):
+    def __init__(self, model, optimizer, z_shape, P, segmented=False, accumulation_steps=1, pipeline_teacher=False):
         assert model.loss is None, "the captured step covers the latent-space loss (loss_type='mse')"
         assert model.training and model.use_teacher_cf_guidance
         self.m, self.opt = model, optimizer
         self.segmented = bool(segmented)
+        self.pipelined = bool(pipeline_teacher)
         self.accum = max(1, int(accumulation_steps))
         self.segments = []       # [(graph, block id it completes)]
         self._micro = 0
         dev = model.device
         B = z_shape[0]
         self.B, self.dev = B, dev
-        f32 = dict(dtype=torch.float32, device=dev)
-        self.z0 = torch.zeros(z_shape, **f32)
-        self.noise = torch.zeros(z_shape, **f32)
-        self.w = torch.zeros(B, **f32)
-        self.t_np1 = torch.zeros(B, **f32)
-        self.t_n = torch.zeros(B, **f32)
-        self.sig = [torch.zeros(B, **f32) for _ in range(8)]
+        # Static inputs of one batch, carved out of ONE flat buffer (so that the pipelined step rotates a whole set with a
+        # single device copy): the latents, the noise, guidance, the two timestep vectors, the eight sigma vectors, and the
+        # two tensors the teacher phase hands to the rest of the step (student input, target-network input).
+        self.cur = self._input_set(z_shape)
+        self.nxt = self._input_set(z_shape) if self.pipelined else self.cur      # what the teacher graph reads / writes
         self.P = {k: v.detach().clone() for k, v in P.items()}
         self.loss = None
         self.graph = None
+        self.teacher_graph = None
         self._pinned = torch.zeros(11, B, dtype=torch.float32).pin_memory()
+        self._primed = False
+        if self.pipelined:
+            self._tstream = torch.cuda.Stream(device=dev)
+            self._ev_teacher = torch.cuda.Event()
+            self._ev_h2d = torch.cuda.Event()
+
+    def _input_set(self, z_shape):
+        B = z_shape[0]
+        nz = int(np.prod(z_shape))
+        flat = torch.zeros(4 * nz + 11 * B, dtype=torch.float32, device=self.dev)
+        S = {"flat": flat}
+        for i, k in enumerate(("z0", "noise", "z_in", "tgt_in")):
+            S[k] = flat[i * nz:(i + 1) * nz].view(z_shape)
+        small = flat[4 * nz:].view(11, B)
+        S["t_np1"], S["t_n"], S["w"] = small[0], small[1], small[2]
+        S["sig"] = [small[3 + i] for i in range(8)]
+        return S
+
+    # the names the tests and bench.py use for the CURRENT batch's static tensors
+    z0 = property(lambda self: self.cur["z0"])
+    noise = property(lambda self: self.cur["noise"])
+    w = property(lambda self: self.cur["w"])
+    t_np1 = property(lambda self: self.cur["t_np1"])
+    t_n = property(lambda self: self.cur["t_n"])
+    sig = property(lambda self: self.cur["sig"])
 
     # -- host side: what the Heun scheduler would look up for this draw, in `_forward_impl`'s call order
     def _sigma_plan(self, inds):
@@ -959,8 +984,10 @@ class _DistillStepGraph:
         plan = [sig[i1], sig[i1 + 1], sig[i2], sig[i2 - 1], sig[i2], sig[i3], sig[inds]]
         return t_np1, t_n, plan
 
-    def _refresh(self, z_0, time_inds, gaussian_noise, guidance_scale):
+    def _refresh(self, z_0, time_inds, gaussian_noise, guidance_scale, S=None):
+        """Fills an input set (default: the one the teacher phase reads) on the CURRENT stream."""
         m, B = self.m, self.B
+        S = self.nxt if S is None else S
         avail = m.noise_scheduler._timesteps_host
         order = 2
         if time_inds is not None:
@@ -975,19 +1002,23 @@ class _DistillStepGraph:
         elif guidance_scale is None:
             guidance_scale = torch.rand(B) * m.max_rand_guidance_scale
         t_np1, t_n, plan = self._sigma_plan(inds.numpy())
+        if self.pipelined:
+            self._ev_h2d.synchronize()       # the previous batch's host -> device copies have left the pinned buffer
         host = self._pinned
         host[0].copy_(torch.from_numpy(np.asarray(t_np1, dtype=np.float32)))
         host[1].copy_(torch.from_numpy(np.asarray(t_n, dtype=np.float32)))
         host[2].copy_(guidance_scale.detach().to("cpu", torch.float32).reshape(-1).expand(B))
         for i, s_ in enumerate(plan):
             host[3 + i].copy_(torch.from_numpy(np.asarray(s_, dtype=np.float32).reshape(-1)))
-        self.t_np1.copy_(host[0], non_blocking=True)
-        self.t_n.copy_(host[1], non_blocking=True)
-        self.w.copy_(host[2], non_blocking=True)
+        S["t_np1"].copy_(host[0], non_blocking=True)
+        S["t_n"].copy_(host[1], non_blocking=True)
+        S["w"].copy_(host[2], non_blocking=True)
         for i in range(len(plan)):
-            self.sig[i].copy_(host[3 + i], non_blocking=True)
-        self.z0.copy_(z_0)
-        self.noise.copy_(noise)
+            S["sig"][i].copy_(host[3 + i], non_blocking=True)
+        S["z0"].copy_(z_0)
+        S["noise"].copy_(noise)
+        if self.pipelined:
+            self._ev_h2d.record()
 
     # -- device side: `_forward_impl` (training branch) + `_student_backward`, on static tensors only
     def _body(self):
@@ -995,57 +1026,88 @@ class _DistillStepGraph:
         self.m._student_backward(pred, target, s_loss, gamma, 1.0 / self.accum, None)
         return out
 
-    def _forward_part(self):
-        m, B, dev = self.m, self.B, self.dev
+    def _teacher_part(self, S):
+        """Noising, the two CFG teacher queries and the Heun step between them (audio_consistency_model.py:268-311) on the
+        input set S: writes the student's input S['z_in'] and the target network's input S['tgt_in'].  Nothing here
+        depends on the student's weights: the pipelined step runs it for batch i + 1 beside the rest of batch i."""
+        m, B = self.m, self.B
         sch = m.noise_scheduler
         L_ = N.lib()
-        z0, noise, w = self.z0, self.noise, self.w
+        z0, noise = S["z0"], S["noise"]
         n = z0[0].numel()
-        s_add, s_next1, s_scale2, s_prev2, s_cur2, s_scale3, s_loss = self.sig[:7]
-        embeds_cf, mask_cf, embeds, mask = m.get_prompt_embeds(self.P, m.use_teacher_cf_guidance, 1)
+        s_add, s_next1, s_scale2, s_prev2, s_cur2, s_scale3 = S["sig"][:6]
+        embeds_cf, mask_cf, _, _ = m.get_prompt_embeds(self.P, m.use_teacher_cf_guidance, 1)
 
-        def scale(x, sg):
-            out = torch.empty_like(x)
+        def scale(x, sg, out=None):
+            out = torch.empty_like(x) if out is None else out
             N.check(L_.ctta_heun_scale_model_input(N.ptr(x), N.ptr(sg), N.ptr(out), B, n, N.stream_ptr()))
             return out
         z_noisy = torch.empty_like(z0)
         N.check(L_.ctta_heun_add_noise(N.ptr(z0), N.ptr(noise), N.ptr(s_add), N.ptr(z_noisy), B, n, N.stream_ptr()))
         z_gauss = noise * float(sch.init_noise_sigma)
         t_max = float(sch._timesteps_host.max())
-        z_np1 = torch.where((self.t_np1 == t_max).reshape(-1, 1, 1, 1), z_gauss, z_noisy)
-        z_np1_scaled = scale(z_np1, s_add)
-        side_pred = None
-        two_stream = os.environ.get("CTTA_TWO_STREAM", "1") != "0"
-        if two_stream:
-            cur = torch.cuda.current_stream(dev)
-            side = m._side_stream(dev)
-            side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                side_pred = m.student_unet.forward_train(z_np1_scaled, self.t_np1, w, embeds, mask)
-        w_t = w if m.teacher_guidance_scale == -1 else None      # None: `_query_teacher` takes the model's fixed scale
-        v1 = m._query_teacher(z_np1_scaled, self.t_np1, embeds_cf, mask_cf, w_t, reuse_text=False)
+        z_np1 = torch.where((S["t_np1"] == t_max).reshape(-1, 1, 1, 1), z_gauss, z_noisy)
+        z_np1_scaled = scale(z_np1, s_add, S["z_in"])
+        if self._fork_student is not None:
+            self._fork_student()      # unpipelined: the student's forward starts here, beside the teacher queries
+        w_t = S["w"] if m.teacher_guidance_scale == -1 else None      # None: `_query_teacher` takes the model's fixed scale
+        v1 = m._query_teacher(z_np1_scaled, S["t_np1"], embeds_cf, mask_cf, w_t, reuse_text=False)
         zhat = torch.empty_like(z0)
         deriv = torch.empty_like(z0)
         N.check(L_.ctta_heun_step_first(N.ptr(v1.contiguous()), N.ptr(z_np1), N.ptr(s_add), N.ptr(s_next1), N.ptr(zhat),
                                         N.ptr(deriv), B, n, N.stream_ptr()))
-        v2 = m._query_teacher(scale(zhat, s_scale2), self.t_n, embeds_cf, mask_cf, w_t, reuse_text=True)   # K / V of query 1
+        v2 = m._query_teacher(scale(zhat, s_scale2), S["t_n"], embeds_cf, mask_cf, w_t, reuse_text=True)   # K / V of query 1
         zhat2 = torch.empty_like(z0)
         N.check(L_.ctta_heun_step_second(N.ptr(v2.contiguous()), N.ptr(zhat), N.ptr(z_np1), N.ptr(deriv), N.ptr(s_prev2),
                                          N.ptr(s_cur2), N.ptr(zhat2), B, n, N.stream_ptr()))
-        target = m.student_target_unet(scale(zhat2, s_scale3), self.t_n, guidance=w, encoder_hidden_states=embeds,
-                                       encoder_attention_mask=mask).sample
-        target = torch.where((self.t_n == 0).reshape(-1, 1, 1, 1), z0, target).contiguous()
-        if side_pred is not None:
-            torch.cuda.current_stream(dev).wait_stream(m._side_stream(dev))
-            pred = side_pred
+        scale(zhat2, s_scale3, S["tgt_in"])
+
+    _fork_student = None
+
+    def _main_part(self, S, teacher_first):
+        """Target network, the student's training forward (on its side stream) and the loss, on the input set S whose
+        teacher phase is done (`teacher_first=False`) or runs first in this same sequence (the unpipelined step)."""
+        m, B, dev = self.m, self.B, self.dev
+        L_ = N.lib()
+        w = S["w"]
+        _, _, embeds, mask = m.get_prompt_embeds(self.P, m.use_teacher_cf_guidance, 1)
+        two_stream = os.environ.get("CTTA_TWO_STREAM", "1") != "0"
+        box = {}
+
+        def fork():
+            if not two_stream:
+                return
+            cur = torch.cuda.current_stream(dev)
+            side = m._side_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                box["pred"] = m.student_unet.forward_train(S["z_in"], S["t_np1"], w, embeds, mask)
+        if teacher_first:
+            self._fork_student = fork
+            try:
+                self._teacher_part(S)
+            finally:
+                self._fork_student = None
         else:
-            pred = m.student_unet.forward_train(z_np1_scaled, self.t_np1, w, embeds, mask)
+            fork()
+        target = m.student_target_unet(S["tgt_in"], S["t_n"], guidance=w, encoder_hidden_states=embeds,
+                                       encoder_attention_mask=mask).sample
+        target = torch.where((S["t_n"] == 0).reshape(-1, 1, 1, 1), S["z0"], target).contiguous()
+        if "pred" in box:
+            torch.cuda.current_stream(dev).wait_stream(m._side_stream(dev))
+            pred = box["pred"]
+        else:
+            pred = m.student_unet.forward_train(S["z_in"], S["t_np1"], w, embeds, mask)
         gamma = m.snr_gamma or 0.0
+        s_loss = S["sig"][6]
         inst = torch.empty(B, dtype=torch.float32, device=dev)
         out = torch.empty(1, dtype=torch.float32, device=dev)
         N.check(L_.ctta_snr_mse_loss(N.ptr(pred.contiguous()), N.ptr(target), N.ptr(s_loss), float(gamma), N.ptr(inst),
                                      N.ptr(out), B, pred[0].numel(), N.stream_ptr()))
         return out, pred, target, s_loss, gamma
+
+    def _forward_part(self):
+        return self._main_part(self.cur, teacher_first=not self.pipelined)
 
     def _capture_segments(self, warm):
         """forward + loss + out head | one graph per backward block, all in one memory pool."""
@@ -1080,11 +1142,18 @@ class _DistillStepGraph:
             warm = torch.cuda.Stream(device=self.dev)
             warm.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(warm):
+                if self.pipelined:
+                    self._teacher_part(self.nxt)
+                    self.cur["flat"].copy_(self.nxt["flat"])
                 self._body()
             torch.cuda.current_stream(self.dev).wait_stream(warm)
             torch.cuda.synchronize(self.dev)
             for net in (m.student_unet, m.student_target_unet):   # their bf16 re-pack belongs to every replay
                 net._h_version = None
+            if self.pipelined:
+                self.teacher_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.teacher_graph, stream=warm, capture_error_mode="thread_local"):
+                    self._teacher_part(self.nxt)
             if self.segmented:
                 self.loss = self._capture_segments(warm)
             else:
@@ -1095,8 +1164,9 @@ class _DistillStepGraph:
         return self
 
     def replay(self, on_block_done=None):
-        """The device work of one micro-step.  Segmented: `on_block_done(block id)` runs between two replays, when that
-        block's gradients are final on the stream (what `ctta_unet_backward_next` reports to `train_step`)."""
+        """The device work of one micro-step on the CURRENT input set.  Segmented: `on_block_done(block id)` runs between
+        two replays, when that block's gradients are final on the stream (what `ctta_unet_backward_next` reports to
+        `train_step`).  Pipelined captures: the teacher phase of the current set is NOT part of this (see `feed`)."""
         if not self.segmented:
             self.graph.replay()
             return
@@ -1105,13 +1175,38 @@ class _DistillStepGraph:
             if on_block_done is not None:
                 on_block_done(blk)
 
+    def feed(self, z_0, time_inds=None, gaussian_noise=None, guidance_scale=None):
+        """Pipelined captures: hands the NEXT batch (latents + draws) to the teacher stream -- inputs refreshed and the
+        teacher graph replayed there, beside whatever the main stream does -- after moving the batch fed before into the
+        current set.  `step` calls it; a training loop may call it directly to prime the pipeline with its first batch."""
+        assert self.pipelined
+        cur = torch.cuda.current_stream(self.dev)
+        if self._primed:
+            cur.wait_event(self._ev_teacher)                 # the teacher phase of the batch fed last time is complete
+            self.cur["flat"].copy_(self.nxt["flat"])         # ... and that batch becomes the current one (one device copy)
+        self._tstream.wait_stream(cur)
+        with torch.cuda.stream(self._tstream):
+            self._refresh(z_0, time_inds, gaussian_noise, guidance_scale)
+            self.teacher_graph.replay()
+            self._ev_teacher.record(self._tstream)
+        was, self._primed = self._primed, True
+        return was
+
     def step(self, z_0, lr_scheduler=None, time_inds=None, gaussian_noise=None, guidance_scale=None, skip_nan=True):
         """`AudioLCM.train_step`: refresh the static inputs, replay, then -- on every `accumulation_steps`-th call -- the
         eager tail (gradient all-reduce joined, AdamW, LR schedule, zero_grad, EMA).  With a process group the capture
         must be `segmented` so that the all-reduce of a finished block is issued before the next block's replay.
-        Returns the (unscaled) loss as a Python float."""
+        Returns the (unscaled) loss as a Python float.
+
+        Pipelined captures (`pipeline_teacher=True`): `z_0` and the draws are those of the NEXT batch -- their teacher
+        phase is queued on the teacher stream and overlaps this call's student / target / backward work, which trains on
+        the batch fed by the PREVIOUS call (the first call primes the pipeline with its batch and trains on it too)."""
         m = self.m
-        self._refresh(z_0, time_inds, gaussian_noise, guidance_scale)
+        if self.pipelined:
+            if not self.feed(z_0, time_inds, gaussian_noise, guidance_scale):
+                self.feed(z_0, time_inds, gaussian_noise, guidance_scale)      # first call: the same batch is also the next one
+        else:
+            self._refresh(z_0, time_inds, gaussian_noise, guidance_scale)
         self._micro += 1
         if self._micro % self.accum != 0:      # DDP's no_sync: gradients only accumulate locally
             self.replay()
@@ -1143,19 +1238,23 @@ class _DistillStepGraph:
         return value
 
 
-def _capture_train_graph(self, optimizer, z_0, prompt, segmented=None, accumulation_steps=1, **draws):
+def _capture_train_graph(self, optimizer, z_0, prompt, segmented=None, accumulation_steps=1, pipeline_teacher=False, **draws):
     """hipGraph-captured distillation step (loss_type='mse'): returns a `_DistillStepGraph` whose
     `.step(z_0, lr_scheduler, ...)` replaces `train_step(z_0, prompt, optimizer, lr_scheduler, ...)` for fixed shapes and a
     fixed prompt batch (`prompt` must be the dict of pre-computed text states; refresh `graph.P[...]` in place to change them).
     `segmented` (default: whenever a process group with more than one rank exists) captures the backward block by block
-    so that the data-parallel gradient all-reduce overlaps it as in the eager `train_step`."""
+    so that the data-parallel gradient all-reduce overlaps it as in the eager `train_step`.
+    `pipeline_teacher=True`: the frozen teacher's two CFG queries + Heun step (a third of the step's device time, and
+    independent of the student's weights) are captured as their own graph and run for batch i + 1 on a second stream
+    beside the student / target / backward work of batch i -- `step(z_next)` then trains on the batch fed one call
+    earlier (software pipelining of the training loop; same arithmetic per batch)."""
     if segmented is None:
         segmented = (dist_util.dist.is_initialized() and dist_util.dist.get_world_size() > 1) or \
             os.environ.get("CTTA_FORCE_COLLECTIVES", "0") == "1"
     if not isinstance(prompt, dict):
         raise N.CttaError("capture_train_graph needs the pre-computed text states (dict), not prompt strings")
     return _DistillStepGraph(self, optimizer, tuple(z_0.shape), prompt, segmented=segmented,
-                             accumulation_steps=accumulation_steps).capture(z_0, **draws)
+                             accumulation_steps=accumulation_steps, pipeline_teacher=pipeline_teacher).capture(z_0, **draws)
 
 
 AudioLCM.capture_train_graph = _capture_train_graph

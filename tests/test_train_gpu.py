@@ -411,6 +411,66 @@ def test_segmented_step_graph_with_rccl_buckets_equals_monolithic_graph_and_eage
             dist.destroy_process_group()
 
 
+def test_pipelined_teacher_step_graph_equals_eager_on_a_sequence_of_batches(golden):
+    """Round 4: `capture_train_graph(pipeline_teacher=True)` -- the frozen teacher's two CFG queries + Heun step of batch
+    i + 1 run as their own hipGraph on a second stream beside the student / target / backward graph of batch i
+    (audio_consistency_model.py:268-311 has no dependence on the student's weights).  Three DIFFERENT batches with
+    different draws, fed one call ahead: every replayed micro-step must give the eager step's loss bit for bit and its
+    gradient to the LayerNorm-atomics round-off -- i.e. the rotation of the input sets (one device copy) hands each
+    batch's teacher outputs, timesteps, sigmas and guidance to the right main-graph replay.  Monolithic and segmented."""
+    g = golden("distill_tiny")
+    gen = torch.Generator().manual_seed(23)
+    batches = []
+    for i in range(4):
+        batches.append(dict(z=(torch.randn(3, 8, 32, 8, generator=gen) * 0.9).to(DEV),
+                            kw=dict(time_inds=torch.randint(0, 17, (3,), generator=gen) * 2,
+                                    gaussian_noise=torch.randn(3, 8, 32, 8, generator=gen).to(DEV),
+                                    guidance_scale=torch.rand(3, generator=gen) * 6)))
+    batches[1]["kw"]["time_inds"][0] = 0           # pure-noise branch
+    batches[2]["kw"]["time_inds"][1] = 32          # t_n = 0: the target is z_0 of THAT batch
+    nets = ("student_unet", "student_target_unet", "student_ema_unet")
+    for segmented in (False, True):
+        m1, P, _ = _lcm()
+        m1.train()
+        o1 = m1.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)
+        m2, _, _ = _lcm()
+        m2.train()
+        o2 = m2.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)
+        gs = m2.capture_train_graph(o2, batches[3]["z"], P, segmented=segmented, pipeline_teacher=True, **batches[3]["kw"])
+        assert gs.pipelined and gs.teacher_graph is not None and float(o2.grad.abs().max()) == 0.0
+        assert gs.feed(batches[0]["z"], **batches[0]["kw"]) is False            # primes the pipeline
+        for i in range(3):
+            b = batches[i]
+            for name in nets:
+                getattr(m2, name)._flat.copy_(getattr(m1, name)._flat)
+                getattr(m2, name).mark_weights_changed()
+            with torch.no_grad():
+                loss, pred, target, sig, gamma = m1._forward_impl(b["z"], None, P, False, True, b["kw"]["time_inds"],
+                                                                  b["kw"]["gaussian_noise"], b["kw"]["guidance_scale"], True)
+                m1._student_backward(pred, target, sig, gamma, 1.0, None)
+            assert gs.feed(batches[i + 1]["z"], **batches[i + 1]["kw"]) is True  # batch i becomes current, i + 1 goes to the teacher
+            gs.replay()
+            torch.cuda.synchronize()
+            l_e, l_g = float(loss), float(gs.loss.item())
+            rel = float((o1.grad - o2.grad).norm() / o1.grad.norm())
+            print("%s, batch %d: eager loss %.9g pipelined %.9g, gradient rel diff %.2e"
+                  % ("segmented" if segmented else "monolithic", i, l_e, l_g, rel))
+            assert l_e == l_g and np.isfinite(l_e) and rel <= 1e-7
+            for o, m in ((o1, m1), (o2, m2)):
+                o.step(grad_scale=1.0)
+                o.zero_grad()
+                m.update_ema()
+        # the public entry point: `step(z_next)` trains on the batch fed before (batch 3 here) and queues z_next
+        for name in nets:
+            getattr(m2, name)._flat.copy_(getattr(m1, name)._flat)
+            getattr(m2, name).mark_weights_changed()
+        v1 = m1.train_step(batches[3]["z"], P, o1, None, **batches[3]["kw"])
+        v2 = gs.step(batches[0]["z"], None, **batches[0]["kw"])
+        assert v1 == v2 and o1.step_count == o2.step_count == 4
+        torch.cuda.synchronize()
+        del gs
+
+
 def test_step_graph_with_a_fixed_teacher_guidance_scale_equals_eager(golden):
     """with teacher_guidance_scale = 3 the eager `_forward_impl` conditions student and target on
     w = 3 (audio_consistency_model.py:300-311: the random draw exists only for scale -1); the captured step must do the

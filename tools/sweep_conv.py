@@ -91,6 +91,23 @@ SHAPES = [
     ("t9 conv 32x2 1024>1024", 9, 32, 2, 1024, 1024, 3, 3, 1),
     ("t9 conv 64x4 2048>1024", 9, 64, 4, 2048, 1024, 3, 3, 1),
     ("t9 conv 256x16 512>256", 9, 256, 16, 512, 256, 3, 3, 1),
+    # round 4: the thin K-heavy rows of launch_table_distill (SWEEP_FILTER=thin)
+    ("thin conv 32x2 b9 1024>1024", 9, 32, 2, 1024, 1024, 3, 3, 1),
+    ("thin conv 32x2 b18 1024>1024", 18, 32, 2, 1024, 1024, 3, 3, 1),
+    ("thin conv 64x4 b9 1024>1024", 9, 64, 4, 1024, 1024, 3, 3, 1),
+    ("thin conv 64x4 b18 1024>1024", 18, 64, 4, 1024, 1024, 3, 3, 1),
+    ("thin conv 128x8 b9 512>512", 9, 128, 8, 512, 512, 3, 3, 1),
+    ("thin conv 128x8 b18 512>512", 18, 128, 8, 512, 512, 3, 3, 1),
+    ("thin conv 256x16 b9 256>256", 9, 256, 16, 256, 256, 3, 3, 1),
+    ("thin conv 256x16 b18 256>256", 18, 256, 16, 256, 256, 3, 3, 1),
+    ("thin lin M2304 1280>1024", 9, 256, 1, 1280, 1024, 1, 1, 1),
+    ("thin lin M2304 1024>1024", 9, 256, 1, 1024, 1024, 1, 1, 1),
+    ("thin lin M2304 4096>1024", 9, 256, 1, 4096, 1024, 1, 1, 1),
+    ("thin lin M9216 640>512", 9, 1024, 1, 640, 512, 1, 1, 1),
+    ("thin lin M9216 512>512", 9, 1024, 1, 512, 512, 1, 1, 1),
+    ("thin lin M36864 320>256", 9, 4096, 1, 320, 256, 1, 1, 1),
+    ("thin lin M36864 256>256", 9, 4096, 1, 256, 256, 1, 1, 1),
+    ("thin lin M73728 320>256", 18, 4096, 1, 320, 256, 1, 1, 1),
     # fused GEGLU (SWEEP_GEGLU=1 SWEEP_FILTER=ff1): N counts value + gate columns
     ("ff1 M131072 256>2048", 32, 4096, 1, 256, 2048, 1, 1, 1),
     ("ff1 M32768 512>4096", 32, 1024, 1, 512, 4096, 1, 1, 1),
@@ -130,7 +147,13 @@ def main():
         x = (torch.randn(B, H, W, Cin, device=DEV) * 0.5).to(torch.bfloat16)
         K = kh * kw * Cin
         k_pad = (K + 63) // 64 * 64
-        w = (torch.randn(Cout, k_pad, device=DEV) * 0.05).to(torch.bfloat16)
+        # SWEEP_COLD=1: every launch reads ANOTHER copy of the weights (> 512 MB of copies in rotation: past the 256 MB
+        # Infinity Cache), as inside the pipeline where a layer's weights arrive cold from HBM
+        ncopy = 1
+        if os.environ.get("SWEEP_COLD", "0") == "1":
+            ncopy = max(2, min(64, (600 << 20) // (Cout * k_pad * 2) + 1))
+        ws = [(torch.randn(Cout, k_pad, device=DEV) * 0.05).to(torch.bfloat16) for _ in range(ncopy)]
+        w = ws[0]
         bias = torch.randn(Cout, device=DEV)
         out = torch.empty(B, H, W, Cout // 2 if geglu else Cout, dtype=torch.bfloat16, device=DEV)
         M = B * H * W
@@ -161,9 +184,10 @@ def main():
             N.check(L.ctta_conv_gemm(ctypes.byref(d), st))
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            reps = 5
+            reps = 5 if ncopy == 1 else 2 * ncopy
             e0.record()
-            for _ in range(reps):
+            for r_ in range(reps):
+                d.w = ws[r_ % ncopy].data_ptr()
                 N.check(L.ctta_conv_gemm(ctypes.byref(d), st))
             e1.record()
             torch.cuda.synchronize()
@@ -178,7 +202,7 @@ def main():
         else:
             print("%-24s M=%8d N=%5d K=%6d  best %-22s %s" % (tag, M, Cout, K, best,
                   " ".join("%6.0f" % t for t in row["tflops"].values())), flush=True)
-        del x, w, out
+        del x, w, ws, out
     if len(sys.argv) > 1:
         json.dump({"variants": names, "shapes": results}, open(sys.argv[1], "w"), indent=1)
 
