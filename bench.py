@@ -569,6 +569,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     # data-parallel step stays eager; both rates are reported.
     dt_eager, launch_mode = dt, "eager launches (two streams + weight-gradient side stream)"
     dt_seg = dt_graph = dt_pipe = dt_seg_pipe = None
+    placements = []
     if not perceptual and os.environ.get("CTTA_BENCH_GRAPH", "1") != "0" and not args.no_latency:
         gdr = torch.Generator().manual_seed(77 + rank)
         kw = dict(time_inds=torch.randint(0, 17, (B,), generator=gdr) * 2,
@@ -578,6 +579,8 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             """Capture, check one replay against an eager forward with the same draws, time n_steps public steps.  Every
             rank runs the same sequence (the segmented step issues the bucket all-reduces between its replays)."""
             gs = m.capture_train_graph(opt, z0, P, segmented=segmented, pipeline_teacher=pipelined, **kw)
+            if pipelined:
+                placements.append(getattr(gs, "placement_ms", None))
             with torch.no_grad():
                 loss_e = float(m._forward_impl(z0, None, P, False, True, kw["time_inds"], kw["gaussian_noise"],
                                                kw["guidance_scale"], True)[0])
@@ -642,6 +645,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         "eager_ms_per_step": round(dt_eager / n_steps * 1e3, 3),
         "segmented_ms_per_step": None if dt_seg is None else round(dt_seg / n_steps * 1e3, 3),
         "segmented_pipelined_ms_per_step": None if dt_seg_pipe is None else round(dt_seg_pipe / n_steps * 1e3, 3),
+        "teacher_stream_placement_ms": placements or None,   # (teacher graph || main graph) per candidate stream, see _place_teacher_stream
         "graph_ms_per_step": None if dt_graph is None else round(dt_graph / n_steps * 1e3, 3),
         "pipelined_ms_per_step": None if dt_pipe is None else round(dt_pipe / n_steps * 1e3, 3),
         "n_gpus": world, "scaling": "weak", "dtype": "bf16 (fp32 master weights, gradients, AdamW moments)",
@@ -680,6 +684,42 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     out["grad_accum_5"] = {"value": round(n_opt / dt5, 4), "unit": "optimizer steps/s", "optimizer_steps": n_opt,
                            "micro_steps_per_s": round(acc * n_opt / dt5, 3), "samples_per_s": round(world * B * acc * n_opt / dt5, 3),
                            "ms_per_optimizer_step": round(dt5 / n_opt * 1e3, 3), "global_batch": B * world * acc}
+    # The same optimizer step -- 5 x 9 samples per GPU -- as ONE micro-batch of 45: accumulation exists in train.sh because the
+    # reference's GPUs cannot hold more than 9 samples; one MI355X holds the activations of 45 (about 30 of its 288 GB).  Same
+    # samples per optimizer step and the same mathematics (tests/test_train_gpu.py::test_fused_accumulation...); 5x larger
+    # GEMMs per launch.  Timed with eager launches (every rank: the all-reduce sequence must not depend on a capture).
+    if os.environ.get("CTTA_BENCH_FUSED_ACCUM", "1") != "0" and not args.no_latency:
+        try:
+            Bf = B * acc
+            gf = torch.Generator(device="cpu").manual_seed(55 + rank)
+            z45 = (torch.randn(Bf, 8, 256, 16, generator=gf) * 0.9).to(dev)
+            enc45 = (torch.randn(Bf, L, 1024, generator=gf) * 0.25).to(dev)
+            lens45 = torch.randint(6, L + 1, (Bf,), generator=gf)
+            mask45 = (torch.arange(L)[None, :] < lens45[:, None]).to(dev)
+            unc45, um45 = torch.zeros_like(enc45), torch.zeros_like(mask45)
+            um45[:, 0] = True
+            P45 = {"embeds_cf": torch.cat([unc45, enc45]), "mask_cf": torch.cat([um45, mask45]), "embeds": enc45, "mask": mask45}
+            for _ in range(2):
+                losses.append(m.train_step(z45, P45, opt, sched))
+            du.barrier(dev)
+            t0 = time.perf_counter()
+            for _ in range(n_opt):
+                losses.append(m.train_step(z45, P45, opt, sched))
+            du.barrier(dev)
+            dtf = du.max_over_ranks(time.perf_counter() - t0, dev)
+            out["grad_accum_5_fused"] = {"value": round(n_opt / dtf, 4), "unit": "optimizer steps/s", "optimizer_steps": n_opt,
+                                         "samples_per_s": round(world * Bf * n_opt / dtf, 3),
+                                         "ms_per_optimizer_step": round(dtf / n_opt * 1e3, 3), "global_batch": Bf * world,
+                                         "micro_batch_per_gpu": Bf,
+                                         "note": "the 45 samples of one optimizer step as ONE micro-batch (no accumulation loop)"}
+            del z45, enc45, P45
+            # back to the per-GPU batch of 9 for the profiled step below (the handles keep their larger arenas)
+            m.train_step(z0, P, opt, sched)
+        except Exception as exc:
+            if world > 1:
+                raise
+            out["grad_accum_5_fused"] = {"error": str(exc)[:200]}
+    assert all(v == v for v in losses), "NaN distillation loss"
     # one more step with the in-library launch profiler on rank 0.  EVERY rank takes the step: at world > 1 it issues
     # the gradient all-reduces, and a collective entered by rank 0 alone would pair up with the other ranks' next
     # barrier and hang the job

@@ -1472,6 +1472,37 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     p[i] = pp; m[i] = mm; v[i] = vv;
   }
 }
+// the same arithmetic on 16-byte vectors, two vectors in flight per thread (seven fp32 streams: the scalar kernel above
+// moved 4.8 TB/s; round 4)
+__global__ __launch_bounds__(256) void adamw4_kernel(float4* __restrict__ p, const float4* __restrict__ g,
+                                                     float4* __restrict__ m, float4* __restrict__ v, long long n4, float lr,
+                                                     float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
+                                                     float grad_scale) {
+  const float decay = 1.0f - lr * wd, step = lr / bc1, omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
+  auto one = [&](float& pp, float gq, float& mm, float& vv) {
+    const float gr = gq * grad_scale;
+    float q = pp * decay;
+    mm = mm + omb1 * (gr - mm);
+    vv = beta2 * vv + omb2 * gr * gr;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    q -= step * (mm / denom);
+    pp = q;
+  };
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+    const long long j = i + stride;
+    const bool two = j < n4;
+    float4 p0 = p[i], g0 = g[i], m0 = m[i], v0 = v[i];
+    float4 p1, g1, m1, v1;
+    if (two) { p1 = p[j]; g1 = g[j]; m1 = m[j]; v1 = v[j]; }
+    one(p0.x, g0.x, m0.x, v0.x); one(p0.y, g0.y, m0.y, v0.y); one(p0.z, g0.z, m0.z, v0.z); one(p0.w, g0.w, m0.w, v0.w);
+    p[i] = p0; m[i] = m0; v[i] = v0;
+    if (two) {
+      one(p1.x, g1.x, m1.x, v1.x); one(p1.y, g1.y, m1.y, v1.y); one(p1.z, g1.z, m1.z, v1.z); one(p1.w, g1.w, m1.w, v1.w);
+      p[j] = p1; m[j] = m1; v[j] = v1;
+    }
+  }
+}
 extern "C" ctta_status ctta_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                        float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                        float grad_scale, void* stream) {
@@ -1479,8 +1510,20 @@ extern "C" ctta_status ctta_adamw_step(float* param, const float* grad, float* e
   // bias corrections in double on the host, like torch's Python-float arithmetic (optim/adamw.py)
   const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
-                     exp_avg_sq, (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
-  CTTA_LAUNCH_CHECK();
+  const bool aligned = (((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0;
+  const long long n4 = aligned ? n / 4 : 0;
+  if (n4 > 0) {
+    hipLaunchKernelGGL(adamw4_kernel, dim3(grid1d(n4, 256, 2048)), dim3(256), 0, (hipStream_t)stream, (float4*)param,
+                       (const float4*)grad, (float4*)exp_avg, (float4*)exp_avg_sq, n4, lr, beta1, beta2, eps, weight_decay, bc1,
+                       bc2s, grad_scale);
+    CTTA_LAUNCH_CHECK();
+  }
+  const long long done = n4 * 4;
+  if (done < n) {
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid1d(n - done, 256, 4096)), dim3(256), 0, (hipStream_t)stream, param + done,
+                       grad + done, exp_avg + done, exp_avg_sq + done, (long long)(n - done), lr, beta1, beta2, eps, weight_decay,
+                       bc1, bc2s, grad_scale);
+    CTTA_LAUNCH_CHECK();
+  }
   return CTTA_OK;
 }

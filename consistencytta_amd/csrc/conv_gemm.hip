@@ -236,12 +236,6 @@ static const Variant kVariants[] = {
     VARIANT(256, 256, 32, 2, 4, 2, 4),  // 34
     VARIANT(512, 128, 32, 4, 2, 2, 2),  // 35  N = 128 layers: 8 waves of 128x64 (the big tile's wave shape) over 512 rows
     VARIANT(512, 128, 64, 4, 2, 2, 2),  // 36  ... with BK = 64: the whole 160 KB of LDS
-    VARIANT(64, 128, 64, 2, 2, 3, 2),   // 37  register prefetch (MODE 3): K tiles ride in VGPRs, STAGES deep, 2-slot LDS ring
-    VARIANT(128, 128, 64, 2, 2, 3, 3),  // 38
-    VARIANT(64, 64, 64, 2, 2, 3, 3),    // 39
-    VARIANT(128, 64, 64, 2, 2, 3, 3),   // 40
-    VARIANT(128, 128, 64, 2, 2, 3, 2),  // 41
-    VARIANT(64, 128, 64, 2, 2, 3, 3),   // 42
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -498,22 +492,6 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       if (wgs >= 512 && wgs * 100 >= rounds * 512 * 85) vid = 27;
     }
   }
-  {   // Register-prefetch twins (MODE 3) of the thin-grid descriptor tiles: the K tiles ride in VGPRs, 2-3 deep, behind a
-      // 2-slot LDS ring -- 2-3x the bytes in flight per CU at the same occupancy (conv_gemm_kernel.h).  CTTA_REGPF=0: off.
-    static int regpf = -1, mink = -1, v64128 = -1, v128128 = -1;
-    if (regpf < 0) {
-      const char* e = getenv("CTTA_REGPF"); regpf = (e && e[0] == '0') ? 0 : 1;
-      e = getenv("CTTA_REGPF_MINK"); mink = e ? atoi(e) : 512;
-      e = getenv("CTTA_REGPF_64128"); v64128 = e ? atoi(e) : 42;
-      e = getenv("CTTA_REGPF_128128"); v128128 = e ? atoi(e) : 38;
-    }
-    if (regpf && d->tile <= 0 && !geglu && K >= mink) {
-      if (vid == 22 || vid == 27) vid = v64128;
-      else if (vid == 17) vid = v128128;
-      else if (vid == 21) vid = 39;
-      else if (vid == 24) vid = 40;
-    }
-  }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
   if (geglu) {   // direct epilogue: <= 8-fragment tiles (64x64, 64x128, 128x64, 256x32); wide-store: also the 128x128 tiles
     const Variant& gv = kVariants[vid - 1];
@@ -522,7 +500,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
                  "conv_gemm: the fused GEGLU epilogue needs a tile with <= 8 fragments per wave (or, wide-store, <= 16): got %s",
                  gv.name);
   }
-  CTTA_REQUIRE(kVariants[vid - 1].mode < 2 || fast_ok(kVariants[vid - 1].bk),
+  CTTA_REQUIRE(kVariants[vid - 1].mode != 2 || fast_ok(kVariants[vid - 1].bk),
                "conv_gemm: variant %s needs (c0+c1) %% BK == 0, one source and <= 32 taps", kVariants[vid - 1].name);
   const Variant& v = kVariants[vid - 1];
   p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;

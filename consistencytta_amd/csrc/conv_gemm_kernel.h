@@ -33,12 +33,6 @@
 // channel base are wave-uniform scalars), <= 32 taps and one source; per row only a pixel base and
 // a tap-validity bitmask are kept, padding chunks are sent out of range (hardware returns zeros),
 // weight rows >= n fall outside the descriptor, and the per-step K advance rides in soffset.
-// MODE 3 (round 4): MODE 2's addressing with the K tiles prefetched into REGISTERS, STAGES tiles deep, and a 2-slot LDS
-// ring behind them.  The thin-grid tiles (64x128, 128x128 at batch 9 / 18) are latency-bound: a K step costs ~1.1 us of
-// L2 / HBM round trip whatever the tile, the bytes in flight per CU set the rate (Little's law), and with LDS-DMA those
-// bytes are bounded by the ring that fits beside 2-3 workgroups (48-72 KB per CU in flight).  The register file holds
-// 512 KB per CU: STAGES x (BM + BN) x BK x 2 bytes per workgroup ride in VGPRs (24-32 registers per stage and lane),
-// 2-3x the bytes in flight at the same occupancy; a stage is written to the free LDS slot one K step before it is used.
 // n / d for 0 <= n < 2^31 with inv = floor(2^32 / d) (0xFFFFFFFF for d == 1): the estimate is q or q - 1
 __device__ __forceinline__ int fast_div(int n, int d, unsigned inv) {
   unsigned q = __umulhi((unsigned)n, inv);
@@ -216,13 +210,10 @@ __device__ __forceinline__ void epilogue_geglu(const ConvParams& p, const f32x4_
 // orders a wave's own LDS writes before its LDS reads (other lanes of the SAME wave) without a workgroup barrier
 #define WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-template <int MODE, int STAGES>
-static constexpr int lds_slots() { return MODE == 3 ? 2 : STAGES; }
 template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN, (MODE == 3 && BM * BN <= 64 * 128) ? 3 : 2) void conv_gemm_kernel(ConvParams p) {
-  constexpr bool GLDS = MODE == 1 || MODE == 2;
-  constexpr int LSTAGES = lds_slots<MODE, STAGES>();      // LDS ring slots (MODE 3: STAGES counts REGISTER stages)
-  static_assert(STAGES == 2 || MODE != 0, "multi-stage ring needs the direct-to-LDS path");
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p) {
+  constexpr bool GLDS = MODE != 0;
+  static_assert(STAGES == 2 || GLDS, "multi-stage ring needs the direct-to-LDS path");
   constexpr int NT = 64 * WM * WN;
   constexpr int LDK = BK;              // bf16 elements per LDS row: no padding, XOR-swizzled chunks
   // 16-byte chunk c of row r lives at chunk position c ^ swz(r): conflict-free for the 16-lane
@@ -240,7 +231,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == 3 && BM * BN <= 64 * 128) ? 
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_raw);               // [STAGES][BM][LDK]
-  bf16_t* Ws = Xs + LSTAGES * BM * LDK;                            // [STAGES][BN][LDK]
+  bf16_t* Ws = Xs + STAGES * BM * LDK;                             // [STAGES][BN][LDK]
   unsigned long long* stamp = nullptr;
   if (p.stamps) {
     stamp = p.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 6;
@@ -275,7 +266,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == 3 && BM * BN <= 64 * 128) ? 
   const int r0 = tid / CPR;
   // logical 16-byte K chunk this thread fetches: register path -> position tid % CPR (swizzled on
   // store); direct-to-LDS path -> the chunk whose swizzled home is position tid % CPR
-  const int kc = (GLDS || MODE == 3) ? ((tid % CPR) ^ ((r0 >> SWZ_SHIFT) & SWZ_MASK)) : (tid % CPR);
+  const int kc = GLDS ? ((tid % CPR) ^ ((r0 >> SWZ_SHIFT) & SWZ_MASK)) : (tid % CPR);
   const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
   constexpr int ROWS_PER_INSTR = 64 / CPR;   // rows one wave-wide 1 KiB LDS-DMA covers
 
@@ -415,7 +406,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == 3 && BM * BN <= 64 * 128) ? 
   int fih0[XP], fiw0[XP];
   int ftap = 0, fkh = 0, fkw = 0, fcb = 0;   // wave-uniform K state (tap index, its (kh,kw), channel base)
   __amdgpu_buffer_rsrc_t rsx, rsw;
-  if constexpr (MODE == 2 || MODE == 3) {
+  if constexpr (MODE == 2) {
     // K order on this path: taps INNERMOST -- K-step s = (channel chunk s / taps, tap s % taps).  All taps of one
     // 64-channel chunk re-read the same (BM + halo) x BK footprint (tens of KB: L1/L2 resident); with channels
     // innermost the whole (BM + halo) x C footprint of every resident workgroup has to survive between taps, which
@@ -517,46 +508,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == 3 && BM * BN <= 64 * 128) ? 
     if (ftap == p.taps) { ftap = 0; fkh = 0; fkw = 0; fcb += BK; }
   };
 
-  // MODE 3: the same addresses, the data into registers (STAGES tiles deep), written to LDS one K step before use
-  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  constexpr int RST = MODE == 3 ? STAGES : 1;
-  u32x4_t xq[RST][XP], wq[RST][WP];
-  auto issue_regs = [&](u32x4_t (&xd)[XP], u32x4_t (&wd)[WP]) {
-    unsigned s_u;
-    bool use_h = false, use_w = false;
-    if (p.ups) {
-      const int bh = fkh == 0 ? -1 : 0, bw = fkw == 0 ? -1 : 0;
-      use_h = fkh != 1; use_w = fkw != 1;
-      s_u = (unsigned)((bh * p.ws + bw) * p.xs0 + fcb) * 2u;
-    } else {
-      s_u = (unsigned)((fkh * p.dh * p.ws + fkw * p.dw) * p.xs0 + fcb) * 2u;
-    }
-    const unsigned tbit = 1u << ftap;
-#pragma unroll
-    for (int i = 0; i < XP; ++i) {
-      unsigned v = fvoff[i] + s_u;
-      if (use_h) v += fph[i];
-      if (use_w) v += fpw[i];
-      v = (fmask[i] & tbit) ? v : 0xFFFFFFF0u;
-      xd[i] = __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)v, 0, 0);
-    }
-    const int soff = (ftap * p.ct + fcb) * 2;
-#pragma unroll
-    for (int j = 0; j < WP; ++j) wd[j] = __builtin_amdgcn_raw_buffer_load_b128(rsw, (int)fwoff[j], soff, 0);
-    ++ftap;
-    if (++fkw == p.kw) { fkw = 0; ++fkh; }
-    if (ftap == p.taps) { ftap = 0; fkh = 0; fkw = 0; fcb += BK; }
-  };
-  // the lane's chunk goes to position tid % CPR of its rows (kc is the logical chunk whose swizzled home that is)
-  auto write_regs = [&](const u32x4_t (&xd)[XP], const u32x4_t (&wd)[WP], int buf) {
-    bf16_t* xs = Xs + buf * BM * LDK + r0 * LDK + (tid % CPR) * 8;
-    bf16_t* ws = Ws + buf * BN * LDK + r0 * LDK + (tid % CPR) * 8;
-#pragma unroll
-    for (int i = 0; i < XP; ++i) *reinterpret_cast<u32x4_t*>(xs + i * RPP * LDK) = xd[i];
-#pragma unroll
-    for (int j = 0; j < WP; ++j) *reinterpret_cast<u32x4_t*>(ws + j * RPP * LDK) = wd[j];
-  };
-
   f32x4_t acc[FN][FM];
 #pragma unroll
   for (int i = 0; i < FN; ++i)
@@ -588,45 +539,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == 3 && BM * BN <= 64 * 128) ? 
     }
   };
 
-  if constexpr (MODE == 3) {
-    constexpr int R = STAGES;
-    // prologue: tiles 0 .. R-1 into register stages 0 .. R-1; tile 0 on to LDS slot 0, its stage refilled with tile R
-#pragma unroll
-    for (int s_ = 0; s_ < R; ++s_) {
-      if (s_ < nk) issue_regs(xq[s_], wq[s_]);
-      if (s_ == 0) full_masks();
-    }
-    write_regs(xq[0], wq[0], 0);
-    if (R < nk) issue_regs(xq[0], wq[0]);
-    __syncthreads();
-    // step kt: LDS slot kt & 1 holds tile kt; stage (kt + 1) % R (tile kt + 1) goes to the other slot (free since the barrier
-    // that ended step kt - 1) and is refilled with tile kt + 1 + R; R tiles stay in flight under the MFMAs.
-    // Steady state without guards (exact wait counts), then a guarded tail; both unrolled by R so that the stage index is static.
-    int kt0 = 0;
-    for (; kt0 + R < nk - R; kt0 += R) {
-#pragma unroll
-      for (int s_ = 0; s_ < R; ++s_) {
-        const int kt = kt0 + s_;
-        constexpr int dummy = 0; (void)dummy;
-        write_regs(xq[(s_ + 1) % R], wq[(s_ + 1) % R], (kt + 1) & 1);
-        issue_regs(xq[(s_ + 1) % R], wq[(s_ + 1) % R]);
-        if (wave_live) compute_tile(kt & 1);
-        __syncthreads();
-      }
-    }
-    for (; kt0 < nk; kt0 += R) {
-#pragma unroll
-      for (int s_ = 0; s_ < R; ++s_) {
-        const int kt = kt0 + s_;
-        if (kt < nk) {
-          if (kt + 1 < nk) write_regs(xq[(s_ + 1) % R], wq[(s_ + 1) % R], (kt + 1) & 1);
-          if (kt + 1 + R < nk) issue_regs(xq[(s_ + 1) % R], wq[(s_ + 1) % R]);
-          if (wave_live) compute_tile(kt & 1);
-          __syncthreads();
-        }
-      }
-    }
-  } else if constexpr (STAGES > 2) {
+  if constexpr (STAGES > 2) {
     constexpr int LPT = XP + WP;                 // LDS-DMA instructions per wave per tile
     constexpr int INFLIGHT = (STAGES - 2) * LPT; // what may stay outstanding while tile kt is consumed
     int issued = 0;
@@ -686,7 +599,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == 3 && BM * BN <= 64 * 128) ? 
   // bias sits in registers because a lane keeps its 4 channels, and the arithmetic runs in one rolled loop.
   if (p.wide_store) {
     constexpr int NW = WM * WN;
-    constexpr size_t RING = (size_t)LSTAGES * (BM + BN) * BK * 2;
+    constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
     constexpr int RSF = TN * 4 + 16;                       // staging row stride (bytes): +16 keeps 16-byte accesses conflict-free
     constexpr int CHR = (FM % 2 == 0 && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;   // rows per chunk
     static_assert((size_t)NW * CHR * RSF <= RING, "wide-store staging does not fit the ring");
@@ -882,7 +795,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == 3 && BM * BN <= 64 * 128) ? 
     // Large wave tiles: unrolling the generic epilogue once per fragment would blow the code size (and
     // a rolled loop cannot index registers), so fragments bounce through thread-private LDS slots in
     // chunks of 8 and a ROLLED loop runs the epilogue on them.  The ring is dead by now.
-    constexpr size_t RING = (size_t)LSTAGES * (BM + BN) * BK * 2;
+    constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
     constexpr int CH = (size_t)8 * NT * 24 <= RING ? 8 : 4;
     static_assert((FM * FN) % CH == 0 && (size_t)CH * NT * 24 <= RING, "stage size");
     __syncthreads();
@@ -929,7 +842,7 @@ static constexpr size_t smem_bytes() { return (size_t)STAGES * (BM + BN) * BK * 
 
 template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES>
 void launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
-  const size_t smem = smem_bytes<BM, BN, BK, lds_slots<GLDS, STAGES>()>();
+  const size_t smem = smem_bytes<BM, BN, BK, STAGES>();
   conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
 }
 
@@ -939,7 +852,7 @@ ctta_status prepare_variant() {
   if (done) return CTTA_OK;
   CTTA_CHECK_HIP(hipFuncSetAttribute(
       reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<BM, BN, BK, lds_slots<GLDS, STAGES>()>()));
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<BM, BN, BK, STAGES>()));
   done = true;
   return CTTA_OK;
 }
@@ -978,14 +891,7 @@ ctta_status prepare_variant() {
   X(256, 128, 64, 4, 2, 2, 2)
 #define CTTA_CONV_VARIANTS_7(X) \
   X(512, 128, 32, 4, 2, 2, 2) \
-  X(512, 128, 64, 4, 2, 2, 2) \
-  X(64, 128, 64, 2, 2, 3, 2) \
-  X(128, 128, 64, 2, 2, 3, 3)
-#define CTTA_CONV_VARIANTS_8(X) \
-  X(64, 64, 64, 2, 2, 3, 3) \
-  X(128, 64, 64, 2, 2, 3, 3) \
-  X(128, 128, 64, 2, 2, 3, 2) \
-  X(64, 128, 64, 2, 2, 3, 3)
+  X(512, 128, 64, 4, 2, 2, 2)
 #define CTTA_CONV_VARIANTS_6(X) \
   X(256, 32, 64, 4, 1, 2, 2) \
   X(64, 64, 64, 2, 2, 2, 2) \
@@ -995,7 +901,7 @@ ctta_status prepare_variant() {
   X(128, 128, 32, 2, 2, 2, 3) \
   X(64, 128, 64, 2, 2, 2, 3) \
   X(256, 128, 32, 4, 2, 2, 2)
-#define CTTA_CONV_VARIANTS_ALL(X) CTTA_CONV_VARIANTS_1(X) CTTA_CONV_VARIANTS_2(X) CTTA_CONV_VARIANTS_3(X) CTTA_CONV_VARIANTS_4(X) CTTA_CONV_VARIANTS_5(X) CTTA_CONV_VARIANTS_6(X) CTTA_CONV_VARIANTS_7(X) CTTA_CONV_VARIANTS_8(X)
+#define CTTA_CONV_VARIANTS_ALL(X) CTTA_CONV_VARIANTS_1(X) CTTA_CONV_VARIANTS_2(X) CTTA_CONV_VARIANTS_3(X) CTTA_CONV_VARIANTS_4(X) CTTA_CONV_VARIANTS_5(X) CTTA_CONV_VARIANTS_6(X) CTTA_CONV_VARIANTS_7(X)
 #define CTTA_CONV_INSTANTIATE(BM, BN, BK, WM, WN, G, S)                                      \
   template void launch_variant<BM, BN, BK, WM, WN, G, S>(const ConvParams&, dim3, hipStream_t); \
   template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S>();

@@ -370,7 +370,7 @@ class _UNetBase(_ParamTree):
                 N.check(N.lib().ctta_unet_reuse_text(self._h_unet, 1))
             N.check(fn(self._h_unet, N.ptr(x), N.ptr(t), N.ptr(g), N.ptr(enc), N.ptr(m), B, L, N.ptr(out),
                        N.stream_ptr()))
-        self._text_key = self._text_key_pending
+        self._text_key = getattr(self, "_text_key_pending", None)
         return out
 
     # ---- distillation step: the reference differentiates `forward` with torch autograd

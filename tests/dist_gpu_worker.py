@@ -106,7 +106,8 @@ def main():
     if mode == "wav":     # clip-sharded generation with the opt-in batch-global centring (hifigan/utilities.py:85)
         v = tiny_vocoder(dev)
         mel = wav_batch()[rank * 2:(rank + 1) * 2].to(dev)
-        res = {"world": v.decode_to_waveform(mel, world_extrema=True), "local": v.decode_to_waveform(mel)}
+        res = {"world": torch.from_numpy(v.decode_to_waveform(mel, world_extrema=True)),
+               "local": torch.from_numpy(v.decode_to_waveform(mel))}
         torch.save(res, os.path.join(out, "rank%d.pt" % rank))
         du.finish()
         return

@@ -526,6 +526,57 @@ def test_gradient_accumulation_matches_one_big_step(golden):
     assert rel < 5e-2        # AdamW's first step is lr*sign-like: tiny gradient differences flip a few near-zero elements
 
 
+def test_fused_accumulation_one_big_micro_batch_equals_the_accumulated_micro_steps(golden):
+    """Round 4 (bench.py `grad_accum_5_fused`): train.sh accumulates 5 micro-batches of 9 per optimizer step because the
+    reference's GPUs cannot hold more; with 288 GB the same 45 samples run as ONE micro-batch.  Same samples, same
+    per-sample draws: the loss is the mean of the micro-losses and the gradient AdamW consumes is the accumulated one up
+    to fp32 / bf16 summation order (a sample's forward does not depend on its batch mates; the loss is a batch mean)."""
+    gen = torch.Generator().manual_seed(31)
+    cfg = cases.TINY_UNET
+    n_micro, b = 3, 2
+    Pbig = {k: v.to(DEV) for k, v in cases.prompt_states(cfg, n_micro * b, 6, "fusedacc").items()}
+    zbig = (torch.randn(n_micro * b, 8, 32, 8, generator=gen) * 0.9).to(DEV)
+    draws = dict(time_inds=torch.randint(0, 17, (n_micro * b,), generator=gen) * 2,
+                 gaussian_noise=torch.randn(n_micro * b, 8, 32, 8, generator=gen).to(DEV),
+                 guidance_scale=torch.rand(n_micro * b, generator=gen) * 6)
+
+    def shard(i):
+        lo, hi = i * b, (i + 1) * b
+        n = n_micro * b
+        P = {"embeds_cf": torch.cat([Pbig["embeds_cf"][:n][lo:hi], Pbig["embeds_cf"][n:][lo:hi]]),
+             "mask_cf": torch.cat([Pbig["mask_cf"][:n][lo:hi], Pbig["mask_cf"][n:][lo:hi]]),
+             "embeds": Pbig["embeds"][lo:hi], "mask": Pbig["mask"][lo:hi]}
+        return P, zbig[lo:hi], {k: v[lo:hi] for k, v in draws.items()}
+
+    seen = {}
+
+    def run(fused):
+        m, _, _ = _lcm()
+        m.train()
+        opt = m.prepare_training(lr=1e-4, weight_decay=0.0, broadcast=False)
+        orig = opt.step
+
+        def step(grad_scale=1.0):
+            seen[fused] = opt.grad.detach().clone()
+            return orig(grad_scale=grad_scale)
+        opt.step = step
+        if fused:
+            losses = [m.train_step(zbig, Pbig, opt, None, **draws)]
+        else:
+            losses = []
+            for i in range(n_micro):
+                P, z, kw = shard(i)
+                losses.append(m.train_step(z, P, opt, None, accumulation_steps=n_micro, **kw))
+        torch.cuda.synchronize()
+        return float(np.mean(losses))
+
+    l_acc, l_fused = run(False), run(True)
+    rel = float((seen[True] - seen[False]).norm() / seen[False].norm())
+    print("accumulated %d x %d vs one batch of %d: loss %.7f vs %.7f, gradient rel diff %.3e" % (n_micro, b, n_micro * b, l_acc, l_fused, rel))
+    assert abs(l_acc - l_fused) <= 1e-5 * abs(l_acc)
+    assert rel <= 1e-2        # the micro-steps round (1/n) * dL/dpred to bf16 per micro-batch, the fused step rounds dL/dpred of the batch mean
+
+
 def test_real_training_step_from_waveforms(golden):
     """The reference's inner loop end to end (tools/train_utils.py:150-183): waveforms -> wav_to_fbank -> VAE
     encode_first_stage -> get_first_stage_encoding -> distillation step, all on the HIP path."""
