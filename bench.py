@@ -178,8 +178,28 @@ def main():
         du.barrier(dev)
         return du.max_over_ranks(time.perf_counter() - t0_, dev)
 
-    dt = time_loop(timed)
+    dt = dt_graph1 = time_loop(timed)
     dt_eager = time_loop(step)      # always, on every rank: the collective sequence must not depend on a rank's capture
+    # The throughput form of the same step: a 3-deep software pipeline over batches (U-Net of batch i, VAE decoder of batch
+    # i - 1, HiFi-GAN of batch i - 2 as three hipGraphs on three streams per step; ConsistencyTTA.capture_pipeline).  Every
+    # timed step runs every stage once on a full batch; a batch's waveforms leave two steps after its text states entered.
+    placement_gen = None
+    if genB is not None and os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0":
+        try:
+            genP = pipe.capture_pipeline(B, L, cfg_scale_input=4.0)
+            for _ in range(3):
+                pp = genP(enc, mask, noise)
+            torch.cuda.synchronize()
+            assert torch.equal(pp, step()[3]), "the pipelined replay differs from the eager step"
+            dt_pipe = time_loop(lambda: genP(enc, mask, noise))
+            placement_gen = genP.placement_ms
+            if dt_pipe < dt:
+                dt = dt_pipe
+                launch_mode = ("three hipGraph replays per step on three streams: U-Net(batch i) | VAE decoder(batch i-1) | "
+                               "HiFi-GAN + int16(batch i-2), handed over by device copies at the step boundary")
+            del genP
+        except Exception as exc:
+            launch_mode += " (pipelined capture failed: %s)" % str(exc)[:100]
     del timed, genB
     out = step()
     lat, mel, wav, pcm = out
@@ -198,6 +218,8 @@ def main():
                    "parallelism": "replicas x%d (clips sharded, no data-path collective)" % world,
                    "launch": launch_mode},
         "eager_clips_per_s": round(world * B * args.steps / dt_eager, 3),
+        "single_graph_clips_per_s": round(world * B * args.steps / dt_graph1, 3),
+        "stage_stream_placement_ms": placement_gen,
     }
 
     if rank == 0:

@@ -145,13 +145,18 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
   desc_init(&d);
   d.x0 = pt; d.c0 = seg; d.x_stride = mp;
   d.batch = 1; d.hi = N; d.wi = 1; d.ho = N; d.wo = 1;
-  d.w = q; d.k_pad = mp; d.n = R;
+  // the GEMM produces the K weight columns only; the bias column K (and the nb per-sample columns behind it) are row sums
+  // of dY^T (ctta_wgrad_rowsum) -- as GEMM rows (the all-ones / indicator rows im2col_t still writes) they cost a whole
+  // extra tile column: N = 257 ran 3 column tiles of 128 for 2 tiles of work
+  const bool sums_apart = (nb == 0 || (ho * wo) % 8 == 0) && mp % (8 * S) == 0;
+  d.w = q; d.k_pad = mp; d.n = sums_apart ? K : R;
   d.out = slabs; d.ldc = ld; d.out_f32 = 1;
   d.groups = S; d.x_group_stride = seg; d.w_group_stride = seg; d.out_group_stride = (int64_t)N * ld;
   if (job.async) ctta_conv_suppress_splitk(1);   // the handle's split-K slabs belong to the main stream's launches
   const ctta_status gst = c.dry ? CTTA_OK : ctta_conv_gemm(&d, c.stream);
   if (job.async) ctta_conv_suppress_splitk(0);
   CTTA_TRY(gst);
+  if (sums_apart) RUN(c, ctta_wgrad_rowsum(pt, N, mp, (int)M, S, ho * wo, nb, slabs, (int64_t)N * ld, ld, K, c.stream));
   out->p = slabs; out->S = S; out->R = R; out->ld = ld; out->N = N;
   return CTTA_OK;
 }

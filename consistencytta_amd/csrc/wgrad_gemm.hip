@@ -266,3 +266,17 @@ extern "C" ctta_status ctta_wgrad_implicit(const void* dyt, int n, int mp, const
   }
   return CTTA_OK;
 }
+
+// The row sums alone (bias gradient, per-sample d temb columns), for the layers whose product runs on conv_gemm (linears,
+// stride-2 / upsampling samplers, conv_in): the all-ones / indicator ROWS that carried them through the GEMM cost a whole
+// extra tile column (N = K + 1: 257 -> 3 tiles of 128 instead of 2) for one useful row.
+extern "C" ctta_status ctta_wgrad_rowsum(const void* dyt, int n, int mp, int m_valid, int splits, int hw, int sample_cols,
+                                         float* slabs, int64_t slab_stride, int ld, int bias_col, void* stream) {
+  CTTA_REQUIRE(dyt && slabs && n >= 1 && splits >= 1 && mp % (8 * splits) == 0 && m_valid >= 1 && m_valid <= mp && bias_col >= 0 &&
+                   bias_col + 1 + sample_cols <= ld, "wgrad_rowsum: bad arguments");
+  CTTA_REQUIRE(sample_cols == 0 || hw % 8 == 0, "wgrad_rowsum: per-sample columns need hw %% 8 == 0");
+  hipLaunchKernelGGL(wgrad_rowsum_kernel, dim3((unsigned)n, (unsigned)splits), dim3(64), 0, (hipStream_t)stream, (const bf16_t*)dyt,
+                     mp, m_valid, mp / splits, hw, sample_cols, slabs, (long long)slab_stride, ld, bias_col);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}

@@ -632,6 +632,10 @@ ctta_status ctta_wgrad_scatter(const float* slabs, int n_slabs, int64_t slab_str
  * sample_cols > 0, per-sample sums into the columns behind it (d temb).  mp % (64 * splits) == 0.
  * ctta_wgrad_implicit_supported: whether a geometry is inside the kernel's range (CTTA_WGRAD_IMPLICIT=0 turns it off). */
 int ctta_wgrad_implicit_supported(int taps, int c, int h, int w, int x_ld, int n);
+/* the row sums alone: slabs[s][r][bias_col] = sum over split s of dY^T[r][m] (+ per-sample sums in the sample_cols columns
+ * behind it): bias gradient / d temb of the layers whose weight-gradient product runs on ctta_conv_gemm */
+ctta_status ctta_wgrad_rowsum(const void* dyt, int n, int mp, int m_valid, int splits, int hw, int sample_cols, float* slabs,
+                              int64_t slab_stride, int ld, int bias_col, void* stream);
 ctta_status ctta_wgrad_implicit(const void* dyt, int n, int mp, const void* x, int x_ld, int c, int batch, int h, int w,
                                 int taps, int m_valid, int splits, int bias_col, int sample_cols, float* slabs,
                                 int64_t slab_stride, int ld, void* stream);

@@ -294,6 +294,38 @@ def test_whole_pipeline_hipgraph_matches_eager():
         assert np.array_equal(pcm.cpu().numpy(), ref)
 
 
+def test_three_stage_batch_pipeline_equals_the_eager_pipeline_two_calls_later():
+    """Round 4 -- ConsistencyTTA.capture_pipeline: U-Net(batch i), VAE decoder(batch i-1) and HiFi-GAN(batch i-2) as three
+    hipGraphs on three streams per call.  Five different batches fed in a row: call j returns the int16 waveforms of
+    batch j-2, bit-identical to the eager pipeline on that batch (the hand-over copies at the call boundary carry the
+    right batch to the right stage)."""
+    from consistencytta_amd import modules
+    from consistencytta_amd.models import ConsistencyTTA
+    cfg = cases.TINY_UNET
+    vae = modules.AutoencoderKL(ddconfig=cases.TINY_VAE_DD, embed_dim=8, scale_factor=0.9, hifigan_config=cases.TINY_HIFIGAN)
+    pipe = ConsistencyTTA(unet_config=cfg, vae=vae)
+    pipe.to(DEV)
+    pipe.unet.init_deterministic(1)
+    vae.init_deterministic(2)
+    pipe.eval().requires_grad_(False)
+    B, L = 2, 7
+    gen = pipe.capture_pipeline(B, L, cfg_scale_input=4.0, cross_attention_dim=cfg["cross_attention_dim"], latent=(8, 32, 16),
+                                candidates=3)
+    assert gen.depth == 2 and set(gen.placement_ms) == {"u", "v"}
+    batches, refs = [], []
+    for seed in range(5):
+        x, _, _, enc, mask = cases.unet_inputs(cfg, B, 32, 16, L, "pipe%d" % seed)
+        batches.append((enc.to(DEV), mask.to(DEV), x.to(DEV)))
+        lat = pipe.generate_latent(*batches[-1], 4.0, 1.0, 1)
+        refs.append(vae.decode_to_waveform(vae.decode_first_stage(lat)))
+    assert not np.array_equal(refs[0], refs[1])
+    outs = []
+    for b in batches + batches[-1:] * 2:                  # two extra calls drain the pipeline
+        outs.append(gen(*b).cpu().numpy().copy())
+    for j, ref in enumerate(refs):
+        assert np.array_equal(outs[j + 2], ref), j
+
+
 class _FakeTokenizer:
     """Whitespace tokenizer with T5's calling convention (the sentencepiece model is not available offline)."""
     model_max_length = 512
