@@ -21,7 +21,7 @@ def main():
     t_beg = t_end - int(win * 1e6)
     if isinstance(win_spec, str) and win_spec.startswith("adamw:"):
         _, i, j = win_spec.split(":")
-        marks = [r[1] for r in rows if r[0].startswith("adamw_kernel")]
+        marks = [r[1] for r in rows if r[0].startswith("adamw4_kernel") or r[0].startswith("adamw_kernel")]
         print("adamw launches:", len(marks))
         t_beg, t_end = marks[int(i)], marks[int(j)]
         rows = [r for r in rows if r[1] < t_end]
@@ -34,6 +34,8 @@ def main():
     active = set()
     conc = {}
     alone = {}
+    idle = {}          # (kernel that ended, kernel that started) -> [count, total idle ns]
+    last_ended = None
     prev = t_beg
     for t, d, i in ev:
         dt = t - prev
@@ -43,11 +45,17 @@ def main():
                 k = rows[next(iter(active))][0].split("(")[0][-60:]
                 a = alone.setdefault(k, [0, 0])
                 a[0] += dt
+            if not active and d > 0 and last_ended is not None:
+                key = (rows[last_ended][0].split("(")[0][-44:], rows[i][0].split("(")[0][-44:])
+                g_ = idle.setdefault(key, [0, 0])
+                g_[0] += 1
+                g_[1] += dt
         prev = t
         if d > 0:
             active.add(i)
         else:
             active.discard(i)
+            last_ended = i
     span = t_end - t_beg
     out = ["window %.1f ms, %d dispatches, columns of `kernels`: %s" % (span / 1e6, len(rows), ",".join(cols)), ""]
     for c in sorted(conc):
@@ -62,6 +70,14 @@ def main():
     out.append("kernels running ALONE (no other kernel on the device), by total time:")
     for k, (t, _) in sorted(alone.items(), key=lambda kv: -kv[1][0])[:40]:
         out.append("%8.3f ms  %s" % (t / 1e6, k))
+    out.append("")
+    out.append("idle gaps (no kernel on the device) by (kernel that ended -> kernel that started): count, total ms, avg us")
+    hist = {}
+    for (a_, b_), (n_, t_) in idle.items():
+        pass
+    for (a_, b_), (n_, t_) in sorted(idle.items(), key=lambda kv: -kv[1][1])[:40]:
+        out.append("%6d x %8.3f ms %6.1f us  %s -> %s" % (n_, t_ / 1e6, t_ / n_ / 1e3, a_, b_))
+    out.append("idle gaps in total: %d, %.3f ms" % (sum(v[0] for v in idle.values()), sum(v[1] for v in idle.values()) / 1e6))
     out.append("")
     out.append("dispatches in the window by kernel (count, total ms, avg us, median gap to the previous dispatch END on the same queue):")
     agg = {}
