@@ -633,8 +633,8 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                     "one target forward, one student forward + backward, AdamW, EMA)")
         try:
             dt_seg = timed_graph(True)
-            launch_seg = ("%d hipGraph replays per micro-step (forward + loss + out head | one graph per backward block, bucket "
-                          "all-reduce issued between replays) + eager AdamW / zero_grad / EMA" % 12)
+            launch_seg = ("8 hipGraph replays per micro-step (forward + loss + the first bucket's blocks | one graph per further "
+                          "bucket of the gradient all-reduce, which is issued between replays) + eager AdamW / zero_grad / EMA")
             if pipe_on:      # what the data-parallel step runs: segmented (bucket all-reduce between replays) AND pipelined
                 dt_seg_pipe = timed_graph(True, True)
             if world > 1:

@@ -917,14 +917,16 @@ class _DistillStepGraph:
     its own stream) overlaps the blocks still to come exactly as in the eager `train_step`; the graphs share one memory
     pool and the engine's arena, so the kernels and their arguments are those of the monolithic capture."""
 
-    def __init__(self, model, optimizer, z_shape, P, segmented=False, accumulation_steps=1, pipeline_teacher=False):
+    def __init__(self, model, optimizer, z_shape, P, segmented=False, accumulation_steps=1, pipeline_teacher=False,
+                 bucket_min_elems=16 << 20):
         assert model.loss is None, "the captured step covers the latent-space loss (loss_type='mse')"
         assert model.training and model.use_teacher_cf_guidance
         self.m, self.opt = model, optimizer
         self.segmented = bool(segmented)
         self.pipelined = bool(pipeline_teacher)
         self.accum = max(1, int(accumulation_steps))
-        self.segments = []       # [(graph, block id it completes)]
+        self.bucket_min_elems = int(bucket_min_elems)     # = GradientBuckets' merge rule (dist_util)
+        self.segments = []       # [(graph, (block ids it completes, ...))]
         self._micro = 0
         dev = model.device
         B = z_shape[0]
@@ -1110,11 +1112,23 @@ class _DistillStepGraph:
         return self._main_part(self.cur, teacher_first=not self.pipelined)
 
     def _capture_segments(self, warm):
-        """forward + loss + out head | one graph per backward block, all in one memory pool."""
+        """forward + loss + the first bucket's blocks | one graph per further BUCKET of the gradient all-reduce, all in one
+        memory pool.  Blocks are merged until they hold `bucket_min_elems` gradient elements -- GradientBuckets' own rule, so
+        every replay ends exactly where a collective can start: 8 graphs instead of 12 for the light U-Net (each graph
+        launch, and each graph's own branch streams, take hardware-queue slots the pipelined teacher graph competes for)."""
         m = self.m
         unet = m.student_unet
         pool = torch.cuda.graph_pool_handle()
         kw = dict(pool=pool, stream=warm, capture_error_mode="thread_local")
+        ranges = unet.block_ranges()
+        min_e = self.bucket_min_elems
+        state = {"fin": False}
+
+        def more_blocks(blocks, pending):
+            while not state["fin"] and pending < min_e:
+                blk, state["fin"] = unet.backward_next()
+                blocks.append(blk)
+                pending += (ranges[blk][1] - ranges[blk][0]) if blk in ranges else 0
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, **kw):
             out, pred, target, s_loss, gamma = self._forward_part()
@@ -1123,14 +1137,15 @@ class _DistillStepGraph:
             N.check(N.lib().ctta_snr_mse_grad(N.ptr(pred), N.ptr(target), N.ptr(s_loss), float(gamma), 1.0 / self.accum,
                                               Bn, C, H * W, 8, N.ptr(d), N.stream_ptr()))
             first = unet.backward_begin(d)
+            blocks = [first]
+            more_blocks(blocks, (ranges[first][1] - ranges[first][0]) if first in ranges else 0)
         self._keep = (pred, target, d)        # read by the later graphs: their pool blocks must stay allocated
-        self.segments = [(self.graph, first)]
-        fin = False
-        while not fin:
-            g = torch.cuda.CUDAGraph()
+        self.segments = [(self.graph, tuple(blocks))]
+        while not state["fin"]:
+            g, blocks = torch.cuda.CUDAGraph(), []
             with torch.cuda.graph(g, **kw):
-                blk, fin = unet.backward_next()
-            self.segments.append((g, blk))
+                more_blocks(blocks, 0)
+            self.segments.append((g, tuple(blocks)))
         return out
 
     def capture(self, z_0, time_inds=None, gaussian_noise=None, guidance_scale=None):
@@ -1206,10 +1221,11 @@ class _DistillStepGraph:
         if not self.segmented:
             self.graph.replay()
             return
-        for g, blk in self.segments:
+        for g, blks in self.segments:
             g.replay()
             if on_block_done is not None:
-                on_block_done(blk)
+                for blk in blks:
+                    on_block_done(blk)
 
     def feed(self, z_0, time_inds=None, gaussian_noise=None, guidance_scale=None):
         """Pipelined captures: hands the NEXT batch (latents + draws) to the teacher stream -- inputs refreshed and the
@@ -1247,7 +1263,7 @@ class _DistillStepGraph:
         if self._micro % self.accum != 0:      # DDP's no_sync: gradients only accumulate locally
             self.replay()
             return float(self.loss.item())
-        buckets = dist_util.GradientBuckets(self.opt.grad, m.student_unet.block_ranges(),
+        buckets = dist_util.GradientBuckets(self.opt.grad, m.student_unet.block_ranges(), min_elems=self.bucket_min_elems,
                                             compress=getattr(m, "allreduce_dtype", None))
         if buckets.enabled and not self.segmented:
             raise N.CttaError("a monolithic step graph cannot interleave the gradient all-reduce with the backward pass: "
@@ -1259,10 +1275,12 @@ class _DistillStepGraph:
             g0, first = self.segments[0]
             g0.replay()
             nan_any = dist_util.AnyRankFlag(torch.isnan(self.loss))     # all ranks skip together (or none)
-            buckets.ready(first)
-            for g, blk in self.segments[1:]:
-                g.replay()
+            for blk in first:
                 buckets.ready(blk)
+            for g, blks in self.segments[1:]:
+                g.replay()
+                for blk in blks:
+                    buckets.ready(blk)
         world = buckets.wait()
         value = float(self.loss.item())
         if not (skip_nan and nan_any.result()):
@@ -1274,7 +1292,8 @@ class _DistillStepGraph:
         return value
 
 
-def _capture_train_graph(self, optimizer, z_0, prompt, segmented=None, accumulation_steps=1, pipeline_teacher=False, **draws):
+def _capture_train_graph(self, optimizer, z_0, prompt, segmented=None, accumulation_steps=1, pipeline_teacher=False,
+                         bucket_min_elems=16 << 20, **draws):
     """hipGraph-captured distillation step (loss_type='mse'): returns a `_DistillStepGraph` whose
     `.step(z_0, lr_scheduler, ...)` replaces `train_step(z_0, prompt, optimizer, lr_scheduler, ...)` for fixed shapes and a
     fixed prompt batch (`prompt` must be the dict of pre-computed text states; refresh `graph.P[...]` in place to change them).
@@ -1290,7 +1309,8 @@ def _capture_train_graph(self, optimizer, z_0, prompt, segmented=None, accumulat
     if not isinstance(prompt, dict):
         raise N.CttaError("capture_train_graph needs the pre-computed text states (dict), not prompt strings")
     return _DistillStepGraph(self, optimizer, tuple(z_0.shape), prompt, segmented=segmented,
-                             accumulation_steps=accumulation_steps, pipeline_teacher=pipeline_teacher).capture(z_0, **draws)
+                             accumulation_steps=accumulation_steps, pipeline_teacher=pipeline_teacher,
+                             bucket_min_elems=bucket_min_elems).capture(z_0, **draws)
 
 
 AudioLCM.capture_train_graph = _capture_train_graph

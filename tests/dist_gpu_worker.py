@@ -67,7 +67,7 @@ def run_step(m, Ps, z, kw, lr=1e-4, compress=None, graph=False):
         g = torch.Generator().manual_seed(5)
         gs = m.capture_train_graph(opt, z, Ps, time_inds=torch.randint(0, 17, (z.shape[0],), generator=g) * 2,
                                    gaussian_noise=torch.randn(z.shape, generator=g).to(z.device),
-                                   guidance_scale=torch.rand(z.shape[0], generator=g) * 6)
+                                   guidance_scale=torch.rand(z.shape[0], generator=g) * 6, bucket_min_elems=1)
         assert gs.segmented and len(gs.segments) == 2 * len(cases.TINY_UNET["block_out_channels"]) + 3
     seen = {}
     orig = opt.step

@@ -362,10 +362,13 @@ def test_segmented_step_graph_with_rccl_buckets_equals_monolithic_graph_and_eage
     os.environ["CTTA_FORCE_COLLECTIVES"] = "1"
     try:
         mono = m_g.capture_train_graph(o_g, z0, P, segmented=False, **draws[0])
-        seg = m_s.capture_train_graph(o_s, z0, P, **draws[0])          # default: segmented under (forced) collectives
+        # default: segmented under (forced) collectives; bucket_min_elems=1: one graph per block (the tiny model's blocks
+        # are far below the 16 M-element merge rule, which is exercised at real size in the B = 9 test below)
+        seg = m_s.capture_train_graph(o_s, z0, P, bucket_min_elems=1, **draws[0])
         assert seg.segmented and not mono.segmented
         n_levels = len(cases.TINY_UNET["block_out_channels"])
-        blocks = [b for _, b in seg.segments]
+        blocks = [b for _, bs in seg.segments for b in bs]
+        assert all(len(bs) == 1 for _, bs in seg.segments)
         assert blocks == [2 * n_levels + 2] + list(range(2 * n_levels + 1, -1, -1)), blocks
         assert float(o_s.grad.abs().max()) == 0.0 and o_s.step_count == 0
         from consistencytta_amd import dist_util as du
@@ -436,7 +439,8 @@ def test_pipelined_teacher_step_graph_equals_eager_on_a_sequence_of_batches(gold
         m2, _, _ = _lcm()
         m2.train()
         o2 = m2.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)
-        gs = m2.capture_train_graph(o2, batches[3]["z"], P, segmented=segmented, pipeline_teacher=True, **batches[3]["kw"])
+        gs = m2.capture_train_graph(o2, batches[3]["z"], P, segmented=segmented, pipeline_teacher=True, bucket_min_elems=1,
+                                    **batches[3]["kw"])
         assert gs.pipelined and gs.teacher_graph is not None and float(o2.grad.abs().max()) == 0.0
         assert gs.feed(batches[0]["z"], **batches[0]["kw"]) is False            # primes the pipeline
         for i in range(3):
@@ -857,5 +861,7 @@ def test_distillation_step_full_batch_is_deterministic_and_blockwise_exact():
                   % ("segmented" if segmented else "monolithic", float(gs.loss.item()), l_e, d))
             assert float(gs.loss.item()) == l_e and d <= 1e-7
             assert not segmented or (seen[0] == 10 and sorted(seen) == list(range(11)))
+            # at this size the merge rule applies: out head + up3 + up2 share the first graph, then one graph per bucket
+            assert not segmented or [bs for _, bs in gs.segments] == [(10, 9, 8), (7,), (6,), (5,), (4,), (3,), (2,), (1, 0)]
         opt.zero_grad()
         del gs
