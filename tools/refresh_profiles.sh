@@ -29,7 +29,12 @@ timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch_d $O/pmc_write_d distill 18 > $O/pmc_traffic_distill.json 2> $O/pmc_traffic_distill.err
 timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_mfma.log 2>&1
 python3 $R/tools/pmc_mfma_util.py $O/pmc_mfma > $O/pmc_mfma_util.json 2> $O/pmc_mfma_util.err
-rm -rf $O/prof_gen $O/prof_distill $O/launch_gen.csv $O/launch_distill.csv $O/launch_distill.csv.distill
+# where a hipGraph-replayed distillation step spends its time: idle / one kernel / two kernels, dispatch counts, idle gaps by kernel
+# pair (three monolithic-graph steps between AdamW launches: eager 1+3, segmented 1+3, monolithic 1+3 -> AdamW launches 8..11)
+CTTA_BENCH_PIPELINE=0 CTTA_BENCH_FUSED_ACCUM=0 rocprofv3 --kernel-trace -d $O/prof_gaps -o p -- python3 $R/bench.py --mode distill --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_gaps.log 2>&1
+db=$(find $O/prof_gaps -name '*.db' | head -1)
+[ -n "$db" ] && python3 $R/tools/rocpd_gaps.py $db $O/gaps_distill.txt adamw:8:11 > /dev/null 2> $O/gaps_distill.err
+rm -rf $O/prof_gen $O/prof_distill $O/prof_gaps $O/launch_gen.csv $O/launch_distill.csv $O/launch_distill.csv.distill
 # the raw counter CSVs are ~85 MB together and gpurun copies back at most 64 MiB: only the summaries travel
 rm -rf $O/pmc_fetch $O/pmc_write $O/pmc_fetch_d $O/pmc_write_d $O/pmc_mfma
 du -sh $O
