@@ -659,6 +659,34 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             except Exception as exc:   # a failed capture must not cost the line
                 launch_mode = "eager launches (graph capture failed: %s)" % str(exc)[:160]
                 dt = dt_eager
+    if perceptual and os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0" and not args.no_latency:
+        # configs[4] cannot be captured whole (torch autograd differentiates the CLAP loss down to the latent), but its teacher
+        # phase can: one hipGraph on its own stream for batch i + 1 beside the eager rest of batch i -- ~1 100 of the step's
+        # launches leave the host's queue as well (`main_eager`; same arithmetic, tests/test_train_gpu.py)
+        try:
+            gdr = torch.Generator().manual_seed(78 + rank)
+            kw = dict(time_inds=torch.randint(0, 17, (B,), generator=gdr) * 2,
+                      gaussian_noise=torch.randn(B, 8, 256, 16, generator=gdr).to(dev), guidance_scale=torch.rand(B, generator=gdr) * 6)
+            gs = m.capture_train_graph(opt, z0, P, pipeline_teacher=True, gt_wav=step_kw["gt_wav"], **kw)
+            placements.append(getattr(gs, "placement_ms", None))
+            for _ in range(n_warm):
+                losses.append(gs.step(z0, sched, gt_wav=step_kw["gt_wav"]))
+            du.barrier(dev)
+            t0 = time.perf_counter()
+            for _ in range(n_steps):
+                losses.append(gs.step(z0, sched, gt_wav=step_kw["gt_wav"]))
+            du.barrier(dev)
+            dt_pipe = du.max_over_ranks(time.perf_counter() - t0, dev)
+            if dt_pipe < dt:
+                dt = dt_pipe
+                launch_mode = ("eager launches (two streams + weight-gradient side stream) for target network, student forward, decode, "
+                               "CLAP loss and backward; the frozen teacher's two CFG queries + Heun step as one hipGraph on a second "
+                               "stream for batch i + 1")
+            del gs
+        except Exception as exc:
+            if world > 1:
+                raise
+            launch_mode += " (pipelined teacher failed: %s)" % str(exc)[:120]
     assert all(v == v for v in losses), "NaN distillation loss"
     out = {
         "metric": "distillation_steps_per_sec", "value": round(n_steps / dt, 4), "unit": "optimizer steps/s",

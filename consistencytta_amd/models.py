@@ -918,12 +918,17 @@ class _DistillStepGraph:
     pool and the engine's arena, so the kernels and their arguments are those of the monolithic capture."""
 
     def __init__(self, model, optimizer, z_shape, P, segmented=False, accumulation_steps=1, pipeline_teacher=False,
-                 bucket_min_elems=16 << 20):
-        assert model.loss is None, "the captured step covers the latent-space loss (loss_type='mse')"
+                 bucket_min_elems=16 << 20, main_eager=None):
         assert model.training and model.use_teacher_cf_guidance
         self.m, self.opt = model, optimizer
         self.segmented = bool(segmented)
         self.pipelined = bool(pipeline_teacher)
+        # main_eager: only the teacher phase is a hipGraph (on its own stream); target network, student forward, loss and
+        # backward run as eager launches -- the form the waveform-domain losses take (loss_type 'mel' / 'stft' / 'clap': torch
+        # autograd differentiates the loss down to the latent, which a capture cannot hold)
+        self.main_eager = bool(model.loss is not None) if main_eager is None else bool(main_eager)
+        assert model.loss is None or self.main_eager, "a captured main graph covers the latent-space loss (loss_type='mse') only"
+        assert not self.main_eager or self.pipelined, "main_eager without a pipelined teacher is the plain train_step"
         self.accum = max(1, int(accumulation_steps))
         self.bucket_min_elems = int(bucket_min_elems)     # = GradientBuckets' merge rule (dist_util)
         self.segments = []       # [(graph, (block ids it completes, ...))]
@@ -934,9 +939,8 @@ class _DistillStepGraph:
         # Static inputs of one batch, carved out of ONE flat buffer (so that the pipelined step rotates a whole set with a
         # single device copy): the latents, the noise, guidance, the two timestep vectors, the eight sigma vectors, and the
         # two tensors the teacher phase hands to the rest of the step (student input, target-network input).
-        self.cur = self._input_set(z_shape)
-        self.nxt = self._input_set(z_shape) if self.pipelined else self.cur      # what the teacher graph reads / writes
-        self.P = {k: v.detach().clone() for k, v in P.items()}
+        self.cur = self._input_set(z_shape, P)
+        self.nxt = self._input_set(z_shape, P) if self.pipelined else self.cur      # what the teacher graph reads / writes
         self.loss = None
         self.graph = None
         self.teacher_graph = None
@@ -947,11 +951,17 @@ class _DistillStepGraph:
             self._ev_teacher = torch.cuda.Event()
             self._ev_h2d = torch.cuda.Event()
 
-    def _input_set(self, z_shape):
+    _P_KEYS = ("embeds_cf", "mask_cf", "embeds", "mask")
+
+    def _input_set(self, z_shape, P):
         B = z_shape[0]
         nz = int(np.prod(z_shape))
         flat = torch.zeros(4 * nz + 11 * B, dtype=torch.float32, device=self.dev)
-        S = {"flat": flat}
+        # the batch's text states ride with it (the teacher graph reads the CFG pair of the NEXT batch while the main
+        # part still reads the current batch's): static copies per set; anything else in the prompt dict (CLAP caption
+        # features) and the ground-truth waveforms of a waveform-domain loss are carried by reference
+        S = {"flat": flat, "P": {k: P[k].detach().clone() for k in self._P_KEYS},
+             "extra": {k: v for k, v in P.items() if k not in self._P_KEYS}, "gt_wav": None}
         for i, k in enumerate(("z0", "noise", "z_in", "tgt_in")):
             S[k] = flat[i * nz:(i + 1) * nz].view(z_shape)
         small = flat[4 * nz:].view(11, B)
@@ -966,6 +976,14 @@ class _DistillStepGraph:
     t_np1 = property(lambda self: self.cur["t_np1"])
     t_n = property(lambda self: self.cur["t_n"])
     sig = property(lambda self: self.cur["sig"])
+    P = property(lambda self: self.cur["P"])
+
+    def _rotate(self):
+        """next -> current: one device copy for the numeric inputs, four for the text states, references for the rest."""
+        self.cur["flat"].copy_(self.nxt["flat"])
+        for k in self._P_KEYS:
+            self.cur["P"][k].copy_(self.nxt["P"][k])
+        self.cur["extra"], self.cur["gt_wav"] = self.nxt["extra"], self.nxt["gt_wav"]
 
     # -- host side: what the Heun scheduler would look up for this draw, in `_forward_impl`'s call order
     def _sigma_plan(self, inds):
@@ -986,10 +1004,16 @@ class _DistillStepGraph:
         plan = [sig[i1], sig[i1 + 1], sig[i2], sig[i2 - 1], sig[i2], sig[i3], sig[inds]]
         return t_np1, t_n, plan
 
-    def _refresh(self, z_0, time_inds, gaussian_noise, guidance_scale, S=None):
-        """Fills an input set (default: the one the teacher phase reads) on the CURRENT stream."""
+    def _refresh(self, z_0, time_inds, gaussian_noise, guidance_scale, S=None, prompt=None, gt_wav=None):
+        """Fills an input set (default: the one the teacher phase reads) on the CURRENT stream.  `prompt`: the batch's
+        pre-computed text states (dict); None keeps the set's (a fixed prompt batch)."""
         m, B = self.m, self.B
         S = self.nxt if S is None else S
+        if prompt is not None:
+            for k in self._P_KEYS:
+                S["P"][k].copy_(prompt[k])
+            S["extra"] = {k: v for k, v in prompt.items() if k not in self._P_KEYS}
+        S["gt_wav"] = gt_wav
         avail = m.noise_scheduler._timesteps_host
         order = 2
         if time_inds is not None:
@@ -1038,7 +1062,7 @@ class _DistillStepGraph:
         z0, noise = S["z0"], S["noise"]
         n = z0[0].numel()
         s_add, s_next1, s_scale2, s_prev2, s_cur2, s_scale3 = S["sig"][:6]
-        embeds_cf, mask_cf, _, _ = m.get_prompt_embeds(self.P, m.use_teacher_cf_guidance, 1)
+        embeds_cf, mask_cf = S["P"]["embeds_cf"], S["P"]["mask_cf"]
 
         def scale(x, sg, out=None):
             out = torch.empty_like(x) if out is None else out
@@ -1072,7 +1096,7 @@ class _DistillStepGraph:
         m, B, dev = self.m, self.B, self.dev
         L_ = N.lib()
         w = S["w"]
-        _, _, embeds, mask = m.get_prompt_embeds(self.P, m.use_teacher_cf_guidance, 1)
+        embeds, mask = S["P"]["embeds"], S["P"]["mask"]
         two_stream = os.environ.get("CTTA_TWO_STREAM", "1") != "0"
         box = {}
 
@@ -1102,6 +1126,12 @@ class _DistillStepGraph:
             pred = m.student_unet.forward_train(S["z_in"], S["t_np1"], w, embeds, mask)
         gamma = m.snr_gamma or 0.0
         s_loss = S["sig"][6]
+        if m.loss is not None:     # waveform-domain loss (eager only): keep the graph from pred to the loss, as `_forward_impl` does
+            leaf = pred.detach().requires_grad_(True)
+            prompt = dict(S["P"], **S["extra"])
+            with torch.enable_grad():
+                graph = m._perceptual_loss(leaf, target, S["gt_wav"], prompt, s_loss, gamma)
+            return graph.detach().reshape(1), pred, (leaf, graph), s_loss, gamma
         inst = torch.empty(B, dtype=torch.float32, device=dev)
         out = torch.empty(1, dtype=torch.float32, device=dev)
         N.check(L_.ctta_snr_mse_loss(N.ptr(pred.contiguous()), N.ptr(target), N.ptr(s_loss), float(gamma), N.ptr(inst),
@@ -1148,18 +1178,18 @@ class _DistillStepGraph:
             self.segments.append((g, tuple(blocks)))
         return out
 
-    def capture(self, z_0, time_inds=None, gaussian_noise=None, guidance_scale=None):
+    def capture(self, z_0, time_inds=None, gaussian_noise=None, guidance_scale=None, gt_wav=None):
         """One eager pass on a side stream (handles, kernel attributes, allocator pool), then the capture.  Both passes
         ACCUMULATE into the gradient buffer like any backward; the caller zeroes it (train_step does after its update)."""
         m = self.m
-        self._refresh(z_0, time_inds, gaussian_noise, guidance_scale)
+        self._refresh(z_0, time_inds, gaussian_noise, guidance_scale, gt_wav=gt_wav)
         with torch.no_grad():
             warm = torch.cuda.Stream(device=self.dev)
             warm.wait_stream(torch.cuda.current_stream(self.dev))
             with torch.cuda.stream(warm):
                 if self.pipelined:
                     self._teacher_part(self.nxt)
-                    self.cur["flat"].copy_(self.nxt["flat"])
+                    self._rotate()
                 self._body()
             torch.cuda.current_stream(self.dev).wait_stream(warm)
             torch.cuda.synchronize(self.dev)
@@ -1169,7 +1199,9 @@ class _DistillStepGraph:
                 self.teacher_graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.teacher_graph, stream=warm, capture_error_mode="thread_local"):
                     self._teacher_part(self.nxt)
-            if self.segmented:
+            if self.main_eager:
+                pass                                  # the main part stays eager launches (see __init__)
+            elif self.segmented:
                 self.loss = self._capture_segments(warm)
             else:
                 self.graph = torch.cuda.CUDAGraph()
@@ -1218,6 +1250,11 @@ class _DistillStepGraph:
         """The device work of one micro-step on the CURRENT input set.  Segmented: `on_block_done(block id)` runs between
         two replays, when that block's gradients are final on the stream (what `ctta_unet_backward_next` reports to
         `train_step`).  Pipelined captures: the teacher phase of the current set is NOT part of this (see `feed`)."""
+        if self.main_eager:
+            with torch.no_grad():
+                self.loss, pred, target, s_loss, gamma = self._forward_part()
+                self.m._student_backward(pred, target, s_loss, gamma, 1.0 / self.accum, on_block_done)
+            return
         if not self.segmented:
             self.graph.replay()
             return
@@ -1227,7 +1264,7 @@ class _DistillStepGraph:
                 for blk in blks:
                     on_block_done(blk)
 
-    def feed(self, z_0, time_inds=None, gaussian_noise=None, guidance_scale=None):
+    def feed(self, z_0, time_inds=None, gaussian_noise=None, guidance_scale=None, prompt=None, gt_wav=None):
         """Pipelined captures: hands the NEXT batch (latents + draws) to the teacher stream -- inputs refreshed and the
         teacher graph replayed there, beside whatever the main stream does -- after moving the batch fed before into the
         current set.  `step` calls it; a training loop may call it directly to prime the pipeline with its first batch."""
@@ -1235,16 +1272,17 @@ class _DistillStepGraph:
         cur = torch.cuda.current_stream(self.dev)
         if self._primed:
             cur.wait_event(self._ev_teacher)                 # the teacher phase of the batch fed last time is complete
-            self.cur["flat"].copy_(self.nxt["flat"])         # ... and that batch becomes the current one (one device copy)
+            self._rotate()                                   # ... and that batch becomes the current one
         self._tstream.wait_stream(cur)
         with torch.cuda.stream(self._tstream):
-            self._refresh(z_0, time_inds, gaussian_noise, guidance_scale)
+            self._refresh(z_0, time_inds, gaussian_noise, guidance_scale, prompt=prompt, gt_wav=gt_wav)
             self.teacher_graph.replay()
             self._ev_teacher.record(self._tstream)
         was, self._primed = self._primed, True
         return was
 
-    def step(self, z_0, lr_scheduler=None, time_inds=None, gaussian_noise=None, guidance_scale=None, skip_nan=True):
+    def step(self, z_0, lr_scheduler=None, time_inds=None, gaussian_noise=None, guidance_scale=None, skip_nan=True,
+             prompt=None, gt_wav=None):
         """`AudioLCM.train_step`: refresh the static inputs, replay, then -- on every `accumulation_steps`-th call -- the
         eager tail (gradient all-reduce joined, AdamW, LR schedule, zero_grad, EMA).  With a process group the capture
         must be `segmented` so that the all-reduce of a finished block is issued before the next block's replay.
@@ -1254,21 +1292,25 @@ class _DistillStepGraph:
         phase is queued on the teacher stream and overlaps this call's student / target / backward work, which trains on
         the batch fed by the PREVIOUS call (the first call primes the pipeline with its batch and trains on it too)."""
         m = self.m
+        draw = dict(time_inds=time_inds, gaussian_noise=gaussian_noise, guidance_scale=guidance_scale, prompt=prompt, gt_wav=gt_wav)
         if self.pipelined:
-            if not self.feed(z_0, time_inds, gaussian_noise, guidance_scale):
-                self.feed(z_0, time_inds, gaussian_noise, guidance_scale)      # first call: the same batch is also the next one
+            if not self.feed(z_0, **draw):
+                self.feed(z_0, **draw)      # first call: the same batch is also the next one
         else:
-            self._refresh(z_0, time_inds, gaussian_noise, guidance_scale)
+            self._refresh(z_0, time_inds, gaussian_noise, guidance_scale, prompt=prompt, gt_wav=gt_wav)
         self._micro += 1
         if self._micro % self.accum != 0:      # DDP's no_sync: gradients only accumulate locally
             self.replay()
             return float(self.loss.item())
         buckets = dist_util.GradientBuckets(self.opt.grad, m.student_unet.block_ranges(), min_elems=self.bucket_min_elems,
                                             compress=getattr(m, "allreduce_dtype", None))
-        if buckets.enabled and not self.segmented:
+        if buckets.enabled and not self.segmented and not self.main_eager:
             raise N.CttaError("a monolithic step graph cannot interleave the gradient all-reduce with the backward pass: "
                               "capture with segmented=True under a process group")
-        if not buckets.enabled:
+        if self.main_eager:
+            self.replay(buckets.ready if buckets.enabled else None)
+            nan_any = dist_util.AnyRankFlag(torch.isnan(self.loss))
+        elif not buckets.enabled:
             self.replay()
             nan_any = dist_util.AnyRankFlag(torch.isnan(self.loss))
         else:
@@ -1293,10 +1335,13 @@ class _DistillStepGraph:
 
 
 def _capture_train_graph(self, optimizer, z_0, prompt, segmented=None, accumulation_steps=1, pipeline_teacher=False,
-                         bucket_min_elems=16 << 20, **draws):
+                         bucket_min_elems=16 << 20, main_eager=None, **draws):
     """hipGraph-captured distillation step (loss_type='mse'): returns a `_DistillStepGraph` whose
     `.step(z_0, lr_scheduler, ...)` replaces `train_step(z_0, prompt, optimizer, lr_scheduler, ...)` for fixed shapes and a
-    fixed prompt batch (`prompt` must be the dict of pre-computed text states; refresh `graph.P[...]` in place to change them).
+    prompt shape (`prompt` must be the dict of pre-computed text states; `step(..., prompt=next_states)` / `feed(..., prompt=)`
+    hands a batch's own text states over with it -- they are double-buffered like the latents).  With a waveform-domain loss
+    (loss_type 'mel' / 'stft' / 'clap') pass pipeline_teacher=True: the teacher phase is a hipGraph on its own stream and the
+    rest of the step stays eager launches (`main_eager`), `step(..., gt_wav=)` carries the ground-truth audio.
     `segmented` (default: whenever a process group with more than one rank exists) captures the backward block by block
     so that the data-parallel gradient all-reduce overlaps it as in the eager `train_step`.
     `pipeline_teacher=True`: the frozen teacher's two CFG queries + Heun step (a third of the step's device time, and
@@ -1310,7 +1355,7 @@ def _capture_train_graph(self, optimizer, z_0, prompt, segmented=None, accumulat
         raise N.CttaError("capture_train_graph needs the pre-computed text states (dict), not prompt strings")
     return _DistillStepGraph(self, optimizer, tuple(z_0.shape), prompt, segmented=segmented,
                              accumulation_steps=accumulation_steps, pipeline_teacher=pipeline_teacher,
-                             bucket_min_elems=bucket_min_elems).capture(z_0, **draws)
+                             bucket_min_elems=bucket_min_elems, main_eager=main_eager).capture(z_0, **draws)
 
 
 AudioLCM.capture_train_graph = _capture_train_graph

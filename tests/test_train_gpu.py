@@ -475,6 +475,56 @@ def test_pipelined_teacher_step_graph_equals_eager_on_a_sequence_of_batches(gold
         del gs
 
 
+def test_pipelined_teacher_with_eager_main_and_changing_prompts(golden):
+    """Round 4: (i) a batch's TEXT STATES travel with it through the pipeline (double-buffered like the latents): three batches
+    with three different prompt sets, fed one call ahead, give the eager step's loss bit for bit; (ii) `main_eager` -- only the
+    teacher phase is a hipGraph, the rest of the step eager launches, the form the waveform-domain losses of configs[4] take
+    (bench.py `perceptual_distill`) -- equals the eager `_forward_impl` + backward on every batch as well (loss bit-identical,
+    gradient to round-off); exercised here with the latent-space loss so that the comparison is exact."""
+    cfg = cases.TINY_UNET
+    gen = torch.Generator().manual_seed(41)
+    batches = []
+    for i in range(4):
+        batches.append(dict(z=(torch.randn(3, 8, 32, 8, generator=gen) * 0.9).to(DEV),
+                            P={k: v.to(DEV) for k, v in cases.prompt_states(cfg, 3, 6, "pp%d" % i).items()},
+                            kw=dict(time_inds=torch.randint(0, 17, (3,), generator=gen) * 2,
+                                    gaussian_noise=torch.randn(3, 8, 32, 8, generator=gen).to(DEV),
+                                    guidance_scale=torch.rand(3, generator=gen) * 6)))
+    nets = ("student_unet", "student_target_unet", "student_ema_unet")
+    for eager_main in (False, True):
+        m1, _, _ = _lcm()
+        m1.train()
+        o1 = m1.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)
+        m2, _, _ = _lcm()
+        m2.train()
+        o2 = m2.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)
+        gs = m2.capture_train_graph(o2, batches[3]["z"], batches[3]["P"], segmented=False, pipeline_teacher=True,
+                                    main_eager=eager_main, **batches[3]["kw"])
+        assert gs.main_eager == eager_main and (gs.graph is None) == eager_main
+        assert gs.feed(batches[0]["z"], prompt=batches[0]["P"], **batches[0]["kw"]) is False
+        for i in range(3):
+            b = batches[i]
+            for name in nets:
+                getattr(m2, name)._flat.copy_(getattr(m1, name)._flat)
+                getattr(m2, name).mark_weights_changed()
+            with torch.no_grad():
+                loss, pred, target, sig, gamma = m1._forward_impl(b["z"], None, b["P"], False, True, b["kw"]["time_inds"],
+                                                                  b["kw"]["gaussian_noise"], b["kw"]["guidance_scale"], True)
+                m1._student_backward(pred, target, sig, gamma, 1.0, None)
+            assert gs.feed(batches[i + 1]["z"], prompt=batches[i + 1]["P"], **batches[i + 1]["kw"]) is True
+            gs.replay()
+            torch.cuda.synchronize()
+            rel = float((o1.grad - o2.grad).norm() / o1.grad.norm())
+            print("main_eager=%s, batch %d: eager loss %.9g pipelined %.9g, gradient rel diff %.2e"
+                  % (eager_main, i, float(loss), float(gs.loss.item()), rel))
+            assert float(loss) == float(gs.loss.item()) and rel <= 1e-7
+            for o, m in ((o1, m1), (o2, m2)):
+                o.step(grad_scale=1.0)
+                o.zero_grad()
+                m.update_ema()
+        del gs
+
+
 def test_step_graph_with_a_fixed_teacher_guidance_scale_equals_eager(golden):
     """with teacher_guidance_scale = 3 the eager `_forward_impl` conditions student and target on
     w = 3 (audio_consistency_model.py:300-311: the random draw exists only for scale -1); the captured step must do the
