@@ -797,6 +797,10 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
     st = unet_forward_impl(U, true, nullptr, nullptr, nullptr, nullptr, (const uint8_t*)1, cfg->max_batch,
                            cfg->max_text_len, nullptr, s, &gn_need);
     if (st == CTTA_OK && cfg->enable_training) {   // training forward + backward need the larger arena
+      {   // known before the dry run: with the side stream on, the backward releases nothing (unet_backward_begin_impl)
+        const char* e = getenv("CTTA_WGRAD_STREAM");   // =0: one stream
+        U->wg.enabled = !(e && e[0] == '0');
+      }
       size_t gn2 = 0;
       st = unet_forward_impl(U, true, nullptr, nullptr, nullptr, nullptr, (const uint8_t*)1, cfg->max_batch,
                              cfg->max_text_len, nullptr, s, &gn2, true);
@@ -811,8 +815,6 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
     size_t slot_bytes = 0;
     for (Arena& a : W.slot) if (a.peak > slot_bytes) slot_bytes = a.peak;
     slot_bytes = (slot_bytes + 4095) & ~(size_t)4095;
-    const char* e = getenv("CTTA_WGRAD_STREAM");   // =0: one stream
-    W.enabled = !(e && e[0] == '0');
     if (hipMalloc((void**)&W.base, slot_bytes * ctta_unet::WgradSide::NS + 4096) != hipSuccess) {
       ctta_set_error("unet_create: hipMalloc of the weight-gradient scratch (%zu bytes) failed", slot_bytes * 2);
       st = CTTA_ERR_NOMEM;

@@ -41,7 +41,10 @@ static ctta_status wg_begin(BCtx& c, WgJob* j) {
   W.slot[j->slot].reset();
   if (j->async) {
     j->w.stream = W.stream;
-    // the slot's previous job must have drained before the main stream writes dY^T into it
+    // the slot's previous job must have drained before the main stream writes dY^T into it.  Jobs that read their operands
+    // in place (ctta_wgrad_tn) never touch the slot from the main stream, but they keep this wait: it is the back-pressure
+    // that lets the main stream run at most two jobs ahead of the side stream.  Without it the main stream races to the
+    // block's wg_join and idles there while the side stream drains alone: 92.4 vs 83.9 ms per pipelined step (round 4).
     if (W.in_use[j->slot]) CTTA_CHECK_HIP(hipStreamWaitEvent(c.stream, W.freed[j->slot], 0));
   }
   return CTTA_OK;
@@ -101,14 +104,40 @@ static int pick_splits(int64_t M, int R, int N) {
 // slabs[s][n][r] = sum_{m in segment s} dY[m][n] * Q[r][m];  x is the layer input in NHWC (a linear is the 1x1 case
 // with batch=1, hi=rows), dy [M][N] contiguous.  Rows of Q: (channel, tap) then the all-ones row, then `nb`
 // per-sample indicator rows.  Both GEMM operands are made m-contiguous (dY^T, im2col^T).
+static bool wgrad_inplace_on() {   // CTTA_WGRAD_INPLACE=0: every linear back on the transposed-copies route (A/B switch)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_WGRAD_INPLACE"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
+// Linear layers whose dY the main stream does not rewrite: both operands are read WHERE THEY LIE by ctta_wgrad_tn on the
+// side stream (no dY^T, no X^T copy).  dY stays valid until the block's wg_join because the backward's arena releases
+// nothing while the side stream is on (unet_backward_begin_impl).
+static bool wgrad_inplace_ok(const WgJob& job, int taps, bool ups, int stride, int pad, int nb, int C, int N, bool dy_volatile) {
+  return wgrad_inplace_on() && taps == 1 && !ups && stride == 1 && pad == 0 && nb == 0 && C % 8 == 0 && N % 8 == 0 &&
+         !(job.async && dy_volatile);
+}
 static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int B, int hi, int wi, bool ups, int ho, int wo,
-                               int kh, int kw, int stride, int pad, const bf16_t* dy, int N, int nb, Slabs* out) {
+                               int kh, int kw, int stride, int pad, const bf16_t* dy, int N, int nb, Slabs* out,
+                               bool dy_volatile = false) {
   BCtx& c = job.w;
   Arena& A = *c.arena;
   const int64_t M = (int64_t)B * ho * wo;
   const int K = kh * kw * C;
   const int R = K + 1 + nb;
   const int ld = round_up(R, 4);
+  if (wgrad_inplace_ok(job, kh * kw, ups, stride, pad, nb, C, N, dy_volatile) && M < (1LL << 31) - 4096) {
+    const int64_t tiles = (int64_t)((N + 127) / 128) * ((C + 127) / 128);
+    int S = 1;
+    // 128 x 128 tiles at two workgroups per CU; the level-0 / level-1 linears have 4..16 tiles over 9 216..36 864 rows: up to 64
+    // splits of >= 4 chunks (16 splits left a 256 x 256 layer with 64 workgroups walking 36 chunks each: 75 us per launch)
+    while (tiles * S < 512 && S < 64 && M / (2 * S) >= 128) S *= 2;
+    const int mp = (int)round_up64(M, 64 * S);
+    float* slabs = A.get<float>((size_t)S * N * ld); ALLOC_OR_FAIL(slabs);
+    if (!cm.dry) CTTA_TRY(wg_handoff(cm, job));
+    RUN(c, ctta_wgrad_tn(dy, N, N, x, C, C, (int)M, mp, S, K, slabs, (int64_t)N * ld, ld, c.stream));
+    out->p = slabs; out->S = S; out->R = R; out->ld = ld; out->N = N;
+    return CTTA_OK;
+  }
   // the layer input read in place through LDS transpose reads (wgrad_gemm.hip) wherever the geometry allows: every linear
   // and every 3x3 stride-1 convolution of the U-Net except conv_in (8 channels); the stride-2 / upsampling samplers and
   // conv_in keep the im2col^T route below
@@ -207,12 +236,14 @@ static ctta_status conv_wgrad(BCtx& c, const ConvLayer& L, const PackMap& m, con
 }
 
 // linear y = x W^T (+b): x [rows][x_ld] (the first k_rows columns are the GEMM K), dy [rows][N]
+// `dy_volatile`: the main stream rewrites dY in place after this call (the transformer's running token-stream gradient, which
+// every LayerNorm backward accumulates into): its transposed copy is then taken on the MAIN stream in program order, as before.
 static ctta_status linear_wgrad(BCtx& c, const PackMap& m, const PackMap* m2, const bf16_t* x, int x_ld, int64_t rows,
-                                const bf16_t* dy, int N) {
+                                const bf16_t* dy, int N, bool dy_volatile = false) {
   WgJob job;
   CTTA_TRY(wg_begin(c, &job));
   Slabs sl;
-  CTTA_TRY(wgrad_slabs(c, job, x, x_ld, 1, (int)rows, 1, false, (int)rows, 1, 1, 1, 1, 0, dy, N, 0, &sl));
+  CTTA_TRY(wgrad_slabs(c, job, x, x_ld, 1, (int)rows, 1, false, (int)rows, 1, 1, 1, 1, 0, dy, N, 0, &sl, dy_volatile));
   CTTA_TRY(scatter_wgrad(job.w, sl, x_ld, m, 0));
   if (m2) CTTA_TRY(scatter_wgrad(job.w, sl, x_ld, *m2, m.n));   // fused [q | k]
   if (!c.dry) CTTA_TRY(wg_end(c, job));
@@ -349,7 +380,7 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
     const size_t m2 = A.mark();
     bf16_t* dgg = A.get<bf16_t>((size_t)M * ffp); ALLOC_OR_FAIL(dgg);
     CTTA_TRY(linear_dgrad(c, T.t_ff2.d, ds, cp, cp, M, dgg, ffp, ffp, false));
-    CTTA_TRY(linear_wgrad(c, T.t_ff2.m, nullptr, S.gg, ffp, M, ds, cp));
+    CTTA_TRY(linear_wgrad(c, T.t_ff2.m, nullptr, S.gg, ffp, M, ds, cp, true));      // ds: ln3's backward adds into it below
     bf16_t* df = A.get<bf16_t>((size_t)M * 2 * ffp); ALLOC_OR_FAIL(df);
     RUN(c, ctta_geglu_bwd(S.f, dgg, df, M, ffp, 1, c.stream));
     bf16_t* dn = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(dn);
@@ -363,7 +394,7 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
     const int Lp = c.Lp;
     bf16_t* datt = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(datt);
     CTTA_TRY(linear_dgrad(c, T.t_out2.d, ds, cp, cp, M, datt, hp, hp, false));
-    CTTA_TRY(linear_wgrad(c, T.t_out2.m, nullptr, S.att2, hp, M, ds, cp));
+    CTTA_TRY(linear_wgrad(c, T.t_out2.m, nullptr, S.att2, hp, M, ds, cp, true));     // ds: ln2's backward adds into it below
     bf16_t* dq = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(dq);
     const size_t kv = (size_t)c.B * Lp * hp;
     bf16_t* dk = A.get<bf16_t>(kv); ALLOC_OR_FAIL(dk);
@@ -386,7 +417,7 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
     const size_t m2 = A.mark();
     bf16_t* datt = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(datt);
     CTTA_TRY(linear_dgrad(c, T.t_out1.d, ds, cp, cp, M, datt, hp, hp, false));
-    CTTA_TRY(linear_wgrad(c, T.t_out1.m, nullptr, S.att1, hp, M, ds, cp));
+    CTTA_TRY(linear_wgrad(c, T.t_out1.m, nullptr, S.att1, hp, M, ds, cp, true));     // ds: ln1's backward adds into it below
     bf16_t* dqk = A.get<bf16_t>((size_t)M * 2 * hp); ALLOC_OR_FAIL(dqk);
     bf16_t* dv = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(dv);
     CTTA_TRY(bwd_attention(c, T.heads, T.dh, S.qk, 2 * hp, S.qk + hp, 2 * hp, N, S.vt, vt_ld, nullptr, N, N, S.att1, datt, hp,
@@ -458,7 +489,10 @@ static ctta_status unet_backward_begin_impl(ctta_unet* U, bool dry, const bf16_t
   const ctta_unet::TrainSaved& S = U->ts;
   Arena& A = U->arena;
   A.off = S.arena_off;
-  A.no_release = false;
+  // With the weight-gradient side stream on, a linear layer's dY is read in place by the SIDE stream some time after the main
+  // stream has moved on: nothing the backward allocates is released before the next training forward resets the arena
+  // (the dry run sizes it under the same policy; a few GB more at batch 9 -- HBM is what this part has).
+  A.no_release = U->wg.enabled && wgrad_inplace_on();
   const int B = S.B, H = cfg.height, W = cfg.width, c0 = cfg.block_out_channels[0];
   U->bw.dtemb_all = A.get<float>((size_t)B * U->temb_total); ALLOC_OR_FAIL(U->bw.dtemb_all);
   U->bw.dskip.assign((size_t)S.n_skips, nullptr);

@@ -280,3 +280,182 @@ extern "C" ctta_status ctta_wgrad_rowsum(const void* dyt, int n, int mp, int m_v
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a LINEAR layer with BOTH operands read where they lie (round 4):
+//     slab[s][n][c] = sum over split s's rows m of dY[m][n] * X[m][c]          dY [M][ldy], X [M][ldx], row-major bf16
+// The conv_gemm route needs both operands m-contiguous and therefore a transposed copy of each (ctta_transpose_bf16 on the
+// main stream + ctta_im2col_t on the side stream: 10.4 + 5.5 GB of the 259 GB a distillation step moves).  Here a workgroup
+// stages natural 64-row tiles of dY (128 columns) and X (128 columns) in LDS -- rows of 256 bytes, coalesced -- and BOTH
+// MFMA operands come out of them through ds_read_b64_tr_b16, the transposing LDS read wgrad_implicit_kernel already uses
+// for X (same k-slot order on both operands: position 32 ks + 16 r + 4 kg + j).  Four waves of 64 (c) x 64 (n); two 64-row
+// chunks ride in registers behind a double-buffered LDS pair, one barrier per chunk.
+struct WgradTnParams {
+  const bf16_t* dy;
+  const bf16_t* x;
+  float* slabs;
+  int N, C, ldy, ldx, ld;
+  int M, mp, seg;
+  long long slab_stride;
+  int bias_col;          // >= C: the workgroups of the first column tile also write the column sums of dY there; < 0: none
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradTnParams p) {
+  constexpr int RS = 128 * 2 + 32;                 // LDS bytes per staged row: = 32 (mod 64), conflict-free transposing reads
+  constexpr int TILE = 64 * RS;                    // one operand tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [dY tile | X tile], ONE buffer (36 KB: a second one
+  // made the kernel 73 KB per workgroup -- two of them fill a CU's LDS and lock the main and teacher streams' 48 KB
+  // conv_gemm workgroups out of it: measured 92 vs 86 ms per pipelined step)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lq = lane & 15, kg = lane >> 4;
+  const int wc = wave & 1, wn = wave >> 1;
+  const int c0 = blockIdx.x * 128, n0 = blockIdx.y * 128, split = blockIdx.z;
+  const int m_lo = split * p.seg, m_hi = min(m_lo + p.seg, p.mp);
+
+  int abase[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) abase[ks][r] = (32 * ks + 16 * r + 4 * kg + (lq >> 2)) * RS + (lq & 3) * 8;
+
+  f32x4_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  // staging plan: thread -> (row = q / 16, 16-byte column chunk = q % 16), four rows apart per vector
+  const int srow = tid >> 4, sch = tid & 15;
+  const bool n_ok = n0 + sch * 8 < p.N, c_ok = c0 + sch * 8 < p.C;
+  uint4 st[2][8];                                  // [register stage][4 dY vectors | 4 X vectors]
+  // bias gradient = column sums of dY: a thread's 8 dY columns never change (sch), so the workgroups of column tile 0 add up
+  // what they stage anyway (a separate column-sum pass over dY cost more than the product: 50 us per launch)
+  const bool do_bias = p.bias_col >= 0 && blockIdx.x == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto fetch = [&](uint4 (&v)[8], int m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + srow + i * 16;
+      uint4 a = make_uint4(0, 0, 0, 0), b = a;
+      if (m < p.M) {
+        if (n_ok) a = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * p.ldy + n0 + sch * 8);
+        if (c_ok) b = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + c0 + sch * 8);
+      }
+      v[i] = a; v[4 + i] = b;
+    }
+  };
+  auto add_bias = [&](const uint4 (&v)[8]) {       // when the stage is parked: its loads have landed
+    if (do_bias) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float f[8];
+        unpack8(v[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+      }
+    }
+  };
+  auto park = [&](const uint4 (&v)[8], int buf) {
+    add_bias(v);
+    unsigned char* d = smem + (size_t)srow * RS + sch * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      *reinterpret_cast<uint4*>(d + (size_t)i * 16 * RS) = v[i];
+      *reinterpret_cast<uint4*>(d + TILE + (size_t)i * 16 * RS) = v[4 + i];
+    }
+  };
+  auto compute = [&](int buf) {
+    const unsigned char* ys = smem + (wn * 64) * 2;
+    const unsigned char* xs = smem + TILE + (wc * 64) * 2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t bf[4];
+#pragma unroll
+      for (int nb = 0; nb < 4; ++nb) {
+        const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ys + abase[ks][0] + nb * 32));
+        const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(ys + abase[ks][1] + nb * 32));
+        const uint2 u0 = __builtin_bit_cast(uint2, b0), u1 = __builtin_bit_cast(uint2, b1);
+        bf[nb] = __builtin_bit_cast(bf16x8_t, make_uint4(u0.x, u0.y, u1.x, u1.y));
+      }
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {
+        const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xs + abase[ks][0] + cb * 32));
+        const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(xs + abase[ks][1] + cb * 32));
+        const uint2 u0 = __builtin_bit_cast(uint2, a0), u1 = __builtin_bit_cast(uint2, a1);
+        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, make_uint4(u0.x, u0.y, u1.x, u1.y));
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) acc[cb][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[nb], acc[cb][nb], 0, 0, 0);
+      }
+    }
+  };
+
+  // chunk j (rows m_lo + 64 j ..) rides in register stage j % 2 (two chunks in flight) until it is parked into the LDS tiles
+  const int nch = (m_hi - m_lo + 63) / 64;
+  if (nch > 0) fetch(st[0], m_lo);
+  if (nch > 1) fetch(st[1], m_lo + 64);
+  for (int j0 = 0; j0 < nch; j0 += 2) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = j0 + u;
+      if (j < nch) {
+        __syncthreads();                                   // chunk j - 1's fragments have been read
+        park(st[u], 0);
+        if (j + 2 < nch) fetch(st[u], m_lo + (j + 2) * 64);
+        __syncthreads();
+        compute(0);
+      }
+    }
+  }
+  __syncthreads();
+
+  // D[i][j]: i = X column 4 kg + e of the fragment, j = dY column lq  ->  row n of the slab gets 4 consecutive floats
+  float* slab = p.slabs + (size_t)split * p.slab_stride;
+  if (do_bias) {       // fold the 16 row phases of every column in a fixed order (the tiles are dead: the loop ended on a barrier)
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[(srow * 16 + sch) * 8 + e] = bsum[e];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < p.N) {
+      float t = 0.f;
+      for (int r = 0; r < 16; ++r) t += red[(r * 16 + (tid >> 3)) * 8 + (tid & 7)];
+      slab[(size_t)(n0 + tid) * p.ld + p.bias_col] = t;
+    }
+  }
+#pragma unroll
+  for (int nb = 0; nb < 4; ++nb) {
+    const int n = n0 + wn * 64 + nb * 16 + lq;
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+      const int cc = c0 + wc * 64 + cb * 16 + kg * 4;
+      if (n < p.N && cc < p.C) {
+        const f32x4_t a = acc[cb][nb];
+        *reinterpret_cast<float4*>(slab + (size_t)n * p.ld + cc) = make_float4(a[0], a[1], a[2], a[3]);
+      }
+    }
+  }
+}
+
+extern "C" ctta_status ctta_wgrad_tn(const void* dy, int ldy, int n, const void* x, int ldx, int c, int m_valid, int mp, int splits,
+                                     int bias_col, float* slabs, int64_t slab_stride, int ld, void* stream) {
+  CTTA_REQUIRE(dy && x && slabs && n >= 1 && c >= 1 && splits >= 1 && m_valid >= 1 && m_valid <= mp, "wgrad_tn: bad arguments");
+  CTTA_REQUIRE(ldy % 8 == 0 && ldx % 8 == 0 && n % 8 == 0 && c % 8 == 0 && ldy >= n && ldx >= c,
+               "wgrad_tn: n=%d c=%d ldy=%d ldx=%d must be multiples of 8", n, c, ldy, ldx);
+  CTTA_REQUIRE(mp % (64 * splits) == 0 && ld % 4 == 0 && ld >= c + (bias_col >= 0 ? 1 : 0) && (bias_col < 0 || bias_col >= c),
+               "wgrad_tn: mp=%d splits=%d ld=%d", mp, splits, ld);
+  static bool attr = false;
+  constexpr int smem = 2 * 64 * (128 * 2 + 32);
+  if (!attr) {
+    CTTA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr = true;
+  }
+  WgradTnParams p;
+  p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.slabs = slabs; p.N = n; p.C = c; p.ldy = ldy; p.ldx = ldx; p.ld = ld;
+  p.M = m_valid; p.mp = mp; p.seg = mp / splits; p.slab_stride = slab_stride; p.bias_col = bias_col;
+  hipStream_t s = (hipStream_t)stream;
+  const bool prof = ctta_prof_active();
+  if (prof) ctta_prof_begin(0, 142, c, n, p.seg, splits, s);
+  hipLaunchKernelGGL(wgrad_tn_kernel, dim3((unsigned)((c + 127) / 128), (unsigned)((n + 127) / 128), (unsigned)splits), dim3(256), smem, s, p);
+  if (prof) ctta_prof_end(s);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}

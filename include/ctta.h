@@ -632,6 +632,13 @@ ctta_status ctta_wgrad_scatter(const float* slabs, int n_slabs, int64_t slab_str
  * sample_cols > 0, per-sample sums into the columns behind it (d temb).  mp % (64 * splits) == 0.
  * ctta_wgrad_implicit_supported: whether a geometry is inside the kernel's range (CTTA_WGRAD_IMPLICIT=0 turns it off). */
 int ctta_wgrad_implicit_supported(int taps, int c, int h, int w, int x_ld, int n);
+/* Weight gradient of a linear layer with BOTH operands read in place (no transposed copies):
+ * slabs[s][r][k] = sum over split s's rows m of dY[m][r] * X[m][k]; dy [m_valid][ldy] (n columns used), x [m_valid][ldx]
+ * (c columns used), row-major bf16; rows beyond m_valid count as zero up to mp (mp %% (64 * splits) == 0).  bias_col >= c
+ * also writes the column sums of dY into slabs[s][r][bias_col].  Replaces autograd's grad_weight / grad_bias of F.linear
+ * (diffusers/models/attention.py:276-334, attention_processor.py:1107-1136) in the student's backward pass. */
+ctta_status ctta_wgrad_tn(const void* dy, int ldy, int n, const void* x, int ldx, int c, int m_valid, int mp, int splits,
+                          int bias_col, float* slabs, int64_t slab_stride, int ld, void* stream);
 /* the row sums alone: slabs[s][r][bias_col] = sum over split s of dY^T[r][m] (+ per-sample sums in the sample_cols columns
  * behind it): bias gradient / d temb of the layers whose weight-gradient product runs on ctta_conv_gemm */
 ctta_status ctta_wgrad_rowsum(const void* dyt, int n, int mp, int m_valid, int splits, int hw, int sample_cols, float* slabs,

@@ -151,6 +151,39 @@ def test_implicit_weight_gradient(B, Cin, Cout, H, W, k, splits, nb):
                                       Cout * ld, ld, st))
 
 
+@pytest.mark.parametrize("M,Cin,Cout,splits,x_ld,dy_ld", [(200, 256, 248, 1, 256, 248), (77, 1280, 40, 2, 1280, 40),
+                                                          (1000, 72, 520, 4, 72, 520), (4096, 320, 256, 2, 384, 512),
+                                                          (333, 136, 264, 1, 136, 264), (9216, 512, 1024, 8, 512, 1024)])
+def test_weight_gradient_with_both_operands_in_place(M, Cin, Cout, splits, x_ld, dy_ld):
+    """ctta_wgrad_tn (csrc/wgrad_gemm.hip, round 4): dW / db of F.linear with dY [M][N] and X [M][K] read WHERE THEY LIE --
+    both MFMA operands through transposing LDS reads, no transposed copies (autograd of attention.py:276-334's linears).
+    Ragged row counts (zero rows up to the 64 * splits padding), column counts that are not multiples of the 128-wide
+    tiles, operands that are column slices of wider matrices (x_ld / dy_ld > width), splits; against torch autograd."""
+    L = lib()
+    st = N.stream_ptr()
+    x = bf16_round(det("tn.x", (M, Cin), 1)).requires_grad_(True)
+    w = bf16_round(det("tn.w", (Cout, Cin), 2) / math.sqrt(Cin)).requires_grad_(True)
+    b = (det("tn.b", (Cout,), 3) * 0.1).requires_grad_(True)
+    y = F.linear(x, w, b)
+    dy = bf16_round(det("tn.dy", (M, Cout), 4))
+    y.backward(dy)
+    xa = torch.full((M, x_ld), 7.0, dtype=torch.bfloat16, device=DEV)          # the columns beyond Cin / Cout must not leak in
+    xa[:, :Cin] = x.detach().to(torch.bfloat16).to(DEV)
+    dya = torch.full((M, dy_ld), -3.0, dtype=torch.bfloat16, device=DEV)
+    dya[:, :Cout] = dy.to(torch.bfloat16).to(DEV)
+    mp = rup(M, 64 * splits)
+    ld = rup(Cin + 1, 4)
+    slabs = torch.full((splits, Cout, ld), float("nan"), device=DEV)
+    N.check(L.ctta_wgrad_tn(N.ptr(dya), dy_ld, Cout, N.ptr(xa), x_ld, Cin, M, mp, splits, Cin, N.ptr(slabs), Cout * ld, ld, st))
+    sync()
+    got = slabs[:, :, :Cin + 1].sum(0).cpu()
+    assert torch.isfinite(got).all()
+    assert rel_err(got[:, :Cin], w.grad) < 2e-3
+    assert rel_err(got[:, Cin], b.grad) < 2e-3
+    with pytest.raises(RuntimeError):       # widths that are not multiples of 8 are refused loudly
+        N.check(L.ctta_wgrad_tn(N.ptr(dya), dy_ld, Cout - 1, N.ptr(xa), x_ld, Cin, M, mp, splits, Cin, N.ptr(slabs), Cout * ld, ld, st))
+
+
 @pytest.mark.parametrize("B,C,H,W,G,silu,eps", [(2, 40, 16, 8, 8, True, 1e-5), (3, 256, 8, 8, 32, False, 1e-6),
                                                 (2, 120, 4, 2, 8, True, 1e-5),
                                                 # many chunks per sample: the chunk walk of gn_bwd_fold split over the block's
