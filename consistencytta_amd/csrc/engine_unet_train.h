@@ -160,6 +160,17 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
   const int seg = mp / S;
   bf16_t* q = nullptr;
   if (!implicit) { q = A.get<bf16_t>((size_t)R * mp); ALLOC_OR_FAIL(q); }
+  // 3x3 convolutions: dY read in place too (no convolution's dY is rewritten by the main stream later) when the arena policy
+  // keeps it alive for the side stream
+  const bool conv_inplace = implicit && kh * kw == 9 && wgrad_inplace_on() && N % 8 == 0 && (nb == 0 || (ho * wo) % 64 == 0) &&
+                            (!job.async || c.U->wg.enabled);
+  if (conv_inplace) {
+    float* slabs = A.get<float>((size_t)S * N * ld); ALLOC_OR_FAIL(slabs);
+    if (!cm.dry) CTTA_TRY(wg_handoff(cm, job));
+    RUN(c, ctta_wgrad_implicit_inplace(dy, N, N, mp, x, C, C, B, hi, wi, 9, (int)M, S, K, nb, slabs, (int64_t)N * ld, ld, c.stream));
+    out->p = slabs; out->S = S; out->R = R; out->ld = ld; out->N = N;
+    return CTTA_OK;
+  }
   bf16_t* pt = A.get<bf16_t>((size_t)N * mp); ALLOC_OR_FAIL(pt);
   float* slabs = A.get<float>((size_t)S * N * ld); ALLOC_OR_FAIL(slabs);
   RUN(cm, ctta_transpose_bf16(dy, 0, (int)M, N, N, 0, pt, 0, mp, 1, cm.stream));   // dY lives in the main stream's arena

@@ -26,6 +26,8 @@ typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 
 struct WgradParams {
+  const bf16_t* dy;      // NAT: [M][ldy] dY where it lies (output channels contiguous)
+  int ldy, bias_col, sample_cols;   // NAT: column sums of dY (bias gradient, per-sample d temb) written by channel tile 0
   const bf16_t* dyt;     // [N][mp]   dY^T, positions contiguous
   const bf16_t* x;       // NHWC pixels, xld elements apart, C channels used
   float* slabs;          // [S][N][ld]
@@ -42,17 +44,22 @@ struct WgTile {
   static constexpr int TC = 64 * CB;                 // channels per workgroup
   static constexpr int RSX = TC * 2 + 32;            // LDS bytes per staged pixel: = 32 (mod 64)
   static constexpr int RSB = 64 * 2 + 16;            // LDS bytes per dY^T row
+  static constexpr int RSN = 64 * 2 + 32;            // NAT: LDS bytes per natural dY row (64 output channels): = 32 (mod 64)
   static constexpr int MAXPIX = T == 9 ? 136 : 64;   // (64 / W + 2) (W + 2) <= 136 for W in {2 .. 32}
   static constexpr int XV = (MAXPIX * (TC / 8) + 255) / 256;   // 16-byte vectors of the patch per thread
 };
 
-template <int T>
+// NAT (round 4): dY is read where it lies -- natural 64-position x 64-channel tiles, the B operand through the same transposing
+// LDS read as X -- and the bias / per-sample column sums are added up by the workgroups of channel tile 0 from the vectors
+// they stage (no dY^T copy, no row-sum launch).
+template <int T, bool NAT>
 __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParams p) {
   using K = WgTile<T>;
-  constexpr int CB = K::CB, TC = K::TC, RSX = K::RSX, RSB = K::RSB, XV = K::XV, NA = T * CB;
+  constexpr int CB = K::CB, TC = K::TC, RSX = K::RSX, RSB = NAT ? K::RSN : K::RSB, XV = K::XV, NA = T * CB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* xs = smem;                                   // [npix][RSX]
-  unsigned char* bs = smem + (size_t)K::MAXPIX * RSX;         // [64 n][RSB]
+  unsigned char* bs = smem + (size_t)K::MAXPIX * RSX;         // [64 n][RSB]   (NAT: [64 positions][RSN])
+  float* red = reinterpret_cast<float*>(bs + 64 * RSB);       // NAT: [32 row phases][64 channels] for the column sums
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kg = lane >> 4;
   const int c0 = blockIdx.x * TC, n0 = blockIdx.y * 64, split = blockIdx.z;
@@ -73,6 +80,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
     }
   // B operand (dY^T, output channels x positions): row lq of block nb, positions 32 ks + 4 kg .. + 3 and 32 ks + 16 + 4 kg .. + 3
   const int bbase = lq * RSB + kg * 8;
+  int nbase[2][2];       // NAT: the transposing read names position row 32 ks + 16 r + 4 kg + lq / 4, channels (lq % 4) * 4 .. + 3
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) nbase[ks][r] = (32 * ks + 16 * r + 4 * kg + (lq >> 2)) * RSB + (lq & 3) * 8;
+  const bool do_sums = NAT && p.bias_col >= 0 && blockIdx.x == 0;
+  float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float tot = 0.f;       // threads 0..63: running column sum of channel n0 + tid over the whole split
+  int acc_sample = -1;   // the sample whose rows bsum holds (per-sample columns only)
+  if (do_sums && tid < 64 && n0 + tid < p.N)     // samples this split does not touch contribute zero (the scatter adds all splits)
+    for (int b = 0; b < p.sample_cols; ++b) p.slabs[(size_t)split * p.slab_stride + (size_t)(n0 + tid) * p.ld + p.bias_col + 1 + b] = 0.f;
 
   f32x4_t acc[NA][4];
 #pragma unroll
@@ -111,8 +129,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
       const int q = tid + i * 256;
       const int row = q >> 3, ch = q & 7;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (n0 + row < p.N) v = *reinterpret_cast<const uint4*>(p.dyt + (size_t)(n0 + row) * p.mp + m0 + ch * 8);   // the pad of dY^T is zero
+      if constexpr (NAT) {
+        if (m0 + row < p.M && n0 + ch * 8 < p.N) v = *reinterpret_cast<const uint4*>(p.dy + (size_t)(m0 + row) * p.ldy + n0 + ch * 8);
+      } else {
+        if (n0 + row < p.N) v = *reinterpret_cast<const uint4*>(p.dyt + (size_t)(n0 + row) * p.mp + m0 + ch * 8);   // the pad of dY^T is zero
+      }
       br[i] = v;
+    }
+  };
+  // NAT column sums: fold the 32 row phases of the chunk range summed so far in a fixed order; threads 0..63 own one channel
+  auto fold_sums = [&](int sample) {     // called by every thread of a do_sums workgroup (uniform)
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[(tid >> 3) * 64 + (tid & 7) * 8 + e] = bsum[e]; bsum[e] = 0.f; }
+    __syncthreads();
+    if (tid < 64) {
+      float t = 0.f;
+      for (int r = 0; r < 32; ++r) t += red[r * 64 + tid];
+      tot += t;
+      if (sample >= 0 && sample < p.sample_cols && n0 + tid < p.N)
+        p.slabs[(size_t)split * p.slab_stride + (size_t)(n0 + tid) * p.ld + p.bias_col + 1 + sample] = t;
     }
   };
   auto park = [&]() {
@@ -126,11 +162,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
     for (int i = 0; i < 2; ++i) {
       const int q = tid + i * 256;
       *reinterpret_cast<uint4*>(bs + (size_t)(q >> 3) * RSB + (q & 7) * 16) = br[i];
+      if (do_sums) {
+        float f[8];
+        unpack8(br[i], f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bsum[e] += f[e];
+      }
     }
   };
 
   if (m_lo < m_hi) fetch(m_lo);
   for (int m0 = m_lo; m0 < m_hi; m0 += 64) {
+    // NAT, per-sample columns: a 64-position chunk lies inside one sample; at a sample boundary what was summed so far
+    // belongs to the previous sample
+    if (do_sums && p.sample_cols > 0 && m0 < p.M) {
+      const int b = m0 / p.HW;
+      if (acc_sample >= 0 && b != acc_sample) fold_sums(acc_sample);
+      acc_sample = b;
+    }
     __syncthreads();                       // the previous chunk's fragments have been read
     park();
     __syncthreads();
@@ -140,9 +189,16 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
       bf16x8_t bf[4];
 #pragma unroll
       for (int nb = 0; nb < 4; ++nb) {
-        const unsigned char* q = bs + bbase + nb * 16 * RSB + ks * 64;
-        const uint2 lo = *reinterpret_cast<const uint2*>(q), hi = *reinterpret_cast<const uint2*>(q + 32);
-        bf[nb] = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        if constexpr (NAT) {
+          const s16x4_t b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bs + nbase[ks][0] + nb * 32));
+          const s16x4_t b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(bs + nbase[ks][1] + nb * 32));
+          const uint2 u0 = __builtin_bit_cast(uint2, b0), u1 = __builtin_bit_cast(uint2, b1);
+          bf[nb] = __builtin_bit_cast(bf16x8_t, make_uint4(u0.x, u0.y, u1.x, u1.y));
+        } else {
+          const unsigned char* q = bs + bbase + nb * 16 * RSB + ks * 64;
+          const uint2 lo = *reinterpret_cast<const uint2*>(q), hi = *reinterpret_cast<const uint2*>(q + 32);
+          bf[nb] = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
       }
 #pragma unroll
       for (int t = 0; t < T; ++t) {
@@ -161,6 +217,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
     }
   }
 
+  if (do_sums) {       // the last sample's share, then the split's total = the bias column
+    fold_sums(acc_sample);
+    if (tid < 64 && n0 + tid < p.N) p.slabs[(size_t)split * p.slab_stride + (size_t)(n0 + tid) * p.ld + p.bias_col] = tot;
+  }
   // ---- D[i][j]: i = channel (4 kg + e inside the wave's block), j = output channel lq.  Row n of the slab receives, from
   // this lane, the 4 T consecutive floats of channels cc .. cc + 3: [e][t] = acc[t][..][e]
   float* slab = p.slabs + (size_t)split * p.slab_stride;
@@ -225,10 +285,29 @@ extern "C" int ctta_wgrad_implicit_supported(int taps, int c, int h, int w, int 
   return ((long long)h * w) % 64 == 0 ? 1 : 0;
 }
 
+static ctta_status wgrad_implicit_launch(const void* dyt, const void* dy_nat, int ldy, int n, int mp, const void* x, int x_ld,
+                                         int c, int batch, int h, int w, int taps, int m_valid, int splits, int bias_col,
+                                         int sample_cols, float* slabs, int64_t slab_stride, int ld, void* stream);
 extern "C" ctta_status ctta_wgrad_implicit(const void* dyt, int n, int mp, const void* x, int x_ld, int c, int batch, int h, int w,
                                            int taps, int m_valid, int splits, int bias_col, int sample_cols, float* slabs,
                                            int64_t slab_stride, int ld, void* stream) {
-  CTTA_REQUIRE(dyt && x && slabs && n >= 1 && c >= 1 && splits >= 1 && mp >= 64 && m_valid >= 1 && m_valid <= mp,
+  CTTA_REQUIRE(dyt, "wgrad_implicit: null pointer");
+  return wgrad_implicit_launch(dyt, nullptr, 0, n, mp, x, x_ld, c, batch, h, w, taps, m_valid, splits, bias_col, sample_cols, slabs,
+                               slab_stride, ld, stream);
+}
+// the same product with dY [m_valid][ldy] read where it lies (3x3 convolutions; the linears have ctta_wgrad_tn)
+extern "C" ctta_status ctta_wgrad_implicit_inplace(const void* dy, int ldy, int n, int mp, const void* x, int x_ld, int c, int batch,
+                                                   int h, int w, int taps, int m_valid, int splits, int bias_col, int sample_cols,
+                                                   float* slabs, int64_t slab_stride, int ld, void* stream) {
+  CTTA_REQUIRE(dy && ldy % 8 == 0 && ldy >= n && n % 8 == 0 && taps == 9, "wgrad_implicit_inplace: dy [m][ldy] with ldy, n multiples of 8, 3x3 only");
+  return wgrad_implicit_launch(nullptr, dy, ldy, n, mp, x, x_ld, c, batch, h, w, taps, m_valid, splits, bias_col, sample_cols, slabs,
+                               slab_stride, ld, stream);
+}
+static ctta_status wgrad_implicit_launch(const void* dyt, const void* dy_nat, int ldy, int n, int mp, const void* x, int x_ld,
+                                         int c, int batch, int h, int w, int taps, int m_valid, int splits, int bias_col,
+                                         int sample_cols, float* slabs, int64_t slab_stride, int ld, void* stream) {
+  const bool nat = dy_nat != nullptr;
+  CTTA_REQUIRE((dyt || dy_nat) && x && slabs && n >= 1 && c >= 1 && splits >= 1 && mp >= 64 && m_valid >= 1 && m_valid <= mp,
                "wgrad_implicit: bad arguments");
   CTTA_REQUIRE(ctta_wgrad_implicit_supported(taps, c, h, w, x_ld, n),
                "wgrad_implicit: taps=%d c=%d h=%d w=%d x_ld=%d is outside the kernel's range (1x1, or 3x3 stride 1 pad 1 with a "
@@ -240,26 +319,32 @@ extern "C" ctta_status ctta_wgrad_implicit(const void* dyt, int n, int mp, const
   CTTA_REQUIRE(bias_col < 0 || sample_cols == 0 || ((h * w) % 8 == 0 && sample_cols <= batch),
                "wgrad_implicit: per-sample columns need h*w %% 8 == 0 and sample_cols <= batch");
   WgradParams p;
+  p.dy = (const bf16_t*)dy_nat; p.ldy = ldy; p.bias_col = bias_col; p.sample_cols = sample_cols;
   p.dyt = (const bf16_t*)dyt; p.x = (const bf16_t*)x; p.slabs = slabs;
   p.N = n; p.C = c; p.xld = x_ld; p.mp = mp; p.ld = ld;
   p.H = h; p.W = w; p.HW = h * w; p.M = m_valid; p.seg = mp / splits; p.slab_stride = slab_stride;
   hipStream_t s = (hipStream_t)stream;
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, 130 + (taps == 9 ? 1 : 0), n, (long long)c * taps, mp / splits, splits, s);
-  if (taps == 9) {
+  if (taps == 9 && nat) {
+    using K = WgTile<9>;
+    const size_t smem = (size_t)K::MAXPIX * K::RSX + 64 * K::RSN + 32 * 64 * sizeof(float);
+    dim3 grid((unsigned)((c + K::TC - 1) / K::TC), (unsigned)((n + 63) / 64), (unsigned)splits);
+    hipLaunchKernelGGL((wgrad_implicit_kernel<9, true>), grid, dim3(256), smem, s, p);
+  } else if (taps == 9) {
     using K = WgTile<9>;
     const size_t smem = (size_t)K::MAXPIX * K::RSX + 64 * K::RSB;
     dim3 grid((unsigned)((c + K::TC - 1) / K::TC), (unsigned)((n + 63) / 64), (unsigned)splits);
-    hipLaunchKernelGGL(wgrad_implicit_kernel<9>, grid, dim3(256), smem, s, p);
+    hipLaunchKernelGGL((wgrad_implicit_kernel<9, false>), grid, dim3(256), smem, s, p);
   } else {
     using K = WgTile<1>;
     const size_t smem = (size_t)K::MAXPIX * K::RSX + 64 * K::RSB;
     dim3 grid((unsigned)((c + K::TC - 1) / K::TC), (unsigned)((n + 63) / 64), (unsigned)splits);
-    hipLaunchKernelGGL(wgrad_implicit_kernel<1>, grid, dim3(256), smem, s, p);
+    hipLaunchKernelGGL((wgrad_implicit_kernel<1, false>), grid, dim3(256), smem, s, p);
   }
   if (prof) ctta_prof_end(s);
   CTTA_LAUNCH_CHECK();
-  if (bias_col >= 0) {
+  if (bias_col >= 0 && !nat) {
     hipLaunchKernelGGL(wgrad_rowsum_kernel, dim3((unsigned)n, (unsigned)splits), dim3(64), 0, s, (const bf16_t*)dyt, mp, m_valid,
                        mp / splits, h * w, sample_cols, slabs, (long long)slab_stride, ld, bias_col);
     CTTA_LAUNCH_CHECK();

@@ -632,6 +632,11 @@ ctta_status ctta_wgrad_scatter(const float* slabs, int n_slabs, int64_t slab_str
  * sample_cols > 0, per-sample sums into the columns behind it (d temb).  mp % (64 * splits) == 0.
  * ctta_wgrad_implicit_supported: whether a geometry is inside the kernel's range (CTTA_WGRAD_IMPLICIT=0 turns it off). */
 int ctta_wgrad_implicit_supported(int taps, int c, int h, int w, int x_ld, int n);
+/* ctta_wgrad_implicit with dY [m_valid][ldy] read where it lies (taps = 9 only): no transposed copy, bias / per-sample
+ * columns summed inside the kernel. */
+ctta_status ctta_wgrad_implicit_inplace(const void* dy, int ldy, int n, int mp, const void* x, int x_ld, int c, int batch, int h,
+                                        int w, int taps, int m_valid, int splits, int bias_col, int sample_cols, float* slabs,
+                                        int64_t slab_stride, int ld, void* stream);
 /* Weight gradient of a linear layer with BOTH operands read in place (no transposed copies):
  * slabs[s][r][k] = sum over split s's rows m of dY[m][r] * X[m][k]; dy [m_valid][ldy] (n columns used), x [m_valid][ldx]
  * (c columns used), row-major bf16; rows beyond m_valid count as zero up to mp (mp %% (64 * splits) == 0).  bias_col >= c

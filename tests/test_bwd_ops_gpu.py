@@ -143,6 +143,17 @@ def test_implicit_weight_gradient(B, Cin, Cout, H, W, k, splits, nb):
     # the route it replaces gives the same numbers up to the fp32 summation order
     dw_old, db_old, _ = wgrad(xa, dya, B, H, W, Cin, Cout, k, 1, pad, False, H, W)
     assert rel_err(got[:, :K].reshape(Cout, Cin, k, k), dw_old) < 1e-4
+    if k == 3 and Cout % 8 == 0:   # round 4: the same product with dY read where it lies (no transposed copy, sums in the kernel)
+        slabs2 = torch.full((splits, Cout, ld), float("nan"), device=DEV)
+        N.check(L.ctta_wgrad_implicit_inplace(N.ptr(dya), Cout, Cout, mp, N.ptr(xa), Cin, Cin, B, H, W, taps, M, splits, K, nb,
+                                              N.ptr(slabs2), Cout * ld, ld, st))
+        sync()
+        got2 = slabs2[:, :, :K + 1 + nb].sum(0).cpu()
+        assert torch.isfinite(got2).all()
+        assert torch.equal(got2[:, :K], got[:, :K])                       # the same MFMA products in the same order
+        assert rel_err(got2[:, K], b.grad) < 2e-3
+        if nb:
+            assert rel_err(got2[:, K + 1:K + 1 + nb].t(), dy.sum(dim=(2, 3))[:nb]) < 2e-3
     # outside the kernel's range: refused loudly
     assert L.ctta_wgrad_implicit_supported(9, 64, 8, 48, 64, 64) == 0 and L.ctta_wgrad_implicit_supported(9, 64, 6, 4, 64, 64) == 0
     assert L.ctta_wgrad_implicit_supported(4, 64, 8, 8, 64, 64) == 0 and L.ctta_wgrad_implicit_supported(1, 8, 8, 8, 8, 64) == 0
