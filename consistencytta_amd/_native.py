@@ -106,6 +106,8 @@ SIGNATURES = {
     "ctta_wgrad_implicit": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                     c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
     "ctta_wgrad_scatter_rows": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ctta_wgrad_scatter_rows_bias": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                            c_void_p, c_void_p, c_int, c_void_p]),
     "ctta_col_scatter": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "ctta_transpose_multi": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "ctta_vae_encoder_create": (c_int, [POINTER(VAEConfig), POINTER(Tensor), c_int, c_void_p, POINTER(c_void_p)]),

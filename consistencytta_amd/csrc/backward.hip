@@ -253,8 +253,21 @@ __global__ __launch_bounds__(256) void wgrad_scatter_rows_kernel(const float* __
                                                                  long long slab_stride, int ldk, int k_cols, int n_rows,
                                                                  const int* __restrict__ row_off,
                                                                  const int* __restrict__ col_off,
-                                                                 float* __restrict__ grad, int accumulate, int vec4) {
+                                                                 float* __restrict__ grad, int accumulate, int vec4,
+                                                                 int bias_col, int n_bias, const int* __restrict__ bias_idx,
+                                                                 float* __restrict__ grad_bias) {
   const int n = blockIdx.y;
+  // the layer's bias gradient rides along (one launch per layer instead of two): the first wave of the row's first block
+  // folds column `bias_col` of the S slabs -- lanes stride the slabs, fixed butterfly
+  if (bias_col >= 0 && blockIdx.x == 0 && threadIdx.x < 64 && n < n_bias) {
+    const int j = bias_idx ? bias_idx[n] : n;
+    if (j >= 0) {
+      float v = 0.f;
+      for (int s = threadIdx.x; s < S; s += 64) v += slabs[(size_t)s * slab_stride + (size_t)n * ldk + bias_col];
+      v = wave_sum(v);
+      if (threadIdx.x == 0) grad_bias[j] = accumulate ? grad_bias[j] + v : v;
+    }
+  }
   const int ro = row_off[n];
   if (ro < 0) return;
   const float* src = slabs + (size_t)n * ldk;
@@ -338,7 +351,15 @@ extern "C" ctta_status ctta_col_scatter(const float* slabs, int n_slabs, int64_t
 extern "C" ctta_status ctta_wgrad_scatter_rows(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int k_cols,
                                                int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad,
                                                int accumulate, void* stream) {
+  return ctta_wgrad_scatter_rows_bias(slabs, n_slabs, slab_stride, ldk, k_cols, n_rows, row_off, col_off, grad, -1, 0, nullptr,
+                                      nullptr, accumulate, stream);
+}
+extern "C" ctta_status ctta_wgrad_scatter_rows_bias(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int k_cols,
+                                                    int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad,
+                                                    int bias_col, int n_bias, const int32_t* bias_idx, float* grad_bias,
+                                                    int accumulate, void* stream) {
   CTTA_REQUIRE(slabs && row_off && grad && n_slabs >= 1 && n_rows >= 1 && k_cols >= 1, "wgrad_scatter_rows: bad arguments");
+  CTTA_REQUIRE(bias_col < 0 || (grad_bias && bias_col < ldk && n_bias <= n_rows), "wgrad_scatter_rows: bad bias arguments");
   // float4 lanes when the column map is the identity and a row starts on a 16-byte boundary on both sides (the kernel
   // looks at its own row offset: every conv / linear weight whose row length is a multiple of 4 qualifies).  The scalar
   // form moved 4 bytes per lane and ran the 1024 x 9216 layers at a quarter of the HBM rate (89 us, round-3 profile).
@@ -347,7 +368,8 @@ extern "C" ctta_status ctta_wgrad_scatter_rows(const float* slabs, int n_slabs, 
   int gx = ((vec4 ? k_cols / 4 : k_cols) + 255) / 256;
   if (gx > 8) gx = 8;
   hipLaunchKernelGGL(wgrad_scatter_rows_kernel, dim3(gx, n_rows), dim3(256), 0, (hipStream_t)stream, slabs, n_slabs,
-                     (long long)slab_stride, ldk, k_cols, n_rows, row_off, col_off, grad, accumulate, vec4);
+                     (long long)slab_stride, ldk, k_cols, n_rows, row_off, col_off, grad, accumulate, vec4, bias_col, n_bias,
+                     bias_idx, grad_bias);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

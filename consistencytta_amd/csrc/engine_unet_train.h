@@ -205,17 +205,20 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
 static ctta_status scatter_wgrad(BCtx& c, const Slabs& sl, int k_rows, const PackMap& m, int row0 = 0) {
   const int64_t stride = (int64_t)sl.N * sl.ld;
   const float* base = sl.p + (size_t)row0 * sl.ld;
-  float* gw;
+  float *gw, *gb = nullptr;
   CTTA_TRY(grad_ptr(c, m.wkey, &gw));
+  if (!m.bkey.empty()) CTTA_TRY(grad_ptr(c, m.bkey, &gb));
+  // weight rows and (same launch) the bias column of the slabs
+  const bool bias_here = !m.bkey.empty() && m.n_bias <= m.n;
+  const int bcol = bias_here ? k_rows : -1;
   if (m.k_ident > 0)
-    RUN(c, ctta_wgrad_scatter_rows(base, sl.S, stride, sl.ld, m.k_ident, m.n, m.ro, nullptr, gw, 1, c.stream));
+    RUN(c, ctta_wgrad_scatter_rows_bias(base, sl.S, stride, sl.ld, m.k_ident, m.n, m.ro, nullptr, gw, bcol, m.n_bias, m.bidx, gb, 1,
+                                        c.stream));
   else
-    RUN(c, ctta_wgrad_scatter_rows(base, sl.S, stride, sl.ld, k_rows, m.n, m.ro, m.co, gw, 1, c.stream));
-  if (!m.bkey.empty()) {
-    float* gb;
-    CTTA_TRY(grad_ptr(c, m.bkey, &gb));
+    RUN(c, ctta_wgrad_scatter_rows_bias(base, sl.S, stride, sl.ld, k_rows, m.n, m.ro, m.co, gw, bcol, m.n_bias, m.bidx, gb, 1,
+                                        c.stream));
+  if (!m.bkey.empty() && !bias_here)
     RUN(c, ctta_col_scatter(base, sl.S, stride, sl.ld, k_rows, 1, m.n_bias, m.bidx, gb, 0, 1, c.stream));
-  }
   return CTTA_OK;
 }
 

@@ -655,6 +655,11 @@ ctta_status ctta_wgrad_scatter_rows(const float* slabs, int n_slabs, int64_t sla
                                     int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad,
                                     int accumulate, void* stream);
 /* dst[j*dst_stride + idx[n]] (+)= sum_s slabs[s][n][col + j], j < n_cols (bias / per-sample columns) */
+/* ctta_wgrad_scatter_rows that also folds column `bias_col` of the slabs into grad_bias[bias_idx[n]] for n < n_bias (the
+ * layer's bias gradient in the same launch; bias_col < 0: none) */
+ctta_status ctta_wgrad_scatter_rows_bias(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int k_cols, int n_rows,
+                                         const int32_t* row_off, const int32_t* col_off, float* grad, int bias_col, int n_bias,
+                                         const int32_t* bias_idx, float* grad_bias, int accumulate, void* stream);
 ctta_status ctta_col_scatter(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int col, int n_cols,
                              int n_rows, const int32_t* idx, float* dst, int64_t dst_stride, int accumulate,
                              void* stream);
