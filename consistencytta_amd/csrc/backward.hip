@@ -845,8 +845,8 @@ __device__ __forceinline__ float ln_row_sum(float v) {
 }
 template <int MAXV, bool HALF>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
-                                                     bf16_t* __restrict__ dx, long long rows, int d, int ld,
-                                                     const float* __restrict__ gamma, float eps, int acc_dx,
+                                                     bf16_t* dx, long long rows, int d, int ld,
+                                                     const float* __restrict__ gamma, float eps, const bf16_t* dx_add,
                                                      float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                      int rows_per_block, float* __restrict__ part) {
   extern __shared__ float sm[];   // [row groups][2][ld]: one (d gamma, d beta) copy per row group of the block
@@ -928,12 +928,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
       const int v = lane + i * LW;
       if (v < VC) {
         float o[8];
-        if (acc_dx) unpack8(*reinterpret_cast<const uint4*>(dx + (size_t)row * ld + v * 8), o);
+        if (dx_add) unpack8(*reinterpret_cast<const uint4*>(dx_add + (size_t)row * ld + v * 8), o);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int c = v * 8 + e;
           const float r = c < d ? rstd * (fd[i][e] - s1 - fx[i][e] * s2) : 0.f;
-          o[e] = acc_dx ? o[e] + r : r;
+          o[e] = dx_add ? o[e] + r : r;
         }
         *reinterpret_cast<uint4*>(dx + (size_t)row * ld + v * 8) = pack8(o);
       }
@@ -1036,6 +1036,12 @@ static float* ln_bwd_workspace(hipStream_t s, size_t bytes) {
 extern "C" ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t rows, int d, int ld,
                                           const float* gamma, float eps, int accumulate_dx, float* dgamma, float* dbeta,
                                           void* stream) {
+  return ctta_layernorm_bwd_add(x, dy, accumulate_dx ? dx : nullptr, dx, rows, d, ld, gamma, eps, dgamma, dbeta, stream);
+}
+// dx = dx_add + dL/dx  (dx_add NULL: plain; dx_add == dx: the in-place accumulate of ctta_layernorm_bwd).  A separate
+// output lets the backward keep the PREVIOUS running gradient untouched for a weight-gradient job that reads it later.
+extern "C" ctta_status ctta_layernorm_bwd_add(const void* x, const void* dy, const void* dx_add, void* dx, int64_t rows, int d,
+                                              int ld, const float* gamma, float eps, float* dgamma, float* dbeta, void* stream) {
   CTTA_REQUIRE(x && dy && dx && gamma && dgamma && dbeta, "layernorm_bwd: null pointer (dgamma/dbeta must be zeroed or hold the running sum)");
   CTTA_REQUIRE(ld % 8 == 0 && d <= ld && ld <= 2048, "layernorm_bwd: d=%d ld=%d", d, ld);
   // rows per block: 64 amortises the per-block dgamma / dbeta atomics on long matrices, but the distillation step's
@@ -1053,7 +1059,7 @@ extern "C" ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* d
   const size_t part_bytes = (size_t)grid.x * 2 * ld * sizeof(float);
   if (two_pass && grid.x >= 16 && part_bytes <= ((size_t)64 << 20)) part = ln_bwd_workspace(s, part_bytes);
 #define LNB(MV, HF) hipLaunchKernelGGL((ln_bwd_kernel<MV, HF>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, \
-                                       (bf16_t*)dx, (long long)rows, d, ld, gamma, eps, accumulate_dx, dgamma, dbeta, rpb, part)
+                                       (bf16_t*)dx, (long long)rows, d, ld, gamma, eps, (const bf16_t*)dx_add, dgamma, dbeta, rpb, part)
   if (ld <= 256) LNB(1, true); else if (ld <= 512) LNB(1, false); else if (ld <= 1024) LNB(2, false); else LNB(4, false);
 #undef LNB
   CTTA_LAUNCH_CHECK();

@@ -109,23 +109,22 @@ static bool wgrad_inplace_on() {   // CTTA_WGRAD_INPLACE=0: every linear back on
   if (v < 0) { const char* e = getenv("CTTA_WGRAD_INPLACE"); v = (e && e[0] == '0') ? 0 : 1; }
   return v != 0;
 }
-// Linear layers whose dY the main stream does not rewrite: both operands are read WHERE THEY LIE by ctta_wgrad_tn on the
-// side stream (no dY^T, no X^T copy).  dY stays valid until the block's wg_join because the backward's arena releases
-// nothing while the side stream is on (unet_backward_begin_impl).
-static bool wgrad_inplace_ok(const WgJob& job, int taps, bool ups, int stride, int pad, int nb, int C, int N, bool dy_volatile) {
-  return wgrad_inplace_on() && taps == 1 && !ups && stride == 1 && pad == 0 && nb == 0 && C % 8 == 0 && N % 8 == 0 &&
-         !(job.async && dy_volatile);
+// Linear layers: both operands are read WHERE THEY LIE by ctta_wgrad_tn on the side stream (no dY^T, no X^T copy).  dY stays
+// valid until the block's wg_join because the backward's arena releases nothing while the side stream is on
+// (unet_backward_begin_impl), and no dY is rewritten in place: the transformer's running token-stream gradient moves to a
+// new buffer at every LayerNorm backward (ctta_layernorm_bwd_add).
+static bool wgrad_inplace_ok(int taps, bool ups, int stride, int pad, int nb, int C, int N) {
+  return wgrad_inplace_on() && taps == 1 && !ups && stride == 1 && pad == 0 && nb == 0 && C % 8 == 0 && N % 8 == 0;
 }
 static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int B, int hi, int wi, bool ups, int ho, int wo,
-                               int kh, int kw, int stride, int pad, const bf16_t* dy, int N, int nb, Slabs* out,
-                               bool dy_volatile = false) {
+                               int kh, int kw, int stride, int pad, const bf16_t* dy, int N, int nb, Slabs* out) {
   BCtx& c = job.w;
   Arena& A = *c.arena;
   const int64_t M = (int64_t)B * ho * wo;
   const int K = kh * kw * C;
   const int R = K + 1 + nb;
   const int ld = round_up(R, 4);
-  if (wgrad_inplace_ok(job, kh * kw, ups, stride, pad, nb, C, N, dy_volatile) && M < (1LL << 31) - 4096) {
+  if (wgrad_inplace_ok(kh * kw, ups, stride, pad, nb, C, N) && M < (1LL << 31) - 4096) {
     const int64_t tiles = (int64_t)((N + 127) / 128) * ((C + 127) / 128);
     int S = 1;
     // 128 x 128 tiles at two workgroups per CU; the level-0 / level-1 linears have 4..16 tiles over 9 216..36 864 rows: up to 64
@@ -250,14 +249,12 @@ static ctta_status conv_wgrad(BCtx& c, const ConvLayer& L, const PackMap& m, con
 }
 
 // linear y = x W^T (+b): x [rows][x_ld] (the first k_rows columns are the GEMM K), dy [rows][N]
-// `dy_volatile`: the main stream rewrites dY in place after this call (the transformer's running token-stream gradient, which
-// every LayerNorm backward accumulates into): its transposed copy is then taken on the MAIN stream in program order, as before.
 static ctta_status linear_wgrad(BCtx& c, const PackMap& m, const PackMap* m2, const bf16_t* x, int x_ld, int64_t rows,
-                                const bf16_t* dy, int N, bool dy_volatile = false) {
+                                const bf16_t* dy, int N) {
   WgJob job;
   CTTA_TRY(wg_begin(c, &job));
   Slabs sl;
-  CTTA_TRY(wgrad_slabs(c, job, x, x_ld, 1, (int)rows, 1, false, (int)rows, 1, 1, 1, 1, 0, dy, N, 0, &sl, dy_volatile));
+  CTTA_TRY(wgrad_slabs(c, job, x, x_ld, 1, (int)rows, 1, false, (int)rows, 1, 1, 1, 1, 0, dy, N, 0, &sl));
   CTTA_TRY(scatter_wgrad(job.w, sl, x_ld, m, 0));
   if (m2) CTTA_TRY(scatter_wgrad(job.w, sl, x_ld, *m2, m.n));   // fused [q | k]
   if (!c.dry) CTTA_TRY(wg_end(c, job));
@@ -304,12 +301,14 @@ static ctta_status gn_backward(BCtx& c, const GNLayer& g, const bf16_t* x, const
                             dg, db, 1, c.gn_scratch, c.stream));
   return CTTA_OK;
 }
-static ctta_status ln_backward(BCtx& c, const LNLayer& l, const bf16_t* x, const bf16_t* dy, bf16_t* dx, int64_t rows,
-                               int d, int ld, bool accumulate_dx) {
+// dx = dx_add + dL/dx (dx_add NULL: plain).  The transformer's running token-stream gradient moves to a NEW buffer at every
+// LayerNorm: the previous one stays as it was for the weight-gradient jobs that read it in place on the side stream.
+static ctta_status ln_backward(BCtx& c, const LNLayer& l, const bf16_t* x, const bf16_t* dy, const bf16_t* dx_add, bf16_t* dx,
+                               int64_t rows, int d, int ld) {
   float *dg, *db;
   CTTA_TRY(grad_ptr(c, l.key + "weight", &dg));
   CTTA_TRY(grad_ptr(c, l.key + "bias", &db));
-  RUN(c, ctta_layernorm_bwd(x, dy, dx, rows, d, ld, l.gamma, 1e-5f, accumulate_dx ? 1 : 0, dg, db, c.stream));
+  RUN(c, ctta_layernorm_bwd_add(x, dy, dx_add, dx, rows, d, ld, l.gamma, 1e-5f, dg, db, c.stream));
   return CTTA_OK;
 }
 
@@ -388,19 +387,22 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
   const size_t mk = A.mark();
   // out = proj_out(s3) + x
   bf16_t* ds = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(ds);   // running gradient of the token stream
+  bf16_t* ds_next[3];                                              // ... after ln3, ln2, ln1 (never rewritten in place)
+  for (int i = 0; i < 3; ++i) { ds_next[i] = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(ds_next[i]); }
   CTTA_TRY(linear_dgrad(c, T.t_proj_out.d, dout, T.c, T.c, M, ds, cp, cp, false));
   CTTA_TRY(linear_wgrad(c, T.t_proj_out.m, nullptr, S.s3, cp, M, dout, T.proj_out.n));
   {  // s3 = ff2(geglu(ff1(ln3(s2)))) + s2
     const size_t m2 = A.mark();
     bf16_t* dgg = A.get<bf16_t>((size_t)M * ffp); ALLOC_OR_FAIL(dgg);
     CTTA_TRY(linear_dgrad(c, T.t_ff2.d, ds, cp, cp, M, dgg, ffp, ffp, false));
-    CTTA_TRY(linear_wgrad(c, T.t_ff2.m, nullptr, S.gg, ffp, M, ds, cp, true));      // ds: ln3's backward adds into it below
+    CTTA_TRY(linear_wgrad(c, T.t_ff2.m, nullptr, S.gg, ffp, M, ds, cp));
     bf16_t* df = A.get<bf16_t>((size_t)M * 2 * ffp); ALLOC_OR_FAIL(df);
     RUN(c, ctta_geglu_bwd(S.f, dgg, df, M, ffp, 1, c.stream));
     bf16_t* dn = A.get<bf16_t>((size_t)M * cp); ALLOC_OR_FAIL(dn);
     CTTA_TRY(linear_dgrad(c, T.t_ff1.d, df, 2 * ffp, 2 * ffp, M, dn, cp, cp, false));
     CTTA_TRY(linear_wgrad(c, T.t_ff1.m, nullptr, S.n3, cp, M, df, 2 * ffp));
-    CTTA_TRY(ln_backward(c, T.ln3, S.s2, dn, ds, M, T.inner, cp, true));
+    CTTA_TRY(ln_backward(c, T.ln3, S.s2, dn, ds, ds_next[0], M, T.inner, cp));
+    ds = ds_next[0];
     A.release(m2);
   }
   {  // s2 = out2(attn(q2(ln2(s1)), k2(enc), v2(enc))) + s1
@@ -408,7 +410,7 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
     const int Lp = c.Lp;
     bf16_t* datt = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(datt);
     CTTA_TRY(linear_dgrad(c, T.t_out2.d, ds, cp, cp, M, datt, hp, hp, false));
-    CTTA_TRY(linear_wgrad(c, T.t_out2.m, nullptr, S.att2, hp, M, ds, cp, true));     // ds: ln2's backward adds into it below
+    CTTA_TRY(linear_wgrad(c, T.t_out2.m, nullptr, S.att2, hp, M, ds, cp));
     bf16_t* dq = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(dq);
     const size_t kv = (size_t)c.B * Lp * hp;
     bf16_t* dk = A.get<bf16_t>(kv); ALLOC_OR_FAIL(dk);
@@ -424,14 +426,15 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
     CTTA_TRY(linear_wgrad(c, T.t_q2.m, nullptr, S.n2, cp, M, dq, hp));
     CTTA_TRY(linear_wgrad(c, T.t_k2.m, nullptr, c.enc_bf, c.U->xp, (int64_t)c.B * Lp, dk, hp));
     CTTA_TRY(linear_wgrad(c, T.t_v2.m, nullptr, c.enc_bf, c.U->xp, (int64_t)c.B * Lp, dv, hp));
-    CTTA_TRY(ln_backward(c, T.ln2, S.s1, dn, ds, M, T.inner, cp, true));
+    CTTA_TRY(ln_backward(c, T.ln2, S.s1, dn, ds, ds_next[1], M, T.inner, cp));
+    ds = ds_next[1];
     A.release(m2);
   }
   {  // s1 = out1(attn(q1(n1), k1(n1), v1(n1))) + s0,  n1 = ln1(s0)
     const size_t m2 = A.mark();
     bf16_t* datt = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(datt);
     CTTA_TRY(linear_dgrad(c, T.t_out1.d, ds, cp, cp, M, datt, hp, hp, false));
-    CTTA_TRY(linear_wgrad(c, T.t_out1.m, nullptr, S.att1, hp, M, ds, cp, true));     // ds: ln1's backward adds into it below
+    CTTA_TRY(linear_wgrad(c, T.t_out1.m, nullptr, S.att1, hp, M, ds, cp));
     bf16_t* dqk = A.get<bf16_t>((size_t)M * 2 * hp); ALLOC_OR_FAIL(dqk);
     bf16_t* dv = A.get<bf16_t>((size_t)M * hp); ALLOC_OR_FAIL(dv);
     CTTA_TRY(bwd_attention(c, T.heads, T.dh, S.qk, 2 * hp, S.qk + hp, 2 * hp, N, S.vt, vt_ld, nullptr, N, N, S.att1, datt, hp,
@@ -442,7 +445,8 @@ static ctta_status bwd_transformer(BCtx& c, Transformer& T, const bf16_t* dout, 
     CTTA_TRY(linear_dgrad(c, T.t_v1.d, dv, hp, hp, M, dn, cp, cp, true));
     CTTA_TRY(linear_wgrad(c, T.t_q1.m, &T.t_k1.m, S.n1, cp, M, dqk, 2 * hp));
     CTTA_TRY(linear_wgrad(c, T.t_v1.m, nullptr, S.n1, cp, M, dv, hp));
-    CTTA_TRY(ln_backward(c, T.ln1, S.s0, dn, ds, M, T.inner, cp, true));
+    CTTA_TRY(ln_backward(c, T.ln1, S.s0, dn, ds, ds_next[2], M, T.inner, cp));
+    ds = ds_next[2];
     A.release(m2);
   }
   // s0 = proj_in(gn(x))

@@ -685,6 +685,9 @@ ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* dx, int batc
 ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t rows, int d, int ld,
                                const float* gamma, float eps, int accumulate_dx, float* dgamma, float* dbeta,
                                void* stream);
+/* dx = dx_add + dL/dx with a separate output (dx_add may be NULL, or equal dx = the in-place accumulate above) */
+ctta_status ctta_layernorm_bwd_add(const void* x, const void* dy, const void* dx_add, void* dx, int64_t rows, int d, int ld,
+                                   const float* gamma, float eps, float* dgamma, float* dbeta, void* stream);
 ctta_status ctta_geglu_bwd(const void* f, const void* dout, void* df, int64_t rows, int hp, int interleaved,
                            void* stream);
 ctta_status ctta_add_slices(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows,
