@@ -29,7 +29,7 @@ def family(name):
         return "conv_gemm_kernel"
     for key in ("conv_gemm_kernel", "conv1d_halo_kernel", "attention_kernel", "attn_bwd", "gn_", "layernorm", "ln_bwd", "geglu",
                 "softmax_rows", "conv_small_n_kernel", "splitk_finish", "adamw_kernel", "ema2_kernel", "pack_weight",
-                "wgrad_scatter", "wgrad_implicit", "wgrad_rowsum", "im2col_t", "transpose"):
+                "wgrad_scatter", "wgrad_implicit", "wgrad_tn", "wgrad_rowsum", "im2col_t", "transpose"):
         if key in name:
             return key.rstrip("_")
     return "other"
