@@ -499,6 +499,10 @@ def teacher_leg(args, dev, world, rank):
     return out
 
 
+class _SlowLeg(RuntimeError):
+    """A replayed leg whose first step is many times slower than the eager step (decided with a MAX over ranks)."""
+
+
 GF_DISTILL_PER_SAMPLE = 4200.0   # SURVEY.md §3.3: 4 teacher + 1 target + 1 student fwd + 1 student bwd (~2 fwd)
 
 
@@ -615,6 +619,15 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             loss_g = float(gs.loss.item())
             opt.zero_grad()
             assert loss_g == loss_e, "hipGraph replay of the distillation step differs from the eager step (%r vs %r)" % (loss_g, loss_e)
+            # one step first, timed on every rank: a transport that cannot keep up between the replays (the gloo rehearsal with
+            # two ranks on one GPU took 50 s per segmented step) must not cost the run -- the ranks agree (MAX) and skip the leg
+            du.barrier(dev)
+            t1 = time.perf_counter()
+            losses.append(gs.step(z0, sched))
+            du.barrier(dev)
+            one = du.max_over_ranks(time.perf_counter() - t1, dev)
+            if one > 6.0 * dt_eager / n_steps:
+                raise _SlowLeg("first replayed step took %.0f ms against %.0f ms eager" % (one * 1e3, dt_eager / n_steps * 1e3))
             for _ in range(n_warm):
                 losses.append(gs.step(z0, sched))
             du.barrier(dev)
@@ -637,10 +650,12 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                           "bucket of the gradient all-reduce, which is issued between replays) + eager AdamW / zero_grad / EMA")
             if pipe_on:      # what the data-parallel step runs: segmented (bucket all-reduce between replays) AND pipelined
                 dt_seg_pipe = timed_graph(True, True)
-            if world > 1:
+            if world > 1 and dt_seg < dt:
                 dt, launch_mode = dt_seg, launch_seg
-                if pipe_on and dt_seg_pipe < dt_seg:
-                    dt, launch_mode = dt_seg_pipe, launch_seg + pipe_txt
+            if world > 1 and pipe_on and dt_seg_pipe < dt:
+                dt, launch_mode = dt_seg_pipe, launch_seg + pipe_txt
+        except _SlowLeg as exc:      # decided collectively (MAX over ranks): every rank is here
+            launch_mode = "eager launches (replayed step skipped: %s)" % exc
         except Exception as exc:
             if world > 1:
                 raise       # the other ranks are inside the same collectives: failing loudly beats a hang
