@@ -195,6 +195,48 @@ def test_weight_gradient_with_both_operands_in_place(M, Cin, Cout, splits, x_ld,
         N.check(L.ctta_wgrad_tn(N.ptr(dya), dy_ld, Cout - 1, N.ptr(xa), x_ld, Cin, M, mp, splits, Cin, N.ptr(slabs), Cout * ld, ld, st))
 
 
+def test_slab_scatter_with_the_bias_column_in_the_same_launch():
+    """ctta_wgrad_scatter_rows_bias (round 4): grad_w[row_off[n] + k] += sum_s slab[s][n][k] AND grad_b[bias_idx[n]] += sum_s
+    slab[s][n][bias_col] in one launch, against ctta_wgrad_scatter_rows + ctta_col_scatter (the two launches it replaces);
+    ctta_wgrad_rowsum: the row sums of dY^T (bias / per-sample columns) against torch."""
+    L = lib()
+    st = N.stream_ptr()
+    S, n_rows, K, ld = 5, 37, 64, 68
+    slabs = det("sc.slab", (S, n_rows, ld), 1).to(DEV).contiguous()
+    ro = torch.arange(n_rows, dtype=torch.int32) * K
+    ro[3] = -1                                            # a padded row: dropped
+    bidx = torch.arange(n_rows, dtype=torch.int32)
+    bidx[3] = -1
+    ro_d, bi_d = ro.to(DEV), bidx.to(DEV)
+    gw0, gb0 = det("sc.gw", (n_rows * K,), 2).to(DEV), det("sc.gb", (n_rows,), 3).to(DEV)
+    gw1, gb1 = gw0.clone(), gb0.clone()
+    N.check(L.ctta_wgrad_scatter_rows_bias(N.ptr(slabs), S, n_rows * ld, ld, K, n_rows, N.ptr(ro_d), None, N.ptr(gw1), K, n_rows,
+                                           N.ptr(bi_d), N.ptr(gb1), 1, st))
+    gw2, gb2 = gw0.clone(), gb0.clone()
+    N.check(L.ctta_wgrad_scatter_rows(N.ptr(slabs), S, n_rows * ld, ld, K, n_rows, N.ptr(ro_d), None, N.ptr(gw2), 1, st))
+    N.check(L.ctta_col_scatter(N.ptr(slabs), S, n_rows * ld, ld, K, 1, n_rows, N.ptr(bi_d), N.ptr(gb2), 0, 1, st))
+    sync()
+    assert torch.equal(gw1, gw2)
+    assert rel_err(gb1.cpu(), gb2.cpu()) < 1e-6 and float(gb1[3]) == float(gb0[3])
+    ref_w = gw0.cpu().view(n_rows, K) + slabs.cpu()[:, :, :K].sum(0)
+    ref_w[3] = gw0.cpu().view(n_rows, K)[3]
+    assert rel_err(gw1.cpu().view(n_rows, K), ref_w) < 1e-6
+    # row sums of dY^T with per-sample columns
+    Nn, B, hw, splits = 24, 3, 64, 2
+    M = B * hw
+    mp = rup(M, 64 * splits)
+    dyt = torch.zeros(Nn, mp, dtype=torch.bfloat16, device=DEV)
+    dyt[:, :M] = bf16_round(det("sc.dyt", (Nn, M), 4)).to(torch.bfloat16).to(DEV)
+    ld2 = rup(8 + 1 + B, 4)
+    out = torch.full((splits, Nn, ld2), float("nan"), device=DEV)
+    N.check(L.ctta_wgrad_rowsum(N.ptr(dyt), Nn, mp, M, splits, hw, B, N.ptr(out), Nn * ld2, ld2, 8, st))
+    sync()
+    got = out[:, :, 8:8 + 1 + B].sum(0).cpu()
+    d = dyt[:, :M].float().cpu()
+    assert rel_err(got[:, 0], d.sum(1)) < 1e-5
+    assert rel_err(got[:, 1:], d.view(Nn, B, hw).sum(2)) < 1e-5
+
+
 @pytest.mark.parametrize("B,C,H,W,G,silu,eps", [(2, 40, 16, 8, 8, True, 1e-5), (3, 256, 8, 8, 32, False, 1e-6),
                                                 (2, 120, 4, 2, 8, True, 1e-5),
                                                 # many chunks per sample: the chunk walk of gn_bwd_fold split over the block's
@@ -245,6 +287,19 @@ def test_layernorm_geglu_backward(rows, d, ld):
     sync()
     assert rel_err(dx.float().cpu()[:, :d], x.grad) < 2 * BF16_TOL
     assert rel_err(dg.cpu(), gamma.grad) < 2e-3 and rel_err(dbt.cpu(), beta.grad) < 2e-3
+    # round 4: dx_out = dx_add + dL/dx with a SEPARATE output (the transformer's token-stream gradient is never rewritten in
+    # place): equals the in-place accumulate bit for bit and leaves dx_add untouched
+    add = bf16_round(det("lb.add", (rows, ld), 7)).to(torch.bfloat16).to(DEV)
+    keep = add.clone()
+    out2, dg2, db2 = torch.empty_like(xd), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    N.check(lib().ctta_layernorm_bwd_add(N.ptr(xd), N.ptr(dyd), N.ptr(add), N.ptr(out2), rows, d, ld, N.ptr(gd), 1e-5, N.ptr(dg2),
+                                         N.ptr(db2), N.stream_ptr()))
+    inpl, dg3, db3 = add.clone(), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    N.check(lib().ctta_layernorm_bwd(N.ptr(xd), N.ptr(dyd), N.ptr(inpl), rows, d, ld, N.ptr(gd), 1e-5, 1, N.ptr(dg3),
+                                     N.ptr(db3), N.stream_ptr()))
+    sync()
+    assert torch.equal(add, keep) and torch.equal(out2, inpl)
+    assert rel_err(out2.float().cpu()[:, :d], add.float().cpu()[:, :d] + x.grad) < 2 * BF16_TOL
     # GEGLU
     hp = ld
     f = bf16_round(det("gg.f", (rows, 2 * hp), 5) * 2).requires_grad_(True)
