@@ -588,11 +588,13 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     du.barrier(dev)
     dt = du.max_over_ranks(time.perf_counter() - t0, dev)
     assert all(v == v for v in losses), "NaN distillation loss"
-    # The step as a single process runs it for fixed shapes: ONE hipGraph replay of the ~5 600 launches of noising, teacher
-    # queries, target network, student forward + backward and loss, then AdamW / zero_grad / EMA eager (AudioLCM.
-    # capture_train_graph; bit-identical to train_step: tests/test_train_gpu.py, and checked here against an eager forward
-    # with the same draws).  With a process group the block-wise all-reduce must interleave with the backward, so the
-    # data-parallel step stays eager; both rates are reported.
+    # The step as the product runs it for fixed shapes (AudioLCM.capture_train_graph; bit-identical to train_step:
+    # tests/test_train_gpu.py, and checked here against an eager forward with the same draws): hipGraph replays of noising,
+    # teacher queries, target network, student forward + backward and loss, then AdamW / zero_grad / EMA eager.  Four forms
+    # are timed: monolithic (one graph), segmented (one graph per all-reduce bucket -- the form a process group needs, the
+    # collectives are issued between the replays), and each of them with the frozen teacher's phase of the NEXT batch as its
+    # own graph on a second stream (pipelined).  Headline: one GPU -> the fastest monolithic form; world > 1 -> the fastest of
+    # eager / segmented / segmented + pipelined.
     dt_eager, launch_mode = dt, "eager launches (two streams + weight-gradient side stream)"
     dt_seg = dt_graph = dt_pipe = dt_seg_pipe = None
     placements = []

@@ -910,10 +910,11 @@ class _DistillStepGraph:
     tests/test_train_gpu.py and by bench.py before it times the replays).
 
     `segmented=True` is the form the DATA-PARALLEL step runs (tools/train_utils.py:152-183 under accelerate's DDP): the
-    sequence is captured as 1 + n hipGraphs -- forward, loss, d loss / d pred and the out head of the backward, then one
-    graph per remaining block of the block-wise backward (`ctta_unet_backward_next`: every call joins its weight-gradient
-    side stream before it returns, so each is a closed sub-sequence).  `step` replays them in order and hands every
-    finished block to `dist_util.GradientBuckets` between two replays, so the bucketed asynchronous all-reduce (RCCL on
+    sequence is captured as several hipGraphs -- forward, loss, d loss / d pred and the blocks of the first all-reduce
+    bucket, then one graph per further bucket of the block-wise backward (`ctta_unet_backward_next`: every call joins its
+    weight-gradient side stream before it returns, so any run of calls is a closed sub-sequence; blocks are merged by
+    `GradientBuckets`' own rule).  `step` replays them in order and hands every finished block to
+    `dist_util.GradientBuckets` between two replays, so the bucketed asynchronous all-reduce (RCCL on
     its own stream) overlaps the blocks still to come exactly as in the eager `train_step`; the graphs share one memory
     pool and the engine's arena, so the kernels and their arguments are those of the monolithic capture."""
 
