@@ -31,6 +31,7 @@ struct ConvParams {
   int m_off;
   // 1: the tile is transposed through LDS and leaves as whole 64..256-byte row segments (see the kernel's epilogue)
   int wide_store;
+  int wide_f32;         // fp32 output, bias-only epilogue: rows leave as whole TN*4-byte segments through the LDS transpose
   unsigned long long* stamps;   // diagnostic (ctta_conv_debug_stamps): per workgroup {hw id, t_begin, t_first_tile, t_main_done, t_epilogue_done}
   unsigned howo_inv, wo_inv;   // floor(2^32 / howo), floor(2^32 / wo) for fast_div
   int epi_fast;      // straight-line wide-store epilogue (bias / rowvec / residual / LeakyReLU / second output)

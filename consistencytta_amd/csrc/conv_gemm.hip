@@ -410,6 +410,12 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
                   (p.plain_out || (!geglu && p.obs % 4 == 0 && d->out_offset % 4 == 0 && d->out_limit % 4 == 0)) &&
                   (!d->res || d->res_ld % 4 == 0) && (!d->rowvec || d->rowvec_ld % 4 == 0))
                      ? 1 : 0;
+  {
+    static int wf = -1;   // CTTA_WIDE_F32=0: the narrow fp32 stores of rounds 1-3 (A/B switch)
+    if (wf < 0) { const char* e = getenv("CTTA_WIDE_F32"); wf = (e && e[0] == '0') ? 0 : 1; }
+    p.wide_f32 = (wf && d->out_f32 && !scalar_store && d->ldc % 4 == 0 && d->n % 4 == 0 && p.plain_out && !d->res && !d->accumulate &&
+                  !d->out2 && d->out_act == 0 && d->alpha == 1.0f && !d->rowvec && !d->bias_m && !geglu && !d->gn_part) ? 1 : 0;
+  }
   p.epi_barrier = epi_barrier_default() ? 1 : 0;
   p.epi_fast_geglu = (epi_fast_default() && !p.epi_barrier && geglu && p.wide_store && p.plain_out &&
                       M * (long long)d->ldc * 2 < 0x7FFFFF00LL) ? 1 : 0;
@@ -579,6 +585,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     q.bias = nullptr; q.bias_m = nullptr; q.rowvec = nullptr; q.res = nullptr; q.out_act = 0; q.alpha = 1.0f;
     q.accumulate = 0; q.out2 = nullptr; q.out = ws; q.ldc = ld; q.out_f32 = 1; q.obs = (long long)p.howo * ld;
     q.wide_store = 0;
+    { static int wf = -1; if (wf < 0) { const char* e = getenv("CTTA_WIDE_F32"); wf = (e && e[0] == '0') ? 0 : 1; } q.wide_f32 = wf; }
     q.ogs = (long long)M * ld;
     grid.z = (unsigned)splits;
     v.launch(q, grid, (hipStream_t)stream);

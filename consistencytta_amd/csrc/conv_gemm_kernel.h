@@ -597,6 +597,48 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   // every wave transposes its tile through the (dead) LDS ring in fp32, CHR rows at a time, and reads it back with
   // TN/4 consecutive lanes per output row: stores -- and the residual reads -- are whole TN*2-byte row segments, the
   // bias sits in registers because a lane keeps its 4 channels, and the arithmetic runs in one rolled loop.
+  if (p.wide_f32) {
+    // fp32 output (split-K partial slabs, the VAE attention's score matrix, weight-gradient slabs of the conv_gemm route):
+    // the same LDS transpose as the bf16 wide store, rows written as float4 per lane = TN * 4 contiguous bytes per row and
+    // wave.  In the MFMA layout a store instruction wrote 16 rows x 64 bytes: half cache lines, and the 2 GiB score slab of
+    // the VAE mid-block attention left at 1.9 TB/s (round 4).
+    constexpr int NW = WM * WN;
+    constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
+    constexpr int RSF = TN * 4 + 16;
+    constexpr int CHR = (FM % 2 == 0 && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;
+    static_assert((size_t)NW * CHR * RSF <= RING, "wide-store staging does not fit the ring");
+    constexpr int CJ = CHR / 16;
+    constexpr int LPR = TN / 4, RPW = 64 / LPR;
+    unsigned char* stg = smem_raw + (size_t)wave * CHR * RSF;
+    const int col4 = lane % LPR, prow = lane / LPR;
+    const int n_lane = n0 + wn * TN + col4 * 4;
+    const bool n_ok = n_lane < p.n;
+    float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && n_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + n_lane);
+    float* outf = reinterpret_cast<float*>(p.out) + (size_t)zs * p.ogs + n_lane;
+    __syncthreads();   // every wave is done with the ring
+#pragma unroll
+    for (int j0 = 0; j0 < FM; j0 += CJ) {
+#pragma unroll
+      for (int jj = 0; jj < CJ; ++jj)
+#pragma unroll
+        for (int i = 0; i < FN; ++i) {
+          const f32x4_t a = acc[i][j0 + jj];
+          *reinterpret_cast<float4*>(stg + (jj * 16 + frow) * RSF + (i * 16 + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+      WAVE_LDS_FENCE();
+#pragma unroll
+      for (int it = 0; it < CHR / RPW; ++it) {
+        const int r = prow + it * RPW;
+        const int m = m0 + wm * TM + j0 * 16 + r;
+        float4 q = *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16);
+        q.x += bias4.x; q.y += bias4.y; q.z += bias4.z; q.w += bias4.w;
+        if (m < p.M && n_ok) *reinterpret_cast<float4*>(outf + (size_t)m * p.ldc) = q;
+      }
+      if (j0 + CJ < FM) WAVE_LDS_FENCE();
+    }
+    return;
+  }
   if (p.wide_store) {
     constexpr int NW = WM * WN;
     constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
