@@ -194,6 +194,21 @@ extern "C" ctta_status ctta_im2col_t(const void* x, int c, int batch, int hi, in
 }
 
 // ------------------------------------------------------------------------------ gradient scatter
+// sum over the S split slabs of one float, in slab order, eight loads in flight: the plain loop compiles to
+// `global_load; s_waitcnt vmcnt(0); v_add` per slab -- S serial memory round trips per lane (S = 64 on the level-0 linears).
+__device__ __forceinline__ float sum_slabs(const float* __restrict__ p, int S, long long stride) {
+  float v = 0.f;
+  int s = 0;
+  for (; s + 8 <= S; s += 8) {
+    float w[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w[u] = p[(size_t)(s + u) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += w[u];
+  }
+  for (; s < S; ++s) v += p[(size_t)s * stride];
+  return v;
+}
 // slabs [S][R][ldn] fp32 (R >= k_rows (+ extra rows)); weight grad:
 //   grad_w[row_off[n] + col_off[k]] (+)= sum_s slab[s][k][n]     (k < k_rows, n < n_cols, offsets >= 0, aux ok)
 __global__ void wgrad_scatter_kernel(const float* __restrict__ slabs, int S, long long slab_stride, int ldn, int k_rows,
@@ -207,8 +222,7 @@ __global__ void wgrad_scatter_kernel(const float* __restrict__ slabs, int S, lon
     const int ro = row_off[n], co = col_off[k];
     if (ro < 0 || co < 0) continue;
     if (aux_limit > 0 && row_aux[n] + col_aux[k] >= aux_limit) continue;
-    float v = 0.f;
-    for (int s = 0; s < S; ++s) v += slabs[(size_t)s * slab_stride + (size_t)k * ldn + n];
+    const float v = sum_slabs(slabs + (size_t)k * ldn + n, S, slab_stride);
     float* g = grad + (size_t)ro + (size_t)co;
     *g = accumulate ? *g + v : v;
   }
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(256) void wgrad_scatter_tiled_kernel(const float* _
     float v = 0.f;
     if (k0 + kk < k_rows && n0 + nn < n_cols) {
       const float* p = slabs + (size_t)(k0 + kk) * ldn + n0 + nn;
-      for (int s = 0; s < S; ++s) v += p[(size_t)s * slab_stride];
+      v = sum_slabs(p, S, slab_stride);
     }
     tile[kk][nn] = v;
   }
@@ -276,7 +290,17 @@ __global__ __launch_bounds__(256) void wgrad_scatter_rows_kernel(const float* __
     const int k4 = k_cols >> 2;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < k4; k += gridDim.x * 256) {
       float4 v = reinterpret_cast<const float4*>(src)[k];
-      for (int s = 1; s < S; ++s) {
+      // eight slabs requested together, added in slab order (the same sum as one at a time: the compiler's own loop was
+      // `load; s_waitcnt vmcnt(0); add` -- 63 serial memory round trips per lane at the 64 splits of the level-0 linears)
+      int s = 1;
+      for (; s + 8 <= S; s += 8) {
+        float4 w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = reinterpret_cast<const float4*>(src + (size_t)(s + u) * slab_stride)[k];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { v.x += w[u].x; v.y += w[u].y; v.z += w[u].z; v.w += w[u].w; }
+      }
+      for (; s < S; ++s) {
         const float4 w = reinterpret_cast<const float4*>(src + (size_t)s * slab_stride)[k];
         v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
       }
@@ -289,8 +313,7 @@ __global__ __launch_bounds__(256) void wgrad_scatter_rows_kernel(const float* __
   for (int k = blockIdx.x * 256 + threadIdx.x; k < k_cols; k += gridDim.x * 256) {
     const int co = col_off ? col_off[k] : k;
     if (co < 0) continue;
-    float v = 0.f;
-    for (int s = 0; s < S; ++s) v += src[(size_t)s * slab_stride + k];
+    const float v = sum_slabs(src + k, S, slab_stride);
     dst[co] = accumulate ? dst[co] + v : v;
   }
 }
@@ -301,8 +324,7 @@ __global__ void row_scatter_kernel(const float* __restrict__ slabs, int S, long 
   if (n >= n_cols) return;
   const int j = idx ? idx[n] : n;
   if (j < 0) return;
-  float v = 0.f;
-  for (int s = 0; s < S; ++s) v += slabs[(size_t)s * slab_stride + (size_t)row * ldn + n];
+  const float v = sum_slabs(slabs + (size_t)row * ldn + n, S, slab_stride);
   dst[j] = accumulate ? dst[j] + v : v;
 }
 
@@ -334,8 +356,7 @@ __global__ void col_scatter_kernel(const float* __restrict__ slabs, int S, long 
   const int j = blockIdx.y;
   const int t = idx ? idx[n] : n;
   if (t < 0) return;
-  float v = 0.f;
-  for (int s = 0; s < S; ++s) v += slabs[(size_t)s * slab_stride + (size_t)n * ldk + col + j];
+  const float v = sum_slabs(slabs + (size_t)n * ldk + col + j, S, slab_stride);
   float* d = dst + (size_t)j * dst_stride + t;
   *d = accumulate ? *d + v : v;
 }

@@ -154,7 +154,17 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvParams p, 
     const int m = (int)(i / n4), n = (int)(i - (long long)m * n4) * 4;
     const float* src = slabs + (size_t)m * ld + n;
     float4 a = *reinterpret_cast<const float4*>(src);
-    for (int s2 = 1; s2 < S; ++s2) {
+    // the partial sums are requested four slabs at a time and added in slab order (the plain loop waits for every load
+    // before it asks for the next: S - 1 serial round trips per lane)
+    int s2 = 1;
+    for (; s2 + 4 <= S; s2 += 4) {
+      float4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = *reinterpret_cast<const float4*>(src + (size_t)(s2 + u) * slab_stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a.x += q[u].x; a.y += q[u].y; a.z += q[u].z; a.w += q[u].w; }
+    }
+    for (; s2 < S; ++s2) {
       const float4 q = *reinterpret_cast<const float4*>(src + (size_t)s2 * slab_stride);
       a.x += q.x; a.y += q.y; a.z += q.z; a.w += q.w;
     }

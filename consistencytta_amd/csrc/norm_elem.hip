@@ -276,19 +276,31 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const bf16_t* __restric
       float s[8], q[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-      for (int pix = p_begin + tp; pix < p_end; pix += PL) {
-        uint4 raw;
-        if (CAT) {
-          raw = v * 8 < C1 ? *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + pix) * C1 + v * 8)
-                           : *reinterpret_cast<const uint4*>(x2 + ((size_t)b * HW + pix) * (C - C1) + v * 8 - C1);
-          *reinterpret_cast<uint4*>(y + ((size_t)b * HW + pix) * C + v * 8) = raw;
-        } else {
-          raw = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + pix) * C + v * 8);
-        }
-        float f[8];
-        unpack8(raw, f);
+      // four pixels requested together, summed in pixel order (the rolled loop was one memory round trip per pixel and
+      // lane; a pixel past the chunk contributes + 0.0: the same sums)
+      for (int pix0 = p_begin + tp; pix0 < p_end; pix0 += 4 * PL) {
+        uint4 raw[4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+        for (int u = 0; u < 4; ++u) {
+          const int pix = pix0 + u * PL;
+          raw[u] = make_uint4(0, 0, 0, 0);
+          if (pix < p_end) {
+            if (CAT)
+              raw[u] = v * 8 < C1 ? *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + pix) * C1 + v * 8)
+                                  : *reinterpret_cast<const uint4*>(x2 + ((size_t)b * HW + pix) * (C - C1) + v * 8 - C1);
+            else
+              raw[u] = *reinterpret_cast<const uint4*>(x + ((size_t)b * HW + pix) * C + v * 8);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int pix = pix0 + u * PL;
+          if (CAT && pix < p_end) *reinterpret_cast<uint4*>(y + ((size_t)b * HW + pix) * C + v * 8) = raw[u];
+          float f[8];
+          unpack8(raw[u], f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { s[e] += f[e]; q[e] += f[e] * f[e]; }
+        }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
