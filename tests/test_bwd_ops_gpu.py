@@ -221,6 +221,18 @@ def test_slab_scatter_with_the_bias_column_in_the_same_launch():
     ref_w = gw0.cpu().view(n_rows, K) + slabs.cpu()[:, :, :K].sum(0)
     ref_w[3] = gw0.cpu().view(n_rows, K)[3]
     assert rel_err(gw1.cpu().view(n_rows, K), ref_w) < 1e-6
+    # many slabs: the eight-loads-in-flight loop and its ragged tail, narrow and wide layers, against the fp64 sum
+    for S2, rows2, K2 in ((64, 19, 256), (33, 7, 320), (16, 5, 512), (21, 3, 1280)):
+        ld2 = K2 + 4
+        sl2 = det("sc.slab2.%d" % K2, (S2, rows2, ld2), 1).to(DEV).contiguous()
+        ro2 = (torch.arange(rows2, dtype=torch.int32) * K2).to(DEV)
+        g0 = det("sc.g2.%d" % K2, (rows2 * K2,), 2).to(DEV)
+        g1 = g0.clone()
+        N.check(L.ctta_wgrad_scatter_rows_bias(N.ptr(sl2), S2, rows2 * ld2, ld2, K2, rows2, N.ptr(ro2), None, N.ptr(g1), -1, 0,
+                                               None, None, 1, st))
+        sync()
+        ref2 = g0.cpu().double().view(rows2, K2) + sl2.cpu().double()[:, :, :K2].sum(0)
+        assert rel_err(g1.cpu().view(rows2, K2), ref2.float()) < 1e-6, (S2, K2)
     # row sums of dY^T with per-sample columns
     Nn, B, hw, splits = 24, 3, 64, 2
     M = B * hw
