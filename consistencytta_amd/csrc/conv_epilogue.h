@@ -3,6 +3,11 @@
 #pragma once
 #include "common.h"
 
+// Which tile variants carry the fp32 wide-store epilogue (`ConvParams::wide_f32`); see the epilogue in conv_gemm_kernel.h.
+constexpr bool conv_wide_f32_ok(int bm, int bn, int bk, int wm, int wn, int mode, int stages) {
+  return !(mode != 0 && bk == 32 && stages == 2 && bm / wm == 64 && bn / wn == 64);
+}
+
 struct ConvParams {
   const bf16_t* x0; const bf16_t* x1; int c0, c1, ct;
   int M, hi, wi, hs, ws, ups, ho, wo, howo;

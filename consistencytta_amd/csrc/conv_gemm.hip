@@ -201,12 +201,13 @@ struct Variant {
   int bm, bn, bk;
   int wm, wn;
   int mode;
+  int stages;
   void (*launch)(const ConvParams&, dim3, hipStream_t);
   ctta_status (*prepare)();
 };
 
 #define VARIANT(BM, BN, BK, WM, WN, G, S) \
-  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN "_m" #G "_s" #S, BM, BN, BK, WM, WN, G, \
+  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN "_m" #G "_s" #S, BM, BN, BK, WM, WN, G, S, \
    launch_variant<BM, BN, BK, WM, WN, G, S>, prepare_variant<BM, BN, BK, WM, WN, G, S>}
 
 static const Variant kVariants[] = {
@@ -519,6 +520,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   CTTA_REQUIRE(kVariants[vid - 1].mode != 2 || fast_ok(kVariants[vid - 1].bk),
                "conv_gemm: variant %s needs (c0+c1) %% BK == 0, one source and <= 32 taps", kVariants[vid - 1].name);
   const Variant& v = kVariants[vid - 1];
+  if (!conv_wide_f32_ok(v.bm, v.bn, v.bk, v.wm, v.wn, v.mode, v.stages)) p.wide_f32 = 0;
   p.x_bytes = (unsigned)x_bytes; p.w_bytes = (unsigned)w_bytes;
   p.zero = zero_page();
   CTTA_REQUIRE(p.zero, "conv_gemm: could not allocate the zero page");
@@ -595,7 +597,8 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     q.bias = nullptr; q.bias_m = nullptr; q.rowvec = nullptr; q.res = nullptr; q.out_act = 0; q.alpha = 1.0f;
     q.accumulate = 0; q.out2 = nullptr; q.out = ws; q.ldc = ld; q.out_f32 = 1; q.obs = (long long)p.howo * ld;
     q.wide_store = 0;
-    { static int wf = -1; if (wf < 0) { const char* e = getenv("CTTA_WIDE_F32"); wf = (e && e[0] == '0') ? 0 : 1; } q.wide_f32 = wf; }
+    { static int wf = -1; if (wf < 0) { const char* e = getenv("CTTA_WIDE_F32"); wf = (e && e[0] == '0') ? 0 : 1; }
+      q.wide_f32 = (wf && conv_wide_f32_ok(v.bm, v.bn, v.bk, v.wm, v.wn, v.mode, v.stages)) ? 1 : 0; }
     q.ogs = (long long)M * ld;
     grid.z = (unsigned)splits;
     v.launch(q, grid, (hipStream_t)stream);

@@ -597,6 +597,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   // every wave transposes its tile through the (dead) LDS ring in fp32, CHR rows at a time, and reads it back with
   // TN/4 consecutive lanes per output row: stores -- and the residual reads -- are whole TN*2-byte row segments, the
   // bias sits in registers because a lane keeps its 4 channels, and the arithmetic runs in one rolled loop.
+  // (Not in the LDS-DMA tiles whose waves own 64 x 64 at BK = 32 with two stages -- 128x128x32 and the 8-wave 256x128x32: they
+  // sit at exactly 128 VGPRs, and with this block compiled in they need 129 = one workgroup less per SIMD quarter; the 8-wave
+  // tile then runs ONE workgroup per CU and its fused-GEGLU launches drop from 796 to 557 TFLOP/s.  conv_wide_f32_ok mirrors
+  // the condition for the host.)
+  if constexpr (conv_wide_f32_ok(BM, BN, BK, WM, WN, MODE, STAGES))
   if (p.wide_f32) {
     // fp32 output (split-K partial slabs, the VAE attention's score matrix, weight-gradient slabs of the conv_gemm route):
     // the same LDS transpose as the bf16 wide store, rows written as float4 per lane = TN * 4 contiguous bytes per row and

@@ -417,6 +417,25 @@ def test_device_code_has_no_swizzled_packed_fp32():
     assert not hits, hits[:5]
 
 
+def test_occupancy_critical_tiles_keep_their_register_budget():
+    """The LDS-DMA tiles whose waves own 64 x 64 at BK = 32 (128x128x32 in both staging modes, the 8-wave 256x128x32) are built
+    to sit at exactly 128 VGPRs: four waves per SIMD, i.e. two 8-wave (four 4-wave) workgroups per CU.  One register more
+    halves the 8-wave tile's occupancy (measured: its fused-GEGLU launches 796 -> 557 TFLOP/s).  No conv_gemm tile spills."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sp = importlib.util.spec_from_file_location("check_isa", os.path.join(root, "tools", "check_isa.py"))
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    regs = mod.kernel_registers(os.path.join(root, "consistencytta_amd", "libctta_hip.so"))
+    conv = {k: v for k, v in regs.items() if k.startswith("_Z16conv_gemm_kernelILi")}
+    assert len(conv) >= 36, sorted(conv)
+    tile = lambda *t: "_Z16conv_gemm_kernelI" + "".join("Li%dE" % x for x in t) + "Ev10ConvParams"
+    for t in ((128, 128, 32, 2, 2, 1, 2), (128, 128, 32, 2, 2, 2, 2), (256, 128, 32, 4, 2, 2, 2)):
+        assert conv[tile(*t)][0] <= 128, (t, conv[tile(*t)])
+    assert all(v[1] == 0 for v in conv.values()), {k: v for k, v in conv.items() if v[1]}
+
+
 def test_eval_metrics_match_the_reference_functions(golden):
     """consistencytta_amd.audioldm_eval.calculate_{fid,isc,kid,kl} (host arithmetic, as in the reference) against the values
     the reference's own audioldm_eval/metrics/*.py returned on the same seeded features (tests/golden/make_golden_eval.py):

@@ -41,6 +41,29 @@ def code_objects(path):
         pos = i + len(MAGIC)
 
 
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+
+
+def kernel_registers(path):
+    """{kernel symbol: (vgpr_count, vgpr_spill_count)} from the code objects' metadata notes.  A tile that sits exactly at an
+    occupancy step (128 VGPRs = four waves per SIMD: two 8-wave workgroups per CU) loses a workgroup per CU with ONE more
+    register -- round 4: an epilogue variant compiled into every tile took 256x128x32 from 128 to 129 and its fused-GEGLU
+    launches from 796 to 557 TFLOP/s, unnoticed for most of the round (tests/test_host_cpu.py pins the three tiles)."""
+    regs = {}
+    for triple, blob in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob)
+            f.flush()
+            out = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
+        for blk in out.split("- .agpr_count")[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+            sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
+            if name and vg:
+                regs[name.group(1)] = (int(vg.group(1)), int(sp.group(1)) if sp else 0)
+    return regs
+
+
 def scan(path):
     hits, n_insn, n_obj = [], 0, 0
     for triple, blob in code_objects(path):

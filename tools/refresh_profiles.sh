@@ -18,6 +18,12 @@ python3 $R/bench.py --mode gen --steps 3 --warmup 1 --no-cpu-baseline --profile-
 python3 $R/tools/launch_table.py $O/launch_gen.csv 60 2 > $O/launch_table_gen.txt 2>&1
 python3 $R/bench.py --mode distill --steps 3 --warmup 1 --no-cpu-baseline --profile-csv $O/launch_distill.csv > /dev/null 2>&1
 python3 $R/tools/launch_table.py $O/launch_distill.csv.distill 60 1 > $O/launch_table_distill.txt 2>&1
+# REFRESH_LIGHT=1: bench line, kernel stats and launch tables only (no counter passes, no gap accounting): ~5 minutes
+if [ "${REFRESH_LIGHT:-0}" = "1" ]; then
+  rm -rf $O/prof_gen $O/prof_distill $O/launch_gen.csv $O/launch_distill.csv $O/launch_distill.csv.distill
+  du -sh $O
+  exit 0
+fi
 timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_fetch.log 2>&1
 timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_write.log 2>&1
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/pmc_traffic.json 2> $O/pmc_traffic.err

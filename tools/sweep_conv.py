@@ -156,6 +156,16 @@ def main():
         w = ws[0]
         bias = torch.randn(Cout, device=DEV)
         out = torch.empty(B, H, W, Cout // 2 if geglu else Cout, dtype=torch.bfloat16, device=DEV)
+        # SWEEP_COLD=2: the ACTIVATIONS rotate too (input and output copies past the Infinity Cache together), as in the
+        # pipeline where a layer's input was written once by its producer and its output goes to arena memory
+        xs, outs = [x], [out]
+        if os.environ.get("SWEEP_COLD", "0") == "2":
+            per = x.numel() * 2 + out.numel() * 2
+            nact = max(2, min(16, (600 << 20) // per + 1))
+            ncopy = max(2, min(64, (600 << 20) // (Cout * k_pad * 2) + 1))
+            ws = ws + [ws[0].clone() for _ in range(ncopy - 1)]
+            xs = [x] + [x.clone() for _ in range(nact - 1)]
+            outs = [out] + [torch.empty_like(out) for _ in range(nact - 1)]
         M = B * H * W
         flops = 2.0 * M * Cout * K
         row = {"tag": tag, "M": M, "N": Cout, "K": K, "tflops": {}}
@@ -188,6 +198,7 @@ def main():
             e0.record()
             for r_ in range(reps):
                 d.w = ws[r_ % ncopy].data_ptr()
+                d.x0, d.out = xs[r_ % len(xs)].data_ptr(), outs[r_ % len(outs)].data_ptr()
                 N.check(L.ctta_conv_gemm(ctypes.byref(d), st))
             e1.record()
             torch.cuda.synchronize()
@@ -202,7 +213,7 @@ def main():
         else:
             print("%-24s M=%8d N=%5d K=%6d  best %-22s %s" % (tag, M, Cout, K, best,
                   " ".join("%6.0f" % t for t in row["tflops"].values())), flush=True)
-        del x, w, ws, out
+        del x, w, ws, out, xs, outs
     if len(sys.argv) > 1:
         json.dump({"variants": names, "shapes": results}, open(sys.argv[1], "w"), indent=1)
 
