@@ -417,23 +417,30 @@ def test_device_code_has_no_swizzled_packed_fp32():
     assert not hits, hits[:5]
 
 
-def test_occupancy_critical_tiles_keep_their_register_budget():
-    """The LDS-DMA tiles whose waves own 64 x 64 at BK = 32 (128x128x32 in both staging modes, the 8-wave 256x128x32) are built
-    to sit at exactly 128 VGPRs: four waves per SIMD, i.e. two 8-wave (four 4-wave) workgroups per CU.  One register more
-    halves the 8-wave tile's occupancy (measured: its fused-GEGLU launches 796 -> 557 TFLOP/s).  No conv_gemm tile spills."""
+def test_no_kernel_lost_occupancy_against_the_committed_table():
+    """tests/golden/kernel_occupancy.json holds, per kernel of the built library, [VGPRs, AGPRs, spilled VGPRs, waves per
+    SIMD] (`python tools/check_isa.py --regs consistencytta_amd/libctta_hip.so tests/golden/kernel_occupancy.json`).  A
+    kernel that fits FEWER waves per SIMD than the table says, or spills more, fails here: round 4 lost 1.3 % of the
+    generation step to ONE register (an epilogue block compiled into every conv tile took the 128x128x32 and the 8-wave
+    256x128x32 tiles from 128 to 129 VGPRs = one workgroup less per CU; fused GEGLU 796 -> 557 TFLOP/s).  Regenerate the
+    table when a change is meant to trade occupancy.  The three tiles built to sit at exactly 128 are named explicitly."""
     import importlib.util
+    import json
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sp = importlib.util.spec_from_file_location("check_isa", os.path.join(root, "tools", "check_isa.py"))
     mod = importlib.util.module_from_spec(sp)
     sp.loader.exec_module(mod)
-    regs = mod.kernel_registers(os.path.join(root, "consistencytta_amd", "libctta_hip.so"))
-    conv = {k: v for k, v in regs.items() if k.startswith("_Z16conv_gemm_kernelILi")}
-    assert len(conv) >= 36, sorted(conv)
+    now = mod.occupancy_table(os.path.join(root, "consistencytta_amd", "libctta_hip.so"))
+    want = json.load(open(os.path.join(root, "tests", "golden", "kernel_occupancy.json")))
+    assert len(now) >= 190 and mod.waves_per_simd(128) == 4 and mod.waves_per_simd(129) == 3 and mod.waves_per_simd(100, 32) == 3
+    lost = {k: (want[k], now[k]) for k in want if k in now and (now[k][3] < want[k][3] or now[k][2] > want[k][2])}
+    assert not lost, "kernels that lost waves per SIMD or spill more than the committed table: %r" % lost
     tile = lambda *t: "_Z16conv_gemm_kernelI" + "".join("Li%dE" % x for x in t) + "Ev10ConvParams"
     for t in ((128, 128, 32, 2, 2, 1, 2), (128, 128, 32, 2, 2, 2, 2), (256, 128, 32, 4, 2, 2, 2)):
-        assert conv[tile(*t)][0] <= 128, (t, conv[tile(*t)])
-    assert all(v[1] == 0 for v in conv.values()), {k: v for k, v in conv.items() if v[1]}
+        assert now[tile(*t)][0] <= 128 and now[tile(*t)][3] == 4, (t, now[tile(*t)])
+    conv = {k: v for k, v in now.items() if k.startswith("_Z16conv_gemm_kernelILi")}
+    assert len(conv) >= 36 and all(v[2] == 0 for v in conv.values()), {k: v for k, v in conv.items() if v[2]}
 
 
 def test_eval_metrics_match_the_reference_functions(golden):

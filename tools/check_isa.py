@@ -10,7 +10,8 @@ round-2 build, all in the small fp32 MLP kernel); it is the reason two engine ha
 different results.  build.sh therefore compiles with -fno-slp-vectorize, and this scan (also run by tests/) keeps the
 form from coming back through hand-written vector code.
 
-    python tools/check_isa.py [path/to/libctta_hip.so]      exit status 1 if a forbidden form is present"""
+    python tools/check_isa.py [path/to/libctta_hip.so]      exit status 1 if a forbidden form is present
+    python tools/check_isa.py --regs lib.so [out.json]      registers and waves per SIMD of every kernel (occupancy table)"""
 import os
 import re
 import struct
@@ -45,23 +46,37 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
 def kernel_registers(path):
-    """{kernel symbol: (vgpr_count, vgpr_spill_count)} from the code objects' metadata notes.  A tile that sits exactly at an
-    occupancy step (128 VGPRs = four waves per SIMD: two 8-wave workgroups per CU) loses a workgroup per CU with ONE more
-    register -- round 4: an epilogue variant compiled into every tile took 256x128x32 from 128 to 129 and its fused-GEGLU
-    launches from 796 to 557 TFLOP/s, unnoticed for most of the round (tests/test_host_cpu.py pins the three tiles)."""
+    """{kernel symbol: (vgpr_count, vgpr_spill_count, agpr_count)} from the code objects' metadata notes.  A tile that sits
+    exactly at an occupancy step (128 VGPRs = four waves per SIMD: two 8-wave workgroups per CU) loses a workgroup per CU with
+    ONE more register -- round 4: an epilogue variant compiled into every tile took 256x128x32 from 128 to 129 and its
+    fused-GEGLU launches from 796 to 557 TFLOP/s, unnoticed for most of the round (tests/test_host_cpu.py pins the table)."""
     regs = {}
     for triple, blob in code_objects(path):
         with tempfile.NamedTemporaryFile(suffix=".co") as f:
             f.write(blob)
             f.flush()
             out = subprocess.run([READELF, "--notes", f.name], capture_output=True, text=True, check=True).stdout
-        for blk in out.split("- .agpr_count")[1:]:
+        for m in re.finditer(r"\.agpr_count:\s+(\d+)(.*?)(?=\.agpr_count:|\Z)", out, re.S):
+            blk = m.group(2)
             name = re.search(r"\.name:\s+(\S+)", blk)
             vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
             sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk)
             if name and vg:
-                regs[name.group(1)] = (int(vg.group(1)), int(sp.group(1)) if sp else 0)
+                regs[name.group(1)] = (int(vg.group(1)), int(sp.group(1)) if sp else 0, int(m.group(1)))
     return regs
+
+
+def waves_per_simd(vgpr, agpr=0):
+    """gfx950: one 512-entry register file per SIMD lane shared by architectural and accumulation registers, allocated in
+    blocks of 8; at most 8 waves per SIMD."""
+    total = (vgpr + 3) // 4 * 4 + agpr if agpr else vgpr
+    return max(1, min(8, 512 // max(8, (total + 7) // 8 * 8)))
+
+
+def occupancy_table(path):
+    """{kernel: [vgpr, agpr, spilled, waves per SIMD]} -- `python tools/check_isa.py --regs lib.so out.json` writes it;
+    tests/golden/kernel_occupancy.json is the committed table the CPU suite compares the built library with."""
+    return {k: [v[0], v[2], v[1], waves_per_simd(v[0], v[2])] for k, v in sorted(kernel_registers(path).items())}
 
 
 def scan(path):
@@ -86,6 +101,14 @@ def scan(path):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "--regs":      # --regs lib.so [out.json]: the occupancy table
+        import json
+        table = occupancy_table(sys.argv[2])
+        if len(sys.argv) > 3:
+            json.dump(table, open(sys.argv[3], "w"), indent=0, sort_keys=True)
+        for k, v in table.items():
+            print("%-100s vgpr %3d agpr %3d spilled %2d waves/SIMD %d" % (k[:100], v[0], v[1], v[2], v[3]))
+        sys.exit(0)
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                                                              "consistencytta_amd", "libctta_hip.so")
     hits, n_insn, n_obj = scan(lib)
