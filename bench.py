@@ -63,6 +63,46 @@ def parse():
     return ap.parse_args()
 
 
+def launcher_command(argv, n, port, script=None):
+    """The command line of the child `torch.distributed.run` that `python bench.py --gpus N` (N > 1, no WORLD_SIZE in the
+    environment) starts: one rank per GPU on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve),
+    the script's own arguments passed through unchanged."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(n)),
+            "--master-addr", "127.0.0.1", "--master-port", str(int(port)), script or os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` by itself: the parent -- which has NOT imported torch, let alone touched the GPU -- starts
+    the N ranks as a CHILD process (never exec: a process that initialised HIP must not be replaced, and this one must stay
+    to relay), relays the child's stdout so that the one JSON line is the last line the parent prints, and returns its exit
+    code.  Under an external torchrun (WORLD_SIZE set) this function is never reached."""
+    import socket
+    import subprocess
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    cmd = launcher_command(argv, args.gpus, port)
+    if os.environ.get("CTTA_BENCH_LAUNCH_DRYRUN") == "1":
+        print(json.dumps({"launcher_command": cmd}), flush=True)
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=env)
+    line_json = None
+    for line in child.stdout:
+        if line.startswith('{"metric"'):
+            line_json = line        # held back: printed last, whatever a rank's C stdio still flushes at exit
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = child.wait()
+    if line_json is not None:
+        sys.stdout.write(line_json)
+        sys.stdout.flush()
+    return rc
+
+
 def flush_c_stdio():
     """RCCL prints its banner (ROCm version / hostname / library path) with C stdio; on a pipe that buffer is only
     flushed at exit, i.e. AFTER the JSON line.  Flushing it here keeps the JSON line the last line on stdout."""
@@ -85,6 +125,8 @@ def emit(result, rank, dev):
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, sys.argv[1:]))     # before `import torch`: the parent never initialises HIP
     if args.mode in ("distill", "perceptual"):
         args.no_cpu_baseline = True
     import torch
@@ -96,7 +138,8 @@ def main():
 
     world, rank, local_rank = du.env_world()
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node %d (or unset WORLD_SIZE and let "
+                         "bench.py start the ranks itself)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     # CTTA_BENCH_BACKEND=gloo rehearses the multi-rank flow (same collective sequence on every rank) on a box with
@@ -107,6 +150,9 @@ def main():
     dev = torch.device("cuda", dev_index)
     du.init(backend, dev)   # "nccl" is RCCL on ROCm: timing barrier / max-reduce, gradient all-reduce of the distill leg
     du.barrier(dev)         # first collective: the communicator (and its banner) exists from here on
+    rccl_ranks = du.count_ranks(dev)      # an all-reduce(SUM) of ones: how many ranks the communicator really joined
+    assert rccl_ranks == world, "the process group sums %d ranks, WORLD_SIZE says %d" % (rccl_ranks, world)
+    args.rccl_ranks, args.backend = rccl_ranks, backend
     flush_c_stdio()
     if args.mode == "teacher":
         d = teacher_leg(args, dev, world, rank)
@@ -157,16 +203,21 @@ def main():
     timed, launch_mode, genB = step, "eager launches", None
     # --no-latency (the PMC passes of tools/refresh_profiles.sh) times eager launches only: graph replays under
     # `rocprofv3 --pmc` hung on this pool in round 1, and counters should not mix replayed and eager steps
+    # Rule for every leg below: a capture / parity check is LOCAL (no collective inside), then the ranks agree
+    # (du.all_agree: one MAX all-reduce of an error flag) and all of them -- or none -- enter the timing collectives.
+    note = None
     if os.environ.get("CTTA_BENCH_GRAPH", "1") != "0" and not args.no_latency:
         try:
             genB = pipe.capture_graph(B, L, cfg_scale_input=4.0)
             pg = genB(enc, mask, noise)
             torch.cuda.synchronize()
             assert torch.equal(pg, step()[3]), "hipGraph replay differs from the eager step"
-            timed, launch_mode = (lambda: genB(enc, mask, noise)), "one hipGraph replay per step"
         except Exception as exc:   # a failed capture must not cost the headline line
-            launch_mode = "eager launches (graph capture failed: %s)" % str(exc)[:120]
-            timed, genB = step, None
+            note, genB = "graph capture failed on rank %d: %s" % (rank, str(exc)[:120]), None
+        if du.all_agree(genB is not None, dev):
+            timed, launch_mode = (lambda: genB(enc, mask, noise)), "one hipGraph replay per step"
+        else:
+            launch_mode, genB = "eager launches (%s)" % (note or "graph capture failed on another rank"), None
 
     def time_loop(fn):
         for _ in range(args.warmup):
@@ -179,27 +230,31 @@ def main():
         return du.max_over_ranks(time.perf_counter() - t0_, dev)
 
     dt = dt_graph1 = time_loop(timed)
-    dt_eager = time_loop(step)      # always, on every rank: the collective sequence must not depend on a rank's capture
+    dt_eager = time_loop(step)      # always, on every rank
     # The throughput form of the same step: a 3-deep software pipeline over batches (U-Net of batch i, VAE decoder of batch
     # i - 1, HiFi-GAN of batch i - 2 as three hipGraphs on three streams per step; ConsistencyTTA.capture_pipeline).  Every
     # timed step runs every stage once on a full batch; a batch's waveforms leave two steps after its text states entered.
     placement_gen = None
-    if genB is not None and os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0":
+    if genB is not None and os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0":      # same decision on every rank (agreed above)
+        genP, note = None, None
         try:
             genP = pipe.capture_pipeline(B, L, cfg_scale_input=4.0)
             for _ in range(3):
                 pp = genP(enc, mask, noise)
             torch.cuda.synchronize()
             assert torch.equal(pp, step()[3]), "the pipelined replay differs from the eager step"
+        except Exception as exc:
+            note, genP = "pipelined capture failed on rank %d: %s" % (rank, str(exc)[:100]), None
+        if du.all_agree(genP is not None, dev):
             dt_pipe = time_loop(lambda: genP(enc, mask, noise))
             placement_gen = genP.placement_ms
             if dt_pipe < dt:
                 dt = dt_pipe
                 launch_mode = ("three hipGraph replays per step on three streams: U-Net(batch i) | VAE decoder(batch i-1) | "
                                "HiFi-GAN + int16(batch i-2), handed over by device copies at the step boundary")
-            del genP
-        except Exception as exc:
-            launch_mode += " (pipelined capture failed: %s)" % str(exc)[:100]
+        else:
+            launch_mode += " (%s)" % (note or "pipelined capture failed on another rank")
+        del genP
     del timed, genB
     out = step()
     lat, mel, wav, pcm = out
@@ -208,7 +263,8 @@ def main():
 
     result = {
         "metric": "10s_audio_clips_per_sec_1step_gen", "value": round(clips_per_s, 3), "unit": "clips/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "n_gpus": world, "rccl_ranks": args.rccl_ranks, "collective_backend": "rccl (torch.distributed 'nccl')" if args.backend == "nccl" else args.backend,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
         "config": {"workload": "configs[1]: batch-32 single-step consistency inference, U-Net(light, 559M) + "
@@ -499,8 +555,9 @@ def teacher_leg(args, dev, world, rank):
     return out
 
 
-class _SlowLeg(RuntimeError):
-    """A replayed leg whose first step is many times slower than the eager step (decided with a MAX over ranks)."""
+class _LegSkipped(RuntimeError):
+    """A replayed leg that every rank skips TOGETHER: its capture / parity check failed somewhere (du.all_agree) or its first
+    step was many times slower than the eager step (MAX over ranks).  Never raised one-sidedly."""
 
 
 GF_DISTILL_PER_SAMPLE = 4200.0   # SURVEY.md §3.3: 4 teacher + 1 target + 1 student fwd + 1 student bwd (~2 fwd)
@@ -579,6 +636,19 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     n_steps, n_warm = (max(args.steps, 10), max(args.warmup, 3)) if args.mode not in ("distill", "perceptual") else (args.steps, max(1, args.warmup))
     # (--mode distill / perceptual, the profiling aids, keep exactly K / W: tools/refresh_profiles.sh counts their steps)
     losses = []
+
+    def fixed_draw_loss():
+        """The consistency loss of ONE fixed draw (timesteps, noise, guidance scales) with the weights as they are now: the
+        per-step losses use fresh random timesteps, so first-vs-last of those is noise; this pair is comparable."""
+        if perceptual:
+            return None
+        gfx = torch.Generator().manual_seed(4242 + rank)
+        ti = torch.randint(0, 17, (B,), generator=gfx) * 2
+        gn = torch.randn(B, 8, 256, 16, generator=gfx).to(dev)
+        gsc = torch.rand(B, generator=gfx) * 6
+        with torch.no_grad():
+            return round(float(m._forward_impl(z0, None, P, False, True, ti, gn, gsc, False)), 6)
+    loss_fixed_before = fixed_draw_loss()
     for _ in range(n_warm):
         losses.append(m.train_step(z0, P, opt, sched, **step_kw))
     du.barrier(dev)
@@ -598,70 +668,83 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     dt_eager, launch_mode = dt, "eager launches (two streams + weight-gradient side stream)"
     dt_seg = dt_graph = dt_pipe = dt_seg_pipe = None
     placements = []
+    timed_graph = None
     if not perceptual and os.environ.get("CTTA_BENCH_GRAPH", "1") != "0" and not args.no_latency:
         gdr = torch.Generator().manual_seed(77 + rank)
         kw = dict(time_inds=torch.randint(0, 17, (B,), generator=gdr) * 2,
                   gaussian_noise=torch.randn(B, 8, 256, 16, generator=gdr).to(dev), guidance_scale=torch.rand(B, generator=gdr) * 6)
 
-        def timed_graph(segmented, pipelined=False):
-            """Capture, check one replay against an eager forward with the same draws, time n_steps public steps.  Every
-            rank runs the same sequence (the segmented step issues the bucket all-reduces between its replays)."""
-            gs = m.capture_train_graph(opt, z0, P, segmented=segmented, pipeline_teacher=pipelined, **kw)
+        def timed_graph(segmented, pipelined=False, z=None, prompt=None, draws=None, steps=None, warm=None):
+            """Phase 1 (LOCAL, no collective inside): capture, check one replay against an eager forward with the same draws.
+            Then the ranks agree (du.all_agree) -- all of them time the leg or none does; a one-sided capture failure or
+            parity assert therefore never leaves the peers alone inside a barrier or a bucket all-reduce.  Phase 2: one
+            public step timed on every rank (MAX) -- a transport that cannot keep up between the replays (the gloo
+            rehearsal with two ranks on one GPU took 50 s per segmented step) skips the leg collectively -- then warm-up
+            and the timed steps.  Returns seconds for `steps` steps, or raises _LegSkipped on EVERY rank."""
+            z = z0 if z is None else z
+            prompt = P if prompt is None else prompt
+            draws = kw if draws is None else draws
+            steps = n_steps if steps is None else steps
+            warm = n_warm if warm is None else warm
+            gs, why = None, None
+            try:
+                gs = m.capture_train_graph(opt, z, prompt, segmented=segmented, pipeline_teacher=pipelined, **draws)
+                with torch.no_grad():
+                    loss_e = float(m._forward_impl(z, None, prompt, False, True, draws["time_inds"], draws["gaussian_noise"],
+                                                   draws["guidance_scale"], True)[0])
+                if pipelined:
+                    gs.feed(z, **draws)       # the teacher phase of this batch on the teacher stream ...
+                    gs.feed(z, **draws)       # ... becomes the current set; the same batch queued again behind it
+                else:
+                    gs._refresh(z, draws["time_inds"], draws["gaussian_noise"], draws["guidance_scale"])
+                gs.replay()
+                loss_g = float(gs.loss.item())
+                opt.zero_grad()
+                assert loss_g == loss_e, "hipGraph replay of the distillation step differs from the eager step (%r vs %r)" % (loss_g, loss_e)
+            except Exception as exc:
+                why, gs = "rank %d: %s" % (rank, str(exc)[:160]), None
+                opt.zero_grad()
+            if not du.all_agree(gs is not None, dev):
+                raise _LegSkipped("capture / parity check failed (%s)" % (why or "on another rank"))
             if pipelined:
                 placements.append(getattr(gs, "placement_ms", None))
-            with torch.no_grad():
-                loss_e = float(m._forward_impl(z0, None, P, False, True, kw["time_inds"], kw["gaussian_noise"],
-                                               kw["guidance_scale"], True)[0])
-            if pipelined:
-                gs.feed(z0, **kw)       # the teacher phase of this batch on the teacher stream ...
-                gs.feed(z0, **kw)       # ... becomes the current set; the same batch queued again behind it
-            else:
-                gs._refresh(z0, kw["time_inds"], kw["gaussian_noise"], kw["guidance_scale"])
-            gs.replay()
-            loss_g = float(gs.loss.item())
-            opt.zero_grad()
-            assert loss_g == loss_e, "hipGraph replay of the distillation step differs from the eager step (%r vs %r)" % (loss_g, loss_e)
-            # one step first, timed on every rank: a transport that cannot keep up between the replays (the gloo rehearsal with
-            # two ranks on one GPU took 50 s per segmented step) must not cost the run -- the ranks agree (MAX) and skip the leg
             du.barrier(dev)
             t1 = time.perf_counter()
-            losses.append(gs.step(z0, sched))
+            losses.append(gs.step(z, sched))
             du.barrier(dev)
             one = du.max_over_ranks(time.perf_counter() - t1, dev)
-            if one > 6.0 * dt_eager / n_steps:
-                raise _SlowLeg("first replayed step took %.0f ms against %.0f ms eager" % (one * 1e3, dt_eager / n_steps * 1e3))
-            for _ in range(n_warm):
-                losses.append(gs.step(z0, sched))
+            if one > 6.0 * dt_eager / n_steps * max(1.0, z.shape[0] / float(B)):
+                raise _LegSkipped("first replayed step took %.0f ms against %.0f ms eager" % (one * 1e3, dt_eager / n_steps * 1e3))
+            for _ in range(warm):
+                losses.append(gs.step(z, sched))
             du.barrier(dev)
             t0 = time.perf_counter()
-            for _ in range(n_steps):
-                losses.append(gs.step(z0, sched))
+            for _ in range(steps):
+                losses.append(gs.step(z, sched))
             du.barrier(dev)
             return du.max_over_ranks(time.perf_counter() - t0, dev)
-        # a capture can fail on one rank only; the ranks then agree (MAX over an error flag) before anyone enters the
-        # collectives of the segmented step alone
-        def all_ok(ok):
-            return du.max_over_ranks(0.0 if ok else 1.0, dev) == 0.0
         pipe_on = os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0"
         pipe_txt = ("; the frozen teacher's two CFG queries + Heun step run as their own hipGraph on a second stream for batch "
                     "i + 1 beside the student / target / backward work of batch i (every timed step holds one teacher phase, "
                     "one target forward, one student forward + backward, AdamW, EMA)")
+        # _LegSkipped is raised on every rank or on none (decided by a collective), so the except branches below are
+        # entered together; any OTHER exception inside phase 2 is one-sided and must end the rank (torchrun then stops
+        # the job): failing loudly beats a hang.
+        launch_seg = ("8 hipGraph replays per micro-step (forward + loss + the first bucket's blocks | one graph per further "
+                      "bucket of the gradient all-reduce, which is issued between replays) + eager AdamW / zero_grad / EMA")
         try:
             dt_seg = timed_graph(True)
-            launch_seg = ("8 hipGraph replays per micro-step (forward + loss + the first bucket's blocks | one graph per further "
-                          "bucket of the gradient all-reduce, which is issued between replays) + eager AdamW / zero_grad / EMA")
-            if pipe_on:      # what the data-parallel step runs: segmented (bucket all-reduce between replays) AND pipelined
-                dt_seg_pipe = timed_graph(True, True)
             if world > 1 and dt_seg < dt:
                 dt, launch_mode = dt_seg, launch_seg
-            if world > 1 and pipe_on and dt_seg_pipe < dt:
-                dt, launch_mode = dt_seg_pipe, launch_seg + pipe_txt
-        except _SlowLeg as exc:      # decided collectively (MAX over ranks): every rank is here
-            launch_mode = "eager launches (replayed step skipped: %s)" % exc
-        except Exception as exc:
-            if world > 1:
-                raise       # the other ranks are inside the same collectives: failing loudly beats a hang
-            launch_mode = "eager launches (segmented graph capture failed: %s)" % str(exc)[:160]
+        except _LegSkipped as exc:
+            launch_mode = "eager launches (segmented replay skipped: %s)" % exc
+        if pipe_on and dt_seg is not None:   # what the data-parallel step runs: segmented (bucket all-reduce between replays) AND pipelined
+            try:
+                dt_seg_pipe = timed_graph(True, True)
+                if world > 1 and dt_seg_pipe < dt:
+                    dt, launch_mode = dt_seg_pipe, launch_seg + pipe_txt
+            except _LegSkipped as exc:
+                launch_mode += " (segmented + pipelined replay skipped: %s)" % exc
         if world == 1:
             try:
                 dt = dt_graph = timed_graph(False)
@@ -671,20 +754,24 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                         dt_pipe = timed_graph(False, True)
                         if dt_pipe < dt:
                             dt, launch_mode = dt_pipe, launch_mode + pipe_txt
-                    except Exception as exc:
-                        launch_mode += " (pipelined capture failed: %s)" % str(exc)[:120]
-            except Exception as exc:   # a failed capture must not cost the line
-                launch_mode = "eager launches (graph capture failed: %s)" % str(exc)[:160]
+                    except _LegSkipped as exc:
+                        launch_mode += " (pipelined capture skipped: %s)" % exc
+            except _LegSkipped as exc:   # a failed capture must not cost the line
+                launch_mode = "eager launches (graph capture skipped: %s)" % exc
                 dt = dt_eager
     if perceptual and os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0" and not args.no_latency:
         # configs[4] cannot be captured whole (torch autograd differentiates the CLAP loss down to the latent), but its teacher
         # phase can: one hipGraph on its own stream for batch i + 1 beside the eager rest of batch i -- ~1 100 of the step's
         # launches leave the host's queue as well (`main_eager`; same arithmetic, tests/test_train_gpu.py)
-        try:
+        gs, why = None, None
+        try:      # phase 1, local: the teacher-phase capture
             gdr = torch.Generator().manual_seed(78 + rank)
             kw = dict(time_inds=torch.randint(0, 17, (B,), generator=gdr) * 2,
                       gaussian_noise=torch.randn(B, 8, 256, 16, generator=gdr).to(dev), guidance_scale=torch.rand(B, generator=gdr) * 6)
             gs = m.capture_train_graph(opt, z0, P, pipeline_teacher=True, gt_wav=step_kw["gt_wav"], **kw)
+        except Exception as exc:
+            why, gs = "rank %d: %s" % (rank, str(exc)[:120]), None
+        if du.all_agree(gs is not None, dev):      # phase 2 on every rank, or on none
             placements.append(getattr(gs, "placement_ms", None))
             for _ in range(n_warm):
                 losses.append(gs.step(z0, sched, gt_wav=step_kw["gt_wav"]))
@@ -699,11 +786,9 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                 launch_mode = ("eager launches (two streams + weight-gradient side stream) for target network, student forward, decode, "
                                "CLAP loss and backward; the frozen teacher's two CFG queries + Heun step as one hipGraph on a second "
                                "stream for batch i + 1")
-            del gs
-        except Exception as exc:
-            if world > 1:
-                raise
-            launch_mode += " (pipelined teacher failed: %s)" % str(exc)[:120]
+        else:
+            launch_mode += " (pipelined teacher skipped: %s)" % (why or "capture failed on another rank")
+        del gs
     assert all(v == v for v in losses), "NaN distillation loss"
     out = {
         "metric": "distillation_steps_per_sec", "value": round(n_steps / dt, 4), "unit": "optimizer steps/s",
@@ -722,8 +807,12 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                    "launch": launch_mode, "grad_accum": 1, "gradient_allreduce": ("fp32 SUM over RCCL, one asynchronous collective per finished backward block, blocks merged to >= 16 M "
                                           "elements (64 MiB), overlapped with the rest of the backward") if world > 1 else "none (1 GPU)",
                    "parallelism": "dp%d" % world},
-        "loss_first_last": [round(losses[0], 6), round(losses[-1], 6)], "build_s": round(build_s, 1),
+        "build_s": round(build_s, 1),
     }
+    if not perceptual:   # (round 4 printed first / last of the per-step losses: random timesteps per step made that pair noise)
+        out["fixed_draw_loss_before_after"] = [loss_fixed_before, fixed_draw_loss()]
+        out["fixed_draw_loss_note"] = ("consistency loss of one fixed (timestep, noise, guidance) draw before the first and after the "
+                                       "last optimizer step of this leg's main loops (%d updates at lr <= 1e-5 * step / 1000)" % len(losses))
     if perceptual:
         out["metric"] = "perceptual_distillation_steps_per_sec"
         out["config"]["workload"] = ("configs[4]: CLAP fine-tuning step -- consistency generation (student / teacher / target "
@@ -756,8 +845,9 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     # samples per optimizer step and the same mathematics (tests/test_train_gpu.py::test_fused_accumulation...); 5x larger
     # GEMMs per launch.  Timed with eager launches (every rank: the all-reduce sequence must not depend on a capture).
     if os.environ.get("CTTA_BENCH_FUSED_ACCUM", "1") != "0" and not args.no_latency:
-        try:
-            Bf = B * acc
+        Bf = B * acc
+        z45 = P45 = kw45 = why = None
+        try:      # phase 1, local: the inputs (the arenas of the four U-Nets grow inside the first train_step)
             gf = torch.Generator(device="cpu").manual_seed(55 + rank)
             z45 = (torch.randn(Bf, 8, 256, 16, generator=gf) * 0.9).to(dev)
             enc45 = (torch.randn(Bf, L, 1024, generator=gf) * 0.25).to(dev)
@@ -766,6 +856,12 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             unc45, um45 = torch.zeros_like(enc45), torch.zeros_like(mask45)
             um45[:, 0] = True
             P45 = {"embeds_cf": torch.cat([unc45, enc45]), "mask_cf": torch.cat([um45, mask45]), "embeds": enc45, "mask": mask45}
+            kw45 = dict(time_inds=torch.randint(0, 17, (Bf,), generator=gf) * 2,
+                        gaussian_noise=torch.randn(Bf, 8, 256, 16, generator=gf).to(dev), guidance_scale=torch.rand(Bf, generator=gf) * 6)
+        except Exception as exc:
+            why, z45 = "rank %d: %s" % (rank, str(exc)[:160]), None
+        if du.all_agree(z45 is not None, dev):      # every rank enters the steps (and their all-reduces), or none does;
+            # an exception INSIDE them is one-sided and ends the rank -- torchrun then stops the job: loud, not hung
             for _ in range(2):
                 losses.append(m.train_step(z45, P45, opt, sched))
             du.barrier(dev)
@@ -777,15 +873,28 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             out["grad_accum_5_fused"] = {"value": round(n_opt / dtf, 4), "unit": "optimizer steps/s", "optimizer_steps": n_opt,
                                          "samples_per_s": round(world * Bf * n_opt / dtf, 3),
                                          "ms_per_optimizer_step": round(dtf / n_opt * 1e3, 3), "global_batch": Bf * world,
-                                         "micro_batch_per_gpu": Bf,
+                                         "micro_batch_per_gpu": Bf, "launch": "eager launches",
                                          "note": "the 45 samples of one optimizer step as ONE micro-batch (no accumulation loop)"}
-            del z45, enc45, P45
+            # The training form this machine wants: the same 45-sample micro-batch as hipGraph replays, SEGMENTED (one graph
+            # per all-reduce bucket -- what a process group needs) AND with the PIPELINED teacher (batch i + 1's teacher
+            # phase beside batch i's student / target / backward work).  This is what world > 1 runs when grad_accum > 1.
+            if timed_graph is not None:
+                n45 = max(3, n_opt)
+                try:
+                    dt45 = timed_graph(True, True, z=z45, prompt=P45, draws=kw45, steps=n45, warm=2)
+                    out["grad_accum_5_fused_pipelined"] = {
+                        "value": round(n45 / dt45, 4), "unit": "optimizer steps/s", "optimizer_steps": n45,
+                        "samples_per_s": round(world * Bf * n45 / dt45, 3), "ms_per_optimizer_step": round(dt45 / n45 * 1e3, 3),
+                        "global_batch": Bf * world, "micro_batch_per_gpu": Bf,
+                        "launch": "segmented hipGraph replays (bucket all-reduce between them) + pipelined teacher graph on its own stream",
+                        "teacher_stream_placement_ms": placements[-1] if placements else None}
+                except _LegSkipped as exc:
+                    out["grad_accum_5_fused_pipelined"] = {"skipped": str(exc)[:300]}
             # back to the per-GPU batch of 9 for the profiled step below (the handles keep their larger arenas)
             m.train_step(z0, P, opt, sched)
-        except Exception as exc:
-            if world > 1:
-                raise
-            out["grad_accum_5_fused"] = {"error": str(exc)[:200]}
+        else:
+            out["grad_accum_5_fused"] = {"skipped": why or "input set-up failed on another rank"}
+        del z45, P45, kw45
     assert all(v == v for v in losses), "NaN distillation loss"
     # one more step with the in-library launch profiler on rank 0.  EVERY rank takes the step: at world > 1 it issues
     # the gradient all-reduces, and a collective entered by rank 0 alone would pair up with the other ranks' next

@@ -243,6 +243,8 @@ SIGNATURES = {
     "ctta_groupnorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "ctta_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "ctta_layernorm_bwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "ctta_layernorm_bwd_scratch_floats": (c_size_t, [c_int64, c_int]),
+    "ctta_layernorm_bwd_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "ctta_geglu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "ctta_add_slices": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_void_p]),
     "ctta_zero_insert2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),

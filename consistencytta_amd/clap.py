@@ -147,8 +147,11 @@ class _LayerNorm(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         scratch = torch.zeros(2, x.shape[1], dtype=torch.float32, device=x.device)   # d gamma / d beta of a frozen layer
-        N.check(N.lib().ctta_layernorm_bwd(N.ptr(x), N.ptr(dy), N.ptr(dx), x.shape[0], ctx.d, x.shape[1], N.ptr(gamma),
-                                           float(ctx.eps), 0, N.ptr(scratch[0]), N.ptr(scratch[1]), N.stream_ptr()))
+        nf = int(N.lib().ctta_layernorm_bwd_scratch_floats(x.shape[0], x.shape[1]))   # the caller owns the partial table
+        part = torch.empty(nf, dtype=torch.float32, device=x.device) if nf else None
+        N.check(N.lib().ctta_layernorm_bwd_ws(N.ptr(x), N.ptr(dy), None, N.ptr(dx), x.shape[0], ctx.d, x.shape[1], N.ptr(gamma),
+                                              float(ctx.eps), N.ptr(scratch[0]), N.ptr(scratch[1]), N.ptr(part), nf,
+                                              N.stream_ptr()))
         return dx, None, None, None, None
 
 

@@ -1030,55 +1030,52 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
     atomicAdd(&dbeta[col], (red[1][0][t] + red[1][1][t]) + (red[1][2][t] + red[1][3][t]));
   }
 }
-// per-stream partial table of ctta_layernorm_bwd (grown on demand; the first, eager pass of a step sees every size before
-// a graph capture replays them)
-static float* ln_bwd_workspace(hipStream_t s, size_t bytes) {
-  struct Ws { float* p = nullptr; size_t bytes = 0; };
-  static std::mutex mu;
-  static std::map<std::pair<int, hipStream_t>, Ws> table;
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-  std::lock_guard<std::mutex> lk(mu);
-  Ws& w = table[std::make_pair(dev, s)];
-  if (w.bytes >= bytes) return w.p;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // no allocation while capturing
-  float* q = nullptr;
-  const size_t want = bytes < ((size_t)8 << 20) ? ((size_t)8 << 20) : bytes;
-  if (hipMalloc((void**)&q, want) != hipSuccess) return nullptr;
-  // The outgrown block is RETIRED, never freed: a captured hipGraph may hold its address as ln_bwd_kernel's `part` table,
-  // and torch hands pooled stream handles out again, so "this stream's previous table" can belong to a graph that is
-  // still replayed.  Tables are <= 64 MB and grow a handful of times per process.
-  static std::vector<float*> retired;
-  if (w.p) retired.push_back(w.p);
-  w.p = q; w.bytes = want;
-  return w.p;
+// Launch geometry of ctta_layernorm_bwd*: rows per block.  64 amortises the per-block dgamma / dbeta atomics on long
+// matrices, but the distillation step's token matrices are short (9 216 .. 36 864 rows): aim for >= ~2000 blocks so that
+// every CU holds several.
+static int ln_bwd_rows_per_block(int64_t rows) {
+  int rpb = (int)(rows / 2048);
+  return rpb < 8 ? 8 : (rpb > 64 ? 64 : (rpb + 7) / 8 * 8);
+}
+static bool ln_bwd_two_pass() {
+  static int two_pass = -1;
+  if (two_pass < 0) { const char* e = getenv("CTTA_LN_BWD_TWO_PASS"); two_pass = (e && e[0] == '0') ? 0 : 1; }
+  return two_pass != 0;
+}
+// The per-block partial table of d gamma / d beta belongs to the CALLER (an engine handle's arena, a torch tensor): the
+// library keeps no table of its own (round 4 kept a process-global one keyed by (device, stream) that could only ever
+// grow -- SURVEY 8b: no global state, one handle per (device, model)).  0 = this shape takes the atomics-only path.
+extern "C" size_t ctta_layernorm_bwd_scratch_floats(int64_t rows, int ld) {
+  if (rows <= 0 || ld <= 0 || !ln_bwd_two_pass()) return 0;
+  const int64_t blocks = cdiv64(rows, ln_bwd_rows_per_block(rows));
+  const size_t floats = (size_t)blocks * 2 * (size_t)ld;
+  return (blocks >= 16 && floats * sizeof(float) <= ((size_t)64 << 20)) ? floats : 0;
 }
 extern "C" ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t rows, int d, int ld,
                                           const float* gamma, float eps, int accumulate_dx, float* dgamma, float* dbeta,
                                           void* stream) {
-  return ctta_layernorm_bwd_add(x, dy, accumulate_dx ? dx : nullptr, dx, rows, d, ld, gamma, eps, dgamma, dbeta, stream);
+  return ctta_layernorm_bwd_ws(x, dy, accumulate_dx ? dx : nullptr, dx, rows, d, ld, gamma, eps, dgamma, dbeta, nullptr, 0, stream);
 }
 // dx = dx_add + dL/dx  (dx_add NULL: plain; dx_add == dx: the in-place accumulate of ctta_layernorm_bwd).  A separate
 // output lets the backward keep the PREVIOUS running gradient untouched for a weight-gradient job that reads it later.
 extern "C" ctta_status ctta_layernorm_bwd_add(const void* x, const void* dy, const void* dx_add, void* dx, int64_t rows, int d,
                                               int ld, const float* gamma, float eps, float* dgamma, float* dbeta, void* stream) {
+  return ctta_layernorm_bwd_ws(x, dy, dx_add, dx, rows, d, ld, gamma, eps, dgamma, dbeta, nullptr, 0, stream);
+}
+// `scratch` (>= ctta_layernorm_bwd_scratch_floats(rows, ld) floats, caller-owned, free again once the call's kernels have
+// run on `stream`): per-block partial sums of d gamma / d beta + a sliced fold (<= 32 atomics per address).  NULL / too
+// small: one atomic per block and column straight into dgamma / dbeta (same result up to the order of the fp32 atomics).
+extern "C" ctta_status ctta_layernorm_bwd_ws(const void* x, const void* dy, const void* dx_add, void* dx, int64_t rows, int d,
+                                             int ld, const float* gamma, float eps, float* dgamma, float* dbeta,
+                                             float* scratch, size_t scratch_floats, void* stream) {
   CTTA_REQUIRE(x && dy && dx && gamma && dgamma && dbeta, "layernorm_bwd: null pointer (dgamma/dbeta must be zeroed or hold the running sum)");
   CTTA_REQUIRE(ld % 8 == 0 && d <= ld && ld <= 2048, "layernorm_bwd: d=%d ld=%d", d, ld);
-  // rows per block: 64 amortises the per-block dgamma / dbeta atomics on long matrices, but the distillation step's
-  // token matrices are short (9 216 .. 36 864 rows): aim for >= ~2000 blocks so that every CU holds several
-  int rpb = (int)(rows / 2048);
-  rpb = rpb < 8 ? 8 : (rpb > 64 ? 64 : (rpb + 7) / 8 * 8);
+  const int rpb = ln_bwd_rows_per_block(rows);
   const dim3 grid((unsigned)cdiv64(rows, rpb));
   const size_t smem = (size_t)(ld <= 256 ? 8 : 4) * 2 * ld * sizeof(float);      // one copy per row group (<= 64 KB at ld = 2048)
   hipStream_t s = (hipStream_t)stream;
-  // d gamma / d beta: per-block partials + a sliced fold when a table of <= 64 MB holds them and the grid is large enough
-  // for the per-address atomics to hurt; a failed allocation falls back to one atomic per block and column
-  static int two_pass = -1;
-  if (two_pass < 0) { const char* e = getenv("CTTA_LN_BWD_TWO_PASS"); two_pass = (e && e[0] == '0') ? 0 : 1; }
-  float* part = nullptr;
-  const size_t part_bytes = (size_t)grid.x * 2 * ld * sizeof(float);
-  if (two_pass && grid.x >= 16 && part_bytes <= ((size_t)64 << 20)) part = ln_bwd_workspace(s, part_bytes);
+  const size_t need = ctta_layernorm_bwd_scratch_floats(rows, ld);
+  float* part = (scratch && need && scratch_floats >= need) ? scratch : nullptr;
 #define LNB(MV, HF) hipLaunchKernelGGL((ln_bwd_kernel<MV, HF>), grid, dim3(256), smem, s, (const bf16_t*)x, (const bf16_t*)dy, \
                                        (bf16_t*)dx, (long long)rows, d, ld, gamma, eps, (const bf16_t*)dx_add, dgamma, dbeta, rpb, part)
   if (ld <= 256) LNB(1, true); else if (ld <= 512) LNB(1, false); else if (ld <= 1024) LNB(2, false); else LNB(4, false);

@@ -308,7 +308,15 @@ static ctta_status ln_backward(BCtx& c, const LNLayer& l, const bf16_t* x, const
   float *dg, *db;
   CTTA_TRY(grad_ptr(c, l.key + "weight", &dg));
   CTTA_TRY(grad_ptr(c, l.key + "bias", &db));
-  RUN(c, ctta_layernorm_bwd_add(x, dy, dx_add, dx, rows, d, ld, l.gamma, 1e-5f, dg, db, c.stream));
+  // the partial table of d gamma / d beta comes from THIS handle's arena and goes back at once: everything that may later
+  // be placed on top of it is written by kernels enqueued on c.stream behind the fold
+  Arena& A = *c.arena;
+  const size_t mk = A.mark();
+  const size_t nf = ctta_layernorm_bwd_scratch_floats(rows, ld);
+  float* part = nf ? A.get<float>(nf) : nullptr;
+  if (nf && !part) { ctta_set_error("arena exhausted (layernorm backward partials)"); return CTTA_ERR_NOMEM; }
+  RUN(c, ctta_layernorm_bwd_ws(x, dy, dx_add, dx, rows, d, ld, l.gamma, 1e-5f, dg, db, part, nf, c.stream));
+  A.release(mk);
   return CTTA_OK;
 }
 

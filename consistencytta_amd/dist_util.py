@@ -40,6 +40,23 @@ def max_over_ranks(seconds, device):
     return float(t.item())
 
 
+def count_ranks(device):
+    """An all-reduce(SUM) of ones: the number of ranks the communicator really joined (1 without a process group).  bench.py
+    prints it as `rccl_ranks` so that a scaling record shows what the collective library saw, not what the flags said."""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(round(float(t.item())))
+
+
+def all_agree(ok, device):
+    """True iff `ok` holds on EVERY rank (one MAX all-reduce of an error flag).  Every rank must call it at the same point:
+    it is how the ranks decide TOGETHER whether to enter a sequence of collectives that a one-sided failure (a hipGraph
+    capture, a parity assert) would otherwise leave half-entered."""
+    return max_over_ranks(0.0 if ok else 1.0, device) == 0.0
+
+
 def global_wav_extrema_(max_min):
     """In place: `max_min` = [max, min] of this rank's waveforms (a 2-element float tensor, device or host) becomes the pair
     over ALL ranks.  vocoder_infer centres with batch-global extrema (hifigan/utilities.py:85), so a clip-sharded batch
@@ -77,14 +94,20 @@ class GradientBuckets:
     before the optimizer.  Blocks are merged until a bucket holds at least `min_elems` elements so that the small
     level-0 blocks do not become many tiny collectives on the per-link-bound xGMI rings."""
 
-    def __init__(self, flat_grad, ranges, min_elems=16 << 20, compress=None):
+    def __init__(self, flat_grad, ranges, min_elems=16 << 20, compress=None, twin=None):
         """`compress=torch.bfloat16` sends every bucket as bf16 (half the xGMI bytes: 1.12 GB instead of 2.24 GB per
-        step) and adds the reduced values back into the fp32 buffer; default fp32 = DDP's exact sum."""
+        step) and adds the reduced values back into the fp32 buffer; default fp32 = DDP's exact sum.
+        `twin`: the persistent low-precision staging buffer of the same length as `flat_grad`, owned by whoever owns the
+        gradient buffer (`FusedAdamW.grad_twin(dtype)`: allocated once, freed with the optimizer); without one this
+        object allocates its own and it lives exactly as long as the object (no module-level cache)."""
         self.flat, self.ranges, self.min_elems = flat_grad, dict(ranges), int(min_elems)
         self.works, self.pending = [], []
         if compress is not None and compress not in (torch.bfloat16, torch.float16):
             raise ValueError("gradient all-reduce dtype must be None (fp32), torch.bfloat16 or torch.float16")
         self.compress = compress
+        if twin is not None and (twin.numel() != flat_grad.numel() or twin.dtype != compress or twin.device != flat_grad.device):
+            raise ValueError("GradientBuckets: the twin buffer must match the gradient buffer's length and device and the compress dtype")
+        self._twin = twin
         # CTTA_FORCE_COLLECTIVES=1 keeps the block-wise path on with a single rank (tests / profiling of the overlap)
         force = os.environ.get("CTTA_FORCE_COLLECTIVES", "0") == "1"
         self.enabled = dist.is_initialized() and (dist.get_world_size() > 1 or force)
@@ -97,7 +120,9 @@ class GradientBuckets:
                 self.works.append((dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, async_op=True), None, lo, hi))
             else:   # a persistent low-precision twin of the flat buffer (allocated once per gradient buffer and dtype,
                 # not one temporary per bucket and step)
-                tmp = _twin(self.flat, self.compress)[lo:hi]
+                if self._twin is None:
+                    self._twin = torch.empty(self.flat.numel(), dtype=self.compress, device=self.flat.device)
+                tmp = self._twin[lo:hi]
                 tmp.copy_(self.flat[lo:hi])
                 self.works.append((dist.all_reduce(tmp, op=dist.ReduceOp.SUM, async_op=True), tmp, lo, hi))
         self.pending = []
@@ -119,18 +144,6 @@ class GradientBuckets:
                     self.flat[lo:hi].copy_(tmp)
         self.works = []
         return self.world
-
-
-_TWINS = {}
-
-
-def _twin(flat, dtype):
-    key = (flat.data_ptr(), flat.numel(), dtype)
-    t = _TWINS.get(key)
-    if t is None or t.device != flat.device:
-        _TWINS.clear()          # one training buffer per process: do not keep stale 1 GB twins alive
-        t = _TWINS[key] = torch.empty(flat.numel(), dtype=dtype, device=flat.device)
-    return t
 
 
 def _merge(ranges):

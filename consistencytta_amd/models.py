@@ -450,8 +450,9 @@ class AudioLCM(AudioDistilledModel):
                 z_0, gt_wav, prompt, False, True, fw.pop("time_inds", None), fw.pop("gaussian_noise", None),
                 fw.pop("guidance_scale", None), True)
             # gradient all-reduce (RCCL) overlapped with the backward pass, block by block
-            buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges(),
-                                                compress=getattr(self, "allreduce_dtype", None))
+            cdt = getattr(self, "allreduce_dtype", None)
+            buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges(), compress=cdt,
+                                                twin=optimizer.grad_twin(cdt) if hasattr(optimizer, "grad_twin") else None)
             nan_any = dist_util.AnyRankFlag(torch.isnan(loss))     # all ranks skip together (or none)
             self._student_backward(pred, target, sig, gamma, 1.0 / max(1, int(accumulation_steps)),
                                    buckets.ready if buckets.enabled else None)
@@ -770,8 +771,9 @@ class AudioGDM(AudioDistilledModel):
         with torch.no_grad():
             loss, pred, target, weights = self._forward_impl(z_0, prompt, True, fw.pop("time_inds", None),
                                                              fw.pop("gaussian_noise", None), fw.pop("guidance_scale", None))
-            buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges(),
-                                                compress=getattr(self, "allreduce_dtype", None))
+            cdt = getattr(self, "allreduce_dtype", None)
+            buckets = dist_util.GradientBuckets(optimizer.grad, self.student_unet.block_ranges(), compress=cdt,
+                                                twin=optimizer.grad_twin(cdt) if hasattr(optimizer, "grad_twin") else None)
             nan_any = dist_util.AnyRankFlag(torch.isnan(loss))
             self._student_backward(pred, target, weights, 1.0, buckets.ready if buckets.enabled else None)
             world = buckets.wait()
@@ -1008,20 +1010,32 @@ class _DistillStepGraph:
     def _refresh(self, z_0, time_inds, gaussian_noise, guidance_scale, S=None, prompt=None, gt_wav=None):
         """Fills an input set (default: the one the teacher phase reads) on the CURRENT stream.  `prompt`: the batch's
         pre-computed text states (dict); None keeps the set's (a fixed prompt batch)."""
-        m, B = self.m, self.B
         S = self.nxt if S is None else S
+        self._refresh_tensors(S, z_0, gaussian_noise, prompt, gt_wav)
+        self._refresh_scalars(S, time_inds, guidance_scale)
+
+    def _refresh_tensors(self, S, z_0, gaussian_noise, prompt, gt_wav):
+        """The device-side half: copies out of the CALLER's tensors (latents, noise, text states), on the current stream --
+        which must be the stream the caller produced them on (`feed` runs this before it hands over to the teacher stream,
+        so the caching allocator never sees a caller tensor read on a stream it does not know about)."""
         if prompt is not None:
             for k in self._P_KEYS:
                 S["P"][k].copy_(prompt[k])
             S["extra"] = {k: v for k, v in prompt.items() if k not in self._P_KEYS}
         S["gt_wav"] = gt_wav
+        S["z0"].copy_(z_0)
+        S["noise"].copy_(gaussian_noise if gaussian_noise is not None else torch.randn_like(z_0))
+
+    def _refresh_scalars(self, S, time_inds, guidance_scale):
+        """The host-side half: timesteps, sigma vectors and guidance scales, computed by the scheduler's own host logic and
+        copied from the pinned staging buffer on the current stream."""
+        m, B = self.m, self.B
         avail = m.noise_scheduler._timesteps_host
         order = 2
         if time_inds is not None:
             inds = time_inds.to("cpu", torch.int64)
         else:
             inds = torch.randint(0, (len(avail) - 1) // order, (B,)) * order
-        noise = gaussian_noise if gaussian_noise is not None else torch.randn_like(z_0)
         if m.teacher_guidance_scale != -1:
             # a fixed teacher scale conditions student and target on that same w (`_forward_impl`: guidance_scale = None
             # -> w = float(teacher_guidance_scale)); `_query_teacher` uses the fixed scale by itself
@@ -1042,8 +1056,6 @@ class _DistillStepGraph:
         S["w"].copy_(host[2], non_blocking=True)
         for i in range(len(plan)):
             S["sig"][i].copy_(host[3 + i], non_blocking=True)
-        S["z0"].copy_(z_0)
-        S["noise"].copy_(noise)
         if self.pipelined:
             self._ev_h2d.record()
 
@@ -1274,13 +1286,35 @@ class _DistillStepGraph:
         if self._primed:
             cur.wait_event(self._ev_teacher)                 # the teacher phase of the batch fed last time is complete
             self._rotate()                                   # ... and that batch becomes the current one
+        # the caller's tensors are read HERE, on the caller's stream (read from the teacher stream without a
+        # record_stream, the caching allocator could recycle them under the copies); only the pinned-buffer host -> device
+        # copies and the graph replay run on the teacher stream
+        self._refresh_tensors(self.nxt, z_0, gaussian_noise, prompt, gt_wav)
         self._tstream.wait_stream(cur)
         with torch.cuda.stream(self._tstream):
-            self._refresh(z_0, time_inds, gaussian_noise, guidance_scale, prompt=prompt, gt_wav=gt_wav)
+            self._refresh_scalars(self.nxt, time_inds, guidance_scale)
             self.teacher_graph.replay()
             self._ev_teacher.record(self._tstream)
         was, self._primed = self._primed, True
+        self._fed_untrained = True
         return was
+
+    def drain(self, lr_scheduler=None, skip_nan=True):
+        """Pipelined captures: one more optimizer step on the batch fed LAST (whose teacher phase is done or in flight)
+        WITHOUT feeding a new one -- the end of an epoch.  A loop `for z in batches: g.step(z)` trains on batches
+        [0, 0, 1, ..., N-2] (the first call primes the pipeline with its batch and trains on it; every later call trains on
+        the batch fed one call earlier); `drain()` then trains on batch N-1, so that every batch is trained on (the
+        reference trains each batch exactly once, tools/train_utils.py:150-183; to make batch 0 count once too, prime with
+        `feed(batch 0)` instead of `step(batch 0)` -- see INTEGRATION.md).  Returns the loss, or None when nothing is
+        waiting."""
+        assert self.pipelined
+        if not self._primed or not getattr(self, "_fed_untrained", False):
+            return None
+        cur = torch.cuda.current_stream(self.dev)
+        cur.wait_event(self._ev_teacher)
+        self._rotate()
+        self._primed = self._fed_untrained = False      # the next feed() starts a fresh pipeline (no teacher phase in flight)
+        return self._train_current(lr_scheduler, skip_nan)
 
     def step(self, z_0, lr_scheduler=None, time_inds=None, gaussian_noise=None, guidance_scale=None, skip_nan=True,
              prompt=None, gt_wav=None):
@@ -1299,12 +1333,18 @@ class _DistillStepGraph:
                 self.feed(z_0, **draw)      # first call: the same batch is also the next one
         else:
             self._refresh(z_0, time_inds, gaussian_noise, guidance_scale, prompt=prompt, gt_wav=gt_wav)
+        return self._train_current(lr_scheduler, skip_nan)
+
+    def _train_current(self, lr_scheduler=None, skip_nan=True):
+        """Replay on the CURRENT input set + (at an accumulation boundary) the eager tail."""
+        m = self.m
         self._micro += 1
         if self._micro % self.accum != 0:      # DDP's no_sync: gradients only accumulate locally
             self.replay()
             return float(self.loss.item())
+        cdt = getattr(m, "allreduce_dtype", None)
         buckets = dist_util.GradientBuckets(self.opt.grad, m.student_unet.block_ranges(), min_elems=self.bucket_min_elems,
-                                            compress=getattr(m, "allreduce_dtype", None))
+                                            compress=cdt, twin=self.opt.grad_twin(cdt) if hasattr(self.opt, "grad_twin") else None)
         if buckets.enabled and not self.segmented and not self.main_eager:
             raise N.CttaError("a monolithic step graph cannot interleave the gradient all-reduce with the backward pass: "
                               "capture with segmented=True under a process group")

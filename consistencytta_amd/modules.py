@@ -422,17 +422,22 @@ class _UNetBase(_ParamTree):
         """First step of the block-wise backward (ctta_unet_backward_begin): the out head.  Returns its block id.  Each
         begin / next call is self-contained on the calling stream (the weight-gradient side stream is joined before it
         returns), so a caller may capture every call into its own hipGraph (`_DistillStepGraph(segmented=True)`)."""
-        tab, keep = self._grad_table()
+        tab, keep = self._bwd_table = self._grad_table()     # kept for the `backward_next` calls of THIS backward pass
         with torch.cuda.device(self.device):
             N.check(N.lib().ctta_unet_backward_begin(self._h_unet, N.ptr(grad_output_nhwc), tab, len(tab), N.stream_ptr()))
         return 2 * len(self._cfg["block_out_channels"]) + 2
 
     def backward_next(self):
         """One more block (ctta_unet_backward_next) -> (block id, finished)."""
-        tab, keep = self._grad_table()
+        # the table `backward_begin` built (690 named gradient tensors: rebuilding it for each of the ~12 calls of one
+        # block-wise backward was host time on the data-parallel step's critical path; the gradient tensors cannot change
+        # between the calls of one pass)
+        tab, keep = getattr(self, "_bwd_table", None) or self._grad_table()
         blk, fin = N.c_int(0), N.c_int(0)
         with torch.cuda.device(self.device):
             N.check(N.lib().ctta_unet_backward_next(self._h_unet, tab, len(tab), N.stream_ptr(), N.byref(blk), N.byref(fin)))
+        if fin.value:
+            self._bwd_table = None
         return blk.value, bool(fin.value)
 
     def block_ranges(self):

@@ -25,6 +25,18 @@ class FusedAdamW:
         self.exp_avg_sq = torch.zeros(self.n, dtype=torch.float32, device=self.flat.device)
         self.param_groups = [dict(lr=float(lr), betas=tuple(betas), eps=float(eps), weight_decay=float(weight_decay))]
         self.step_count = 0
+        self._grad_twin = None
+
+    def grad_twin(self, dtype):
+        """The persistent low-precision twin of the flat gradient buffer that a compressed gradient all-reduce stages its
+        buckets in (`dist_util.GradientBuckets(..., compress=dtype, twin=...)`): owned by the optimizer that owns the
+        gradient buffer -- allocated on first use, replaced when the dtype changes, freed with the optimizer."""
+        if dtype is None:
+            return None
+        t = self._grad_twin
+        if t is None or t.dtype != dtype or t.numel() != self.grad.numel() or t.device != self.grad.device:
+            t = self._grad_twin = torch.empty(self.grad.numel(), dtype=dtype, device=self.grad.device)
+        return t
 
     def zero_grad(self, set_to_none=False):
         self.grad.zero_()

@@ -688,6 +688,12 @@ ctta_status ctta_layernorm_bwd(const void* x, const void* dy, void* dx, int64_t 
 /* dx = dx_add + dL/dx with a separate output (dx_add may be NULL, or equal dx = the in-place accumulate above) */
 ctta_status ctta_layernorm_bwd_add(const void* x, const void* dy, const void* dx_add, void* dx, int64_t rows, int d, int ld,
                                    const float* gamma, float eps, float* dgamma, float* dbeta, void* stream);
+/* The same with a CALLER-OWNED partial table for d gamma / d beta (per-block sums + a sliced fold instead of one atomic per
+   block and column); scratch may be NULL (atomics path).  The library holds no workspace of its own for this call. */
+size_t ctta_layernorm_bwd_scratch_floats(int64_t rows, int ld);
+ctta_status ctta_layernorm_bwd_ws(const void* x, const void* dy, const void* dx_add, void* dx, int64_t rows, int d, int ld,
+                                  const float* gamma, float eps, float* dgamma, float* dbeta, float* scratch,
+                                  size_t scratch_floats, void* stream);
 ctta_status ctta_geglu_bwd(const void* f, const void* dout, void* df, int64_t rows, int hp, int interleaved,
                            void* stream);
 ctta_status ctta_add_slices(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int64_t rows,

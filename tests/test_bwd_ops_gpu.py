@@ -280,7 +280,7 @@ def test_groupnorm_backward(B, C, H, W, G, silu, eps):
     assert rel_err(dg.cpu(), gamma.grad) < 2e-3 and rel_err(dbt.cpu(), beta.grad) < 2e-3
 
 
-@pytest.mark.parametrize("rows,d,ld", [(70, 39, 64), (130, 255, 256), (9, 1020, 1024)])
+@pytest.mark.parametrize("rows,d,ld", [(70, 39, 64), (130, 255, 256), (9, 1020, 1024), (4100, 255, 256), (2304, 510, 512)])
 def test_layernorm_geglu_backward(rows, d, ld):
     x = bf16_round(det("lb.x", (rows, d), 1) * 3 + 0.5).requires_grad_(True)
     gamma = (1 + 0.2 * det("lb.g", (d,), 2)).requires_grad_(True)
@@ -312,6 +312,19 @@ def test_layernorm_geglu_backward(rows, d, ld):
     sync()
     assert torch.equal(add, keep) and torch.equal(out2, inpl)
     assert rel_err(out2.float().cpu()[:, :d], add.float().cpu()[:, :d] + x.grad) < 2 * BF16_TOL
+    # round 5: the per-block partial table of d gamma / d beta is the CALLER's (no workspace inside the library): with it
+    # the fold is per-block sums + a sliced reduce, without it one atomic per block and column -- same dx bit for bit,
+    # same parameter gradients up to the order of the fp32 additions
+    nf = int(lib().ctta_layernorm_bwd_scratch_floats(rows, ld))
+    assert (nf > 0) == (rows >= 2000)
+    part = torch.empty(max(nf, 1), device=DEV)
+    out4, dg4, db4 = torch.empty_like(xd), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
+    N.check(lib().ctta_layernorm_bwd_ws(N.ptr(xd), N.ptr(dyd), None, N.ptr(out4), rows, d, ld, N.ptr(gd), 1e-5, N.ptr(dg4),
+                                        N.ptr(db4), N.ptr(part), nf, N.stream_ptr()))
+    sync()
+    assert torch.equal(out4, dx)
+    assert rel_err(dg4.cpu(), gamma.grad) < 2e-3 and rel_err(db4.cpu(), beta.grad) < 2e-3
+    assert rel_err(dg4.cpu(), dg.cpu()) < 1e-5 and rel_err(db4.cpu(), dbt.cpu()) < 1e-5
     # GEGLU
     hp = ld
     f = bf16_round(det("gg.f", (rows, 2 * hp), 5) * 2).requires_grad_(True)

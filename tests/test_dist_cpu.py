@@ -46,6 +46,8 @@ def _worker(rank, world, port, q):
         b3.ready(blk)
     assert b3.wait() == 2 and g3.tolist() == [3.0 * i for i in range(11)] and g3.dtype == torch.float32
     # NaN-loss skip: one rank's flag reaches every rank (all skip the update together)
+    assert du.count_ranks(dev) == world                         # bench.py's `rccl_ranks`: an all-reduce of ones
+    assert du.all_agree(True, dev) is True and du.all_agree(rank == 0, dev) is False   # one failing rank -> nobody proceeds
     flag_any = du.AnyRankFlag(torch.tensor(rank == 1)).result()
     flag_none = du.AnyRankFlag(torch.tensor(False)).result()
     assert flag_any is True and flag_none is False
@@ -75,3 +77,51 @@ def test_allreduce_is_identity_without_a_process_group():
     from consistencytta_amd import dist_util as du
     g = torch.arange(6, dtype=torch.float32)
     assert du.allreduce_sum_(g) == 1 and g.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+
+
+def _load_bench():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec_ = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    mod = importlib.util.module_from_spec(spec_)
+    spec_.loader.exec_module(mod)
+    return mod, root
+
+
+def test_bench_builds_the_rank_launcher_command_line():
+    """`python bench.py --gpus N` starts its own ranks: N processes on this node, rendezvous on 127.0.0.1, the script's
+    arguments passed through unchanged (VERDICT r4 #1; the reference's launcher is `accelerate launch`, train.sh:29)."""
+    import sys
+    bench, root = _load_bench()
+    cmd = bench.launcher_command(["--gpus", "8", "--steps", "20", "--warmup", "3"], 8, 29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    i = cmd.index(os.path.join(root, "bench.py"))
+    assert cmd[i + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "3"]
+    assert not any("exec" in c for c in cmd)
+
+
+def test_bench_parent_launches_a_child_and_never_touches_the_gpu(tmp_path):
+    """The parent of a self-launched run must not import torch (so it cannot initialise HIP), must start the ranks as a
+    CHILD process and hand back the child's exit code.  Dry run: the command line; real run on this GPU-less container:
+    both ranks refuse to run without a GPU and the parent returns their non-zero code instead of hanging."""
+    import json
+    import subprocess
+    import sys
+    _, root = _load_bench()
+    probe = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '2', '--steps', '1', '--warmup', '0']\n"
+             "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n    code = e.code\n"
+             "print('TORCH_IMPORTED', 'torch' in sys.modules, 'RC', code)\n" % os.path.join(root, "bench.py"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["CTTA_BENCH_LAUNCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, env=env, timeout=120)
+    assert "TORCH_IMPORTED False RC 0" in r.stdout, r.stdout + r.stderr
+    cmd = json.loads(r.stdout.splitlines()[0])["launcher_command"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2"
+    env.pop("CTTA_BENCH_LAUNCH_DRYRUN")
+    env["CTTA_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-c", probe], capture_output=True, text=True, env=env, timeout=600)
+    assert "TORCH_IMPORTED False" in r.stdout, r.stdout + r.stderr
+    assert "RC 0" not in r.stdout                       # the ranks' failure is the parent's exit code
+    assert "bench.py needs a GPU" in r.stderr           # ... and it came from real child ranks

@@ -433,7 +433,7 @@ def test_no_kernel_lost_occupancy_against_the_committed_table():
     sp.loader.exec_module(mod)
     now = mod.occupancy_table(os.path.join(root, "consistencytta_amd", "libctta_hip.so"))
     want = json.load(open(os.path.join(root, "tests", "golden", "kernel_occupancy.json")))
-    assert len(now) >= 190 and mod.waves_per_simd(128) == 4 and mod.waves_per_simd(129) == 3 and mod.waves_per_simd(100, 32) == 3
+    assert len(now) >= 190 and mod.waves_per_simd(128) == 4 and mod.waves_per_simd(129) == 3 and mod.waves_per_simd(100, 32) == 4
     lost = {k: (want[k], now[k]) for k in want if k in now and (now[k][3] < want[k][3] or now[k][2] > want[k][2])}
     assert not lost, "kernels that lost waves per SIMD or spill more than the committed table: %r" % lost
     tile = lambda *t: "_Z16conv_gemm_kernelI" + "".join("Li%dE" % x for x in t) + "Ev10ConvParams"

@@ -475,6 +475,45 @@ def test_pipelined_teacher_step_graph_equals_eager_on_a_sequence_of_batches(gold
         del gs
 
 
+def test_pipelined_step_trains_every_batch_once_with_feed_and_drain(golden):
+    """the reference trains every batch exactly once (tools/train_utils.py:150-183).  With the pipelined
+    teacher, `feed(b0); step(b1); step(b2); drain()` is that loop: the losses are the eager `train_step` losses of
+    b0, b1, b2 in order (same draws, parameters evolving identically), `drain()` with nothing waiting returns None, and
+    the pipeline can be primed again afterwards."""
+    gen = torch.Generator().manual_seed(29)
+    batches = []
+    for i in range(3):
+        batches.append(dict(z=(torch.randn(3, 8, 32, 8, generator=gen) * 0.9).to(DEV),
+                            kw=dict(time_inds=torch.randint(0, 17, (3,), generator=gen) * 2,
+                                    gaussian_noise=torch.randn(3, 8, 32, 8, generator=gen).to(DEV),
+                                    guidance_scale=torch.rand(3, generator=gen) * 6)))
+    m1, P, _ = _lcm()
+    m1.train()
+    o1 = m1.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)
+    m2, _, _ = _lcm()
+    m2.train()
+    o2 = m2.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)
+    gs = m2.capture_train_graph(o2, batches[0]["z"], P, segmented=False, pipeline_teacher=True, **batches[0]["kw"])
+    assert gs.drain() is None                                   # nothing fed yet
+    eager = [m1.train_step(b["z"], P, o1, None, **b["kw"]) for b in batches]
+    got = []
+    assert gs.feed(batches[0]["z"], **batches[0]["kw"]) is False
+    got.append(gs.step(batches[1]["z"], None, **batches[1]["kw"]))     # trains on batch 0
+    got.append(gs.step(batches[2]["z"], None, **batches[2]["kw"]))     # trains on batch 1
+    got.append(gs.drain())                                               # trains on batch 2, feeds nothing
+    torch.cuda.synchronize()
+    print("eager losses", eager, "feed/step/step/drain losses", got)
+    assert o1.step_count == o2.step_count == 3 and gs.drain() is None
+    assert got[0] == eager[0]
+    for a, b in zip(got[1:], eager[1:]):                         # parameters differ by the LayerNorm-atomics round-off only
+        assert abs(a - b) <= 1e-5 * abs(b)
+    upd = float((o1.flat - o2.flat).norm() / o1.flat.norm())
+    assert upd <= 1e-6
+    assert gs.feed(batches[0]["z"], **batches[0]["kw"]) is False    # a fresh pipeline
+    assert gs.drain() is not None
+    del gs
+
+
 def test_pipelined_teacher_with_eager_main_and_changing_prompts(golden):
     """Round 4: (i) a batch's TEXT STATES travel with it through the pipeline (double-buffered like the latents): three batches
     with three different prompt sets, fed one call ahead, give the eager step's loss bit for bit; (ii) `main_eager` -- only the
@@ -915,3 +954,25 @@ def test_distillation_step_full_batch_is_deterministic_and_blockwise_exact():
             assert not segmented or [bs for _, bs in gs.segments] == [(10, 9, 8), (7,), (6,), (5,), (4,), (3,), (2,), (1, 0)]
         opt.zero_grad()
         del gs
+    # the PIPELINED teacher (the form bench.py's headline distillation number runs) at this size --
+    # the whole gradient against the eager step, for both draws fed one call ahead
+    gs = m.capture_train_graph(opt, z0, P, segmented=False, pipeline_teacher=True, **kw)
+    gs.feed(z0, **kw)
+    for draw, nxt in ((kw, kw2), (kw2, kw)):
+        torch.cuda.synchronize()     # the eager reference below uses the SAME teacher handle as the teacher graph in flight
+        opt.zero_grad()
+        with torch.no_grad():
+            loss, pred, target, sig, gamma = m._forward_impl(z0, None, P, False, True, draw["time_inds"],
+                                                             draw["gaussian_noise"], draw["guidance_scale"], True)
+            m._student_backward(pred, target, sig, gamma, 1.0, None)
+        torch.cuda.synchronize()
+        g_e, l_e = opt.grad.detach().clone(), float(loss)
+        opt.zero_grad()
+        assert gs.feed(z0, **nxt) is True           # `draw` becomes the current set, `nxt` goes to the teacher stream
+        gs.replay()
+        torch.cuda.synchronize()
+        d = float((opt.grad - g_e).norm() / g_e.norm())
+        print("B=9 light, pipelined teacher: loss %.9g vs eager %.9g, gradient rel diff %.2e" % (float(gs.loss.item()), l_e, d))
+        assert float(gs.loss.item()) == l_e and d <= 1e-7
+    opt.zero_grad()
+    del gs

@@ -68,9 +68,11 @@ def kernel_registers(path):
 
 def waves_per_simd(vgpr, agpr=0):
     """gfx950: one 512-entry register file per SIMD lane shared by architectural and accumulation registers, allocated in
-    blocks of 8; at most 8 waves per SIMD."""
-    total = (vgpr + 3) // 4 * 4 + agpr if agpr else vgpr
-    return max(1, min(8, 512 // max(8, (total + 7) // 8 * 8)))
+    blocks of 8; at most 8 waves per SIMD.  In gfx90a+ code-object metadata `.vgpr_count` is ALREADY the unified total
+    (align4(architectural) + accumulation; e.g. `ln_bwd_kernel<4,false>`: vgpr 264 with agpr 8), so occupancy follows from
+    it alone -- `agpr` is accepted for the table's sake and ignored (round 4 added it on top and under-counted kernels
+    with accumulation registers by one step: ADVICE r4)."""
+    return max(1, min(8, 512 // max(8, (vgpr + 7) // 8 * 8)))
 
 
 def occupancy_table(path):
