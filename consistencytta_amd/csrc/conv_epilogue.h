@@ -30,6 +30,13 @@ struct ConvParams {
   // [x * xcd_per, (x + 1) * xcd_per) and walks it with the N tiles innermost, so the tiles that share input rows
   // (neighbouring image rows, all N tiles of one M tile) meet in the same 4 MB L2 close in time.  0 = plain 2-D grid.
   int xcd_per, m_tiles, n_tiles, n_inner;   // n_inner = 0: M tiles innermost (many N tiles: keep the weight slice hot)
+  // Weight-slab affinity (1-D grid; weight-dominated launches: every split-K launch, and launches with few row tiles).  A
+  // "slab" is one (K-split, N-tile) pair = one slice of the weight matrix; work item i = slab * m_tiles + mt with
+  // slab = zs * n_tiles + nt.  XCD x owns the contiguous item range [x * slab_per, (x + 1) * slab_per): all row tiles of a
+  // slab run on ONE XCD, close in time, so a weight byte crosses the fabric into one L2 once (the plain 3-D grid spreads
+  // the row tiles of a slab over all eight XCDs and every L2 pulls the whole weight matrix: 157.6 MB read for an
+  // 18.9 MB matrix, profiles/pmc_by_shape_r01.txt).  The K-split index stays the summation slot: results are unchanged.
+  int slab_total, slab_per;                 // slab_total = ksplit * n_tiles * m_tiles; 0 = off
   // first output row of this launch (a multiple of 4; normally 0).  The host splits the ragged last row tile of a
   // 256-row-tile launch off into a second launch with small tiles when that tile alone would open another round of the
   // 256 CUs (HiFi-GAN: M = 32 * 5121 = 640 * 256 + 32 rows x 2 column tiles = 5.008 rounds).

@@ -247,6 +247,10 @@ static const Variant kVariants[] = {
     VARIANT(256, 256, 32, 2, 4, 2, 4),  // 34
     VARIANT(512, 128, 32, 4, 2, 2, 2),  // 35  N = 128 layers: 8 waves of 128x64 (the big tile's wave shape) over 512 rows
     VARIANT(512, 128, 64, 4, 2, 2, 2),  // 36  ... with BK = 64: the whole 160 KB of LDS
+    VARIANT(64, 128, 64, 2, 2, 2, 4),   // 37  deeper rings for thin K-heavy launches (latency-bound: one K tile in flight per
+    VARIANT(128, 128, 64, 2, 2, 2, 3),  // 38  workgroup is ~1.1 us per K step whatever the tile)
+    VARIANT(128, 64, 64, 2, 2, 2, 3),   // 39
+    VARIANT(128, 128, 64, 2, 2, 2, 4),  // 40
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -274,6 +278,16 @@ static bool xcd_default() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("CTTA_XCD"); v = (e && e[0] == '0') ? 0 : 1; }
   return v != 0;
+}
+static bool tile_rules_r5() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_TILE_RULES_R5"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
+static int xcd_slab_default() {   // CTTA_XCD_SLAB: 0 = off, 1 (default) = split-K launches + few-row-tile launches, 2 = split-K launches only
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_XCD_SLAB"); v = e ? atoi(e) : 1; }
+  return v;
 }
 static bool wide_store_default() {
   static int v = -1;
@@ -446,6 +460,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     CTTA_LAUNCH_CHECK();
     return CTTA_OK;
   }
+  bool thin_ring = false;
   if (vid <= 0 || vid > kNumVariants) {
     if (!d->in_act && !geglu && glds_default() && want_big_tile(M, d->n, K, groups) && fast_ok(kVariants[kBigTile - 1].bk)) {
       vid = kBigTile;
@@ -469,7 +484,13 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       {
         static int m64 = -1;     // rows up to which the 64x128x64 tile (+ split-K, + the 3-stage ring when it fills) is taken
         if (m64 < 0) { const char* e = getenv("CTTA_SPLITK_M64"); m64 = e ? atoi(e) : 1280; }
-        vid = !tile_rules_r3() ? 1 : M <= 640 ? 8 : M <= m64 ? 6 : 1;
+        // round 5 (profiles/sweep_r05_thin.txt, weights cold): a K step of these launches takes ~1750 clocks whatever the
+        // tile (one K tile in flight per workgroup, ~2 workgroups per CU: tools/thin_timeline.py), so the tile that does
+        // the most work per step while split-K still fills one round of the CUs wins: M <= 640: 64x128x64 with the 3-stage
+        // ring and 7 splits (504 workgroups on 512 slots) 373 vs 304 TFLOP/s on 128x64x64; M <= 1280: 128x128x64 with 7
+        // splits 571 vs 420 on 64x128x64
+        thin_ring = tile_rules_r5() && M <= 640;
+        vid = !tile_rules_r3() ? 1 : tile_rules_r5() ? (M <= 640 ? 6 : 1) : M <= 640 ? 8 : M <= m64 ? 6 : 1;
       }
       if (!d->in_act && glds_default() && vid <= 8) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
       // 64 < N <= 128 with enough rows: the 256x128x32 tile (8 waves of 64x64) stages 25 % fewer bytes per FLOP than
@@ -506,7 +527,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
         if (sp > 1) wgs *= sp;
       }
       const long long rounds = (wgs + 511) / 512;
-      if (wgs >= 512 && wgs * 100 >= rounds * 512 * 85) vid = 27;
+      if ((wgs >= 512 && wgs * 100 >= rounds * 512 * 85) || (thin_ring && wgs > 384 && wgs <= 512)) vid = 27;
     }
   }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
@@ -588,12 +609,31 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       }
     }
   }
+  // Weight-slab affinity (see ConvParams::slab_total): every split-K launch, and unsplit launches whose few row tiles the
+  // M-range mapping above does not take (grid.x < 64) when the weights outweigh the activations and there are slabs enough
+  // to give every XCD its own.
+  bool slab = false;
+  if (groups == 1 && xcd_default() && xcd_slab_default() > 0 && p.xcd_per == 0) {
+    if (splits > 1) slab = true;
+    else if (xcd_slab_default() == 1 && grid.y >= 2 && (long long)grid.x * grid.y >= 16 && w_bytes > x_bytes && tail_rows == 0) slab = true;
+  }
+  if (slab && splits == 1) {
+    p.m_tiles = (int)grid.x; p.n_tiles = (int)grid.y;
+    p.slab_total = p.m_tiles * p.n_tiles;
+    p.slab_per = (p.slab_total + 7) / 8;
+    grid = dim3((unsigned)(8 * p.slab_per), 1, 1);
+  }
   if (splits > 1) {
     const int ld = (d->n + 3) / 4 * 4;
     ConvParams q = p;   // first pass: raw partial sums
     q.nk_split = (p.nk + splits - 1) / splits;
     splits = (p.nk + q.nk_split - 1) / q.nk_split;   // every split owns at least one K-tile
     q.ksplit = splits;
+    if (slab) {
+      q.m_tiles = (int)grid.x; q.n_tiles = (int)grid.y;
+      q.slab_total = q.m_tiles * q.n_tiles * splits;
+      q.slab_per = (q.slab_total + 7) / 8;
+    }
     q.bias = nullptr; q.bias_m = nullptr; q.rowvec = nullptr; q.res = nullptr; q.out_act = 0; q.alpha = 1.0f;
     q.accumulate = 0; q.out2 = nullptr; q.out = ws; q.ldc = ld; q.out_f32 = 1; q.obs = (long long)p.howo * ld;
     q.wide_store = 0;
@@ -601,6 +641,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       q.wide_f32 = (wf && conv_wide_f32_ok(v.bm, v.bn, v.bk, v.wm, v.wn, v.mode, v.stages)) ? 1 : 0; }
     q.ogs = (long long)M * ld;
     grid.z = (unsigned)splits;
+    if (slab) grid = dim3((unsigned)(8 * q.slab_per), 1, 1);
     v.launch(q, grid, (hipStream_t)stream);
     const long long total = M * (ld / 4);
     int fb = (int)((total + 255) / 256);
@@ -614,7 +655,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       CTTA_TRY(tv.prepare());
       ConvParams t = p;
       t.m_off = (int)(M - tail_rows);
-      t.xcd_per = 0; t.m_tiles = 0; t.n_tiles = 0; t.n_inner = 0;
+      t.xcd_per = 0; t.m_tiles = 0; t.n_tiles = 0; t.n_inner = 0; t.slab_total = 0; t.slab_per = 0;
       t.nk = (int)((K + tv.bk - 1) / tv.bk);
       t.nk_split = t.nk;
       tv.launch(t, dim3((unsigned)((tail_rows + tv.bm - 1) / tv.bm), (unsigned)((d->n + tv.bn - 1) / tv.bn), 1), (hipStream_t)stream);

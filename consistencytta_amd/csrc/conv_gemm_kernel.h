@@ -242,8 +242,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  int mt = blockIdx.x, nt = blockIdx.y;
-  if (p.xcd_per > 0) {
+  int mt = blockIdx.x, nt = blockIdx.y, zs_ = blockIdx.z;
+  if (p.slab_total > 0) {
+    const int item = (int)(blockIdx.x & 7) * p.slab_per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= p.slab_per || item >= p.slab_total) return;   // padding blocks (whole workgroup, before any barrier)
+    const int slab = item / p.m_tiles;
+    mt = item - slab * p.m_tiles;
+    zs_ = slab / p.n_tiles;
+    nt = slab - zs_ * p.n_tiles;
+  } else if (p.xcd_per > 0) {
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     if (p.n_inner) { nt = local % p.n_tiles; mt = xcd * p.xcd_per + local / p.n_tiles; }
     else { nt = local / p.xcd_per; mt = xcd * p.xcd_per + local % p.xcd_per; }
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   // a wave whose TM rows all lie past M (the last row tile of M = k * BM + a few rows) skips its MFMAs: its SIMD partner
   // then runs at full matrix-pipe rate and the tail tile of a one-workgroup-per-CU launch takes about half a tile time
   const bool wave_live = m0 + (wave / WN) * TM < p.M;
-  const int zs = blockIdx.z;
+  const int zs = zs_;
   const int g = p.ksplit > 1 ? 0 : zs;                    // group index (pointer offsets)
   const int kt_begin = p.ksplit > 1 ? zs * p.nk_split : 0;
   const int nk = p.ksplit > 1 ? min(p.nk - kt_begin, p.nk_split) : p.nk;
@@ -948,7 +955,12 @@ ctta_status prepare_variant() {
   X(128, 128, 32, 2, 2, 2, 3) \
   X(64, 128, 64, 2, 2, 2, 3) \
   X(256, 128, 32, 4, 2, 2, 2)
-#define CTTA_CONV_VARIANTS_ALL(X) CTTA_CONV_VARIANTS_1(X) CTTA_CONV_VARIANTS_2(X) CTTA_CONV_VARIANTS_3(X) CTTA_CONV_VARIANTS_4(X) CTTA_CONV_VARIANTS_5(X) CTTA_CONV_VARIANTS_6(X) CTTA_CONV_VARIANTS_7(X)
+#define CTTA_CONV_VARIANTS_8(X) \
+  X(64, 128, 64, 2, 2, 2, 4) \
+  X(128, 128, 64, 2, 2, 2, 3) \
+  X(128, 64, 64, 2, 2, 2, 3) \
+  X(128, 128, 64, 2, 2, 2, 4)
+#define CTTA_CONV_VARIANTS_ALL(X) CTTA_CONV_VARIANTS_8(X) CTTA_CONV_VARIANTS_1(X) CTTA_CONV_VARIANTS_2(X) CTTA_CONV_VARIANTS_3(X) CTTA_CONV_VARIANTS_4(X) CTTA_CONV_VARIANTS_5(X) CTTA_CONV_VARIANTS_6(X) CTTA_CONV_VARIANTS_7(X)
 #define CTTA_CONV_INSTANTIATE(BM, BN, BK, WM, WN, G, S)                                      \
   template void launch_variant<BM, BN, BK, WM, WN, G, S>(const ConvParams&, dim3, hipStream_t); \
   template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S>();

