@@ -94,6 +94,9 @@ SIGNATURES = {
     "ctta_unet_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "ctta_attention_lse": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                    c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "ctta_attention_bwd_inplace": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                                           c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                           c_int, c_int, c_int, c_int, c_int, c_float, c_void_p, c_int64, c_void_p]),
     "ctta_attention_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int,
                                    c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                    c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,

@@ -641,7 +641,56 @@ struct AttnBwdParams {
   int q_tiles_per_split, batch, hp;
   const float* full_bias;   // FULL kernels: [full_nb][heads][nq][nk], log2 domain (window attention)
   int full_nb;
+  // TR kernels (round 5): Q, K, dO are read where they lie and V as the forward keeps it, transposed [B][heads*64][vt_ld];
+  // kt / qt / dot / vn are unused
+  const bf16_t* vt;
+  int vt_ld;
 };
+
+typedef short att_s16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) att_s16x4_t* att_lds_s16x4_ptr;
+// The transposing LDS read (ds_read_b64_tr_b16): lane t of a 16-lane group NAMES the address of row k0 + t / 4, columns
+// 4 (t % 4) .. + 3 of a row-major bf16 tile and RECEIVES column t % 16, rows k0 .. k0 + 3.  Two of them (rows k0 .. + 3 and
+// k0 + 16 .. + 19) make one MFMA operand fragment whose k slots (g = lane / 16, e) are rows 4 g + e (e < 4) and 16 + 4 g + e - 4
+// of a 32-row chunk: the order in which the S / dS accumulators of the kernels below already hold their 32 positions, so an
+// operand that is needed "the other way round" is read out of the tile the kernel stages anyway -- no transposed copy of
+// Q, K or dO in HBM (wgrad_tn_kernel uses the same read on both of its operands).  `row0` = first of the 32 rows, `col0` =
+// first of the fragment's 16 columns, `ld` = row stride in elements (160-byte rows: = 32 mod 64, conflict-free).
+__device__ __forceinline__ bf16x8_t tr_frag(const bf16_t* tile, int ld, int row0, int col0, int lq, int lg) {
+  const bf16_t* a = tile + (row0 + lg * 4 + (lq >> 2)) * ld + col0 + (lq & 3) * 4;
+  const att_s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s16x4_ptr)a);
+  const att_s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((att_lds_s16x4_ptr)(a + 16 * ld));
+  const uint2 u0 = __builtin_bit_cast(uint2, v0), u1 = __builtin_bit_cast(uint2, v1);
+  return __builtin_bit_cast(bf16x8_t, make_uint4(u0.x, u0.y, u1.x, u1.y));
+}
+// 8 values of a row in the k-slot order of tr_frag: columns c0 + 4 g .. + 3 and c0 + 16 + 4 g .. + 3 (g = lane / 16)
+__device__ __forceinline__ bf16x8_t load_perm8(const bf16_t* row, int c0, int lg) {
+  const uint2 lo = *reinterpret_cast<const uint2*>(row + c0 + lg * 4);
+  const uint2 hi = *reinterpret_cast<const uint2*>(row + c0 + 16 + lg * 4);
+  return __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+// a [64 d][64 keys] tile of V^T (rows vt_ld apart) into registers; keys >= nk come back as zeros (vt_ld >= nk, both
+// multiples of 8 apart from nk itself: a vector that straddles nk is masked)
+__device__ __forceinline__ void fetch_vt_rows(uint4 (&reg)[2], const bf16_t* src, size_t src_ld, int key0, int nk, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int chunk = tid + i * 256;
+    const int r = chunk >> 3, cc = (chunk & 7) * 8;
+    const int nv = nk - (key0 + cc);          // valid keys in this vector
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (nv > 0) {
+      v = *reinterpret_cast<const uint4*>(src + (size_t)r * src_ld + key0 + cc);
+      if (nv < 8) {
+        unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (2 * j >= nv) ? 0u : ((2 * j + 1 >= nv) ? (w[j] & 0xffffu) : w[j]);
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    reg[i] = v;
+  }
+}
+
 
 // stages a [64 rows][64 cols] bf16 tile (row stride ld in LDS); rows >= rows_valid are zero
 __device__ __forceinline__ void stage_rows(bf16_t* lds, int ld, const bf16_t* src, size_t src_ld, int rows_valid, int tid) {
@@ -678,11 +727,11 @@ __device__ __forceinline__ void put_rows(bf16_t* lds, int ld, const uint4 (&reg)
 // PLAIN: no additive term (bias == nullptr, no full table) and nk % 64 == 0 -- the softmax rebuild on 4-vectors: P =
 // exp2(s * scale - lse) and dS = P * (dP * scale - D * scale) are one packed FMA + exp, one packed FMA and one packed
 // multiply per pair of elements instead of seven scalar operations and a key-range test per element.
-template <bool FULL, bool PLAIN>
+template <bool FULL, bool PLAIN, bool TR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * ATT_LDK];    // [key][d]
-  __shared__ __attribute__((aligned(16))) bf16_t Vn[64 * ATT_LDK];    // [key][d]
-  __shared__ __attribute__((aligned(16))) bf16_t KTs[64 * ATT_LDV];   // [d][key]
+  __shared__ __attribute__((aligned(16))) bf16_t Vn[64 * ATT_LDK];    // [key][d]   (TR: the V^T tile, [d][key])
+  __shared__ __attribute__((aligned(16))) bf16_t KTs[TR ? 8 : 64 * ATT_LDV];   // [d][key]   (TR: K^T is read out of Ks)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y;
   const int b = bh / p.heads, h = bh - b * p.heads;
@@ -691,8 +740,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   const bf16_t* qb = p.q + (size_t)b * p.nq * p.q_ld + h * 64;
   const bf16_t* dob = p.dO + (size_t)b * p.nq * p.do_ld + h * 64;
   const bf16_t* kb = p.k + (size_t)b * p.k_rows * p.k_ld + h * 64;
-  const bf16_t* vb = p.vn + (size_t)b * p.vn_rows * p.vn_ld + h * 64;
-  const bf16_t* ktb = p.kt + ((size_t)b * p.heads + h) * 64 * p.kt_ld;
+  const bf16_t* vb = TR ? p.vt + ((size_t)b * p.heads + h) * 64 * p.vt_ld : p.vn + (size_t)b * p.vn_rows * p.vn_ld + h * 64;
+  const bf16_t* ktb = TR ? nullptr : p.kt + ((size_t)b * p.heads + h) * 64 * p.kt_ld;
   const float* bb = p.bias ? p.bias + (size_t)b * p.nk : nullptr;
   const float* fb = FULL ? p.full_bias + ((size_t)(b % p.full_nb) * p.heads + h) * p.nq * p.nk : nullptr;
 
@@ -707,7 +756,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) {
       qf[jq][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qb + (size_t)qi * p.q_ld + ds * 32 + lg * 8));
-      dof[jq][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(dob + (size_t)qi * p.do_ld + ds * 32 + lg * 8));
+      // TR: dP = dO V^T contracts over d in the k-slot order of the transposing read that delivers V out of the V^T tile
+      if constexpr (TR) dof[jq][ds] = load_perm8(dob + (size_t)qi * p.do_ld, ds * 32, lg);
+      else dof[jq][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(dob + (size_t)qi * p.do_ld + ds * 32 + lg * 8));
     }
     lse_q[jq] = p.lse[((size_t)b * p.heads + h) * p.nq + qi];
     d_q[jq] = p.dsum[((size_t)b * p.heads + h) * p.nq + qi];
@@ -722,8 +773,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   uint4 rk[2], rv[2], rkt[2];
   auto fetch = [&](int key0) {
     fetch_rows(rk, kb + (size_t)key0 * p.k_ld, p.k_ld, p.nk - key0, tid);
-    fetch_rows(rv, vb + (size_t)key0 * p.vn_ld, p.vn_ld, p.nk - key0, tid);
-    fetch_rows(rkt, ktb + key0, p.kt_ld, 64, tid);   // zero beyond nk by construction of K^T
+    if constexpr (TR) {
+      fetch_vt_rows(rv, vb, p.vt_ld, key0, p.nk, tid);
+    } else {
+      fetch_rows(rv, vb + (size_t)key0 * p.vn_ld, p.vn_ld, p.nk - key0, tid);
+      fetch_rows(rkt, ktb + key0, p.kt_ld, 64, tid);   // zero beyond nk by construction of K^T
+    }
   };
   fetch(0);
   for (int t = 0; t < ntiles; ++t) {
@@ -731,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
     __syncthreads();
     put_rows(Ks, ATT_LDK, rk, tid);
     put_rows(Vn, ATT_LDK, rv, tid);
-    put_rows(KTs, ATT_LDV, rkt, tid);
+    if constexpr (!TR) put_rows(KTs, ATT_LDV, rkt, tid);
     __syncthreads();
     if (t + 1 < ntiles) fetch(key0 + 64);
     f32x4_t s[4][2], dp[4][2];
@@ -742,7 +797,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
 #pragma unroll
       for (int ds = 0; ds < 2; ++ds) {
         const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Ks + (ik * 16 + lq) * ATT_LDK + ds * 32 + lg * 8));
-        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Vn + (ik * 16 + lq) * ATT_LDK + ds * 32 + lg * 8));
+        bf16x8_t vf;      // V rows of keys ik * 16 + lq: natural tile, or (TR) out of the [d][key] tile
+        if constexpr (TR) vf = tr_frag(Vn, ATT_LDK, ds * 32, ik * 16, lq, lg);
+        else vf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(Vn + (ik * 16 + lq) * ATT_LDK + ds * 32 + lg * 8));
 #pragma unroll
         for (int jq = 0; jq < 2; ++jq) {
           s[ik][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[jq][ds], s[ik][jq], 0, 0, 0);
@@ -797,10 +854,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
       }
 #pragma unroll
       for (int jd = 0; jd < 4; ++jd) {
-        const bf16_t* kr = KTs + (jd * 16 + lq) * ATT_LDV + kk * 32 + lg * 4;
-        const uint2 lo = *reinterpret_cast<const uint2*>(kr);
-        const uint2 hi = *reinterpret_cast<const uint2*>(kr + 16);
-        const bf16x8_t af = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        bf16x8_t af;      // K^T rows d = jd * 16 + lq over the 32 keys of chunk kk
+        if constexpr (TR) {
+          af = tr_frag(Ks, ATT_LDK, kk * 32, jd * 16, lq, lg);
+        } else {
+          const bf16_t* kr = KTs + (jd * 16 + lq) * ATT_LDV + kk * 32 + lg * 4;
+          const uint2 lo = *reinterpret_cast<const uint2*>(kr);
+          const uint2 hi = *reinterpret_cast<const uint2*>(kr + 16);
+          af = __builtin_bit_cast(bf16x8_t, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
 #pragma unroll
         for (int jq = 0; jq < 2; ++jq) o[jd][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, sf[jq], o[jd][jq], 0, 0, 0);
       }
@@ -822,12 +884,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
   }
 }
 
-template <bool FULL, bool PLAIN>
+template <bool FULL, bool PLAIN, bool TR>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * ATT_LDK];     // [query][d]
   __shared__ __attribute__((aligned(16))) bf16_t dOs[64 * ATT_LDK];    // [query][d]
-  __shared__ __attribute__((aligned(16))) bf16_t QTs[64 * ATT_LDV];    // [d][query]
-  __shared__ __attribute__((aligned(16))) bf16_t dOTs[64 * ATT_LDV];   // [d][query]
+  __shared__ __attribute__((aligned(16))) bf16_t QTs[TR ? 8 : 64 * ATT_LDV];    // [d][query]   (TR: read out of Qs / dOs)
+  __shared__ __attribute__((aligned(16))) bf16_t dOTs[TR ? 8 : 64 * ATT_LDV];   // [d][query]
   __shared__ __attribute__((aligned(16))) float lse_s[64];
   __shared__ __attribute__((aligned(16))) float d_s[64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -838,9 +900,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   const bf16_t* qb = p.q + (size_t)b * p.nq * p.q_ld + h * 64;
   const bf16_t* dob = p.dO + (size_t)b * p.nq * p.do_ld + h * 64;
   const bf16_t* kb = p.k + (size_t)b * p.k_rows * p.k_ld + h * 64;
-  const bf16_t* vb = p.vn + (size_t)b * p.vn_rows * p.vn_ld + h * 64;
-  const bf16_t* qtb = p.qt + ((size_t)b * p.heads + h) * 64 * p.qt_ld;
-  const bf16_t* dotb = p.dot + ((size_t)b * p.heads + h) * 64 * p.qt_ld;
+  const bf16_t* vb = TR ? p.vt + ((size_t)b * p.heads + h) * 64 * p.vt_ld : p.vn + (size_t)b * p.vn_rows * p.vn_ld + h * 64;
+  const bf16_t* qtb = TR ? nullptr : p.qt + ((size_t)b * p.heads + h) * 64 * p.qt_ld;
+  const bf16_t* dotb = TR ? nullptr : p.dot + ((size_t)b * p.heads + h) * 64 * p.qt_ld;
   const float* lseb = p.lse + ((size_t)b * p.heads + h) * p.nq;
   const float* dsb = p.dsum + ((size_t)b * p.heads + h) * p.nq;
   const float* fb = FULL ? p.full_bias + ((size_t)(b % p.full_nb) * p.heads + h) * p.nq * p.nk : nullptr;
@@ -854,7 +916,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds) {
       kf[jk][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(kb + (size_t)kc * p.k_ld + ds * 32 + lg * 8));
-      vf[jk][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(vb + (size_t)kc * p.vn_ld + ds * 32 + lg * 8));
+      if constexpr (TR) {   // this key's 8 consecutive d out of V^T [d][key]: 8 strided 2-byte loads, once per workgroup
+        unsigned short e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = vb[(size_t)(ds * 32 + lg * 8 + i) * p.vt_ld + kc];
+        vf[jk][ds] = __builtin_bit_cast(bf16x8_t, make_uint4(e[0] | ((unsigned)e[1] << 16), e[2] | ((unsigned)e[3] << 16),
+                                                               e[4] | ((unsigned)e[5] << 16), e[6] | ((unsigned)e[7] << 16)));
+      } else {
+        vf[jk][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(vb + (size_t)kc * p.vn_ld + ds * 32 + lg * 8));
+      }
     }
     kb2[jk] = key < p.nk ? (p.bias ? p.bias[(size_t)b * p.nk + key] * 1.4426950408889634f : 0.f) : -INFINITY;
   }
@@ -872,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
   auto fetch = [&](int q0) {   // dO^T stays a synchronous stage: a fourth register tile spills the accumulators
     fetch_rows(rq, qb + (size_t)q0 * p.q_ld, p.q_ld, p.nq - q0, tid);
     fetch_rows(rdo, dob + (size_t)q0 * p.do_ld, p.do_ld, p.nq - q0, tid);
-    fetch_rows(rqt, qtb + q0, p.qt_ld, 64, tid);     // zero beyond nq by construction
+    if constexpr (!TR) fetch_rows(rqt, qtb + q0, p.qt_ld, 64, tid);     // zero beyond nq by construction
     if (tid < 64) {
       const bool ok = q0 + tid < p.nq;
       r_lse = ok ? lseb[q0 + tid] : INFINITY;   // exp2(-inf) = 0 for padded queries
@@ -885,8 +955,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
     __syncthreads();
     put_rows(Qs, ATT_LDK, rq, tid);
     put_rows(dOs, ATT_LDK, rdo, tid);
-    put_rows(QTs, ATT_LDV, rqt, tid);
-    stage_rows(dOTs, ATT_LDV, dotb + q0, p.qt_ld, 64, tid);
+    if constexpr (!TR) {
+      put_rows(QTs, ATT_LDV, rqt, tid);
+      stage_rows(dOTs, ATT_LDV, dotb + q0, p.qt_ld, 64, tid);
+    }
     if (tid < 64) {   // PLAIN keeps them negated (and D pre-scaled): operands of the packed FMAs below
       lse_s[tid] = PLAIN ? -r_lse : r_lse;
       d_s[tid] = PLAIN ? -r_d * p.scale : r_d;
@@ -959,12 +1031,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(AttnBwdParams p) {
       }
 #pragma unroll
       for (int jd = 0; jd < 4; ++jd) {
-        const bf16_t* dr = dOTs + (jd * 16 + lq) * ATT_LDV + kk * 32 + lg * 4;
-        const bf16_t* qr = QTs + (jd * 16 + lq) * ATT_LDV + kk * 32 + lg * 4;
-        const uint2 dlo = *reinterpret_cast<const uint2*>(dr), dhi = *reinterpret_cast<const uint2*>(dr + 16);
-        const uint2 qlo = *reinterpret_cast<const uint2*>(qr), qhi = *reinterpret_cast<const uint2*>(qr + 16);
-        const bf16x8_t daf = __builtin_bit_cast(bf16x8_t, make_uint4(dlo.x, dlo.y, dhi.x, dhi.y));
-        const bf16x8_t qaf = __builtin_bit_cast(bf16x8_t, make_uint4(qlo.x, qlo.y, qhi.x, qhi.y));
+        bf16x8_t daf, qaf;    // dO^T / Q^T rows d = jd * 16 + lq over the 32 queries of chunk kk
+        if constexpr (TR) {
+          daf = tr_frag(dOs, ATT_LDK, kk * 32, jd * 16, lq, lg);
+          qaf = tr_frag(Qs, ATT_LDK, kk * 32, jd * 16, lq, lg);
+        } else {
+          const bf16_t* dr = dOTs + (jd * 16 + lq) * ATT_LDV + kk * 32 + lg * 4;
+          const bf16_t* qr = QTs + (jd * 16 + lq) * ATT_LDV + kk * 32 + lg * 4;
+          const uint2 dlo = *reinterpret_cast<const uint2*>(dr), dhi = *reinterpret_cast<const uint2*>(dr + 16);
+          const uint2 qlo = *reinterpret_cast<const uint2*>(qr), qhi = *reinterpret_cast<const uint2*>(qr + 16);
+          daf = __builtin_bit_cast(bf16x8_t, make_uint4(dlo.x, dlo.y, dhi.x, dhi.y));
+          qaf = __builtin_bit_cast(bf16x8_t, make_uint4(qlo.x, qlo.y, qhi.x, qhi.y));
+        }
 #pragma unroll
         for (int jk = 0; jk < 2; ++jk) {
           dv[jd][jk] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(daf, pf[jk], dv[jd][jk], 0, 0, 0);
@@ -1056,12 +1134,14 @@ static ctta_status attention_bwd_impl(const void* q, int q_ld, const void* k, in
                                       const void* dout, int do_ld, const float* lse, float* dsum, void* dq, int dq_ld,
                                       void* dk, int dk_ld, void* dv, int dv_ld, int batch, int heads, int nq, int nk,
                                       float scale, float* partial, int64_t partial_floats, void* stream,
-                                      const float* full_bias, int full_nb) {
-  CTTA_REQUIRE(q && k && vn && kt && qt && dot && out && dout && lse && dsum && dq && dk && dv, "attention_bwd: null pointer");
-  CTTA_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && vn_ld % 8 == 0 && kt_ld % 64 == 0 && qt_ld % 64 == 0 && do_ld % 8 == 0 &&
-                   out_ld % 8 == 0 && dq_ld % 4 == 0 && dk_ld % 4 == 0 && dv_ld % 4 == 0,
+                                      const float* full_bias, int full_nb, const void* vt = nullptr, int vt_ld = 0) {
+  const bool tr = vt != nullptr;      // operands read where they lie (ctta_attention_bwd_inplace)
+  CTTA_REQUIRE(q && k && out && dout && lse && dsum && dq && dk && dv && (tr ? !full_bias : (vn && kt && qt && dot)),
+               "attention_bwd: null pointer");
+  CTTA_REQUIRE(q_ld % 8 == 0 && k_ld % 8 == 0 && do_ld % 8 == 0 && out_ld % 8 == 0 && dq_ld % 4 == 0 && dk_ld % 4 == 0 && dv_ld % 4 == 0 &&
+                   (tr ? (vt_ld % 8 == 0 && vt_ld >= nk) : (vn_ld % 8 == 0 && kt_ld % 64 == 0 && qt_ld % 64 == 0)),
                "attention_bwd: row strides (transposed operands need 64-multiples)");
-  CTTA_REQUIRE(nq > 0 && nk > 0 && k_rows >= nk && vn_rows >= nk && kt_ld >= nk && qt_ld >= nq, "attention_bwd: bad lengths");
+  CTTA_REQUIRE(nq > 0 && nk > 0 && k_rows >= nk && (tr || (vn_rows >= nk && kt_ld >= nk && qt_ld >= nq)), "attention_bwd: bad lengths");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)(((long long)batch * nq + 3) / 4)), dim3(256), 0, s,
                      (const bf16_t*)dout, do_ld, (const bf16_t*)out, out_ld, dsum, batch, heads, nq);
@@ -1074,13 +1154,17 @@ static ctta_status attention_bwd_impl(const void* q, int q_ld, const void* k, in
   p.dq = (bf16_t*)dq; p.dk = (bf16_t*)dk; p.dv = (bf16_t*)dv; p.dq_ld = dq_ld; p.dk_ld = dk_ld; p.dv_ld = dv_ld;
   p.heads = heads; p.nq = nq; p.nk = nk; p.scale = scale; p.scale_log2e = scale * 1.4426950408889634f;
   p.full_bias = full_bias; p.full_nb = full_nb > 0 ? full_nb : 1;
+  p.vt = (const bf16_t*)vt; p.vt_ld = vt_ld;
   const bool prof = ctta_prof_active();
   // executed flops: 7 products of 2*nq*nk*64 per head (S and dP are computed by both kernels)
   if (prof) ctta_prof_begin(1, 1, nq, nk, 448, (long long)batch * heads, s);
   const bool plain = !full_bias && !p.bias && nk % 64 == 0 && nq % 64 == 0 && attn_plain_enabled();   // self-attention over whole tiles
-  if (full_bias) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false>), dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
-  else if (plain) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true>), dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false>), dim3((nq + 127) / 128, batch * heads), dim3(256), 0, s, p);
+  const dim3 gq((nq + 127) / 128, batch * heads);
+  if (full_bias) hipLaunchKernelGGL((attn_bwd_dq_kernel<true, false, false>), gq, dim3(256), 0, s, p);
+  else if (plain && tr) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true, true>), gq, dim3(256), 0, s, p);
+  else if (plain) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, true, false>), gq, dim3(256), 0, s, p);
+  else if (tr) hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false, true>), gq, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dq_kernel<false, false, false>), gq, dim3(256), 0, s, p);
   // few keys (cross-attention): split the query walk so that the launch still fills the chip
   const int ntiles = (nq + 63) / 64, kblocks = (nk + 127) / 128, hp = heads * 64;
   int nz = 1;
@@ -1091,9 +1175,12 @@ static ctta_status attention_bwd_impl(const void* q, int q_ld, const void* k, in
   p.q_tiles_per_split = (ntiles + nz - 1) / nz;
   p.part = nz > 1 ? partial : nullptr;
   p.batch = batch; p.hp = hp;
-  if (full_bias) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false>), dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
-  else if (plain) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true>), dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
-  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false>), dim3(kblocks, batch * heads, nz), dim3(256), 0, s, p);
+  const dim3 gk(kblocks, batch * heads, nz);
+  if (full_bias) hipLaunchKernelGGL((attn_bwd_dkv_kernel<true, false, false>), gk, dim3(256), 0, s, p);
+  else if (plain && tr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true, true>), gk, dim3(256), 0, s, p);
+  else if (plain) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, true, false>), gk, dim3(256), 0, s, p);
+  else if (tr) hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, true>), gk, dim3(256), 0, s, p);
+  else hipLaunchKernelGGL((attn_bwd_dkv_kernel<false, false, false>), gk, dim3(256), 0, s, p);
   if (nz > 1) {
     CTTA_REQUIRE(dk_ld >= hp && dv_ld >= hp, "attention_bwd: split path needs dk/dv rows of at least heads*64");
     const long long total = (long long)batch * nk * hp;
@@ -1114,6 +1201,19 @@ extern "C" ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k
   return attention_bwd_impl(q, q_ld, k, k_ld, k_rows, vn, vn_ld, vn_rows, kt, kt_ld, qt, dot, qt_ld, bias, out, out_ld, dout,
                             do_ld, lse, dsum, dq, dq_ld, dk, dk_ld, dv, dv_ld, batch, heads, nq, nk, scale, partial,
                             partial_floats, stream, nullptr, 1);
+}
+// The same backward with every operand read WHERE IT LIES (round 5): q / k / dout natural, V as the forward keeps it
+// (vt [B][heads*64][vt_ld], what ctta_attention consumes) -- no K^T, Q^T, dO^T or natural-V copies: the kernels take the
+// operands that need the other orientation out of the tiles they stage anyway through transposing LDS reads.
+extern "C" ctta_status ctta_attention_bwd_inplace(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
+                                                  int vt_ld, const float* bias, const void* out, int out_ld, const void* dout,
+                                                  int do_ld, const float* lse, float* dsum, void* dq, int dq_ld, void* dk,
+                                                  int dk_ld, void* dv, int dv_ld, int batch, int heads, int nq, int nk,
+                                                  float scale, float* partial, int64_t partial_floats, void* stream) {
+  CTTA_REQUIRE(vt, "attention_bwd_inplace: null pointer");
+  return attention_bwd_impl(q, q_ld, k, k_ld, k_rows, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, 0, bias, out, out_ld, dout, do_ld,
+                            lse, dsum, dq, dq_ld, dk, dk_ld, dv, dv_ld, batch, heads, nq, nk, scale, partial, partial_floats, stream,
+                            nullptr, 1, vt, vt_ld);
 }
 // Backward of ctta_attention_fullbias (same operands as ctta_attention_bwd; no per-key bias, no split path)
 extern "C" ctta_status ctta_attention_fullbias_bwd(const void* q, int q_ld, const void* k, int k_ld, int k_rows,

@@ -352,7 +352,14 @@ static ctta_status bwd_resnet(BCtx& c, Resnet& R, const bf16_t* dout, bf16_t** d
 // ------------------------------------------------------------------------------ attention
 // q [B][nq][ldq], k [B][krows][ldk] (head h at columns h*64), vt [B][hp][vt_ld]; out / dO [B*nq][hp].
 // Writes dq [B*nq][lddq], dk [B*krows][lddk], dv [B*krows][hp] for keys < nk (head-padded lanes come
-// out zero).  Flash-style: four whole-tensor transposes feed ctta_attention_bwd (no score matrix).
+// out zero).  Flash-style (no score matrix).  Round 5: Q, K, dO are read where they lie and V as the forward keeps it
+// (transposed) -- ctta_attention_bwd_inplace takes the operands it needs in the other orientation out of its own LDS tiles
+// through transposing reads; the four whole-tensor transposes per call of rounds 1-4 (CTTA_ATTN_BWD_INPLACE=0) are gone.
+static bool attn_bwd_inplace_on() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_ATTN_BWD_INPLACE"); v = (e && e[0] == '0') ? 0 : 1; }
+  return v != 0;
+}
 static ctta_status bwd_attention(BCtx& c, int heads, int dh, const bf16_t* q, int ldq, const bf16_t* k, int ldk, int krows,
                                  const bf16_t* vt, int vt_ld, const float* bias, int nq, int nk, const bf16_t* out,
                                  const bf16_t* dO, int hp, const float* lse, bf16_t* dq, int lddq, bf16_t* dk, int lddk,
@@ -361,16 +368,26 @@ static ctta_status bwd_attention(BCtx& c, int heads, int dh, const bf16_t* q, in
   const int B = c.B;
   const int nk64 = round_up(nk, 64), nq64 = round_up(nq, 64);
   const size_t mk = A.mark();
-  bf16_t* vn = A.get<bf16_t>((size_t)B * vt_ld * hp); ALLOC_OR_FAIL(vn);      // V   [B][vt_ld][hp]
-  bf16_t* kt = A.get<bf16_t>((size_t)B * hp * nk64); ALLOC_OR_FAIL(kt);       // K^T [B][hp][nk64]
-  bf16_t* qt = A.get<bf16_t>((size_t)B * hp * nq64); ALLOC_OR_FAIL(qt);       // Q^T
-  bf16_t* dot = A.get<bf16_t>((size_t)B * hp * nq64); ALLOC_OR_FAIL(dot);     // dO^T
+  const bool inplace = attn_bwd_inplace_on() && vt_ld % 8 == 0 && vt_ld >= nk;
+  bf16_t *vn = nullptr, *kt = nullptr, *qt = nullptr, *dot = nullptr;
+  if (!inplace) {
+    vn = A.get<bf16_t>((size_t)B * vt_ld * hp); ALLOC_OR_FAIL(vn);      // V   [B][vt_ld][hp]
+    kt = A.get<bf16_t>((size_t)B * hp * nk64); ALLOC_OR_FAIL(kt);       // K^T [B][hp][nk64]
+    qt = A.get<bf16_t>((size_t)B * hp * nq64); ALLOC_OR_FAIL(qt);       // Q^T
+    dot = A.get<bf16_t>((size_t)B * hp * nq64); ALLOC_OR_FAIL(dot);     // dO^T
+  }
   float* dsum = A.get<float>((size_t)B * heads * nq); ALLOC_OR_FAIL(dsum);
   float* part = nullptr;
   int64_t part_floats = 0;
   if (nk <= 128) {   // cross-attention: room for 32 query splits of the dk/dv kernel
     part_floats = (int64_t)32 * 2 * B * krows * hp;
     part = A.get<float>((size_t)part_floats); ALLOC_OR_FAIL(part);
+  }
+  if (inplace) {
+    RUN(c, ctta_attention_bwd_inplace(q, ldq, k, ldk, krows, vt, vt_ld, bias, out, hp, dO, hp, lse, dsum, dq, lddq, dk, lddk, dv, hp,
+                                      B, heads, nq, nk, 1.0f / sqrtf((float)dh), part, part_floats, c.stream));
+    A.release(mk);
+    return CTTA_OK;
   }
   RUN(c, ctta_transpose_bf16(vt, (int64_t)hp * vt_ld, hp, vt_ld, vt_ld, 0, vn, (int64_t)vt_ld * hp, hp, B, c.stream));
   RUN(c, ctta_transpose_bf16(k, (int64_t)krows * ldk, nk, hp, ldk, 0, kt, (int64_t)hp * nk64, nk64, B, c.stream));

@@ -514,6 +514,14 @@ ctta_status ctta_attention_bwd(const void* q, int q_ld, const void* k, int k_ld,
                                const float* lse, float* dsum, void* dq, int dq_ld, void* dk, int dk_ld,
                                void* dv, int dv_ld, int batch, int heads, int nq, int nk, float scale,
                                float* partial, int64_t partial_floats, void* stream);
+/* The same backward with every operand read where it lies (replaces the four whole-tensor transposes per call that fed
+ * ctta_attention_bwd): q / k / dout as above, vt = V TRANSPOSED exactly as ctta_attention[_lse] took it
+ * ([B][heads*64][vt_ld], vt_ld >= nk, a multiple of 8).  Same results (autograd of attention_processor.py:1127-1129). */
+ctta_status ctta_attention_bwd_inplace(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
+                                       int vt_ld, const float* bias, const void* out, int out_ld, const void* dout,
+                                       int do_ld, const float* lse, float* dsum, void* dq, int dq_ld, void* dk, int dk_ld,
+                                       void* dv, int dv_ld, int batch, int heads, int nq, int nk, float scale,
+                                       float* partial, int64_t partial_floats, void* stream);
 
 /* Window attention of the CLAP audio tower (Swin, laion_clap/clap_module/htsat.py:336-361): the flash kernels above with a
  * FULL additive bias table full_bias_log2 [n_bias_batches][heads][nq][nk] (already multiplied by log2 e; relative-position

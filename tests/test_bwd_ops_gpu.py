@@ -514,3 +514,20 @@ def test_flash_attention_backward(B, heads, dh, nq, nk, krows, use_bias):
     # head-padding lanes stay exactly zero (they feed the projection data-gradient GEMMs)
     if dh < 64:
         assert float(dq[:, :, dh:64].float().abs().max()) == 0.0 and float(dk[:, :nk, dh:64].float().abs().max()) == 0.0
+    # round 5: the same backward with q / k / dout read where they lie and V as the forward took it (no K^T, Q^T, dO^T,
+    # natural-V copies): same MFMA products in the same order -> bit-identical gradients
+    dq2 = torch.full((B, nq, hp), float("nan"), dtype=torch.bfloat16, device=DEV)
+    dk2 = torch.zeros(B, krows, hp, dtype=torch.bfloat16, device=DEV)
+    dv2 = torch.zeros(B, krows, hp, dtype=torch.bfloat16, device=DEV)
+    if vt_ld > nk:
+        vt[:, :, nk:] = float("nan")           # whatever lies beyond the valid keys must never reach a product
+    dsum2 = torch.empty(B, heads, nq, device=DEV)
+    N.check(L.ctta_attention_bwd_inplace(N.ptr(qd), hp, N.ptr(kd), hp, krows, N.ptr(vt), vt_ld, N.ptr(bd), N.ptr(out), hp,
+                                         N.ptr(dod), hp, N.ptr(lse), N.ptr(dsum2), N.ptr(dq2), hp, N.ptr(dk2), hp, N.ptr(dv2), hp,
+                                         B, heads, nq, nk, scale, N.ptr(part), part.numel() if part is not None else 0, st))
+    sync()
+    for name, a, b_ in (("dq", dq2, dq), ("dk", dk2[:, :nk], dk[:, :nk]), ("dv", dv2[:, :nk], dv[:, :nk])):
+        assert bool(torch.isfinite(a.float()).all()), name
+        e = rel_err(a.float().cpu(), b_.float().cpu())
+        print("in-place %s vs transposed-copies route: rel diff %.3e" % (name, e))
+        assert e <= 2e-3, (name, e)     # dP contracts over d in another slot order: fp32 sums differ in the last bits
