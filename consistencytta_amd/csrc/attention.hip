@@ -645,6 +645,11 @@ struct AttnBwdParams {
   // kt / qt / dot / vn are unused
   const bf16_t* vt;
   int vt_ld;
+  // D = rowsum(dO * O) computed by the dq kernel itself (it holds every query's dO row in registers) and written to dsum
+  // for the dkv kernel behind it: no separate row-dot launch (76 launches per distillation step)
+  const bf16_t* o;
+  int o_ld;
+  float* dsum_out;
 };
 
 typedef short att_s16x4_t __attribute__((ext_vector_type(4)));
@@ -761,7 +766,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(AttnBwdParams p) {
       else dof[jq][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(dob + (size_t)qi * p.do_ld + ds * 32 + lg * 8));
     }
     lse_q[jq] = p.lse[((size_t)b * p.heads + h) * p.nq + qi];
-    d_q[jq] = p.dsum[((size_t)b * p.heads + h) * p.nq + qi];
+    if (p.dsum_out) {     // this lane's 16 of the query's 64 products, then the four lane rows (fixed butterfly)
+      const bf16_t* orow = p.o + ((size_t)b * p.nq + qi) * p.o_ld + h * 64;
+      float part = 0.f;
+#pragma unroll
+      for (int ds = 0; ds < 2; ++ds) {
+        bf16x8_t of;
+        if constexpr (TR) of = load_perm8(orow, ds * 32, lg);
+        else of = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(orow + ds * 32 + lg * 8));
+        float a[8], g[8];
+        unpack8(__builtin_bit_cast(uint4, dof[jq][ds]), a);
+        unpack8(__builtin_bit_cast(uint4, of), g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) part += a[e] * g[e];
+      }
+      d_q[jq] = rows_sum(part);
+      if (lg == 0 && q0 + jq * 16 + lq < p.nq) p.dsum_out[((size_t)b * p.heads + h) * p.nq + qi] = d_q[jq];
+    } else {
+      d_q[jq] = p.dsum[((size_t)b * p.heads + h) * p.nq + qi];
+    }
   }
   f32x4_t o[4][2];   // dQ^T accumulators [d block][q block]
 #pragma unroll
@@ -1143,10 +1166,15 @@ static ctta_status attention_bwd_impl(const void* q, int q_ld, const void* k, in
                "attention_bwd: row strides (transposed operands need 64-multiples)");
   CTTA_REQUIRE(nq > 0 && nk > 0 && k_rows >= nk && (tr || (vn_rows >= nk && kt_ld >= nk && qt_ld >= nq)), "attention_bwd: bad lengths");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)(((long long)batch * nq + 3) / 4)), dim3(256), 0, s,
-                     (const bf16_t*)dout, do_ld, (const bf16_t*)out, out_ld, dsum, batch, heads, nq);
-  CTTA_LAUNCH_CHECK();
+  static int fuse_dsum = -1;      // CTTA_ATTN_FUSE_DSUM=0: the separate row-dot launch of rounds 1-4 (A/B switch)
+  if (fuse_dsum < 0) { const char* e = getenv("CTTA_ATTN_FUSE_DSUM"); fuse_dsum = (e && e[0] == '0') ? 0 : 1; }
+  if (!fuse_dsum) {
+    hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)(((long long)batch * nq + 3) / 4)), dim3(256), 0, s,
+                       (const bf16_t*)dout, do_ld, (const bf16_t*)out, out_ld, dsum, batch, heads, nq);
+    CTTA_LAUNCH_CHECK();
+  }
   AttnBwdParams p;
+  p.o = (const bf16_t*)out; p.o_ld = out_ld; p.dsum_out = fuse_dsum ? dsum : nullptr;
   p.q = (const bf16_t*)q; p.k = (const bf16_t*)k; p.vn = (const bf16_t*)vn; p.kt = (const bf16_t*)kt;
   p.qt = (const bf16_t*)qt; p.dot = (const bf16_t*)dot; p.dO = (const bf16_t*)dout;
   p.q_ld = q_ld; p.k_ld = k_ld; p.k_rows = k_rows; p.vn_ld = vn_ld; p.vn_rows = vn_rows; p.kt_ld = kt_ld; p.qt_ld = qt_ld;

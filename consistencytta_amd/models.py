@@ -968,6 +968,7 @@ class _DistillStepGraph:
         for i, k in enumerate(("z0", "noise", "z_in", "tgt_in")):
             S[k] = flat[i * nz:(i + 1) * nz].view(z_shape)
         small = flat[4 * nz:].view(11, B)
+        S["small"] = small
         S["t_np1"], S["t_n"], S["w"] = small[0], small[1], small[2]
         S["sig"] = [small[3 + i] for i in range(8)]
         return S
@@ -1051,11 +1052,9 @@ class _DistillStepGraph:
         host[2].copy_(guidance_scale.detach().to("cpu", torch.float32).reshape(-1).expand(B))
         for i, s_ in enumerate(plan):
             host[3 + i].copy_(torch.from_numpy(np.asarray(s_, dtype=np.float32).reshape(-1)))
-        S["t_np1"].copy_(host[0], non_blocking=True)
-        S["t_n"].copy_(host[1], non_blocking=True)
-        S["w"].copy_(host[2], non_blocking=True)
-        for i in range(len(plan)):
-            S["sig"][i].copy_(host[3 + i], non_blocking=True)
+        # ONE host -> device copy: the pinned block has the layout of the set's (11, B) scalar block (round 4 issued eleven
+        # copies, ~65 us apart on the stream: 1.4 ms per unpipelined step by the idle-gap table of profiles/gaps_distill_r04.txt)
+        S["small"].copy_(host, non_blocking=True)
         if self.pipelined:
             self._ev_h2d.record()
 

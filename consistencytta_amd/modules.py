@@ -130,6 +130,35 @@ class _ParamTree(nn.Module):
         lo, hi = g.data_ptr(), g.data_ptr() + g.numel() * 4
         return all(p.grad is not None and lo <= p.grad.data_ptr() < hi for p in self.parameters() if p.requires_grad)
 
+    def grads_alias_flat_sampled(self, k=8):
+        """The per-step form of `grads_alias_flat` (called by FusedAdamW.step): the first and the last trainable parameter
+        plus `k` more, rotating from call to call.  What breaks the aliasing in practice -- `zero_grad(set_to_none=True)`
+        followed by a backward that allocates fresh gradients -- breaks it for EVERY parameter and is seen by the very
+        next call; a single hand-assigned `p.grad` is seen within n / k calls.  The full walk costs 690 `p.grad` look-ups =
+        1.5-3 ms of host time per optimizer step, more than the AdamW kernel itself on a slow host (round 4: 3.48 vs
+        2.78 ms for the same launch on two boxes -- it was this walk inside the timed bracket)."""
+        g = getattr(self, "_flat_grad", None)
+        if g is None:
+            return False
+        tr = getattr(self, "_trainable_cache", None)
+        if tr is None or tr[0] != getattr(self, "_rehome_count", 0):
+            tr = self._trainable_cache = (getattr(self, "_rehome_count", 0), [p for p in self.parameters() if p.requires_grad])
+            self._alias_cursor = 0
+            return self.grads_alias_flat()
+        ps = tr[1]
+        n = len(ps)
+        if n == 0:
+            return True
+        lo, hi = g.data_ptr(), g.data_ptr() + g.numel() * 4
+        cur = self._alias_cursor
+        idx = [0, n - 1] + [(cur + i) % n for i in range(k)]
+        self._alias_cursor = (cur + k) % n
+        for i in idx:
+            gr = ps[i].grad
+            if gr is None or not (lo <= gr.data_ptr() < hi):
+                return False
+        return True
+
     def realias_grads_(self):
         """Points every trainable `p.grad` back at its slice of the flat gradient buffer (after set_to_none)."""
         g = getattr(self, "_flat_grad", None)

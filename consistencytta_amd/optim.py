@@ -48,7 +48,7 @@ class FusedAdamW:
         if not self.module.flat_is_current() or self.module._flat is not self.flat:
             raise N.CttaError("FusedAdamW: the module's parameters no longer alias the flat buffer this optimizer "
                               "was built on (model.to()/.float() after prepare_training?) -- build a new optimizer")
-        if not self.module.grads_alias_flat():
+        if not self.module.grads_alias_flat_sampled():
             self.module.realias_grads_()
             raise N.CttaError("FusedAdamW: parameter gradients were not views of the flat gradient buffer (zero_grad("
                               "set_to_none=True) + a foreign backward?); they have been re-aliased -- redo the backward")
