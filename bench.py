@@ -724,6 +724,9 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             du.barrier(dev)
             return du.max_over_ranks(time.perf_counter() - t0, dev)
         pipe_on = os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0"
+        # CTTA_BENCH_DISTILL_FORMS (profiling aid): which replayed forms are timed -- seg, segpipe, graph, pipe; "accum" keeps the
+        # accumulation legs.  Default: all.  One form per rocprofv3 run gives a kernel table that belongs to ONE launch form.
+        forms = set(os.environ.get("CTTA_BENCH_DISTILL_FORMS", "seg,segpipe,graph,pipe,accum").split(","))
         pipe_txt = ("; the frozen teacher's two CFG queries + Heun step run as their own hipGraph on a second stream for batch "
                     "i + 1 beside the student / target / backward work of batch i (every timed step holds one teacher phase, "
                     "one target forward, one student forward + backward, AdamW, EMA)")
@@ -733,23 +736,25 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         launch_seg = ("8 hipGraph replays per micro-step (forward + loss + the first bucket's blocks | one graph per further "
                       "bucket of the gradient all-reduce, which is issued between replays) + eager AdamW / zero_grad / EMA")
         try:
-            dt_seg = timed_graph(True)
-            if world > 1 and dt_seg < dt:
-                dt, launch_mode = dt_seg, launch_seg
+            if "seg" in forms or world > 1:
+                dt_seg = timed_graph(True)
+                if world > 1 and dt_seg < dt:
+                    dt, launch_mode = dt_seg, launch_seg
         except _LegSkipped as exc:
             launch_mode = "eager launches (segmented replay skipped: %s)" % exc
-        if pipe_on and dt_seg is not None:   # what the data-parallel step runs: segmented (bucket all-reduce between replays) AND pipelined
+        if pipe_on and (dt_seg is not None or "seg" not in forms) and ("segpipe" in forms or world > 1):   # what the data-parallel step runs: segmented (bucket all-reduce between replays) AND pipelined
             try:
                 dt_seg_pipe = timed_graph(True, True)
                 if world > 1 and dt_seg_pipe < dt:
                     dt, launch_mode = dt_seg_pipe, launch_seg + pipe_txt
             except _LegSkipped as exc:
                 launch_mode += " (segmented + pipelined replay skipped: %s)" % exc
-        if world == 1:
+        if world == 1 and ("graph" in forms or "pipe" in forms):
             try:
-                dt = dt_graph = timed_graph(False)
+                if "graph" in forms:
+                    dt = dt_graph = timed_graph(False)
                 launch_mode = "one hipGraph replay per micro-step (forward + backward + loss) + eager AdamW / zero_grad / EMA"
-                if pipe_on:
+                if pipe_on and "pipe" in forms:
                     try:
                         dt_pipe = timed_graph(False, True)
                         if dt_pipe < dt:
@@ -826,6 +831,9 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     # train.sh:33's recipe accumulates 5 micro-batches per optimizer step (SURVEY 8d "grad-accum 1 and 5"): 4 local
     # micro-steps (loss + backward, DDP no_sync) and a 5th that also all-reduces, steps AdamW and updates the EMAs
     acc, n_opt = 5, max(2, args.steps // 5)
+    if "accum" not in set(os.environ.get("CTTA_BENCH_DISTILL_FORMS", "accum").split(",")):     # profiling aid: no accumulation legs
+        del m, opt
+        return out
     m._micro = 0
     for _ in range(acc):
         m.train_step(z0, P, opt, sched, accumulation_steps=acc)

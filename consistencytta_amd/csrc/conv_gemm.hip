@@ -251,6 +251,9 @@ static const Variant kVariants[] = {
     VARIANT(128, 128, 64, 2, 2, 2, 3),  // 38  workgroup is ~1.1 us per K step whatever the tile)
     VARIANT(128, 64, 64, 2, 2, 2, 3),   // 39
     VARIANT(128, 128, 64, 2, 2, 2, 4),  // 40
+    VARIANT(64, 128, 64, 1, 4, 4, 3),   // 41  MODE 4: weights straight from L2 into the MFMA fragment registers (pixels through the ring)
+    VARIANT(64, 128, 64, 2, 2, 4, 3),   // 42
+    VARIANT(128, 128, 64, 2, 2, 4, 3),  // 43
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -283,6 +286,11 @@ static bool tile_rules_r5() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("CTTA_TILE_RULES_R5"); v = (e && e[0] == '0') ? 0 : 1; }
   return v != 0;
+}
+static int splitk_min_nk() {   // K tiles from which a launch with few output tiles is split over K (CTTA_SPLITK_MIN_NK, tuning knob)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("CTTA_SPLITK_MIN_NK"); v = e ? atoi(e) : 32; }
+  return v;
 }
 static int xcd_slab_default() {   // CTTA_XCD_SLAB: 0 = off, 1 (default) = split-K launches + few-row-tile launches, 2 = split-K launches only
   static int v = -1;
@@ -538,7 +546,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
                  "conv_gemm: the fused GEGLU epilogue needs a tile with <= 8 fragments per wave (or, wide-store, <= 16): got %s",
                  gv.name);
   }
-  CTTA_REQUIRE(kVariants[vid - 1].mode != 2 || fast_ok(kVariants[vid - 1].bk),
+  CTTA_REQUIRE((kVariants[vid - 1].mode != 2 && kVariants[vid - 1].mode != 4) || fast_ok(kVariants[vid - 1].bk),
                "conv_gemm: variant %s needs (c0+c1) %% BK == 0, one source and <= 32 taps", kVariants[vid - 1].name);
   const Variant& v = kVariants[vid - 1];
   if (!conv_wide_f32_ok(v.bm, v.bn, v.bk, v.wm, v.wn, v.mode, v.stages)) p.wide_f32 = 0;
@@ -559,13 +567,16 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   static int tiles_gate = -1;   // launches with fewer tiles than this are split over K (CTTA_SPLITK_TILES, tuning knob)
   if (tiles_gate < 0) { const char* e = getenv("CTTA_SPLITK_TILES"); tiles_gate = e ? atoi(e) : 192; }
   if (splitk_default() && groups == 1 && !scalar_store && !geglu && d->out_limit == 0 && d->out_offset == 0 &&
-      tiles < tiles_gate && p.nk >= 32 && (ws = splitk_workspace(&ws_bytes)) != nullptr) {
+      tiles < tiles_gate && p.nk >= splitk_min_nk() && (ws = splitk_workspace(&ws_bytes)) != nullptr) {
     static int target = -1, cap = -1;   // tuning knobs: workgroups aimed for / most splits
     if (target < 0) { const char* e = getenv("CTTA_SPLITK_TARGET"); target = e ? atoi(e) : 512; }
     if (cap < 0) { const char* e = getenv("CTTA_SPLITK_MAX"); cap = e ? atoi(e) : 8; }
     splits = (int)(target / tiles);
     if (splits > cap) splits = cap;
-    if (splits > p.nk / 8) splits = p.nk / 8;
+    static int min_steps = -1;   // K tiles every split keeps at least (CTTA_SPLITK_MIN_STEPS)
+    if (min_steps < 0) { const char* e = getenv("CTTA_SPLITK_MIN_STEPS"); min_steps = e ? atoi(e) : 8; if (min_steps < 1) min_steps = 1; }
+    if (splits > p.nk / min_steps) splits = p.nk / min_steps;
+    if (splits < 1) splits = 1;
     const int ld = (d->n + 3) / 4 * 4;
     if ((long long)splits * M * ld * 4 > (long long)ws_bytes) splits = 1;
   }

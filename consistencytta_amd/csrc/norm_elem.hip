@@ -1026,9 +1026,60 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
   }
 }
 
+// The same softmax with the row held in registers: NV float4 per thread (cols = 1024 * NV), ONE read of the fp32 scores
+// (the three-pass form above re-reads the 16 KB row from L2 twice and evaluates every exponential twice).  Same operation
+// order per element (max -> exp(s * scale - max * scale) -> sum -> * 1 / sum), same reduction trees: bit-identical output.
+template <int NV>
+__global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __restrict__ s, bf16_t* __restrict__ p,
+                                                               float scale) {
+  __shared__ float red[8];
+  const long long row = blockIdx.x;
+  constexpr int cols = NV * 1024;
+  const float* sr = s + (size_t)row * cols;
+  bf16_t* pr = p + (size_t)row * cols;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(sr + tid * 4 + i * 1024);
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) mx = fmaxf(fmaxf(mx, v[i].x), fmaxf(v[i].y, fmaxf(v[i].z, v[i].w)));
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    v[i].x = __expf(v[i].x * scale - mx); v[i].y = __expf(v[i].y * scale - mx);
+    v[i].z = __expf(v[i].z * scale - mx); v[i].w = __expf(v[i].w * scale - mx);
+    sum += v[i].x + v[i].y + v[i].z + v[i].w;
+  }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    uint2 o;
+    o.x = pack2bf(v[i].x * inv, v[i].y * inv);
+    o.y = pack2bf(v[i].z * inv, v[i].w * inv);
+    *reinterpret_cast<uint2*>(pr + tid * 4 + i * 1024) = o;
+  }
+}
+
 extern "C" ctta_status ctta_softmax_rows(const float* s, void* p, int64_t rows, int cols, float scale,
                                          void* stream) {
   CTTA_REQUIRE(s && p && cols % 4 == 0 && scale > 0.f, "softmax_rows: bad arguments");
+  static int reg = -1;     // CTTA_SOFTMAX_REG=0: the three-pass kernel of rounds 1-4 (A/B switch)
+  if (reg < 0) { const char* e = getenv("CTTA_SOFTMAX_REG"); reg = (e && e[0] == '0') ? 0 : 1; }
+  if (reg && (cols == 4096 || cols == 2048 || cols == 1024)) {
+    if (cols == 4096) hipLaunchKernelGGL((softmax_rows_reg_kernel<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, scale);
+    else if (cols == 2048) hipLaunchKernelGGL((softmax_rows_reg_kernel<2>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, scale);
+    else hipLaunchKernelGGL((softmax_rows_reg_kernel<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, scale);
+    CTTA_LAUNCH_CHECK();
+    return CTTA_OK;
+  }
   hipLaunchKernelGGL(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s,
                      (bf16_t*)p, cols, scale);
   CTTA_LAUNCH_CHECK();

@@ -99,6 +99,10 @@ def main():
         gaps.sort()
         med = gaps[len(gaps) // 2] / 1e3 if gaps else 0.0
         out.append("%6d x %8.3f ms %8.1f us  gap %6.1f us  %s" % (n, t / 1e6, t / n / 1e3, med, k))
+    out.append("")
+    out.append("the same by total time:")
+    for k, (n, t, gaps) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:60]:
+        out.append("%6d x %8.3f ms %8.1f us  %s" % (n, t / 1e6, t / n / 1e3, k))
     open(sys.argv[2], "w").write("\n".join(out) + "\n")
     print("\n".join(out[:60]))
 
