@@ -251,9 +251,6 @@ static const Variant kVariants[] = {
     VARIANT(128, 128, 64, 2, 2, 2, 3),  // 38  workgroup is ~1.1 us per K step whatever the tile)
     VARIANT(128, 64, 64, 2, 2, 2, 3),   // 39
     VARIANT(128, 128, 64, 2, 2, 2, 4),  // 40
-    VARIANT(64, 128, 64, 1, 4, 4, 3),   // 41  MODE 4: weights straight from L2 into the MFMA fragment registers (pixels through the ring)
-    VARIANT(64, 128, 64, 2, 2, 4, 3),   // 42
-    VARIANT(128, 128, 64, 2, 2, 4, 3),  // 43
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -520,7 +517,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       // 2.25 rounds of 512 slots where the 2-stage tile has 768) lose 2.3 ms of the distillation step with it, so the rule
       // looks at the round fill, like the tile rules above (A/B of round 3: tools/r3_probe26.sh; CTTA_THIN_RING=0: off).
     static int ring = -1;
-    if (ring < 0) { const char* e = getenv("CTTA_THIN_RING"); ring = (e && e[0] == '0') ? 0 : 1; }
+    if (ring < 0) { const char* e = getenv("CTTA_THIN_RING"); ring = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1; }
     // (the same move for the 128x128x64 tile -- 128x128x32 with a 3-stage ring, 48 KB -- measured slower at batch 32 and 16:
     // 25.4 vs 24.8 ms and 14.7 vs 14.5 ms per U-Net forward, tools/r3_probe35.sh)
     if (ring && tile_rules_r3() && d->tile <= 0 && vid == 22 && K >= 4096 && !geglu) {
@@ -535,7 +532,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
         if (sp > 1) wgs *= sp;
       }
       const long long rounds = (wgs + 511) / 512;
-      if ((wgs >= 512 && wgs * 100 >= rounds * 512 * 85) || (thin_ring && wgs > 384 && wgs <= 512)) vid = 27;
+      if ((wgs >= 512 && wgs * 100 >= rounds * 512 * 85) || (thin_ring && wgs > 384 && wgs <= 512)) vid = ring == 2 ? 17 : 27;   // CTTA_THIN_RING=2: 128x128x64 instead (A/B)
     }
   }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
@@ -546,7 +543,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
                  "conv_gemm: the fused GEGLU epilogue needs a tile with <= 8 fragments per wave (or, wide-store, <= 16): got %s",
                  gv.name);
   }
-  CTTA_REQUIRE((kVariants[vid - 1].mode != 2 && kVariants[vid - 1].mode != 4) || fast_ok(kVariants[vid - 1].bk),
+  CTTA_REQUIRE(kVariants[vid - 1].mode != 2 || fast_ok(kVariants[vid - 1].bk),
                "conv_gemm: variant %s needs (c0+c1) %% BK == 0, one source and <= 32 taps", kVariants[vid - 1].name);
   const Variant& v = kVariants[vid - 1];
   if (!conv_wide_f32_ok(v.bm, v.bn, v.bk, v.wm, v.wn, v.mode, v.stages)) p.wide_f32 = 0;
@@ -598,7 +595,9 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       grid.x -= 1;
     }
   }
-  if (splits == 1 && groups == 1 && xcd_default() && grid.x >= 64) {
+  // (launches whose weights outweigh their activations take the weight-slab mapping below instead, whatever their row tiles)
+  const bool slab_pref = xcd_slab_default() == 1 && groups == 1 && grid.y >= 2 && w_bytes > x_bytes && tail_rows == 0;
+  if (splits == 1 && groups == 1 && xcd_default() && grid.x >= 64 && !slab_pref) {
     p.m_tiles = (int)grid.x; p.n_tiles = (int)grid.y;
     p.xcd_per = (p.m_tiles + 7) / 8;
     // few N tiles: visit them back to back per M tile (the input tile is read once per XCD); many N tiles (wide

@@ -26,7 +26,6 @@
 #include <stdlib.h>
 
 #include "conv_epilogue.h"
-#include <type_traits>
 
 // MODE 0: register-staged tiles (supports in_act).  MODE 1: direct-to-LDS, generic gather (per-lane
 // global pointers, zero page).  MODE 2: direct-to-LDS through BUFFER descriptors with the address
@@ -214,15 +213,12 @@ __device__ __forceinline__ void epilogue_geglu(const ConvParams& p, const f32x4_
 template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p) {
   constexpr bool GLDS = MODE != 0;
-  // MODE 4 (round 5): MODE 2's descriptor path for the PIXEL operand; the WEIGHT operand never touches LDS -- a packed weight
-  // row is K-contiguous, so the 16 bytes a lane needs for its MFMA fragment (row n0 + .. + lane % 16, K chunk lane / 16) are
-  // one global load straight from L2 into the fragment register.  The thin launches are bound by the CU's global -> LDS
-  // rate (~30 B/clk/CU whatever the tile, tools/thin_timeline.py), and two thirds of a 64x128 tile's LDS-DMA bytes are
-  // weights: this takes them off that path (and off the LDS read path).  The loads are inline asm with hand-counted
-  // vmcnt (beside LDS-DMA the compiler waits vmcnt(0) for any register-destination load, which would drain the ring).
-  constexpr bool FAST = MODE == 2 || MODE == 4;
-  constexpr bool WREG = MODE == 4;
-  static_assert(!WREG || STAGES == 3, "MODE 4 is written for the 3-stage ring");
+  // (Round 5 built and removed a MODE 4 -- the pixel operand through the LDS-DMA ring, the WEIGHT operand straight from L2 into
+  // the MFMA fragment registers: a packed weight row is K-contiguous, a lane's 16 bytes are its fragment; inline-asm
+  // global_load_dwordx4 with hand-counted vmcnt, parity-green.  It takes two thirds of a 64x128 tile's bytes off the global ->
+  // LDS path that bounds the thin launches -- and runs at 0.3-0.6x the LDS-DMA tiles on every shape
+  // (profiles/sweep_r05_mode4.txt): a fragment load touches 16 rows x 64 bytes, a quarter of the rate of full-line DMA.)
+  constexpr bool FAST = MODE == 2;
   static_assert(STAGES == 2 || GLDS, "multi-stage ring needs the direct-to-LDS path");
   constexpr int NT = 64 * WM * WN;
   constexpr int LDK = BK;              // bf16 elements per LDS row: no padding, XOR-swizzled chunks
@@ -493,7 +489,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       fmask[i] = mask;
     }
   };
-  int w_soff = 0;
   auto issue_fast = [&](int kt, int buf) {
     bf16_t* xs = Xs + buf * BM * LDK + wave_u * ROWS_PER_INSTR * LDK;
     bf16_t* ws = Ws + buf * BN * LDK + wave_u * ROWS_PER_INSTR * LDK;
@@ -517,13 +512,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
                                                (int)v, 0, 0, 0);
     }
     const int soff = (ftap * p.ct + fcb) * 2;   // weight columns stay (tap, channel)-ordered; only the walk changes
-    w_soff = soff;                               // MODE 4: the weight fragments of this K tile are loaded by load_w()
-    if constexpr (!WREG) {
 #pragma unroll
-      for (int j = 0; j < WP; ++j)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ws + j * RPP * LDK), 16,
-                                                 (int)fwoff[j], soff, 0, 0);
-    }
+    for (int j = 0; j < WP; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ws + j * RPP * LDK), 16,
+                                               (int)fwoff[j], soff, 0, 0);
     ++ftap;
     if (++fkw == p.kw) { fkw = 0; ++fkh; }
     if (ftap == p.taps) { ftap = 0; fkh = 0; fkw = 0; fcb += BK; }
@@ -560,73 +552,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     }
   };
 
-  if constexpr (WREG) {
-    constexpr int KS = BK / 32;
-    static_assert(KS == 2, "MODE 4: BK = 64");
-    constexpr int LPT = XP + FN * KS;            // vmcnt events per wave per K tile: pixel LDS-DMA + weight fragment loads
-    typedef unsigned wq_t __attribute__((ext_vector_type(4)));     // a native vector: asm operands cannot tie a struct type
-    wq_t wq[3][FN][KS];                          // three register stages of this wave's weight fragments
-    unsigned wvoff[FN];
-#pragma unroll
-    for (int i = 0; i < FN; ++i) {
-      int n = n0 + wn * TN + i * 16 + frow;
-      n = n < p.n ? n : p.n - 1;                 // rows past N are computed on a duplicate and never stored
-      wvoff[i] = (unsigned)n * (unsigned)p.k_pad * 2u + (unsigned)fchunk * 16u;      // bytes (< 4 GB: checked by the host)
-    }
-    // (plain lambdas with a literal stage at every call site: variables that appear only in inline-asm operands are not
-    // captured by a GENERIC lambda; after inlining the stage index is a constant and wq stays in registers)
-    auto load_w = [&](const int U) __attribute__((always_inline)) {
-      const unsigned char* wk = reinterpret_cast<const unsigned char*>(wbase) + w_soff;     // wave-uniform
-#pragma unroll
-      for (int i = 0; i < FN; ++i) {
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(wq[U][i][0]) : "v"(wvoff[i]), "s"(wk) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:64" : "=v"(wq[U][i][1]) : "v"(wvoff[i]), "s"(wk) : "memory");
-      }
-    };
-    // the wait names the stage's registers as in/out operands: everything that reads them is ordered behind it
-    auto wait_w = [&](const int U, bool more_in_flight) __attribute__((always_inline)) {
-      if (more_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPT) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < FN; ++i) asm volatile("" : "+v"(wq[U][i][0]), "+v"(wq[U][i][1]));
-    };
-    auto compute_w = [&](const int U) __attribute__((always_inline)) {
-      const bf16_t* xs = Xs + U * BM * LDK + (wm * TM + frow) * LDK;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        bf16x8_t bfr[FM];
-        const int koff = (((ks * 4 + fchunk) ^ fswz) & SWZ_MASK) * 8;
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-          bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xs + j * 16 * LDK + koff));
-#pragma unroll
-        for (int i = 0; i < FN; ++i) {
-          const bf16x8_t af = __builtin_bit_cast(bf16x8_t, wq[U][i][ks]);
-#pragma unroll
-          for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bfr[j], acc[i][j], 0, 0, 0);
-        }
-      }
-    };
-    int issued = 0;
-    issue_fast(kt_begin, 0); load_w(0); full_masks(); issued = 1;
-    if (nk > 1) { issue_fast(kt_begin + 1, 1); load_w(1); issued = 2; }
-    auto step = [&](const int U, int kt) __attribute__((always_inline)) {
-      if (kt >= nk) return;
-      wait_w(U, issued - kt - 1 >= 1);
-      __builtin_amdgcn_s_barrier();              // tile kt landed for every wave; slot (U + 2) % 3 is free
-      if (issued < nk) {
-        issue_fast(kt_begin + issued, (U + 2) % 3);
-        load_w((U + 2) % 3);
-        ++issued;
-      }
-      if (wave_live) compute_w(U);
-    };
-    for (int kt = 0; kt < nk; kt += 3) {
-      step(0, kt);
-      step(1, kt + 1);
-      step(2, kt + 2);
-    }
-  } else if constexpr (STAGES > 2) {
+  if constexpr (STAGES > 2) {
     constexpr int LPT = XP + WP;                 // LDS-DMA instructions per wave per tile
     constexpr int INFLIGHT = (STAGES - 2) * LPT; // what may stay outstanding while tile kt is consumed
     int issued = 0;
@@ -1039,10 +965,7 @@ ctta_status prepare_variant() {
   X(64, 128, 64, 2, 2, 2, 4) \
   X(128, 128, 64, 2, 2, 2, 3) \
   X(128, 64, 64, 2, 2, 2, 3) \
-  X(128, 128, 64, 2, 2, 2, 4) \
-  X(64, 128, 64, 1, 4, 4, 3) \
-  X(64, 128, 64, 2, 2, 4, 3) \
-  X(128, 128, 64, 2, 2, 4, 3)
+  X(128, 128, 64, 2, 2, 2, 4)
 #define CTTA_CONV_VARIANTS_ALL(X) CTTA_CONV_VARIANTS_8(X) CTTA_CONV_VARIANTS_1(X) CTTA_CONV_VARIANTS_2(X) CTTA_CONV_VARIANTS_3(X) CTTA_CONV_VARIANTS_4(X) CTTA_CONV_VARIANTS_5(X) CTTA_CONV_VARIANTS_6(X) CTTA_CONV_VARIANTS_7(X)
 #define CTTA_CONV_INSTANTIATE(BM, BN, BK, WM, WN, G, S)                                      \
   template void launch_variant<BM, BN, BK, WM, WN, G, S>(const ConvParams&, dim3, hipStream_t); \

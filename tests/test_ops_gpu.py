@@ -65,7 +65,7 @@ def _conv_case(B, Cin, H, W, Cout, k, stride, pad, tile=0, upsample=False, c_spl
     return rel_err(from_nhwc(out), ref)
 
 
-@pytest.mark.parametrize("tile", list(range(0, 44)))
+@pytest.mark.parametrize("tile", list(range(0, 41)))
 def test_conv3x3_all_tiles(tile):
     assert _conv_case(2, 64, 24, 16, 96, 3, 1, 1, tile=tile, tag="t%d" % tile) < BF16_TOL
 
@@ -79,7 +79,7 @@ def test_conv_shapes():
     assert _conv_case(3, 256, 4, 2, 256, 3, 1, 1, tag="deepk") < BF16_TOL        # K = 2304
 
 
-@pytest.mark.parametrize("tile", [0, 9, 17, 18, 22, 24, 27, 29, 31, 32, 37, 38, 41, 42, 43])
+@pytest.mark.parametrize("tile", [0, 9, 17, 18, 22, 24, 27, 29, 31, 32, 37, 38])
 def test_conv_geometries_on_direct_to_lds_paths(tile):
     """Upsample-fused, stride-2, ragged and deep-K geometries through the generic (mode 1) and
     descriptor (mode 2) direct-to-LDS paths (Cin multiples of 64 so that mode 2 is eligible)."""
