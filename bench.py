@@ -278,7 +278,8 @@ def main():
         "stage_stream_placement_ms": placement_gen,
     }
 
-    if rank == 0:
+    minimal = os.environ.get("CTTA_BENCH_MINIMAL", "0") == "1"   # profiling aid: the timed loops only (a kernel table with a known step count)
+    if rank == 0 and not minimal:
         # ---- per-stage split (HIP events on the current stream)
         # median of five eager passes (one pass is +-2 ms on the U-Net's ~500 launches; round 3 reported single passes)
         passes = []
@@ -370,8 +371,10 @@ def main():
         if td and conv_cnt:   # per launch like `achieved`: HBM-side bytes of the family per step / its launches per step
             result["roofline"]["traffic"] = int((td["read_GB_per_step"] + td["write_GB_per_step"]) * 1e9 / conv_cnt)
             result["roofline"]["traffic_unit"] = ("bytes per conv_gemm launch (PMC FETCH_SIZE x2 + WRITE_SIZE of the family "
-                                                  "per step / launches per step); algorithmic operand bytes per launch: %d"
-                                                  % int(GB_CLIP_FUSED * 1e9 * B / conv_cnt))
+                                                  "per step / launches per step) -- the counter bytes are READ FROM THE COMMITTED %s "
+                                                  "(two separate rocprofv3 --pmc passes over this command: counters cannot be collected "
+                                                  "inside the timed run), the launch count is this run's; algorithmic operand bytes per "
+                                                  "launch: %d" % (td.get("source"), int(GB_CLIP_FUSED * 1e9 * B / conv_cnt)))
         # ---- the HBM-bound kernel class of the clip: GroupNorm + SiLU at the two largest layer shapes,
         # priced on the layer-boundary bytes (read x once, write y once; the statistics pass re-reads x)
         def gn_pass(tag, HW, C):
@@ -640,7 +643,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     def fixed_draw_loss():
         """The consistency loss of ONE fixed draw (timesteps, noise, guidance scales) with the weights as they are now: the
         per-step losses use fresh random timesteps, so first-vs-last of those is noise; this pair is comparable."""
-        if perceptual:
+        if perceptual or args.no_latency:      # (--no-latency = the PMC passes: training steps only in the trace)
             return None
         gfx = torch.Generator().manual_seed(4242 + rank)
         ti = torch.randint(0, 17, (B,), generator=gfx) * 2
@@ -726,7 +729,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         pipe_on = os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0"
         # CTTA_BENCH_DISTILL_FORMS (profiling aid): which replayed forms are timed -- seg, segpipe, graph, pipe; "accum" keeps the
         # accumulation legs.  Default: all.  One form per rocprofv3 run gives a kernel table that belongs to ONE launch form.
-        forms = set(os.environ.get("CTTA_BENCH_DISTILL_FORMS", "seg,segpipe,graph,pipe,accum").split(","))
+        forms = set(os.environ.get("CTTA_BENCH_DISTILL_FORMS", "seg,segpipe,graph,pipe,accum").split(","))   # "eager": none of them
         pipe_txt = ("; the frozen teacher's two CFG queries + Heun step run as their own hipGraph on a second stream for batch "
                     "i + 1 beside the student / target / backward work of batch i (every timed step holds one teacher phase, "
                     "one target forward, one student forward + backward, AdamW, EMA)")
@@ -831,28 +834,31 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     # train.sh:33's recipe accumulates 5 micro-batches per optimizer step (SURVEY 8d "grad-accum 1 and 5"): 4 local
     # micro-steps (loss + backward, DDP no_sync) and a 5th that also all-reduces, steps AdamW and updates the EMAs
     acc, n_opt = 5, max(2, args.steps // 5)
-    if "accum" not in set(os.environ.get("CTTA_BENCH_DISTILL_FORMS", "accum").split(",")):     # profiling aid: no accumulation legs
+    forms_env = set(os.environ.get("CTTA_BENCH_DISTILL_FORMS", "accum").split(","))
+    accum_on = "accum" in forms_env                      # profiling aids: "eager" / "pipe" ... alone = no accumulation legs
+    if "eager" in forms_env and len(forms_env) == 1:     # ... and "eager" alone ends here: a kernel table of the main loop only
         del m, opt
         return out
-    m._micro = 0
-    for _ in range(acc):
-        m.train_step(z0, P, opt, sched, accumulation_steps=acc)
-    du.barrier(dev)
-    t0 = time.perf_counter()
-    for _ in range(acc * n_opt):
-        losses.append(m.train_step(z0, P, opt, sched, accumulation_steps=acc))
-    du.barrier(dev)
-    dt5 = du.max_over_ranks(time.perf_counter() - t0, dev)
-    m._micro = 0
-    assert all(v == v for v in losses), "NaN distillation loss"
-    out["grad_accum_5"] = {"value": round(n_opt / dt5, 4), "unit": "optimizer steps/s", "optimizer_steps": n_opt,
-                           "micro_steps_per_s": round(acc * n_opt / dt5, 3), "samples_per_s": round(world * B * acc * n_opt / dt5, 3),
-                           "ms_per_optimizer_step": round(dt5 / n_opt * 1e3, 3), "global_batch": B * world * acc}
+    if accum_on:
+        m._micro = 0
+        for _ in range(acc):
+            m.train_step(z0, P, opt, sched, accumulation_steps=acc)
+        du.barrier(dev)
+        t0 = time.perf_counter()
+        for _ in range(acc * n_opt):
+            losses.append(m.train_step(z0, P, opt, sched, accumulation_steps=acc))
+        du.barrier(dev)
+        dt5 = du.max_over_ranks(time.perf_counter() - t0, dev)
+        m._micro = 0
+        assert all(v == v for v in losses), "NaN distillation loss"
+        out["grad_accum_5"] = {"value": round(n_opt / dt5, 4), "unit": "optimizer steps/s", "optimizer_steps": n_opt,
+                               "micro_steps_per_s": round(acc * n_opt / dt5, 3), "samples_per_s": round(world * B * acc * n_opt / dt5, 3),
+                               "ms_per_optimizer_step": round(dt5 / n_opt * 1e3, 3), "global_batch": B * world * acc}
     # The same optimizer step -- 5 x 9 samples per GPU -- as ONE micro-batch of 45: accumulation exists in train.sh because the
     # reference's GPUs cannot hold more than 9 samples; one MI355X holds the activations of 45 (about 30 of its 288 GB).  Same
     # samples per optimizer step and the same mathematics (tests/test_train_gpu.py::test_fused_accumulation...); 5x larger
     # GEMMs per launch.  Timed with eager launches (every rank: the all-reduce sequence must not depend on a capture).
-    if os.environ.get("CTTA_BENCH_FUSED_ACCUM", "1") != "0" and not args.no_latency:
+    if accum_on and os.environ.get("CTTA_BENCH_FUSED_ACCUM", "1") != "0" and not args.no_latency:
         Bf = B * acc
         z45 = P45 = kw45 = why = None
         try:      # phase 1, local: the inputs (the arenas of the four U-Nets grow inside the first train_step)
@@ -947,7 +953,8 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         if td and td.get("read_GB_per_step") is not None and td.get("write_GB_per_step") is not None and cnt.value:
             # the PMC families of tools/pmc_traffic.py that hold the MFMA kernels of the step, per launch like `achieved`
             out["roofline"]["traffic"] = int((td["read_GB_per_step"] + td["write_GB_per_step"]) * 1e9 / cnt.value)
-            out["roofline"]["traffic_unit"] = "bytes per MFMA launch (PMC FETCH_SIZE x2 + WRITE_SIZE of conv_gemm + attention families per step / launches per step)"
+            out["roofline"]["traffic_unit"] = ("bytes per MFMA launch (PMC FETCH_SIZE x2 + WRITE_SIZE of conv_gemm + attention families per step / "
+                                               "launches per step) -- counter bytes read from the committed %s, not measured in this run" % td.get("source"))
     if rank == 0 and not args.no_latency:   # the HBM-bound kernel class of the step: fused training-state passes over 559 M fp32
         def timed(fn, reps=5):
             fn()

@@ -29,10 +29,16 @@ def family(name):
         return "conv_gemm_kernel"
     for key in ("conv_gemm_kernel", "conv1d_halo_kernel", "attention_kernel", "attn_bwd", "gn_", "layernorm", "ln_bwd", "geglu",
                 "softmax_rows", "conv_small_n_kernel", "splitk_finish", "adamw_kernel", "ema2_kernel", "pack_weight",
-                "wgrad_scatter", "wgrad_implicit", "wgrad_tn", "wgrad_rowsum", "im2col_t", "transpose"):
+                "wgrad_scatter", "wgrad_implicit", "wgrad_tn", "wgrad_rowsum", "im2col_t", "transpose", "adamw4_kernel",
+                "add_slices", "linear_f32", "ctta_zero_kernel", "copy_segments", "concat", "pool2_sum", "zero_insert",
+                "col_scatter", "heun_", "cfg_combine", "snr_mse", "nhwc", "time_features", "fourier_features", "gelu",
+                "copyBuffer", "at::native"):
         if key in name:
-            return key.rstrip("_")
+            return {"adamw4_kernel": "adamw_kernel", "at::native": "torch_elementwise (at::native::*)"}.get(key, key.rstrip("_"))
     return "other"
+
+
+OTHER = defaultdict(float)      # (counter, kernel name) -> KiB of the kernels no family claims: listed in the output
 
 
 def load(directory, counter, step_kernel=r"conv_small_n_kernel<1[,>]"):
@@ -47,6 +53,8 @@ def load(directory, counter, step_kernel=r"conv_small_n_kernel<1[,>]"):
         if row["Counter_Name"] != counter:
             continue
         tot[family(row["Kernel_Name"])] += float(row["Counter_Value"])
+        if family(row["Kernel_Name"]) == "other":
+            OTHER[(counter, row["Kernel_Name"].split("(")[0][:70])] += float(row["Counter_Value"])
         if re.search(step_kernel, row["Kernel_Name"]) and row["Dispatch_Id"] not in seen:
             seen.add(row["Dispatch_Id"])
             steps += 1
@@ -73,6 +81,9 @@ def main():
         tr += rd or 0.0
         tw += wr or 0.0
         out["families"][fam] = {"read_GB": rd, "write_GB": wr, "total_GB": None if rd is None or wr is None else round(rd + wr, 3)}
+    top = sorted(OTHER.items(), key=lambda kv: -kv[1] * (2 if kv[0][0] == "FETCH_SIZE" else 1))[:8]
+    out["other_top_kernels_GB_per_step"] = [{"counter": c, "kernel": k, "GB": round(v * 1024 * (2 if c == "FETCH_SIZE" else 1) / (fs if c == "FETCH_SIZE" else wsteps) / 1e9, 3)}
+                                            for (c, k), v in top]
     out["all_kernels"] = {"read_GB": None if fetch is None else round(tr, 3), "write_GB": None if write is None else round(tw, 3)}
     json.dump(out, sys.stdout, indent=1)
     print()
