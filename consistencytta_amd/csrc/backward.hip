@@ -650,14 +650,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_cols_kernel(const bf16_t* __
 // group's two coefficients and writes dx -- x and dy are read once instead of twice, and the partial / fold / apply
 // launches (5-20 us each plus their dependent-launch gaps on the step's main stream) become one.  red[b][2][C] receives
 // the per-channel sums for gn_bwd_param_kernel exactly like the fold kernels leave them.
+template <bool SILU, bool ACC>
 __global__ __launch_bounds__(256) void gn_bwd_small_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy,
                                                            bf16_t* __restrict__ dx, int HW, int C, int G,
                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, int silu, int acc_dx,
-                                                           float* __restrict__ red) {
+                                                           const float* __restrict__ beta, float* __restrict__ red) {
   constexpr int MAXV = 8;
   __shared__ float sA[256][9], sB[256][9];          // [thread][8 channels], padded
   __shared__ float chA[128], chB[128], coef[2];     // per-channel sums of the group (cpg <= 128), the two coefficients
+  __shared__ double wsum[4];                        // per-wave fp64 sums of gamma * A, gamma * Bc (waves 0, 1)
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int cpg = C / G, vpr = cpg / 8;              // vectors per pixel row of this group; vpr divides 256 (host)
   const int nvec = HW * vpr;
@@ -667,7 +668,22 @@ __global__ __launch_bounds__(256) void gn_bwd_small_kernel(const bf16_t* __restr
   float gm[8], bt[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { gm[e] = gamma[g * cpg + cv * 8 + e]; bt[e] = beta[g * cpg + cv * 8 + e]; }
-  float xh[MAXV][8], dz[MAXV][8];
+  // ALL of the thread's vectors are requested before the first one is used (round 4 loaded, waited and consumed one pair
+  // per iteration: eight serial memory round trips per thread, and eight more for the old dx in the accumulate form --
+  // 28-32 us per launch for slabs that move in 3-6 us; SILU / ACC are template flags: no per-element branch); the raw bf16
+  // vectors stay in registers (64 VGPRs) and xhat / dz are recomputed in the apply phase instead of being kept as 128 floats
+  uint4 xr[MAXV], dr[MAXV], orr[MAXV];
+#pragma unroll
+  for (int i = 0; i < MAXV; ++i) {
+    const int idx = tid + i * 256;
+    const size_t off = base + (size_t)(idx < nvec ? idx / vpr : 0) * C + cv * 8;
+    xr[i] = make_uint4(0, 0, 0, 0); dr[i] = make_uint4(0, 0, 0, 0); orr[i] = make_uint4(0, 0, 0, 0);
+    if (idx < nvec) {
+      xr[i] = *reinterpret_cast<const uint4*>(x + off);
+      dr[i] = *reinterpret_cast<const uint4*>(dy + off);
+      if (ACC) orr[i] = *reinterpret_cast<const uint4*>(dx + off);
+    }
+  }
   float a[8], bb[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) { a[e] = 0.f; bb[e] = 0.f; }
@@ -675,16 +691,14 @@ __global__ __launch_bounds__(256) void gn_bwd_small_kernel(const bf16_t* __restr
   for (int i = 0; i < MAXV; ++i) {
     const int idx = tid + i * 256;
     if (idx < nvec) {
-      const int pix = idx / vpr;
       float fx[8], fd[8];
-      unpack8(*reinterpret_cast<const uint4*>(x + base + (size_t)pix * C + cv * 8), fx);
-      unpack8(*reinterpret_cast<const uint4*>(dy + base + (size_t)pix * C + cv * 8), fd);
+      unpack8(xr[i], fx);
+      unpack8(dr[i], fd);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         const float h = (fx[e] - mean) * rstd;
         float z = fd[e];
-        if (silu) z *= silu_grad(h * gm[e] + bt[e]);
-        xh[i][e] = h; dz[i][e] = z;
+        if (SILU) z *= silu_grad(h * gm[e] + bt[e]);
         a[e] += z; bb[e] += z * h;
       }
     }
@@ -701,11 +715,25 @@ __global__ __launch_bounds__(256) void gn_bwd_small_kernel(const bf16_t* __restr
     red[(size_t)b * 2 * C + C + g * cpg + tid] = tb;
   }
   __syncthreads();
-  if (tid == 0) {
+  // the group's two coefficients: sum over its <= 128 channels of gamma * A / gamma * Bc in fp64, as a fixed tree (one term per
+  // thread, xor butterfly inside each wave, the two waves' sums added in wave order) -- round 4 had thread 0 walk the channels
+  // alone: up to 128 dependent global loads of gamma, ~12 us of a kernel whose data moves in ~1 us (31.6 us per launch, 41
+  // launches per distillation step on the backward's main stream)
+  {
     double s1 = 0.0, s2 = 0.0;
-    for (int c = 0; c < cpg; ++c) { s1 += (double)gamma[g * cpg + c] * chA[c]; s2 += (double)gamma[g * cpg + c] * chB[c]; }
+    if (tid < cpg) { const double gmc = (double)gamma[g * cpg + tid]; s1 = gmc * (double)chA[tid]; s2 = gmc * (double)chB[tid]; }
+    if (tid < 128) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+      if ((tid & 63) == 0) { wsum[tid >> 6] = s1; wsum[2 + (tid >> 6)] = s2; }
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const double t1 = wsum[0] + wsum[1];
+    const double t2 = wsum[2] + wsum[3];
     const double n = (double)HW * cpg;
-    coef[0] = (float)(s1 / n); coef[1] = (float)(s2 / n);
+    coef[0] = (float)(t1 / n); coef[1] = (float)(t2 / n);
   }
   __syncthreads();
   const float c0 = coef[0], c1 = coef[1];
@@ -713,14 +741,18 @@ __global__ __launch_bounds__(256) void gn_bwd_small_kernel(const bf16_t* __restr
   for (int i = 0; i < MAXV; ++i) {
     const int idx = tid + i * 256;
     if (idx < nvec) {
-      const int pix = idx / vpr;
-      bf16_t* o = dx + base + (size_t)pix * C + cv * 8;
-      float fo[8];
-      if (acc_dx) unpack8(*reinterpret_cast<const uint4*>(o), fo);
+      bf16_t* o = dx + base + (size_t)(idx / vpr) * C + cv * 8;
+      float fx[8], fd[8], fo[8];
+      unpack8(xr[i], fx);
+      unpack8(dr[i], fd);
+      if (ACC) unpack8(orr[i], fo);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float r = rstd * (dz[i][e] * gm[e] - c0 - xh[i][e] * c1);
-        fo[e] = acc_dx ? fo[e] + r : r;
+        const float h = (fx[e] - mean) * rstd;         // the same expressions as in the first phase: the same bits
+        float z = fd[e];
+        if (SILU) z *= silu_grad(h * gm[e] + bt[e]);
+        const float r = rstd * (z * gm[e] - c0 - h * c1);
+        fo[e] = ACC ? fo[e] + r : r;
       }
       *reinterpret_cast<uint4*>(o) = pack8(fo);
     }
@@ -762,8 +794,11 @@ extern "C" ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* d
   float* red = part + (size_t)batch * nchunk * 2 * c;
   float* coef = red + (size_t)batch * 2 * c;
   if (gn_bwd_small_ok(hw, c, groups)) {
-    hipLaunchKernelGGL(gn_bwd_small_kernel, dim3(groups, batch), dim3(256), 0, s, (const bf16_t*)x, (const bf16_t*)dy,
-                       (bf16_t*)dx, hw, c, groups, stats, gamma, beta, silu, accumulate_dx, red);
+#define GNBS(SI, AC) hipLaunchKernelGGL((gn_bwd_small_kernel<SI, AC>), dim3(groups, batch), dim3(256), 0, s, (const bf16_t*)x, \
+                                        (const bf16_t*)dy, (bf16_t*)dx, hw, c, groups, stats, gamma, beta, red)
+    if (silu) { if (accumulate_dx) GNBS(true, true); else GNBS(true, false); }
+    else { if (accumulate_dx) GNBS(false, true); else GNBS(false, false); }
+#undef GNBS
     CTTA_LAUNCH_CHECK();
     if (dgamma) {
       CTTA_REQUIRE(dbeta, "groupnorm_bwd: dgamma without dbeta");

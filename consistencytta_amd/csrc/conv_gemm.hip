@@ -348,7 +348,9 @@ static bool want_big_tile(long long M, int N, long long K, int groups) {
   if (M % 256 != 0 && groups == 1 && t_cut >= 1 && (t_cut + 255) / 256 < (t256 + 255) / 256) tq = t_cut;
   const long long rounds = (tq + 255) / 256;
   const bool fills = !tile_rules_r3() || tq >= 1024 || tq * 10 >= rounds * 256 * 7;
-  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= 512 && t256 >= 192 && fills;   // (K >= 512 since the straight-line epilogue, profiles/sweep_r02*.json)
+  static int min_k = -1;    // CTTA_BIG_TILE_MIN_K (tuning knob; default 512)
+  if (min_k < 0) { const char* e = getenv("CTTA_BIG_TILE_MIN_K"); min_k = e ? atoi(e) : 512; }
+  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= min_k && t256 >= 192 && fills;   // (K >= 512 since the straight-line epilogue, profiles/sweep_r02*.json)
 }
 static int pick_variant(long long M, int N, long long K, int groups) {
   if (N <= 32) {                                           // 256x32; few row tiles (the per-sample cross-attention

@@ -129,7 +129,14 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
     int S = 1;
     // 128 x 128 tiles at two workgroups per CU; the level-0 / level-1 linears have 4..16 tiles over 9 216..36 864 rows: up to 64
     // splits of >= 4 chunks (16 splits left a 256 x 256 layer with 64 workgroups walking 36 chunks each: 75 us per launch)
-    while (tiles * S < 512 && S < 64 && M / (2 * S) >= 128) S *= 2;
+    static int tn_cap = -1, tn_target = -1;    // CTTA_WGRAD_TN_MAX_SPLITS / CTTA_WGRAD_TN_TARGET (tuning knobs)
+    // round 5: 256 workgroups / <= 32 splits instead of 512 / 64.  In a replayed step ONE kernel has the device to itself 79 % of
+    // the time (profiles/gaps_distill_pipelined_r05.txt): a launch that fills every CU pushes the other streams' kernels behind
+    // it, a narrower, longer one runs BESIDE them, and every halving of the splits halves the slab bytes.  Pipelined step
+    // 77.5 -> 76.2 ms at (256, 16..32); too narrow (64 workgroups, 8 splits) loses 4 ms (gpurun r5c15 / r5c16).
+    if (tn_cap < 0) { const char* e = getenv("CTTA_WGRAD_TN_MAX_SPLITS"); tn_cap = e ? atoi(e) : 32; }
+    if (tn_target < 0) { const char* e = getenv("CTTA_WGRAD_TN_TARGET"); tn_target = e ? atoi(e) : 256; }
+    while (tiles * S < tn_target && S < tn_cap && M / (2 * S) >= 128) S *= 2;
     const int mp = (int)round_up64(M, 64 * S);
     float* slabs = A.get<float>((size_t)S * N * ld); ALLOC_OR_FAIL(slabs);
     if (!cm.dry) CTTA_TRY(wg_handoff(cm, job));
@@ -153,7 +160,10 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
   if (implicit) {   // 64 x 64 (x 9 taps) / 64 x 256 tiles, two workgroups per CU
     const int64_t tiles = (int64_t)((N + 63) / 64) * ((C + (taps == 9 ? 63 : 255)) / (taps == 9 ? 64 : 256));
     S = 1;
-    while (tiles * S < 512 && S < 16 && M / (2 * S) >= 256) S *= 2;
+    static int im_cap = -1, im_target = -1;    // CTTA_WGRAD_CONV_MAX_SPLITS / CTTA_WGRAD_CONV_TARGET (tuning knobs)
+    if (im_cap < 0) { const char* e = getenv("CTTA_WGRAD_CONV_MAX_SPLITS"); im_cap = e ? atoi(e) : 16; }
+    if (im_target < 0) { const char* e = getenv("CTTA_WGRAD_CONV_TARGET"); im_target = e ? atoi(e) : 256; }     // (round 5: 256, see the linears above)
+    while (tiles * S < im_target && S < im_cap && M / (2 * S) >= 256) S *= 2;
   }
   const int mp = (int)round_up64(M, 64 * S);
   const int seg = mp / S;

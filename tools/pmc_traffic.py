@@ -27,6 +27,8 @@ from collections import defaultdict
 def family(name):
     if "resunit_kernel" in name:       # the fused vocoder ResBlock units are convolutions of the conv_gemm family
         return "conv_gemm_kernel"
+    if "attention_plain2_kernel" in name:   # the self-attention forward kernel of round 3 (rounds 3-4 left it in "other": that
+        return "attention_kernel"           # was the unexplained 35.6 GB of pmc_traffic_distill_r04.json)
     for key in ("conv_gemm_kernel", "conv1d_halo_kernel", "attention_kernel", "attn_bwd", "gn_", "layernorm", "ln_bwd", "geglu",
                 "softmax_rows", "conv_small_n_kernel", "splitk_finish", "adamw_kernel", "ema2_kernel", "pack_weight",
                 "wgrad_scatter", "wgrad_implicit", "wgrad_tn", "wgrad_rowsum", "im2col_t", "transpose", "adamw4_kernel",
