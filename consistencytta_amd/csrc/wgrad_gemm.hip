@@ -21,9 +21,42 @@
 // Bias and per-sample (time-embedding) columns -- the all-ones / indicator rows of the old Q -- are plain row sums of
 // dY^T: wgrad_rowsum_kernel.
 #include "common.h"
+#include "wgrad_fold.h"
+#include <string.h>
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+// "Direct" epilogue (round 5): a launch with ONE split adds its tile straight into the layer's gradient tensors through the
+// pack map -- grad_w[row_off[n] + col(k)] += acc, grad_b[bias_idx[n]] += column sum -- instead of writing an fp32 slab that a
+// scatter launch reads back (the slab round trip is 8 bytes per weight, the launch ~17 us + its dependent-launch gap on the
+// weight-gradient stream).  Every gradient element belongs to exactly one workgroup, and old + acc is the sum the scatter
+// forms for one slab: the same bits.
+struct WgradDirect {
+  float* grad_w;          // NULL: slab output
+  const int* row_off;     // [n_rows] element offset of packed row n in grad_w, < 0: padding row
+  const int* col_off;     // [k_cols] or NULL = identity
+  int n_rows, k_cols;
+  float* grad_b;          // NULL: no bias
+  const int* bias_idx;    // [n_bias] or NULL = identity
+  int n_bias;
+};
+__device__ __forceinline__ void direct_add4(const WgradDirect& d, int ro, int k, const float v[4]) {
+  // four consecutive slab columns k .. k + 3 of one row
+  if (!d.col_off && k + 3 < d.k_cols && ((ro + k) & 3) == 0) {
+    float4* dst = reinterpret_cast<float4*>(d.grad_w + (size_t)ro + k);
+    float4 o = *dst;
+    o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+    *dst = o;
+    return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    if (k + e >= d.k_cols) continue;
+    const int co = d.col_off ? d.col_off[k + e] : k + e;
+    if (co >= 0) d.grad_w[(size_t)ro + co] += v[e];
+  }
+}
 
 struct WgradParams {
   const bf16_t* dy;      // NAT: [M][ldy] dY where it lies (output channels contiguous)
@@ -36,6 +69,8 @@ struct WgradParams {
   int M;                 // valid positions
   int seg;               // positions per split, a multiple of 64
   long long slab_stride;
+  WgradDirect direct;
+  WgradFold fold;        // the PREVIOUS layer's slabs, folded into its gradients by this launch's workgroups first
 };
 
 template <int T>
@@ -63,6 +98,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kg = lane >> 4;
   const int c0 = blockIdx.x * TC, n0 = blockIdx.y * 64, split = blockIdx.z;
+  if (p.fold.slabs)
+    wgrad_fold_rows(p.fold, (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y * gridDim.z));
   const int W = p.W, Wp = W + 2;
   const int npix = T == 9 ? (64 / W + 2) * Wp : 64;
   const int m_lo = split * p.seg, m_hi = min(m_lo + p.seg, p.mp);
@@ -89,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float tot = 0.f;       // threads 0..63: running column sum of channel n0 + tid over the whole split
   int acc_sample = -1;   // the sample whose rows bsum holds (per-sample columns only)
-  if (do_sums && tid < 64 && n0 + tid < p.N)     // samples this split does not touch contribute zero (the scatter adds all splits)
+  if (do_sums && !p.direct.grad_w && tid < 64 && n0 + tid < p.N)     // samples this split does not touch contribute zero (the scatter adds all splits)
     for (int b = 0; b < p.sample_cols; ++b) p.slabs[(size_t)split * p.slab_stride + (size_t)(n0 + tid) * p.ld + p.bias_col + 1 + b] = 0.f;
 
   f32x4_t acc[NA][4];
@@ -147,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
       float t = 0.f;
       for (int r = 0; r < 32; ++r) t += red[r * 64 + tid];
       tot += t;
-      if (sample >= 0 && sample < p.sample_cols && n0 + tid < p.N)
+      if (!p.direct.grad_w && sample >= 0 && sample < p.sample_cols && n0 + tid < p.N)
         p.slabs[(size_t)split * p.slab_stride + (size_t)(n0 + tid) * p.ld + p.bias_col + 1 + sample] = t;
     }
   };
@@ -219,7 +256,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
 
   if (do_sums) {       // the last sample's share, then the split's total = the bias column
     fold_sums(acc_sample);
-    if (tid < 64 && n0 + tid < p.N) p.slabs[(size_t)split * p.slab_stride + (size_t)(n0 + tid) * p.ld + p.bias_col] = tot;
+    if (tid < 64 && n0 + tid < p.N) {
+      if (p.direct.grad_w) {     // direct: one split, no per-sample columns (host)
+        const int n = n0 + tid;
+        if (p.direct.grad_b && n < p.direct.n_bias) {
+          const int j = p.direct.bias_idx ? p.direct.bias_idx[n] : n;
+          if (j >= 0) p.direct.grad_b[j] += tot;
+        }
+      } else {
+        p.slabs[(size_t)split * p.slab_stride + (size_t)(n0 + tid) * p.ld + p.bias_col] = tot;
+      }
+    }
   }
   // ---- D[i][j]: i = channel (4 kg + e inside the wave's block), j = output channel lq.  Row n of the slab receives, from
   // this lane, the 4 T consecutive floats of channels cc .. cc + 3: [e][t] = acc[t][..][e]
@@ -231,14 +278,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
     for (int cb = 0; cb < CB; ++cb) {
       const int cc = c0 + (cb * 4 + wave) * 16 + kg * 4;
       if (n < p.N && cc < p.C) {
-        float* dst = slab + (size_t)n * p.ld + (size_t)cc * T;
         float v[4 * T];
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int t = 0; t < T; ++t) v[e * T + t] = acc[t * CB + cb][nb][e];
+        if (p.direct.grad_w) {
+          const int ro = n < p.direct.n_rows ? p.direct.row_off[n] : -1;
+          if (ro >= 0) {
 #pragma unroll
-        for (int q = 0; q < T; ++q) *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+            for (int q = 0; q < T; ++q) direct_add4(p.direct, ro, cc * T + 4 * q, v + 4 * q);
+          }
+        } else {
+          float* dst = slab + (size_t)n * p.ld + (size_t)cc * T;
+#pragma unroll
+          for (int q = 0; q < T; ++q) *reinterpret_cast<float4*>(dst + 4 * q) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+        }
       }
     }
   }
@@ -274,6 +329,30 @@ __global__ __launch_bounds__(64) void wgrad_rowsum_kernel(const bf16_t* __restri
   if (lane == 0) out[0] = total;
 }
 
+// The fold the NEXT ctta_wgrad_tn* / ctta_wgrad_implicit_inplace / _direct launch of this host thread carries (consumed by it;
+// other launches ignore and keep it).  Host-thread state like ctta_conv_bind_workspace: the engine sets it right before the
+// launch that takes it.
+static thread_local WgradFold t_fold = {};
+extern "C" ctta_status ctta_wgrad_set_pending_fold(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int k_cols,
+                                                   int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad,
+                                                   int bias_col, int n_bias, const int32_t* bias_idx, float* grad_bias) {
+  if (!slabs) { t_fold = WgradFold{}; return CTTA_OK; }
+  CTTA_REQUIRE(row_off && grad && n_slabs >= 1 && n_rows >= 1 && k_cols >= 1, "wgrad_set_pending_fold: bad arguments");
+  CTTA_REQUIRE(bias_col < 0 || (grad_bias && bias_col < ldk && n_bias <= n_rows), "wgrad_set_pending_fold: bad bias arguments");
+  WgradFold f;
+  f.slabs = slabs; f.S = n_slabs; f.slab_stride = slab_stride; f.ldk = ldk; f.k_cols = k_cols; f.n_rows = n_rows;
+  f.row_off = row_off; f.col_off = col_off; f.grad = grad;
+  f.vec4 = (!col_off && (k_cols % 4) == 0 && (ldk % 4) == 0 && (slab_stride % 4) == 0 && (((uintptr_t)slabs | (uintptr_t)grad) & 15) == 0) ? 1 : 0;
+  f.bias_col = bias_col; f.n_bias = n_bias; f.bias_idx = bias_idx; f.grad_bias = grad_bias;
+  t_fold = f;
+  return CTTA_OK;
+}
+static WgradFold take_fold(bool carries) {
+  WgradFold f = {};
+  if (carries) { f = t_fold; t_fold = WgradFold{}; }
+  return f;
+}
+
 extern "C" int ctta_wgrad_implicit_supported(int taps, int c, int h, int w, int x_ld, int n) {
   static int env = -1;
   if (env < 0) { const char* e = getenv("CTTA_WGRAD_IMPLICIT"); env = (e && e[0] == '0') ? 0 : 1; }
@@ -287,7 +366,8 @@ extern "C" int ctta_wgrad_implicit_supported(int taps, int c, int h, int w, int 
 
 static ctta_status wgrad_implicit_launch(const void* dyt, const void* dy_nat, int ldy, int n, int mp, const void* x, int x_ld,
                                          int c, int batch, int h, int w, int taps, int m_valid, int splits, int bias_col,
-                                         int sample_cols, float* slabs, int64_t slab_stride, int ld, void* stream);
+                                         int sample_cols, float* slabs, int64_t slab_stride, int ld, void* stream,
+                                         const WgradDirect* direct = nullptr);
 extern "C" ctta_status ctta_wgrad_implicit(const void* dyt, int n, int mp, const void* x, int x_ld, int c, int batch, int h, int w,
                                            int taps, int m_valid, int splits, int bias_col, int sample_cols, float* slabs,
                                            int64_t slab_stride, int ld, void* stream) {
@@ -303,10 +383,30 @@ extern "C" ctta_status ctta_wgrad_implicit_inplace(const void* dy, int ldy, int 
   return wgrad_implicit_launch(nullptr, dy, ldy, n, mp, x, x_ld, c, batch, h, w, taps, m_valid, splits, bias_col, sample_cols, slabs,
                                slab_stride, ld, stream);
 }
+// One split, the tile added straight into the gradient tensors through the pack map (identity columns: a 3x3 weight row is
+// (cin, kh, kw)-contiguous like the kernel's own row): no slab, no scatter launch.
+extern "C" ctta_status ctta_wgrad_implicit_direct(const void* dy, int ldy, int n, int mp, const void* x, int x_ld, int c, int batch,
+                                                  int h, int w, int m_valid, int k_cols, int n_rows, const int32_t* row_off,
+                                                  float* grad_w, int n_bias, const int32_t* bias_idx, float* grad_b, void* stream) {
+  CTTA_REQUIRE(dy && ldy % 8 == 0 && ldy >= n && n % 8 == 0 && grad_w && row_off && k_cols >= 1 && n_rows >= 1,
+               "wgrad_implicit_direct: bad arguments");
+  WgradDirect d;
+  d.grad_w = grad_w; d.row_off = row_off; d.col_off = nullptr; d.n_rows = n_rows; d.k_cols = k_cols;
+  d.grad_b = grad_b; d.bias_idx = bias_idx; d.n_bias = grad_b ? n_bias : 0;
+  return wgrad_implicit_launch(nullptr, dy, ldy, n, mp, x, x_ld, c, batch, h, w, 9, m_valid, 1, grad_b ? c * 9 : -1, 0, nullptr, 0, 0,
+                               stream, &d);
+}
 static ctta_status wgrad_implicit_launch(const void* dyt, const void* dy_nat, int ldy, int n, int mp, const void* x, int x_ld,
                                          int c, int batch, int h, int w, int taps, int m_valid, int splits, int bias_col,
-                                         int sample_cols, float* slabs, int64_t slab_stride, int ld, void* stream) {
+                                         int sample_cols, float* slabs, int64_t slab_stride, int ld, void* stream,
+                                         const WgradDirect* direct) {
   const bool nat = dy_nat != nullptr;
+  if (direct) {     // the tile goes straight into the gradient tensors: no slab (the alignment checks below look at a dummy)
+    CTTA_REQUIRE(nat && taps == 9 && splits == 1 && sample_cols == 0 && direct->grad_w && direct->row_off,
+                 "wgrad_implicit_direct: 3x3, dY in place, one split, no per-sample columns");
+    slabs = reinterpret_cast<float*>((uintptr_t)16);
+    ld = (c * taps + 1 + 3) / 4 * 4; slab_stride = (int64_t)n * ld;
+  }
   CTTA_REQUIRE((dyt || dy_nat) && x && slabs && n >= 1 && c >= 1 && splits >= 1 && mp >= 64 && m_valid >= 1 && m_valid <= mp,
                "wgrad_implicit: bad arguments");
   CTTA_REQUIRE(ctta_wgrad_implicit_supported(taps, c, h, w, x_ld, n),
@@ -323,6 +423,8 @@ static ctta_status wgrad_implicit_launch(const void* dyt, const void* dy_nat, in
   p.dyt = (const bf16_t*)dyt; p.x = (const bf16_t*)x; p.slabs = slabs;
   p.N = n; p.C = c; p.xld = x_ld; p.mp = mp; p.ld = ld;
   p.H = h; p.W = w; p.HW = h * w; p.M = m_valid; p.seg = mp / splits; p.slab_stride = slab_stride;
+  if (direct) p.direct = *direct; else memset(&p.direct, 0, sizeof(p.direct));
+  p.fold = take_fold(taps == 9 && nat);       // only the in-place 3x3 kernel carries a pending fold
   hipStream_t s = (hipStream_t)stream;
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, 130 + (taps == 9 ? 1 : 0), n, (long long)c * taps, mp / splits, splits, s);
@@ -383,6 +485,8 @@ struct WgradTnParams {
   int M, mp, seg;
   long long slab_stride;
   int bias_col;          // >= C: the workgroups of the first column tile also write the column sums of dY there; < 0: none
+  WgradDirect direct;
+  WgradFold fold;
 };
 
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradTnParams p) {
@@ -396,6 +500,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradTnParams p)
   const int wc = wave & 1, wn = wave >> 1;
   const int c0 = blockIdx.x * 128, n0 = blockIdx.y * 128, split = blockIdx.z;
   const int m_lo = split * p.seg, m_hi = min(m_lo + p.seg, p.mp);
+  if (p.fold.slabs)
+    wgrad_fold_rows(p.fold, (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y * gridDim.z));
 
   int abase[2][2];
 #pragma unroll
@@ -503,7 +609,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradTnParams p)
     if (tid < 128 && n0 + tid < p.N) {
       float t = 0.f;
       for (int r = 0; r < 16; ++r) t += red[(r * 16 + (tid >> 3)) * 8 + (tid & 7)];
-      slab[(size_t)(n0 + tid) * p.ld + p.bias_col] = t;
+      if (p.direct.grad_w) {
+        const int n = n0 + tid;
+        if (p.direct.grad_b && n < p.direct.n_bias) {
+          const int j = p.direct.bias_idx ? p.direct.bias_idx[n] : n;
+          if (j >= 0) p.direct.grad_b[j] += t;
+        }
+      } else {
+        slab[(size_t)(n0 + tid) * p.ld + p.bias_col] = t;
+      }
     }
   }
 #pragma unroll
@@ -514,14 +628,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradTnParams p)
       const int cc = c0 + wc * 64 + cb * 16 + kg * 4;
       if (n < p.N && cc < p.C) {
         const f32x4_t a = acc[cb][nb];
-        *reinterpret_cast<float4*>(slab + (size_t)n * p.ld + cc) = make_float4(a[0], a[1], a[2], a[3]);
+        if (p.direct.grad_w) {
+          const int ro = n < p.direct.n_rows ? p.direct.row_off[n] : -1;
+          const float v[4] = {a[0], a[1], a[2], a[3]};
+          if (ro >= 0) direct_add4(p.direct, ro, cc, v);
+        } else {
+          *reinterpret_cast<float4*>(slab + (size_t)n * p.ld + cc) = make_float4(a[0], a[1], a[2], a[3]);
+        }
       }
     }
   }
 }
 
+static ctta_status wgrad_tn_launch(const void* dy, int ldy, int n, const void* x, int ldx, int c, int m_valid, int mp, int splits,
+                                   int bias_col, float* slabs, int64_t slab_stride, int ld, void* stream, const WgradDirect* direct);
 extern "C" ctta_status ctta_wgrad_tn(const void* dy, int ldy, int n, const void* x, int ldx, int c, int m_valid, int mp, int splits,
                                      int bias_col, float* slabs, int64_t slab_stride, int ld, void* stream) {
+  return wgrad_tn_launch(dy, ldy, n, x, ldx, c, m_valid, mp, splits, bias_col, slabs, slab_stride, ld, stream, nullptr);
+}
+// One split, the tile added straight into the gradient tensors through the pack map (col_off NULL = identity columns).
+extern "C" ctta_status ctta_wgrad_tn_direct(const void* dy, int ldy, int n, const void* x, int ldx, int c, int m_valid, int mp,
+                                            int k_cols, int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad_w,
+                                            int n_bias, const int32_t* bias_idx, float* grad_b, void* stream) {
+  CTTA_REQUIRE(grad_w && row_off && k_cols >= 1 && k_cols <= c && n_rows >= 1, "wgrad_tn_direct: bad arguments");
+  WgradDirect d;
+  d.grad_w = grad_w; d.row_off = row_off; d.col_off = col_off; d.n_rows = n_rows; d.k_cols = k_cols;
+  d.grad_b = grad_b; d.bias_idx = bias_idx; d.n_bias = grad_b ? n_bias : 0;
+  const int ld = (c + 1 + 3) / 4 * 4;
+  return wgrad_tn_launch(dy, ldy, n, x, ldx, c, m_valid, mp, 1, grad_b ? c : -1, reinterpret_cast<float*>((uintptr_t)16), (int64_t)n * ld, ld,
+                         stream, &d);
+}
+static ctta_status wgrad_tn_launch(const void* dy, int ldy, int n, const void* x, int ldx, int c, int m_valid, int mp, int splits,
+                                   int bias_col, float* slabs, int64_t slab_stride, int ld, void* stream, const WgradDirect* direct) {
   CTTA_REQUIRE(dy && x && slabs && n >= 1 && c >= 1 && splits >= 1 && m_valid >= 1 && m_valid <= mp, "wgrad_tn: bad arguments");
   CTTA_REQUIRE(ldy % 8 == 0 && ldx % 8 == 0 && n % 8 == 0 && c % 8 == 0 && ldy >= n && ldx >= c,
                "wgrad_tn: n=%d c=%d ldy=%d ldx=%d must be multiples of 8", n, c, ldy, ldx);
@@ -536,6 +674,8 @@ extern "C" ctta_status ctta_wgrad_tn(const void* dy, int ldy, int n, const void*
   WgradTnParams p;
   p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.slabs = slabs; p.N = n; p.C = c; p.ldy = ldy; p.ldx = ldx; p.ld = ld;
   p.M = m_valid; p.mp = mp; p.seg = mp / splits; p.slab_stride = slab_stride; p.bias_col = bias_col;
+  if (direct) p.direct = *direct; else memset(&p.direct, 0, sizeof(p.direct));
+  p.fold = take_fold(true);
   hipStream_t s = (hipStream_t)stream;
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, 142, c, n, p.seg, splits, s);

@@ -652,6 +652,24 @@ ctta_status ctta_wgrad_implicit_inplace(const void* dy, int ldy, int n, int mp, 
  * (diffusers/models/attention.py:276-334, attention_processor.py:1107-1136) in the student's backward pass. */
 ctta_status ctta_wgrad_tn(const void* dy, int ldy, int n, const void* x, int ldx, int c, int m_valid, int mp, int splits,
                           int bias_col, float* slabs, int64_t slab_stride, int ld, void* stream);
+/* The same two products with ONE split and the tile added STRAIGHT into the layer's gradient tensors through the pack map
+ * (autograd's accumulate into .grad, tools/train_utils.py:166): grad_w[row_off[n] + col(k)] += dW[n][k] for k < k_cols, rows with
+ * row_off[n] < 0 skipped (padding), col = col_off[k] (< 0 skipped) or the identity when col_off is NULL;
+ * grad_b[bias_idx[n] or n] += column sum of dY for n < n_bias (grad_b NULL: no bias).  No fp32 slab, no scatter launch; the
+ * same bits as slab + ctta_wgrad_scatter_rows_bias(accumulate = 1) with one slab. */
+/* Launch-boundary reduce: the slab fold of ctta_wgrad_scatter_rows_bias(accumulate = 1) handed to the NEXT ctta_wgrad_tn /
+ * ctta_wgrad_tn_direct / ctta_wgrad_implicit_inplace / ctta_wgrad_implicit_direct launch of the calling host thread, whose
+ * workgroups run it in their prologue (the slabs must be complete on that launch's stream: same stream, issued earlier) --
+ * one launch per layer instead of two.  slabs NULL clears a fold that was set and not taken. */
+ctta_status ctta_wgrad_set_pending_fold(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int k_cols,
+                                        int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad,
+                                        int bias_col, int n_bias, const int32_t* bias_idx, float* grad_bias);
+ctta_status ctta_wgrad_tn_direct(const void* dy, int ldy, int n, const void* x, int ldx, int c, int m_valid, int mp,
+                                 int k_cols, int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad_w,
+                                 int n_bias, const int32_t* bias_idx, float* grad_b, void* stream);
+ctta_status ctta_wgrad_implicit_direct(const void* dy, int ldy, int n, int mp, const void* x, int x_ld, int c, int batch,
+                                       int h, int w, int m_valid, int k_cols, int n_rows, const int32_t* row_off,
+                                       float* grad_w, int n_bias, const int32_t* bias_idx, float* grad_b, void* stream);
 /* the row sums alone: slabs[s][r][bias_col] = sum over split s of dY^T[r][m] (+ per-sample sums in the sample_cols columns
  * behind it): bias gradient / d temb of the layers whose weight-gradient product runs on ctta_conv_gemm */
 ctta_status ctta_wgrad_rowsum(const void* dyt, int n, int mp, int m_valid, int splits, int hw, int sample_cols, float* slabs,

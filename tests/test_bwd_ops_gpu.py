@@ -154,6 +154,27 @@ def test_implicit_weight_gradient(B, Cin, Cout, H, W, k, splits, nb):
         assert rel_err(got2[:, K], b.grad) < 2e-3
         if nb:
             assert rel_err(got2[:, K + 1:K + 1 + nb].t(), dy.sum(dim=(2, 3))[:nb]) < 2e-3
+        # round 5: ONE split, the tile added straight into the gradient tensors through the pack map (no slab, no scatter):
+        # bit-identical to slab + ctta_wgrad_scatter_rows_bias(accumulate = 1), padded rows and bias slots dropped
+        mp1 = rup(M, 64)
+        ld1 = rup(K + 1, 4)
+        slab1 = torch.full((1, Cout, ld1), float("nan"), device=DEV)
+        N.check(L.ctta_wgrad_implicit_inplace(N.ptr(dya), Cout, Cout, mp1, N.ptr(xa), Cin, Cin, B, H, W, taps, M, 1, K, 0,
+                                              N.ptr(slab1), Cout * ld1, ld1, st))
+        ro = torch.arange(Cout, dtype=torch.int32) * K
+        bidx = torch.arange(Cout, dtype=torch.int32)
+        ro[1], bidx[2] = -1, -1
+        ro_d, bi_d = ro.to(DEV), bidx.to(DEV)
+        gw0, gb0 = det("wi.gw", (Cout * K,), 8).to(DEV), det("wi.gb", (Cout,), 9).to(DEV)
+        gw_s, gb_s, gw_d, gb_d = gw0.clone(), gb0.clone(), gw0.clone(), gb0.clone()
+        N.check(L.ctta_wgrad_scatter_rows_bias(N.ptr(slab1), 1, Cout * ld1, ld1, K, Cout, N.ptr(ro_d), None, N.ptr(gw_s), K, Cout,
+                                               N.ptr(bi_d), N.ptr(gb_s), 1, st))
+        N.check(L.ctta_wgrad_implicit_direct(N.ptr(dya), Cout, Cout, mp1, N.ptr(xa), Cin, Cin, B, H, W, M, K, Cout, N.ptr(ro_d),
+                                             N.ptr(gw_d), Cout, N.ptr(bi_d), N.ptr(gb_d), st))
+        sync()
+        assert torch.equal(gw_d, gw_s) and torch.equal(gb_d, gb_s)
+        assert torch.equal(gw_d.view(Cout, K)[1], gw0.view(Cout, K)[1]) and float(gb_d[2]) == float(gb0[2])
+        assert rel_err((gw_d - gw0).cpu().view(Cout, K)[2:].reshape(Cout - 2, Cin, k, k), w.grad[2:]) < 2e-3
     # outside the kernel's range: refused loudly
     assert L.ctta_wgrad_implicit_supported(9, 64, 8, 48, 64, 64) == 0 and L.ctta_wgrad_implicit_supported(9, 64, 6, 4, 64, 64) == 0
     assert L.ctta_wgrad_implicit_supported(4, 64, 8, 8, 64, 64) == 0 and L.ctta_wgrad_implicit_supported(1, 8, 8, 8, 8, 64) == 0
@@ -193,6 +214,31 @@ def test_weight_gradient_with_both_operands_in_place(M, Cin, Cout, splits, x_ld,
     assert rel_err(got[:, Cin], b.grad) < 2e-3
     with pytest.raises(RuntimeError):       # widths that are not multiples of 8 are refused loudly
         N.check(L.ctta_wgrad_tn(N.ptr(dya), dy_ld, Cout - 1, N.ptr(xa), x_ld, Cin, M, mp, splits, Cin, N.ptr(slabs), Cout * ld, ld, st))
+    # round 5: one split, added straight into the gradient tensors -- with a column map that drops two padding columns (the
+    # transformer's inner width 255 -> 256) and with the identity map; bit-identical to slab + scatter
+    mp1 = rup(M, 64)
+    slab1 = torch.full((1, Cout, ld), float("nan"), device=DEV)
+    N.check(L.ctta_wgrad_tn(N.ptr(dya), dy_ld, Cout, N.ptr(xa), x_ld, Cin, M, mp1, 1, Cin, N.ptr(slab1), Cout * ld, ld, st))
+    for use_map in (False, True):
+        Kd = Cin - 2 if use_map else Cin
+        co = None
+        if use_map:
+            co = torch.arange(Cin, dtype=torch.int32) - 1
+            co[0], co[Cin - 1] = -1, -1                    # columns 0 and Cin - 1 are padding: dropped
+            co = co.to(DEV)
+        ro = (torch.arange(Cout, dtype=torch.int32) * Kd)
+        bidx = torch.arange(Cout, dtype=torch.int32)
+        ro[0], bidx[1] = -1, -1
+        ro_d, bi_d = ro.to(DEV), bidx.to(DEV)
+        gw0, gb0 = det("tn.gw", (Cout * Kd,), 8).to(DEV), det("tn.gb", (Cout,), 9).to(DEV)
+        gw_s, gb_s, gw_d, gb_d = gw0.clone(), gb0.clone(), gw0.clone(), gb0.clone()
+        N.check(L.ctta_wgrad_scatter_rows_bias(N.ptr(slab1), 1, Cout * ld, ld, Cin, Cout, N.ptr(ro_d), N.ptr(co), N.ptr(gw_s), Cin, Cout,
+                                               N.ptr(bi_d), N.ptr(gb_s), 1, st))
+        N.check(L.ctta_wgrad_tn_direct(N.ptr(dya), dy_ld, Cout, N.ptr(xa), x_ld, Cin, M, mp1, Cin, Cout, N.ptr(ro_d), N.ptr(co),
+                                       N.ptr(gw_d), Cout, N.ptr(bi_d), N.ptr(gb_d), st))
+        sync()
+        assert torch.equal(gw_d, gw_s) and torch.equal(gb_d, gb_s), use_map
+        assert bool(torch.isfinite(gw_d).all()) and not torch.equal(gw_d, gw0)
 
 
 def test_slab_scatter_with_the_bias_column_in_the_same_launch():
