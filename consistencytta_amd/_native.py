@@ -104,8 +104,6 @@ SIGNATURES = {
     "ctta_wgrad_implicit_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "ctta_wgrad_implicit_inplace": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                            c_int, c_int, c_void_p, c_int64, c_int, c_void_p]),
-    "ctta_wgrad_set_pending_fold": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                            c_void_p, c_void_p]),
     "ctta_wgrad_tn_direct": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                      c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
     "ctta_wgrad_implicit_direct": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,

@@ -165,15 +165,6 @@ struct ctta_unet {
     bool was_capturing = false;        // whether the previous backward was recorded into a hipGraph capture
     int next = 0;
     bool enabled = false;
-    // the slab fold of the LAST weight-gradient job, not launched yet: the next job's kernel runs it in its prologue
-    // (ctta_wgrad_set_pending_fold), a job that cannot carry it -- or the block's join -- flushes it as a scatter launch
-    struct Pend {
-      bool valid = false;
-      const float* slabs = nullptr; int S = 0; int64_t stride = 0; int ld = 0, k_cols = 0, n_rows = 0;
-      const int32_t *ro = nullptr, *co = nullptr; float* gw = nullptr; int bcol = -1, n_bias = 0; const int32_t* bidx = nullptr;
-      float* gb = nullptr;
-      int slot = 0; bool async = false; hipStream_t stream = nullptr;
-    } pend;
   } wg;
   struct BackwardState {   // between ctta_unet_backward_begin / _next calls
     bool active = false;

@@ -60,45 +60,15 @@ static ctta_status wg_handoff(BCtx& c, WgJob& j) {
 static ctta_status wg_end(BCtx& c, WgJob& j) {
   if (!j.async) return CTTA_OK;
   ctta_unet::WgradSide& W = c.U->wg;
-  // a job whose slab fold is still pending keeps its slot until the fold has run (wg_fold_done records the event then)
-  if (!(W.pend.valid && W.pend.slot == j.slot)) CTTA_CHECK_HIP(hipEventRecord(W.freed[j.slot], W.stream));
+  CTTA_CHECK_HIP(hipEventRecord(W.freed[j.slot], W.stream));
   W.in_use[j.slot] = true;
   W.dirty = true;
   return CTTA_OK;
-}
-static bool wgrad_defer_on() {   // CTTA_WGRAD_DEFER_FOLD=0: every layer's slab fold as its own scatter launch (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_WGRAD_DEFER_FOLD"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
-// the pending fold has been issued on its stream (inside a carrying launch, or as a scatter launch): its slot is free behind it
-static ctta_status wg_fold_done(ctta_unet::WgradSide& W) {
-  if (W.pend.async) CTTA_CHECK_HIP(hipEventRecord(W.freed[W.pend.slot], W.pend.stream));
-  W.pend.valid = false;
-  return CTTA_OK;
-}
-// hands the pending fold to the NEXT carrying launch of this host thread; call wg_fold_done after that launch
-static ctta_status wg_fold_attach(ctta_unet::WgradSide& W, bool* attached) {
-  *attached = false;
-  if (!W.pend.valid) return CTTA_OK;
-  const ctta_unet::WgradSide::Pend& q = W.pend;
-  CTTA_TRY(ctta_wgrad_set_pending_fold(q.slabs, q.S, q.stride, q.ld, q.k_cols, q.n_rows, q.ro, q.co, q.gw, q.bcol, q.n_bias, q.bidx, q.gb));
-  *attached = true;
-  return CTTA_OK;
-}
-// a launch that cannot carry it (or the block's join) comes next: run the pending fold as the scatter launch it replaces
-static ctta_status wg_fold_flush(ctta_unet::WgradSide& W) {
-  if (!W.pend.valid) return CTTA_OK;
-  const ctta_unet::WgradSide::Pend& q = W.pend;
-  CTTA_TRY(ctta_wgrad_scatter_rows_bias(q.slabs, q.S, q.stride, q.ld, q.k_cols, q.n_rows, q.ro, q.co, q.gw, q.bcol, q.n_bias, q.bidx,
-                                        q.gb, 1, q.stream));
-  return wg_fold_done(W);
 }
 // the main stream waits for every weight-gradient job issued so far (block boundaries: the caller may start the
 // all-reduce of the block's gradients; before the embedding MLPs, which read d temb)
 static ctta_status wg_join(BCtx& c) {
   ctta_unet::WgradSide& W = c.U->wg;
-  if (!c.dry) CTTA_TRY(wg_fold_flush(W));      // the last job's slab fold, if still pending
   if (c.dry || !W.dirty) return CTTA_OK;
   CTTA_CHECK_HIP(hipEventRecord(W.joined, W.stream));
   CTTA_CHECK_HIP(hipStreamWaitEvent(c.stream, W.joined, 0));
@@ -181,20 +151,14 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
       CTTA_TRY(grad_ptr(c, dm->wkey, &gw));
       if (!dm->bkey.empty()) CTTA_TRY(grad_ptr(c, dm->bkey, &gb));
       if (!cm.dry) CTTA_TRY(wg_handoff(cm, job));
-      bool att = false;
-      if (!c.dry) CTTA_TRY(wg_fold_attach(c.U->wg, &att));
       RUN(c, ctta_wgrad_tn_direct(dy, N, N, x, C, C, (int)M, mp, dm->k_ident > 0 ? dm->k_ident : K, dm->n, dm->ro,
                                   dm->k_ident > 0 ? nullptr : dm->co, gw, dm->n_bias, dm->bidx, gb, c.stream));
-      if (att) CTTA_TRY(wg_fold_done(c.U->wg));
       out->p = nullptr; out->S = 1; out->R = R; out->ld = ld; out->N = N;
       return CTTA_OK;
     }
     float* slabs = A.get<float>((size_t)S * N * ld); ALLOC_OR_FAIL(slabs);
     if (!cm.dry) CTTA_TRY(wg_handoff(cm, job));
-    bool att = false;
-    if (!c.dry) CTTA_TRY(wg_fold_attach(c.U->wg, &att));
     RUN(c, ctta_wgrad_tn(dy, N, N, x, C, C, (int)M, mp, S, K, slabs, (int64_t)N * ld, ld, c.stream));
-    if (att) CTTA_TRY(wg_fold_done(c.U->wg));
     out->p = slabs; out->S = S; out->R = R; out->ld = ld; out->N = N;
     return CTTA_OK;
   }
@@ -233,27 +197,20 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
     CTTA_TRY(grad_ptr(c, dm->wkey, &gw));
     if (!dm->bkey.empty()) CTTA_TRY(grad_ptr(c, dm->bkey, &gb));
     if (!cm.dry) CTTA_TRY(wg_handoff(cm, job));
-    bool att = false;
-    if (!c.dry) CTTA_TRY(wg_fold_attach(c.U->wg, &att));
     RUN(c, ctta_wgrad_implicit_direct(dy, N, N, mp, x, C, C, B, hi, wi, (int)M, dm->k_ident, dm->n, dm->ro, gw, dm->n_bias, dm->bidx, gb,
                                       c.stream));
-    if (att) CTTA_TRY(wg_fold_done(c.U->wg));
     out->p = nullptr; out->S = 1; out->R = R; out->ld = ld; out->N = N;
     return CTTA_OK;
   }
   if (conv_inplace) {
     float* slabs = A.get<float>((size_t)S * N * ld); ALLOC_OR_FAIL(slabs);
     if (!cm.dry) CTTA_TRY(wg_handoff(cm, job));
-    bool att = false;
-    if (!c.dry) CTTA_TRY(wg_fold_attach(c.U->wg, &att));
     RUN(c, ctta_wgrad_implicit_inplace(dy, N, N, mp, x, C, C, B, hi, wi, 9, (int)M, S, K, nb, slabs, (int64_t)N * ld, ld, c.stream));
-    if (att) CTTA_TRY(wg_fold_done(c.U->wg));
     out->p = slabs; out->S = S; out->R = R; out->ld = ld; out->N = N;
     return CTTA_OK;
   }
   bf16_t* pt = A.get<bf16_t>((size_t)N * mp); ALLOC_OR_FAIL(pt);
   float* slabs = A.get<float>((size_t)S * N * ld); ALLOC_OR_FAIL(slabs);
-  if (!c.dry) CTTA_TRY(wg_fold_flush(c.U->wg));      // this route's launches cannot carry the previous job's pending fold
   RUN(cm, ctta_transpose_bf16(dy, 0, (int)M, N, N, 0, pt, 0, mp, 1, cm.stream));   // dY lives in the main stream's arena
   if (!cm.dry) CTTA_TRY(wg_handoff(cm, job));
   if (implicit) {
@@ -283,8 +240,7 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
 }
 
 // slab rows [row0, row0 + m.n) -> weight / bias gradients of the layer described by `m`
-// `defer_job` (may be NULL): the job whose ONLY fold this is -- it is then left pending for the next job's launch to carry
-static ctta_status scatter_wgrad(BCtx& c, const Slabs& sl, int k_rows, const PackMap& m, int row0 = 0, const WgJob* defer_job = nullptr) {
+static ctta_status scatter_wgrad(BCtx& c, const Slabs& sl, int k_rows, const PackMap& m, int row0 = 0) {
   const int64_t stride = (int64_t)sl.N * sl.ld;
   const float* base = sl.p + (size_t)row0 * sl.ld;
   float *gw, *gb = nullptr;
@@ -293,17 +249,6 @@ static ctta_status scatter_wgrad(BCtx& c, const Slabs& sl, int k_rows, const Pac
   // weight rows and (same launch) the bias column of the slabs
   const bool bias_here = !m.bkey.empty() && m.n_bias <= m.n;
   const int bcol = bias_here ? k_rows : -1;
-  if (defer_job && !c.dry && wgrad_defer_on() && (m.bkey.empty() || bias_here)) {
-    ctta_unet::WgradSide& W = c.U->wg;
-    CTTA_TRY(wg_fold_flush(W));        // (never pending here: the job's own launch carried or flushed it)
-    ctta_unet::WgradSide::Pend& q = W.pend;
-    q.slabs = base; q.S = sl.S; q.stride = stride; q.ld = sl.ld;
-    q.k_cols = m.k_ident > 0 ? m.k_ident : k_rows; q.n_rows = m.n; q.ro = m.ro; q.co = m.k_ident > 0 ? nullptr : m.co;
-    q.gw = gw; q.bcol = bcol; q.n_bias = m.n_bias; q.bidx = m.bidx; q.gb = gb;
-    q.slot = defer_job->slot; q.async = defer_job->async; q.stream = c.stream;
-    q.valid = true;
-    return CTTA_OK;
-  }
   if (m.k_ident > 0)
     RUN(c, ctta_wgrad_scatter_rows_bias(base, sl.S, stride, sl.ld, m.k_ident, m.n, m.ro, nullptr, gw, bcol, m.n_bias, m.bidx, gb, 1,
                                         c.stream));
@@ -327,7 +272,7 @@ static ctta_status conv_wgrad(BCtx& c, const ConvLayer& L, const PackMap& m, con
   CTTA_TRY(wgrad_slabs(c, job, x, L.cin_pad, c.B, hi, wi, ups, ho, wo, L.kh, L.kw, L.stride, L.pad, dy, L.p.n, nb, &sl,
                        nb == 0 ? &m : nullptr));
   const int K = L.kh * L.kw * L.cin_pad;
-  if (sl.p) CTTA_TRY(scatter_wgrad(w, sl, K, m, 0, nb == 0 ? &job : nullptr));      // sl.p == NULL: the kernel added into the gradients itself
+  if (sl.p) CTTA_TRY(scatter_wgrad(w, sl, K, m));      // sl.p == NULL: the kernel added into the gradients itself
   if (nb > 0)   // d temb[b][off + n] = sum over the sample's pixels of dY: columns K+1 .. K+B of the slab
     RUN(w, ctta_col_scatter(sl.p, sl.S, (int64_t)sl.N * sl.ld, sl.ld, K + 1, nb, L.cout, nullptr,
                             c.dtemb_all + temb_off, c.U->temb_total, 0, w.stream));
@@ -350,7 +295,7 @@ static ctta_status linear_wgrad(BCtx& c, const PackMap& m, const PackMap* m2, co
   CTTA_TRY(wg_begin(c, &job));
   Slabs sl;
   CTTA_TRY(wgrad_slabs(c, job, x, x_ld, 1, (int)rows, 1, false, (int)rows, 1, 1, 1, 1, 0, dy, N, 0, &sl, m2 ? nullptr : &m));
-  if (sl.p) CTTA_TRY(scatter_wgrad(job.w, sl, x_ld, m, 0, m2 ? nullptr : &job));
+  if (sl.p) CTTA_TRY(scatter_wgrad(job.w, sl, x_ld, m, 0));
   if (m2) CTTA_TRY(scatter_wgrad(job.w, sl, x_ld, *m2, m.n));   // fused [q | k]
   if (!c.dry) CTTA_TRY(wg_end(c, job));
   return CTTA_OK;

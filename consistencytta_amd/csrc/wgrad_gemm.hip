@@ -21,7 +21,6 @@
 // Bias and per-sample (time-embedding) columns -- the all-ones / indicator rows of the old Q -- are plain row sums of
 // dY^T: wgrad_rowsum_kernel.
 #include "common.h"
-#include "wgrad_fold.h"
 #include <string.h>
 
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
@@ -70,7 +69,6 @@ struct WgradParams {
   int seg;               // positions per split, a multiple of 64
   long long slab_stride;
   WgradDirect direct;
-  WgradFold fold;        // the PREVIOUS layer's slabs, folded into its gradients by this launch's workgroups first
 };
 
 template <int T>
@@ -98,8 +96,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lq = lane & 15, kg = lane >> 4;
   const int c0 = blockIdx.x * TC, n0 = blockIdx.y * 64, split = blockIdx.z;
-  if (p.fold.slabs)
-    wgrad_fold_rows(p.fold, (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y * gridDim.z));
   const int W = p.W, Wp = W + 2;
   const int npix = T == 9 ? (64 / W + 2) * Wp : 64;
   const int m_lo = split * p.seg, m_hi = min(m_lo + p.seg, p.mp);
@@ -329,30 +325,6 @@ __global__ __launch_bounds__(64) void wgrad_rowsum_kernel(const bf16_t* __restri
   if (lane == 0) out[0] = total;
 }
 
-// The fold the NEXT ctta_wgrad_tn* / ctta_wgrad_implicit_inplace / _direct launch of this host thread carries (consumed by it;
-// other launches ignore and keep it).  Host-thread state like ctta_conv_bind_workspace: the engine sets it right before the
-// launch that takes it.
-static thread_local WgradFold t_fold = {};
-extern "C" ctta_status ctta_wgrad_set_pending_fold(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int k_cols,
-                                                   int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad,
-                                                   int bias_col, int n_bias, const int32_t* bias_idx, float* grad_bias) {
-  if (!slabs) { t_fold = WgradFold{}; return CTTA_OK; }
-  CTTA_REQUIRE(row_off && grad && n_slabs >= 1 && n_rows >= 1 && k_cols >= 1, "wgrad_set_pending_fold: bad arguments");
-  CTTA_REQUIRE(bias_col < 0 || (grad_bias && bias_col < ldk && n_bias <= n_rows), "wgrad_set_pending_fold: bad bias arguments");
-  WgradFold f;
-  f.slabs = slabs; f.S = n_slabs; f.slab_stride = slab_stride; f.ldk = ldk; f.k_cols = k_cols; f.n_rows = n_rows;
-  f.row_off = row_off; f.col_off = col_off; f.grad = grad;
-  f.vec4 = (!col_off && (k_cols % 4) == 0 && (ldk % 4) == 0 && (slab_stride % 4) == 0 && (((uintptr_t)slabs | (uintptr_t)grad) & 15) == 0) ? 1 : 0;
-  f.bias_col = bias_col; f.n_bias = n_bias; f.bias_idx = bias_idx; f.grad_bias = grad_bias;
-  t_fold = f;
-  return CTTA_OK;
-}
-static WgradFold take_fold(bool carries) {
-  WgradFold f = {};
-  if (carries) { f = t_fold; t_fold = WgradFold{}; }
-  return f;
-}
-
 extern "C" int ctta_wgrad_implicit_supported(int taps, int c, int h, int w, int x_ld, int n) {
   static int env = -1;
   if (env < 0) { const char* e = getenv("CTTA_WGRAD_IMPLICIT"); env = (e && e[0] == '0') ? 0 : 1; }
@@ -424,7 +396,6 @@ static ctta_status wgrad_implicit_launch(const void* dyt, const void* dy_nat, in
   p.N = n; p.C = c; p.xld = x_ld; p.mp = mp; p.ld = ld;
   p.H = h; p.W = w; p.HW = h * w; p.M = m_valid; p.seg = mp / splits; p.slab_stride = slab_stride;
   if (direct) p.direct = *direct; else memset(&p.direct, 0, sizeof(p.direct));
-  p.fold = take_fold(taps == 9 && nat);       // only the in-place 3x3 kernel carries a pending fold
   hipStream_t s = (hipStream_t)stream;
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, 130 + (taps == 9 ? 1 : 0), n, (long long)c * taps, mp / splits, splits, s);
@@ -486,7 +457,6 @@ struct WgradTnParams {
   long long slab_stride;
   int bias_col;          // >= C: the workgroups of the first column tile also write the column sums of dY there; < 0: none
   WgradDirect direct;
-  WgradFold fold;
 };
 
 __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradTnParams p) {
@@ -500,8 +470,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradTnParams p)
   const int wc = wave & 1, wn = wave >> 1;
   const int c0 = blockIdx.x * 128, n0 = blockIdx.y * 128, split = blockIdx.z;
   const int m_lo = split * p.seg, m_hi = min(m_lo + p.seg, p.mp);
-  if (p.fold.slabs)
-    wgrad_fold_rows(p.fold, (int)((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x), (int)(gridDim.x * gridDim.y * gridDim.z));
 
   int abase[2][2];
 #pragma unroll
@@ -675,7 +643,6 @@ static ctta_status wgrad_tn_launch(const void* dy, int ldy, int n, const void* x
   p.dy = (const bf16_t*)dy; p.x = (const bf16_t*)x; p.slabs = slabs; p.N = n; p.C = c; p.ldy = ldy; p.ldx = ldx; p.ld = ld;
   p.M = m_valid; p.mp = mp; p.seg = mp / splits; p.slab_stride = slab_stride; p.bias_col = bias_col;
   if (direct) p.direct = *direct; else memset(&p.direct, 0, sizeof(p.direct));
-  p.fold = take_fold(true);
   hipStream_t s = (hipStream_t)stream;
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, 142, c, n, p.seg, splits, s);

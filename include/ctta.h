@@ -657,13 +657,6 @@ ctta_status ctta_wgrad_tn(const void* dy, int ldy, int n, const void* x, int ldx
  * row_off[n] < 0 skipped (padding), col = col_off[k] (< 0 skipped) or the identity when col_off is NULL;
  * grad_b[bias_idx[n] or n] += column sum of dY for n < n_bias (grad_b NULL: no bias).  No fp32 slab, no scatter launch; the
  * same bits as slab + ctta_wgrad_scatter_rows_bias(accumulate = 1) with one slab. */
-/* Launch-boundary reduce: the slab fold of ctta_wgrad_scatter_rows_bias(accumulate = 1) handed to the NEXT ctta_wgrad_tn /
- * ctta_wgrad_tn_direct / ctta_wgrad_implicit_inplace / ctta_wgrad_implicit_direct launch of the calling host thread, whose
- * workgroups run it in their prologue (the slabs must be complete on that launch's stream: same stream, issued earlier) --
- * one launch per layer instead of two.  slabs NULL clears a fold that was set and not taken. */
-ctta_status ctta_wgrad_set_pending_fold(const float* slabs, int n_slabs, int64_t slab_stride, int ldk, int k_cols,
-                                        int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad,
-                                        int bias_col, int n_bias, const int32_t* bias_idx, float* grad_bias);
 ctta_status ctta_wgrad_tn_direct(const void* dy, int ldy, int n, const void* x, int ldx, int c, int m_valid, int mp,
                                  int k_cols, int n_rows, const int32_t* row_off, const int32_t* col_off, float* grad_w,
                                  int n_bias, const int32_t* bias_idx, float* grad_b, void* stream);
