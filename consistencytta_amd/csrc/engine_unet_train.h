@@ -141,7 +141,7 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
     // round 5: 256 workgroups / <= 32 splits instead of 512 / 64.  In a replayed step ONE kernel has the device to itself 79 % of
     // the time (profiles/gaps_distill_pipelined_r05.txt): a launch that fills every CU pushes the other streams' kernels behind
     // it, a narrower, longer one runs BESIDE them, and every halving of the splits halves the slab bytes.  Pipelined step
-    // 77.5 -> 76.2 ms at (256, 16..32); too narrow (64 workgroups, 8 splits) loses 4 ms (gpurun r5c15 / r5c16).
+    // 77.5 -> 76.2 ms at (256, 16..32); too narrow (64 workgroups, 8 splits) loses 4 ms (profiles/ab_r05_wgrad_splits.txt).
     if (tn_cap < 0) { const char* e = getenv("CTTA_WGRAD_TN_MAX_SPLITS"); tn_cap = e ? atoi(e) : 32; }
     if (tn_target < 0) { const char* e = getenv("CTTA_WGRAD_TN_TARGET"); tn_target = e ? atoi(e) : 256; }
     while (tiles * S < tn_target && S < tn_cap && M / (2 * S) >= 128) S *= 2;
