@@ -133,19 +133,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
 
   // ---- staging plan: this thread's vectors of the patch and of the dY^T tile
   uint4 xr[XV], br[2];
+  bool xok[XV], bok[2];        // what must read as zero is selected when the vectors are parked (see wgrad_tn_kernel)
+#pragma unroll
+  for (int i = 0; i < XV; ++i) xok[i] = true;
+  bok[0] = bok[1] = true;
   auto fetch = [&](int m0) {
     if (T == 9) {
-      const int img = m0 / p.HW, oh0 = (m0 - img * p.HW) / W;       // a 64-chunk never straddles an image (HW % 64 == 0)
+      // (branch-free like wgrad_tn_kernel's fetch: clamped addresses, zeros selected afterwards -- counted vmcnt waits)
+      const int m0c = m0 < p.M ? m0 : 0;
+      const int img = m0c / p.HW, oh0 = (m0c - img * p.HW) / W;       // a 64-chunk never straddles an image (HW % 64 == 0)
 #pragma unroll
       for (int i = 0; i < XV; ++i) {
         const int q = tid + i * 256;
         const int pix = q / (TC / 8), ch = q - pix * (TC / 8);
         const int pr = pix / Wp, pc = pix - pr * Wp;
         const int ih = oh0 - 1 + pr, iw = pc - 1;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (pix < npix && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)W && c0 + ch * 8 < p.C && m0 < p.M)
-          v = *reinterpret_cast<const uint4*>(p.x + ((size_t)(img * p.H + ih) * W + iw) * p.xld + c0 + ch * 8);
-        xr[i] = v;
+        const bool ok = pix < npix && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)W && c0 + ch * 8 < p.C && m0 < p.M;
+        const int ihc = ih < 0 ? 0 : (ih >= p.H ? p.H - 1 : ih), iwc = iw < 0 ? 0 : (iw >= W ? W - 1 : iw);
+        const int cc = c0 + ch * 8 < p.C ? c0 + ch * 8 : 0;
+        xr[i] = *reinterpret_cast<const uint4*>(p.x + ((size_t)(img * p.H + ihc) * W + iwc) * p.xld + cc);
+        xok[i] = ok;
       }
     } else {
 #pragma unroll
@@ -163,7 +170,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
       const int row = q >> 3, ch = q & 7;
       uint4 v = make_uint4(0, 0, 0, 0);
       if constexpr (NAT) {
-        if (m0 + row < p.M && n0 + ch * 8 < p.N) v = *reinterpret_cast<const uint4*>(p.dy + (size_t)(m0 + row) * p.ldy + n0 + ch * 8);
+        const bool ok = m0 + row < p.M && n0 + ch * 8 < p.N;
+        const int rc = m0 + row < p.M ? m0 + row : p.M - 1, nc = n0 + ch * 8 < p.N ? n0 + ch * 8 : 0;
+        v = *reinterpret_cast<const uint4*>(p.dy + (size_t)rc * p.ldy + nc);
+        bok[i] = ok;
       } else {
         if (n0 + row < p.N) v = *reinterpret_cast<const uint4*>(p.dyt + (size_t)(n0 + row) * p.mp + m0 + ch * 8);   // the pad of dY^T is zero
       }
@@ -189,11 +199,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_implicit_kernel(const WgradParam
     for (int i = 0; i < XV; ++i) {
       const int q = tid + i * 256;
       const int pix = q / (TC / 8), ch = q - pix * (TC / 8);
-      if (pix < npix) *reinterpret_cast<uint4*>(xs + (size_t)pix * RSX + ch * 16) = xr[i];
+      if (pix < npix) *reinterpret_cast<uint4*>(xs + (size_t)pix * RSX + ch * 16) = xok[i] ? xr[i] : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int q = tid + i * 256;
+      if (!bok[i]) br[i] = make_uint4(0, 0, 0, 0);
       *reinterpret_cast<uint4*>(bs + (size_t)(q >> 3) * RSB + (q & 7) * 16) = br[i];
       if (do_sums) {
         float f[8];
@@ -491,16 +502,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradTnParams p)
   // what they stage anyway (a separate column-sum pass over dY cost more than the product: 50 us per launch)
   const bool do_bias = p.bias_col >= 0 && blockIdx.x == 0;
   float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  // BRANCH-FREE: every load is issued (row clamped into the matrix, column chunk clamped to chunk 0 where the tile hangs over
+  // the edge) and what must read as zero is selected afterwards.  With the loads under `if (m < M)` the compiler cannot count
+  // vmcnt across the divergent branches and puts s_waitcnt vmcnt(0) in front of every park: the "two chunks in flight" of the
+  // register stages were one (ISA of round 4's kernel: vmcnt(0) twice per chunk).
+  const int ncol = n_ok ? n0 + sch * 8 : 0, ccol = c_ok ? c0 + sch * 8 : 0;
   auto fetch = [&](uint4 (&v)[8], int m0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + srow + i * 16;
-      uint4 a = make_uint4(0, 0, 0, 0), b = a;
-      if (m < p.M) {
-        if (n_ok) a = *reinterpret_cast<const uint4*>(p.dy + (size_t)m * p.ldy + n0 + sch * 8);
-        if (c_ok) b = *reinterpret_cast<const uint4*>(p.x + (size_t)m * p.ldx + c0 + sch * 8);
-      }
-      v[i] = a; v[4 + i] = b;
+      const int mc = m < p.M ? m : p.M - 1;
+      v[i] = *reinterpret_cast<const uint4*>(p.dy + (size_t)mc * p.ldy + ncol);
+      v[4 + i] = *reinterpret_cast<const uint4*>(p.x + (size_t)mc * p.ldx + ccol);
+    }
+  };
+  // ... the zeros are selected when the stage is PARKED (its loads have landed by then; a select next to the load would make
+  // the compiler wait for it on the spot)
+  auto mask = [&](uint4 (&v)[8], int m0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool row_ok = m0 + srow + i * 16 < p.M;
+      if (!(row_ok && n_ok)) v[i] = make_uint4(0, 0, 0, 0);
+      if (!(row_ok && c_ok)) v[4 + i] = make_uint4(0, 0, 0, 0);
     }
   };
   auto add_bias = [&](const uint4 (&v)[8]) {       // when the stage is parked: its loads have landed
@@ -514,7 +537,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradTnParams p)
       }
     }
   };
-  auto park = [&](const uint4 (&v)[8], int buf) {
+  auto park = [&](uint4 (&v)[8], int m0) {
+    mask(v, m0);
     add_bias(v);
     unsigned char* d = smem + (size_t)srow * RS + sch * 16;
 #pragma unroll
@@ -558,7 +582,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_tn_kernel(const WgradTnParams p)
       const int j = j0 + u;
       if (j < nch) {
         __syncthreads();                                   // chunk j - 1's fragments have been read
-        park(st[u], 0);
+        park(st[u], m_lo + j * 64);
         if (j + 2 < nch) fetch(st[u], m_lo + (j + 2) * 64);
         __syncthreads();
         compute(0);
