@@ -337,12 +337,28 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 //   * ONE workgroup barrier per tile: at the top of iteration t every wave has finished tile t-1, so K slot t & 1 (read by
 //     the scores of tile t, computed during iteration t-1) and V slot (t+1) & 1 (read by PV of tile t-1) are free, and the
 //     DMA issued an iteration ago has landed (s_waitcnt vmcnt(0) in front of the barrier).
-__global__ __launch_bounds__(256, 2) void attention_plain2_kernel(
+// Round 5 (counter passes of tools/pmc_attn.sh: per wave and tile ~830 cycles of VALU issue + 512 of MFMA against 1 270
+// elapsed per SIMD -- the SIMD's issue port is busy 84 % of the time, so what is left is instruction COUNT):
+//   * the loop is unrolled by two with the two score register sets swapping roles: the 32 v_mov_b64 per tile that
+//     copied the next tile's scores into place are gone (the scores of the tile behind the last one are computed from a
+//     stale K slot and never used -- a conditional write would make the compiler carry the old register set across the
+//     branch, which is the same 32 copies again);
+//   * the workgroup's Q fragments live in LDS (4 waves x 4 fragments x 1 KB, lane order, read back by the wave that wrote
+//     them: no barrier) instead of 16 registers for the whole loop; the second LDS-DMA instruction of a stream covers rows
+//     + 32 (same swizzle key, so its source is the first one's plus a UNIFORM offset that rides in the scalar operand);
+//     the V slot sits in the ds_read offset field (a literal per unrolled copy).  168 registers = 3 waves per SIMD with
+//     nothing spilled inside the loop.
+// Same-box A/B against the round-3 form (B 32, 5 heads, 4096 tokens): 0.887 -> 0.865 ms (775 -> 794 TFLOP/s executed).
+// Measured and NOT kept: scale / -max / row sum as v_pk_fma_f32 / v_pk_add_f32 on whole accumulator registers (same time
+// to the microsecond: a packed fp32 operation costs two issue slots beside MFMAs); 256 queries per 512-thread workgroup
+// (one LDS-DMA instruction per wave, stream and tile instead of two: 0.97 ms, one workgroup per CU leaves nobody to run
+// while its eight waves sit at the barrier); two waves per SIMD at 186 registers (same time as three).
+__global__ __launch_bounds__(256, 3) void attention_plain2_kernel(
     const bf16_t* __restrict__ q, int q_ld, const bf16_t* __restrict__ k, int k_ld, int k_rows,
     const bf16_t* __restrict__ vt, int vt_ld, bf16_t* __restrict__ out, int out_ld, int heads, int nq, int nk,
     float scale_log2e, float* __restrict__ lse) {
   // ONE LDS object: with two, hipcc waits vmcnt(0) (all LDS-DMA landed) in front of every ds_read of the other array
-  __shared__ __attribute__((aligned(16))) bf16_t smem[4 * ATT_KT * 64];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[4 * ATT_KT * 64 + 4 * 2048];
   bf16_t (*Ks)[ATT_KT * 64] = reinterpret_cast<bf16_t (*)[ATT_KT * 64]>(smem);                    // [slot][key][d], swizzled chunks
   bf16_t (*Vs)[ATT_KT * 64] = reinterpret_cast<bf16_t (*)[ATT_KT * 64]>(smem + 2 * ATT_KT * 64);  // [slot][d][key], swizzled chunks
   const int tid = threadIdx.x, lane = tid & 63;
@@ -355,57 +371,52 @@ __global__ __launch_bounds__(256, 2) void attention_plain2_kernel(
   const bf16_t* kb = k + (size_t)b * k_rows * k_ld + h * 64;
   const bf16_t* vb = vt + ((size_t)b * heads + h) * 64 * vt_ld;
 
-  bf16x8_t qf[2][2];
+  uint4* const qs = reinterpret_cast<uint4*>(smem + 4 * ATT_KT * 64) + wave * 256 + lane;   // [fragment jq*2 + ds][lane]
 #pragma unroll
   for (int jq = 0; jq < 2; ++jq) {
     int qi = q0 + jq * 16 + lq;
     if (qi >= nq) qi = nq - 1;   // clamp (never stored)
 #pragma unroll
     for (int ds = 0; ds < 2; ++ds)
-      qf[jq][ds] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qb + (size_t)qi * q_ld + ds * 32 + lg * 8));
+      qs[(jq * 2 + ds) * 64] = *reinterpret_cast<const uint4*>(qb + (size_t)qi * q_ld + ds * 32 + lg * 8);
   }
   // LDS-DMA: a wave instruction covers 8 rows x 128 bytes; lane -> (row = lane / 8, chunk position = lane % 8), which
-  // receives the logical chunk (lane % 8) ^ ((row >> 1) & 7) of that row.  A tile is 8 instructions: 2 per wave.
-  // Through buffer descriptors (as conv_gemm does): the per-lane byte offsets are loop invariant, the tile advance rides
-  // in the scalar offset -- and, unlike __builtin_amdgcn_global_load_lds, hipcc does not put s_waitcnt vmcnt(0) in front
-  // of later ds_reads of the OTHER ring slot.
-  const int drow = wave * 16 + (lane >> 3);          // + 8 for the wave's second instruction
+  // receives the logical chunk (lane % 8) ^ ((row >> 1) & 7) of that row.  A tile is 8 instructions: 2 per wave, rows
+  // wave*8 + lane/8 and + 32.  Through buffer descriptors (as conv_gemm does): the per-lane byte offset is loop invariant,
+  // the tile advance rides in the scalar offset -- and, unlike __builtin_amdgcn_global_load_lds, hipcc does not put
+  // s_waitcnt vmcnt(0) in front of later ds_reads of the OTHER ring slot.
+  const int drow = wave * 8 + (lane >> 3);
   const __amdgpu_buffer_rsrc_t rsk = __builtin_amdgcn_make_buffer_rsrc(
       (void*)kb, 0, (unsigned)(((long long)(nk - 1) * k_ld + 64) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsv = __builtin_amdgcn_make_buffer_rsrc(
       (void*)vb, 0, (unsigned)(((long long)63 * vt_ld + nk) * 2), 0x00020000);
-  int koff[2], voff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = drow + i * 8;
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
-    koff[i] = (r * k_ld + c * 8) * 2;
-    voff[i] = (r * vt_ld + c * 8) * 2;
-  }
+  const int dchunk = (lane & 7) ^ ((drow >> 1) & 7);
+  const int koff = (drow * k_ld + dchunk * 8) * 2;
+  const int voff = (drow * vt_ld + dchunk * 8) * 2;
   auto issue_k = [&](int key0, int slot) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(&Ks[slot][(wave * 16 + i * 8) * 64]), 16,
-                                               koff[i], key0 * k_ld * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsk, (__attribute__((address_space(3))) void*)(&Ks[slot][(wave * 8 + i * 32) * 64]), 16,
+                                               koff, (key0 + i * 32) * k_ld * 2, 0, 0);
   };
   auto issue_v = [&](int key0, int slot) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(&Vs[slot][(wave * 16 + i * 8) * 64]), 16,
-                                               voff[i], key0 * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsv, (__attribute__((address_space(3))) void*)(&Vs[slot][(wave * 8 + i * 32) * 64]), 16,
+                                               voff, key0 * 2 + i * 32 * vt_ld * 2, 0, 0);
   };
   const int fsw = (lq >> 1) & 7;                      // swizzle of the fragment rows this lane reads (row % 16 == lq)
   auto scores = [&](int slot, f32x4_t (&s)[4][2]) {
 #pragma unroll
-    for (int ik = 0; ik < 4; ++ik) {
+    for (int ds = 0; ds < 2; ++ds) {
+      const bf16x8_t qa = __builtin_bit_cast(bf16x8_t, qs[ds * 64]), qc = __builtin_bit_cast(bf16x8_t, qs[(2 + ds) * 64]);
 #pragma unroll
-      for (int jq = 0; jq < 2; ++jq) s[ik][jq] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ds = 0; ds < 2; ++ds) {
+      for (int ik = 0; ik < 4; ++ik) {
         const bf16x8_t kf = __builtin_bit_cast(
             bf16x8_t, *reinterpret_cast<const uint4*>(&Ks[slot][(ik * 16 + lq) * 64 + (((ds * 4 + lg) ^ fsw) * 8)]));
-#pragma unroll
-        for (int jq = 0; jq < 2; ++jq) s[ik][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[jq][ds], s[ik][jq], 0, 0, 0);
+        const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
+        s[ik][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qa, ds ? s[ik][0] : z, 0, 0, 0);
+        s[ik][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qc, ds ? s[ik][1] : z, 0, 0, 0);
       }
     }
   };
@@ -434,14 +445,15 @@ __global__ __launch_bounds__(256, 2) void attention_plain2_kernel(
   if (ntiles > 1) issue_k(ATT_KT, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  f32x4_t sc[4][2], sn[4][2];
-  scores(0, sc);
-  for (int t = 0; t < ntiles; ++t) {
+  f32x4_t sa[4][2], sb[4][2];
+  scores(0, sa);
+  // one tile: `sc` holds the raw scores of tile t, `sn` receives those of tile t + 1; `par` = t & 1 as a literal
+  auto tile_step = [&](int t, const int par, f32x4_t (&sc)[4][2], f32x4_t (&sn)[4][2]) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of K(t+1) / V(t) has landed ...
     __builtin_amdgcn_s_barrier();                        // ... and so has everybody else's; tile t-1 is finished everywhere
-    if (t + 2 < ntiles) issue_k((t + 2) * ATT_KT, t & 1);
-    if (t + 1 < ntiles) issue_v((t + 1) * ATT_KT, (t + 1) & 1);
-    if (t + 1 < ntiles) scores((t + 1) & 1, sn);
+    if (t + 2 < ntiles) issue_k((t + 2) * ATT_KT, par);
+    if (t + 1 < ntiles) issue_v((t + 1) * ATT_KT, par ^ 1);
+    scores(par ^ 1, sn);
     // ---- softmax of tile t on the raw products (scale > 0): max, then scale and -max folded into one FMA before exp2
 #pragma unroll
     for (int jq = 0; jq < 2; ++jq) {
@@ -477,17 +489,15 @@ __global__ __launch_bounds__(256, 2) void attention_plain2_kernel(
     // order, so the compiler's own counted lgkmcnt waits stay correct (at worst they wait for more); the values read
     // here are consumed behind an explicit lgkmcnt(0).
     // (Measured alternatives, tools/attn_bench.py at B=32, 5 heads, 4096 tokens: all 16 reads up front + PV per query
-    // block behind its half of the softmax: 192 VGPRs = 2 waves per SIMD, 727 TFLOP/s; this form: 164 VGPRs = 3 waves per
-    // SIMD, 790; round 2's kernel 717.)
-    const unsigned vs_off = (unsigned)(2 * ATT_KT * 64 * 2 + (t & 1) * (ATT_KT * 64 * 2));   // byte offset of V slot t & 1 in smem
+    // block behind its half of the softmax: 192 VGPRs = 2 waves per SIMD, 727 TFLOP/s; this form 790; round 2's kernel 717.)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       uint2 lo[4], hi[4];
-      const unsigned a0 = lds_base + vs_off + vbase[kk][0], a1 = lds_base + vs_off + vbase[kk][1];
+      const unsigned a0 = lds_base + vbase[kk][0], a1 = lds_base + vbase[kk][1];
 #pragma unroll
-      for (int jd = 0; jd < 4; ++jd) {
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo[jd]) : "v"(a0), "n"(jd * 2048));
-        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi[jd]) : "v"(a1), "n"(jd * 2048));
+      for (int jd = 0; jd < 4; ++jd) {   // "i": a constant once tile_step is inlined with a literal `par`
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(lo[jd]) : "v"(a0), "i"(2 * ATT_KT * 64 * 2 + par * (ATT_KT * 64 * 2) + jd * 2048));
+        asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(hi[jd]) : "v"(a1), "i"(2 * ATT_KT * 64 * 2 + par * (ATT_KT * 64 * 2) + jd * 2048));
       }
       bf16x8_t pf[2];
 #pragma unroll
@@ -508,13 +518,13 @@ __global__ __launch_bounds__(256, 2) void attention_plain2_kernel(
         for (int jq = 0; jq < 2; ++jq) o[jd][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[jq], o[jd][jq], 0, 0, 0);
       }
     }
-    if (t + 1 < ntiles) {
-#pragma unroll
-      for (int ik = 0; ik < 4; ++ik)
-#pragma unroll
-        for (int jq = 0; jq < 2; ++jq) sc[ik][jq] = sn[ik][jq];
-    }
+  };
+  int t = 0;
+  for (; t + 1 < ntiles; t += 2) {
+    tile_step(t, 0, sa, sb);
+    tile_step(t + 1, 1, sb, sa);
   }
+  if (t < ntiles) tile_step(t, 0, sa, sb);
 #pragma unroll
   for (int jq = 0; jq < 2; ++jq) {
     const float l = rows_sum(lrun[jq]);

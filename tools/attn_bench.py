@@ -15,7 +15,10 @@ DEV = "cuda:0"
 
 def main():
     L = N.lib()
-    for (B, H, n, dh) in [(32, 5, 4096, 51), (32, 10, 1024, 51), (32, 20, 256, 51), (9, 5, 4096, 51), (2, 3, 320, 51)]:
+    shapes = [(32, 5, 4096, 51), (32, 10, 1024, 51), (32, 20, 256, 51), (9, 5, 4096, 51), (2, 3, 320, 51)]
+    if os.environ.get("ATTN_SHAPES"):            # e.g. ATTN_SHAPES=0 for counter passes: one shape only
+        shapes = [shapes[int(i)] for i in os.environ["ATTN_SHAPES"].split(",")]
+    for (B, H, n, dh) in shapes:
         hp = H * 64
         g = torch.Generator().manual_seed(n)
         q = torch.zeros(B, n, hp)
