@@ -183,6 +183,7 @@ SIGNATURES = {
     "ctta_conv_workspace_bytes": (c_size_t, []),
     "ctta_conv_suppress_splitk": (None, [c_int]),
     "ctta_conv_debug_stamps": (None, [c_void_p]),
+    "ctta_attention_debug_stamps": (None, [c_void_p]),
     "ctta_conv_gemm_num_variants": (c_int, []),
     "ctta_conv_gemm_variant_name": (c_char_p, [c_int]),
     "ctta_attention_fullbias": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p,

@@ -353,12 +353,20 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(
 // to the microsecond: a packed fp32 operation costs two issue slots beside MFMAs); 256 queries per 512-thread workgroup
 // (one LDS-DMA instruction per wave, stream and tile instead of two: 0.97 ms, one workgroup per CU leaves nobody to run
 // while its eight waves sit at the barrier); two waves per SIMD at 186 registers (same time as three).
+// STAMP (tools/attn_timeline.py): every wave notes s_memtime at six points of every tile (first 64 tiles) in LDS and the
+// workgroup dumps them -- plus the hardware id of each wave -- when it is done.
+// ABL (timing only, WRONG results; CTTA_ATTN_ABLATE): 1 no LDS-DMA inside the loop, 2 plain FMAs instead of the
+// exponentials, 4 no score MFMAs, 6 no cross-lane row maximum -- what each component costs with everything else in place
+// (profiles/attn_timeline_r05.txt: 0.866 ms whole; 0.753 / 0.776 / 0.751 / 0.835 without: every part costs its 4-13 % and none
+// hides behind another -- the loop is bound by the number of instructions a SIMD issues, not by one pipe).
+template <bool STAMP, int ABL>
 __global__ __launch_bounds__(256, 3) void attention_plain2_kernel(
     const bf16_t* __restrict__ q, int q_ld, const bf16_t* __restrict__ k, int k_ld, int k_rows,
     const bf16_t* __restrict__ vt, int vt_ld, bf16_t* __restrict__ out, int out_ld, int heads, int nq, int nk,
-    float scale_log2e, float* __restrict__ lse) {
+    float scale_log2e, float* __restrict__ lse, unsigned* __restrict__ stamps) {
   // ONE LDS object: with two, hipcc waits vmcnt(0) (all LDS-DMA landed) in front of every ds_read of the other array
-  __shared__ __attribute__((aligned(16))) bf16_t smem[4 * ATT_KT * 64 + 4 * 2048];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[4 * ATT_KT * 64 + 4 * 2048 + (STAMP ? 4 * 64 * 6 * 2 : 0)];
+  unsigned* const stl = reinterpret_cast<unsigned*>(smem + 4 * ATT_KT * 64 + 4 * 2048);   // [wave][tile][6]
   bf16_t (*Ks)[ATT_KT * 64] = reinterpret_cast<bf16_t (*)[ATT_KT * 64]>(smem);                    // [slot][key][d], swizzled chunks
   bf16_t (*Vs)[ATT_KT * 64] = reinterpret_cast<bf16_t (*)[ATT_KT * 64]>(smem + 2 * ATT_KT * 64);  // [slot][d][key], swizzled chunks
   const int tid = threadIdx.x, lane = tid & 63;
@@ -415,8 +423,13 @@ __global__ __launch_bounds__(256, 3) void attention_plain2_kernel(
         const bf16x8_t kf = __builtin_bit_cast(
             bf16x8_t, *reinterpret_cast<const uint4*>(&Ks[slot][(ik * 16 + lq) * 64 + (((ds * 4 + lg) ^ fsw) * 8)]));
         const f32x4_t z = {0.f, 0.f, 0.f, 0.f};
-        s[ik][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qa, ds ? s[ik][0] : z, 0, 0, 0);
-        s[ik][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qc, ds ? s[ik][1] : z, 0, 0, 0);
+        if constexpr (ABL == 4) {
+          s[ik][0] = ds ? s[ik][0] + __builtin_bit_cast(f32x4_t, kf) : __builtin_bit_cast(f32x4_t, qa);
+          s[ik][1] = ds ? s[ik][1] + __builtin_bit_cast(f32x4_t, kf) : __builtin_bit_cast(f32x4_t, qc);
+        } else {
+          s[ik][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qa, ds ? s[ik][0] : z, 0, 0, 0);
+          s[ik][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qc, ds ? s[ik][1] : z, 0, 0, 0);
+        }
       }
     }
   };
@@ -449,11 +462,16 @@ __global__ __launch_bounds__(256, 3) void attention_plain2_kernel(
   scores(0, sa);
   // one tile: `sc` holds the raw scores of tile t, `sn` receives those of tile t + 1; `par` = t & 1 as a literal
   auto tile_step = [&](int t, const int par, f32x4_t (&sc)[4][2], f32x4_t (&sn)[4][2]) __attribute__((always_inline)) {
+    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0, ts3 = 0, ts4 = 0, ts5 = 0;
+    if constexpr (STAMP) ts0 = __builtin_amdgcn_s_memtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of K(t+1) / V(t) has landed ...
     __builtin_amdgcn_s_barrier();                        // ... and so has everybody else's; tile t-1 is finished everywhere
-    if (t + 2 < ntiles) issue_k((t + 2) * ATT_KT, par);
-    if (t + 1 < ntiles) issue_v((t + 1) * ATT_KT, par ^ 1);
+    if constexpr (STAMP) ts1 = __builtin_amdgcn_s_memtime();
+    if (ABL != 1 && t + 2 < ntiles) issue_k((t + 2) * ATT_KT, par);
+    if (ABL != 1 && t + 1 < ntiles) issue_v((t + 1) * ATT_KT, par ^ 1);
+    if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); ts5 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     scores(par ^ 1, sn);
+    if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); ts2 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     // ---- softmax of tile t on the raw products (scale > 0): max, then scale and -max folded into one FMA before exp2
 #pragma unroll
     for (int jq = 0; jq < 2; ++jq) {
@@ -464,7 +482,7 @@ __global__ __launch_bounds__(256, 3) void attention_plain2_kernel(
         mx = vmax3(mx, sc[ik][jq][0], sc[ik][jq][1]);
         mx = vmax3(mx, sc[ik][jq][2], sc[ik][jq][3]);
       }
-      mx = rows_max(mx);
+      if constexpr (ABL != 6) mx = rows_max(mx); else mx = sc[0][jq][0];
       const float mnew = vmax2(mrun[jq], mx * scale_log2e);
       const float alpha = fast_exp2(mrun[jq] - mnew);
       mrun[jq] = mnew;
@@ -473,7 +491,7 @@ __global__ __launch_bounds__(256, 3) void attention_plain2_kernel(
       for (int ik = 0; ik < 4; ++ik)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float pv = fast_exp2(fmaf(sc[ik][jq][r], scale_log2e, -mnew));
+          const float pv = ABL == 2 ? fmaf(sc[ik][jq][r], scale_log2e, -mnew) : fast_exp2(fmaf(sc[ik][jq][r], scale_log2e, -mnew));
           sc[ik][jq][r] = pv;
           ps += pv;
         }
@@ -483,6 +501,7 @@ __global__ __launch_bounds__(256, 3) void attention_plain2_kernel(
         for (int jd = 0; jd < 4; ++jd) o[jd][jq] *= alpha;
       }
     }
+    if constexpr (STAMP) { __builtin_amdgcn_sched_barrier(0); ts3 = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); }
     // ---- O^T += V^T P^T.  The V^T fragments are read with inline-asm ds_read_b64: hipcc merges the compiler-visible
     // form into ds_read2st64_b64 and then waits vmcnt(0) -- i.e. for the LDS-DMA of the NEXT tiles, issued a few hundred
     // cycles earlier -- in front of it (the K fragments' ds_read_b128 get no such wait).  LDS operations return in
@@ -518,6 +537,14 @@ __global__ __launch_bounds__(256, 3) void attention_plain2_kernel(
         for (int jq = 0; jq < 2; ++jq) o[jd][jq] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf[jq], o[jd][jq], 0, 0, 0);
       }
     }
+    if constexpr (STAMP) {
+      __builtin_amdgcn_sched_barrier(0);
+      ts4 = __builtin_amdgcn_s_memtime();
+      if (t < 64 && lane == 0) {
+        unsigned* d = stl + (wave * 64 + t) * 6;
+        d[0] = (unsigned)ts0; d[1] = (unsigned)ts1; d[2] = (unsigned)ts5; d[3] = (unsigned)ts2; d[4] = (unsigned)ts3; d[5] = (unsigned)ts4;
+      }
+    }
   };
   int t = 0;
   for (; t + 1 < ntiles; t += 2) {
@@ -542,7 +569,19 @@ __global__ __launch_bounds__(256, 3) void attention_plain2_kernel(
       }
     }
   }
+  if constexpr (STAMP) {
+    __syncthreads();
+    unsigned* dst = stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (4 * 64 * 6 + 8);
+    for (int i = tid; i < 4 * 64 * 6; i += 256) dst[i] = stl[i];
+    if (lane == 0) {
+      dst[4 * 64 * 6 + wave] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));       // HW_ID
+      dst[4 * 64 * 6 + 4 + wave] = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));   // XCC_ID
+    }
+  }
 }
+// debugging aid, like ctta_conv_debug_stamps: buf = (4 * 64 * 6 + 8) unsigned per workgroup of the next self-attention launches
+static thread_local unsigned* t_attn_stamps = nullptr;
+extern "C" void ctta_attention_debug_stamps(void* buf) { t_attn_stamps = (unsigned*)buf; }
 static int attn_v2_mode() {   // CTTA_ATTN_V2=0: round 2's kernel for self-attention (A/B switch)
   static int v = -1;
   if (v < 0) { const char* e = getenv("CTTA_ATTN_V2"); v = e ? atoi(e) : 1; }
@@ -568,9 +607,21 @@ extern "C" ctta_status ctta_attention_lse(const void* q, int q_ld, const void* k
   // executed flops: QK^T and PV over the padded head dim (2 * 2*nq*nk*64 per head)
   if (prof) ctta_prof_begin(1, 0, nq, nk, 128, (long long)batch * heads, (hipStream_t)stream);
   if (!bias && nk % ATT_KT == 0 && attn_plain_enabled() && attn_v2_mode() && nk >= 2 * ATT_KT)
-    hipLaunchKernelGGL(attention_plain2_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
-                       (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, (bf16_t*)out, out_ld, heads, nq, nk,
-                       scale * 1.4426950408889634f, lse);
+  {
+#define CTTA_ATTN_LAUNCH(ST, AB, SP)                                                                                          \
+  hipLaunchKernelGGL((attention_plain2_kernel<ST, AB>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,     \
+                     (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, (bf16_t*)out, out_ld, heads, nq, nk,          \
+                     scale * 1.4426950408889634f, lse, SP)
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("CTTA_ATTN_ABLATE"); abl = e ? atoi(e) : 0; }
+    if (t_attn_stamps) CTTA_ATTN_LAUNCH(true, 0, t_attn_stamps);
+    else if (abl == 1) CTTA_ATTN_LAUNCH(false, 1, nullptr);
+    else if (abl == 2) CTTA_ATTN_LAUNCH(false, 2, nullptr);
+    else if (abl == 4) CTTA_ATTN_LAUNCH(false, 4, nullptr);
+    else if (abl == 6) CTTA_ATTN_LAUNCH(false, 6, nullptr);
+    else CTTA_ATTN_LAUNCH(false, 0, nullptr);
+#undef CTTA_ATTN_LAUNCH
+  }
   else if (!bias && nk % ATT_KT == 0 && attn_plain_enabled())   // self-attention over whole key tiles: no additive term
     hipLaunchKernelGGL(attention_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,
                        (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, bias, (bf16_t*)out, out_ld, heads,

@@ -359,6 +359,11 @@ void ctta_conv_suppress_splitk(int on);
  * {HW_ID register, s_memtime at entry, after the first K-tile landed, after the main loop, after the epilogue's last
  * store was issued, before the first K-tile request} to buf[6 * linear workgroup index] (tools/tile_timeline.py).  buf: >= 48 bytes per workgroup. */
 void ctta_conv_debug_stamps(void* buf);
+/* Diagnostic: while `buf` is non-NULL the self-attention forward launches of this host thread (no bias, nk % 64 == 0) run an
+ * instrumented twin that writes, per workgroup, 4 waves x 64 key tiles x 6 s_memtime stamps (low 32 bits: tile top, after
+ * the barrier, after the LDS-DMA issue, after the next tile's scores, after the softmax, after P V) followed by the four
+ * waves' HW_ID and XCC_ID registers: (4 * 64 * 6 + 8) 32-bit words per workgroup (tools/attn_timeline.py). */
+void ctta_attention_debug_stamps(void* buf);
 size_t ctta_conv_workspace_bytes(void);
 int ctta_conv_gemm_num_variants(void);
 const char* ctta_conv_gemm_variant_name(int id);
