@@ -251,7 +251,6 @@ static const Variant kVariants[] = {
     VARIANT(128, 128, 64, 2, 2, 2, 3),  // 38  workgroup is ~1.1 us per K step whatever the tile)
     VARIANT(128, 64, 64, 2, 2, 2, 3),   // 39
     VARIANT(128, 128, 64, 2, 2, 2, 4),  // 40
-    VARIANT(256, 256, 64, 2, 4, 3, 2),  // 41  slab mode of the big tile: stride-1 1-D convolutions stage (BM + halo) rows once per channel chunk
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -538,20 +537,6 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       if ((wgs >= 512 && wgs * 100 >= rounds * 512 * 85) || (thin_ring && wgs > 384 && wgs <= 512)) vid = ring == 2 ? 17 : 27;   // CTTA_THIN_RING=2: 128x128x64 instead (A/B)
     }
   }
-  // Slab mode (variant 41): what the kernel's MODE 3 assumes -- a stride-1 "same" 1-D convolution of one source whose
-  // channel count is a multiple of 64, a halo of at most 64 rows, sequences longer than a tile, no K split.
-  auto slab_ok = [&]() {
-    return d->kh == 1 && d->hi == 1 && d->ho == 1 && d->stride_w == 1 && !d->upsample && p.c1 == 0 && !d->in_act &&
-           p.ct % 64 == 0 && p.taps >= 2 && (p.taps - 1) * d->dil_w <= 64 && d->wo == d->wi && d->wo >= 512 &&
-           2 * d->pad_w == (p.taps - 1) * d->dil_w && groups == 1 && !geglu && fast_ok(64) &&
-           M * (long long)p.xs0 * 2 < 0xFFFFFF00LL;
-  };
-  {
-    static int slab_env = -1;   // CTTA_SLAB=0: the per-tap descriptor path for every big-tile launch (A/B switch)
-    if (slab_env < 0) { const char* e = getenv("CTTA_SLAB"); slab_env = (e && e[0] == '0') ? 0 : 1; }
-    if (slab_env && d->tile <= 0 && vid == kBigTile && p.taps >= 3 && slab_ok()) vid = 41;
-  }
-  CTTA_REQUIRE(kVariants[vid - 1].mode != 3 || slab_ok(), "conv_gemm: variant %s is for stride-1 'same' 1-D convolutions (c %% 64 == 0, halo <= 64 rows)", kVariants[vid - 1].name);
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
   if (geglu) {   // direct epilogue: <= 8-fragment tiles (64x64, 64x128, 128x64, 256x32); wide-store: also the 128x128 tiles
     const Variant& gv = kVariants[vid - 1];
@@ -580,7 +565,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   size_t ws_bytes = 0;
   static int tiles_gate = -1;   // launches with fewer tiles than this are split over K (CTTA_SPLITK_TILES, tuning knob)
   if (tiles_gate < 0) { const char* e = getenv("CTTA_SPLITK_TILES"); tiles_gate = e ? atoi(e) : 192; }
-  if (splitk_default() && groups == 1 && !scalar_store && !geglu && d->out_limit == 0 && d->out_offset == 0 && v.mode != 3 &&
+  if (splitk_default() && groups == 1 && !scalar_store && !geglu && d->out_limit == 0 && d->out_offset == 0 &&
       tiles < tiles_gate && p.nk >= splitk_min_nk() && (ws = splitk_workspace(&ws_bytes)) != nullptr) {
     static int target = -1, cap = -1;   // tuning knobs: workgroups aimed for / most splits
     if (target < 0) { const char* e = getenv("CTTA_SPLITK_TARGET"); target = e ? atoi(e) : 512; }

@@ -24,7 +24,6 @@
 #include "common.h"
 
 #include <stdlib.h>
-#include <type_traits>
 
 #include "conv_epilogue.h"
 
@@ -220,17 +219,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   // LDS path that bounds the thin launches -- and runs at 0.3-0.6x the LDS-DMA tiles on every shape
   // (profiles/sweep_r05_mode4.txt): a fragment load touches 16 rows x 64 bytes, a quarter of the rate of full-line DMA.)
   constexpr bool FAST = MODE == 2;
-  // MODE 3 ("slab", round 5): stride-1 1-D convolutions on the big tile.  The descriptor path above re-stages the BM x BK
-  // activation tile for EVERY tap although consecutive taps of one channel chunk read the same rows shifted by the
-  // dilation; an LDS-DMA instruction costs ~55 cycles of its SIMD (profiles/attn_timeline_r05.txt), and with the
-  // activation LDS-DMA ablated the big tile runs 12-14 % faster.  Here the BM + (taps - 1) * dilation rows a channel chunk's
-  // taps touch are staged ONCE per chunk (double-buffered, (BM + 64) rows each), a tap is a row offset into that slab --
-  // the chunk swizzle key is row & 7, conflict-free for ANY 16-row window -- and only the weight tile is staged per K
-  // step.  Tiles stay flat over M (whole rounds of the CUs); a tile whose slab crosses a sequence boundary zeroes, per
-  // fragment and tap, the rows whose tap leaves their own sequence (the slab holds the neighbour's rows there).
-  constexpr bool SLAB = MODE == 3;
-  constexpr int SLAB_ROWS = BM + 64;
-  static_assert(!SLAB || (BK == 64 && STAGES == 2), "slab mode: BK = 64, two-slot weight ring");
   static_assert(STAGES == 2 || GLDS, "multi-stage ring needs the direct-to-LDS path");
   constexpr int NT = 64 * WM * WN;
   constexpr int LDK = BK;              // bf16 elements per LDS row: no padding, XOR-swizzled chunks
@@ -249,7 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_raw);               // [STAGES][BM][LDK]
-  bf16_t* Ws = Xs + (SLAB ? 2 * SLAB_ROWS : STAGES * BM) * LDK;    // [STAGES][BN][LDK]   (slab mode: Xs = [2][SLAB_ROWS][LDK])
+  bf16_t* Ws = Xs + STAGES * BM * LDK;                             // [STAGES][BN][LDK]
   unsigned long long* stamp = nullptr;
   if (p.stamps) {
     stamp = p.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 6;
@@ -533,47 +521,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     if (ftap == p.taps) { ftap = 0; fkh = 0; fkw = 0; fcb += BK; }
   };
 
-  // ---------------- MODE 3: slab path (1-D, stride 1, one source, taps innermost like MODE 2)
-  constexpr int SP = SLAB_ROWS / RPP;          // slab rows per thread (one LDS-DMA instruction each)
-  unsigned svoff[SLAB ? SP : 1];
-  bool slab_edge = false;                       // the slab crosses a sequence boundary: masked fragments
-  int slab_l0 = 0;                              // position inside its sequence of this lane's first fragment row
-  if constexpr (SLAB) {
-    rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x0, 0, p.x_bytes, 0x00020000);
-    rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, p.w_bytes, 0x00020000);
-    const int p0 = m0 - p.pw;                   // flat position of slab row 0
-#pragma unroll
-    for (int i = 0; i < SP; ++i) {
-      const int pos = p0 + r0 + i * RPP;
-      svoff[i] = (unsigned)pos < (unsigned)p.M ? (unsigned)(pos * p.xs0 + kc * 8) * 2u : 0xFFFFFFF0u;   // outside the tensor: zeros
-    }
-#pragma unroll
-    for (int j = 0; j < WP; ++j) fwoff[j] = (unsigned)((n0 + r0 + j * RPP) * p.k_pad + kc * 8) * 2u;
-    const int L = p.howo;
-    const int lo = max(p0, 0), hi_ = min(p0 + BM + (p.taps - 1) * p.dw, p.M) - 1;
-    slab_edge = fast_div(lo, L, p.howo_inv) != fast_div(hi_, L, p.howo_inv);
-    const int mrow = m0 + wm * TM + (lane & 15);
-    slab_l0 = mrow - fast_div(min(mrow, p.M - 1), L, p.howo_inv) * L;
-  }
-  auto issue_slab = [&](int cb, int buf) {      // channel chunk cb (64 channels) -> slab buffer buf
-    bf16_t* xs = Xs + buf * SLAB_ROWS * LDK + wave_u * ROWS_PER_INSTR * LDK;
-#pragma unroll
-    for (int i = 0; i < SP; ++i) {
-      const unsigned v = svoff[i] == 0xFFFFFFF0u ? svoff[i] : svoff[i] + (unsigned)(cb * BK * 2);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (__attribute__((address_space(3))) void*)(xs + i * RPP * LDK), 16,
-                                               (int)v, 0, 0, 0);
-    }
-  };
-  auto issue_w = [&](int kt, int buf) {         // weight tile of K step kt = (chunk kt / taps, tap kt % taps)
-    bf16_t* ws = Ws + buf * BN * LDK + wave_u * ROWS_PER_INSTR * LDK;
-    const int soff = (ftap * p.ct + fcb) * 2;
-#pragma unroll
-    for (int j = 0; j < WP; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ws + j * RPP * LDK), 16,
-                                               (int)fwoff[j], soff, 0, 0);
-    if (++ftap == p.taps) { ftap = 0; fcb += BK; }
-  };
-
   f32x4_t acc[FN][FM];
 #pragma unroll
   for (int i = 0; i < FN; ++i)
@@ -605,61 +552,6 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     }
   };
 
-  // slab mode: the position fragments come out of slab buffer `sbuf` at row offset `toff` = tap * dilation
-  auto compute_slab = [&](int wbuf, int sbuf, int toff, int tap_shift, auto masked) {
-    const bf16_t* xs = Xs + sbuf * SLAB_ROWS * LDK + (wm * TM + frow + toff) * LDK;
-    const bf16_t* ws = Ws + wbuf * BN * LDK + (wn * TN + frow) * LDK;
-    const int xswz = (frow + toff) & SWZ_MASK;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      bf16x8_t af[FN], bfr[FM];
-      const int koff = (((ks * 4 + fchunk) ^ fswz) & SWZ_MASK) * 8;
-      const int xoff = (((ks * 4 + fchunk) ^ xswz) & SWZ_MASK) * 8;
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-        af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ws + i * 16 * LDK + koff));
-#pragma unroll
-      for (int j = 0; j < FM; ++j) {
-        uint4 v = *reinterpret_cast<const uint4*>(xs + j * 16 * LDK + xoff);
-        if constexpr (decltype(masked)::value) {   // this row's tap leaves its sequence: zero padding, not the neighbour's rows
-          int l = slab_l0 + j * 16;
-          if (l >= p.howo) l -= p.howo;
-          if ((unsigned)(l + tap_shift) >= (unsigned)p.howo) v = make_uint4(0, 0, 0, 0);
-        }
-        bfr[j] = __builtin_bit_cast(bf16x8_t, v);
-      }
-#pragma unroll
-      for (int i = 0; i < FN; ++i)
-#pragma unroll
-        for (int j = 0; j < FM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-  };
-
-  if constexpr (SLAB) {
-    // K step kt = (chunk cb, tap): weights two-slot ring one step ahead; the slab of chunk cb + 1 goes out at tap 0 of chunk
-    // cb into the buffer chunk cb - 1 used (every wave is past it: it passed this step's barrier).
-    const int nchunk = nk / p.taps;
-    issue_slab(0, 0);
-    issue_w(0, 0);
-    auto k_loop = [&](auto masked) __attribute__((always_inline)) {   // two copies of the loop, not a branch inside it
-      int tap = 0, cb = 0;
-      bool slab_in_flight = false;   // the previous step sent the next chunk's slab out BEHIND its weight tile: let it fly
-      for (int kt = 0; kt < nk; ++kt) {
-        if (slab_in_flight) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SP) : "memory");   // (it is waited for one step later,
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                            //  taps - 1 steps before its use)
-        __builtin_amdgcn_s_barrier();
-        if (kt + 1 < nk) issue_w(kt + 1, (kt + 1) & 1);
-        slab_in_flight = tap == 0 && cb + 1 < nchunk && kt + 1 < nk;
-        if (tap == 0 && cb + 1 < nchunk) issue_slab(cb + 1, (cb + 1) & 1);
-        if (wave_live) compute_slab(kt & 1, cb & 1, tap * p.dw, tap * p.dw - p.pw, masked);
-        if (++tap == p.taps) { tap = 0; ++cb; }
-      }
-    };
-    if (slab_edge) k_loop(std::true_type{});
-    else k_loop(std::false_type{});
-    __syncthreads();
-  } else
   if constexpr (STAGES > 2) {
     constexpr int LPT = XP + WP;                 // LDS-DMA instructions per wave per tile
     constexpr int INFLIGHT = (STAGES - 2) * LPT; // what may stay outstanding while tile kt is consumed
@@ -1005,14 +897,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 
 
 // ---- launchers (explicitly instantiated in conv_gemm_i1..6.hip so that the tile variants compile in parallel)
-template <int BM, int BN, int BK, int STAGES, int MODE = 0>
-static constexpr size_t smem_bytes() {
-  return MODE == 3 ? (size_t)(2 * (BM + 64) + STAGES * BN) * BK * 2 : (size_t)STAGES * (BM + BN) * BK * 2;
-}
+template <int BM, int BN, int BK, int STAGES>
+static constexpr size_t smem_bytes() { return (size_t)STAGES * (BM + BN) * BK * 2; }
 
 template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES>
 void launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
-  const size_t smem = smem_bytes<BM, BN, BK, STAGES, GLDS>();
+  const size_t smem = smem_bytes<BM, BN, BK, STAGES>();
   conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
 }
 
@@ -1022,7 +912,7 @@ ctta_status prepare_variant() {
   if (done) return CTTA_OK;
   CTTA_CHECK_HIP(hipFuncSetAttribute(
       reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<BM, BN, BK, STAGES, GLDS>()));
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<BM, BN, BK, STAGES>()));
   done = true;
   return CTTA_OK;
 }
@@ -1071,14 +961,12 @@ ctta_status prepare_variant() {
   X(128, 128, 32, 2, 2, 2, 3) \
   X(64, 128, 64, 2, 2, 2, 3) \
   X(256, 128, 32, 4, 2, 2, 2)
-#define CTTA_CONV_VARIANTS_9(X) \
-  X(256, 256, 64, 2, 4, 3, 2)
 #define CTTA_CONV_VARIANTS_8(X) \
   X(64, 128, 64, 2, 2, 2, 4) \
   X(128, 128, 64, 2, 2, 2, 3) \
   X(128, 64, 64, 2, 2, 2, 3) \
   X(128, 128, 64, 2, 2, 2, 4)
-#define CTTA_CONV_VARIANTS_ALL(X) CTTA_CONV_VARIANTS_9(X) CTTA_CONV_VARIANTS_8(X) CTTA_CONV_VARIANTS_1(X) CTTA_CONV_VARIANTS_2(X) CTTA_CONV_VARIANTS_3(X) CTTA_CONV_VARIANTS_4(X) CTTA_CONV_VARIANTS_5(X) CTTA_CONV_VARIANTS_6(X) CTTA_CONV_VARIANTS_7(X)
+#define CTTA_CONV_VARIANTS_ALL(X) CTTA_CONV_VARIANTS_8(X) CTTA_CONV_VARIANTS_1(X) CTTA_CONV_VARIANTS_2(X) CTTA_CONV_VARIANTS_3(X) CTTA_CONV_VARIANTS_4(X) CTTA_CONV_VARIANTS_5(X) CTTA_CONV_VARIANTS_6(X) CTTA_CONV_VARIANTS_7(X)
 #define CTTA_CONV_INSTANTIATE(BM, BN, BK, WM, WN, G, S)                                      \
   template void launch_variant<BM, BN, BK, WM, WN, G, S>(const ConvParams&, dim3, hipStream_t); \
   template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S>();

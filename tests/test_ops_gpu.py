@@ -186,49 +186,6 @@ def test_conv1d_halo_kernel(C, k, d, L):
     assert rel_err(outs[0], outs[1]) < BF16_TOL      # halo kernel vs generic kernel
 
 
-@pytest.mark.parametrize("C,Co,k,d,L,B", [(64, 64, 11, 5, 600, 3), (128, 256, 7, 3, 513, 2), (64, 72, 3, 1, 1024, 2),
-                                          (256, 64, 11, 1, 777, 3), (64, 64, 3, 5, 2000, 1), (128, 64, 7, 5, 640, 4)])
-def test_conv1d_slab_mode_of_the_big_tile(C, Co, k, d, L, B):
-    """Tile 41 (conv_gemm MODE 3): stride-1 'same' 1-D convolutions stage the BM + halo rows of a channel chunk once and read
-    every tap as a row offset; tiles are flat over batch x length, so sequence ends fall inside tiles (masked fragments)
-    and at tile borders.  Same K order and MFMA sequence as the per-tap big tile (29): BIT-identical to it, and both
-    against F.conv1d; with the residual / accumulate / second-output epilogue."""
-    x = bf16_round(det("slab.x", (B, C, L), 1))
-    w = bf16_round(det("slab.w", (Co, C, k), 2) * (1.0 / math.sqrt(C * k)))
-    b = det("slab.b", (Co,), 3) * 0.1
-    res = bf16_round(det("slab.r", (B, Co, L), 4))
-    old = bf16_round(det("slab.o", (B, Co, L), 5))
-    pad = (k * d - d) // 2
-    ref = F.leaky_relu((F.conv1d(x, w, b, dilation=d, padding=pad) + res + old) * 0.5, 0.1)
-    wp, k_pad = pack_conv_weight(w[:, :, None, :])
-    xa = x.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
-    rs = res.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
-    bd = b.to(DEV)
-    outs = []
-    for tile in (41, 29):
-        out = old.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
-        out2 = torch.empty_like(out)
-        run_conv(conv_desc(x0=xa, c0=C, batch=B, hi=1, wi=L, ho=1, wo=L, kh=1, kw=k, pad_w=pad, dil_w=d, w=wp, k_pad=k_pad,
-                           n=Co, bias=bd, res=rs, res_ld=Co, accumulate=1, alpha=0.5, out_act=3, out_slope=0.1, out=out, ldc=Co,
-                           out2=out2, out2_slope=0.1, tile=tile))
-        got = out.to(torch.float32).permute(0, 2, 1).cpu()
-        assert rel_err(got, ref) < 2 * BF16_TOL, tile
-        assert torch.equal(out2.float().cpu(), bf16_round(F.leaky_relu(out.float().cpu(), 0.1)))
-        outs.append(got)
-    if C * k // 64 < 32:
-        assert torch.equal(outs[0], outs[1])
-    else:                                   # few tiles and >= 32 K steps: the forced tile 29 splits K (other summation order)
-        assert rel_err(outs[0], outs[1]) <= 2.0 ** -7
-    # plain epilogue, and a geometry the slab mode does not take is refused when forced
-    out = torch.empty(B, L, Co, dtype=torch.bfloat16, device=DEV)
-    run_conv(conv_desc(x0=xa, c0=C, batch=B, hi=1, wi=L, ho=1, wo=L, kh=1, kw=k, pad_w=pad, dil_w=d, w=wp, k_pad=k_pad, n=Co,
-                       bias=bd, out=out, ldc=Co, tile=41))
-    assert rel_err(out.float().permute(0, 2, 1).cpu(), F.conv1d(x, w, b, dilation=d, padding=pad)) < BF16_TOL
-    with pytest.raises(Exception, match="variant"):
-        run_conv(conv_desc(x0=xa, c0=C, batch=B, hi=1, wi=L, ho=1, wo=L - 2, kh=1, kw=k, pad_w=pad - 1, dil_w=d, w=wp,
-                           k_pad=k_pad, n=Co, bias=bd, out=out, ldc=Co, tile=41))
-
-
 @pytest.mark.parametrize("C,k,d,L,B", [(128, 11, 5, 700, 2), (128, 3, 1, 129, 1), (128, 7, 3, 128, 2), (64, 11, 5, 1000, 2),
                                        (64, 3, 3, 255, 1), (64, 7, 1, 513, 2), (32, 11, 5, 1500, 2), (32, 3, 1, 40, 3),
                                        (32, 7, 5, 1025, 1), (128, 11, 1, 50, 1)])
