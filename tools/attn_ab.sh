@@ -4,7 +4,7 @@
 set -u
 R=$PWD
 O=$R/gpurun_out/attn_ab; rm -rf $O; mkdir -p $O
-for v in ${ATTN_AB_VALUES:-2 1 2 1}; do
+for v in ${ATTN_AB_VALUES:-0 1 0 1}; do
   echo "== CTTA_ATTN_V2=$v"
   CTTA_ATTN_V2=$v python3 $R/tools/attn_bench.py
 done 2>&1 | grep -v "^$" | tee $O/attn_ab.txt
