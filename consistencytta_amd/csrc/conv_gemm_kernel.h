@@ -26,6 +26,12 @@
 #include <stdlib.h>
 
 #include "conv_epilogue.h"
+#ifndef CTTA_XBAR
+#define CTTA_XBAR 1
+#endif
+#ifndef CTTA_XBAR_MIN
+#define CTTA_XBAR_MIN 32
+#endif
 
 // MODE 0: register-staged tiles (supports in_act).  MODE 1: direct-to-LDS, generic gather (per-lane
 // global pointers, zero page).  MODE 2: direct-to-LDS through BUFFER descriptors with the address
@@ -586,6 +592,55 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     }
     __syncthreads();
     if (stamp && threadIdx.x == 0) stamp[2] = __builtin_amdgcn_s_memtime();
+    // XBAR (round 5): the tiles whose waves own 32 fragments (128x64 per wave: the big tile, 512x128x64, 256x128x64 with
+    // four waves) keep the SECOND half of a K tile's fragments in registers across the barrier and issue its 32 MFMAs right
+    // behind the next barrier, while the first fragments of the new tile are still on their way from LDS -- otherwise all
+    // eight waves start a K step with reads and the matrix pipe idles for their latency.  Same MFMA order per accumulator
+    // (bit-identical results), +14 registers, same occupancy.  Same-box A/B, three alternating rounds of the generation
+    // leg: 392.8 -> 398.5 clips/s (VAE decoder -0.45 ms, HiFi-GAN -0.6 ms, U-Net -0.15 ms).  For the tiles with fewer
+    // fragments per wave (three to five workgroups per CU fill each other's gaps) it measures nothing: 398.7 vs 399.4
+    // clips/s, distillation 77.2 vs 77.4 ms (-DCTTA_XBAR_MIN=8); -DCTTA_XBAR=0 compiles the round-4 loop.
+    constexpr bool XBAR = FAST && BK == 64 && FM * FN >= CTTA_XBAR_MIN && CTTA_XBAR;
+    if constexpr (XBAR) {
+      bf16x8_t ha[FN], hb[FM];
+      const bf16_t* xs0 = Xs + (wm * TM + frow) * LDK;
+      const bf16_t* ws0 = Ws + (wn * TN + frow) * LDK;
+      const int koff0 = ((fchunk ^ fswz) & SWZ_MASK) * 8, koff1 = (((4 + fchunk) ^ fswz) & SWZ_MASK) * 8;
+      for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue_fast(kt_begin + kt + 1, buf ^ 1);
+        if (wave_live) {
+          const bf16_t* xs = xs0 + buf * BM * LDK;
+          const bf16_t* ws = ws0 + buf * BN * LDK;
+          bf16x8_t fa[FN], fb[FM];
+#pragma unroll
+          for (int i = 0; i < FN; ++i) fa[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ws + i * 16 * LDK + koff0));
+#pragma unroll
+          for (int j = 0; j < FM; ++j) fb[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xs + j * 16 * LDK + koff0));
+          if (kt > 0) {
+#pragma unroll
+            for (int i = 0; i < FN; ++i)
+#pragma unroll
+              for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+          }
+#pragma unroll
+          for (int i = 0; i < FN; ++i) ha[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ws + i * 16 * LDK + koff1));
+#pragma unroll
+          for (int j = 0; j < FM; ++j) hb[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xs + j * 16 * LDK + koff1));
+#pragma unroll
+          for (int i = 0; i < FN; ++i)
+#pragma unroll
+            for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+      if (wave_live && nk > 0) {
+#pragma unroll
+        for (int i = 0; i < FN; ++i)
+#pragma unroll
+          for (int j = 0; j < FM; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ha[i], hb[j], acc[i][j], 0, 0, 0);
+      }
+    } else
     for (int kt = 0; kt < nk; ++kt) {
       const int buf = kt & 1;
       if (kt + 1 < nk) {
