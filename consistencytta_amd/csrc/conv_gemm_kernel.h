@@ -600,6 +600,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     // leg: 392.8 -> 398.5 clips/s (VAE decoder -0.45 ms, HiFi-GAN -0.6 ms, U-Net -0.15 ms).  For the tiles with fewer
     // fragments per wave (three to five workgroups per CU fill each other's gaps) it measures nothing: 398.7 vs 399.4
     // clips/s, distillation 77.2 vs 77.4 ms (-DCTTA_XBAR_MIN=8); -DCTTA_XBAR=0 compiles the round-4 loop.
+    // (Measured on top of it and not kept, profiles/ab_r05_xbar2_midstep_issue.txt: a second barrier in the middle of the
+    // step -- the tile's LDS reads are over by then -- behind which tile t + 2 is issued into the freed buffer, so that every
+    // LDS-DMA has 1.5 steps to land with the same two buffers: parity-green, 256 registers, 2.4 % SLOWER.  Like the deeper
+    // rings at BK = 32, it says the step is not waiting for the LDS-DMA's latency.)
     constexpr bool XBAR = FAST && BK == 64 && FM * FN >= CTTA_XBAR_MIN && CTTA_XBAR;
     if constexpr (XBAR) {
       bf16x8_t ha[FN], hb[FM];
