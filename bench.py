@@ -103,6 +103,14 @@ def self_launch(args, argv):
     return rc
 
 
+def trace(msg):
+    """CTTA_BENCH_TRACE=1: leg boundaries with wall-clock stamps on stderr (every rank) -- tells a slow multi-rank run through a
+    host-side backend from a hung one."""
+    if os.environ.get("CTTA_BENCH_TRACE", "0") != "0":
+        sys.stderr.write("[bench %s rank %s] %s\n" % (time.strftime("%H:%M:%S"), os.environ.get("RANK", "0"), msg))
+        sys.stderr.flush()
+
+
 def flush_c_stdio():
     """RCCL prints its banner (ROCm version / hostname / library path) with C stdio; on a pipe that buffer is only
     flushed at exit, i.e. AFTER the JSON line.  Flushing it here keeps the JSON line the last line on stdout."""
@@ -633,6 +641,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         step_kw["gt_wav"] = (torch.rand(B, 160000, generator=g) * 2 - 1).to(dev) * 0.3
     torch.manual_seed(100 + rank)       # per-rank timestep / guidance / noise streams
     build_s = time.perf_counter() - t_build
+    trace("distill%s: models built in %.1f s, eager loop next" % (" (perceptual)" if perceptual else "", build_s))
 
     # the extra legs time >= 10 steps behind >= 3 warm-up steps whatever K / W the headline uses (the first steps of a
     # training loop pay allocator and clock ramp-up: 119 vs 112 ms per step at 5 / 2 against 10 / 3 on the same box)
@@ -660,6 +669,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         losses.append(m.train_step(z0, P, opt, sched, **step_kw))
     du.barrier(dev)
     dt = du.max_over_ranks(time.perf_counter() - t0, dev)
+    trace("distill%s: eager and replayed forms done" % (" (perceptual)" if perceptual else ""))
     assert all(v == v for v in losses), "NaN distillation loss"
     # The step as the product runs it for fixed shapes (AudioLCM.capture_train_graph; bit-identical to train_step:
     # tests/test_train_gpu.py, and checked here against an eager forward with the same draws): hipGraph replays of noising,
@@ -678,6 +688,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                   gaussian_noise=torch.randn(B, 8, 256, 16, generator=gdr).to(dev), guidance_scale=torch.rand(B, generator=gdr) * 6)
 
         def timed_graph(segmented, pipelined=False, z=None, prompt=None, draws=None, steps=None, warm=None):
+            trace("distill: replayed form segmented=%s pipelined=%s batch=%s" % (segmented, pipelined, "fused" if z is not None else "micro"))
             """Phase 1 (LOCAL, no collective inside): capture, check one replay against an eager forward with the same draws.
             Then the ranks agree (du.all_agree) -- all of them time the leg or none does; a one-sided capture failure or
             parity assert therefore never leaves the peers alone inside a barrier or a bucket all-reduce.  Phase 2: one
@@ -860,6 +871,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     # GEMMs per launch.  Timed with eager launches (every rank: the all-reduce sequence must not depend on a capture).
     if accum_on and os.environ.get("CTTA_BENCH_FUSED_ACCUM", "1") != "0" and not args.no_latency:
         Bf = B * acc
+        trace("distill: grad_accum fused micro-batch legs")
         z45 = P45 = kw45 = why = None
         try:      # phase 1, local: the inputs (the arenas of the four U-Nets grow inside the first train_step)
             gf = torch.Generator(device="cpu").manual_seed(55 + rank)
