@@ -669,7 +669,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         losses.append(m.train_step(z0, P, opt, sched, **step_kw))
     du.barrier(dev)
     dt = du.max_over_ranks(time.perf_counter() - t0, dev)
-    trace("distill%s: eager and replayed forms done" % (" (perceptual)" if perceptual else ""))
+    trace("distill%s: eager loop done" % (" (perceptual)" if perceptual else ""))
     assert all(v == v for v in losses), "NaN distillation loss"
     # The step as the product runs it for fixed shapes (AudioLCM.capture_train_graph; bit-identical to train_step:
     # tests/test_train_gpu.py, and checked here against an eager forward with the same draws): hipGraph replays of noising,
