@@ -603,7 +603,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     // (Measured on top of it and not kept, profiles/ab_r05_xbar2_midstep_issue.txt: a second barrier in the middle of the
     // step -- the tile's LDS reads are over by then -- behind which tile t + 2 is issued into the freed buffer, so that every
     // LDS-DMA has 1.5 steps to land with the same two buffers: parity-green, 256 registers, 2.4 % SLOWER.  Like the deeper
-    // rings at BK = 32, it says the step is not waiting for the LDS-DMA's latency.)
+    // rings at BK = 32, it says the step is not waiting for the LDS-DMA's latency.  And a hand-pinned two-phase schedule --
+    // sched_group_barrier: per position fragment four MFMAs, then the read that takes over its registers, so that no read
+    // is waited for behind the barrier at all (in the loop below the compiler sinks the first-half reads under the held
+    // MFMAs) -- runs at exactly the same speed with 14 more registers: profiles/ab_r05_xbar3_streaming_schedule.txt.)
     constexpr bool XBAR = FAST && BK == 64 && FM * FN >= CTTA_XBAR_MIN && CTTA_XBAR;
     if constexpr (XBAR) {
       bf16x8_t ha[FN], hb[FM];
