@@ -60,6 +60,7 @@ struct WideCtx {
 #define WAVE_LDS_FENCE_() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // out = act((acc + (bias + rowvec) + res [+ old]) * alpha) for one wave tile of FM x FN fragments, CJ fragments (CHR rows)
 // per staging chunk, RPW rows per read-back pass.  (bias + rowvec) is one per-lane constant here (a tile on this path
 // lies inside one sample); every epilogue of the library adds in this order -- acc + (bias + rowvec), then the residual --
@@ -695,7 +696,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     const bool n_ok = n_lane < p.n;
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + n_lane);
-    float* outf = reinterpret_cast<float*>(p.out) + (size_t)zs * p.ogs + n_lane;
+    // Stores through a buffer descriptor over THIS wave's rows (base = its first row, extent = its rows inside M): rows past
+    // M and lanes past n fall outside and are dropped by the bounds check, so there is no divergent `if (m < M)` around a
+    // store -- behind one the compiler waits vmcnt(0) in front of every read-back, i.e. each of the 16-32 row sweeps waited
+    // for the previous store to be acknowledged (the bf16 epilogue got the same treatment in round 2).
+    const int m_w = m0 + (wave_u / WN) * TM;                           // wave-uniform, and known to be (scalar descriptor: no waterfall loop)
+    const int rows_in = min(TM, p.M - m_w);                            // <= 0: nothing of this wave's rows is inside M
+    float* obase = reinterpret_cast<float*>(p.out) + (size_t)zs * p.ogs + (size_t)(rows_in > 0 ? m_w : 0) * p.ldc;
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)obase, 0, rows_in > 0 ? (unsigned)rows_in * (unsigned)p.ldc * 4u : 0u, 0x00020000);
+    const unsigned ovoff = n_ok ? (unsigned)(prow * p.ldc + n_lane) * 4u : 0xFFFFFFF0u;
+    const unsigned ostep = (unsigned)(RPW * p.ldc) * 4u;              // bytes per row sweep
     __syncthreads();   // every wave is done with the ring
 #pragma unroll
     for (int j0 = 0; j0 < FM; j0 += CJ) {
@@ -710,10 +721,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 #pragma unroll
       for (int it = 0; it < CHR / RPW; ++it) {
         const int r = prow + it * RPW;
-        const int m = m0 + wm * TM + j0 * 16 + r;
         float4 q = *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16);
         q.x += bias4.x; q.y += bias4.y; q.z += bias4.z; q.w += bias4.w;
-        if (m < p.M && n_ok) *reinterpret_cast<float4*>(outf + (size_t)m * p.ldc) = q;
+        typedef float st4_t __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (st4_t){q.x, q.y, q.z, q.w}), rso, ovoff,
+                                               (j0 * 16 / RPW + it) * ostep, 0);
       }
       if (j0 + CJ < FM) WAVE_LDS_FENCE();
     }
