@@ -443,6 +443,27 @@ def test_no_kernel_lost_occupancy_against_the_committed_table():
     assert len(conv) >= 36 and all(v[2] == 0 for v in conv.values()), {k: v for k, v in conv.items() if v[2]}
 
 
+def test_no_kernel_gained_conservative_store_waits():
+    """tests/golden/kernel_vmcnt0.json holds the number of `s_waitcnt vmcnt(0)` instructions of every kernel of the built
+    library (`python tools/isa_vmcnt0_scan.py --json consistencytta_amd/libctta_hip.so tests/golden/kernel_vmcnt0.json`).
+    Global stores inside divergent `if (row < M)` blocks of a straight-line epilogue make the compiler wait vmcnt(0) in front
+    of every later read-back, i.e. every row sweep waits for the previous store's acknowledgement (the bf16 wide-store
+    epilogue of conv_gemm in round 2, its fp32 twin in round 5: 0.7 ms of a distillation step).  A kernel whose count grows
+    by more than a tenth (and by more than 4) over the committed table fails here; regenerate the table when it is meant."""
+    import importlib.util
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sp = importlib.util.spec_from_file_location("isa_vmcnt0_scan", os.path.join(root, "tools", "isa_vmcnt0_scan.py"))
+    mod = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(mod)
+    now = {nm: w for w, _, _, nm in mod.scan(os.path.join(root, "consistencytta_amd", "libctta_hip.so"))}
+    want = json.load(open(os.path.join(root, "tests", "golden", "kernel_vmcnt0.json")))
+    assert len(now) >= 190
+    grown = {k: (want[k], now[k]) for k in want if k in now and now[k] > want[k] + max(4, want[k] // 10)}
+    assert not grown, "kernels with more `s_waitcnt vmcnt(0)` than the committed table: %r" % grown
+
+
 def test_eval_metrics_match_the_reference_functions(golden):
     """consistencytta_amd.audioldm_eval.calculate_{fid,isc,kid,kl} (host arithmetic, as in the reference) against the values
     the reference's own audioldm_eval/metrics/*.py returned on the same seeded features (tests/golden/make_golden_eval.py):
