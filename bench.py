@@ -374,6 +374,8 @@ def main():
             "share_of_step_time": round(conv_ms / (dt / args.steps * 1e3), 3),
             "mfma_launch_ms_per_step_all_kinds": round(all_ms, 3),
             "stage_frac": stage_frac,
+            # ALL algorithmic FLOPs of the clip (attention included) / the HEADLINE step time (every kernel, every gap)
+            "frac_end_to_end": round(sum(gf_stage.values()) * 1e9 * B / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
         }
         td = result["roofline"]["traffic_detail"]
         if td and conv_cnt:   # per launch like `achieved`: HBM-side bytes of the family per step / its launches per step
@@ -913,6 +915,7 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                         "samples_per_s": round(world * Bf * n45 / dt45, 3), "ms_per_optimizer_step": round(dt45 / n45 * 1e3, 3),
                         "global_batch": Bf * world, "micro_batch_per_gpu": Bf,
                         "launch": "segmented hipGraph replays (bucket all-reduce between them) + pipelined teacher graph on its own stream",
+                        "frac_end_to_end": round(GF_DISTILL_PER_SAMPLE * 1e9 * Bf / (dt45 / n45) / 1e12 / PEAK_BF16_TFLOPS, 4),
                         "teacher_stream_placement_ms": placements[-1] if placements else None}
                 except _LegSkipped as exc:
                     out["grad_accum_5_fused_pipelined"] = {"skipped": str(exc)[:300]}
@@ -930,14 +933,19 @@ def distill_leg(args, dev, world, rank, perceptual=False):
     L_ = N.lib()
     if rank == 0:
         L_.ctta_prof_enable(1)
-    # the profiled step keeps every launch on ONE stream: with the student forward on its side stream the bracketed
+    # the profiled step keeps every launch on ONE stream: with the student forward on its side stream, or the weight-gradient
+    # jobs on the handle's side stream (round 5 left that one on: kernel_ms_per_step 84.8 > ms_per_step 75.4), the bracketed
     # launch times of concurrent kernels overlap and their sum is not a duration any more
     two_stream = os.environ.get("CTTA_TWO_STREAM")
     os.environ["CTTA_TWO_STREAM"] = "0"
+    wg_stream = N.get_option("wgrad_stream")
+    N.set_option("wgrad_stream", 0)
+    torch.cuda.synchronize()
     ev[0].record()
     m.train_step(z0, P, opt, sched)
     ev[1].record()
     torch.cuda.synchronize()
+    N.set_option("wgrad_stream", wg_stream)
     if two_stream is None:
         del os.environ["CTTA_TWO_STREAM"]
     else:
@@ -950,6 +958,9 @@ def distill_leg(args, dev, world, rank, perceptual=False):
         # attention forward / backward kernels, not in conv_gemm
         N.check(L_.ctta_prof_collect(-1, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt), csv))
         algo = GF_DISTILL_PER_SAMPLE * 1e9 * B
+        wall_ms = ev[0].elapsed_time(ev[1])
+        assert ms.value <= wall_ms, ("the bracketed MFMA launches of the single-stream step sum to %.2f ms, more than the step's own "
+                                     "%.2f ms: some launches still overlap" % (ms.value, wall_ms))
         out["roofline"] = {
             "kernel": "all MFMA kernels of the step: conv_gemm_kernel (forward, data-gradient and weight-gradient GEMMs) + "
                       "flash attention forward / backward",
@@ -958,8 +969,12 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             "traffic": None, "traffic_detail": pmc_traffic_distill(B),   # reads unavailable (the FETCH_SIZE pass hangs)
             "algorithmic_gflop_per_sample": GF_DISTILL_PER_SAMPLE, "launches_per_step": int(cnt.value),
             "kernel_ms_per_step": round(ms.value, 3),
+            "profiled_step_ms": round(wall_ms, 3),
+            "profiled_step": "one eager step with every launch on ONE stream (no student side stream, no weight-gradient side stream)",
             "executed_tflops_incl_padding": round(fl.value / (ms.value * 1e-3) / 1e12, 2),
-            "share_of_step_time": round(ms.value / ev[0].elapsed_time(ev[1]), 3),
+            "share_of_step_time": round(ms.value / wall_ms, 3),
+            # algorithmic FLOPs of the step / the HEADLINE step time (every kernel, every gap, the optimizer tail)
+            "frac_end_to_end": round(algo / (dt / n_steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
         }
         td = out["roofline"]["traffic_detail"]
         if td and td.get("read_GB_per_step") is not None and td.get("write_GB_per_step") is not None and cnt.value:

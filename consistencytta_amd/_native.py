@@ -179,6 +179,9 @@ SIGNATURES = {
     "ctta_conv_gemm": (c_int, [POINTER(ConvDesc), c_void_p]),
     "ctta_conv_last_gn_chunks": (c_int, []),
     "ctta_conv_bind_workspace": (None, [c_void_p, c_size_t]),
+    "ctta_conv_bind_workspace_ex": (None, [c_void_p, c_size_t, c_int]),
+    "ctta_conv_bound_workspace_header": (c_int, []),
+    "ctta_conv_workspace_header_bytes": (c_size_t, []),
     "ctta_conv_bound_workspace": (None, [POINTER(c_void_p), POINTER(c_size_t)]),
     "ctta_conv_workspace_bytes": (c_size_t, []),
     "ctta_conv_suppress_splitk": (None, [c_int]),
@@ -266,6 +269,11 @@ SIGNATURES = {
     "ctta_snr_mse_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "ctta_prof_enable": (None, [c_int]),
+    "ctta_set_option": (c_int, [c_char_p, c_int]),
+    "ctta_get_option": (c_int, [c_char_p, POINTER(c_int)]),
+    "ctta_num_options": (c_int, []),
+    "ctta_option_name": (c_char_p, [c_int]),
+    "ctta_option_default": (c_int, [c_int]),
     "ctta_set_gn_fuse": (None, [c_int]),
     "ctta_get_gn_fuse": (c_int, []),
     "ctta_prof_collect": (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(c_int64), c_char_p]),
@@ -302,7 +310,30 @@ def lib():
         fn.restype = res
         fn.argtypes = args
     _lib = L
+    # CTTA_OPT_<NAME>=<int> in the environment of the PYTHON process sets a library option at load time (A/B scripts:
+    # tools/gpu_call.sh ab).  The library itself reads no environment variable; see ctta_set_option in include/ctta.h.
+    for i in range(L.ctta_num_options()):
+        name = L.ctta_option_name(i).decode()
+        v = os.environ.get("CTTA_OPT_" + name.upper())
+        if v is not None:
+            set_option(name, int(v))
     return L
+
+
+def set_option(name, value):
+    """ctta_set_option (include/ctta.h): the library's only switches."""
+    check(lib().ctta_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = c_int()
+    check(lib().ctta_get_option(name.encode(), ctypes.byref(v)))
+    return v.value
+
+
+def options():
+    L = lib()
+    return {L.ctta_option_name(i).decode(): get_option(L.ctta_option_name(i).decode()) for i in range(L.ctta_num_options())}
 
 
 class CttaError(RuntimeError):

@@ -47,13 +47,39 @@ void ctta_prof_end(hipStream_t s) {
 
 extern "C" void ctta_prof_enable(int on) { g_prof_on = on != 0; }
 
-// GroupNorm statistics from the producing convolution's epilogue (engine_common.h: gn_fuse_enabled)
-static int g_gn_fuse = -1;
-bool ctta_gn_fuse_on() {
-  if (g_gn_fuse < 0) { const char* e = getenv("CTTA_GN_FUSE"); g_gn_fuse = (e && e[0] == '0') ? 0 : 1; }
-  return g_gn_fuse != 0;
+// ------------------------------------------------------------------------------------------
+// Options: one table, one setter (include/ctta.h).  No environment variable is read anywhere in the library.
+struct OptDef { const char* name; int def; int lo, hi; };
+static const OptDef kOpts[CTTA_OPT_COUNT] = {
+    {"xcd", 1, 0, 1},          {"splitk", 1, 0, 1},       {"streamk", 1, 0, 1},   {"streamk_grid", 0, 0, 1984},
+    {"mf32", 1, 0, 1},         {"wgrad_stream", 1, 0, 1}, {"gn_fuse", 1, 0, 1},   {"fused_res", 1, 0, 1},
+};
+int g_ctta_opt[CTTA_OPT_COUNT] = {1, 1, 1, 0, 1, 1, 1, 1};
+static int opt_index(const char* name) {
+  if (!name) return -1;
+  for (int i = 0; i < CTTA_OPT_COUNT; ++i) if (strcmp(name, kOpts[i].name) == 0) return i;
+  return -1;
 }
-extern "C" void ctta_set_gn_fuse(int on) { g_gn_fuse = on ? 1 : 0; }
+extern "C" ctta_status ctta_set_option(const char* name, int value) {
+  const int i = opt_index(name);
+  CTTA_REQUIRE(i >= 0, "ctta_set_option: unknown option '%s'", name ? name : "(null)");
+  CTTA_REQUIRE(value >= kOpts[i].lo && value <= kOpts[i].hi, "ctta_set_option: %s = %d outside [%d, %d]", name, value, kOpts[i].lo, kOpts[i].hi);
+  g_ctta_opt[i] = value;
+  return CTTA_OK;
+}
+extern "C" ctta_status ctta_get_option(const char* name, int* value) {
+  const int i = opt_index(name);
+  CTTA_REQUIRE(i >= 0 && value, "ctta_get_option: unknown option '%s'", name ? name : "(null)");
+  *value = g_ctta_opt[i];
+  return CTTA_OK;
+}
+extern "C" int ctta_num_options(void) { return CTTA_OPT_COUNT; }
+extern "C" const char* ctta_option_name(int i) { return (i >= 0 && i < CTTA_OPT_COUNT) ? kOpts[i].name : nullptr; }
+extern "C" int ctta_option_default(int i) { return (i >= 0 && i < CTTA_OPT_COUNT) ? kOpts[i].def : 0; }
+
+// GroupNorm statistics from the producing convolution's epilogue (engine_common.h: gn_fuse_enabled)
+bool ctta_gn_fuse_on() { return ctta_opt(CTTA_OPT_GN_FUSE) != 0; }
+extern "C" void ctta_set_gn_fuse(int on) { g_ctta_opt[CTTA_OPT_GN_FUSE] = on ? 1 : 0; }
 extern "C" int ctta_get_gn_fuse(void) { return ctta_gn_fuse_on() ? 1 : 0; }
 
 // Synchronises, sums the records of `kind` (0 conv_gemm, 1 attention, -1 all), optionally appends

@@ -89,6 +89,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ---- host side ---------------------------------------------------------------------------
+// Library options (include/ctta.h: ctta_set_option / ctta_get_option).  The ONLY switches of the library: nothing in it reads
+// the environment.  Values are plain ints read at the call that uses them.
+enum CttaOption {
+  CTTA_OPT_XCD = 0,            // XCD-aware tile order of the conv_gemm launches (default 1)
+  CTTA_OPT_SPLITK,             // K decomposition of deep thin launches: two-pass split-K / stream-K (default 1; 0: one tile per workgroup, whole K)
+  CTTA_OPT_STREAMK,            // stream-K (one persistent launch, in-launch fold) where the rules choose it (default 1); 0: two-pass split-K only
+  CTTA_OPT_STREAMK_GRID,       // tuning: workgroups of a stream-K launch (0 = one per CU slot)
+  CTTA_OPT_MF32,               // the 128x64-per-wave tiles on v_mfma_f32_32x32x16_bf16 where the rules choose them (default 1)
+  CTTA_OPT_WGRAD_STREAM,       // weight-gradient launches on the handle's side stream (default 1); read per backward call
+  CTTA_OPT_GN_FUSE,            // GroupNorm statistics from the producing convolution's epilogue (default 1)
+  CTTA_OPT_FUSED_RES,          // HiFi-GAN ResBlock units as fused pair kernels (default 1)
+  CTTA_OPT_COUNT
+};
+extern int g_ctta_opt[CTTA_OPT_COUNT];
+static inline int ctta_opt(CttaOption o) { return g_ctta_opt[o]; }
 void ctta_set_error(const char* fmt, ...);
 bool ctta_prof_active();
 bool ctta_gn_fuse_on();

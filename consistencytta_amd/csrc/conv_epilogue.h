@@ -56,7 +56,22 @@ struct ConvParams {
   // chunk = row-tile index inside sample b (gn_hw rows per sample, a multiple of BM) -- the layout gn_finalize_kernel folds.
   float* gn_part;
   int gn_cpg, gn_G, gn_hw, gn_nchunk;
+  // Stream-K (conv_gemm_sk_kernel: ONE persistent launch of <= one workgroup per CU slot, groups == 1): the (output tile,
+  // K step) items -- tile-major, sk_tiles * nk of them -- are cut into gridDim.x equal contiguous ranges.  A workgroup whose
+  // range starts inside a tile writes that tile's partial accumulators (fp32, accumulator layout: fragment f of thread t at
+  // float4 index f * threads + t) to sk_slots + id * BM * BN and raises sk_hdr[SK_FLAGS + id]; the workgroup that holds the
+  // tile's FIRST K step adds the partials of the ids behind it in id (= K) order and runs the fused epilogue: the summation
+  // order is fixed by the decomposition, never by arrival.  sk_hdr[0..3] = {start ticket, finished count, epoch, timeouts}:
+  // logical id = gridDim.x - 1 - ticket, so an owner only ever waits for workgroups that STARTED before it (forward progress
+  // whatever is resident); flags carry epoch + 1, the last workgroup to finish zeroes the two counters and advances the epoch
+  // (no memset node per launch; the header is zeroed once where the workspace is allocated).
+  unsigned* sk_hdr;
+  float* sk_slots;
+  int sk_tiles, sk_m_inner;   // sk_m_inner != 0: tile = nt * m_tiles + mt (row tiles innermost), else mt * n_tiles + nt
 };
+constexpr int SK_FLAGS = 64;            // first flag word of the stream-K header
+constexpr int SK_HDR_WORDS = 2048;      // header words in front of the partial slots (8 KB)
+constexpr int SK_MAX_GRID = SK_HDR_WORDS - SK_FLAGS;
 
 // The fused epilogue on 4 consecutive channels of one output row, for the wide-store paths (plain row-major bf16
 // destination: element (m, n) at m*ldc + n): same operation order as epilogue_store.

@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 CTTA_CONV_VARIANTS_ALL(CTTA_CONV_DECLARE)
+CTTA_CONV_VARIANTS_KIND(CTTA_CONV_DECLARE_K)
 
 // ------------------------------------------------------------------------------------------
 // 1-D "halo" convolution for the narrowest layers (C = Cin = Cout = 32, stride 1): the HiFi-GAN ResBlock
@@ -176,22 +177,45 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const ConvParams p, 
 // thread for the duration of each entry point (ctta_conv_bind_workspace), so handles running on different streams
 // or host threads never share partial-sum slabs.  Raw ctta_conv_gemm callers that bound nothing get a lazily
 // allocated workspace PER DEVICE (mutex-guarded); launches that share it must be ordered on one stream.
+// The first SK_HDR_WORDS 32-bit words of a workspace are the stream-K header (ConvParams::sk_hdr): zero when the workspace is
+// created, kept consistent by the stream-K launches themselves afterwards.  Partial slabs / slots start behind it.
 static const size_t kSplitWsBytes = (size_t)192 << 20;
 static thread_local float* t_ws = nullptr;
 static thread_local size_t t_ws_bytes = 0;
-extern "C" void ctta_conv_bind_workspace(void* ws, size_t bytes) { t_ws = (float*)ws; t_ws_bytes = ws ? bytes : 0; }
+static thread_local int t_ws_hdr = 0;     // the bound workspace's header was zeroed by its owner: stream-K launches may use it
+extern "C" void ctta_conv_bind_workspace(void* ws, size_t bytes) { t_ws = (float*)ws; t_ws_bytes = ws ? bytes : 0; t_ws_hdr = 0; }
+extern "C" void ctta_conv_bind_workspace_ex(void* ws, size_t bytes, int header_zeroed) {
+  t_ws = (float*)ws; t_ws_bytes = ws ? bytes : 0; t_ws_hdr = (ws && header_zeroed) ? 1 : 0;
+}
 extern "C" void ctta_conv_bound_workspace(void** ws, size_t* bytes) { if (ws) *ws = t_ws; if (bytes) *bytes = t_ws_bytes; }
+extern "C" int ctta_conv_bound_workspace_header(void) { return t_ws_hdr; }
 extern "C" size_t ctta_conv_workspace_bytes(void) { return kSplitWsBytes; }
+extern "C" size_t ctta_conv_workspace_header_bytes(void) { return (size_t)SK_HDR_WORDS * 4; }
 #include <mutex>
-static float* splitk_workspace(size_t* bytes) {
-  if (t_ws) { *bytes = t_ws_bytes; return t_ws; }
+static float* splitk_workspace(size_t* bytes, bool* hdr_ok = nullptr) {
+  if (t_ws) { *bytes = t_ws_bytes; if (hdr_ok) *hdr_ok = t_ws_hdr != 0; return t_ws; }
   static std::mutex mu;
   static float* per_dev[64] = {nullptr};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   std::lock_guard<std::mutex> lk(mu);
-  if (!per_dev[dev] && hipMalloc((void**)&per_dev[dev], kSplitWsBytes) != hipSuccess) per_dev[dev] = nullptr;
+  if (!per_dev[dev]) {
+    if (hipMalloc((void**)&per_dev[dev], kSplitWsBytes) != hipSuccess) per_dev[dev] = nullptr;
+    else if (hipMemset(per_dev[dev], 0, (size_t)SK_HDR_WORDS * 4) != hipSuccess) { (void)hipFree(per_dev[dev]); per_dev[dev] = nullptr; }
+  }
   *bytes = kSplitWsBytes;
+  if (hdr_ok) *hdr_ok = per_dev[dev] != nullptr;
+  return per_dev[dev];
+}
+static int cu_count() {      // compute units of the current device (256 on MI355X); cached per device
+  static int per_dev[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!per_dev[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    per_dev[dev] = n;
+  }
   return per_dev[dev];
 }
 
@@ -202,13 +226,17 @@ struct Variant {
   int wm, wn;
   int mode;
   int stages;
+  int kind;     // 0: 16x16x32 MFMA, one tile per workgroup; 1: 32x32x16 MFMA; 2 / 3: stream-K (persistent) on 16x16x32 / 32x32x16
   void (*launch)(const ConvParams&, dim3, hipStream_t);
   ctta_status (*prepare)();
 };
 
 #define VARIANT(BM, BN, BK, WM, WN, G, S) \
-  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN "_m" #G "_s" #S, BM, BN, BK, WM, WN, G, S, \
-   launch_variant<BM, BN, BK, WM, WN, G, S>, prepare_variant<BM, BN, BK, WM, WN, G, S>}
+  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN "_m" #G "_s" #S, BM, BN, BK, WM, WN, G, S, 0, \
+   launch_variant<BM, BN, BK, WM, WN, G, S, 0>, prepare_variant<BM, BN, BK, WM, WN, G, S, 0>}
+#define VARIANT_K(BM, BN, BK, WM, WN, G, S, KIND, TAG) \
+  {#BM "x" #BN "x" #BK "_w" #WM "x" #WN "_m" #G "_s" #S TAG, BM, BN, BK, WM, WN, G, S, KIND, \
+   launch_variant<BM, BN, BK, WM, WN, G, S, KIND>, prepare_variant<BM, BN, BK, WM, WN, G, S, KIND>}
 
 static const Variant kVariants[] = {
     VARIANT(128, 128, 64, 2, 2, 0, 2),  // 1   register-staged (support in_act)
@@ -251,6 +279,14 @@ static const Variant kVariants[] = {
     VARIANT(128, 128, 64, 2, 2, 2, 3),  // 38  workgroup is ~1.1 us per K step whatever the tile)
     VARIANT(128, 64, 64, 2, 2, 2, 3),   // 39
     VARIANT(128, 128, 64, 2, 2, 2, 4),  // 40
+    VARIANT_K(256, 256, 64, 2, 4, 2, 2, 1, "_mf32"),   // 41  twins of 29 / 31 / 36 on v_mfma_f32_32x32x16_bf16
+    VARIANT_K(256, 128, 64, 2, 2, 2, 2, 1, "_mf32"),   // 42
+    VARIANT_K(512, 128, 64, 4, 2, 2, 2, 1, "_mf32"),   // 43
+    VARIANT_K(256, 256, 64, 2, 4, 2, 2, 2, "_sk"),     // 44  stream-K (one persistent launch, in-launch fold)
+    VARIANT_K(256, 128, 64, 2, 2, 2, 2, 2, "_sk"),     // 45
+    VARIANT_K(128, 128, 64, 2, 2, 2, 2, 2, "_sk"),     // 46
+    VARIANT_K(256, 256, 64, 2, 4, 2, 2, 3, "_sk_mf32"),   // 47
+    VARIANT_K(256, 128, 64, 2, 2, 2, 2, 3, "_sk_mf32"),   // 48
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -274,11 +310,7 @@ static const bf16_t* zero_page() {   // 256 zero bytes per device (source of out
   return per_dev[dev];
 }
 
-static bool xcd_default() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_XCD"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
+static bool xcd_default() { return ctta_opt(CTTA_OPT_XCD) != 0; }
 static bool tile_rules_r5() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("CTTA_TILE_RULES_R5"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -304,11 +336,7 @@ extern "C" void ctta_conv_debug_stamps(void* buf) { t_stamps = (unsigned long lo
 unsigned long long* ctta_debug_stamps_current() { return t_stamps; }
 static thread_local int t_no_splitk = 0;
 extern "C" void ctta_conv_suppress_splitk(int on) { t_no_splitk = on ? 1 : 0; }
-static bool splitk_default() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_SPLITK"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0 && !t_no_splitk;
-}
+static bool splitk_default() { return ctta_opt(CTTA_OPT_SPLITK) != 0 && !t_no_splitk; }
 static bool epi_fast_default() {
   static int v = -1;
   if (v < 0) { const char* e = getenv("CTTA_EPI_FAST"); v = (e && e[0] == '0') ? 0 : 1; }
@@ -557,6 +585,49 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   CTTA_TRY(v.prepare());
   dim3 grid((unsigned)((M + v.bm - 1) / v.bm), (unsigned)((d->n + v.bn - 1) / v.bn), (unsigned)groups);
   p.ksplit = 1; p.nk_split = p.nk;
+  if (v.kind >= 2) {
+    // Stream-K: one persistent launch, at most one workgroup per CU slot; every workgroup walks an equal share of the (tile, K
+    // step) items and the partial tiles are folded inside the launch in K order (ConvParams::sk_hdr, conv_gemm_sk_kernel)
+    CTTA_REQUIRE(groups == 1 && !geglu && !t_stamps, "conv_gemm: stream-K variant %s takes ungrouped launches without the fused GEGLU", v.name);
+    size_t wsb = 0;
+    bool hdr_ok = false;
+    float* wsp = splitk_workspace(&wsb, &hdr_ok);
+    CTTA_REQUIRE(wsp && hdr_ok, "conv_gemm: stream-K needs a workspace whose header was zeroed (ctta_conv_bind_workspace_ex)");
+    const long long T = (long long)grid.x * grid.y;
+    const long long items = T * p.nk;
+    const int per_cu = (int)((160 * 1024) / ((size_t)v.stages * (v.bm + v.bn) * v.bk * 2));
+    long long G = (long long)cu_count() * (per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu);
+    if (ctta_opt(CTTA_OPT_STREAMK_GRID) > 0) G = ctta_opt(CTTA_OPT_STREAMK_GRID);
+    if (G > items / 4) G = items / 4;          // >= 4 K steps per workgroup
+    if (G > SK_MAX_GRID) G = SK_MAX_GRID;
+    if (G < 1) G = 1;
+    const size_t slot = (size_t)v.bm * v.bn * 4;
+    if ((size_t)SK_HDR_WORDS * 4 + (size_t)G * slot > wsb) G = (long long)((wsb - (size_t)SK_HDR_WORDS * 4) / slot);
+    CTTA_REQUIRE(G >= 1, "conv_gemm: workspace too small for stream-K");
+    p.m_tiles = (int)grid.x; p.n_tiles = (int)grid.y; p.sk_tiles = (int)T;
+    p.sk_m_inner = w_bytes > x_bytes ? 1 : 0;       // weight-dominated: the row tiles of one weight slab run next to each other
+    p.sk_hdr = reinterpret_cast<unsigned*>(wsp);
+    p.sk_slots = wsp + SK_HDR_WORDS;
+    const bool prof_sk = ctta_prof_active();
+    if (prof_sk) ctta_prof_begin(0, vid + ((p.epi_fast || p.epi_fast_geglu) ? 0 : 100), M, d->n, K, groups, (hipStream_t)stream);
+    if (d->gn_part && d->gn_groups > 0 && d->gn_hw > 0 && p.wide_store) {
+      const int cpg = d->n % d->gn_groups == 0 ? d->n / d->gn_groups : 0;
+      const int tn = v.bn / v.wn;
+      if (cpg >= 4 && (cpg & (cpg - 1)) == 0 && v.bn % cpg == 0 && d->gn_hw % v.bm == 0 && M % d->gn_hw == 0) {
+        const int sub = cpg > tn ? cpg / tn : 1;
+        const int nchunk = d->gn_hw / v.bm * v.wm * sub;
+        if ((long long)(M / d->gn_hw) * nchunk * d->gn_groups * 2 <= (long long)d->gn_part_floats) {
+          p.gn_part = (float*)d->gn_part; p.gn_cpg = cpg; p.gn_G = d->gn_groups; p.gn_hw = d->gn_hw;
+          p.gn_nchunk = nchunk;
+          t_last_gn_chunks = nchunk;
+        }
+      }
+    }
+    v.launch(p, dim3((unsigned)G, 1, 1), (hipStream_t)stream);
+    if (prof_sk) ctta_prof_end((hipStream_t)stream);
+    CTTA_LAUNCH_CHECK();
+    return CTTA_OK;
+  }
   // split-K: deep, narrow problems (the 1024-channel levels at small batch: M <= 2304, K = 9216 / 18432) launch
   // too few workgroups to fill 256 CUs; split the K walk over blockIdx.z and reduce in a second pass
   const long long tiles = (long long)grid.x * grid.y;
@@ -566,7 +637,9 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   static int tiles_gate = -1;   // launches with fewer tiles than this are split over K (CTTA_SPLITK_TILES, tuning knob)
   if (tiles_gate < 0) { const char* e = getenv("CTTA_SPLITK_TILES"); tiles_gate = e ? atoi(e) : 192; }
   if (splitk_default() && groups == 1 && !scalar_store && !geglu && d->out_limit == 0 && d->out_offset == 0 &&
-      tiles < tiles_gate && p.nk >= splitk_min_nk() && (ws = splitk_workspace(&ws_bytes)) != nullptr) {
+      tiles < tiles_gate && p.nk >= splitk_min_nk() && (ws = splitk_workspace(&ws_bytes)) != nullptr &&
+      ws_bytes > (size_t)SK_HDR_WORDS * 4) {
+    ws += SK_HDR_WORDS; ws_bytes -= (size_t)SK_HDR_WORDS * 4;       // the stream-K header stays untouched
     static int target = -1, cap = -1;   // tuning knobs: workgroups aimed for / most splits
     if (target < 0) { const char* e = getenv("CTTA_SPLITK_TARGET"); target = e ? atoi(e) : 512; }
     if (cap < 0) { const char* e = getenv("CTTA_SPLITK_MAX"); cap = e ? atoi(e) : 8; }

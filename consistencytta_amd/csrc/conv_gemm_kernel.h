@@ -100,7 +100,8 @@ __device__ __forceinline__ void gn_partial_store(const ConvParams& p, float s1, 
 // fp32 GroupNorm sees; two packed adds and two packed FMAs per 4 outputs) and writes the wave's partials
 // (gn_partial_store); BM / WM only matter then.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-template <int FM, int FN, int CJ, int CHR, int RPW, bool RES, bool OUT2, bool ACC, bool ACT, bool GN = false, int BM = 0, int WM = 0>
+template <int FM, int FN, int CJ, int CHR, int RPW, bool RES, bool OUT2, bool ACC, bool ACT, bool GN = false, int BM = 0, int WM = 0,
+          int RB = 16, int CB = 16>     // RB x CB: pixel rows x channels of one accumulator fragment (32 x 8 behind the 32x32x16 MFMA)
 __device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t (&acc)[FN][FM], const WideCtx& w) {
   constexpr int IT = CHR / RPW;          // read-back passes per chunk
   constexpr int NCH = FM / CJ;           // chunks
@@ -134,7 +135,7 @@ __device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t 
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
         const f32x4_t a = acc[i][ch * CJ + jj];
-        *reinterpret_cast<float4*>(w.stg + (jj * 16 + w.frow) * w.rsf + (i * 16 + w.nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4*>(w.stg + (jj * RB + w.frow) * w.rsf + (i * CB + w.nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
       }
     WAVE_LDS_FENCE_();
 #pragma unroll
@@ -189,7 +190,7 @@ __device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t 
     }
     if (ch + 1 < NCH) WAVE_LDS_FENCE_();     // the staging rows are rewritten by the next chunk
   }
-  if constexpr (GN) gn_partial_store<BM, WM, FN * 16>(p, gs1[0] + gs1[1], gs2[0] + gs2[1], w.m0, w.wm, w.wn, w.prow, w.col4, w.n_lane, true);
+  if constexpr (GN) gn_partial_store<BM, WM, FN * CB>(p, gs1[0] + gs1[1], gs2[0] + gs2[1], w.m0, w.wm, w.wn, w.prow, w.col4, w.n_lane, true);
 }
 
 // Fused GEGLU epilogue (out_act 4): the weight rows are packed in 16-row blocks [16 value][16 gate], so fragment
@@ -217,8 +218,19 @@ __device__ __forceinline__ void epilogue_geglu(const ConvParams& p, const f32x4_
 // orders a wave's own LDS writes before its LDS reads (other lanes of the SAME wave) without a workgroup barrier
 #define WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p) {
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+// One (output tile, K range) segment of a stream-K workgroup (ConvParams::sk_hdr).  mode 0: the whole K walk (plain
+// epilogue); 1: a later part of the tile's K walk -> the accumulators go to this workgroup's slot; 2: the first part ->
+// the partials of ids first_partner .. first_partner + n_partners - 1 are added in that order, then the epilogue.
+struct SkSeg { int kt_begin, nk, mode, id, first_partner, n_partners; unsigned tag; };
+// One output tile: K walk + fused epilogue.  MF = 16: v_mfma_f32_16x16x32_bf16 (a fragment = 16 pixels x 16 channels, a
+// lane holds 4 channels of one pixel); MF = 32: v_mfma_f32_32x32x16_bf16 (32 cycles per instruction on a SIMD for twice the
+// FLOPs of a 16-17 cycle 16x16x32: half the MFMA issue slots of a K step, same fragment bytes, same accumulator registers;
+// the 16 accumulator registers of a 32 x 32 block are four "fragments" of 32 pixels x 8 channels, a lane again holding 4
+// consecutive channels of one pixel, so every epilogue below only sees other fragment extents RB x CB).  SK: see SkSeg.
+template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES, int MF, bool SK>
+__device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* smem_raw, const int mt, const int nt, const int zs_,
+                                          const SkSeg& sk) {
   constexpr bool GLDS = MODE != 0;
   // (Round 5 built and removed a MODE 4 -- the pixel operand through the LDS-DMA ring, the WEIGHT operand straight from L2 into
   // the MFMA fragment registers: a packed weight row is K-contiguous, a lane's 16 bytes are its fragment; inline-asm
@@ -231,44 +243,38 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   constexpr int LDK = BK;              // bf16 elements per LDS row: no padding, XOR-swizzled chunks
   // 16-byte chunk c of row r lives at chunk position c ^ swz(r): conflict-free for the 16-lane
   // groups of ds_read_b128 (rows r..r+15 at one logical chunk) and for the row-contiguous writes.
-  constexpr int SWZ_SHIFT = (BK == 64) ? 0 : 1;
+  // (MF = 32: a fragment read covers 32 rows at one chunk, the 16-lane groups of ds_read_b128 then hold 8 even and 8 odd rows:
+  // the key (row >> 1) & 7 gives each of them its own 16-byte slot of the 256-byte bank window; row & 7 would be 2-way)
+  constexpr int SWZ_SHIFT = (BK == 64 && MF == 16) ? 0 : 1;
+  static_assert(MF == 16 || (MF == 32 && BK == 64 && MODE == 2 && STAGES == 2), "the 32x32x16 loop exists for the BK = 64 descriptor tiles");
   constexpr int SWZ_MASK = BK / 8 - 1;
   constexpr int CPR = BK / 8;          // 16-byte chunks per row
   constexpr int RPP = NT / CPR;        // rows staged per pass
   constexpr int XP = BM / RPP;
   constexpr int WP = BN / RPP;
   constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int FM = TM / 16, FN = TN / 16;
+  constexpr int RB = MF == 32 ? 32 : 16, CB = MF == 32 ? 8 : 16;     // pixel rows x channels of one accumulator fragment
+  constexpr int FM = TM / RB, FN = TN / CB;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/pass mismatch");
-  static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile");
+  static_assert(TM % MF == 0 && TN % MF == 0, "wave tile");
 
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_raw);               // [STAGES][BM][LDK]
   bf16_t* Ws = Xs + STAGES * BM * LDK;                             // [STAGES][BN][LDK]
   unsigned long long* stamp = nullptr;
-  if (p.stamps) {
+  if (!SK && p.stamps) {
     stamp = p.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 6;
     if (threadIdx.x == 0) { stamp[0] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32); stamp[1] = __builtin_amdgcn_s_memtime(); }
   }
 
-  const int tid = threadIdx.x;
+  int tid_ = threadIdx.x;
+  // (stream-K calls this body in a loop: everything derived from the thread index alone is loop-invariant, and hoisted in front of
+  // the loop -- the epilogue's lane constants, the staging offsets -- it stays live across the main loop: 242 spilled registers.
+  // An opaque copy per call keeps every value where the one-tile kernel computes it.)
+  if constexpr (SK) asm volatile("" : "+v"(tid_));
+  const int tid = tid_;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  int mt = blockIdx.x, nt = blockIdx.y, zs_ = blockIdx.z;
-  if (p.slab_total > 0) {
-    const int item = (int)(blockIdx.x & 7) * p.slab_per + (int)(blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= p.slab_per || item >= p.slab_total) return;   // padding blocks (whole workgroup, before any barrier)
-    const int slab = item / p.m_tiles;
-    mt = item - slab * p.m_tiles;
-    zs_ = slab / p.n_tiles;
-    nt = slab - zs_ * p.n_tiles;
-  } else if (p.xcd_per > 0) {
-    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    if (p.n_inner) { nt = local % p.n_tiles; mt = xcd * p.xcd_per + local / p.n_tiles; }
-    else { nt = local / p.xcd_per; mt = xcd * p.xcd_per + local % p.xcd_per; }
-    if (mt >= p.m_tiles) return;   // padding blocks of the last XCD range (whole workgroup, before any barrier)
-  }
   const int m0 = p.m_off + mt * BM;
   const int n0 = nt * BN;
   // a wave whose TM rows all lie past M (the last row tile of M = k * BM + a few rows) skips its MFMAs: its SIMD partner
@@ -276,8 +282,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   const bool wave_live = m0 + (wave / WN) * TM < p.M;
   const int zs = zs_;
   const int g = p.ksplit > 1 ? 0 : zs;                    // group index (pointer offsets)
-  const int kt_begin = p.ksplit > 1 ? zs * p.nk_split : 0;
-  const int nk = p.ksplit > 1 ? min(p.nk - kt_begin, p.nk_split) : p.nk;
+  const int kt_begin = SK ? sk.kt_begin : (p.ksplit > 1 ? zs * p.nk_split : 0);
+  const int nk = SK ? sk.nk : (p.ksplit > 1 ? min(p.nk - kt_begin, p.nk_split) : p.nk);
 
   const bf16_t* x0 = p.x0 + (size_t)g * p.xgs;
   const bf16_t* x1 = p.x1;
@@ -529,18 +535,46 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   };
 
   f32x4_t acc[FN][FM];
+  // MF = 32: the MFMA accumulators proper -- 16 registers per 32 (channels) x 32 (pixels) block; acc[][] is filled from them
+  // behind the main loop (register renaming: every index is a compile-time constant)
+  constexpr int BI = MF == 32 ? TN / 32 : 1, BJ = MF == 32 ? TM / 32 : 1;
+  f32x16_t big[BI][BJ];
+  if constexpr (MF == 32) {
 #pragma unroll
-  for (int i = 0; i < FN; ++i)
+    for (int i = 0; i < BI; ++i)
 #pragma unroll
-    for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < BJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) big[i][j][e] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < FN; ++i)
+#pragma unroll
+      for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  }
 
-  const int frow = lane & 15;
-  const int fchunk = lane >> 4;                       // logical 16-byte chunk within a 32-wide k-slab
+  const int frow = lane & (RB - 1);
+  const int fchunk = lane / RB;                       // logical 16-byte chunk within a 32-wide (MF = 32: 16-wide) k-slab
   const int fswz = (frow >> SWZ_SHIFT) & SWZ_MASK;    // tile/frag row offsets are multiples of 16
 
   auto compute_tile = [&](int buf) {
     const bf16_t* xs = Xs + buf * BM * LDK + (wm * TM + frow) * LDK;
     const bf16_t* ws = Ws + buf * BN * LDK + (wn * TN + frow) * LDK;
+    if constexpr (MF == 32) {
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8_t af[BI], bfr[BJ];
+        const int koff = (((ks * 2 + fchunk) ^ fswz) & SWZ_MASK) * 8;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ws + i * 32 * LDK + koff));
+#pragma unroll
+        for (int j = 0; j < BJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xs + j * 32 * LDK + koff));
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+#pragma unroll
+          for (int j = 0; j < BJ; ++j) big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], big[i][j], 0, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8_t af[FN], bfr[FM];
@@ -609,7 +643,61 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     // is waited for behind the barrier at all (in the loop below the compiler sinks the first-half reads under the held
     // MFMAs) -- runs at exactly the same speed with 14 more registers: profiles/ab_r05_xbar3_streaming_schedule.txt.)
     constexpr bool XBAR = FAST && BK == 64 && FM * FN >= CTTA_XBAR_MIN && CTTA_XBAR;
-    if constexpr (XBAR) {
+    if constexpr (XBAR && MF == 32) {
+      // the same schedule on the 32x32x16 MFMA: a K tile is four 16-wide slabs; slabs 2 and 3 are held across the barrier
+      bf16x8_t ha[2][BI], hb[2][BJ];
+      const bf16_t* xs0 = Xs + (wm * TM + frow) * LDK;
+      const bf16_t* ws0 = Ws + (wn * TN + frow) * LDK;
+      int koff[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) koff[ks] = (((ks * 2 + fchunk) ^ fswz) & SWZ_MASK) * 8;
+      for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue_fast(kt_begin + kt + 1, buf ^ 1);
+        if (wave_live) {
+          const bf16_t* xs = xs0 + buf * BM * LDK;
+          const bf16_t* ws = ws0 + buf * BN * LDK;
+          bf16x8_t fa[2][BI], fb[2][BJ];
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < BI; ++i) fa[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ws + i * 32 * LDK + koff[ks]));
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) fb[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xs + j * 32 * LDK + koff[ks]));
+          }
+          if (kt > 0) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+              for (int i = 0; i < BI; ++i)
+#pragma unroll
+                for (int j = 0; j < BJ; ++j) big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[ks][i], hb[ks][j], big[i][j], 0, 0, 0);
+          }
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < BI; ++i) ha[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ws + i * 32 * LDK + koff[2 + ks]));
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) hb[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xs + j * 32 * LDK + koff[2 + ks]));
+          }
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < BI; ++i)
+#pragma unroll
+              for (int j = 0; j < BJ; ++j) big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], big[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+      if (wave_live && nk > 0) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < BI; ++i)
+#pragma unroll
+            for (int j = 0; j < BJ; ++j) big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[ks][i], hb[ks][j], big[i][j], 0, 0, 0);
+      }
+    } else if constexpr (XBAR) {
       bf16x8_t ha[FN], hb[FM];
       const bf16_t* xs0 = Xs + (wm * TM + frow) * LDK;
       const bf16_t* ws0 = Ws + (wn * TN + frow) * LDK;
@@ -665,8 +753,118 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   }
 
   if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
-  // ---- epilogue: lane holds n = nb + (lane>>4)*4 + {0..3} (rows of D), m = mb + (lane&15)
-  const int nsub = (lane >> 4) * 4;
+  if constexpr (MF == 32) {   // register r of a 32x32 block: channel (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), pixel lane & 31
+#pragma unroll
+    for (int i = 0; i < BI; ++i)
+#pragma unroll
+      for (int j = 0; j < BJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[i * 4 + q][j] = (f32x4_t){big[i][j][4 * q], big[i][j][4 * q + 1], big[i][j][4 * q + 2], big[i][j][4 * q + 3]};
+  }
+  // ---- stream-K (ConvParams::sk_hdr).  A split tile's partial sums travel as fp32 ROWS ([BM][BN] per workgroup slot, written
+  // through the LDS transpose of the wide-store epilogues), the OWNER's own part included, and the owner then runs the
+  // split-K finish over its tile: rows summed slot by slot in id = K order, fused epilogue per 4 channels (epilogue_store).
+  // (Not built the cheaper-looking way -- partners' partials added to the owner's accumulators, or to its staged rows inside the
+  // straight-line epilogues: any VALU write to the 32 MFMA tuples between main loop and epilogue, even `+= 1.0f`, and any
+  // runtime loop inside the unrolled epilogue variants costs this compiler 50-240 spilled registers INSIDE the main loop.)
+  const int nsub = (lane / RB) * 4;
+  if constexpr (SK) {
+    if (sk.mode != 0) {
+      // the wave's TM x TN block through its staging rows, out as whole TN * 4-byte row segments, write-through (sc1) so that
+      // no release fence has anything to write back; every wave drains its stores, one lane raises the flag
+      // (cdna_hip_programming.md Guideline 16, form R1)
+      constexpr int NW = WM * WN;
+      constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
+      constexpr int RSF = TN * 4 + 16;
+      constexpr int CHR = ((FM % 2 == 0 || RB == 32) && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;
+      static_assert((size_t)NW * CHR * RSF <= RING && CHR % RB == 0, "stream-K staging does not fit the ring");
+      constexpr int CJ = CHR / RB, LPR = TN / 4, RPW = 64 / LPR;
+      unsigned char* stg = smem_raw + (size_t)wave * CHR * RSF;
+      const int col4 = lane % LPR, prow = lane / LPR;
+      const int m_w = m0 + (wave_u / WN) * TM;
+      const int rows_in = min(TM, p.M - m_w);            // rows past M are never read back
+      float* obase = p.sk_slots + (size_t)sk.id * (BM * BN) + (size_t)((wave_u / WN) * TM) * BN;
+      const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)obase, 0, rows_in > 0 ? (unsigned)rows_in * (unsigned)BN * 4u : 0u, 0x00020000);
+      const unsigned ovoff = (unsigned)(prow * BN + wn * TN + col4 * 4) * 4u;
+      constexpr unsigned ostep = (unsigned)(RPW * BN) * 4u;
+      __syncthreads();   // every wave is done with the ring
+#pragma unroll
+      for (int j0 = 0; j0 < FM; j0 += CJ) {
+#pragma unroll
+        for (int jj = 0; jj < CJ; ++jj)
+#pragma unroll
+          for (int i = 0; i < FN; ++i) {
+            const f32x4_t a = acc[i][j0 + jj];
+            *reinterpret_cast<float4*>(stg + (jj * RB + frow) * RSF + (i * CB + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+          }
+        WAVE_LDS_FENCE();
+#pragma unroll
+        for (int it = 0; it < CHR / RPW; ++it) {
+          const float4 q = *reinterpret_cast<const float4*>(stg + (prow + it * RPW) * RSF + col4 * 16);
+          typedef float st4_t __attribute__((ext_vector_type(4)));
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (st4_t){q.x, q.y, q.z, q.w}), rso, ovoff,
+                                                 (j0 * RB / RPW + it) * ostep, 16);
+        }
+        if (j0 + CJ < FM) WAVE_LDS_FENCE();
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (sk.mode == 1) {
+        if (tid == 0) __hip_atomic_store(p.sk_hdr + SK_FLAGS + sk.id, sk.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+      // owner: one lane polls the partners' flags (relaxed, bounded), ONE agent-scope acquire (it also drops this CU's stale L1
+      // lines of its own slot), then plain loads
+      if (tid == 0) {
+        for (int c = 0; c < sk.n_partners; ++c) {
+          const unsigned* f = p.sk_hdr + SK_FLAGS + sk.first_partner + c;
+          unsigned spins = 0;
+          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.tag) {
+            if (++spins > (1u << 22)) { __hip_atomic_fetch_add(p.sk_hdr + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(8);
+          }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      }
+      __syncthreads();
+      const int rows = min(BM, p.M - m0);
+      const unsigned tile_bytes = (unsigned)rows * BN * 4u;      // loads past the valid rows return zeros (and are dropped below)
+      constexpr int U = 8;                                       // float4s per lane in flight per slot
+      constexpr int C4 = BN / 4;
+      const float* own = p.sk_slots + (size_t)sk.id * (BM * BN);
+      const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)own, 0, tile_bytes, 0x00020000);
+      for (int base = 0; base < rows * C4; base += NT * U) {
+        u32x4_t a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, (base + u * NT + tid) * 16, 0, 0);
+        for (int c = 0; c < sk.n_partners; ++c) {
+          const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
+              (void*)(p.sk_slots + (size_t)(sk.first_partner + c) * (BM * BN)), 0, tile_bytes, 0x00020000);
+          u32x4_t t[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(rsc, (base + u * NT + tid) * 16, 0, 0);
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[u][e] = __float_as_uint(__uint_as_float(a[u][e]) + __uint_as_float(t[u][e]));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int idx = base + u * NT + tid;
+          const int row = idx / C4, m = m0 + row, n = n0 + (idx - row * C4) * 4;
+          if (row < rows && n < p.n) {
+            const int b = m / p.howo;
+            epilogue_store(p, (f32x4_t){__uint_as_float(a[u][0]), __uint_as_float(a[u][1]), __uint_as_float(a[u][2]), __uint_as_float(a[u][3])},
+                           m, n, b, m - (long long)b * p.howo, 0);
+          }
+        }
+      }
+      return;
+    }
+  }
+  // ---- epilogue: lane holds n = nb + (lane / RB) * 4 + {0..3} (rows of D), m = mb + (lane & (RB - 1))
   // Wide-store epilogue (bf16 output, plain row-major destination).  In the MFMA layout a store instruction writes
   // 16 rows x 32 bytes; measured, a launch then pays ~0.5 us per MB of output on top of its main loop (335 MB outputs:
   // 180 of 300 us of K-independent time) because workgroups cannot retire before their scattered stores drain.  Here
@@ -686,9 +884,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     constexpr int NW = WM * WN;
     constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
     constexpr int RSF = TN * 4 + 16;
-    constexpr int CHR = (FM % 2 == 0 && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;
-    static_assert((size_t)NW * CHR * RSF <= RING, "wide-store staging does not fit the ring");
-    constexpr int CJ = CHR / 16;
+    constexpr int CHR = ((FM % 2 == 0 || RB == 32) && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;
+    static_assert((size_t)NW * CHR * RSF <= RING && CHR % RB == 0, "wide-store staging does not fit the ring");
+    constexpr int CJ = CHR / RB;
     constexpr int LPR = TN / 4, RPW = 64 / LPR;
     unsigned char* stg = smem_raw + (size_t)wave * CHR * RSF;
     const int col4 = lane % LPR, prow = lane / LPR;
@@ -715,7 +913,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
           const f32x4_t a = acc[i][j0 + jj];
-          *reinterpret_cast<float4*>(stg + (jj * 16 + frow) * RSF + (i * 16 + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+          *reinterpret_cast<float4*>(stg + (jj * RB + frow) * RSF + (i * CB + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
       WAVE_LDS_FENCE();
 #pragma unroll
@@ -725,7 +923,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         q.x += bias4.x; q.y += bias4.y; q.z += bias4.z; q.w += bias4.w;
         typedef float st4_t __attribute__((ext_vector_type(4)));
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, (st4_t){q.x, q.y, q.z, q.w}), rso, ovoff,
-                                               (j0 * 16 / RPW + it) * ostep, 0);
+                                               (j0 * RB / RPW + it) * ostep, 0);
       }
       if (j0 + CJ < FM) WAVE_LDS_FENCE();
     }
@@ -735,9 +933,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     constexpr int NW = WM * WN;
     constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
     constexpr int RSF = TN * 4 + 16;                       // staging row stride (bytes): +16 keeps 16-byte accesses conflict-free
-    constexpr int CHR = (FM % 2 == 0 && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;   // rows per chunk
-    static_assert((size_t)NW * CHR * RSF <= RING, "wide-store staging does not fit the ring");
-    constexpr int CJ = CHR / 16;
+    constexpr int CHR = ((FM % 2 == 0 || RB == 32) && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;   // rows per chunk
+    static_assert((size_t)NW * CHR * RSF <= RING && CHR % RB == 0, "wide-store staging does not fit the ring");
+    constexpr int CJ = CHR / RB;
     constexpr int LPR = TN / 4;                            // lanes per output row (4 channels each)
     constexpr int RPW = 64 / LPR;                          // rows per pass of the wave
     unsigned char* stg = smem_raw + (size_t)wave * CHR * RSF;
@@ -747,7 +945,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + n_lane);
     __syncthreads();   // every wave is done with the ring
-    if constexpr (FM * FN <= 16 && FN % 2 == 0) {
+    if constexpr (MF == 16 && FM * FN <= 16 && FN % 2 == 0) {
       if (p.out_act == 4) {   // fused GEGLU: hidden unit hl of the wave's row = value column (hl/16)*32 + hl%16, gate 16 further
         constexpr int LPG = TN / 8, RPG = 64 / LPG;          // lanes per output row (4 hidden units each), rows per pass
         const int h4 = lane % LPG, grow = lane / LPG;
@@ -851,22 +1049,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
       }
       const WideCtx wc = {stg, RSF, frow, nsub, prow, col4, m0 + wm * TM + prow, (size_t)g * p.ogs, n_lane, c4, m0, wm, wn};
       if (p.gn_part) {       // host: no accumulate, no second output, alpha == 1, no activation on this path
-        if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, false, true, BM, WM>(p, acc, wc);
-        else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false, false, true, BM, WM>(p, acc, wc);
+        if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, false, true, BM, WM, RB, CB>(p, acc, wc);
+        else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false, false, true, BM, WM, RB, CB>(p, acc, wc);
       } else if (p.epi_act) {
         if (p.accumulate) {
-          if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, true, true>(p, acc, wc);
-          else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, true, true>(p, acc, wc);
-        } else if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, true>(p, acc, wc);
-        else if (!p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false, true>(p, acc, wc);
-        else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, true, false, true>(p, acc, wc);
+          if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, true, true, false, 0, 0, RB, CB>(p, acc, wc);
+          else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, true, true, false, 0, 0, RB, CB>(p, acc, wc);
+        } else if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, true, false, 0, 0, RB, CB>(p, acc, wc);
+        else if (!p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false, true, false, 0, 0, RB, CB>(p, acc, wc);
+        else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, true, false, true, false, 0, 0, RB, CB>(p, acc, wc);
       } else {
         if (p.accumulate) {
-          if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, true, false>(p, acc, wc);
-          else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, true, false>(p, acc, wc);
-        } else if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, false>(p, acc, wc);
-        else if (!p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false, false>(p, acc, wc);
-        else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, true, false, false>(p, acc, wc);
+          if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, true, false, false, 0, 0, RB, CB>(p, acc, wc);
+          else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, true, false, false, 0, 0, RB, CB>(p, acc, wc);
+        } else if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, false, false, 0, 0, RB, CB>(p, acc, wc);
+        else if (!p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false, false, false, 0, 0, RB, CB>(p, acc, wc);
+        else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, true, false, false, false, 0, 0, RB, CB>(p, acc, wc);
       }
       if (stamp && threadIdx.x == 0) stamp[4] = __builtin_amdgcn_s_memtime();
       return;
@@ -879,13 +1077,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 #pragma unroll
         for (int i = 0; i < FN; ++i) {
           const f32x4_t a = acc[i][j0 + jj];
-          *reinterpret_cast<float4*>(stg + (jj * 16 + frow) * RSF + (i * 16 + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+          *reinterpret_cast<float4*>(stg + (jj * RB + frow) * RSF + (i * CB + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
       // the staging rows are private to the wave and a wave's LDS operations execute in order: no workgroup barrier
       if (p.epi_barrier) __syncthreads(); else WAVE_LDS_FENCE();
 #pragma unroll 2
       for (int r = prow; r < CHR; r += RPW) {
-        const int m = m0 + wm * TM + j0 * 16 + r;
+        const int m = m0 + wm * TM + j0 * RB + r;
         if (m < p.M && n_ok)
           epilogue_wide4(p, *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16), bias4, m, n_lane, (size_t)g * p.ogs,
                          &gacc);
@@ -898,7 +1096,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   }
   // fused GEGLU: only compiled into the small-fragment tiles (a longer epilogue on the 16-fragment tiles
   // pushes their accumulators into scratch)
-  if constexpr (FM * FN <= 8 && FN % 2 == 0) {
+  if constexpr (MF == 16 && FM * FN <= 8 && FN % 2 == 0) {
     if (p.out_act == 4) {
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
@@ -915,13 +1113,13 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
   if constexpr (FM * FN <= 16) {
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
-      const int m = m0 + wm * TM + j * 16 + frow;
+      const int m = m0 + wm * TM + j * RB + frow;
       const bool m_ok = m < p.M;
       const int b = m_ok ? m / p.howo : 0;
       const long long mrem = m - (long long)b * p.howo;
 #pragma unroll
       for (int i = 0; i < FN; ++i) {
-        const int n = n0 + wn * TN + i * 16 + nsub;
+        const int n = n0 + wn * TN + i * CB + nsub;
         if (m_ok && n < p.n) epilogue_store(p, acc[i][j], m, n, b, mrem, zs);
       }
     }
@@ -945,8 +1143,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         const f32x4_t a = acc[idx / FM][idx % FM];
         stage[f * NT + tid] = make_float4(a[0], a[1], a[2], a[3]);
         if (p.res) {
-          const int m = m0 + wm * TM + (idx % FM) * 16 + frow;
-          const int n = n0 + wn * TN + (idx / FM) * 16 + nsub;
+          const int m = m0 + wm * TM + (idx % FM) * RB + frow;
+          const int n = n0 + wn * TN + (idx / FM) * CB + nsub;
           uint2 rr = make_uint2(0, 0);
           if (m < p.M && n < p.n) rr = *reinterpret_cast<const uint2*>(p.res + (size_t)m * p.res_ld + n);
           rstage[f * NT + tid] = rr;
@@ -958,8 +1156,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
         const int i = idx / FM, j = idx % FM;
         const float4 q = stage[f * NT + tid];
         const uint2 rr = p.res ? rstage[f * NT + tid] : make_uint2(0, 0);
-        const int m = m0 + wm * TM + j * 16 + frow;
-        const int n = n0 + wn * TN + i * 16 + nsub;
+        const int m = m0 + wm * TM + j * RB + frow;
+        const int n = n0 + wn * TN + i * CB + nsub;
         if (m < p.M && n < p.n) {
           const int b = m / p.howo;
           epilogue_store(p, (f32x4_t){q.x, q.y, q.z, q.w}, m, n, b, m - (long long)b * p.howo, zs, &rr);
@@ -970,23 +1168,119 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_kernel(ConvParams p
 }
 
 
-// ---- launchers (explicitly instantiated in conv_gemm_i1..6.hip so that the tile variants compile in parallel)
+// blockIdx -> (row tile, column tile, group / K split) of the one-tile-per-workgroup launches; false: a padding block
+__device__ __forceinline__ bool conv_block_tile(const ConvParams& p, int& mt, int& nt, int& zs_) {
+  mt = blockIdx.x; nt = blockIdx.y; zs_ = blockIdx.z;
+  if (p.slab_total > 0) {
+    const int item = (int)(blockIdx.x & 7) * p.slab_per + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= p.slab_per || item >= p.slab_total) return false;   // padding blocks (whole workgroup, before any barrier)
+    const int slab = item / p.m_tiles;
+    mt = item - slab * p.m_tiles;
+    zs_ = slab / p.n_tiles;
+    nt = slab - zs_ * p.n_tiles;
+  } else if (p.xcd_per > 0) {
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    if (p.n_inner) { nt = local % p.n_tiles; mt = xcd * p.xcd_per + local / p.n_tiles; }
+    else { nt = local / p.xcd_per; mt = xcd * p.xcd_per + local % p.xcd_per; }
+    if (mt >= p.m_tiles) return false;   // padding blocks of the last XCD range (whole workgroup, before any barrier)
+  }
+  return true;
+}
+// Waves per SIMD the register allocation must leave room for.  The LDS-DMA tiles whose waves own 64 x 64 at BK = 32 with two
+// stages (128x128x32, the 8-wave 256x128x32) run FOUR per SIMD and sat at exactly 128 VGPRs by luck of the allocator: round 4
+// lost 1.3 % of a generation step when one epilogue line made it 129, and the move of the body into conv_tile did it again.
+// Declared, the bound is the compiler's problem.
+constexpr int conv_min_waves(int bm, int bn, int bk, int wm, int wn, int mode, int stages) {
+  return (mode != 0 && bk == 32 && stages == 2 && bm / wm == 64 && bn / wn == 64) ? 4 : 2;
+}
+template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN, conv_min_waves(BM, BN, BK, WM, WN, MODE, STAGES)) void conv_gemm_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int mt, nt, zs_;
+  if (!conv_block_tile(p, mt, nt, zs_)) return;
+  conv_tile<BM, BN, BK, WM, WN, MODE, STAGES, 16, false>(p, smem_raw, mt, nt, zs_, SkSeg{});
+}
+// the same launch geometry on v_mfma_f32_32x32x16_bf16 (the tiles whose waves own 128 x 64)
+template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_mf32_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int mt, nt, zs_;
+  if (!conv_block_tile(p, mt, nt, zs_)) return;
+  conv_tile<BM, BN, BK, WM, WN, MODE, STAGES, 32, false>(p, smem_raw, mt, nt, zs_, SkSeg{});
+}
+// Stream-K: one persistent launch (ConvParams::sk_hdr explains the protocol; conv_gemm.hip decides which launches take it).
+template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES, int MF>
+__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_sk_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned* bc = reinterpret_cast<unsigned*>(smem_raw);
+  if (threadIdx.x == 0) {
+    bc[0] = __hip_atomic_fetch_add(p.sk_hdr + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bc[1] = __hip_atomic_load(p.sk_hdr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  const int G = (int)gridDim.x;
+  const int id = G - 1 - (int)__builtin_amdgcn_readfirstlane(bc[0]);     // later start = lower id: partners (higher ids) started earlier
+  const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane(bc[1]) + 1u;
+  const long long items = (long long)p.sk_tiles * p.nk;
+  long long a = (long long)id * items / G;
+  const long long b = (long long)(id + 1) * items / G;
+  while (a < b) {
+    const int tile = (int)(a / p.nk);
+    const int k0 = (int)(a - (long long)tile * p.nk);
+    const long long tile_end = (long long)(tile + 1) * p.nk;
+    const int k1 = (int)((b < tile_end ? b : tile_end) - (long long)tile * p.nk);
+    SkSeg sk;
+    sk.kt_begin = k0; sk.nk = k1 - k0; sk.id = id; sk.tag = tag; sk.first_partner = id + 1; sk.n_partners = 0;
+    sk.mode = k0 > 0 ? 1 : 0;
+    if (k0 == 0 && k1 < p.nk) {     // the workgroup that holds item tile_end - 1 is the last partner
+      const int last = (int)((tile_end * G - 1) / items);
+      sk.mode = 2; sk.n_partners = last - id;
+    }
+    int mt, nt;
+    if (p.sk_m_inner) { nt = tile / p.m_tiles; mt = tile - nt * p.m_tiles; }
+    else { mt = tile / p.n_tiles; nt = tile - mt * p.n_tiles; }
+    __syncthreads();      // the previous segment's epilogue (and the ticket words) are done with the ring
+    conv_tile<BM, BN, BK, WM, WN, MODE, STAGES, MF, true>(p, smem_raw, mt, nt, 0, sk);
+    a += k1 - k0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned d = __hip_atomic_fetch_add(p.sk_hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (d == (unsigned)G - 1u) {      // every workgroup drew its ticket and read the epoch long ago
+      __hip_atomic_store(p.sk_hdr + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.sk_hdr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(p.sk_hdr + 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// ---- launchers (explicitly instantiated in conv_gemm_i1..9.hip so that the tile variants compile in parallel)
+// KIND 0: conv_gemm_kernel, 1: conv_gemm_mf32_kernel, 2: conv_gemm_sk_kernel (16x16x32), 3: conv_gemm_sk_kernel (32x32x16)
 template <int BM, int BN, int BK, int STAGES>
 static constexpr size_t smem_bytes() { return (size_t)STAGES * (BM + BN) * BK * 2; }
 
-template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES>
+template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES, int KIND>
+static const void* variant_symbol() {
+  if constexpr (KIND == 1) return reinterpret_cast<const void*>(&conv_gemm_mf32_kernel<BM, BN, BK, WM, WN, GLDS, STAGES>);
+  else if constexpr (KIND == 2) return reinterpret_cast<const void*>(&conv_gemm_sk_kernel<BM, BN, BK, WM, WN, GLDS, STAGES, 16>);
+  else if constexpr (KIND == 3) return reinterpret_cast<const void*>(&conv_gemm_sk_kernel<BM, BN, BK, WM, WN, GLDS, STAGES, 32>);
+  else return reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES>);
+}
+template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES, int KIND = 0>
 void launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
   const size_t smem = smem_bytes<BM, BN, BK, STAGES>();
-  conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
+  if constexpr (KIND == 1) conv_gemm_mf32_kernel<BM, BN, BK, WM, WN, GLDS, STAGES><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
+  else if constexpr (KIND == 2) conv_gemm_sk_kernel<BM, BN, BK, WM, WN, GLDS, STAGES, 16><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
+  else if constexpr (KIND == 3) conv_gemm_sk_kernel<BM, BN, BK, WM, WN, GLDS, STAGES, 32><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
+  else conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES>
+template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES, int KIND = 0>
 ctta_status prepare_variant() {
   static bool done = false;
   if (done) return CTTA_OK;
-  CTTA_CHECK_HIP(hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<BM, BN, BK, STAGES>()));
+  CTTA_CHECK_HIP(hipFuncSetAttribute(variant_symbol<BM, BN, BK, WM, WN, GLDS, STAGES, KIND>(),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_bytes<BM, BN, BK, STAGES>()));
   done = true;
   return CTTA_OK;
 }
@@ -1040,10 +1334,29 @@ ctta_status prepare_variant() {
   X(128, 128, 64, 2, 2, 2, 3) \
   X(128, 64, 64, 2, 2, 2, 3) \
   X(128, 128, 64, 2, 2, 2, 4)
+// (BM, BN, BK, WM, WN, MODE, STAGES, KIND) of the 32x32x16 and stream-K kernels
+#define CTTA_CONV_VARIANTS_9(X) \
+  X(256, 256, 64, 2, 4, 2, 2, 1) \
+  X(256, 128, 64, 2, 2, 2, 2, 1) \
+  X(512, 128, 64, 4, 2, 2, 2, 1)
+#define CTTA_CONV_VARIANTS_10(X) \
+  X(256, 256, 64, 2, 4, 2, 2, 2) \
+  X(256, 128, 64, 2, 2, 2, 2, 2) \
+  X(128, 128, 64, 2, 2, 2, 2, 2)
+#define CTTA_CONV_VARIANTS_11(X) \
+  X(256, 256, 64, 2, 4, 2, 2, 3) \
+  X(256, 128, 64, 2, 2, 2, 2, 3)
+#define CTTA_CONV_VARIANTS_KIND(X) CTTA_CONV_VARIANTS_9(X) CTTA_CONV_VARIANTS_10(X) CTTA_CONV_VARIANTS_11(X)
+#define CTTA_CONV_INSTANTIATE_K(BM, BN, BK, WM, WN, G, S, KIND)                                      \
+  template void launch_variant<BM, BN, BK, WM, WN, G, S, KIND>(const ConvParams&, dim3, hipStream_t); \
+  template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S, KIND>();
+#define CTTA_CONV_DECLARE_K(BM, BN, BK, WM, WN, G, S, KIND)                                                     \
+  extern template void launch_variant<BM, BN, BK, WM, WN, G, S, KIND>(const ConvParams&, dim3, hipStream_t); \
+  extern template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S, KIND>();
 #define CTTA_CONV_VARIANTS_ALL(X) CTTA_CONV_VARIANTS_8(X) CTTA_CONV_VARIANTS_1(X) CTTA_CONV_VARIANTS_2(X) CTTA_CONV_VARIANTS_3(X) CTTA_CONV_VARIANTS_4(X) CTTA_CONV_VARIANTS_5(X) CTTA_CONV_VARIANTS_6(X) CTTA_CONV_VARIANTS_7(X)
 #define CTTA_CONV_INSTANTIATE(BM, BN, BK, WM, WN, G, S)                                      \
-  template void launch_variant<BM, BN, BK, WM, WN, G, S>(const ConvParams&, dim3, hipStream_t); \
-  template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S>();
+  template void launch_variant<BM, BN, BK, WM, WN, G, S, 0>(const ConvParams&, dim3, hipStream_t); \
+  template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S, 0>();
 #define CTTA_CONV_DECLARE(BM, BN, BK, WM, WN, G, S)                                                     \
-  extern template void launch_variant<BM, BN, BK, WM, WN, G, S>(const ConvParams&, dim3, hipStream_t); \
-  extern template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S>();
+  extern template void launch_variant<BM, BN, BK, WM, WN, G, S, 0>(const ConvParams&, dim3, hipStream_t); \
+  extern template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S, 0>();

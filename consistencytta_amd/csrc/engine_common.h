@@ -41,6 +41,8 @@ struct SplitWs {
   ctta_status init() {
     bytes = ctta_conv_workspace_bytes();
     if (hipMalloc(&p, bytes) != hipSuccess) { p = nullptr; ctta_set_error("hipMalloc of the split-K workspace failed"); return CTTA_ERR_NOMEM; }
+    // the stream-K header (ticket / finished / epoch words and the flags) starts at zero; the launches keep it consistent
+    if (hipMemset(p, 0, ctta_conv_workspace_header_bytes()) != hipSuccess) { destroy(); ctta_set_error("hipMemset of the stream-K header failed"); return CTTA_ERR_HIP; }
     return CTTA_OK;
   }
   void destroy() { if (p) (void)hipFree(p); p = nullptr; }
@@ -48,8 +50,13 @@ struct SplitWs {
 struct WsBind {   // re-entrant: the previous binding of the thread (a raw caller's, or an outer handle's) comes back
   void* prev = nullptr;
   size_t prev_bytes = 0;
-  explicit WsBind(const SplitWs& w) { ctta_conv_bound_workspace(&prev, &prev_bytes); ctta_conv_bind_workspace(w.p, w.bytes); }
-  ~WsBind() { ctta_conv_bind_workspace(prev, prev_bytes); }
+  int prev_hdr = 0;
+  explicit WsBind(const SplitWs& w) {
+    ctta_conv_bound_workspace(&prev, &prev_bytes);
+    prev_hdr = ctta_conv_bound_workspace_header();
+    ctta_conv_bind_workspace_ex(w.p, w.bytes, 1);
+  }
+  ~WsBind() { ctta_conv_bind_workspace_ex(prev, prev_bytes, prev_hdr); }
   WsBind(const WsBind&) = delete;
   WsBind& operator=(const WsBind&) = delete;
 };

@@ -152,7 +152,7 @@ struct ctta_unet {
   // SECOND stream: the data-gradient chain on the caller's stream is the critical path of the backward pass, its thin
   // batch-9 launches leave CUs idle, and a layer's weight gradient depends on nothing that comes after it.  Each job
   // owns one of NS scratch slots (dY^T is written by the main stream, everything else by the side stream); events
-  // order slot reuse and the joins at block boundaries.  CTTA_WGRAD_STREAM=0 keeps everything on one stream.
+  // order slot reuse and the joins at block boundaries.  Option "wgrad_stream" = 0 keeps everything on one stream.
   struct WgradSide {
     static constexpr int NS = 2;
     hipStream_t stream = nullptr;
@@ -798,8 +798,7 @@ extern "C" ctta_status ctta_unet_create(const ctta_unet_config* cfg, const ctta_
                            cfg->max_text_len, nullptr, s, &gn_need);
     if (st == CTTA_OK && cfg->enable_training) {   // training forward + backward need the larger arena
       {   // known before the dry run: with the side stream on, the backward releases nothing (unet_backward_begin_impl)
-        const char* e = getenv("CTTA_WGRAD_STREAM");   // =0: one stream
-        U->wg.enabled = !(e && e[0] == '0');
+        U->wg.enabled = ctta_opt(CTTA_OPT_WGRAD_STREAM) != 0;   // 0 at creation: one stream, and the backward releases its arena blocks
       }
       size_t gn2 = 0;
       st = unet_forward_impl(U, true, nullptr, nullptr, nullptr, nullptr, (const uint8_t*)1, cfg->max_batch,

@@ -35,10 +35,17 @@ static ctta_status wg_begin(BCtx& c, WgJob* j) {
   ctta_unet::WgradSide& W = c.U->wg;
   j->slot = W.next;
   W.next = (W.next + 1) % ctta_unet::WgradSide::NS;
-  j->async = !c.dry && W.enabled && W.stream != nullptr;
+  // ("wgrad_stream" is read per job: switched off between two backward passes -- bench.py's profiled step, whose per-launch
+  // event brackets must not overlap -- the jobs run on the caller's stream in the same slots; the handle's arena policy,
+  // W.enabled, was fixed when it was created)
+  j->async = !c.dry && W.enabled && W.stream != nullptr && ctta_opt(CTTA_OPT_WGRAD_STREAM) != 0;
   j->w = c;
   j->w.arena = &W.slot[j->slot];
   W.slot[j->slot].reset();
+  if (!j->async && !c.dry && W.in_use[j->slot]) {      // a side-stream job of an earlier pass may still own the slot
+    CTTA_CHECK_HIP(hipStreamWaitEvent(c.stream, W.freed[j->slot], 0));
+    W.in_use[j->slot] = false;
+  }
   if (j->async) {
     j->w.stream = W.stream;
     // the slot's previous job must have drained before the main stream writes dY^T into it.  Jobs that read their operands

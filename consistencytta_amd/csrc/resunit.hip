@@ -654,9 +654,7 @@ static ctta_status launch_resunit(const ResUnitParams& p, int batch, hipStream_t
 }
 
 extern "C" int ctta_resunit_supported(int channels, int k, int dil) {
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("CTTA_FUSED_RES"); env = (e && e[0] == '0') ? 0 : 1; }
-  if (!env) return 0;
+  if (!ctta_opt(CTTA_OPT_FUSED_RES)) return 0;
   if (channels != 32 && channels != 64 && channels != 128) return 0;
   if (k < 1 || k > 11 || (k & 1) == 0 || dil < 1) return 0;
   const int T = channels == 128 ? 128 : channels == 64 ? 256 : 512;

@@ -35,6 +35,27 @@ typedef enum {
 const char* ctta_last_error(void);
 int ctta_version(void);
 
+/* Library options -- the only switches of the library (nothing in it reads the environment; there is no other global state
+ * than this table and the per-thread bindings documented below).  Process-wide plain ints, read by the call that uses
+ * them; set them before the handles they concern are created or between calls, not while another host thread is inside
+ * the library.  Names, defaults and what each one trades:
+ *   "xcd"          1  blockIdx -> tile order that keeps the tiles sharing operands on one XCD's L2 (0: plain 2-D grids)
+ *   "splitk"       1  deep thin GEMMs (few output tiles, long K) are cut over K: two-pass split-K or stream-K (0: never)
+ *   "streamk"      1  ... as ONE persistent launch that folds its partial tiles itself, where the tile rules choose it
+ *                     (0: two-pass split-K only); needs a workspace with a zeroed header (ctta_conv_bind_workspace_ex)
+ *   "streamk_grid" 0  tuning: workgroups of a stream-K launch (0: one per CU slot)
+ *   "mf32"         1  the 128x64-per-wave tiles issue v_mfma_f32_32x32x16_bf16 where the tile rules choose it (0: 16x16x32 only)
+ *   "wgrad_stream" 1  weight-gradient launches of ctta_unet_backward* go to the handle's side stream (0: everything on the
+ *                     caller's stream -- what a per-launch profile needs; read at every backward call)
+ *   "gn_fuse"      1  GroupNorm statistics come from the producing convolution's epilogue (= ctta_set_gn_fuse)
+ *   "fused_res"    1  HiFi-GAN ResBlock units run as fused pair kernels (0: one conv_gemm launch per convolution)
+ * Every option is exercised in its non-default position by tests/test_options_gpu.py. */
+ctta_status ctta_set_option(const char* name, int value);
+ctta_status ctta_get_option(const char* name, int* value);
+int ctta_num_options(void);
+const char* ctta_option_name(int i);
+int ctta_option_default(int i);
+
 /* One entry of a state dict: reference key name, fp32 device data, shape. */
 typedef struct {
   const char* name;
@@ -348,6 +369,15 @@ int ctta_conv_last_gn_chunks(void);
  * device: launches that share it must be ordered on ONE stream -- or the caller binds its own buffer of
  * ctta_conv_workspace_bytes() bytes for the calling thread (NULL unbinds). */
 void ctta_conv_bind_workspace(void* ws, size_t bytes);
+/* The same with a promise about the workspace's first ctta_conv_workspace_header_bytes() bytes: header_zeroed != 0 says they were
+ * zero when the buffer was created and have only been touched by this library since.  Stream-K launches (one persistent
+ * launch that folds its partial tiles itself: start tickets, an epoch and one flag word per workgroup live there; the launches
+ * leave the header consistent for the next one) are only taken with such a workspace; the engine handles bind theirs this
+ * way, ctta_conv_bind_workspace() promises nothing and keeps the two-pass split-K.  The per-device default workspace is
+ * created with a zero header. */
+void ctta_conv_bind_workspace_ex(void* ws, size_t bytes, int header_zeroed);
+int ctta_conv_bound_workspace_header(void);
+size_t ctta_conv_workspace_header_bytes(void);
 /* The calling thread's current binding (NULL / 0 when none).  Engine / STFT / mel / T5 entry points bind their own
  * handle's workspace while they enqueue work and RESTORE the caller's binding on return (round 3; before, they left the
  * thread unbound and later raw launches silently fell back to the shared per-device workspace). */

@@ -65,9 +65,87 @@ def _conv_case(B, Cin, H, W, Cout, k, stride, pad, tile=0, upsample=False, c_spl
     return rel_err(from_nhwc(out), ref)
 
 
-@pytest.mark.parametrize("tile", list(range(0, 41)))
+@pytest.mark.parametrize("tile", list(range(0, 49)))
 def test_conv3x3_all_tiles(tile):
+    """41-43: the 128x64-per-wave tiles on v_mfma_f32_32x32x16_bf16; 44-48: their stream-K forms (M = 768: three row tiles of
+    nine K steps on six workgroups -- every tile is split, one of them over three workgroups)."""
     assert _conv_case(2, 64, 24, 16, 96, 3, 1, 1, tile=tile, tag="t%d" % tile) < BF16_TOL
+
+
+SK_TILES = [44, 45, 46, 47, 48]
+
+
+@pytest.mark.parametrize("tile", [41, 42, 43] + SK_TILES)
+def test_conv_geometries_on_mf32_and_streamk_tiles(tile):
+    assert _conv_case(2, 64, 8, 4, 64, 3, 1, 1, upsample=True, tile=tile, tag="g_up") < BF16_TOL
+    assert _conv_case(2, 64, 16, 8, 72, 3, 2, 1, tile=tile, tag="g_s2") < BF16_TOL
+    assert _conv_case(1, 128, 9, 7, 24, 1, 1, 0, tile=tile, tag="g_1x1") < BF16_TOL
+    assert _conv_case(3, 256, 4, 2, 256, 3, 1, 1, tile=tile, tag="g_deepk") < BF16_TOL
+    assert _conv_case(2, 64, 8, 8, 64, 3, 1, 1, epilogue=True, tile=tile, tag="g_epi") < BF16_TOL
+    assert _conv_case(5, 128, 32, 16, 320, 3, 1, 1, epilogue=True, tile=tile, tag="g_big") < BF16_TOL   # M = 2560, two column tiles
+
+
+@pytest.mark.parametrize("tile", SK_TILES)
+@pytest.mark.parametrize("B,Cin,Cout,H,W,f32", [(9, 1024, 1024, 32, 2, False), (18, 512, 512, 16, 8, False), (9, 1024, 512, 8, 4, True),
+                                                (7, 256, 320, 37, 3, False)])
+def test_streamk_fold_is_exact_ordered_and_repeatable(tile, B, Cin, Cout, H, W, f32):
+    """conv_gemm_sk_kernel (ConvParams::sk_hdr): ONE persistent launch whose workgroups walk equal shares of the (tile, K step)
+    items; split tiles are folded inside the launch, in K order, by the workgroup that holds the tile's first K step.
+    Checked: (a) against F.conv2d with the whole fused epilogue (bias, per-sample row vector, residual, SiLU; or an fp32
+    output), on the distillation step's deep thin shapes (M = 576 x N = 1024 x K = 9216 ...) and on a ragged one (M = 777,
+    N = 320: partial row and column tiles); (b) 40 launches in a row on one workspace give BIT-identical outputs (the fold order
+    is fixed by the decomposition, the epoch / ticket words are left consistent by every launch); (c) the header afterwards:
+    tickets and finished count back at zero, no poll ever timed out, the epoch advanced once per launch."""
+    L_ = lib()
+    x = bf16_round(det("skf.x", (B, Cin, H, W), 1))
+    w = bf16_round(det("skf.w", (Cout, Cin, 3, 3), 2) * (1.0 / math.sqrt(Cin * 9)))
+    b = det("skf.b", (Cout,), 3) * 0.1
+    rv = det("skf.rv", (B, Cout), 4) * 0.2
+    res = bf16_round(det("skf.r", (B, Cout, H, W), 5))
+    conv = F.conv2d(x, w, b, padding=1)
+    ref = conv if f32 else F.silu(conv + rv[:, :, None, None] + res)
+    wp, k_pad = pack_conv_weight(w)
+    xa, ra = nhwc_bf16(x), nhwc_bf16(res)
+    bd, rvd = b.to(DEV), rv.to(DEV).contiguous()
+    ws = torch.zeros(L_.ctta_conv_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    L_.ctta_conv_bind_workspace_ex(N.ptr(ws), ws.numel(), 1)
+    try:
+        outs = []
+        for rep in range(40):
+            out = torch.full((B, H, W, Cout), float("nan"), dtype=torch.float32 if f32 else torch.bfloat16, device=DEV)
+            kw = dict(x0=xa, c0=Cin, batch=B, hi=H, wi=W, ho=H, wo=W, kh=3, kw=3, pad_h=1, pad_w=1, w=wp, k_pad=k_pad, n=Cout,
+                      bias=bd, out=out, ldc=Cout, tile=tile)
+            if f32:
+                kw.update(out_f32=1)
+            else:
+                kw.update(rowvec=rvd, rowvec_ld=Cout, res=ra, res_ld=Cout, out_act=1)
+            dsc = conv_desc(**kw)
+            N.check(L_.ctta_conv_gemm(ctypes.byref(dsc), N.stream_ptr()))      # back to back: launch i + 1 queues behind launch i
+            outs.append(out)
+        sync()
+        got = outs[0].float().permute(0, 3, 1, 2).cpu()
+        assert rel_err(got, ref) < 2 * BF16_TOL
+        for o in outs[1:]:
+            assert torch.equal(o, outs[0])
+        hdr = ws[:16].view(torch.int32).cpu().tolist()
+        assert hdr[0] == 0 and hdr[1] == 0 and hdr[3] == 0 and hdr[2] == 40, hdr
+    finally:
+        L_.ctta_conv_bind_workspace(None, 0)
+
+
+def test_streamk_needs_a_workspace_with_a_zeroed_header():
+    """A buffer bound with ctta_conv_bind_workspace() promises nothing about its first bytes: a stream-K tile is refused there
+    (and never chosen automatically); the two-pass split-K keeps working on it."""
+    L_ = lib()
+    mine = torch.full((L_.ctta_conv_workspace_bytes(),), 0x5A, dtype=torch.uint8, device=DEV)
+    L_.ctta_conv_bind_workspace(N.ptr(mine), mine.numel())
+    try:
+        with pytest.raises(RuntimeError, match="stream-K needs a workspace"):
+            _conv_case(3, 256, 4, 2, 256, 3, 1, 1, tile=44, tag="skh")
+        assert _conv_case(9, 512, 8, 2, 256, 3, 1, 1, tag="skh2") < BF16_TOL      # split over K, slabs behind the header
+        assert bool((mine[:L_.ctta_conv_workspace_header_bytes()] == 0x5A).all())    # the header bytes were left alone
+    finally:
+        L_.ctta_conv_bind_workspace(None, 0)
 
 
 def test_conv_shapes():
