@@ -71,35 +71,47 @@ def launcher_command(argv, n, port, script=None):
             "--master-addr", "127.0.0.1", "--master-port", str(int(port)), script or os.path.abspath(__file__)] + list(argv)
 
 
-def self_launch(args, argv):
+def self_launch(args, argv, script=None):
     """`python bench.py --gpus N` by itself: the parent -- which has NOT imported torch, let alone touched the GPU -- starts
     the N ranks as a CHILD process (never exec: a process that initialised HIP must not be replaced, and this one must stay
     to relay), relays the child's stdout so that the one JSON line is the last line the parent prints, and returns its exit
-    code.  Under an external torchrun (WORLD_SIZE set) this function is never reached."""
+    code.  Under an external torchrun (WORLD_SIZE set) this function is never reached.
+    The rendezvous port is found by bind(0) and handed to the child after the socket is closed: another process may take it
+    in between (two launches on one node).  A child that fails within a minute WITHOUT having printed a line is therefore
+    started again on a fresh port, twice at most, with a note on stderr; any other failure is the parent's exit code."""
     import socket
     import subprocess
-    with socket.socket() as s_:
-        s_.bind(("127.0.0.1", 0))
-        port = s_.getsockname()[1]
-    cmd = launcher_command(argv, args.gpus, port)
-    if os.environ.get("CTTA_BENCH_LAUNCH_DRYRUN") == "1":
-        print(json.dumps({"launcher_command": cmd}), flush=True)
-        return 0
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
-    env.setdefault("OMP_NUM_THREADS", "4")
-    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=env)
-    line_json = None
-    for line in child.stdout:
-        if line.startswith('{"metric"'):
-            line_json = line        # held back: printed last, whatever a rank's C stdio still flushes at exit
-        else:
-            sys.stdout.write(line)
+    rc = 1
+    for attempt in range(3):
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        cmd = launcher_command(argv, args.gpus, port, script)
+        if os.environ.get("CTTA_BENCH_LAUNCH_DRYRUN") == "1":
+            print(json.dumps({"launcher_command": cmd}), flush=True)
+            return 0
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this driver
+        env.setdefault("OMP_NUM_THREADS", "4")
+        t0 = time.time()
+        child = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, bufsize=1, env=env)
+        line_json, printed = None, 0
+        for line in child.stdout:
+            printed += 1
+            if line.startswith('{"metric"'):
+                line_json = line        # held back: printed last, whatever a rank's C stdio still flushes at exit
+            else:
+                sys.stdout.write(line)
+                sys.stdout.flush()
+        rc = child.wait()
+        if line_json is not None:
+            sys.stdout.write(line_json)
             sys.stdout.flush()
-    rc = child.wait()
-    if line_json is not None:
-        sys.stdout.write(line_json)
-        sys.stdout.flush()
+        if rc == 0 or printed > 0 or time.time() - t0 > 60.0 or attempt == 2:
+            return rc
+        sys.stderr.write("[bench] the rank launcher exited with code %d before any rank printed (rendezvous port %d taken by "
+                         "another process?); starting it again on a fresh port\n" % (rc, port))
+        sys.stderr.flush()
     return rc
 
 
@@ -690,13 +702,14 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                   gaussian_noise=torch.randn(B, 8, 256, 16, generator=gdr).to(dev), guidance_scale=torch.rand(B, generator=gdr) * 6)
 
         def timed_graph(segmented, pipelined=False, z=None, prompt=None, draws=None, steps=None, warm=None):
-            trace("distill: replayed form segmented=%s pipelined=%s batch=%s" % (segmented, pipelined, "fused" if z is not None else "micro"))
             """Phase 1 (LOCAL, no collective inside): capture, check one replay against an eager forward with the same draws.
             Then the ranks agree (du.all_agree) -- all of them time the leg or none does; a one-sided capture failure or
             parity assert therefore never leaves the peers alone inside a barrier or a bucket all-reduce.  Phase 2: one
             public step timed on every rank (MAX) -- a transport that cannot keep up between the replays (the gloo
             rehearsal with two ranks on one GPU took 50 s per segmented step) skips the leg collectively -- then warm-up
-            and the timed steps.  Returns seconds for `steps` steps, or raises _LegSkipped on EVERY rank."""
+            and the timed steps.  Returns seconds for `steps` steps, or raises _LegSkipped on EVERY rank.  (One rank alone has
+            no peer to leave hanging: there ANY exception of phase 2 becomes a skipped leg instead of costing the line.)"""
+            trace("distill: replayed form segmented=%s pipelined=%s batch=%s" % (segmented, pipelined, "fused" if z is not None else "micro"))
             z = z0 if z is None else z
             prompt = P if prompt is None else prompt
             draws = kw if draws is None else draws
@@ -724,21 +737,29 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                 raise _LegSkipped("capture / parity check failed (%s)" % (why or "on another rank"))
             if pipelined:
                 placements.append(getattr(gs, "placement_ms", None))
-            du.barrier(dev)
-            t1 = time.perf_counter()
-            losses.append(gs.step(z, sched))
-            du.barrier(dev)
-            one = du.max_over_ranks(time.perf_counter() - t1, dev)
-            if one > 6.0 * dt_eager / n_steps * max(1.0, z.shape[0] / float(B)):
-                raise _LegSkipped("first replayed step took %.0f ms against %.0f ms eager" % (one * 1e3, dt_eager / n_steps * 1e3))
-            for _ in range(warm):
+            try:
+                du.barrier(dev)
+                t1 = time.perf_counter()
                 losses.append(gs.step(z, sched))
-            du.barrier(dev)
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                losses.append(gs.step(z, sched))
-            du.barrier(dev)
-            return du.max_over_ranks(time.perf_counter() - t0, dev)
+                du.barrier(dev)
+                one = du.max_over_ranks(time.perf_counter() - t1, dev)
+                if one > 6.0 * dt_eager / n_steps * max(1.0, z.shape[0] / float(B)):
+                    raise _LegSkipped("first replayed step took %.0f ms against %.0f ms eager" % (one * 1e3, dt_eager / n_steps * 1e3))
+                for _ in range(warm):
+                    losses.append(gs.step(z, sched))
+                du.barrier(dev)
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    losses.append(gs.step(z, sched))
+                du.barrier(dev)
+                return du.max_over_ranks(time.perf_counter() - t0, dev)
+            except _LegSkipped:
+                raise
+            except Exception as exc:
+                if world > 1:      # one-sided: ending the rank (torchrun then stops the job) beats a hang
+                    raise
+                opt.zero_grad()
+                raise _LegSkipped("replayed steps failed: %s" % str(exc)[:160])
         pipe_on = os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0"
         # CTTA_BENCH_DISTILL_FORMS (profiling aid): which replayed forms are timed -- seg, segpipe, graph, pipe; "accum" keeps the
         # accumulation legs.  Default: all.  One form per rocprofv3 run gives a kernel table that belongs to ONE launch form.
@@ -767,14 +788,15 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                 launch_mode += " (segmented + pipelined replay skipped: %s)" % exc
         if world == 1 and ("graph" in forms or "pipe" in forms):
             try:
+                mono_txt = "one hipGraph replay per micro-step (forward + backward + loss) + the optimizer tail (AdamW, zero_grad, EMA: one launch)"
                 if "graph" in forms:
                     dt = dt_graph = timed_graph(False)
-                launch_mode = "one hipGraph replay per micro-step (forward + backward + loss) + eager AdamW / zero_grad / EMA"
+                    launch_mode = mono_txt
                 if pipe_on and "pipe" in forms:
                     try:
                         dt_pipe = timed_graph(False, True)
                         if dt_pipe < dt:
-                            dt, launch_mode = dt_pipe, launch_mode + pipe_txt
+                            dt, launch_mode = dt_pipe, mono_txt + pipe_txt
                     except _LegSkipped as exc:
                         launch_mode += " (pipelined capture skipped: %s)" % exc
             except _LegSkipped as exc:   # a failed capture must not cost the line
@@ -1008,6 +1030,10 @@ def distill_leg(args, dev, world, rank, perceptual=False):
             ("ema2_kernel (AudioLCM.update_ema: the launch + its O(1) host checks)", "read student, 2 shadows; write 2 shadows (fp32)",
              20 * n_all, m.update_ema),
             ("zero_grad (fill)", "write g (fp32)", 4 * opt.grad.numel(), opt.zero_grad),
+            # what the training step runs since round 6 (AudioLCM._optimizer_tail): the three passes above as one
+            ("adamw_ema2_zero_kernel (optimizer.step + zero_grad + update_ema as ONE pass: the step's tail)",
+             "read p, g, m, v, 2 shadows; write p, m, v, 2 shadows, g = 0 (fp32)", 48 * n_tr + 24 * (n_all - n_tr),
+             lambda: m._optimizer_tail(opt, None, 1.0, True)),
         ]
         rows = []
         for name, what, nbytes, fn in passes:

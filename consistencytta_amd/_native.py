@@ -267,6 +267,8 @@ SIGNATURES = {
     "ctta_softmax_bwd_rows": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "ctta_linear_f32_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "ctta_snr_mse_grad": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_float, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_adamw_ema2_zero": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_double, c_void_p, c_double, c_int,
+                                     c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "ctta_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_float, c_float, c_int, c_float, c_void_p]),
     "ctta_prof_enable": (None, [c_int]),
     "ctta_set_option": (c_int, [c_char_p, c_int]),

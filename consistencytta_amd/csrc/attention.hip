@@ -58,11 +58,7 @@ __device__ __forceinline__ float rows_sum(float x) {
   return b + o;
 }
 
-static bool attn_plain_enabled() {   // CTTA_ATTN_PLAIN=0: always the general kernels (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_ATTN_PLAIN"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
+static constexpr bool attn_plain_enabled() { return true; }   // the plain self-attention kernels wherever they apply
 #define ATT_KT 64          // keys per tile
 #define ATT_LDK 80         // K tile row stride (bf16): 160 B rows are conflict-free for ds_read_b128
 #define ATT_LDV 72         // V^T tile row stride: 144 B rows are conflict-free for the paired ds_read_b64
@@ -582,11 +578,7 @@ __global__ __launch_bounds__(256, 3) void attention_plain2_kernel(
 // debugging aid, like ctta_conv_debug_stamps: buf = (4 * 64 * 6 + 8) unsigned per workgroup of the next self-attention launches
 static thread_local unsigned* t_attn_stamps = nullptr;
 extern "C" void ctta_attention_debug_stamps(void* buf) { t_attn_stamps = (unsigned*)buf; }
-static int attn_v2_mode() {   // CTTA_ATTN_V2=0: round 2's kernel for self-attention (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_ATTN_V2"); v = e ? atoi(e) : 1; }
-  return v;
-}
+static constexpr int attn_v2_mode() { return 1; }   // round 3's self-attention kernel (round 2's stays for the shapes it does not take)
 
 extern "C" ctta_status ctta_attention(const void* q, int q_ld, const void* k, int k_ld, int k_rows, const void* vt,
                                       int vt_ld, const float* bias, void* out, int out_ld, int batch,
@@ -612,13 +604,8 @@ extern "C" ctta_status ctta_attention_lse(const void* q, int q_ld, const void* k
   hipLaunchKernelGGL((attention_plain2_kernel<ST, AB>), grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, q_ld,     \
                      (const bf16_t*)k, k_ld, k_rows, (const bf16_t*)vt, vt_ld, (bf16_t*)out, out_ld, heads, nq, nk,          \
                      scale * 1.4426950408889634f, lse, SP)
-    static int abl = -1;
-    if (abl < 0) { const char* e = getenv("CTTA_ATTN_ABLATE"); abl = e ? atoi(e) : 0; }
+    // (round 5's timing-only ablations -- AB = 1 / 2 / 4 / 6 of the kernel template -- are no longer instantiated)
     if (t_attn_stamps) CTTA_ATTN_LAUNCH(true, 0, t_attn_stamps);
-    else if (abl == 1) CTTA_ATTN_LAUNCH(false, 1, nullptr);
-    else if (abl == 2) CTTA_ATTN_LAUNCH(false, 2, nullptr);
-    else if (abl == 4) CTTA_ATTN_LAUNCH(false, 4, nullptr);
-    else if (abl == 6) CTTA_ATTN_LAUNCH(false, 6, nullptr);
     else CTTA_ATTN_LAUNCH(false, 0, nullptr);
 #undef CTTA_ATTN_LAUNCH
   }
@@ -1227,8 +1214,7 @@ static ctta_status attention_bwd_impl(const void* q, int q_ld, const void* k, in
                "attention_bwd: row strides (transposed operands need 64-multiples)");
   CTTA_REQUIRE(nq > 0 && nk > 0 && k_rows >= nk && (tr || (vn_rows >= nk && kt_ld >= nk && qt_ld >= nq)), "attention_bwd: bad lengths");
   hipStream_t s = (hipStream_t)stream;
-  static int fuse_dsum = -1;      // CTTA_ATTN_FUSE_DSUM=0: the separate row-dot launch of rounds 1-4 (A/B switch)
-  if (fuse_dsum < 0) { const char* e = getenv("CTTA_ATTN_FUSE_DSUM"); fuse_dsum = (e && e[0] == '0') ? 0 : 1; }
+  constexpr bool fuse_dsum = true;      // D = rowsum(dO * O) inside the dq kernel (round 5); the row-dot launch serves callers without it
   if (!fuse_dsum) {
     hipLaunchKernelGGL(attn_rowdot_kernel, dim3((unsigned)(((long long)batch * nq + 3) / 4)), dim3(256), 0, s,
                        (const bf16_t*)dout, do_ld, (const bf16_t*)out, out_ld, dsum, batch, heads, nq);

@@ -759,9 +759,7 @@ __global__ __launch_bounds__(256) void gn_bwd_small_kernel(const bf16_t* __restr
   }
 }
 static bool gn_bwd_small_ok(int hw, int c, int groups) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("CTTA_GN_BWD_SMALL"); on = (e && e[0] == '0') ? 0 : 1; }
-  if (!on || c % groups) return false;
+  if (c % groups) return false;
   const int cpg = c / groups;
   if (cpg % 8 || cpg > 128) return false;
   const int vpr = cpg / 8;
@@ -815,9 +813,7 @@ extern "C" ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* d
   {
     const int cpg = c / groups;
     const int gpb = cpg >= 64 ? 1 : 64 / cpg;
-    static int slices = -1;
-    if (slices < 0) { const char* e = getenv("CTTA_GN_BWD_FOLD_SLICES"); slices = (e && e[0] == '0') ? 0 : 1; }
-    if (slices && cpg * gpb <= 1024)
+    if (cpg * gpb <= 1024)
       hipLaunchKernelGGL(gn_bwd_fold_slices_kernel, dim3((groups + gpb - 1) / gpb, batch), dim3(1024), 0, s, part, nchunk, groups, c,
                          hw, gamma, coef, red, gpb);
     else
@@ -831,9 +827,7 @@ extern "C" ctta_status ctta_groupnorm_bwd(const void* x, const void* dy, void* d
     CTTA_LAUNCH_CHECK();
   }
   const long long total_vec = (long long)batch * hw * VC;
-  static int cols = -1;
-  if (cols < 0) { const char* e = getenv("CTTA_GN_BWD_COLS"); cols = (e && e[0] == '0') ? 0 : 1; }
-  if (cols && VC <= 256) {
+  if (VC <= 256) {
     const int bd = 256 / VC * VC;
     const long long per_sample = (long long)hw * VC;
     long long bps = (per_sample + bd * 8 - 1) / (bd * 8);               // >= 8 vectors per thread
@@ -1072,11 +1066,7 @@ static int ln_bwd_rows_per_block(int64_t rows) {
   int rpb = (int)(rows / 2048);
   return rpb < 8 ? 8 : (rpb > 64 ? 64 : (rpb + 7) / 8 * 8);
 }
-static bool ln_bwd_two_pass() {
-  static int two_pass = -1;
-  if (two_pass < 0) { const char* e = getenv("CTTA_LN_BWD_TWO_PASS"); two_pass = (e && e[0] == '0') ? 0 : 1; }
-  return two_pass != 0;
-}
+static constexpr bool ln_bwd_two_pass() { return true; }
 // The per-block partial table of d gamma / d beta belongs to the CALLER (an engine handle's arena, a torch tensor): the
 // library keeps no table of its own (round 4 kept a process-global one keyed by (device, stream) that could only ever
 // grow -- SURVEY 8b: no global state, one handle per (device, model)).  0 = this shape takes the atomics-only path.
@@ -1540,16 +1530,27 @@ extern "C" ctta_status ctta_conv_cout1_dgrad(const float* gy, const float* y_tan
 }
 
 // ------------------------------------------------------------------------------ AdamW (torch.optim.AdamW, no amsgrad)
+// One element's update with the contractions written out: left to the compiler (-ffp-contract=fast), `beta2 * v + omb2 * g * g`
+// became fma(beta2, v, (omb2 g) g) in one kernel and fma(omb2 g, g, beta2 v) in another -- two valid roundings, and the fused
+// optimizer tail below was not bit-identical to the three launches it replaces.  Every AdamW kernel of the library goes
+// through this function.
+struct AdamWConst { float decay, step, omb1, omb2, beta2, bc2_sqrt, eps, grad_scale; };
+__device__ __forceinline__ void adamw_one(float& pp, float gq, float& mm, float& vv, const AdamWConst& c) {
+#pragma clang fp contract(off)
+  const float gr = gq * c.grad_scale;
+  const float q = pp * c.decay;
+  mm = fmaf(c.omb1, gr - mm, mm);                       // exp_avg.lerp_(grad, 1 - beta1)
+  vv = fmaf(c.omb2 * gr, gr, c.beta2 * vv);
+  const float denom = sqrtf(vv) / c.bc2_sqrt + c.eps;
+  pp = fmaf(-c.step, mm / denom, q);
+}
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, long long n, float lr, float beta1, float beta2, float eps, float wd,
                              float bc1, float bc2_sqrt, float grad_scale) {
+  const AdamWConst c = {1.0f - lr * wd, lr / bc1, 1.0f - beta1, 1.0f - beta2, beta2, bc2_sqrt, eps, grad_scale};
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float gr = g[i] * grad_scale;
-    float pp = p[i] * (1.0f - lr * wd);
-    const float mm = m[i] + (1.0f - beta1) * (gr - m[i]);          // exp_avg.lerp_(grad, 1 - beta1)
-    const float vv = beta2 * v[i] + (1.0f - beta2) * gr * gr;
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    pp -= (lr / bc1) * (mm / denom);
+    float pp = p[i], mm = m[i], vv = v[i];
+    adamw_one(pp, g[i], mm, vv, c);
     p[i] = pp; m[i] = mm; v[i] = vv;
   }
 }
@@ -1559,16 +1560,8 @@ __global__ __launch_bounds__(256) void adamw4_kernel(float4* __restrict__ p, con
                                                      float4* __restrict__ m, float4* __restrict__ v, long long n4, float lr,
                                                      float beta1, float beta2, float eps, float wd, float bc1, float bc2_sqrt,
                                                      float grad_scale) {
-  const float decay = 1.0f - lr * wd, step = lr / bc1, omb1 = 1.0f - beta1, omb2 = 1.0f - beta2;
-  auto one = [&](float& pp, float gq, float& mm, float& vv) {
-    const float gr = gq * grad_scale;
-    float q = pp * decay;
-    mm = mm + omb1 * (gr - mm);
-    vv = beta2 * vv + omb2 * gr * gr;
-    const float denom = sqrtf(vv) / bc2_sqrt + eps;
-    q -= step * (mm / denom);
-    pp = q;
-  };
+  const AdamWConst c = {1.0f - lr * wd, lr / bc1, 1.0f - beta1, 1.0f - beta2, beta2, bc2_sqrt, eps, grad_scale};
+  auto one = [&](float& pp, float gq, float& mm, float& vv) { adamw_one(pp, gq, mm, vv, c); };
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
     const long long j = i + stride;
@@ -1584,6 +1577,91 @@ __global__ __launch_bounds__(256) void adamw4_kernel(float4* __restrict__ p, con
     }
   }
 }
+// ------------------------------------------------------------------------------ the optimizer tail as ONE pass
+// tools/train_utils.py:177-183 runs optimizer.step() -> optimizer.zero_grad() -> update_ema() (255-282) back to back: three
+// passes over the training state, 7 + 1 + 5 = 13 fp32 streams of 559 M elements = 29.1 GB per step.  One pass reads p, g, m, v
+// and the two shadows and writes p, m, v, both shadows and g = 0: 12 streams; every element sees the same fp32 operations in
+// the same order as in the three launches (AdamW contracted like adamw4_kernel in this translation unit, the EMA line
+// uncontracted like elementwise.hip's ema2_kernel), so the results are bit-identical (tests/test_bwd_ops_gpu.py).
+// Elements [0, n_train) take the AdamW update (unless do_step == 0: the reference skips it on a NaN loss but still zeroes
+// the gradients and moves the shadows); [n_train, n_all) are the frozen suffix of the flat buffers.
+__device__ __forceinline__ float ema_lerp(float s, float p, float k) {
+#pragma clang fp contract(off)
+  return s + k * (p - s);
+}
+template <bool TWO>
+__global__ __launch_bounds__(256) void adamw_ema2_zero_kernel(float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m,
+                                                              float4* __restrict__ v, float4* __restrict__ sa, float ka,
+                                                              float4* __restrict__ sb, float kb, long long nt4, long long n4,
+                                                              int do_step, float lr, float beta1, float beta2, float eps, float wd,
+                                                              float bc1, float bc2_sqrt, float grad_scale) {
+  const AdamWConst c = {1.0f - lr * wd, lr / bc1, 1.0f - beta1, 1.0f - beta2, beta2, bc2_sqrt, eps, grad_scale};
+  auto one = [&](float& pp, float gq, float& mm, float& vv) { adamw_one(pp, gq, mm, vv, c); };
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n4; i += 2 * stride) {
+    const long long j = i + stride;
+    const bool two = j < n4;
+    const bool ti = do_step && i < nt4, tj = do_step && two && j < nt4;
+    float4 p0 = p[i], a0 = sa[i], b0, p1, a1, b1, g0, m0, v0, g1, m1, v1;
+    if (TWO) b0 = sb[i];
+    if (ti) { g0 = g[i]; m0 = m[i]; v0 = v[i]; }
+    if (two) { p1 = p[j]; a1 = sa[j]; if (TWO) b1 = sb[j]; }
+    if (tj) { g1 = g[j]; m1 = m[j]; v1 = v[j]; }
+    if (ti) {
+      one(p0.x, g0.x, m0.x, v0.x); one(p0.y, g0.y, m0.y, v0.y); one(p0.z, g0.z, m0.z, v0.z); one(p0.w, g0.w, m0.w, v0.w);
+      p[i] = p0; m[i] = m0; v[i] = v0;
+    }
+    g[i] = zero;
+    a0.x = ema_lerp(a0.x, p0.x, ka); a0.y = ema_lerp(a0.y, p0.y, ka); a0.z = ema_lerp(a0.z, p0.z, ka); a0.w = ema_lerp(a0.w, p0.w, ka);
+    sa[i] = a0;
+    if (TWO) {
+      b0.x = ema_lerp(b0.x, p0.x, kb); b0.y = ema_lerp(b0.y, p0.y, kb); b0.z = ema_lerp(b0.z, p0.z, kb); b0.w = ema_lerp(b0.w, p0.w, kb);
+      sb[i] = b0;
+    }
+    if (two) {
+      if (tj) {
+        one(p1.x, g1.x, m1.x, v1.x); one(p1.y, g1.y, m1.y, v1.y); one(p1.z, g1.z, m1.z, v1.z); one(p1.w, g1.w, m1.w, v1.w);
+        p[j] = p1; m[j] = m1; v[j] = v1;
+      }
+      g[j] = zero;
+      a1.x = ema_lerp(a1.x, p1.x, ka); a1.y = ema_lerp(a1.y, p1.y, ka); a1.z = ema_lerp(a1.z, p1.z, ka); a1.w = ema_lerp(a1.w, p1.w, ka);
+      sa[j] = a1;
+      if (TWO) {
+        b1.x = ema_lerp(b1.x, p1.x, kb); b1.y = ema_lerp(b1.y, p1.y, kb); b1.z = ema_lerp(b1.z, p1.z, kb); b1.w = ema_lerp(b1.w, p1.w, kb);
+        sb[j] = b1;
+      }
+    }
+  }
+}
+extern "C" ctta_status ctta_adamw_ema2_zero(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n_train,
+                                            int64_t n_all, float* shadow_a, double decay_a, float* shadow_b, double decay_b,
+                                            int do_step, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                            int step, float grad_scale, void* stream) {
+  CTTA_REQUIRE(param && grad && exp_avg && exp_avg_sq && shadow_a && step >= 1, "adamw_ema2_zero: bad arguments");
+  CTTA_REQUIRE(n_train >= 0 && n_train <= n_all && n_train % 4 == 0 && n_all % 4 == 0,
+               "adamw_ema2_zero: n_train=%lld / n_all=%lld must be multiples of 4 with n_train <= n_all", (long long)n_train, (long long)n_all);
+  CTTA_REQUIRE(decay_a >= 0.0 && decay_a <= 1.0 && decay_b >= 0.0 && decay_b <= 1.0, "adamw_ema2_zero: decay outside [0,1]");
+  CTTA_REQUIRE((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)shadow_a | (uintptr_t)shadow_b) & 15) == 0,
+               "adamw_ema2_zero: buffers must be 16-byte aligned");
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  const float ka = (float)(1.0 - decay_a), kb = (float)(1.0 - decay_b);
+  const long long n4 = n_all / 4, nt4 = n_train / 4;
+  if (n4 == 0) return CTTA_OK;
+  const dim3 grid(grid1d(n4, 256, 2048)), block(256);
+  if (shadow_b)
+    hipLaunchKernelGGL(adamw_ema2_zero_kernel<true>, grid, block, 0, (hipStream_t)stream, (float4*)param, (float4*)grad, (float4*)exp_avg,
+                       (float4*)exp_avg_sq, (float4*)shadow_a, ka, (float4*)shadow_b, kb, nt4, n4, do_step, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2s, grad_scale);
+  else
+    hipLaunchKernelGGL(adamw_ema2_zero_kernel<false>, grid, block, 0, (hipStream_t)stream, (float4*)param, (float4*)grad, (float4*)exp_avg,
+                       (float4*)exp_avg_sq, (float4*)shadow_a, ka, (float4*)nullptr, 0.f, nt4, n4, do_step, lr, beta1, beta2, eps,
+                       weight_decay, bc1, bc2s, grad_scale);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
 extern "C" ctta_status ctta_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                        float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                                        float grad_scale, void* stream) {

@@ -96,7 +96,6 @@ enum CttaOption {
   CTTA_OPT_SPLITK,             // K decomposition of deep thin launches: two-pass split-K / stream-K (default 1; 0: one tile per workgroup, whole K)
   CTTA_OPT_STREAMK,            // stream-K (one persistent launch, in-launch fold) where the rules choose it (default 1); 0: two-pass split-K only
   CTTA_OPT_STREAMK_GRID,       // tuning: workgroups of a stream-K launch (0 = one per CU slot)
-  CTTA_OPT_MF32,               // the 128x64-per-wave tiles on v_mfma_f32_32x32x16_bf16 where the rules choose them (default 1)
   CTTA_OPT_WGRAD_STREAM,       // weight-gradient launches on the handle's side stream (default 1); read per backward call
   CTTA_OPT_GN_FUSE,            // GroupNorm statistics from the producing convolution's epilogue (default 1)
   CTTA_OPT_FUSED_RES,          // HiFi-GAN ResBlock units as fused pair kernels (default 1)

@@ -49,7 +49,6 @@ struct ConvParams {
   int epi_fast;      // straight-line wide-store epilogue (bias / rowvec / residual / LeakyReLU / second output)
   int epi_act;       // ... with alpha != 1 or a LeakyReLU (the ACT instantiations)
   int epi_fast_geglu;
-  int epi_barrier;   // debug: workgroup barriers between the staging write and read-back of the wide-store epilogue
   int plain_out;   // destination element (m, n) sits at m*ldc + n (no per-batch stride, offset or limit)
   // GroupNorm statistics of the OUTPUT tensor from the epilogue (wide-store path only): every workgroup writes
   // (sum, sum of squares) of its BM x BN tile per channel group to gn_part[((b * gn_nchunk + chunk) * gn_G + g) * 2],
@@ -58,16 +57,17 @@ struct ConvParams {
   int gn_cpg, gn_G, gn_hw, gn_nchunk;
   // Stream-K (conv_gemm_sk_kernel: ONE persistent launch of <= one workgroup per CU slot, groups == 1): the (output tile,
   // K step) items -- tile-major, sk_tiles * nk of them -- are cut into gridDim.x equal contiguous ranges.  A workgroup whose
-  // range starts inside a tile writes that tile's partial accumulators (fp32, accumulator layout: fragment f of thread t at
-  // float4 index f * threads + t) to sk_slots + id * BM * BN and raises sk_hdr[SK_FLAGS + id]; the workgroup that holds the
-  // tile's FIRST K step adds the partials of the ids behind it in id (= K) order and runs the fused epilogue: the summation
-  // order is fixed by the decomposition, never by arrival.  sk_hdr[0..3] = {start ticket, finished count, epoch, timeouts}:
+  // range starts inside a tile writes that tile's partial sums (fp32 rows, [BM][BN]) to slot id of sk_slots and raises
+  // sk_hdr[SK_FLAGS + id]; the workgroup that holds the tile's FIRST K step writes its own part to slot gridDim.x + id, then
+  // adds the parts of the ids behind it in id (= K) order and runs the fused epilogue: the summation order is fixed by the
+  // decomposition, never by arrival.  sk_hdr[0..3] = {start ticket, finished count, epoch, timeouts}:
   // logical id = gridDim.x - 1 - ticket, so an owner only ever waits for workgroups that STARTED before it (forward progress
   // whatever is resident); flags carry epoch + 1, the last workgroup to finish zeroes the two counters and advances the epoch
   // (no memset node per launch; the header is zeroed once where the workspace is allocated).
   unsigned* sk_hdr;
   float* sk_slots;
   int sk_tiles, sk_m_inner;   // sk_m_inner != 0: tile = nt * m_tiles + mt (row tiles innermost), else mt * n_tiles + nt
+  int sk_chunks;              // 8, 4, 2 or 1 XCD chunks (conv_gemm_sk_kernel); gridDim.x is a multiple of it
 };
 constexpr int SK_FLAGS = 64;            // first flag word of the stream-K header
 constexpr int SK_HDR_WORDS = 2048;      // header words in front of the partial slots (8 KB)

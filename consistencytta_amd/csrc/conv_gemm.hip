@@ -134,9 +134,6 @@ static void launch_halo(const ConvParams& p, int batch, hipStream_t s) {
 // (profiles/): 1.7x over the generic kernel at C=32; at C=64 an LDS weight ring only ties and at C=128 the
 // activation tile limits the CU to one workgroup and loses 2x, so those widths stay on conv_gemm_kernel.
 static bool halo_eligible(const ctta_conv_desc* d, const ConvParams& p, int groups) {
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("CTTA_HALO"); env = (e && e[0] == '0') ? 0 : 1; }
-  if (!env) return false;
   const int C = p.c0;
   if (C != 32 || p.c1 != 0 || d->n != C || groups != 1) return false;
   if (d->kh != 1 || d->hi != 1 || d->ho != 1 || d->stride_w != 1 || d->upsample || d->in_act) return false;
@@ -226,7 +223,7 @@ struct Variant {
   int wm, wn;
   int mode;
   int stages;
-  int kind;     // 0: 16x16x32 MFMA, one tile per workgroup; 1: 32x32x16 MFMA; 2 / 3: stream-K (persistent) on 16x16x32 / 32x32x16
+  int kind;     // 0: one tile per workgroup; 2: stream-K (one persistent launch)
   void (*launch)(const ConvParams&, dim3, hipStream_t);
   ctta_status (*prepare)();
 };
@@ -279,14 +276,9 @@ static const Variant kVariants[] = {
     VARIANT(128, 128, 64, 2, 2, 2, 3),  // 38  workgroup is ~1.1 us per K step whatever the tile)
     VARIANT(128, 64, 64, 2, 2, 2, 3),   // 39
     VARIANT(128, 128, 64, 2, 2, 2, 4),  // 40
-    VARIANT_K(256, 256, 64, 2, 4, 2, 2, 1, "_mf32"),   // 41  twins of 29 / 31 / 36 on v_mfma_f32_32x32x16_bf16
-    VARIANT_K(256, 128, 64, 2, 2, 2, 2, 1, "_mf32"),   // 42
-    VARIANT_K(512, 128, 64, 4, 2, 2, 2, 1, "_mf32"),   // 43
-    VARIANT_K(256, 256, 64, 2, 4, 2, 2, 2, "_sk"),     // 44  stream-K (one persistent launch, in-launch fold)
-    VARIANT_K(256, 128, 64, 2, 2, 2, 2, 2, "_sk"),     // 45
-    VARIANT_K(128, 128, 64, 2, 2, 2, 2, 2, "_sk"),     // 46
-    VARIANT_K(256, 256, 64, 2, 4, 2, 2, 3, "_sk_mf32"),   // 47
-    VARIANT_K(256, 128, 64, 2, 2, 2, 2, 3, "_sk_mf32"),   // 48
+    VARIANT_K(256, 256, 64, 2, 4, 2, 2, 2, "_sk"),     // 41  stream-K (one persistent launch, in-launch fold): twins of 29 / 31 / 17
+    VARIANT_K(256, 128, 64, 2, 2, 2, 2, 2, "_sk"),     // 42
+    VARIANT_K(128, 128, 64, 2, 2, 2, 2, 2, "_sk"),     // 43
 };
 static const int kNumVariants = sizeof(kVariants) / sizeof(kVariants[0]);
 
@@ -311,61 +303,25 @@ static const bf16_t* zero_page() {   // 256 zero bytes per device (source of out
 }
 
 static bool xcd_default() { return ctta_opt(CTTA_OPT_XCD) != 0; }
-static bool tile_rules_r5() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_TILE_RULES_R5"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
-static int splitk_min_nk() {   // K tiles from which a launch with few output tiles is split over K (CTTA_SPLITK_MIN_NK, tuning knob)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_SPLITK_MIN_NK"); v = e ? atoi(e) : 32; }
-  return v;
-}
-static int xcd_slab_default() {   // CTTA_XCD_SLAB: 0 = off, 1 (default) = split-K launches + few-row-tile launches, 2 = split-K launches only
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_XCD_SLAB"); v = e ? atoi(e) : 1; }
-  return v;
-}
-static bool wide_store_default() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_WIDE_STORE"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
+// Settled constants (their A/B switches went with round 6; the sweeps and A/Bs that fixed them are in profiles/ and LABNOTES.md)
+static constexpr int kSplitkMinNk = 32;       // K tiles from which a launch with few output tiles is split over K
+static constexpr int kSplitkTiles = 192;      // ... "few": fewer output tiles than this
+static constexpr int kSplitkTarget = 512;     // workgroups a split launch aims for
+static constexpr int kSplitkMax = 8;          // most splits
+static constexpr int kSplitkMinSteps = 8;     // K tiles every split keeps at least
+static constexpr int kBigTileMinK = 512;      // the 256x256x64 tile from this K up (straight-line epilogue, profiles/sweep_r02*.json)
 static thread_local unsigned long long* t_stamps = nullptr;
 extern "C" void ctta_conv_debug_stamps(void* buf) { t_stamps = (unsigned long long*)buf; }
 unsigned long long* ctta_debug_stamps_current() { return t_stamps; }
 static thread_local int t_no_splitk = 0;
 extern "C" void ctta_conv_suppress_splitk(int on) { t_no_splitk = on ? 1 : 0; }
 static bool splitk_default() { return ctta_opt(CTTA_OPT_SPLITK) != 0 && !t_no_splitk; }
-static bool epi_fast_default() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_EPI_FAST"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
-static bool epi_barrier_default() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_EPI_BARRIER"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v != 0;
-}
-static bool glds_default() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CTTA_GLDS");
-    v = e ? atoi(e) : 1;
-  }
-  return v != 0;
-}
 
 // Tile choice from the on-device sweep (tools/sweep_conv.py, profiles/sweep_r01*.json); ids index
 // kVariants (1-based).  Returns a register-staged id (1..8); the caller adds +8 / +16 for the
 // direct-to-LDS twins.  kBigTile (256x256x64, 8 waves of 128x64) is chosen separately: it halves the
 // L1->LDS bytes per FLOP, which is what bounds the 128-wide tiles (64 B/clk/CU vs 512 MFMA-cycles).
 static const int kBigTile = 29;
-static bool tile_rules_r3() {   // CTTA_TILE_RULES=2: round 2's tile choice (A/B switch for the round-3 rules)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_TILE_RULES"); v = (e && e[0] == '2') ? 0 : 1; }
-  return v != 0;
-}
 static bool want_big_tile(long long M, int N, long long K, int groups) {
   const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * groups;
   // one workgroup per CU: 288 tiles (the distillation teacher's batch 18 at level 0) are two rounds of the 256 CUs with the
@@ -375,10 +331,8 @@ static bool want_big_tile(long long M, int N, long long K, int groups) {
   const long long t_cut = (M / 256) * ((N + 255) / 256) * groups;
   if (M % 256 != 0 && groups == 1 && t_cut >= 1 && (t_cut + 255) / 256 < (t256 + 255) / 256) tq = t_cut;
   const long long rounds = (tq + 255) / 256;
-  const bool fills = !tile_rules_r3() || tq >= 1024 || tq * 10 >= rounds * 256 * 7;
-  static int min_k = -1;    // CTTA_BIG_TILE_MIN_K (tuning knob; default 512)
-  if (min_k < 0) { const char* e = getenv("CTTA_BIG_TILE_MIN_K"); min_k = e ? atoi(e) : 512; }
-  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= min_k && t256 >= 192 && fills;   // (K >= 512 since the straight-line epilogue, profiles/sweep_r02*.json)
+  const bool fills = tq >= 1024 || tq * 10 >= rounds * 256 * 7;
+  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= kBigTileMinK && t256 >= 192 && fills;
 }
 static int pick_variant(long long M, int N, long long K, int groups) {
   if (N <= 32) {                                           // 256x32; few row tiles (the per-sample cross-attention
@@ -392,9 +346,9 @@ static int pick_variant(long long M, int N, long long K, int groups) {
   // linears (M = 8192, t128 = 512: 736-824 vs 588-682 TFLOP/s on the thin-grid tile) and the Heun teacher's batch 16 at
   // level 1 (t128 = 512: 1024 vs 740, 1109 vs 786, 928 vs 665) take it; batch 18 (t128 = 576 = 2.25 tiles per slot pair)
   // and batch 9 (288) do NOT: 723 vs 866, 665 vs 768 -- profiles/sweep_r03.txt, u32 / t16 / t18 rows.
-  if (tile_rules_r3() && t128 >= 400 && t128 < 1024 && K >= 512 && t128 * 100 >= ((t128 + 511) / 512) * 512 * 85) return 1;
+  if (t128 >= 400 && t128 < 1024 && K >= 512 && t128 * 100 >= ((t128 + 511) / 512) * 512 * 85) return 1;
   if (t128 < 1024 && (K < 4096 || t128 < 400 || N <= 512)) return 6;                    // thin grids (distillation micro-batch): 64x128x64 doubles the workgroups
-  if (tile_rules_r3() && t128 < 1536 && K >= 1024 && N <= 512) return 6;      // batch 18 at level 0 (M = 73728, N = 256: 1152 tiles): 828-910 vs 730 on 128x128x32
+  if (t128 < 1536 && K >= 1024 && N <= 512) return 6;      // batch 18 at level 0 (M = 73728, N = 256: 1152 tiles): 828-910 vs 730 on 128x128x32
   if (K >= 4096) return N >= 256 ? 1 : 6;                  // 128x128x64 / 64x128x64
   if (K > 1536) return M >= 400000 ? 6 : 2;                // 64x128x64 / 128x128x32
   return N >= 256 ? 2 : 6;                                 // 128x128x32 / 64x128x64 (re-swept with the wide-store epilogue)
@@ -466,20 +420,17 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
                        d->stride_w == 1 && d->dil_h == 1 && d->dil_w == 1));
   };
   p.plain_out = (d->out_limit == 0 && d->out_offset == 0 && p.obs == (long long)p.howo * d->ldc) ? 1 : 0;
-  p.wide_store = (wide_store_default() && !d->out_f32 && !scalar_store && d->ldc % 4 == 0 && d->n % 4 == 0 &&
+  p.wide_store = (!d->out_f32 && !scalar_store && d->ldc % 4 == 0 && d->n % 4 == 0 &&
                   (p.plain_out || (!geglu && p.obs % 4 == 0 && d->out_offset % 4 == 0 && d->out_limit % 4 == 0)) &&
                   (!d->res || d->res_ld % 4 == 0) && (!d->rowvec || d->rowvec_ld % 4 == 0))
                      ? 1 : 0;
   {
-    static int wf = -1;   // CTTA_WIDE_F32=0: the narrow fp32 stores of rounds 1-3 (A/B switch)
-    if (wf < 0) { const char* e = getenv("CTTA_WIDE_F32"); wf = (e && e[0] == '0') ? 0 : 1; }
-    p.wide_f32 = (wf && d->out_f32 && !scalar_store && d->ldc % 4 == 0 && d->n % 4 == 0 && p.plain_out && !d->res && !d->accumulate &&
+    p.wide_f32 = (d->out_f32 && !scalar_store && d->ldc % 4 == 0 && d->n % 4 == 0 && p.plain_out && !d->res && !d->accumulate &&
                   !d->out2 && d->out_act == 0 && d->alpha == 1.0f && !d->rowvec && !d->bias_m && !geglu && !d->gn_part) ? 1 : 0;
   }
-  p.epi_barrier = epi_barrier_default() ? 1 : 0;
-  p.epi_fast_geglu = (epi_fast_default() && !p.epi_barrier && geglu && p.wide_store && p.plain_out &&
+  p.epi_fast_geglu = (geglu && p.wide_store && p.plain_out &&
                       M * (long long)d->ldc * 2 < 0x7FFFFF00LL) ? 1 : 0;
-  p.epi_fast = (epi_fast_default() && !p.epi_barrier && p.wide_store && M * (long long)d->ldc * 2 < 0x7FFFFF00LL &&
+  p.epi_fast = (p.wide_store && M * (long long)d->ldc * 2 < 0x7FFFFF00LL &&
                 (!d->res || M * (long long)d->res_ld * 2 < 0x7FFFFF00LL) && p.plain_out && !geglu && !d->bias_m && !(d->gn_part && (d->accumulate || d->out2)) && !(d->accumulate && d->out2) &&
                 (d->out_act == 0 || (d->out_act == 3 && d->out_slope >= 0.f && d->out_slope <= 1.f)) &&
                 (!d->out2 || (d->res && d->out2_slope >= 0.f && d->out2_slope <= 1.f))) ? 1 : 0;
@@ -497,7 +448,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   }
   bool thin_ring = false;
   if (vid <= 0 || vid > kNumVariants) {
-    if (!d->in_act && !geglu && glds_default() && want_big_tile(M, d->n, K, groups) && fast_ok(kVariants[kBigTile - 1].bk)) {
+    if (!d->in_act && !geglu && want_big_tile(M, d->n, K, groups) && fast_ok(kVariants[kBigTile - 1].bk)) {
       vid = kBigTile;
       // (round 1 sent short-K launches with a residual / second output / accumulate to the 256x128x32 tile because the
       // big tile's rolled epilogue could not hide behind another workgroup; with the straight-line epilogue the big tile
@@ -508,7 +459,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       // keeps its accumulators in registers); the direct epilogue only exists in the <= 8-fragment tiles (64x128x64)
       // (round 3, after the GELU rewrite: 256x128x32 with 8 waves of 64x64 wins from K = 512 up and on the batch-9 / 16
       // shapes -- 796 vs 727, 919 vs 795, 625 vs 591 TFLOP/s, profiles/sweep_r03.txt; the K = 256 batch-32 launch stays)
-      if (geglu) vid = !p.wide_store ? 6 : (tile_rules_r3() && (K >= 512 || M < 100000) && fast_ok(32) && glds_default()) ? 28 : 2;
+      if (geglu) vid = !p.wide_store ? 6 : ((K >= 512 || M < 100000) && fast_ok(32)) ? 28 : 2;
       // deep and narrow (few 128x128 tiles, long K): the 128x128 tile with split-K beats small tiles that only
       // exist to create workgroups (measured: M=1152, N=1024, K=9216 at 176 TFLOP/s on 64x64 tiles)
       const long long t128 = ((M + 127) / 128) * ((d->n + 127) / 128);
@@ -517,26 +468,24 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
         // M = 1024 / 1152 (teacher batches, level 3): 64x128x64 + split-K 502-523 vs 414-450 TFLOP/s on 128x128x64;
         // M = 576 (batch 9, level 3): 128x64x64 346 vs 295
       {
-        static int m64 = -1;     // rows up to which the 64x128x64 tile (+ split-K, + the 3-stage ring when it fills) is taken
-        if (m64 < 0) { const char* e = getenv("CTTA_SPLITK_M64"); m64 = e ? atoi(e) : 1280; }
         // round 5 (profiles/sweep_r05_thin.txt, weights cold): a K step of these launches takes ~1750 clocks whatever the
         // tile (one K tile in flight per workgroup, ~2 workgroups per CU: tools/thin_timeline.py), so the tile that does
         // the most work per step while split-K still fills one round of the CUs wins: M <= 640: 64x128x64 with the 3-stage
         // ring and 7 splits (504 workgroups on 512 slots) 373 vs 304 TFLOP/s on 128x64x64; M <= 1280: 128x128x64 with 7
         // splits 571 vs 420 on 64x128x64
-        thin_ring = tile_rules_r5() && M <= 640;
-        vid = !tile_rules_r3() ? 1 : tile_rules_r5() ? (M <= 640 ? 6 : 1) : M <= 640 ? 8 : M <= m64 ? 6 : 1;
+        thin_ring = M <= 640;
+        vid = M <= 640 ? 6 : 1;
       }
-      if (!d->in_act && glds_default() && vid <= 8) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
+      if (!d->in_act && vid <= 8) vid += fast_ok(kVariants[vid - 1].bk) ? 16 : 8;
       // 64 < N <= 128 with enough rows: the 256x128x32 tile (8 waves of 64x64) stages 25 % fewer bytes per FLOP than
       // 128x128 / 64x128 and, with the wide-store epilogue, wins from K = 384 up (sweep: +12..22 %)
       const long long t28 = ((M + 255) / 256) * groups;
-      if (!geglu && !d->in_act && glds_default() && d->n > 64 && d->n <= 128 && K >= 384 && t28 >= 512 && fast_ok(32) &&
+      if (!geglu && !d->in_act && d->n > 64 && d->n <= 128 && K >= 384 && t28 >= 512 && fast_ok(32) &&
           vid != 1 + 16) {
         vid = 28;
         // ... and from K = 1024 up with >= 2 rounds of 512-row tiles: 512x128x64 (8 waves of 128x64 = the big tile's wave
         // shape, all 160 KB of LDS): 978 vs 937-959 (K = 1152), 1074 vs 961 (K = 2304), 895 vs 806 (k = 11 conv1d) TFLOP/s
-        if (tile_rules_r3() && K >= 1024 && (M + 511) / 512 * groups >= 512 && fast_ok(64)) vid = 36;
+        if (K >= 1024 && (M + 511) / 512 * groups >= 512 && fast_ok(64)) vid = 36;
       }
     }
   }
@@ -545,16 +494,12 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
       // arrive cold from HBM, 1.3 us per K step with one tile in flight).  Teacher loop at batch 16 (M = 4096 x N = 1024:
       // 512 workgroups; M = 16384 x N = 512: 1024): 67.7 -> 70.1 U-Net queries/s.  Batch 9 / 18 (576, 1152 workgroups: 1.1 and
       // 2.25 rounds of 512 slots where the 2-stage tile has 768) lose 2.3 ms of the distillation step with it, so the rule
-      // looks at the round fill, like the tile rules above (A/B of round 3: tools/r3_probe26.sh; CTTA_THIN_RING=0: off).
-    static int ring = -1;
-    if (ring < 0) { const char* e = getenv("CTTA_THIN_RING"); ring = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : 1; }
+      // looks at the round fill, like the tile rules above (A/B of round 3).
     // (the same move for the 128x128x64 tile -- 128x128x32 with a 3-stage ring, 48 KB -- measured slower at batch 32 and 16:
     // 25.4 vs 24.8 ms and 14.7 vs 14.5 ms per U-Net forward, tools/r3_probe35.sh)
-    if (ring && tile_rules_r3() && d->tile <= 0 && vid == 22 && K >= 4096 && !geglu) {
+    if (d->tile <= 0 && vid == 22 && K >= 4096 && !geglu) {
       long long wgs = ((M + 63) / 64) * ((d->n + 127) / 128) * groups;
-      static int tg = -1;
-      if (tg < 0) { const char* e = getenv("CTTA_SPLITK_TILES"); tg = e ? atoi(e) : 192; }
-      if (wgs < tg && groups == 1 && splitk_default()) {      // the split-K factor the launch below will choose
+      if (wgs < kSplitkTiles && groups == 1 && splitk_default()) {      // the split-K factor the launch below will choose
         const long long nk = (K + 63) / 64;
         long long sp = 512 / wgs;
         if (sp > 8) sp = 8;
@@ -562,7 +507,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
         if (sp > 1) wgs *= sp;
       }
       const long long rounds = (wgs + 511) / 512;
-      if ((wgs >= 512 && wgs * 100 >= rounds * 512 * 85) || (thin_ring && wgs > 384 && wgs <= 512)) vid = ring == 2 ? 17 : 27;   // CTTA_THIN_RING=2: 128x128x64 instead (A/B)
+      if ((wgs >= 512 && wgs * 100 >= rounds * 512 * 85) || (thin_ring && wgs > 384 && wgs <= 512)) vid = 27;
     }
   }
   CTTA_REQUIRE(!(kVariants[vid - 1].mode != 0 && d->in_act), "conv_gemm: in_act needs a register-staged variant (tile 1..8)");
@@ -588,7 +533,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   if (v.kind >= 2) {
     // Stream-K: one persistent launch, at most one workgroup per CU slot; every workgroup walks an equal share of the (tile, K
     // step) items and the partial tiles are folded inside the launch in K order (ConvParams::sk_hdr, conv_gemm_sk_kernel)
-    CTTA_REQUIRE(groups == 1 && !geglu && !t_stamps, "conv_gemm: stream-K variant %s takes ungrouped launches without the fused GEGLU", v.name);
+    CTTA_REQUIRE(groups == 1 && !geglu, "conv_gemm: stream-K variant %s takes ungrouped launches without the fused GEGLU", v.name);
     size_t wsb = 0;
     bool hdr_ok = false;
     float* wsp = splitk_workspace(&wsb, &hdr_ok);
@@ -602,8 +547,18 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     if (G > SK_MAX_GRID) G = SK_MAX_GRID;
     if (G < 1) G = 1;
     const size_t slot = (size_t)v.bm * v.bn * 4;
-    if ((size_t)SK_HDR_WORDS * 4 + (size_t)G * slot > wsb) G = (long long)((wsb - (size_t)SK_HDR_WORDS * 4) / slot);
+    if ((size_t)SK_HDR_WORDS * 4 + (size_t)2 * G * slot > wsb) G = (long long)((wsb - (size_t)SK_HDR_WORDS * 4) / (2 * slot));   // two slots per workgroup
     CTTA_REQUIRE(G >= 1, "conv_gemm: workspace too small for stream-K");
+    if (G >= 8) G &= ~7LL;      // whole rounds of the 8 XCDs (the chunk arithmetic of the kernel needs it)
+    // XCD chunks (conv_gemm_sk_kernel): the most chunks of whole tiles whose largest is within 6 % of the mean
+    int nch = 1;
+    for (int c = 8; c > 1; c >>= 1) {
+      if (G % 8 != 0 || T < c) continue;
+      const long long big = (T + c - 1) / c;
+      if (big * c * 100 <= T * 106 && (T / c) * p.nk >= 4 * (G / c)) { nch = c; break; }
+    }
+    if (xcd_default() == false) nch = 1;
+    p.sk_chunks = nch;
     p.m_tiles = (int)grid.x; p.n_tiles = (int)grid.y; p.sk_tiles = (int)T;
     p.sk_m_inner = w_bytes > x_bytes ? 1 : 0;       // weight-dominated: the row tiles of one weight slab run next to each other
     p.sk_hdr = reinterpret_cast<unsigned*>(wsp);
@@ -634,20 +589,13 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   int splits = 1;
   float* ws = nullptr;
   size_t ws_bytes = 0;
-  static int tiles_gate = -1;   // launches with fewer tiles than this are split over K (CTTA_SPLITK_TILES, tuning knob)
-  if (tiles_gate < 0) { const char* e = getenv("CTTA_SPLITK_TILES"); tiles_gate = e ? atoi(e) : 192; }
   if (splitk_default() && groups == 1 && !scalar_store && !geglu && d->out_limit == 0 && d->out_offset == 0 &&
-      tiles < tiles_gate && p.nk >= splitk_min_nk() && (ws = splitk_workspace(&ws_bytes)) != nullptr &&
+      tiles < kSplitkTiles && p.nk >= kSplitkMinNk && (ws = splitk_workspace(&ws_bytes)) != nullptr &&
       ws_bytes > (size_t)SK_HDR_WORDS * 4) {
     ws += SK_HDR_WORDS; ws_bytes -= (size_t)SK_HDR_WORDS * 4;       // the stream-K header stays untouched
-    static int target = -1, cap = -1;   // tuning knobs: workgroups aimed for / most splits
-    if (target < 0) { const char* e = getenv("CTTA_SPLITK_TARGET"); target = e ? atoi(e) : 512; }
-    if (cap < 0) { const char* e = getenv("CTTA_SPLITK_MAX"); cap = e ? atoi(e) : 8; }
-    splits = (int)(target / tiles);
-    if (splits > cap) splits = cap;
-    static int min_steps = -1;   // K tiles every split keeps at least (CTTA_SPLITK_MIN_STEPS)
-    if (min_steps < 0) { const char* e = getenv("CTTA_SPLITK_MIN_STEPS"); min_steps = e ? atoi(e) : 8; if (min_steps < 1) min_steps = 1; }
-    if (splits > p.nk / min_steps) splits = p.nk / min_steps;
+    splits = (int)(kSplitkTarget / tiles);
+    if (splits > kSplitkMax) splits = kSplitkMax;
+    if (splits > p.nk / kSplitkMinSteps) splits = p.nk / kSplitkMinSteps;
     if (splits < 1) splits = 1;
     const int ld = (d->n + 3) / 4 * 4;
     if ((long long)splits * M * ld * 4 > (long long)ws_bytes) splits = 1;
@@ -660,18 +608,16 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   // of two half-idle workgroups, plus ~16 small workgroups.
   int tail_rows = 0;
   {
-    static int tail_env = -1;
-    if (tail_env < 0) { const char* e = getenv("CTTA_TAIL_SPLIT"); tail_env = (e && e[0] == '0') ? 0 : 1; }
     const long long slots = 256LL * (vid == 28 ? 2 : 1);
     const long long t_all = (long long)grid.x * grid.y, t_cut = (long long)(grid.x - 1) * grid.y;
-    if (tail_env && d->tile <= 0 && v.bm == 256 && v.mode != 0 && splits == 1 && groups == 1 && M % 256 != 0 && grid.x > 1 &&
+    if (d->tile <= 0 && v.bm == 256 && v.mode != 0 && splits == 1 && groups == 1 && M % 256 != 0 && grid.x > 1 &&
         !geglu && !d->gn_part && !t_stamps && (t_all + slots - 1) / slots > (t_cut + slots - 1) / slots) {
       tail_rows = (int)(M % 256);
       grid.x -= 1;
     }
   }
   // (launches whose weights outweigh their activations take the weight-slab mapping below instead, whatever their row tiles)
-  const bool slab_pref = xcd_slab_default() == 1 && groups == 1 && grid.y >= 2 && w_bytes > x_bytes && tail_rows == 0;
+  const bool slab_pref = groups == 1 && grid.y >= 2 && w_bytes > x_bytes && tail_rows == 0;
   if (splits == 1 && groups == 1 && xcd_default() && grid.x >= 64 && !slab_pref) {
     p.m_tiles = (int)grid.x; p.n_tiles = (int)grid.y;
     p.xcd_per = (p.m_tiles + 7) / 8;
@@ -698,9 +644,9 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   // M-range mapping above does not take (grid.x < 64) when the weights outweigh the activations and there are slabs enough
   // to give every XCD its own.
   bool slab = false;
-  if (groups == 1 && xcd_default() && xcd_slab_default() > 0 && p.xcd_per == 0) {
+  if (groups == 1 && xcd_default() && p.xcd_per == 0) {
     if (splits > 1) slab = true;
-    else if (xcd_slab_default() == 1 && grid.y >= 2 && (long long)grid.x * grid.y >= 16 && w_bytes > x_bytes && tail_rows == 0) slab = true;
+    else if (grid.y >= 2 && (long long)grid.x * grid.y >= 16 && w_bytes > x_bytes && tail_rows == 0) slab = true;
   }
   if (slab && splits == 1) {
     p.m_tiles = (int)grid.x; p.n_tiles = (int)grid.y;
@@ -722,8 +668,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     q.bias = nullptr; q.bias_m = nullptr; q.rowvec = nullptr; q.res = nullptr; q.out_act = 0; q.alpha = 1.0f;
     q.accumulate = 0; q.out2 = nullptr; q.out = ws; q.ldc = ld; q.out_f32 = 1; q.obs = (long long)p.howo * ld;
     q.wide_store = 0;
-    { static int wf = -1; if (wf < 0) { const char* e = getenv("CTTA_WIDE_F32"); wf = (e && e[0] == '0') ? 0 : 1; }
-      q.wide_f32 = (wf && conv_wide_f32_ok(v.bm, v.bn, v.bk, v.wm, v.wn, v.mode, v.stages)) ? 1 : 0; }
+    q.wide_f32 = conv_wide_f32_ok(v.bm, v.bn, v.bk, v.wm, v.wn, v.mode, v.stages) ? 1 : 0;
     q.ogs = (long long)M * ld;
     grid.z = (unsigned)splits;
     if (slab) grid = dim3((unsigned)(8 * q.slab_per), 1, 1);

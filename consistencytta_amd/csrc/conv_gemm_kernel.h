@@ -218,17 +218,19 @@ __device__ __forceinline__ void epilogue_geglu(const ConvParams& p, const f32x4_
 // orders a wave's own LDS writes before its LDS reads (other lanes of the SAME wave) without a workgroup barrier
 #define WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // One (output tile, K range) segment of a stream-K workgroup (ConvParams::sk_hdr).  mode 0: the whole K walk (plain
 // epilogue); 1: a later part of the tile's K walk -> the accumulators go to this workgroup's slot; 2: the first part ->
 // the partials of ids first_partner .. first_partner + n_partners - 1 are added in that order, then the epilogue.
 struct SkSeg { int kt_begin, nk, mode, id, first_partner, n_partners; unsigned tag; };
-// One output tile: K walk + fused epilogue.  MF = 16: v_mfma_f32_16x16x32_bf16 (a fragment = 16 pixels x 16 channels, a
-// lane holds 4 channels of one pixel); MF = 32: v_mfma_f32_32x32x16_bf16 (32 cycles per instruction on a SIMD for twice the
-// FLOPs of a 16-17 cycle 16x16x32: half the MFMA issue slots of a K step, same fragment bytes, same accumulator registers;
-// the 16 accumulator registers of a 32 x 32 block are four "fragments" of 32 pixels x 8 channels, a lane again holding 4
-// consecutive channels of one pixel, so every epilogue below only sees other fragment extents RB x CB).  SK: see SkSeg.
-template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES, int MF, bool SK>
+// One output tile: K walk + fused epilogue on v_mfma_f32_16x16x32_bf16 (a fragment = RB x CB = 16 pixels x 16 channels, a lane
+// holds 4 channels of one pixel).  SK: see SkSeg.
+// (Round 6 built the 128x64-per-wave tiles on v_mfma_f32_32x32x16_bf16 as well -- 32 cycles per instruction for twice the FLOPs
+// of a 16-17 cycle 16x16x32, half the MFMA issue slots, same fragment bytes and accumulator registers; 16 accumulator registers
+// of a 32 x 32 block = four fragments of 32 pixels x 8 channels, LDS key (row >> 1) & 7 for conflict-free 32-row fragment
+// reads; parity-green, no lost wave -- and measured -3..+2.5 % on the 256x256x64 tile, -2..-7 % on 512x128x64, +5 % on the
+// 4-wave 256x128x64 that no rule picks (profiles/sweep_r06_mf32.txt): the loop is not bound by MFMA issue slots.  Removed
+// again; commit d0e0819 holds it.)
+template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES, bool SK>
 __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* smem_raw, const int mt, const int nt, const int zs_,
                                           const SkSeg& sk) {
   constexpr bool GLDS = MODE != 0;
@@ -243,24 +245,23 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
   constexpr int LDK = BK;              // bf16 elements per LDS row: no padding, XOR-swizzled chunks
   // 16-byte chunk c of row r lives at chunk position c ^ swz(r): conflict-free for the 16-lane
   // groups of ds_read_b128 (rows r..r+15 at one logical chunk) and for the row-contiguous writes.
-  // (MF = 32: a fragment read covers 32 rows at one chunk, the 16-lane groups of ds_read_b128 then hold 8 even and 8 odd rows:
-  // the key (row >> 1) & 7 gives each of them its own 16-byte slot of the 256-byte bank window; row & 7 would be 2-way)
-  constexpr int SWZ_SHIFT = (BK == 64 && MF == 16) ? 0 : 1;
-  static_assert(MF == 16 || (MF == 32 && BK == 64 && MODE == 2 && STAGES == 2), "the 32x32x16 loop exists for the BK = 64 descriptor tiles");
+  constexpr int SWZ_SHIFT = (BK == 64) ? 0 : 1;
   constexpr int SWZ_MASK = BK / 8 - 1;
   constexpr int CPR = BK / 8;          // 16-byte chunks per row
   constexpr int RPP = NT / CPR;        // rows staged per pass
   constexpr int XP = BM / RPP;
   constexpr int WP = BN / RPP;
   constexpr int TM = BM / WM, TN = BN / WN;
-  constexpr int RB = MF == 32 ? 32 : 16, CB = MF == 32 ? 8 : 16;     // pixel rows x channels of one accumulator fragment
+  constexpr int RB = 16, CB = 16;     // pixel rows x channels of one accumulator fragment
   constexpr int FM = TM / RB, FN = TN / CB;
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/pass mismatch");
-  static_assert(TM % MF == 0 && TN % MF == 0, "wave tile");
+  static_assert(TM % 16 == 0 && TN % 16 == 0, "wave tile");
 
   bf16_t* Xs = reinterpret_cast<bf16_t*>(smem_raw);               // [STAGES][BM][LDK]
   bf16_t* Ws = Xs + STAGES * BM * LDK;                             // [STAGES][BN][LDK]
   unsigned long long* stamp = nullptr;
+  unsigned long long* skst = nullptr;     // stream-K stamps (tools/sk_timeline.py): 8 words per workgroup id
+  if constexpr (SK) { if (p.stamps) skst = p.stamps + (size_t)sk.id * 8; }
   if (!SK && p.stamps) {
     stamp = p.stamps + ((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 6;
     if (threadIdx.x == 0) { stamp[0] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) | ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32); stamp[1] = __builtin_amdgcn_s_memtime(); }
@@ -535,46 +536,18 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
   };
 
   f32x4_t acc[FN][FM];
-  // MF = 32: the MFMA accumulators proper -- 16 registers per 32 (channels) x 32 (pixels) block; acc[][] is filled from them
-  // behind the main loop (register renaming: every index is a compile-time constant)
-  constexpr int BI = MF == 32 ? TN / 32 : 1, BJ = MF == 32 ? TM / 32 : 1;
-  f32x16_t big[BI][BJ];
-  if constexpr (MF == 32) {
 #pragma unroll
-    for (int i = 0; i < BI; ++i)
+  for (int i = 0; i < FN; ++i)
 #pragma unroll
-      for (int j = 0; j < BJ; ++j)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) big[i][j][e] = 0.f;
-  } else {
-#pragma unroll
-    for (int i = 0; i < FN; ++i)
-#pragma unroll
-      for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  }
+    for (int j = 0; j < FM; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & (RB - 1);
-  const int fchunk = lane / RB;                       // logical 16-byte chunk within a 32-wide (MF = 32: 16-wide) k-slab
+  const int fchunk = lane / RB;                       // logical 16-byte chunk within a 32-wide k-slab
   const int fswz = (frow >> SWZ_SHIFT) & SWZ_MASK;    // tile/frag row offsets are multiples of 16
 
   auto compute_tile = [&](int buf) {
     const bf16_t* xs = Xs + buf * BM * LDK + (wm * TM + frow) * LDK;
     const bf16_t* ws = Ws + buf * BN * LDK + (wn * TN + frow) * LDK;
-    if constexpr (MF == 32) {
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        bf16x8_t af[BI], bfr[BJ];
-        const int koff = (((ks * 2 + fchunk) ^ fswz) & SWZ_MASK) * 8;
-#pragma unroll
-        for (int i = 0; i < BI; ++i) af[i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ws + i * 32 * LDK + koff));
-#pragma unroll
-        for (int j = 0; j < BJ; ++j) bfr[j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xs + j * 32 * LDK + koff));
-#pragma unroll
-        for (int i = 0; i < BI; ++i)
-#pragma unroll
-          for (int j = 0; j < BJ; ++j) big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], big[i][j], 0, 0, 0);
-      }
-    } else
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       bf16x8_t af[FN], bfr[FM];
@@ -643,61 +616,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
     // is waited for behind the barrier at all (in the loop below the compiler sinks the first-half reads under the held
     // MFMAs) -- runs at exactly the same speed with 14 more registers: profiles/ab_r05_xbar3_streaming_schedule.txt.)
     constexpr bool XBAR = FAST && BK == 64 && FM * FN >= CTTA_XBAR_MIN && CTTA_XBAR;
-    if constexpr (XBAR && MF == 32) {
-      // the same schedule on the 32x32x16 MFMA: a K tile is four 16-wide slabs; slabs 2 and 3 are held across the barrier
-      bf16x8_t ha[2][BI], hb[2][BJ];
-      const bf16_t* xs0 = Xs + (wm * TM + frow) * LDK;
-      const bf16_t* ws0 = Ws + (wn * TN + frow) * LDK;
-      int koff[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) koff[ks] = (((ks * 2 + fchunk) ^ fswz) & SWZ_MASK) * 8;
-      for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue_fast(kt_begin + kt + 1, buf ^ 1);
-        if (wave_live) {
-          const bf16_t* xs = xs0 + buf * BM * LDK;
-          const bf16_t* ws = ws0 + buf * BN * LDK;
-          bf16x8_t fa[2][BI], fb[2][BJ];
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < BI; ++i) fa[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ws + i * 32 * LDK + koff[ks]));
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) fb[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xs + j * 32 * LDK + koff[ks]));
-          }
-          if (kt > 0) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-              for (int i = 0; i < BI; ++i)
-#pragma unroll
-                for (int j = 0; j < BJ; ++j) big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[ks][i], hb[ks][j], big[i][j], 0, 0, 0);
-          }
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-            for (int i = 0; i < BI; ++i) ha[ks][i] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(ws + i * 32 * LDK + koff[2 + ks]));
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) hb[ks][j] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xs + j * 32 * LDK + koff[2 + ks]));
-          }
-#pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < BI; ++i)
-#pragma unroll
-              for (int j = 0; j < BJ; ++j) big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][i], fb[ks][j], big[i][j], 0, 0, 0);
-        }
-        __syncthreads();
-      }
-      if (wave_live && nk > 0) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-          for (int i = 0; i < BI; ++i)
-#pragma unroll
-            for (int j = 0; j < BJ; ++j) big[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ha[ks][i], hb[ks][j], big[i][j], 0, 0, 0);
-      }
-    } else if constexpr (XBAR) {
+    if constexpr (XBAR) {
       bf16x8_t ha[FN], hb[FM];
       const bf16_t* xs0 = Xs + (wm * TM + frow) * LDK;
       const bf16_t* ws0 = Ws + (wn * TN + frow) * LDK;
@@ -753,15 +672,6 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
   }
 
   if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
-  if constexpr (MF == 32) {   // register r of a 32x32 block: channel (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), pixel lane & 31
-#pragma unroll
-    for (int i = 0; i < BI; ++i)
-#pragma unroll
-      for (int j = 0; j < BJ; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          acc[i * 4 + q][j] = (f32x4_t){big[i][j][4 * q], big[i][j][4 * q + 1], big[i][j][4 * q + 2], big[i][j][4 * q + 3]};
-  }
   // ---- stream-K (ConvParams::sk_hdr).  A split tile's partial sums travel as fp32 ROWS ([BM][BN] per workgroup slot, written
   // through the LDS transpose of the wide-store epilogues), the OWNER's own part included, and the owner then runs the
   // split-K finish over its tile: rows summed slot by slot in id = K order, fused epilogue per 4 channels (epilogue_store).
@@ -770,6 +680,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
   // runtime loop inside the unrolled epilogue variants costs this compiler 50-240 spilled registers INSIDE the main loop.)
   const int nsub = (lane / RB) * 4;
   if constexpr (SK) {
+    if (skst && threadIdx.x == 0) skst[sk.mode == 1 ? 2 : 4] = __builtin_amdgcn_s_memtime();
     if (sk.mode != 0) {
       // the wave's TM x TN block through its staging rows, out as whole TN * 4-byte row segments, write-through (sc1) so that
       // no release fence has anything to write back; every wave drains its stores, one lane raises the flag
@@ -777,14 +688,17 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
       constexpr int NW = WM * WN;
       constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
       constexpr int RSF = TN * 4 + 16;
-      constexpr int CHR = ((FM % 2 == 0 || RB == 32) && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;
+      constexpr int CHR = (FM % 2 == 0 && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;
       static_assert((size_t)NW * CHR * RSF <= RING && CHR % RB == 0, "stream-K staging does not fit the ring");
       constexpr int CJ = CHR / RB, LPR = TN / 4, RPW = 64 / LPR;
       unsigned char* stg = smem_raw + (size_t)wave * CHR * RSF;
       const int col4 = lane % LPR, prow = lane / LPR;
       const int m_w = m0 + (wave_u / WN) * TM;
       const int rows_in = min(TM, p.M - m_w);            // rows past M are never read back
-      float* obase = p.sk_slots + (size_t)sk.id * (BM * BN) + (size_t)((wave_u / WN) * TM) * BN;
+      // slot id: the part this workgroup CONTRIBUTES to its first tile; slot gridDim.x + id: its own part of the tile it OWNS (a
+      // workgroup can be both, and the owner of its first tile may read slot id long after this workgroup has moved on)
+      const int my_slot = sk.mode == 1 ? sk.id : (int)gridDim.x + sk.id;
+      float* obase = p.sk_slots + (size_t)my_slot * (BM * BN) + (size_t)((wave_u / WN) * TM) * BN;
       const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
           (void*)obase, 0, rows_in > 0 ? (unsigned)rows_in * (unsigned)BN * 4u : 0u, 0x00020000);
       const unsigned ovoff = (unsigned)(prow * BN + wn * TN + col4 * 4) * 4u;
@@ -813,8 +727,10 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
       __syncthreads();
       if (sk.mode == 1) {
         if (tid == 0) __hip_atomic_store(p.sk_hdr + SK_FLAGS + sk.id, sk.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (skst && threadIdx.x == 0) skst[3] = __builtin_amdgcn_s_memtime();
         return;
       }
+      if (skst && threadIdx.x == 0) skst[5] = __builtin_amdgcn_s_memtime();
       // owner: one lane polls the partners' flags (relaxed, bounded), ONE agent-scope acquire (it also drops this CU's stale L1
       // lines of its own slot), then plain loads
       if (tid == 0) {
@@ -827,28 +743,47 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
           }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (skst) skst[6] = __builtin_amdgcn_s_memtime();
       }
       __syncthreads();
+      // The fold streams: per pass a lane holds U float4 of the own slot and of two partners' slots in flight (the accumulators
+      // are dead by now: ~200 free registers); partner c + 1 is requested before partner c is added, partners that do not
+      // exist are read through an empty descriptor (zeros, no traffic): the loop body has no branches, the waits are counted.
+      // (The first form -- 8 loads in flight, one partner at a time behind a wait -- folded at ~14 GB/s per workgroup: 65 of the
+      // 112 us of a 4608 x 1024 x 9216 launch, profiles/sweep_r06_streamk_v1.txt.)
       const int rows = min(BM, p.M - m0);
       const unsigned tile_bytes = (unsigned)rows * BN * 4u;      // loads past the valid rows return zeros (and are dropped below)
-      constexpr int U = 8;                                       // float4s per lane in flight per slot
       constexpr int C4 = BN / 4;
-      const float* own = p.sk_slots + (size_t)sk.id * (BM * BN);
-      const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)own, 0, tile_bytes, 0x00020000);
+      constexpr int U = 8;                                       // float4s per lane and slot in flight (x 3 buffers)
+      auto slot_rsrc = [&](int c) {       // c = 0: own part, 1 .. n_partners: the partners' in K order (ids id + 1 ...), beyond: empty
+        const bool ok = c <= sk.n_partners;
+        const int slot = c == 0 ? (int)gridDim.x + sk.id : (ok ? sk.id + c : 0);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.sk_slots + (size_t)slot * (BM * BN)), 0, ok ? tile_bytes : 0u, 0x00020000);
+      };
       for (int base = 0; base < rows * C4; base += NT * U) {
-        u32x4_t a[U];
+        const int vo = (base + tid) * 16;
+        u32x4_t a[U], t0[U], t1[U];
+        __amdgpu_buffer_rsrc_t r = slot_rsrc(0);
 #pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = __builtin_amdgcn_raw_buffer_load_b128(rs0, (base + u * NT + tid) * 16, 0, 0);
-        for (int c = 0; c < sk.n_partners; ++c) {
-          const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc(
-              (void*)(p.sk_slots + (size_t)(sk.first_partner + c) * (BM * BN)), 0, tile_bytes, 0x00020000);
-          u32x4_t t[U];
+        for (int u = 0; u < U; ++u) a[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
+        r = slot_rsrc(1);
 #pragma unroll
-          for (int u = 0; u < U; ++u) t[u] = __builtin_amdgcn_raw_buffer_load_b128(rsc, (base + u * NT + tid) * 16, 0, 0);
+        for (int u = 0; u < U; ++u) t0[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
+        for (int c = 1; c <= sk.n_partners; c += 2) {
+          r = slot_rsrc(c + 1);
+#pragma unroll
+          for (int u = 0; u < U; ++u) t1[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
 #pragma unroll
           for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) a[u][e] = __float_as_uint(__uint_as_float(a[u][e]) + __uint_as_float(t[u][e]));
+            for (int e = 0; e < 4; ++e) a[u][e] = __float_as_uint(__uint_as_float(a[u][e]) + __uint_as_float(t0[u][e]));
+          r = slot_rsrc(c + 2);
+#pragma unroll
+          for (int u = 0; u < U; ++u) t0[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
+#pragma unroll
+          for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[u][e] = __float_as_uint(__uint_as_float(a[u][e]) + __uint_as_float(t1[u][e]));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -884,7 +819,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
     constexpr int NW = WM * WN;
     constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
     constexpr int RSF = TN * 4 + 16;
-    constexpr int CHR = ((FM % 2 == 0 || RB == 32) && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;
+    constexpr int CHR = (FM % 2 == 0 && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;
     static_assert((size_t)NW * CHR * RSF <= RING && CHR % RB == 0, "wide-store staging does not fit the ring");
     constexpr int CJ = CHR / RB;
     constexpr int LPR = TN / 4, RPW = 64 / LPR;
@@ -933,7 +868,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
     constexpr int NW = WM * WN;
     constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
     constexpr int RSF = TN * 4 + 16;                       // staging row stride (bytes): +16 keeps 16-byte accesses conflict-free
-    constexpr int CHR = ((FM % 2 == 0 || RB == 32) && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;   // rows per chunk
+    constexpr int CHR = (FM % 2 == 0 && (size_t)NW * 32 * RSF <= RING) ? 32 : 16;   // rows per chunk
     static_assert((size_t)NW * CHR * RSF <= RING && CHR % RB == 0, "wide-store staging does not fit the ring");
     constexpr int CJ = CHR / RB;
     constexpr int LPR = TN / 4;                            // lanes per output row (4 channels each)
@@ -945,7 +880,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
     float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias && n_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + n_lane);
     __syncthreads();   // every wave is done with the ring
-    if constexpr (MF == 16 && FM * FN <= 16 && FN % 2 == 0) {
+    if constexpr (FM * FN <= 16 && FN % 2 == 0) {
       if (p.out_act == 4) {   // fused GEGLU: hidden unit hl of the wave's row = value column (hl/16)*32 + hl%16, gate 16 further
         constexpr int LPG = TN / 8, RPG = 64 / LPG;          // lanes per output row (4 hidden units each), rows per pass
         const int h4 = lane % LPG, grow = lane / LPG;
@@ -1005,7 +940,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
               const f32x4_t a = acc[i][j0 + jj];
               *reinterpret_cast<float4*>(stg + (jj * 16 + frow) * RSF + (i * 16 + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
             }
-          if (p.epi_barrier) __syncthreads(); else WAVE_LDS_FENCE();   // wave-private staging rows
+          WAVE_LDS_FENCE();   // wave-private staging rows
 #pragma unroll 2
           for (int r = grow; r < CHR; r += RPG) {
             const int m = m0 + wm * TM + j0 * 16 + r;
@@ -1023,7 +958,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
               *reinterpret_cast<uint2*>(og + (size_t)m * p.ldc) = pk;
             }
           }
-          if (j0 + CJ < FM) { if (p.epi_barrier) __syncthreads(); else WAVE_LDS_FENCE(); }
+          if (j0 + CJ < FM) { WAVE_LDS_FENCE(); }
         }
         return;
       }
@@ -1080,7 +1015,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
           *reinterpret_cast<float4*>(stg + (jj * RB + frow) * RSF + (i * CB + nsub) * 4) = make_float4(a[0], a[1], a[2], a[3]);
         }
       // the staging rows are private to the wave and a wave's LDS operations execute in order: no workgroup barrier
-      if (p.epi_barrier) __syncthreads(); else WAVE_LDS_FENCE();
+      WAVE_LDS_FENCE();
 #pragma unroll 2
       for (int r = prow; r < CHR; r += RPW) {
         const int m = m0 + wm * TM + j0 * RB + r;
@@ -1088,7 +1023,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
           epilogue_wide4(p, *reinterpret_cast<const float4*>(stg + r * RSF + col4 * 16), bias4, m, n_lane, (size_t)g * p.ogs,
                          &gacc);
       }
-      if (j0 + CJ < FM) { if (p.epi_barrier) __syncthreads(); else WAVE_LDS_FENCE(); }
+      if (j0 + CJ < FM) { WAVE_LDS_FENCE(); }
     }
     if (stamp && threadIdx.x == 0) stamp[4] = __builtin_amdgcn_s_memtime();
     if (p.gn_part) gn_partial_store<BM, WM, TN>(p, gacc.x, gacc.y, m0, wm, wn, prow, col4, n_lane, n_ok);
@@ -1096,7 +1031,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
   }
   // fused GEGLU: only compiled into the small-fragment tiles (a longer epilogue on the 16-fragment tiles
   // pushes their accumulators into scratch)
-  if constexpr (MF == 16 && FM * FN <= 8 && FN % 2 == 0) {
+  if constexpr (FM * FN <= 8 && FN % 2 == 0) {
     if (p.out_act == 4) {
 #pragma unroll
       for (int j = 0; j < FM; ++j) {
@@ -1198,18 +1133,10 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(BM, BN, BK, WM, WN, MO
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int mt, nt, zs_;
   if (!conv_block_tile(p, mt, nt, zs_)) return;
-  conv_tile<BM, BN, BK, WM, WN, MODE, STAGES, 16, false>(p, smem_raw, mt, nt, zs_, SkSeg{});
-}
-// the same launch geometry on v_mfma_f32_32x32x16_bf16 (the tiles whose waves own 128 x 64)
-template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES>
-__global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_mf32_kernel(ConvParams p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  int mt, nt, zs_;
-  if (!conv_block_tile(p, mt, nt, zs_)) return;
-  conv_tile<BM, BN, BK, WM, WN, MODE, STAGES, 32, false>(p, smem_raw, mt, nt, zs_, SkSeg{});
+  conv_tile<BM, BN, BK, WM, WN, MODE, STAGES, false>(p, smem_raw, mt, nt, zs_, SkSeg{});
 }
 // Stream-K: one persistent launch (ConvParams::sk_hdr explains the protocol; conv_gemm.hip decides which launches take it).
-template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES, int MF>
+template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_sk_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* bc = reinterpret_cast<unsigned*>(smem_raw);
@@ -1218,32 +1145,56 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_sk_kernel(ConvParam
     bc[1] = __hip_atomic_load(p.sk_hdr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads();
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   const int G = (int)gridDim.x;
-  const int id = G - 1 - (int)__builtin_amdgcn_readfirstlane(bc[0]);     // later start = lower id: partners (higher ids) started earlier
+  const int ticket = (int)__builtin_amdgcn_readfirstlane(bc[0]);
   const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane(bc[1]) + 1u;
-  const long long items = (long long)p.sk_tiles * p.nk;
-  long long a = (long long)id * items / G;
-  const long long b = (long long)(id + 1) * items / G;
+  // XCD chunks.  Workgroups are dispatched round-robin over the 8 XCDs (block b on XCD b % 8: observed, not promised -- only
+  // speed depends on it) and tickets follow dispatch, so the tickets t with (t % 8) / r equal -- r = 8 / sk_chunks XCDs -- form
+  // one CHUNK that owns a contiguous range of whole tiles and walks it stream-K fashion with its G / sk_chunks workgroups: the
+  // tiles of one weight slab / of neighbouring rows meet in the same L2(s), as in the one-tile-per-workgroup launches (without
+  // it every XCD touches every tile at shifted K phases and nothing is re-used: stream-K ran no faster than the same tile
+  // unsplit, profiles/sweep_r06_streamk_v2.txt).  Inside a chunk a LATER ticket gets a LOWER local id, so the partners of an
+  // owner (the ids behind it) always started before it: forward progress whatever is resident.  No tile spans two chunks.
+  const int nch = p.sk_chunks, r = 8 / nch, per = G / nch;
+  const int chunk = (ticket & 7) / r;
+  const int lid = per - 1 - ((ticket >> 3) * r + (ticket & 7) % r);
+  const int id = chunk * per + lid;                                  // slot / flag index
+  const int tile_lo = (int)((long long)chunk * p.sk_tiles / nch), tile_hi = (int)((long long)(chunk + 1) * p.sk_tiles / nch);
+  const long long items = (long long)(tile_hi - tile_lo) * p.nk;     // of this chunk
+  long long a = (long long)lid * items / per;
+  const long long b = (long long)(lid + 1) * items / per;
+  unsigned steps_a = 0, steps_b = 0, tiles_b = 0;
   while (a < b) {
-    const int tile = (int)(a / p.nk);
-    const int k0 = (int)(a - (long long)tile * p.nk);
-    const long long tile_end = (long long)(tile + 1) * p.nk;
-    const int k1 = (int)((b < tile_end ? b : tile_end) - (long long)tile * p.nk);
+    const int tl = (int)(a / p.nk);                                  // tile index inside the chunk
+    const int tile = tile_lo + tl;
+    const int k0 = (int)(a - (long long)tl * p.nk);
+    const long long tile_end = (long long)(tl + 1) * p.nk;
+    const int k1 = (int)((b < tile_end ? b : tile_end) - (long long)tl * p.nk);
     SkSeg sk;
     sk.kt_begin = k0; sk.nk = k1 - k0; sk.id = id; sk.tag = tag; sk.first_partner = id + 1; sk.n_partners = 0;
     sk.mode = k0 > 0 ? 1 : 0;
-    if (k0 == 0 && k1 < p.nk) {     // the workgroup that holds item tile_end - 1 is the last partner
-      const int last = (int)((tile_end * G - 1) / items);
-      sk.mode = 2; sk.n_partners = last - id;
+    if (k0 == 0 && k1 < p.nk) {     // the workgroup of this chunk that holds item tile_end - 1 is the last partner
+      const int last = (int)((tile_end * per - 1) / items);
+      sk.mode = 2; sk.n_partners = last - lid;
     }
     int mt, nt;
     if (p.sk_m_inner) { nt = tile / p.m_tiles; mt = tile - nt * p.m_tiles; }
     else { mt = tile / p.n_tiles; nt = tile - mt * p.n_tiles; }
+    if (sk.mode == 1) steps_a += k1 - k0; else { steps_b += k1 - k0; ++tiles_b; }
     __syncthreads();      // the previous segment's epilogue (and the ticket words) are done with the ring
-    conv_tile<BM, BN, BK, WM, WN, MODE, STAGES, MF, true>(p, smem_raw, mt, nt, 0, sk);
+    conv_tile<BM, BN, BK, WM, WN, MODE, STAGES, true>(p, smem_raw, mt, nt, 0, sk);
     a += k1 - k0;
   }
   __syncthreads();
+  if (p.stamps && threadIdx.x == 0) {      // {hw id | xcc << 32 | K steps as contributor << 36 | as owner << 48 | owned tiles << 60, begin, ..., end}
+    unsigned long long* st = p.stamps + (size_t)id * 8;
+    st[0] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |
+            ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) | ((unsigned long long)(steps_a & 0xfff) << 36) |
+            ((unsigned long long)(steps_b & 0xfff) << 48) | ((unsigned long long)(tiles_b & 0xf) << 60);
+    st[1] = t_begin;
+    st[7] = __builtin_amdgcn_s_memtime();
+  }
   if (threadIdx.x == 0) {
     const unsigned d = __hip_atomic_fetch_add(p.sk_hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (d == (unsigned)G - 1u) {      // every workgroup drew its ticket and read the epoch long ago
@@ -1255,23 +1206,19 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_sk_kernel(ConvParam
 }
 
 // ---- launchers (explicitly instantiated in conv_gemm_i1..9.hip so that the tile variants compile in parallel)
-// KIND 0: conv_gemm_kernel, 1: conv_gemm_mf32_kernel, 2: conv_gemm_sk_kernel (16x16x32), 3: conv_gemm_sk_kernel (32x32x16)
+// KIND 0: conv_gemm_kernel, 2: conv_gemm_sk_kernel
 template <int BM, int BN, int BK, int STAGES>
 static constexpr size_t smem_bytes() { return (size_t)STAGES * (BM + BN) * BK * 2; }
 
 template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES, int KIND>
 static const void* variant_symbol() {
-  if constexpr (KIND == 1) return reinterpret_cast<const void*>(&conv_gemm_mf32_kernel<BM, BN, BK, WM, WN, GLDS, STAGES>);
-  else if constexpr (KIND == 2) return reinterpret_cast<const void*>(&conv_gemm_sk_kernel<BM, BN, BK, WM, WN, GLDS, STAGES, 16>);
-  else if constexpr (KIND == 3) return reinterpret_cast<const void*>(&conv_gemm_sk_kernel<BM, BN, BK, WM, WN, GLDS, STAGES, 32>);
+  if constexpr (KIND == 2) return reinterpret_cast<const void*>(&conv_gemm_sk_kernel<BM, BN, BK, WM, WN, GLDS, STAGES>);
   else return reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES>);
 }
 template <int BM, int BN, int BK, int WM, int WN, int GLDS, int STAGES, int KIND = 0>
 void launch_variant(const ConvParams& p, dim3 grid, hipStream_t s) {
   const size_t smem = smem_bytes<BM, BN, BK, STAGES>();
-  if constexpr (KIND == 1) conv_gemm_mf32_kernel<BM, BN, BK, WM, WN, GLDS, STAGES><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
-  else if constexpr (KIND == 2) conv_gemm_sk_kernel<BM, BN, BK, WM, WN, GLDS, STAGES, 16><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
-  else if constexpr (KIND == 3) conv_gemm_sk_kernel<BM, BN, BK, WM, WN, GLDS, STAGES, 32><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
+  if constexpr (KIND == 2) conv_gemm_sk_kernel<BM, BN, BK, WM, WN, GLDS, STAGES><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
   else conv_gemm_kernel<BM, BN, BK, WM, WN, GLDS, STAGES><<<grid, dim3(64 * WM * WN), smem, s>>>(p);
 }
 
@@ -1334,19 +1281,12 @@ ctta_status prepare_variant() {
   X(128, 128, 64, 2, 2, 2, 3) \
   X(128, 64, 64, 2, 2, 2, 3) \
   X(128, 128, 64, 2, 2, 2, 4)
-// (BM, BN, BK, WM, WN, MODE, STAGES, KIND) of the 32x32x16 and stream-K kernels
+// (BM, BN, BK, WM, WN, MODE, STAGES, KIND) of the stream-K kernels
 #define CTTA_CONV_VARIANTS_9(X) \
-  X(256, 256, 64, 2, 4, 2, 2, 1) \
-  X(256, 128, 64, 2, 2, 2, 2, 1) \
-  X(512, 128, 64, 4, 2, 2, 2, 1)
-#define CTTA_CONV_VARIANTS_10(X) \
   X(256, 256, 64, 2, 4, 2, 2, 2) \
   X(256, 128, 64, 2, 2, 2, 2, 2) \
   X(128, 128, 64, 2, 2, 2, 2, 2)
-#define CTTA_CONV_VARIANTS_11(X) \
-  X(256, 256, 64, 2, 4, 2, 2, 3) \
-  X(256, 128, 64, 2, 2, 2, 2, 3)
-#define CTTA_CONV_VARIANTS_KIND(X) CTTA_CONV_VARIANTS_9(X) CTTA_CONV_VARIANTS_10(X) CTTA_CONV_VARIANTS_11(X)
+#define CTTA_CONV_VARIANTS_KIND(X) CTTA_CONV_VARIANTS_9(X)
 #define CTTA_CONV_INSTANTIATE_K(BM, BN, BK, WM, WN, G, S, KIND)                                      \
   template void launch_variant<BM, BN, BK, WM, WN, G, S, KIND>(const ConvParams&, dim3, hipStream_t); \
   template ctta_status prepare_variant<BM, BN, BK, WM, WN, G, S, KIND>();

@@ -603,9 +603,7 @@ static ctta_status unet_forward_impl(ctta_unet* U, bool dry, const float* sample
   bf16_t* a = A.get<bf16_t>((size_t)B * H * W * c0); ALLOC_OR_FAIL(a);
   float* st_out = nullptr;
   CTTA_TRY(gn(c, U->norm_out, h, a, H * W, cfg.norm_eps, true, &st_out));
-  static int co_direct = -1;   // CTTA_CONV_OUT_DIRECT=1: round 2's direct fp32-weight kernel (290 us at batch 32)
-  if (co_direct < 0) { const char* e = getenv("CTTA_CONV_OUT_DIRECT"); co_direct = (e && e[0] == '1') ? 1 : 0; }
-  if (co_direct || cfg.out_channels % 4 != 0) {
+  if (cfg.out_channels % 4 != 0) {     // the direct fp32-weight kernel of round 2 (290 us at batch 32) for odd channel counts
     RUN(c, ctta_conv_small_n(a, c0, B, H, W, 3, 3, 1, 1, U->conv_out_w, U->conv_out_b, cfg.out_channels, 0,
                              0.f, 0, out, nullptr, stream));
   } else {   // conv_gemm on the matrix pipe (N = 8 of a 32-wide tile), fp32 [pixel][channel] result, then the NCHW hop

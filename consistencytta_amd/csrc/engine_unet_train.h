@@ -111,11 +111,7 @@ static int pick_splits(int64_t M, int R, int N) {
 // slabs[s][n][r] = sum_{m in segment s} dY[m][n] * Q[r][m];  x is the layer input in NHWC (a linear is the 1x1 case
 // with batch=1, hi=rows), dy [M][N] contiguous.  Rows of Q: (channel, tap) then the all-ones row, then `nb`
 // per-sample indicator rows.  Both GEMM operands are made m-contiguous (dY^T, im2col^T).
-static bool wgrad_inplace_on() {   // CTTA_WGRAD_INPLACE=0: every linear back on the transposed-copies route (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_WGRAD_INPLACE"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
+static constexpr bool wgrad_inplace_on() { return true; }   // operands read where they lie (round 5); the copies route serves the geometries it does not
 // Linear layers: both operands are read WHERE THEY LIE by ctta_wgrad_tn on the side stream (no dY^T, no X^T copy).  dY stays
 // valid until the block's wg_join because the backward's arena releases nothing while the side stream is on
 // (unet_backward_begin_impl), and no dY is rewritten in place: the transformer's running token-stream gradient moves to a
@@ -123,11 +119,7 @@ static bool wgrad_inplace_on() {   // CTTA_WGRAD_INPLACE=0: every linear back on
 static bool wgrad_inplace_ok(int taps, bool ups, int stride, int pad, int nb, int C, int N) {
   return wgrad_inplace_on() && taps == 1 && !ups && stride == 1 && pad == 0 && nb == 0 && C % 8 == 0 && N % 8 == 0;
 }
-static bool wgrad_direct_on() {   // CTTA_WGRAD_DIRECT=0: every layer through slab + scatter (A/B switch)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_WGRAD_DIRECT"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
+static constexpr bool wgrad_direct_on() { return true; }    // one-split layers add their tiles straight into the gradient tensors
 // `dm` (may be NULL): the layer's pack map when the caller allows the DIRECT form -- one split: the kernel adds its tiles
 // straight into the gradient tensors and `out->p` comes back NULL (nothing to scatter).
 static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int B, int hi, int wi, bool ups, int ho, int wo,
@@ -144,13 +136,11 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
     int S = 1;
     // 128 x 128 tiles at two workgroups per CU; the level-0 / level-1 linears have 4..16 tiles over 9 216..36 864 rows: up to 64
     // splits of >= 4 chunks (16 splits left a 256 x 256 layer with 64 workgroups walking 36 chunks each: 75 us per launch)
-    static int tn_cap = -1, tn_target = -1;    // CTTA_WGRAD_TN_MAX_SPLITS / CTTA_WGRAD_TN_TARGET (tuning knobs)
+    constexpr int tn_cap = 32, tn_target = 256;    // splits aimed at 256 workgroups, at most 32 (round 5)
     // round 5: 256 workgroups / <= 32 splits instead of 512 / 64.  In a replayed step ONE kernel has the device to itself 79 % of
     // the time (profiles/gaps_distill_pipelined_r05.txt): a launch that fills every CU pushes the other streams' kernels behind
     // it, a narrower, longer one runs BESIDE them, and every halving of the splits halves the slab bytes.  Pipelined step
     // 77.5 -> 76.2 ms at (256, 16..32); too narrow (64 workgroups, 8 splits) loses 4 ms (profiles/ab_r05_wgrad_splits.txt).
-    if (tn_cap < 0) { const char* e = getenv("CTTA_WGRAD_TN_MAX_SPLITS"); tn_cap = e ? atoi(e) : 32; }
-    if (tn_target < 0) { const char* e = getenv("CTTA_WGRAD_TN_TARGET"); tn_target = e ? atoi(e) : 256; }
     while (tiles * S < tn_target && S < tn_cap && M / (2 * S) >= 128) S *= 2;
     const int mp = (int)round_up64(M, 64 * S);
     if (S == 1 && dm && wgrad_direct_on() && dm->n <= N && (dm->bkey.empty() || dm->n_bias <= dm->n)) {
@@ -175,8 +165,7 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
   // Linears (taps == 1) stay on the transposed-operand route by default: there the old Q is ONE transposed copy of X, not
   // nine, and the implicit kernel's 1-tap tiling reads LDS once per MFMA (round-3 profile: 7.5 ms of side-stream kernel
   // time per step against 3.9 ms for ALL gradient GEMMs before); CTTA_WGRAD_IMPLICIT_LINEAR=1 routes them through it too.
-  static int implicit_linear = -1;
-  if (implicit_linear < 0) { const char* e = getenv("CTTA_WGRAD_IMPLICIT_LINEAR"); implicit_linear = (e && e[0] == '1') ? 1 : 0; }
+  constexpr bool implicit_linear = false;
   const int taps = kh * kw;
   const bool implicit = !ups && stride == 1 && ho == hi && wo == wi &&
                         ((taps == 9 && kh == 3 && pad == 1) || (taps == 1 && pad == 0 && implicit_linear)) &&
@@ -185,9 +174,7 @@ static ctta_status wgrad_slabs(BCtx& cm, WgJob& job, const bf16_t* x, int C, int
   if (implicit) {   // 64 x 64 (x 9 taps) / 64 x 256 tiles, two workgroups per CU
     const int64_t tiles = (int64_t)((N + 63) / 64) * ((C + (taps == 9 ? 63 : 255)) / (taps == 9 ? 64 : 256));
     S = 1;
-    static int im_cap = -1, im_target = -1;    // CTTA_WGRAD_CONV_MAX_SPLITS / CTTA_WGRAD_CONV_TARGET (tuning knobs)
-    if (im_cap < 0) { const char* e = getenv("CTTA_WGRAD_CONV_MAX_SPLITS"); im_cap = e ? atoi(e) : 16; }
-    if (im_target < 0) { const char* e = getenv("CTTA_WGRAD_CONV_TARGET"); im_target = e ? atoi(e) : 256; }     // (round 5: 256, see the linears above)
+    constexpr int im_cap = 16, im_target = 256;    // (round 5: 256 workgroups, see the linears above)
     while (tiles * S < im_target && S < im_cap && M / (2 * S) >= 256) S *= 2;
   }
   const int mp = (int)round_up64(M, 64 * S);
@@ -402,11 +389,7 @@ static ctta_status bwd_resnet(BCtx& c, Resnet& R, const bf16_t* dout, bf16_t** d
 // out zero).  Flash-style (no score matrix).  Round 5: Q, K, dO are read where they lie and V as the forward keeps it
 // (transposed) -- ctta_attention_bwd_inplace takes the operands it needs in the other orientation out of its own LDS tiles
 // through transposing reads; the four whole-tensor transposes per call of rounds 1-4 (CTTA_ATTN_BWD_INPLACE=0) are gone.
-static bool attn_bwd_inplace_on() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_ATTN_BWD_INPLACE"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
+static constexpr bool attn_bwd_inplace_on() { return true; }
 static ctta_status bwd_attention(BCtx& c, int heads, int dh, const bf16_t* q, int ldq, const bf16_t* k, int ldk, int krows,
                                  const bf16_t* vt, int vt_ld, const float* bias, int nq, int nk, const bf16_t* out,
                                  const bf16_t* dO, int hp, const float* lse, bf16_t* dq, int lddq, bf16_t* dk, int lddk,

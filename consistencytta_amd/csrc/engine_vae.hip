@@ -230,9 +230,7 @@ static ctta_status run_vae_attn(VCtx& c, VaeAttn* V, const bf16_t* x, int H, int
   // scores / probabilities in sample chunks small enough to stay in the 256 MB Infinity Cache between the three
   // launches (QK^T -> softmax -> PV): the (N x N) fp32 score matrix of one sample is 64 MB at N = 4096, the whole batch
   // at B = 32 would be 2 GiB of arena and 6 GB of HBM traffic per decode (modules.py:204-230 materialises it too)
-  static int chunk_mb = -1;
-  if (chunk_mb < 0) { const char* e = getenv("CTTA_VAE_ATTN_MB"); chunk_mb = e ? atoi(e) : 0; }
-  if (chunk_mb <= 0) chunk_mb = 1 << 20;   // default: the whole batch in one go (measured fastest; the chunks exist for memory-tight boxes)
+  const int chunk_mb = 1 << 20;   // the whole batch in one go (measured fastest; 288 GB of HBM hold the 2 GiB slab of batch 32)
   int gb = (int)(((size_t)chunk_mb << 20) / ((size_t)N * N * 6));
   if (gb < 1) gb = 1;
   if (gb > B) gb = B;
@@ -1239,10 +1237,7 @@ static ctta_status hifigan_build(ctta_hifigan* G) {
       // the chained form (one launch per ResBlock) is correct and tested, but measured SLOWER than three unit launches
       // once those lost their serialised staging loads (round 3, B = 32: C = 32 k = 3 0.76 vs 0.63 ms, k = 7 1.34 vs 0.81 ms:
       // the recomputed halo and two workgroups per CU cost more than the two saved HBM round trips): opt-in only
-      {
-        const char* e = getenv("CTTA_RES_CHAIN");
-        R.chained = e && e[0] == '1' && R.fused && ctta_reschain_supported(ch, k, cfg.resblock_dilations[j]) != 0;
-      }
+      R.chained = false;      // (ctta_reschain_conv1d stays an exported, tested operator; this engine does not take it)
       if (R.fused) {
         for (int m = 0; m < 3; ++m) {
           R.f1[m] = ws.arena.get<bf16_t>((size_t)ch * k * ch);

@@ -422,11 +422,7 @@ __global__ __launch_bounds__(256) void gn_finalize_wide_kernel(const float* __re
   }
 }
 
-static bool gn_finalize_wide_on() {   // CTTA_GN_FINALIZE_WIDE=0: the one-block-per-sample form everywhere (A/B)
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("CTTA_GN_FINALIZE_WIDE"); v = (e && e[0] == '0') ? 0 : 1; }
-  return v != 0;
-}
+static constexpr bool gn_finalize_wide_on() { return true; }
 
 // Pass 3: apply (+SiLU).  grid = (blocks per sample, batch): a block stays inside one sample, and because its stride
 // (gridDim.x * 256 vectors) is a multiple of the C / 8 vector columns whenever C / 8 divides 256, a thread keeps ONE
@@ -609,10 +605,8 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const bf16_t* __restrict_
   }
 }
 static bool gn_small_ok(int hw, int c, int groups) {
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("CTTA_GN_SMALL"); env = (e && e[0] == '0') ? 0 : 1; }
   const int cpg = c / groups;
-  return env && cpg % 8 == 0 && (long long)hw * cpg <= 16384 && groups <= 65535;
+  return cpg % 8 == 0 && (long long)hw * cpg <= 16384 && groups <= 65535;
 }
 
 static void gn_geometry(int hw, int c, int* pix_per_chunk, int* nchunk) {
@@ -705,9 +699,7 @@ extern "C" ctta_status ctta_groupnorm_from_partials(const void* x, void* y, int 
   CTTA_REQUIRE(c % 8 == 0 && groups > 0 && c % groups == 0, "groupnorm_from_partials: C=%d groups=%d unsupported", c, groups);
   hipStream_t s = (hipStream_t)stream;
   const int VC = c / 8;
-  static int fused = -1;   // CTTA_GN_APPLY_FUSED=0: always the two-launch form (A/B switch)
-  if (fused < 0) { const char* e = getenv("CTTA_GN_APPLY_FUSED"); fused = (e && e[0] == '0') ? 0 : 1; }
-  if (fused && !stats && (long long)nchunk * groups <= 2048 && c <= 4096) {
+  if (!stats && (long long)nchunk * groups <= 2048 && c <= 4096) {
     gn_launch_apply(x, y, batch, hw, c, scratch, silu, true, groups, partials, nchunk, gamma, beta, eps, s);
     CTTA_LAUNCH_CHECK();
     return CTTA_OK;
@@ -927,9 +919,7 @@ extern "C" ctta_status ctta_layernorm(const void* x, void* y, int64_t rows, int 
   CTTA_REQUIRE(ld % 8 == 0 && d <= ld && d > 0 && ld <= 2048, "layernorm: d=%d ld=%d unsupported", d, ld);
   const dim3 grid((unsigned)cdiv64(rows, 4));
   hipStream_t s = (hipStream_t)stream;
-  static int fast = -1;   // CTTA_LN_FAST=0: round 2's kernels (A/B switch)
-  if (fast < 0) { const char* e = getenv("CTTA_LN_FAST"); fast = (e && e[0] == '0') ? 0 : 1; }
-  if (fast && (ld == 256 || ld == 512 || ld == 1024)) {
+  if ((ld == 256 || ld == 512 || ld == 1024)) {
     if (ld == 256)
       hipLaunchKernelGGL((layernorm_fast_kernel<32, 1, 8>), dim3((unsigned)cdiv64(rows, 8 * 8)), dim3(256), 0, s, (const bf16_t*)x,
                          (bf16_t*)y, (long long)rows, d, ld, gamma, beta, eps);
@@ -1071,9 +1061,7 @@ __global__ __launch_bounds__(256) void softmax_rows_reg_kernel(const float* __re
 extern "C" ctta_status ctta_softmax_rows(const float* s, void* p, int64_t rows, int cols, float scale,
                                          void* stream) {
   CTTA_REQUIRE(s && p && cols % 4 == 0 && scale > 0.f, "softmax_rows: bad arguments");
-  static int reg = -1;     // CTTA_SOFTMAX_REG=0: the three-pass kernel of rounds 1-4 (A/B switch)
-  if (reg < 0) { const char* e = getenv("CTTA_SOFTMAX_REG"); reg = (e && e[0] == '0') ? 0 : 1; }
-  if (reg && (cols == 4096 || cols == 2048 || cols == 1024)) {
+  if ((cols == 4096 || cols == 2048 || cols == 1024)) {
     if (cols == 4096) hipLaunchKernelGGL((softmax_rows_reg_kernel<4>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, scale);
     else if (cols == 2048) hipLaunchKernelGGL((softmax_rows_reg_kernel<2>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, scale);
     else hipLaunchKernelGGL((softmax_rows_reg_kernel<1>), dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, s, (bf16_t*)p, scale);

@@ -337,9 +337,6 @@ __global__ __launch_bounds__(64) void wgrad_rowsum_kernel(const bf16_t* __restri
 }
 
 extern "C" int ctta_wgrad_implicit_supported(int taps, int c, int h, int w, int x_ld, int n) {
-  static int env = -1;
-  if (env < 0) { const char* e = getenv("CTTA_WGRAD_IMPLICIT"); env = (e && e[0] == '0') ? 0 : 1; }
-  if (!env) return 0;
   if (c < 32 || c % 8 != 0 || x_ld % 8 != 0 || n < 8) return 0;
   if (taps == 1) return 1;
   if (taps != 9) return 0;

@@ -35,6 +35,34 @@ def randn_tensor(shape, generator=None, device=None, dtype=None):
     return torch.randn(shape, generator=generator, device=device, dtype=dtype)
 
 
+def optimizer_tail(source_model, shadow_models, decay_consts, optimizer, lr_scheduler, grad_scale, do_step):
+    """The end of a training step, tools/train_utils.py:177-183: optimizer.step() (skipped on a NaN loss, :167-172) ->
+    lr_scheduler.step() -> optimizer.zero_grad() -> update_ema().  With the fused AdamW on `source_model` and every network
+    still in the flat buffers `do_ema_update` validated on an earlier step, the three device passes are ONE launch
+    (FusedAdamW.step_zero_ema; bit-identical state, tests/test_train_gpu.py); anything else -- a torch optimizer, the first
+    step, re-homed parameters, CTTA_FUSED_TAIL=0 -- takes the three calls."""
+    nets = [source_model] + list(shadow_models)
+    sig = tuple((id(m), getattr(m, "_rehome_count", 0)) for m in nets)
+    flats = [getattr(m, "_flat", None) for m in nets]
+    if (hasattr(optimizer, "step_zero_ema") and optimizer.module is source_model and os.environ.get("CTTA_FUSED_TAIL", "1") != "0"
+            and getattr(source_model, "_ema_validated", None) == sig and all(f is not None for f in flats)
+            and all(m.flat_is_current() for m in nets) and optimizer.can_fuse_tail(flats[1:])):
+        for d in decay_consts:
+            assert 0 <= d <= 1
+        optimizer.step_zero_ema(flats[1:], decay_consts, grad_scale=grad_scale, do_step=do_step)
+        if do_step and lr_scheduler is not None:
+            lr_scheduler.step()
+        for m in shadow_models:
+            m.mark_weights_changed()
+        return
+    if do_step:
+        optimizer.step(grad_scale=grad_scale)
+        if lr_scheduler is not None:
+            lr_scheduler.step()
+    optimizer.zero_grad()
+    do_ema_update(source_model, shadow_models, decay_consts)
+
+
 def do_ema_update(source_model, shadow_models, decay_consts):
     """tools/train_utils.py:255-282 with one fused pass per parameter for up to two shadows:
     shadow += (1 - decay) * (param - shadow).  Buffers: the U-Net mirrors have none."""
@@ -297,6 +325,11 @@ class AudioLCM(AudioDistilledModel):
         do_ema_update(self.student_unet, [self.student_target_unet, self.student_ema_unet],
                       [self.target_ema_decay, self.ema_decay])
 
+    def _optimizer_tail(self, optimizer, lr_scheduler, grad_scale, do_step):
+        assert self.training, "EMA update should only be called during training"
+        optimizer_tail(self.student_unet, [self.student_target_unet, self.student_ema_unet],
+                       [self.target_ema_decay, self.ema_decay], optimizer, lr_scheduler, grad_scale, do_step)
+
     def check_eval_mode(self):
         super().check_eval_mode()
         assert self.student_target_unet.training is False, "The student_target_unet is not in eval mode."
@@ -458,12 +491,8 @@ class AudioLCM(AudioDistilledModel):
                                    buckets.ready if buckets.enabled else None)
             world = buckets.wait()
             value = float(loss.item())
-            if not (skip_nan and nan_any.result()):    # train_utils.py:167-172: a NaN loss skips the update
-                optimizer.step(grad_scale=1.0 / world)
-                if lr_scheduler is not None:
-                    lr_scheduler.step()
-            optimizer.zero_grad()
-            self.update_ema()
+            # train_utils.py:167-172: a NaN loss skips the update (not the zero_grad, not the EMA)
+            self._optimizer_tail(optimizer, lr_scheduler, 1.0 / world, not (skip_nan and nan_any.result()))
         return value
 
     def _forward_impl(self, z_0, gt_wav, prompt, validation_mode, run_teacher, time_inds, gaussian_noise,
@@ -682,6 +711,10 @@ class AudioGDM(AudioDistilledModel):
         assert self.training, "EMA update should only be called during training"
         do_ema_update(self.student_unet, [self.student_ema_unet], [self.ema_decay])
 
+    def _optimizer_tail(self, optimizer, lr_scheduler, grad_scale, do_step):
+        assert self.training, "EMA update should only be called during training"
+        optimizer_tail(self.student_unet, [self.student_ema_unet], [self.ema_decay], optimizer, lr_scheduler, grad_scale, do_step)
+
     def _grad_anchor(self):
         a = getattr(self, "_anchor", None)
         if a is None or a.device != self.device:
@@ -778,12 +811,7 @@ class AudioGDM(AudioDistilledModel):
             self._student_backward(pred, target, weights, 1.0, buckets.ready if buckets.enabled else None)
             world = buckets.wait()
             value = float(loss.item())
-            if not (skip_nan and nan_any.result()):
-                optimizer.step(grad_scale=1.0 / world)
-                if lr_scheduler is not None:
-                    lr_scheduler.step()
-            optimizer.zero_grad()
-            self.update_ema()
+            self._optimizer_tail(optimizer, lr_scheduler, 1.0 / world, not (skip_nan and nan_any.result()))
         return value
 
     @torch.no_grad()
@@ -1365,12 +1393,7 @@ class _DistillStepGraph:
                     buckets.ready(blk)
         world = buckets.wait()
         value = float(self.loss.item())
-        if not (skip_nan and nan_any.result()):
-            self.opt.step(grad_scale=1.0 / world)
-            if lr_scheduler is not None:
-                lr_scheduler.step()
-        self.opt.zero_grad()
-        m.update_ema()
+        m._optimizer_tail(self.opt, lr_scheduler, 1.0 / world, not (skip_nan and nan_any.result()))
         return value
 
 

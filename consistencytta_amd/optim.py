@@ -60,6 +60,40 @@ class FusedAdamW:
                                             N.stream_ptr()))
         self.module.mark_weights_changed()
 
+    def can_fuse_tail(self, shadow_flats):
+        """Whether `step_zero_ema` may replace step() + zero_grad() + the EMA launch: shadows with this optimizer's flat
+        layout, vector-aligned extents (the fused kernel has no scalar tail)."""
+        n_all = self.flat.numel()
+        return (self.n % 4 == 0 and n_all % 4 == 0 and self.grad.numel() == n_all and 1 <= len(shadow_flats) <= 2
+                and all(f is not None and f.numel() == n_all and f.device == self.flat.device and f.dtype == torch.float32
+                        and f.data_ptr() % 16 == 0 for f in shadow_flats)
+                and all(t.data_ptr() % 16 == 0 for t in (self.flat, self.grad, self.exp_avg, self.exp_avg_sq)))
+
+    def step_zero_ema(self, shadow_flats, decays, grad_scale=1.0, do_step=True):
+        """optimizer.step() -> optimizer.zero_grad() -> EMA of up to two shadow networks (tools/train_utils.py:177-183,
+        255-282) as ONE pass over the training state (`ctta_adamw_ema2_zero`: 12 fp32 streams instead of 7 + 1 + 5);
+        bit-identical to the three launches.  `do_step=False`: the update is skipped (NaN loss), the gradients are still
+        zeroed and the shadows still move, as in the reference.  The caller has checked `can_fuse_tail` and that the
+        shadows still live in `shadow_flats`."""
+        g = self.param_groups[0]
+        if not self.module.flat_is_current() or self.module._flat is not self.flat:
+            raise N.CttaError("FusedAdamW: the module's parameters no longer alias the flat buffer this optimizer "
+                              "was built on (model.to()/.float() after prepare_training?) -- build a new optimizer")
+        if do_step:
+            if not self.module.grads_alias_flat_sampled():
+                self.module.realias_grads_()
+                raise N.CttaError("FusedAdamW: parameter gradients were not views of the flat gradient buffer (zero_grad("
+                                  "set_to_none=True) + a foreign backward?); they have been re-aliased -- redo the backward")
+            self.step_count += 1
+        with torch.cuda.device(self.flat.device):
+            N.check(N.lib().ctta_adamw_ema2_zero(
+                N.ptr(self.flat), N.ptr(self.grad), N.ptr(self.exp_avg), N.ptr(self.exp_avg_sq), self.n, self.flat.numel(),
+                N.ptr(shadow_flats[0]), float(decays[0]), N.ptr(shadow_flats[1]) if len(shadow_flats) > 1 else N.c_void_p(0),
+                float(decays[1]) if len(shadow_flats) > 1 else 0.0, 1 if do_step else 0, g["lr"], g["betas"][0], g["betas"][1],
+                g["eps"], g["weight_decay"], max(1, self.step_count), float(grad_scale), N.stream_ptr()))
+        if do_step:
+            self.module.mark_weights_changed()
+
     # checkpoint / resume (accelerator.save_state stores the optimizer state, train.py:497-505): the layout is
     # torch.optim.AdamW.state_dict() over `student_unet.parameters()` (tools/train_utils.py:38-39,59-63), so that
     # optimizer.bin written here resumes a reference run and vice versa:

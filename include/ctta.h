@@ -44,7 +44,6 @@ int ctta_version(void);
  *   "streamk"      1  ... as ONE persistent launch that folds its partial tiles itself, where the tile rules choose it
  *                     (0: two-pass split-K only); needs a workspace with a zeroed header (ctta_conv_bind_workspace_ex)
  *   "streamk_grid" 0  tuning: workgroups of a stream-K launch (0: one per CU slot)
- *   "mf32"         1  the 128x64-per-wave tiles issue v_mfma_f32_32x32x16_bf16 where the tile rules choose it (0: 16x16x32 only)
  *   "wgrad_stream" 1  weight-gradient launches of ctta_unet_backward* go to the handle's side stream (0: everything on the
  *                     caller's stream -- what a per-launch profile needs; read at every backward call)
  *   "gn_fuse"      1  GroupNorm statistics come from the producing convolution's epilogue (= ctta_set_gn_fuse)
@@ -771,12 +770,23 @@ ctta_status ctta_snr_mse_grad(const float* pred, const float* target, const floa
 ctta_status ctta_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                             float lr, float beta1, float beta2, float eps, float weight_decay, int step,
                             float grad_scale, void* stream);
+/* The optimizer tail of one training step as ONE pass over the training state: optimizer.step() -> optimizer.zero_grad() ->
+ * update_ema() (tools/train_utils.py:177-183, 255-282).  param / grad / both shadows are the flat fp32 buffers of n_all
+ * elements (trainable prefix of n_train elements first, see AudioLCM.prepare_training); exp_avg / exp_avg_sq cover the
+ * prefix.  Reads p, g, m, v, shadow_a, shadow_b; writes p, m, v, both shadows and g = 0.  do_step = 0 leaves p, m, v alone
+ * (the reference skips the update on a NaN loss, train_utils.py:167-172, but still zeroes the gradients and moves the
+ * shadows).  shadow_b may be NULL.  Per element the same fp32 operations in the same order as ctta_adamw_step followed by
+ * ctta_ema_update2: bit-identical state.  n_train and n_all must be multiples of 4, all buffers 16-byte aligned. */
+ctta_status ctta_adamw_ema2_zero(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n_train, int64_t n_all,
+                                 float* shadow_a, double decay_a, float* shadow_b, double decay_b, int do_step, float lr,
+                                 float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                 void* stream);
 
 /* Opt-in launch profiler (bench.py's live roofline leg): when enabled, every conv_gemm (kind 0)
  * and attention (kind 1) launch is bracketed by hipEvents on its own stream.  collect() waits
  * for the recorded launches, returns their summed duration / executed FLOPs / count, optionally
  * appends one CSV line per launch (kind,variant,m,n,k,groups,ms,tflops) and clears the log. */
-/* GroupNorm statistics from the producing convolution's epilogue (default on; CTTA_GN_FUSE=0 in the environment or
+/* GroupNorm statistics from the producing convolution's epilogue (default on; option "gn_fuse" = 0 /
  * ctta_set_gn_fuse(0) turn it off, process-wide, taking effect at the next engine call).  Off: a sample's result is
  * bit-identical at every batch size; on: at a fixed batch size. */
 void ctta_set_gn_fuse(int on);

@@ -1,6 +1,6 @@
 """Worker of tests/test_models_gpu.py::test_heun_teacher_loop_at_real_size_graph_equals_eager: BASELINE configs[2] at its
 real size (559 M-parameter light teacher U-Net, B = 8 prompts = CFG batch 16, L = 32 text tokens, latent 8 x 256 x 16)
-in a fresh process, because the tile rules (`CTTA_THIN_RING`) are read once per process.
+in a fresh process (its own handles, arenas and caches).
 
     python tests/teacher_loop_worker.py <out.pt> <steps> [notextcache]
 """

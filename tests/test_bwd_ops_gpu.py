@@ -577,3 +577,39 @@ def test_flash_attention_backward(B, heads, dh, nq, nk, krows, use_bias):
         e = rel_err(a.float().cpu(), b_.float().cpu())
         print("in-place %s vs transposed-copies route: rel diff %.3e" % (name, e))
         assert e <= 2e-3, (name, e)     # dP contracts over d in another slot order: fp32 sums differ in the last bits
+
+
+@pytest.mark.parametrize("n_train,n_all,two", [(4096 * 37 + 64, 4096 * 37 + 320, True), (1 << 22, 1 << 22, True), (8192, 8200, False)])
+def test_optimizer_tail_in_one_pass_is_bit_identical_to_the_three_launches(n_train, n_all, two):
+    """ctta_adamw_ema2_zero = optimizer.step() -> optimizer.zero_grad() -> update_ema() (tools/train_utils.py:177-183, 255-282) as
+    ONE pass over the training state: 12 fp32 streams instead of 7 + 1 + 5.  Same fp32 operations in the same order per element
+    as ctta_adamw_step + fill + ctta_ema_update2, so after three steps (the middle one with do_step = 0: the NaN-loss skip)
+    every buffer is BIT-identical; the frozen suffix [n_train, n_all) only moves its shadows and loses its gradient."""
+    L = N.lib()
+    st = N.stream_ptr()
+    gen = torch.Generator().manual_seed(n_all)
+    def mk(scale=1.0):
+        return (torch.randn(n_all, generator=gen) * scale).to(DEV)
+    p0, sa0, sb0 = mk(), mk(), mk()
+    A = dict(p=p0.clone(), m=torch.zeros(n_train, device=DEV), v=torch.zeros(n_train, device=DEV), sa=sa0.clone(), sb=sb0.clone())
+    B = {k: t.clone() for k, t in A.items()}
+    for step in range(1, 4):
+        g = mk(0.1)
+        do = step != 2
+        ga, gb = g.clone(), g.clone()
+        if do:
+            N.check(L.ctta_adamw_step(N.ptr(A["p"]), N.ptr(ga), N.ptr(A["m"]), N.ptr(A["v"]), n_train, 1e-3, 0.9, 0.999, 1e-8, 1e-2,
+                                      step if step < 2 else step - 1, 0.5, st))
+        ga.zero_()
+        N.check(L.ctta_ema_update2(N.ptr(A["p"]), N.ptr(A["sa"]), 0.95, N.ptr(A["sb"]) if two else N.c_void_p(0), 0.999, n_all, st))
+        N.check(L.ctta_adamw_ema2_zero(N.ptr(B["p"]), N.ptr(gb), N.ptr(B["m"]), N.ptr(B["v"]), n_train, n_all, N.ptr(B["sa"]), 0.95,
+                                       N.ptr(B["sb"]) if two else N.c_void_p(0), 0.999, 1 if do else 0, 1e-3, 0.9, 0.999, 1e-8, 1e-2,
+                                       step if step < 2 else step - 1, 0.5, st))
+        torch.cuda.synchronize()
+        assert not bool(gb.any())
+        for k in A:
+            if k == "sb" and not two:
+                assert torch.equal(B[k], sb0)
+                continue
+            assert torch.equal(A[k], B[k]), (k, step)
+    assert not torch.equal(A["p"], p0) and not torch.equal(A["sa"], sa0)

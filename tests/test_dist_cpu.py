@@ -125,3 +125,37 @@ def test_bench_parent_launches_a_child_and_never_touches_the_gpu(tmp_path):
     assert "TORCH_IMPORTED False" in r.stdout, r.stdout + r.stderr
     assert "RC 0" not in r.stdout                       # the ranks' failure is the parent's exit code
     assert "bench.py needs a GPU" in r.stderr           # ... and it came from real child ranks
+
+
+def test_eight_ranks_with_late_banners_keep_the_json_line_last(tmp_path, capsys):
+    """`python bench.py --gpus 8` relays its child's stdout; the ONE JSON line must be the last line the parent prints even when
+    eight ranks flush C-stdio banners (RCCL prints its version / library path that way) AFTER rank 0 printed it.  A stub script
+    in place of bench.py, started through the real launcher path (`self_launch` -> `torch.distributed.run`, 8 processes on
+    127.0.0.1): every rank leaves an unflushed C `printf` banner behind, rank 0 prints the line in the middle."""
+    import argparse
+    import json
+    bench, root = _load_bench()
+    stub = tmp_path / "stub_bench.py"
+    stub.write_text(
+        "import ctypes, json, os, sys, time\n"
+        "rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])\n"
+        "libc = ctypes.CDLL(None)\n"
+        "os.write(1, ('rank %d of %d started\\n' % (rank, world)).encode())      # one write per line: ranks share the pipe\n"
+        "libc.printf(b'RCCL version 2.x banner of rank %d (flushed at exit)\\n', rank)\n"
+        "time.sleep(0.2 * (world - rank))\n"
+        "if rank == 0:\n"
+        "    os.write(1, (json.dumps({'metric': 'stub', 'value': 1.0, 'n_gpus': world, 'rccl_ranks': world}) + '\\n').encode())\n"
+        "time.sleep(0.5)\n")
+    env_keys = ("WORLD_SIZE", "RANK", "LOCAL_RANK", "CTTA_BENCH_LAUNCH_DRYRUN")
+    saved = {k: os.environ.pop(k) for k in env_keys if k in os.environ}
+    try:
+        rc = bench.self_launch(argparse.Namespace(gpus=8), ["--gpus", "8"], script=str(stub))
+    finally:
+        os.environ.update(saved)
+    out = [l for l in capsys.readouterr().out.splitlines() if l.strip()]
+    assert rc == 0, out
+    assert sum(1 for l in out if l.startswith("rank ") and l.endswith("started")) == 8, out
+    assert sum(1 for l in out if "banner of rank" in l) == 8
+    last = json.loads(out[-1])
+    assert last["metric"] == "stub" and last["n_gpus"] == 8 and last["rccl_ranks"] == 8
+    assert sum(1 for l in out if l.startswith('{"metric"')) == 1

@@ -222,6 +222,41 @@ def test_train_step_adamw_and_ema_match_torch(golden):
     assert abs(m.train_step(z0, P, opt, sched, **kw) - float(g["train_loss"])) > 1e-6
 
 
+def test_fused_optimizer_tail_gives_the_same_training_state_as_the_three_launches(golden, monkeypatch):
+    """AudioLCM.train_step ends with AdamW -> zero_grad -> EMA x 2 (tools/train_utils.py:177-183).  From the second step on
+    (the first one validates the flat-buffer layout of the four networks) that tail is ONE launch, ctta_adamw_ema2_zero;
+    CTTA_FUSED_TAIL=0 keeps the three.  Same draws, four steps each way: student, target and EMA weights, both Adam moments
+    and the learning-rate schedule are bit-identical, the gradient buffer is zero, and the fused form really ran."""
+    from consistencytta_amd.optim import WarmupSchedule
+    g = golden("distill_tiny")
+    kw = dict(time_inds=torch.from_numpy(g["time_inds"]) * 2, gaussian_noise=torch.from_numpy(g["noise"]).to(DEV),
+              guidance_scale=torch.from_numpy(g["guidance"]))
+    states = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("CTTA_FUSED_TAIL", fused)
+        m, P, z0 = _lcm()
+        m.train()
+        opt = m.prepare_training(lr=1e-3, weight_decay=1e-2, broadcast=False)
+        sched = WarmupSchedule(opt, "linear", num_warmup_steps=2, num_training_steps=10)
+        calls = []
+        real = opt.step_zero_ema
+        opt.step_zero_ema = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+        losses = [m.train_step(z0, P, opt, sched, **kw) for _ in range(4)]
+        torch.cuda.synchronize()
+        if opt.n % 4 == 0 and opt.flat.numel() % 4 == 0:
+            assert len(calls) == (3 if fused == "1" else 0), calls
+        assert not bool(opt.grad.any())
+        states.append((losses, [p.detach().clone() for n_ in ("student_unet", "student_target_unet", "student_ema_unet")
+                                for p in getattr(m, n_).parameters()], opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
+                       opt.param_groups[0]["lr"], opt.step_count))
+        del m, opt
+    (la, pa, ma, va, lra, sa), (lb, pb, mb, vb, lrb, sb_) = states
+    assert la == lb and lra == lrb and sa == sb_ == 4
+    assert torch.equal(ma, mb) and torch.equal(va, vb)
+    for x, y in zip(pa, pb):
+        assert torch.equal(x, y)
+
+
 def test_blockwise_backward_with_rccl_buckets_equals_monolithic(golden):
     """The overlapped data-parallel path on one GPU: a 1-rank RCCL process group with CTTA_FORCE_COLLECTIVES=1 makes
     train_step run the block-wise backward and issue the bucketed all-reduces; the parameters after one optimisation
@@ -926,7 +961,7 @@ def test_distillation_step_full_batch_is_deterministic_and_blockwise_exact():
     d12, d13 = float((g1 - g2).norm()) / ref, float((g1 - g3).norm()) / ref
     print("B=9 light: loss %.6f, |grad| %.4e, run-to-run rel diff %.2e, block-wise vs monolithic %.2e" % (l1, ref, d12, d13))
     # Only the LayerNorm gamma/beta fp32 atomics may differ in the last bit: 1.5e-8 measured with BOTH stream overlaps on
-    # (the default: CTTA_TWO_STREAM / CTTA_WGRAD_STREAM).  The 1.5e-7..3.8e-7 once seen with a second hardware queue were the
+    # (the default: CTTA_TWO_STREAM / option "wgrad_stream").  The 1.5e-7..3.8e-7 once seen with a second hardware queue were the
     # v_pk_fma_f32 op_sel hazard, gone since the library is built with -fno-slp-vectorize.
     assert d12 <= 1e-7 and d13 <= 1e-7
     # the hipGraph-captured step at THIS size (what bench.py times) against the eager one -- loss bit

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Self-attention microbenchmark through the C ABI: executed TFLOP/s (2 * 2 * nq * nk * 64 per head) and max error vs an fp32
-torch reference on the same bf16 operands.  CTTA_ATTN_V2=0/1 selects the round-2 / round-3 kernel (read once per process)."""
+torch reference on the same bf16 operands.  (Until round 5 an environment knob selected the round-2 kernel; the library reads no environment any more.)"""
 import os
 import sys
 
@@ -58,8 +58,7 @@ def main():
             ts.append(e[0].elapsed_time(e[1]) / 5)
         ms = sorted(ts)[len(ts) // 2]
         fl = 4.0 * n * n * 64 * B * H
-        print("B%d H%d n%d: %.3f ms  %.1f TF/s executed  (max err %.2e)  V2=%s" % (B, H, n, ms, fl / ms / 1e9, err,
-                                                                                  os.environ.get("CTTA_ATTN_V2", "1")), flush=True)
+        print("B%d H%d n%d: %.3f ms  %.1f TF/s executed  (max err %.2e)" % (B, H, n, ms, fl / ms / 1e9, err), flush=True)
 
 
 if __name__ == "__main__":

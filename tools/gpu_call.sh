@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parameterised GPU-box script (replaces round 3's fifty one-off r3_probe*.sh / r3_full*.sh):
 #   gpurun --timeout 2400 -- 'bash tools/gpu_call.sh full'                 # whole GPU suite + smoke + default bench
-#   gpurun --timeout 900  -- 'bash tools/gpu_call.sh ab CTTA_THIN_RING distill 1 0 1 0'   # A/B an env knob on a bench mode
+#   gpurun --timeout 900  -- 'bash tools/gpu_call.sh ab CTTA_OPT_STREAMK distill 1 0 1 0'   # A/B a library option (CTTA_OPT_<NAME>, applied by _native at load) on a bench mode
 #   gpurun --timeout 600  -- 'bash tools/gpu_call.sh pmc_distill'          # FETCH / WRITE PMC passes of the distillation leg
 #   gpurun --timeout 600  -- 'bash tools/gpu_call.sh tests "-k segmented" tests/test_train_gpu.py'
 # Profiles for profiles/ come from tools/refresh_profiles.sh.

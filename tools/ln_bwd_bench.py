@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """LayerNorm backward microbenchmark through the C ABI at the distillation step's token-matrix shapes (batch 9):
-us per call and GB/s over the three tensor passes (x, dy read; dx written).  CTTA_LN_BWD_TWO_PASS=0/1 selects the
+us per call and GB/s over the three tensor passes (x, dy read; dx written).  (Until round 5 an environment knob selected the
 parameter-gradient reduction (global atomics / partial table + fixed-order fold)."""
 import os
 import sys
@@ -38,8 +38,7 @@ def main():
             torch.cuda.synchronize()
             ts.append(e[0].elapsed_time(e[1]) / 10)
         ms = sorted(ts)[2]
-        print("rows %6d d %4d: %.1f us  %.0f GB/s over 3 passes  two_pass=%s" % (rows, d, ms * 1e3, 3 * x.numel() * 2 / ms / 1e6,
-                                                                                 os.environ.get("CTTA_LN_BWD_TWO_PASS", "1")), flush=True)
+        print("rows %6d d %4d: %.1f us  %.0f GB/s over 3 passes" % (rows, d, ms * 1e3, 3 * x.numel() * 2 / ms / 1e6), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How far do two bf16 runs of the light U-Net drift apart when only the fp32 accumulation ORDER changes?
-Runs one clip (B=1) and writes the latent; run it under different CTTA_SPLITK / CTTA_XCD / tile settings and
+Runs one clip (B=1) and writes the latent; run it under different CTTA_OPT_SPLITK / CTTA_OPT_XCD settings (library options, applied by _native at load) and
 compare the files (tools/order_noise.py out.pt [compare.pt])."""
 import os
 import sys

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Counter passes over the self-attention forward kernel alone (tools/attn_bench.py, first shape: B 32, 5 heads, 4096 tokens).
-# gpurun --timeout 900 -- 'bash tools/pmc_attn.sh'        (CTTA_ATTN_V2 selects the kernel form)
+# gpurun --timeout 900 -- 'bash tools/pmc_attn.sh'        
 set -u
 R=$PWD; O=$R/gpurun_out/pmc_attn; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 export ATTN_SHAPES=0

@@ -3,7 +3,7 @@
 without the weight-slab XCD mapping.
 
   run:    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d DIR -o p -- python3 tools/pmc_thin_shapes.py run DIR/manifest.json
-  parse:  python3 tools/pmc_thin_shapes.py parse DIR [DIR2 ...]     (one DIR per CTTA_XCD_SLAB setting; prints one table)
+  parse:  python3 tools/pmc_thin_shapes.py parse DIR [DIR2 ...]     (one DIR per library build / option setting; prints one table)
 
 `run` launches every shape REPS times on rotating weight copies (cold, as inside the pipeline) and writes the manifest the
 parser needs to cut the profiler's dispatch list into shapes (one conv_gemm_kernel dispatch per launch, in launch order).
