@@ -56,14 +56,15 @@ struct ConvParams {
   float* gn_part;
   int gn_cpg, gn_G, gn_hw, gn_nchunk;
   // Stream-K (conv_gemm_sk_kernel: ONE persistent launch of <= one workgroup per CU slot, groups == 1): the (output tile,
-  // K step) items -- tile-major, sk_tiles * nk of them -- are cut into gridDim.x equal contiguous ranges.  A workgroup whose
-  // range starts inside a tile writes that tile's partial sums (fp32 rows, [BM][BN]) to slot id of sk_slots and raises
-  // sk_hdr[SK_FLAGS + id]; the workgroup that holds the tile's FIRST K step writes its own part to slot gridDim.x + id, then
-  // adds the parts of the ids behind it in id (= K) order and runs the fused epilogue: the summation order is fixed by the
-  // decomposition, never by arrival.  sk_hdr[0..3] = {start ticket, finished count, epoch, timeouts}:
-  // logical id = gridDim.x - 1 - ticket, so an owner only ever waits for workgroups that STARTED before it (forward progress
-  // whatever is resident); flags carry epoch + 1, the last workgroup to finish zeroes the two counters and advances the epoch
-  // (no memset node per launch; the header is zeroed once where the workspace is allocated).
+  // K step) items -- tile-major inside each of sk_chunks XCD chunks of whole tiles -- are cut into equal contiguous ranges, one
+  // per workgroup.  A tile whose K walk is split over several workgroups leaves as fp32 partial tiles ([BM][BN] rows): the part
+  // with the first K step in slot gridDim.x + id of sk_slots, every later part in slot id of its writer.  Each written part is
+  // counted in sk_hdr[SK_FLAGS + tile]; the workgroups that wrote a tile's parts then fold it together -- fold blocks of a few
+  // rows claimed from sk_hdr[SK_FLAGS + sk_tiles + tile], every block = the sum of the parts in K order + the fused epilogue,
+  // so the result does not depend on who folds or when.  The writer of the LAST part folds at once; the others wait a bounded
+  // time at the end of their own K walk and help: no unbounded wait anywhere, forward progress whatever is resident.
+  // sk_hdr[0..2] = {start ticket, finished count, launches}; the last workgroup to finish zeroes tickets and counters (no
+  // memset node per launch; the header is zeroed once where the workspace is allocated).
   unsigned* sk_hdr;
   float* sk_slots;
   int sk_tiles, sk_m_inner;   // sk_m_inner != 0: tile = nt * m_tiles + mt (row tiles innermost), else mt * n_tiles + nt

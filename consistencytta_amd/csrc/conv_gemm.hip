@@ -322,7 +322,9 @@ static bool splitk_default() { return ctta_opt(CTTA_OPT_SPLITK) != 0 && !t_no_sp
 // direct-to-LDS twins.  kBigTile (256x256x64, 8 waves of 128x64) is chosen separately: it halves the
 // L1->LDS bytes per FLOP, which is what bounds the 128-wide tiles (64 B/clk/CU vs 512 MFMA-cycles).
 static const int kBigTile = 29;
-static bool want_big_tile(long long M, int N, long long K, int groups) {
+static const int kBigTileSk = 41;     // its stream-K twin
+// 0: no; 1: the 256x256x64 tile, one tile per workgroup; 2: the deep case below (stream-K where the workspace allows, else 1)
+static int want_big_tile(long long M, int N, long long K, int groups) {
   const long long t256 = ((M + 255) / 256) * ((N + 255) / 256) * groups;
   // one workgroup per CU: 288 tiles (the distillation teacher's batch 18 at level 0) are two rounds of the 256 CUs with the
   // second one 12 % full -- 659-741 TFLOP/s against 828-910 on the thin-grid tile (profiles/sweep_r03.txt, t18 rows)
@@ -332,7 +334,17 @@ static bool want_big_tile(long long M, int N, long long K, int groups) {
   if (M % 256 != 0 && groups == 1 && t_cut >= 1 && (t_cut + 255) / 256 < (t256 + 255) / 256) tq = t_cut;
   const long long rounds = (tq + 255) / 256;
   const bool fills = tq >= 1024 || tq * 10 >= rounds * 256 * 7;
-  return N >= 256 && (N % 256 == 0 || N >= 1024) && K >= kBigTileMinK && t256 >= 192 && fills;
+  if (N >= 256 && (N % 256 == 0 || N >= 1024) && K >= kBigTileMinK && t256 >= 192 && fills) return 1;
+  // Round 6 (profiles/sweep_r06_streamk_v3_coop_fold.txt, weights cold): a DEEP launch (K >= 8192) with 64 .. 191 big tiles is
+  // bound by the bytes its workgroups stage per CU-clock, and the small tiles that fill every CU stage the most per FLOP.  On
+  // the big tile: as stream-K (one persistent launch, one workgroup per CU, partial tiles folded in the launch) 4608 x 1024 x
+  // 9216 822 TFLOP/s, 4096 x 1024 x 9216 845, 4096 x 1024 x 18432 1063, 18432 x 512 x 9216 1014; with the two-pass split-K
+  // (7-8 splits) 764 / 727 / 982 / 968; round 5's choices (64x128x64, 3-stage ring, + split-K) 628 / 737 / 757 / 686.
+  // Not when the 128x128x64 tile fills its 512 slots evenly (8192 x 1024 x 9216: 1049 vs 1050), which pick_variant tests first;
+  // not below 64 tiles (2304 x 1024 x 9216: 548 vs 676 -- the fold traffic does not shrink with M).
+  const long long t128 = ((M + 127) / 128) * ((N + 127) / 128) * groups;
+  const bool even128 = t128 >= 400 && t128 < 1024 && t128 * 100 >= ((t128 + 511) / 512) * 512 * 85;
+  return (N >= 512 && N % 256 == 0 && K >= 8192 && groups == 1 && t256 >= 64 && t256 < 192 && !even128) ? 2 : 0;
 }
 static int pick_variant(long long M, int N, long long K, int groups) {
   if (N <= 32) {                                           // 256x32; few row tiles (the per-sample cross-attention
@@ -430,10 +442,14 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   }
   p.epi_fast_geglu = (geglu && p.wide_store && p.plain_out &&
                       M * (long long)d->ldc * 2 < 0x7FFFFF00LL) ? 1 : 0;
-  p.epi_fast = (p.wide_store && M * (long long)d->ldc * 2 < 0x7FFFFF00LL &&
-                (!d->res || M * (long long)d->res_ld * 2 < 0x7FFFFF00LL) && p.plain_out && !geglu && !d->bias_m && !(d->gn_part && (d->accumulate || d->out2)) && !(d->accumulate && d->out2) &&
+  // (a per-sample strided, shifted, clipped destination -- the ConvTranspose upsamplers -- takes it too since round 6: one
+  // descriptor per sample does the clipping; its rows cover the sample: (howo + 1) * ldc elements at most)
+  const bool strided_ok = !p.plain_out && !d->res && !d->accumulate && !d->gn_part && !d->rowvec && d->out_limit > 0 &&
+                          d->out_limit * 2 < 0x7FFFFF00LL && ((long long)p.howo + 1) * d->ldc * 2 < 0x7FFFFF00LL;
+  p.epi_fast = (p.wide_store && (p.plain_out ? M * (long long)d->ldc * 2 < 0x7FFFFF00LL : strided_ok) &&
+                (!d->res || M * (long long)d->res_ld * 2 < 0x7FFFFF00LL) && !geglu && !d->bias_m && !(d->gn_part && (d->accumulate || d->out2)) && !(d->accumulate && d->out2) &&
                 (d->out_act == 0 || (d->out_act == 3 && d->out_slope >= 0.f && d->out_slope <= 1.f)) &&
-                (!d->out2 || (d->res && d->out2_slope >= 0.f && d->out2_slope <= 1.f))) ? 1 : 0;
+                (!d->out2 || (d->out2_slope >= 0.f && d->out2_slope <= 1.f))) ? 1 : 0;
   p.epi_act = (d->alpha != 1.0f || d->out_act == 3) ? 1 : 0;
   if (p.epi_act && d->gn_part) p.epi_fast = 0;   // the statistics instantiations carry no scale / activation
   p.stamps = t_stamps;
@@ -448,8 +464,14 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
   }
   bool thin_ring = false;
   if (vid <= 0 || vid > kNumVariants) {
-    if (!d->in_act && !geglu && want_big_tile(M, d->n, K, groups) && fast_ok(kVariants[kBigTile - 1].bk)) {
+    const int big = (!d->in_act && !geglu && fast_ok(kVariants[kBigTile - 1].bk)) ? want_big_tile(M, d->n, K, groups) : 0;
+    if (big) {
       vid = kBigTile;
+      if (big == 2 && splitk_default() && ctta_opt(CTTA_OPT_STREAMK)) {      // stream-K needs a workspace with a live header
+        size_t wsb = 0;
+        bool hdr_ok = false;
+        if (splitk_workspace(&wsb, &hdr_ok) && hdr_ok && !t_stamps) vid = kBigTileSk;
+      }
       // (round 1 sent short-K launches with a residual / second output / accumulate to the 256x128x32 tile because the
       // big tile's rolled epilogue could not hide behind another workgroup; with the straight-line epilogue the big tile
       // wins there too: profiles/sweep_r02_epi.json, 670 vs 626 TFLOP/s at K = 768)
@@ -539,6 +561,7 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     float* wsp = splitk_workspace(&wsb, &hdr_ok);
     CTTA_REQUIRE(wsp && hdr_ok, "conv_gemm: stream-K needs a workspace whose header was zeroed (ctta_conv_bind_workspace_ex)");
     const long long T = (long long)grid.x * grid.y;
+    CTTA_REQUIRE(2 * T <= SK_MAX_GRID, "conv_gemm: stream-K takes at most %d output tiles (got %lld)", SK_MAX_GRID / 2, T);
     const long long items = T * p.nk;
     const int per_cu = (int)((160 * 1024) / ((size_t)v.stages * (v.bm + v.bn) * v.bk * 2));
     long long G = (long long)cu_count() * (per_cu < 1 ? 1 : per_cu > 2 ? 2 : per_cu);
@@ -565,19 +588,8 @@ extern "C" ctta_status ctta_conv_gemm(const ctta_conv_desc* d, void* stream) {
     p.sk_slots = wsp + SK_HDR_WORDS;
     const bool prof_sk = ctta_prof_active();
     if (prof_sk) ctta_prof_begin(0, vid + ((p.epi_fast || p.epi_fast_geglu) ? 0 : 100), M, d->n, K, groups, (hipStream_t)stream);
-    if (d->gn_part && d->gn_groups > 0 && d->gn_hw > 0 && p.wide_store) {
-      const int cpg = d->n % d->gn_groups == 0 ? d->n / d->gn_groups : 0;
-      const int tn = v.bn / v.wn;
-      if (cpg >= 4 && (cpg & (cpg - 1)) == 0 && v.bn % cpg == 0 && d->gn_hw % v.bm == 0 && M % d->gn_hw == 0) {
-        const int sub = cpg > tn ? cpg / tn : 1;
-        const int nchunk = d->gn_hw / v.bm * v.wm * sub;
-        if ((long long)(M / d->gn_hw) * nchunk * d->gn_groups * 2 <= (long long)d->gn_part_floats) {
-          p.gn_part = (float*)d->gn_part; p.gn_cpg = cpg; p.gn_G = d->gn_groups; p.gn_hw = d->gn_hw;
-          p.gn_nchunk = nchunk;
-          t_last_gn_chunks = nchunk;
-        }
-      }
-    }
+    // (no GroupNorm statistics from this launch: split tiles leave through the fold, not through the statistics epilogue;
+    // ctta_conv_last_gn_chunks() stays 0 and the caller runs its statistics pass)
     v.launch(p, dim3((unsigned)G, 1, 1), (hipStream_t)stream);
     if (prof_sk) ctta_prof_end((hipStream_t)stream);
     CTTA_LAUNCH_CHECK();

@@ -56,6 +56,13 @@ struct WideCtx {
   int n_lane;
   float4 c4;               // bias + the sample's row vector for the lane's 4 channels (loop invariant on this path)
   int m0, wm, wn;          // tile origin row and the wave's coordinates in the workgroup (GroupNorm partials)
+  // destination of the lane's (chunk 0, pass 0) element: byte offset inside a descriptor of out_bytes bytes at out + gofs.
+  // Plain destination: the whole matrix, offset (m_first * ldc + n_lane) * 2.  ConvTranspose phases (one GEMM row = `stride`
+  // output positions x Cout, per-sample stride, shifted by the padding and clipped at both ends of the sample): the wave's
+  // rows lie in ONE sample b, the descriptor covers that sample's out_limit elements at out + b * obs, the offset is
+  // ((m_first - b * howo) * ldc + n_lane + out_offset) * 2 -- negative (as unsigned: huge) for the elements the padding cuts
+  // off in front, past the extent for those behind: the bounds check is the clipping.
+  int voff0; unsigned out_bytes;
 };
 #define WAVE_LDS_FENCE_() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
@@ -101,21 +108,21 @@ __device__ __forceinline__ void gn_partial_store(const ConvParams& p, float s1, 
 // (gn_partial_store); BM / WM only matter then.
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <int FM, int FN, int CJ, int CHR, int RPW, bool RES, bool OUT2, bool ACC, bool ACT, bool GN = false, int BM = 0, int WM = 0,
-          int RB = 16, int CB = 16>     // RB x CB: pixel rows x channels of one accumulator fragment (32 x 8 behind the 32x32x16 MFMA)
+          int RB = 16, int CB = 16,     // RB x CB: pixel rows x channels of one accumulator fragment
+          bool STR = false>             // strided destination (WideCtx::voff0): the row advance rides in the VECTOR offset
 __device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t (&acc)[FN][FM], const WideCtx& w) {
   constexpr int IT = CHR / RPW;          // read-back passes per chunk
   constexpr int NCH = FM / CJ;           // chunks
   constexpr int QB = (RES || ACC) ? 2 : 4;        // passes read back from LDS at a time
   const float slope = p.out_act == 3 ? p.out_slope : 1.0f;      // max(v, v * 1) == v
   const float alpha = p.alpha, slope2 = p.out2_slope;
-  const unsigned rows_bytes = (unsigned)(((long long)(p.M - 1) * p.ldc + p.n) * 2);
   const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)(reinterpret_cast<bf16_t*>(p.out) + w.gofs), 0, rows_bytes, 0x00020000);
+      (void*)(reinterpret_cast<bf16_t*>(p.out) + w.gofs), 0, w.out_bytes, 0x00020000);
   __amdgpu_buffer_rsrc_t rs2 = rso, rsr = rso;
-  if constexpr (OUT2) rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out2 + w.gofs), 0, rows_bytes, 0x00020000);
+  if constexpr (OUT2) rs2 = __builtin_amdgcn_make_buffer_rsrc((void*)(p.out2 + w.gofs), 0, w.out_bytes, 0x00020000);
   if constexpr (RES)
     rsr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (unsigned)(((long long)(p.M - 1) * p.res_ld + p.n) * 2), 0x00020000);
-  const int voff = (w.m_first * p.ldc + w.n_lane) * 2;          // byte offset of the lane's (chunk 0, pass 0) element
+  const int voff = w.voff0;                                     // byte offset of the lane's (chunk 0, pass 0) element
   const int roff = RES ? (w.m_first * p.res_ld + w.n_lane) * 2 : 0;
   const int ostep = RPW * p.ldc * 2, rstep = RPW * p.res_ld * 2;   // bytes per read-back pass (wave-uniform)
   u32x2_t rr[RES ? IT : 1], oo[ACC ? IT : 1];      // residual / old-output rows, requested a chunk ahead
@@ -169,7 +176,10 @@ __device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t 
           u32x2_t pk;
           pk.x = pack2bf(v[0], v[1]);
           pk.y = pack2bf(v[2], v[3]);
-          __builtin_amdgcn_raw_buffer_store_b64(pk, rso, voff, pass * ostep, 0);
+          // (STR: a lane whose first element the padding cuts off has a NEGATIVE voff; the hardware adds the scalar offset
+          // without wrap-around, so with the row advance there all its later rows would be dropped too)
+          if constexpr (STR) __builtin_amdgcn_raw_buffer_store_b64(pk, rso, voff + pass * ostep, 0, 0);
+          else __builtin_amdgcn_raw_buffer_store_b64(pk, rso, voff, pass * ostep, 0);
           if constexpr (GN) {
             const f32x2_t a = {v[0], v[1]}, b2 = {v[2], v[3]};
             gs1 += a; gs1 += b2;
@@ -183,7 +193,8 @@ __device__ __forceinline__ void wide_epilogue_fast(const ConvParams& p, f32x4_t 
             u32x2_t pk2;
             pk2.x = pack2bf(w2[0], w2[1]);
             pk2.y = pack2bf(w2[2], w2[3]);
-            __builtin_amdgcn_raw_buffer_store_b64(pk2, rs2, voff, pass * ostep, 0);
+            if constexpr (STR) __builtin_amdgcn_raw_buffer_store_b64(pk2, rs2, voff + pass * ostep, 0, 0);
+            else __builtin_amdgcn_raw_buffer_store_b64(pk2, rs2, voff, pass * ostep, 0);
           }
         }
       }
@@ -219,9 +230,8 @@ __device__ __forceinline__ void epilogue_geglu(const ConvParams& p, const f32x4_
 #define WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
                               __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 // One (output tile, K range) segment of a stream-K workgroup (ConvParams::sk_hdr).  mode 0: the whole K walk (plain
-// epilogue); 1: a later part of the tile's K walk -> the accumulators go to this workgroup's slot; 2: the first part ->
-// the partials of ids first_partner .. first_partner + n_partners - 1 are added in that order, then the epilogue.
-struct SkSeg { int kt_begin, nk, mode, id, first_partner, n_partners; unsigned tag; };
+// epilogue); 1: a part of a split tile's K walk -> the accumulators go, as fp32 rows, to partial-tile slot `slot`.
+struct SkSeg { int kt_begin, nk, mode, id, slot; };
 // One output tile: K walk + fused epilogue on v_mfma_f32_16x16x32_bf16 (a fragment = RB x CB = 16 pixels x 16 channels, a lane
 // holds 4 channels of one pixel).  SK: see SkSeg.
 // (Round 6 built the 128x64-per-wave tiles on v_mfma_f32_32x32x16_bf16 as well -- 32 cycles per instruction for twice the FLOPs
@@ -672,18 +682,18 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
   }
 
   if (stamp && threadIdx.x == 0) stamp[3] = __builtin_amdgcn_s_memtime();
-  // ---- stream-K (ConvParams::sk_hdr).  A split tile's partial sums travel as fp32 ROWS ([BM][BN] per workgroup slot, written
-  // through the LDS transpose of the wide-store epilogues), the OWNER's own part included, and the owner then runs the
-  // split-K finish over its tile: rows summed slot by slot in id = K order, fused epilogue per 4 channels (epilogue_store).
+  // ---- stream-K (ConvParams::sk_hdr).  A split tile's partial sums travel as fp32 ROWS ([BM][BN] per slot, written through
+  // the LDS transpose of the wide-store epilogues), the part that holds the tile's first K step included; sk_fold_tile (called
+  // by the kernel below) sums them in K order and runs the fused epilogue.
   // (Not built the cheaper-looking way -- partners' partials added to the owner's accumulators, or to its staged rows inside the
   // straight-line epilogues: any VALU write to the 32 MFMA tuples between main loop and epilogue, even `+= 1.0f`, and any
   // runtime loop inside the unrolled epilogue variants costs this compiler 50-240 spilled registers INSIDE the main loop.)
   const int nsub = (lane / RB) * 4;
   if constexpr (SK) {
-    if (skst && threadIdx.x == 0) skst[sk.mode == 1 ? 2 : 4] = __builtin_amdgcn_s_memtime();
+    if (skst && threadIdx.x == 0) skst[sk.mode == 1 && sk.kt_begin > 0 ? 2 : 4] = __builtin_amdgcn_s_memtime();
     if (sk.mode != 0) {
       // the wave's TM x TN block through its staging rows, out as whole TN * 4-byte row segments, write-through (sc1) so that
-      // no release fence has anything to write back; every wave drains its stores, one lane raises the flag
+      // no release fence has anything to write back; every wave drains its stores before the caller counts the part as arrived
       // (cdna_hip_programming.md Guideline 16, form R1)
       constexpr int NW = WM * WN;
       constexpr size_t RING = (size_t)STAGES * (BM + BN) * BK * 2;
@@ -695,10 +705,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
       const int col4 = lane % LPR, prow = lane / LPR;
       const int m_w = m0 + (wave_u / WN) * TM;
       const int rows_in = min(TM, p.M - m_w);            // rows past M are never read back
-      // slot id: the part this workgroup CONTRIBUTES to its first tile; slot gridDim.x + id: its own part of the tile it OWNS (a
-      // workgroup can be both, and the owner of its first tile may read slot id long after this workgroup has moved on)
-      const int my_slot = sk.mode == 1 ? sk.id : (int)gridDim.x + sk.id;
-      float* obase = p.sk_slots + (size_t)my_slot * (BM * BN) + (size_t)((wave_u / WN) * TM) * BN;
+      float* obase = p.sk_slots + (size_t)sk.slot * (BM * BN) + (size_t)((wave_u / WN) * TM) * BN;
       const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc(
           (void*)obase, 0, rows_in > 0 ? (unsigned)rows_in * (unsigned)BN * 4u : 0u, 0x00020000);
       const unsigned ovoff = (unsigned)(prow * BN + wn * TN + col4 * 4) * 4u;
@@ -725,77 +732,7 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (sk.mode == 1) {
-        if (tid == 0) __hip_atomic_store(p.sk_hdr + SK_FLAGS + sk.id, sk.tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (skst && threadIdx.x == 0) skst[3] = __builtin_amdgcn_s_memtime();
-        return;
-      }
-      if (skst && threadIdx.x == 0) skst[5] = __builtin_amdgcn_s_memtime();
-      // owner: one lane polls the partners' flags (relaxed, bounded), ONE agent-scope acquire (it also drops this CU's stale L1
-      // lines of its own slot), then plain loads
-      if (tid == 0) {
-        for (int c = 0; c < sk.n_partners; ++c) {
-          const unsigned* f = p.sk_hdr + SK_FLAGS + sk.first_partner + c;
-          unsigned spins = 0;
-          while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.tag) {
-            if (++spins > (1u << 22)) { __hip_atomic_fetch_add(p.sk_hdr + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            __builtin_amdgcn_s_sleep(8);
-          }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (skst) skst[6] = __builtin_amdgcn_s_memtime();
-      }
-      __syncthreads();
-      // The fold streams: per pass a lane holds U float4 of the own slot and of two partners' slots in flight (the accumulators
-      // are dead by now: ~200 free registers); partner c + 1 is requested before partner c is added, partners that do not
-      // exist are read through an empty descriptor (zeros, no traffic): the loop body has no branches, the waits are counted.
-      // (The first form -- 8 loads in flight, one partner at a time behind a wait -- folded at ~14 GB/s per workgroup: 65 of the
-      // 112 us of a 4608 x 1024 x 9216 launch, profiles/sweep_r06_streamk_v1.txt.)
-      const int rows = min(BM, p.M - m0);
-      const unsigned tile_bytes = (unsigned)rows * BN * 4u;      // loads past the valid rows return zeros (and are dropped below)
-      constexpr int C4 = BN / 4;
-      constexpr int U = 8;                                       // float4s per lane and slot in flight (x 3 buffers)
-      auto slot_rsrc = [&](int c) {       // c = 0: own part, 1 .. n_partners: the partners' in K order (ids id + 1 ...), beyond: empty
-        const bool ok = c <= sk.n_partners;
-        const int slot = c == 0 ? (int)gridDim.x + sk.id : (ok ? sk.id + c : 0);
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(p.sk_slots + (size_t)slot * (BM * BN)), 0, ok ? tile_bytes : 0u, 0x00020000);
-      };
-      for (int base = 0; base < rows * C4; base += NT * U) {
-        const int vo = (base + tid) * 16;
-        u32x4_t a[U], t0[U], t1[U];
-        __amdgpu_buffer_rsrc_t r = slot_rsrc(0);
-#pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
-        r = slot_rsrc(1);
-#pragma unroll
-        for (int u = 0; u < U; ++u) t0[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
-        for (int c = 1; c <= sk.n_partners; c += 2) {
-          r = slot_rsrc(c + 1);
-#pragma unroll
-          for (int u = 0; u < U; ++u) t1[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[u][e] = __float_as_uint(__uint_as_float(a[u][e]) + __uint_as_float(t0[u][e]));
-          r = slot_rsrc(c + 2);
-#pragma unroll
-          for (int u = 0; u < U; ++u) t0[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
-#pragma unroll
-          for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) a[u][e] = __float_as_uint(__uint_as_float(a[u][e]) + __uint_as_float(t1[u][e]));
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const int idx = base + u * NT + tid;
-          const int row = idx / C4, m = m0 + row, n = n0 + (idx - row * C4) * 4;
-          if (row < rows && n < p.n) {
-            const int b = m / p.howo;
-            epilogue_store(p, (f32x4_t){__uint_as_float(a[u][0]), __uint_as_float(a[u][1]), __uint_as_float(a[u][2]), __uint_as_float(a[u][3])},
-                           m, n, b, m - (long long)b * p.howo, 0);
-          }
-        }
-      }
+      if (skst && threadIdx.x == 0) skst[sk.kt_begin > 0 ? 3 : 5] = __builtin_amdgcn_s_memtime();
       return;
     }
   }
@@ -972,9 +909,12 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
     // make the compiler's wait counts conservative; rows past M fall to the buffer bounds check; edge waves take the
     // generic loop, there is no barrier)
     bool fast_wave = false;
+    const int m_wv = m0 + (wave_u / WN) * TM;                 // this wave's first row
     if (p.epi_fast && n0 + wn * TN + TN <= p.n) {
       const bool one_sample = m0 / p.howo == (min(m0 + BM, p.M) - 1) / p.howo;
       fast_wave = !p.rowvec || one_sample;
+      // a destination with a per-sample stride: the wave's rows (below M) in one sample
+      if (!p.plain_out) fast_wave = fast_wave && (m_wv >= p.M || m_wv / p.howo == (min(m_wv + TM, p.M) - 1) / p.howo);
     }
     if (fast_wave) {
       float4 c4 = bias4;
@@ -982,22 +922,39 @@ __device__ __forceinline__ void conv_tile(const ConvParams& p, unsigned char* sm
         const float4 rv4 = *reinterpret_cast<const float4*>(p.rowvec + (size_t)(m0 / p.howo) * p.rowvec_ld + n_lane);
         c4.x += rv4.x; c4.y += rv4.y; c4.z += rv4.z; c4.w += rv4.w;
       }
-      const WideCtx wc = {stg, RSF, frow, nsub, prow, col4, m0 + wm * TM + prow, (size_t)g * p.ogs, n_lane, c4, m0, wm, wn};
-      if (p.gn_part) {       // host: no accumulate, no second output, alpha == 1, no activation on this path
+      WideCtx wc = {stg, RSF, frow, nsub, prow, col4, m0 + wm * TM + prow, (size_t)g * p.ogs, n_lane, c4, m0, wm, wn,
+                    ((m0 + wm * TM + prow) * p.ldc + n_lane) * 2, (unsigned)(((long long)(p.M - 1) * p.ldc + p.n) * 2)};
+      if (!p.plain_out) {
+        const int b = min(m_wv, p.M - 1) / p.howo;
+        wc.gofs += (size_t)((long long)b * p.obs);
+        wc.voff0 = (int)(((long long)(m0 + wm * TM + prow - b * p.howo) * p.ldc + n_lane + p.out_offset) * 2);
+        wc.out_bytes = (unsigned)(p.out_limit * 2);
+      }
+      if (!p.plain_out) {    // host: no residual, no accumulate, no statistics, no row vector (the ConvTranspose upsamplers)
+        if (p.epi_act) {
+          if (p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, true, false, true, false, 0, 0, RB, CB, true>(p, acc, wc);
+          else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, true, false, 0, 0, RB, CB, true>(p, acc, wc);
+        } else {
+          if (p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, true, false, false, false, 0, 0, RB, CB, true>(p, acc, wc);
+          else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, false, false, 0, 0, RB, CB, true>(p, acc, wc);
+        }
+      } else if (p.gn_part) {       // host: no accumulate, no second output, alpha == 1, no activation on this path
         if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, false, true, BM, WM, RB, CB>(p, acc, wc);
         else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false, false, true, BM, WM, RB, CB>(p, acc, wc);
       } else if (p.epi_act) {
         if (p.accumulate) {
           if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, true, true, false, 0, 0, RB, CB>(p, acc, wc);
           else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, true, true, false, 0, 0, RB, CB>(p, acc, wc);
-        } else if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, true, false, 0, 0, RB, CB>(p, acc, wc);
+        } else if (!p.res && p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, true, false, true, false, 0, 0, RB, CB>(p, acc, wc);
+        else if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, true, false, 0, 0, RB, CB>(p, acc, wc);
         else if (!p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false, true, false, 0, 0, RB, CB>(p, acc, wc);
         else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, true, false, true, false, 0, 0, RB, CB>(p, acc, wc);
       } else {
         if (p.accumulate) {
           if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, true, false, false, 0, 0, RB, CB>(p, acc, wc);
           else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, true, false, false, 0, 0, RB, CB>(p, acc, wc);
-        } else if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, false, false, 0, 0, RB, CB>(p, acc, wc);
+        } else if (!p.res && p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, true, false, false, false, 0, 0, RB, CB>(p, acc, wc);
+        else if (!p.res) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, false, false, false, false, false, 0, 0, RB, CB>(p, acc, wc);
         else if (!p.out2) wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, false, false, false, false, 0, 0, RB, CB>(p, acc, wc);
         else wide_epilogue_fast<FM, FN, CJ, CHR, RPW, true, true, false, false, false, 0, 0, RB, CB>(p, acc, wc);
       }
@@ -1135,36 +1092,124 @@ __global__ __launch_bounds__(64 * WM * WN, conv_min_waves(BM, BN, BK, WM, WN, MO
   if (!conv_block_tile(p, mt, nt, zs_)) return;
   conv_tile<BM, BN, BK, WM, WN, MODE, STAGES, false>(p, smem_raw, mt, nt, zs_, SkSeg{});
 }
+// Stream-K fold: rows [blk * FB, (blk + 1) * FB) of one split tile = the sum of its `parts` partial tiles (slot of part 0, then
+// slot1, slot1 + 1, ...: K order) through the fused epilogue.  Streams: per pass a lane holds U float4 of three slots in flight
+// (part c + 1 is requested before part c is added; parts that do not exist are read through an empty descriptor: zeros, no
+// traffic, no branch).  Whoever runs it gets the same bits: the order is the decomposition's.
+template <int BM, int BN, int NT, int FB>
+__device__ __forceinline__ void sk_fold_block(const ConvParams& p, int mt, int nt, int blk, int slot0, int slot1, int parts) {
+  constexpr int C4 = BN / 4;
+  constexpr int PER = FB * C4 / NT;                       // float4s per lane and block
+  static_assert(PER >= 1 && (FB * C4) % NT == 0 && NT % C4 == 0, "fold block");
+  const int tid = threadIdx.x;
+  const int m0 = p.m_off + mt * BM, n0 = nt * BN;
+  const int rows = min(BM, p.M - m0);
+  const int r_lo = blk * FB;
+  if (r_lo >= rows) return;
+  const unsigned tile_bytes = (unsigned)rows * BN * 4u;   // loads past the valid rows return zeros (and are dropped below)
+  auto rsrc = [&](int c) {
+    const bool ok = c < parts;
+    const int slot = c == 0 ? slot0 : slot1 + c - 1;
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(p.sk_slots + (size_t)(ok ? slot : slot0) * (BM * BN)), 0, ok ? tile_bytes : 0u, 0x00020000);
+  };
+  const int vo = (r_lo * C4 + tid) * 16;
+  u32x4_t a[PER], t0[PER], t1[PER];
+  __amdgpu_buffer_rsrc_t r = rsrc(0);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) a[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
+  r = rsrc(1);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) t0[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
+  for (int c = 1; c < parts; c += 2) {
+    r = rsrc(c + 1);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) t1[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[u][e] = __float_as_uint(__uint_as_float(a[u][e]) + __uint_as_float(t0[u][e]));
+    r = rsrc(c + 2);
+#pragma unroll
+    for (int u = 0; u < PER; ++u) t0[u] = __builtin_amdgcn_raw_buffer_load_b128(r, vo, u * NT * 16, 0);
+#pragma unroll
+    for (int u = 0; u < PER; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[u][e] = __float_as_uint(__uint_as_float(a[u][e]) + __uint_as_float(t1[u][e]));
+  }
+  // the lane's column never changes (NT % C4 == 0): its bias vector is loaded once
+  const int n = n0 + (tid % C4) * 4;
+  const bool n_ok = n < p.n;
+  const bool wide = p.wide_store != 0;
+  float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (wide && p.bias && n_ok) bias4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int row = r_lo + (u * NT + tid) / C4, m = m0 + row;
+    if (row < rows && n_ok) {
+      const float4 q = make_float4(__uint_as_float(a[u][0]), __uint_as_float(a[u][1]), __uint_as_float(a[u][2]), __uint_as_float(a[u][3]));
+      if (wide) epilogue_wide4(p, q, bias4, m, n, 0);
+      else { const int b = m / p.howo; epilogue_store(p, (f32x4_t){q.x, q.y, q.z, q.w}, m, n, b, m - (long long)b * p.howo, 0); }
+    }
+  }
+}
 // Stream-K: one persistent launch (ConvParams::sk_hdr explains the protocol; conv_gemm.hip decides which launches take it).
 template <int BM, int BN, int BK, int WM, int WN, int MODE, int STAGES>
 __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_sk_kernel(ConvParams p) {
+  constexpr int NT = 64 * WM * WN;
+  constexpr int FB = NT * 4 / (BN / 4) < BM ? NT * 4 / (BN / 4) : BM;      // rows per fold block: 4 float4 per lane
+  constexpr int NB = BM / FB;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned* bc = reinterpret_cast<unsigned*>(smem_raw);
-  if (threadIdx.x == 0) {
-    bc[0] = __hip_atomic_fetch_add(p.sk_hdr + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bc[1] = __hip_atomic_load(p.sk_hdr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (threadIdx.x == 0) bc[0] = __hip_atomic_fetch_add(p.sk_hdr + 0, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
   const int G = (int)gridDim.x;
   const int ticket = (int)__builtin_amdgcn_readfirstlane(bc[0]);
-  const unsigned tag = (unsigned)__builtin_amdgcn_readfirstlane(bc[1]) + 1u;
   // XCD chunks.  Workgroups are dispatched round-robin over the 8 XCDs (block b on XCD b % 8: observed, not promised -- only
   // speed depends on it) and tickets follow dispatch, so the tickets t with (t % 8) / r equal -- r = 8 / sk_chunks XCDs -- form
   // one CHUNK that owns a contiguous range of whole tiles and walks it stream-K fashion with its G / sk_chunks workgroups: the
-  // tiles of one weight slab / of neighbouring rows meet in the same L2(s), as in the one-tile-per-workgroup launches (without
-  // it every XCD touches every tile at shifted K phases and nothing is re-used: stream-K ran no faster than the same tile
-  // unsplit, profiles/sweep_r06_streamk_v2.txt).  Inside a chunk a LATER ticket gets a LOWER local id, so the partners of an
-  // owner (the ids behind it) always started before it: forward progress whatever is resident.  No tile spans two chunks.
+  // tiles of one weight slab / of neighbouring rows meet in the same L2(s), as in the one-tile-per-workgroup launches.  No
+  // tile spans two chunks.
   const int nch = p.sk_chunks, r = 8 / nch, per = G / nch;
   const int chunk = (ticket & 7) / r;
-  const int lid = per - 1 - ((ticket >> 3) * r + (ticket & 7) % r);
-  const int id = chunk * per + lid;                                  // slot / flag index
+  const int lid = (ticket >> 3) * r + (ticket & 7) % r;
+  const int id = chunk * per + lid;                                  // slot index
   const int tile_lo = (int)((long long)chunk * p.sk_tiles / nch), tile_hi = (int)((long long)(chunk + 1) * p.sk_tiles / nch);
   const long long items = (long long)(tile_hi - tile_lo) * p.nk;     // of this chunk
   long long a = (long long)lid * items / per;
   const long long b = (long long)(lid + 1) * items / per;
   unsigned steps_a = 0, steps_b = 0, tiles_b = 0;
+  // Fold duty.  A split tile is folded by the workgroups that wrote its parts: each part's arrival is counted in
+  // sk_hdr[SK_FLAGS + tile]; whoever brings the count to `parts` folds at once, the others come back when their own K walk is
+  // over and wait a BOUNDED time for it; every one of them then claims fold blocks (FB rows) from sk_hdr[SK_FLAGS + sk_tiles +
+  // tile] until none is left.  Nobody waits without a bound and the last arriver never waits at all: the launch completes
+  // whatever is resident, whatever the dispatch order (a helper whose patience runs out simply leaves the blocks to the others).
+  int duty0 = -1, duty1 = -1;        // (two scalars: an array indexed at run time would live in scratch)
+  auto tile_parts = [&](int tl, int& first_lid, int& parts) {     // the workgroups (local ids) whose ranges cover chunk tile tl
+    first_lid = (int)((((long long)tl * p.nk + 1) * per - 1) / items);
+    const int last = (int)((((long long)(tl + 1) * p.nk) * per - 1) / items);
+    parts = last - first_lid + 1;
+  };
+  auto tile_mn = [&](int tile, int& mt, int& nt) {
+    if (p.sk_m_inner) { nt = tile / p.m_tiles; mt = tile - nt * p.m_tiles; }
+    else { mt = tile / p.n_tiles; nt = tile - mt * p.n_tiles; }
+  };
+  auto fold = [&](int tl) {       // claim and fold blocks of chunk tile tl (its parts have all arrived)
+    int first_lid, parts, mt, nt;
+    tile_parts(tl, first_lid, parts);
+    tile_mn(tile_lo + tl, mt, nt);
+    const int slot0 = G + chunk * per + first_lid, slot1 = chunk * per + first_lid + 1;
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    for (;;) {
+      __syncthreads();
+      if (threadIdx.x == 0) bc[2] = __hip_atomic_fetch_add(p.sk_hdr + SK_FLAGS + p.sk_tiles + tile_lo + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int blk = (int)__builtin_amdgcn_readfirstlane(bc[2]);
+      if (blk >= NB) break;
+      sk_fold_block<BM, BN, NT, FB>(p, mt, nt, blk, slot0, slot1, parts);
+    }
+  };
+  int n_seg = 0;
   while (a < b) {
     const int tl = (int)(a / p.nk);                                  // tile index inside the chunk
     const int tile = tile_lo + tl;
@@ -1172,22 +1217,48 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_sk_kernel(ConvParam
     const long long tile_end = (long long)(tl + 1) * p.nk;
     const int k1 = (int)((b < tile_end ? b : tile_end) - (long long)tl * p.nk);
     SkSeg sk;
-    sk.kt_begin = k0; sk.nk = k1 - k0; sk.id = id; sk.tag = tag; sk.first_partner = id + 1; sk.n_partners = 0;
-    sk.mode = k0 > 0 ? 1 : 0;
-    if (k0 == 0 && k1 < p.nk) {     // the workgroup of this chunk that holds item tile_end - 1 is the last partner
-      const int last = (int)((tile_end * per - 1) / items);
-      sk.mode = 2; sk.n_partners = last - lid;
-    }
+    sk.kt_begin = k0; sk.nk = k1 - k0; sk.id = id;
+    sk.mode = (k0 > 0 || k1 < p.nk) ? 1 : 0;
+    sk.slot = k0 > 0 ? id : G + id;                                  // the part with the tile's first K step is part 0
     int mt, nt;
-    if (p.sk_m_inner) { nt = tile / p.m_tiles; mt = tile - nt * p.m_tiles; }
-    else { mt = tile / p.n_tiles; nt = tile - mt * p.n_tiles; }
-    if (sk.mode == 1) steps_a += k1 - k0; else { steps_b += k1 - k0; ++tiles_b; }
-    __syncthreads();      // the previous segment's epilogue (and the ticket words) are done with the ring
+    tile_mn(tile, mt, nt);
+    if (k0 > 0) steps_a += k1 - k0; else { steps_b += k1 - k0; ++tiles_b; }
+    __syncthreads();      // the previous segment's epilogue / fold (and the broadcast words) are done with the ring
     conv_tile<BM, BN, BK, WM, WN, MODE, STAGES, true>(p, smem_raw, mt, nt, 0, sk);
+    if (sk.mode == 1) {   // the part is in memory (every wave drained its write-through stores): count it
+      int first_lid, parts;
+      tile_parts(tl, first_lid, parts);
+      __syncthreads();
+      if (threadIdx.x == 0) bc[1] = __hip_atomic_fetch_add(p.sk_hdr + SK_FLAGS + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      if ((int)__builtin_amdgcn_readfirstlane(bc[1]) == parts - 1) fold(tl);      // the last to arrive: fold now, no waiting
+      else if (n_seg == 0) duty0 = tl;                                            // come back at the end
+      else duty1 = tl;
+      ++n_seg;
+    }
     a += k1 - k0;
   }
+  if (p.stamps && threadIdx.x == 0) (p.stamps + (size_t)id * 8)[6] = __builtin_amdgcn_s_memtime();
+#pragma unroll
+  for (int d = 0; d < 2; ++d) {
+    const int tl = d == 0 ? duty0 : duty1;
+    if (tl < 0) continue;
+    int first_lid, parts;
+    tile_parts(tl, first_lid, parts);
+    __syncthreads();
+    if (threadIdx.x == 0) {     // bounded patience: 48 polls, a few tens of microseconds
+      unsigned spins = 0, ok = 1;
+      while (__hip_atomic_load(p.sk_hdr + SK_FLAGS + tile_lo + tl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)parts) {
+        if (++spins > 48u) { ok = 0; break; }
+        __builtin_amdgcn_s_sleep(4);
+      }
+      bc[3] = ok;
+    }
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(bc[3])) fold(tl);
+  }
   __syncthreads();
-  if (p.stamps && threadIdx.x == 0) {      // {hw id | xcc << 32 | K steps as contributor << 36 | as owner << 48 | owned tiles << 60, begin, ..., end}
+  if (p.stamps && threadIdx.x == 0) {      // {hw id | xcc << 32 | K steps in later parts << 36 | in first parts / whole tiles << 48 | those tiles << 60, begin, ..., end}
     unsigned long long* st = p.stamps + (size_t)id * 8;
     st[0] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |
             ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) << 32) | ((unsigned long long)(steps_a & 0xfff) << 36) |
@@ -1195,12 +1266,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void conv_gemm_sk_kernel(ConvParam
     st[1] = t_begin;
     st[7] = __builtin_amdgcn_s_memtime();
   }
-  if (threadIdx.x == 0) {
-    const unsigned d = __hip_atomic_fetch_add(p.sk_hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (d == (unsigned)G - 1u) {      // every workgroup drew its ticket and read the epoch long ago
+  if (threadIdx.x == 0) bc[1] = __hip_atomic_fetch_add(p.sk_hdr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (__builtin_amdgcn_readfirstlane(bc[1]) == (unsigned)G - 1u) {
+    // the last workgroup to finish: every ticket was drawn, every part counted, every block claimed long ago -- the header goes
+    // back to zeros for the next launch on this workspace
+    for (int i = threadIdx.x; i < 2 * p.sk_tiles; i += NT) __hip_atomic_store(p.sk_hdr + SK_FLAGS + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
       __hip_atomic_store(p.sk_hdr + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(p.sk_hdr + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(p.sk_hdr + 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(p.sk_hdr + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // launches seen (tests)
     }
   }
 }

@@ -545,6 +545,60 @@ def test_conv_transpose1d_as_phase_gemm(k, u):
     assert rel_err(got, ref) < BF16_TOL
 
 
+@pytest.mark.parametrize("tile", [0, 17, 29, 31, 36])
+@pytest.mark.parametrize("with_out2", [False, True])
+def test_conv_transpose1d_rows_leave_through_the_straight_line_epilogue(tile, with_out2):
+    """The HiFi-GAN upsamplers at a size where the 128x64-per-wave tiles run (B = 3, L = 333 -> 1332, 128 -> 64 channels, k = 8,
+    u = 4: one GEMM row = 4 output positions x 64 channels, per-sample stride, shifted by the padding, clipped at both ends).
+    Since round 6 a wave whose rows lie in one sample stores through ONE buffer descriptor over that sample -- the bounds check
+    does the clipping, no divergent `if (row < M)` around a store -- with or without the second (LeakyReLU'd) output; waves that
+    straddle two samples (Q = 334 rows per sample against 64..128-row wave blocks) take the generic loop.  Both must give
+    conv_transpose1d, and the poisoned bytes around every sample must stay untouched."""
+    B, Cin, Cout, L, k, u = 3, 128, 64, 333, 8, 4
+    pad = (k - u) // 2
+    x = bf16_round(det("ctf.x", (B, Cin, L), 1))
+    w = bf16_round(det("ctf.w", (Cin, Cout, k), 2) * (1.0 / math.sqrt(Cin * k / u)))
+    b = det("ctf.b", (Cout,), 3) * 0.1
+    ref = F.conv_transpose1d(x, w, b, stride=u, padding=pad)
+    Lout = ref.shape[2]
+    taps = (k + u - 1) // u
+    K = taps * Cin
+    k_pad = (K + 63) // 64 * 64
+    n = u * Cout
+    ro = torch.tensor([o * k + r for r in range(u) for o in range(Cout)], dtype=torch.int32)
+    ra = torch.tensor([r for r in range(u) for o in range(Cout)], dtype=torch.int32)
+    co = torch.full((k_pad,), -1, dtype=torch.int32)
+    ca = torch.zeros(k_pad, dtype=torch.int32)
+    for t in range(taps):
+        m = taps - 1 - t
+        for c in range(Cin):
+            co[t * Cin + c] = c * Cout * k + m * u
+            ca[t * Cin + c] = m * u
+    wd = w.contiguous().to(DEV)
+    wp = torch.empty(n, k_pad, dtype=torch.bfloat16, device=DEV)
+    ro, co, ra, ca = ro.to(DEV), co.to(DEV), ra.to(DEV), ca.to(DEV)
+    N.check(lib().ctta_pack_weight(N.ptr(wd), N.ptr(ro), N.ptr(co), N.ptr(ra), N.ptr(ca), k, n, k_pad, N.ptr(wp), N.stream_ptr()))
+    bias = b.repeat(u).contiguous().to(DEV)
+    Q = (Lout - 1 + pad) // u + 1
+    guard = 256                                       # poisoned elements in front of / behind the whole output
+    buf = torch.full((guard + B * Lout * Cout + guard,), 7.0, dtype=torch.bfloat16, device=DEV)
+    buf2 = torch.full_like(buf, 9.0)
+    out, out2 = buf[guard:guard + B * Lout * Cout], buf2[guard:guard + B * Lout * Cout]
+    xa = x.permute(0, 2, 1).contiguous().to(torch.bfloat16).to(DEV)
+    kw = dict(x0=xa, c0=Cin, batch=B, hi=1, wi=L, ho=1, wo=Q, kh=1, kw=taps, pad_w=taps - 1, w=wp, k_pad=k_pad, n=n, bias=bias,
+              out=out, ldc=u * Cout, out_batch_stride=Lout * Cout, out_offset=-pad * Cout, out_limit=Lout * Cout, tile=tile)
+    if with_out2:
+        kw.update(out2=out2, out2_slope=0.1)
+    run_conv(conv_desc(**kw))
+    got = out.view(B, Lout, Cout).to(torch.float32).permute(0, 2, 1).cpu()
+    assert rel_err(got, ref) < BF16_TOL
+    assert bool((buf[:guard] == 7.0).all()) and bool((buf[-guard:] == 7.0).all())
+    if with_out2:
+        got2 = out2.view(B, Lout, Cout).to(torch.float32).permute(0, 2, 1).cpu()
+        assert torch.equal(got2, bf16_round(F.leaky_relu(got, 0.1)))      # leaky_relu of the SAME (bf16-rounded) values
+        assert bool((buf2[:guard] == 9.0).all()) and bool((buf2[-guard:] == 9.0).all())
+
+
 def test_batched_gemm_f32_and_transposed_product():
     """q k^T per batch with fp32 output (VAE AttnBlock scores) and V^T = Wv X^T + bv[row]."""
     B, Nt, C = 2, 128, 64

@@ -86,6 +86,22 @@ def test_splitk_off_walks_the_whole_k_in_one_workgroup(option):
     assert torch.equal(a, c)              # this shape takes the two-pass split either way
 
 
+def test_streamk_off_takes_the_two_pass_split_on_the_same_tile(option):
+    """The rule's own territory (K >= 8192, 64 .. 191 big tiles: the distillation teacher's 4608 x 1024 x 9216): by default the
+    launch is stream-K on the 256x256x64 tile = what tile 41 gives bit for bit; "streamk" = 0 leaves the same tile with the
+    two-pass split-K = tile 29 bit for bit; both within the bf16 tolerance of F.conv2d and of each other."""
+    shape = (18, 1024, 64, 4, 1024)
+    a, ref = _conv(*shape)
+    a41, _ = _conv(*shape, tile=41)
+    option("streamk", 0)
+    b, _ = _conv(*shape)
+    b29, _ = _conv(*shape, tile=29)
+    option("streamk", 1)
+    assert torch.equal(a, a41) and torch.equal(b, b29) and not torch.equal(a, b)
+    assert rel_err(from_nhwc(a), ref) < 2 * BF16_TOL and rel_err(from_nhwc(b), ref) < 2 * BF16_TOL
+    assert rel_err(from_nhwc(a), from_nhwc(b)) < BF16_TOL
+
+
 @pytest.mark.parametrize("grid", [3, 8, 24, 100])
 def test_streamk_grid_changes_the_decomposition_not_the_result(option, grid):
     """"streamk_grid" = G: a stream-K launch (tile 41) on G workgroups instead of one per CU slot.  Every G gives another cut
@@ -103,7 +119,7 @@ def test_streamk_grid_changes_the_decomposition_not_the_result(option, grid):
 
 def test_wgrad_stream_off_gives_the_same_gradients(option):
     """"wgrad_stream" = 0 at a backward call: the weight-gradient jobs run on the caller's stream in the same scratch slots
-    (what bench.py's profiled step needs).  Same kernels, same operands, same order per tensor: bit-identical gradients; and a
+    (what bench.py's profiled step needs).  Same kernels, same operands: the gradients agree to run-to-run round-off; and a
     handle CREATED with the option off (no side stream at all, the backward releases its arena blocks) agrees too."""
     cfg = cases.TINY_UNET
     sd = cases.unet_weights(cfg, True, 1)
@@ -130,10 +146,14 @@ def test_wgrad_stream_off_gives_the_same_gradients(option):
     g_never = grads(m2)                    # a handle that never had one
     option("wgrad_stream", 1)
     g_back = grads(m)
+    # (not bit-for-bit: LayerNorm's d gamma / d beta and the embedding MLPs fold per-block partials with fp32 atomics, whose
+    # order differs from run to run even with every setting equal -- test_train_gpu.py states 1e-7 for two runs)
+    def close(a, b_):
+        return float((a - b_).norm() / b_.norm().clamp_min(1e-20)) < 2e-6
     for k in g_on:
-        assert torch.equal(g_on[k], g_off[k]), k
-        assert torch.equal(g_on[k], g_never[k]), k
-        assert torch.equal(g_on[k], g_back[k]), k
+        assert close(g_off[k], g_on[k]), k
+        assert close(g_never[k], g_on[k]), k
+        assert close(g_back[k], g_on[k]), k
 
 
 def test_gn_fuse_and_fused_res_off_agree_with_the_defaults(option):

@@ -225,36 +225,63 @@ def test_train_step_adamw_and_ema_match_torch(golden):
 def test_fused_optimizer_tail_gives_the_same_training_state_as_the_three_launches(golden, monkeypatch):
     """AudioLCM.train_step ends with AdamW -> zero_grad -> EMA x 2 (tools/train_utils.py:177-183).  From the second step on
     (the first one validates the flat-buffer layout of the four networks) that tail is ONE launch, ctta_adamw_ema2_zero;
-    CTTA_FUSED_TAIL=0 keeps the three.  Same draws, four steps each way: student, target and EMA weights, both Adam moments
-    and the learning-rate schedule are bit-identical, the gradient buffer is zero, and the fused form really ran."""
+    CTTA_FUSED_TAIL=0 keeps the three.  Here the tail alone, on the model's own buffers: the SAME gradient, weights, moments
+    and schedule go through `_optimizer_tail` both ways (the whole step cannot be compared bit for bit across two runs: the
+    backward folds some partials with fp32 atomics, and AdamW turns 1e-8 of gradient noise into lr-sized steps).  Student,
+    target and EMA weights, both moments, the learning rate and the step count come out bit-identical, the gradient buffer
+    zero, and the fused form really ran -- also with do_step = False, the NaN-loss skip."""
     from consistencytta_amd.optim import WarmupSchedule
     g = golden("distill_tiny")
     kw = dict(time_inds=torch.from_numpy(g["time_inds"]) * 2, gaussian_noise=torch.from_numpy(g["noise"]).to(DEV),
               guidance_scale=torch.from_numpy(g["guidance"]))
-    states = []
-    for fused in ("1", "0"):
-        monkeypatch.setenv("CTTA_FUSED_TAIL", fused)
-        m, P, z0 = _lcm()
-        m.train()
-        opt = m.prepare_training(lr=1e-3, weight_decay=1e-2, broadcast=False)
-        sched = WarmupSchedule(opt, "linear", num_warmup_steps=2, num_training_steps=10)
-        calls = []
-        real = opt.step_zero_ema
-        opt.step_zero_ema = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
-        losses = [m.train_step(z0, P, opt, sched, **kw) for _ in range(4)]
-        torch.cuda.synchronize()
-        if opt.n % 4 == 0 and opt.flat.numel() % 4 == 0:
-            assert len(calls) == (3 if fused == "1" else 0), calls
-        assert not bool(opt.grad.any())
-        states.append((losses, [p.detach().clone() for n_ in ("student_unet", "student_target_unet", "student_ema_unet")
-                                for p in getattr(m, n_).parameters()], opt.exp_avg.clone(), opt.exp_avg_sq.clone(),
-                       opt.param_groups[0]["lr"], opt.step_count))
-        del m, opt
-    (la, pa, ma, va, lra, sa), (lb, pb, mb, vb, lrb, sb_) = states
-    assert la == lb and lra == lrb and sa == sb_ == 4
-    assert torch.equal(ma, mb) and torch.equal(va, vb)
-    for x, y in zip(pa, pb):
-        assert torch.equal(x, y)
+    m, P, z0 = _lcm()
+    m.train()
+    opt = m.prepare_training(lr=1e-3, weight_decay=1e-2, broadcast=False)
+    sched = WarmupSchedule(opt, "linear", num_warmup_steps=2, num_training_steps=10)
+    m.train_step(z0, P, opt, sched, **kw)            # validates the layout (three launches), leaves real moments behind
+    nets = (m.student_unet, m.student_target_unet, m.student_ema_unet)
+    gen = torch.Generator().manual_seed(3)
+    grad = (torch.randn(opt.grad.numel(), generator=gen) * 1e-3).to(DEV)
+    grad[opt.n:] = 0
+
+    def snapshot():
+        return ([n_._flat.clone() for n_ in nets], opt.exp_avg.clone(), opt.exp_avg_sq.clone(), opt.step_count,
+                opt.param_groups[0]["lr"], dict(sched.__dict__) if hasattr(sched, "__dict__") else None)
+
+    def restore(s_):
+        for n_, f in zip(nets, s_[0]):
+            n_._flat.copy_(f)
+        opt.exp_avg.copy_(s_[1]); opt.exp_avg_sq.copy_(s_[2])
+        opt.step_count = s_[3]
+        opt.param_groups[0]["lr"] = s_[4]
+        if s_[5] is not None:
+            sched.__dict__.update(s_[5])
+
+    start = snapshot()
+    can_fuse = opt.n % 4 == 0 and opt.flat.numel() % 4 == 0
+    for do_step in (True, False):
+        results = []
+        for fused in ("1", "0"):
+            monkeypatch.setenv("CTTA_FUSED_TAIL", fused)
+            restore(start)
+            opt.grad.copy_(grad)
+            calls = []
+            real = opt.step_zero_ema
+            opt.step_zero_ema = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+            m._optimizer_tail(opt, sched, 0.5, do_step)
+            opt.step_zero_ema = real
+            torch.cuda.synchronize()
+            if can_fuse:
+                assert len(calls) == (1 if fused == "1" else 0), (fused, calls)
+            assert not bool(opt.grad.any())
+            results.append(snapshot())
+        a, b = results
+        assert a[3] == b[3] == start[3] + (1 if do_step else 0) and a[4] == b[4]
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        for x, y in zip(a[0], b[0]):
+            assert torch.equal(x, y)
+        assert not torch.equal(a[0][1], start[0][1])                     # the shadows moved ...
+        assert torch.equal(a[0][0], start[0][0]) == (not do_step)        # ... and the student only when the step was taken
 
 
 def test_blockwise_backward_with_rccl_buckets_equals_monolithic(golden):

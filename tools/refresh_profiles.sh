@@ -12,11 +12,14 @@ python3 $R/bench.py > $O/bench.json 2> $O/bench.err
 #   gen:     CTTA_BENCH_MINIMAL=1 CTTA_BENCH_GRAPH=0 -> 2 x (1 warm-up + 5 timed) + 1 = 13 eager batch-32 steps, nothing else
 #   distill: CTTA_BENCH_DISTILL_FORMS=eager          -> 1 + 5 eager optimizer steps at batch 9 (+ 2 loss-only forwards of the fixed draw)
 CTTA_BENCH_MINIMAL=1 CTTA_BENCH_GRAPH=0 rocprofv3 --kernel-trace --stats -d $O/prof_gen -o p -- python3 $R/bench.py --mode gen --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_gen.log 2>&1
-CTTA_BENCH_DISTILL_FORMS=eager rocprofv3 --kernel-trace --stats -d $O/prof_distill -o p -- python3 $R/bench.py --mode distill --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_distill.log 2>&1
+# (round 6: the distillation table is taken in the SINGLE-STREAM form -- no student side stream, no weight-gradient side stream --
+#  so that the kernel times of the table add up to a duration: CTTA_TWO_STREAM=0 is AudioLCM's switch, CTTA_OPT_WGRAD_STREAM=0 the
+#  library option "wgrad_stream" as _native applies it at load)
+CTTA_TWO_STREAM=0 CTTA_OPT_WGRAD_STREAM=0 CTTA_BENCH_DISTILL_FORMS=eager rocprofv3 --kernel-trace --stats -d $O/prof_distill -o p -- python3 $R/bench.py --mode distill --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_distill.log 2>&1
 db=$(find $O/prof_gen -name '*.db' | head -1)
 [ -n "$db" ] && python3 $R/tools/rocpd_stats.py $db $O/rocprof_stats_gen.md "rocprofv3 --kernel-trace over: CTTA_BENCH_MINIMAL=1 CTTA_BENCH_GRAPH=0 bench.py --mode gen --steps 5 --warmup 1 = 13 eager batch-32 generation steps (2 x (1 + 5) timed-loop steps + 1), model set-up kernels (weight init / pack) included" > /dev/null
 db=$(find $O/prof_distill -name '*.db' | head -1)
-[ -n "$db" ] && python3 $R/tools/rocpd_stats.py $db $O/rocprof_stats_distill.md "rocprofv3 --kernel-trace over: CTTA_BENCH_DISTILL_FORMS=eager bench.py --mode distill --steps 5 --warmup 1 = 6 eager optimizer steps at batch 9 (two streams + weight-gradient side stream) + 2 loss-only forward passes of the fixed draw, model set-up kernels included" > /dev/null
+[ -n "$db" ] && python3 $R/tools/rocpd_stats.py $db $O/rocprof_stats_distill.md "rocprofv3 --kernel-trace over: CTTA_BENCH_DISTILL_FORMS=eager bench.py --mode distill --steps 5 --warmup 1 = 6 eager optimizer steps at batch 9, every launch on ONE stream (CTTA_TWO_STREAM=0, option wgrad_stream=0: kernel times add up) + 2 loss-only forward passes of the fixed draw + the single-stream profiled step of the roofline object = 7 step-equivalents of MFMA work, model set-up kernels included" > /dev/null
 python3 $R/bench.py --mode gen --steps 3 --warmup 1 --no-cpu-baseline --profile-csv $O/launch_gen.csv > /dev/null 2>&1
 python3 $R/tools/launch_table.py $O/launch_gen.csv 60 2 > $O/launch_table_gen.txt 2>&1
 CTTA_BENCH_DISTILL_FORMS=none python3 $R/bench.py --mode distill --steps 3 --warmup 1 --no-cpu-baseline --profile-csv $O/launch_distill.csv > /dev/null 2>&1

@@ -90,23 +90,22 @@ sa = ((w0 >> np.uint64(36)) & np.uint64(0xfff)).astype(np.int64)
 sb = ((w0 >> np.uint64(48)) & np.uint64(0xfff)).astype(np.int64)
 tb = ((w0 >> np.uint64(60)) & np.uint64(0xf)).astype(np.int64)
 xcc = ((w0 >> np.uint64(32)) & np.uint64(0xf)).astype(np.int64)
-t = s[:, 1:8].astype(np.float64) / MHz     # begin, A main end, A end, B main end, B dump end, partners ready, end
-t0 = t[:, 0].min()
-print(" stream-K: %d workgroups (per XCC %s), span %.1f us; K steps per workgroup: contributor %.1f + owner %.1f" % (
-    len(s), np.bincount(xcc, minlength=8).tolist(), t[:, 6].max() - t0, sa.mean(), sb.mean()))
-stats("start after first (us)", t[:, 0] - t0)
+t = s[:, 1:8].astype(np.float64) / MHz     # begin, later-part main end, its write-out end, first-part main end, its write-out end, K walk over, end
+# (s_memtime is per XCD: only differences inside one workgroup mean anything)
+print(" stream-K: %d workgroups (per XCC %s); K steps per workgroup: later parts %.1f + first parts / whole tiles %.1f" % (
+    len(s), np.bincount(xcc, minlength=8).tolist(), sa.mean(), sb.mean()))
 ca = sa > 0
-stats("contributor segment: main (us)", (t[ca, 1] - t[ca, 0]))
-stats("   per K step (us)", (t[ca, 1] - t[ca, 0]) / np.maximum(sa[ca], 1))
-stats("   write-out + flag (us)", t[ca, 2] - t[ca, 1])
+stats("later part of a tile: main (ticks/100)", (t[ca, 1] - t[ca, 0]))
+stats("   per K step", (t[ca, 1] - t[ca, 0]) / np.maximum(sa[ca], 1))
+stats("   write-out", t[ca, 2] - t[ca, 1])
 ob = (sb > 0) & (tb == 1)
 start_b = np.where(ca, t[:, 2], t[:, 0])
-stats("owner segment (one tile): main (us)", t[ob, 3] - start_b[ob])
-stats("   per K step (us)", (t[ob, 3] - start_b[ob]) / np.maximum(sb[ob], 1))
+stats("first part / whole tile: main", t[ob, 3] - start_b[ob])
+stats("   per K step", (t[ob, 3] - start_b[ob]) / np.maximum(sb[ob], 1))
 sp = ob & (s[:, 5] != 0)
-stats("   split tiles: own write-out (us)", t[sp, 4] - t[sp, 3])
-stats("   wait for partners + acquire (us)", t[sp, 5] - t[sp, 4])
-stats("   fold + epilogue (us)", t[sp, 6] - t[sp, 5])
+stats("   split: write-out", t[sp, 4] - t[sp, 3])
+stats("   split: count + inline fold", t[sp, 5] - t[sp, 4])
 un = ob & (s[:, 5] == 0)
-stats("   whole tiles: epilogue (us)", t[un, 6] - t[un, 3])
-stats("end after first start (us)", t[:, 6] - t0)
+stats("   whole: epilogue", t[un, 5] - t[un, 3])
+stats("after the K walk: waits + folds", t[:, 6] - t[:, 5])
+stats("whole workgroup", t[:, 6] - t[:, 0])
