@@ -57,6 +57,8 @@ def parse():
                     help="for the rocprofv3 --pmc passes: no hipGraph anywhere (the headline loop times eager launches, the "
                          "single-clip eager/hipGraph latency leg is skipped -- a graph replay under --pmc hung on this pool in "
                          "round 1) and, in --mode distill, no AdamW / EMA timing passes and no wav -> latent leg")
+    ap.add_argument("--perceptual-fused-batch", type=int, default=45,
+                    help="micro-batch of the configs[4] `fused_micro_batch` leg (train.sh accumulates 15 x 3 samples per GPU)")
     ap.add_argument("--perceptual-batch", type=int, default=4,
                     help="per-GPU micro-batch of the perceptual-loss leg (configs[4] without CLAP)")
     ap.add_argument("--profile-csv", default=None, help="append one line per MFMA launch (tuning aid)")
@@ -864,6 +866,56 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                                      "ground-truth clip, RoBERTa-base text features) and its input gradient back through "
                                      "vocoder, decoder and U-Net; CLAPLoss(mse 1.0, clap 0.1); AdamW, EMA; random-init CLAP "
                                      "weights (no checkpoint offline)")
+        # train.sh:38-46 reaches its 45 samples per optimizer step as 15 accumulated micro-batches of 3 per GPU -- what fits a
+        # 40-80 GB card next to four U-Nets, the decoder, the vocoder and two CLAP towers with their activations.  One MI355X
+        # holds far more: the same optimizer step as FEWER, LARGER micro-batches (same samples per step, same mathematics:
+        # tests/test_train_gpu.py::test_fused_accumulation...), eager launches.  --perceptual-fused-batch sets the micro-batch.
+        Bf = int(args.perceptual_fused_batch)
+        if Bf > B and not args.no_latency and os.environ.get("CTTA_BENCH_FUSED_ACCUM", "1") != "0":
+            zf = Pf = gtf = why = None
+            try:
+                gf = torch.Generator(device="cpu").manual_seed(56 + rank)
+                zf = (torch.randn(Bf, 8, 256, 16, generator=gf) * 0.9).to(dev)
+                encf = (torch.randn(Bf, L, 1024, generator=gf) * 0.25).to(dev)
+                lensf = torch.randint(6, L + 1, (Bf,), generator=gf)
+                maskf = (torch.arange(L)[None, :] < lensf[:, None]).to(dev)
+                uncf, umf = torch.zeros_like(encf), torch.zeros_like(maskf)
+                umf[:, 0] = True
+                idsf = torch.randint(4, 50000, (Bf, 77), generator=gf)
+                tlf = torch.randint(5, 30, (Bf,), generator=gf)
+                tmf = (torch.arange(77)[None, :] < tlf[:, None]).long()
+                idsf = torch.where(tmf == 1, idsf, torch.ones_like(idsf))
+                Pf = {"embeds_cf": torch.cat([uncf, encf]), "mask_cf": torch.cat([umf, maskf]), "embeds": encf, "mask": maskf,
+                      "clap_text_features": clap.model.get_text_embedding({"input_ids": idsf.to(dev), "attention_mask": tmf.to(dev)})}
+                gtf = (torch.rand(Bf, 160000, generator=gf) * 2 - 1).to(dev) * 0.3
+            except Exception as exc:
+                why, zf = "rank %d: %s" % (rank, str(exc)[:160]), None
+            if du.all_agree(zf is not None, dev):
+                ok, n_f = True, 3
+                try:
+                    for _ in range(2):
+                        losses.append(m.train_step(zf, Pf, opt, sched, gt_wav=gtf))
+                    du.barrier(dev)
+                    t0 = time.perf_counter()
+                    for _ in range(n_f):
+                        losses.append(m.train_step(zf, Pf, opt, sched, gt_wav=gtf))
+                    du.barrier(dev)
+                    dtf = du.max_over_ranks(time.perf_counter() - t0, dev)
+                except Exception as exc:      # (an out-of-memory at this size must not cost the line on one GPU)
+                    if world > 1:
+                        raise
+                    ok, why = False, str(exc)[:200]
+                if ok:
+                    out["fused_micro_batch"] = {"micro_batch_per_gpu": Bf, "samples_per_s": round(world * Bf * n_f / dtf, 3),
+                                                "ms_per_step": round(dtf / n_f * 1e3, 3), "steps": n_f, "launch": "eager launches",
+                                                "frac_end_to_end_unet_only": round(GF_DISTILL_PER_SAMPLE * 1e9 * Bf / (dtf / n_f) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                                "note": "%d samples as ONE micro-batch (train.sh accumulates 15 x 3 per GPU); samples_per_s of the "
+                                                        "headline above: %.1f" % (Bf, world * B * n_steps / dt)}
+                else:
+                    out["fused_micro_batch"] = {"skipped": why}
+            else:
+                out["fused_micro_batch"] = {"skipped": why or "input set-up failed on another rank"}
+            del zf, Pf, gtf
         del m, opt, vae, clap
         return out
     # train.sh:33's recipe accumulates 5 micro-batches per optimizer step (SURVEY 8d "grad-accum 1 and 5"): 4 local

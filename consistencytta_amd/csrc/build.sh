@@ -6,7 +6,7 @@ OUT=../libctta_hip.so
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 # -fno-slp-vectorize: clang's SLP vectoriser pairs scalar fp32 work into v_pk_*_f32 with op_sel source swizzles, and
 # `v_pk_fma_f32 ... op_sel:[0,1,0]` returns wrong low-lane results on these MI355X boxes while waves of ANOTHER kernel issue
-# MFMAs on the same CU (tools/pk_hazard.py) -- which is what two engine handles on two streams do.
+# MFMAs on the same CU (tools/pk_hazard.py; LABNOTES.md 5) -- which is what two engine handles on two streams do.
 # tools/check_isa.py (also a test) verifies that the built library contains no such form.
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-variable -Wno-pass-failed ${CTTA_EXTRA_FLAGS:-}"
 mkdir -p build

@@ -360,7 +360,10 @@ static int pick_variant(long long M, int N, long long K, int groups) {
   // and batch 9 (288) do NOT: 723 vs 866, 665 vs 768 -- profiles/sweep_r03.txt, u32 / t16 / t18 rows.
   if (t128 >= 400 && t128 < 1024 && K >= 512 && t128 * 100 >= ((t128 + 511) / 512) * 512 * 85) return 1;
   if (t128 < 1024 && (K < 4096 || t128 < 400 || N <= 512)) return 6;                    // thin grids (distillation micro-batch): 64x128x64 doubles the workgroups
-  if (t128 < 1536 && K >= 1024 && N <= 512) return 6;      // batch 18 at level 0 (M = 73728, N = 256: 1152 tiles): 828-910 vs 730 on 128x128x32
+  // batch 18 at level 0 (M = 73728, N = 256: 1152 tiles = 2.25 rounds of 512 slots): the thin-grid tile beats 128x128x32
+  // (828-910 vs 730, round 3) -- and from K = 2048 up 128x128x64 beats both (round 6, profiles/sweep_r06_streamk_v3_coop_fold.txt:
+  // K = 4608 942 vs 798 on the 3-stage ring, K = 2304 866 vs 746-779)
+  if (t128 < 1536 && K >= 1024 && N <= 512) return K >= 2048 ? 1 : 6;
   if (K >= 4096) return N >= 256 ? 1 : 6;                  // 128x128x64 / 64x128x64
   if (K > 1536) return M >= 400000 ? 6 : 2;                // 64x128x64 / 128x128x32
   return N >= 256 ? 2 : 6;                                 // 128x128x32 / 64x128x64 (re-swept with the wide-store epilogue)

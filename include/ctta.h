@@ -788,7 +788,7 @@ ctta_status ctta_adamw_ema2_zero(float* param, float* grad, float* exp_avg, floa
  * appends one CSV line per launch (kind,variant,m,n,k,groups,ms,tflops) and clears the log. */
 /* GroupNorm statistics from the producing convolution's epilogue (default on; option "gn_fuse" = 0 /
  * ctta_set_gn_fuse(0) turn it off, process-wide, taking effect at the next engine call).  Off: a sample's result is
- * bit-identical at every batch size; on: at a fixed batch size. */
+ * bit-identical at every batch size; on: at a fixed batch size (LABNOTES.md 4). */
 void ctta_set_gn_fuse(int on);
 int ctta_get_gn_fuse(void);
 void ctta_prof_enable(int on);

@@ -24,7 +24,7 @@ from oracle import clap as oclap  # noqa: E402
 KAISER = dict(lowpass_filter_width=64, rolloff=0.9475937167399596, beta=14.769656459379492)
 # Sampled-gradient budget of the real-size CLAP fine-tuning step (per block and overall).  Measured on MI355X: loss 0.547995
 # vs the reference's 0.547909, sampled gradient rel-L2 5.1e-3 over all blocks, worst block 9.0e-3, worst per-tensor norm
-# deviation 2.2e-3 -- the MSE term dominates the gradient at this size, so the vocoder's mask flips (0.13..0.19 on
+# deviation 2.2e-3 -- the MSE term dominates the gradient at this size, so the vocoder's mask flips (LABNOTES.md 4b: 0.13..0.19 on
 # the vocoder's own input gradient) stay below the bf16 noise of the U-Net backward.  Budget = the distillation step's.
 CLAPFT_GRAD_REL_L2 = 4e-2
 
@@ -258,7 +258,8 @@ def test_clap_loss_end_to_end_matches_oracle():
     np.testing.assert_allclose(inst.detach().cpu().numpy(), ref.detach().numpy(), rtol=3e-2)
     gl2 = rel_l2(zd.grad, zo.grad)
     print("CLAP loss d/d latent rel_l2 %.3e" % gl2)
-    assert gl2 < 0.3      # dominated by the piecewise-linear vocoder's mask flips; the tower alone: 5e-2
+    assert gl2 < 4e-2     # measured 3.0e-2 on MI355X (round 6) + 30 %: the piecewise-linear vocoder's mask flips dominate it
+                          # (LABNOTES.md 4b: 0.13..0.19 on the vocoder's OWN input gradient); the bound stood at 0.3 for three rounds
 
 
 def test_audiolcm_clap_finetune_step_runs_and_moves_the_student():

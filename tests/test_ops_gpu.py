@@ -1045,7 +1045,7 @@ def test_stft_magnitude_and_input_gradient_against_torch_stft_float64(fft, hop, 
 def test_fp32_mlp_kernel_is_exact_beside_a_concurrent_conv_gemm():
     """Two engine handles on two streams put kernels of different kinds on one CU.  The fp32 MLP kernel once returned wrong
     rows there: an SLP-generated `v_pk_fma_f32 ... op_sel:[0,1,0]` reads a wrong dword beside another kernel's MFMA waves
-    (tools/pk_hazard.py, DESIGN.md 5).  The library is built without that form (tools/check_isa.py is the static guard);
+    (tools/pk_hazard.py, LABNOTES.md 5).  The library is built without that form (tools/check_isa.py is the static guard);
     this is the dynamic one: a dependent pair of ctta_linear_f32 launches on fresh inputs beside three big conv_gemm
     launches on a second stream must match torch every time."""
     L = N.lib()

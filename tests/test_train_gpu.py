@@ -989,7 +989,7 @@ def test_distillation_step_full_batch_is_deterministic_and_blockwise_exact():
     print("B=9 light: loss %.6f, |grad| %.4e, run-to-run rel diff %.2e, block-wise vs monolithic %.2e" % (l1, ref, d12, d13))
     # Only the LayerNorm gamma/beta fp32 atomics may differ in the last bit: 1.5e-8 measured with BOTH stream overlaps on
     # (the default: CTTA_TWO_STREAM / option "wgrad_stream").  The 1.5e-7..3.8e-7 once seen with a second hardware queue were the
-    # v_pk_fma_f32 op_sel hazard, gone since the library is built with -fno-slp-vectorize.
+    # v_pk_fma_f32 op_sel hazard (LABNOTES.md 5), gone since the library is built with -fno-slp-vectorize.
     assert d12 <= 1e-7 and d13 <= 1e-7
     # the hipGraph-captured step at THIS size (what bench.py times) against the eager one -- loss bit
     # for bit and the whole 559 M-element gradient, for the monolithic capture and for the segmented one (1 + 11 graphs,

@@ -7,7 +7,7 @@
 A loop body (label .. backward branch to it, no other label inside) with one or two `global_load` / `buffer_load`
 instructions, an `s_waitcnt vmcnt(0)` and no MFMA is one memory round trip per iteration and lane: fine for a tail loop,
 a latency chain when it is the main loop of a streaming kernel (round 4: the slab sums of `wgrad_scatter_rows_kernel` and
-`splitk_finish_kernel`, the pixel loop of `gn_partial_kernel` -- DESIGN.md 4e).  Prints `file kernel loads lines` per loop."""
+`splitk_finish_kernel`, the pixel loop of `gn_partial_kernel` -- LABNOTES.md 4e).  Prints `file kernel loads lines` per loop."""
 import re
 import sys
 

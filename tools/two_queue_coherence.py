@@ -8,7 +8,7 @@ torch.  Side stream (non-blocking), concurrently: nothing / three big-tile ctta_
 launches / twenty torch matmuls.  Measured on MI355X, ROCm 7.0 runtime of the PyTorch wheel: `conv` 40 of 40 iterations
 wrong (stale reads: the rerun without concurrency is right), `none` / `lin` / `torch` 0 of 40, GPU_MAX_HW_QUEUES=1 0 of 40,
 agent-scope atomic loads in the consumer 0 of 40 (round-2 build WITH the SLP vectoriser).  The cause turned out to be an
-instruction form, not coherence: tools/pk_hazard.py; built with -fno-slp-vectorize this script reports 0 of 40
+instruction form, not coherence: tools/pk_hazard.py, LABNOTES.md 5; built with -fno-slp-vectorize this script reports 0 of 40
 in every mode.  MAIN2=1 runs the chain on an explicit stream instead of the null stream, TILE=n picks the conv variant."""
 import os, sys, ctypes
 import numpy as np, torch
