@@ -25,8 +25,10 @@ from collections import defaultdict
 
 
 def family(name):
-    if "resunit_kernel" in name:       # the fused vocoder ResBlock units are convolutions of the conv_gemm family
-        return "conv_gemm_kernel"
+    if "resunit_kernel" in name or "conv_gemm_sk_kernel" in name:   # the fused vocoder ResBlock units and the stream-K launches
+        return "conv_gemm_kernel"                                     # (round 6) belong to the conv_gemm family
+    if "adamw_ema2_zero_kernel" in name:                              # the one-pass optimizer tail (round 6)
+        return "adamw_kernel"
     if "attention_plain2_kernel" in name:   # the self-attention forward kernel of round 3 (rounds 3-4 left it in "other": that
         return "attention_kernel"           # was the unexplained 35.6 GB of pmc_traffic_distill_r04.json)
     for key in ("conv_gemm_kernel", "conv1d_halo_kernel", "attention_kernel", "attn_bwd", "gn_", "layernorm", "ln_bwd", "geglu",

@@ -21,7 +21,8 @@ def main():
     t_beg = t_end - int(win * 1e6)
     if isinstance(win_spec, str) and win_spec.startswith("adamw:"):
         _, i, j = win_spec.split(":")
-        marks = [r[1] for r in rows if r[0].startswith("adamw4_kernel") or r[0].startswith("adamw_kernel")]
+        # one mark per optimizer step: the AdamW launch of the three-launch tail or the one-pass tail (round 6: adamw_ema2_zero_kernel)
+        marks = [r[1] for r in rows if "adamw4_kernel" in r[0] or "adamw_ema2_zero_kernel" in r[0] or r[0].startswith("adamw_kernel")]
         print("adamw launches:", len(marks))
         t_beg, t_end = marks[int(i)], marks[int(j)]
         rows = [r for r in rows if r[1] < t_end]
