@@ -133,6 +133,54 @@ def test_streamk_fold_is_exact_ordered_and_repeatable(tile, B, Cin, Cout, H, W, 
         L_.ctta_conv_bind_workspace(None, 0)
 
 
+def test_two_streamk_launches_on_two_streams_share_the_device_without_waiting_for_each_other():
+    """Two persistent launches at once, each wanting every CU (the pipelined distillation step does this: the teacher graph's
+    deep GEMMs beside the main graph's): whatever share of its workgroups is resident, a stream-K launch must finish -- its only
+    waits are bounded, the writer of a tile's last part never waits -- and give the bits it gives alone.  30 rounds of
+    (launch A on stream 1 | launch B on stream 2), each launch with its own workspace, an elementwise kernel streaming beside
+    them for uneven load; every output compared with the launch run alone."""
+    L_ = lib()
+    shapes = [(18, 1024, 64, 4, 1024), (16, 1024, 64, 4, 1024)]
+    cases_ = []
+    for si, (B, Cin, H, W, Cout) in enumerate(shapes):
+        x = bf16_round(det("sk2.x%d" % si, (B, Cin, H, W), 1))
+        w = bf16_round(det("sk2.w%d" % si, (Cout, Cin, 3, 3), 2) * (1.0 / math.sqrt(Cin * 9)))
+        wp, k_pad = pack_conv_weight(w)
+        xa = nhwc_bf16(x)
+        ws = torch.zeros(L_.ctta_conv_workspace_bytes(), dtype=torch.uint8, device=DEV)
+        out = torch.empty(B, H, W, Cout, dtype=torch.bfloat16, device=DEV)
+        d = conv_desc(x0=xa, c0=Cin, batch=B, hi=H, wi=W, ho=H, wo=W, kh=3, kw=3, pad_h=1, pad_w=1, w=wp, k_pad=k_pad, n=Cout,
+                      out=out, ldc=Cout, tile=41)
+        cases_.append(dict(d=d, ws=ws, out=out, keep=(xa, wp)))
+    try:
+        alone = []
+        for c in cases_:
+            L_.ctta_conv_bind_workspace_ex(N.ptr(c["ws"]), c["ws"].numel(), 1)
+            N.check(L_.ctta_conv_gemm(ctypes.byref(c["d"]), N.stream_ptr()))
+            sync()
+            alone.append(c["out"].clone())
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        noise = torch.zeros(64 << 20, device=DEV)
+        for rnd in range(30):
+            for c in cases_:
+                c["out"].fill_(float("nan"))
+            sync()
+            noise.add_(1.0)                                  # something else on the device while both launch
+            for c, st in zip(cases_, streams):
+                L_.ctta_conv_bind_workspace_ex(N.ptr(c["ws"]), c["ws"].numel(), 1)
+                with torch.cuda.stream(st):
+                    N.check(L_.ctta_conv_gemm(ctypes.byref(c["d"]), N.stream_ptr()))
+            noise.mul_(0.5)
+            sync()
+            for c, ref in zip(cases_, alone):
+                assert torch.equal(c["out"], ref), rnd
+        for c in cases_:
+            hdr = c["ws"][:16].view(torch.int32).cpu().tolist()
+            assert hdr[0] == 0 and hdr[1] == 0 and hdr[2] == 31, hdr
+    finally:
+        L_.ctta_conv_bind_workspace(None, 0)
+
+
 def test_streamk_needs_a_workspace_with_a_zeroed_header():
     """A buffer bound with ctta_conv_bind_workspace() promises nothing about its first bytes: a stream-K tile is refused there
     (and never chosen automatically); the two-pass split-K keeps working on it."""
