@@ -42,7 +42,10 @@ struct WgradDirect {
 };
 __device__ __forceinline__ void direct_add4(const WgradDirect& d, int ro, int k, const float v[4]) {
   // four consecutive slab columns k .. k + 3 of one row
-  if (!d.col_off && k + 3 < d.k_cols && ((ro + k) & 3) == 0) {
+  // (the ABSOLUTE address decides: the flat gradient buffer packs the tensors back to back, and 155 of the light U-Net's 691
+  // start at element offsets that are not multiples of 4 -- the 255-wide transformer layers -- so `(ro + k) & 3` alone let
+  // misaligned dwordx4 accesses through, which only the GPU's unaligned-access mode made work)
+  if (!d.col_off && k + 3 < d.k_cols && (reinterpret_cast<uintptr_t>(d.grad_w + (size_t)ro + k) & 15) == 0) {
     float4* dst = reinterpret_cast<float4*>(d.grad_w + (size_t)ro + k);
     float4 o = *dst;
     o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];

@@ -141,22 +141,33 @@ class _ParamTree(nn.Module):
         if g is None:
             return False
         tr = getattr(self, "_trainable_cache", None)
-        if tr is None or tr[0] != getattr(self, "_rehome_count", 0):
-            tr = self._trainable_cache = (getattr(self, "_rehome_count", 0), [p for p in self.parameters() if p.requires_grad])
+        key = (getattr(self, "_rehome_count", 0), tuple(getattr(self, "_frozen_keys", ())))
+        if tr is None or tr[0] != key:
+            tr = self._trainable_cache = (key, [p for p in self.parameters() if p.requires_grad])
             self._alias_cursor = 0
+            self._alias_calls = 0
             return self.grads_alias_flat()
         ps = tr[1]
         n = len(ps)
         if n == 0:
             return True
+        # every 64th call walks everything (a single hand-assigned p.grad is then seen within 64 steps whatever n / k is)
+        self._alias_calls = getattr(self, "_alias_calls", 0) + 1
+        if self._alias_calls % 64 == 0:
+            return self.grads_alias_flat()
         lo, hi = g.data_ptr(), g.data_ptr() + g.numel() * 4
         cur = self._alias_cursor
         idx = [0, n - 1] + [(cur + i) % n for i in range(k)]
         self._alias_cursor = (cur + k) % n
         for i in idx:
-            gr = ps[i].grad
+            p = ps[i]
+            if not p.requires_grad:       # frozen after the cache was built (requires_grad_(False) by hand): rebuild, walk
+                self._trainable_cache = None
+                return self.grads_alias_flat()
+            gr = p.grad
             if gr is None or not (lo <= gr.data_ptr() < hi):
-                return False
+                # the sample says no: let the full walk decide (it filters on requires_grad at call time) before step() raises
+                return self.grads_alias_flat()
         return True
 
     def realias_grads_(self):

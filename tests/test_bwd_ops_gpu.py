@@ -239,6 +239,19 @@ def test_weight_gradient_with_both_operands_in_place(M, Cin, Cout, splits, x_ld,
         sync()
         assert torch.equal(gw_d, gw_s) and torch.equal(gb_d, gb_s), use_map
         assert bool(torch.isfinite(gw_d).all()) and not torch.equal(gw_d, gw0)
+        # a gradient tensor that starts 1 .. 3 floats past a 16-byte boundary (a caller's own sub-view of a flat buffer): the
+        # four-wide add is chosen on the ABSOLUTE address, so the result is the aligned one bit for bit and the floats either
+        # side of the view are untouched
+        for off in (1, 2, 3):
+            buf = torch.full((Cout * Kd + 8,), 123.0, device=DEV)
+            gw_o, gb_o = buf[off:off + Cout * Kd], gb0.clone()
+            gw_o.copy_(gw0)
+            assert N.ptr(gw_o).value % 16 == 4 * off
+            N.check(L.ctta_wgrad_tn_direct(N.ptr(dya), dy_ld, Cout, N.ptr(xa), x_ld, Cin, M, mp1, Cin, Cout, N.ptr(ro_d), N.ptr(co),
+                                           N.ptr(gw_o), Cout, N.ptr(bi_d), N.ptr(gb_o), st))
+            sync()
+            assert torch.equal(gw_o, gw_d) and torch.equal(gb_o, gb_d), (use_map, off)
+            assert bool((buf[:off] == 123.0).all()) and bool((buf[off + Cout * Kd:] == 123.0).all())
 
 
 def test_slab_scatter_with_the_bias_column_in_the_same_launch():

@@ -219,6 +219,21 @@ def test_flat_alias_checks_and_schedule_state():
     assert not m.grads_alias_flat()
     m.realias_grads_()
     assert m.grads_alias_flat() and m._flat_grad is g
+    # the per-step sampled form (FusedAdamW.step): first call walks everything, later ones sample -- and a parameter
+    # frozen AFTER the cache was built does not make every n / k-th step raise: the sample defers to the full walk, which filters
+    # on requires_grad at call time; a hand-assigned foreign gradient is found by the full walk of every 64th call at the latest
+    assert m.grads_alias_flat_sampled() and m.grads_alias_flat_sampled()
+    ps = [p for p in m.parameters() if p.requires_grad]
+    ps[3].requires_grad_(False)
+    ps[3].grad = None
+    assert all(m.grads_alias_flat_sampled() for _ in range(2 * len(ps) // 8 + 2))
+    ps[3].requires_grad_(True)
+    m.realias_grads_()
+    ps[5].grad = torch.zeros_like(ps[5])           # one gradient re-pointed by hand
+    seen = [m.grads_alias_flat_sampled() for _ in range(70)]
+    assert not all(seen) and seen.index(False) < 70
+    m.realias_grads_()
+    assert m.grads_alias_flat()
     m.double().float()                             # re-homes p.data: the flat buffer is stale now
     assert not m.flat_is_current()
     assert m.flatten_parameters_() is not flat and m.flat_is_current()
