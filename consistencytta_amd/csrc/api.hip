@@ -53,8 +53,9 @@ struct OptDef { const char* name; int def; int lo, hi; };
 static const OptDef kOpts[CTTA_OPT_COUNT] = {
     {"xcd", 1, 0, 1},          {"splitk", 1, 0, 1},       {"streamk", 1, 0, 1},   {"streamk_grid", 0, 0, 1984},
     {"wgrad_stream", 1, 0, 1}, {"gn_fuse", 1, 0, 1},      {"fused_res", 1, 0, 1},
+    {"ffn_fuse", 1, 0, 1},
 };
-int g_ctta_opt[CTTA_OPT_COUNT] = {1, 1, 1, 0, 1, 1, 1};
+int g_ctta_opt[CTTA_OPT_COUNT] = {1, 1, 1, 0, 1, 1, 1, 1};
 static int opt_index(const char* name) {
   if (!name) return -1;
   for (int i = 0; i < CTTA_OPT_COUNT; ++i) if (strcmp(name, kOpts[i].name) == 0) return i;

@@ -11,7 +11,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-variable -Wno-pass-failed ${CTTA_EXTRA_FLAGS:-}"
 mkdir -p build
 pids=()
-for f in conv_gemm_i1 conv_gemm_i2 conv_gemm_i3 conv_gemm_i4 conv_gemm_i5 conv_gemm_i6 conv_gemm_i7 conv_gemm_i8 conv_gemm_i9 api conv_gemm resunit clap_ops eval_ops wgrad_gemm norm_elem attention backward engine_unet engine_vae engine_t5 mel_frontend stft_loss; do
+for f in conv_gemm_i1 conv_gemm_i2 conv_gemm_i3 conv_gemm_i4 conv_gemm_i5 conv_gemm_i6 conv_gemm_i7 conv_gemm_i8 conv_gemm_i9 api conv_gemm resunit ffn_fused clap_ops eval_ops wgrad_gemm norm_elem attention backward engine_unet engine_vae engine_t5 mel_frontend stft_loss; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ common.h -nt build/$f.o ] || [ engine_common.h -nt build/$f.o ] || [ conv_epilogue.h -nt build/$f.o ] || { [[ $f == conv_gemm* ]] && [ conv_gemm_kernel.h -nt build/$f.o ]; } || [ engine_unet_train.h -nt build/$f.o ] || [ ../../include/ctta.h -nt build/$f.o ]; then
     $HIPCC $FLAGS -c $f.hip -o build/$f.o &
     pids+=($!)

@@ -99,6 +99,7 @@ enum CttaOption {
   CTTA_OPT_WGRAD_STREAM,       // weight-gradient launches on the handle's side stream (default 1); read per backward call
   CTTA_OPT_GN_FUSE,            // GroupNorm statistics from the producing convolution's epilogue (default 1)
   CTTA_OPT_FUSED_RES,          // HiFi-GAN ResBlock units as fused pair kernels (default 1)
+  CTTA_OPT_FFN_FUSE,           // transformer feed-forward of the 256-wide level as one row-tile kernel (ffn_fused.hip) in the inference forward
   CTTA_OPT_COUNT
 };
 extern int g_ctta_opt[CTTA_OPT_COUNT];

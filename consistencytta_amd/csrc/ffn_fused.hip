@@ -1,0 +1,296 @@
+// Fused GEGLU feed-forward of a transformer block for the narrow U-Net levels (inner width 256 after padding):
+//
+//   out = x_res + ff2( value * gelu(gate) ) + b2,   [value | gate] = ff1(n) + b1        diffusers/models/attention.py:276-334, 430-432
+//
+// As two conv_gemm launches (ff1 with the GEGLU epilogue, ff2 with the residual epilogue) the hidden activations -- M x 1024
+// bf16 -- make a round trip through HBM, both launches run short K walks (K = 256: four steps of the big tile; 652 / 692
+// TFLOP/s at M = 131 072) and each pays its own prologue and epilogue.  Here ONE workgroup owns BM = 128 token rows for the
+// whole feed-forward:
+//   1. the 128 x CP LayerNorm output tile is staged ONCE in LDS (A tile, 66 KB);
+//   2. the hidden width is walked in chunks of 128 units.  Per chunk, GEMM1: wave w of 8 computes value and gate of ITS 16
+//      hidden units for all 128 rows (2 weight fragments x 8 row blocks, K = CP) from the A tile; bias + GEGLU in registers,
+//      the bf16 result goes to an LDS tile H[128 rows][128 hidden] (double-buffered, one barrier per chunk);
+//   3. GEMM2: wave w accumulates ITS CP / 8 output channels for all 128 rows over the chunk's 128 hidden units from H; the
+//      accumulators (16 fragments) live across the chunks;
+//   4. epilogue from the accumulators: + b2 + residual, bf16, 8-byte stores (64 contiguous bytes per row and wave).
+// HBM sees the A tile once, the residual once and the output once; the hidden activations never leave the CU.
+//
+// WEIGHT-STATIONARY like resunit.hip: every weight element is used by exactly one wave of a workgroup, so the waves stream
+// their own fragments straight from L2 into registers (ctta_ffn_pack lays the two matrices out as ONE contiguous stream per
+// wave: no address arithmetic, no LDS space, no barrier inside a GEMM); L2 -> CU traffic is 1 byte per 128 flops (the big
+// conv_gemm tile: 131).  MFMA mapping as everywhere in this library (v_mfma_f32_16x16x32_bf16, weights = A operand, token rows
+// = B operand, a lane owns 4 consecutive channels of one row).  Same products, same K order, same rounding points (bf16 after
+// GEGLU, bf16 after the residual) as the two-launch form: bit-identical to it (tests/test_ops_gpu.py).
+#include "conv_epilogue.h"
+
+#include <string.h>
+
+struct FfnParams {
+  const bf16_t* x; int ld_x;      // LayerNorm output [M][ld_x], CP columns used
+  const bf16_t* w1s;              // per-wave streams, see ffn_pack_kernel
+  const bf16_t* w2s;
+  const float* b1;                // [2 * ffp] in ff1's packed row order ([16 value][16 gate] blocks)
+  const float* b2;                // [CP]
+  const bf16_t* res; int res_ld;
+  bf16_t* out; int ldc;
+  int M, nchunk, n_valid;         // n_valid: output columns stored (<= CP, multiple of 4)
+};
+
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+#define FFN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+constexpr int FFN_BM = 128, FFN_NW = 8, FFN_HC = 128;     // rows per workgroup, waves, hidden units per chunk
+constexpr int FFN_PF = 2;                                 // weight prefetch distance (K steps)
+
+template <int CP>
+__global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
+  constexpr int RS = CP + 8;                 // A tile row stride (bf16): 16 B of padding spreads ds_read_b128 over the banks
+  constexpr int HS = FFN_HC + 8;
+  constexpr int S1 = CP / 32;                // GEMM1 K steps per chunk
+  constexpr int S2 = FFN_HC / 32;            // GEMM2 K steps per chunk
+  constexpr int NC2 = CP / 16 / FFN_NW;      // output-channel blocks per wave
+  constexpr int PB = FFN_BM / 16;            // row blocks
+  constexpr int R = FFN_PF + 1;              // prefetch ring size
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  bf16_t* atile = reinterpret_cast<bf16_t*>(smem_raw);
+  bf16_t* htile = atile + FFN_BM * RS;       // [2][BM][HS]
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int lq = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * FFN_BM;
+  const int nchunk = p.nchunk;
+
+  // weight streams of this wave: [chunk][S1][2][64][8] and [chunk][S2][NC2][64][8] (+ FFN_PF steps of padding at the end)
+  const uint4* w1p = reinterpret_cast<const uint4*>(p.w1s) + (size_t)w * ((size_t)nchunk * S1 + FFN_PF) * 2 * 64 + lane;
+  const uint4* w2p = reinterpret_cast<const uint4*>(p.w2s) + (size_t)w * ((size_t)nchunk * S2 + FFN_PF) * NC2 * 64 + lane;
+  bf16x8_t r1[R][2], r2[R][NC2];
+#pragma unroll
+  for (int s = 0; s < FFN_PF; ++s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r1[s][i] = __builtin_bit_cast(bf16x8_t, w1p[(s * 2 + i) * 64]);
+#pragma unroll
+    for (int i = 0; i < NC2; ++i) r2[s][i] = __builtin_bit_cast(bf16x8_t, w2p[(s * NC2 + i) * 64]);
+  }
+  w1p += FFN_PF * 2 * 64;
+  w2p += FFN_PF * NC2 * 64;
+
+  // ---- 1. A tile -> LDS (rows past M read as zeros through the descriptor's bounds check)
+  {
+    const __amdgpu_buffer_rsrc_t rsx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((size_t)p.M * p.ld_x * 2), 0x00020000);
+    constexpr int CV = CP / 8, RPS = 512 / CV, NSW = FFN_BM / RPS;
+    const int cc = tid % CV, rr = tid / CV;
+    u32x4_t v[NSW];
+#pragma unroll
+    for (int u = 0; u < NSW; ++u)
+      v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ((m0 + rr + u * RPS) * p.ld_x + cc * 8) * 2, 0, 0);
+#pragma unroll
+    for (int u = 0; u < NSW; ++u)
+      *reinterpret_cast<uint4*>(atile + (rr + u * RPS) * RS + cc * 8) = make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]);
+  }
+  __syncthreads();
+
+  f32x4_t acc2[NC2][PB];
+#pragma unroll
+  for (int i = 0; i < NC2; ++i)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+  const bf16_t* aw = atile + lq * RS + lg * 8;
+  const float* b1p = p.b1 + w * 32 + lg * 4;
+
+#pragma unroll 1
+  for (int c = 0; c < nchunk; ++c) {
+    // ---- GEMM1: value / gate of this wave's 16 hidden units, all rows
+    f32x4_t acc1[2][PB];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < PB; ++j) acc1[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const float4 bv = *reinterpret_cast<const float4*>(b1p + (size_t)c * (FFN_NW * 32));
+    const float4 bg = *reinterpret_cast<const float4*>(b1p + (size_t)c * (FFN_NW * 32) + 16);
+#pragma unroll
+    for (int st = 0; st < S1; ++st) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) r1[FFN_PF][i] = __builtin_bit_cast(bf16x8_t, w1p[(st * 2 + i) * 64]);
+      __builtin_amdgcn_sched_barrier(0);     // the prefetch stays HERE: two steps ahead of its use
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(aw + pb * 16 * RS + st * 32));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc1[i][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r1[0][i], bf, acc1[i][pb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < FFN_PF; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) r1[s][i] = r1[s + 1][i];
+    }
+    w1p += S1 * 2 * 64;
+    // ---- GEGLU -> H[c & 1]
+    bf16_t* hw = htile + (c & 1) * (FFN_BM * HS) + lq * HS + w * 16 + lg * 4;
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const f32x4_t av = acc1[0][pb], ag = acc1[1][pb];
+      const float o0 = (av[0] + bv.x) * gelu_erf_f(ag[0] + bg.x);
+      const float o1 = (av[1] + bv.y) * gelu_erf_f(ag[1] + bg.y);
+      const float o2 = (av[2] + bv.z) * gelu_erf_f(ag[2] + bg.z);
+      const float o3 = (av[3] + bv.w) * gelu_erf_f(ag[3] + bg.w);
+      uint2 pk;
+      pk.x = pack2bf(o0, o1);
+      pk.y = pack2bf(o2, o3);
+      *reinterpret_cast<uint2*>(hw + pb * 16 * HS) = pk;
+    }
+    FFN_LDS_BARRIER();
+    // ---- GEMM2: this wave's output channels += H[c & 1] x W2 chunk
+    const bf16_t* hr = htile + (c & 1) * (FFN_BM * HS) + lq * HS + lg * 8;
+#pragma unroll
+    for (int ks = 0; ks < S2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < NC2; ++i) r2[FFN_PF][i] = __builtin_bit_cast(bf16x8_t, w2p[(ks * NC2 + i) * 64]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(hr + pb * 16 * HS + ks * 32));
+#pragma unroll
+        for (int i = 0; i < NC2; ++i)
+          acc2[i][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2[0][i], bf, acc2[i][pb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < FFN_PF; ++s)
+#pragma unroll
+        for (int i = 0; i < NC2; ++i) r2[s][i] = r2[s + 1][i];
+    }
+    w2p += S2 * NC2 * 64;
+  }
+
+  // ---- epilogue: + b2 + residual -> bf16.  Descriptors bounded to M rows (rows past M read zeros / are dropped), a lane whose
+  //      columns lie past n_valid gets an offset outside them: no branch, all residual loads in flight before the first store
+  {
+    const __amdgpu_buffer_rsrc_t rsr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (unsigned)((size_t)p.M * p.res_ld * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rso =
+        __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (unsigned)((size_t)p.M * p.ldc * 2), 0x00020000);
+    const int n0 = w * NC2 * 16 + lg * 4;
+#pragma unroll
+    for (int i = 0; i < NC2; ++i) {
+      const int n = n0 + i * 16;
+      const float4 bb = *reinterpret_cast<const float4*>(p.b2 + n);
+      const bool live = n < p.n_valid;
+      const int vr = live ? ((m0 + lq) * p.res_ld + n) * 2 : (int)0x80000000, vo = live ? ((m0 + lq) * p.ldc + n) * 2 : (int)0x80000000;   // extents < 2^31 - 2^20 (host check)
+      u32x2_t r[PB];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) r[pb] = __builtin_amdgcn_raw_buffer_load_b64(rsr, vr + pb * 16 * p.res_ld * 2, 0, 0);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const f32x4_t a = acc2[i][pb];
+        const float v0 = a[0] + bb.x + __uint_as_float(r[pb][0] << 16);
+        const float v1 = a[1] + bb.y + __uint_as_float(r[pb][0] & 0xffff0000u);
+        const float v2 = a[2] + bb.z + __uint_as_float(r[pb][1] << 16);
+        const float v3 = a[3] + bb.w + __uint_as_float(r[pb][1] & 0xffff0000u);
+        u32x2_t pk;
+        pk[0] = pack2bf(v0, v1);
+        pk[1] = pack2bf(v2, v3);
+        __builtin_amdgcn_raw_buffer_store_b64(pk, rso, vo + pb * 16 * p.ldc * 2, 0, 0);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// packed ff1 [2*ffp][k_pad1] and ff2 [cp][k_pad2] (conv_gemm's layout, K contiguous) -> one stream per wave:
+//   w1s[w][c][st][i][lane][8] = W1[(c*8 + w)*32 + i*16 + lq][st*32 + lg*8 ..]          i = 0 value rows, 1 gate rows
+//   w2s[w][c][ks][i][lane][8] = W2[(w*NC2 + i)*16 + lq][(c*4 + ks)*32 + lg*8 ..]
+// each stream followed by FFN_PF steps of zeros (the prefetch runs that far past the last chunk).
+__global__ void ffn_pack_kernel(const bf16_t* __restrict__ w1, int k_pad1, const bf16_t* __restrict__ w2, int k_pad2, int cp,
+                                int nchunk, bf16_t* __restrict__ w1s, bf16_t* __restrict__ w2s) {
+  const int S1 = cp / 32, S2 = FFN_HC / 32, NC2 = cp / 16 / FFN_NW;
+  const long long per1 = ((long long)nchunk * S1 + FFN_PF) * 2 * 64, per2 = ((long long)nchunk * S2 + FFN_PF) * NC2 * 64;
+  const long long total = FFN_NW * (per1 + per2);
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (t < FFN_NW * per1) {
+      const int wv = (int)(t / per1);
+      const long long r = t - wv * per1;
+      const int lane = (int)(r & 63), i = (int)((r >> 6) & 1);
+      const long long s = r >> 7;
+      const int c = (int)(s / S1), st = (int)(s % S1);
+      if (c < nchunk)
+        v = *reinterpret_cast<const uint4*>(w1 + (size_t)((c * FFN_NW + wv) * 32 + i * 16 + (lane & 15)) * k_pad1 + st * 32 + (lane >> 4) * 8);
+      reinterpret_cast<uint4*>(w1s)[t] = v;
+    } else {
+      const long long t2 = t - FFN_NW * per1;
+      const int wv = (int)(t2 / per2);
+      const long long r = t2 - wv * per2;
+      const int lane = (int)(r & 63);
+      const long long f = r >> 6;
+      const int i = (int)(f % NC2);
+      const long long s = f / NC2;
+      const int c = (int)(s / S2), ks = (int)(s % S2);
+      if (c < nchunk)
+        v = *reinterpret_cast<const uint4*>(w2 + (size_t)((wv * NC2 + i) * 16 + (lane & 15)) * k_pad2 + (c * S2 + ks) * 32 + (lane >> 4) * 8);
+      reinterpret_cast<uint4*>(w2s)[t2] = v;
+    }
+  }
+}
+
+static size_t ffn_smem(int cp) { return (size_t)FFN_BM * (cp + 8) * 2 + (size_t)2 * FFN_BM * (FFN_HC + 8) * 2; }
+
+extern "C" int ctta_ffn_geglu_supported(int cp, int ffp) {
+  if (!ctta_opt(CTTA_OPT_FFN_FUSE)) return 0;
+  return cp == 256 && ffp > 0 && ffp % FFN_HC == 0 ? 1 : 0;
+}
+
+extern "C" size_t ctta_ffn_pack_bytes(int cp, int ffp) {
+  if (cp % 128 != 0 || ffp % FFN_HC != 0) return 0;
+  const size_t nchunk = ffp / FFN_HC, S1 = cp / 32, S2 = FFN_HC / 32, NC2 = cp / 16 / FFN_NW;
+  return (size_t)FFN_NW * ((nchunk * S1 + FFN_PF) * 2 + (nchunk * S2 + FFN_PF) * NC2) * 64 * 16;
+}
+
+extern "C" ctta_status ctta_ffn_pack(const void* w1_packed, int k_pad1, const void* w2_packed, int k_pad2, int cp, int ffp,
+                                     void* dst, void* stream) {
+  CTTA_REQUIRE(w1_packed && w2_packed && dst, "ffn_pack: null pointer");
+  CTTA_REQUIRE(cp == 256 && ffp > 0 && ffp % FFN_HC == 0 && k_pad1 >= cp && k_pad2 >= ffp && k_pad1 % 8 == 0 && k_pad2 % 8 == 0,
+               "ffn_pack: cp=%d (256), ffp=%d (a multiple of %d), k_pad1=%d >= cp, k_pad2=%d >= ffp", cp, ffp, FFN_HC, k_pad1, k_pad2);
+  const int nchunk = ffp / FFN_HC;
+  const size_t per1 = ((size_t)nchunk * (cp / 32) + FFN_PF) * 2 * 64;
+  bf16_t* w1s = (bf16_t*)dst;
+  bf16_t* w2s = w1s + (size_t)FFN_NW * per1 * 8;
+  hipLaunchKernelGGL(ffn_pack_kernel, dim3(1024), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w1_packed, k_pad1,
+                     (const bf16_t*)w2_packed, k_pad2, cp, nchunk, w1s, w2s);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_ffn_geglu(const void* x, int ld_x, int64_t M, int cp, int ffp, const void* packed, const float* b1,
+                                      const float* b2, const void* res, int res_ld, void* out, int ldc, int n_valid,
+                                      void* stream) {
+  CTTA_REQUIRE(x && packed && b1 && b2 && res && out, "ffn_geglu: null pointer");
+  CTTA_REQUIRE(cp == 256 && ffp > 0 && ffp % FFN_HC == 0, "ffn_geglu: cp=%d ffp=%d is outside the fused kernel's range (cp = 256, ffp a multiple of %d)", cp, ffp, FFN_HC);
+  CTTA_REQUIRE(M >= 1 && ld_x >= cp && ld_x % 8 == 0 && (long long)(M + 128) * ld_x * 2 < 0x7FF00000LL && (long long)(M + 128) * res_ld * 2 < 0x7FF00000LL &&
+               (long long)(M + 128) * ldc * 2 < 0x7FF00000LL && res_ld % 4 == 0 && ldc % 4 == 0 &&
+               n_valid > 0 && n_valid <= cp && n_valid % 4 == 0 && res_ld >= n_valid && ldc >= n_valid,
+               "ffn_geglu: bad extents (M=%lld ld_x=%d res_ld=%d ldc=%d n_valid=%d)", (long long)M, ld_x, res_ld, ldc, n_valid);
+  FfnParams p;
+  memset(&p, 0, sizeof(p));
+  const int nchunk = ffp / FFN_HC;
+  const size_t per1 = ((size_t)nchunk * (cp / 32) + FFN_PF) * 2 * 64;
+  p.x = (const bf16_t*)x; p.ld_x = ld_x;
+  p.w1s = (const bf16_t*)packed; p.w2s = p.w1s + (size_t)FFN_NW * per1 * 8;
+  p.b1 = b1; p.b2 = b2; p.res = (const bf16_t*)res; p.res_ld = res_ld; p.out = (bf16_t*)out; p.ldc = ldc;
+  p.M = (int)M; p.nchunk = nchunk; p.n_valid = n_valid;
+  const size_t smem = ffn_smem(cp);
+  static bool configured = false;
+  if (!configured) {
+    CTTA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_geglu_kernel<256>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    configured = true;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const bool prof = ctta_prof_active();
+  if (prof) ctta_prof_begin(0, 44, M, cp, 3LL * ffp, 1, s);   // 2 M (2 ffp cp + cp ffp) flops = 2 M cp (3 ffp)
+  ffn_geglu_kernel<256><<<dim3((unsigned)((M + FFN_BM - 1) / FFN_BM)), dim3(512), smem, s>>>(p);
+  if (prof) ctta_prof_end(s);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}

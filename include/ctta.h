@@ -48,6 +48,8 @@ int ctta_version(void);
  *                     caller's stream -- what a per-launch profile needs; read at every backward call)
  *   "gn_fuse"      1  GroupNorm statistics come from the producing convolution's epilogue (= ctta_set_gn_fuse)
  *   "fused_res"    1  HiFi-GAN ResBlock units run as fused pair kernels (0: one conv_gemm launch per convolution)
+ *   "ffn_fuse"     1  the inference forward runs the 256-wide transformer feed-forward as one row-tile kernel
+ *                     (ctta_ffn_geglu; 0: ff1 + GEGLU epilogue and ff2 as two conv_gemm launches); read when a handle is built
  * Every option is exercised in its non-default position by tests/test_options_gpu.py. */
 ctta_status ctta_set_option(const char* name, int value);
 ctta_status ctta_get_option(const char* name, int* value);
@@ -417,6 +419,21 @@ ctta_status ctta_reschain_conv1d(const void* x, int batch, int len, int channels
                                  const void* const* w1_frag, const float* const* b1, const void* const* w2_frag,
                                  const float* const* b2, float slope, void* out, int accumulate, float alpha,
                                  float out_slope, void* stream);
+
+/* Fused GEGLU feed-forward of a transformer block (diffusers/models/attention.py:276-334, 383-386, 430-432: ff.net.0.proj ->
+ * chunk -> value * gelu(gate) -> ff.net.2, plus the residual) for the 256-wide level, ONE launch:
+ *   out[m][0..n_valid) = res[m][..] + b2 + W2 . ( (W1v . x[m] + b1v) * gelu(W1g . x[m] + b1g) )
+ * x: bf16 [M][ld_x] (the LayerNorm output, cp = 256 columns used); the hidden activations (ffp columns) never leave the CU.
+ * `packed` = ctta_ffn_pack's per-wave weight streams (ctta_ffn_pack_bytes bytes) made from the conv_gemm operands of the two
+ * linears: ff1 [2*ffp][k_pad1] with its rows in 16-blocks [16 value][16 gate] (what the out_act = 4 epilogue takes), ff2
+ * [cp][k_pad2].  b1 follows ff1's row order.  Bit-identical to ctta_conv_gemm(out_act = 4) + ctta_conv_gemm(res).
+ * ctta_ffn_geglu_supported: 1 when (cp, ffp) fits the kernel and option "ffn_fuse" is on. */
+int ctta_ffn_geglu_supported(int cp, int ffp);
+size_t ctta_ffn_pack_bytes(int cp, int ffp);
+ctta_status ctta_ffn_pack(const void* w1_packed, int k_pad1, const void* w2_packed, int k_pad2, int cp, int ffp, void* dst,
+                          void* stream);
+ctta_status ctta_ffn_geglu(const void* x, int ld_x, int64_t M, int cp, int ffp, const void* packed, const float* b1,
+                           const float* b2, const void* res, int res_ld, void* out, int ldc, int n_valid, void* stream);
 
 /* Direct convolution for tiny Cout (<= 8): bf16 NHWC in, fp32 weights [n][kh][kw][c],
  * fp32 planar (NCHW) out, optional input leaky-relu and output tanh. */
