@@ -216,10 +216,11 @@ SIGNATURES = {
     "ctta_mean_tokens_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_resunit_supported": (c_int, [c_int, c_int, c_int]),
     "ctta_ffn_geglu_supported": (c_int, [c_int, c_int]),
+    "ctta_ffn_geglu_wanted": (c_int, [c_int, c_int, c_int64]),
     "ctta_ffn_pack_bytes": (c_size_t, [c_int, c_int]),
     "ctta_ffn_pack": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_ffn_geglu": (c_int, [c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p,
-                               c_int, c_int, c_void_p]),
+                               c_int, c_int, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "ctta_frag_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_resunit_conv1d": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_float, c_void_p, c_int, c_float, c_float, c_void_p]),

@@ -47,6 +47,18 @@ void ctta_prof_end(hipStream_t s) {
 
 extern "C" void ctta_prof_enable(int on) { g_prof_on = on != 0; }
 
+int ctta_cu_count() {      // compute units of the current device (256 on MI355X); cached per device
+  static int per_dev[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  if (!per_dev[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    per_dev[dev] = n;
+  }
+  return per_dev[dev];
+}
+
 // ------------------------------------------------------------------------------------------
 // Options: one table, one setter (include/ctta.h).  No environment variable is read anywhere in the library.
 struct OptDef { const char* name; int def; int lo, hi; };

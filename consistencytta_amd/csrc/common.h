@@ -77,6 +77,30 @@ __device__ __forceinline__ void gelu_cdf_pdf(float g, float& cdf, float& pdf) {
   pdf = 0.3989422804014327f * e;
 }
 
+// Row sums of the LayerNorm kernels: the total of GL = 32 / 64 consecutive lanes in every one of them, folded on the VALU (DPP
+// row rotations inside 16 lanes, v_permlane16/32_swap across them); ONE summation order for every kernel that normalises rows.
+__device__ __forceinline__ float dpp_row_sum(float v) {   // total of the 16 lanes of a DPP row, in every lane
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+template <int GL>
+__device__ __forceinline__ float ln_group_sum(float v) {
+  v = dpp_row_sum(v);
+  {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  if constexpr (GL == 64) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  return v;
+}
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -103,6 +127,7 @@ enum CttaOption {
   CTTA_OPT_COUNT
 };
 extern int g_ctta_opt[CTTA_OPT_COUNT];
+int ctta_cu_count();   // api.hip
 static inline int ctta_opt(CttaOption o) { return g_ctta_opt[o]; }
 void ctta_set_error(const char* fmt, ...);
 bool ctta_prof_active();

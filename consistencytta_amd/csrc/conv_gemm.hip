@@ -204,17 +204,7 @@ static float* splitk_workspace(size_t* bytes, bool* hdr_ok = nullptr) {
   if (hdr_ok) *hdr_ok = per_dev[dev] != nullptr;
   return per_dev[dev];
 }
-static int cu_count() {      // compute units of the current device (256 on MI355X); cached per device
-  static int per_dev[64] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-  if (!per_dev[dev]) {
-    int n = 0;
-    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    per_dev[dev] = n;
-  }
-  return per_dev[dev];
-}
+static int cu_count() { return ctta_cu_count(); }
 
 // ------------------------------------------------------------------------------------------
 struct Variant {

@@ -26,7 +26,7 @@
 #include <string.h>
 
 struct FfnParams {
-  const bf16_t* x; int ld_x;      // LayerNorm output [M][ld_x], CP columns used
+  const bf16_t* x; int ld_x;      // [M][ld_x], CP columns used: the LayerNorm output -- or, with ln_gamma, its INPUT
   const bf16_t* w1s;              // per-wave streams, see ffn_pack_kernel
   const bf16_t* w2s;
   const float* b1;                // [2 * ffp] in ff1's packed row order ([16 value][16 gate] blocks)
@@ -34,30 +34,32 @@ struct FfnParams {
   const bf16_t* res; int res_ld;
   bf16_t* out; int ldc;
   int M, nchunk, n_valid;         // n_valid: output columns stored (<= CP, multiple of 4)
+  const float* ln_gamma; const float* ln_beta; int ln_d; float ln_eps;   // LayerNorm over the first ln_d columns while staging
 };
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 #define FFN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-constexpr int FFN_BM = 128, FFN_NW = 8, FFN_HC = 128;     // rows per workgroup, waves, hidden units per chunk
-constexpr int FFN_PF = 2;                                 // weight prefetch distance (K steps)
+constexpr int FFN_NW = 8, FFN_HC = 128;     // waves per workgroup, hidden units per chunk (16 per wave)
+constexpr int FFN_PF = 2;                   // weight prefetch distance (K steps)
 
-template <int CP>
+template <int CP, int BM>
 __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
   constexpr int RS = CP + 8;                 // A tile row stride (bf16): 16 B of padding spreads ds_read_b128 over the banks
   constexpr int HS = FFN_HC + 8;
   constexpr int S1 = CP / 32;                // GEMM1 K steps per chunk
   constexpr int S2 = FFN_HC / 32;            // GEMM2 K steps per chunk
   constexpr int NC2 = CP / 16 / FFN_NW;      // output-channel blocks per wave
-  constexpr int PB = FFN_BM / 16;            // row blocks
+  constexpr int PB = BM / 16;                // row blocks
   constexpr int R = FFN_PF + 1;              // prefetch ring size
+  static_assert(BM % 16 == 0 && PB >= S2 - 1, "row tile");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   bf16_t* atile = reinterpret_cast<bf16_t*>(smem_raw);
-  bf16_t* htile = atile + FFN_BM * RS;       // [2][BM][HS]
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  bf16_t* htile = atile + BM * RS;           // [2][BM][HS]
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lq = lane & 15, lg = lane >> 4;
-  const int m0 = blockIdx.x * FFN_BM;
+  const int m0 = blockIdx.x * BM;
   const int nchunk = p.nchunk;
 
   // weight streams of this wave: [chunk][S1][2][64][8] and [chunk][S2][NC2][64][8] (+ FFN_PF steps of padding at the end)
@@ -74,19 +76,54 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
   w1p += FFN_PF * 2 * 64;
   w2p += FFN_PF * NC2 * 64;
 
-  // ---- 1. A tile -> LDS (rows past M read as zeros through the descriptor's bounds check)
+  // ---- 1. A tile -> LDS (rows past M read as zeros through the descriptor's bounds check).  With ln_gamma the rows are
+  //         layer-normalised on the way: CP / 8 lanes share a row, 8 consecutive channels each -- the lane mapping, the
+  //         summation order (ln_group_sum) and the arithmetic of ctta_layernorm's kernel for this width, bit for bit.
   {
     const __amdgpu_buffer_rsrc_t rsx =
         __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((size_t)p.M * p.ld_x * 2), 0x00020000);
-    constexpr int CV = CP / 8, RPS = 512 / CV, NSW = FFN_BM / RPS;
+    constexpr int CV = CP / 8, RPS = 512 / CV, NSW = BM / RPS;
     const int cc = tid % CV, rr = tid / CV;
     u32x4_t v[NSW];
 #pragma unroll
     for (int u = 0; u < NSW; ++u)
       v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ((m0 + rr + u * RPS) * p.ld_x + cc * 8) * 2, 0, 0);
+    if (p.ln_gamma) {
+      const int d = p.ln_d;
+      const float inv_d = 1.0f / (float)d, eps = p.ln_eps;
+      float g[8], bt[8];
 #pragma unroll
-    for (int u = 0; u < NSW; ++u)
-      *reinterpret_cast<uint4*>(atile + (rr + u * RPS) * RS + cc * 8) = make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]);
+      for (int e = 0; e < 8; ++e) {
+        const int c = cc * 8 + e;
+        g[e] = c < d ? p.ln_gamma[c] : 0.f;
+        bt[e] = c < d ? p.ln_beta[c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < NSW; ++u) {
+        float f[8];
+        unpack8(make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]), f);
+        float sum = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if (cc * 8 + e >= d) f[e] = 0.f;
+          sum += f[e];
+        }
+        const float mean = ln_group_sum<CV>(sum) * inv_d;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+          if (cc * 8 + e < d) { const float t = f[e] - mean; q += t * t; }
+        const float rstd = rsqrtf(ln_group_sum<CV>(q) * inv_d + eps);
+        float o8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o8[e] = cc * 8 + e < d ? (f[e] - mean) * rstd * g[e] + bt[e] : 0.f;
+        *reinterpret_cast<uint4*>(atile + (rr + u * RPS) * RS + cc * 8) = pack8(o8);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NSW; ++u)
+        *reinterpret_cast<uint4*>(atile + (rr + u * RPS) * RS + cc * 8) = make_uint4(v[u][0], v[u][1], v[u][2], v[u][3]);
+    }
   }
   __syncthreads();
 
@@ -95,25 +132,23 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
   for (int i = 0; i < NC2; ++i)
 #pragma unroll
     for (int j = 0; j < PB; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc1[2][PB];
 
   const bf16_t* aw = atile + lq * RS + lg * 8;
   const float* b1p = p.b1 + w * 32 + lg * 4;
 
-#pragma unroll 1
-  for (int c = 0; c < nchunk; ++c) {
-    // ---- GEMM1: value / gate of this wave's 16 hidden units, all rows
-    f32x4_t acc1[2][PB];
+  // GEMM1 of the next chunk: value / gate of this wave's 16 hidden units, all rows, from the A tile
+  auto gemm1 = [&]() {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int j = 0; j < PB; ++j) acc1[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const float4 bv = *reinterpret_cast<const float4*>(b1p + (size_t)c * (FFN_NW * 32));
-    const float4 bg = *reinterpret_cast<const float4*>(b1p + (size_t)c * (FFN_NW * 32) + 16);
 #pragma unroll
     for (int st = 0; st < S1; ++st) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) r1[FFN_PF][i] = __builtin_bit_cast(bf16x8_t, w1p[(st * 2 + i) * 64]);
-      __builtin_amdgcn_sched_barrier(0);     // the prefetch stays HERE: two steps ahead of its use
+      __builtin_amdgcn_sched_barrier(0);     // the prefetch stays HERE, two steps ahead of its use (left alone the scheduler
+                                             // sinks every load to the MFMA that consumes it: s_waitcnt vmcnt(0) per step)
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(aw + pb * 16 * RS + st * 32));
@@ -127,10 +162,11 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
         for (int i = 0; i < 2; ++i) r1[s][i] = r1[s + 1][i];
     }
     w1p += S1 * 2 * 64;
-    // ---- GEGLU -> H[c & 1]
-    bf16_t* hw = htile + (c & 1) * (FFN_BM * HS) + lq * HS + w * 16 + lg * 4;
+  };
+  // bias + GEGLU of row blocks [pb0, pb1) from the GEMM1 accumulators -> H
+  auto geglu_rows = [&](const float4 bv, const float4 bg, bf16_t* hw, const int pb0, const int pb1) {
 #pragma unroll
-    for (int pb = 0; pb < PB; ++pb) {
+    for (int pb = pb0; pb < pb1; ++pb) {
       const f32x4_t av = acc1[0][pb], ag = acc1[1][pb];
       const float o0 = (av[0] + bv.x) * gelu_erf_f(ag[0] + bg.x);
       const float o1 = (av[1] + bv.y) * gelu_erf_f(ag[1] + bg.y);
@@ -141,27 +177,60 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
       pk.y = pack2bf(o2, o3);
       *reinterpret_cast<uint2*>(hw + pb * 16 * HS) = pk;
     }
-    FFN_LDS_BARRIER();
-    // ---- GEMM2: this wave's output channels += H[c & 1] x W2 chunk
-    const bf16_t* hr = htile + (c & 1) * (FFN_BM * HS) + lq * HS + lg * 8;
+  };
+  // One K step of GEMM2(c): this wave's output channels += H[c & 1] x W2 chunk
+  auto gemm2_step = [&](const bf16_t* hr, const int ks) {
+#pragma unroll
+    for (int i = 0; i < NC2; ++i) r2[FFN_PF][i] = __builtin_bit_cast(bf16x8_t, w2p[(ks * NC2 + i) * 64]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int pb = 0; pb < PB; ++pb) {
+      const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(hr + pb * 16 * HS + ks * 32));
+#pragma unroll
+      for (int i = 0; i < NC2; ++i)
+        acc2[i][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2[0][i], bf, acc2[i][pb], 0, 0, 0);
+    }
+  };
+  auto ring2 = [&]() {
+#pragma unroll
+    for (int s = 0; s < FFN_PF; ++s)
+#pragma unroll
+      for (int i = 0; i < NC2; ++i) r2[s][i] = r2[s + 1][i];
+  };
+  // chunk a: GEGLU(a) -> H[a & 1], interleaved (when WITH2) with GEMM2(a - 1) from H[(a - 1) & 1]: per K step of GEMM2 the
+  // GELUs of a quarter of the row blocks sit in the same scheduling region, so the VALU work runs under the matrix pipe
+  auto fused = [&](const int a, const bool with2) {
+    const float4 bv = *reinterpret_cast<const float4*>(b1p + (size_t)a * (FFN_NW * 32));
+    const float4 bg = *reinterpret_cast<const float4*>(b1p + (size_t)a * (FFN_NW * 32) + 16);
+    bf16_t* hw = htile + (a & 1) * (BM * HS) + lq * HS + w * 16 + lg * 4;
+    const bf16_t* hr = htile + ((a - 1) & 1) * (BM * HS) + lq * HS + lg * 8;
 #pragma unroll
     for (int ks = 0; ks < S2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < NC2; ++i) r2[FFN_PF][i] = __builtin_bit_cast(bf16x8_t, w2p[(ks * NC2 + i) * 64]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int pb = 0; pb < PB; ++pb) {
-        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(hr + pb * 16 * HS + ks * 32));
-#pragma unroll
-        for (int i = 0; i < NC2; ++i)
-          acc2[i][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2[0][i], bf, acc2[i][pb], 0, 0, 0);
-      }
-#pragma unroll
-      for (int s = 0; s < FFN_PF; ++s)
-#pragma unroll
-        for (int i = 0; i < NC2; ++i) r2[s][i] = r2[s + 1][i];
+      if (with2) gemm2_step(hr, ks);
+      geglu_rows(bv, bg, hw, ks * PB / S2, (ks + 1) * PB / S2);
+      if (with2) ring2();
     }
-    w2p += S2 * NC2 * 64;
+    if (with2) w2p += S2 * NC2 * 64;
+  };
+
+  // Barrier a closes H[a & 1] (every wave has written its 16 hidden units of chunk a); GEMM2(a - 1) of the next block reads
+  // H[(a - 1) & 1] while GEGLU(a) writes the other buffer, which the barrier before it has freed (every GEMM2(a - 2) done).
+  gemm1();
+  fused(0, false);
+  FFN_LDS_BARRIER();
+#pragma unroll 1
+  for (int a = 1; a < nchunk; ++a) {
+    gemm1();
+    fused(a, true);
+    FFN_LDS_BARRIER();
+  }
+  {
+    const bf16_t* hr = htile + ((nchunk - 1) & 1) * (BM * HS) + lq * HS + lg * 8;
+#pragma unroll
+    for (int ks = 0; ks < S2; ++ks) {
+      gemm2_step(hr, ks);
+      ring2();
+    }
   }
 
   // ---- epilogue: + b2 + residual -> bf16.  Descriptors bounded to M rows (rows past M read zeros / are dropped), a lane whose
@@ -234,15 +303,16 @@ __global__ void ffn_pack_kernel(const bf16_t* __restrict__ w1, int k_pad1, const
   }
 }
 
-static size_t ffn_smem(int cp) { return (size_t)FFN_BM * (cp + 8) * 2 + (size_t)2 * FFN_BM * (FFN_HC + 8) * 2; }
+static size_t ffn_smem(int cp, int bm) { return (size_t)bm * (cp + 8) * 2 + (size_t)2 * bm * (FFN_HC + 8) * 2; }
+static bool ffn_shape_ok(int cp, int ffp) { return (cp == 256 || cp == 512) && ffp >= 2 * FFN_HC && ffp % FFN_HC == 0; }
 
 extern "C" int ctta_ffn_geglu_supported(int cp, int ffp) {
   if (!ctta_opt(CTTA_OPT_FFN_FUSE)) return 0;
-  return cp == 256 && ffp > 0 && ffp % FFN_HC == 0 ? 1 : 0;
+  return ffn_shape_ok(cp, ffp) ? 1 : 0;
 }
 
 extern "C" size_t ctta_ffn_pack_bytes(int cp, int ffp) {
-  if (cp % 128 != 0 || ffp % FFN_HC != 0) return 0;
+  if (!ffn_shape_ok(cp, ffp)) return 0;
   const size_t nchunk = ffp / FFN_HC, S1 = cp / 32, S2 = FFN_HC / 32, NC2 = cp / 16 / FFN_NW;
   return (size_t)FFN_NW * ((nchunk * S1 + FFN_PF) * 2 + (nchunk * S2 + FFN_PF) * NC2) * 64 * 16;
 }
@@ -250,8 +320,9 @@ extern "C" size_t ctta_ffn_pack_bytes(int cp, int ffp) {
 extern "C" ctta_status ctta_ffn_pack(const void* w1_packed, int k_pad1, const void* w2_packed, int k_pad2, int cp, int ffp,
                                      void* dst, void* stream) {
   CTTA_REQUIRE(w1_packed && w2_packed && dst, "ffn_pack: null pointer");
-  CTTA_REQUIRE(cp == 256 && ffp > 0 && ffp % FFN_HC == 0 && k_pad1 >= cp && k_pad2 >= ffp && k_pad1 % 8 == 0 && k_pad2 % 8 == 0,
-               "ffn_pack: cp=%d (256), ffp=%d (a multiple of %d), k_pad1=%d >= cp, k_pad2=%d >= ffp", cp, ffp, FFN_HC, k_pad1, k_pad2);
+  CTTA_REQUIRE(ffn_shape_ok(cp, ffp) && k_pad1 >= cp && k_pad2 >= ffp && k_pad1 % 8 == 0 && k_pad2 % 8 == 0,
+               "ffn_pack: cp=%d (256 or 512), ffp=%d (a multiple of %d, >= %d), k_pad1=%d >= cp, k_pad2=%d >= ffp", cp, ffp, FFN_HC,
+               2 * FFN_HC, k_pad1, k_pad2);
   const int nchunk = ffp / FFN_HC;
   const size_t per1 = ((size_t)nchunk * (cp / 32) + FFN_PF) * 2 * 64;
   bf16_t* w1s = (bf16_t*)dst;
@@ -262,15 +333,61 @@ extern "C" ctta_status ctta_ffn_pack(const void* w1_packed, int k_pad1, const vo
   return CTTA_OK;
 }
 
+template <int CP, int BM>
+static ctta_status launch_ffn(const FfnParams& p, hipStream_t s) {
+  const size_t smem = ffn_smem(CP, BM);
+  static bool configured = false;
+  if (!configured) {
+    CTTA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_geglu_kernel<CP, BM>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    configured = true;
+  }
+  ffn_geglu_kernel<CP, BM><<<dim3((unsigned)((p.M + BM - 1) / BM)), dim3(512), smem, s>>>(p);
+  return CTTA_OK;
+}
+
+static int g_ffn_bm = 0;   // tools/ffn_bench.py: force the row tile (0 = the rule below)
+extern "C" void ctta_ffn_debug_rows(int bm) { g_ffn_bm = bm; }
+
+// Row tiles per width.  One workgroup per CU (LDS), so a launch takes ceil(tiles / CUs) rounds of about (BM + 16) row-times
+// each: the tile is chosen to make that product smallest -- 144 = 9 x 16 rows turn the distillation's M = 9 x 4096 / 18 x 4096
+// into exactly 1 / 2 rounds of 256 tiles where 128-row tiles need 2 / 3 (the last one 12.5 / 25 % full).
+static const int kFfnRows256[] = {128, 144}, kFfnRows512[] = {64, 80, 48};
+static int ffn_pick_rows(int cp, long long M, long long* rounds_out, long long* tiles_out) {
+  const int* cand = cp == 256 ? kFfnRows256 : kFfnRows512;
+  const int n = cp == 256 ? 2 : 3;
+  const int cus = ctta_cu_count();
+  int best = cand[0];
+  long long best_cost = -1;
+  for (int i = 0; i < n; ++i) {
+    const long long tiles = (M + cand[i] - 1) / cand[i], rounds = (tiles + cus - 1) / cus, cost = rounds * (cand[i] + 16);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cand[i]; *rounds_out = rounds; *tiles_out = tiles; }
+  }
+  return best;
+}
+
+// 1: this (cp, ffp, M) runs as the fused kernel -- the shape fits, option "ffn_fuse" is on, and the best row tile fills its
+// rounds to >= 60 % (or there is only one round): below that the two conv_gemm launches, whose small tiles fill the chip, win
+// (measured: M = 36 864 on 128-row tiles, 288 tiles = 2 rounds at 56 %: 0.103 vs 0.092 ms).
+extern "C" int ctta_ffn_geglu_wanted(int cp, int ffp, int64_t M) {
+  if (!ctta_ffn_geglu_supported(cp, ffp) || M < 1) return 0;
+  long long rounds = 0, tiles = 0;
+  (void)ffn_pick_rows(cp, M, &rounds, &tiles);
+  if (rounds == 1) return tiles * 4 >= ctta_cu_count() ? 1 : 0;      // a launch that leaves > 3/4 of the CUs idle: small tiles
+  return tiles * 10 >= rounds * ctta_cu_count() * 6 ? 1 : 0;
+}
+
 extern "C" ctta_status ctta_ffn_geglu(const void* x, int ld_x, int64_t M, int cp, int ffp, const void* packed, const float* b1,
                                       const float* b2, const void* res, int res_ld, void* out, int ldc, int n_valid,
-                                      void* stream) {
+                                      const float* ln_gamma, const float* ln_beta, int ln_d, float ln_eps, void* stream) {
   CTTA_REQUIRE(x && packed && b1 && b2 && res && out, "ffn_geglu: null pointer");
-  CTTA_REQUIRE(cp == 256 && ffp > 0 && ffp % FFN_HC == 0, "ffn_geglu: cp=%d ffp=%d is outside the fused kernel's range (cp = 256, ffp a multiple of %d)", cp, ffp, FFN_HC);
+  CTTA_REQUIRE(ffn_shape_ok(cp, ffp), "ffn_geglu: cp=%d ffp=%d is outside the fused kernel's range (cp 256 or 512, ffp a multiple of %d, >= %d)",
+               cp, ffp, FFN_HC, 2 * FFN_HC);
   CTTA_REQUIRE(M >= 1 && ld_x >= cp && ld_x % 8 == 0 && (long long)(M + 128) * ld_x * 2 < 0x7FF00000LL && (long long)(M + 128) * res_ld * 2 < 0x7FF00000LL &&
                (long long)(M + 128) * ldc * 2 < 0x7FF00000LL && res_ld % 4 == 0 && ldc % 4 == 0 &&
                n_valid > 0 && n_valid <= cp && n_valid % 4 == 0 && res_ld >= n_valid && ldc >= n_valid,
                "ffn_geglu: bad extents (M=%lld ld_x=%d res_ld=%d ldc=%d n_valid=%d)", (long long)M, ld_x, res_ld, ldc, n_valid);
+  CTTA_REQUIRE(!ln_gamma || (ln_beta && ln_d > 0 && ln_d <= cp), "ffn_geglu: LayerNorm on load needs gamma, beta and 0 < ln_d=%d <= cp", ln_d);
   FfnParams p;
   memset(&p, 0, sizeof(p));
   const int nchunk = ffp / FFN_HC;
@@ -279,18 +396,18 @@ extern "C" ctta_status ctta_ffn_geglu(const void* x, int ld_x, int64_t M, int cp
   p.w1s = (const bf16_t*)packed; p.w2s = p.w1s + (size_t)FFN_NW * per1 * 8;
   p.b1 = b1; p.b2 = b2; p.res = (const bf16_t*)res; p.res_ld = res_ld; p.out = (bf16_t*)out; p.ldc = ldc;
   p.M = (int)M; p.nchunk = nchunk; p.n_valid = n_valid;
-  const size_t smem = ffn_smem(cp);
-  static bool configured = false;
-  if (!configured) {
-    CTTA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_geglu_kernel<256>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    configured = true;
-  }
+  p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_d = ln_d; p.ln_eps = ln_eps;
+  long long rounds = 0, tiles = 0;
+  int bm = ffn_pick_rows(cp, M, &rounds, &tiles);
+  if (g_ffn_bm) bm = g_ffn_bm;
   hipStream_t s = (hipStream_t)stream;
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, 44, M, cp, 3LL * ffp, 1, s);   // 2 M (2 ffp cp + cp ffp) flops = 2 M cp (3 ffp)
-  ffn_geglu_kernel<256><<<dim3((unsigned)((M + FFN_BM - 1) / FFN_BM)), dim3(512), smem, s>>>(p);
+  ctta_status st;
+  if (cp == 512) st = bm == 80 ? launch_ffn<512, 80>(p, s) : bm == 48 ? launch_ffn<512, 48>(p, s) : launch_ffn<512, 64>(p, s);
+  else st = bm == 144 ? launch_ffn<256, 144>(p, s) : launch_ffn<256, 128>(p, s);
   if (prof) ctta_prof_end(s);
+  CTTA_TRY(st);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }

@@ -832,28 +832,7 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __res
 // 17 MB level-2 tensor, a quarter of the launches' time was the launch itself); gamma / beta of the lane's columns sit in
 // registers; the row sums fold on the VALU -- DPP row rotations inside 16 lanes, v_permlane16/32_swap across them --
 // instead of ten ds_bpermute round trips per row.  Same two-pass variance as before.
-__device__ __forceinline__ float dpp_row_sum(float v) {   // total of the 16 lanes of a DPP row, in every lane
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
-  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
-  return v;
-}
-template <int GL>
-__device__ __forceinline__ float group_sum(float v) {
-  v = dpp_row_sum(v);
-  {
-    const unsigned u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  if constexpr (GL == 64) {
-    const unsigned u = __float_as_uint(v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  return v;
-}
+// (dpp_row_sum / ln_group_sum: common.h -- shared with the LayerNorm-on-load of ffn_fused.hip)
 template <int GL, int VPL, int RPG>
 __global__ __launch_bounds__(256) void layernorm_fast_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
                                                              long long rows, int d, int ld,
@@ -893,14 +872,14 @@ __global__ __launch_bounds__(256) void layernorm_fast_kernel(const bf16_t* __res
         s += f[i][e];
       }
     }
-    const float mean = group_sum<GL>(s) * inv_d;
+    const float mean = ln_group_sum<GL>(s) * inv_d;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < VPL; ++i)
 #pragma unroll
       for (int e = 0; e < 8; ++e)
         if ((sub + i * GL) * 8 + e < d) { const float t = f[i][e] - mean; q += t * t; }
-    const float rstd = rsqrtf(group_sum<GL>(q) * inv_d + eps);
+    const float rstd = rsqrtf(ln_group_sum<GL>(q) * inv_d + eps);
     if (row0 + r < rows) {
 #pragma unroll
       for (int i = 0; i < VPL; ++i) {

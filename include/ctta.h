@@ -421,19 +421,25 @@ ctta_status ctta_reschain_conv1d(const void* x, int batch, int len, int channels
                                  float out_slope, void* stream);
 
 /* Fused GEGLU feed-forward of a transformer block (diffusers/models/attention.py:276-334, 383-386, 430-432: ff.net.0.proj ->
- * chunk -> value * gelu(gate) -> ff.net.2, plus the residual) for the 256-wide level, ONE launch:
+ * chunk -> value * gelu(gate) -> ff.net.2, plus the residual) for the 256- and 512-wide levels, ONE launch:
  *   out[m][0..n_valid) = res[m][..] + b2 + W2 . ( (W1v . x[m] + b1v) * gelu(W1g . x[m] + b1g) )
- * x: bf16 [M][ld_x] (the LayerNorm output, cp = 256 columns used); the hidden activations (ffp columns) never leave the CU.
+ * x: bf16 [M][ld_x] (the LayerNorm output, cp = 256 or 512 columns used); the hidden activations (ffp columns) never leave the
+ * CU.  With ln_gamma != NULL x is the LayerNorm's INPUT and the rows are normalised over their first ln_d columns while they
+ * are staged (norm3 of the block, attention.py:329-334; same arithmetic and summation order as ctta_layernorm: bit-identical
+ * to running it first) -- the normalised tensor never exists in HBM either.
  * `packed` = ctta_ffn_pack's per-wave weight streams (ctta_ffn_pack_bytes bytes) made from the conv_gemm operands of the two
  * linears: ff1 [2*ffp][k_pad1] with its rows in 16-blocks [16 value][16 gate] (what the out_act = 4 epilogue takes), ff2
  * [cp][k_pad2].  b1 follows ff1's row order.  Bit-identical to ctta_conv_gemm(out_act = 4) + ctta_conv_gemm(res).
- * ctta_ffn_geglu_supported: 1 when (cp, ffp) fits the kernel and option "ffn_fuse" is on. */
+ * ctta_ffn_geglu_supported: 1 when (cp, ffp) fits the kernel and option "ffn_fuse" is on; ctta_ffn_geglu_wanted: ... and M rows
+ * fill the kernel's row tiles (one workgroup per CU) well enough to beat the two launches -- what the engines ask. */
 int ctta_ffn_geglu_supported(int cp, int ffp);
+int ctta_ffn_geglu_wanted(int cp, int ffp, int64_t M);
 size_t ctta_ffn_pack_bytes(int cp, int ffp);
 ctta_status ctta_ffn_pack(const void* w1_packed, int k_pad1, const void* w2_packed, int k_pad2, int cp, int ffp, void* dst,
                           void* stream);
 ctta_status ctta_ffn_geglu(const void* x, int ld_x, int64_t M, int cp, int ffp, const void* packed, const float* b1,
-                           const float* b2, const void* res, int res_ld, void* out, int ldc, int n_valid, void* stream);
+                           const float* b2, const void* res, int res_ld, void* out, int ldc, int n_valid,
+                           const float* ln_gamma, const float* ln_beta, int ln_d, float ln_eps, void* stream);
 
 /* Direct convolution for tiny Cout (<= 8): bf16 NHWC in, fp32 weights [n][kh][kw][c],
  * fp32 planar (NCHW) out, optional input leaky-relu and output tanh. */

@@ -18,61 +18,96 @@ from gpu_util import conv_desc, pack_conv_weight  # noqa: E402
 DEV = "cuda:0"
 
 
-def time_ms(fn, reps=10, rounds=5):
-    fn()
+def time_many(fns, reps=20, rounds=7, warm=40):
+    """median ms per call of each fn, the candidates alternating inside every round (the first-timed candidate of a cold
+    device otherwise reads 5-15 % slow)."""
+    for _ in range(warm):
+        fns[0]()
     torch.cuda.synchronize()
     e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    ts = []
+    ts = [[] for _ in fns]
     for _ in range(rounds):
-        e[0].record()
-        for _ in range(reps):
+        for k, fn in enumerate(fns):
             fn()
-        e[1].record()
-        torch.cuda.synchronize()
-        ts.append(e[0].elapsed_time(e[1]) / reps)
-    return sorted(ts)[len(ts) // 2]
+            e[0].record()
+            for _ in range(reps):
+                fn()
+            e[1].record()
+            torch.cuda.synchronize()
+            ts[k].append(e[0].elapsed_time(e[1]) / reps)
+    return [sorted(t)[len(t) // 2] for t in ts]
 
 
 def main():
     L = N.lib()
-    cp, ffp = 256, 1024
+    cp = int(os.environ.get("FFN_CP", "256"))
+    ffp, d = 4 * cp, cp - cp // 256       # 255 -> 256, 510 -> 512: the U-Net's inner widths (heads x 51) and their padding
     g = torch.Generator().manual_seed(1)
     w1 = (torch.randn(2 * ffp, cp, generator=g) * (1.5 / math.sqrt(cp)))
+    w1[:, d:] = 0
     b1 = torch.randn(2 * ffp, generator=g) * 0.2
     w2 = torch.randn(cp, ffp, generator=g) * (1.0 / math.sqrt(ffp))
     b2 = torch.randn(cp, generator=g) * 0.1
+    gamma, beta = (1 + 0.1 * torch.randn(d, generator=g)).to(DEV), (0.1 * torch.randn(d, generator=g)).to(DEV)
     w1p, k1 = pack_conv_weight(w1[:, :, None, None])
     w2p, k2 = pack_conv_weight(w2[:, :, None, None])
     packed = torch.empty(L.ctta_ffn_pack_bytes(cp, ffp), dtype=torch.uint8, device=DEV)
     N.check(L.ctta_ffn_pack(N.ptr(w1p), k1, N.ptr(w2p), k2, cp, ffp, N.ptr(packed), N.stream_ptr()))
     b1d, b2d = b1.to(DEV), b2.to(DEV)
     st = N.stream_ptr()
-    for M in ([int(a) for a in sys.argv[1:]] or [131072, 36864, 300]):
-        x = (torch.randn(M, cp, generator=g)).to(torch.bfloat16).to(DEV)
-        res = (torch.randn(M, cp, generator=g)).to(torch.bfloat16).to(DEV)
+    fl_row = 2.0 * cp * 3 * ffp
+    for M in ([int(a) for a in sys.argv[1:]] or [131072, 73728, 36864, 300]):
+        s2 = (torch.randn(M, cp, generator=g)).to(torch.bfloat16).to(DEV)
+        s2[:, d:] = 0
+        n3 = torch.empty_like(s2)
         gg = torch.empty(M, ffp, dtype=torch.bfloat16, device=DEV)
         out_a = torch.empty(M, cp, dtype=torch.bfloat16, device=DEV)
         out_b = torch.full((M, cp), 7.0, dtype=torch.bfloat16, device=DEV)
-        d1 = conv_desc(x0=x, c0=cp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w1p, k_pad=k1, n=2 * ffp, bias=b1d, out=gg, ldc=ffp, out_act=4)
-        d2 = conv_desc(x0=gg, c0=ffp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w2p, k_pad=k2, n=cp, bias=b2d, res=res, res_ld=cp,
+        out_c = torch.full((M, cp), 7.0, dtype=torch.bfloat16, device=DEV)
+        d1 = conv_desc(x0=n3, c0=cp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w1p, k_pad=k1, n=2 * ffp, bias=b1d, out=gg, ldc=ffp, out_act=4)
+        d2 = conv_desc(x0=gg, c0=ffp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w2p, k_pad=k2, n=cp, bias=b2d, res=s2, res_ld=cp,
                        out=out_a, ldc=cp)
+
+        def ln():
+            N.check(L.ctta_layernorm(N.ptr(s2), N.ptr(n3), M, d, cp, N.ptr(gamma), N.ptr(beta), 1e-5, st))
 
         def two():
             N.check(L.ctta_conv_gemm(ctypes.byref(d1), st))
             N.check(L.ctta_conv_gemm(ctypes.byref(d2), st))
 
-        def one():
-            N.check(L.ctta_ffn_geglu(N.ptr(x), cp, M, cp, ffp, N.ptr(packed), N.ptr(b1d), N.ptr(b2d), N.ptr(res), cp, N.ptr(out_b),
-                                     cp, cp, st))
-        two()
+        def three():
+            ln()
+            two()
+
+        def one(out=out_b):
+            N.check(L.ctta_ffn_geglu(N.ptr(n3), cp, M, cp, ffp, N.ptr(packed), N.ptr(b1d), N.ptr(b2d), N.ptr(s2), cp, N.ptr(out),
+                                     cp, cp, None, None, 0, 0.0, st))
+
+        def one_ln(out=out_c):
+            N.check(L.ctta_ffn_geglu(N.ptr(s2), cp, M, cp, ffp, N.ptr(packed), N.ptr(b1d), N.ptr(b2d), N.ptr(s2), cp, N.ptr(out),
+                                     cp, cp, N.ptr(gamma), N.ptr(beta), d, 1e-5, st))
+
+        def rows(bm, f):
+            def r():
+                L.ctta_ffn_debug_rows(bm)
+                f()
+                L.ctta_ffn_debug_rows(0)
+            return r
+        three()
         one()
+        one_ln()
         torch.cuda.synchronize()
         same = torch.equal(out_a, out_b)
-        diff = float((out_a.float() - out_b.float()).abs().max())
-        fl = 2.0 * M * cp * 3 * ffp
-        t2, t1 = time_ms(two), time_ms(one)
-        print("M %7d: two launches %.3f ms (%.0f TF/s)   fused %.3f ms (%.0f TF/s)   bit-identical %s (max |diff| %.3g)"
-              % (M, t2, fl / t2 / 1e9, t1, fl / t1 / 1e9, same, diff), flush=True)
+        same_ln = torch.equal(out_a, out_c)
+        diff = float((out_a.float() - out_c.float()).abs().max())
+        cands = [("LN + ff1 + ff2 (3 launches)", three), ("ff1 + ff2 (2 launches)", two), ("fused", one), ("fused + LN on load", one_ln)]
+        for bm in ((128, 144) if cp == 256 else (48, 64, 80)):
+            cands.append(("fused, %d-row tile" % bm, rows(bm, one)))
+        tt = time_many([c[1] for c in cands])
+        print("cp %d  M %d (fused wanted: %d): fused == two launches: %s; fused with LayerNorm on load == three launches: %s (max |diff| %.3g)"
+              % (cp, M, L.ctta_ffn_geglu_wanted(cp, ffp, M), same, same_ln, diff))
+        for (name, _), t in zip(cands, tt):
+            print("   %-30s %.4f ms  %.0f TF/s" % (name, t, fl_row * M / t / 1e9), flush=True)
 
 
 if __name__ == "__main__":
