@@ -379,7 +379,7 @@ def main():
         algo_flops = gf_clip * 1e9 * B
         achieved = algo_flops / (conv_ms * 1e-3) / 1e12
         result["roofline"] = {
-            "kernel": "conv_gemm_kernel family (implicit-GEMM conv / linear / bmm + the fused vocoder ResBlock units, v_mfma_f32_16x16x32_bf16)",
+            "kernel": "conv_gemm_kernel family (implicit-GEMM conv / linear / bmm + the fused vocoder ResBlock units + the fused transformer feed-forward, v_mfma_f32_16x16x32_bf16)",
             "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "traffic_detail": pmc_traffic(B),
             "algorithmic_gflop_per_clip": round(gf_clip, 1), "launches_per_step": int(conv_cnt),

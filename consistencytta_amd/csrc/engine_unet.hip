@@ -78,6 +78,7 @@ struct Transformer {
   PackedW proj_in, qk1, v1, out1, q2, k2, v2, out2, ff1, ff2, proj_out;
   LNLayer ln1, ln2, ln3;
   bf16_t *k2c = nullptr, *vt2c = nullptr;   // persistent cross-attention K / V^T of the text states (text cache)
+  bf16_t* ffn_stream = nullptr;             // ff1 / ff2 as per-wave weight streams of the fused feed-forward (ffn_fused.hip)
   LinTrain t_proj_in, t_q1, t_k1, t_v1, t_out1, t_q2, t_k2, t_v2, t_out2, t_ff1, t_ff2, t_proj_out;
   struct Saved {
     const bf16_t *x = nullptr, *g = nullptr, *s0 = nullptr, *n1 = nullptr, *qk = nullptr, *vt = nullptr, *att1 = nullptr,
@@ -265,6 +266,16 @@ static ctta_status make_transformer(ctta_unet* U, const std::string& p, int c, i
   }
   CTTA_TRY(lin(t + "ff.net.2.weight", t + "ff.net.2.bias", inner, ffh, identity_map(inner, cp), identity_map(ffh, ffp),
                &T->ff2, &T->t_ff2));
+  // 256- / 512-wide blocks: the inference forward runs ff1 -> GEGLU -> ff2 + residual as ONE row-tile launch (ctta_ffn_geglu)
+  // that streams both matrices in its own layout; the copy is re-derived from the packed operands after every (re)load
+  if (ctta_ffn_geglu_supported(cp, ffp) && T->ff1.k_pad >= cp && T->ff2.k_pad >= ffp) {
+    T->ffn_stream = reinterpret_cast<bf16_t*>(ws.arena.get<unsigned char>(ctta_ffn_pack_bytes(cp, ffp)));
+    if (!T->ffn_stream) { ctta_set_error("weight store exhausted (feed-forward weight streams)"); return CTTA_ERR_NOMEM; }
+    const bf16_t *w1 = T->ff1.w, *w2 = T->ff2.w;
+    const int k1 = T->ff1.k_pad, k2 = T->ff2.k_pad;
+    bf16_t* dst = T->ffn_stream;
+    ws.jobs.push_back([=](const WeightTable&, hipStream_t s) -> ctta_status { return ctta_ffn_pack(w1, k1, w2, k2, cp, ffp, dst, s); });
+  }
   CTTA_TRY(make_ln(ws, t + "norm1.", inner, &T->ln1));
   CTTA_TRY(make_ln(ws, t + "norm2.", inner, &T->ln2));
   CTTA_TRY(make_ln(ws, t + "norm3.", inner, &T->ln3));
@@ -387,6 +398,15 @@ static ctta_status run_transformer(UCtx& c, Transformer& T, const bf16_t* x, int
     CTTA_TRY(run_linear(c, T.ff1, n, cp, M, f, 2 * T.ffp, nullptr, 0));
     gg = A.get<bf16_t>(M * T.ffp); ALLOC_OR_FAIL(gg);
     RUN(c, ctta_geglu(f, gg, M, T.ffp, 1, c.stream));
+  } else if (T.ffn_stream && ctta_ffn_geglu_wanted(cp, T.ffp, (int64_t)M)) {
+    // ff1 -> GEGLU -> ff2 + residual in one launch: neither the projection nor the hidden activations reach HBM
+    bf16_t* s3f = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s3f);
+    RUN(c, ctta_ffn_geglu(n, cp, (int64_t)M, cp, T.ffp, T.ffn_stream, T.ff1.bias, T.ff2.bias, s2, cp, s3f, cp, T.ff2.n, nullptr,
+                          nullptr, 0, 0.f, c.stream));
+    CTTA_TRY(run_linear(c, T.proj_out, s3f, cp, M, out, T.c, x, T.c));
+    A.release(mk);
+    *out_p = out;
+    return CTTA_OK;
   } else {         // value * gelu(gate) in the GEMM epilogue: the (M, 2*ffp) projection never reaches HBM
     gg = A.get<bf16_t>(M * T.ffp); ALLOC_OR_FAIL(gg);
     ctta_conv_desc d;

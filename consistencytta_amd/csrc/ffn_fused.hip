@@ -366,11 +366,12 @@ static int ffn_pick_rows(int cp, long long M, long long* rounds_out, long long* 
   return best;
 }
 
-// 1: this (cp, ffp, M) runs as the fused kernel -- the shape fits, option "ffn_fuse" is on, and the best row tile fills its
-// rounds to >= 60 % (or there is only one round): below that the two conv_gemm launches, whose small tiles fill the chip, win
-// (measured: M = 36 864 on 128-row tiles, 288 tiles = 2 rounds at 56 %: 0.103 vs 0.092 ms).
+// 1: M rows of this (cp, ffp) are better off in the fused kernel -- the shape fits and the best row tile fills its rounds to
+// >= 60 % (or there is only one round): below that the two conv_gemm launches, whose small tiles fill the chip, win (measured:
+// M = 36 864 on 128-row tiles, 288 tiles = 2 rounds at 56 %: 0.103 vs 0.092 ms).  A pure function of its arguments and the CU
+// count -- the option is read by ctta_ffn_geglu_supported when a handle decides to keep the weight streams.
 extern "C" int ctta_ffn_geglu_wanted(int cp, int ffp, int64_t M) {
-  if (!ctta_ffn_geglu_supported(cp, ffp) || M < 1) return 0;
+  if (!ffn_shape_ok(cp, ffp) || M < 1) return 0;
   long long rounds = 0, tiles = 0;
   (void)ffn_pick_rows(cp, M, &rounds, &tiles);
   if (rounds == 1) return tiles * 4 >= ctta_cu_count() ? 1 : 0;      // a launch that leaves > 3/4 of the CUs idle: small tiles

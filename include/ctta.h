@@ -430,8 +430,9 @@ ctta_status ctta_reschain_conv1d(const void* x, int batch, int len, int channels
  * `packed` = ctta_ffn_pack's per-wave weight streams (ctta_ffn_pack_bytes bytes) made from the conv_gemm operands of the two
  * linears: ff1 [2*ffp][k_pad1] with its rows in 16-blocks [16 value][16 gate] (what the out_act = 4 epilogue takes), ff2
  * [cp][k_pad2].  b1 follows ff1's row order.  Bit-identical to ctta_conv_gemm(out_act = 4) + ctta_conv_gemm(res).
- * ctta_ffn_geglu_supported: 1 when (cp, ffp) fits the kernel and option "ffn_fuse" is on; ctta_ffn_geglu_wanted: ... and M rows
- * fill the kernel's row tiles (one workgroup per CU) well enough to beat the two launches -- what the engines ask. */
+ * ctta_ffn_geglu_supported: 1 when (cp, ffp) fits the kernel and option "ffn_fuse" is on (asked when a handle is built: it then
+ * keeps the weight streams); ctta_ffn_geglu_wanted: 1 when M rows of a fitting (cp, ffp) fill the kernel's row tiles (one
+ * workgroup per CU) well enough to beat the two launches (asked per forward; a pure function of its arguments). */
 int ctta_ffn_geglu_supported(int cp, int ffp);
 int ctta_ffn_geglu_wanted(int cp, int ffp, int64_t M);
 size_t ctta_ffn_pack_bytes(int cp, int ffp);

@@ -260,6 +260,126 @@ def test_linear_with_fused_geglu_epilogue(rows, k, hid, tile):
     assert float(got[:, hid:].abs().max()) == 0.0 if hidp > hid else True
 
 
+def _ffn_case(cp, hid_valid, M, seed):
+    """weights of one GEGLU feed-forward in the engine's packed layouts + the two-launch form as a closure"""
+    ffp = 4 * cp
+    d = cp - cp // 256                                     # 255 -> 256, 510 -> 512: the light U-Net's inner widths
+    w1 = bf16_round(det("ffn.w1.%d" % cp, (2 * hid_valid, d), seed) * (1.5 / math.sqrt(d)))
+    b1 = det("ffn.b1.%d" % cp, (2 * hid_valid,), seed + 1) * 0.2
+    w2 = bf16_round(det("ffn.w2.%d" % cp, (d, hid_valid), seed + 2) * (1.0 / math.sqrt(hid_valid)))
+    b2 = det("ffn.b2.%d" % cp, (d,), seed + 3) * 0.1
+    wi, bi = torch.zeros(2 * ffp, cp), torch.zeros(2 * ffp)          # ff1 rows in 16-blocks [16 value][16 gate], K padded to cp
+    for j in range(hid_valid):
+        wi[(j // 16) * 32 + j % 16, :d], wi[(j // 16) * 32 + 16 + j % 16, :d] = w1[j], w1[hid_valid + j]
+        bi[(j // 16) * 32 + j % 16], bi[(j // 16) * 32 + 16 + j % 16] = b1[j], b1[hid_valid + j]
+    w2i, b2i = torch.zeros(cp, ffp), torch.zeros(cp)
+    w2i[:d, :hid_valid], b2i[:d] = w2, b2
+    w1p, k1 = pack_conv_weight(wi[:, :, None, None])
+    w2p, k2 = pack_conv_weight(w2i[:, :, None, None])
+    L = lib()
+    packed = torch.empty(L.ctta_ffn_pack_bytes(cp, ffp), dtype=torch.uint8, device=DEV)
+    N.check(L.ctta_ffn_pack(N.ptr(w1p), k1, N.ptr(w2p), k2, cp, ffp, N.ptr(packed), N.stream_ptr()))
+    return dict(cp=cp, ffp=ffp, d=d, w1=w1, b1=b1, w2=w2, b2=b2, w1p=w1p, k1=k1, w2p=w2p, k2=k2, b1d=bi.to(DEV), b2d=b2i.to(DEV),
+                packed=packed, hid=hid_valid)
+
+
+def _ffn_two_launches(c, n3, s2, out):
+    """(with "splitk" off: at a few hundred rows the K = 2048 ff2 launch of the 512-wide block would be cut over K -- another
+    summation order than the one walk the engine's launches take at their sizes)"""
+    M, cp, ffp = n3.shape[0], c["cp"], c["ffp"]
+    gg = torch.empty(M, ffp, dtype=torch.bfloat16, device=DEV)
+    N.set_option("splitk", 0)
+    run_conv(conv_desc(x0=n3, c0=cp, batch=1, hi=M, wi=1, ho=M, wo=1, w=c["w1p"], k_pad=c["k1"], n=2 * ffp, bias=c["b1d"], out=gg,
+                       ldc=ffp, out_act=4))
+    run_conv(conv_desc(x0=gg, c0=ffp, batch=1, hi=M, wi=1, ho=M, wo=1, w=c["w2p"], k_pad=c["k2"], n=cp, bias=c["b2d"], res=s2,
+                       res_ld=cp, out=out, ldc=cp))
+    N.set_option("splitk", 1)
+
+
+@pytest.mark.parametrize("cp,M", [(256, 300), (256, 1), (256, 128 * 5 + 17), (512, 300), (512, 48 * 7 + 5), (512, 16)])
+def test_fused_geglu_feed_forward_equals_the_two_launches_bit_for_bit(cp, M):
+    """ctta_ffn_geglu (csrc/ffn_fused.hip): ff1 -> chunk -> value * gelu(gate) -> ff2 + bias + residual of one transformer block
+    (attention.py:276-334, 383-386, 430-432) in ONE launch, the hidden activations in LDS.  Same products in the same K order with
+    the same two bf16 roundings as ctta_conv_gemm(out_act = 4) + ctta_conv_gemm(res): equal bit for bit, with EVERY row tile of the
+    width (ragged last tiles included), and within the bf16 tolerance of the fp32 torch expression.  The output's pad columns
+    and the rows past M are left alone."""
+    L = lib()
+    c = _ffn_case(cp, 4 * (cp - cp // 256), M, 11)
+    d, ffp = c["d"], c["ffp"]
+    n3 = torch.zeros(M, cp)
+    n3[:, :d] = bf16_round(det("ffn.n3", (M, d), 5))
+    s2 = torch.zeros(M, cp)
+    s2[:, :d] = bf16_round(det("ffn.s2", (M, d), 6))
+    proj = F.linear(n3[:, :d], c["w1"], c["b1"])
+    ref = s2[:, :d] + F.linear(bf16_round(proj[:, :c["hid"]] * F.gelu(proj[:, c["hid"]:])), c["w2"], c["b2"])
+    n3d, s2d = n3.to(torch.bfloat16).to(DEV), s2.to(torch.bfloat16).to(DEV)
+    two = torch.full((M, cp), 3.0, dtype=torch.bfloat16, device=DEV)
+    _ffn_two_launches(c, n3d, s2d, two)
+    assert rel_err(two[:, :d].float().cpu(), ref) < 2 * BF16_TOL
+    for bm in ((0, 128, 144) if cp == 256 else (0, 48, 64, 80)):
+        L.ctta_ffn_debug_rows(bm)
+        big = torch.full((M + 3, cp + 8), 3.0, dtype=torch.bfloat16, device=DEV)          # a wider, longer destination
+        N.check(L.ctta_ffn_geglu(N.ptr(n3d), cp, M, cp, ffp, N.ptr(c["packed"]), N.ptr(c["b1d"]), N.ptr(c["b2d"]), N.ptr(s2d), cp,
+                                 N.ptr(big), cp + 8, cp, None, None, 0, 0.0, N.stream_ptr()))
+        sync()
+        L.ctta_ffn_debug_rows(0)
+        assert torch.equal(big[:M, :cp], two), (cp, M, bm)
+        assert bool((big[M:] == 3.0).all()) and bool((big[:, cp:] == 3.0).all()), (cp, M, bm)
+    # n_valid < cp: only the first n_valid columns are written (what a destination narrower than the padded width needs)
+    part = torch.full((M, cp), 3.0, dtype=torch.bfloat16, device=DEV)
+    N.check(L.ctta_ffn_geglu(N.ptr(n3d), cp, M, cp, ffp, N.ptr(c["packed"]), N.ptr(c["b1d"]), N.ptr(c["b2d"]), N.ptr(s2d), cp,
+                             N.ptr(part), cp, cp - 12, None, None, 0, 0.0, N.stream_ptr()))
+    sync()
+    assert torch.equal(part[:, :cp - 12], two[:, :cp - 12]) and bool((part[:, cp - 12:] == 3.0).all())
+
+
+@pytest.mark.parametrize("cp,M", [(256, 777), (512, 333)])
+def test_fused_feed_forward_with_layernorm_on_load(cp, M):
+    """ln_gamma != NULL: x is norm3's INPUT, the rows are normalised while the workgroup stages them (the lane mapping, the
+    summation order and the arithmetic of ctta_layernorm's kernel for the width): bit-identical to ctta_layernorm followed by the
+    fused call -- and therefore to the three launches."""
+    L = lib()
+    c = _ffn_case(cp, 4 * (cp - cp // 256), M, 21)
+    d, ffp = c["d"], c["ffp"]
+    s2 = torch.zeros(M, cp)
+    s2[:, :d] = bf16_round(det("ffnln.s2", (M, d), 6) * 1.3 + 0.2)
+    s2d = s2.to(torch.bfloat16).to(DEV)
+    gamma, beta = (1 + 0.2 * det("ffnln.g", (d,), 7)).to(DEV), (0.1 * det("ffnln.b", (d,), 8)).to(DEV)
+    n3d = torch.empty_like(s2d)
+    N.check(L.ctta_layernorm(N.ptr(s2d), N.ptr(n3d), M, d, cp, N.ptr(gamma), N.ptr(beta), 1e-5, N.stream_ptr()))
+    three = torch.empty(M, cp, dtype=torch.bfloat16, device=DEV)
+    _ffn_two_launches(c, n3d, s2d, three)
+    got = torch.empty(M, cp, dtype=torch.bfloat16, device=DEV)
+    N.check(L.ctta_ffn_geglu(N.ptr(s2d), cp, M, cp, ffp, N.ptr(c["packed"]), N.ptr(c["b1d"]), N.ptr(c["b2d"]), N.ptr(s2d), cp,
+                             N.ptr(got), cp, cp, N.ptr(gamma), N.ptr(beta), d, 1e-5, N.stream_ptr()))
+    sync()
+    assert torch.equal(got, three)
+    n_ref = F.layer_norm(s2[:, :d], (d,), gamma.cpu(), beta.cpu(), 1e-5)
+    proj = F.linear(bf16_round(n_ref), c["w1"], c["b1"])
+    ref = s2[:, :d] + F.linear(bf16_round(proj[:, :c["hid"]] * F.gelu(proj[:, c["hid"]:])), c["w2"], c["b2"])
+    assert rel_err(got[:, :d].float().cpu(), ref) < 3 * BF16_TOL
+
+
+def test_fused_feed_forward_refuses_what_it_cannot_run_and_picks_tiles_by_rounds():
+    L = lib()
+    assert L.ctta_ffn_geglu_supported(256, 1024) == 1 and L.ctta_ffn_geglu_supported(512, 2048) == 1
+    assert L.ctta_ffn_geglu_supported(1024, 4096) == 0 and L.ctta_ffn_geglu_supported(256, 128) == 0 and L.ctta_ffn_geglu_supported(320, 1280) == 0
+    assert L.ctta_ffn_pack_bytes(320, 1280) == 0
+    # the rule the engines ask (256 CUs): full rounds and single rounds of >= 64 tiles are wanted, a second round left > 40 % empty is not
+    for cp, M, want in ((256, 131072, 1), (256, 73728, 1), (256, 36864, 1), (256, 8192, 1), (256, 4096, 0), (256, 37000, 0),
+                        (512, 32768, 1), (512, 18432, 1), (512, 9216, 1), (512, 1024, 0), (1024, 8192, 0)):
+        assert L.ctta_ffn_geglu_wanted(cp, 4 * cp, M) == want, (cp, M)
+    x = torch.zeros(64, 256, dtype=torch.bfloat16, device=DEV)
+    pk = torch.zeros(L.ctta_ffn_pack_bytes(256, 1024), dtype=torch.uint8, device=DEV)
+    b = torch.zeros(2048, device=DEV)
+    with pytest.raises(RuntimeError, match="outside the fused kernel's range"):
+        N.check(L.ctta_ffn_geglu(N.ptr(x), 256, 64, 320, 1280, N.ptr(pk), N.ptr(b), N.ptr(b), N.ptr(x), 256, N.ptr(x), 256, 256, None, None, 0,
+                                 0.0, N.stream_ptr()))
+    with pytest.raises(RuntimeError, match="bad extents"):
+        N.check(L.ctta_ffn_geglu(N.ptr(x), 250, 64, 256, 1024, N.ptr(pk), N.ptr(b), N.ptr(b), N.ptr(x), 256, N.ptr(x), 256, 256, None, None, 0,
+                                 0.0, N.stream_ptr()))
+
+
 def test_conv1d_dilated_lrelu_and_accumulate():
     B, C, L, k, d = 2, 32, 200, 7, 3
     x = bf16_round(det("c1d.x", (B, C, L), 1))

@@ -1,6 +1,6 @@
 """Every library option (include/ctta.h: ctta_set_option) in its NON-default position, through the C ABI.
 
-The library reads no environment variable; these seven ints are its only switches.  Each test sets one option away from its
+The library reads no environment variable; these eight ints are its only switches.  Each test sets one option away from its
 default, runs the path the option governs, compares with the default position (bit-identical where the option only moves
 work between streams / launches / XCDs, within the bf16 tolerance where it changes a summation order), and restores it."""
 import ctypes
@@ -34,7 +34,7 @@ def option():
 def test_option_table_is_complete_and_rejects_what_it_does_not_know():
     L = N.lib()
     names = [L.ctta_option_name(i).decode() for i in range(L.ctta_num_options())]
-    assert names == ["xcd", "splitk", "streamk", "streamk_grid", "wgrad_stream", "gn_fuse", "fused_res"]
+    assert names == ["xcd", "splitk", "streamk", "streamk_grid", "wgrad_stream", "gn_fuse", "fused_res", "ffn_fuse"]
     for i, n in enumerate(names):
         assert N.get_option(n) == L.ctta_option_default(i), n      # nothing in the test process has moved one
     with pytest.raises(N.CttaError, match="unknown option"):
@@ -180,3 +180,34 @@ def test_gn_fuse_and_fused_res_off_agree_with_the_defaults(option):
     print("gn_fuse / fused_res off vs on: mel rel_l2 %.2e, wav rel_l2 %.2e" % (l2(mel1, mel0), l2(wav1, wav0)))
     assert l2(mel1, mel0) < 2.5e-2 and l2(wav1, wav0) < 2.5e-2
     assert not torch.equal(wav1, wav0)     # the other path really ran
+
+
+def test_ffn_fuse_off_runs_the_two_launches_and_gives_the_same_bits(option):
+    """"ffn_fuse" = 0 (read when a handle is built): the inference forward runs every transformer feed-forward as ff1 (+ GEGLU
+    epilogue) and ff2 (+ residual); by default the 256- and 512-wide blocks take ONE ctta_ffn_geglu launch each when their token
+    count fills its row tiles.  A U-Net with 256 / 512 / 64 / 64 channels at 128 x 64 latents: ten blocks fuse (ten launches
+    fewer), the 64-wide ones do not, and the output is the same bit for bit."""
+    cfg = dict(spec.LIGHT_UNET_CONFIG, block_out_channels=[256, 512, 64, 64], attention_head_dim=[5, 10, 2, 2], cross_attention_dim=48)
+    sd = cases.unet_weights(cfg, True, 3)
+    x, ts, gs, enc, mask = cases.unet_inputs(cfg, 2, 128, 64, 7, "ffn_opt")
+    L = N.lib()
+
+    def run():
+        m = modules.UNet2DConditionGuidedModel.from_config(cfg)
+        m.load_state_dict(sd)
+        m = m.to(DEV).eval().requires_grad_(False)
+        with torch.no_grad():
+            m(x.to(DEV), ts.to(DEV), gs.to(DEV), enc.to(DEV), encoder_attention_mask=mask.to(DEV))          # sizing + warm-up
+            L.ctta_prof_enable(1)
+            out = m(x.to(DEV), ts.to(DEV), gs.to(DEV), enc.to(DEV), encoder_attention_mask=mask.to(DEV)).sample.clone()
+            torch.cuda.synchronize()
+            L.ctta_prof_enable(0)
+        ms, fl, cnt = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        N.check(L.ctta_prof_collect(0, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(cnt), None))
+        return out, cnt.value
+    a, n_on = run()
+    option("ffn_fuse", 0)
+    b, n_off = run()
+    option("ffn_fuse", 1)
+    assert n_off - n_on == 10, (n_on, n_off)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())

@@ -25,7 +25,7 @@ from collections import defaultdict
 
 
 def family(name):
-    if "resunit_kernel" in name or "conv_gemm_sk_kernel" in name:   # the fused vocoder ResBlock units and the stream-K launches
+    if "resunit_kernel" in name or "conv_gemm_sk_kernel" in name or "ffn_geglu_kernel" in name:   # the fused vocoder ResBlock units, the stream-K launches, the fused feed-forward
         return "conv_gemm_kernel"                                     # (round 6) belong to the conv_gemm family
     if "adamw_ema2_zero_kernel" in name:                              # the one-pass optimizer tail (round 6)
         return "adamw_kernel"
