@@ -63,6 +63,15 @@ class HifiganConfig(Structure):
     ]
 
 
+class FfnDesc(Structure):
+    """ctta_ffn_desc (include/ctta.h)"""
+    _fields_ = [("x", c_void_p), ("ld_x", c_int), ("M", c_int64), ("cp", c_int), ("ffp", c_int),
+                ("packed", c_void_p), ("b1", c_void_p), ("b2", c_void_p), ("res", c_void_p), ("res_ld", c_int),
+                ("out", c_void_p), ("ldc", c_int), ("n_valid", c_int),
+                ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_d", c_int), ("ln_eps", c_float),
+                ("proj_packed", c_void_p), ("proj_bias", c_void_p), ("proj_res", c_void_p), ("proj_res_ld", c_int)]
+
+
 class ConvDesc(Structure):
     _fields_ = [
         ("x0", c_void_p), ("c0", c_int), ("x1", c_void_p), ("c1", c_int),
@@ -215,6 +224,10 @@ SIGNATURES = {
     "ctta_mean_tokens": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_mean_tokens_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_resunit_supported": (c_int, [c_int, c_int, c_int]),
+    "ctta_ffn_desc_init": (None, [c_void_p]),
+    "ctta_ffn_proj_pack_bytes": (c_size_t, [c_int]),
+    "ctta_ffn_proj_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_ffn_block": (c_int, [c_void_p, c_void_p]),
     "ctta_ffn_geglu_supported": (c_int, [c_int, c_int]),
     "ctta_ffn_geglu_wanted": (c_int, [c_int, c_int, c_int64]),
     "ctta_ffn_pack_bytes": (c_size_t, [c_int, c_int]),

@@ -79,6 +79,8 @@ struct Transformer {
   LNLayer ln1, ln2, ln3;
   bf16_t *k2c = nullptr, *vt2c = nullptr;   // persistent cross-attention K / V^T of the text states (text cache)
   bf16_t* ffn_stream = nullptr;             // ff1 / ff2 as per-wave weight streams of the fused feed-forward (ffn_fused.hip)
+  bool want_proj_stream = false;
+  bf16_t* proj_stream = nullptr;            // ... and proj_out as its tail projection (when its width is the block's padded inner width)
   LinTrain t_proj_in, t_q1, t_k1, t_v1, t_out1, t_q2, t_k2, t_v2, t_out2, t_ff1, t_ff2, t_proj_out;
   struct Saved {
     const bf16_t *x = nullptr, *g = nullptr, *s0 = nullptr, *n1 = nullptr, *qk = nullptr, *vt = nullptr, *att1 = nullptr,
@@ -275,12 +277,20 @@ static ctta_status make_transformer(ctta_unet* U, const std::string& p, int c, i
     const int k1 = T->ff1.k_pad, k2 = T->ff2.k_pad;
     bf16_t* dst = T->ffn_stream;
     ws.jobs.push_back([=](const WeightTable&, hipStream_t s) -> ctta_status { return ctta_ffn_pack(w1, k1, w2, k2, cp, ffp, dst, s); });
+    T->want_proj_stream = true;
   }
   CTTA_TRY(make_ln(ws, t + "norm1.", inner, &T->ln1));
   CTTA_TRY(make_ln(ws, t + "norm2.", inner, &T->ln2));
   CTTA_TRY(make_ln(ws, t + "norm3.", inner, &T->ln3));
   CTTA_TRY(lin(p + "proj_out.weight", p + "proj_out.bias", c, inner, identity_map(c, round_up(c, 4)), in_cols,
                &T->proj_out, &T->t_proj_out));
+  if (T->want_proj_stream && T->proj_out.n == cp && T->proj_out.k_pad == cp && c == cp) {
+    T->proj_stream = reinterpret_cast<bf16_t*>(ws.arena.get<unsigned char>(ctta_ffn_proj_pack_bytes(cp)));
+    if (!T->proj_stream) { ctta_set_error("weight store exhausted (projection weight stream)"); return CTTA_ERR_NOMEM; }
+    const bf16_t* w3 = T->proj_out.w;
+    bf16_t* dst = T->proj_stream;
+    ws.jobs.push_back([=](const WeightTable&, hipStream_t s) -> ctta_status { return ctta_ffn_proj_pack(w3, cp, cp, dst, s); });
+  }
   return CTTA_OK;
 }
 
@@ -399,11 +409,22 @@ static ctta_status run_transformer(UCtx& c, Transformer& T, const bf16_t* x, int
     gg = A.get<bf16_t>(M * T.ffp); ALLOC_OR_FAIL(gg);
     RUN(c, ctta_geglu(f, gg, M, T.ffp, 1, c.stream));
   } else if (T.ffn_stream && ctta_ffn_geglu_wanted(cp, T.ffp, (int64_t)M)) {
-    // ff1 -> GEGLU -> ff2 + residual in one launch: neither the projection nor the hidden activations reach HBM
-    bf16_t* s3f = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s3f);
-    RUN(c, ctta_ffn_geglu(n, cp, (int64_t)M, cp, T.ffp, T.ffn_stream, T.ff1.bias, T.ff2.bias, s2, cp, s3f, cp, T.ff2.n, nullptr,
-                          nullptr, 0, 0.f, c.stream));
-    CTTA_TRY(run_linear(c, T.proj_out, s3f, cp, M, out, T.c, x, T.c));
+    // ff1 -> GEGLU -> ff2 + residual (-> proj_out + block input) in one launch: neither the projection, the hidden activations
+    // nor (with the tail) the feed-forward result reach HBM
+    ctta_ffn_desc fd;
+    ctta_ffn_desc_init(&fd);
+    fd.x = n; fd.ld_x = cp; fd.M = (int64_t)M; fd.cp = cp; fd.ffp = T.ffp; fd.packed = T.ffn_stream;
+    fd.b1 = T.ff1.bias; fd.b2 = T.ff2.bias; fd.res = s2; fd.res_ld = cp;
+    if (T.proj_stream) {
+      fd.proj_packed = T.proj_stream; fd.proj_bias = T.proj_out.bias; fd.proj_res = x; fd.proj_res_ld = T.c;
+      fd.out = out; fd.ldc = T.c; fd.n_valid = T.proj_out.n;
+      RUN(c, ctta_ffn_block(&fd, c.stream));
+    } else {
+      bf16_t* s3f = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s3f);
+      fd.out = s3f; fd.ldc = cp; fd.n_valid = T.ff2.n;
+      RUN(c, ctta_ffn_block(&fd, c.stream));
+      CTTA_TRY(run_linear(c, T.proj_out, s3f, cp, M, out, T.c, x, T.c));
+    }
     A.release(mk);
     *out_p = out;
     return CTTA_OK;

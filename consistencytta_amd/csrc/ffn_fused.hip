@@ -35,6 +35,7 @@ struct FfnParams {
   bf16_t* out; int ldc;
   int M, nchunk, n_valid;         // n_valid: output columns stored (<= CP, multiple of 4)
   const float* ln_gamma; const float* ln_beta; int ln_d; float ln_eps;   // LayerNorm over the first ln_d columns while staging
+  const bf16_t* w3s; const float* b3; const bf16_t* res3; int res3_ld;   // tail projection [CP][CP] (stream as w2s with S1 steps)
 };
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -233,23 +234,25 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
     }
   }
 
-  // ---- epilogue: + b2 + residual -> bf16.  Descriptors bounded to M rows (rows past M read zeros / are dropped), a lane whose
-  //      columns lie past n_valid gets an offset outside them: no branch, all residual loads in flight before the first store
-  {
+  // ---- epilogue: acc + bias + residual -> bf16.  Descriptors bounded to M rows (rows past M read zeros / are dropped), a lane
+  //      whose columns lie past n_valid gets an offset outside them: no branch, all residual loads in flight before the first
+  //      store.  TO_LDS: the rows go to the A tile region instead ([BM][RS] bf16: the operand of the tail projection).
+  const int n0 = w * NC2 * 16 + lg * 4;
+  auto finish = [&](const float* bias, const bf16_t* res, const int res_ld, bf16_t* out, const int ldc, const int n_valid,
+                    const bool to_lds) {
     const __amdgpu_buffer_rsrc_t rsr =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, (unsigned)((size_t)p.M * p.res_ld * 2), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, (unsigned)((size_t)p.M * res_ld * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rso =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, (unsigned)((size_t)p.M * p.ldc * 2), 0x00020000);
-    const int n0 = w * NC2 * 16 + lg * 4;
+        __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, to_lds ? 0u : (unsigned)((size_t)p.M * ldc * 2), 0x00020000);
 #pragma unroll
     for (int i = 0; i < NC2; ++i) {
       const int n = n0 + i * 16;
-      const float4 bb = *reinterpret_cast<const float4*>(p.b2 + n);
-      const bool live = n < p.n_valid;
-      const int vr = live ? ((m0 + lq) * p.res_ld + n) * 2 : (int)0x80000000, vo = live ? ((m0 + lq) * p.ldc + n) * 2 : (int)0x80000000;   // extents < 2^31 - 2^20 (host check)
+      const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+      const bool live = n < n_valid;
+      const int vr = live ? ((m0 + lq) * res_ld + n) * 2 : (int)0x80000000, vo = live ? ((m0 + lq) * ldc + n) * 2 : (int)0x80000000;   // extents < 2^31 - 2^20 (host check)
       u32x2_t r[PB];
 #pragma unroll
-      for (int pb = 0; pb < PB; ++pb) r[pb] = __builtin_amdgcn_raw_buffer_load_b64(rsr, vr + pb * 16 * p.res_ld * 2, 0, 0);
+      for (int pb = 0; pb < PB; ++pb) r[pb] = __builtin_amdgcn_raw_buffer_load_b64(rsr, vr + pb * 16 * res_ld * 2, 0, 0);
 #pragma unroll
       for (int pb = 0; pb < PB; ++pb) {
         const f32x4_t a = acc2[i][pb];
@@ -260,10 +263,47 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
         u32x2_t pk;
         pk[0] = pack2bf(v0, v1);
         pk[1] = pack2bf(v2, v3);
-        __builtin_amdgcn_raw_buffer_store_b64(pk, rso, vo + pb * 16 * p.ldc * 2, 0, 0);
+        if (to_lds) *reinterpret_cast<u32x2_t*>(atile + (pb * 16 + lq) * RS + n) = pk;
+        else __builtin_amdgcn_raw_buffer_store_b64(pk, rso, vo + pb * 16 * ldc * 2, 0, 0);
       }
     }
+  };
+  if (!p.w3s) {
+    finish(p.b2, p.res, p.res_ld, p.out, p.ldc, p.n_valid, false);
+    return;
   }
+  // ---- tail projection (proj_out of the Transformer2DModel, transformer_2d.py:  out = proj(s3) + bias + block input): the
+  //      feed-forward result s3 (bf16, exactly what the two-launch form stores) becomes the A tile of one more GEMM with K = CP
+  //      -- every GEMM1 is behind the loop's last barrier, so the LayerNorm tile is dead; s3 never reaches HBM.
+  finish(p.b2, p.res, p.res_ld, nullptr, 0, CP, true);
+  {
+    const uint4* w3p = reinterpret_cast<const uint4*>(p.w3s) + (size_t)w * (S1 + FFN_PF) * NC2 * 64 + lane;
+#pragma unroll
+    for (int s = 0; s < FFN_PF; ++s)
+#pragma unroll
+      for (int i = 0; i < NC2; ++i) r2[s][i] = __builtin_bit_cast(bf16x8_t, w3p[(s * NC2 + i) * 64]);
+    w3p += FFN_PF * NC2 * 64;
+#pragma unroll
+    for (int i = 0; i < NC2; ++i)
+#pragma unroll
+      for (int j = 0; j < PB; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    FFN_LDS_BARRIER();
+#pragma unroll
+    for (int st = 0; st < S1; ++st) {
+#pragma unroll
+      for (int i = 0; i < NC2; ++i) r2[FFN_PF][i] = __builtin_bit_cast(bf16x8_t, w3p[(st * NC2 + i) * 64]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(aw + pb * 16 * RS + st * 32));
+#pragma unroll
+        for (int i = 0; i < NC2; ++i)
+          acc2[i][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2[0][i], bf, acc2[i][pb], 0, 0, 0);
+      }
+      ring2();
+    }
+  }
+  finish(p.b3, p.res3, p.res3_ld, p.out, p.ldc, p.n_valid, false);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -300,6 +340,22 @@ __global__ void ffn_pack_kernel(const bf16_t* __restrict__ w1, int k_pad1, const
         v = *reinterpret_cast<const uint4*>(w2 + (size_t)((wv * NC2 + i) * 16 + (lane & 15)) * k_pad2 + (c * S2 + ks) * 32 + (lane >> 4) * 8);
       reinterpret_cast<uint4*>(w2s)[t2] = v;
     }
+  }
+}
+
+// tail projection [cp][k_pad] -> w3s[w][st][i][lane][8] = W3[(w*NC2 + i)*16 + lq][st*32 + lg*8 ..], st < cp / 32, + FFN_PF steps of zeros
+__global__ void ffn_pack_proj_kernel(const bf16_t* __restrict__ w3, int k_pad, int cp, bf16_t* __restrict__ w3s) {
+  const int S1 = cp / 32, NC2 = cp / 16 / FFN_NW;
+  const long long per = (long long)(S1 + FFN_PF) * NC2 * 64, total = FFN_NW * per;
+  for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+    const int wv = (int)(t / per);
+    const long long r = t - wv * per;
+    const int lane = (int)(r & 63);
+    const long long f = r >> 6;
+    const int i = (int)(f % NC2), st = (int)(f / NC2);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (st < S1) v = *reinterpret_cast<const uint4*>(w3 + (size_t)((wv * NC2 + i) * 16 + (lane & 15)) * k_pad + st * 32 + (lane >> 4) * 8);
+    reinterpret_cast<uint4*>(w3s)[t] = v;
   }
 }
 
@@ -378,32 +434,53 @@ extern "C" int ctta_ffn_geglu_wanted(int cp, int ffp, int64_t M) {
   return tiles * 10 >= rounds * ctta_cu_count() * 6 ? 1 : 0;
 }
 
-extern "C" ctta_status ctta_ffn_geglu(const void* x, int ld_x, int64_t M, int cp, int ffp, const void* packed, const float* b1,
-                                      const float* b2, const void* res, int res_ld, void* out, int ldc, int n_valid,
-                                      const float* ln_gamma, const float* ln_beta, int ln_d, float ln_eps, void* stream) {
-  CTTA_REQUIRE(x && packed && b1 && b2 && res && out, "ffn_geglu: null pointer");
-  CTTA_REQUIRE(ffn_shape_ok(cp, ffp), "ffn_geglu: cp=%d ffp=%d is outside the fused kernel's range (cp 256 or 512, ffp a multiple of %d, >= %d)",
+extern "C" size_t ctta_ffn_proj_pack_bytes(int cp) {
+  if (cp != 256 && cp != 512) return 0;
+  return (size_t)FFN_NW * (cp / 32 + FFN_PF) * (cp / 16 / FFN_NW) * 64 * 16;
+}
+
+extern "C" ctta_status ctta_ffn_proj_pack(const void* w_packed, int k_pad, int cp, void* dst, void* stream) {
+  CTTA_REQUIRE(w_packed && dst, "ffn_proj_pack: null pointer");
+  CTTA_REQUIRE((cp == 256 || cp == 512) && k_pad >= cp && k_pad % 8 == 0, "ffn_proj_pack: cp=%d (256 or 512), k_pad=%d >= cp", cp, k_pad);
+  hipLaunchKernelGGL(ffn_pack_proj_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_packed, k_pad, cp, (bf16_t*)dst);
+  CTTA_LAUNCH_CHECK();
+  return CTTA_OK;
+}
+
+extern "C" void ctta_ffn_desc_init(ctta_ffn_desc* d) { memset(d, 0, sizeof(*d)); }
+
+extern "C" ctta_status ctta_ffn_block(const ctta_ffn_desc* d, void* stream) {
+  CTTA_REQUIRE(d, "ffn_block: null descriptor");
+  const int cp = d->cp, ffp = d->ffp, ld_x = d->ld_x, res_ld = d->res_ld, ldc = d->ldc, n_valid = d->n_valid;
+  const int64_t M = d->M;
+  CTTA_REQUIRE(d->x && d->packed && d->b1 && d->b2 && d->res && d->out, "ffn_block: null pointer");
+  CTTA_REQUIRE(ffn_shape_ok(cp, ffp), "ffn_block: cp=%d ffp=%d is outside the fused kernel's range (cp 256 or 512, ffp a multiple of %d, >= %d)",
                cp, ffp, FFN_HC, 2 * FFN_HC);
-  CTTA_REQUIRE(M >= 1 && ld_x >= cp && ld_x % 8 == 0 && (long long)(M + 128) * ld_x * 2 < 0x7FF00000LL && (long long)(M + 128) * res_ld * 2 < 0x7FF00000LL &&
-               (long long)(M + 128) * ldc * 2 < 0x7FF00000LL && res_ld % 4 == 0 && ldc % 4 == 0 &&
-               n_valid > 0 && n_valid <= cp && n_valid % 4 == 0 && res_ld >= n_valid && ldc >= n_valid,
-               "ffn_geglu: bad extents (M=%lld ld_x=%d res_ld=%d ldc=%d n_valid=%d)", (long long)M, ld_x, res_ld, ldc, n_valid);
-  CTTA_REQUIRE(!ln_gamma || (ln_beta && ln_d > 0 && ln_d <= cp), "ffn_geglu: LayerNorm on load needs gamma, beta and 0 < ln_d=%d <= cp", ln_d);
+  CTTA_REQUIRE(M >= 1 && ld_x >= cp && ld_x % 8 == 0 && (long long)(M + 144) * ld_x * 2 < 0x7FF00000LL && (long long)(M + 144) * res_ld * 2 < 0x7FF00000LL &&
+               (long long)(M + 144) * ldc * 2 < 0x7FF00000LL && res_ld % 4 == 0 && ldc % 4 == 0 &&
+               n_valid > 0 && n_valid <= cp && n_valid % 4 == 0 && res_ld >= (d->proj_packed ? cp : n_valid) && ldc >= n_valid,
+               "ffn_block: bad extents (M=%lld ld_x=%d res_ld=%d ldc=%d n_valid=%d)", (long long)M, ld_x, res_ld, ldc, n_valid);
+  CTTA_REQUIRE(!d->ln_gamma || (d->ln_beta && d->ln_d > 0 && d->ln_d <= cp), "ffn_block: LayerNorm on load needs gamma, beta and 0 < ln_d=%d <= cp", d->ln_d);
+  CTTA_REQUIRE(!d->proj_packed || (d->proj_bias && d->proj_res && d->proj_res_ld >= n_valid && d->proj_res_ld % 4 == 0 &&
+                                   (long long)(M + 144) * d->proj_res_ld * 2 < 0x7FF00000LL),
+               "ffn_block: the tail projection needs its bias and its residual (proj_res_ld=%d >= n_valid)", d->proj_res_ld);
   FfnParams p;
   memset(&p, 0, sizeof(p));
   const int nchunk = ffp / FFN_HC;
   const size_t per1 = ((size_t)nchunk * (cp / 32) + FFN_PF) * 2 * 64;
-  p.x = (const bf16_t*)x; p.ld_x = ld_x;
-  p.w1s = (const bf16_t*)packed; p.w2s = p.w1s + (size_t)FFN_NW * per1 * 8;
-  p.b1 = b1; p.b2 = b2; p.res = (const bf16_t*)res; p.res_ld = res_ld; p.out = (bf16_t*)out; p.ldc = ldc;
+  p.x = (const bf16_t*)d->x; p.ld_x = ld_x;
+  p.w1s = (const bf16_t*)d->packed; p.w2s = p.w1s + (size_t)FFN_NW * per1 * 8;
+  p.b1 = d->b1; p.b2 = d->b2; p.res = (const bf16_t*)d->res; p.res_ld = res_ld; p.out = (bf16_t*)d->out; p.ldc = ldc;
   p.M = (int)M; p.nchunk = nchunk; p.n_valid = n_valid;
-  p.ln_gamma = ln_gamma; p.ln_beta = ln_beta; p.ln_d = ln_d; p.ln_eps = ln_eps;
+  p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_d = d->ln_d; p.ln_eps = d->ln_eps;
+  p.w3s = (const bf16_t*)d->proj_packed; p.b3 = d->proj_bias; p.res3 = (const bf16_t*)d->proj_res; p.res3_ld = d->proj_res_ld;
   long long rounds = 0, tiles = 0;
   int bm = ffn_pick_rows(cp, M, &rounds, &tiles);
   if (g_ffn_bm) bm = g_ffn_bm;
   hipStream_t s = (hipStream_t)stream;
   const bool prof = ctta_prof_active();
-  if (prof) ctta_prof_begin(0, 44, M, cp, 3LL * ffp, 1, s);   // 2 M (2 ffp cp + cp ffp) flops = 2 M cp (3 ffp)
+  // 2 M cp (2 ffp + ffp [+ cp]) flops as one "launch" of K = 3 ffp [+ cp]
+  if (prof) ctta_prof_begin(0, 44, M, cp, 3LL * ffp + (d->proj_packed ? cp : 0), 1, s);
   ctta_status st;
   if (cp == 512) st = bm == 80 ? launch_ffn<512, 80>(p, s) : bm == 48 ? launch_ffn<512, 48>(p, s) : launch_ffn<512, 64>(p, s);
   else st = bm == 144 ? launch_ffn<256, 144>(p, s) : launch_ffn<256, 128>(p, s);
@@ -411,4 +488,14 @@ extern "C" ctta_status ctta_ffn_geglu(const void* x, int ld_x, int64_t M, int cp
   CTTA_TRY(st);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
+}
+
+extern "C" ctta_status ctta_ffn_geglu(const void* x, int ld_x, int64_t M, int cp, int ffp, const void* packed, const float* b1,
+                                      const float* b2, const void* res, int res_ld, void* out, int ldc, int n_valid,
+                                      const float* ln_gamma, const float* ln_beta, int ln_d, float ln_eps, void* stream) {
+  ctta_ffn_desc d;
+  memset(&d, 0, sizeof(d));
+  d.x = x; d.ld_x = ld_x; d.M = M; d.cp = cp; d.ffp = ffp; d.packed = packed; d.b1 = b1; d.b2 = b2; d.res = res; d.res_ld = res_ld;
+  d.out = out; d.ldc = ldc; d.n_valid = n_valid; d.ln_gamma = ln_gamma; d.ln_beta = ln_beta; d.ln_d = ln_d; d.ln_eps = ln_eps;
+  return ctta_ffn_block(&d, stream);
 }

@@ -441,6 +441,24 @@ ctta_status ctta_ffn_pack(const void* w1_packed, int k_pad1, const void* w2_pack
 ctta_status ctta_ffn_geglu(const void* x, int ld_x, int64_t M, int cp, int ffp, const void* packed, const float* b1,
                            const float* b2, const void* res, int res_ld, void* out, int ldc, int n_valid,
                            const float* ln_gamma, const float* ln_beta, int ln_d, float ln_eps, void* stream);
+/* The same launch by descriptor, with the optional TAIL PROJECTION of the Transformer2DModel (transformer_2d.py: proj_out + the
+ * block's input as residual): with proj_packed != NULL
+ *   out[m][0..n_valid) = proj_res[m][..] + proj_bias + Wp . bf16( res[m] + b2 + W2 . (...) )
+ * i.e. the feed-forward result is rounded to bf16 (what the separate launch would store), becomes the operand of one more
+ * cp x cp GEMM inside the workgroup and never reaches HBM.  proj_packed = ctta_ffn_proj_pack's stream of the conv_gemm operand
+ * [cp][k_pad]; `out` / `ldc` / `n_valid` then describe the projection's output.  Bit-identical to the three launches. */
+typedef struct {
+  const void* x; int ld_x; int64_t M; int cp, ffp;
+  const void* packed; const float* b1; const float* b2;
+  const void* res; int res_ld;
+  void* out; int ldc; int n_valid;
+  const float* ln_gamma; const float* ln_beta; int ln_d; float ln_eps;
+  const void* proj_packed; const float* proj_bias; const void* proj_res; int proj_res_ld;
+} ctta_ffn_desc;
+void ctta_ffn_desc_init(ctta_ffn_desc* d);
+size_t ctta_ffn_proj_pack_bytes(int cp);
+ctta_status ctta_ffn_proj_pack(const void* w_packed, int k_pad, int cp, void* dst, void* stream);
+ctta_status ctta_ffn_block(const ctta_ffn_desc* d, void* stream);
 
 /* Direct convolution for tiny Cout (<= 8): bf16 NHWC in, fp32 weights [n][kh][kw][c],
  * fp32 planar (NCHW) out, optional input leaky-relu and output tanh. */

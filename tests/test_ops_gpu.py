@@ -360,6 +360,58 @@ def test_fused_feed_forward_with_layernorm_on_load(cp, M):
     assert rel_err(got[:, :d].float().cpu(), ref) < 3 * BF16_TOL
 
 
+@pytest.mark.parametrize("cp,M", [(256, 500), (256, 144 * 3), (512, 333)])
+def test_fused_feed_forward_with_the_tail_projection(cp, M):
+    """ctta_ffn_block with proj_packed: proj_out of the Transformer2DModel (+ bias + the block's input as residual,
+    transformer_2d.py) as one more GEMM inside the workgroup, on the bf16-rounded feed-forward result that the separate launch
+    would have stored: bit-identical to ff1 + ff2 + proj_out as three ctta_conv_gemm launches, every row tile, a destination
+    narrower than the padded width."""
+    L = lib()
+    c = _ffn_case(cp, 4 * (cp - cp // 256), M, 31)
+    d, ffp = c["d"], c["ffp"]
+    n_out = cp - 4
+    wp_ = bf16_round(det("ffnp.w", (n_out, d), 9) * (1.0 / math.sqrt(d)))
+    bp_ = det("ffnp.b", (n_out,), 10) * 0.1
+    wpi, bpi = torch.zeros(cp, cp), torch.zeros(cp)
+    wpi[:n_out, :d], bpi[:n_out] = wp_, bp_
+    w3p, k3 = pack_conv_weight(wpi[:, :, None, None])
+    assert k3 == cp
+    pstream = torch.empty(L.ctta_ffn_proj_pack_bytes(cp), dtype=torch.uint8, device=DEV)
+    N.check(L.ctta_ffn_proj_pack(N.ptr(w3p), k3, cp, N.ptr(pstream), N.stream_ptr()))
+    n3 = torch.zeros(M, cp)
+    n3[:, :d] = bf16_round(det("ffnp.n3", (M, d), 5))
+    s2 = torch.zeros(M, cp)
+    s2[:, :d] = bf16_round(det("ffnp.s2", (M, d), 6))
+    xin = bf16_round(det("ffnp.x", (M, cp), 7))
+    n3d, s2d, xd = n3.to(torch.bfloat16).to(DEV), s2.to(torch.bfloat16).to(DEV), xin.to(torch.bfloat16).to(DEV)
+    s3 = torch.empty(M, cp, dtype=torch.bfloat16, device=DEV)
+    _ffn_two_launches(c, n3d, s2d, s3)
+    three = torch.full((M, cp), 3.0, dtype=torch.bfloat16, device=DEV)
+    bpd = bpi.to(DEV)
+    run_conv(conv_desc(x0=s3, c0=cp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w3p, k_pad=k3, n=n_out, bias=bpd, res=xd, res_ld=cp, out=three,
+                       ldc=cp))
+    ref = xin[:, :n_out] + F.linear(s3[:, :d].float().cpu(), wp_, bp_)
+    assert rel_err(three[:, :n_out].float().cpu(), ref) < 2 * BF16_TOL
+    fd = N.FfnDesc()
+    L.ctta_ffn_desc_init(ctypes.byref(fd))
+    fd.x, fd.ld_x, fd.M, fd.cp, fd.ffp = n3d.data_ptr(), cp, M, cp, ffp
+    fd.packed, fd.b1, fd.b2 = c["packed"].data_ptr(), c["b1d"].data_ptr(), c["b2d"].data_ptr()
+    fd.res, fd.res_ld = s2d.data_ptr(), cp
+    fd.proj_packed, fd.proj_bias, fd.proj_res, fd.proj_res_ld = pstream.data_ptr(), bpd.data_ptr(), xd.data_ptr(), cp
+    for bm in ((0, 128, 144) if cp == 256 else (0, 48, 64, 80)):
+        got = torch.full((M + 2, cp), 3.0, dtype=torch.bfloat16, device=DEV)
+        fd.out, fd.ldc, fd.n_valid = got.data_ptr(), cp, n_out
+        L.ctta_ffn_debug_rows(bm)
+        N.check(L.ctta_ffn_block(ctypes.byref(fd), N.stream_ptr()))
+        sync()
+        L.ctta_ffn_debug_rows(0)
+        assert torch.equal(got[:M], three), (cp, M, bm)
+        assert bool((got[M:] == 3.0).all())
+    fd.proj_bias = None
+    with pytest.raises(RuntimeError, match="tail projection needs"):
+        N.check(L.ctta_ffn_block(ctypes.byref(fd), N.stream_ptr()))
+
+
 def test_fused_feed_forward_refuses_what_it_cannot_run_and_picks_tiles_by_rounds():
     L = lib()
     assert L.ctta_ffn_geglu_supported(256, 1024) == 1 and L.ctta_ffn_geglu_supported(512, 2048) == 1
