@@ -69,7 +69,9 @@ class FfnDesc(Structure):
                 ("packed", c_void_p), ("b1", c_void_p), ("b2", c_void_p), ("res", c_void_p), ("res_ld", c_int),
                 ("out", c_void_p), ("ldc", c_int), ("n_valid", c_int),
                 ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_d", c_int), ("ln_eps", c_float),
-                ("proj_packed", c_void_p), ("proj_bias", c_void_p), ("proj_res", c_void_p), ("proj_res_ld", c_int)]
+                ("proj_packed", c_void_p), ("proj_bias", c_void_p), ("proj_res", c_void_p), ("proj_res_ld", c_int),
+                ("front_packed", c_void_p), ("front_bias", c_void_p), ("att", c_void_p), ("att_ld", c_int), ("front_k", c_int),
+                ("front_res", c_void_p), ("front_res_ld", c_int), ("s2_out", c_void_p), ("s2_ld", c_int)]
 
 
 class ConvDesc(Structure):
@@ -225,8 +227,8 @@ SIGNATURES = {
     "ctta_mean_tokens_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_resunit_supported": (c_int, [c_int, c_int, c_int]),
     "ctta_ffn_desc_init": (None, [c_void_p]),
-    "ctta_ffn_proj_pack_bytes": (c_size_t, [c_int]),
-    "ctta_ffn_proj_pack": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "ctta_ffn_proj_pack_bytes": (c_size_t, [c_int, c_int]),
+    "ctta_ffn_proj_pack": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ctta_ffn_block": (c_int, [c_void_p, c_void_p]),
     "ctta_ffn_geglu_supported": (c_int, [c_int, c_int]),
     "ctta_ffn_geglu_wanted": (c_int, [c_int, c_int, c_int64]),

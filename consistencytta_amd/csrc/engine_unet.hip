@@ -80,6 +80,7 @@ struct Transformer {
   bf16_t *k2c = nullptr, *vt2c = nullptr;   // persistent cross-attention K / V^T of the text states (text cache)
   bf16_t* ffn_stream = nullptr;             // ff1 / ff2 as per-wave weight streams of the fused feed-forward (ffn_fused.hip)
   bool want_proj_stream = false;
+  bf16_t* front_stream = nullptr;           // ... and attn2.to_out as its front projection
   bf16_t* proj_stream = nullptr;            // ... and proj_out as its tail projection (when its width is the block's padded inner width)
   LinTrain t_proj_in, t_q1, t_k1, t_v1, t_out1, t_q2, t_k2, t_v2, t_out2, t_ff1, t_ff2, t_proj_out;
   struct Saved {
@@ -284,12 +285,19 @@ static ctta_status make_transformer(ctta_unet* U, const std::string& p, int c, i
   CTTA_TRY(make_ln(ws, t + "norm3.", inner, &T->ln3));
   CTTA_TRY(lin(p + "proj_out.weight", p + "proj_out.bias", c, inner, identity_map(c, round_up(c, 4)), in_cols,
                &T->proj_out, &T->t_proj_out));
+  if (T->want_proj_stream && T->out2.n == cp && T->out2.k_pad == hp && T->out2.bias && ctta_ffn_proj_pack_bytes(cp, hp)) {
+    T->front_stream = reinterpret_cast<bf16_t*>(ws.arena.get<unsigned char>(ctta_ffn_proj_pack_bytes(cp, hp)));
+    if (!T->front_stream) { ctta_set_error("weight store exhausted (front projection weight stream)"); return CTTA_ERR_NOMEM; }
+    const bf16_t* w0 = T->out2.w;
+    bf16_t* dst = T->front_stream;
+    ws.jobs.push_back([=](const WeightTable&, hipStream_t s) -> ctta_status { return ctta_ffn_proj_pack(w0, hp, hp, cp, dst, s); });
+  }
   if (T->want_proj_stream && T->proj_out.n == cp && T->proj_out.k_pad == cp && c == cp) {
-    T->proj_stream = reinterpret_cast<bf16_t*>(ws.arena.get<unsigned char>(ctta_ffn_proj_pack_bytes(cp)));
+    T->proj_stream = reinterpret_cast<bf16_t*>(ws.arena.get<unsigned char>(ctta_ffn_proj_pack_bytes(cp, cp)));
     if (!T->proj_stream) { ctta_set_error("weight store exhausted (projection weight stream)"); return CTTA_ERR_NOMEM; }
     const bf16_t* w3 = T->proj_out.w;
     bf16_t* dst = T->proj_stream;
-    ws.jobs.push_back([=](const WeightTable&, hipStream_t s) -> ctta_status { return ctta_ffn_proj_pack(w3, cp, cp, dst, s); });
+    ws.jobs.push_back([=](const WeightTable&, hipStream_t s) -> ctta_status { return ctta_ffn_proj_pack(w3, cp, cp, cp, dst, s); });
   }
   return CTTA_OK;
 }
@@ -397,10 +405,16 @@ static ctta_status run_transformer(UCtx& c, Transformer& T, const bf16_t* x, int
   }
   CTTA_TRY(run_attention(c, q2, hp, k2, hp, c.Lp, vt2, c.Lp, c.mask_bias, att, hp, T.heads, N, c.L, T.dh, &T.sv.lse2));
   bf16_t* s2 = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(s2);
-  CTTA_TRY(run_linear(c, T.out2, att, hp, M, s2, cp, s1, cp));
-  // --- GEGLU feed-forward
-  if (c.train) { n = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(n); }
-  RUN(c, ctta_layernorm(s2, n, M, T.inner, cp, T.ln3.gamma, T.ln3.beta, 1e-5f, c.stream));
+  // the fused feed-forward (inference forward, widths 256 / 512, enough rows to fill its tiles) also takes attn2.to_out + residual
+  // and norm3 in front and proj_out + residual behind: five launches in one, s2 the only intermediate that reaches HBM
+  const bool ffn_fused = !c.train && T.ffn_stream && ctta_ffn_geglu_wanted(cp, T.ffp, (int64_t)M);
+  const bool ffn_front = ffn_fused && T.front_stream;
+  if (!ffn_front) {
+    CTTA_TRY(run_linear(c, T.out2, att, hp, M, s2, cp, s1, cp));
+    // --- GEGLU feed-forward
+    if (c.train) { n = A.get<bf16_t>(M * cp); ALLOC_OR_FAIL(n); }
+    RUN(c, ctta_layernorm(s2, n, M, T.inner, cp, T.ln3.gamma, T.ln3.beta, 1e-5f, c.stream));
+  }
   bf16_t* f = nullptr;
   bf16_t* gg = nullptr;
   if (c.train) {   // the backward pass needs the pre-activation: unfused
@@ -408,13 +422,19 @@ static ctta_status run_transformer(UCtx& c, Transformer& T, const bf16_t* x, int
     CTTA_TRY(run_linear(c, T.ff1, n, cp, M, f, 2 * T.ffp, nullptr, 0));
     gg = A.get<bf16_t>(M * T.ffp); ALLOC_OR_FAIL(gg);
     RUN(c, ctta_geglu(f, gg, M, T.ffp, 1, c.stream));
-  } else if (T.ffn_stream && ctta_ffn_geglu_wanted(cp, T.ffp, (int64_t)M)) {
+  } else if (ffn_fused) {
     // ff1 -> GEGLU -> ff2 + residual (-> proj_out + block input) in one launch: neither the projection, the hidden activations
     // nor (with the tail) the feed-forward result reach HBM
     ctta_ffn_desc fd;
     ctta_ffn_desc_init(&fd);
     fd.x = n; fd.ld_x = cp; fd.M = (int64_t)M; fd.cp = cp; fd.ffp = T.ffp; fd.packed = T.ffn_stream;
     fd.b1 = T.ff1.bias; fd.b2 = T.ff2.bias; fd.res = s2; fd.res_ld = cp;
+    if (ffn_front) {
+      fd.front_packed = T.front_stream; fd.front_bias = T.out2.bias; fd.att = att; fd.att_ld = hp; fd.front_k = hp;
+      fd.front_res = s1; fd.front_res_ld = cp; fd.s2_out = s2; fd.s2_ld = cp;
+      fd.ln_gamma = T.ln3.gamma; fd.ln_beta = T.ln3.beta; fd.ln_d = T.inner; fd.ln_eps = 1e-5f;
+      c.gn_ready_x = nullptr;      // (what run_linear(out2) did: a linear ends the producer -> GroupNorm adjacency)
+    }
     if (T.proj_stream) {
       fd.proj_packed = T.proj_stream; fd.proj_bias = T.proj_out.bias; fd.proj_res = x; fd.proj_res_ld = T.c;
       fd.out = out; fd.ldc = T.c; fd.n_valid = T.proj_out.n;

@@ -36,6 +36,8 @@ struct FfnParams {
   int M, nchunk, n_valid;         // n_valid: output columns stored (<= CP, multiple of 4)
   const float* ln_gamma; const float* ln_beta; int ln_d; float ln_eps;   // LayerNorm over the first ln_d columns while staging
   const bf16_t* w3s; const float* b3; const bf16_t* res3; int res3_ld;   // tail projection [CP][CP] (stream as w2s with S1 steps)
+  // front projection: x := att[M][att_ld] (k0 columns) . W0^T + b0 + res0 -> s2 (stored to s2out, then the LayerNorm's input)
+  const bf16_t* w0s; const float* b0; const bf16_t* att; int att_ld, k0; const bf16_t* res0; int res0_ld; bf16_t* s2out; int s2_ld;
 };
 
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -77,18 +79,129 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
   w1p += FFN_PF * 2 * 64;
   w2p += FFN_PF * NC2 * 64;
 
-  // ---- 1. A tile -> LDS (rows past M read as zeros through the descriptor's bounds check).  With ln_gamma the rows are
-  //         layer-normalised on the way: CP / 8 lanes share a row, 8 consecutive channels each -- the lane mapping, the
-  //         summation order (ln_group_sum) and the arithmetic of ctta_layernorm's kernel for this width, bit for bit.
+  f32x4_t acc2[NC2][PB];
+#pragma unroll
+  for (int i = 0; i < NC2; ++i)
+#pragma unroll
+    for (int j = 0; j < PB; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  f32x4_t acc1[2][PB];
+  const bf16_t* aw = atile + lq * RS + lg * 8;
+
+  // ---- epilogue of a GEMM whose accumulators are acc2: acc + bias + residual -> bf16, to HBM and / or to the A tile region
+  //      ([BM][RS] bf16: the operand of the next GEMM).  Descriptors bounded to M rows (rows past M read zeros / are dropped),
+  //      a lane whose columns lie past n_valid gets an offset outside them: no branch, all residual loads in flight before
+  //      the first store.
+  const int n0 = w * NC2 * 16 + lg * 4;
+  auto finish = [&](const float* bias, const bf16_t* res, const int res_ld, bf16_t* out, const int ldc, const int n_valid,
+                    const bool to_lds, const bool to_hbm) {
+    const __amdgpu_buffer_rsrc_t rsr =
+        __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, (unsigned)((size_t)p.M * res_ld * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rso =
+        __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, to_hbm ? (unsigned)((size_t)p.M * ldc * 2) : 0u, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < NC2; ++i) {
+      const int n = n0 + i * 16;
+      const float4 bb = *reinterpret_cast<const float4*>(bias + n);
+      const bool live = n < n_valid;
+      const int vr = live ? ((m0 + lq) * res_ld + n) * 2 : (int)0x80000000, vo = live ? ((m0 + lq) * ldc + n) * 2 : (int)0x80000000;   // extents < 2^31 - 2^20 (host check)
+      u32x2_t r[PB];
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) r[pb] = __builtin_amdgcn_raw_buffer_load_b64(rsr, vr + pb * 16 * res_ld * 2, 0, 0);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const f32x4_t a = acc2[i][pb];
+        const float v0 = a[0] + bb.x + __uint_as_float(r[pb][0] << 16);
+        const float v1 = a[1] + bb.y + __uint_as_float(r[pb][0] & 0xffff0000u);
+        const float v2 = a[2] + bb.z + __uint_as_float(r[pb][1] << 16);
+        const float v3 = a[3] + bb.w + __uint_as_float(r[pb][1] & 0xffff0000u);
+        u32x2_t pk;
+        pk[0] = pack2bf(v0, v1);
+        pk[1] = pack2bf(v2, v3);
+        if (to_lds) *reinterpret_cast<u32x2_t*>(atile + (pb * 16 + lq) * RS + n) = pk;
+        if (to_hbm) __builtin_amdgcn_raw_buffer_store_b64(pk, rso, vo + pb * 16 * ldc * 2, 0, 0);
+      }
+    }
+  };
+  // a cp-wide GEMM of this wave's NC2 output-channel blocks over `steps` K steps: B operand = LDS rows of stride `rs` (bf16)
+  // at `base`, A operand = the wave's stream `wp` ([step][NC2][64][8], FFN_PF steps of padding behind it)
+  auto gemm_rows = [&](const uint4* wp, const bf16_t* base, const int rs, const int steps) {
+    bf16x8_t r0[R][NC2];
+#pragma unroll
+    for (int s = 0; s < FFN_PF; ++s)
+#pragma unroll
+      for (int i = 0; i < NC2; ++i) r0[s][i] = __builtin_bit_cast(bf16x8_t, wp[(s * NC2 + i) * 64]);
+    wp += FFN_PF * NC2 * 64;
+    const bf16_t* bw = base + lq * rs + lg * 8;
+    for (int st = 0; st < steps; ++st) {
+#pragma unroll
+      for (int i = 0; i < NC2; ++i) r0[FFN_PF][i] = __builtin_bit_cast(bf16x8_t, wp[(st * NC2 + i) * 64]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) {
+        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(bw + pb * 16 * rs + st * 32));
+#pragma unroll
+        for (int i = 0; i < NC2; ++i)
+          acc2[i][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r0[0][i], bf, acc2[i][pb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < FFN_PF; ++s)
+#pragma unroll
+        for (int i = 0; i < NC2; ++i) r0[s][i] = r0[s + 1][i];
+    }
+  };
+
+  // ---- 1. A tile -> LDS.  CP / 8 lanes share a row, 8 consecutive channels each; with ln_gamma the rows are layer-normalised
+  //         on the way -- the lane mapping, the summation order (ln_group_sum) and the arithmetic of ctta_layernorm's kernel
+  //         for this width, bit for bit.  Source: global rows (rows past M read as zeros through the descriptor's bounds
+  //         check), or -- FRONT -- the rows a projection GEMM of this workgroup has just left in the tile region.
   {
-    const __amdgpu_buffer_rsrc_t rsx =
-        __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((size_t)p.M * p.ld_x * 2), 0x00020000);
     constexpr int CV = CP / 8, RPS = 512 / CV, NSW = BM / RPS;
     const int cc = tid % CV, rr = tid / CV;
     u32x4_t v[NSW];
+    if (p.w0s) {
+      // front projection (attn2.to_out + residual, attention.py:318-327): s2 = att . W0^T + b0 + s1, K = k0 (the head-padded
+      // attention width).  The att tile [BM][k0 + 8] starts at the tile region's base and may reach into H (unused so far).
+      const int k0 = p.k0, rs0 = k0 + 8, cv0 = k0 / 8, total = BM * cv0;
+      const __amdgpu_buffer_rsrc_t rsa =
+          __builtin_amdgcn_make_buffer_rsrc((void*)p.att, 0, (unsigned)((size_t)p.M * p.att_ld * 2), 0x00020000);
+      for (int base = 0; base < total; base += 4 * 512) {
+        u32x4_t t4[4];
+        int row[4], col[4];
 #pragma unroll
-    for (int u = 0; u < NSW; ++u)
-      v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ((m0 + rr + u * RPS) * p.ld_x + cc * 8) * 2, 0, 0);
+        for (int u = 0; u < 4; ++u) {
+          const int idx = base + u * 512 + tid;
+          row[u] = idx / cv0;
+          col[u] = idx - row[u] * cv0;
+          t4[u] = __builtin_amdgcn_raw_buffer_load_b128(rsa, idx < total ? ((m0 + row[u]) * p.att_ld + col[u] * 8) * 2 : (int)0x80000000, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (base + u * 512 + tid < total)
+            *reinterpret_cast<uint4*>(atile + row[u] * rs0 + col[u] * 8) = make_uint4(t4[u][0], t4[u][1], t4[u][2], t4[u][3]);
+      }
+      __syncthreads();
+      gemm_rows(reinterpret_cast<const uint4*>(p.w0s) + (size_t)w * (k0 / 32 + FFN_PF) * NC2 * 64 + lane, atile, rs0, k0 / 32);
+      __syncthreads();                 // every wave is done with the att tile: s2 takes its place
+      finish(p.b0, p.res0, p.res0_ld, p.s2out, p.s2_ld, CP, true, true);
+      // the feed-forward's residual is read back from s2out by the lanes that wrote it: the stores are acknowledged first
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NC2; ++i)
+#pragma unroll
+        for (int j = 0; j < PB; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NSW; ++u) {
+        const uint4 t = *reinterpret_cast<const uint4*>(atile + (rr + u * RPS) * RS + cc * 8);
+        v[u] = (u32x4_t){t.x, t.y, t.z, t.w};
+      }
+    } else {
+      const __amdgpu_buffer_rsrc_t rsx =
+          __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (unsigned)((size_t)p.M * p.ld_x * 2), 0x00020000);
+#pragma unroll
+      for (int u = 0; u < NSW; ++u)
+        v[u] = __builtin_amdgcn_raw_buffer_load_b128(rsx, ((m0 + rr + u * RPS) * p.ld_x + cc * 8) * 2, 0, 0);
+    }
     if (p.ln_gamma) {
       const int d = p.ln_d;
       const float inv_d = 1.0f / (float)d, eps = p.ln_eps;
@@ -128,14 +241,6 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
   }
   __syncthreads();
 
-  f32x4_t acc2[NC2][PB];
-#pragma unroll
-  for (int i = 0; i < NC2; ++i)
-#pragma unroll
-    for (int j = 0; j < PB; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  f32x4_t acc1[2][PB];
-
-  const bf16_t* aw = atile + lq * RS + lg * 8;
   const float* b1p = p.b1 + w * 32 + lg * 4;
 
   // GEMM1 of the next chunk: value / gate of this wave's 16 hidden units, all rows, from the A tile
@@ -234,76 +339,24 @@ __global__ __launch_bounds__(512, 2) void ffn_geglu_kernel(const FfnParams p) {
     }
   }
 
-  // ---- epilogue: acc + bias + residual -> bf16.  Descriptors bounded to M rows (rows past M read zeros / are dropped), a lane
-  //      whose columns lie past n_valid gets an offset outside them: no branch, all residual loads in flight before the first
-  //      store.  TO_LDS: the rows go to the A tile region instead ([BM][RS] bf16: the operand of the tail projection).
-  const int n0 = w * NC2 * 16 + lg * 4;
-  auto finish = [&](const float* bias, const bf16_t* res, const int res_ld, bf16_t* out, const int ldc, const int n_valid,
-                    const bool to_lds) {
-    const __amdgpu_buffer_rsrc_t rsr =
-        __builtin_amdgcn_make_buffer_rsrc((void*)res, 0, (unsigned)((size_t)p.M * res_ld * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rso =
-        __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, to_lds ? 0u : (unsigned)((size_t)p.M * ldc * 2), 0x00020000);
-#pragma unroll
-    for (int i = 0; i < NC2; ++i) {
-      const int n = n0 + i * 16;
-      const float4 bb = *reinterpret_cast<const float4*>(bias + n);
-      const bool live = n < n_valid;
-      const int vr = live ? ((m0 + lq) * res_ld + n) * 2 : (int)0x80000000, vo = live ? ((m0 + lq) * ldc + n) * 2 : (int)0x80000000;   // extents < 2^31 - 2^20 (host check)
-      u32x2_t r[PB];
-#pragma unroll
-      for (int pb = 0; pb < PB; ++pb) r[pb] = __builtin_amdgcn_raw_buffer_load_b64(rsr, vr + pb * 16 * res_ld * 2, 0, 0);
-#pragma unroll
-      for (int pb = 0; pb < PB; ++pb) {
-        const f32x4_t a = acc2[i][pb];
-        const float v0 = a[0] + bb.x + __uint_as_float(r[pb][0] << 16);
-        const float v1 = a[1] + bb.y + __uint_as_float(r[pb][0] & 0xffff0000u);
-        const float v2 = a[2] + bb.z + __uint_as_float(r[pb][1] << 16);
-        const float v3 = a[3] + bb.w + __uint_as_float(r[pb][1] & 0xffff0000u);
-        u32x2_t pk;
-        pk[0] = pack2bf(v0, v1);
-        pk[1] = pack2bf(v2, v3);
-        if (to_lds) *reinterpret_cast<u32x2_t*>(atile + (pb * 16 + lq) * RS + n) = pk;
-        else __builtin_amdgcn_raw_buffer_store_b64(pk, rso, vo + pb * 16 * ldc * 2, 0, 0);
-      }
-    }
-  };
+  // ---- epilogue
+  const bf16_t* res = p.w0s ? p.s2out : p.res;
+  const int res_ld = p.w0s ? p.s2_ld : p.res_ld;
   if (!p.w3s) {
-    finish(p.b2, p.res, p.res_ld, p.out, p.ldc, p.n_valid, false);
+    finish(p.b2, res, res_ld, p.out, p.ldc, p.n_valid, false, true);
     return;
   }
   // ---- tail projection (proj_out of the Transformer2DModel, transformer_2d.py:  out = proj(s3) + bias + block input): the
   //      feed-forward result s3 (bf16, exactly what the two-launch form stores) becomes the A tile of one more GEMM with K = CP
   //      -- every GEMM1 is behind the loop's last barrier, so the LayerNorm tile is dead; s3 never reaches HBM.
-  finish(p.b2, p.res, p.res_ld, nullptr, 0, CP, true);
-  {
-    const uint4* w3p = reinterpret_cast<const uint4*>(p.w3s) + (size_t)w * (S1 + FFN_PF) * NC2 * 64 + lane;
+  finish(p.b2, res, res_ld, nullptr, 0, CP, true, false);
 #pragma unroll
-    for (int s = 0; s < FFN_PF; ++s)
+  for (int i = 0; i < NC2; ++i)
 #pragma unroll
-      for (int i = 0; i < NC2; ++i) r2[s][i] = __builtin_bit_cast(bf16x8_t, w3p[(s * NC2 + i) * 64]);
-    w3p += FFN_PF * NC2 * 64;
-#pragma unroll
-    for (int i = 0; i < NC2; ++i)
-#pragma unroll
-      for (int j = 0; j < PB; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    FFN_LDS_BARRIER();
-#pragma unroll
-    for (int st = 0; st < S1; ++st) {
-#pragma unroll
-      for (int i = 0; i < NC2; ++i) r2[FFN_PF][i] = __builtin_bit_cast(bf16x8_t, w3p[(st * NC2 + i) * 64]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int pb = 0; pb < PB; ++pb) {
-        const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(aw + pb * 16 * RS + st * 32));
-#pragma unroll
-        for (int i = 0; i < NC2; ++i)
-          acc2[i][pb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(r2[0][i], bf, acc2[i][pb], 0, 0, 0);
-      }
-      ring2();
-    }
-  }
-  finish(p.b3, p.res3, p.res3_ld, p.out, p.ldc, p.n_valid, false);
+    for (int j = 0; j < PB; ++j) acc2[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+  FFN_LDS_BARRIER();
+  gemm_rows(reinterpret_cast<const uint4*>(p.w3s) + (size_t)w * (S1 + FFN_PF) * NC2 * 64 + lane, atile, RS, S1);
+  finish(p.b3, p.res3, p.res3_ld, p.out, p.ldc, p.n_valid, false, true);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -343,10 +396,11 @@ __global__ void ffn_pack_kernel(const bf16_t* __restrict__ w1, int k_pad1, const
   }
 }
 
-// tail projection [cp][k_pad] -> w3s[w][st][i][lane][8] = W3[(w*NC2 + i)*16 + lq][st*32 + lg*8 ..], st < cp / 32, + FFN_PF steps of zeros
-__global__ void ffn_pack_proj_kernel(const bf16_t* __restrict__ w3, int k_pad, int cp, bf16_t* __restrict__ w3s) {
-  const int S1 = cp / 32, NC2 = cp / 16 / FFN_NW;
-  const long long per = (long long)(S1 + FFN_PF) * NC2 * 64, total = FFN_NW * per;
+// a projection [cp][k_pad] with k used columns -> stream[w][st][i][lane][8] = W[(w*NC2 + i)*16 + lq][st*32 + lg*8 ..], st < k / 32,
+// + FFN_PF steps of zeros (gemm_rows' operand: the tail projection with k = cp, the front projection with k = the attention width)
+__global__ void ffn_pack_proj_kernel(const bf16_t* __restrict__ w3, int k_pad, int k, int cp, bf16_t* __restrict__ w3s) {
+  const int S = k / 32, NC2 = cp / 16 / FFN_NW;
+  const long long per = (long long)(S + FFN_PF) * NC2 * 64, total = FFN_NW * per;
   for (long long t = blockIdx.x * (long long)blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
     const int wv = (int)(t / per);
     const long long r = t - wv * per;
@@ -354,12 +408,15 @@ __global__ void ffn_pack_proj_kernel(const bf16_t* __restrict__ w3, int k_pad, i
     const long long f = r >> 6;
     const int i = (int)(f % NC2), st = (int)(f / NC2);
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (st < S1) v = *reinterpret_cast<const uint4*>(w3 + (size_t)((wv * NC2 + i) * 16 + (lane & 15)) * k_pad + st * 32 + (lane >> 4) * 8);
+    if (st < S) v = *reinterpret_cast<const uint4*>(w3 + (size_t)((wv * NC2 + i) * 16 + (lane & 15)) * k_pad + st * 32 + (lane >> 4) * 8);
     reinterpret_cast<uint4*>(w3s)[t] = v;
   }
 }
 
-static size_t ffn_smem(int cp, int bm) { return (size_t)bm * (cp + 8) * 2 + (size_t)2 * bm * (FFN_HC + 8) * 2; }
+static size_t ffn_smem(int cp, int bm, int k0) {
+  const size_t main_ = (size_t)bm * (cp + 8) * 2 + (size_t)2 * bm * (FFN_HC + 8) * 2, front = (size_t)bm * (k0 + 8) * 2;
+  return front > main_ ? front : main_;
+}
 static bool ffn_shape_ok(int cp, int ffp) { return (cp == 256 || cp == 512) && ffp >= 2 * FFN_HC && ffp % FFN_HC == 0; }
 
 extern "C" int ctta_ffn_geglu_supported(int cp, int ffp) {
@@ -391,12 +448,13 @@ extern "C" ctta_status ctta_ffn_pack(const void* w1_packed, int k_pad1, const vo
 
 template <int CP, int BM>
 static ctta_status launch_ffn(const FfnParams& p, hipStream_t s) {
-  const size_t smem = ffn_smem(CP, BM);
-  static bool configured = false;
-  if (!configured) {
+  const size_t smem = ffn_smem(CP, BM, p.w0s ? p.k0 : 0);
+  CTTA_REQUIRE(smem <= (size_t)160 * 1024, "ffn_block: the %d-row tile of the front projection (k = %d) does not fit the LDS", BM, p.k0);
+  static size_t configured = 0;
+  if (smem > configured) {
     CTTA_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_geglu_kernel<CP, BM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    configured = true;
+    configured = smem;
   }
   ffn_geglu_kernel<CP, BM><<<dim3((unsigned)((p.M + BM - 1) / BM)), dim3(512), smem, s>>>(p);
   return CTTA_OK;
@@ -434,15 +492,16 @@ extern "C" int ctta_ffn_geglu_wanted(int cp, int ffp, int64_t M) {
   return tiles * 10 >= rounds * ctta_cu_count() * 6 ? 1 : 0;
 }
 
-extern "C" size_t ctta_ffn_proj_pack_bytes(int cp) {
-  if (cp != 256 && cp != 512) return 0;
-  return (size_t)FFN_NW * (cp / 32 + FFN_PF) * (cp / 16 / FFN_NW) * 64 * 16;
+static bool ffn_proj_ok(int cp, int k) { return (cp == 256 || cp == 512) && k >= 32 && k % 32 == 0 && k <= 1024; }
+extern "C" size_t ctta_ffn_proj_pack_bytes(int cp, int k) {
+  if (!ffn_proj_ok(cp, k)) return 0;
+  return (size_t)FFN_NW * (k / 32 + FFN_PF) * (cp / 16 / FFN_NW) * 64 * 16;
 }
 
-extern "C" ctta_status ctta_ffn_proj_pack(const void* w_packed, int k_pad, int cp, void* dst, void* stream) {
+extern "C" ctta_status ctta_ffn_proj_pack(const void* w_packed, int k_pad, int k, int cp, void* dst, void* stream) {
   CTTA_REQUIRE(w_packed && dst, "ffn_proj_pack: null pointer");
-  CTTA_REQUIRE((cp == 256 || cp == 512) && k_pad >= cp && k_pad % 8 == 0, "ffn_proj_pack: cp=%d (256 or 512), k_pad=%d >= cp", cp, k_pad);
-  hipLaunchKernelGGL(ffn_pack_proj_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_packed, k_pad, cp, (bf16_t*)dst);
+  CTTA_REQUIRE(ffn_proj_ok(cp, k) && k_pad >= k && k_pad % 8 == 0, "ffn_proj_pack: cp=%d (256 or 512), k=%d (a multiple of 32, <= 1024), k_pad=%d >= k", cp, k, k_pad);
+  hipLaunchKernelGGL(ffn_pack_proj_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w_packed, k_pad, k, cp, (bf16_t*)dst);
   CTTA_LAUNCH_CHECK();
   return CTTA_OK;
 }
@@ -453,13 +512,21 @@ extern "C" ctta_status ctta_ffn_block(const ctta_ffn_desc* d, void* stream) {
   CTTA_REQUIRE(d, "ffn_block: null descriptor");
   const int cp = d->cp, ffp = d->ffp, ld_x = d->ld_x, res_ld = d->res_ld, ldc = d->ldc, n_valid = d->n_valid;
   const int64_t M = d->M;
-  CTTA_REQUIRE(d->x && d->packed && d->b1 && d->b2 && d->res && d->out, "ffn_block: null pointer");
+  const bool front = d->front_packed != nullptr;
+  CTTA_REQUIRE((front || (d->x && d->res)) && d->packed && d->b1 && d->b2 && d->out, "ffn_block: null pointer");
   CTTA_REQUIRE(ffn_shape_ok(cp, ffp), "ffn_block: cp=%d ffp=%d is outside the fused kernel's range (cp 256 or 512, ffp a multiple of %d, >= %d)",
                cp, ffp, FFN_HC, 2 * FFN_HC);
-  CTTA_REQUIRE(M >= 1 && ld_x >= cp && ld_x % 8 == 0 && (long long)(M + 144) * ld_x * 2 < 0x7FF00000LL && (long long)(M + 144) * res_ld * 2 < 0x7FF00000LL &&
-               (long long)(M + 144) * ldc * 2 < 0x7FF00000LL && res_ld % 4 == 0 && ldc % 4 == 0 &&
-               n_valid > 0 && n_valid <= cp && n_valid % 4 == 0 && res_ld >= (d->proj_packed ? cp : n_valid) && ldc >= n_valid,
+  CTTA_REQUIRE(M >= 1 && (front || (ld_x >= cp && ld_x % 8 == 0 && (long long)(M + 144) * ld_x * 2 < 0x7FF00000LL &&
+                                    (long long)(M + 144) * res_ld * 2 < 0x7FF00000LL && res_ld % 4 == 0 &&
+                                    res_ld >= (d->proj_packed ? cp : n_valid))) &&
+               (long long)(M + 144) * ldc * 2 < 0x7FF00000LL && ldc % 4 == 0 && n_valid > 0 && n_valid <= cp && n_valid % 4 == 0 && ldc >= n_valid,
                "ffn_block: bad extents (M=%lld ld_x=%d res_ld=%d ldc=%d n_valid=%d)", (long long)M, ld_x, res_ld, ldc, n_valid);
+  CTTA_REQUIRE(!front || (d->front_bias && d->att && d->front_res && d->s2_out && ffn_proj_ok(cp, d->front_k) && d->att_ld >= d->front_k &&
+                          d->att_ld % 8 == 0 && d->front_res_ld >= cp && d->front_res_ld % 4 == 0 && d->s2_ld >= cp && d->s2_ld % 8 == 0 &&
+                          (long long)(M + 144) * d->att_ld * 2 < 0x7FF00000LL && (long long)(M + 144) * d->front_res_ld * 2 < 0x7FF00000LL &&
+                          (long long)(M + 144) * d->s2_ld * 2 < 0x7FF00000LL),
+               "ffn_block: the front projection needs its bias, operand (att_ld=%d >= front_k=%d, a multiple of 32), residual and the s2 "
+               "destination (s2_ld=%d >= cp, a multiple of 8)", d->att_ld, d->front_k, d->s2_ld);
   CTTA_REQUIRE(!d->ln_gamma || (d->ln_beta && d->ln_d > 0 && d->ln_d <= cp), "ffn_block: LayerNorm on load needs gamma, beta and 0 < ln_d=%d <= cp", d->ln_d);
   CTTA_REQUIRE(!d->proj_packed || (d->proj_bias && d->proj_res && d->proj_res_ld >= n_valid && d->proj_res_ld % 4 == 0 &&
                                    (long long)(M + 144) * d->proj_res_ld * 2 < 0x7FF00000LL),
@@ -474,13 +541,15 @@ extern "C" ctta_status ctta_ffn_block(const ctta_ffn_desc* d, void* stream) {
   p.M = (int)M; p.nchunk = nchunk; p.n_valid = n_valid;
   p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta; p.ln_d = d->ln_d; p.ln_eps = d->ln_eps;
   p.w3s = (const bf16_t*)d->proj_packed; p.b3 = d->proj_bias; p.res3 = (const bf16_t*)d->proj_res; p.res3_ld = d->proj_res_ld;
+  p.w0s = (const bf16_t*)d->front_packed; p.b0 = d->front_bias; p.att = (const bf16_t*)d->att; p.att_ld = d->att_ld; p.k0 = d->front_k;
+  p.res0 = (const bf16_t*)d->front_res; p.res0_ld = d->front_res_ld; p.s2out = (bf16_t*)d->s2_out; p.s2_ld = d->s2_ld;
   long long rounds = 0, tiles = 0;
   int bm = ffn_pick_rows(cp, M, &rounds, &tiles);
   if (g_ffn_bm) bm = g_ffn_bm;
   hipStream_t s = (hipStream_t)stream;
   const bool prof = ctta_prof_active();
   // 2 M cp (2 ffp + ffp [+ cp]) flops as one "launch" of K = 3 ffp [+ cp]
-  if (prof) ctta_prof_begin(0, 44, M, cp, 3LL * ffp + (d->proj_packed ? cp : 0), 1, s);
+  if (prof) ctta_prof_begin(0, 44, M, cp, 3LL * ffp + (d->proj_packed ? cp : 0) + (front ? d->front_k : 0), 1, s);
   ctta_status st;
   if (cp == 512) st = bm == 80 ? launch_ffn<512, 80>(p, s) : bm == 48 ? launch_ffn<512, 48>(p, s) : launch_ffn<512, 64>(p, s);
   else st = bm == 144 ? launch_ffn<256, 144>(p, s) : launch_ffn<256, 128>(p, s);

@@ -441,12 +441,17 @@ ctta_status ctta_ffn_pack(const void* w1_packed, int k_pad1, const void* w2_pack
 ctta_status ctta_ffn_geglu(const void* x, int ld_x, int64_t M, int cp, int ffp, const void* packed, const float* b1,
                            const float* b2, const void* res, int res_ld, void* out, int ldc, int n_valid,
                            const float* ln_gamma, const float* ln_beta, int ln_d, float ln_eps, void* stream);
-/* The same launch by descriptor, with the optional TAIL PROJECTION of the Transformer2DModel (transformer_2d.py: proj_out + the
- * block's input as residual): with proj_packed != NULL
+/* The same launch by descriptor, with two optional neighbours of the feed-forward inside the workgroup:
+ * TAIL PROJECTION (proj_packed != NULL; proj_out of the Transformer2DModel + the block's input as residual, transformer_2d.py):
  *   out[m][0..n_valid) = proj_res[m][..] + proj_bias + Wp . bf16( res[m] + b2 + W2 . (...) )
- * i.e. the feed-forward result is rounded to bf16 (what the separate launch would store), becomes the operand of one more
- * cp x cp GEMM inside the workgroup and never reaches HBM.  proj_packed = ctta_ffn_proj_pack's stream of the conv_gemm operand
- * [cp][k_pad]; `out` / `ldc` / `n_valid` then describe the projection's output.  Bit-identical to the three launches. */
+ * the feed-forward result is rounded to bf16 (what the separate launch would store), becomes the operand of one more cp x cp
+ * GEMM and never reaches HBM; `out` / `ldc` / `n_valid` then describe the projection's output.
+ * FRONT PROJECTION (front_packed != NULL; attn2.to_out + residual and norm3, attention.py:318-334):
+ *   s2[m] = front_res[m] + front_bias + W0 . att[m][0..front_k)      (bf16, stored to s2_out: the feed-forward's residual)
+ *   x[m]  = LayerNorm(s2[m])   (ln_gamma / ln_beta / ln_d / ln_eps; the normalised rows exist in LDS only)
+ * `x` / `ld_x` / `res` / `res_ld` are ignored.  The streams of both projections are made by ctta_ffn_proj_pack from their
+ * conv_gemm operands [cp][k_pad] (k = cp for the tail, k = the head-padded attention width for the front).
+ * Bit-identical to the separate launches (ctta_conv_gemm x 4 + ctta_layernorm). */
 typedef struct {
   const void* x; int ld_x; int64_t M; int cp, ffp;
   const void* packed; const float* b1; const float* b2;
@@ -454,10 +459,12 @@ typedef struct {
   void* out; int ldc; int n_valid;
   const float* ln_gamma; const float* ln_beta; int ln_d; float ln_eps;
   const void* proj_packed; const float* proj_bias; const void* proj_res; int proj_res_ld;
+  const void* front_packed; const float* front_bias; const void* att; int att_ld; int front_k;
+  const void* front_res; int front_res_ld; void* s2_out; int s2_ld;
 } ctta_ffn_desc;
 void ctta_ffn_desc_init(ctta_ffn_desc* d);
-size_t ctta_ffn_proj_pack_bytes(int cp);
-ctta_status ctta_ffn_proj_pack(const void* w_packed, int k_pad, int cp, void* dst, void* stream);
+size_t ctta_ffn_proj_pack_bytes(int cp, int k);
+ctta_status ctta_ffn_proj_pack(const void* w_packed, int k_pad, int k, int cp, void* dst, void* stream);
 ctta_status ctta_ffn_block(const ctta_ffn_desc* d, void* stream);
 
 /* Direct convolution for tiny Cout (<= 8): bf16 NHWC in, fp32 weights [n][kh][kw][c],

@@ -376,8 +376,8 @@ def test_fused_feed_forward_with_the_tail_projection(cp, M):
     wpi[:n_out, :d], bpi[:n_out] = wp_, bp_
     w3p, k3 = pack_conv_weight(wpi[:, :, None, None])
     assert k3 == cp
-    pstream = torch.empty(L.ctta_ffn_proj_pack_bytes(cp), dtype=torch.uint8, device=DEV)
-    N.check(L.ctta_ffn_proj_pack(N.ptr(w3p), k3, cp, N.ptr(pstream), N.stream_ptr()))
+    pstream = torch.empty(L.ctta_ffn_proj_pack_bytes(cp, cp), dtype=torch.uint8, device=DEV)
+    N.check(L.ctta_ffn_proj_pack(N.ptr(w3p), k3, cp, cp, N.ptr(pstream), N.stream_ptr()))
     n3 = torch.zeros(M, cp)
     n3[:, :d] = bf16_round(det("ffnp.n3", (M, d), 5))
     s2 = torch.zeros(M, cp)
@@ -409,6 +409,81 @@ def test_fused_feed_forward_with_the_tail_projection(cp, M):
         assert bool((got[M:] == 3.0).all())
     fd.proj_bias = None
     with pytest.raises(RuntimeError, match="tail projection needs"):
+        N.check(L.ctta_ffn_block(ctypes.byref(fd), N.stream_ptr()))
+
+
+@pytest.mark.parametrize("cp,M,tail", [(256, 500, True), (256, 144 * 2 + 9, False), (512, 333, True), (512, 80 * 3, False)])
+def test_fused_feed_forward_with_the_front_projection(cp, M, tail):
+    """ctta_ffn_block with front_packed: attn2.to_out + bias + residual (attention.py:318-327) as a GEMM of the workgroup in
+    front of the feed-forward -- its result s2 is stored (the residual of ff2), normalised in LDS (norm3) and fed on; with the
+    tail projection that is the transformer block from the cross-attention's output to the Transformer2DModel's output in one
+    launch.  Bit-identical to ctta_conv_gemm (to_out) + ctta_layernorm + ff1 + ff2 (+ proj_out) as separate launches, every
+    row tile, s2 included."""
+    L = lib()
+    c = _ffn_case(cp, 4 * (cp - cp // 256), M, 41)
+    d, ffp = c["d"], c["ffp"]
+    hp, hv = cp // 4 * 5, cp // 256 * 255                    # 320 / 640 head-padded attention width: heads x 64, 51 of 64 live
+    w0 = bf16_round(det("ffnf.w0", (d, hp), 3) * (1.0 / math.sqrt(hv)))
+    w0.view(d, hp // 64, 64)[:, :, 51:] = 0
+    b0 = det("ffnf.b0", (d,), 4) * 0.1
+    w0i, b0i = torch.zeros(cp, hp), torch.zeros(cp)
+    w0i[:d], b0i[:d] = w0, b0
+    w0p, k0 = pack_conv_weight(w0i[:, :, None, None], k_mult=32)
+    assert k0 == hp
+    fstream = torch.empty(L.ctta_ffn_proj_pack_bytes(cp, hp), dtype=torch.uint8, device=DEV)
+    N.check(L.ctta_ffn_proj_pack(N.ptr(w0p), k0, hp, cp, N.ptr(fstream), N.stream_ptr()))
+    att = bf16_round(det("ffnf.att", (M, hp), 5))
+    s1 = torch.zeros(M, cp)
+    s1[:, :d] = bf16_round(det("ffnf.s1", (M, d), 6))
+    xin = bf16_round(det("ffnf.x", (M, cp), 7))
+    attd, s1d, xd = att.to(torch.bfloat16).to(DEV), s1.to(torch.bfloat16).to(DEV), xin.to(torch.bfloat16).to(DEV)
+    gamma, beta = (1 + 0.2 * det("ffnf.g", (d,), 8)).to(DEV), (0.1 * det("ffnf.be", (d,), 9)).to(DEV)
+    b0d = b0i.to(DEV)
+    # the separate launches
+    s2 = torch.full((M, cp), 3.0, dtype=torch.bfloat16, device=DEV)
+    run_conv(conv_desc(x0=attd, c0=hp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w0p, k_pad=k0, n=cp, bias=b0d, res=s1d, res_ld=cp, out=s2,
+                       ldc=cp))
+    assert rel_err(s2[:, :d].float().cpu(), s1[:, :d] + F.linear(att, w0, b0)) < 2 * BF16_TOL
+    n3 = torch.empty_like(s2)
+    N.check(L.ctta_layernorm(N.ptr(s2), N.ptr(n3), M, d, cp, N.ptr(gamma), N.ptr(beta), 1e-5, N.stream_ptr()))
+    s3 = torch.empty(M, cp, dtype=torch.bfloat16, device=DEV)
+    _ffn_two_launches(c, n3, s2, s3)
+    want = s3
+    fd = N.FfnDesc()
+    L.ctta_ffn_desc_init(ctypes.byref(fd))
+    fd.M, fd.cp, fd.ffp = M, cp, ffp
+    fd.packed, fd.b1, fd.b2 = c["packed"].data_ptr(), c["b1d"].data_ptr(), c["b2d"].data_ptr()
+    fd.front_packed, fd.front_bias, fd.att, fd.att_ld, fd.front_k = fstream.data_ptr(), b0d.data_ptr(), attd.data_ptr(), hp, hp
+    fd.front_res, fd.front_res_ld = s1d.data_ptr(), cp
+    fd.ln_gamma, fd.ln_beta, fd.ln_d, fd.ln_eps = gamma.data_ptr(), beta.data_ptr(), d, 1e-5
+    n_out = cp
+    if tail:
+        n_out = cp - 8
+        wp_ = bf16_round(det("ffnf.wp", (n_out, d), 10) * (1.0 / math.sqrt(d)))
+        wpi, bpi = torch.zeros(cp, cp), torch.zeros(cp)
+        wpi[:n_out, :d], bpi[:n_out] = wp_, det("ffnf.bp", (n_out,), 11) * 0.1
+        w3p, k3 = pack_conv_weight(wpi[:, :, None, None])
+        pstream = torch.empty(L.ctta_ffn_proj_pack_bytes(cp, cp), dtype=torch.uint8, device=DEV)
+        N.check(L.ctta_ffn_proj_pack(N.ptr(w3p), k3, cp, cp, N.ptr(pstream), N.stream_ptr()))
+        bpd = bpi.to(DEV)
+        want = torch.full((M, cp), 3.0, dtype=torch.bfloat16, device=DEV)
+        run_conv(conv_desc(x0=s3, c0=cp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w3p, k_pad=k3, n=n_out, bias=bpd, res=xd, res_ld=cp, out=want,
+                           ldc=cp))
+        fd.proj_packed, fd.proj_bias, fd.proj_res, fd.proj_res_ld = pstream.data_ptr(), bpd.data_ptr(), xd.data_ptr(), cp
+    for bm in ((0, 128, 144) if cp == 256 else (0, 48, 64, 80)):
+        got = torch.full((M + 2, cp), 3.0, dtype=torch.bfloat16, device=DEV)
+        s2g = torch.full((M + 2, cp), 5.0, dtype=torch.bfloat16, device=DEV)
+        fd.out, fd.ldc, fd.n_valid = got.data_ptr(), cp, n_out
+        fd.s2_out, fd.s2_ld = s2g.data_ptr(), cp
+        L.ctta_ffn_debug_rows(bm)
+        N.check(L.ctta_ffn_block(ctypes.byref(fd), N.stream_ptr()))
+        sync()
+        L.ctta_ffn_debug_rows(0)
+        assert torch.equal(s2g[:M], s2) and bool((s2g[M:] == 5.0).all()), (cp, M, bm)
+        assert torch.equal(got[:M], want), (cp, M, bm)
+        assert bool((got[M:] == 3.0).all())
+    fd.s2_out = None
+    with pytest.raises(RuntimeError, match="front projection needs"):
         N.check(L.ctta_ffn_block(ctypes.byref(fd), N.stream_ptr()))
 
 

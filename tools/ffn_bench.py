@@ -93,6 +93,68 @@ def main():
                 f()
                 L.ctta_ffn_debug_rows(0)
             return r
+        # the whole tail of a transformer block: attn2.to_out + residual, norm3, ff1, ff2 + residual, proj_out + residual
+        hp = cp // 4 * 5
+        w0 = torch.randn(cp, hp, generator=g) * (1.0 / math.sqrt(hp))
+        w0p, k0 = pack_conv_weight(w0[:, :, None, None], k_mult=32)
+        wp = torch.randn(cp, cp, generator=g) * (1.0 / math.sqrt(cp))
+        w3p, k3 = pack_conv_weight(wp[:, :, None, None])
+        fstream = torch.empty(L.ctta_ffn_proj_pack_bytes(cp, hp), dtype=torch.uint8, device=DEV)
+        pstream = torch.empty(L.ctta_ffn_proj_pack_bytes(cp, cp), dtype=torch.uint8, device=DEV)
+        N.check(L.ctta_ffn_proj_pack(N.ptr(w0p), k0, hp, cp, N.ptr(fstream), st))
+        N.check(L.ctta_ffn_proj_pack(N.ptr(w3p), k3, cp, cp, N.ptr(pstream), st))
+        att = torch.randn(M, hp, generator=g).to(torch.bfloat16).to(DEV)
+        s1 = torch.randn(M, cp, generator=g).to(torch.bfloat16).to(DEV)
+        xin = torch.randn(M, cp, generator=g).to(torch.bfloat16).to(DEV)
+        s2b, s3b = torch.empty_like(s1), torch.empty_like(s1)
+        o5, o3, o1 = torch.empty_like(s1), torch.empty_like(s1), torch.empty_like(s1)
+        d0 = conv_desc(x0=att, c0=hp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w0p, k_pad=k0, n=cp, bias=b2d, res=s1, res_ld=cp, out=s2b, ldc=cp)
+        d1b = conv_desc(x0=n3, c0=cp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w1p, k_pad=k1, n=2 * ffp, bias=b1d, out=gg, ldc=ffp, out_act=4)
+        d2b = conv_desc(x0=gg, c0=ffp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w2p, k_pad=k2, n=cp, bias=b2d, res=s2b, res_ld=cp, out=s3b, ldc=cp)
+        d3 = conv_desc(x0=s3b, c0=cp, batch=1, hi=M, wi=1, ho=M, wo=1, w=w3p, k_pad=k3, n=cp, bias=b2d, res=xin, res_ld=cp, out=o5, ldc=cp)
+
+        def fdesc(front, tail, out):
+            fd = N.FfnDesc()
+            L.ctta_ffn_desc_init(ctypes.byref(fd))
+            fd.M, fd.cp, fd.ffp = M, cp, ffp
+            fd.packed, fd.b1, fd.b2 = packed.data_ptr(), b1d.data_ptr(), b2d.data_ptr()
+            fd.x, fd.ld_x, fd.res, fd.res_ld = n3.data_ptr(), cp, s2b.data_ptr(), cp
+            if front:
+                fd.front_packed, fd.front_bias, fd.att, fd.att_ld, fd.front_k = fstream.data_ptr(), b2d.data_ptr(), att.data_ptr(), hp, hp
+                fd.front_res, fd.front_res_ld, fd.s2_out, fd.s2_ld = s1.data_ptr(), cp, s2b.data_ptr(), cp
+                fd.ln_gamma, fd.ln_beta, fd.ln_d, fd.ln_eps = gamma.data_ptr(), beta.data_ptr(), d, 1e-5
+            if tail:
+                fd.proj_packed, fd.proj_bias, fd.proj_res, fd.proj_res_ld = pstream.data_ptr(), b2d.data_ptr(), xin.data_ptr(), cp
+            fd.out, fd.ldc, fd.n_valid = out.data_ptr(), cp, cp
+            return fd
+        fd_t, fd_ft = fdesc(False, True, o3), fdesc(True, True, o1)
+
+        def ln_b():
+            N.check(L.ctta_layernorm(N.ptr(s2b), N.ptr(n3), M, d, cp, N.ptr(gamma), N.ptr(beta), 1e-5, st))
+
+        def five():
+            N.check(L.ctta_conv_gemm(ctypes.byref(d0), st))
+            ln_b()
+            N.check(L.ctta_conv_gemm(ctypes.byref(d1b), st))
+            N.check(L.ctta_conv_gemm(ctypes.byref(d2b), st))
+            N.check(L.ctta_conv_gemm(ctypes.byref(d3), st))
+
+        def three_t():
+            N.check(L.ctta_conv_gemm(ctypes.byref(d0), st))
+            ln_b()
+            N.check(L.ctta_ffn_block(ctypes.byref(fd_t), st))
+
+        def one_ft():
+            N.check(L.ctta_ffn_block(ctypes.byref(fd_ft), st))
+        five()
+        three_t()
+        one_ft()
+        torch.cuda.synchronize()
+        fl5 = fl_row + 2.0 * cp * (hp + cp)
+        tb = time_many([five, three_t, one_ft])
+        print("cp %d  M %d block tail (to_out, norm3, ff1, ff2, proj_out): all equal %s" % (cp, M, torch.equal(o5, o3) and torch.equal(o5, o1)))
+        for name, t in zip(("five launches", "to_out + norm3 + fused(ffn, proj_out)", "one launch (front + ffn + tail)"), tb):
+            print("   %-40s %.4f ms  %.0f TF/s" % (name, t, fl5 * M / t / 1e9), flush=True)
         three()
         one()
         one_ln()
