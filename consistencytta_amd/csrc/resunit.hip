@@ -1,4 +1,5 @@
-// Fused HiFi-GAN ResBlock unit for the narrow vocoder stages (C = 32 / 64 / 128 channels):
+// Fused HiFi-GAN ResBlock unit (C = 32 / 64 / 128 channels: four waves, three workgroups per CU; round 6: C = 256 and, for
+// k = 3, C = 512 with eight waves and one workgroup per CU):
 //
 //   out = x + conv2( leaky_relu( conv1( leaky_relu(x, 0.1) ) + b1, 0.1 ) ) + b2        hifigan/models.py:56-63
 //   (conv1: k taps, dilation d; conv2: k taps, dilation 1; both "same"-padded, stride 1)
@@ -44,8 +45,13 @@ typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
 // KT: the tap count when it is one of the vocoder's (3 / 7 / 11: both K loops fully unrolled, so the weight prefetch keeps
 // its distance without a back edge), 0 = read it from the parameters.
 template <int C, int WC, int WP, int T, int KT>
-__global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) {
-  static_assert(WC * WP == 4, "four waves per workgroup");
+__global__ __launch_bounds__(WC * WP * 64, WC * WP == 4 ? 3 : 2) void resunit_kernel(const ResUnitParams p) {
+  static_assert(WC * WP == 4 || WC * WP == 8, "four waves per workgroup (C <= 128) or eight (C = 256: one workgroup per CU)");
+  constexpr int NT = WC * WP * 64;           // threads per workgroup
+  // Round 6: without the scheduling barrier behind each weight prefetch the compiler sinks the loads to the MFMAs that consume
+  // them (s_waitcnt vmcnt(0) per K step, the same thing ffn_fused.hip's first version showed): pinned, C = 128 k = 11 / 7 / 3
+  // 0.885 / 0.603 / 0.328 -> 0.749 / 0.518 / 0.304 ms per unit at B = 32 (1 262 / 1 162 / 849 TFLOP/s), C = 64 k = 11 0.503 -> 0.428
+  constexpr bool RU_PIN = true;
   constexpr int RS = C + 8;                  // LDS row stride (bf16): 16 B of padding spreads ds_read_b128 over banks
   constexpr int NCB = C / 16 / WC;           // cout blocks per wave
   constexpr int NCH = C / 32;                // 32-channel chunks per tap
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
   // ---- 1. leaky_relu(x) tile -> LDS (zero outside the sequence: F.conv1d pads the ACTIVATED signal with zeros; the
   //         descriptor's bounds check returns those zeros, so the loop is branch-free and SU loads are in flight per thread)
   {
-    constexpr int SU = 4, CV = C / 8, RPS = 256 / CV;          // uint4 per row, rows per sweep of the workgroup
+    constexpr int SU = 4, CV = C / 8, RPS = NT / CV;           // uint4 per row, rows per sweep of the workgroup
     const int cc = tid % CV, rr = tid / CV;
     // the whole byte offset in the VGPR: the bounds check looks at it alone, and a negative one (left halo of the first
     // tile) must stay out of range whatever the row advance is
@@ -149,6 +155,7 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
         const int nx = st + 2 < nsteps ? st + 2 : nsteps - 1;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) a2[cb] = __builtin_bit_cast(bf16x8_t, wf[(size_t)(cb * nsteps + nx) * 64]);
+        if (RU_PIN) __builtin_amdgcn_sched_barrier(0);     // the prefetch stays two steps ahead of its use (see ffn_fused.hip)
 #pragma unroll
         for (int pb = 0; pb < MBW; ++pb) {
           const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xt + ch * 32 + pb * 16 * RS));
@@ -217,6 +224,7 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
         const int nx = st + 2 < nsteps ? st + 2 : nsteps - 1;
 #pragma unroll
         for (int cb = 0; cb < NCB; ++cb) a2[cb] = __builtin_bit_cast(bf16x8_t, wf[(size_t)(cb * nsteps + nx) * 64]);
+        if (RU_PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int pb = 0; pb < OB; ++pb) {
           const bf16x8_t bf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(xt + ch * 32 + pb * 16 * RS));
@@ -248,7 +256,7 @@ __global__ __launch_bounds__(256, 3) void resunit_kernel(const ResUnitParams p) 
   constexpr int RSF = C * 4 + 16;            // staging row stride (bytes)
   constexpr int CH_ROWS = 32;                // rows per part and pass
   constexpr int LPR = C / 4;                 // lanes per output row
-  constexpr int RPP = 256 / LPR;             // rows finished per sweep of the workgroup
+  constexpr int RPP = NT / LPR;              // rows finished per sweep of the workgroup
   constexpr int NSW = WP * CH_ROWS / RPP;    // sweeps per pass
   constexpr int NP = OB / 2;                 // passes
   const int col4 = tid % LPR, prow = tid / LPR;
@@ -639,7 +647,7 @@ static ctta_status launch_resunit_k(const ResUnitParams& p, int batch, hipStream
     configured = smem;
   }
   dim3 grid((unsigned)((p.L + T - 1) / T), (unsigned)batch);
-  resunit_kernel<C, WC, WP, T, KT><<<grid, dim3(256), smem, s>>>(p);
+  resunit_kernel<C, WC, WP, T, KT><<<grid, dim3(WC * WP * 64), smem, s>>>(p);
   return CTTA_OK;
 }
 
@@ -655,8 +663,13 @@ static ctta_status launch_resunit(const ResUnitParams& p, int batch, hipStream_t
 
 extern "C" int ctta_resunit_supported(int channels, int k, int dil) {
   if (!ctta_opt(CTTA_OPT_FUSED_RES)) return 0;
-  if (channels != 32 && channels != 64 && channels != 128) return 0;
   if (k < 1 || k > 11 || (k & 1) == 0 || dil < 1) return 0;
+  // C = 256 / 512: eight waves, one workgroup per CU (T = 128 / 64 positions).  Measured against the two conv_gemm launches
+  // (B = 32, ms per unit): C = 256: k = 3 0.53 vs 0.68, k = 7 1.01 vs 1.15, k = 11 1.52 vs 1.64; C = 512: k = 3 0.51 vs 0.56 but
+  // k = 7 1.08 vs 1.05 and k = 11 1.66 vs 1.57 (64 positions per workgroup stream every weight byte twice as often as 128)
+  if (channels == 256) return resunit_smem(256, 1, 128, k, dil) <= (size_t)112 * 1024 ? 1 : 0;
+  if (channels == 512) return k == 3 && resunit_smem(512, 1, 64, k, dil) <= (size_t)160 * 1024 ? 1 : 0;
+  if (channels != 32 && channels != 64 && channels != 128) return 0;
   const int T = channels == 128 ? 128 : channels == 64 ? 256 : 512;
   const int WP = channels == 128 ? 1 : channels == 64 ? 2 : 4;
   return resunit_smem(channels, WP, T, k, dil) <= (size_t)64 * 1024 ? 1 : 0;
@@ -671,8 +684,8 @@ extern "C" ctta_status ctta_resunit_conv1d(const void* x, int batch, int len, in
   CTTA_REQUIRE(out_slope >= 0.f && out_slope <= 1.f, "resunit_conv1d: out_slope=%g must lie in [0, 1]", (double)out_slope);
   CTTA_REQUIRE(slope >= 0.f && slope <= 1.f, "resunit_conv1d: slope=%g must lie in [0, 1]", (double)slope);
   CTTA_REQUIRE(ctta_resunit_supported(channels, k, dil),
-               "resunit_conv1d: channels=%d k=%d dilation=%d is outside the fused kernel's range (C in {32,64,128}, odd k <= 11, "
-               "tile <= 64 KB of LDS)", channels, k, dil);
+               "resunit_conv1d: channels=%d k=%d dilation=%d is outside the fused kernel's range (C in {32,64,128,256}, odd k <= 11, "
+               "tile <= 64 KB of LDS (C <= 128); C = 512: k = 3)", channels, k, dil);
   ResUnitParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const bf16_t*)x; p.w1f = (const bf16_t*)w1_frag; p.w2f = (const bf16_t*)w2_frag; p.b1 = b1;
@@ -688,7 +701,9 @@ extern "C" ctta_status ctta_resunit_conv1d(const void* x, int batch, int len, in
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, 40, (long long)batch * len, channels, 2LL * k * channels, 1, s);
   ctta_status st;
-  if (channels == 128) st = launch_resunit<128, 4, 1, 128>(p, batch, s);
+  if (channels == 512) st = launch_resunit_k<512, 8, 1, 64, 3>(p, batch, s);
+  else if (channels == 256) st = launch_resunit<256, 8, 1, 128>(p, batch, s);
+  else if (channels == 128) st = launch_resunit<128, 4, 1, 128>(p, batch, s);
   else if (channels == 64) st = launch_resunit<64, 2, 2, 256>(p, batch, s);
   else st = launch_resunit<32, 1, 4, 512>(p, batch, s);
   if (prof) ctta_prof_end(s);
