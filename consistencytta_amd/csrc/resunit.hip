@@ -424,6 +424,7 @@ __global__ __launch_bounds__(256, 2) void reschain_kernel(const ResChainParams p
           const int nx = st + 2 < nsteps ? st + 2 : nsteps - 1;
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) a2[cb] = __builtin_bit_cast(bf16x8_t, wf[(size_t)(cb * nsteps + nx) * 64]);
+          __builtin_amdgcn_sched_barrier(0);     // (as in resunit_kernel: the prefetch stays two steps ahead)
 #pragma unroll
           for (int pb = 0; pb < MBW; ++pb) {
             if (pb < nmb) {
@@ -491,6 +492,7 @@ __global__ __launch_bounds__(256, 2) void reschain_kernel(const ResChainParams p
           const int nx = st + 2 < nsteps ? st + 2 : nsteps - 1;
 #pragma unroll
           for (int cb = 0; cb < NCB; ++cb) a2[cb] = __builtin_bit_cast(bf16x8_t, wf[(size_t)(cb * nsteps + nx) * 64]);
+          __builtin_amdgcn_sched_barrier(0);     // (as in resunit_kernel: the prefetch stays two steps ahead)
 #pragma unroll
           for (int pb = 0; pb < MBW; ++pb) {
             if (pb < nmb2) {
