@@ -805,17 +805,20 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                 launch_mode = "eager launches (graph capture skipped: %s)" % exc
                 dt = dt_eager
     if perceptual and os.environ.get("CTTA_BENCH_PIPELINE", "1") != "0" and not args.no_latency:
-        # configs[4] cannot be captured whole (torch autograd differentiates the CLAP loss down to the latent), but its teacher
-        # phase can: one hipGraph on its own stream for batch i + 1 beside the eager rest of batch i -- ~1 100 of the step's
-        # launches leave the host's queue as well (`main_eager`; same arithmetic, tests/test_train_gpu.py)
+        # configs[4]: the teacher phase as one hipGraph on its own stream for batch i + 1; the rest of batch i -- target network,
+        # student forward, decode + vocoder + CLAP towers, torch's backward through the loss down to the latent, the engine's
+        # backward -- as a second hipGraph (round 6: `main_eager=False`; tests/test_clap_gpu.py checks replay == eager).
+        # CTTA_BENCH_PERCEPTUAL_GRAPH=0: only the teacher phase replayed, the rest eager launches (rounds 4-5)
         gs, why = None, None
         try:      # phase 1, local: the teacher-phase capture
             gdr = torch.Generator().manual_seed(78 + rank)
             kw = dict(time_inds=torch.randint(0, 17, (B,), generator=gdr) * 2,
                       gaussian_noise=torch.randn(B, 8, 256, 16, generator=gdr).to(dev), guidance_scale=torch.rand(B, generator=gdr) * 6)
-            gs = m.capture_train_graph(opt, z0, P, pipeline_teacher=True, gt_wav=step_kw["gt_wav"], **kw)
+            gs = m.capture_train_graph(opt, z0, P, pipeline_teacher=True, gt_wav=step_kw["gt_wav"],
+                                       main_eager=None if os.environ.get("CTTA_BENCH_PERCEPTUAL_GRAPH", "1") == "0" else False, **kw)
         except Exception as exc:
-            why, gs = "rank %d: %s" % (rank, str(exc)[:120]), None
+            why, gs = "rank %d: %s" % (rank, str(exc)[:300]), None
+            trace("perceptual capture failed: %s" % why)
         if du.all_agree(gs is not None, dev):      # phase 2 on every rank, or on none
             placements.append(getattr(gs, "placement_ms", None))
             for _ in range(n_warm):
@@ -826,11 +829,15 @@ def distill_leg(args, dev, world, rank, perceptual=False):
                 losses.append(gs.step(z0, sched, gt_wav=step_kw["gt_wav"]))
             du.barrier(dev)
             dt_pipe = du.max_over_ranks(time.perf_counter() - t0, dev)
+            if not gs.main_eager:
+                dt_graph = dt_pipe       # the replayed form of this leg IS the pipelined one (there is no unpipelined capture of it)
             if dt_pipe < dt:
                 dt = dt_pipe
-                launch_mode = ("eager launches (two streams + weight-gradient side stream) for target network, student forward, decode, "
-                               "CLAP loss and backward; the frozen teacher's two CFG queries + Heun step as one hipGraph on a second "
-                               "stream for batch i + 1")
+                launch_mode = (("one hipGraph replay for target network, student forward, decode, CLAP loss and the backward through all "
+                                "of them" if not gs.main_eager else
+                                "eager launches (two streams + weight-gradient side stream) for target network, student forward, decode, "
+                                "CLAP loss and backward") +
+                               "; the frozen teacher's two CFG queries + Heun step as one hipGraph on a second stream for batch i + 1")
         else:
             launch_mode += " (pipelined teacher skipped: %s)" % (why or "capture failed on another rank")
         del gs

@@ -957,8 +957,10 @@ class _DistillStepGraph:
         # main_eager: only the teacher phase is a hipGraph (on its own stream); target network, student forward, loss and
         # backward run as eager launches -- the form the waveform-domain losses take (loss_type 'mel' / 'stft' / 'clap': torch
         # autograd differentiates the loss down to the latent, which a capture cannot hold)
+        # (round 6: `main_eager=False` with a waveform-domain loss captures that part too -- the decode, the loss modules and
+        # torch's backward through them are recorded like any other launch sequence; the ground-truth audio and the prompt's
+        # extra tensors then live in static buffers of the input set.  Opt-in: the default stays eager.)
         self.main_eager = bool(model.loss is not None) if main_eager is None else bool(main_eager)
-        assert model.loss is None or self.main_eager, "a captured main graph covers the latent-space loss (loss_type='mse') only"
         assert not self.main_eager or self.pipelined, "main_eager without a pipelined teacher is the plain train_step"
         self.accum = max(1, int(accumulation_steps))
         self.bucket_min_elems = int(bucket_min_elems)     # = GradientBuckets' merge rule (dist_util)
@@ -1015,7 +1017,19 @@ class _DistillStepGraph:
         self.cur["flat"].copy_(self.nxt["flat"])
         for k in self._P_KEYS:
             self.cur["P"][k].copy_(self.nxt["P"][k])
-        self.cur["extra"], self.cur["gt_wav"] = self.nxt["extra"], self.nxt["gt_wav"]
+        if self.main_eager or self.m.loss is None:
+            self.cur["extra"], self.cur["gt_wav"] = self.nxt["extra"], self.nxt["gt_wav"]
+            return
+        # captured main part: the graph reads the CURRENT set's own buffers
+        def own(dst, src):
+            if torch.is_tensor(src):
+                if torch.is_tensor(dst) and dst.shape == src.shape and dst.data_ptr() != src.data_ptr():
+                    dst.copy_(src)
+                    return dst
+                return src.detach().clone()
+            return src
+        self.cur["extra"] = {k: own(self.cur["extra"].get(k), v) for k, v in self.nxt["extra"].items()}
+        self.cur["gt_wav"] = own(self.cur.get("gt_wav"), self.nxt["gt_wav"])
 
     # -- host side: what the Heun scheduler would look up for this draw, in `_forward_impl`'s call order
     def _sigma_plan(self, inds):
@@ -1050,8 +1064,25 @@ class _DistillStepGraph:
         if prompt is not None:
             for k in self._P_KEYS:
                 S["P"][k].copy_(prompt[k])
-            S["extra"] = {k: v for k, v in prompt.items() if k not in self._P_KEYS}
-        S["gt_wav"] = gt_wav
+            extra = {k: v for k, v in prompt.items() if k not in self._P_KEYS}
+            if self.main_eager or self.m.loss is None:
+                S["extra"] = extra
+            else:                              # captured main part: static copies (the graph holds their addresses)
+                for k, v in extra.items():
+                    if torch.is_tensor(v):
+                        if k not in S["extra"] or not torch.is_tensor(S["extra"][k]) or S["extra"][k].shape != v.shape or S["extra"][k] is v:
+                            S["extra"][k] = v.detach().clone()
+                        else:
+                            S["extra"][k].copy_(v)
+                    else:
+                        S["extra"][k] = v
+        if gt_wav is not None and not self.main_eager and self.m.loss is not None:
+            if S.get("gt_wav") is None or S["gt_wav"].shape != gt_wav.shape or S["gt_wav"] is gt_wav:
+                S["gt_wav"] = gt_wav.detach().clone()
+            else:
+                S["gt_wav"].copy_(gt_wav)
+        else:
+            S["gt_wav"] = gt_wav
         S["z0"].copy_(z_0)
         S["noise"].copy_(gaussian_noise if gaussian_noise is not None else torch.randn_like(z_0))
 
@@ -1404,7 +1435,9 @@ def _capture_train_graph(self, optimizer, z_0, prompt, segmented=None, accumulat
     prompt shape (`prompt` must be the dict of pre-computed text states; `step(..., prompt=next_states)` / `feed(..., prompt=)`
     hands a batch's own text states over with it -- they are double-buffered like the latents).  With a waveform-domain loss
     (loss_type 'mel' / 'stft' / 'clap') pass pipeline_teacher=True: the teacher phase is a hipGraph on its own stream and the
-    rest of the step stays eager launches (`main_eager`), `step(..., gt_wav=)` carries the ground-truth audio.
+    rest of the step stays eager launches (`main_eager`, the default) or -- `main_eager=False`, round 6 -- becomes a second
+    hipGraph that holds the decode, the loss modules and torch's backward through them as well (the ground-truth audio and the
+    prompt's extra tensors are then copied into static buffers of the input set); `step(..., gt_wav=)` carries the audio.
     `segmented` (default: whenever a process group with more than one rank exists) captures the backward block by block
     so that the data-parallel gradient all-reduce overlaps it as in the eager `train_step`.
     `pipeline_teacher=True`: the frozen teacher's two CFG queries + Heun step (a third of the step's device time, and

@@ -440,6 +440,44 @@ def test_clap_finetune_step_at_light_widths_matches_reference(golden):
         assert all(p.grad is None for p in getattr(m, name).parameters())
 
 
+def test_clap_finetune_step_as_a_replayed_graph_equals_the_eager_step(golden):
+    """`capture_train_graph(..., pipeline_teacher=True, main_eager=False)` with loss_type='clap' -- target network,
+    student forward, VAE decode + vocoder + resampler + CLAP towers and torch's backward through them down to the latent, then
+    the engine's backward, recorded as ONE hipGraph (the teacher phase as its own graph one batch ahead): the replay gives the
+    eager step's loss and the student's gradient (same kernels, same order; fp32 atomics in the loss modules leave round-off)."""
+    g, m, P, z0, gt, kw = _clapft_light(golden)
+    opt = m.prepare_training(lr=2e-5, weight_decay=0.0, broadcast=False)
+    with torch.no_grad():
+        loss, pred, target, sig, gamma = m._forward_impl(z0, gt, P, False, True, kw["time_inds"], kw["gaussian_noise"],
+                                                         kw["guidance_scale"], True)
+        m._student_backward(pred, target, sig, gamma, 1.0, None)
+    torch.cuda.synchronize()
+    g_eager, l_eager = opt.grad.clone(), float(loss)
+    opt.zero_grad()
+    gs = m.capture_train_graph(opt, z0, P, segmented=False, pipeline_teacher=True, main_eager=False, gt_wav=gt, **kw)
+    assert gs.main_eager is False and gs.graph is not None
+    assert gs.feed(z0, prompt=P, gt_wav=gt, **kw) is False
+    for rnd in range(2):                       # the second replay reads the rotated static copies of gt / text features
+        assert gs.feed(z0, prompt=P, gt_wav=gt, **kw) is True
+        gs.replay()
+        torch.cuda.synchronize()
+        rel = float((opt.grad - g_eager).norm() / g_eager.norm())
+        print("replayed CLAP fine-tuning step %d: loss %.7f (eager %.7f), gradient rel diff %.2e" % (rnd, float(gs.loss.item()), l_eager, rel))
+        assert abs(float(gs.loss.item()) - l_eager) <= 1e-5 * abs(l_eager) and rel <= 1e-4
+        opt.zero_grad()
+    # a batch with OTHER ground-truth audio and caption features changes the loss: the static copies are what the graph reads
+    P2 = dict(P, clap_text_features=F.normalize(P["clap_text_features"].flip(-1) + 0.1, dim=-1))
+    assert gs.feed(z0, prompt=P2, gt_wav=gt.flip(-1) * 0.5, **kw) is True
+    gs.replay()                                # still the first batch's inputs (fed one call ahead)
+    assert abs(float(gs.loss.item()) - l_eager) <= 1e-5 * abs(l_eager)
+    opt.zero_grad()
+    assert gs.feed(z0, prompt=P, gt_wav=gt, **kw) is True
+    gs.replay()                                # now batch 2
+    torch.cuda.synchronize()
+    assert abs(float(gs.loss.item()) - l_eager) > 1e-4 * abs(l_eager)
+    opt.zero_grad()
+
+
 def test_clap_finetune_loss_decreases_at_light_widths(golden):
     """The fixed-draw decrease test of the toy size, at configs[4]'s real size: twenty optimizer steps on ONE clip with the
     fixture's draws held fixed must lower the CLAP fine-tuning loss."""
