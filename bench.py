@@ -388,6 +388,9 @@ def main():
             "share_of_step_time": round(conv_ms / (dt / args.steps * 1e3), 3),
             "mfma_launch_ms_per_step_all_kinds": round(all_ms, 3),
             "stage_frac": stage_frac,
+            # the same fractions over each stage replayed alone as a hipGraph (no host gaps): what the kernels of the stage reach
+            "stage_frac_graph": ({k: round(gf_stage[k] * 1e9 * B / (result["stage_ms_graph"][k] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)
+                                  for k in gf_stage} if "error" not in result.get("stage_ms_graph", {"error": 1}) else None),
             # ALL algorithmic FLOPs of the clip (attention included) / the HEADLINE step time (every kernel, every gap)
             "frac_end_to_end": round(sum(gf_stage.values()) * 1e9 * B / (dt / args.steps) / 1e12 / PEAK_BF16_TFLOPS, 4),
         }

@@ -30,16 +30,28 @@ if [ "${REFRESH_LIGHT:-0}" = "1" ]; then
   du -sh $O
   exit 0
 fi
-timeout 420 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_fetch.log 2>&1
-timeout 420 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_write.log 2>&1
+# one counter pass; repeated once when rocprofv3 died before it wrote a counter table (these passes have failed intermittently
+# at start-up since round 1: the log then ends after "HSA version ... initialized")
+pmc_pass() {   # <counter> <out dir name> <timeout> <bench args...>
+  local ctr=$1 dir=$2 to=$3; shift 3
+  for try in 1 2; do
+    rm -rf $O/$dir
+    timeout $to rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$dir -o p -- python3 $R/bench.py "$@" > $O/$dir.log 2>&1
+    [ -n "$(find $O/$dir -name '*counter_collection.csv' -size +1k 2>/dev/null | head -1)" ] && return 0
+    echo "pmc pass $dir: no counter table (try $try)" >> $O/pmc_retries.txt
+  done
+  return 1
+}
+pmc_pass FETCH_SIZE pmc_fetch 420 --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency
+pmc_pass WRITE_SIZE pmc_write 420 --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch $O/pmc_write > $O/pmc_traffic.json 2> $O/pmc_traffic.err
 # Distillation leg: the PMC passes of that mode hung intermittently in round 1; one step, no warm-up, no latency legs
 # keeps each pass short, and a 300 s timeout bounds the loss when one hangs (tools/pmc_traffic.py ... distill <steps>;
 # steps = 1 timed + 1 warm-up minimum + 10 accumulation micro-steps + 1 profiled = see the script's own count)
-timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_d -o p -- python3 $R/bench.py --mode distill --steps 1 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_fetch_d.log 2>&1
-timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_d -o p -- python3 $R/bench.py --mode distill --steps 1 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_write_d.log 2>&1
+pmc_pass FETCH_SIZE pmc_fetch_d 300 --mode distill --steps 1 --warmup 1 --no-cpu-baseline --no-latency
+pmc_pass WRITE_SIZE pmc_write_d 300 --mode distill --steps 1 --warmup 1 --no-cpu-baseline --no-latency
 python3 $R/tools/pmc_traffic.py $O/pmc_fetch_d $O/pmc_write_d distill 18 > $O/pmc_traffic_distill.json 2> $O/pmc_traffic_distill.err
-timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d $O/pmc_mfma -o p -- python3 $R/bench.py --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency > $O/pmc_mfma.log 2>&1
+pmc_pass SQ_VALU_MFMA_BUSY_CYCLES pmc_mfma 300 --mode gen --steps 2 --warmup 1 --no-cpu-baseline --no-latency
 python3 $R/tools/pmc_mfma_util.py $O/pmc_mfma > $O/pmc_mfma_util.json 2> $O/pmc_mfma_util.err
 # where a hipGraph-replayed distillation step spends its time: idle / one kernel / two kernels, dispatch counts, idle gaps by kernel
 # pair (three monolithic-graph steps between AdamW launches: eager 1+3, segmented 1+3, monolithic 1+3 -> AdamW launches 8..11)
