@@ -258,7 +258,7 @@ __global__ __launch_bounds__(WC * WP * 64, WC * WP == 4 ? 3 : 2) void resunit_ke
   constexpr int LPR = C / 4;                 // lanes per output row
   constexpr int RPP = NT / LPR;              // rows finished per sweep of the workgroup
   constexpr int NSW = WP * CH_ROWS / RPP;    // sweeps per pass
-  constexpr int NP = OB / 2;                 // passes
+  constexpr int NP = (OB + 1) / 2;           // passes (an odd OB -- the 80-position tile of C = 512 -- leaves half a pass)
   const int col4 = tid % LPR, prow = tid / LPR;
   const ConvParams& e = p.epi;
   const float4 bias4 = e.bias ? *reinterpret_cast<const float4*>(e.bias + col4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -269,15 +269,20 @@ __global__ __launch_bounds__(WC * WP * 64, WC * WP == 4 ? 3 : 2) void resunit_ke
   const int voff = ((l0 + prow) * C + col4 * 4) * 2;
   // sequence position of (pass, sweep) relative to l0 + prow: part = sweep * RPP / 32 rows of 32, OB blocks per part
   auto rel = [](int pass, int sw) { return (((sw * RPP) / CH_ROWS) * OB + pass * 2) * 16 + (sw * RPP) % CH_ROWS; };
+  // the second 16-row block of the last pass does not exist when OB is odd: its sweeps are skipped (compile-time, the loops
+  // are unrolled) -- their positions belong to the NEXT tile
+  auto live = [](int pass, int sw) { return !((OB & 1) && pass == NP - 1 && (sw * RPP) % CH_ROWS >= 16); };
   u32x2_t rx[NSW], ro[NSW];
 #pragma unroll
   for (int sw = 0; sw < NSW; ++sw) {
-    rx[sw] = __builtin_amdgcn_raw_buffer_load_b64(rsx, voff, rel(0, sw) * C * 2, 0);
+    rx[sw] = (u32x2_t){0u, 0u};
+    if (live(0, sw)) rx[sw] = __builtin_amdgcn_raw_buffer_load_b64(rsx, voff, rel(0, sw) * C * 2, 0);
     ro[sw] = (u32x2_t){0u, 0u};
   }
   if (acc_old) {
 #pragma unroll
-    for (int sw = 0; sw < NSW; ++sw) ro[sw] = __builtin_amdgcn_raw_buffer_load_b64(rso, voff, rel(0, sw) * C * 2, 0);
+    for (int sw = 0; sw < NSW; ++sw)
+      if (live(0, sw)) ro[sw] = __builtin_amdgcn_raw_buffer_load_b64(rso, voff, rel(0, sw) * C * 2, 0);
   }
 #pragma unroll
   for (int pass = 0; pass < NP; ++pass) {
@@ -285,23 +290,26 @@ __global__ __launch_bounds__(WC * WP * 64, WC * WP == 4 ? 3 : 2) void resunit_ke
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int pb = pass * 2 + h;
-      unsigned char* row = smem_raw + (size_t)(wp * CH_ROWS + h * 16 + lq) * RSF;
+      if (pb < OB) {
+        unsigned char* row = smem_raw + (size_t)(wp * CH_ROWS + h * 16 + lq) * RSF;
 #pragma unroll
-      for (int cb = 0; cb < NCB; ++cb) {
-        const f32x4_t a = acc2[cb][pb];
-        *reinterpret_cast<float4*>(row + ((cb0 + cb) * 16 + lg * 4) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        for (int cb = 0; cb < NCB; ++cb) {
+          const f32x4_t a = acc2[cb][pb < OB ? pb : 0];
+          *reinterpret_cast<float4*>(row + ((cb0 + cb) * 16 + lg * 4) * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        }
       }
     }
     LDS_BARRIER();
     float4 q[NSW];
 #pragma unroll
     for (int sw = 0; sw < NSW; ++sw)
-      q[sw] = *reinterpret_cast<const float4*>(smem_raw + (size_t)(prow + sw * RPP) * RSF + col4 * 16);
+      if (live(pass, sw)) q[sw] = *reinterpret_cast<const float4*>(smem_raw + (size_t)(prow + sw * RPP) * RSF + col4 * 16);
 #pragma unroll
     for (int sw = 0; sw < NSW; ++sw) {
+      if (!live(pass, sw)) continue;
       float v[4] = {q[sw].x + bias4.x, q[sw].y + bias4.y, q[sw].z + bias4.z, q[sw].w + bias4.w};
       const u32x2_t r2 = rx[sw], o2 = ro[sw];
-      if (pass + 1 < NP) {
+      if (pass + 1 < NP && live(pass + 1, sw)) {
         rx[sw] = __builtin_amdgcn_raw_buffer_load_b64(rsx, voff, rel(pass + 1, sw) * C * 2, 0);
         if (acc_old) ro[sw] = __builtin_amdgcn_raw_buffer_load_b64(rso, voff, rel(pass + 1, sw) * C * 2, 0);
       }
@@ -663,14 +671,24 @@ static ctta_status launch_resunit(const ResUnitParams& p, int batch, hipStream_t
   }
 }
 
+// C = 512: positions per workgroup.  k = 3 fits 64 (two workgroups' worth of LDS would not); k = 7 / 11 take the longest tile whose
+// rows (1 040 B each, halo included) fit 160 KB: 96, or 80 for k = 11 at dilation 5.  Anything else: the two conv_gemm launches.
+static int resunit_tile512(int k, int dil) {
+  if (k == 3) return resunit_smem(512, 1, 64, k, dil) <= (size_t)160 * 1024 ? 64 : 0;
+  if (k != 7 && k != 11) return 0;
+  if (resunit_smem(512, 1, 96, k, dil) <= (size_t)160 * 1024) return 96;
+  if (resunit_smem(512, 1, 80, k, dil) <= (size_t)160 * 1024) return 80;
+  return 0;
+}
+
 extern "C" int ctta_resunit_supported(int channels, int k, int dil) {
   if (!ctta_opt(CTTA_OPT_FUSED_RES)) return 0;
   if (k < 1 || k > 11 || (k & 1) == 0 || dil < 1) return 0;
-  // C = 256 / 512: eight waves, one workgroup per CU (T = 128 / 64 positions).  Measured against the two conv_gemm launches
-  // (B = 32, ms per unit): C = 256: k = 3 0.53 vs 0.68, k = 7 1.01 vs 1.15, k = 11 1.52 vs 1.64; C = 512: k = 3 0.51 vs 0.56 but
-  // k = 7 1.08 vs 1.05 and k = 11 1.66 vs 1.57 (64 positions per workgroup stream every weight byte twice as often as 128)
+  // C = 256 / 512: eight waves, one workgroup per CU.  Measured against the two conv_gemm launches (B = 32, ms per unit): C = 256
+  // (T = 128): k = 3 0.53 vs 0.68, k = 7 1.01 vs 1.15, k = 11 1.52 vs 1.64; C = 512: k = 3 (T = 64) 0.51 vs 0.56, k = 7 (T = 96) 0.93
+  // vs 1.05, k = 11 (T = 96) 1.42 vs 1.57 -- at T = 64 k = 7 / 11 lost (1.08 / 1.66): every weight byte is streamed once per T rows
   if (channels == 256) return resunit_smem(256, 1, 128, k, dil) <= (size_t)112 * 1024 ? 1 : 0;
-  if (channels == 512) return k == 3 && resunit_smem(512, 1, 64, k, dil) <= (size_t)160 * 1024 ? 1 : 0;
+  if (channels == 512) return resunit_tile512(k, dil) > 0 ? 1 : 0;
   if (channels != 32 && channels != 64 && channels != 128) return 0;
   const int T = channels == 128 ? 128 : channels == 64 ? 256 : 512;
   const int WP = channels == 128 ? 1 : channels == 64 ? 2 : 4;
@@ -703,7 +721,12 @@ extern "C" ctta_status ctta_resunit_conv1d(const void* x, int batch, int len, in
   const bool prof = ctta_prof_active();
   if (prof) ctta_prof_begin(0, 40, (long long)batch * len, channels, 2LL * k * channels, 1, s);
   ctta_status st;
-  if (channels == 512) st = launch_resunit_k<512, 8, 1, 64, 3>(p, batch, s);
+  if (channels == 512) {
+    const int t512 = resunit_tile512(k, dil);
+    st = k == 3 ? launch_resunit_k<512, 8, 1, 64, 3>(p, batch, s)
+       : k == 7 ? launch_resunit_k<512, 8, 1, 96, 7>(p, batch, s)
+       : t512 == 96 ? launch_resunit_k<512, 8, 1, 96, 11>(p, batch, s) : launch_resunit_k<512, 8, 1, 80, 11>(p, batch, s);
+  }
   else if (channels == 256) st = launch_resunit<256, 8, 1, 128>(p, batch, s);
   else if (channels == 128) st = launch_resunit<128, 4, 1, 128>(p, batch, s);
   else if (channels == 64) st = launch_resunit<64, 2, 2, 256>(p, batch, s);

@@ -562,7 +562,8 @@ def test_conv1d_halo_kernel(C, k, d, L):
 @pytest.mark.parametrize("C,k,d,L,B", [(128, 11, 5, 700, 2), (128, 3, 1, 129, 1), (128, 7, 3, 128, 2), (64, 11, 5, 1000, 2),
                                        (64, 3, 3, 255, 1), (64, 7, 1, 513, 2), (32, 11, 5, 1500, 2), (32, 3, 1, 40, 3),
                                        (32, 7, 5, 1025, 1), (128, 11, 1, 50, 1), (256, 3, 1, 700, 2), (256, 3, 5, 129, 1),
-                                       (256, 7, 3, 128, 3), (256, 11, 5, 300, 1), (512, 3, 5, 200, 2), (512, 3, 1, 64, 1)])
+                                       (256, 7, 3, 128, 3), (256, 11, 5, 300, 1), (512, 3, 5, 200, 2), (512, 3, 1, 64, 1),
+                                       (512, 7, 5, 200, 2), (512, 11, 3, 97, 1), (512, 11, 5, 245, 2), (512, 11, 5, 80, 1)])
 def test_fused_resblock_unit(C, k, d, L, B):
     """hifigan/models.py:56-63 as ONE launch (resunit.hip): x + conv2(lrelu(conv1(lrelu(x)))) with the intermediate in
     LDS, vs F.conv1d on the same bf16-rounded operands (intermediate rounded to bf16 like the two-launch path), for
@@ -610,7 +611,7 @@ def test_fused_resblock_unit(C, k, d, L, B):
     ref = F.leaky_relu((old + unit) / 3.0, 0.01)
     assert rel_err(out.float().permute(0, 2, 1).cpu(), ref) < 2 * BF16_TOL
     # unsupported shapes are refused loudly
-    assert L_.ctta_resunit_supported(1024, 3, 1) == 0 and L_.ctta_resunit_supported(64, 4, 1) == 0 and L_.ctta_resunit_supported(512, 7, 1) == 0
+    assert L_.ctta_resunit_supported(1024, 3, 1) == 0 and L_.ctta_resunit_supported(64, 4, 1) == 0 and L_.ctta_resunit_supported(512, 5, 1) == 0
     with pytest.raises(RuntimeError):
         N.check(L_.ctta_resunit_conv1d(N.ptr(xa), B, L, 1024, k, d, N.ptr(frags[0][0]), N.ptr(b1d), N.ptr(frags[1][0]),
                                        N.ptr(b2d), 0.1, N.ptr(out), 0, 1.0, 0.0, N.stream_ptr()))
