@@ -671,10 +671,11 @@ static ctta_status launch_resunit(const ResUnitParams& p, int batch, hipStream_t
   }
 }
 
-// C = 512: positions per workgroup.  k = 3 fits 64 (two workgroups' worth of LDS would not); k = 7 / 11 take the longest tile whose
-// rows (1 040 B each, halo included) fit 160 KB: 96, or 80 for k = 11 at dilation 5.  Anything else: the two conv_gemm launches.
+// C = 512: positions per workgroup = the longest tile whose rows (1 040 B each, halo included) fit 160 KB AND that cuts the
+// stage's 5 121 positions into rounds of 256 workgroups without a near-empty last one: 96 (54 tiles x 32 samples = 6.75 rounds;
+// 128 -> 5.125 rounds measured 0.500 ms per k = 3 unit, 64 -> 0.509, 96 -> 0.449), 80 for k = 11 at dilation 5 (LDS).
 static int resunit_tile512(int k, int dil) {
-  if (k == 3) return resunit_smem(512, 1, 64, k, dil) <= (size_t)160 * 1024 ? 64 : 0;
+  if (k == 3) return resunit_smem(512, 1, 96, k, dil) <= (size_t)160 * 1024 ? 96 : resunit_smem(512, 1, 64, k, dil) <= (size_t)160 * 1024 ? 64 : 0;
   if (k != 7 && k != 11) return 0;
   if (resunit_smem(512, 1, 96, k, dil) <= (size_t)160 * 1024) return 96;
   if (resunit_smem(512, 1, 80, k, dil) <= (size_t)160 * 1024) return 80;
@@ -684,10 +685,11 @@ static int resunit_tile512(int k, int dil) {
 extern "C" int ctta_resunit_supported(int channels, int k, int dil) {
   if (!ctta_opt(CTTA_OPT_FUSED_RES)) return 0;
   if (k < 1 || k > 11 || (k & 1) == 0 || dil < 1) return 0;
-  // C = 256 / 512: eight waves, one workgroup per CU.  Measured against the two conv_gemm launches (B = 32, ms per unit): C = 256
-  // (T = 128): k = 3 0.53 vs 0.68, k = 7 1.01 vs 1.15, k = 11 1.52 vs 1.64; C = 512: k = 3 (T = 64) 0.51 vs 0.56, k = 7 (T = 96) 0.93
-  // vs 1.05, k = 11 (T = 96) 1.42 vs 1.57 -- at T = 64 k = 7 / 11 lost (1.08 / 1.66): every weight byte is streamed once per T rows
-  if (channels == 256) return resunit_smem(256, 1, 128, k, dil) <= (size_t)112 * 1024 ? 1 : 0;
+  // C = 256 / 512: eight waves, one workgroup per CU; every weight byte is streamed once per T positions, so T is as long as the
+  // tile's rows fit the LDS.  Measured against the two conv_gemm launches (B = 32, ms per unit): C = 256: k = 3 (T = 192) 0.52 vs
+  // 0.69, k = 7 (T = 224) 0.96 vs 1.17, k = 11 (T = 224) 1.42 vs 1.67 (T = 128: 0.53 / 1.01 / 1.52); C = 512: k = 3 (T = 96) 0.45 vs
+  // 0.57, k = 7 (T = 96) 0.93 vs 1.05, k = 11 (T = 96; 80 at dilation 5) 1.42 (1.58) vs 1.57 -- at T = 64 k = 7 / 11 lost (1.08 / 1.66)
+  if (channels == 256) return resunit_smem(256, 1, k <= 3 ? 192 : 224, k, dil) <= (size_t)160 * 1024 ? 1 : 0;
   if (channels == 512) return resunit_tile512(k, dil) > 0 ? 1 : 0;
   if (channels != 32 && channels != 64 && channels != 128) return 0;
   const int T = channels == 128 ? 128 : channels == 64 ? 256 : 512;
@@ -705,7 +707,7 @@ extern "C" ctta_status ctta_resunit_conv1d(const void* x, int batch, int len, in
   CTTA_REQUIRE(slope >= 0.f && slope <= 1.f, "resunit_conv1d: slope=%g must lie in [0, 1]", (double)slope);
   CTTA_REQUIRE(ctta_resunit_supported(channels, k, dil),
                "resunit_conv1d: channels=%d k=%d dilation=%d is outside the fused kernel's range (C in {32,64,128,256}, odd k <= 11, "
-               "tile <= 64 KB of LDS (C <= 128); C = 512: k = 3)", channels, k, dil);
+               "tile <= 64 KB of LDS (C <= 128); C = 512: k in {3, 7, 11})", channels, k, dil);
   ResUnitParams p;
   memset(&p, 0, sizeof(p));
   p.x = (const bf16_t*)x; p.w1f = (const bf16_t*)w1_frag; p.w2f = (const bf16_t*)w2_frag; p.b1 = b1;
@@ -723,11 +725,11 @@ extern "C" ctta_status ctta_resunit_conv1d(const void* x, int batch, int len, in
   ctta_status st;
   if (channels == 512) {
     const int t512 = resunit_tile512(k, dil);
-    st = k == 3 ? launch_resunit_k<512, 8, 1, 64, 3>(p, batch, s)
+    st = k == 3 ? (t512 == 96 ? launch_resunit_k<512, 8, 1, 96, 3>(p, batch, s) : launch_resunit_k<512, 8, 1, 64, 3>(p, batch, s))
        : k == 7 ? launch_resunit_k<512, 8, 1, 96, 7>(p, batch, s)
        : t512 == 96 ? launch_resunit_k<512, 8, 1, 96, 11>(p, batch, s) : launch_resunit_k<512, 8, 1, 80, 11>(p, batch, s);
   }
-  else if (channels == 256) st = launch_resunit<256, 8, 1, 128>(p, batch, s);
+  else if (channels == 256) st = k <= 3 ? launch_resunit<256, 8, 1, 192>(p, batch, s) : launch_resunit<256, 8, 1, 224>(p, batch, s);
   else if (channels == 128) st = launch_resunit<128, 4, 1, 128>(p, batch, s);
   else if (channels == 64) st = launch_resunit<64, 2, 2, 256>(p, batch, s);
   else st = launch_resunit<32, 1, 4, 512>(p, batch, s);

@@ -399,7 +399,7 @@ size_t ctta_conv_workspace_bytes(void);
 int ctta_conv_gemm_num_variants(void);
 const char* ctta_conv_gemm_variant_name(int id);
 
-/* Fused HiFi-GAN ResBlock unit (hifigan/models.py:56-63) for C = 32 / 64 / 128 / 256 channels, odd k <= 11 (C = 512: k = 3):
+/* Fused HiFi-GAN ResBlock unit (hifigan/models.py:56-63) for C = 32 / 64 / 128 / 256 channels, odd k <= 11 (C = 512: k = 3 / 7 / 11):
  *   out = act( alpha * ( [old out +] x + conv2(leaky_relu(conv1(leaky_relu(x, slope)) + b1, slope)) + b2 ) )
  * conv1: k taps, dilation `dil`; conv2: k taps, dilation 1; "same" zero padding; x / out bf16 [batch][len][channels].
  * The intermediate never leaves LDS.  Weights are FRAGMENT-MAJOR copies ([n/16][k*channels/32][64][8] bf16) of the
