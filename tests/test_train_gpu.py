@@ -885,6 +885,54 @@ def test_multi_resolution_stft_loss_runs_through_the_differentiable_vocoder():
     assert float((inst.detach().cpu() - ref).abs().max()) <= 5e-2 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("loss_type", ["mel", "stft"])
+def test_waveform_loss_step_as_a_replayed_graph_equals_the_eager_step(golden, loss_type):
+    """`capture_train_graph(pipeline_teacher=True, main_eager=False)` with a waveform-domain loss (round 6; the CLAP form at the
+    real widths is in tests/test_clap_gpu.py): the decode, the loss module and torch's backward through them are recorded in the
+    main hipGraph.  At the toy size, for the two losses that need no CLAP towers: the replay gives the eager step's loss and
+    the student's gradient, twice in a row."""
+    from consistencytta_amd.models import AudioLCM
+    g = golden("distill_tiny")
+    vae, _ = _tiny_vae(0.9227914214134216)
+    cfg = cases.TINY_UNET
+    m = AudioLCM(text_encoder_name="google/flan-t5-large", scheduler_name="stabilityai/stable-diffusion-2-1",
+                 unet_model_config_path="tiny_light.json", unet_config=cfg, snr_gamma=5.0, use_edm=True,
+                 teacher_guidance_scale=-1, num_diffusion_steps=18, vae=vae, loss_type=loss_type,
+                 target_ema_decay=0.95, ema_decay=0.999)
+    m.teacher_unet.load_state_dict(cases.unet_weights(cfg, False, 0))
+    m.student_unet.load_state_dict(cases.unet_weights(cfg, True, 1))
+    m.student_target_unet.load_state_dict(cases.unet_weights(cfg, True, 2))
+    m.student_ema_unet.load_state_dict(cases.unet_weights(cfg, True, 3))
+    m.to(DEV)
+    m.train()
+    P = {k: v.to(DEV) for k, v in cases.prompt_states(cfg, 3, 6, "distill").items()}
+    # (the STFT loss runs the vocoder: 64 mel bins = a latent 16 wide; the mel loss keeps the fixture's 32 x 8 latent and draws)
+    zs = (3, 8, 16, 16) if loss_type == "stft" else (3, 8, 32, 8)
+    z0 = (cases.t(spec.det_uniform("distill.z0", zs, 14)) * 0.9).to(DEV)
+    noise = torch.from_numpy(g["noise"]) if loss_type == "mel" else cases.t(spec.det_uniform("distill.noise16", zs, 15))
+    kw = dict(time_inds=torch.from_numpy(g["time_inds"]) * 2, gaussian_noise=noise.to(DEV),
+              guidance_scale=torch.from_numpy(g["guidance"]))
+    opt = m.prepare_training(lr=1e-5, weight_decay=1e-4, broadcast=False)
+    with torch.no_grad():
+        loss, pred, target, sig, gamma = m._forward_impl(z0, None, P, False, True, kw["time_inds"], kw["gaussian_noise"],
+                                                         kw["guidance_scale"], True)
+        m._student_backward(pred, target, sig, gamma, 1.0, None)
+    torch.cuda.synchronize()
+    g_eager, l_eager = opt.grad.clone(), float(loss)
+    opt.zero_grad()
+    gs = m.capture_train_graph(opt, z0, P, segmented=False, pipeline_teacher=True, main_eager=False, **kw)
+    assert gs.main_eager is False and gs.graph is not None
+    assert gs.feed(z0, prompt=P, **kw) is False
+    for rnd in range(2):
+        assert gs.feed(z0, prompt=P, **kw) is True
+        gs.replay()
+        torch.cuda.synchronize()
+        rel = float((opt.grad - g_eager).norm() / g_eager.norm())
+        print("replayed %s-loss step %d: loss %.7f (eager %.7f), gradient rel diff %.2e" % (loss_type, rnd, float(gs.loss.item()), l_eager, rel))
+        assert abs(float(gs.loss.item()) - l_eager) <= 1e-5 * abs(l_eager) and rel <= 1e-4
+        opt.zero_grad()
+
+
 # ------------------------------------------------------------------------------------------------
 # The distillation step at the REAL widths (559 M-parameter light U-Nets, latent 8 x 256 x 16): loss and student
 # gradients against the reference's own AudioLCM + torch autograd (tests/golden/make_golden_distill_light.py).
