@@ -53,6 +53,25 @@ def test_struct_layouts_match_header_field_order():
         decl = re.sub(r"^(const\s+)?(void|float|int64_t|int)\s*\*?", "", decl).strip()
         names += [n.strip().lstrip("*") for n in decl.split(",")]
     assert names == [f[0] for f in N.ConvDesc._fields_]
+    # ctta_ffn_desc (round 6): same field order, and the same byte size as the C compiler gives it
+    end = text.index("} ctta_ffn_desc;")
+    body = re.sub(r"/\*.*?\*/", "", text[text.rindex("typedef struct {", 0, end) + len("typedef struct {"):end], flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = re.sub(r"^(const\s+)?(void|float|int64_t|int)\s*\*?", "", decl.strip()).strip()
+        if decl:
+            names += [n.strip().lstrip("*") for n in decl.split(",")]
+    assert names == [f[0] for f in N.FfnDesc._fields_]
+    import ctypes
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src = os.path.join(td, "s.c")
+        open(src, "w").write('#include <stdio.h>\n#include "ctta.h"\nint main(void) { printf("%zu %zu\\n", sizeof(ctta_ffn_desc), sizeof(ctta_conv_desc)); return 0; }\n')
+        exe = os.path.join(td, "s")
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        ffn_size, conv_size = (int(v) for v in subprocess.check_output([exe]).split())
+    assert ffn_size == ctypes.sizeof(N.FfnDesc) and conv_size == ctypes.sizeof(N.ConvDesc)
 
 
 def test_mirror_state_dict_keys_are_the_references(golden):
